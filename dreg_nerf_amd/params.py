@@ -1,0 +1,142 @@
+"""Parameter inventory of the registration network and deterministic synthetic fills.
+
+The key names, shapes and ORDER reproduce ``NeRFRegTr.state_dict()`` of the reference
+(conerf/register/nerf_regtr.py:73-110, conerf/model/resnet3d.py:116-155,
+conerf/model/feature_pyramid_net.py:39-56,182-207, conerf/register/transformer.py:112-147):
+772 keys, the ResNet appearing under two aliases that share storage.
+"""
+import math
+import zlib
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import torch
+
+RESNET50_BLOCKS = (3, 4, 6, 3)
+RESNET50_PLANES = (64, 128, 256, 512)
+ALIAS_SRC = "fpn3d.backbone_net."
+ALIAS_DST = "fpn3d.feature_pyramid.resnet."
+
+
+def _bn_keys(spec, p, c):
+    spec[p + ".weight"] = ((c,), "bn_weight")
+    spec[p + ".bias"] = ((c,), "bn_bias")
+    spec[p + ".running_mean"] = ((c,), "bn_mean")
+    spec[p + ".running_var"] = ((c,), "bn_var")
+    spec[p + ".num_batches_tracked"] = ((), "bn_count")
+
+
+def resnet_spec(prefix: str = ALIAS_SRC) -> "OrderedDict[str, Tuple[tuple, str]]":
+    spec = OrderedDict()
+    spec[prefix + "conv1.weight"] = ((64, 4, 5, 5, 5), "conv")
+    _bn_keys(spec, prefix + "bn1", 64)
+    inpl = 64
+    for li, (nblk, pl) in enumerate(zip(RESNET50_BLOCKS, RESNET50_PLANES)):
+        for b in range(nblk):
+            p = f"{prefix}layer{li + 1}.{b}"
+            spec[p + ".conv1.weight"] = ((pl, inpl, 1, 1, 1), "conv")
+            _bn_keys(spec, p + ".bn1", pl)
+            spec[p + ".conv2.weight"] = ((pl, pl, 3, 3, 3), "conv")
+            _bn_keys(spec, p + ".bn2", pl)
+            spec[p + ".conv3.weight"] = ((pl * 4, pl, 1, 1, 1), "conv")
+            _bn_keys(spec, p + ".bn3", pl * 4)
+            if b == 0:
+                spec[p + ".downsample.0.weight"] = ((pl * 4, inpl, 1, 1, 1), "conv")
+                _bn_keys(spec, p + ".downsample.1", pl * 4)
+            inpl = pl * 4
+    return spec
+
+
+def regtr_spec() -> "OrderedDict[str, Tuple[tuple, str]]":
+    """key -> (shape, kind) in reference state_dict order (both ResNet aliases listed)."""
+    spec = OrderedDict()
+    spec.update(resnet_spec(ALIAS_SRC))
+    spec.update(resnet_spec(ALIAS_DST))
+    q = "fpn3d.feature_pyramid."
+    spec[q + "pyramid_transformation_1.weight"] = ((256, 64, 3, 3, 3), "conv")
+    spec[q + "pyramid_transformation_1.bias"] = ((256,), "bias")
+    for i, cin in zip((2, 3, 4, 5), (256, 512, 1024, 2048)):
+        spec[q + f"pyramid_transformation_{i}.weight"] = ((256, cin, 1, 1, 1), "conv")
+        spec[q + f"pyramid_transformation_{i}.bias"] = ((256,), "bias")
+    for i in (1, 2, 3, 4):
+        spec[q + f"upsample_transform_{i}.weight"] = ((256, 256, 3, 3, 3), "conv")
+        spec[q + f"upsample_transform_{i}.bias"] = ((256,), "bias")
+    for l in range(6):
+        p = f"transformer_encoder.layers.{l}."
+        for att in ("self_attn", "cross_attn"):
+            spec[p + att + ".in_proj_weight"] = ((768, 256), "linear")
+            spec[p + att + ".in_proj_bias"] = ((768,), "bias")
+            spec[p + att + ".out_proj.weight"] = ((256, 256), "linear")
+            spec[p + att + ".out_proj.bias"] = ((256,), "bias")
+        spec[p + "linear1.weight"] = ((1024, 256), "linear")
+        spec[p + "linear1.bias"] = ((1024,), "bias")
+        spec[p + "linear2.weight"] = ((256, 1024), "linear")
+        spec[p + "linear2.bias"] = ((256,), "bias")
+        for n in ("norm1", "norm2", "norm3"):
+            spec[p + n + ".weight"] = ((256,), "ln_weight")
+            spec[p + n + ".bias"] = ((256,), "bias")
+    spec["transformer_encoder.norm.weight"] = ((256,), "ln_weight")
+    spec["transformer_encoder.norm.bias"] = ((256,), "bias")
+    p = "correspondence_decoder."
+    spec[p + "q_norm.weight"] = ((256,), "ln_weight")
+    spec[p + "q_norm.bias"] = ((256,), "bias")
+    spec[p + "q_proj.weight"] = ((256, 256), "linear")
+    spec[p + "q_proj.bias"] = ((256,), "bias")
+    spec[p + "k_proj.weight"] = ((256, 256), "linear")
+    spec[p + "k_proj.bias"] = ((256,), "bias")
+    spec[p + "conf_logits_decoder.weight"] = ((1, 256), "linear")
+    spec[p + "conf_logits_decoder.bias"] = ((1,), "bias")
+    return spec
+
+
+def is_buffer(kind: str) -> bool:
+    return kind in ("bn_mean", "bn_var", "bn_count")
+
+
+def _fill(key: str, shape: tuple, kind: str, seed: int) -> torch.Tensor:
+    g = torch.Generator().manual_seed((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    if kind == "bn_count":
+        return torch.zeros((), dtype=torch.int64)
+    n = torch.randn(shape, generator=g, dtype=torch.float32)
+    if kind == "conv":
+        rf = shape[2] * shape[3] * shape[4]
+        return n * math.sqrt(2.0 / ((shape[0] + shape[1]) * rf))
+    if kind == "linear":
+        return n * math.sqrt(2.0 / (shape[0] + shape[1]))
+    if kind in ("bn_weight", "ln_weight"):
+        return 1.0 + 0.1 * n
+    if kind == "bn_var":
+        return 1.0 + 0.1 * n.abs()
+    return 0.05 * n  # biases, bn_mean
+
+
+def synth_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Deterministic, key-seeded fill of every entry (fp32, CPU).  Both ResNet aliases point
+    at the same tensors, as in the reference module."""
+    sd = OrderedDict()
+    for key, (shape, kind) in regtr_spec().items():
+        if key.startswith(ALIAS_DST):
+            sd[key] = sd[ALIAS_SRC + key[len(ALIAS_DST):]]
+        else:
+            sd[key] = _fill(key, shape, kind, seed)
+    return sd
+
+
+def clone_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Deep copy that keeps the alias sharing."""
+    out = OrderedDict()
+    for key, v in sd.items():
+        if key.startswith(ALIAS_DST):
+            out[key] = out[ALIAS_SRC + key[len(ALIAS_DST):]]
+        else:
+            out[key] = v.clone()
+    return out
+
+
+def num_parameters() -> int:
+    n = 0
+    for key, (shape, kind) in regtr_spec().items():
+        if key.startswith(ALIAS_DST) or is_buffer(kind):
+            continue
+        n += int(math.prod(shape)) if shape else 1
+    return n

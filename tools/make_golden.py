@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python (imported from
+/root/reference, which exists only in the build container) on seeded inputs.
+
+Nothing of the reference travels: only inputs' seeds and expected outputs (data) are stored.
+Third-party native packages the reference imports but this image lacks (MinkowskiEngine,
+tinycudann, nerfacc, torch_scatter, trimesh, ...) are replaced by empty mock modules so the
+torch-only parts import; the one MinkowskiEngine call on the path
+(conerf/register/grid_downsample.py:24-36) is replaced by oracle.regtr_oracle.grid_subsample,
+so row A4 stays "parity unpinned" (SURVEY.md §8(c)).
+
+Usage:  python tools/make_golden.py            (writes tests/golden/)
+"""
+import os
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from dreg_nerf_amd import params, synth  # noqa: E402
+from oracle import regtr_oracle as O  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference not present: golden vectors can only be generated in the build container")
+    for name in ["MinkowskiEngine", "torch_scatter", "nerfacc", "nerfacc.cuda", "nerfacc.contraction",
+                 "nerfacc.grid", "nerfacc.intersection", "nerfacc.vol_rendering", "nerfacc.pack",
+                 "tinycudann", "trimesh", "cv2", "matplotlib", "matplotlib.backends",
+                 "matplotlib.backends.backend_agg", "matplotlib.figure", "matplotlib.cm",
+                 "robust_loss_pytorch", "robust_loss_pytorch.general", "tensorboardX", "visdom",
+                 "open3d", "imageio", "imageio.v2", "lpips", "sklearn", "sklearn.cluster", "easydict", "scipy.spatial.transform"]:
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = mock.MagicMock(name=name)
+    sys.path.insert(0, REF)
+    import conerf.register.grid_downsample as gd
+
+    def patched(points, features, batched_lengths, sample_dl=0.1):
+        p, f, l = O.grid_subsample(points, features, batched_lengths, sample_dl)
+        return torch.cat([p, f], dim=-1), l
+
+    gd.batched_grid_subsample = patched
+    import conerf.register.nerf_regtr as nr
+    return nr
+
+
+def sample_idx(numel: int, n: int, seed: int) -> np.ndarray:
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, numel, (n,), generator=g).numpy()
+
+
+def ref_model(nr, sd):
+    m = nr.NeRFRegTr()
+    keys = list(m.state_dict().keys())
+    assert keys == list(params.regtr_spec().keys()), "state_dict key order differs from params.regtr_spec()"
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == params.regtr_spec()[k][0], k
+    m.load_state_dict(params.clone_state_dict(sd), strict=True)
+    assert sum(p.numel() for p in m.parameters()) == params.num_parameters() == 61124225
+    return m
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    nr = import_reference()
+    from conerf.register.se3 import compute_rigid_transform
+    from conerf.register.position_embedding import PositionEmbeddingCoordsSine
+    from conerf.loss.feature_loss import InfoNCELoss
+    import train_nerf_regtr as tr  # evaluate_camera_alignment / rotation_distance only
+
+    sd = params.synth_state_dict(seed=0)
+
+    # ---------------------------------------------------------------- small components
+    g = torch.Generator().manual_seed(11)
+    xyz = (torch.rand(37, 3, generator=g) - 0.5) * 3
+    pe = PositionEmbeddingCoordsSine(3, 256, scale=1.0)(xyz)
+    a = torch.randn(6, 50, 3, generator=g)
+    Rgt = synth.fixed_pose()
+    b = a @ Rgt[:3, :3].T + Rgt[:3, 3] + 0.01 * torch.randn(6, 50, 3, generator=g)
+    w = torch.rand(6, 50, generator=g)
+    kab = compute_rigid_transform(a, b, w)
+    pred = kab[:, :3, :]
+    gt = Rgt[None].expand(6, -1, -1)
+    rre = tr.rotation_distance(pred[..., :3, :3], gt[..., :3, :3])
+    rte = (pred[..., :3, 3] - gt[..., :3, 3]).norm(dim=-1)
+    np.savez(os.path.join(OUT, "small_ops.npz"),
+             pe_xyz=xyz.numpy(), pe=pe.numpy(),
+             kab_a=a.numpy(), kab_b=b.numpy(), kab_w=w.numpy(), kab_T=kab.numpy(),
+             rre=rre.numpy(), rte=rte.numpy(), pose_gt=Rgt.numpy())
+    print("small_ops done")
+
+    # ---------------------------------------------------------------- transformer + decoder on random features
+    m = ref_model(nr, sd).eval()
+    g = torch.Generator().manual_seed(12)
+    ns, nt = 70, 55
+    s_xyz = (torch.rand(ns, 3, generator=g) - 0.5) * 2
+    t_xyz = (torch.rand(nt, 3, generator=g) - 0.5) * 2
+    s_f = torch.randn(ns, 256, generator=g)
+    t_f = torch.randn(nt, 256, generator=g)
+    with torch.no_grad():
+        s_pe, t_pe = m.pos_embed(s_xyz), m.pos_embed(t_xyz)
+        sc, tc = m.transformer_encoder(
+            src=s_f[:, None], tgt=t_f[:, None],
+            src_key_padding_mask=torch.zeros(1, ns, dtype=torch.bool),
+            tgt_key_padding_mask=torch.zeros(1, nt, dtype=torch.bool),
+            src_pos=s_pe[:, None], tgt_pos=t_pe[:, None])
+        scl, tcl, sol, tol = m.correspondence_decoder(sc, tc, [s_xyz], [t_xyz])
+    np.savez(os.path.join(OUT, "transformer.npz"),
+             s_xyz=s_xyz.numpy(), t_xyz=t_xyz.numpy(), s_f=s_f.numpy(), t_f=t_f.numpy(),
+             s_cond=sc[:, :, 0].numpy(), t_cond=tc[:, :, 0].numpy(),
+             s_corr=scl[0].numpy(), t_corr=tcl[0].numpy(), s_ov=sol[0].numpy(), t_ov=tol[0].numpy())
+    print("transformer done")
+
+    # ---------------------------------------------------------------- FPN, eval mode, 32^3 (config 1) + e2e forward
+    data = synth.shell_pair(32, 1, 2, pose=synth.fixed_pose())
+    with torch.no_grad():
+        p1 = m.fpn3d(data["src_xyz_rgba"][:, 3:])
+        out = m({k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()})
+    idx = sample_idx(p1.numel(), 2048, 21)
+    rr, rt = tr.rotation_distance(out["pose"][-1][:, :3, :3], data["pose"][:, :3, :3]), \
+        (out["pose"][-1][:, :3, 3] - data["pose"][:, :3, 3]).norm(dim=-1)
+    np.savez(os.path.join(OUT, "e2e_eval32.npz"),
+             p1_idx=idx, p1_val=p1.flatten()[idx].numpy(), p1_absmean=p1.abs().mean().numpy(),
+             pose=out["pose"].numpy(),
+             n_src=out["src_kp"][0].shape[0], n_tgt=out["tgt_kp"][0].shape[0],
+             src_kp=out["src_kp"][0].numpy(), tgt_kp=out["tgt_kp"][0].numpy(),
+             src_kp_warped_last=out["src_kp_warped"][0][-1].numpy(),
+             tgt_kp_warped_last=out["tgt_kp_warped"][0][-1].numpy(),
+             src_overlap_last=out["src_overlap"][0][-1].numpy(),
+             tgt_overlap_last=out["tgt_overlap"][0][-1].numpy(),
+             src_feats_last_absmean=out["src_feats"][0][-1].abs().mean().numpy(),
+             rre=rr.numpy(), rte=rt.numpy())
+    print("e2e_eval32 done; N =", out["src_kp"][0].shape[0], out["tgt_kp"][0].shape[0])
+
+    # ---------------------------------------------------------------- training step, 64^3, train-mode BN
+    m = ref_model(nr, sd).train()
+    data = synth.shell_pair(64, 1, 2, pose=synth.fixed_pose())
+    feature_loss = InfoNCELoss(d_embed=256, r_p=0.2, r_n=0.4)
+    gW = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        feature_loss.W.copy_(0.1 * torch.randn(256, 256, generator=gW))
+    pred = m({k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()})
+    s_kp, t_kp = pred["src_kp"][0], pred["tgt_kp"][0]
+    s_gt, t_gt = synth.synthetic_overlap_gt(s_kp), synth.synthetic_overlap_gt(t_kp)
+    with torch.no_grad():
+        s_tl = torch.stack([synth.synthetic_overlap_gt(pred["src_kp_warped"][0][l], 1)[0] for l in range(6)])
+        t_tl = torch.stack([synth.synthetic_overlap_gt(pred["tgt_kp_warped"][0][l], 1)[0] for l in range(6)])
+    # the reference's loss code, argument for argument (train_nerf_regtr.py:186-228)
+    from conerf.register.se3 import se3_transform_list, se3_inv
+    from conerf.loss.correspondence_loss import CorrespondenceLoss
+    pose_gt = data["pose"]
+    losses = {}
+    ov_gt = torch.cat([s_gt] + [t_gt], dim=-2)
+    ov_pred = torch.cat(pred["src_overlap"] + pred["tgt_overlap"], dim=-2)
+    losses["overlap"] = torch.nn.BCEWithLogitsLoss()(ov_gt[-1], ov_pred[-1])
+    losses["nerf_cont"] = torch.nn.functional.smooth_l1_loss(ov_gt, torch.cat([s_tl] + [t_tl], dim=-2))
+    losses["feature"] = feature_loss([f[-1] for f in pred["src_feats"]], [f[-1] for f in pred["tgt_feats"]],
+                                     se3_transform_list(pose_gt, pred["src_kp"]), pred["tgt_kp"])
+    cl = CorrespondenceLoss(metric="mae", robust_loss=False)
+    losses["corr"] = cl(pred["src_kp"], [w_[-1] for w_ in pred["src_kp_warped"]], pose_gt, overlap_weights=[s_gt]) + \
+        cl(pred["tgt_kp"], [w_[-1] for w_ in pred["tgt_kp_warped"]],
+           torch.stack([se3_inv(p) for p in pose_gt]), overlap_weights=[t_gt])
+    wd = {"overlap": 1.0, "nerf_cont": 1.0, "feature": 0.1, "corr": 1.0}
+    losses["total"] = torch.sum(torch.stack([losses[k] * wd[k] for k in wd]))
+    losses["total"].backward()
+    gnorm = {}
+    named = dict(m.named_parameters())
+    groups = {"resnet": "fpn3d.backbone_net.", "fpn_head": "fpn3d.feature_pyramid.",
+              "transformer": "transformer_encoder.", "decoder": "correspondence_decoder."}
+    for gname, pref in groups.items():
+        sq = 0.0
+        for k, p in named.items():
+            if k.startswith(pref) and p.grad is not None:
+                sq += float(p.grad.double().pow(2).sum())
+        gnorm[gname] = sq ** 0.5
+    probes = ["fpn3d.backbone_net.conv1.weight", "fpn3d.backbone_net.layer1.0.conv2.weight",
+              "fpn3d.backbone_net.layer4.2.bn3.weight", "fpn3d.feature_pyramid.upsample_transform_1.weight",
+              "fpn3d.feature_pyramid.pyramid_transformation_1.bias",
+              "transformer_encoder.layers.0.self_attn.in_proj_weight",
+              "transformer_encoder.layers.5.linear2.weight", "correspondence_decoder.q_proj.weight"]
+    gp = {}
+    for k in probes:
+        gr = named[k].grad.flatten()
+        idx = sample_idx(gr.numel(), 64, 31)
+        gp["gidx/" + k] = idx
+        gp["gval/" + k] = gr[idx].numpy()
+    total_norm = float(torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=0.1))
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=1e-4)
+    before = {k: p.detach().clone() for k, p in named.items()}
+    opt.step()
+    dnorm = {gname: float(sum((named[k].detach() - before[k]).double().pow(2).sum()
+                              for k in named if k.startswith(pref)) ** 0.5)
+             for gname, pref in groups.items()}
+    bn_probe = m.state_dict()["fpn3d.backbone_net.layer3.1.bn2.running_var"][:16].numpy()
+    bn_probe_m = m.state_dict()["fpn3d.backbone_net.bn1.running_mean"][:16].numpy()
+    np.savez(os.path.join(OUT, "train64.npz"),
+             n_src=s_kp.shape[0], n_tgt=t_kp.shape[0],
+             pose=pred["pose"].detach().numpy(),
+             **{"loss_" + k: float(v) for k, v in losses.items()},
+             **{"gnorm_" + k: v for k, v in gnorm.items()},
+             **{"dnorm_" + k: v for k, v in dnorm.items()},
+             total_grad_norm=total_norm, bn_running_var_probe=bn_probe, bn_running_mean_probe=bn_probe_m,
+             W_seed=5, **gp)
+    print("train64 done", {k: float(v) for k, v in losses.items()}, gnorm, total_norm)
+
+
+if __name__ == "__main__":
+    main()
