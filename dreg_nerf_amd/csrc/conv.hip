@@ -1,0 +1,590 @@
+// 3-D convolution as implicit GEMM on gfx950 MFMA (bf16 16x16x32 / exact-f32 16x16x4).
+//
+// Replaces the cuDNN conv3d calls behind nn.Conv3d on the reference hot path
+// (conerf/model/resnet3d.py:79-84,120,143-147; conerf/model/feature_pyramid_net.py:47-56) and, with
+// ksz = 1, the cuBLAS GEMMs behind nn.Linear (conerf/register/transformer.py:131-133,
+// conerf/register/nerf_regtr.py:268-270).
+//
+// Layouts (HBM):
+//   activations  NDHWC  [B, D, H, W, C]   (channels contiguous; C a power of two, >= 8)
+//   packed weight for the gather form: [Cout][tap][Cin] with the K = tap*Cin+ci axis padded to a
+//   multiple of 128 bytes (zero filled) -> both MFMA operands are K-contiguous.
+//   One kernel serves forward (coordinate o*s - p + d) and data-gradient (coordinate (i + p - d)/s,
+//   valid only when divisible) through the (sn, dsign, off, sd) coordinate map.
+//
+// Tile: 128 output voxels x BN output channels per 256-thread workgroup (4 waves, 2x2, each 64 x BN/2),
+// 128 bytes of K per step, register-staged double-buffered LDS with a 16-byte-slot XOR swizzle
+// (slot ^= (row>>1)&7) so the ds_read_b128 fragment reads of 16 consecutive rows are conflict free.
+#include "common.h"
+
+struct ConvGeom {
+    int B, Di, Hi, Wi, Cin, log2Cin;  // gathered operand [B,Di,Hi,Wi,Cin]; ksz==1: log2Cin=30 (tap always 0)
+    int Cmask;                        // (1<<log2Cin)-1
+    int Do, Ho, Wo, Cout;             // row space [B,Do,Ho,Wo] x Cout
+    int ksz, ntaps;
+    int sn, dsign, off, sd;           // gathered coord = (o*sn + off + dsign*d) / sd
+    uint32_t M;                       // B*Do*Ho*Wo
+    uint32_t magW, magH, magD;        // magic reciprocals of Wo, Ho, Do
+    int Kpad;                         // padded K (elements) = packed weight row stride
+};
+
+__device__ __forceinline__ void tap_decode(int tap, int ksz, int& dz, int& dy, int& dx) {
+    if (ksz == 1) { dz = dy = dx = 0; }
+    else if (ksz == 3) { dz = tap / 9; int r = tap - dz * 9; dy = r / 3; dx = r - dy * 3; }
+    else { int k2 = ksz * ksz; dz = tap / k2; int r = tap - dz * k2; dy = r / ksz; dx = r - dy * ksz; }
+}
+
+__device__ __forceinline__ void vox_decode(uint32_t m, const ConvGeom& g, int& b, int& z, int& y, int& x) {
+    uint32_t q1 = fdiv(m, g.magW); x = (int)(m - q1 * g.Wo);
+    uint32_t q2 = fdiv(q1, g.magH); y = (int)(q1 - q2 * g.Ho);
+    uint32_t q3 = fdiv(q2, g.magD); z = (int)(q2 - q3 * g.Do);
+    b = (int)q3;
+}
+
+__device__ __forceinline__ uint32_t swz(int row, int slot) { return (uint32_t)row * 128u + (uint32_t)((slot ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
+    uint32_t xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / data-gradient
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename TO, int BN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(
+    const T* __restrict__ in, const T* __restrict__ wt, TO* __restrict__ out,
+    const float* __restrict__ bias, const TO* __restrict__ addend, ConvGeom g,
+    int relu, int Da, int Ha, int Wa, int tilesN)
+{
+    constexpr int BM = 128;
+    constexpr int G = 16 / sizeof(T);
+    constexpr int BKe = 128 / sizeof(T);
+    constexpr int WN = BN / 2;
+    constexpr int TM = 4, TN = WN / 16;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int NB = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const uint32_t lid = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t tile_m = lid / tilesN, tile_n = lid - tile_m * tilesN;
+    const uint32_t m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int gq = t & 7, rbase = t >> 3;
+
+    int zb[4], yb[4], xb[4];
+    uint32_t vb[4];
+    bool mv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t m = m0 + rbase + 32 * i;
+        mv[i] = m < g.M;
+        int b, z, y, x;
+        vox_decode(mv[i] ? m : 0, g, b, z, y, x);
+        zb[i] = z * g.sn + g.off; yb[i] = y * g.sn + g.off; xb[i] = x * g.sn + g.off;
+        vb[i] = (uint32_t)b * (uint32_t)(g.Di * g.Hi * g.Wi);
+    }
+
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[4], rb[NB];
+    const int nk = g.Kpad / BKe;
+
+    auto load_g = [&](int k) {
+        const int kel = k * BKe + gq * G;
+        const int tap = kel >> g.log2Cin, ci = kel & g.Cmask;
+        int dz, dy, dx;
+        tap_decode(tap, g.ksz, dz, dy, dx);
+        dz *= g.dsign; dy *= g.dsign; dx *= g.dsign;
+        const bool tv = tap < g.ntaps && ci < g.Cin;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int z = zb[i] + dz, y = yb[i] + dy, x = xb[i] + dx;
+            bool v = mv[i] && tv;
+            if (g.sd == 2) { v = v && !((z | y | x) & 1); z >>= 1; y >>= 1; x >>= 1; }
+            v = v && (unsigned)z < (unsigned)g.Di && (unsigned)y < (unsigned)g.Hi && (unsigned)x < (unsigned)g.Wi;
+            uint32_t vox = vb[i] + (uint32_t)((z * g.Hi + y) * g.Wi + x);
+            const T* p = in + (size_t)vox * g.Cin + ci;
+            ra[i] = v ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const T* p = wt + (size_t)(n0 + rbase + 32 * i) * g.Kpad + (size_t)k * BKe + gq * G;
+            rb[i] = *reinterpret_cast<const uint4*>(p);
+        }
+    };
+    auto store_l = [&](int buf) {
+        char* sA = smem + buf * STAGE;
+        char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(sA + swz(rbase + 32 * i, gq)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(sB + swz(rbase + 32 * i, gq)) = rb[i];
+    };
+    auto compute = [&](int buf) {
+        const char* sA = smem + buf * STAGE;
+        const char* sB = sA + A_BYTES;
+        const int fr = lane & 15, kg = lane >> 4;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sA + swz(wm * 64 + i * 16 + fr, ks * 4 + kg));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(sB + swz(wn * WN + j * 16 + fr, ks * 4 + kg));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // exact f32: lane group kg owns k = kg*8 + j; MFMA j multiplies the j-th element of every group.
+            float bfv[TN][8];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * WN + j * 16 + fr;
+                float4 lo = *reinterpret_cast<const float4*>(sB + swz(row, 2 * kg));
+                float4 hi = *reinterpret_cast<const float4*>(sB + swz(row, 2 * kg + 1));
+                bfv[j][0] = lo.x; bfv[j][1] = lo.y; bfv[j][2] = lo.z; bfv[j][3] = lo.w;
+                bfv[j][4] = hi.x; bfv[j][5] = hi.y; bfv[j][6] = hi.z; bfv[j][7] = hi.w;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * 64 + i * 16 + fr;
+                float4 lo = *reinterpret_cast<const float4*>(sA + swz(row, 2 * kg));
+                float4 hi = *reinterpret_cast<const float4*>(sA + swz(row, 2 * kg + 1));
+                float av[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bfv[j][e], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    load_g(0);
+    store_l(0);
+    __syncthreads();
+    for (int k = 0; k < nk; ++k) {
+        if (k + 1 < nk) load_g(k + 1);
+        compute(k & 1);
+        if (k + 1 < nk) store_l((k + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+    const int col_l = lane & 15, rowq = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t m = m0 + wm * 64 + i * 16 + rowq + r;
+            if (m >= g.M) continue;
+            size_t arow = 0;
+            if (addend) {
+                int b, z, y, x;
+                vox_decode(m, g, b, z, y, x);
+                arow = ((size_t)((b * Da + (z >> 1)) * Ha + (y >> 1)) * Wa + (x >> 1)) * g.Cout;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + col_l;
+                float v = acc[i][j][r];
+                if (bias) v += bias[n];
+                if (addend) v += Elem<TO>::ld(addend + arow + n);
+                if (relu) v = fmaxf(v, 0.f);
+                Elem<TO>::st(out + (size_t)m * g.Cout + n, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient: part[s][co][n] = sum_{voxels of split s} gout[m][co] * in[gather(m, tap(n))][ci(n)]
+// rows = co (128 / block), cols = packed K index n (BNC / block), reduction over voxels in steps of 32.
+// Both operands are reduction-strided in memory ([voxel][channel]); bf16 fragments are formed with the
+// LDS transpose read ds_read_b64_tr_b16 (TR = true) or by eight 16-bit reads (TR = false, the checker).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BNC, bool TR>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(
+    const T* __restrict__ gout, const T* __restrict__ in, float* __restrict__ part,
+    ConvGeom g, int tilesCol, uint32_t vox_per_split)
+{
+    constexpr int KV = 32;
+    constexpr int G = 16 / sizeof(T);
+    constexpr int RSA = BM * sizeof(T), RSB = BNC * sizeof(T);  // LDS row strides (bytes)
+    constexpr int GPA = RSA / 16, GPB = RSB / 16;                // granules per row
+    constexpr int A_BYTES = KV * RSA, B_BYTES = KV * RSB, STAGE = A_BYTES + B_BYTES;
+    constexpr int NA = KV * GPA / 256, NBG = KV * GPB / 256;     // granules per thread
+    constexpr int WN = BNC / 2, WM = BM / 2, TM = WM / 16, TN = WN / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const uint32_t tile_r = blockIdx.x / tilesCol, tile_c = blockIdx.x - tile_r * tilesCol;
+    const int co0 = tile_r * BM, n0 = tile_c * BNC;
+    const uint32_t v_begin = blockIdx.y * vox_per_split;
+    const uint32_t v_end = min(v_begin + vox_per_split, g.M);
+
+    // B-side per-thread constants: one voxel row per thread per step, NBG granules in that row
+    // thread t -> row rB = t / (GPB / NBG) ... keep it simple: granule id q = t + 256*i, row = q / GPB, gc = q % GPB
+    int b_dz[NBG], b_dy[NBG], b_dx[NBG], b_ci[NBG];
+    bool b_tv[NBG];
+#pragma unroll
+    for (int i = 0; i < NBG; ++i) {
+        const int q = t + 256 * i, gc = q % GPB;
+        const int n = n0 + gc * G;
+        const int tap = n >> g.log2Cin;
+        b_ci[i] = n & g.Cmask;
+        tap_decode(tap, g.ksz, b_dz[i], b_dy[i], b_dx[i]);
+        b_dz[i] *= g.dsign; b_dy[i] *= g.dsign; b_dx[i] *= g.dsign;
+        b_tv[i] = tap < g.ntaps && b_ci[i] < g.Cin;
+    }
+
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[NA], rb[NBG];
+    auto load_g = [&](uint32_t v0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int q = t + 256 * i, row = q / GPA, ga = q % GPA;
+            const uint32_t m = v0 + row;
+            const T* p = gout + (size_t)m * g.Cout + co0 + ga * G;
+            ra[i] = (m < v_end) ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NBG; ++i) {
+            const int q = t + 256 * i, row = q / GPB;
+            const uint32_t m = v0 + row;
+            bool v = (m < v_end) && b_tv[i];
+            int b, z, y, x;
+            vox_decode(v ? m : 0, g, b, z, y, x);
+            z = z * g.sn + g.off + b_dz[i]; y = y * g.sn + g.off + b_dy[i]; x = x * g.sn + g.off + b_dx[i];
+            if (g.sd == 2) { v = v && !((z | y | x) & 1); z >>= 1; y >>= 1; x >>= 1; }
+            v = v && (unsigned)z < (unsigned)g.Di && (unsigned)y < (unsigned)g.Hi && (unsigned)x < (unsigned)g.Wi;
+            const uint32_t vox = (uint32_t)b * (uint32_t)(g.Di * g.Hi * g.Wi) + (uint32_t)((z * g.Hi + y) * g.Wi + x);
+            const T* p = in + (size_t)vox * g.Cin + b_ci[i];
+            rb[i] = v ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_l = [&](int buf) {
+        char* sA = smem + buf * STAGE;
+        char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) { const int q = t + 256 * i; *reinterpret_cast<uint4*>(sA + q * 16) = ra[i]; }
+#pragma unroll
+        for (int i = 0; i < NBG; ++i) { const int q = t + 256 * i; *reinterpret_cast<uint4*>(sB + q * 16) = rb[i]; }
+    };
+    auto compute = [&](int buf) {
+        const char* sA = smem + buf * STAGE;
+        const char* sB = sA + A_BYTES;
+        const int fi = lane & 15, kb = (lane >> 4) * 8;
+        if constexpr (sizeof(T) == 2) {
+            bf16x8_t af[TM], bf[TN];
+            if constexpr (TR) {
+                // 16-lane group reads a [4 voxel][16 channel] block; lane fi supplies row fi>>2, 8 bytes at column (fi&3)*4
+                typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int cb = wm * WM + i * 16;
+                    const char* p0 = sA + (kb + (fi >> 2)) * RSA + (cb + (fi & 3) * 4) * 2;
+                    bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0));
+                    bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0 + 4 * RSA));
+                    af[i] = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int cb = wn * WN + j * 16;
+                    const char* p0 = sB + (kb + (fi >> 2)) * RSB + (cb + (fi & 3) * 4) * 2;
+                    bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0));
+                    bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0 + 4 * RSB));
+                    bf[j] = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        af[i][e] = *reinterpret_cast<const short*>(sA + (kb + e) * RSA + (wm * WM + i * 16 + fi) * 2);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        bf[j][e] = *reinterpret_cast<const short*>(sB + (kb + e) * RSB + (wn * WN + j * 16 + fi) * 2);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        } else {
+            float bfv[TN][8];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    bfv[j][e] = *reinterpret_cast<const float*>(sB + (kb + e) * RSB + (wn * WN + j * 16 + fi) * 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float av[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    av[e] = *reinterpret_cast<const float*>(sA + (kb + e) * RSA + (wm * WM + i * 16 + fi) * 4);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bfv[j][e], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    if (v_begin < v_end) {
+        const int nk = (int)((v_end - v_begin + KV - 1) / KV);
+        load_g(v_begin);
+        store_l(0);
+        __syncthreads();
+        for (int k = 0; k < nk; ++k) {
+            if (k + 1 < nk) load_g(v_begin + (uint32_t)(k + 1) * KV);
+            compute(k & 1);
+            if (k + 1 < nk) store_l((k + 1) & 1);
+            __syncthreads();
+        }
+    }
+    float* dst = part + (size_t)blockIdx.y * g.Cout * g.Kpad;
+    const int col_l = lane & 15, rowq = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + wm * WM + i * 16 + rowq + r;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                dst[(size_t)co * g.Kpad + n0 + wn * WN + j * 16 + col_l] = acc[i][j][r];
+        }
+}
+
+// sum the split partials and scatter into the torch layout [Cout][Cin_real][ntaps] (fp32), optionally accumulating
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int Cout,
+                                    int Kpad, int ntaps, int Cin, int log2Cin, int Cin_real, int accumulate)
+{
+    const size_t total = (size_t)Cout * ntaps * Cin_real;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        // iterate in packed order for coalesced reads: i -> (co, tap, ci)
+        const int ci = (int)(i % Cin_real);
+        const size_t r = i / Cin_real;
+        const int tap = (int)(r % ntaps), co = (int)(r / ntaps);
+        const size_t src = (size_t)co * Kpad + (size_t)tap * Cin + ci;
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * Cout * Kpad + src];
+        const size_t d = ((size_t)co * Cin_real + ci) * ntaps + tap;
+        dw[d] = accumulate ? dw[d] + s : s;
+    }
+}
+
+// torch weight [Cout][Cin_real][ntaps] fp32 -> gather-form pack [Cout][Kpad] (K = tap*Cin + ci), zero padded.
+template <typename T>
+__global__ void pack_weight_fwd_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin_real,
+                                       int ntaps, int Cin, int log2Cin, int Kpad)
+{
+    const size_t total = (size_t)Cout * Kpad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kpad), co = (int)(i / Kpad);
+        const int tap = k / Cin, ci = k - tap * Cin;
+        float v = (tap < ntaps && ci < Cin_real) ? w[((size_t)co * Cin_real + ci) * ntaps + tap] : 0.f;
+        Elem<T>::st(out + i, v);
+    }
+}
+// torch weight -> data-gradient pack [Cin_real][Kpad'] with K' = tap*Cout + co
+template <typename T>
+__global__ void pack_weight_dgrad_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin_real,
+                                         int ntaps, int log2Cout, int Kpad)
+{
+    const size_t total = (size_t)Cin_real * Kpad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kpad), ci = (int)(i / Kpad);
+        const int tap = k / Cout, co = k - tap * Cout;
+        float v = (tap < ntaps) ? w[((size_t)co * Cin_real + ci) * ntaps + tap] : 0.f;
+        Elem<T>::st(out + i, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+static int fill_geom(ConvGeom& g, int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                     int ksz, int stride, int pad, int transposed, int esize)
+{
+    if ((ksz != 1 && !is_pow2(Cin)) || (Cin * esize) % 16 != 0 || !(ksz == 1 || ksz == 3 || ksz == 5) || !(stride == 1 || stride == 2)) return DREG_EINVAL;
+    g.B = B; g.Di = Di; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.log2Cin = (ksz == 1) ? 30 : ilog2(Cin);
+    g.Cmask = (1 << g.log2Cin) - 1;
+    g.Do = Do; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout;
+    g.ksz = ksz; g.ntaps = ksz * ksz * ksz;
+    if (!transposed) { g.sn = stride; g.dsign = 1; g.off = -pad; g.sd = 1; }
+    else { g.sn = 1; g.dsign = -1; g.off = pad; g.sd = stride; }
+    const uint64_t M = (uint64_t)B * Do * Ho * Wo;
+    const uint64_t dmax = (uint64_t)(Wo > Ho ? (Wo > Do ? Wo : Do) : (Ho > Do ? Ho : Do));
+    if (M * dmax >= (1ull << 32)) return DREG_EINVAL;
+    if ((uint64_t)B * Di * Hi * Wi * Cin * esize >= (1ull << 40)) return DREG_EINVAL;
+    g.M = (uint32_t)M;
+    g.magW = host_magic(Wo); g.magH = host_magic(Ho); g.magD = host_magic(Do);
+    const int bke = 128 / esize;
+    g.Kpad = ((g.ntaps * Cin + bke - 1) / bke) * bke;
+    return DREG_OK;
+}
+
+template <typename T, typename TO>
+static int launch_conv(const void* in, const void* wt, void* out, const float* bias, const void* addend,
+                       const ConvGeom& g, int relu, int Da, int Ha, int Wa, hipStream_t st)
+{
+    const int tilesM = (g.M + 127) / 128;
+    if (g.Cout % 128 == 0) {
+        const int tilesN = g.Cout / 128;
+        const size_t lds = 2 * (128 + 128) * 128;
+        hipLaunchKernelGGL((conv_igemm_kernel<T, TO, 128>), dim3(tilesM * tilesN), dim3(256), lds, st,
+                           (const T*)in, (const T*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, tilesN);
+    } else if (g.Cout % 64 == 0) {
+        const int tilesN = g.Cout / 64;
+        const size_t lds = 2 * (128 + 64) * 128;
+        hipLaunchKernelGGL((conv_igemm_kernel<T, TO, 64>), dim3(tilesM * tilesN), dim3(256), lds, st,
+                           (const T*)in, (const T*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, tilesN);
+    } else return DREG_EINVAL;
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+extern "C" {
+
+// dtype: 0 = bf16 activations/weights (fp32 accumulate), 1 = fp32 (exact-f32 MFMA).  out_f32: bf16 inputs, fp32 output.
+// transposed = 0: out[b,o,:] = sum_d in[b, o*stride - pad + d, :] . W[:, d, :]           (forward)
+// transposed = 1: out[b,i,:] = sum_d in[b, (i + pad - d)/stride, :] . W'[:, d, :]       (data gradient; "in" = dOut)
+// addend (optional, same dtype as out): [B, Da, Ha, Wa, Cout] added with nearest x2 upsampling (FPN top-down path).
+int dreg_conv3d_igemm(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
+                      int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                      int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa,
+                      int dtype, int out_f32, void* stream)
+{
+    ConvGeom g;
+    const int es = dtype == 0 ? 2 : 4;
+    int rc = fill_geom(g, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, ksz, stride, pad, transposed, es);
+    if (rc) return rc;
+    if (g.M == 0) return DREG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0) {
+        if (out_f32) return launch_conv<bf16_t, float>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, st);
+        return launch_conv<bf16_t, bf16_t>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, st);
+    }
+    return launch_conv<float, float>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, st);
+}
+
+// K padding of the packed weight row for (ntaps, Cin) at dtype.
+int dreg_conv3d_kpad(int ksz, int Cin, int dtype) {
+    const int bke = dtype == 0 ? 64 : 32;
+    return ((ksz * ksz * ksz * Cin + bke - 1) / bke) * bke;
+}
+
+int dreg_pack_conv_weight(const float* w, void* out, int Cout, int Cin_real, int Cin, int ksz, int for_dgrad,
+                          int dtype, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int ntaps = ksz * ksz * ksz;
+    if (!for_dgrad) {
+        if ((ksz != 1 && !is_pow2(Cin)) || Cin < Cin_real) return DREG_EINVAL;
+        const int Kpad = dreg_conv3d_kpad(ksz, Cin, dtype);
+        const size_t total = (size_t)Cout * Kpad;
+        const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+        if (dtype == 0) hipLaunchKernelGGL(pack_weight_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, w, (bf16_t*)out, Cout, Cin_real, ntaps, Cin, ilog2(Cin), Kpad);
+        else hipLaunchKernelGGL(pack_weight_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, w, (float*)out, Cout, Cin_real, ntaps, Cin, ilog2(Cin), Kpad);
+    } else {
+        if (ksz != 1 && !is_pow2(Cout)) return DREG_EINVAL;
+        const int Kpad = dreg_conv3d_kpad(ksz, Cout, dtype);
+        const size_t total = (size_t)Cin_real * Kpad;
+        const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+        if (dtype == 0) hipLaunchKernelGGL(pack_weight_dgrad_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, w, (bf16_t*)out, Cout, Cin_real, ntaps, ilog2(Cout), Kpad);
+        else hipLaunchKernelGGL(pack_weight_dgrad_kernel<float>, dim3(blocks), dim3(256), 0, st, w, (float*)out, Cout, Cin_real, ntaps, ilog2(Cout), Kpad);
+    }
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// number of voxel splits the weight-gradient kernel will use (pure function of the shape)
+int dreg_conv3d_wgrad_splits(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int dtype) {
+    const int es = dtype == 0 ? 2 : 4;
+    const int bke = 128 / es;
+    const int Kpad = ((ksz * ksz * ksz * Cin + bke - 1) / bke) * bke;
+    const int bnc = (Kpad % 128 == 0) ? 128 : 64;
+    const long tiles = (long)((Cout % 128 == 0) ? Cout / 128 : Cout / 64) * (Kpad / bnc);
+    const long M = (long)B * Do * Ho * Wo;
+    long s = (2048 + tiles - 1) / tiles;
+    const long maxs = (M + 255) / 256;  // at least 256 voxels per split
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return (int)s;
+}
+size_t dreg_conv3d_wgrad_workspace_bytes(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int dtype) {
+    const int es = dtype == 0 ? 2 : 4;
+    const int bke = 128 / es;
+    const int Kpad = ((ksz * ksz * ksz * Cin + bke - 1) / bke) * bke;
+    return (size_t)dreg_conv3d_wgrad_splits(B, Do, Ho, Wo, Cin, Cout, ksz, dtype) * Cout * Kpad * sizeof(float);
+}
+
+// dW[Cout][Cin_real][ntaps] (torch layout, fp32) (+)= sum_m gout[m][:]^T x gathered in[m][tap][:]
+// gout: [B,Do,Ho,Wo,Cout], in: [B,Di,Hi,Wi,Cin] (same dtype).  use_tr: 1 = LDS transpose reads (bf16 only).
+int dreg_conv3d_wgrad(const void* gout, const void* in, float* dw, void* workspace, size_t workspace_bytes,
+                      int B, int Di, int Hi, int Wi, int Cin, int Cin_real, int Do, int Ho, int Wo, int Cout,
+                      int ksz, int stride, int pad, int accumulate, int dtype, int use_tr, void* stream)
+{
+    ConvGeom g;
+    const int es = dtype == 0 ? 2 : 4;
+    int rc = fill_geom(g, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, ksz, stride, pad, 0, es);
+    if (rc) return rc;
+    if (Cout % 128 != 0 && Cout != 64) return DREG_EINVAL;
+    if (workspace_bytes < dreg_conv3d_wgrad_workspace_bytes(B, Do, Ho, Wo, Cin, Cout, ksz, dtype)) return DREG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nsplit = dreg_conv3d_wgrad_splits(B, Do, Ho, Wo, Cin, Cout, ksz, dtype);
+    uint32_t vps = (uint32_t)((g.M + nsplit - 1) / nsplit);
+    vps = ((vps + 31) / 32) * 32;
+    const int bm = (Cout % 128 == 0) ? 128 : 64;
+    const int tilesRow = Cout / bm;
+    const int bnc = (g.Kpad % 128 == 0) ? 128 : 64;
+    const int tilesCol = g.Kpad / bnc;
+    dim3 grid(tilesRow * tilesCol, nsplit);
+    const size_t lds = (size_t)2 * 32 * (bm + bnc) * es;
+    float* part = (float*)workspace;
+#define WG_LAUNCH(T, BMv, BNv, TRv) hipLaunchKernelGGL((conv_wgrad_kernel<T, BMv, BNv, TRv>), grid, dim3(256), lds, st, (const T*)gout, (const T*)in, part, g, tilesCol, vps)
+#define WG_DISPATCH(T, TRv) do { \
+        if (bm == 128 && bnc == 128) WG_LAUNCH(T, 128, 128, TRv); \
+        else if (bm == 128 && bnc == 64) WG_LAUNCH(T, 128, 64, TRv); \
+        else if (bm == 64 && bnc == 128) WG_LAUNCH(T, 64, 128, TRv); \
+        else WG_LAUNCH(T, 64, 64, TRv); } while (0)
+    if (dtype == 0) { if (use_tr) WG_DISPATCH(bf16_t, true); else WG_DISPATCH(bf16_t, false); }
+    else WG_DISPATCH(float, false);
+#undef WG_DISPATCH
+#undef WG_LAUNCH
+    DREG_LAUNCH_CHECK();
+    const size_t total = (size_t)Cout * g.ntaps * Cin_real;
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, part, dw, nsplit, Cout, g.Kpad, g.ntaps, Cin, g.log2Cin, Cin_real, accumulate);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+}  // extern "C"

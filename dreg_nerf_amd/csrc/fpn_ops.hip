@@ -1,0 +1,575 @@
+// Memory-bound companions of the 3-D convolutions on the FPN3D path (gfx950): per-grid BatchNorm
+// (statistics / apply / backward), 3x3x3 stride-2 max-pool, the top-down 2x nearest "downsample-sum"
+// (backward of the upsample-add fused in the conv epilogue), channel column sums (bias gradients) and the
+// fused trilinear gather that replaces F.interpolate + advanced indexing.
+//
+// Reference call sites: conerf/model/resnet3d.py:95-113,121-123,157-161 (BatchNorm3d/ReLU/MaxPool3d),
+// conerf/model/feature_pyramid_net.py:58-61 (_upsample), conerf/register/nerf_regtr.py:138-147 (gather).
+// All tensors are NDHWC, 16-byte channel granules per thread, fp32 math.
+#include "common.h"
+
+template <typename T> struct Gran;
+template <> struct Gran<float> {
+    static constexpr int G = 4;
+    static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) { float4 q = *reinterpret_cast<const float4*>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+    static __device__ __forceinline__ void st(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Gran<bf16_t> {
+    static constexpr int G = 8;
+    static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
+        uint4 q = *reinterpret_cast<const uint4*>(p);
+        uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ BN statistics
+// partial[b][chunk][c][2] = (sum x, sum x^2) over the chunk's voxels.  grid (chunks, B, slabs), 256 threads.
+// MODE 0: plain sums of x.  MODE 1 (backward): sums of g and g*xhat with g = dy * (y > 0 if relu).
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(
+    const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y, const float* __restrict__ mean_rstd,
+    float* __restrict__ partial, int V, int C, int rows_per_chunk, int relu)
+{
+    constexpr int G = Gran<T>::G;
+    const int CG = C / G;
+    const int cgs = CG < 256 ? CG : 256;          // granule columns handled by this block
+    const int rpi = 256 / cgs;                    // rows per iteration
+    const int t = threadIdx.x;
+    const int cg = blockIdx.z * cgs + (t % cgs), r0 = t / cgs;
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int v0 = chunk * rows_per_chunk, v1 = min(v0 + rows_per_chunk, V);
+    float s1[G], s2[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) s1[i] = s2[i] = 0.f;
+    float mu[G], rs[G];
+    if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) { mu[i] = mean_rstd[((size_t)b * C + cg * G + i) * 2]; rs[i] = mean_rstd[((size_t)b * C + cg * G + i) * 2 + 1]; }
+    }
+    if (r0 < rpi) {
+        for (int v = v0 + r0; v < v1; v += rpi) {
+            const size_t off = ((size_t)b * V + v) * C + (size_t)cg * G;
+            float xv[G];
+            Gran<T>::ld(x + off, xv);
+            if (MODE == 0) {
+#pragma unroll
+                for (int i = 0; i < G; ++i) { s1[i] += xv[i]; s2[i] += xv[i] * xv[i]; }
+            } else {
+                float gv[G], yv[G];
+                Gran<T>::ld(dy + off, gv);
+                if (relu) { Gran<T>::ld(y + off, yv);
+#pragma unroll
+                    for (int i = 0; i < G; ++i) gv[i] = yv[i] > 0.f ? gv[i] : 0.f; }
+#pragma unroll
+                for (int i = 0; i < G; ++i) { s1[i] += gv[i]; s2[i] += gv[i] * (xv[i] - mu[i]) * rs[i]; }
+            }
+        }
+    }
+    __shared__ float red[256][2 * 8 + 1];
+#pragma unroll
+    for (int i = 0; i < G; ++i) { red[t][i] = s1[i]; red[t][G + i] = s2[i]; }
+    __syncthreads();
+    if (t < cgs) {
+        float a1[G], a2[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) { a1[i] = 0.f; a2[i] = 0.f; }
+        for (int r = 0; r < rpi; ++r)
+#pragma unroll
+            for (int i = 0; i < G; ++i) { a1[i] += red[r * cgs + t][i]; a2[i] += red[r * cgs + t][G + i]; }
+        float* dst = partial + (((size_t)b * nchunks + chunk) * C + (size_t)cg * G) * 2;
+#pragma unroll
+        for (int i = 0; i < G; ++i) { dst[2 * i] = a1[i]; dst[2 * i + 1] = a2[i]; }
+    }
+}
+
+// one thread per channel: finalise mean / biased var per grid, update running stats sequentially over the grids
+// (reference: one grid per BatchNorm call, src then tgt — nerf_regtr.py:135), emit scale/shift and (mean, rstd).
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ scale_shift, float* __restrict__ mean_rstd,
+                                   int B, int nchunks, int C, int V, float eps, float momentum, int train)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float ga = gamma[c], be = beta[c];
+    if (!train) {
+        const float rstd = 1.0f / sqrtf(running_var[c] + eps);
+        for (int b = 0; b < B; ++b) {
+            scale_shift[((size_t)b * C + c) * 2] = ga * rstd;
+            scale_shift[((size_t)b * C + c) * 2 + 1] = be - running_mean[c] * ga * rstd;
+            mean_rstd[((size_t)b * C + c) * 2] = running_mean[c];
+            mean_rstd[((size_t)b * C + c) * 2 + 1] = rstd;
+        }
+        return;
+    }
+    float rm = running_mean[c], rv = running_var[c];
+    for (int b = 0; b < B; ++b) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < nchunks; ++k) {
+            const float* p = partial + (((size_t)b * nchunks + k) * C + c) * 2;
+            s1 += p[0]; s2 += p[1];
+        }
+        const double mean = s1 / V;
+        double var = s2 / V - mean * mean;
+        if (var < 0) var = 0;
+        const float rstd = 1.0f / sqrtf((float)var + eps);
+        scale_shift[((size_t)b * C + c) * 2] = ga * rstd;
+        scale_shift[((size_t)b * C + c) * 2 + 1] = be - (float)mean * ga * rstd;
+        mean_rstd[((size_t)b * C + c) * 2] = (float)mean;
+        mean_rstd[((size_t)b * C + c) * 2 + 1] = rstd;
+        const float unbiased = V > 1 ? (float)(var * V / (V - 1)) : (float)var;
+        rm = (1.f - momentum) * rm + momentum * (float)mean;
+        rv = (1.f - momentum) * rv + momentum * unbiased;
+    }
+    running_mean[c] = rm; running_var[c] = rv;
+}
+
+// y = [relu]( x * scale[b,c] + shift[b,c] [+ res] )
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale_shift, const T* __restrict__ res,
+                                T* __restrict__ y, size_t total_gran, int V, int C, int relu)
+{
+    constexpr int G = Gran<T>::G;
+    const int CG = C / G;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total_gran; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        const int b = (int)((i / CG) / V);
+        float xv[G], rv[G];
+        Gran<T>::ld(x + i * G, xv);
+        if (res) Gran<T>::ld(res + i * G, rv);
+        const float* ss = scale_shift + ((size_t)b * C + (size_t)cg * G) * 2;
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            float v = xv[k] * ss[2 * k] + ss[2 * k + 1];
+            if (res) v += rv[k];
+            xv[k] = relu ? fmaxf(v, 0.f) : v;
+        }
+        Gran<T>::st(y + i * G, xv);
+    }
+}
+
+// backward finalize: per (b,c) coefficients c1 = sum(g)/V, c2 = sum(g*xhat)/V; dgamma/dbeta summed over grids.
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ coef, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int B, int nchunks, int C, int V, int accumulate)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double dg = 0.0, db = 0.0;
+    for (int b = 0; b < B; ++b) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < nchunks; ++k) {
+            const float* p = partial + (((size_t)b * nchunks + k) * C + c) * 2;
+            s1 += p[0]; s2 += p[1];
+        }
+        coef[((size_t)b * C + c) * 2] = (float)(s1 / V);
+        coef[((size_t)b * C + c) * 2 + 1] = (float)(s2 / V);
+        db += s1; dg += s2;
+    }
+    dgamma[c] = accumulate ? dgamma[c] + (float)dg : (float)dg;
+    dbeta[c] = accumulate ? dbeta[c] + (float)db : (float)db;
+}
+
+// dx = gamma*rstd * (g - c1 - xhat*c2),  g = dy * (y > 0 if relu);  dres = g (optional)
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
+                                    const float* __restrict__ mean_rstd, const float* __restrict__ scale_shift,
+                                    const float* __restrict__ coef, T* __restrict__ dx, T* __restrict__ dres,
+                                    size_t total_gran, int V, int C, int relu)
+{
+    constexpr int G = Gran<T>::G;
+    const int CG = C / G;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total_gran; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        const int b = (int)((i / CG) / V);
+        float xv[G], gv[G], yv[G];
+        Gran<T>::ld(x + i * G, xv);
+        Gran<T>::ld(dy + i * G, gv);
+        if (relu) { Gran<T>::ld(y + i * G, yv);
+#pragma unroll
+            for (int k = 0; k < G; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f; }
+        if (dres) Gran<T>::st(dres + i * G, gv);
+        const size_t pc = ((size_t)b * C + (size_t)cg * G) * 2;
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const float xh = (xv[k] - mean_rstd[pc + 2 * k]) * mean_rstd[pc + 2 * k + 1];
+            xv[k] = scale_shift[pc + 2 * k] * (gv[k] - coef[pc + 2 * k] - xh * coef[pc + 2 * k + 1]);
+        }
+        Gran<T>::st(dx + i * G, xv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ max-pool 3^3 s2 p1
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ arg,
+                                   int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C)
+{
+    constexpr int G = Gran<T>::G;
+    const int CG = C / G;
+    const size_t total = (size_t)B * Do * Ho * Wo * CG;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        size_t r = i / CG;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho); r /= Ho;
+        const int oz = (int)(r % Do);
+        const int b = (int)(r / Do);
+        float best[G];
+        int bi[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) { best[k] = -INFINITY; bi[k] = 0; }
+        for (int dz = 0; dz < 3; ++dz) {
+            const int z = oz * 2 - 1 + dz; if ((unsigned)z >= (unsigned)Di) continue;
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yy = oy * 2 - 1 + dy; if ((unsigned)yy >= (unsigned)Hi) continue;
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int xx = ox * 2 - 1 + dx; if ((unsigned)xx >= (unsigned)Wi) continue;
+                    float v[G];
+                    Gran<T>::ld(x + ((((size_t)b * Di + z) * Hi + yy) * Wi + xx) * C + (size_t)cg * G, v);
+                    const int tap = (dz * 3 + dy) * 3 + dx;
+#pragma unroll
+                    for (int k = 0; k < G; ++k) if (v[k] > best[k]) { best[k] = v[k]; bi[k] = tap; }
+                }
+            }
+        }
+        Gran<T>::st(y + i * G, best);
+#pragma unroll
+        for (int k = 0; k < G; ++k) arg[i * G + k] = (uint8_t)bi[k];
+    }
+}
+
+// gather-form backward: every input voxel sums the dy of the windows whose arg-max tap points at it
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ arg, T* __restrict__ dx,
+                                   int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C)
+{
+    constexpr int G = Gran<T>::G;
+    const int CG = C / G;
+    const size_t total = (size_t)B * Di * Hi * Wi * CG;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        size_t r = i / CG;
+        const int ix = (int)(r % Wi); r /= Wi;
+        const int iy = (int)(r % Hi); r /= Hi;
+        const int iz = (int)(r % Di);
+        const int b = (int)(r / Di);
+        float acc[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) acc[k] = 0.f;
+        for (int oz = max(0, iz / 2); oz <= min(Do - 1, (iz + 1) / 2); ++oz) {
+            const int dz = iz - 2 * oz + 1; if (dz < 0 || dz > 2) continue;
+            for (int oy = max(0, iy / 2); oy <= min(Ho - 1, (iy + 1) / 2); ++oy) {
+                const int dyy = iy - 2 * oy + 1; if (dyy < 0 || dyy > 2) continue;
+                for (int ox = max(0, ix / 2); ox <= min(Wo - 1, (ix + 1) / 2); ++ox) {
+                    const int dxx = ix - 2 * ox + 1; if (dxx < 0 || dxx > 2) continue;
+                    const int tap = (dz * 3 + dyy) * 3 + dxx;
+                    const size_t o = ((((size_t)b * Do + oz) * Ho + oy) * Wo + ox) * C + (size_t)cg * G;
+                    float g[G];
+                    Gran<T>::ld(dy + o, g);
+#pragma unroll
+                    for (int k = 0; k < G; ++k) if (arg[o + k] == tap) acc[k] += g[k];
+                }
+            }
+        }
+        Gran<T>::st(dx + i * G, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ 2x downsample-sum
+// out[b,z,y,x,:] = sum over the (cropped) 2x2x2 children of g  (backward of nearest x2 upsample + crop)
+template <typename T>
+__global__ void downsample_sum_kernel(const T* __restrict__ g, T* __restrict__ out, int B, int Df, int Hf, int Wf,
+                                      int Dc, int Hc, int Wc, int C)
+{
+    constexpr int G = Gran<T>::G;
+    const int CG = C / G;
+    const size_t total = (size_t)B * Dc * Hc * Wc * CG;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        size_t r = i / CG;
+        const int x = (int)(r % Wc); r /= Wc;
+        const int y = (int)(r % Hc); r /= Hc;
+        const int z = (int)(r % Dc);
+        const int b = (int)(r / Dc);
+        float acc[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) acc[k] = 0.f;
+        for (int a = 0; a < 2; ++a) { const int zz = 2 * z + a; if (zz >= Df) continue;
+            for (int c = 0; c < 2; ++c) { const int yy = 2 * y + c; if (yy >= Hf) continue;
+                for (int d = 0; d < 2; ++d) { const int xx = 2 * x + d; if (xx >= Wf) continue;
+                    float v[G];
+                    Gran<T>::ld(g + ((((size_t)b * Df + zz) * Hf + yy) * Wf + xx) * C + (size_t)cg * G, v);
+#pragma unroll
+                    for (int k = 0; k < G; ++k) acc[k] += v[k];
+                } } }
+        Gran<T>::st(out + i * G, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+// out[c] (+)= sum_m g[m][c]   two-stage: partial[chunk][c] then a final pass
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ g, float* __restrict__ partial, size_t M, int C, int rows_per_chunk)
+{
+    constexpr int G = Gran<T>::G;
+    const int CG = C / G;
+    const int cgs = CG < 256 ? CG : 256, rpi = 256 / cgs;
+    const int t = threadIdx.x, cg = blockIdx.y * cgs + (t % cgs), r0 = t / cgs;
+    const size_t v0 = (size_t)blockIdx.x * rows_per_chunk, v1 = min(v0 + (size_t)rows_per_chunk, M);
+    float s[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) s[i] = 0.f;
+    if (r0 < rpi)
+        for (size_t v = v0 + r0; v < v1; v += rpi) {
+            float x[G];
+            Gran<T>::ld(g + v * C + (size_t)cg * G, x);
+#pragma unroll
+            for (int i = 0; i < G; ++i) s[i] += x[i];
+        }
+    __shared__ float red[256][9];
+#pragma unroll
+    for (int i = 0; i < G; ++i) red[t][i] = s[i];
+    __syncthreads();
+    if (t < cgs) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) { float a = 0.f; for (int r = 0; r < rpi; ++r) a += red[r * cgs + t][i]; partial[(size_t)blockIdx.x * C + (size_t)cg * G + i] = a; }
+    }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nchunks, int C, int accumulate)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < nchunks; ++k) s += partial[(size_t)k * C + c];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------ trilinear gather
+// feats[n][:] = trilinear sample (align_corners=True) of p1[b] at fine voxel index idx[n] of a (Zr,Xr,Yr) grid whose
+// flat index is (x*Yr + y)*Zr + z  (nerf_regtr.py:144-147).  p1 dims (d,h,w) correspond to (z,x,y).
+struct TriAxis { int i0, i1; float t; };
+__device__ __forceinline__ TriAxis tri_axis(int i, int n_out, int n_in) {
+    const float s = n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f;
+    const float f = (float)i * s;
+    TriAxis a;
+    a.i0 = min((int)f, n_in - 1);
+    a.i1 = min(a.i0 + 1, n_in - 1);
+    a.t = f - (float)a.i0;
+    return a;
+}
+template <typename T, typename TO>
+__global__ void trilinear_gather_fwd_kernel(const T* __restrict__ p1, const int64_t* __restrict__ idx, const int* __restrict__ pt_batch,
+                                            TO* __restrict__ out, int N, int d, int h, int w, int C, int Zr, int Xr, int Yr)
+{
+    constexpr int G = Gran<T>::G;
+    const int CG = C / G;
+    const size_t total = (size_t)N * CG;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG), n = (int)(i / CG);
+        const int64_t f = idx[n];
+        const int z = (int)(f % Zr), y = (int)((f / Zr) % Yr), x = (int)(f / ((int64_t)Zr * Yr));
+        const int b = pt_batch[n];
+        const TriAxis az = tri_axis(z, Zr, d), ax = tri_axis(x, Xr, h), ay = tri_axis(y, Yr, w);
+        float acc[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int zi = (c & 4) ? az.i1 : az.i0, xi = (c & 2) ? ax.i1 : ax.i0, yi = (c & 1) ? ay.i1 : ay.i0;
+            const float wgt = ((c & 4) ? az.t : 1.f - az.t) * ((c & 2) ? ax.t : 1.f - ax.t) * ((c & 1) ? ay.t : 1.f - ay.t);
+            float v[G];
+            Gran<T>::ld(p1 + ((((size_t)b * d + zi) * h + xi) * w + yi) * C + (size_t)cg * G, v);
+#pragma unroll
+            for (int k = 0; k < G; ++k) acc[k] += v[k] * wgt;
+        }
+        if constexpr (sizeof(TO) == 4) {
+#pragma unroll
+            for (int k = 0; k < G; ++k) out[(size_t)n * C + (size_t)cg * G + k] = acc[k];
+        } else {
+            Gran<T>::st((T*)out + (size_t)n * C + (size_t)cg * G, acc);
+        }
+    }
+}
+// backward: scatter-add of dfeats into an fp32 grid gradient (atomics; the gradient is sparse around the mask)
+template <typename TG>
+__global__ void trilinear_gather_bwd_kernel(const TG* __restrict__ dfeat, const int64_t* __restrict__ idx, const int* __restrict__ pt_batch,
+                                            float* __restrict__ dp1, int N, int d, int h, int w, int C, int Zr, int Xr, int Yr)
+{
+    const size_t total = (size_t)N * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), n = (int)(i / C);
+        const int64_t f = idx[n];
+        const int z = (int)(f % Zr), y = (int)((f / Zr) % Yr), x = (int)(f / ((int64_t)Zr * Yr));
+        const int b = pt_batch[n];
+        const TriAxis az = tri_axis(z, Zr, d), ax = tri_axis(x, Xr, h), ay = tri_axis(y, Yr, w);
+        const float g = Elem<TG>::ld(dfeat + i);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int zi = (k & 4) ? az.i1 : az.i0, xi = (k & 2) ? ax.i1 : ax.i0, yi = (k & 1) ? ay.i1 : ay.i0;
+            const float wgt = ((k & 4) ? az.t : 1.f - az.t) * ((k & 2) ? ax.t : 1.f - ax.t) * ((k & 1) ? ay.t : 1.f - ay.t);
+            if (wgt != 0.f) atomicAdd(dp1 + ((((size_t)b * d + zi) * h + xi) * w + yi) * C + c, g * wgt);
+        }
+    }
+}
+
+// fp32 <-> T conversions (contiguous)
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) Elem<T>::st(out + i, in[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+static inline int nblocks(size_t total, int per = 256, int cap = 8192) {
+    size_t b = (total + per - 1) / per;
+    return (int)(b > (size_t)cap ? cap : (b ? b : 1));
+}
+static inline int bn_rows_per_chunk(int V) { return V >= 4096 ? 1024 : (V >= 256 ? 256 : V); }
+
+extern "C" {
+
+int dreg_bn_num_chunks(int V) { const int r = bn_rows_per_chunk(V); return (V + r - 1) / r; }
+
+// Forward BatchNorm3d over B independent grids (per-grid statistics).  x,y,res: [B,V,C] (dtype 0 bf16 / 1 fp32).
+// workspace: fp32 [B * chunks * C * 2].  scale_shift, mean_rstd: fp32 [B,C,2] outputs (saved for backward).
+int dreg_bn3d_fwd(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                  float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
+                  int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int G = dtype == 0 ? 8 : 4;
+    if (C % G) return DREG_EINVAL;
+    const int rpc = bn_rows_per_chunk(V), nch = (V + rpc - 1) / rpc;
+    const int CG = C / G, slabs = (CG + 255) / 256;
+    if (train) {
+        if (train && V < 2) return DREG_EINVAL;  // torch raises for one value per channel
+        dim3 grid(nch, B, slabs);
+        if (dtype == 0) hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 0>), grid, dim3(256), 0, st, (const bf16_t*)x, nullptr, nullptr, nullptr, workspace, V, C, rpc, 0);
+        else hipLaunchKernelGGL((bn_partial_kernel<float, 0>), grid, dim3(256), 0, st, (const float*)x, nullptr, nullptr, nullptr, workspace, V, C, rpc, 0);
+        DREG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, workspace, gamma, beta, running_mean, running_var,
+                       scale_shift, mean_rstd, B, nch, C, V, eps, momentum, train);
+    DREG_LAUNCH_CHECK();
+    const size_t tg = (size_t)B * V * CG;
+    if (dtype == 0) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(nblocks(tg)), dim3(256), 0, st, (const bf16_t*)x, scale_shift, (const bf16_t*)res, (bf16_t*)y, tg, V, C, relu);
+    else hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(nblocks(tg)), dim3(256), 0, st, (const float*)x, scale_shift, (const float*)res, (float*)y, tg, V, C, relu);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// Backward of y = [relu](bn(x) [+ res]) in training mode.  dres may be null.  coef: fp32 [B,C,2] scratch.
+int dreg_bn3d_bwd(const void* x, const void* dy, const void* y, const float* scale_shift, const float* mean_rstd,
+                  void* dx, void* dres, float* dgamma, float* dbeta, float* coef, float* workspace,
+                  int B, int V, int C, int relu, int accumulate, int dtype, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int G = dtype == 0 ? 8 : 4;
+    if (C % G) return DREG_EINVAL;
+    const int rpc = bn_rows_per_chunk(V), nch = (V + rpc - 1) / rpc;
+    const int CG = C / G, slabs = (CG + 255) / 256;
+    dim3 grid(nch, B, slabs);
+    if (dtype == 0) hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean_rstd, workspace, V, C, rpc, relu);
+    else hipLaunchKernelGGL((bn_partial_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y, mean_rstd, workspace, V, C, rpc, relu);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, workspace, coef, dgamma, dbeta, B, nch, C, V, accumulate);
+    DREG_LAUNCH_CHECK();
+    const size_t tg = (size_t)B * V * CG;
+    if (dtype == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(nblocks(tg)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean_rstd, scale_shift, coef, (bf16_t*)dx, (bf16_t*)dres, tg, V, C, relu);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(nblocks(tg)), dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y, mean_rstd, scale_shift, coef, (float*)dx, (float*)dres, tg, V, C, relu);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+int dreg_maxpool3d_fwd(const void* x, void* y, uint8_t* argmax, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int dtype, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int G = dtype == 0 ? 8 : 4;
+    const size_t total = (size_t)B * Do * Ho * Wo * (C / G);
+    if (dtype == 0) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, B, Di, Hi, Wi, Do, Ho, Wo, C);
+    else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(nblocks(total)), dim3(256), 0, st, (const float*)x, (float*)y, argmax, B, Di, Hi, Wi, Do, Ho, Wo, C);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+int dreg_maxpool3d_bwd(const void* dy, const uint8_t* argmax, void* dx, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int dtype, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int G = dtype == 0 ? 8 : 4;
+    const size_t total = (size_t)B * Di * Hi * Wi * (C / G);
+    if (dtype == 0) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, B, Di, Hi, Wi, Do, Ho, Wo, C);
+    else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(nblocks(total)), dim3(256), 0, st, (const float*)dy, argmax, (float*)dx, B, Di, Hi, Wi, Do, Ho, Wo, C);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+int dreg_downsample_sum(const void* g, void* out, int B, int Df, int Hf, int Wf, int Dc, int Hc, int Wc, int C, int dtype, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int G = dtype == 0 ? 8 : 4;
+    const size_t total = (size_t)B * Dc * Hc * Wc * (C / G);
+    if (dtype == 0) hipLaunchKernelGGL(downsample_sum_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, st, (const bf16_t*)g, (bf16_t*)out, B, Df, Hf, Wf, Dc, Hc, Wc, C);
+    else hipLaunchKernelGGL(downsample_sum_kernel<float>, dim3(nblocks(total)), dim3(256), 0, st, (const float*)g, (float*)out, B, Df, Hf, Wf, Dc, Hc, Wc, C);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+size_t dreg_colsum_workspace_bytes(size_t M, int C) { const size_t nch = (M + 1023) / 1024; return nch * C * sizeof(float); }
+int dreg_colsum(const void* g, float* out, float* workspace, size_t M, int C, int accumulate, int dtype, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int G = dtype == 0 ? 8 : 4;
+    if (C % G) return DREG_EINVAL;
+    const int nch = (int)((M + 1023) / 1024);
+    const int CG = C / G, slabs = (CG + 255) / 256;
+    if (dtype == 0) hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3(nch, slabs), dim3(256), 0, st, (const bf16_t*)g, workspace, M, C, 1024);
+    else hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(nch, slabs), dim3(256), 0, st, (const float*)g, workspace, M, C, 1024);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 127) / 128), dim3(128), 0, st, workspace, out, nch, C, accumulate);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// p1: [B,d,h,w,C] (dtype), idx: int64 [N] flat fine-grid indices, pt_batch: int32 [N] grid id of every point.
+// out: [N,C] fp32 (out_f32 = 1) or dtype.
+int dreg_trilinear_gather_fwd(const void* p1, const int64_t* idx, const int* pt_batch, void* out, int N, int d, int h, int w, int C,
+                              int Zr, int Xr, int Yr, int dtype, int out_f32, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int G = dtype == 0 ? 8 : 4;
+    const size_t total = (size_t)N * (C / G);
+    if (N == 0) return DREG_OK;
+    if (dtype == 0) {
+        if (out_f32) hipLaunchKernelGGL((trilinear_gather_fwd_kernel<bf16_t, float>), dim3(nblocks(total)), dim3(256), 0, st, (const bf16_t*)p1, idx, pt_batch, (float*)out, N, d, h, w, C, Zr, Xr, Yr);
+        else hipLaunchKernelGGL((trilinear_gather_fwd_kernel<bf16_t, bf16_t>), dim3(nblocks(total)), dim3(256), 0, st, (const bf16_t*)p1, idx, pt_batch, (bf16_t*)out, N, d, h, w, C, Zr, Xr, Yr);
+    } else hipLaunchKernelGGL((trilinear_gather_fwd_kernel<float, float>), dim3(nblocks(total)), dim3(256), 0, st, (const float*)p1, idx, pt_batch, (float*)out, N, d, h, w, C, Zr, Xr, Yr);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// dfeat: [N,C] fp32 -> dp1_f32 [B,d,h,w,C] fp32 (must be zeroed by the caller), atomically accumulated.
+int dreg_trilinear_gather_bwd(const float* dfeat, const int64_t* idx, const int* pt_batch, float* dp1_f32, int N, int d, int h, int w, int C,
+                              int Zr, int Xr, int Yr, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (N == 0) return DREG_OK;
+    const size_t total = (size_t)N * C;
+    hipLaunchKernelGGL(trilinear_gather_bwd_kernel<float>, dim3(nblocks(total)), dim3(256), 0, st, dfeat, idx, pt_batch, dp1_f32, N, d, h, w, C, Zr, Xr, Yr);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+int dreg_cast_from_f32(const float* in, void* out, size_t n, int dtype, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0) hipLaunchKernelGGL(cast_from_f32_kernel<bf16_t>, dim3(nblocks(n)), dim3(256), 0, st, in, (bf16_t*)out, n);
+    else hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, in, (float*)out, n);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+"""ctypes binding of the C-ABI library (include/dreg_nerf.h).  No CPU fallback: if the shared object is
+missing or a symbol fails, the product path raises."""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdreg_nerf_hip.so")
+
+DT_BF16 = 0
+DT_F32 = 1
+
+_lib = None
+
+
+class DregError(RuntimeError):
+    pass
+
+
+def _sig(lib, name, restype, argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = argtypes
+    return fn
+
+
+P, I, F, Z = c_void_p, c_int, c_float, c_size_t
+
+SIGNATURES = {
+    # conv.hip
+    "dreg_conv3d_igemm": (I, [P, P, P, P, P] + [I] * 17 + [I, I, P]),
+    "dreg_conv3d_kpad": (I, [I, I, I]),
+    "dreg_pack_conv_weight": (I, [P, P, I, I, I, I, I, I, P]),
+    "dreg_conv3d_wgrad_splits": (I, [I] * 8),
+    "dreg_conv3d_wgrad_workspace_bytes": (Z, [I] * 8),
+    "dreg_conv3d_wgrad": (I, [P, P, P, P, Z] + [I] * 16 + [P]),
+    # fpn_ops.hip
+    "dreg_bn_num_chunks": (I, [I]),
+    "dreg_bn3d_fwd": (I, [P] * 10 + [I, I, I, F, F, I, I, I, P]),
+    "dreg_bn3d_bwd": (I, [P] * 11 + [I, I, I, I, I, I, P]),
+    "dreg_maxpool3d_fwd": (I, [P, P, P] + [I] * 9 + [P]),
+    "dreg_maxpool3d_bwd": (I, [P, P, P] + [I] * 9 + [P]),
+    "dreg_downsample_sum": (I, [P, P] + [I] * 9 + [P]),
+    "dreg_colsum_workspace_bytes": (Z, [Z, I]),
+    "dreg_colsum": (I, [P, P, P, Z, I, I, I, P]),
+    "dreg_trilinear_gather_fwd": (I, [P, P, P, P] + [I] * 10 + [P]),
+    "dreg_trilinear_gather_bwd": (I, [P, P, P, P] + [I] * 8 + [P]),
+    "dreg_cast_from_f32": (I, [P, P, Z, I, P]),
+}
+
+
+def load():
+    """Load the library once; raise loudly when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DregError(
+                f"{LIB_PATH} not found: build it with `python -m dreg_nerf_amd.build` "
+                "(hipcc --offload-arch=gfx950); dreg_nerf_amd has no CPU/eager fallback")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (rt, at) in SIGNATURES.items():
+            _sig(lib, name, rt, at)
+        _lib = lib
+    return _lib
+
+
+def declared_symbols():
+    return list(SIGNATURES.keys())
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_contiguous(), "non-contiguous tensor handed to the C ABI"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_DEBUG_SYNC = bool(int(os.environ.get("DREG_DEBUG_SYNC", "0")))
+
+
+def check(rc, name):
+    if rc != 0:
+        raise DregError(f"{name} failed with code {rc}")
+    if _DEBUG_SYNC:  # localise asynchronous faults: DREG_DEBUG_SYNC=1
+        import sys
+        print(f"[dreg] {name} launched", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
+
+
+def dt_of(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    if t.dtype == torch.float32:
+        return DT_F32
+    raise DregError(f"unsupported dtype {t.dtype}")
+
+
+def torch_dtype(dt: int):
+    return torch.bfloat16 if dt == DT_BF16 else torch.float32

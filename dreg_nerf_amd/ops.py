@@ -1,0 +1,279 @@
+"""torch.autograd.Function wrappers over the C ABI (raw pointers + the current HIP stream).
+
+Activations are NDHWC tensors ``[B, D, H, W, C]`` in bf16 (production) or fp32 (exact-f32 MFMA parity
+mode).  Master weights stay fp32 in torch layout; the kernels consume per-step packed copies.
+"""
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# --------------------------------------------------------------------------- weight packing (cached per parameter version)
+import weakref
+
+_pack_cache = {}
+
+
+def clear_pack_cache():
+    _pack_cache.clear()
+
+
+def packed_weight(w: torch.Tensor, cin_pad: int, for_dgrad: bool, dt: int) -> torch.Tensor:
+    """w: fp32 [Cout, Cin, k, k, k] (or [Cout, Cin] for linear layers, possibly a row slice of a parameter).
+    The pack is cached against the owning parameter object (weak reference) and its in-place version counter."""
+    base = w._base if w._base is not None else w
+    key = (id(base), w.storage_offset(), tuple(w.shape), cin_pad, for_dgrad, dt)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is base and hit[1] == base._version:
+        return hit[2]
+    lib = L.load()
+    cout, cin_real = w.shape[0], w.shape[1]
+    ksz = w.shape[2] if w.dim() == 5 else 1
+    wd = w.detach().contiguous()
+    if not for_dgrad:
+        kpad = lib.dreg_conv3d_kpad(ksz, cin_pad, dt)
+        out = torch.empty(cout, kpad, dtype=L.torch_dtype(dt), device=w.device)
+    else:
+        kpad = lib.dreg_conv3d_kpad(ksz, cout, dt)
+        out = torch.empty(cin_real, kpad, dtype=L.torch_dtype(dt), device=w.device)
+    L.check(lib.dreg_pack_conv_weight(L.ptr(wd), L.ptr(out), cout, cin_real, cin_pad, ksz, int(for_dgrad), dt, L.stream()),
+            "dreg_pack_conv_weight")
+    if len(_pack_cache) > 4096:  # entries of dead parameters
+        for k in [k for k, v in _pack_cache.items() if v[0]() is None]:
+            del _pack_cache[k]
+    _pack_cache[key] = (weakref.ref(base), base._version, out)
+    return out
+
+
+def _out_dim(i, k, s, p):
+    return (i + 2 * p - k) // s + 1
+
+
+# --------------------------------------------------------------------------- convolution
+def conv_igemm(x, wpk, bias, addend, out_shape, cin, cout, ksz, stride, pad, transposed, relu=False, out_f32=False):
+    """Raw launcher.  x: [B,Di,Hi,Wi,cin]; returns [B,*out_shape,cout]."""
+    lib = L.load()
+    dt = L.dt_of(x)
+    B, Di, Hi, Wi = x.shape[0], x.shape[1], x.shape[2], x.shape[3]
+    Do, Ho, Wo = out_shape
+    odt = torch.float32 if (out_f32 or dt == L.DT_F32) else torch.bfloat16
+    out = torch.empty(B, Do, Ho, Wo, cout, dtype=odt, device=x.device)
+    Da = Ha = Wa = 0
+    if addend is not None:
+        assert addend.dtype == odt and addend.shape[0] == B and addend.shape[4] == cout
+        Da, Ha, Wa = addend.shape[1], addend.shape[2], addend.shape[3]
+        assert 2 * Da >= Do and 2 * Ha >= Ho and 2 * Wa >= Wo
+    L.check(lib.dreg_conv3d_igemm(L.ptr(x), L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(addend),
+                                  B, Di, Hi, Wi, cin, Do, Ho, Wo, cout, ksz, stride, pad, int(transposed), int(relu),
+                                  Da, Ha, Wa, dt, int(out_f32 and dt == L.DT_BF16), L.stream()), "dreg_conv3d_igemm")
+    return out
+
+
+def conv_wgrad(gout, x, w_shape, cin_pad, ksz, stride, pad, use_tr=True):
+    lib = L.load()
+    dt = L.dt_of(x)
+    B, Di, Hi, Wi = x.shape[:4]
+    Do, Ho, Wo, cout = gout.shape[1:]
+    cin_real = w_shape[1]
+    nbytes = lib.dreg_conv3d_wgrad_workspace_bytes(B, Do, Ho, Wo, cin_pad, cout, ksz, dt)
+    ws = _ws(nbytes, x.device)
+    dw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
+    L.check(lib.dreg_conv3d_wgrad(L.ptr(gout), L.ptr(x), L.ptr(dw), L.ptr(ws), nbytes, B, Di, Hi, Wi, cin_pad, cin_real,
+                                  Do, Ho, Wo, cout, ksz, stride, pad, 0, dt, int(use_tr and dt == L.DT_BF16), L.stream()),
+            "dreg_conv3d_wgrad")
+    return dw
+
+
+def colsum(g2d: torch.Tensor) -> torch.Tensor:
+    lib = L.load()
+    M, C = g2d.shape
+    ws = _ws(lib.dreg_colsum_workspace_bytes(M, C), g2d.device)
+    out = torch.empty(C, dtype=torch.float32, device=g2d.device)
+    L.check(lib.dreg_colsum(L.ptr(g2d), L.ptr(out), L.ptr(ws), M, C, 0, L.dt_of(g2d), L.stream()), "dreg_colsum")
+    return out
+
+
+def downsample_sum(g, coarse_shape):
+    lib = L.load()
+    B, Df, Hf, Wf, C = g.shape
+    Dc, Hc, Wc = coarse_shape
+    out = torch.empty(B, Dc, Hc, Wc, C, dtype=g.dtype, device=g.device)
+    L.check(lib.dreg_downsample_sum(L.ptr(g), L.ptr(out), B, Df, Hf, Wf, Dc, Hc, Wc, C, L.dt_of(g), L.stream()),
+            "dreg_downsample_sum")
+    return out
+
+
+USE_TR = True  # LDS transpose reads in the bf16 weight-gradient kernel (False = 16-bit gather checker path)
+
+
+class Conv3dFn(torch.autograd.Function):
+    """y = conv3d(x, w) [+ bias] [+ nearest_up2(addend)]  — NDHWC, MFMA implicit GEMM forward,
+    data gradient (same kernel, transposed coordinate map) and split-K weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, addend, stride: int, pad: int):
+        dt = L.dt_of(x)
+        cin_pad = x.shape[4]
+        cout = w.shape[0]
+        ksz = w.shape[2] if w.dim() == 5 else 1
+        out_shape = tuple(_out_dim(x.shape[i + 1], ksz, stride, pad) for i in range(3))
+        wpk = packed_weight(w, cin_pad, False, dt)
+        b32 = bias.detach().float().contiguous() if bias is not None else None
+        y = conv_igemm(x, wpk, b32, addend, out_shape, cin_pad, cout, ksz, stride, pad, False)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, ksz, cin_pad, bias is not None, None if addend is None else tuple(addend.shape[1:4]))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, pad, ksz, cin_pad, has_bias, add_shape = ctx.cfg
+        dt = L.dt_of(x)
+        gy = gy.contiguous()
+        cout = w.shape[0]
+        gx = gw = gb = ga = None
+        if ctx.needs_input_grad[0]:
+            wpk = packed_weight(w, cin_pad, True, dt)
+            gx = conv_igemm(gy, wpk, None, None, tuple(x.shape[1:4]), cout, w.shape[1], ksz, stride, pad, True)
+        if ctx.needs_input_grad[1]:
+            gw = conv_wgrad(gy, x, tuple(w.shape), cin_pad, ksz, stride, pad, USE_TR)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = colsum(gy.view(-1, cout))
+        if add_shape is not None and ctx.needs_input_grad[3]:
+            ga = downsample_sum(gy, add_shape)
+        return gx, gw, gb, ga, None, None
+
+
+def conv3d(x, w, bias=None, addend=None, stride=1, pad=0):
+    return Conv3dFn.apply(x, w, bias, addend, stride, pad)
+
+
+def linear(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """[N, Cin] x [Cout, Cin]^T through the 1x1x1 path of the same kernels."""
+    n, cin = x2d.shape
+    y = Conv3dFn.apply(x2d.view(1, 1, 1, n, cin), w, bias, None, 1, 0)
+    return y.view(n, w.shape[0])
+
+
+# --------------------------------------------------------------------------- BatchNorm (+res) (+ReLU), per-grid statistics
+class BatchNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, res, relu: bool, train: bool, eps: float, momentum: float):
+        lib = L.load()
+        dt = L.dt_of(x)
+        B, C = x.shape[0], x.shape[4]
+        V = x.shape[1] * x.shape[2] * x.shape[3]
+        nch = lib.dreg_bn_num_chunks(V)
+        ws = torch.empty(B * nch * C * 2, dtype=torch.float32, device=x.device)
+        ss = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
+        mr = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        L.check(lib.dreg_bn3d_fwd(L.ptr(x), L.ptr(res), L.ptr(y), L.ptr(gamma.detach()), L.ptr(beta.detach()),
+                                  L.ptr(running_mean), L.ptr(running_var), L.ptr(ss), L.ptr(mr), L.ptr(ws),
+                                  B, V, C, eps, momentum, int(train), int(relu), dt, L.stream()), "dreg_bn3d_fwd")
+        ctx.save_for_backward(x, y, ss, mr)
+        ctx.cfg = (relu, train, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, ss, mr = ctx.saved_tensors
+        relu, train, has_res = ctx.cfg
+        if not train:
+            raise L.DregError("BatchNorm backward is implemented for training-mode statistics only")
+        lib = L.load()
+        dt = L.dt_of(x)
+        gy = gy.contiguous()
+        B, C = x.shape[0], x.shape[4]
+        V = x.shape[1] * x.shape[2] * x.shape[3]
+        nch = lib.dreg_bn_num_chunks(V)
+        ws = torch.empty(B * nch * C * 2, dtype=torch.float32, device=x.device)
+        coef = torch.empty(B, C, 2, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        L.check(lib.dreg_bn3d_bwd(L.ptr(x), L.ptr(gy), L.ptr(y), L.ptr(ss), L.ptr(mr), L.ptr(dx), L.ptr(dres),
+                                  L.ptr(dg), L.ptr(db), L.ptr(coef), L.ptr(ws), B, V, C, int(relu), 0, dt, L.stream()),
+                "dreg_bn3d_bwd")
+        return dx, dg, db, None, None, dres, None, None, None, None
+
+
+def batchnorm(x, gamma, beta, running_mean, running_var, res=None, relu=True, train=True, eps=1e-5, momentum=0.1):
+    return BatchNormFn.apply(x, gamma, beta, running_mean, running_var, res, relu, train, eps, momentum)
+
+
+# --------------------------------------------------------------------------- MaxPool3d(3, 2, 1)
+class MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = L.load()
+        B, Di, Hi, Wi, C = x.shape
+        Do, Ho, Wo = (_out_dim(Di, 3, 2, 1), _out_dim(Hi, 3, 2, 1), _out_dim(Wi, 3, 2, 1))
+        y = torch.empty(B, Do, Ho, Wo, C, dtype=x.dtype, device=x.device)
+        arg = torch.empty(B, Do, Ho, Wo, C, dtype=torch.uint8, device=x.device)
+        L.check(lib.dreg_maxpool3d_fwd(L.ptr(x), L.ptr(y), L.ptr(arg), B, Di, Hi, Wi, Do, Ho, Wo, C, L.dt_of(x), L.stream()),
+                "dreg_maxpool3d_fwd")
+        ctx.save_for_backward(arg)
+        ctx.in_shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (arg,) = ctx.saved_tensors
+        lib = L.load()
+        B, Di, Hi, Wi, C = ctx.in_shape
+        Do, Ho, Wo = arg.shape[1:4]
+        gy = gy.contiguous()
+        dx = torch.empty(ctx.in_shape, dtype=gy.dtype, device=gy.device)
+        L.check(lib.dreg_maxpool3d_bwd(L.ptr(gy), L.ptr(arg), L.ptr(dx), B, Di, Hi, Wi, Do, Ho, Wo, C, L.dt_of(gy), L.stream()),
+                "dreg_maxpool3d_bwd")
+        return dx
+
+
+def maxpool3d(x):
+    return MaxPoolFn.apply(x)
+
+
+# --------------------------------------------------------------------------- fused trilinear upsample + gather
+class TrilinearGatherFn(torch.autograd.Function):
+    """feats[n] = trilinear(align_corners) sample of p1[batch[n]] at fine voxel idx[n]; output fp32 [N, C]."""
+
+    @staticmethod
+    def forward(ctx, p1, idx, pt_batch, fine_res):
+        lib = L.load()
+        B, d, h, w, C = p1.shape
+        N = idx.shape[0]
+        out = torch.empty(N, C, dtype=torch.float32, device=p1.device)
+        Zr, Xr, Yr = fine_res
+        L.check(lib.dreg_trilinear_gather_fwd(L.ptr(p1), L.ptr(idx), L.ptr(pt_batch), L.ptr(out), N, d, h, w, C, Zr, Xr, Yr,
+                                              L.dt_of(p1), 1, L.stream()), "dreg_trilinear_gather_fwd")
+        ctx.save_for_backward(idx, pt_batch)
+        ctx.cfg = (tuple(p1.shape), p1.dtype, fine_res)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        idx, pt_batch = ctx.saved_tensors
+        shape, dtype, (Zr, Xr, Yr) = ctx.cfg
+        lib = L.load()
+        B, d, h, w, C = shape
+        gout = gout.contiguous().float()
+        g32 = torch.zeros(shape, dtype=torch.float32, device=gout.device)
+        L.check(lib.dreg_trilinear_gather_bwd(L.ptr(gout), L.ptr(idx), L.ptr(pt_batch), L.ptr(g32), idx.shape[0], d, h, w, C,
+                                              Zr, Xr, Yr, L.stream()), "dreg_trilinear_gather_bwd")
+        if dtype == torch.float32:
+            return g32, None, None, None
+        g = torch.empty(shape, dtype=dtype, device=gout.device)
+        L.check(lib.dreg_cast_from_f32(L.ptr(g32), L.ptr(g), g32.numel(), L.dt_of(g), L.stream()), "dreg_cast_from_f32")
+        return g, None, None, None
+
+
+def trilinear_gather(p1, idx, pt_batch, fine_res):
+    return TrilinearGatherFn.apply(p1, idx, pt_batch, fine_res)

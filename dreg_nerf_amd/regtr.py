@@ -1,0 +1,210 @@
+"""Host-side mirror of the reference registration network for MI355X.
+
+``NeRFRegTr`` keeps the reference's constructor, ``forward(data) -> dict`` contract and the 772-key
+``state_dict`` (conerf/register/nerf_regtr.py:72-248) while running every hot op through the HIP
+kernels in ``csrc/`` (NDHWC, bf16 MFMA by default, exact-f32 MFMA in ``precision='fp32'``).
+Differences by design: several pairs may be batched in one call (``forward_batch``); BatchNorm keeps
+the reference's one-grid-per-call statistics by computing them per grid inside the batch.
+"""
+import math
+from typing import Dict, List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import lib as L
+from . import ops, params
+from . import transformer_ops as T
+from . import attn_ops as A
+
+
+class _Node(nn.Module):
+    """Anonymous container used to reproduce the reference's dotted parameter names."""
+
+
+def _build_tree(root: nn.Module, spec, init_from=None):
+    made = {}
+    for key, (shape, kind) in spec.items():
+        if key.startswith(params.ALIAS_DST):
+            continue
+        parts = key.split(".")
+        mod = root
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                setattr(mod, p, _Node())
+            mod = getattr(mod, p)
+        t = torch.zeros(shape, dtype=torch.int64 if kind == "bn_count" else torch.float32)
+        if params.is_buffer(kind):
+            mod.register_buffer(parts[-1], t)
+        else:
+            mod.register_parameter(parts[-1], nn.Parameter(t))
+        made[key] = kind
+    # alias: feature_pyramid.resnet is the same module object as backbone_net (feature_pyramid_net.py:194-200)
+    root.fpn3d.feature_pyramid.resnet = root.fpn3d.backbone_net
+    # module registration order must give the reference's state_dict order: move 'resnet' first in feature_pyramid
+    fp = root.fpn3d.feature_pyramid
+    mods = fp._modules
+    reordered = {"resnet": mods["resnet"]}
+    reordered.update({k: v for k, v in mods.items() if k != "resnet"})
+    fp._modules = reordered
+
+
+def _reset_parameters(model: nn.Module, spec):
+    """Reference initialisation distributions: Xavier-normal convs / zero FPN bias / BN (1,0)
+    (resnet3d.py:133-138, feature_pyramid_net.py:10-18); nn.MultiheadAttention / nn.Linear / LayerNorm
+    defaults for the transformer, all six encoder layers identical (deepcopy, transformer.py:18-19)."""
+    sd = dict(model.named_parameters())
+    bufs = dict(model.named_buffers())
+    with torch.no_grad():
+        for key, (shape, kind) in spec.items():
+            if key.startswith(params.ALIAS_DST):
+                continue
+            if kind == "conv":
+                nn.init.xavier_normal_(sd[key])
+            elif kind in ("bn_weight", "ln_weight"):
+                sd[key].fill_(1.0)
+            elif kind == "bn_var":
+                bufs[key].fill_(1.0)
+            elif kind == "linear":
+                if key.endswith("in_proj_weight"):
+                    nn.init.xavier_uniform_(sd[key])
+                else:
+                    nn.init.kaiming_uniform_(sd[key], a=math.sqrt(5))
+            elif kind == "bias":
+                wkey = key[:-4] + "weight"
+                if key.startswith("fpn3d") or key.endswith("in_proj_bias") or "out_proj" in key or "norm" in key:
+                    sd[key].zero_()
+                elif wkey in sd and sd[wkey].dim() == 2:
+                    bound = 1.0 / math.sqrt(sd[wkey].shape[1])
+                    sd[key].uniform_(-bound, bound)
+        for key in list(sd.keys()):
+            if key.startswith("transformer_encoder.layers.0."):
+                for l in range(1, 6):
+                    sd[key.replace("layers.0.", f"layers.{l}.")].copy_(sd[key])
+
+
+class NeRFRegTr(nn.Module):
+    def __init__(self, pos_emb_type: str = "sine", pos_emb_dim: int = 256, pos_emb_scaling: float = 1.0,
+                 num_downsample: int = 6, precision: str = "bf16"):
+        super().__init__()
+        if pos_emb_type != "sine" or pos_emb_dim != 256:
+            raise NotImplementedError("only the reference default (sine, 256) position embedding is built")
+        self.num_downsample = num_downsample
+        self.pos_emb_scaling = pos_emb_scaling
+        self.precision = precision
+        self._spec = params.regtr_spec()
+        _build_tree(self, self._spec)
+        _reset_parameters(self, self._spec)
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def act_dtype(self):
+        return torch.bfloat16 if self.precision == "bf16" else torch.float32
+
+    def _P(self) -> Dict[str, torch.Tensor]:
+        d = dict(self.named_parameters(remove_duplicate=False))
+        d.update(dict(self.named_buffers(remove_duplicate=False)))
+        return d
+
+    # ------------------------------------------------------------------ A1/A2: FPN3D over a batch of grids
+    def fpn(self, x: torch.Tensor) -> torch.Tensor:
+        """x: [B, D, H, W, 8] (rgba + 4 zero channels), activation dtype.  Returns P1 [B, D/2, H/2, W/2, 256]."""
+        P = self._P()
+        train = self.training
+        r = "fpn3d.backbone_net."
+
+        def bn(t, name, res=None, relu=True):
+            if train:
+                P[name + ".num_batches_tracked"] += t.shape[0]
+            return ops.batchnorm(t, P[name + ".weight"], P[name + ".bias"], P[name + ".running_mean"],
+                                 P[name + ".running_var"], res=res, relu=relu, train=train)
+
+        c1 = bn(ops.conv3d(x, P[r + "conv1.weight"], stride=2, pad=2), r + "bn1")
+        h = ops.maxpool3d(c1)
+        feats = [c1]
+        for li, nblk in enumerate(params.RESNET50_BLOCKS):
+            for b in range(nblk):
+                p = f"{r}layer{li + 1}.{b}"
+                stride = 2 if (b == 0 and li > 0) else 1
+                o = bn(ops.conv3d(h, P[p + ".conv1.weight"]), p + ".bn1")
+                o = bn(ops.conv3d(o, P[p + ".conv2.weight"], stride=stride, pad=1), p + ".bn2")
+                o = ops.conv3d(o, P[p + ".conv3.weight"])
+                if (p + ".downsample.0.weight") in P:
+                    res = bn(ops.conv3d(h, P[p + ".downsample.0.weight"], stride=stride), p + ".downsample.1", relu=False)
+                else:
+                    res = h
+                h = bn(o, p + ".bn3", res=res, relu=True)
+            feats.append(h)
+        c1, c2, c3, c4, c5 = feats
+        q = "fpn3d.feature_pyramid."
+
+        def conv(name, t, pad, addend=None):
+            return ops.conv3d(t, P[q + name + ".weight"], P[q + name + ".bias"], addend=addend, pad=pad)
+
+        p5 = conv("pyramid_transformation_5", c5, 0)
+        p4 = conv("upsample_transform_4", conv("pyramid_transformation_4", c4, 0, addend=p5), 1)
+        p3 = conv("upsample_transform_3", conv("pyramid_transformation_3", c3, 0, addend=p4), 1)
+        p2 = conv("upsample_transform_2", conv("pyramid_transformation_2", c2, 0, addend=p3), 1)
+        p1 = conv("upsample_transform_1", conv("pyramid_transformation_1", c1, 1, addend=p2), 1)
+        return p1
+
+    @staticmethod
+    def pack_grids(grids: List[torch.Tensor], dtype) -> torch.Tensor:
+        """List of [1,7,Z,X,Y] fp32 grids -> NDHWC [B,Z,X,Y,8]: rgba (channels 3:7) + 4 zero pad channels."""
+        rgba = torch.cat([g[:, 3:] for g in grids], dim=0).permute(0, 2, 3, 4, 1)
+        return F.pad(rgba, (0, 4)).to(dtype).contiguous()
+
+    # ------------------------------------------------------------------ A3..A9 for a batch of pairs
+    def forward_batch(self, batch: List[dict]) -> List[dict]:
+        """Each element: the reference's ``data`` dict for one pair.  Returns one output dict per pair."""
+        dev = self.fpn3d.backbone_net.conv1.weight.device
+        grids, idxs, pbatch, xyzs = [], [], [], []
+        for i, d in enumerate(batch):
+            for j, side in enumerate(("src", "tgt")):
+                g = d[side + "_xyz_rgba"]
+                if g.dim() == 6:
+                    g = g.squeeze(0)
+                m = d[side + "_mask"]
+                if m.dim() == 2:
+                    m = m.squeeze(0)
+                grids.append(g)
+                idxs.append(m)
+                pbatch.append(torch.full((m.shape[0],), 2 * i + j, dtype=torch.int32, device=dev))
+                xyzs.append(g[:, :3].permute(0, 3, 4, 2, 1).reshape(-1, 3)[m])
+        res = tuple(grids[0].shape[-3:])
+        A.set_precision(self.precision)
+        p1 = self.fpn(self.pack_grids(grids, self.act_dtype))
+        feats = ops.trilinear_gather(p1, torch.cat(idxs).contiguous(), torch.cat(pbatch), res)
+        P = self._P()
+        outs = []
+        off = 0
+        for i, d in enumerate(batch):
+            ns, nt = idxs[2 * i].shape[0], idxs[2 * i + 1].shape[0]
+            f = feats[off:off + ns + nt]
+            off += ns + nt
+            pts = torch.cat([xyzs[2 * i], xyzs[2 * i + 1]])
+            pts, f, lens = T.hierarchical_grid_subsample(pts, f, torch.tensor([ns, nt], device=dev), self.num_downsample)
+            n0 = int(lens[0])
+            s_xyz, t_xyz, s_f, t_f = pts[:n0], pts[n0:], f[:n0], f[n0:]
+            s_pe = T.posenc_sine(s_xyz, scale=self.pos_emb_scaling)
+            t_pe = T.posenc_sine(t_xyz, scale=self.pos_emb_scaling)
+            s_c, t_c = T.cross_encoder(P, s_f, t_f, s_pe, t_pe)
+            s_corr, t_corr, s_ov, t_ov = T.corr_decoder(P, s_c, t_c, s_xyz, t_xyz, s_pe, t_pe)
+            nl = s_c.shape[0]
+            a = torch.cat([s_xyz.expand(nl, -1, -1), t_corr], dim=1)
+            b = torch.cat([s_corr, t_xyz.expand(nl, -1, -1)], dim=1)
+            w = torch.cat([s_ov[..., 0], t_ov[..., 0]], dim=1)
+            pose = T.weighted_kabsch(a.detach(), b.detach(), w.detach())[:, None]
+            outs.append({
+                "src_feats": [s_c], "tgt_feats": [t_c],
+                "src_kp": [s_xyz], "src_kp_warped": [s_corr],
+                "tgt_kp": [t_xyz], "tgt_kp_warped": [t_corr],
+                "src_overlap": [s_ov], "tgt_overlap": [t_ov],
+                "pose": pose,
+            })
+        return outs
+
+    def forward(self, data: dict) -> dict:
+        """Reference contract (nerf_regtr.py:112-248): one pair in, the 9-key dict out."""
+        return self.forward_batch([data])[0]

@@ -1,0 +1,196 @@
+"""GPU: each HIP kernel of the FPN3D path against a plain PyTorch fp32 CPU computation of the same op
+(through the C ABI via dreg_nerf_amd.ops).  fp32 mode = exact-f32 MFMA (tolerance: fp32 round-off);
+bf16 mode is compared against the fp32 result on bf16-rounded operands."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from dreg_nerf_amd import ops  # noqa: E402
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def ndhwc(t):  # NCDHW -> NDHWC
+    return t.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def ncdhw(t):
+    return t.permute(0, 4, 1, 2, 3).contiguous()
+
+
+CONV_CASES = [
+    # B, (D,H,W), Cin_real, Cin_pad, Cout, k, stride, pad
+    (1, (8, 8, 8), 64, 64, 64, 1, 1, 0),
+    (2, (9, 10, 11), 64, 64, 128, 3, 1, 1),
+    (1, (12, 9, 10), 128, 128, 128, 3, 2, 1),
+    (2, (7, 8, 9), 256, 256, 256, 1, 2, 0),
+    (1, (16, 14, 12), 4, 8, 64, 5, 2, 2),
+    (1, (6, 6, 6), 256, 256, 256, 3, 1, 1),
+    (1, (1, 1, 300), 256, 256, 768, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3d_fwd_bwd(case, dtype):
+    dev = _dev()
+    B, dims, cin, cin_pad, cout, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = torch.randn(B, cin, *dims, generator=g)
+    w = torch.randn(cout, cin, k, k, k, generator=g) / (cin * k ** 3) ** 0.5
+    b = torch.randn(cout, generator=g)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+        wq = w.bfloat16().float()
+    else:
+        wq = w
+    xr = x.clone().requires_grad_(cin > 4)
+    wr = wq.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    y_ref = F.conv3d(xr, wr, br, stride=s, padding=p)
+    gy = torch.randn(y_ref.shape, generator=g)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    y_ref.backward(gy)
+
+    xd = ndhwc(F.pad(x, (0, 0, 0, 0, 0, 0, 0, cin_pad - cin))).to(dev, dtype).requires_grad_(cin > 4)
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True)
+    y = ops.conv3d(xd, wd, bd, None, s, p)
+    y.backward(ndhwc(gy).to(dev, dtype))
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    yscale = float(y_ref.abs().max())
+    np.testing.assert_allclose(ncdhw(y.detach().float().cpu()).numpy(), y_ref.detach().numpy(), atol=tol * yscale)
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), wr.grad.numpy(), atol=tol * float(wr.grad.abs().max()) * 2)
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), br.grad.numpy(), atol=tol * float(br.grad.abs().max()) * 2)
+    if cin > 4:
+        gx = ncdhw(xd.grad.float().cpu())[:, :cin]
+        np.testing.assert_allclose(gx.numpy(), xr.grad.numpy(), atol=tol * float(xr.grad.abs().max()) * 2)
+
+
+def test_wgrad_transpose_read_matches_gather_path():
+    """bf16 weight gradient: ds_read_b64_tr_b16 fragments == eight 16-bit LDS reads, bit for bit."""
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 9, 10, 11, 128, generator=g).to(dev, torch.bfloat16)
+    gy = torch.randn(2, 9, 10, 11, 256, generator=g).to(dev, torch.bfloat16)
+    a = ops.conv_wgrad(gy, x, (256, 128, 3, 3, 3), 128, 3, 1, 1, use_tr=True)
+    b = ops.conv_wgrad(gy, x, (256, 128, 3, 3, 3), 128, 3, 1, 1, use_tr=False)
+    assert torch.equal(a, b)
+
+
+def test_conv_upsample_add_epilogue():
+    dev = _dev()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 64, 7, 6, 5, generator=g)
+    w = torch.randn(256, 64, 1, 1, 1, generator=g) / 8
+    b = torch.randn(256, generator=g)
+    prev = torch.randn(2, 256, 4, 3, 3, generator=g)
+    xr, pr = x.clone().requires_grad_(True), prev.clone().requires_grad_(True)
+    y_ref = F.conv3d(xr, w, b) + F.interpolate(pr, scale_factor=2)[:, :, :7, :6, :5]
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    xd = ndhwc(x).to(dev).requires_grad_(True)
+    pd = ndhwc(prev).to(dev).requires_grad_(True)
+    y = ops.conv3d(xd, w.to(dev), b.to(dev), pd, 1, 0)
+    y.backward(ndhwc(gy).to(dev))
+    np.testing.assert_allclose(ncdhw(y.detach().cpu()).numpy(), y_ref.detach().numpy(), atol=1e-4)
+    np.testing.assert_allclose(ncdhw(pd.grad.cpu()).numpy(), pr.grad.numpy(), atol=1e-4)
+    np.testing.assert_allclose(ncdhw(xd.grad.cpu()).numpy(), xr.grad.numpy(), atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 6, 5, 7, 64), (1, 2, 2, 2, 2048), (3, 16, 16, 16, 256)])
+def test_batchnorm_train_fwd_bwd(shape, dtype):
+    dev = _dev()
+    B, D, H, W, C = shape
+    g = torch.Generator().manual_seed(C + D)
+    x = (torch.randn(B, C, D, H, W, generator=g) * 2 + 0.5)
+    res = torch.randn(B, C, D, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        x, res = x.bfloat16().float(), res.bfloat16().float()
+    gamma = 1 + 0.1 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    rm0, rv0 = 0.1 * torch.randn(C, generator=g), 1 + 0.1 * torch.rand(C, generator=g)
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = rm0.clone(), rv0.clone()
+    ys = []
+    for b in range(B):  # reference semantics: one grid per BatchNorm call
+        ys.append(F.relu(F.batch_norm(xr[b:b + 1], rm, rv, gr, br, True, 0.1, 1e-5) + rr[b:b + 1]))
+    y_ref = torch.cat(ys)
+    gy = torch.randn(y_ref.shape, generator=g)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    y_ref.backward(gy)
+
+    xd = ndhwc(x).to(dev, dtype).requires_grad_(True)
+    rd = ndhwc(res).to(dev, dtype).requires_grad_(True)
+    gd, bd = gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+    rmd, rvd = rm0.to(dev), rv0.to(dev)
+    y = ops.batchnorm(xd, gd, bd, rmd, rvd, res=rd, relu=True, train=True)
+    y.backward(ndhwc(gy).to(dev, dtype))
+    tol = 3e-5 if dtype == torch.float32 else 3e-2
+    np.testing.assert_allclose(ncdhw(y.detach().float().cpu()).numpy(), y_ref.detach().numpy(), atol=tol * float(y_ref.abs().max()))
+    np.testing.assert_allclose(rmd.cpu().numpy(), rm.numpy(), atol=1e-5)
+    np.testing.assert_allclose(rvd.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ncdhw(xd.grad.float().cpu()).numpy(), xr.grad.numpy(), atol=tol * float(xr.grad.abs().max()) * 2)
+    np.testing.assert_allclose(ncdhw(rd.grad.float().cpu()).numpy(), rr.grad.numpy(), atol=tol * float(rr.grad.abs().max()))
+    np.testing.assert_allclose(gd.grad.cpu().numpy(), gr.grad.numpy(), atol=tol * float(gr.grad.abs().max()) * 2)
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), br.grad.numpy(), atol=tol * float(br.grad.abs().max()) * 2)
+
+
+def test_batchnorm_eval():
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 4, 5, 6, generator=g)
+    gamma, beta = torch.randn(64, generator=g), torch.randn(64, generator=g)
+    rm, rv = torch.randn(64, generator=g), 1 + torch.rand(64, generator=g)
+    y_ref = F.relu(F.batch_norm(x, rm, rv, gamma, beta, False, 0.1, 1e-5))
+    y = ops.batchnorm(ndhwc(x).to(dev), gamma.to(dev), beta.to(dev), rm.to(dev), rv.to(dev), relu=True, train=False)
+    np.testing.assert_allclose(ncdhw(y.cpu()).numpy(), y_ref.numpy(), atol=1e-5)
+
+
+@pytest.mark.parametrize("dims", [(8, 8, 8), (7, 9, 6)])
+def test_maxpool(dims):
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 64, *dims, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.max_pool3d(xr, 3, 2, 1)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    xd = ndhwc(x).to(dev).requires_grad_(True)
+    y = ops.maxpool3d(xd)
+    y.backward(ndhwc(gy).to(dev))
+    assert torch.equal(ncdhw(y.detach().cpu()), y_ref.detach())
+    np.testing.assert_allclose(ncdhw(xd.grad.cpu()).numpy(), xr.grad.numpy(), atol=1e-6)
+
+
+def test_trilinear_gather():
+    dev = _dev()
+    from oracle import regtr_oracle as O
+    g = torch.Generator().manual_seed(4)
+    B, C = 2, 256
+    p1 = torch.randn(B, C, 5, 6, 7, generator=g)
+    res = (10, 12, 14)
+    n = res[0] * res[1] * res[2]
+    masks = [torch.randperm(n, generator=g)[:150].sort().values for _ in range(B)]
+    p1r = p1.clone().requires_grad_(True)
+    refs = [O.upsample_gather(p1r[b:b + 1], torch.zeros(1, 3, *res), masks[b])[1] for b in range(B)]
+    ref = torch.cat(refs)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    pd = ndhwc(p1).to(dev).requires_grad_(True)
+    idx = torch.cat(masks).to(dev)
+    pb = torch.cat([torch.full((150,), b, dtype=torch.int32) for b in range(B)]).to(dev)
+    out = ops.trilinear_gather(pd, idx, pb, res)
+    out.backward(gy.to(dev))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-5)
+    np.testing.assert_allclose(ncdhw(pd.grad.cpu()).numpy(), p1r.grad.numpy(), atol=2e-5)

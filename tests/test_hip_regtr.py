@@ -1,0 +1,95 @@
+"""GPU: the assembled network (HIP path, fp32 exact-MFMA mode) against the reference-generated golden
+vectors and the oracle; bf16 mode sanity (loose tolerances)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from dreg_nerf_amd import losses as LS, params, synth  # noqa: E402
+from dreg_nerf_amd.regtr import NeRFRegTr  # noqa: E402
+
+
+def _to(data, dev):
+    return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()}
+
+
+def _model(precision, train):
+    m = NeRFRegTr(precision=precision)
+    m.load_state_dict(params.synth_state_dict(0), strict=True)
+    m = m.cuda()
+    m.train(train)
+    return m
+
+
+def test_fpn_and_e2e_eval32_fp32(golden_dir):
+    g = np.load(os.path.join(golden_dir, "e2e_eval32.npz"))
+    m = _model("fp32", False)
+    data = synth.shell_pair(32, 1, 2, pose=synth.fixed_pose())
+    with torch.no_grad():
+        p1 = m.fpn(m.pack_grids([data["src_xyz_rgba"].cuda()], torch.float32))
+        out = m(_to(data, "cuda"))
+    p1_ncdhw = p1.permute(0, 4, 1, 2, 3).contiguous().cpu()
+    np.testing.assert_allclose(p1_ncdhw.flatten()[g["p1_idx"]].numpy(), g["p1_val"], rtol=1e-3, atol=2e-4 * float(g["p1_absmean"]))
+    assert out["src_kp"][0].shape[0] == int(g["n_src"]) and out["tgt_kp"][0].shape[0] == int(g["n_tgt"])
+    np.testing.assert_allclose(out["src_kp"][0].cpu().numpy(), g["src_kp"], atol=1e-6)
+    np.testing.assert_allclose(out["src_kp_warped"][0][-1].cpu().numpy(), g["src_kp_warped_last"], atol=2e-4)
+    np.testing.assert_allclose(out["tgt_overlap"][0][-1].cpu().numpy(), g["tgt_overlap_last"], atol=2e-4)
+    # north-star tolerance: rotation / translation within 1e-4 of the reference on identical inputs
+    np.testing.assert_allclose(out["pose"].cpu().numpy(), g["pose"], atol=1e-4)
+    rre, rte = LS.rre_rte(out["pose"][-1].cpu(), data["pose"])
+    np.testing.assert_allclose(rre.numpy(), g["rre"], atol=1e-2)
+    np.testing.assert_allclose(rte.numpy(), g["rte"], atol=1e-4)
+
+
+def test_train_step_64_fp32(golden_dir):
+    g = np.load(os.path.join(golden_dir, "train64.npz"))
+    m = _model("fp32", True)
+    data = synth.shell_pair(64, 1, 2, pose=synth.fixed_pose())
+    pred = m(_to(data, "cuda"))
+    assert pred["src_kp"][0].shape[0] == int(g["n_src"])
+    s_kp, t_kp = pred["src_kp"][0], pred["tgt_kp"][0]
+    s_gt, t_gt = synth.synthetic_overlap_gt(s_kp), synth.synthetic_overlap_gt(t_kp)
+    with torch.no_grad():
+        s_tl = torch.stack([synth.synthetic_overlap_gt(pred["src_kp_warped"][0][l], 1)[0] for l in range(6)])
+        t_tl = torch.stack([synth.synthetic_overlap_gt(pred["tgt_kp_warped"][0][l], 1)[0] for l in range(6)])
+    fl = LS.InfoNCELoss().cuda()
+    with torch.no_grad():
+        fl.W.copy_((0.1 * torch.randn(256, 256, generator=torch.Generator().manual_seed(int(g["W_seed"])))).cuda())
+    losses = LS.training_losses(pred, data["pose"].cuda(), fl, s_gt, t_gt, s_tl, t_tl, robust=False)
+    for k in ("overlap", "nerf_cont", "feature", "corr", "total"):
+        # 'feature' thresholds pairwise distances (r_p, r_n): one anchor flipping moves it by ~1/N
+        np.testing.assert_allclose(float(losses[k].detach()), float(g["loss_" + k]), rtol=5e-3 if k == "feature" else 1e-3)
+    np.testing.assert_allclose(pred["pose"].detach().cpu().numpy(), g["pose"], atol=5e-4)
+    losses["total"].backward()
+    named = dict(m.named_parameters())
+    groups = {"resnet": "fpn3d.backbone_net.", "fpn_head": "fpn3d.feature_pyramid.",
+              "transformer": "transformer_encoder.", "decoder": "correspondence_decoder."}
+    for name, pref in groups.items():
+        sq = sum(float(p.grad.double().pow(2).sum()) for k, p in named.items() if k.startswith(pref) and p.grad is not None)
+        np.testing.assert_allclose(sq ** 0.5, float(g["gnorm64_" + name]), rtol=2e-2)
+    # gradient probes: distance to the fp64 truth must be of the order of the fp32 reference's own distance
+    for key in g.files:
+        if key.startswith("gidx/"):
+            k = key[5:]
+            got = named[k].grad.flatten().cpu()[g[key]].double().numpy()
+            ref32, ref64 = g["gval/" + k].astype(np.float64), g["gval64/" + k]
+            scale = np.linalg.norm(ref64)
+            err_ref = np.linalg.norm(ref32 - ref64) / scale
+            err_got = np.linalg.norm(got - ref64) / scale
+            assert err_got <= max(4 * err_ref, 2e-3), (k, err_got, err_ref)
+    np.testing.assert_allclose(m.state_dict()["fpn3d.backbone_net.bn1.running_mean"][:16].cpu().numpy(),
+                               g["bn_running_mean_probe"], rtol=1e-3, atol=1e-5)
+
+
+def test_e2e_eval32_bf16_close_to_fp32(golden_dir):
+    g = np.load(os.path.join(golden_dir, "e2e_eval32.npz"))
+    m = _model("bf16", False)
+    data = synth.shell_pair(32, 1, 2, pose=synth.fixed_pose())
+    with torch.no_grad():
+        out = m(_to(data, "cuda"))
+    assert out["src_kp"][0].shape[0] == int(g["n_src"])
+    err = np.abs(out["pose"][-1].cpu().numpy() - g["pose"][-1]).max()
+    assert err < 0.05, err
