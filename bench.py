@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Benchmark of the DReg-NeRF registration hot path on MI355X.
+
+A "step" is one optimizer step of RegTR training (forward + backward + clip + AdamW) over a batch of
+synthetic shell-R NeRF pairs at 128^3 (BASELINE.json configs[1]: batch 4 pairs = 8 grids per GPU, bf16
+MFMA with fp32 accumulate / fp32 master weights).  With --gpus N the driver launches N ranks through
+torch.distributed.run; every rank takes its own 4 pairs (weak scaling) and gradients are averaged over RCCL.
+
+Prints ONE JSON line on rank 0 (see the contract in the repo brief): value = pairs/s over all ranks,
+plus "roofline" for the dominant kernel (HIP-event timed inside the timed region) and "cpu_baseline"
+(the oracle = PyTorch-CPU restatement of the reference, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md chip table
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--res", type=int, default=128)
+    ap.add_argument("--pairs", type=int, default=4, help="pairs per GPU per step (BASELINE batch = 4)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-res", type=int, default=64, help="resolution of the bounded CPU sample")
+    ap.add_argument("--kernel-report", default="", help="write the per-kernel/per-shape event timing table here")
+    return ap.parse_args()
+
+
+def cpu_baseline(res: int, target_res: int):
+    """Oracle (kind 'port': CPU restatement pinned to the reference by tests/golden) fwd+bwd of ONE pair at `res`,
+    train mode, fp32, all host cores.  Converted to pairs/s at `target_res` by the conv FLOP ratio (res^3)."""
+    from dreg_nerf_amd import params, synth
+    from oracle import regtr_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = params.synth_state_dict(0)
+    for k, (shape, kind) in params.regtr_spec().items():
+        if not params.is_buffer(kind) and not k.startswith(params.ALIAS_DST):
+            sd[k].requires_grad_(True)
+    data = synth.shell_pair(res, 1, 2, pose=synth.fixed_pose())
+    W = 0.1 * torch.randn(256, 256, generator=torch.Generator().manual_seed(5))
+    t0 = time.time()
+    pred = O.regtr_forward(sd, data, train=True)
+    s_kp, t_kp = pred["src_kp"][0], pred["tgt_kp"][0]
+    s_gt, t_gt = synth.synthetic_overlap_gt(s_kp), synth.synthetic_overlap_gt(t_kp)
+    with torch.no_grad():
+        s_tl = torch.stack([synth.synthetic_overlap_gt(pred["src_kp_warped"][0][l], 1)[0] for l in range(6)])
+        t_tl = torch.stack([synth.synthetic_overlap_gt(pred["tgt_kp_warped"][0][l], 1)[0] for l in range(6)])
+    losses = O.training_losses(pred, data["pose"], W, s_gt, t_gt, s_tl, t_tl)
+    losses["total"].backward()
+    dt = time.time() - t0
+    scale = (target_res / res) ** 3
+    return {
+        "value": 1.0 / (dt * scale), "unit": "pairs/s", "cores": cores, "kind": "port",
+        "sample": f"oracle (PyTorch-CPU fp32 restatement) fwd+bwd of 1 shell-R pair at {res}^3 in {dt:.1f}s, "
+                  f"scaled x{scale:.0f} (conv FLOPs ~ res^3) to {target_res}^3",
+        "measured_seconds": dt,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from dreg_nerf_amd import ops, synth
+    from dreg_nerf_amd.regtr import NeRFRegTr
+    from dreg_nerf_amd.train_step import TrainStep
+
+    torch.manual_seed(3407)
+    model = NeRFRegTr(precision=args.precision).to(dev).train()
+    if world > 1:  # identical initial weights on every rank
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+    ts = TrainStep(model)
+
+    # inputs resident in HBM before the timed region; every rank owns different pairs
+    pose = synth.fixed_pose()
+    batch = []
+    for i in range(args.pairs):
+        s = 1 + 2 * (rank * args.pairs + i)
+        d = synth.shell_pair(args.res, s, s + 1, pose=pose)
+        batch.append({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()})
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ts.step(batch)
+    sync()
+    ops.PROFILER = ops.KernelTimer()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts.step(batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILER = ops.PROFILER, None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        by_name, by_label = prof.summary()
+        dom = max(by_name.items(), key=lambda kv: kv[1][1])
+        name, (calls, ms, flops) = dom
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else 157.3,
+                    "unit": "TFLOP/s", "frac": achieved / (MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else 157.3),
+                    "traffic": None, "launches": calls, "avg_launch_ms": ms / max(calls, 1),
+                    "algorithmic_flops_per_launch": flops / max(calls, 1)}
+        if args.kernel_report:
+            with open(args.kernel_report, "w") as f:
+                f.write("kernel\tshape\tcalls\ttotal_ms\tavg_ms\tTFLOP/s\n")
+                for (n, l), (c, m, fl) in sorted(by_label.items(), key=lambda kv: -kv[1][1]):
+                    f.write(f"{n}\t{l}\t{c}\t{m:.3f}\t{m / c:.4f}\t{fl / (m * 1e-3) / 1e12 if m > 0 else 0:.1f}\n")
+        pairs = args.pairs * world * args.steps
+        out = {
+            "metric": "nerf_pairs_per_sec_regtr_fwd_bwd_128", "value": pairs / elapsed, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"RegTR fwd+bwd+AdamW, shell-R synthetic pairs, {args.res}^3 grids, "
+                                   f"{args.pairs} pairs ({2 * args.pairs} grids) per GPU per step, random-init weights",
+                       "global_batch_pairs": args.pairs * world, "resolution": args.res,
+                       "parallelism": f"dp{world}"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_res, args.res)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

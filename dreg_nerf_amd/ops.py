@@ -14,6 +14,35 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+class KernelTimer:
+    """HIP-event timing of individual launches on the stream they are launched on (torch's current stream).
+    bench.py enables it over the timed region; entries are (kernel name, shape label, algorithmic flops, start, end)."""
+
+    def __init__(self):
+        self.entries = []
+
+    def record(self, name, label, flops):
+        start = torch.cuda.Event(enable_timing=True)
+        end = torch.cuda.Event(enable_timing=True)
+        self.entries.append((name, label, flops, start, end))
+        return start, end
+
+    def summary(self):
+        torch.cuda.synchronize()
+        by_name, by_label = {}, {}
+        for name, label, flops, s, e in self.entries:
+            ms = s.elapsed_time(e)
+            for d, k in ((by_name, name), (by_label, (name, label))):
+                a = d.setdefault(k, [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += ms
+                a[2] += flops
+        return by_name, by_label
+
+
+PROFILER: Optional[KernelTimer] = None
+
+
 # --------------------------------------------------------------------------- weight packing (cached per parameter version)
 import weakref
 
@@ -56,7 +85,8 @@ def _out_dim(i, k, s, p):
 
 
 # --------------------------------------------------------------------------- convolution
-def conv_igemm(x, wpk, bias, addend, out_shape, cin, cout, ksz, stride, pad, transposed, relu=False, out_f32=False):
+def conv_igemm(x, wpk, bias, addend, out_shape, cin, cout, ksz, stride, pad, transposed, relu=False, out_f32=False,
+               flop_cin=None):
     """Raw launcher.  x: [B,Di,Hi,Wi,cin]; returns [B,*out_shape,cout]."""
     lib = L.load()
     dt = L.dt_of(x)
@@ -69,9 +99,21 @@ def conv_igemm(x, wpk, bias, addend, out_shape, cin, cout, ksz, stride, pad, tra
         assert addend.dtype == odt and addend.shape[0] == B and addend.shape[4] == cout
         Da, Ha, Wa = addend.shape[1], addend.shape[2], addend.shape[3]
         assert 2 * Da >= Do and 2 * Ha >= Ho and 2 * Wa >= Wo
+    ev = None
+    if PROFILER is not None:
+        tn = "bf16" if dt == L.DT_BF16 else "f32"
+        name = f"conv_igemm_kernel<{tn},{'f32' if odt == torch.float32 else 'bf16'},{128 if cout % 128 == 0 else 64}>"
+        label = f"{'dgrad' if transposed else 'fwd'} B{B} {Di}x{Hi}x{Wi}x{cin}->{Do}x{Ho}x{Wo}x{cout} k{ksz}s{stride}"
+        flops = 2.0 * B * Do * Ho * Wo * cout * (ksz ** 3) * (flop_cin or cin)
+        if transposed and stride == 2:
+            flops /= 8.0  # only 1/8 of the taps of a stride-2 data gradient are algorithmically non-zero
+        ev = PROFILER.record(name, label, flops)
+        ev[0].record()
     L.check(lib.dreg_conv3d_igemm(L.ptr(x), L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(addend),
                                   B, Di, Hi, Wi, cin, Do, Ho, Wo, cout, ksz, stride, pad, int(transposed), int(relu),
                                   Da, Ha, Wa, dt, int(out_f32 and dt == L.DT_BF16), L.stream()), "dreg_conv3d_igemm")
+    if ev is not None:
+        ev[1].record()
     return out
 
 
@@ -84,9 +126,17 @@ def conv_wgrad(gout, x, w_shape, cin_pad, ksz, stride, pad, use_tr=True):
     nbytes = lib.dreg_conv3d_wgrad_workspace_bytes(B, Do, Ho, Wo, cin_pad, cout, ksz, dt)
     ws = _ws(nbytes, x.device)
     dw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
+    ev = None
+    if PROFILER is not None:
+        tn = "bf16" if dt == L.DT_BF16 else "f32"
+        label = f"wgrad B{B} {Di}x{Hi}x{Wi}x{cin_pad} g{Do}x{Ho}x{Wo}x{cout} k{ksz}s{stride}"
+        ev = PROFILER.record(f"conv_wgrad_kernel<{tn}>+reduce", label, 2.0 * B * Do * Ho * Wo * cout * (ksz ** 3) * cin_real)
+        ev[0].record()
     L.check(lib.dreg_conv3d_wgrad(L.ptr(gout), L.ptr(x), L.ptr(dw), L.ptr(ws), nbytes, B, Di, Hi, Wi, cin_pad, cin_real,
                                   Do, Ho, Wo, cout, ksz, stride, pad, 0, dt, int(use_tr and dt == L.DT_BF16), L.stream()),
             "dreg_conv3d_wgrad")
+    if ev is not None:
+        ev[1].record()
     return dw
 
 
@@ -125,7 +175,7 @@ class Conv3dFn(torch.autograd.Function):
         out_shape = tuple(_out_dim(x.shape[i + 1], ksz, stride, pad) for i in range(3))
         wpk = packed_weight(w, cin_pad, False, dt)
         b32 = bias.detach().float().contiguous() if bias is not None else None
-        y = conv_igemm(x, wpk, b32, addend, out_shape, cin_pad, cout, ksz, stride, pad, False)
+        y = conv_igemm(x, wpk, b32, addend, out_shape, cin_pad, cout, ksz, stride, pad, False, flop_cin=w.shape[1])
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, pad, ksz, cin_pad, bias is not None, None if addend is None else tuple(addend.shape[1:4]))
         return y
