@@ -1,94 +1,249 @@
-"""Operator layer of the point-set half.  Every entry is the single place where the op is dispatched to
-its HIP kernel; ops that still run as torch device ops are marked SCAFFOLD (tracked in DESIGN.md) and
-are replaced kernel by kernel without touching transformer_ops.py."""
+"""Operator layer of the point-set half: every op dispatches to a HIP kernel through the C ABI
+(attention.hip, pointset.hip, and the 1x1x1 path of conv.hip for the linear layers).
+
+Precision: 'bf16' = GEMM/attention operands bf16 with fp32 accumulation and an fp32 residual stream;
+'fp32' = exact-f32 MFMA everywhere (the parity mode)."""
 import math
 
 import torch
-import torch.nn.functional as F
 
 from . import lib as L
 from . import ops
 
-# fp32 GEMMs of the point-set half go through the exact-f32 MFMA path of the conv kernel when True.
-USE_HIP_LINEAR = True
 _COMPUTE_DTYPE = torch.float32
 
 
 def set_precision(precision: str):
-    """'bf16': GEMM operands are rounded to bf16 (fp32 accumulate, fp32 residual stream); 'fp32': exact-f32 MFMA."""
     global _COMPUTE_DTYPE
     _COMPUTE_DTYPE = torch.bfloat16 if precision == "bf16" else torch.float32
 
 
-def linear(x, w, b, relu: bool = False):
-    if USE_HIP_LINEAR and x.is_cuda and w.shape[0] % 64 == 0:
-        y = ops.linear(x.to(_COMPUTE_DTYPE).contiguous(), w, b).float()
-    else:
-        y = F.linear(x, w, b)  # SCAFFOLD (only the 1-row overlap head lands here)
-    return F.relu(y) if relu else y
+def compute_dtype():
+    return _COMPUTE_DTYPE
 
 
-def layer_norm(x, w, b, eps: float = 1e-5):
-    return F.layer_norm(x, (x.shape[-1],), w, b, eps)  # SCAFFOLD
+# --------------------------------------------------------------------------- linear layers (MFMA GEMM, fused epilogues)
+def linear(x, w, b, relu: bool = False, residual=None, out_f32: bool = False):
+    """x [N,Cin] in the compute dtype; returns compute dtype, or fp32 when out_f32 (then `residual` fp32 is added)."""
+    return ops.linear(x, w, b, relu=relu, residual=residual, out_f32=out_f32)
 
 
-def attention(q, k, v, n_heads: int, scale: float):
-    """q [Nq,E], k,v [Nk,E] -> softmax(q k^T * scale) v per head, heads concatenated."""
-    nq, e = q.shape
-    dh = e // n_heads
-    qh = q.view(nq, n_heads, dh).transpose(0, 1)
-    kh = k.view(-1, n_heads, dh).transpose(0, 1)
-    vh = v.view(-1, n_heads, dh).transpose(0, 1)
-    att = torch.softmax((qh * scale) @ kh.transpose(1, 2), dim=-1)  # SCAFFOLD
-    return (att @ vh).transpose(0, 1).reshape(nq, e)
+# --------------------------------------------------------------------------- LayerNorm (+pe)
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, b, pe, out_dtype):
+        lib = L.load()
+        x = x.contiguous()
+        n = x.shape[0]
+        y = torch.empty(n, 256, dtype=out_dtype, device=x.device)
+        stats = torch.empty(n, 2, dtype=torch.float32, device=x.device)
+        L.check(lib.dreg_layernorm_fwd(L.ptr(x), L.ptr(g.detach()), L.ptr(b.detach()), L.ptr(pe), L.ptr(y), L.ptr(stats),
+                                       n, 256, 1e-5, L.dt_of(y), L.stream()), "dreg_layernorm_fwd")
+        ctx.save_for_backward(x, g, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, g, stats = ctx.saved_tensors
+        lib = L.load()
+        gy = gy.contiguous()
+        n = x.shape[0]
+        dx = torch.empty_like(x)
+        dg = torch.empty(256, dtype=torch.float32, device=x.device)
+        db = torch.empty(256, dtype=torch.float32, device=x.device)
+        ws = torch.empty(lib.dreg_layernorm_bwd_workspace_bytes(n) // 4 + 4, dtype=torch.float32, device=x.device)
+        L.check(lib.dreg_layernorm_bwd(L.ptr(x), L.ptr(gy), L.ptr(g.detach()), L.ptr(stats), L.ptr(dx), L.ptr(dg), L.ptr(db),
+                                       L.ptr(ws), n, 256, L.dt_of(gy), 0, 0, L.stream()), "dreg_layernorm_bwd")
+        return dx, dg, db, None, None
+
+
+def layer_norm(x, w, b, pe=None, out_dtype=None):
+    """x fp32 [N,256] -> LN(x)*w + b (+pe) in out_dtype (default: the compute dtype)."""
+    return LayerNormFn.apply(x, w, b, pe, out_dtype or _COMPUTE_DTYPE)
+
+
+# --------------------------------------------------------------------------- multi-head attention core
+class _MHAFn(torch.autograd.Function):
+    """q_src [Nq, ldq] holds q at column q_off; kv_src [Nk, ldk] holds k at k_off and v at v_off (packed projections)."""
+
+    @staticmethod
+    def forward(ctx, q_src, kv_src, q_off, k_off, v_off, n_heads, scale):
+        lib = L.load()
+        nq, nk = q_src.shape[0], kv_src.shape[0]
+        es = q_src.element_size()
+        o = torch.empty(nq, 32 * n_heads, dtype=q_src.dtype, device=q_src.device)
+        lse = torch.empty(n_heads, nq, dtype=torch.float32, device=q_src.device)
+        L.check(lib.dreg_mha_fwd(q_src.data_ptr() + q_off * es, kv_src.data_ptr() + k_off * es, kv_src.data_ptr() + v_off * es,
+                                 L.ptr(o), L.ptr(lse), nq, nk, n_heads, q_src.shape[1], kv_src.shape[1], kv_src.shape[1],
+                                 o.shape[1], scale, L.dt_of(q_src), L.stream()), "dreg_mha_fwd")
+        ctx.save_for_backward(q_src, kv_src, o, lse)
+        ctx.cfg = (q_off, k_off, v_off, n_heads, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        q_src, kv_src, o, lse = ctx.saved_tensors
+        q_off, k_off, v_off, n_heads, scale = ctx.cfg
+        lib = L.load()
+        go = go.contiguous()
+        nq, nk = q_src.shape[0], kv_src.shape[0]
+        es = q_src.element_size()
+        same = q_src.data_ptr() == kv_src.data_ptr() and nq == nk
+        e = 32 * n_heads
+        if same:  # packed (q|k|v) of one point set: every column is written
+            dq_src = torch.empty_like(q_src)
+            dkv_src = dq_src
+        else:     # row slices of a packed projection: the columns this call does not own stay zero
+            dq_src = torch.zeros_like(q_src) if q_src.shape[1] > e else torch.empty_like(q_src)
+            dkv_src = torch.zeros_like(kv_src) if kv_src.shape[1] > 2 * e else torch.empty_like(kv_src)
+        dvec = torch.empty(n_heads, nq, dtype=torch.float32, device=q_src.device)
+        L.check(lib.dreg_mha_bwd(q_src.data_ptr() + q_off * es, kv_src.data_ptr() + k_off * es, kv_src.data_ptr() + v_off * es,
+                                 L.ptr(o), L.ptr(go), L.ptr(lse), L.ptr(dvec),
+                                 dq_src.data_ptr() + q_off * es, dkv_src.data_ptr() + k_off * es, dkv_src.data_ptr() + v_off * es,
+                                 nq, nk, n_heads, q_src.shape[1], kv_src.shape[1], kv_src.shape[1], o.shape[1], scale,
+                                 L.dt_of(q_src), L.stream()), "dreg_mha_bwd")
+        if same:
+            return dq_src, None, None, None, None, None, None
+        return dq_src, dkv_src, None, None, None, None, None
+
+
+def mha_packed(q_rows, kv_rows, n_heads: int, scale: float):
+    """q_rows [Nq, 3E], kv_rows [Nk, 3E]: row slices of a packed (q | k | v) projection -> [Nq, E].
+    Self-attention passes the same slice twice; cross-attention passes the two point sets' slices."""
+    e = q_rows.shape[1] // 3
+    return _MHAFn.apply(q_rows, kv_rows, 0, e, 2 * e, n_heads, scale)
+
+
+# --------------------------------------------------------------------------- correspondence attention (V = xyz)
+class _CorrAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, xyz, scale):
+        lib = L.load()
+        nl, nq, nk = q.shape[0], q.shape[1], k.shape[1]
+        q, k, xyz = q.contiguous(), k.contiguous(), xyz.contiguous()
+        out = torch.empty(nl, nq, 3, dtype=torch.float32, device=q.device)
+        lse = torch.empty(nl, nq, dtype=torch.float32, device=q.device)
+        L.check(lib.dreg_corr_attention_fwd(L.ptr(q), L.ptr(k), L.ptr(xyz), L.ptr(out), L.ptr(lse), nl, nq, nk, scale,
+                                            L.dt_of(q), L.stream()), "dreg_corr_attention_fwd")
+        ctx.save_for_backward(q, k, xyz, out, lse)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, xyz, out, lse = ctx.saved_tensors
+        lib = L.load()
+        nl, nq, nk = q.shape[0], q.shape[1], k.shape[1]
+        go = go.contiguous().float()
+        dq, dk = torch.empty_like(q), torch.empty_like(k)
+        dvec = torch.empty(nl, nq, dtype=torch.float32, device=q.device)
+        L.check(lib.dreg_corr_attention_bwd(L.ptr(q), L.ptr(k), L.ptr(xyz), L.ptr(out), L.ptr(go), L.ptr(lse), L.ptr(dvec),
+                                            L.ptr(dq), L.ptr(dk), nl, nq, nk, ctx.scale, L.dt_of(q), L.stream()),
+                "dreg_corr_attention_bwd")
+        return dq, dk, None, None
 
 
 def attention_xyz(q, k, xyz, scale: float):
-    """q [L,Nq,E], k [L,Nk,E], xyz [Nk,3] -> softmax(q k^T * scale) xyz : [L,Nq,3]."""
-    att = torch.softmax((q * scale) @ k.transpose(1, 2), dim=-1)  # SCAFFOLD
-    return att @ xyz
+    """q [L,Nq,256], k [L,Nk,256] (compute dtype), xyz fp32 [Nk,3] -> softmax(scale q k^T) xyz : fp32 [L,Nq,3]."""
+    return _CorrAttnFn.apply(q, k, xyz, scale)
+
+
+# --------------------------------------------------------------------------- overlap head
+class _OverlapFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f, w, b):
+        lib = L.load()
+        f = f.contiguous()
+        n = f.shape[0]
+        s = torch.empty(n, dtype=torch.float32, device=f.device)
+        L.check(lib.dreg_overlap_fwd(L.ptr(f), L.ptr(w.detach().contiguous()), L.ptr(b.detach()), L.ptr(s), n, L.stream()), "dreg_overlap_fwd")
+        ctx.save_for_backward(f, w, s)
+        return s
+
+    @staticmethod
+    def backward(ctx, gs):
+        f, w, s = ctx.saved_tensors
+        lib = L.load()
+        n = f.shape[0]
+        gs = gs.contiguous()
+        df = torch.empty_like(f)
+        dw = torch.empty(256, dtype=torch.float32, device=f.device)
+        db = torch.empty(1, dtype=torch.float32, device=f.device)
+        ws = torch.empty(lib.dreg_overlap_bwd_workspace_bytes(n) // 4 + 4, dtype=torch.float32, device=f.device)
+        L.check(lib.dreg_overlap_bwd(L.ptr(f), L.ptr(w.detach().contiguous()), L.ptr(s), L.ptr(gs), L.ptr(df), L.ptr(dw), L.ptr(db),
+                                     L.ptr(ws), n, L.stream()), "dreg_overlap_bwd")
+        return df, dw.view_as(w), db
 
 
 def overlap_head(f, w, b):
-    return torch.sigmoid(F.linear(f, w, b))  # SCAFFOLD
+    """f fp32 [..., 256] -> sigmoid(f . w + b) [..., 1]."""
+    shp = f.shape[:-1]
+    return _OverlapFn.apply(f.reshape(-1, 256), w, b).view(*shp, 1)
 
 
+# --------------------------------------------------------------------------- position embedding / downsample / Kabsch
 def posenc_sine(xyz, d_model=256, temperature=1000.0, scale=1.0):
-    n_dim = xyz.shape[-1]
-    npf = d_model // n_dim // 2 * 2
-    i = torch.arange(npf, dtype=torch.float32, device=xyz.device)
-    dim_t = temperature ** (2 * torch.div(i, 2, rounding_mode="trunc") / npf)
-    v = (xyz * (scale * 2 * math.pi)).unsqueeze(-1) / dim_t
-    emb = torch.stack([v[..., 0::2].sin(), v[..., 1::2].cos()], dim=-1).reshape(*xyz.shape[:-1], -1)  # SCAFFOLD
-    return F.pad(emb, (0, d_model - npf * n_dim))
+    lib = L.load()
+    assert d_model == 256 and xyz.shape[-1] == 3
+    xyz = xyz.detach().contiguous().float()
+    pe = torch.empty(xyz.shape[0], 256, dtype=torch.float32, device=xyz.device)
+    L.check(lib.dreg_posenc_sine(L.ptr(xyz), L.ptr(pe), xyz.shape[0], float(scale), float(temperature), L.stream()), "dreg_posenc_sine")
+    return pe
+
+
+class _VoxelMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, feats, pt_batch, nbatch, dl):
+        lib = L.load()
+        n, c = feats.shape
+        dev = feats.device
+        points, feats = points.contiguous(), feats.contiguous()
+        out_p = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        out_f = torch.empty(n, c, dtype=torch.float32, device=dev)
+        meta = torch.zeros(2 + nbatch, dtype=torch.int32, device=dev)  # n_out, err, counts...
+        inv_seg = torch.empty(n, dtype=torch.int32, device=dev)
+        inv_cnt = torch.empty(n, dtype=torch.float32, device=dev)
+        nbytes = lib.dreg_voxel_downsample_workspace_bytes(n)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        L.check(lib.dreg_voxel_downsample_fwd(L.ptr(points), L.ptr(feats), L.ptr(pt_batch), L.ptr(out_p), L.ptr(out_f),
+                                              meta.data_ptr(), meta.data_ptr() + 8, L.ptr(inv_seg), L.ptr(inv_cnt), meta.data_ptr() + 4,
+                                              L.ptr(ws), nbytes, n, c, nbatch, float(dl), L.stream()), "dreg_voxel_downsample_fwd")
+        host = meta.tolist()  # one host sync per round, as the reference's .shape[0] test (grid_downsample.py:91)
+        if host[1]:
+            raise L.DregError("voxel coordinates overflow the 16-bit cell range")
+        m = host[0]
+        ctx.save_for_backward(inv_seg, inv_cnt)
+        ctx.n = n
+        ctx.mark_non_differentiable(out_p)
+        counts = torch.tensor(host[2:], dtype=torch.int64)
+        return out_p[:m], out_f[:m], counts
+
+    @staticmethod
+    def backward(ctx, gp, gf, gc):
+        inv_seg, inv_cnt = ctx.saved_tensors
+        lib = L.load()
+        gf = gf.contiguous()
+        gin = torch.empty(ctx.n, gf.shape[1], dtype=torch.float32, device=gf.device)
+        L.check(lib.dreg_voxel_downsample_bwd(L.ptr(gf), L.ptr(inv_seg), L.ptr(inv_cnt), L.ptr(gin), ctx.n, gf.shape[1], L.stream()),
+                "dreg_voxel_downsample_bwd")
+        return None, gin, None, None, None
 
 
 def voxel_mean_downsample(points, feats, lengths, dl: float):
-    n = points.shape[0]
-    dev = points.device
-    b_idx = torch.repeat_interleave(torch.arange(len(lengths), device=dev), lengths)
-    cell = torch.floor(points / dl).to(torch.int32)
-    key = torch.cat([b_idx[:, None].to(torch.int32), cell], dim=1)
-    uniq, inv = torch.unique(key, dim=0, return_inverse=True)  # SCAFFOLD
-    m = uniq.shape[0]
-    fp = torch.cat([points, feats], dim=1)
-    acc = torch.zeros(m, fp.shape[1], dtype=fp.dtype, device=dev).index_add_(0, inv, fp)
-    cnt = torch.zeros(m, dtype=fp.dtype, device=dev).index_add_(0, inv, torch.ones(n, dtype=fp.dtype, device=dev))
-    out = acc / cnt[:, None]
-    new_len = torch.stack([(uniq[:, 0] == b).sum() for b in range(len(lengths))]).to(torch.int64)
-    return out[:, :3], out[:, 3:], new_len
+    """lengths: python list / CPU tensor of per-batch row counts (rows grouped by batch)."""
+    lens = [int(v) for v in lengths]
+    dev = feats.device
+    pt_batch = torch.repeat_interleave(torch.arange(len(lens), dtype=torch.int32, device=dev),
+                                       torch.tensor(lens, device=dev))
+    p, f, counts = _VoxelMeanFn.apply(points, feats, pt_batch, len(lens), dl)
+    return p, f, counts
 
 
 def weighted_kabsch(a, b, w, eps: float = 1e-6):
-    wn = w[..., None] / torch.clamp_min(w.sum(-1, keepdim=True)[..., None], eps)
-    ca, cb = (a * wn).sum(-2), (b * wn).sum(-2)
-    cov = (a - ca[..., None, :]).transpose(-2, -1) @ ((b - cb[..., None, :]) * wn)
-    u, _, vh = torch.linalg.svd(cov.cpu())  # SCAFFOLD (3x3 SVD on host)
-    u, vh = u.to(a.device), vh.to(a.device)
-    v = vh.transpose(-1, -2)
-    r_pos = v @ u.transpose(-1, -2)
-    v_neg = v.clone()
-    v_neg[..., 2] *= -1
-    r = torch.where(torch.det(r_pos)[..., None, None] > 0, r_pos, v_neg @ u.transpose(-1, -2))
-    t = -r @ ca[..., :, None] + cb[..., :, None]
-    return torch.cat([r, t], dim=-1)
+    """a,b [P,N,3], w [P,N] -> [P,3,4] (no gradient: the pose enters no loss, train_nerf_regtr.py:186-228)."""
+    lib = L.load()
+    a, b, w = a.detach().contiguous().float(), b.detach().contiguous().float(), w.detach().contiguous().float()
+    out = torch.empty(a.shape[0], 3, 4, dtype=torch.float32, device=a.device)
+    L.check(lib.dreg_weighted_kabsch(L.ptr(a), L.ptr(b), L.ptr(w), L.ptr(out), a.shape[0], a.shape[1], eps, L.stream()),
+            "dreg_weighted_kabsch")
+    return out

@@ -1,0 +1,516 @@
+// Flash-style softmax attention on gfx950 MFMA for the RegTR point-set transformer.
+//
+// Replaces the un-fused nn.MultiheadAttention path (need_weights=True materialises [1,N,N] weights;
+// conerf/register/transformer.py:242-281) and the correspondence decoder's einsum/softmax/einsum
+// (conerf/register/nerf_regtr.py:289-306).  Two instantiations:
+//   D = 32  : 8-head attention, V is [Nk, 32] per head, output in the operand dtype.
+//   D = 256 : single-head correspondence attention over the 6 stacked layer outputs, V = xyz (3 fp32 columns,
+//             accumulated on the VALU in fp32 so key-point coordinates never round to bf16).
+// One workgroup = 4 waves = 64 query (or key) rows of one head; each wave owns 16 rows; the other operand is
+// streamed through LDS in 64-row tiles.  S = Q K^T uses one 16x16x32 MFMA per 32 channels; probabilities are
+// re-laid out to the A-operand layout through a per-wave LDS scratch; strided B operands (V, K, Q, dO as
+// [row][channel]) are read with ds_read_b64_tr_b16 (bf16) or gathered (fp32).  fp32 operands use the exact
+// 16x16x4 f32 MFMA with the k-permutation "lane group g owns k = 8g..8g+7".
+#include "common.h"
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { bf16x8_t v; };
+template <> struct Frag<float> { float v[8]; };
+
+__device__ __forceinline__ f32x4_t mma(const Frag<bf16_t>& a, const Frag<bf16_t>& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_t mma(const Frag<float>& a, const Frag<float>& b, f32x4_t c) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[e], b.v[e], c, 0, 0, 0);
+    return c;
+}
+// 8 consecutive elements [row][k0 .. k0+7] of a row-major LDS tile
+__device__ __forceinline__ Frag<bf16_t> frag_row(const char* base, int rs, int row, int k0, bf16_t) {
+    Frag<bf16_t> f; f.v = *reinterpret_cast<const bf16x8_t*>(base + row * rs + k0 * 2); return f;
+}
+__device__ __forceinline__ Frag<float> frag_row(const char* base, int rs, int row, int k0, float) {
+    Frag<float> f;
+    float4 lo = *reinterpret_cast<const float4*>(base + row * rs + k0 * 4);
+    float4 hi = *reinterpret_cast<const float4*>(base + row * rs + k0 * 4 + 16);
+    f.v[0] = lo.x; f.v[1] = lo.y; f.v[2] = lo.z; f.v[3] = lo.w; f.v[4] = hi.x; f.v[5] = hi.y; f.v[6] = hi.z; f.v[7] = hi.w;
+    return f;
+}
+// same from global memory (row pointer given)
+__device__ __forceinline__ Frag<bf16_t> frag_glob(const bf16_t* p, bool valid) {
+    Frag<bf16_t> f;
+    if (valid) f.v = *reinterpret_cast<const bf16x8_t*>(p); else f.v = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+    return f;
+}
+__device__ __forceinline__ Frag<float> frag_glob(const float* p, bool valid) {
+    Frag<float> f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f.v[e] = valid ? p[e] : 0.f;
+    return f;
+}
+// B operand from a [k][col] row-major tile: element j = tile[k0 + j][col], col = cb + (lane & 15), k0 = kb0 + (lane>>4)*8
+__device__ __forceinline__ Frag<bf16_t> frag_col(const char* base, int rs, int kb0, int cb, int lane, bf16_t) {
+    typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
+    const int fi = lane & 15, kb = kb0 + (lane >> 4) * 8;
+    const char* p0 = base + (kb + (fi >> 2)) * rs + (cb + (fi & 3) * 4) * 2;
+    bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0));
+    bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0 + 4 * rs));
+    Frag<bf16_t> f; f.v = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f;
+}
+__device__ __forceinline__ Frag<float> frag_col(const char* base, int rs, int kb0, int cb, int lane, float) {
+    const int fi = lane & 15, kb = kb0 + (lane >> 4) * 8;
+    Frag<float> f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f.v[e] = *reinterpret_cast<const float*>(base + (kb + e) * rs + (cb + fi) * 4);
+    return f;
+}
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct AttnArgs {
+    const void *q, *k, *v;     // operand type T;  v = fp32 xyz [Nk,3] when XYZ
+    void* o;                   // T [Nq, ...] or fp32 [H, Nq, 3] when XYZ
+    float* lse;                // [H, Nq]
+    int Nq, Nk;
+    int ldq, ldk, ldv, ldo;    // row strides (elements)
+    long hq, hk, hv, ho;       // per-head (or per-layer) element offsets
+    float scale;
+    // backward
+    const void* dout;          // T [Nq,...] (ldo/ho) or fp32 [H,Nq,3]
+    float* dvec;               // [H, Nq]   rowsum(dO * O)
+    void *dq, *dk, *dv;        // outputs, operand type T, same strides as q/k/v
+};
+
+template <typename T, int D>
+__device__ __forceinline__ void load_tile(char* dst, int rs, const T* src, long ld, int row0, int nrows_valid, int tid) {
+    constexpr int GPR = D * sizeof(T) / 16;  // 16-byte granules per row
+    for (int q = tid; q < 64 * GPR; q += 256) {
+        const int r = q / GPR, g = q % GPR;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (row0 + r < nrows_valid) val = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(src + (long)(row0 + r) * ld) + g * 16);
+        *reinterpret_cast<uint4*>(dst + r * rs + g * 16) = val;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <typename T, int D, bool XYZ>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a)
+{
+    constexpr int DV = 32;
+    constexpr int KRS = D * sizeof(T) + 16, VRS = XYZ ? 16 : DV * sizeof(T) + 16, PRS = 64 * sizeof(T) + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = sK + 64 * KRS;
+    char* sP = sV + 64 * VRS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.y;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const T* Q = (const T*)a.q + h * a.hq;
+    const T* K = (const T*)a.k + h * a.hk;
+    const int fr = lane & 15, kg = lane >> 4;
+    char* myP = sP + wave * 16 * PRS;
+
+    Frag<T> qf[D / 32];
+#pragma unroll
+    for (int kk = 0; kk < D / 32; ++kk) qf[kk] = frag_glob(Q + (long)(q0 + fr) * a.ldq + kk * 32 + kg * 8, q0 + fr < a.Nq);
+
+    float m[4], l[4];
+    f32x4_t o[2];
+    float o3[4][3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; o3[r][0] = o3[r][1] = o3[r][2] = 0.f; }
+    o[0] = o[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < a.Nk; k0 += 64) {
+        __syncthreads();
+        load_tile<T, D>(sK, KRS, K, a.ldk, k0, a.Nk, tid);
+        if constexpr (XYZ) {
+            if (tid < 64) {
+                const float* x = (const float*)a.v;
+                float4 val = make_float4(0, 0, 0, 0);
+                if (k0 + tid < a.Nk) val = make_float4(x[(long)(k0 + tid) * 3], x[(long)(k0 + tid) * 3 + 1], x[(long)(k0 + tid) * 3 + 2], 0.f);
+                *reinterpret_cast<float4*>(sV + tid * 16) = val;
+            }
+        } else {
+            load_tile<T, DV>(sV, VRS, (const T*)a.v + h * a.hv, a.ldv, k0, a.Nk, tid);
+        }
+        __syncthreads();
+        f32x4_t s[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < D / 32; ++kk) s[t] = mma(qf[kk], frag_row(sK, KRS, t * 16 + fr, kk * 32 + kg * 8, T()), s[t]);
+        }
+        float alpha[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s[t][r] = (k0 + t * 16 + fr < a.Nk) ? s[t][r] * a.scale : -INFINITY;
+                mx = fmaxf(mx, s[t][r]);
+            }
+            mx = group16_max(mx);
+            const float mn = fmaxf(m[r], mx);
+            alpha[r] = __expf(m[r] - mn);
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { s[t][r] = __expf(s[t][r] - mn); sum += s[t][r]; }
+            sum = group16_sum(sum);
+            l[r] = l[r] * alpha[r] + sum;
+            m[r] = mn;
+        }
+        if constexpr (XYZ) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o3[r][c] *= alpha[r];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float4 x = *reinterpret_cast<const float4*>(sV + (t * 16 + fr) * 16);
+                    o3[r][0] += s[t][r] * x.x; o3[r][1] += s[t][r] * x.y; o3[r][2] += s[t][r] * x.z;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o[0][r] *= alpha[r]; o[1][r] *= alpha[r]; }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Elem<T>::st(reinterpret_cast<T*>(myP + (kg * 4 + r) * PRS) + t * 16 + fr, s[t][r]);
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                Frag<T> pf = frag_row(myP, PRS, fr, ks * 32 + kg * 8, T());
+#pragma unroll
+                for (int u = 0; u < 2; ++u) o[u] = mma(pf, frag_col(sV, VRS, ks * 32, u * 16, lane, T()), o[u]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qr = q0 + kg * 4 + r;
+        const float inv = 1.f / l[r];
+        if constexpr (XYZ) {
+            float x = group16_sum(o3[r][0]), y = group16_sum(o3[r][1]), z = group16_sum(o3[r][2]);
+            if (fr == 0 && qr < a.Nq) {
+                float* op = (float*)a.o + ((long)h * a.Nq + qr) * 3;
+                op[0] = x * inv; op[1] = y * inv; op[2] = z * inv;
+            }
+        } else if (qr < a.Nq) {
+            T* op = (T*)a.o + h * a.ho + (long)qr * a.ldo;
+            Elem<T>::st(op + fr, o[0][r] * inv);
+            Elem<T>::st(op + 16 + fr, o[1][r] * inv);
+        }
+        if (fr == 0 && qr < a.Nq) a.lse[(long)h * a.Nq + qr] = m[r] + __logf(l[r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ
+template <typename T, int D, bool XYZ>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a)
+{
+    constexpr int DV = 32;
+    constexpr int KRS = D * sizeof(T) + 16, VRS = XYZ ? 16 : DV * sizeof(T) + 16, PRS = 64 * sizeof(T) + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = sK + 64 * KRS;
+    char* sP = sV + 64 * VRS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.y;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const T* Q = (const T*)a.q + h * a.hq;
+    const T* K = (const T*)a.k + h * a.hk;
+    const int fr = lane & 15, kg = lane >> 4;
+    char* myP = sP + wave * 16 * PRS;
+
+    Frag<T> qf[D / 32];
+#pragma unroll
+    for (int kk = 0; kk < D / 32; ++kk) qf[kk] = frag_glob(Q + (long)(q0 + fr) * a.ldq + kk * 32 + kg * 8, q0 + fr < a.Nq);
+    // per-row quantities in the C layout rows (kg*4 + r)
+    float lse[4], dv_[4], do3[4][3];
+    Frag<T> dof;  // dO as A operand (rows q = fr)
+    if constexpr (!XYZ) {
+        const T* dO = (const T*)a.dout + h * a.ho;
+        const T* O = (const T*)a.o + h * a.ho;
+        dof = frag_glob(dO + (long)(q0 + fr) * a.ldo + kg * 8, q0 + fr < a.Nq);
+        // D[q] = sum_dv dO*O : each lane sums its 8 columns of row fr, then the 4 lane groups are combined
+        Frag<T> of = frag_glob(O + (long)(q0 + fr) * a.ldo + kg * 8, q0 + fr < a.Nq);
+        float part = 0.f;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part += bf2f((bf16_t)dof.v[e]) * bf2f((bf16_t)of.v[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part += dof.v[e] * of.v[e];
+        }
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);   // every lane with the same fr now holds D[row fr]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dv_[r] = __shfl(part, kg * 4 + r, 64);
+        if (kg == 0 && q0 + fr < a.Nq) a.dvec[(long)h * a.Nq + q0 + fr] = part;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qr = q0 + kg * 4 + r;
+        lse[r] = qr < a.Nq ? a.lse[(long)h * a.Nq + qr] : 0.f;
+        if constexpr (XYZ) {
+            const float* dO = (const float*)a.dout + ((long)h * a.Nq + qr) * 3;
+            const float* O = (const float*)a.o + ((long)h * a.Nq + qr) * 3;
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { do3[r][c] = qr < a.Nq ? dO[c] : 0.f; d += do3[r][c] * (qr < a.Nq ? O[c] : 0.f); }
+            dv_[r] = d;
+            if (fr == 0 && qr < a.Nq) a.dvec[(long)h * a.Nq + qr] = d;
+        }
+    }
+    f32x4_t dq[D / 16];
+#pragma unroll
+    for (int u = 0; u < D / 16; ++u) dq[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < a.Nk; k0 += 64) {
+        __syncthreads();
+        load_tile<T, D>(sK, KRS, K, a.ldk, k0, a.Nk, tid);
+        if constexpr (XYZ) {
+            if (tid < 64) {
+                const float* x = (const float*)a.v;
+                float4 val = make_float4(0, 0, 0, 0);
+                if (k0 + tid < a.Nk) val = make_float4(x[(long)(k0 + tid) * 3], x[(long)(k0 + tid) * 3 + 1], x[(long)(k0 + tid) * 3 + 2], 0.f);
+                *reinterpret_cast<float4*>(sV + tid * 16) = val;
+            }
+        } else {
+            load_tile<T, DV>(sV, VRS, (const T*)a.v + h * a.hv, a.ldv, k0, a.Nk, tid);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < D / 32; ++kk) s = mma(qf[kk], frag_row(sK, KRS, t * 16 + fr, kk * 32 + kg * 8, T()), s);
+            f32x4_t dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            if constexpr (!XYZ) dp = mma(dof, frag_row(sV, VRS, t * 16 + fr, kg * 8, T()), dp);
+            const bool kv = k0 + t * 16 + fr < a.Nk;
+            float4 x = make_float4(0, 0, 0, 0);
+            if constexpr (XYZ) x = *reinterpret_cast<const float4*>(sV + (t * 16 + fr) * 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = kv ? __expf(s[r] * a.scale - lse[r]) : 0.f;
+                float dpv = dp[r];
+                if constexpr (XYZ) dpv = do3[r][0] * x.x + do3[r][1] * x.y + do3[r][2] * x.z;
+                Elem<T>::st(reinterpret_cast<T*>(myP + (kg * 4 + r) * PRS) + t * 16 + fr, p * (dpv - dv_[r]) * a.scale);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag<T> df = frag_row(myP, PRS, fr, ks * 32 + kg * 8, T());
+#pragma unroll
+            for (int u = 0; u < D / 16; ++u) dq[u] = mma(df, frag_col(sK, KRS, ks * 32, u * 16, lane, T()), dq[u]);
+        }
+    }
+    T* dQ = (T*)a.dq + h * a.hq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qr = q0 + kg * 4 + r;
+        if (qr < a.Nq)
+#pragma unroll
+            for (int u = 0; u < D / 16; ++u) Elem<T>::st(dQ + (long)qr * a.ldq + u * 16 + fr, dq[u][r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+template <typename T, int D, bool XYZ>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a)
+{
+    constexpr int DV = 32;
+    constexpr int QRS = D * sizeof(T) + 16, ORS = XYZ ? 16 : DV * sizeof(T) + 16, PRS = 64 * sizeof(T) + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sQ = smem;
+    char* sO = sQ + 64 * QRS;             // dO tile
+    char* sP = sO + 64 * ORS;             // two scratch tiles per wave: p^T and dS^T
+    float* sL = reinterpret_cast<float*>(sP + 4 * 2 * 16 * PRS);  // lse[64], dvec[64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.y;
+    const int key0 = blockIdx.x * 64 + wave * 16;
+    const T* Q = (const T*)a.q + h * a.hq;
+    const T* K = (const T*)a.k + h * a.hk;
+    const int fr = lane & 15, kg = lane >> 4;
+    char* myP = sP + wave * 2 * 16 * PRS;
+    char* myS = myP + 16 * PRS;
+
+    Frag<T> kf[D / 32], vf;
+#pragma unroll
+    for (int kk = 0; kk < D / 32; ++kk) kf[kk] = frag_glob(K + (long)(key0 + fr) * a.ldk + kk * 32 + kg * 8, key0 + fr < a.Nk);
+    float x3[4][3];
+    if constexpr (!XYZ) {
+        vf = frag_glob((const T*)a.v + h * a.hv + (long)(key0 + fr) * a.ldv + kg * 8, key0 + fr < a.Nk);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kr = key0 + kg * 4 + r;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x3[r][c] = kr < a.Nk ? ((const float*)a.v)[(long)kr * 3 + c] : 0.f;
+        }
+    }
+    f32x4_t dk[D / 16], dvv[2];
+#pragma unroll
+    for (int u = 0; u < D / 16; ++u) dk[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    dvv[0] = dvv[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    for (int q0 = 0; q0 < a.Nq; q0 += 64) {
+        __syncthreads();
+        load_tile<T, D>(sQ, QRS, Q, a.ldq, q0, a.Nq, tid);
+        if constexpr (XYZ) {
+            if (tid < 64) {
+                const float* g = (const float*)a.dout + ((long)h * a.Nq + q0 + tid) * 3;
+                float4 val = make_float4(0, 0, 0, 0);
+                if (q0 + tid < a.Nq) val = make_float4(g[0], g[1], g[2], 0.f);
+                *reinterpret_cast<float4*>(sO + tid * 16) = val;
+            }
+        } else {
+            load_tile<T, DV>(sO, ORS, (const T*)a.dout + h * a.ho, a.ldo, q0, a.Nq, tid);
+        }
+        if (tid < 64) {
+            sL[tid] = q0 + tid < a.Nq ? a.lse[(long)h * a.Nq + q0 + tid] : 0.f;
+            sL[64 + tid] = q0 + tid < a.Nq ? a.dvec[(long)h * a.Nq + q0 + tid] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            // S^T[key][q] : rows = keys (this wave's 16), cols = queries t*16 + fr
+            f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < D / 32; ++kk) s = mma(kf[kk], frag_row(sQ, QRS, t * 16 + fr, kk * 32 + kg * 8, T()), s);
+            f32x4_t dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            if constexpr (!XYZ) dp = mma(vf, frag_row(sO, ORS, t * 16 + fr, kg * 8, T()), dp);
+            const int qc = t * 16 + fr;
+            const bool qv = q0 + qc < a.Nq;
+            const float lse = sL[qc], dvec = sL[64 + qc];
+            float4 g = make_float4(0, 0, 0, 0);
+            if constexpr (XYZ) g = *reinterpret_cast<const float4*>(sO + qc * 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool kv = key0 + kg * 4 + r < a.Nk;
+                const float p = (qv && kv) ? __expf(s[r] * a.scale - lse) : 0.f;
+                float dpv = dp[r];
+                if constexpr (XYZ) dpv = x3[r][0] * g.x + x3[r][1] * g.y + x3[r][2] * g.z;
+                if constexpr (!XYZ) Elem<T>::st(reinterpret_cast<T*>(myP + (kg * 4 + r) * PRS) + qc, p);
+                Elem<T>::st(reinterpret_cast<T*>(myS + (kg * 4 + r) * PRS) + qc, p * (dpv - dvec) * a.scale);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag<T> sf = frag_row(myS, PRS, fr, ks * 32 + kg * 8, T());
+#pragma unroll
+            for (int u = 0; u < D / 16; ++u) dk[u] = mma(sf, frag_col(sQ, QRS, ks * 32, u * 16, lane, T()), dk[u]);
+            if constexpr (!XYZ) {
+                Frag<T> pf = frag_row(myP, PRS, fr, ks * 32 + kg * 8, T());
+#pragma unroll
+                for (int u = 0; u < 2; ++u) dvv[u] = mma(pf, frag_col(sO, ORS, ks * 32, u * 16, lane, T()), dvv[u]);
+            }
+        }
+    }
+    T* dK = (T*)a.dk + h * a.hk;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int kr = key0 + kg * 4 + r;
+        if (kr < a.Nk) {
+#pragma unroll
+            for (int u = 0; u < D / 16; ++u) Elem<T>::st(dK + (long)kr * a.ldk + u * 16 + fr, dk[u][r]);
+            if constexpr (!XYZ) {
+                T* dV = (T*)a.dv + h * a.hv + (long)kr * a.ldv;
+                Elem<T>::st(dV + fr, dvv[0][r]);
+                Elem<T>::st(dV + 16 + fr, dvv[1][r]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+template <typename T, int D, bool XYZ>
+static int launch_attn(const AttnArgs& a, int H, int mode, hipStream_t st)
+{
+    constexpr int DV = 32;
+    const size_t krs = D * sizeof(T) + 16, vrs = XYZ ? 16 : DV * sizeof(T) + 16, prs = 64 * sizeof(T) + 16;
+    if (mode == 0) {
+        const size_t lds = 64 * krs + 64 * vrs + 4 * 16 * prs;
+        hipLaunchKernelGGL((attn_fwd_kernel<T, D, XYZ>), dim3((a.Nq + 63) / 64, H), dim3(256), lds, st, a);
+    } else if (mode == 1) {
+        const size_t lds = 64 * krs + 64 * vrs + 4 * 16 * prs;
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, XYZ>), dim3((a.Nq + 63) / 64, H), dim3(256), lds, st, a);
+    } else {
+        const size_t lds = 64 * krs + 64 * vrs + 4 * 2 * 16 * prs + 128 * sizeof(float);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, XYZ>), dim3((a.Nk + 63) / 64, H), dim3(256), lds, st, a);
+    }
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+static int dispatch_attn(const AttnArgs& a, int H, int D, int xyz, int dtype, int mode, hipStream_t st)
+{
+    if (a.Nq <= 0 || a.Nk <= 0) return DREG_EINVAL;
+    if (D == 32 && !xyz) return dtype == 0 ? launch_attn<bf16_t, 32, false>(a, H, mode, st) : launch_attn<float, 32, false>(a, H, mode, st);
+    if (D == 256 && xyz) return dtype == 0 ? launch_attn<bf16_t, 256, true>(a, H, mode, st) : launch_attn<float, 256, true>(a, H, mode, st);
+    return DREG_EINVAL;
+}
+
+extern "C" {
+
+// Multi-head attention core, head dim 32: o[:, h*32:(h+1)*32] = softmax(scale * q_h k_h^T) v_h.
+// q [Nq, ldq], k [Nk, ldk], v [Nk, ldv], o [Nq, ldo] (dtype 0 bf16 / 1 fp32, heads at column offset h*32); lse fp32 [H, Nq].
+int dreg_mha_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int Nq, int Nk, int H,
+                 int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream)
+{
+    AttnArgs a = {};
+    a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.Nq = Nq; a.Nk = Nk;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.hq = a.hk = a.hv = a.ho = 32; a.scale = scale;
+    return dispatch_attn(a, H, 32, 0, dtype, 0, (hipStream_t)stream);
+}
+// Gradients dq, dk, dv (same layouts/strides as q, k, v) from dout (layout of o).  dvec: fp32 [H, Nq] scratch.
+int dreg_mha_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                 float* dvec, void* dq, void* dk, void* dv, int Nq, int Nk, int H,
+                 int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream)
+{
+    AttnArgs a = {};
+    a.q = q; a.k = k; a.v = v; a.o = (void*)o; a.lse = (float*)lse; a.Nq = Nq; a.Nk = Nk;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.hq = a.hk = a.hv = a.ho = 32; a.scale = scale;
+    a.dout = dout; a.dvec = dvec; a.dq = dq; a.dk = dk; a.dv = dv;
+    int rc = dispatch_attn(a, H, 32, 0, dtype, 1, (hipStream_t)stream);
+    if (rc) return rc;
+    return dispatch_attn(a, H, 32, 0, dtype, 2, (hipStream_t)stream);
+}
+// Correspondence attention over L stacked layers: out[l] = softmax(scale * q[l] k[l]^T) xyz.
+// q [L,Nq,256], k [L,Nk,256] (dtype), xyz fp32 [Nk,3], out fp32 [L,Nq,3], lse fp32 [L,Nq].
+int dreg_corr_attention_fwd(const void* q, const void* k, const float* xyz, float* out, float* lse, int L, int Nq, int Nk,
+                            float scale, int dtype, void* stream)
+{
+    AttnArgs a = {};
+    a.q = q; a.k = k; a.v = xyz; a.o = out; a.lse = lse; a.Nq = Nq; a.Nk = Nk;
+    a.ldq = a.ldk = 256; a.hq = (long)Nq * 256; a.hk = (long)Nk * 256; a.scale = scale;
+    return dispatch_attn(a, L, 256, 1, dtype, 0, (hipStream_t)stream);
+}
+int dreg_corr_attention_bwd(const void* q, const void* k, const float* xyz, const float* out, const float* dout,
+                            const float* lse, float* dvec, void* dq, void* dk, int L, int Nq, int Nk,
+                            float scale, int dtype, void* stream)
+{
+    AttnArgs a = {};
+    a.q = q; a.k = k; a.v = xyz; a.o = (void*)out; a.lse = (float*)lse; a.Nq = Nq; a.Nk = Nk;
+    a.ldq = a.ldk = 256; a.hq = (long)Nq * 256; a.hk = (long)Nk * 256; a.scale = scale;
+    a.dout = dout; a.dvec = dvec; a.dq = dq; a.dk = dk;
+    int rc = dispatch_attn(a, L, 256, 1, dtype, 1, (hipStream_t)stream);
+    if (rc) return rc;
+    return dispatch_attn(a, L, 256, 1, dtype, 2, (hipStream_t)stream);
+}
+
+}  // extern "C"

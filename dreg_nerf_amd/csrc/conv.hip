@@ -55,7 +55,7 @@ template <typename T, typename TO, int BN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const T* __restrict__ in, const T* __restrict__ wt, TO* __restrict__ out,
     const float* __restrict__ bias, const TO* __restrict__ addend, ConvGeom g,
-    int relu, int Da, int Ha, int Wa, int tilesN)
+    int relu, int Da, int Ha, int Wa, int add_shift, int tilesN)
 {
     constexpr int BM = 128;
     constexpr int G = 16 / sizeof(T);
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
             if (addend) {
                 int b, z, y, x;
                 vox_decode(m, g, b, z, y, x);
-                arow = ((size_t)((b * Da + (z >> 1)) * Ha + (y >> 1)) * Wa + (x >> 1)) * g.Cout;
+                arow = ((size_t)((b * Da + (z >> add_shift)) * Ha + (y >> add_shift)) * Wa + (x >> add_shift)) * g.Cout;
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -452,19 +452,19 @@ static int fill_geom(ConvGeom& g, int B, int Di, int Hi, int Wi, int Cin, int Do
 
 template <typename T, typename TO>
 static int launch_conv(const void* in, const void* wt, void* out, const float* bias, const void* addend,
-                       const ConvGeom& g, int relu, int Da, int Ha, int Wa, hipStream_t st)
+                       const ConvGeom& g, int relu, int Da, int Ha, int Wa, int add_shift, hipStream_t st)
 {
     const int tilesM = (g.M + 127) / 128;
     if (g.Cout % 128 == 0) {
         const int tilesN = g.Cout / 128;
         const size_t lds = 2 * (128 + 128) * 128;
         hipLaunchKernelGGL((conv_igemm_kernel<T, TO, 128>), dim3(tilesM * tilesN), dim3(256), lds, st,
-                           (const T*)in, (const T*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, tilesN);
+                           (const T*)in, (const T*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN);
     } else if (g.Cout % 64 == 0) {
         const int tilesN = g.Cout / 64;
         const size_t lds = 2 * (128 + 64) * 128;
         hipLaunchKernelGGL((conv_igemm_kernel<T, TO, 64>), dim3(tilesM * tilesN), dim3(256), lds, st,
-                           (const T*)in, (const T*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, tilesN);
+                           (const T*)in, (const T*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN);
     } else return DREG_EINVAL;
     DREG_LAUNCH_CHECK();
     return DREG_OK;
@@ -475,12 +475,14 @@ extern "C" {
 // dtype: 0 = bf16 activations/weights (fp32 accumulate), 1 = fp32 (exact-f32 MFMA).  out_f32: bf16 inputs, fp32 output.
 // transposed = 0: out[b,o,:] = sum_d in[b, o*stride - pad + d, :] . W[:, d, :]           (forward)
 // transposed = 1: out[b,i,:] = sum_d in[b, (i + pad - d)/stride, :] . W'[:, d, :]       (data gradient; "in" = dOut)
-// addend (optional, same dtype as out): [B, Da, Ha, Wa, Cout] added with nearest x2 upsampling (FPN top-down path).
+// addend (optional, same dtype as out): [B, Da, Ha, Wa, Cout] added with nearest x2 upsampling (FPN top-down path),
+// or element-wise when add_same = 1 (residual connections of the transformer, Da,Ha,Wa = Do,Ho,Wo).
 int dreg_conv3d_igemm(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
                       int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
-                      int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa,
+                      int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
                       int dtype, int out_f32, void* stream)
 {
+    const int add_shift = add_same ? 0 : 1;
     ConvGeom g;
     const int es = dtype == 0 ? 2 : 4;
     int rc = fill_geom(g, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, ksz, stride, pad, transposed, es);
@@ -488,10 +490,10 @@ int dreg_conv3d_igemm(const void* in, const void* wt_packed, void* out, const fl
     if (g.M == 0) return DREG_OK;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0) {
-        if (out_f32) return launch_conv<bf16_t, float>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, st);
-        return launch_conv<bf16_t, bf16_t>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, st);
+        if (out_f32) return launch_conv<bf16_t, float>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st);
+        return launch_conv<bf16_t, bf16_t>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st);
     }
-    return launch_conv<float, float>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, st);
+    return launch_conv<float, float>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st);
 }
 
 // K padding of the packed weight row for (ntaps, Cin) at dtype.

@@ -1,0 +1,516 @@
+// Row-wise / small kernels of the point-set half (gfx950): LayerNorm (+position embedding) forward/backward,
+// sine position embedding, overlap head (GEMV + sigmoid), ReLU backward, weighted Kabsch (3x3 SVD on device),
+// voxel-average downsampling (sorted keys + segmented mean) and the flat AdamW / gradient-norm kernels.
+//
+// Reference call sites: conerf/register/transformer.py:238-293 (LayerNorm, with_pos_embed),
+// conerf/register/position_embedding.py:30-53, conerf/register/nerf_regtr.py:384-387 (overlap),
+// conerf/register/se3.py:89-140 (Kabsch), conerf/register/grid_downsample.py:6-44 (MinkowskiEngine average),
+// train_nerf_regtr.py:96-102,232-239 (clip_grad_norm_ + AdamW).
+#include "common.h"
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+// ------------------------------------------------------------------------------------------------ LayerNorm (C = 256)
+// y = LN(x) * g + b [+ pe]; one wave per row, 4 channels per lane.  Saves (mean, rstd) per row.
+template <typename TO>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                            const float* __restrict__ pe, TO* __restrict__ y, float* __restrict__ stats, int N, float eps)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * 256 + lane * 4);
+    const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
+    const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+    const float var = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / 256.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4), bb = *reinterpret_cast<const float4*>(b + lane * 4);
+    float o[4] = {d0 * rstd * gg.x + bb.x, d1 * rstd * gg.y + bb.y, d2 * rstd * gg.z + bb.z, d3 * rstd * gg.w + bb.w};
+    if (pe) { const float4 p = *reinterpret_cast<const float4*>(pe + (size_t)row * 256 + lane * 4); o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Elem<TO>::st(y + (size_t)row * 256 + lane * 4 + i, o[i]);
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+// dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  partial dgamma/dbeta per block of rows
+template <typename TG>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const TG* __restrict__ dy, const float* __restrict__ g,
+                                                            const float* __restrict__ stats, float* __restrict__ dx, float* __restrict__ part,
+                                                            int N, int rows_per_block, int accumulate_dx)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4);
+    float dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
+    const int r0 = blockIdx.x * rows_per_block;
+    for (int row = r0 + wave; row < min(r0 + rows_per_block, N); row += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * 256 + lane * 4);
+        float d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = Elem<TG>::ld(dy + (size_t)row * 256 + lane * 4 + i);
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        const float xh[4] = {(v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd};
+        const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s1 += d[i] * gv[i]; s2 += d[i] * gv[i] * xh[i]; dg[i] += d[i] * xh[i]; db[i] += d[i]; }
+        s1 = wave_sum(s1) * (1.f / 256.f); s2 = wave_sum(s2) * (1.f / 256.f);
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = rstd * (d[i] * gv[i] - s1 - xh[i] * s2);
+        float* p = dx + (size_t)row * 256 + lane * 4;
+        if (accumulate_dx) { const float4 old = *reinterpret_cast<const float4*>(p); o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w; }
+        *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __shared__ float red[4][512];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[wave][lane * 4 + i] = dg[i]; red[wave][256 + lane * 4 + i] = db[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 512; c += 256) part[(size_t)blockIdx.x * 512 + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+__global__ void layernorm_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ dg, float* __restrict__ db, int nblk, int accumulate)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 512) return;
+    double s = 0.0;
+    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * 512 + c];
+    float* dst = c < 256 ? dg + c : db + (c - 256);
+    *dst = accumulate ? *dst + (float)s : (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------ sine position embedding
+// 84 features per coordinate: feature i of coordinate c = (i even ? sin : cos)(x_c * 2*pi*scale / T^(2*floor(i/2)/84)); 252..255 = 0
+__global__ void posenc_sine_kernel(const float* __restrict__ xyz, float* __restrict__ pe, int N, float scale2pi, float log_temp)
+{
+    const size_t total = (size_t)N * 256;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i & 255), n = (int)(i >> 8);
+        float v = 0.f;
+        if (c < 252) {
+            const int coord = c / 84, f = c - coord * 84;
+            const float dim_t = powf(expf(log_temp), (float)(2 * (f >> 1)) / 84.f);
+            const float arg = (xyz[(size_t)n * 3 + coord] * scale2pi) / dim_t;
+            v = (f & 1) ? cosf(arg) : sinf(arg);
+        }
+        pe[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ overlap head
+// s[n] = sigmoid(f[n,:] . w + b)   (one wave per row);  backward: dlogit = gy*s*(1-s); df = dlogit*w; dw/db partials
+__global__ __launch_bounds__(256) void overlap_fwd_kernel(const float* __restrict__ f, const float* __restrict__ w, const float* __restrict__ b,
+                                                          float* __restrict__ s, int N)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float4 v = *reinterpret_cast<const float4*>(f + (size_t)row * 256 + lane * 4);
+    const float4 ww = *reinterpret_cast<const float4*>(w + lane * 4);
+    const float z = wave_sum(v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w) + b[0];
+    if (lane == 0) s[row] = 1.f / (1.f + expf(-z));
+}
+__global__ __launch_bounds__(256) void overlap_bwd_kernel(const float* __restrict__ f, const float* __restrict__ w, const float* __restrict__ s,
+                                                          const float* __restrict__ gy, float* __restrict__ df, float* __restrict__ part,
+                                                          int N, int rows_per_block)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float4 ww = *reinterpret_cast<const float4*>(w + lane * 4);
+    float dw[4] = {0, 0, 0, 0}, dbias = 0.f;
+    const int r0 = blockIdx.x * rows_per_block;
+    for (int row = r0 + wave; row < min(r0 + rows_per_block, N); row += 4) {
+        const float sv = s[row], dl = gy[row] * sv * (1.f - sv);
+        const float4 v = *reinterpret_cast<const float4*>(f + (size_t)row * 256 + lane * 4);
+        *reinterpret_cast<float4*>(df + (size_t)row * 256 + lane * 4) = make_float4(dl * ww.x, dl * ww.y, dl * ww.z, dl * ww.w);
+        dw[0] += dl * v.x; dw[1] += dl * v.y; dw[2] += dl * v.z; dw[3] += dl * v.w;
+        dbias += dl;
+    }
+    __shared__ float red[4][257];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][lane * 4 + i] = dw[i];
+    if (lane == 0) red[wave][256] = dbias;
+    __syncthreads();
+    for (int c = threadIdx.x; c < 257; c += 256) part[(size_t)blockIdx.x * 257 + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+__global__ void overlap_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblk)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 257) return;
+    double s = 0.0;
+    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * 257 + c];
+    if (c < 256) dw[c] = (float)s; else db[0] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise helpers
+// g_out = (y > 0) ? g : 0, cast to TO
+template <typename TY, typename TG, typename TO>
+__global__ void relu_bwd_kernel(const TY* __restrict__ y, const TG* __restrict__ g, TO* __restrict__ out, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        Elem<TO>::st(out + i, Elem<TY>::ld(y + i) > 0.f ? Elem<TG>::ld(g + i) : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------ weighted Kabsch
+// One workgroup per problem: T with T*a = b minimising sum w |R a + t - b|^2.  a,b [P,N,3], w [P,N] -> out [P,3,4].
+// Covariance accumulated in fp64; 3x3 SVD by two-sided Jacobi on H^T H (fp64); R = V U^T with the reflection fix.
+__device__ void jacobi_eig3(double A[3][3], double V[3][3])
+{
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = (i == j);
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq; }
+                for (int k = 0; k < 3; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk; }
+                for (int k = 0; k < 3; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
+            }
+    }
+}
+__global__ __launch_bounds__(256) void kabsch_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ w,
+                                                     float* __restrict__ out, int N, float eps)
+{
+    const int p = blockIdx.x, t = threadIdx.x;
+    const float* A = a + (size_t)p * N * 3;
+    const float* Bp = b + (size_t)p * N * 3;
+    const float* W = w + (size_t)p * N;
+    __shared__ double red[256];
+    __shared__ double acc[16];
+    auto block_sum = [&](double v) -> double {
+        red[t] = v; __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
+        const double r = red[0]; __syncthreads(); return r;
+    };
+    double sw = 0.0;
+    for (int i = t; i < N; i += 256) sw += W[i];
+    sw = block_sum(sw);
+    const double norm = fmax(sw, (double)eps);
+    double ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
+    for (int i = t; i < N; i += 256) {
+        const double wn = W[i] / norm;
+        for (int c = 0; c < 3; ++c) { ca[c] += wn * A[i * 3 + c]; cb[c] += wn * Bp[i * 3 + c]; }
+    }
+    for (int c = 0; c < 3; ++c) { ca[c] = block_sum(ca[c]); cb[c] = block_sum(cb[c]); }
+    double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int i = t; i < N; i += 256) {
+        const double wn = W[i] / norm;
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r][c] += (A[i * 3 + r] - ca[r]) * (Bp[i * 3 + c] - cb[c]) * wn;
+    }
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r][c] = block_sum(H[r][c]);
+    if (t == 0) {
+        // H = U S V^T.  Eigen-decompose H^T H = V S^2 V^T, sort descending, U = H V S^-1 (last column by cross product).
+        double HtH[3][3], V[3][3];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += H[k][i] * H[k][j]; HtH[i][j] = s; }
+        jacobi_eig3(HtH, V);
+        double ev[3] = {HtH[0][0], HtH[1][1], HtH[2][2]};
+        int idx[3] = {0, 1, 2};
+        for (int i = 0; i < 2; ++i) for (int j = i + 1; j < 3; ++j) if (ev[idx[j]] > ev[idx[i]]) { int tmp = idx[i]; idx[i] = idx[j]; idx[j] = tmp; }
+        double Vs[3][3], U[3][3];
+        for (int k = 0; k < 3; ++k) for (int j = 0; j < 3; ++j) Vs[k][j] = V[k][idx[j]];
+        for (int j = 0; j < 2; ++j) {
+            double n2 = 0;
+            for (int i = 0; i < 3; ++i) { double s = 0; for (int k = 0; k < 3; ++k) s += H[i][k] * Vs[k][j]; U[i][j] = s; n2 += s * s; }
+            const double n = sqrt(n2);
+            for (int i = 0; i < 3; ++i) U[i][j] = n > 0 ? U[i][j] / n : (i == j);
+        }
+        // third singular vectors from cross products so that det(U), det(V) are consistent with the two computed columns
+        double u2[3] = {U[1][0] * U[2][1] - U[2][0] * U[1][1], U[2][0] * U[0][1] - U[0][0] * U[2][1], U[0][0] * U[1][1] - U[1][0] * U[0][1]};
+        double v2[3] = {Vs[1][0] * Vs[2][1] - Vs[2][0] * Vs[1][1], Vs[2][0] * Vs[0][1] - Vs[0][0] * Vs[2][1], Vs[0][0] * Vs[1][1] - Vs[1][0] * Vs[0][1]};
+        // R = V diag(1,1,d) U^T with d = +1 here gives det(R) = +1 by construction (both bases right-handed),
+        // which is exactly the reference's "flip the last column of V when det(V U^T) < 0" rule (se3.py:128-134).
+        double R[3][3];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i][j] = Vs[i][0] * U[j][0] + Vs[i][1] * U[j][1] + v2[i] * u2[j];
+        float* o = out + (size_t)p * 12;
+        for (int i = 0; i < 3; ++i) {
+            double tr = cb[i];
+            for (int j = 0; j < 3; ++j) { o[i * 4 + j] = (float)R[i][j]; tr -= R[i][j] * ca[j]; }
+            o[i * 4 + 3] = (float)tr;
+        }
+    }
+    (void)acc;
+}
+
+// ------------------------------------------------------------------------------------------------ voxel-average downsample
+__global__ void voxel_keys_kernel(const float* __restrict__ pts, const int* __restrict__ pt_batch, uint64_t* __restrict__ keys,
+                                  uint32_t* __restrict__ vals, int N, float dl, int* __restrict__ err)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    uint64_t key = (uint64_t)(uint32_t)pt_batch[i] << 48;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float q = floorf(pts[(size_t)i * 3 + c] / dl);   // true division, as the CPU oracle
+        const int ci = (int)q + 32768;
+        if (ci < 0 || ci > 65535) atomicExch(err, 1);
+        key |= (uint64_t)(uint32_t)(ci & 0xffff) << (32 - 16 * c);
+    }
+    keys[i] = key; vals[i] = (uint32_t)i;
+}
+__global__ void segment_heads_kernel(const uint64_t* __restrict__ keys, uint32_t* __restrict__ head, int N)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+// seg[i] = inclusive_scan(head)[i] - 1 ; starts[seg] = i for heads ; counts per batch
+__global__ void segment_starts_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ head, const uint32_t* __restrict__ scan,
+                                      uint32_t* __restrict__ starts, int* __restrict__ batch_counts, int* __restrict__ nseg, int N)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (head[i]) { starts[scan[i] - 1] = (uint32_t)i; atomicAdd(batch_counts + (int)(keys[i] >> 48), 1); }
+    if (i == N - 1) { *nseg = (int)scan[i]; starts[scan[i]] = (uint32_t)N; }
+}
+// one wave per output row: mean over the segment's members (ascending original index = stable sort order)
+__global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restrict__ pts, const float* __restrict__ feats, const uint32_t* __restrict__ order,
+                                                           const uint32_t* __restrict__ starts, const int* __restrict__ nseg,
+                                                           float* __restrict__ out_pts, float* __restrict__ out_feats, uint32_t* __restrict__ inv_seg,
+                                                           float* __restrict__ inv_cnt, int C)
+{
+    const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (seg >= *nseg) return;
+    const uint32_t s0 = starts[seg], s1 = starts[seg + 1];
+    const float inv = 1.f / (float)(s1 - s0);
+    for (int c0 = lane * 4; c0 < C; c0 += 256) {
+        float4 acc = make_float4(0, 0, 0, 0);
+        for (uint32_t j = s0; j < s1; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(feats + (size_t)order[j] * C + c0);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out_feats + (size_t)seg * C + c0) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    }
+    if (lane < 3) {
+        float acc = 0.f;
+        for (uint32_t j = s0; j < s1; ++j) acc += pts[(size_t)order[j] * 3 + lane];
+        out_pts[(size_t)seg * 3 + lane] = acc * inv;
+    }
+    for (uint32_t j = s0 + lane; j < s1; j += 64) { inv_seg[order[j]] = (uint32_t)seg; inv_cnt[order[j]] = inv; }
+}
+// backward: dfeat_in[i] = dfeat_out[seg(i)] / count
+__global__ void segment_mean_bwd_kernel(const float* __restrict__ gout, const uint32_t* __restrict__ inv_seg, const float* __restrict__ inv_cnt,
+                                        float* __restrict__ gin, int N, int C)
+{
+    const size_t total = (size_t)N * (C / 4);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % (C / 4)), n = (int)(i / (C / 4));
+        const float s = inv_cnt[n];
+        const float4 g = *reinterpret_cast<const float4*>(gout + (size_t)inv_seg[n] * C + c4 * 4);
+        *reinterpret_cast<float4*>(gin + (size_t)n * C + c4 * 4) = make_float4(g.x * s, g.y * s, g.z * s, g.w * s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ optimizer
+// partial sum of squares of a flat fp32 gradient buffer
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, float* __restrict__ part, size_t n)
+{
+    float s = 0.f;
+    for (size_t i = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        if (i + 3 < n) { const float4 v = *reinterpret_cast<const float4*>(g + i); s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+        else for (size_t k = i; k < n; ++k) s += g[k] * g[k];
+    }
+    s = wave_sum(s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sumsq_final_kernel(const float* __restrict__ part, float* __restrict__ norm_out, int nblk)
+{
+    double s = 0.0;
+    for (int k = threadIdx.x; k < nblk; k += 64) s += part[k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) norm_out[0] = (float)sqrt(s);
+}
+// torch.optim.AdamW step on flat buffers with clip_grad_norm_ folded in:
+//   g *= min(1, max_norm / (norm + 1e-6));  p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+//   p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ norm,
+                             size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float max_norm)
+{
+    float clip = 1.f;
+    if (max_norm > 0.f) { clip = max_norm / (norm[0] + 1e-6f); clip = clip < 1.f ? clip : 1.f; }
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * clip;
+        g[i] = gi;
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+static inline int nblocks(size_t total, int per = 256, int cap = 4096) {
+    size_t b = (total + per - 1) / per;
+    return (int)(b > (size_t)cap ? cap : (b ? b : 1));
+}
+
+extern "C" {
+
+int dreg_layernorm_fwd(const float* x, const float* gamma, const float* beta, const float* pe, void* y, float* stats,
+                       int N, int C, float eps, int out_dtype, void* stream)
+{
+    if (C != 256) return DREG_EINVAL;
+    if (N == 0) return DREG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (out_dtype == 0) hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, dim3((N + 3) / 4), dim3(256), 0, st, x, gamma, beta, pe, (bf16_t*)y, stats, N, eps);
+    else hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, st, x, gamma, beta, pe, (float*)y, stats, N, eps);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+size_t dreg_layernorm_bwd_workspace_bytes(int N) { return (size_t)((N + 63) / 64) * 512 * sizeof(float); }
+// dy in g_dtype (0 bf16 / 1 fp32); dx fp32 (accumulated into when accumulate_dx); dgamma/dbeta fp32 (accumulated when accumulate_w)
+int dreg_layernorm_bwd(const float* x, const void* dy, const float* gamma, const float* stats, float* dx, float* dgamma, float* dbeta,
+                       float* workspace, int N, int C, int g_dtype, int accumulate_dx, int accumulate_w, void* stream)
+{
+    if (C != 256) return DREG_EINVAL;
+    if (N == 0) return DREG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = (N + 63) / 64;
+    if (g_dtype == 0) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, x, (const bf16_t*)dy, gamma, stats, dx, workspace, N, 64, accumulate_dx);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nblk), dim3(256), 0, st, x, (const float*)dy, gamma, stats, dx, workspace, N, 64, accumulate_dx);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3(2), dim3(256), 0, st, workspace, dgamma, dbeta, nblk, accumulate_w);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+int dreg_posenc_sine(const float* xyz, float* pe, int N, float scale, float temperature, void* stream)
+{
+    if (N == 0) return DREG_OK;
+    hipLaunchKernelGGL(posenc_sine_kernel, dim3(nblocks((size_t)N * 256)), dim3(256), 0, (hipStream_t)stream, xyz, pe, N,
+                       scale * 6.283185307179586f, logf(temperature));
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+int dreg_overlap_fwd(const float* f, const float* w, const float* b, float* s, int N, void* stream)
+{
+    if (N == 0) return DREG_OK;
+    hipLaunchKernelGGL(overlap_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, f, w, b, s, N);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+size_t dreg_overlap_bwd_workspace_bytes(int N) { return (size_t)((N + 63) / 64) * 257 * sizeof(float); }
+int dreg_overlap_bwd(const float* f, const float* w, const float* s, const float* gy, float* df, float* dw, float* db,
+                     float* workspace, int N, void* stream)
+{
+    if (N == 0) return DREG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = (N + 63) / 64;
+    hipLaunchKernelGGL(overlap_bwd_kernel, dim3(nblk), dim3(256), 0, st, f, w, s, gy, df, workspace, N, 64);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(overlap_bwd_final_kernel, dim3(2), dim3(256), 0, st, workspace, dw, db, nblk);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// out = (y > 0 ? g : 0) cast to out_dtype.  y_dtype / g_dtype / out_dtype: 0 bf16, 1 fp32
+int dreg_relu_bwd(const void* y, const void* g, void* out, size_t n, int y_dtype, int g_dtype, int out_dtype, void* stream)
+{
+    if (n == 0) return DREG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = nblocks(n);
+#define RB(TY, TG, TO) hipLaunchKernelGGL((relu_bwd_kernel<TY, TG, TO>), dim3(nb), dim3(256), 0, st, (const TY*)y, (const TG*)g, (TO*)out, n)
+    const int code = y_dtype * 4 + g_dtype * 2 + out_dtype;
+    switch (code) {
+        case 0: RB(bf16_t, bf16_t, bf16_t); break; case 1: RB(bf16_t, bf16_t, float); break;
+        case 2: RB(bf16_t, float, bf16_t); break;  case 3: RB(bf16_t, float, float); break;
+        case 4: RB(float, bf16_t, bf16_t); break;  case 5: RB(float, bf16_t, float); break;
+        case 6: RB(float, float, bf16_t); break;   default: RB(float, float, float); break;
+    }
+#undef RB
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+int dreg_weighted_kabsch(const float* a, const float* b, const float* w, float* out, int P, int N, float eps, void* stream)
+{
+    if (P == 0) return DREG_OK;
+    hipLaunchKernelGGL(kabsch_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, a, b, w, out, N, eps);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// Voxel-average downsample of (xyz | feat) rows sharing (batch, floor(p/dl)); output rows ordered by (batch, ix, iy, iz).
+// Outputs sized for the worst case N rows; n_out (device int) and batch_counts (device int[nbatch], zeroed here) report
+// the sizes; inv_seg / inv_cnt (per input row) feed the backward pass.  err: device int, set to 1 on coordinate overflow.
+size_t dreg_voxel_downsample_workspace_bytes(int N)
+{
+    size_t sort_bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)N);
+    size_t scan_bytes = 0;
+    (void)rocprim::inclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)N, rocprim::plus<uint32_t>());
+    const size_t tmp = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+    const size_t a = ((size_t)N * 8 + 255) / 256 * 256, b4 = ((size_t)(N + 1) * 4 + 255) / 256 * 256;
+    return 2 * a + 5 * b4 + tmp + 256;
+}
+int dreg_voxel_downsample_fwd(const float* pts, const float* feats, const int* pt_batch, float* out_pts, float* out_feats,
+                              int* n_out, int* batch_counts, uint32_t* inv_seg, float* inv_cnt, int* err,
+                              void* workspace, size_t workspace_bytes, int N, int C, int nbatch, float dl, void* stream)
+{
+    if (N <= 0 || C % 4) return DREG_EINVAL;
+    if (workspace_bytes < dreg_voxel_downsample_workspace_bytes(N)) return DREG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t a = ((size_t)N * 8 + 255) / 256 * 256, b4 = ((size_t)(N + 1) * 4 + 255) / 256 * 256;
+    char* w = (char*)workspace;
+    uint64_t* keys = (uint64_t*)w; w += a;
+    uint64_t* keys_s = (uint64_t*)w; w += a;
+    uint32_t* vals = (uint32_t*)w; w += b4;
+    uint32_t* order = (uint32_t*)w; w += b4;
+    uint32_t* head = (uint32_t*)w; w += b4;
+    uint32_t* scan = (uint32_t*)w; w += b4;
+    uint32_t* starts = (uint32_t*)w; w += b4;
+    void* tmp = w;
+    size_t tmp_bytes = workspace_bytes - (size_t)(w - (char*)workspace);
+    if (hipMemsetAsync(batch_counts, 0, sizeof(int) * nbatch, st) != hipSuccess) return DREG_ELAUNCH;
+    if (hipMemsetAsync(err, 0, sizeof(int), st) != hipSuccess) return DREG_ELAUNCH;
+    const int nb = (N + 255) / 256;
+    hipLaunchKernelGGL(voxel_keys_kernel, dim3(nb), dim3(256), 0, st, pts, pt_batch, keys, vals, N, dl, err);
+    DREG_LAUNCH_CHECK();
+    size_t sb = tmp_bytes;
+    if (rocprim::radix_sort_pairs(tmp, sb, keys, keys_s, vals, order, (size_t)N, 0, 64, st) != hipSuccess) return DREG_ELAUNCH;
+    hipLaunchKernelGGL(segment_heads_kernel, dim3(nb), dim3(256), 0, st, keys_s, head, N);
+    DREG_LAUNCH_CHECK();
+    sb = tmp_bytes;
+    if (rocprim::inclusive_scan(tmp, sb, head, scan, (size_t)N, rocprim::plus<uint32_t>(), st) != hipSuccess) return DREG_ELAUNCH;
+    hipLaunchKernelGGL(segment_starts_kernel, dim3(nb), dim3(256), 0, st, keys_s, head, scan, starts, batch_counts, n_out, N);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(segment_mean_kernel, dim3((N + 3) / 4), dim3(256), 0, st, pts, feats, order, starts, n_out, out_pts, out_feats, inv_seg, inv_cnt, C);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+int dreg_voxel_downsample_bwd(const float* gout, const uint32_t* inv_seg, const float* inv_cnt, float* gin, int N, int C, void* stream)
+{
+    if (N == 0) return DREG_OK;
+    hipLaunchKernelGGL(segment_mean_bwd_kernel, dim3(nblocks((size_t)N * (C / 4))), dim3(256), 0, (hipStream_t)stream, gout, inv_seg, inv_cnt, gin, N, C);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// norm_out[0] = ||g||_2 over a flat fp32 buffer.  workspace: fp32 [1024].
+int dreg_grad_norm(const float* g, float* norm_out, float* workspace, size_t n, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = nblocks((n + 3) / 4, 256, 1024);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, g, workspace, n);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, st, workspace, norm_out, nb);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// One AdamW step (torch.optim.AdamW semantics, step count `step` >= 1) over flat fp32 p/g/m/v with the gradient first
+// scaled by clip_grad_norm_(max_norm) using the device-resident norm (max_norm <= 0: no clipping).
+int dreg_adamw_step(float* p, float* g, float* m, float* v, const float* norm, size_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, float max_norm, void* stream)
+{
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, norm, n, lr, beta1, beta2,
+                       eps, weight_decay, bc1, sqrtf(bc2), max_norm);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+}  // extern "C"

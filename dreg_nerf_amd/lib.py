@@ -30,7 +30,7 @@ P, I, F, Z = c_void_p, c_int, c_float, c_size_t
 
 SIGNATURES = {
     # conv.hip
-    "dreg_conv3d_igemm": (I, [P, P, P, P, P] + [I] * 17 + [I, I, P]),
+    "dreg_conv3d_igemm": (I, [P, P, P, P, P] + [I] * 18 + [I, I, P]),
     "dreg_conv3d_kpad": (I, [I, I, I]),
     "dreg_pack_conv_weight": (I, [P, P, I, I, I, I, I, I, P]),
     "dreg_conv3d_wgrad_splits": (I, [I] * 8),
@@ -48,6 +48,26 @@ SIGNATURES = {
     "dreg_trilinear_gather_fwd": (I, [P, P, P, P] + [I] * 10 + [P]),
     "dreg_trilinear_gather_bwd": (I, [P, P, P, P] + [I] * 8 + [P]),
     "dreg_cast_from_f32": (I, [P, P, Z, I, P]),
+    # attention.hip
+    "dreg_mha_fwd": (I, [P] * 5 + [I] * 7 + [F, I, P]),
+    "dreg_mha_bwd": (I, [P] * 10 + [I] * 7 + [F, I, P]),
+    "dreg_corr_attention_fwd": (I, [P] * 5 + [I] * 3 + [F, I, P]),
+    "dreg_corr_attention_bwd": (I, [P] * 9 + [I] * 3 + [F, I, P]),
+    # pointset.hip
+    "dreg_layernorm_fwd": (I, [P] * 6 + [I, I, F, I, P]),
+    "dreg_layernorm_bwd_workspace_bytes": (Z, [I]),
+    "dreg_layernorm_bwd": (I, [P] * 8 + [I] * 5 + [P]),
+    "dreg_posenc_sine": (I, [P, P, I, F, F, P]),
+    "dreg_overlap_fwd": (I, [P, P, P, P, I, P]),
+    "dreg_overlap_bwd_workspace_bytes": (Z, [I]),
+    "dreg_overlap_bwd": (I, [P] * 8 + [I, P]),
+    "dreg_relu_bwd": (I, [P, P, P, Z, I, I, I, P]),
+    "dreg_weighted_kabsch": (I, [P, P, P, P, I, I, F, P]),
+    "dreg_voxel_downsample_workspace_bytes": (Z, [I]),
+    "dreg_voxel_downsample_fwd": (I, [P] * 11 + [Z, I, I, I, F, P]),
+    "dreg_voxel_downsample_bwd": (I, [P, P, P, P, I, I, P]),
+    "dreg_grad_norm": (I, [P, P, P, Z, P]),
+    "dreg_adamw_step": (I, [P] * 5 + [Z] + [F] * 5 + [I, F, P]),
 }
 
 

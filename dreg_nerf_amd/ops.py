@@ -86,7 +86,7 @@ def _out_dim(i, k, s, p):
 
 # --------------------------------------------------------------------------- convolution
 def conv_igemm(x, wpk, bias, addend, out_shape, cin, cout, ksz, stride, pad, transposed, relu=False, out_f32=False,
-               flop_cin=None):
+               flop_cin=None, add_same=False):
     """Raw launcher.  x: [B,Di,Hi,Wi,cin]; returns [B,*out_shape,cout]."""
     lib = L.load()
     dt = L.dt_of(x)
@@ -98,7 +98,10 @@ def conv_igemm(x, wpk, bias, addend, out_shape, cin, cout, ksz, stride, pad, tra
     if addend is not None:
         assert addend.dtype == odt and addend.shape[0] == B and addend.shape[4] == cout
         Da, Ha, Wa = addend.shape[1], addend.shape[2], addend.shape[3]
-        assert 2 * Da >= Do and 2 * Ha >= Ho and 2 * Wa >= Wo
+        if add_same:
+            assert (Da, Ha, Wa) == (Do, Ho, Wo)
+        else:
+            assert 2 * Da >= Do and 2 * Ha >= Ho and 2 * Wa >= Wo
     ev = None
     if PROFILER is not None:
         tn = "bf16" if dt == L.DT_BF16 else "f32"
@@ -111,7 +114,7 @@ def conv_igemm(x, wpk, bias, addend, out_shape, cin, cout, ksz, stride, pad, tra
         ev[0].record()
     L.check(lib.dreg_conv3d_igemm(L.ptr(x), L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(addend),
                                   B, Di, Hi, Wi, cin, Do, Ho, Wo, cout, ksz, stride, pad, int(transposed), int(relu),
-                                  Da, Ha, Wa, dt, int(out_f32 and dt == L.DT_BF16), L.stream()), "dreg_conv3d_igemm")
+                                  Da, Ha, Wa, int(add_same), dt, int(out_f32 and dt == L.DT_BF16), L.stream()), "dreg_conv3d_igemm")
     if ev is not None:
         ev[1].record()
     return out
@@ -162,12 +165,29 @@ def downsample_sum(g, coarse_shape):
 USE_TR = True  # LDS transpose reads in the bf16 weight-gradient kernel (False = 16-bit gather checker path)
 
 
+def relu_bwd_cast(y, g, out_dtype):
+    """(y > 0 ? g : 0) cast to out_dtype; y = None means a plain cast."""
+    lib = L.load()
+    g = g.contiguous()
+    out = torch.empty(g.shape, dtype=out_dtype, device=g.device)
+    if y is None:
+        if g.dtype == out_dtype:
+            return g
+        assert g.dtype == torch.float32
+        L.check(lib.dreg_cast_from_f32(L.ptr(g), L.ptr(out), g.numel(), L.dt_of(out), L.stream()), "dreg_cast_from_f32")
+        return out
+    L.check(lib.dreg_relu_bwd(L.ptr(y), L.ptr(g), L.ptr(out), g.numel(), L.dt_of(y), L.dt_of(g), L.dt_of(out), L.stream()),
+            "dreg_relu_bwd")
+    return out
+
+
 class Conv3dFn(torch.autograd.Function):
-    """y = conv3d(x, w) [+ bias] [+ nearest_up2(addend)]  — NDHWC, MFMA implicit GEMM forward,
-    data gradient (same kernel, transposed coordinate map) and split-K weight gradient."""
+    """y = [relu](conv3d(x, w) [+ bias] [+ addend])  — NDHWC, MFMA implicit GEMM forward, data gradient (same kernel,
+    transposed coordinate map) and split-K weight gradient.  addend: nearest-x2-upsampled coarser map (FPN) or, with
+    add_same, a same-shape residual.  out_f32: bf16 operands, fp32 result (fp32 residual stream of the transformer)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, addend, stride: int, pad: int):
+    def forward(ctx, x, w, bias, addend, stride: int, pad: int, relu: bool = False, out_f32: bool = False, add_same: bool = False):
         dt = L.dt_of(x)
         cin_pad = x.shape[4]
         cout = w.shape[0]
@@ -175,39 +195,45 @@ class Conv3dFn(torch.autograd.Function):
         out_shape = tuple(_out_dim(x.shape[i + 1], ksz, stride, pad) for i in range(3))
         wpk = packed_weight(w, cin_pad, False, dt)
         b32 = bias.detach().float().contiguous() if bias is not None else None
-        y = conv_igemm(x, wpk, b32, addend, out_shape, cin_pad, cout, ksz, stride, pad, False, flop_cin=w.shape[1])
-        ctx.save_for_backward(x, w)
-        ctx.cfg = (stride, pad, ksz, cin_pad, bias is not None, None if addend is None else tuple(addend.shape[1:4]))
+        y = conv_igemm(x, wpk, b32, addend, out_shape, cin_pad, cout, ksz, stride, pad, False, relu=relu, out_f32=out_f32,
+                       flop_cin=w.shape[1], add_same=add_same)
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.cfg = (stride, pad, ksz, cin_pad, bias is not None, None if addend is None else tuple(addend.shape[1:4]), add_same)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
-        stride, pad, ksz, cin_pad, has_bias, add_shape = ctx.cfg
+        x, w, y = ctx.saved_tensors
+        stride, pad, ksz, cin_pad, has_bias, add_shape, add_same = ctx.cfg
         dt = L.dt_of(x)
         gy = gy.contiguous()
         cout = w.shape[0]
         gx = gw = gb = ga = None
+        if add_shape is not None and ctx.needs_input_grad[3] and y is None:
+            ga = gy if add_same else downsample_sum(gy, add_shape)
+        g = relu_bwd_cast(y, gy, x.dtype)  # operand dtype for the MFMA passes, ReLU mask applied
+        if add_shape is not None and ctx.needs_input_grad[3] and y is not None:
+            ga = g if add_same else downsample_sum(g, add_shape)
         if ctx.needs_input_grad[0]:
             wpk = packed_weight(w, cin_pad, True, dt)
-            gx = conv_igemm(gy, wpk, None, None, tuple(x.shape[1:4]), cout, w.shape[1], ksz, stride, pad, True)
+            gx = conv_igemm(g, wpk, None, None, tuple(x.shape[1:4]), cout, w.shape[1], ksz, stride, pad, True)
         if ctx.needs_input_grad[1]:
-            gw = conv_wgrad(gy, x, tuple(w.shape), cin_pad, ksz, stride, pad, USE_TR)
+            gw = conv_wgrad(g, x, tuple(w.shape), cin_pad, ksz, stride, pad, USE_TR)
         if has_bias and ctx.needs_input_grad[2]:
-            gb = colsum(gy.view(-1, cout))
-        if add_shape is not None and ctx.needs_input_grad[3]:
-            ga = downsample_sum(gy, add_shape)
-        return gx, gw, gb, ga, None, None
+            gb = colsum(g.view(-1, cout))
+        return gx, gw, gb, ga, None, None, None, None, None
 
 
 def conv3d(x, w, bias=None, addend=None, stride=1, pad=0):
     return Conv3dFn.apply(x, w, bias, addend, stride, pad)
 
 
-def linear(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
-    """[N, Cin] x [Cout, Cin]^T through the 1x1x1 path of the same kernels."""
+def linear(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = False, residual=None,
+           out_f32: bool = False) -> torch.Tensor:
+    """[N, Cin] x [Cout, Cin]^T (+bias) (+residual) (relu) through the 1x1x1 path of the same kernels."""
     n, cin = x2d.shape
-    y = Conv3dFn.apply(x2d.view(1, 1, 1, n, cin), w, bias, None, 1, 0)
+    res = residual.view(1, 1, 1, n, w.shape[0]) if residual is not None else None
+    y = Conv3dFn.apply(x2d.view(1, 1, 1, n, cin), w, bias, res, 1, 0, relu, out_f32, residual is not None)
     return y.view(n, w.shape[0])
 
 

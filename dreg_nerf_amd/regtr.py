@@ -184,7 +184,7 @@ class NeRFRegTr(nn.Module):
             f = feats[off:off + ns + nt]
             off += ns + nt
             pts = torch.cat([xyzs[2 * i], xyzs[2 * i + 1]])
-            pts, f, lens = T.hierarchical_grid_subsample(pts, f, torch.tensor([ns, nt], device=dev), self.num_downsample)
+            pts, f, lens = T.hierarchical_grid_subsample(pts, f, [ns, nt], self.num_downsample)
             n0 = int(lens[0])
             s_xyz, t_xyz, s_f, t_f = pts[:n0], pts[n0:], f[:n0], f[n0:]
             s_pe = T.posenc_sine(s_xyz, scale=self.pos_emb_scaling)

@@ -2,6 +2,10 @@
 downsampling, sine position embedding, the 6-layer self/cross-attention encoder, the correspondence
 decoder and the weighted Kabsch solve.  Functions take the model's flat parameter dict.
 
+Source and target rows are kept concatenated ([Ns+Nt, 256], fp32 residual stream) so every LayerNorm / linear
+layer runs once per encoder layer for both point sets (the reference applies the same weights to both,
+transformer.py:225-299); only the attention cores see the two sets separately.
+
 Reference: conerf/register/grid_downsample.py:6-94, position_embedding.py:30-53, transformer.py:50-86,225-299,
 nerf_regtr.py:273-308,350-394, se3.py:89-140.
 """
@@ -9,7 +13,6 @@ import math
 from typing import Dict
 
 import torch
-import torch.nn.functional as F
 
 from . import attn_ops as A
 
@@ -40,58 +43,48 @@ def posenc_sine(xyz: torch.Tensor, d_model: int = 256, temperature: float = 1000
 
 
 # --------------------------------------------------------------------------- A6
-def _ln(P, p, x):
-    return A.layer_norm(x, P[p + ".weight"], P[p + ".bias"])
-
-
-def _mha(P, p, q_in, k_in, v_in, self_attn: bool):
-    w, b = P[p + ".in_proj_weight"], P[p + ".in_proj_bias"]
-    e = w.shape[1]
-    if self_attn:
-        qkv = A.linear(q_in, w, b)
-        q, k, v = qkv[:, :e], qkv[:, e:2 * e], qkv[:, 2 * e:]
-    else:
-        q = A.linear(q_in, w[:e], b[:e])
-        kv = A.linear(k_in, w[e:], b[e:])
-        k, v = kv[:, :e], kv[:, e:]
-    o = A.attention(q, k, v, N_HEADS, 1.0 / math.sqrt(e // N_HEADS))
-    return A.linear(o, P[p + ".out_proj.weight"], P[p + ".out_proj.bias"])
-
-
-def encoder_layer(P, p, src, tgt, src_pe, tgt_pe):
-    s2 = _ln(P, p + ".norm1", src) + src_pe
-    src = src + _mha(P, p + ".self_attn", s2, s2, s2, True)
-    t2 = _ln(P, p + ".norm1", tgt) + tgt_pe
-    tgt = tgt + _mha(P, p + ".self_attn", t2, t2, t2, True)
-    s2 = _ln(P, p + ".norm2", src) + src_pe
-    t2 = _ln(P, p + ".norm2", tgt) + tgt_pe
-    s3 = _mha(P, p + ".cross_attn", s2, t2, t2, False)
-    t3 = _mha(P, p + ".cross_attn", t2, s2, s2, False)
-    src, tgt = src + s3, tgt + t3
-
-    def ffn(x):
-        h = _ln(P, p + ".norm3", x)
-        h = A.linear(h, P[p + ".linear1.weight"], P[p + ".linear1.bias"], relu=True)
-        return A.linear(h, P[p + ".linear2.weight"], P[p + ".linear2.bias"])
-
-    return src + ffn(src), tgt + ffn(tgt)
+def encoder_layer(P, p, x, pe, ns: int):
+    """x fp32 [Ns+Nt, 256] (src rows first), pe same shape.  forward_pre of transformer.py:225-299."""
+    sc = 1.0 / math.sqrt(256 // N_HEADS)
+    # self attention: q = k = v = LN1(x) + pe
+    h = A.layer_norm(x, P[p + ".norm1.weight"], P[p + ".norm1.bias"], pe)
+    qkv = A.linear(h, P[p + ".self_attn.in_proj_weight"], P[p + ".self_attn.in_proj_bias"])
+    o = torch.cat([A.mha_packed(qkv[:ns], qkv[:ns], N_HEADS, sc), A.mha_packed(qkv[ns:], qkv[ns:], N_HEADS, sc)])
+    x = A.linear(o, P[p + ".self_attn.out_proj.weight"], P[p + ".self_attn.out_proj.bias"], residual=x, out_f32=True)
+    # cross attention: q = LN2(x) + pe of one set, k = v = LN2(other) + pe
+    h = A.layer_norm(x, P[p + ".norm2.weight"], P[p + ".norm2.bias"], pe)
+    qkv = A.linear(h, P[p + ".cross_attn.in_proj_weight"], P[p + ".cross_attn.in_proj_bias"])
+    o = torch.cat([A.mha_packed(qkv[:ns], qkv[ns:], N_HEADS, sc), A.mha_packed(qkv[ns:], qkv[:ns], N_HEADS, sc)])
+    x = A.linear(o, P[p + ".cross_attn.out_proj.weight"], P[p + ".cross_attn.out_proj.bias"], residual=x, out_f32=True)
+    # feed-forward
+    h = A.layer_norm(x, P[p + ".norm3.weight"], P[p + ".norm3.bias"])
+    h = A.linear(h, P[p + ".linear1.weight"], P[p + ".linear1.bias"], relu=True)
+    return A.linear(h, P[p + ".linear2.weight"], P[p + ".linear2.bias"], residual=x, out_f32=True)
 
 
 def cross_encoder(P, src, tgt, src_pe, tgt_pe):
-    outs_s, outs_t = [], []
+    """Returns (src_cond [6,Ns,256], tgt_cond [6,Nt,256]) fp32: every layer's output through the shared final norm."""
+    ns = src.shape[0]
+    x = torch.cat([src, tgt]).float().contiguous()
+    pe = torch.cat([src_pe, tgt_pe]).contiguous()
+    outs = []
     for l in range(N_LAYERS):
-        src, tgt = encoder_layer(P, f"transformer_encoder.layers.{l}", src, tgt, src_pe, tgt_pe)
-        outs_s.append(_ln(P, "transformer_encoder.norm", src))
-        outs_t.append(_ln(P, "transformer_encoder.norm", tgt))
-    return torch.stack(outs_s), torch.stack(outs_t)
+        x = encoder_layer(P, f"transformer_encoder.layers.{l}", x, pe, ns)
+        outs.append(A.layer_norm(x, P["transformer_encoder.norm.weight"], P["transformer_encoder.norm.bias"],
+                                 out_dtype=torch.float32))
+    out = torch.stack(outs)
+    return out[:, :ns], out[:, ns:]
 
 
 # --------------------------------------------------------------------------- A7
 def corr_decoder(P, src_f, tgt_f, src_xyz, tgt_xyz, src_pe, tgt_pe):
+    """nerf_regtr.py:350-394.  src_f/tgt_f fp32 [6,N,256] (already through the final LayerNorm)."""
     p = "correspondence_decoder"
     nl, ns, e = src_f.shape
     nt = tgt_f.shape[1]
-    s2, t2 = (src_f + src_pe).reshape(nl * ns, e), (tgt_f + tgt_pe).reshape(nl * nt, e)
+    cdt = A.compute_dtype()
+    s2 = (src_f + src_pe).to(cdt).reshape(nl * ns, e)
+    t2 = (tgt_f + tgt_pe).to(cdt).reshape(nl * nt, e)
     both = torch.cat([s2, t2])
     q = A.linear(both, P[p + ".q_proj.weight"], P[p + ".q_proj.bias"])
     k = A.linear(both, P[p + ".k_proj.weight"], P[p + ".k_proj.bias"])
@@ -101,7 +94,7 @@ def corr_decoder(P, src_f, tgt_f, src_xyz, tgt_xyz, src_pe, tgt_pe):
     src_corr = A.attention_xyz(qs, kt, tgt_xyz, sc)
     tgt_corr = A.attention_xyz(qt, ks, src_xyz, sc)
     w, b = P[p + ".conf_logits_decoder.weight"], P[p + ".conf_logits_decoder.bias"]
-    return src_corr, tgt_corr, A.overlap_head(src_f, w, b), A.overlap_head(tgt_f, w, b)
+    return src_corr, tgt_corr, A.overlap_head(src_f.contiguous(), w, b), A.overlap_head(tgt_f.contiguous(), w, b)
 
 
 # --------------------------------------------------------------------------- A8

@@ -1,0 +1,154 @@
+/* dreg_nerf.h — C ABI of libdreg_nerf_hip.so (gfx950 / MI355X).
+ *
+ * The reference (AIBluefisher/DReg-NeRF) has no FFI layer of its own: its hot path reaches native code only through
+ * third-party Python packages (torch/cuDNN/cuBLAS, tiny-cuda-nn, MinkowskiEngine, nerfacc, torch_scatter).  Each entry
+ * point below replaces one such call site; the citation names the reference line that makes the call.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every buffer (inputs, outputs, workspace) is owned by the caller and must be
+ *     device memory of the current HIP device; nothing is retained after return; no allocation inside.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no implicit synchronisation.
+ *   - return 0 on success, DREG_EINVAL (-1) for unsupported shapes/arguments, otherwise the hipError_t of the launch.
+ *   - `dtype`: 0 = bfloat16 storage (fp32 accumulate), 1 = float32 (exact-f32 MFMA) — applies to activations and
+ *     packed weights; statistics, biases, gradients of parameters are always fp32.
+ *   - activations are NDHWC: [B, D, H, W, C] with C contiguous and C*sizeof(elem) a multiple of 16 bytes.
+ */
+#ifndef DREG_NERF_H
+#define DREG_NERF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DREG_OK 0
+#define DREG_EINVAL (-1)
+
+/* ---------------------------------------------------------------------------------------------- convolution / GEMM
+ * Replaces torch.nn.Conv3d -> cuDNN (conerf/model/resnet3d.py:79-84,120,143-147;
+ * conerf/model/feature_pyramid_net.py:21-36,47-56) and torch.nn.Linear -> cuBLAS
+ * (conerf/register/transformer.py:127-133,242-293; conerf/register/nerf_regtr.py:268-270,289-290) with ksz = 1. */
+
+/* padded K (elements) of one packed weight row for a ksz^3 kernel over Cin channels */
+int dreg_conv3d_kpad(int ksz, int Cin, int dtype);
+
+/* torch-layout fp32 weight [Cout][Cin_real][ksz^3] -> packed operand.
+ * for_dgrad = 0: [Cout][kpad(ksz,Cin)] with K = tap*Cin + ci (Cin >= Cin_real = zero-padded channel count)
+ * for_dgrad = 1: [Cin_real][kpad(ksz,Cout)] with K = tap*Cout + co (operand of the data-gradient pass) */
+int dreg_pack_conv_weight(const float* w, void* out, int Cout, int Cin_real, int Cin, int ksz, int for_dgrad,
+                          int dtype, void* stream);
+
+/* Implicit-GEMM convolution on MFMA.
+ * transposed = 0 (forward):        out[b,o,:] = sum_d in[b, o*stride - pad + d, :] . W[:, d, :]  (+bias) (+up2(addend)) (relu)
+ * transposed = 1 (data gradient):  out[b,i,:] = sum_d in[b, (i + pad - d)/stride, :] . W'[:, d, :]   ("in" is dOut)
+ * in [B,Di,Hi,Wi,Cin], out [B,Do,Ho,Wo,Cout]; Cout % 64 == 0; ksz in {1,3,5}; stride in {1,2}; Cin a power of two
+ * unless ksz == 1.  addend (optional, dtype of out) is [B,Da,Ha,Wa,Cout], added with nearest x2 upsampling + crop
+ * (FeaturePyramid_v1._upsample, feature_pyramid_net.py:58-61), or element-wise when add_same = 1 (the transformer's
+ * residual connections, transformer.py:250,262,283-284,289,293).  out_f32 = 1: bf16 operands, fp32 output. */
+int dreg_conv3d_igemm(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
+                      int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                      int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
+                      int dtype, int out_f32, void* stream);
+
+/* Weight gradient (split over voxels, deterministic two-stage reduction):
+ * dw[Cout][Cin_real][ksz^3] (fp32, torch layout) (+)= sum_m gout[m,:]^T x in[gather(m, tap), :]. */
+int dreg_conv3d_wgrad_splits(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int dtype);
+size_t dreg_conv3d_wgrad_workspace_bytes(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int dtype);
+int dreg_conv3d_wgrad(const void* gout, const void* in, float* dw, void* workspace, size_t workspace_bytes,
+                      int B, int Di, int Hi, int Wi, int Cin, int Cin_real, int Do, int Ho, int Wo, int Cout,
+                      int ksz, int stride, int pad, int accumulate, int dtype, int use_tr, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- FPN3D companions
+ * BatchNorm3d with the reference's one-grid-per-call statistics (resnet3d.py:121,159; nerf_regtr.py:135), fused
+ * residual add + ReLU (resnet3d.py:95-113). x,res,y: [B,V,C]; scale_shift, mean_rstd: fp32 [B,C,2] (saved for bwd);
+ * workspace fp32 [B * dreg_bn_num_chunks(V) * C * 2].  train = 0 uses the running statistics. */
+int dreg_bn_num_chunks(int V);
+int dreg_bn3d_fwd(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                  float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
+                  int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, void* stream);
+int dreg_bn3d_bwd(const void* x, const void* dy, const void* y, const float* scale_shift, const float* mean_rstd,
+                  void* dx, void* dres, float* dgamma, float* dbeta, float* coef, float* workspace,
+                  int B, int V, int C, int relu, int accumulate, int dtype, void* stream);
+
+/* nn.MaxPool3d(3, 2, 1) (resnet3d.py:123,161); argmax: uint8 [B,Do,Ho,Wo,C] tap index for the backward pass. */
+int dreg_maxpool3d_fwd(const void* x, void* y, uint8_t* argmax, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
+                       int C, int dtype, void* stream);
+int dreg_maxpool3d_bwd(const void* dy, const uint8_t* argmax, void* dx, int B, int Di, int Hi, int Wi, int Do, int Ho,
+                       int Wo, int C, int dtype, void* stream);
+
+/* backward of the nearest x2 upsample + crop: out[b,z,y,x,:] = sum of the in-range 2x2x2 children of g */
+int dreg_downsample_sum(const void* g, void* out, int B, int Df, int Hf, int Wf, int Dc, int Hc, int Wc, int C,
+                        int dtype, void* stream);
+
+/* out[c] (+)= sum_m g[m][c]  (bias gradients) */
+size_t dreg_colsum_workspace_bytes(size_t M, int C);
+int dreg_colsum(const void* g, float* out, float* workspace, size_t M, int C, int accumulate, int dtype, void* stream);
+
+/* F.interpolate(trilinear, align_corners=True) + masked gather fused (nerf_regtr.py:138-147): p1 [B,d,h,w,C],
+ * idx int64 [N] = (x*Yr + y)*Zr + z flat fine-grid index, pt_batch int32 [N] grid id; out [N,C]. */
+int dreg_trilinear_gather_fwd(const void* p1, const int64_t* idx, const int* pt_batch, void* out, int N, int d, int h,
+                              int w, int C, int Zr, int Xr, int Yr, int dtype, int out_f32, void* stream);
+int dreg_trilinear_gather_bwd(const float* dfeat, const int64_t* idx, const int* pt_batch, float* dp1_f32, int N, int d,
+                              int h, int w, int C, int Zr, int Xr, int Yr, void* stream);
+int dreg_cast_from_f32(const float* in, void* out, size_t n, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- point-set half
+ * Attention core of nn.MultiheadAttention (8 heads, d_head 32; transformer.py:242-281): q [Nq,ldq], k [Nk,ldk],
+ * v [Nk,ldv], o [Nq,ldo], head h at column offset 32*h, lse fp32 [H,Nq].  Flash-style, nothing N x N is materialised. */
+int dreg_mha_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int Nq, int Nk, int H,
+                 int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream);
+int dreg_mha_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                 float* dvec, void* dq, void* dk, void* dv, int Nq, int Nk, int H,
+                 int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream);
+/* CorrespondenceDecoder.simple_attention (nerf_regtr.py:273-308) for the L stacked layer outputs at once:
+ * out[l] = softmax(scale * q[l] k[l]^T) xyz;  q [L,Nq,256], k [L,Nk,256] (dtype), xyz fp32 [Nk,3], out fp32 [L,Nq,3]. */
+int dreg_corr_attention_fwd(const void* q, const void* k, const float* xyz, float* out, float* lse, int L, int Nq, int Nk,
+                            float scale, int dtype, void* stream);
+int dreg_corr_attention_bwd(const void* q, const void* k, const float* xyz, const float* out, const float* dout,
+                            const float* lse, float* dvec, void* dq, void* dk, int L, int Nq, int Nk,
+                            float scale, int dtype, void* stream);
+
+/* nn.LayerNorm(256) fused with the position-embedding add (transformer.py:238-239,252-253,265-267): y = LN(x)*g + b (+pe).
+ * x fp32 [N,256]; y in out_dtype; stats fp32 [N,2] = (mean, rstd). */
+int dreg_layernorm_fwd(const float* x, const float* gamma, const float* beta, const float* pe, void* y, float* stats,
+                       int N, int C, float eps, int out_dtype, void* stream);
+size_t dreg_layernorm_bwd_workspace_bytes(int N);
+int dreg_layernorm_bwd(const float* x, const void* dy, const float* gamma, const float* stats, float* dx, float* dgamma,
+                       float* dbeta, float* workspace, int N, int C, int g_dtype, int accumulate_dx, int accumulate_w,
+                       void* stream);
+
+/* PositionEmbeddingCoordsSine.forward (position_embedding.py:30-53): xyz fp32 [N,3] -> pe fp32 [N,256]. */
+int dreg_posenc_sine(const float* xyz, float* pe, int N, float scale, float temperature, void* stream);
+
+/* conf_logits_decoder + sigmoid (nerf_regtr.py:384-387): s[n] = sigmoid(f[n,:] . w + b). */
+int dreg_overlap_fwd(const float* f, const float* w, const float* b, float* s, int N, void* stream);
+size_t dreg_overlap_bwd_workspace_bytes(int N);
+int dreg_overlap_bwd(const float* f, const float* w, const float* s, const float* gy, float* df, float* dw, float* db,
+                     float* workspace, int N, void* stream);
+
+/* out = (y > 0 ? g : 0) cast to out_dtype (backward of the fused ReLU epilogue; also the fp32 -> bf16 gradient cast). */
+int dreg_relu_bwd(const void* y, const void* g, void* out, size_t n, int y_dtype, int g_dtype, int out_dtype, void* stream);
+
+/* compute_rigid_transform (se3.py:89-140): a,b fp32 [P,N,3], w fp32 [P,N] -> out fp32 [P,3,4]; 3x3 SVD on device. */
+int dreg_weighted_kabsch(const float* a, const float* b, const float* w, float* out, int P, int N, float eps, void* stream);
+
+/* batched_grid_subsample (grid_downsample.py:6-44; MinkowskiEngine UNWEIGHTED_AVERAGE): mean of (xyz | feat) over rows
+ * sharing (batch, floor(p/dl)); rows out ordered by (batch, ix, iy, iz).  Outputs sized for N rows; n_out / batch_counts
+ * are device ints; inv_seg / inv_cnt (per input row) feed the backward pass; err is set when |p/dl| >= 32768. */
+size_t dreg_voxel_downsample_workspace_bytes(int N);
+int dreg_voxel_downsample_fwd(const float* pts, const float* feats, const int* pt_batch, float* out_pts, float* out_feats,
+                              int* n_out, int* batch_counts, uint32_t* inv_seg, float* inv_cnt, int* err,
+                              void* workspace, size_t workspace_bytes, int N, int C, int nbatch, float dl, void* stream);
+int dreg_voxel_downsample_bwd(const float* gout, const uint32_t* inv_seg, const float* inv_cnt, float* gin, int N, int C,
+                              void* stream);
+
+/* clip_grad_norm_ + torch.optim.AdamW on flat fp32 buffers (train_nerf_regtr.py:96-102,232-237). */
+int dreg_grad_norm(const float* g, float* norm_out, float* workspace, size_t n, void* stream);
+int dreg_adamw_step(float* p, float* g, float* m, float* v, const float* norm, size_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, float max_norm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DREG_NERF_H */
