@@ -1,0 +1,335 @@
+// Instant-NGP dense query on gfx950: multiresolution hash-grid encoding fused with the density MLP, and the
+// 18-direction colour MLP, one wavefront per 64 samples, MLP layers on fp16 MFMA (16x16x32) with fp32 accumulation.
+//
+// Replaces the tiny-cuda-nn calls of the reference (arithmetic lives upstream, git master, unpinned):
+//   NGPradianceField.query_density   conerf/radiance_fields/ngp.py:148-176  (HashGrid L=16 F=2 T=2^19 Nmin=16 b=1.4472692
+//                                    + FullyFusedMLP 32->64->16, config ngp.py:92-110)
+//   NGPradianceField.query_rgb       ngp.py:178-193  (SH degree 4 + FullyFusedMLP 32->64->64->16, sigmoid, ngp.py:112-146)
+//   called 1 + 18 times per grid by SampleGrid.query_radiance_and_density_from_camera (conerf/register/sample_grid.py:321-341).
+// Build-side specification: table and weights are fp16 (tcnn's inference precision), trilinear
+// interpolation in fp32 rounded to fp16, layer inputs fp16, accumulation fp32 (tcnn accumulates in fp16 — unpinned).
+// The 18 viewing directions are constants of the caller, so the SH half of the colour net's first layer collapses to one
+// bias vector per direction (c_k = W1[:, :16] sh_k, computed by the caller) and the geometry half is computed once per point.
+#include "common.h"
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+struct NgpLevels {
+    uint32_t offset[16];   // first entry of the level (entries of 2 features)
+    uint32_t size[16];     // entries in the level
+    uint32_t res[16];
+    float scale[16];
+    uint32_t hashed[16];
+};
+
+__device__ __forceinline__ uint32_t grid_index(uint32_t x, uint32_t y, uint32_t z, uint32_t res, uint32_t size, uint32_t hashed) {
+    uint32_t idx = hashed ? (x ^ (y * 2654435761u) ^ (z * 805459861u)) : (x + y * res + z * res * res);
+    return idx % size;
+}
+
+__device__ __forceinline__ f16x8_t ldsfrag(const char* base, int rs, int row, int k0) {
+    return *reinterpret_cast<const f16x8_t*>(base + row * rs + k0 * 2);
+}
+
+// ------------------------------------------------------------------------------------------------ density
+// x world [Np,3] fp32 -> density fp32 [Np] (= exp(h0 - 1) * inside), raw fp16 [Np,16] (h0 | 15 geometry features)
+__global__ __launch_bounds__(256) void ngp_density_kernel(const float* __restrict__ x, const _Float16* __restrict__ table,
+                                                          const _Float16* __restrict__ w1, const _Float16* __restrict__ w2,
+                                                          float* __restrict__ density, _Float16* __restrict__ raw,
+                                                          NgpLevels lv, float lo0, float lo1, float lo2, float hi0, float hi1, float hi2, int Np)
+{
+    constexpr int XRS = 32 * 2 + 16, HRS = 64 * 2 + 16;
+    __shared__ __attribute__((aligned(16))) char smem[4 * (64 * XRS + 64 * HRS + 64 * 4)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* sX = smem + wave * (64 * XRS + 64 * HRS + 64 * 4);
+    char* sH = sX + 64 * XRS;
+    float* sSel = reinterpret_cast<float*>(sH + 64 * HRS);
+    const int p0 = (blockIdx.x * 4 + wave) * 64;
+    const int p = p0 + lane;
+    float u[3] = {0.f, 0.f, 0.f};
+    bool inside = false;
+    if (p < Np) {
+        const float lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
+        inside = true;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            u[c] = (x[(size_t)p * 3 + c] - lo[c]) / (hi[c] - lo[c]);
+            inside = inside && (u[c] > 0.f) && (u[c] < 1.f);
+            u[c] = fminf(fmaxf(u[c], 0.f), 1.f);
+        }
+    }
+    sSel[lane] = inside ? 1.f : 0.f;
+#pragma unroll 1
+    for (int l = 0; l < 16; ++l) {
+        const float sc = lv.scale[l];
+        const uint32_t res = lv.res[l], size = lv.size[l], hashed = lv.hashed[l];
+        const _Float16* tl = table + (size_t)lv.offset[l] * 2;
+        float pos[3], w[3];
+        uint32_t g[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { pos[c] = u[c] * sc + 0.5f; const float fl = floorf(pos[c]); g[c] = (uint32_t)fl; w[c] = pos[c] - fl; }
+        float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const uint32_t cx = g[0] + (corner & 1), cy = g[1] + ((corner >> 1) & 1), cz = g[2] + ((corner >> 2) & 1);
+            const float wt = ((corner & 1) ? w[0] : 1.f - w[0]) * ((corner & 2) ? w[1] : 1.f - w[1]) * ((corner & 4) ? w[2] : 1.f - w[2]);
+            const uint32_t idx = grid_index(cx, cy, cz, res, size, hashed);
+            const uint32_t pr = *reinterpret_cast<const uint32_t*>(tl + (size_t)idx * 2);
+            union { uint32_t u32; _Float16 h[2]; } cv; cv.u32 = pr;
+            f0 += wt * (float)cv.h[0]; f1 += wt * (float)cv.h[1];
+        }
+        _Float16* xr = reinterpret_cast<_Float16*>(sX + lane * XRS);
+        xr[2 * l] = (_Float16)f0; xr[2 * l + 1] = (_Float16)f1;
+    }
+    __syncthreads();
+    const int fr = lane & 15, kg = lane >> 4;
+    f32x4_t acc[4][4];
+    {
+        f16x8_t bf[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) bf[cb] = *reinterpret_cast<const f16x8_t*>(w1 + (cb * 16 + fr) * 32 + kg * 8);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const f16x8_t af = ldsfrag(sX, XRS, rb * 16 + fr, kg * 8);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[cb], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                reinterpret_cast<_Float16*>(sH + (rb * 16 + kg * 4 + r) * HRS)[cb * 16 + fr] = (_Float16)fmaxf(acc[rb][cb][r], 0.f);
+    __syncthreads();
+    f16x8_t w2f[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) w2f[kb] = *reinterpret_cast<const f16x8_t*>(w2 + fr * 64 + kb * 32 + kg * 8);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ldsfrag(sH, HRS, rb * 16 + fr, kb * 32 + kg * 8), w2f[kb], o, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rb * 16 + kg * 4 + r;
+            if (p0 + row < Np) {
+                const _Float16 hv = (_Float16)o[r];
+                raw[(size_t)(p0 + row) * 16 + fr] = hv;
+                if (fr == 0) density[p0 + row] = __expf((float)hv - 1.f) * sSel[row];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ colour, 18 directions
+// raw fp16 [Np,16] (col 0 ignored, cols 1..15 geometry features) -> rgb fp32 [Np,3] = mean_k sigmoid(net(sh_k | feat | 1))
+// w1 fp16 [64][32], w2 fp16 [64][64], w3 fp16 [16][64]; dirbias fp32 [ndir][64] = W1[:, :16] . fp16(sh_k)
+__global__ __launch_bounds__(256) void ngp_rgb_kernel(const _Float16* __restrict__ raw, const _Float16* __restrict__ w1, const _Float16* __restrict__ w2,
+                                                      const _Float16* __restrict__ w3, const float* __restrict__ dirbias,
+                                                      float* __restrict__ rgb, int ndir, int Np)
+{
+    constexpr int XRS = 32 * 2 + 16, HRS = 64 * 2 + 16;
+    __shared__ __attribute__((aligned(16))) char smem[4 * (64 * XRS + 2 * 64 * HRS)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* sX = smem + wave * (64 * XRS + 2 * 64 * HRS);
+    char* sH1 = sX + 64 * XRS;
+    char* sH2 = sH1 + 64 * HRS;
+    const int p0 = (blockIdx.x * 4 + wave) * 64;
+    const int p = p0 + lane;
+    {   // X = (0 x16 | feat[1..15] | 1)
+        _Float16* xr = reinterpret_cast<_Float16*>(sX + lane * XRS);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xr[j] = (_Float16)0.f;
+#pragma unroll
+        for (int j = 0; j < 15; ++j) xr[16 + j] = p < Np ? raw[(size_t)p * 16 + 1 + j] : (_Float16)0.f;
+        xr[31] = (_Float16)1.f;
+    }
+    __syncthreads();
+    const int fr = lane & 15, kg = lane >> 4;
+    f32x4_t base[4][4];
+    {
+        f16x8_t bf[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) bf[cb] = *reinterpret_cast<const f16x8_t*>(w1 + (cb * 16 + fr) * 32 + kg * 8);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const f16x8_t af = ldsfrag(sX, XRS, rb * 16 + fr, kg * 8);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) base[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[cb], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+    }
+    f16x8_t w3f[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) w3f[kb] = *reinterpret_cast<const f16x8_t*>(w3 + fr * 64 + kb * 32 + kg * 8);
+    float sum[4][4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[rb][r] = 0.f;
+
+#pragma unroll 1
+    for (int k = 0; k < ndir; ++k) {
+        float cb_[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) cb_[cb] = dirbias[k * 64 + cb * 16 + fr];
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    reinterpret_cast<_Float16*>(sH1 + (rb * 16 + kg * 4 + r) * HRS)[cb * 16 + fr] = (_Float16)fmaxf(base[rb][cb][r] + cb_[cb], 0.f);
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            f16x8_t af[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) af[kb] = ldsfrag(sH1, HRS, rb * 16 + fr, kb * 32 + kg * 8);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                f32x4_t h = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+                    h = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kb], *reinterpret_cast<const f16x8_t*>(w2 + (cb * 16 + fr) * 64 + kb * 32 + kg * 8), h, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    reinterpret_cast<_Float16*>(sH2 + (rb * 16 + kg * 4 + r) * HRS)[cb * 16 + fr] = (_Float16)fmaxf(h[r], 0.f);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ldsfrag(sH2, HRS, rb * 16 + fr, kb * 32 + kg * 8), w3f[kb], o, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float hv = (float)(_Float16)o[r];
+                sum[rb][r] += (float)(_Float16)(1.f / (1.f + __expf(-hv)));
+            }
+        }
+    }
+    if (fr < 3) {
+        const float inv = 1.f / (float)ndir;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = p0 + rb * 16 + kg * 4 + r;
+                if (row < Np) rgb[(size_t)row * 3 + fr] = sum[rb][r] * inv;
+            }
+    }
+}
+
+// grid[idx[n]] = (xyz, rgb, alpha) for kept points  (eval_ngp_nerf.py:397-405)
+__global__ void grid_scatter7_kernel(const float* __restrict__ xyz, const float* __restrict__ rgb, const float* __restrict__ alpha,
+                                     const int64_t* __restrict__ idx, const uint8_t* __restrict__ keep, float* __restrict__ grid, int Np)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Np || !keep[n]) return;
+    float* g = grid + (size_t)idx[n] * 7;
+    g[0] = xyz[(size_t)n * 3]; g[1] = xyz[(size_t)n * 3 + 1]; g[2] = xyz[(size_t)n * 3 + 2];
+    g[3] = rgb[(size_t)n * 3]; g[4] = rgb[(size_t)n * 3 + 1]; g[5] = rgb[(size_t)n * 3 + 2];
+    g[6] = alpha[n];
+}
+
+// occupied-cell sample positions: world = lo + (cell + jitter) / res * (hi - lo)  (sample_grid.py:226-242, AABB contraction)
+__global__ void grid_sample_points_kernel(const int64_t* __restrict__ idx, const float* __restrict__ jitter, float* __restrict__ world,
+                                          int rx, int ry, int rz, float lo0, float lo1, float lo2, float hi0, float hi1, float hi2, int Np)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Np) return;
+    const int64_t f = idx[n];
+    const int z = (int)(f % rz), y = (int)((f / rz) % ry), xx = (int)(f / ((int64_t)rz * ry));
+    const float u0 = ((float)xx + jitter[(size_t)n * 3]) / (float)rx, u1 = ((float)y + jitter[(size_t)n * 3 + 1]) / (float)ry,
+                u2 = ((float)z + jitter[(size_t)n * 3 + 2]) / (float)rz;
+    world[(size_t)n * 3] = u0 * (hi0 - lo0) + lo0;
+    world[(size_t)n * 3 + 1] = u1 * (hi1 - lo1) + lo1;
+    world[(size_t)n * 3 + 2] = u2 * (hi2 - lo2) + lo2;
+}
+
+template <typename T> __global__ void f32_to_f16_kernel(const float* __restrict__ in, _Float16* __restrict__ out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (_Float16)in[i];
+}
+
+extern "C" {
+
+// level table of the HashGrid (n_levels 16, base 16, per_level_scale b, log2_hashmap_size): fills 5 x 16 host arrays,
+// returns the total number of table entries (of 2 features).
+uint32_t dreg_ngp_level_table(float per_level_scale, int log2_hashmap_size, int base_resolution,
+                              uint32_t* offset, uint32_t* size, uint32_t* res, float* scale, uint32_t* hashed)
+{
+    uint32_t off = 0;
+    const uint32_t cap = 1u << log2_hashmap_size;
+    for (int l = 0; l < 16; ++l) {
+        const float sc = exp2f((float)l * log2f(per_level_scale)) * (float)base_resolution - 1.0f;
+        const uint32_t r = (uint32_t)ceilf(sc) + 1u;
+        uint64_t n = (uint64_t)r * r * r;
+        n = (n + 7) / 8 * 8;
+        const uint32_t sz = n > cap ? cap : (uint32_t)n;
+        offset[l] = off; size[l] = sz; res[l] = r; scale[l] = sc;
+        hashed[l] = ((uint64_t)r * r * r > sz) ? 1u : 0u;
+        off += sz;
+    }
+    return off;
+}
+
+int dreg_f32_to_f16(const float* in, void* out, size_t n, void* stream)
+{
+    if (n == 0) return DREG_OK;
+    size_t b = (n + 255) / 256; if (b > 4096) b = 4096;
+    hipLaunchKernelGGL(f32_to_f16_kernel<float>, dim3((int)b), dim3(256), 0, (hipStream_t)stream, in, (_Float16*)out, n);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// x fp32 [Np,3] world; table fp16 [entries,2]; w1 fp16 [64,32]; w2 fp16 [16,64]; levels: 5 x 16 arrays as produced by
+// dreg_ngp_level_table; aabb = (lo xyz, hi xyz).  Outputs density fp32 [Np], raw fp16 [Np,16].
+int dreg_ngp_density_fwd(const float* x, const void* table, const void* w1, const void* w2, float* density, void* raw,
+                         const uint32_t* offset, const uint32_t* size, const uint32_t* res, const float* scale, const uint32_t* hashed,
+                         const float* aabb, int Np, void* stream)
+{
+    if (Np == 0) return DREG_OK;
+    NgpLevels lv;
+    for (int l = 0; l < 16; ++l) { lv.offset[l] = offset[l]; lv.size[l] = size[l]; lv.res[l] = res[l]; lv.scale[l] = scale[l]; lv.hashed[l] = hashed[l]; }
+    hipLaunchKernelGGL(ngp_density_kernel, dim3((Np + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)table,
+                       (const _Float16*)w1, (const _Float16*)w2, density, (_Float16*)raw, lv,
+                       aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// raw fp16 [Np,16] -> rgb fp32 [Np,3], mean over ndir directions; dirbias fp32 [ndir,64] on the device.
+int dreg_ngp_rgb_mean_fwd(const void* raw, const void* w1, const void* w2, const void* w3, const float* dirbias, float* rgb,
+                          int ndir, int Np, void* stream)
+{
+    if (Np == 0) return DREG_OK;
+    hipLaunchKernelGGL(ngp_rgb_kernel, dim3((Np + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const _Float16*)raw,
+                       (const _Float16*)w1, (const _Float16*)w2, (const _Float16*)w3, dirbias, rgb, ndir, Np);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+int dreg_grid_scatter7(const float* xyz, const float* rgb, const float* alpha, const int64_t* idx, const uint8_t* keep,
+                       float* grid, int Np, void* stream)
+{
+    if (Np == 0) return DREG_OK;
+    hipLaunchKernelGGL(grid_scatter7_kernel, dim3((Np + 255) / 256), dim3(256), 0, (hipStream_t)stream, xyz, rgb, alpha, idx, keep, grid, Np);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+int dreg_grid_sample_points(const int64_t* idx, const float* jitter, float* world, int rx, int ry, int rz, const float* aabb,
+                            int Np, void* stream)
+{
+    if (Np == 0) return DREG_OK;
+    hipLaunchKernelGGL(grid_sample_points_kernel, dim3((Np + 255) / 256), dim3(256), 0, (hipStream_t)stream, idx, jitter, world,
+                       rx, ry, rz, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+}  // extern "C"

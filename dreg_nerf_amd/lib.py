@@ -68,6 +68,13 @@ SIGNATURES = {
     "dreg_voxel_downsample_bwd": (I, [P, P, P, P, I, I, P]),
     "dreg_grad_norm": (I, [P, P, P, Z, P]),
     "dreg_adamw_step": (I, [P] * 5 + [Z] + [F] * 5 + [I, F, P]),
+    # ngp.hip
+    "dreg_ngp_level_table": (ctypes.c_uint32, [F, I, I, P, P, P, P, P]),
+    "dreg_f32_to_f16": (I, [P, P, Z, P]),
+    "dreg_ngp_density_fwd": (I, [P] * 6 + [P] * 5 + [P, I, P]),
+    "dreg_ngp_rgb_mean_fwd": (I, [P] * 6 + [I, I, P]),
+    "dreg_grid_scatter7": (I, [P] * 6 + [I, P]),
+    "dreg_grid_sample_points": (I, [P, P, P, I, I, I, P, I, P]),
 }
 
 

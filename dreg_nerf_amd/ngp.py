@@ -1,0 +1,275 @@
+"""Host-side mirror of the reference's Instant-NGP radiance field and dense grid sampler (rows B1-B4 of SURVEY.md §8),
+running the hash-grid + MLP queries through ngp.hip.
+
+  NGPradianceField   conerf/radiance_fields/ngp.py:66-208  (state_dict: aabb, mlp_base.params, color_mlp.params)
+  SampleGrid         conerf/register/sample_grid.py:59-343 (dense-query part; the ray-marched surface mask is row N1)
+  save_voxel_grid    eval_ngp_nerf.py:383-412              (voxel_grid.pt fp32 [X,Y,Z,7], voxel_mask.pt int64 ascending)
+"""
+import enum
+import math
+import os
+import sys
+import types
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import lib as L
+
+PER_LEVEL_SCALE = 1.4472692012786865
+
+
+class ContractionType(enum.Enum):
+    """Stand-in for nerfacc.ContractionType (NeRF checkpoints pickle this enum: train_ngp_nerf.py:204)."""
+    AABB = 0
+    UN_BOUNDED_TANH = 1
+    UN_BOUNDED_SPHERE = 2
+
+
+def install_pickle_shims():
+    """Make torch.load of a reference NeRF checkpoint work without nerfacc: register a module named
+    nerfacc.contraction exposing ContractionType (only when the real package is absent)."""
+    try:
+        import nerfacc  # noqa: F401
+        return
+    except Exception:
+        pass
+    pkg = types.ModuleType("nerfacc")
+    sub = types.ModuleType("nerfacc.contraction")
+    ContractionType.__module__ = "nerfacc.contraction"
+    sub.ContractionType = ContractionType
+    pkg.contraction = sub
+    pkg.ContractionType = ContractionType
+    sys.modules.setdefault("nerfacc", pkg)
+    sys.modules.setdefault("nerfacc.contraction", sub)
+
+
+def _level_table(log2_hashmap_size: int = 19):
+    lib = L.load()
+    import ctypes
+    arrs = [(ctypes.c_uint32 * 16)(), (ctypes.c_uint32 * 16)(), (ctypes.c_uint32 * 16)(), (ctypes.c_float * 16)(), (ctypes.c_uint32 * 16)()]
+    total = lib.dreg_ngp_level_table(PER_LEVEL_SCALE, log2_hashmap_size, 16, *arrs)
+    return arrs, int(total)
+
+
+class _Params(nn.Module):
+    def __init__(self, n):
+        super().__init__()
+        self.params = nn.Parameter(torch.zeros(n, dtype=torch.float32))
+
+
+class NGPradianceField(nn.Module):
+    """Instant-NGP radiance field with the reference's call surface: query_density(x, return_feat), query_rgb(dir, embedding),
+    forward(positions, directions).  `embedding` here is the fp16 [N,16] raw network output (density logit | 15 features);
+    query_density(..., return_feat=True) returns (density [N,1], feat [N,15] fp32) like the reference and caches nothing."""
+
+    def __init__(self, aabb: Union[torch.Tensor, List[float]], num_dim: int = 3, use_viewdirs: bool = True,
+                 unbounded: bool = False, geo_feat_dim: int = 15, n_levels: int = 16, log2_hashmap_size: int = 19):
+        super().__init__()
+        if unbounded:
+            raise NotImplementedError("unbounded scenes (contract_to_unisphere) are outside the registration path")
+        if not isinstance(aabb, torch.Tensor):
+            aabb = torch.tensor(aabb, dtype=torch.float32)
+        assert n_levels == 16 and geo_feat_dim == 15 and num_dim == 3 and use_viewdirs
+        self.register_buffer("aabb", aabb.float())
+        self.unbounded = unbounded
+        self.geo_feat_dim = geo_feat_dim
+        self._levels, total = _level_table(log2_hashmap_size)
+        self.mlp_base = _Params(3072 + 2 * total)
+        self.color_mlp = _Params(7168)
+        self._prep = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        with torch.no_grad():  # tcnn defaults: hash table U(-1e-4, 1e-4), MLP weights Xavier-uniform
+            p = self.mlp_base.params
+            p[:2048].uniform_(-math.sqrt(6 / 96), math.sqrt(6 / 96))
+            p[2048:3072].uniform_(-math.sqrt(6 / 80), math.sqrt(6 / 80))
+            p[3072:].uniform_(-1e-4, 1e-4)
+            c = self.color_mlp.params
+            c[:2048].uniform_(-math.sqrt(6 / 96), math.sqrt(6 / 96))
+            c[2048:6144].uniform_(-math.sqrt(6 / 128), math.sqrt(6 / 128))
+            c[6144:].uniform_(-math.sqrt(6 / 80), math.sqrt(6 / 80))
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        sd = {k: v for k, v in state_dict.items() if k in ("aabb", "mlp_base.params", "color_mlp.params")}
+        extra = [k for k in state_dict if k not in sd and state_dict[k].numel() > 0]
+        if strict and extra:
+            raise RuntimeError(f"unexpected non-empty keys in NeRF state_dict: {extra}")
+        self._prep = None
+        return super().load_state_dict(sd, strict=strict)
+
+    # fp16 inference copies (tcnn's params_inference), refreshed when the fp32 parameters change
+    def _prepared(self):
+        key = (self.mlp_base.params._version, self.color_mlp.params._version, self.mlp_base.params.data_ptr())
+        if self._prep is None or self._prep[0] != key:
+            lib = L.load()
+            dev = self.mlp_base.params.device
+            base16 = torch.empty(self.mlp_base.params.numel(), dtype=torch.float16, device=dev)
+            col16 = torch.empty(7168, dtype=torch.float16, device=dev)
+            L.check(lib.dreg_f32_to_f16(L.ptr(self.mlp_base.params.detach()), L.ptr(base16), base16.numel(), L.stream()), "dreg_f32_to_f16")
+            L.check(lib.dreg_f32_to_f16(L.ptr(self.color_mlp.params.detach()), L.ptr(col16), col16.numel(), L.stream()), "dreg_f32_to_f16")
+            self._prep = (key, base16, col16)
+        return self._prep[1], self._prep[2]
+
+    @torch.no_grad()
+    def query_raw(self, x: torch.Tensor):
+        """x [N,3] world -> (density fp32 [N], raw fp16 [N,16])."""
+        lib = L.load()
+        import ctypes
+        base16, _ = self._prepared()
+        x = x.reshape(-1, 3).contiguous().float()
+        n = x.shape[0]
+        density = torch.empty(n, dtype=torch.float32, device=x.device)
+        raw = torch.empty(n, 16, dtype=torch.float16, device=x.device)
+        aabb = (ctypes.c_float * 6)(*[float(v) for v in self.aabb.tolist()])
+        L.check(lib.dreg_ngp_density_fwd(L.ptr(x), base16.data_ptr() + 3072 * 2, base16.data_ptr(), base16.data_ptr() + 2048 * 2,
+                                         L.ptr(density), L.ptr(raw), *self._levels, aabb, n, L.stream()), "dreg_ngp_density_fwd")
+        return density, raw
+
+    @torch.no_grad()
+    def query_density(self, x, return_feat: bool = False):
+        shp = x.shape[:-1]
+        density, raw = self.query_raw(x)
+        density = density.view(*shp, 1)
+        if return_feat:
+            return density, raw[:, 1:].float().view(*shp, self.geo_feat_dim)
+        return density
+
+    def dir_bias(self, dirs: torch.Tensor) -> torch.Tensor:
+        """c_k = fp16(W1[:, :16]) . fp16(SH4(dir_k))  for the colour net's first layer: [ndir, 64] fp32."""
+        _, col16 = self._prepared()
+        w1 = col16[:2048].view(64, 32)[:, :16].float()
+        sh = sh4(dirs.to(w1.device)).half().float()
+        return (sh @ w1.T).contiguous()
+
+    @torch.no_grad()
+    def query_rgb_mean(self, raw: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
+        """Mean over the given viewing directions of the colour net's output: raw fp16 [N,16], dirs [K,3] -> [N,3] fp32."""
+        lib = L.load()
+        _, col16 = self._prepared()
+        n = raw.shape[0]
+        rgb = torch.empty(n, 3, dtype=torch.float32, device=raw.device)
+        bias = self.dir_bias(dirs)
+        L.check(lib.dreg_ngp_rgb_mean_fwd(L.ptr(raw.contiguous()), col16.data_ptr(), col16.data_ptr() + 2048 * 2, col16.data_ptr() + 6144 * 2,
+                                          L.ptr(bias), L.ptr(rgb), dirs.shape[0], n, L.stream()), "dreg_ngp_rgb_mean_fwd")
+        return rgb
+
+    @torch.no_grad()
+    def query_rgb(self, dir, embedding):
+        """Reference signature: one direction per point.  Implemented for the dense-query use (a single direction
+        repeated for all points, sample_grid.py:332-337); per-point directions belong to rendering (out of scope)."""
+        d = dir.reshape(-1, 3)
+        if not torch.allclose(d, d[:1].expand_as(d)):
+            raise NotImplementedError("per-point viewing directions (volume rendering) are outside the registration path")
+        raw = torch.cat([torch.zeros(embedding.reshape(-1, 15).shape[0], 1, device=embedding.device), embedding.reshape(-1, 15)], dim=1).half()
+        return self.query_rgb_mean(raw, d[:1]).view(*embedding.shape[:-1], 3)
+
+    def forward(self, positions, directions=None):
+        density, feat = self.query_density(positions, return_feat=True)
+        return self.query_rgb(directions, feat), density
+
+
+def sh4(d: torch.Tensor) -> torch.Tensor:
+    x, y, z = d[..., 0], d[..., 1], d[..., 2]
+    xy, xz, yz, x2, y2, z2 = x * y, x * z, y * z, x * x, y * y, z * z
+    return torch.stack([
+        torch.full_like(x, 0.28209479177387814),
+        -0.48860251190291987 * y, 0.48860251190291987 * z, -0.48860251190291987 * x,
+        1.0925484305920792 * xy, -1.0925484305920792 * yz, 0.94617469575755997 * z2 - 0.31539156525251999,
+        -1.0925484305920792 * xz, 0.54627421529603959 * x2 - 0.54627421529603959 * y2,
+        0.59004358992664352 * y * (-3.0 * x2 + y2), 2.8906114426405538 * xy * z,
+        0.45704579946446572 * y * (1.0 - 5.0 * z2), 0.3731763325901154 * z * (5.0 * z2 - 3.0),
+        0.45704579946446572 * x * (1.0 - 5.0 * z2), 1.4453057213202769 * z * (x2 - y2),
+        0.59004358992664352 * x * (-x2 + 3.0 * y2)], dim=-1)
+
+
+class SampleGrid(nn.Module):
+    NUM_DIM = 3
+
+    def __init__(self, roi_aabb, resolution=128, contraction_type=ContractionType.AABB):
+        super().__init__()
+        if isinstance(resolution, int):
+            resolution = [resolution] * 3
+        resolution = torch.as_tensor(resolution, dtype=torch.int32)
+        roi_aabb = torch.as_tensor(roi_aabb, dtype=torch.float32)
+        assert resolution.shape == (3,) and roi_aabb.shape == (6,)
+        if getattr(contraction_type, "name", "AABB") != "AABB":
+            raise NotImplementedError("only ContractionType.AABB is used by the registration data (config.py:63, Objaverse)")
+        self.num_voxels = int(resolution.prod().item())
+        self.register_buffer("_binary", torch.zeros(resolution.tolist(), dtype=torch.bool))
+        self.register_buffer("resolution", resolution)
+        self.register_buffer("_roi_aabb", roi_aabb)
+        self._contraction_type = contraction_type
+        self._delta = 1e-2
+        self._viewdirs = self._generate_fixed_viewing_directions()
+
+    @property
+    def binary(self):
+        return self._binary
+
+    @torch.no_grad()
+    def set_binary_fields(self, binary):
+        self._binary = binary
+
+    @staticmethod
+    def _generate_fixed_viewing_directions() -> torch.Tensor:
+        """sample_grid.py:131-145, kept as written there (x == y, not unit length; quirk Q10)."""
+        phis = [math.pi / 3, 0, -math.pi]
+        thetas = [k * math.pi / 3 for k in range(6)]
+        return torch.tensor([[math.cos(p) * math.sin(t), math.cos(p) * math.sin(t), math.sin(t)] for p in phis for t in thetas],
+                            dtype=torch.float32)
+
+    @torch.no_grad()
+    def uniform_sample_occupied_voxels(self) -> torch.Tensor:
+        return torch.nonzero(self._binary.flatten())[:, 0]
+
+    @torch.no_grad()
+    def query_dense(self, radiance_field: NGPradianceField, device, density_thre: float = 0.7, jitter: Optional[torch.Tensor] = None):
+        """Dense-query part of query_radiance_and_density_from_camera (sample_grid.py:223-242, 321-341).
+        jitter [Np,3] in [0,1): drawn with torch.rand on `device` when not given (reference: rand_like, quirk Q11)."""
+        lib = L.load()
+        import ctypes
+        indices = self.uniform_sample_occupied_voxels().to(device)
+        n = indices.shape[0]
+        if jitter is None:
+            jitter = torch.rand(n, 3, dtype=torch.float32, device=device)
+        jitter = jitter.to(device).contiguous()
+        world = torch.empty(n, 3, dtype=torch.float32, device=device)
+        rx, ry, rz = [int(v) for v in self.resolution.tolist()]
+        aabb = (ctypes.c_float * 6)(*[float(v) for v in self._roi_aabb.tolist()])
+        L.check(lib.dreg_grid_sample_points(L.ptr(indices), L.ptr(jitter), L.ptr(world), rx, ry, rz, aabb, n, L.stream()), "dreg_grid_sample_points")
+        density, raw = radiance_field.query_raw(world)
+        rgb = radiance_field.query_rgb_mean(raw, self._viewdirs.to(device))
+        alpha = torch.clip(1 - torch.exp(-self._delta * density), 0, 1)
+        return world, rgb, alpha[:, None], indices, density > density_thre
+
+    @torch.no_grad()
+    def query_radiance_and_density_from_camera(self, radiance_field, occupancy_grid, meta_data, device,
+                                               density_thre: float = 0.7, cut_off: float = 0.5, jitter=None):
+        """Reference 6-tuple (sample_grid.py:343).  The ray-marched surface mask (sample_grid.py:244-318) is row N1 of
+        SURVEY.md §8(f), not built yet: every queried point is reported as surface-visible."""
+        world, rgb, alpha, indices, density_mask = self.query_dense(radiance_field, device, density_thre, jitter)
+        surface_mask = torch.ones_like(density_mask)
+        return world, rgb, alpha, indices, density_mask, surface_mask
+
+
+@torch.no_grad()
+def build_voxel_grid(world, rgb, alpha, indices, keep, resolution: int):
+    """eval_ngp_nerf.py:383-405: zeros [res^3, 7] with (xyz, rgb, alpha) written at the kept indices; returns
+    (voxel_grid fp32 [res,res,res,7], voxel_mask int64 ascending)."""
+    lib = L.load()
+    dev = world.device
+    grid = torch.zeros(resolution ** 3, 7, dtype=torch.float32, device=dev)
+    keep_u8 = keep.to(torch.uint8).contiguous()
+    L.check(lib.dreg_grid_scatter7(L.ptr(world.contiguous()), L.ptr(rgb.contiguous()), L.ptr(alpha.reshape(-1).contiguous()),
+                                   L.ptr(indices.contiguous()), L.ptr(keep_u8), L.ptr(grid), world.shape[0], L.stream()), "dreg_grid_scatter7")
+    return grid.view(resolution, resolution, resolution, 7), indices[keep]
+
+
+def save_voxel_grid(out_dir: str, voxel_grid: torch.Tensor, voxel_mask: torch.Tensor, prefix: str = "voxel"):
+    os.makedirs(out_dir, exist_ok=True)
+    torch.save(voxel_grid.cpu(), os.path.join(out_dir, f"{prefix}_grid.pt"))
+    torch.save(voxel_mask.cpu(), os.path.join(out_dir, f"{prefix}_mask.pt"))

@@ -148,6 +148,29 @@ int dreg_grad_norm(const float* g, float* norm_out, float* workspace, size_t n, 
 int dreg_adamw_step(float* p, float* g, float* m, float* v, const float* norm, size_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, float max_norm, void* stream);
 
+/* ---------------------------------------------------------------------------------------------- NGP dense query
+ * Replaces tiny-cuda-nn behind NGPradianceField (conerf/radiance_fields/ngp.py:92-146): HashGrid(L=16,F=2,T=2^19,
+ * Nmin=16,b=1.4472692) + FullyFusedMLP 32->64->16 for density (ngp.py:148-176) and SH4 + FullyFusedMLP 32->64->64->16
+ * (sigmoid) for colour (ngp.py:178-193), as used by SampleGrid.query_radiance_and_density_from_camera
+ * (conerf/register/sample_grid.py:223-242,321-341) and Evaluator.sample_points (eval_ngp_nerf.py:383-405).
+ * Level arrays and aabb are HOST pointers (16 entries each / 6 floats); everything else is device memory. */
+uint32_t dreg_ngp_level_table(float per_level_scale, int log2_hashmap_size, int base_resolution,
+                              uint32_t* offset, uint32_t* size, uint32_t* res, float* scale, uint32_t* hashed);
+int dreg_f32_to_f16(const float* in, void* out, size_t n, void* stream);
+/* x fp32 [Np,3] world -> density fp32 [Np] (= exp(h0-1) * inside-aabb), raw fp16 [Np,16] (h0 | 15 geometry features) */
+int dreg_ngp_density_fwd(const float* x, const void* table, const void* w1, const void* w2, float* density, void* raw,
+                         const uint32_t* offset, const uint32_t* size, const uint32_t* res, const float* scale,
+                         const uint32_t* hashed, const float* aabb, int Np, void* stream);
+/* mean over ndir fixed viewing directions of the colour net: dirbias fp32 [ndir,64] = W1[:, :16] . sh4(dir_k) */
+int dreg_ngp_rgb_mean_fwd(const void* raw, const void* w1, const void* w2, const void* w3, const float* dirbias, float* rgb,
+                          int ndir, int Np, void* stream);
+/* jittered sample of every occupied cell mapped to world space (sample_grid.py:226-242, AABB contraction) */
+int dreg_grid_sample_points(const int64_t* idx, const float* jitter, float* world, int rx, int ry, int rz, const float* aabb,
+                            int Np, void* stream);
+/* grid[idx[n]] = (xyz, rgb, alpha) for keep[n] != 0   (eval_ngp_nerf.py:397-405) */
+int dreg_grid_scatter7(const float* xyz, const float* rgb, const float* alpha, const int64_t* idx, const uint8_t* keep,
+                       float* grid, int Np, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,100 @@
+"""GPU: NGP dense-query kernels (ngp.hip) against the oracle restatement (oracle/ngp_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from dreg_nerf_amd import ngp  # noqa: E402
+from oracle import ngp_oracle as N  # noqa: E402
+
+DEV = "cuda:0"
+AABB = [-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]
+
+
+def _field(seed, table_scale=0.5):
+    f = ngp.NGPradianceField(AABB)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        p = f.mlp_base.params
+        p[:3072] = torch.randn(3072, generator=g) * 0.25
+        p[3072:] = torch.randn(p.numel() - 3072, generator=g) * table_scale
+        f.color_mlp.params.copy_(torch.randn(7168, generator=g) * 0.2)
+    return f
+
+
+def test_level_table_matches_oracle():
+    f = ngp.NGPradianceField(AABB)
+    rows, total = N.level_table()
+    off, size, res, scale, hashed = f._levels
+    assert [int(v) for v in off] == [r["offset"] for r in rows]
+    assert [int(v) for v in size] == [r["size"] for r in rows]
+    assert [int(v) for v in res] == [r["res"] for r in rows]
+    assert [bool(v) for v in hashed] == [r["hashed"] for r in rows]
+    np.testing.assert_allclose([float(v) for v in scale], [r["scale"] for r in rows], rtol=1e-6)
+    assert f.mlp_base.params.numel() == 12602992
+
+
+def test_all_ones_table_known_answer():
+    f = _field(0)
+    with torch.no_grad():
+        f.mlp_base.params[3072:] = 1.0
+    f = f.to(DEV)
+    x = (torch.rand(1000, 3, generator=torch.Generator().manual_seed(1)) - 0.5) * 2.9
+    _, raw = f.query_raw(x.to(DEV))
+    w1, w2, _ = N.split_density_params(f.mlp_base.params.detach().cpu())
+    expect = N.f16(N.f16(torch.relu(torch.ones(1, 32) @ N.f16(w1).T)) @ N.f16(w2).T)
+    assert (raw.float().cpu() - expect).abs().max() <= 2e-3 * expect.abs().max()
+
+
+def test_density_and_rgb_vs_oracle():
+    f = _field(2)
+    params_b, params_c = f.mlp_base.params.detach().clone(), f.color_mlp.params.detach().clone()
+    f = f.to(DEV)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(6000, 3, generator=g) - 0.5) * 3.2  # some points outside the aabb
+    d, raw = f.query_raw(x.to(DEV))
+    d_ref, raw_ref = N.query_density(x, torch.tensor(AABB), params_b)
+    inside = ((x > -1.5) & (x < 1.5)).all(-1)
+    scale = float(raw_ref.abs().max())
+    err = (raw.float().cpu() - raw_ref)[inside].abs().max()
+    assert err <= 4e-3 * scale, (float(err), scale)
+    assert torch.equal(d.cpu()[~inside], torch.zeros(int((~inside).sum())))
+    np.testing.assert_allclose(d.cpu()[inside].numpy(), d_ref[inside].numpy(), rtol=2e-2)
+    # density mask: bit-exact away from the threshold
+    far = (d_ref - 0.7).abs() > 0.02 * d_ref.clamp(min=0.7)
+    assert torch.equal((d.cpu() > 0.7)[far], (d_ref > 0.7)[far])
+    # colour: mean over the 18 fixed directions, on the oracle's raw so that only the colour net is compared
+    dirs = N.fixed_viewdirs()
+    rgb = f.query_rgb_mean(raw_ref.half().to(DEV), dirs.to(DEV)).cpu()
+    rgb_ref = torch.stack([N.query_rgb(dirs[k].expand(x.shape[0], 3), raw_ref, params_c) for k in range(18)]).mean(0)
+    np.testing.assert_allclose(rgb.numpy(), rgb_ref.numpy(), atol=3e-3)
+
+
+def test_dense_query_and_grid_writer(tmp_path):
+    res = 32
+    f = _field(4, table_scale=1.0)
+    params_b, params_c = f.mlp_base.params.detach().clone(), f.color_mlp.params.detach().clone()
+    f = f.to(DEV)
+    g = torch.Generator().manual_seed(5)
+    binary = torch.rand(res, res, res, generator=g) < 0.1
+    sg = ngp.SampleGrid(AABB, res).to(DEV)
+    sg.set_binary_fields(binary.to(DEV))
+    n = int(binary.sum())
+    jitter = torch.rand(n, 3, generator=g)
+    world, rgb, alpha, indices, dmask, smask = sg.query_radiance_and_density_from_camera(f, None, {}, DEV, jitter=jitter)
+    w_ref, rgb_ref, alpha_ref, idx_ref, dmask_ref = N.dense_query(binary, jitter, torch.tensor(AABB), torch.tensor(AABB), params_b, params_c)
+    assert torch.equal(indices.cpu(), idx_ref)
+    np.testing.assert_allclose(world.cpu().numpy(), w_ref.numpy(), atol=1e-6)
+    np.testing.assert_allclose(alpha.cpu().numpy()[:, 0], alpha_ref.numpy(), rtol=2e-2, atol=1e-5)
+    np.testing.assert_allclose(rgb.cpu().numpy(), rgb_ref.numpy(), atol=5e-3)
+    grid, mask = ngp.build_voxel_grid(world, rgb, alpha, indices, dmask & smask, res)
+    assert grid.shape == (res, res, res, 7) and mask.dtype == torch.int64
+    assert torch.all(mask[1:] > mask[:-1])
+    flat = grid.view(-1, 7).cpu()
+    assert torch.equal(flat[mask.cpu(), :3], world.cpu()[(dmask & smask).cpu()])
+    untouched = torch.ones(res ** 3, dtype=torch.bool)
+    untouched[mask.cpu()] = False
+    assert float(flat[untouched].abs().sum()) == 0.0
+    ngp.save_voxel_grid(str(tmp_path), grid, mask)
+    assert torch.load(str(tmp_path / "voxel_grid.pt")).shape == (res, res, res, 7)
