@@ -44,7 +44,7 @@ def cpu_baseline(res: int, target_res: int):
     train mode, fp32, all host cores.  Converted to pairs/s at `target_res` by the conv FLOP ratio (res^3)."""
     from dreg_nerf_amd import params, synth
     from oracle import regtr_oracle as O
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)  # more threads than this slow torch's CPU conv3d down at batch 1
     torch.set_num_threads(cores)
     sd = params.synth_state_dict(0)
     for k, (shape, kind) in params.regtr_spec().items():
