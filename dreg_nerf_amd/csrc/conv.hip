@@ -210,6 +210,147 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward / stride-1 data gradient, bf16, direct-to-LDS staging (buffer_load ... lds, 16 B per lane).
+// Requirements: Cin % 64 == 0, ntaps <= 32, sd == 1.  The LDS image is lane-linear per wave-instruction (8 rows x 8
+// slots), so the XOR swizzle is applied on the SOURCE side: physical slot s of row r fetches logical granule
+// s ^ ((r>>1)&7) of that row's 128-byte K chunk.  Padding taps and rows beyond M point their lane at an out-of-range
+// buffer offset: the hardware bounds check of the raw buffer returns zeros into LDS.  Per-row tap validity is a
+// 27-bit mask computed once per block, so the K loop spends 3 VALU ops per row on addressing.
+// ------------------------------------------------------------------------------------------------
+template <typename TO, int BN>
+__global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
+    const bf16_t* __restrict__ in, const bf16_t* __restrict__ wt, TO* __restrict__ out,
+    const float* __restrict__ bias, const TO* __restrict__ addend, ConvGeom g,
+    int relu, int Da, int Ha, int Wa, int add_shift, int tilesN, uint32_t in_bytes, uint32_t wt_bytes)
+{
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    constexpr int NW = BN == 256 ? 8 : 4, WAVES_N = BN == 256 ? 4 : 2;   // waves: 2 (M) x WAVES_N (N), 64 x (BN/WAVES_N) each
+    constexpr int BM = 128, BKe = 64, WN = BN / WAVES_N, TM = 4, TN = WN / 16;
+    constexpr int IA = 16 / NW, IBW = (BN / 8) / NW;                      // wave-instructions per wave per stage
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr uint32_t OOB = 0x7fffff00u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const uint32_t lid = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t tile_m = lid / tilesN, tile_n = lid - tile_m * tilesN;
+    const uint32_t m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)wt, 0, wt_bytes, 0x00020000);
+
+    // staging roles: wave-instruction i of this wave covers tile rows (wave*IA + i)*8 + (lane>>3), physical slot lane&7
+    uint32_t abase[IA], amask[IA];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+        const int r = (wave * IA + i) * 8 + (lane >> 3);
+        const int gl = (lane & 7) ^ ((r >> 1) & 7);
+        const uint32_t m = m0 + r;
+        int b, z, y, x;
+        vox_decode(m < g.M ? m : 0, g, b, z, y, x);
+        const int zb = z * g.sn + g.off, yb = y * g.sn + g.off, xb = x * g.sn + g.off;
+        uint32_t mask = 0;
+        if (m < g.M) {
+            for (int tap = 0; tap < g.ntaps; ++tap) {
+                int dz, dy, dx;
+                tap_decode(tap, g.ksz, dz, dy, dx);
+                const int zz = zb + dz * g.dsign, yy = yb + dy * g.dsign, xx = xb + dx * g.dsign;
+                if ((unsigned)zz < (unsigned)g.Di && (unsigned)yy < (unsigned)g.Hi && (unsigned)xx < (unsigned)g.Wi) mask |= 1u << tap;
+            }
+        }
+        amask[i] = mask;
+        // byte offset of the d = 0 corner (may be "negative": only used together with a valid tap, where the sum is in range)
+        abase[i] = (uint32_t)(((int)(b * g.Di + zb) * g.Hi + yb) * g.Wi + xb) * (uint32_t)(g.Cin * 2) + (uint32_t)(gl * 16);
+    }
+    uint32_t bbase[IBW];
+#pragma unroll
+    for (int i = 0; i < IBW; ++i) {
+        const int r = (wave * IBW + i) * 8 + (lane >> 3);
+        const int gl = (lane & 7) ^ ((r >> 1) & 7);
+        bbase[i] = (uint32_t)(n0 + r) * (uint32_t)(g.Kpad * 2) + (uint32_t)(gl * 16);
+    }
+    const int chunks = g.Cin / BKe;            // K steps per tap
+    const int nk = g.ntaps * chunks;
+
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int k, int buf) {
+        const int tap = k / chunks, c = k - tap * chunks;
+        int dz, dy, dx;
+        tap_decode(tap, g.ksz, dz, dy, dx);
+        const int toff = (((dz * g.Hi + dy) * g.Wi + dx) * g.dsign * g.Cin + c * BKe) * 2;
+        char* sA = smem + buf * STAGE + wave * IA * 1024;
+        char* sB = smem + buf * STAGE + A_BYTES + wave * IBW * 1024;
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const uint32_t voff = ((amask[i] >> tap) & 1u) ? abase[i] + (uint32_t)toff : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sA + i * 1024), 16, (int)voff, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < IBW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, (lds_ptr_t)(sB + i * 1024), 16, (int)(bbase[i] + (uint32_t)(k * BKe * 2)), 0, 0, 0);
+    };
+    auto compute = [&](int buf) {
+        const char* sA = smem + buf * STAGE;
+        const char* sB = sA + A_BYTES;
+        const int fr = lane & 15, kg = lane >> 4;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sA + swz(wm * 64 + i * 16 + fr, ks * 4 + kg));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(sB + swz(wn * WN + j * 16 + fr, ks * 4 + kg));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    issue(0, 0);
+    for (int k = 0; k < nk; ++k) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (k + 1 < nk) issue(k + 1, (k + 1) & 1);
+        compute(k & 1);
+    }
+
+    const int col_l = lane & 15, rowq = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t m = m0 + wm * 64 + i * 16 + rowq + r;
+            if (m >= g.M) continue;
+            size_t arow = 0;
+            if (addend) {
+                int b, z, y, x;
+                vox_decode(m, g, b, z, y, x);
+                arow = ((size_t)((b * Da + (z >> add_shift)) * Ha + (y >> add_shift)) * Wa + (x >> add_shift)) * g.Cout;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + col_l;
+                float v = acc[i][j][r];
+                if (bias) v += bias[n];
+                if (addend) v += Elem<TO>::ld(addend + arow + n);
+                if (relu) v = fmaxf(v, 0.f);
+                Elem<TO>::st(out + (size_t)m * g.Cout + n, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight gradient: part[s][co][n] = sum_{voxels of split s} gout[m][co] * in[gather(m, tap(n))][ci(n)]
 // rows = co (128 / block), cols = packed K index n (BNC / block), reduction over voxels in steps of 32.
 // Both operands are reduction-strided in memory ([voxel][channel]); bf16 fragments are formed with the
@@ -378,6 +519,159 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
         }
 }
 
+// bf16 weight gradient with direct-to-LDS staging (buffer_load ... lds).  Tiles are [64 voxels][channels] row-major and
+// lane-linear per wave-instruction; rows past the split's end and padding taps use the buffer bounds check to zero-fill.
+// Bank conflicts of the transpose reads (a 16-lane group touches 4 voxel rows x 32 B at the same column) are removed by an
+// XOR of the 16-byte granule index with f(row), applied on the SOURCE side of the DMA and on the read address:
+// 256-byte rows: f = ((row&3) + 4*((row>>3)&1)) * 2;  128-byte rows: f = (((row>>1)&1) + 2*((row>>3)&1)) * 2.
+// (ds_read_b64_tr_b16 services a 32-lane half-wave per cycle: voxel rows r..r+3 and r+8..r+11 must land on disjoint banks)
+template <int GP> __device__ __forceinline__ int wg_swz(int row) {
+    return GP == 16 ? (((row & 3) + 4 * ((row >> 3) & 1)) << 1) : ((((row >> 1) & 1) + 2 * ((row >> 3) & 1)) << 1);
+}
+
+template <int BM, int BNC>
+__global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(
+    const bf16_t* __restrict__ gout, const bf16_t* __restrict__ in, float* __restrict__ part,
+    ConvGeom g, int tilesCol, uint32_t vox_per_split, uint32_t gout_bytes, uint32_t in_bytes)
+{
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
+    constexpr int KV = 64;
+    constexpr int RSA = BM * 2, RSB = BNC * 2;
+    constexpr int GPA = RSA / 16, GPB = RSB / 16;          // granules per row (16 or 8)
+    constexpr int A_BYTES = KV * RSA, B_BYTES = KV * RSB, STAGE = A_BYTES + B_BYTES;
+    constexpr int IA = A_BYTES / 1024 / 4, IB = B_BYTES / 1024 / 4;   // wave-instructions per wave per tile
+    constexpr int RPA = 64 / GPA, RPB = 64 / GPB;          // rows per wave-instruction
+    constexpr int WN = BNC / 2, WM = BM / 2, TM = WM / 16, TN = WN / 16;
+    constexpr uint32_t OOB = 0x7fffff00u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const uint32_t tile_r = blockIdx.x / tilesCol, tile_c = blockIdx.x - tile_r * tilesCol;
+    const int co0 = tile_r * BM, n0 = tile_c * BNC;
+    const uint32_t v_begin = blockIdx.y * vox_per_split;
+    const uint32_t v_end = min(v_begin + vox_per_split, g.M);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)gout, 0, gout_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
+
+    // per wave-instruction lane constants (the tile row of instruction j is j*RP + lane/GP; j = wave*I + i)
+    const int ra = lane / GPA, rb = lane / GPB;
+    uint32_t a_col[IA];
+    int b_dz[IB], b_dy[IB], b_dx[IB], b_ci[IB];
+    bool b_tv[IB];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+        const int row = (wave * IA + i) * RPA + ra;
+        a_col[i] = (uint32_t)(co0 + (((lane % GPA) ^ wg_swz<GPA>(row)) * 8)) * 2u;
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+        const int row = (wave * IB + i) * RPB + rb;
+        const int n = n0 + (((lane % GPB) ^ wg_swz<GPB>(row)) * 8);
+        const int tap = n >> g.log2Cin;
+        b_ci[i] = n & g.Cmask;
+        tap_decode(tap, g.ksz, b_dz[i], b_dy[i], b_dx[i]);
+        b_dz[i] *= g.dsign; b_dy[i] *= g.dsign; b_dx[i] *= g.dsign;
+        b_tv[i] = tap < g.ntaps && b_ci[i] < g.Cin;
+    }
+
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](uint32_t v0, int buf) {
+        char* sA = smem + buf * STAGE;
+        char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const int j = wave * IA + i;
+            const uint32_t m = v0 + j * RPA + ra;
+            const uint32_t voff = (m < v_end) ? m * (uint32_t)(g.Cout * 2) + a_col[i] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(sA + j * 1024), 16, (int)voff, 0, 0, 0);
+        }
+        // one full voxel decode per K step (row of instruction 0); the wave's other rows are +RPB, +2*RPB ... voxels
+        // further along x with at most one carry when Wo >= IB*RPB (else every row is decoded in full)
+        const uint32_t mb = v0 + (wave * IB) * RPB + rb;
+        int b0, z0, y0, x0;
+        vox_decode(mb < g.M ? mb : 0, g, b0, z0, y0, x0);
+        const bool fast = g.Wo >= IB * RPB;
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            const int j = wave * IB + i;
+            const uint32_t m = mb + i * RPB;
+            bool v = (m < v_end) && b_tv[i];
+            int b = b0, z = z0, y = y0, x = x0 + i * RPB;
+            if (fast) {
+                if (x >= g.Wo) { x -= g.Wo; if (++y >= g.Ho) { y = 0; if (++z >= g.Do) { z = 0; ++b; } } }
+            } else {
+                vox_decode(v ? m : 0, g, b, z, y, x);
+            }
+            z = z * g.sn + g.off + b_dz[i]; y = y * g.sn + g.off + b_dy[i]; x = x * g.sn + g.off + b_dx[i];
+            if (g.sd == 2) { v = v && !((z | y | x) & 1); z >>= 1; y >>= 1; x >>= 1; }
+            v = v && (unsigned)z < (unsigned)g.Di && (unsigned)y < (unsigned)g.Hi && (unsigned)x < (unsigned)g.Wi;
+            const uint32_t vox = (uint32_t)b * (uint32_t)(g.Di * g.Hi * g.Wi) + (uint32_t)((z * g.Hi + y) * g.Wi + x);
+            const uint32_t voff = v ? (vox * (uint32_t)g.Cin + (uint32_t)b_ci[i]) * 2u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sB + j * 1024), 16, (int)voff, 0, 0, 0);
+        }
+    };
+    auto compute = [&](int buf) {
+        const char* sA = smem + buf * STAGE;
+        const char* sB = sA + A_BYTES;
+        const int fi = lane & 15;
+#pragma unroll
+        for (int ks = 0; ks < KV / 32; ++ks) {
+            const int kb = ks * 32 + (lane >> 4) * 8;
+            const int r0 = kb + (fi >> 2), r1 = r0 + 4;
+            bf16x8_t af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int gi = (wm * WM + i * 16) / 8 + ((fi & 3) >> 1), o8 = (fi & 1) * 8;
+                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(sA + r0 * RSA + ((gi ^ wg_swz<GPA>(r0)) << 4) + o8));
+                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(sA + r1 * RSA + ((gi ^ wg_swz<GPA>(r1)) << 4) + o8));
+                af[i] = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int gi = (wn * WN + j * 16) / 8 + ((fi & 3) >> 1), o8 = (fi & 1) * 8;
+                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(sB + r0 * RSB + ((gi ^ wg_swz<GPB>(r0)) << 4) + o8));
+                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(sB + r1 * RSB + ((gi ^ wg_swz<GPB>(r1)) << 4) + o8));
+                bf[j] = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (v_begin < v_end) {
+        const int nk = (int)((v_end - v_begin + KV - 1) / KV);
+        issue(v_begin, 0);
+        for (int k = 0; k < nk; ++k) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (k + 1 < nk) issue(v_begin + (uint32_t)(k + 1) * KV, (k + 1) & 1);
+            compute(k & 1);
+        }
+    }
+    float* dst = part + (size_t)blockIdx.y * g.Cout * g.Kpad;
+    const int col_l = lane & 15, rowq = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + wm * WM + i * 16 + rowq + r;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                dst[(size_t)co * g.Kpad + n0 + wn * WN + j * 16 + col_l] = acc[i][j][r];
+        }
+}
+
 // sum the split partials and scatter into the torch layout [Cout][Cin_real][ntaps] (fp32), optionally accumulating
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int Cout,
                                     int Kpad, int ntaps, int Cin, int log2Cin, int Cin_real, int accumulate)
@@ -450,11 +744,38 @@ static int fill_geom(ConvGeom& g, int B, int Di, int Hi, int Wi, int Cin, int Do
     return DREG_OK;
 }
 
+static int g_use_glds = 1;
+
 template <typename T, typename TO>
 static int launch_conv(const void* in, const void* wt, void* out, const float* bias, const void* addend,
                        const ConvGeom& g, int relu, int Da, int Ha, int Wa, int add_shift, hipStream_t st)
 {
     const int tilesM = (g.M + 127) / 128;
+    if constexpr (sizeof(T) == 2) {
+        const uint64_t in_bytes = (uint64_t)g.B * g.Di * g.Hi * g.Wi * g.Cin * 2, wt_bytes = (uint64_t)g.Cout * g.Kpad * 2;
+        if (g_use_glds && g.sd == 1 && g.Cin % 64 == 0 && g.ntaps <= 32 && in_bytes < 0x7fffff00ull && wt_bytes < 0x7fffff00ull) {
+            if (g.Cout % 256 == 0 && g_use_glds == 3 && tilesM >= 512) {
+                const int tilesN = g.Cout / 256;
+                static bool attr_set = false;
+                if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<TO, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 256) * 128); attr_set = true; }
+                hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, 256>), dim3(tilesM * tilesN), dim3(512), 2 * (128 + 256) * 128, st,
+                                   (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN,
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes);
+            } else if (g.Cout % 128 == 0) {
+                const int tilesN = g.Cout / 128;
+                hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, 128>), dim3(tilesM * tilesN), dim3(256), 2 * (128 + 128) * 128, st,
+                                   (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN,
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes);
+            } else if (g.Cout % 64 == 0) {
+                const int tilesN = g.Cout / 64;
+                hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, 64>), dim3(tilesM * tilesN), dim3(256), 2 * (128 + 64) * 128, st,
+                                   (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN,
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes);
+            } else return DREG_EINVAL;
+            DREG_LAUNCH_CHECK();
+            return DREG_OK;
+        }
+    }
     if (g.Cout % 128 == 0) {
         const int tilesN = g.Cout / 128;
         const size_t lds = 2 * (128 + 128) * 128;
@@ -495,6 +816,10 @@ int dreg_conv3d_igemm(const void* in, const void* wt_packed, void* out, const fl
     }
     return launch_conv<float, float>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st);
 }
+
+// 1 (default): bf16 stride-1 convolutions use the direct-to-LDS kernel (128 x {128|64} tiles); 3: also the 8-wave 128x256
+// tile when Cout % 256 == 0 (measured equal to 128x128 in round 1); 0: always the register-staged kernel (A/B checks).
+void dreg_conv_set_glds(int enable) { g_use_glds = enable; }
 
 // K padding of the packed weight row for (ntaps, Cin) at dtype.
 int dreg_conv3d_kpad(int ksz, int Cin, int dtype) {
@@ -563,7 +888,7 @@ int dreg_conv3d_wgrad(const void* gout, const void* in, float* dw, void* workspa
     hipStream_t st = (hipStream_t)stream;
     const int nsplit = dreg_conv3d_wgrad_splits(B, Do, Ho, Wo, Cin, Cout, ksz, dtype);
     uint32_t vps = (uint32_t)((g.M + nsplit - 1) / nsplit);
-    vps = ((vps + 31) / 32) * 32;
+    vps = ((vps + 63) / 64) * 64;
     const int bm = (Cout % 128 == 0) ? 128 : 64;
     const int tilesRow = Cout / bm;
     const int bnc = (g.Kpad % 128 == 0) ? 128 : 64;
@@ -577,6 +902,13 @@ int dreg_conv3d_wgrad(const void* gout, const void* in, float* dw, void* workspa
         else if (bm == 128 && bnc == 64) WG_LAUNCH(T, 128, 64, TRv); \
         else if (bm == 64 && bnc == 128) WG_LAUNCH(T, 64, 128, TRv); \
         else WG_LAUNCH(T, 64, 64, TRv); } while (0)
+    const uint64_t gbytes = (uint64_t)g.M * Cout * 2, ibytes = (uint64_t)B * Di * Hi * Wi * Cin * 2;
+    if (dtype == 0 && use_tr && g_use_glds && gbytes < 0x7fffff00ull && ibytes < 0x7fffff00ull) {
+#define WGG(BMv, BNv) hipLaunchKernelGGL((conv_wgrad_glds_kernel<BMv, BNv>), grid, dim3(256), (size_t)2 * 64 * (bm + bnc) * 2, st, (const bf16_t*)gout, (const bf16_t*)in, part, g, tilesCol, vps, (uint32_t)gbytes, (uint32_t)ibytes)
+        if (bm == 128 && bnc == 128) WGG(128, 128); else if (bm == 128 && bnc == 64) WGG(128, 64);
+        else if (bm == 64 && bnc == 128) WGG(64, 128); else WGG(64, 64);
+#undef WGG
+    } else
     if (dtype == 0) { if (use_tr) WG_DISPATCH(bf16_t, true); else WG_DISPATCH(bf16_t, false); }
     else WG_DISPATCH(float, false);
 #undef WG_DISPATCH

@@ -519,16 +519,18 @@ int dreg_downsample_sum(const void* g, void* out, int B, int Df, int Hf, int Wf,
     return DREG_OK;
 }
 
-size_t dreg_colsum_workspace_bytes(size_t M, int C) { const size_t nch = (M + 1023) / 1024; return nch * C * sizeof(float); }
+static inline int colsum_rows_per_chunk(size_t M) { return M >= 262144 ? 1024 : (M >= 16384 ? 256 : 32); }
+size_t dreg_colsum_workspace_bytes(size_t M, int C) { const size_t r = colsum_rows_per_chunk(M); return ((M + r - 1) / r) * C * sizeof(float); }
 int dreg_colsum(const void* g, float* out, float* workspace, size_t M, int C, int accumulate, int dtype, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
     const int G = dtype == 0 ? 8 : 4;
     if (C % G) return DREG_EINVAL;
-    const int nch = (int)((M + 1023) / 1024);
+    const int rpc = colsum_rows_per_chunk(M);
+    const int nch = (int)((M + rpc - 1) / rpc);
     const int CG = C / G, slabs = (CG + 255) / 256;
-    if (dtype == 0) hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3(nch, slabs), dim3(256), 0, st, (const bf16_t*)g, workspace, M, C, 1024);
-    else hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(nch, slabs), dim3(256), 0, st, (const float*)g, workspace, M, C, 1024);
+    if (dtype == 0) hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3(nch, slabs), dim3(256), 0, st, (const bf16_t*)g, workspace, M, C, rpc);
+    else hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(nch, slabs), dim3(256), 0, st, (const float*)g, workspace, M, C, rpc);
     DREG_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 127) / 128), dim3(128), 0, st, workspace, out, nch, C, accumulate);
     DREG_LAUNCH_CHECK();

@@ -32,6 +32,7 @@ SIGNATURES = {
     # conv.hip
     "dreg_conv3d_igemm": (I, [P, P, P, P, P] + [I] * 18 + [I, I, P]),
     "dreg_conv3d_kpad": (I, [I, I, I]),
+    "dreg_conv_set_glds": (None, [I]),
     "dreg_pack_conv_weight": (I, [P, P, I, I, I, I, I, I, P]),
     "dreg_conv3d_wgrad_splits": (I, [I] * 8),
     "dreg_conv3d_wgrad_workspace_bytes": (Z, [I] * 8),

@@ -51,6 +51,9 @@ int dreg_conv3d_igemm(const void* in, const void* wt_packed, void* out, const fl
                       int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
                       int dtype, int out_f32, void* stream);
 
+/* 1 (default): bf16 stride-1 convolutions stage operands with buffer_load...lds; 0: register-staged kernel (A/B checks) */
+void dreg_conv_set_glds(int enable);
+
 /* Weight gradient (split over voxels, deterministic two-stage reduction):
  * dw[Cout][Cin_real][ksz^3] (fp32, torch layout) (+)= sum_m gout[m,:]^T x in[gather(m, tap), :]. */
 int dreg_conv3d_wgrad_splits(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int dtype);
