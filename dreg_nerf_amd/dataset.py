@@ -1,0 +1,116 @@
+"""Registration dataset with the reference's on-disk layout and sample contract
+(conerf/datasets/register/dataset.py:94-134,221-331):
+
+  <root>/<dataset>/images/<scene>/world_frame_transforms.json      {block_id: 4x4}
+  <root>/<dataset>/nerf_models/<scene>/block_<k>/{model.pth, voxel_grid.pt, voxel_mask.pt}
+  <json_dir>/<dataset>.json + obj_id_names.json                     train/test scene lists
+
+A sample: 'src_xyz_rgba'/'tgt_xyz_rgba' fp32 [1,7,Z,X,Y], 'src_mask'/'tgt_mask' int64, 'pose' [1,4,4] = T_tgt T_src^-1,
+nerf paths.  Training-time augmentation (jitter sigma 0.005 on masked xyz, centred SE(3) perturbation std 0.1, random swap;
+dataset.py:277-331) is applied on the tensors' device.  `SyntheticRegDataset` generates shell-R scenes so the
+entry points run without the external Objaverse data."""
+import json
+import math
+import os
+import random
+from typing import List
+
+import torch
+
+from . import synth
+
+
+def _small_se3(std: float, gen=None) -> torch.Tensor:
+    """Random small rigid transform: rotation vector ~ N(0, std), translation ~ N(0, std) (dataset.py:24-33)."""
+    v = torch.randn(6, generator=gen) * std
+    w, t = v[:3], v[3:]
+    th = w.norm().clamp_min(1e-12)
+    k = w / th
+    K = torch.tensor([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = torch.eye(3) + torch.sin(th) * K + (1 - torch.cos(th)) * (K @ K)
+    T = torch.eye(4)
+    T[:3, :3], T[:3, 3] = R, t
+    return T
+
+
+def augment(data: dict, jitter: float = 0.005, std: float = 0.1) -> dict:
+    """dataset.py:277-331 on whatever device the tensors live on."""
+    for side in ("src", "tgt"):
+        g, m = data[side + "_xyz_rgba"], data[side + "_mask"]
+        flat = g[0, :3].permute(2, 3, 1, 0).reshape(-1, 3)
+        flat[m] = flat[m] + torch.randn(m.shape[0], 3, device=g.device) * jitter
+        g[0, :3] = flat.view(g.shape[3], g.shape[4], g.shape[2], 3).permute(3, 2, 0, 1)
+    perturb = _small_se3(std).to(data["pose"].device)
+    side = "src" if random.random() > 0.5 else "tgt"
+    g, m = data[side + "_xyz_rgba"], data[side + "_mask"]
+    flat = g[0, :3].permute(2, 3, 1, 0).reshape(-1, 3)
+    c = flat.mean(dim=0)  # the reference centres on the mean over ALL voxels (zeros included), dataset.py:305-306
+    Tc = torch.eye(4, device=g.device)
+    Tc[:3, 3] = -c
+    P = torch.linalg.inv(Tc) @ perturb @ Tc
+    flat[m] = flat[m] @ P[:3, :3].T + P[:3, 3]
+    g[0, :3] = flat.view(g.shape[3], g.shape[4], g.shape[2], 3).permute(3, 2, 0, 1)
+    if side == "src":
+        data["pose"] = data["pose"] @ torch.linalg.inv(P)
+    else:
+        data["pose"] = P @ data["pose"]
+    if random.random() > 0.5:
+        for a, b in (("src_xyz_rgba", "tgt_xyz_rgba"), ("src_mask", "tgt_mask"), ("src_nerf_path", "tgt_nerf_path")):
+            data[a], data[b] = data[b], data[a]
+        data["pose"] = torch.linalg.inv(data["pose"])
+    return data
+
+
+class NeRFRegDataset:
+    def __init__(self, root_fp: str, json_dir: str, dataset: str = "objaverse", split: str = "train", model_dir: str = "nerf_models"):
+        self.mode = split
+        self.meta = []
+        names = json.load(open(os.path.join(json_dir, f"{dataset}.json")))
+        scenes = names[split] if isinstance(names, dict) else names
+        for scene in scenes:
+            tf = os.path.join(root_fp, dataset, "images", scene, "world_frame_transforms.json")
+            if not os.path.exists(tf):
+                continue
+            transforms = {int(k): torch.tensor(v, dtype=torch.float32) for k, v in json.load(open(tf)).items()}
+            blocks = {}
+            for k in sorted(transforms):
+                d = os.path.join(root_fp, dataset, model_dir, scene, f"block_{k}")
+                if os.path.exists(os.path.join(d, "voxel_grid.pt")):
+                    blocks[k] = {"dir": d, "transform": transforms[k]}
+            if len(blocks) >= 2:
+                self.meta.append({"scene": scene, "dataset": dataset, "blocks": blocks})
+
+    def __len__(self):
+        return len(self.meta)
+
+    def __getitem__(self, index):
+        sm = self.meta[index]
+        ids = list(sm["blocks"].keys())
+        random.shuffle(ids)  # also in test mode, as the reference (quirk Q15)
+        s, t = sm["blocks"][ids[0]], sm["blocks"][ids[1]]
+        data = {
+            "src_xyz_rgba": torch.load(os.path.join(s["dir"], "voxel_grid.pt")).permute(3, 2, 0, 1).unsqueeze(0).contiguous(),
+            "tgt_xyz_rgba": torch.load(os.path.join(t["dir"], "voxel_grid.pt")).permute(3, 2, 0, 1).unsqueeze(0).contiguous(),
+            "src_mask": torch.load(os.path.join(s["dir"], "voxel_mask.pt")), "tgt_mask": torch.load(os.path.join(t["dir"], "voxel_mask.pt")),
+            "src_nerf_path": os.path.join(s["dir"], "model.pth"), "tgt_nerf_path": os.path.join(t["dir"], "model.pth"),
+            "pose": (t["transform"] @ torch.linalg.inv(s["transform"]))[None],
+            "scene": sm["scene"], "dataset": sm["dataset"], "index": index, "block_list": ids[:2],
+        }
+        return augment(data) if self.mode == "train" else data
+
+
+class SyntheticRegDataset:
+    """N shell-R scenes with a fixed, scene-dependent relative pose (stand-in for the external Objaverse data)."""
+
+    def __init__(self, n_scenes: int, res: int = 128, split: str = "train"):
+        self.n, self.res, self.mode = n_scenes, res, split
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, index):
+        g = torch.Generator().manual_seed(1000 + index)
+        pose = _small_se3(0.25, g)
+        data = synth.shell_pair(self.res, 2 * index + 1, 2 * index + 2, pose=pose)
+        data.update({"scene": f"shell_{index:04d}", "dataset": "synthetic", "index": index, "block_list": [0, 1]})
+        return augment(data) if self.mode == "train" else data

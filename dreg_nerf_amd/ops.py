@@ -47,10 +47,17 @@ PROFILER: Optional[KernelTimer] = None
 import weakref
 
 _pack_cache = {}
+_weight_generation = 0
 
 
 def clear_pack_cache():
     _pack_cache.clear()
+
+
+def bump_weight_generation():
+    """Called by optimizers that update parameters behind torch's version counters (FlatAdamW)."""
+    global _weight_generation
+    _weight_generation += 1
 
 
 def packed_weight(w: torch.Tensor, cin_pad: int, for_dgrad: bool, dt: int) -> torch.Tensor:
@@ -59,7 +66,7 @@ def packed_weight(w: torch.Tensor, cin_pad: int, for_dgrad: bool, dt: int) -> to
     base = w._base if w._base is not None else w
     key = (id(base), w.storage_offset(), tuple(w.shape), cin_pad, for_dgrad, dt)
     hit = _pack_cache.get(key)
-    if hit is not None and hit[0]() is base and hit[1] == base._version:
+    if hit is not None and hit[0]() is base and hit[1] == (base._version, _weight_generation):
         return hit[2]
     lib = L.load()
     cout, cin_real = w.shape[0], w.shape[1]
@@ -76,7 +83,7 @@ def packed_weight(w: torch.Tensor, cin_pad: int, for_dgrad: bool, dt: int) -> to
     if len(_pack_cache) > 4096:  # entries of dead parameters
         for k in [k for k, v in _pack_cache.items() if v[0]() is None]:
             del _pack_cache[k]
-    _pack_cache[key] = (weakref.ref(base), base._version, out)
+    _pack_cache[key] = (weakref.ref(base), (base._version, _weight_generation), out)
     return out
 
 

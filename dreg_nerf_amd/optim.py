@@ -1,0 +1,125 @@
+"""Flat-buffer AdamW + gradient clipping on the HIP kernels (dreg_grad_norm / dreg_adamw_step).
+
+Reference: torch.optim.AdamW(model.parameters(), lr, weight_decay=1e-4) preceded by clip_grad_norm_(0.1)
+(train_nerf_regtr.py:96-102,232-237).  All parameters live in one fp32 buffer (the nn.Parameters become views of
+it, so state_dict()/checkpoints are unchanged), gradients in a second one that autograd accumulates into in
+place; the data-parallel all-reduce runs directly on slices of the gradient buffer."""
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+from . import lib as L
+from . import ops
+
+
+class FlatAdamW:
+    def __init__(self, params: List[torch.nn.Parameter], lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-4, max_norm: float = 0.1):
+        self.params = [p for p in params]
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.n = n
+        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.offsets = []
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                self.flat_p[off:off + k].copy_(p.data.reshape(-1))
+                p.data = self.flat_p[off:off + k].view(p.shape)
+                p.grad = self.flat_g[off:off + k].view(p.shape)
+                self.offsets.append(off)
+                off += k
+        self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
+        self.step_count = 0
+        self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._ws = torch.zeros(1024, dtype=torch.float32, device=dev)
+        self.param_groups = [{"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}]
+        ops.bump_weight_generation()
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        for p, off in zip(self.params, self.offsets):  # autograd may have replaced .grad if it was unset
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + off * 4:
+                p.grad = self.flat_g[off:off + p.numel()].view(p.shape)
+
+    def all_reduce_mean(self, world: int, bucket_elems: int = (25 << 20) // 4):
+        """Average gradients over the ranks: async all-reduce of ~25 MB slices issued from the END of the buffer
+        (decoder/transformer/FPN-head gradients, which backward produces first, sit at the highest offsets)."""
+        handles = []
+        hi = self.n
+        while hi > 0:
+            lo = max(0, hi - bucket_elems)
+            handles.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            hi = lo
+        for h in handles:
+            h.wait()
+        self.flat_g.div_(world)
+
+    def step(self):
+        lib = L.load()
+        self.step_count += 1
+        lr = self.param_groups[0]["lr"]
+        if self.max_norm > 0:
+            L.check(lib.dreg_grad_norm(L.ptr(self.flat_g), L.ptr(self._norm), L.ptr(self._ws), self.n, L.stream()), "dreg_grad_norm")
+        L.check(lib.dreg_adamw_step(L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), L.ptr(self._norm),
+                                    self.n, lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
+                                    float(self.max_norm), L.stream()), "dreg_adamw_step")
+        ops.bump_weight_generation()  # the kernel wrote the parameters behind torch's version counters
+
+    def grad_norm(self) -> torch.Tensor:
+        return self._norm
+
+    # torch.optim.AdamW-compatible state (CheckPointManager stores optimizer.state_dict(): checkpoint_manager.py:58-80)
+    def state_dict(self):
+        state = {}
+        for i, (p, off) in enumerate(zip(self.params, self.offsets)):
+            k = p.numel()
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.exp_avg[off:off + k].view(p.shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + k].view(p.shape).clone()}
+        g = dict(self.param_groups[0])
+        g.update({"amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                  "fused": None, "params": list(range(len(self.params)))})
+        return {"state": state if self.step_count > 0 else {}, "param_groups": [g]}
+
+    def load_state_dict(self, sd):
+        st = sd.get("state", {})
+        with torch.no_grad():
+            for i, (p, off) in enumerate(zip(self.params, self.offsets)):
+                if i in st:
+                    k = p.numel()
+                    self.exp_avg[off:off + k].copy_(st[i]["exp_avg"].reshape(-1))
+                    self.exp_avg_sq[off:off + k].copy_(st[i]["exp_avg_sq"].reshape(-1))
+                    self.step_count = int(float(st[i]["step"]))
+        if sd.get("param_groups"):
+            self.param_groups[0]["lr"] = sd["param_groups"][0].get("lr", self.lr)
+
+
+class StepLR:
+    """torch.optim.lr_scheduler.StepLR(step_size, gamma) on FlatAdamW (train_nerf_regtr.py:100-102)."""
+
+    def __init__(self, optimizer: FlatAdamW, step_size: int, gamma: float):
+        self.opt, self.step_size, self.gamma = optimizer, step_size, gamma
+        self.base_lr = optimizer.param_groups[0]["lr"]
+        self.last_epoch = 0
+
+    def step(self):
+        self.last_epoch += 1
+        self.opt.param_groups[0]["lr"] = self.base_lr * self.gamma ** (self.last_epoch // self.step_size)
+
+    def get_last_lr(self):
+        return [self.opt.param_groups[0]["lr"]]
+
+    def state_dict(self):
+        return {"step_size": self.step_size, "gamma": self.gamma, "base_lrs": [self.base_lr], "last_epoch": self.last_epoch,
+                "_step_count": self.last_epoch + 1, "_last_lr": self.get_last_lr()}
+
+    def load_state_dict(self, sd):
+        self.last_epoch = sd.get("last_epoch", 0)
+        self.base_lr = sd.get("base_lrs", [self.base_lr])[0]
+        self.opt.param_groups[0]["lr"] = self.base_lr * self.gamma ** (self.last_epoch // self.step_size)

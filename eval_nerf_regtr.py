@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Evaluate NeRF registration on MI355X — drop-in for the metric part of the reference's eval_nerf_regtr.py
+(:224-301): per-scene RRE/RTE + forward time (with a device sync, unlike the reference — quirk Q13) written to
+<root>/eval/<expname>/<dataset>/metrics_<split>.json with the reference's schema.  Scenes are sharded over ranks
+when launched with torch.distributed.run (replicas only, results gathered on rank 0)."""
+import json
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from dreg_nerf_amd import losses as LS
+from dreg_nerf_amd.checkpoint import CheckPointManager
+from dreg_nerf_amd.config import config_parser
+from dreg_nerf_amd.dataset import NeRFRegDataset, SyntheticRegDataset
+from dreg_nerf_amd.regtr import NeRFRegTr
+
+
+def main():
+    cfg = config_parser()
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", cfg.local_rank))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    split = "test"
+    ds = SyntheticRegDataset(cfg.synthetic, cfg.synthetic_res, split) if cfg.synthetic > 0 else \
+        NeRFRegDataset(cfg.root_dir, cfg.json_dir, cfg.dataset, split)
+    model = NeRFRegTr(cfg.position_embedding_type, cfg.position_embedding_dim, cfg.position_embedding_scaling,
+                      cfg.num_downsample, precision=cfg.precision).to(dev).eval()
+    ckpt_path = cfg.ckpt_path or os.path.join(cfg.root_dir, "out", cfg.expname, "model.pth")
+    CheckPointManager(verbose=rank == 0).load(ckpt_path, models={"model": model}, map_location=dev)
+    rows = {}
+    with torch.no_grad():
+        for i in range(rank, len(ds), world):
+            data = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in ds[i].items()}
+            torch.cuda.synchronize()
+            t0 = time.time()
+            pred = model(data)
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            err = LS.evaluate_camera_alignment(pred["pose"][-1], data["pose"])
+            rows[data["scene"]] = {"R_mean": float(err["R_error_mean"]), "t_mean": float(err["t_error_mean"]),
+                                   "R_med": float(err["R_error_med"]), "t_med": float(err["t_error_med"]), "time": dt}
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rows)
+        rows = {k: v for g in gathered for k, v in g.items()}
+    if rank == 0:
+        out = dict(rows)
+        out["R_mean"] = sum(r["R_mean"] for r in rows.values()) / max(len(rows), 1)
+        out["t_mean"] = sum(r["t_mean"] for r in rows.values()) / max(len(rows), 1)
+        d = os.path.join(cfg.root_dir, "eval", cfg.expname, cfg.dataset or "synthetic")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, f"metrics_{split}.json"), "w") as f:
+            json.dump(out, f, indent=2)
+        print(f"{len(rows)} scenes: R_mean={out['R_mean']:.3f} deg, t_mean={out['t_mean']:.4f} -> {d}/metrics_{split}.json", flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

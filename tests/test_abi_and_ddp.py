@@ -1,5 +1,5 @@
 """CPU: the C-ABI library loads and exports every symbol include/*.h declares (no compute calls);
-the data-parallel gradient path (GradBuckets) with gloo, world_size 2."""
+the data-parallel gradient path (FlatAdamW.all_reduce_mean) with gloo, world_size 2."""
 import ctypes
 import os
 import re
@@ -48,14 +48,15 @@ def _ddp_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from dreg_nerf_amd.train_step import GradBuckets
+    from dreg_nerf_amd.optim import FlatAdamW
     torch.manual_seed(0)
     ps = [torch.nn.Parameter(torch.zeros(n)) for n in (7, 300, 5, 1000)]
+    opt = FlatAdamW(ps)
+    opt.zero_grad()
     for i, p in enumerate(ps):
-        if not (rank == 1 and i == 2):  # one rank leaves a gradient unset: treated as zero
-            p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
-    gb = GradBuckets(ps, bucket_bytes=1024)
-    gb.all_reduce_mean(world)
+        if not (rank == 1 and i == 2):  # one rank contributes no gradient for a parameter: it stays zero there
+            p.grad.add_(float(rank + 1) * (i + 1))
+    opt.all_reduce_mean(world, bucket_elems=256)
     q.put((rank, [p.grad.tolist() for p in ps]))
     dist.barrier()
     dist.destroy_process_group()

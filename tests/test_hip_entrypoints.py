@@ -1,0 +1,51 @@
+"""GPU: the drop-in entry points run end to end on synthetic data: train (2 steps) -> checkpoint in the reference
+format -> eval metrics JSON with the reference schema; NeRF block checkpoint -> voxel_grid.pt / voxel_mask.pt."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, timeout=600):
+    r = subprocess.run([sys.executable] + args, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_train_then_eval_synthetic(tmp_path):
+    root = str(tmp_path)
+    _run(["train_nerf_regtr.py", "--synthetic", "2", "--synthetic_res", "64", "--epochs", "1", "--root_dir", root,
+          "--expname", "t", "--n_tensorboard", "1", "--n_checkpoint", "1000"])
+    ck = torch.load(os.path.join(root, "out", "t", "model.pth"), map_location="cpu", weights_only=False)
+    assert set(["step", "model", "feature_loss", "optimizer", "scheduler"]) <= set(ck.keys())
+    assert len(ck["model"]) == 772 and ck["feature_loss"]["W"].shape == (256, 256)
+    assert os.path.exists(os.path.join(root, "out", "t", "model_best.pth")) and os.path.exists(os.path.join(root, "out", "t", "checkpoints.txt"))
+    out = _run(["eval_nerf_regtr.py", "--synthetic", "2", "--synthetic_res", "64", "--root_dir", root, "--expname", "t"])
+    m = json.load(open(os.path.join(root, "eval", "t", "synthetic", "metrics_test.json")))
+    assert "R_mean" in m and "t_mean" in m and "shell_0000" in m and set(m["shell_0000"]) == {"R_mean", "t_mean", "R_med", "t_med", "time"}
+
+
+def test_grid_extraction_from_block_checkpoint(tmp_path):
+    from dreg_nerf_amd import ngp
+    res = 32
+    d = tmp_path / "objaverse" / "nerf_models" / "sceneA" / "block_0"
+    d.mkdir(parents=True)
+    f = ngp.NGPradianceField([-1.5] * 3 + [1.5] * 3)
+    with torch.no_grad():
+        f.mlp_base.params[3072:].normal_(0, 1.0, generator=torch.Generator().manual_seed(0))
+    binary = torch.rand(res, res, res, generator=torch.Generator().manual_seed(1)) < 0.05
+    torch.save({"step": 1, "model": f.state_dict(), "occupancy_grid": {"_binary": binary, "resolution": torch.tensor([res] * 3)},
+                "aabb": [-1.5] * 3 + [1.5] * 3, "unbounded": False, "grid_resolution": res,
+                "contraction_type": ngp.ContractionType.AABB, "render_step_size": 0.005, "alpha_thre": 0.0, "cone_angle": 0.0,
+                "camera_poses": torch.eye(4)[None], "block_id": 0}, str(d / "model.pth"))
+    _run(["eval_ngp_nerf.py", "--root_dir", str(tmp_path), "--dataset", "objaverse", "--multi_blocks"])
+    grid = torch.load(str(d / "voxel_grid.pt"))
+    mask = torch.load(str(d / "voxel_mask.pt"))
+    assert grid.shape == (res, res, res, 7) and mask.dtype == torch.int64 and mask.numel() > 0
+    assert torch.all(binary.flatten()[mask])

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Train the NeRF registration network on MI355X — drop-in for the reference's train_nerf_regtr.py
+(flags: conerf/utils/config.py; loop: train_nerf_regtr.py:124-169; step: dreg_nerf_amd/train_step.py).
+
+Single GPU:  python train_nerf_regtr.py --root_dir <root> --json_dir <json> --dataset objaverse --expname regtr
+8 GPUs:      python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_nerf_regtr.py ... (plain DDP over RCCL)
+No data:     python train_nerf_regtr.py --synthetic 16 --synthetic_res 128 --epochs 1 --root_dir /tmp/dreg
+"""
+import os
+import random
+
+import torch
+import torch.distributed as dist
+
+from dreg_nerf_amd import losses as LS
+from dreg_nerf_amd.checkpoint import CheckPointManager
+from dreg_nerf_amd.config import config_parser
+from dreg_nerf_amd.dataset import NeRFRegDataset, SyntheticRegDataset
+from dreg_nerf_amd.regtr import NeRFRegTr
+from dreg_nerf_amd.train_step import TrainStep
+
+
+def to_device(d, dev):
+    return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+@torch.no_grad()
+def validate(model, dataset, dev, frac=0.2):
+    """train_nerf_regtr.py:258-291: RRE/RTE on the first 20 % of the validation scenes; score = n / sum(R_mean)."""
+    model.eval()
+    n = max(1, int(len(dataset) * frac))
+    r_sum = t_sum = 0.0
+    for i in range(n):
+        data = to_device(dataset[i], dev)
+        pred = model(data)
+        err = LS.evaluate_camera_alignment(pred["pose"][-1], data["pose"])
+        r_sum += float(err["R_error_mean"])
+        t_sum += float(err["t_error_mean"])
+    model.train()
+    return n / max(r_sum, 1e-9), r_sum / n, t_sum / n
+
+
+def main():
+    cfg = config_parser()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", cfg.local_rank))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    random.seed(cfg.seed + rank)
+    torch.manual_seed(cfg.seed)
+
+    if cfg.synthetic > 0:
+        train_ds, val_ds = SyntheticRegDataset(cfg.synthetic, cfg.synthetic_res, "train"), SyntheticRegDataset(max(2, cfg.synthetic // 4), cfg.synthetic_res, "test")
+    else:
+        train_ds = NeRFRegDataset(cfg.root_dir, cfg.json_dir, cfg.dataset, "train")
+        val_ds = NeRFRegDataset(cfg.root_dir, cfg.json_dir, cfg.dataset, "test")
+    model = NeRFRegTr(cfg.position_embedding_type, cfg.position_embedding_dim, cfg.position_embedding_scaling,
+                      cfg.num_downsample, precision=cfg.precision).to(dev).train()
+    if world > 1:
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+    ts = TrainStep(model, lr=cfg.lr, robust_loss=cfg.robust_loss, finetune=cfg.finetune)
+    save_dir = os.path.join(cfg.root_dir, "out", cfg.expname)
+    ckpt = CheckPointManager(save_dir if rank == 0 else None, verbose=rank == 0)
+    if rank == 0:
+        os.makedirs(save_dir, exist_ok=True)
+    models = {"model": model, "feature_loss": ts.feature_loss}
+    start = CheckPointManager(save_dir, verbose=rank == 0).load(
+        cfg.ckpt_path or None, models=models,
+        optimizers=None if cfg.no_load_opt else {"optimizer": ts.optimizer},
+        schedulers=None if cfg.no_load_scheduler else {"scheduler": ts.scheduler}, map_location=dev)
+    iteration = 0 if cfg.finetune else start
+    per_step = cfg.pairs_per_step
+    log = open(os.path.join(save_dir, "log.txt"), "a") if rank == 0 else None
+    score = 0.0
+    for epoch in range(cfg.epochs):
+        ids = list(range(len(train_ds)))
+        random.Random(cfg.seed + epoch).shuffle(ids)
+        ids = ids[rank::world]
+        for b in range(0, len(ids) - per_step + 1, per_step):
+            batch = [to_device(train_ds[i], dev) for i in ids[b:b + per_step]]
+            out = ts.step(batch)
+            iteration += 1
+            if rank == 0 and iteration % cfg.n_tensorboard == 0:
+                pred, data = ts.last_preds[0], batch[0]
+                err = LS.evaluate_camera_alignment(pred["pose"][-1].detach(), data["pose"])
+                msg = f"it {iteration} " + " ".join(f"{k}={float(v):.4f}" for k, v in out["losses"].items()) + \
+                      f" R={float(err['R_error_mean']):.3f}deg t={float(err['t_error_mean']):.4f} lr={ts.scheduler.get_last_lr()[0]:.2e}"
+                print(msg, flush=True)
+                log.write(msg + "\n"); log.flush()
+            if iteration % cfg.n_validation == 0 and rank == 0:
+                score, r, t = validate(model, val_ds, dev)
+                print(f"val it {iteration}: R_mean={r:.3f} t_mean={t:.4f}", flush=True)
+            if iteration % cfg.n_checkpoint == 0 and rank == 0:
+                ckpt.save(iteration, models=models, optimizers={"optimizer": ts.optimizer}, schedulers={"scheduler": ts.scheduler}, score=score)
+    if rank == 0:
+        score, r, t = validate(model, val_ds, dev)
+        print(f"final val: R_mean={r:.3f} t_mean={t:.4f}", flush=True)
+        ckpt.save(iteration, models=models, optimizers={"optimizer": ts.optimizer}, schedulers={"scheduler": ts.scheduler}, score=score)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
