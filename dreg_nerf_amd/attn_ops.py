@@ -114,6 +114,101 @@ def mha_packed(q_rows, kv_rows, n_heads: int, scale: float):
     return _MHAFn.apply(q_rows, kv_rows, 0, e, 2 * e, n_heads, scale)
 
 
+class ProblemTable:
+    """Row ranges of the attention problems of one step: every pair i contributes a source segment and a target
+    segment of the shared row space.  self: q = kv = segment; cross: q = one segment, kv = the pair's other one."""
+
+    def __init__(self, seg_lengths, device):
+        """seg_lengths: [(ns_0, nt_0), (ns_1, nt_1), ...] in row order."""
+        starts, off = [], 0
+        for ns, nt in seg_lengths:
+            starts.append((off, ns, off + ns, nt))
+            off += ns + nt
+        self.R = off
+        self.segs = starts
+        self_p, cross_p = [], []
+        for (s0, ns, t0, nt) in starts:
+            self_p += [[s0, ns, s0, ns], [t0, nt, t0, nt]]
+            cross_p += [[s0, ns, t0, nt], [t0, nt, s0, ns]]
+        self.self_probs = torch.tensor(self_p, dtype=torch.int32, device=device)
+        self.cross_probs = torch.tensor(cross_p, dtype=torch.int32, device=device)
+        self.max_len = max(max(ns, nt) for ns, nt in seg_lengths)
+        self.nprob = len(self_p)
+
+
+class _MHAVarlenFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, probs, nprob, max_len, n_heads, scale):
+        lib = L.load()
+        R, e3 = qkv.shape
+        e = e3 // 3
+        es = qkv.element_size()
+        o = torch.empty(R, e, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty(n_heads, R, dtype=torch.float32, device=qkv.device)
+        L.check(lib.dreg_mha_varlen_fwd(qkv.data_ptr(), qkv.data_ptr() + e * es, qkv.data_ptr() + 2 * e * es, L.ptr(o), L.ptr(lse),
+                                        L.ptr(probs), nprob, max_len, max_len, R, n_heads, e3, e3, e3, e, scale, L.dt_of(qkv), L.stream()),
+                "dreg_mha_varlen_fwd")
+        ctx.save_for_backward(qkv, o, lse, probs)
+        ctx.cfg = (nprob, max_len, n_heads, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        qkv, o, lse, probs = ctx.saved_tensors
+        nprob, max_len, n_heads, scale = ctx.cfg
+        lib = L.load()
+        go = go.contiguous()
+        R, e3 = qkv.shape
+        e = e3 // 3
+        es = qkv.element_size()
+        dqkv = torch.empty_like(qkv)  # every row is a query of one problem and a key/value of one problem
+        dvec = torch.empty(n_heads, R, dtype=torch.float32, device=qkv.device)
+        L.check(lib.dreg_mha_varlen_bwd(qkv.data_ptr(), qkv.data_ptr() + e * es, qkv.data_ptr() + 2 * e * es, L.ptr(o), L.ptr(go),
+                                        L.ptr(lse), L.ptr(dvec), dqkv.data_ptr(), dqkv.data_ptr() + e * es, dqkv.data_ptr() + 2 * e * es,
+                                        L.ptr(probs), nprob, max_len, max_len, R, n_heads, e3, e3, e3, e, scale, L.dt_of(qkv), L.stream()),
+                "dreg_mha_varlen_bwd")
+        return dqkv, None, None, None, None, None
+
+
+def mha_varlen(qkv, probs, nprob, max_len, n_heads: int, scale: float):
+    """qkv [R, 3E] packed projections of all point sets; probs int32 [nprob,4] (ProblemTable) -> [R, E]."""
+    return _MHAVarlenFn.apply(qkv, probs, nprob, max_len, n_heads, scale)
+
+
+class _CorrAttnVarlenFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, xyz, probs, nprob, max_len, scale):
+        lib = L.load()
+        nl, R = q.shape[0], q.shape[1]
+        q, k, xyz = q.contiguous(), k.contiguous(), xyz.contiguous()
+        out = torch.empty(nl, R, 3, dtype=torch.float32, device=q.device)
+        lse = torch.empty(nl, R, dtype=torch.float32, device=q.device)
+        L.check(lib.dreg_corr_attention_varlen_fwd(L.ptr(q), L.ptr(k), L.ptr(xyz), L.ptr(out), L.ptr(lse), L.ptr(probs), nprob,
+                                                   max_len, max_len, nl, R, scale, L.dt_of(q), L.stream()), "dreg_corr_attention_varlen_fwd")
+        ctx.save_for_backward(q, k, xyz, out, lse, probs)
+        ctx.cfg = (nprob, max_len, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, xyz, out, lse, probs = ctx.saved_tensors
+        nprob, max_len, scale = ctx.cfg
+        lib = L.load()
+        nl, R = q.shape[0], q.shape[1]
+        go = go.contiguous().float()
+        dq, dk = torch.empty_like(q), torch.empty_like(k)
+        dvec = torch.empty(nl, R, dtype=torch.float32, device=q.device)
+        L.check(lib.dreg_corr_attention_varlen_bwd(L.ptr(q), L.ptr(k), L.ptr(xyz), L.ptr(out), L.ptr(go), L.ptr(lse), L.ptr(dvec),
+                                                   L.ptr(dq), L.ptr(dk), L.ptr(probs), nprob, max_len, max_len, nl, R, scale,
+                                                   L.dt_of(q), L.stream()), "dreg_corr_attention_varlen_bwd")
+        return dq, dk, None, None, None, None, None
+
+
+def attention_xyz_varlen(q, k, xyz, probs, nprob, max_len, scale: float):
+    """q, k [L,R,256] (compute dtype), xyz fp32 [R,3]; problem p: softmax(scale q[rows_q] k[rows_kv]^T) xyz[rows_kv] -> fp32 [L,R,3]."""
+    return _CorrAttnVarlenFn.apply(q, k, xyz, probs, nprob, max_len, scale)
+
+
 # --------------------------------------------------------------------------- correspondence attention (V = xyz)
 class _CorrAttnFn(torch.autograd.Function):
     @staticmethod

@@ -88,7 +88,17 @@ struct AttnArgs {
     const void* dout;          // T [Nq,...] (ldo/ho) or fp32 [H,Nq,3]
     float* dvec;               // [H, Nq]   rowsum(dO * O)
     void *dq, *dk, *dv;        // outputs, operand type T, same strides as q/k/v
+    // variable-length batching: blockIdx.z selects a problem {q_start, q_len, kv_start, kv_len} (rows of the shared tensors)
+    const int4* probs;
+    int Rq;                    // total query rows (row stride of lse / dvec / xyz-outputs per head)
 };
+
+struct Prob { int Nq, Nk; long q0, k0; };
+__device__ __forceinline__ Prob get_prob(const AttnArgs& a) {
+    Prob p; p.Nq = a.Nq; p.Nk = a.Nk; p.q0 = 0; p.k0 = 0;
+    if (a.probs) { const int4 t = a.probs[blockIdx.z]; p.q0 = t.x; p.Nq = t.y; p.k0 = t.z; p.Nk = t.w; }
+    return p;
+}
 
 template <typename T, int D>
 __device__ __forceinline__ void load_tile(char* dst, int rs, const T* src, long ld, int row0, int nrows_valid, int tid) {
@@ -113,15 +123,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a)
     char* sP = sV + 64 * VRS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.y;
+    const Prob pb = get_prob(a);
+    if (blockIdx.x * 64 >= pb.Nq) return;
     const int q0 = blockIdx.x * 64 + wave * 16;
-    const T* Q = (const T*)a.q + h * a.hq;
-    const T* K = (const T*)a.k + h * a.hk;
+    const T* Q = (const T*)a.q + h * a.hq + pb.q0 * a.ldq;
+    const T* K = (const T*)a.k + h * a.hk + pb.k0 * a.ldk;
     const int fr = lane & 15, kg = lane >> 4;
     char* myP = sP + wave * 16 * PRS;
 
     Frag<T> qf[D / 32];
 #pragma unroll
-    for (int kk = 0; kk < D / 32; ++kk) qf[kk] = frag_glob(Q + (long)(q0 + fr) * a.ldq + kk * 32 + kg * 8, q0 + fr < a.Nq);
+    for (int kk = 0; kk < D / 32; ++kk) qf[kk] = frag_glob(Q + (long)(q0 + fr) * a.ldq + kk * 32 + kg * 8, q0 + fr < pb.Nq);
 
     float m[4], l[4];
     f32x4_t o[2];
@@ -130,18 +142,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a)
     for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; o3[r][0] = o3[r][1] = o3[r][2] = 0.f; }
     o[0] = o[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < a.Nk; k0 += 64) {
+    for (int k0 = 0; k0 < pb.Nk; k0 += 64) {
         __syncthreads();
-        load_tile<T, D>(sK, KRS, K, a.ldk, k0, a.Nk, tid);
+        load_tile<T, D>(sK, KRS, K, a.ldk, k0, pb.Nk, tid);
         if constexpr (XYZ) {
             if (tid < 64) {
-                const float* x = (const float*)a.v;
+                const float* x = (const float*)a.v + pb.k0 * 3;
                 float4 val = make_float4(0, 0, 0, 0);
-                if (k0 + tid < a.Nk) val = make_float4(x[(long)(k0 + tid) * 3], x[(long)(k0 + tid) * 3 + 1], x[(long)(k0 + tid) * 3 + 2], 0.f);
+                if (k0 + tid < pb.Nk) val = make_float4(x[(long)(k0 + tid) * 3], x[(long)(k0 + tid) * 3 + 1], x[(long)(k0 + tid) * 3 + 2], 0.f);
                 *reinterpret_cast<float4*>(sV + tid * 16) = val;
             }
         } else {
-            load_tile<T, DV>(sV, VRS, (const T*)a.v + h * a.hv, a.ldv, k0, a.Nk, tid);
+            load_tile<T, DV>(sV, VRS, (const T*)a.v + h * a.hv + pb.k0 * a.ldv, a.ldv, k0, pb.Nk, tid);
         }
         __syncthreads();
         f32x4_t s[4];
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a)
             float mx = -INFINITY;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                s[t][r] = (k0 + t * 16 + fr < a.Nk) ? s[t][r] * a.scale : -INFINITY;
+                s[t][r] = (k0 + t * 16 + fr < pb.Nk) ? s[t][r] * a.scale : -INFINITY;
                 mx = fmaxf(mx, s[t][r]);
             }
             mx = group16_max(mx);
@@ -203,16 +215,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a)
         const float inv = 1.f / l[r];
         if constexpr (XYZ) {
             float x = group16_sum(o3[r][0]), y = group16_sum(o3[r][1]), z = group16_sum(o3[r][2]);
-            if (fr == 0 && qr < a.Nq) {
-                float* op = (float*)a.o + ((long)h * a.Nq + qr) * 3;
+            if (fr == 0 && qr < pb.Nq) {
+                float* op = (float*)a.o + ((long)h * a.Rq + pb.q0 + qr) * 3;
                 op[0] = x * inv; op[1] = y * inv; op[2] = z * inv;
             }
-        } else if (qr < a.Nq) {
-            T* op = (T*)a.o + h * a.ho + (long)qr * a.ldo;
+        } else if (qr < pb.Nq) {
+            T* op = (T*)a.o + h * a.ho + (pb.q0 + qr) * a.ldo;
             Elem<T>::st(op + fr, o[0][r] * inv);
             Elem<T>::st(op + 16 + fr, o[1][r] * inv);
         }
-        if (fr == 0 && qr < a.Nq) a.lse[(long)h * a.Nq + qr] = m[r] + __logf(l[r]);
+        if (fr == 0 && qr < pb.Nq) a.lse[(long)h * a.Rq + pb.q0 + qr] = m[r] + __logf(l[r]);
     }
 }
 
@@ -228,24 +240,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a)
     char* sP = sV + 64 * VRS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.y;
+    const Prob pb = get_prob(a);
+    if (blockIdx.x * 64 >= pb.Nq) return;
     const int q0 = blockIdx.x * 64 + wave * 16;
-    const T* Q = (const T*)a.q + h * a.hq;
-    const T* K = (const T*)a.k + h * a.hk;
+    const T* Q = (const T*)a.q + h * a.hq + pb.q0 * a.ldq;
+    const T* K = (const T*)a.k + h * a.hk + pb.k0 * a.ldk;
     const int fr = lane & 15, kg = lane >> 4;
     char* myP = sP + wave * 16 * PRS;
 
     Frag<T> qf[D / 32];
 #pragma unroll
-    for (int kk = 0; kk < D / 32; ++kk) qf[kk] = frag_glob(Q + (long)(q0 + fr) * a.ldq + kk * 32 + kg * 8, q0 + fr < a.Nq);
+    for (int kk = 0; kk < D / 32; ++kk) qf[kk] = frag_glob(Q + (long)(q0 + fr) * a.ldq + kk * 32 + kg * 8, q0 + fr < pb.Nq);
     // per-row quantities in the C layout rows (kg*4 + r)
     float lse[4], dv_[4], do3[4][3];
     Frag<T> dof;  // dO as A operand (rows q = fr)
     if constexpr (!XYZ) {
-        const T* dO = (const T*)a.dout + h * a.ho;
-        const T* O = (const T*)a.o + h * a.ho;
-        dof = frag_glob(dO + (long)(q0 + fr) * a.ldo + kg * 8, q0 + fr < a.Nq);
+        const T* dO = (const T*)a.dout + h * a.ho + pb.q0 * a.ldo;
+        const T* O = (const T*)a.o + h * a.ho + pb.q0 * a.ldo;
+        dof = frag_glob(dO + (long)(q0 + fr) * a.ldo + kg * 8, q0 + fr < pb.Nq);
         // D[q] = sum_dv dO*O : each lane sums its 8 columns of row fr, then the 4 lane groups are combined
-        Frag<T> of = frag_glob(O + (long)(q0 + fr) * a.ldo + kg * 8, q0 + fr < a.Nq);
+        Frag<T> of = frag_glob(O + (long)(q0 + fr) * a.ldo + kg * 8, q0 + fr < pb.Nq);
         float part = 0.f;
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -258,38 +272,38 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a)
         part += __shfl_xor(part, 32, 64);   // every lane with the same fr now holds D[row fr]
 #pragma unroll
         for (int r = 0; r < 4; ++r) dv_[r] = __shfl(part, kg * 4 + r, 64);
-        if (kg == 0 && q0 + fr < a.Nq) a.dvec[(long)h * a.Nq + q0 + fr] = part;
+        if (kg == 0 && q0 + fr < pb.Nq) a.dvec[(long)h * a.Rq + pb.q0 + q0 + fr] = part;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int qr = q0 + kg * 4 + r;
-        lse[r] = qr < a.Nq ? a.lse[(long)h * a.Nq + qr] : 0.f;
+        lse[r] = qr < pb.Nq ? a.lse[(long)h * a.Rq + pb.q0 + qr] : 0.f;
         if constexpr (XYZ) {
-            const float* dO = (const float*)a.dout + ((long)h * a.Nq + qr) * 3;
-            const float* O = (const float*)a.o + ((long)h * a.Nq + qr) * 3;
+            const float* dO = (const float*)a.dout + ((long)h * a.Rq + pb.q0 + qr) * 3;
+            const float* O = (const float*)a.o + ((long)h * a.Rq + pb.q0 + qr) * 3;
             float d = 0.f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { do3[r][c] = qr < a.Nq ? dO[c] : 0.f; d += do3[r][c] * (qr < a.Nq ? O[c] : 0.f); }
+            for (int c = 0; c < 3; ++c) { do3[r][c] = qr < pb.Nq ? dO[c] : 0.f; d += do3[r][c] * (qr < pb.Nq ? O[c] : 0.f); }
             dv_[r] = d;
-            if (fr == 0 && qr < a.Nq) a.dvec[(long)h * a.Nq + qr] = d;
+            if (fr == 0 && qr < pb.Nq) a.dvec[(long)h * a.Rq + pb.q0 + qr] = d;
         }
     }
     f32x4_t dq[D / 16];
 #pragma unroll
     for (int u = 0; u < D / 16; ++u) dq[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < a.Nk; k0 += 64) {
+    for (int k0 = 0; k0 < pb.Nk; k0 += 64) {
         __syncthreads();
-        load_tile<T, D>(sK, KRS, K, a.ldk, k0, a.Nk, tid);
+        load_tile<T, D>(sK, KRS, K, a.ldk, k0, pb.Nk, tid);
         if constexpr (XYZ) {
             if (tid < 64) {
-                const float* x = (const float*)a.v;
+                const float* x = (const float*)a.v + pb.k0 * 3;
                 float4 val = make_float4(0, 0, 0, 0);
-                if (k0 + tid < a.Nk) val = make_float4(x[(long)(k0 + tid) * 3], x[(long)(k0 + tid) * 3 + 1], x[(long)(k0 + tid) * 3 + 2], 0.f);
+                if (k0 + tid < pb.Nk) val = make_float4(x[(long)(k0 + tid) * 3], x[(long)(k0 + tid) * 3 + 1], x[(long)(k0 + tid) * 3 + 2], 0.f);
                 *reinterpret_cast<float4*>(sV + tid * 16) = val;
             }
         } else {
-            load_tile<T, DV>(sV, VRS, (const T*)a.v + h * a.hv, a.ldv, k0, a.Nk, tid);
+            load_tile<T, DV>(sV, VRS, (const T*)a.v + h * a.hv + pb.k0 * a.ldv, a.ldv, k0, pb.Nk, tid);
         }
         __syncthreads();
 #pragma unroll
@@ -299,7 +313,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a)
             for (int kk = 0; kk < D / 32; ++kk) s = mma(qf[kk], frag_row(sK, KRS, t * 16 + fr, kk * 32 + kg * 8, T()), s);
             f32x4_t dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             if constexpr (!XYZ) dp = mma(dof, frag_row(sV, VRS, t * 16 + fr, kg * 8, T()), dp);
-            const bool kv = k0 + t * 16 + fr < a.Nk;
+            const bool kv = k0 + t * 16 + fr < pb.Nk;
             float4 x = make_float4(0, 0, 0, 0);
             if constexpr (XYZ) x = *reinterpret_cast<const float4*>(sV + (t * 16 + fr) * 16);
 #pragma unroll
@@ -318,11 +332,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a)
             for (int u = 0; u < D / 16; ++u) dq[u] = mma(df, frag_col(sK, KRS, ks * 32, u * 16, lane, T()), dq[u]);
         }
     }
-    T* dQ = (T*)a.dq + h * a.hq;
+    T* dQ = (T*)a.dq + h * a.hq + pb.q0 * a.ldq;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int qr = q0 + kg * 4 + r;
-        if (qr < a.Nq)
+        if (qr < pb.Nq)
 #pragma unroll
             for (int u = 0; u < D / 16; ++u) Elem<T>::st(dQ + (long)qr * a.ldq + u * 16 + fr, dq[u][r]);
     }
@@ -341,25 +355,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a)
     float* sL = reinterpret_cast<float*>(sP + 4 * 2 * 16 * PRS);  // lse[64], dvec[64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.y;
+    const Prob pb = get_prob(a);
+    if (blockIdx.x * 64 >= pb.Nk) return;
     const int key0 = blockIdx.x * 64 + wave * 16;
-    const T* Q = (const T*)a.q + h * a.hq;
-    const T* K = (const T*)a.k + h * a.hk;
+    const T* Q = (const T*)a.q + h * a.hq + pb.q0 * a.ldq;
+    const T* K = (const T*)a.k + h * a.hk + pb.k0 * a.ldk;
     const int fr = lane & 15, kg = lane >> 4;
     char* myP = sP + wave * 2 * 16 * PRS;
     char* myS = myP + 16 * PRS;
 
     Frag<T> kf[D / 32], vf;
 #pragma unroll
-    for (int kk = 0; kk < D / 32; ++kk) kf[kk] = frag_glob(K + (long)(key0 + fr) * a.ldk + kk * 32 + kg * 8, key0 + fr < a.Nk);
+    for (int kk = 0; kk < D / 32; ++kk) kf[kk] = frag_glob(K + (long)(key0 + fr) * a.ldk + kk * 32 + kg * 8, key0 + fr < pb.Nk);
     float x3[4][3];
     if constexpr (!XYZ) {
-        vf = frag_glob((const T*)a.v + h * a.hv + (long)(key0 + fr) * a.ldv + kg * 8, key0 + fr < a.Nk);
+        vf = frag_glob((const T*)a.v + h * a.hv + pb.k0 * a.ldv + (long)(key0 + fr) * a.ldv + kg * 8, key0 + fr < pb.Nk);
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int kr = key0 + kg * 4 + r;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) x3[r][c] = kr < a.Nk ? ((const float*)a.v)[(long)kr * 3 + c] : 0.f;
+            for (int c = 0; c < 3; ++c) x3[r][c] = kr < pb.Nk ? ((const float*)a.v)[(pb.k0 + kr) * 3 + c] : 0.f;
         }
     }
     f32x4_t dk[D / 16], dvv[2];
@@ -367,22 +383,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a)
     for (int u = 0; u < D / 16; ++u) dk[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     dvv[0] = dvv[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    for (int q0 = 0; q0 < a.Nq; q0 += 64) {
+    for (int q0 = 0; q0 < pb.Nq; q0 += 64) {
         __syncthreads();
-        load_tile<T, D>(sQ, QRS, Q, a.ldq, q0, a.Nq, tid);
+        load_tile<T, D>(sQ, QRS, Q, a.ldq, q0, pb.Nq, tid);
         if constexpr (XYZ) {
             if (tid < 64) {
-                const float* g = (const float*)a.dout + ((long)h * a.Nq + q0 + tid) * 3;
+                const float* g = (const float*)a.dout + ((long)h * a.Rq + pb.q0 + q0 + tid) * 3;
                 float4 val = make_float4(0, 0, 0, 0);
-                if (q0 + tid < a.Nq) val = make_float4(g[0], g[1], g[2], 0.f);
+                if (q0 + tid < pb.Nq) val = make_float4(g[0], g[1], g[2], 0.f);
                 *reinterpret_cast<float4*>(sO + tid * 16) = val;
             }
         } else {
-            load_tile<T, DV>(sO, ORS, (const T*)a.dout + h * a.ho, a.ldo, q0, a.Nq, tid);
+            load_tile<T, DV>(sO, ORS, (const T*)a.dout + h * a.ho + pb.q0 * a.ldo, a.ldo, q0, pb.Nq, tid);
         }
         if (tid < 64) {
-            sL[tid] = q0 + tid < a.Nq ? a.lse[(long)h * a.Nq + q0 + tid] : 0.f;
-            sL[64 + tid] = q0 + tid < a.Nq ? a.dvec[(long)h * a.Nq + q0 + tid] : 0.f;
+            sL[tid] = q0 + tid < pb.Nq ? a.lse[(long)h * a.Rq + pb.q0 + q0 + tid] : 0.f;
+            sL[64 + tid] = q0 + tid < pb.Nq ? a.dvec[(long)h * a.Rq + pb.q0 + q0 + tid] : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -394,13 +410,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a)
             f32x4_t dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             if constexpr (!XYZ) dp = mma(vf, frag_row(sO, ORS, t * 16 + fr, kg * 8, T()), dp);
             const int qc = t * 16 + fr;
-            const bool qv = q0 + qc < a.Nq;
+            const bool qv = q0 + qc < pb.Nq;
             const float lse = sL[qc], dvec = sL[64 + qc];
             float4 g = make_float4(0, 0, 0, 0);
             if constexpr (XYZ) g = *reinterpret_cast<const float4*>(sO + qc * 16);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool kv = key0 + kg * 4 + r < a.Nk;
+                const bool kv = key0 + kg * 4 + r < pb.Nk;
                 const float p = (qv && kv) ? __expf(s[r] * a.scale - lse) : 0.f;
                 float dpv = dp[r];
                 if constexpr (XYZ) dpv = x3[r][0] * g.x + x3[r][1] * g.y + x3[r][2] * g.z;
@@ -421,15 +437,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a)
             }
         }
     }
-    T* dK = (T*)a.dk + h * a.hk;
+    T* dK = (T*)a.dk + h * a.hk + pb.k0 * a.ldk;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int kr = key0 + kg * 4 + r;
-        if (kr < a.Nk) {
+        if (kr < pb.Nk) {
 #pragma unroll
             for (int u = 0; u < D / 16; ++u) Elem<T>::st(dK + (long)kr * a.ldk + u * 16 + fr, dk[u][r]);
             if constexpr (!XYZ) {
-                T* dV = (T*)a.dv + h * a.hv + (long)kr * a.ldv;
+                T* dV = (T*)a.dv + h * a.hv + (pb.k0 + kr) * a.ldv;
                 Elem<T>::st(dV + fr, dvv[0][r]);
                 Elem<T>::st(dV + 16 + fr, dvv[1][r]);
             }
@@ -439,29 +455,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a)
 
 // ------------------------------------------------------------------------------------------------ C ABI
 template <typename T, int D, bool XYZ>
-static int launch_attn(const AttnArgs& a, int H, int mode, hipStream_t st)
+static int launch_attn(const AttnArgs& a, int H, int mode, hipStream_t st, int nprob = 1, int maxq = 0, int maxk = 0)
 {
+    const int gq = ((a.probs ? maxq : a.Nq) + 63) / 64, gk = ((a.probs ? maxk : a.Nk) + 63) / 64;
     constexpr int DV = 32;
     const size_t krs = D * sizeof(T) + 16, vrs = XYZ ? 16 : DV * sizeof(T) + 16, prs = 64 * sizeof(T) + 16;
     if (mode == 0) {
         const size_t lds = 64 * krs + 64 * vrs + 4 * 16 * prs;
-        hipLaunchKernelGGL((attn_fwd_kernel<T, D, XYZ>), dim3((a.Nq + 63) / 64, H), dim3(256), lds, st, a);
+        if (lds > 65536) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, XYZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, D, XYZ>), dim3(gq, H, nprob), dim3(256), lds, st, a);
     } else if (mode == 1) {
         const size_t lds = 64 * krs + 64 * vrs + 4 * 16 * prs;
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, XYZ>), dim3((a.Nq + 63) / 64, H), dim3(256), lds, st, a);
+        if (lds > 65536) (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<T, D, XYZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, XYZ>), dim3(gq, H, nprob), dim3(256), lds, st, a);
     } else {
         const size_t lds = 64 * krs + 64 * vrs + 4 * 2 * 16 * prs + 128 * sizeof(float);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, XYZ>), dim3((a.Nk + 63) / 64, H), dim3(256), lds, st, a);
+        if (lds > 65536) (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, D, XYZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, XYZ>), dim3(gk, H, nprob), dim3(256), lds, st, a);
     }
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
 
-static int dispatch_attn(const AttnArgs& a, int H, int D, int xyz, int dtype, int mode, hipStream_t st)
+static int dispatch_attn(const AttnArgs& a, int H, int D, int xyz, int dtype, int mode, hipStream_t st, int nprob = 1, int maxq = 0, int maxk = 0)
 {
-    if (a.Nq <= 0 || a.Nk <= 0) return DREG_EINVAL;
-    if (D == 32 && !xyz) return dtype == 0 ? launch_attn<bf16_t, 32, false>(a, H, mode, st) : launch_attn<float, 32, false>(a, H, mode, st);
-    if (D == 256 && xyz) return dtype == 0 ? launch_attn<bf16_t, 256, true>(a, H, mode, st) : launch_attn<float, 256, true>(a, H, mode, st);
+    if (!a.probs && (a.Nq <= 0 || a.Nk <= 0)) return DREG_EINVAL;
+    if (a.probs && (nprob <= 0 || maxq <= 0 || maxk <= 0)) return DREG_EINVAL;
+    if (D == 32 && !xyz) return dtype == 0 ? launch_attn<bf16_t, 32, false>(a, H, mode, st, nprob, maxq, maxk) : launch_attn<float, 32, false>(a, H, mode, st, nprob, maxq, maxk);
+    if (D == 256 && xyz) return dtype == 0 ? launch_attn<bf16_t, 256, true>(a, H, mode, st, nprob, maxq, maxk) : launch_attn<float, 256, true>(a, H, mode, st, nprob, maxq, maxk);
     return DREG_EINVAL;
 }
 
@@ -474,7 +495,7 @@ int dreg_mha_fwd(const void* q, const void* k, const void* v, void* o, float* ls
 {
     AttnArgs a = {};
     a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.Nq = Nq; a.Nk = Nk;
-    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.hq = a.hk = a.hv = a.ho = 32; a.scale = scale;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.hq = a.hk = a.hv = a.ho = 32; a.scale = scale; a.Rq = Nq;
     return dispatch_attn(a, H, 32, 0, dtype, 0, (hipStream_t)stream);
 }
 // Gradients dq, dk, dv (same layouts/strides as q, k, v) from dout (layout of o).  dvec: fp32 [H, Nq] scratch.
@@ -485,7 +506,7 @@ int dreg_mha_bwd(const void* q, const void* k, const void* v, const void* o, con
     AttnArgs a = {};
     a.q = q; a.k = k; a.v = v; a.o = (void*)o; a.lse = (float*)lse; a.Nq = Nq; a.Nk = Nk;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.hq = a.hk = a.hv = a.ho = 32; a.scale = scale;
-    a.dout = dout; a.dvec = dvec; a.dq = dq; a.dk = dk; a.dv = dv;
+    a.dout = dout; a.dvec = dvec; a.dq = dq; a.dk = dk; a.dv = dv; a.Rq = Nq;
     int rc = dispatch_attn(a, H, 32, 0, dtype, 1, (hipStream_t)stream);
     if (rc) return rc;
     return dispatch_attn(a, H, 32, 0, dtype, 2, (hipStream_t)stream);
@@ -497,7 +518,7 @@ int dreg_corr_attention_fwd(const void* q, const void* k, const float* xyz, floa
 {
     AttnArgs a = {};
     a.q = q; a.k = k; a.v = xyz; a.o = out; a.lse = lse; a.Nq = Nq; a.Nk = Nk;
-    a.ldq = a.ldk = 256; a.hq = (long)Nq * 256; a.hk = (long)Nk * 256; a.scale = scale;
+    a.ldq = a.ldk = 256; a.hq = (long)Nq * 256; a.hk = (long)Nk * 256; a.scale = scale; a.Rq = Nq;
     return dispatch_attn(a, L, 256, 1, dtype, 0, (hipStream_t)stream);
 }
 int dreg_corr_attention_bwd(const void* q, const void* k, const float* xyz, const float* out, const float* dout,
@@ -507,10 +528,54 @@ int dreg_corr_attention_bwd(const void* q, const void* k, const float* xyz, cons
     AttnArgs a = {};
     a.q = q; a.k = k; a.v = xyz; a.o = (void*)out; a.lse = (float*)lse; a.Nq = Nq; a.Nk = Nk;
     a.ldq = a.ldk = 256; a.hq = (long)Nq * 256; a.hk = (long)Nk * 256; a.scale = scale;
-    a.dout = dout; a.dvec = dvec; a.dq = dq; a.dk = dk;
+    a.dout = dout; a.dvec = dvec; a.dq = dq; a.dk = dk; a.Rq = Nq;
     int rc = dispatch_attn(a, L, 256, 1, dtype, 1, (hipStream_t)stream);
     if (rc) return rc;
     return dispatch_attn(a, L, 256, 1, dtype, 2, (hipStream_t)stream);
+}
+
+// ---- variable-length batched forms: `probs` is a device array of nprob x {q_start, q_len, kv_start, kv_len} (int32) selecting
+// row ranges of shared [R, ld] tensors (all pairs of a step in one launch); max_q / max_k bound the per-problem lengths.
+int dreg_mha_varlen_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* probs, int nprob,
+                        int max_q, int max_k, int R, int H, int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream)
+{
+    AttnArgs a = {};
+    a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.probs = (const int4*)probs; a.Rq = R;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.hq = a.hk = a.hv = a.ho = 32; a.scale = scale;
+    return dispatch_attn(a, H, 32, 0, dtype, 0, (hipStream_t)stream, nprob, max_q, max_k);
+}
+int dreg_mha_varlen_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                        float* dvec, void* dq, void* dk, void* dv, const int* probs, int nprob, int max_q, int max_k, int R, int H,
+                        int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream)
+{
+    AttnArgs a = {};
+    a.q = q; a.k = k; a.v = v; a.o = (void*)o; a.lse = (float*)lse; a.probs = (const int4*)probs; a.Rq = R;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.hq = a.hk = a.hv = a.ho = 32; a.scale = scale;
+    a.dout = dout; a.dvec = dvec; a.dq = dq; a.dk = dk; a.dv = dv;
+    int rc = dispatch_attn(a, H, 32, 0, dtype, 1, (hipStream_t)stream, nprob, max_q, max_k);
+    if (rc) return rc;
+    return dispatch_attn(a, H, 32, 0, dtype, 2, (hipStream_t)stream, nprob, max_q, max_k);
+}
+// q, k: [L, R, 256]; xyz fp32 [R, 3]; out fp32 [L, R, 3]; lse fp32 [L, R]
+int dreg_corr_attention_varlen_fwd(const void* q, const void* k, const float* xyz, float* out, float* lse, const int* probs, int nprob,
+                                   int max_q, int max_k, int L, int R, float scale, int dtype, void* stream)
+{
+    AttnArgs a = {};
+    a.q = q; a.k = k; a.v = xyz; a.o = out; a.lse = lse; a.probs = (const int4*)probs; a.Rq = R;
+    a.ldq = a.ldk = 256; a.hq = a.hk = (long)R * 256; a.scale = scale;
+    return dispatch_attn(a, L, 256, 1, dtype, 0, (hipStream_t)stream, nprob, max_q, max_k);
+}
+int dreg_corr_attention_varlen_bwd(const void* q, const void* k, const float* xyz, const float* out, const float* dout,
+                                   const float* lse, float* dvec, void* dq, void* dk, const int* probs, int nprob,
+                                   int max_q, int max_k, int L, int R, float scale, int dtype, void* stream)
+{
+    AttnArgs a = {};
+    a.q = q; a.k = k; a.v = xyz; a.o = (void*)out; a.lse = (float*)lse; a.probs = (const int4*)probs; a.Rq = R;
+    a.ldq = a.ldk = 256; a.hq = a.hk = (long)R * 256; a.scale = scale;
+    a.dout = dout; a.dvec = dvec; a.dq = dq; a.dk = dk;
+    int rc = dispatch_attn(a, L, 256, 1, dtype, 1, (hipStream_t)stream, nprob, max_q, max_k);
+    if (rc) return rc;
+    return dispatch_attn(a, L, 256, 1, dtype, 2, (hipStream_t)stream, nprob, max_q, max_k);
 }
 
 }  // extern "C"

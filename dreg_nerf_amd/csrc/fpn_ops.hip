@@ -90,19 +90,25 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(
     }
 }
 
-// one thread per channel: finalise mean / biased var per grid, update running stats sequentially over the grids
-// (reference: one grid per BatchNorm call, src then tgt — nerf_regtr.py:135), emit scale/shift and (mean, rstd).
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma, const float* __restrict__ beta,
+// one wave per channel: finalise mean / biased var per grid (lanes stride over the chunk partials), update running stats
+// sequentially over the grids (reference: one grid per BatchNorm call, src then tgt — nerf_regtr.py:135), emit scale/shift
+// and (mean, rstd).
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ scale_shift, float* __restrict__ mean_rstd,
                                    int B, int nchunks, int C, int V, float eps, float momentum, int train)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     const float ga = gamma[c], be = beta[c];
     if (!train) {
         const float rstd = 1.0f / sqrtf(running_var[c] + eps);
-        for (int b = 0; b < B; ++b) {
+        for (int b = lane; b < B; b += 64) {
             scale_shift[((size_t)b * C + c) * 2] = ga * rstd;
             scale_shift[((size_t)b * C + c) * 2 + 1] = be - running_mean[c] * ga * rstd;
             mean_rstd[((size_t)b * C + c) * 2] = running_mean[c];
@@ -113,23 +119,26 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, const floa
     float rm = running_mean[c], rv = running_var[c];
     for (int b = 0; b < B; ++b) {
         double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < nchunks; ++k) {
+        for (int k = lane; k < nchunks; k += 64) {
             const float* p = partial + (((size_t)b * nchunks + k) * C + c) * 2;
             s1 += p[0]; s2 += p[1];
         }
+        s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
         const double mean = s1 / V;
         double var = s2 / V - mean * mean;
         if (var < 0) var = 0;
         const float rstd = 1.0f / sqrtf((float)var + eps);
-        scale_shift[((size_t)b * C + c) * 2] = ga * rstd;
-        scale_shift[((size_t)b * C + c) * 2 + 1] = be - (float)mean * ga * rstd;
-        mean_rstd[((size_t)b * C + c) * 2] = (float)mean;
-        mean_rstd[((size_t)b * C + c) * 2 + 1] = rstd;
+        if (lane == 0) {
+            scale_shift[((size_t)b * C + c) * 2] = ga * rstd;
+            scale_shift[((size_t)b * C + c) * 2 + 1] = be - (float)mean * ga * rstd;
+            mean_rstd[((size_t)b * C + c) * 2] = (float)mean;
+            mean_rstd[((size_t)b * C + c) * 2 + 1] = rstd;
+        }
         const float unbiased = V > 1 ? (float)(var * V / (V - 1)) : (float)var;
         rm = (1.f - momentum) * rm + momentum * (float)mean;
         rv = (1.f - momentum) * rv + momentum * unbiased;
     }
-    running_mean[c] = rm; running_var[c] = rv;
+    if (lane == 0) { running_mean[c] = rm; running_var[c] = rv; }
 }
 
 // y = [relu]( x * scale[b,c] + shift[b,c] [+ res] )
@@ -156,25 +165,30 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
     }
 }
 
-// backward finalize: per (b,c) coefficients c1 = sum(g)/V, c2 = sum(g*xhat)/V; dgamma/dbeta summed over grids.
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ coef, float* __restrict__ dgamma,
+// backward finalize (one wave per channel): per (b,c) coefficients c1 = sum(g)/V, c2 = sum(g*xhat)/V; dgamma/dbeta summed over grids.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ coef, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, int B, int nchunks, int C, int V, int accumulate)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double dg = 0.0, db = 0.0;
     for (int b = 0; b < B; ++b) {
         double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < nchunks; ++k) {
+        for (int k = lane; k < nchunks; k += 64) {
             const float* p = partial + (((size_t)b * nchunks + k) * C + c) * 2;
             s1 += p[0]; s2 += p[1];
         }
-        coef[((size_t)b * C + c) * 2] = (float)(s1 / V);
-        coef[((size_t)b * C + c) * 2 + 1] = (float)(s2 / V);
+        s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+        if (lane == 0) {
+            coef[((size_t)b * C + c) * 2] = (float)(s1 / V);
+            coef[((size_t)b * C + c) * 2 + 1] = (float)(s2 / V);
+        }
         db += s1; dg += s2;
     }
-    dgamma[c] = accumulate ? dgamma[c] + (float)dg : (float)dg;
-    dbeta[c] = accumulate ? dbeta[c] + (float)db : (float)db;
+    if (lane == 0) {
+        dgamma[c] = accumulate ? dgamma[c] + (float)dg : (float)dg;
+        dbeta[c] = accumulate ? dbeta[c] + (float)db : (float)db;
+    }
 }
 
 // dx = gamma*rstd * (g - c1 - xhat*c2),  g = dy * (y > 0 if relu);  dres = g (optional)
@@ -454,7 +468,7 @@ int dreg_bn3d_fwd(const void* x, const void* res, void* y, const float* gamma, c
         else hipLaunchKernelGGL((bn_partial_kernel<float, 0>), grid, dim3(256), 0, st, (const float*)x, nullptr, nullptr, nullptr, workspace, V, C, rpc, 0);
         DREG_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, workspace, gamma, beta, running_mean, running_var,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, gamma, beta, running_mean, running_var,
                        scale_shift, mean_rstd, B, nch, C, V, eps, momentum, train);
     DREG_LAUNCH_CHECK();
     const size_t tg = (size_t)B * V * CG;
@@ -478,7 +492,7 @@ int dreg_bn3d_bwd(const void* x, const void* dy, const void* y, const float* sca
     if (dtype == 0) hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean_rstd, workspace, V, C, rpc, relu);
     else hipLaunchKernelGGL((bn_partial_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y, mean_rstd, workspace, V, C, rpc, relu);
     DREG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, workspace, coef, dgamma, dbeta, B, nch, C, V, accumulate);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, coef, dgamma, dbeta, B, nch, C, V, accumulate);
     DREG_LAUNCH_CHECK();
     const size_t tg = (size_t)B * V * CG;
     if (dtype == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(nblocks(tg)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean_rstd, scale_shift, coef, (bf16_t*)dx, (bf16_t*)dres, tg, V, C, relu);
@@ -519,7 +533,7 @@ int dreg_downsample_sum(const void* g, void* out, int B, int Df, int Hf, int Wf,
     return DREG_OK;
 }
 
-static inline int colsum_rows_per_chunk(size_t M) { return M >= 262144 ? 1024 : (M >= 16384 ? 256 : 32); }
+static inline int colsum_rows_per_chunk(size_t M) { size_t r = (M + 255) / 256; r = (r + 31) / 32 * 32; return (int)(r < 32 ? 32 : r); }
 size_t dreg_colsum_workspace_bytes(size_t M, int C) { const size_t r = colsum_rows_per_chunk(M); return ((M + r - 1) / r) * C * sizeof(float); }
 int dreg_colsum(const void* g, float* out, float* workspace, size_t M, int C, int accumulate, int dtype, void* stream)
 {

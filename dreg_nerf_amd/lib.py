@@ -54,6 +54,10 @@ SIGNATURES = {
     "dreg_mha_bwd": (I, [P] * 10 + [I] * 7 + [F, I, P]),
     "dreg_corr_attention_fwd": (I, [P] * 5 + [I] * 3 + [F, I, P]),
     "dreg_corr_attention_bwd": (I, [P] * 9 + [I] * 3 + [F, I, P]),
+    "dreg_mha_varlen_fwd": (I, [P] * 6 + [I] * 9 + [F, I, P]),
+    "dreg_mha_varlen_bwd": (I, [P] * 11 + [I] * 9 + [F, I, P]),
+    "dreg_corr_attention_varlen_fwd": (I, [P] * 6 + [I] * 5 + [F, I, P]),
+    "dreg_corr_attention_varlen_bwd": (I, [P] * 10 + [I] * 5 + [F, I, P]),
     # pointset.hip
     "dreg_layernorm_fwd": (I, [P] * 6 + [I, I, F, I, P]),
     "dreg_layernorm_bwd_workspace_bytes": (Z, [I]),

@@ -127,7 +127,9 @@ def conv_igemm(x, wpk, bias, addend, out_shape, cin, cout, ksz, stride, pad, tra
     return out
 
 
-def conv_wgrad(gout, x, w_shape, cin_pad, ksz, stride, pad, use_tr=True):
+def conv_wgrad(gout, x, w_shape, cin_pad, ksz, stride, pad, use_tr=True, accumulate_into=None):
+    """accumulate_into: an existing fp32 gradient tensor of w_shape (e.g. a view of the flat gradient buffer) that the
+    reduce kernel adds into; the function then returns None."""
     lib = L.load()
     dt = L.dt_of(x)
     B, Di, Hi, Wi = x.shape[:4]
@@ -135,7 +137,7 @@ def conv_wgrad(gout, x, w_shape, cin_pad, ksz, stride, pad, use_tr=True):
     cin_real = w_shape[1]
     nbytes = lib.dreg_conv3d_wgrad_workspace_bytes(B, Do, Ho, Wo, cin_pad, cout, ksz, dt)
     ws = _ws(nbytes, x.device)
-    dw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
+    dw = accumulate_into if accumulate_into is not None else torch.empty(w_shape, dtype=torch.float32, device=x.device)
     ev = None
     if PROFILER is not None:
         tn = "bf16" if dt == L.DT_BF16 else "f32"
@@ -143,20 +145,33 @@ def conv_wgrad(gout, x, w_shape, cin_pad, ksz, stride, pad, use_tr=True):
         ev = PROFILER.record(f"conv_wgrad_kernel<{tn}>+reduce", label, 2.0 * B * Do * Ho * Wo * cout * (ksz ** 3) * cin_real)
         ev[0].record()
     L.check(lib.dreg_conv3d_wgrad(L.ptr(gout), L.ptr(x), L.ptr(dw), L.ptr(ws), nbytes, B, Di, Hi, Wi, cin_pad, cin_real,
-                                  Do, Ho, Wo, cout, ksz, stride, pad, 0, dt, int(use_tr and dt == L.DT_BF16), L.stream()),
+                                  Do, Ho, Wo, cout, ksz, stride, pad, int(accumulate_into is not None), dt,
+                                  int(use_tr and dt == L.DT_BF16), L.stream()),
             "dreg_conv3d_wgrad")
     if ev is not None:
         ev[1].record()
-    return dw
+    return None if accumulate_into is not None else dw
 
 
-def colsum(g2d: torch.Tensor) -> torch.Tensor:
+def colsum(g2d: torch.Tensor, accumulate_into=None):
     lib = L.load()
     M, C = g2d.shape
     ws = _ws(lib.dreg_colsum_workspace_bytes(M, C), g2d.device)
-    out = torch.empty(C, dtype=torch.float32, device=g2d.device)
-    L.check(lib.dreg_colsum(L.ptr(g2d), L.ptr(out), L.ptr(ws), M, C, 0, L.dt_of(g2d), L.stream()), "dreg_colsum")
-    return out
+    out = accumulate_into if accumulate_into is not None else torch.empty(C, dtype=torch.float32, device=g2d.device)
+    L.check(lib.dreg_colsum(L.ptr(g2d), L.ptr(out), L.ptr(ws), M, C, int(accumulate_into is not None), L.dt_of(g2d), L.stream()), "dreg_colsum")
+    return None if accumulate_into is not None else out
+
+
+def _grad_sink(p):
+    """A preallocated, contiguous fp32 .grad of a leaf parameter (FlatAdamW's buffer views) that kernels may accumulate
+    into directly, skipping autograd's separate add; None otherwise (slices of parameters, no .grad yet, ...)."""
+    if DIRECT_GRAD_ACCUMULATE and p.is_leaf and p._base is None and p.grad is not None and p.grad.is_contiguous() \
+            and p.grad.dtype == torch.float32:
+        return p.grad
+    return None
+
+
+DIRECT_GRAD_ACCUMULATE = True
 
 
 def downsample_sum(g, coarse_shape):
@@ -205,6 +220,7 @@ class Conv3dFn(torch.autograd.Function):
         y = conv_igemm(x, wpk, b32, addend, out_shape, cin_pad, cout, ksz, stride, pad, False, relu=relu, out_f32=out_f32,
                        flop_cin=w.shape[1], add_same=add_same)
         ctx.save_for_backward(x, w, y if relu else None)
+        ctx.bias_ref = bias if (bias is not None and bias.is_leaf) else None
         ctx.cfg = (stride, pad, ksz, cin_pad, bias is not None, None if addend is None else tuple(addend.shape[1:4]), add_same)
         return y
 
@@ -225,9 +241,9 @@ class Conv3dFn(torch.autograd.Function):
             wpk = packed_weight(w, cin_pad, True, dt)
             gx = conv_igemm(g, wpk, None, None, tuple(x.shape[1:4]), cout, w.shape[1], ksz, stride, pad, True)
         if ctx.needs_input_grad[1]:
-            gw = conv_wgrad(g, x, tuple(w.shape), cin_pad, ksz, stride, pad, USE_TR)
+            gw = conv_wgrad(g, x, tuple(w.shape), cin_pad, ksz, stride, pad, USE_TR, accumulate_into=_grad_sink(w))
         if has_bias and ctx.needs_input_grad[2]:
-            gb = colsum(g.view(-1, cout))
+            gb = colsum(g.view(-1, cout), accumulate_into=_grad_sink(ctx.bias_ref) if ctx.bias_ref is not None else None)
         return gx, gw, gb, ga, None, None, None, None, None
 
 

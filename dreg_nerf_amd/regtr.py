@@ -177,20 +177,27 @@ class NeRFRegTr(nn.Module):
         p1 = self.fpn(self.pack_grids(grids, self.act_dtype))
         feats = ops.trilinear_gather(p1, torch.cat(idxs).contiguous(), torch.cat(pbatch), res)
         P = self._P()
-        outs = []
+        # A4 per pair (its stopping rule is per pair), then the whole point-set half once for all pairs
         off = 0
+        pts_l, feat_l, segs = [], [], []
         for i, d in enumerate(batch):
             ns, nt = idxs[2 * i].shape[0], idxs[2 * i + 1].shape[0]
             f = feats[off:off + ns + nt]
             off += ns + nt
             pts = torch.cat([xyzs[2 * i], xyzs[2 * i + 1]])
             pts, f, lens = T.hierarchical_grid_subsample(pts, f, [ns, nt], self.num_downsample)
-            n0 = int(lens[0])
-            s_xyz, t_xyz, s_f, t_f = pts[:n0], pts[n0:], f[:n0], f[n0:]
-            s_pe = T.posenc_sine(s_xyz, scale=self.pos_emb_scaling)
-            t_pe = T.posenc_sine(t_xyz, scale=self.pos_emb_scaling)
-            s_c, t_c = T.cross_encoder(P, s_f, t_f, s_pe, t_pe)
-            s_corr, t_corr, s_ov, t_ov = T.corr_decoder(P, s_c, t_c, s_xyz, t_xyz, s_pe, t_pe)
+            pts_l.append(pts)
+            feat_l.append(f)
+            segs.append((int(lens[0]), int(lens[1])))
+        tab = A.ProblemTable(segs, dev)
+        xyz_all = torch.cat(pts_l) if len(pts_l) > 1 else pts_l[0]
+        cond, corr, ov = T.encode_decode_batched(P, torch.cat(feat_l) if len(feat_l) > 1 else feat_l[0], xyz_all, tab)
+        outs = []
+        for (s0, ns, t0, nt) in tab.segs:
+            s_xyz, t_xyz = xyz_all[s0:s0 + ns], xyz_all[t0:t0 + nt]
+            s_c, t_c = cond[:, s0:s0 + ns], cond[:, t0:t0 + nt]
+            s_corr, t_corr = corr[:, s0:s0 + ns], corr[:, t0:t0 + nt]
+            s_ov, t_ov = ov[:, s0:s0 + ns], ov[:, t0:t0 + nt]
             nl = s_c.shape[0]
             a = torch.cat([s_xyz.expand(nl, -1, -1), t_corr], dim=1)
             b = torch.cat([s_corr, t_xyz.expand(nl, -1, -1)], dim=1)

@@ -97,6 +97,46 @@ def corr_decoder(P, src_f, tgt_f, src_xyz, tgt_xyz, src_pe, tgt_pe):
     return src_corr, tgt_corr, A.overlap_head(src_f.contiguous(), w, b), A.overlap_head(tgt_f.contiguous(), w, b)
 
 
+# --------------------------------------------------------------------------- A6 + A7 for all pairs of a step at once
+def encoder_layer_batched(P, p, x, pe, tab):
+    """x fp32 [R,256]: rows of every pair's (src | tgt) point sets; tab: attn_ops.ProblemTable."""
+    sc = 1.0 / math.sqrt(256 // N_HEADS)
+    h = A.layer_norm(x, P[p + ".norm1.weight"], P[p + ".norm1.bias"], pe)
+    qkv = A.linear(h, P[p + ".self_attn.in_proj_weight"], P[p + ".self_attn.in_proj_bias"])
+    o = A.mha_varlen(qkv, tab.self_probs, tab.nprob, tab.max_len, N_HEADS, sc)
+    x = A.linear(o, P[p + ".self_attn.out_proj.weight"], P[p + ".self_attn.out_proj.bias"], residual=x, out_f32=True)
+    h = A.layer_norm(x, P[p + ".norm2.weight"], P[p + ".norm2.bias"], pe)
+    qkv = A.linear(h, P[p + ".cross_attn.in_proj_weight"], P[p + ".cross_attn.in_proj_bias"])
+    o = A.mha_varlen(qkv, tab.cross_probs, tab.nprob, tab.max_len, N_HEADS, sc)
+    x = A.linear(o, P[p + ".cross_attn.out_proj.weight"], P[p + ".cross_attn.out_proj.bias"], residual=x, out_f32=True)
+    h = A.layer_norm(x, P[p + ".norm3.weight"], P[p + ".norm3.bias"])
+    h = A.linear(h, P[p + ".linear1.weight"], P[p + ".linear1.bias"], relu=True)
+    return A.linear(h, P[p + ".linear2.weight"], P[p + ".linear2.bias"], residual=x, out_f32=True)
+
+
+def encode_decode_batched(P, feats, xyz, tab):
+    """feats fp32 [R,256], xyz fp32 [R,3] (rows ordered pair by pair, src then tgt), tab: ProblemTable.
+    Returns (cond fp32 [6,R,256], corr fp32 [6,R,3], overlap fp32 [6,R,1])."""
+    x = feats.float().contiguous()
+    xyz = xyz.contiguous()
+    pe = A.posenc_sine(xyz)
+    outs = []
+    for l in range(N_LAYERS):
+        x = encoder_layer_batched(P, f"transformer_encoder.layers.{l}", x, pe, tab)
+        outs.append(x)
+    R = x.shape[0]
+    allx = torch.cat(outs)  # [6R,256]: one final-LayerNorm launch for the six intermediate outputs
+    nw, nb = P["transformer_encoder.norm.weight"], P["transformer_encoder.norm.bias"]
+    cond = A.layer_norm(allx, nw, nb, out_dtype=torch.float32)
+    dec_in = A.layer_norm(allx, nw, nb, pe.repeat(N_LAYERS, 1))  # LN(x) + pe in the compute dtype
+    p = "correspondence_decoder"
+    q = A.linear(dec_in, P[p + ".q_proj.weight"], P[p + ".q_proj.bias"]).view(N_LAYERS, R, 256)
+    k = A.linear(dec_in, P[p + ".k_proj.weight"], P[p + ".k_proj.bias"]).view(N_LAYERS, R, 256)
+    corr = A.attention_xyz_varlen(q, k, xyz, tab.cross_probs, tab.nprob, tab.max_len, 1.0 / math.sqrt(256))
+    ov = A.overlap_head(cond, P[p + ".conf_logits_decoder.weight"], P[p + ".conf_logits_decoder.bias"]).view(N_LAYERS, R, 1)
+    return cond.view(N_LAYERS, R, 256), corr, ov
+
+
 # --------------------------------------------------------------------------- A8
 def weighted_kabsch(a, b, w, eps: float = 1e-6):
     return A.weighted_kabsch(a, b, w, eps)

@@ -112,6 +112,19 @@ int dreg_corr_attention_bwd(const void* q, const void* k, const float* xyz, cons
                             const float* lse, float* dvec, void* dq, void* dk, int L, int Nq, int Nk,
                             float scale, int dtype, void* stream);
 
+/* Variable-length batched forms (all pairs of a step in one launch): `probs` is a device array of nprob x
+ * {q_start, q_len, kv_start, kv_len} (int32) selecting row ranges of shared [R, ld] tensors; max_q / max_k bound the lengths. */
+int dreg_mha_varlen_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* probs, int nprob,
+                        int max_q, int max_k, int R, int H, int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream);
+int dreg_mha_varlen_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                        float* dvec, void* dq, void* dk, void* dv, const int* probs, int nprob, int max_q, int max_k, int R, int H,
+                        int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream);
+int dreg_corr_attention_varlen_fwd(const void* q, const void* k, const float* xyz, float* out, float* lse, const int* probs, int nprob,
+                                   int max_q, int max_k, int L, int R, float scale, int dtype, void* stream);
+int dreg_corr_attention_varlen_bwd(const void* q, const void* k, const float* xyz, const float* out, const float* dout,
+                                   const float* lse, float* dvec, void* dq, void* dk, const int* probs, int nprob,
+                                   int max_q, int max_k, int L, int R, float scale, int dtype, void* stream);
+
 /* nn.LayerNorm(256) fused with the position-embedding add (transformer.py:238-239,252-253,265-267): y = LN(x)*g + b (+pe).
  * x fp32 [N,256]; y in out_dtype; stats fp32 [N,2] = (mean, rstd). */
 int dreg_layernorm_fwd(const float* x, const float* gamma, const float* beta, const float* pe, void* y, float* stats,

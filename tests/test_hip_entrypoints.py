@@ -38,7 +38,10 @@ def test_grid_extraction_from_block_checkpoint(tmp_path):
     d.mkdir(parents=True)
     f = ngp.NGPradianceField([-1.5] * 3 + [1.5] * 3)
     with torch.no_grad():
-        f.mlp_base.params[3072:].normal_(0, 1.0, generator=torch.Generator().manual_seed(0))
+        g = torch.Generator().manual_seed(0)
+        f.mlp_base.params[:3072] = torch.randn(3072, generator=g) * 0.4
+        f.mlp_base.params[3072:] = torch.randn(f.mlp_base.params.numel() - 3072, generator=g)
+        f.color_mlp.params.copy_(torch.randn(7168, generator=g) * 0.2)
     binary = torch.rand(res, res, res, generator=torch.Generator().manual_seed(1)) < 0.05
     torch.save({"step": 1, "model": f.state_dict(), "occupancy_grid": {"_binary": binary, "resolution": torch.tensor([res] * 3)},
                 "aabb": [-1.5] * 3 + [1.5] * 3, "unbounded": False, "grid_resolution": res,
