@@ -532,15 +532,17 @@ template <int GP> __device__ __forceinline__ int wg_swz(int row) {
 template <int BM, int BNC>
 __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(
     const bf16_t* __restrict__ gout, const bf16_t* __restrict__ in, float* __restrict__ part,
-    ConvGeom g, int tilesCol, uint32_t vox_per_split, uint32_t gout_bytes, uint32_t in_bytes)
+    ConvGeom g, int tilesCol, int tiles, int nsplit, uint32_t vox_per_split, uint32_t gout_bytes, uint32_t in_bytes)
 {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
-    constexpr int KV = 64;
+    constexpr int KV = 64, NS = 2;                        // voxels per stage, LDS ring depth (prefetch distance NS-1)
     constexpr int RSA = BM * 2, RSB = BNC * 2;
     constexpr int GPA = RSA / 16, GPB = RSB / 16;          // granules per row (16 or 8)
     constexpr int A_BYTES = KV * RSA, B_BYTES = KV * RSB, STAGE = A_BYTES + B_BYTES;
     constexpr int IA = A_BYTES / 1024 / 4, IB = B_BYTES / 1024 / 4;   // wave-instructions per wave per tile
+    constexpr int LPS = IA + IB;                           // DMA instructions per wave per stage (for counted vmcnt)
+    static_assert(IA >= 1 && IB >= 1, "stage too small for 4 waves");
     constexpr int RPA = 64 / GPA, RPB = 64 / GPB;          // rows per wave-instruction
     constexpr int WN = BNC / 2, WM = BM / 2, TM = WM / 16, TN = WN / 16;
     constexpr uint32_t OOB = 0x7fffff00u;
@@ -549,9 +551,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const uint32_t tile_r = blockIdx.x / tilesCol, tile_c = blockIdx.x - tile_r * tilesCol;
+    // XCD-aware placement (block b runs on XCD b % 8): every XCD owns the voxel splits s == xcd (mod 8) and runs all
+    // (co, n) tiles of a split back to back, so both streamed operands are fetched from HBM by ONE L2 and re-used there.
+    uint32_t split, tile;
+    if ((nsplit & 7) == 0) { const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3; split = (j / tiles) * 8 + xcd; tile = j % tiles; }
+    else { split = blockIdx.x / tiles; tile = blockIdx.x - split * tiles; }
+    const uint32_t tile_r = tile / tilesCol, tile_c = tile - tile_r * tilesCol;
     const int co0 = tile_r * BM, n0 = tile_c * BNC;
-    const uint32_t v_begin = blockIdx.y * vox_per_split;
+    const uint32_t v_begin = split * vox_per_split;
     const uint32_t v_end = min(v_begin + vox_per_split, g.M);
     const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)gout, 0, gout_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
@@ -618,29 +625,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sB + j * 1024), 16, (int)voff, 0, 0, 0);
         }
     };
+    // The transpose reads go through inline asm: hipcc otherwise orders ds_read_b64_tr_b16 behind every pending LDS-DMA with an
+    // s_waitcnt vmcnt(0), which would drain the stages prefetched above.  All 16 reads of a step are issued, then one
+    // lgkmcnt(0) + sched_barrier (an MFMA may not be hoisted above the wait: it only touches registers).
+    typedef __attribute__((ext_vector_type(2))) int i32x2_t;
+    auto tr_read = [&](uint32_t addr) -> i32x2_t {
+        i32x2_t v;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+        return v;
+    };
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     auto compute = [&](int buf) {
-        const char* sA = smem + buf * STAGE;
-        const char* sB = sA + A_BYTES;
+        const uint32_t sA = lds_base + buf * STAGE;
+        const uint32_t sB = sA + A_BYTES;
         const int fi = lane & 15;
 #pragma unroll
         for (int ks = 0; ks < KV / 32; ++ks) {
             const int kb = ks * 32 + (lane >> 4) * 8;
             const int r0 = kb + (fi >> 2), r1 = r0 + 4;
-            bf16x8_t af[TM], bf[TN];
+            i32x2_t alo[TM], ahi[TM], blo[TN], bhi[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int gi = (wm * WM + i * 16) / 8 + ((fi & 3) >> 1), o8 = (fi & 1) * 8;
-                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(sA + r0 * RSA + ((gi ^ wg_swz<GPA>(r0)) << 4) + o8));
-                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(sA + r1 * RSA + ((gi ^ wg_swz<GPA>(r1)) << 4) + o8));
-                af[i] = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                alo[i] = tr_read(sA + r0 * RSA + ((gi ^ wg_swz<GPA>(r0)) << 4) + o8);
+                ahi[i] = tr_read(sA + r1 * RSA + ((gi ^ wg_swz<GPA>(r1)) << 4) + o8);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int gi = (wn * WN + j * 16) / 8 + ((fi & 3) >> 1), o8 = (fi & 1) * 8;
-                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(sB + r0 * RSB + ((gi ^ wg_swz<GPB>(r0)) << 4) + o8));
-                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(sB + r1 * RSB + ((gi ^ wg_swz<GPB>(r1)) << 4) + o8));
-                bf[j] = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                blo[j] = tr_read(sB + r0 * RSB + ((gi ^ wg_swz<GPB>(r0)) << 4) + o8);
+                bhi[j] = tr_read(sB + r1 * RSB + ((gi ^ wg_swz<GPB>(r1)) << 4) + o8);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8_t af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { typedef __attribute__((ext_vector_type(4))) int i32x4_t; i32x4_t t4 = {alo[i][0], alo[i][1], ahi[i][0], ahi[i][1]}; af[i] = __builtin_bit_cast(bf16x8_t, t4); }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { typedef __attribute__((ext_vector_type(4))) int i32x4_t; i32x4_t t4 = {blo[j][0], blo[j][1], bhi[j][0], bhi[j][1]}; bf[j] = __builtin_bit_cast(bf16x8_t, t4); }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -650,16 +672,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(
     };
 
     if (v_begin < v_end) {
+        // NS-deep LDS ring, loads issued 3 stages ahead; stage k is consumed after a COUNTED wait (the two younger stages stay
+        // in flight across the barrier) + a raw s_barrier (a __syncthreads() here would drain the DMA queue with vmcnt(0)).
         const int nk = (int)((v_end - v_begin + KV - 1) / KV);
-        issue(v_begin, 0);
+        for (int p = 0; p < NS - 1 && p < nk; ++p) issue(v_begin + (uint32_t)p * KV, p);
         for (int k = 0; k < nk; ++k) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (k + 1 < nk) issue(v_begin + (uint32_t)(k + 1) * KV, (k + 1) & 1);
-            compute(k & 1);
+            const int ahead = min(nk - 1 - k, NS - 2);   // stages issued after stage k that may stay in flight
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (k + NS - 1 < nk) issue(v_begin + (uint32_t)(k + NS - 1) * KV, (k + NS - 1) % NS);
+            compute(k % NS);
         }
     }
-    float* dst = part + (size_t)blockIdx.y * g.Cout * g.Kpad;
+    float* dst = part + (size_t)split * g.Cout * g.Kpad;
     const int col_l = lane & 15, rowq = (lane >> 4) * 4;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -864,6 +891,7 @@ int dreg_conv3d_wgrad_splits(int B, int Do, int Ho, int Wo, int Cin, int Cout, i
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
+    if (s > 8) s = (s + 7) / 8 * 8;   // whole multiples of the 8 XCDs (see the block placement of the glds kernel)
     return (int)s;
 }
 size_t dreg_conv3d_wgrad_workspace_bytes(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int dtype) {
@@ -904,7 +932,7 @@ int dreg_conv3d_wgrad(const void* gout, const void* in, float* dw, void* workspa
         else WG_LAUNCH(T, 64, 64, TRv); } while (0)
     const uint64_t gbytes = (uint64_t)g.M * Cout * 2, ibytes = (uint64_t)B * Di * Hi * Wi * Cin * 2;
     if (dtype == 0 && use_tr && g_use_glds && gbytes < 0x7fffff00ull && ibytes < 0x7fffff00ull) {
-#define WGG(BMv, BNv) hipLaunchKernelGGL((conv_wgrad_glds_kernel<BMv, BNv>), grid, dim3(256), (size_t)2 * 64 * (bm + bnc) * 2, st, (const bf16_t*)gout, (const bf16_t*)in, part, g, tilesCol, vps, (uint32_t)gbytes, (uint32_t)ibytes)
+#define WGG(BMv, BNv) hipLaunchKernelGGL((conv_wgrad_glds_kernel<BMv, BNv>), dim3(tilesRow * tilesCol * nsplit), dim3(256), (size_t)2 * 64 * (bm + bnc) * 2, st, (const bf16_t*)gout, (const bf16_t*)in, part, g, tilesCol, tilesRow * tilesCol, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes)
         if (bm == 128 && bnc == 128) WGG(128, 128); else if (bm == 128 && bnc == 64) WGG(128, 64);
         else if (bm == 64 && bnc == 128) WGG(64, 128); else WGG(64, 64);
 #undef WGG
