@@ -324,28 +324,57 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
         compute(k & 1);
     }
 
+    // Epilogue through LDS: accumulators -> fp32 tile [128][BN] (16-column blocks XOR-ed with (row>>2)&1 so the two row groups
+    // of a 32-lane write phase hit different banks) -> coalesced 16-byte rows with bias / addend / ReLU applied in fp32.
+    __syncthreads();
+    float* sC = reinterpret_cast<float*>(smem);
     const int col_l = lane & 15, rowq = (lane >> 4) * 4;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint32_t m = m0 + wm * 64 + i * 16 + rowq + r;
-            if (m >= g.M) continue;
-            size_t arow = 0;
-            if (addend) {
-                int b, z, y, x;
-                vox_decode(m, g, b, z, y, x);
-                arow = ((size_t)((b * Da + (z >> add_shift)) * Ha + (y >> add_shift)) * Wa + (x >> add_shift)) * g.Cout;
-            }
+            const int row = wm * 64 + i * 16 + rowq + r;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * WN + j * 16 + col_l;
-                float v = acc[i][j][r];
-                if (bias) v += bias[n];
-                if (addend) v += Elem<TO>::ld(addend + arow + n);
-                if (relu) v = fmaxf(v, 0.f);
-                Elem<TO>::st(out + (size_t)m * g.Cout + n, v);
+                const int blk = (wn * WN + j * 16) >> 4;
+                sC[row * BN + ((blk ^ ((row >> 2) & 1)) << 4) + col_l] = acc[i][j][r];
             }
+        }
+    __syncthreads();
+    constexpr int CPR = BN / 8;                    // 8-column chunks per row
+    constexpr int NTHR = BN == 256 ? 512 : 256;
+    for (int c = t; c < BM * CPR; c += NTHR) {
+        const int row = c / CPR, cc = (c - row * CPR) * 8;
+        const uint32_t m = m0 + row;
+        if (m >= g.M) continue;
+        const float* src = sC + row * BN + ((((cc >> 4) ^ ((row >> 2) & 1)) << 4) | (cc & 8));
+        const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const int n = n0 + cc;
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bias[n + e];
+        }
+        if (addend) {
+            int b, z, y, x;
+            vox_decode(m, g, b, z, y, x);
+            const TO* ap = addend + ((size_t)((b * Da + (z >> add_shift)) * Ha + (y >> add_shift)) * Wa + (x >> add_shift)) * g.Cout + n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += Elem<TO>::ld(ap + e);
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        TO* dst = out + (size_t)m * g.Cout + n;
+        if constexpr (sizeof(TO) == 4) {
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+            *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
 }
