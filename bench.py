@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-res", type=int, default=64, help="resolution of the bounded CPU sample")
     ap.add_argument("--kernel-report", default="", help="write the per-kernel/per-shape event timing table here")
+    ap.add_argument("--dense-head", action="store_true", help="evaluate the FPN head densely (BASELINE.md FLOP accounting) instead of on the active set")
     return ap.parse_args()
 
 
@@ -90,6 +91,7 @@ def main():
 
     torch.manual_seed(3407)
     model = NeRFRegTr(precision=args.precision).to(dev).train()
+    model.active_set = not args.dense_head
     if world > 1:  # identical initial weights on every rank
         for p in model.parameters():
             dist.broadcast(p.data, 0)
@@ -146,6 +148,7 @@ def main():
             "config": {"workload": f"RegTR fwd+bwd+AdamW, shell-R synthetic pairs, {args.res}^3 grids, "
                                    f"{args.pairs} pairs ({2 * args.pairs} grids) per GPU per step, random-init weights",
                        "global_batch_pairs": args.pairs * world, "resolution": args.res,
+                       "fpn_head": "dense" if args.dense_head else "active-set (identical results; rows around occupied voxels)",
                        "parallelism": f"dp{world}"},
             "roofline": roofline,
         }

@@ -221,7 +221,8 @@ template <typename TO, int BN>
 __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
     const bf16_t* __restrict__ in, const bf16_t* __restrict__ wt, TO* __restrict__ out,
     const float* __restrict__ bias, const TO* __restrict__ addend, ConvGeom g,
-    int relu, int Da, int Ha, int Wa, int add_shift, int tilesN, uint32_t in_bytes, uint32_t wt_bytes)
+    int relu, int Da, int Ha, int Wa, int add_shift, int tilesN, uint32_t in_bytes, uint32_t wt_bytes,
+    const int* __restrict__ rowlist, uint32_t nrows)
 {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     constexpr int NW = BN == 256 ? 8 : 4, WAVES_N = BN == 256 ? 4 : 2;   // waves: 2 (M) x WAVES_N (N), 64 x (BN/WAVES_N) each
@@ -248,12 +249,14 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
     for (int i = 0; i < IA; ++i) {
         const int r = (wave * IA + i) * 8 + (lane >> 3);
         const int gl = (lane & 7) ^ ((r >> 1) & 7);
-        const uint32_t m = m0 + r;
+        const uint32_t ri = m0 + r;            // row of the (possibly sparse) row space
+        const bool rv = ri < nrows;
+        const uint32_t m = rowlist ? (rv ? (uint32_t)rowlist[ri] : 0u) : ri;   // output voxel
         int b, z, y, x;
-        vox_decode(m < g.M ? m : 0, g, b, z, y, x);
+        vox_decode(rv ? m : 0, g, b, z, y, x);
         const int zb = z * g.sn + g.off, yb = y * g.sn + g.off, xb = x * g.sn + g.off;
         uint32_t mask = 0;
-        if (m < g.M) {
+        if (rv) {
             for (int tap = 0; tap < g.ntaps; ++tap) {
                 int dz, dy, dx;
                 tap_decode(tap, g.ksz, dz, dy, dx);
@@ -345,8 +348,8 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
     constexpr int NTHR = BN == 256 ? 512 : 256;
     for (int c = t; c < BM * CPR; c += NTHR) {
         const int row = c / CPR, cc = (c - row * CPR) * 8;
-        const uint32_t m = m0 + row;
-        if (m >= g.M) continue;
+        if (m0 + row >= nrows) continue;
+        const uint32_t m = rowlist ? (uint32_t)rowlist[m0 + row] : m0 + row;
         const float* src = sC + row * BN + ((((cc >> 4) ^ ((row >> 2) & 1)) << 4) | (cc & 8));
         const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
         float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -558,10 +561,11 @@ template <int GP> __device__ __forceinline__ int wg_swz(int row) {
     return GP == 16 ? (((row & 3) + 4 * ((row >> 3) & 1)) << 1) : ((((row >> 1) & 1) + 2 * ((row >> 3) & 1)) << 1);
 }
 
-template <int BM, int BNC>
+template <int BM, int BNC, bool ROWS>
 __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(
     const bf16_t* __restrict__ gout, const bf16_t* __restrict__ in, float* __restrict__ part,
-    ConvGeom g, int tilesCol, int tiles, int nsplit, uint32_t vox_per_split, uint32_t gout_bytes, uint32_t in_bytes)
+    ConvGeom g, int tilesCol, int tiles, int nsplit, uint32_t vox_per_split, uint32_t gout_bytes, uint32_t in_bytes,
+    const int* __restrict__ rowlist, uint32_t nrows)
 {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
@@ -588,7 +592,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(
     const uint32_t tile_r = tile / tilesCol, tile_c = tile - tile_r * tilesCol;
     const int co0 = tile_r * BM, n0 = tile_c * BNC;
     const uint32_t v_begin = split * vox_per_split;
-    const uint32_t v_end = min(v_begin + vox_per_split, g.M);
+    const uint32_t v_end = min(v_begin + vox_per_split, nrows);   // positions in the row space (dense: voxels; sparse: list entries)
+    // ROWS: this block's slice of the row list is copied to LDS up front (plain loads inside the K loop would make hipcc
+    // drain the DMA queue with vmcnt(0) every step); it sits behind the NS stages.
+    const int* srow = reinterpret_cast<const int*>(smem + NS * STAGE);
+    if constexpr (ROWS) {
+        int* w_ = reinterpret_cast<int*>(smem + NS * STAGE);
+        for (uint32_t i = v_begin + t; i < v_end; i += 256) w_[i - v_begin] = rowlist[i];
+        __syncthreads();
+    }
     const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)gout, 0, gout_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
 
@@ -625,21 +637,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
             const int j = wave * IA + i;
-            const uint32_t m = v0 + j * RPA + ra;
-            const uint32_t voff = (m < v_end) ? m * (uint32_t)(g.Cout * 2) + a_col[i] : OOB;
+            const uint32_t vi = v0 + j * RPA + ra;
+            uint32_t m = vi;
+            if constexpr (ROWS) m = vi < v_end ? (uint32_t)srow[vi - v_begin] : 0u;
+            const uint32_t voff = (vi < v_end) ? m * (uint32_t)(g.Cout * 2) + a_col[i] : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(sA + j * 1024), 16, (int)voff, 0, 0, 0);
         }
         // one full voxel decode per K step (row of instruction 0); the wave's other rows are +RPB, +2*RPB ... voxels
         // further along x with at most one carry when Wo >= IB*RPB (else every row is decoded in full)
         const uint32_t mb = v0 + (wave * IB) * RPB + rb;
         int b0, z0, y0, x0;
-        vox_decode(mb < g.M ? mb : 0, g, b0, z0, y0, x0);
-        const bool fast = g.Wo >= IB * RPB;
+        vox_decode((!ROWS && mb < g.M) ? mb : 0, g, b0, z0, y0, x0);
+        const bool fast = !ROWS && g.Wo >= IB * RPB;
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
             const int j = wave * IB + i;
-            const uint32_t m = mb + i * RPB;
-            bool v = (m < v_end) && b_tv[i];
+            const uint32_t vi = mb + i * RPB;
+            uint32_t m = vi;
+            if constexpr (ROWS) m = vi < v_end ? (uint32_t)srow[vi - v_begin] : 0u;
+            bool v = (vi < v_end) && b_tv[i];
             int b = b0, z = z0, y = y0, x = x0 + i * RPB;
             if (fast) {
                 if (x >= g.Wo) { x -= g.Wo; if (++y >= g.Ho) { y = 0; if (++z >= g.Do) { z = 0; ++b; } } }
@@ -804,9 +820,12 @@ static int g_use_glds = 1;
 
 template <typename T, typename TO>
 static int launch_conv(const void* in, const void* wt, void* out, const float* bias, const void* addend,
-                       const ConvGeom& g, int relu, int Da, int Ha, int Wa, int add_shift, hipStream_t st)
+                       const ConvGeom& g, int relu, int Da, int Ha, int Wa, int add_shift, hipStream_t st,
+                       const int* rowlist = nullptr, uint32_t nrows_in = 0)
 {
-    const int tilesM = (g.M + 127) / 128;
+    const uint32_t nrows = rowlist ? nrows_in : g.M;
+    const int tilesM = (nrows + 127) / 128;
+    if (rowlist && nrows == 0) return DREG_OK;
     if constexpr (sizeof(T) == 2) {
         const uint64_t in_bytes = (uint64_t)g.B * g.Di * g.Hi * g.Wi * g.Cin * 2, wt_bytes = (uint64_t)g.Cout * g.Kpad * 2;
         if (g_use_glds && g.sd == 1 && g.Cin % 64 == 0 && g.ntaps <= 32 && in_bytes < 0x7fffff00ull && wt_bytes < 0x7fffff00ull) {
@@ -816,22 +835,23 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
                 if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<TO, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 256) * 128); attr_set = true; }
                 hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, 256>), dim3(tilesM * tilesN), dim3(512), 2 * (128 + 256) * 128, st,
                                    (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN,
-                                   (uint32_t)in_bytes, (uint32_t)wt_bytes);
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows);
             } else if (g.Cout % 128 == 0) {
                 const int tilesN = g.Cout / 128;
                 hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, 128>), dim3(tilesM * tilesN), dim3(256), 2 * (128 + 128) * 128, st,
                                    (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN,
-                                   (uint32_t)in_bytes, (uint32_t)wt_bytes);
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows);
             } else if (g.Cout % 64 == 0) {
                 const int tilesN = g.Cout / 64;
                 hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, 64>), dim3(tilesM * tilesN), dim3(256), 2 * (128 + 64) * 128, st,
                                    (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN,
-                                   (uint32_t)in_bytes, (uint32_t)wt_bytes);
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows);
             } else return DREG_EINVAL;
             DREG_LAUNCH_CHECK();
             return DREG_OK;
         }
     }
+    if (rowlist) return DREG_EINVAL;  // row lists are served by the direct-to-LDS kernel only
     if (g.Cout % 128 == 0) {
         const int tilesN = g.Cout / 128;
         const size_t lds = 2 * (128 + 128) * 128;
@@ -932,9 +952,10 @@ size_t dreg_conv3d_wgrad_workspace_bytes(int B, int Do, int Ho, int Wo, int Cin,
 
 // dW[Cout][Cin_real][ntaps] (torch layout, fp32) (+)= sum_m gout[m][:]^T x gathered in[m][tap][:]
 // gout: [B,Do,Ho,Wo,Cout], in: [B,Di,Hi,Wi,Cin] (same dtype).  use_tr: 1 = LDS transpose reads (bf16 only).
-int dreg_conv3d_wgrad(const void* gout, const void* in, float* dw, void* workspace, size_t workspace_bytes,
+static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspace, size_t workspace_bytes,
                       int B, int Di, int Hi, int Wi, int Cin, int Cin_real, int Do, int Ho, int Wo, int Cout,
-                      int ksz, int stride, int pad, int accumulate, int dtype, int use_tr, void* stream)
+                      int ksz, int stride, int pad, int accumulate, int dtype, int use_tr, void* stream,
+                      const int* rowlist, uint32_t nrows_list)
 {
     ConvGeom g;
     const int es = dtype == 0 ? 2 : 4;
@@ -943,9 +964,12 @@ int dreg_conv3d_wgrad(const void* gout, const void* in, float* dw, void* workspa
     if (Cout % 128 != 0 && Cout != 64) return DREG_EINVAL;
     if (workspace_bytes < dreg_conv3d_wgrad_workspace_bytes(B, Do, Ho, Wo, Cin, Cout, ksz, dtype)) return DREG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    const uint32_t nrows = rowlist ? nrows_list : g.M;
+    if (rowlist && !(dtype == 0 && use_tr && g_use_glds)) return DREG_EINVAL;
     const int nsplit = dreg_conv3d_wgrad_splits(B, Do, Ho, Wo, Cin, Cout, ksz, dtype);
-    uint32_t vps = (uint32_t)((g.M + nsplit - 1) / nsplit);
+    uint32_t vps = (uint32_t)((nrows + nsplit - 1) / nsplit);
     vps = ((vps + 63) / 64) * 64;
+    if (vps == 0) vps = 64;
     const int bm = (Cout % 128 == 0) ? 128 : 64;
     const int tilesRow = Cout / bm;
     const int bnc = (g.Kpad % 128 == 0) ? 128 : 64;
@@ -961,7 +985,17 @@ int dreg_conv3d_wgrad(const void* gout, const void* in, float* dw, void* workspa
         else WG_LAUNCH(T, 64, 64, TRv); } while (0)
     const uint64_t gbytes = (uint64_t)g.M * Cout * 2, ibytes = (uint64_t)B * Di * Hi * Wi * Cin * 2;
     if (dtype == 0 && use_tr && g_use_glds && gbytes < 0x7fffff00ull && ibytes < 0x7fffff00ull) {
-#define WGG(BMv, BNv) hipLaunchKernelGGL((conv_wgrad_glds_kernel<BMv, BNv>), dim3(tilesRow * tilesCol * nsplit), dim3(256), (size_t)2 * 64 * (bm + bnc) * 2, st, (const bf16_t*)gout, (const bf16_t*)in, part, g, tilesCol, tilesRow * tilesCol, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes)
+#define WGG(BMv, BNv) do { if (rowlist) hipLaunchKernelGGL((conv_wgrad_glds_kernel<BMv, BNv, true>), dim3(tilesRow * tilesCol * nsplit), dim3(256), (size_t)2 * 64 * (bm + bnc) * 2 + (size_t)vps * 4, st, (const bf16_t*)gout, (const bf16_t*)in, part, g, tilesCol, tilesRow * tilesCol, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows); \
+        else hipLaunchKernelGGL((conv_wgrad_glds_kernel<BMv, BNv, false>), dim3(tilesRow * tilesCol * nsplit), dim3(256), (size_t)2 * 64 * (bm + bnc) * 2, st, (const bf16_t*)gout, (const bf16_t*)in, part, g, tilesCol, tilesRow * tilesCol, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows); } while (0)
+        if (rowlist && vps > 20480) return DREG_EINVAL;   // the row-list slice must fit in LDS behind the stages (caller falls back to dense)
+        if (rowlist) {
+            const int ldsr = 2 * 64 * (bm + bnc) * 2 + (int)vps * 4;
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<128, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<64, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<64, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)ldsr;
+        }
         if (bm == 128 && bnc == 128) WGG(128, 128); else if (bm == 128 && bnc == 64) WGG(128, 64);
         else if (bm == 64 && bnc == 128) WGG(64, 128); else WGG(64, 64);
 #undef WGG
@@ -976,6 +1010,42 @@ int dreg_conv3d_wgrad(const void* gout, const void* in, float* dw, void* workspa
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, part, dw, nsplit, Cout, g.Kpad, g.ntaps, Cin, g.log2Cin, Cin_real, accumulate);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
+}
+
+int dreg_conv3d_wgrad(const void* gout, const void* in, float* dw, void* workspace, size_t workspace_bytes,
+                      int B, int Di, int Hi, int Wi, int Cin, int Cin_real, int Do, int Ho, int Wo, int Cout,
+                      int ksz, int stride, int pad, int accumulate, int dtype, int use_tr, void* stream)
+{
+    return wgrad_impl(gout, in, dw, workspace, workspace_bytes, B, Di, Hi, Wi, Cin, Cin_real, Do, Ho, Wo, Cout, ksz, stride, pad,
+                      accumulate, dtype, use_tr, stream, nullptr, 0);
+}
+
+// ---- active-set ("row list") forms, bf16, stride 1: only the output voxels rows[0..nrows) (ascending int32 flat indices
+// b*Do*Ho*Wo + ...) are computed / reduced over; the other rows of `out` are left untouched.  Used for the two FPN head
+// convolutions whose outputs are consumed only around the occupied voxels (nerf_regtr.py:138-147).
+int dreg_conv3d_igemm_rows(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
+                           const int* rows, int nrows,
+                           int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                           int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
+                           int out_f32, void* stream)
+{
+    ConvGeom g;
+    int rc = fill_geom(g, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, ksz, stride, pad, transposed, 2);
+    if (rc) return rc;
+    if (!rows || nrows < 0) return DREG_EINVAL;
+    const int add_shift = add_same ? 0 : 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (out_f32) return launch_conv<bf16_t, float>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st, rows, (uint32_t)nrows);
+    return launch_conv<bf16_t, bf16_t>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st, rows, (uint32_t)nrows);
+}
+int dreg_conv3d_wgrad_rows(const void* gout, const void* in, float* dw, void* workspace, size_t workspace_bytes,
+                           const int* rows, int nrows,
+                           int B, int Di, int Hi, int Wi, int Cin, int Cin_real, int Do, int Ho, int Wo, int Cout,
+                           int ksz, int stride, int pad, int accumulate, void* stream)
+{
+    if (!rows || nrows < 0) return DREG_EINVAL;
+    return wgrad_impl(gout, in, dw, workspace, workspace_bytes, B, Di, Hi, Wi, Cin, Cin_real, Do, Ho, Wo, Cout, ksz, stride, pad,
+                      accumulate, 0, 1, stream, rows, (uint32_t)nrows);
 }
 
 }  // extern "C"

@@ -37,6 +37,8 @@ SIGNATURES = {
     "dreg_conv3d_wgrad_splits": (I, [I] * 8),
     "dreg_conv3d_wgrad_workspace_bytes": (Z, [I] * 8),
     "dreg_conv3d_wgrad": (I, [P, P, P, P, Z] + [I] * 16 + [P]),
+    "dreg_conv3d_igemm_rows": (I, [P] * 5 + [P, I] + [I] * 18 + [I, P]),
+    "dreg_conv3d_wgrad_rows": (I, [P, P, P, P, Z] + [P, I] + [I] * 14 + [P]),
     # fpn_ops.hip
     "dreg_bn_num_chunks": (I, [I]),
     "dreg_bn3d_fwd": (I, [P] * 10 + [I, I, I, F, F, I, I, I, P]),

@@ -251,6 +251,122 @@ def conv3d(x, w, bias=None, addend=None, stride=1, pad=0):
     return Conv3dFn.apply(x, w, bias, addend, stride, pad)
 
 
+# --------------------------------------------------------------------------- active-set convolution (row lists)
+def _igemm_rows(x, wpk, bias, addend, out, rows, cin, cout, ksz, pad, transposed, flop_cin=None):
+    lib = L.load()
+    B, Di, Hi, Wi = x.shape[:4]
+    Do, Ho, Wo = out.shape[1:4]
+    Da = Ha = Wa = 0
+    if addend is not None:
+        Da, Ha, Wa = addend.shape[1:4]
+    ev = None
+    if PROFILER is not None:
+        label = f"{'dgrad' if transposed else 'fwd'}-rows B{B} {Di}x{Hi}x{Wi}x{cin}->{Do}x{Ho}x{Wo}x{cout} k{ksz} rows{rows.shape[0]}"
+        ev = PROFILER.record(f"conv_igemm_kernel<bf16,bf16,{128 if cout % 128 == 0 else 64}>", label,
+                             2.0 * rows.shape[0] * cout * (ksz ** 3) * (flop_cin or cin))
+        ev[0].record()
+    L.check(lib.dreg_conv3d_igemm_rows(L.ptr(x), L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(addend), L.ptr(rows), rows.shape[0],
+                                       B, Di, Hi, Wi, cin, Do, Ho, Wo, cout, ksz, 1, pad, int(transposed), 0, Da, Ha, Wa, 0, 0,
+                                       L.stream()), "dreg_conv3d_igemm_rows")
+    if ev is not None:
+        ev[1].record()
+    return out
+
+
+class SparseConv3dFn(torch.autograd.Function):
+    """Stride-1 conv3d evaluated on an active set: the forward computes only the output voxels `out_rows`; the backward's
+    input gradient is non-zero only on `in_rows` (= out_rows dilated by the kernel footprint) and the weight gradient is
+    reduced over `out_rows`.  Contract: the incoming gradient is zero outside `out_rows` (true for the FPN head: it comes
+    from the trilinear-gather backward, or from the data gradient of the next active-set convolution)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, addend, pad: int, out_rows, in_rows):
+        dt = L.dt_of(x)
+        assert dt == L.DT_BF16, "active-set convolutions are built for the bf16 production mode"
+        cin, cout, ksz = x.shape[4], w.shape[0], w.shape[2]
+        wpk = packed_weight(w, cin, False, dt)
+        b32 = bias.detach().float().contiguous() if bias is not None else None
+        y = torch.empty(x.shape[0], x.shape[1], x.shape[2], x.shape[3], cout, dtype=x.dtype, device=x.device)
+        _igemm_rows(x, wpk, b32, addend, y, out_rows, cin, cout, ksz, pad, False, flop_cin=w.shape[1])
+        ctx.save_for_backward(x, w, out_rows, in_rows)
+        ctx.bias_ref = bias if (bias is not None and bias.is_leaf) else None
+        ctx.cfg = (pad, ksz, bias is not None, None if addend is None else tuple(addend.shape[1:4]))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, out_rows, in_rows = ctx.saved_tensors
+        pad, ksz, has_bias, add_shape = ctx.cfg
+        lib = L.load()
+        gy = gy.contiguous()
+        cin, cout = x.shape[4], w.shape[0]
+        gx = gw = gb = ga = None
+        if ctx.needs_input_grad[0]:
+            wpk = packed_weight(w, cin, True, L.DT_BF16)
+            gx = torch.zeros_like(x)
+            _igemm_rows(gy, wpk, None, None, gx, in_rows, cout, cin, ksz, pad, True)
+        if ctx.needs_input_grad[1]:
+            B, Di, Hi, Wi = x.shape[:4]
+            nbytes = lib.dreg_conv3d_wgrad_workspace_bytes(B, Di, Hi, Wi, cin, cout, ksz, 0)
+            ws = _ws(nbytes, x.device)
+            sink = _grad_sink(w)
+            gw_t = sink if sink is not None else torch.empty(tuple(w.shape), dtype=torch.float32, device=x.device)
+            ev = None
+            if PROFILER is not None:
+                ev = PROFILER.record("conv_wgrad_kernel<bf16>+reduce", f"wgrad-rows B{B} {Di}x{Hi}x{Wi}x{cin} g{cout} k{ksz} rows{out_rows.shape[0]}",
+                                     2.0 * out_rows.shape[0] * cout * (ksz ** 3) * w.shape[1])
+                ev[0].record()
+            L.check(lib.dreg_conv3d_wgrad_rows(L.ptr(gy), L.ptr(x), L.ptr(gw_t), L.ptr(ws), nbytes, L.ptr(out_rows), out_rows.shape[0],
+                                               B, Di, Hi, Wi, cin, w.shape[1], Di, Hi, Wi, cout, ksz, 1, pad, int(sink is not None),
+                                               L.stream()), "dreg_conv3d_wgrad_rows")
+            if ev is not None:
+                ev[1].record()
+            gw = None if sink is not None else gw_t
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = colsum(gy.view(-1, cout), accumulate_into=_grad_sink(ctx.bias_ref) if ctx.bias_ref is not None else None)
+        if add_shape is not None and ctx.needs_input_grad[3]:
+            ga = downsample_sum(gy, add_shape)
+        return gx, gw, gb, ga, None, None, None
+
+
+def conv3d_rows(x, w, bias, addend, pad, out_rows, in_rows):
+    return SparseConv3dFn.apply(x, w, bias, addend, pad, out_rows, in_rows)
+
+
+def active_sets(idx_list, fine_res, coarse_dims, device):
+    """Row lists for the FPN head: S1 = trilinear-gather corner voxels of the occupied fine voxels (where P1 is consumed),
+    S2 = S1 dilated by 3^3 (where the lateral sum is consumed), S3 = S2 dilated (where dc1 of the head is non-zero).
+    idx_list: per grid int64 flat fine indices ((x*Yr + y)*Zr + z).  Returns three ascending int32 tensors of flat indices
+    into [B, d, h, w].  The corner arithmetic repeats tri_axis() of fpn_ops.hip in float32 bit for bit."""
+    import torch.nn.functional as F
+    Zr, Xr, Yr = fine_res
+    d, h, w = coarse_dims
+    B = len(idx_list)
+    flags = torch.zeros(B, d, h, w, dtype=torch.bool, device=device)
+
+    def axis(i, n_out, n_in):
+        s = (torch.tensor(float(n_in - 1), dtype=torch.float32) / torch.tensor(float(n_out - 1), dtype=torch.float32)).item() if n_out > 1 else 0.0
+        f = i.to(torch.float32) * torch.tensor(s, dtype=torch.float32, device=device)
+        i0 = f.to(torch.int64).clamp_(max=n_in - 1)
+        return i0, (i0 + 1).clamp_(max=n_in - 1)
+
+    for b, f in enumerate(idx_list):
+        z, y, x = f % Zr, (f // Zr) % Yr, f // (Zr * Yr)
+        zs, xs, ys = axis(z, Zr, d), axis(x, Xr, h), axis(y, Yr, w)
+        for zi in zs:
+            for xi in xs:
+                for yi in ys:
+                    flags[b, zi, xi, yi] = True
+    f1 = flags.float()[:, None]
+    f2 = F.max_pool3d(f1, 3, 1, 1)
+    f3 = F.max_pool3d(f2, 3, 1, 1)
+    to_rows = lambda t: torch.nonzero(t.flatten() > 0)[:, 0].to(torch.int32).contiguous()
+    s1, s2, s3 = to_rows(f1), to_rows(f2), to_rows(f3)
+    if s3.shape[0] > 0.2 * B * d * h * w:   # dense scenes: the row lists stop paying (and the wgrad slice cap applies)
+        return None
+    return s1, s2, s3
+
+
 def linear(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = False, residual=None,
            out_f32: bool = False) -> torch.Tensor:
     """[N, Cin] x [Cout, Cin]^T (+bias) (+residual) (relu) through the 1x1x1 path of the same kernels."""

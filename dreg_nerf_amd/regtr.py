@@ -93,6 +93,9 @@ class NeRFRegTr(nn.Module):
         self.num_downsample = num_downsample
         self.pos_emb_scaling = pos_emb_scaling
         self.precision = precision
+        # Evaluate the two FPN head convolutions only where their outputs are consumed (around the occupied voxels):
+        # identical results, a fraction of the FLOPs.  False = dense 64^3 evaluation (the BASELINE.md FLOP accounting).
+        self.active_set = True
         self._spec = params.regtr_spec()
         _build_tree(self, self._spec)
         _reset_parameters(self, self._spec)
@@ -108,8 +111,10 @@ class NeRFRegTr(nn.Module):
         return d
 
     # ------------------------------------------------------------------ A1/A2: FPN3D over a batch of grids
-    def fpn(self, x: torch.Tensor) -> torch.Tensor:
-        """x: [B, D, H, W, 8] (rgba + 4 zero channels), activation dtype.  Returns P1 [B, D/2, H/2, W/2, 256]."""
+    def fpn(self, x: torch.Tensor, rows=None) -> torch.Tensor:
+        """x: [B, D, H, W, 8] (rgba + 4 zero channels), activation dtype.  Returns P1 [B, D/2, H/2, W/2, 256].
+        rows = (S1, S2, S3) from ops.active_sets: the two head convolutions are evaluated on the active set only
+        (P1 is then defined on S1, which is all the trilinear gather reads)."""
         P = self._P()
         train = self.training
         r = "fpn3d.backbone_net."
@@ -146,7 +151,12 @@ class NeRFRegTr(nn.Module):
         p4 = conv("upsample_transform_4", conv("pyramid_transformation_4", c4, 0, addend=p5), 1)
         p3 = conv("upsample_transform_3", conv("pyramid_transformation_3", c3, 0, addend=p4), 1)
         p2 = conv("upsample_transform_2", conv("pyramid_transformation_2", c2, 0, addend=p3), 1)
-        p1 = conv("upsample_transform_1", conv("pyramid_transformation_1", c1, 1, addend=p2), 1)
+        if rows is None:
+            p1 = conv("upsample_transform_1", conv("pyramid_transformation_1", c1, 1, addend=p2), 1)
+        else:
+            s1, s2, s3 = rows
+            lat1 = ops.conv3d_rows(c1, P[q + "pyramid_transformation_1.weight"], P[q + "pyramid_transformation_1.bias"], p2, 1, s2, s3)
+            p1 = ops.conv3d_rows(lat1, P[q + "upsample_transform_1.weight"], P[q + "upsample_transform_1.bias"], None, 1, s1, s2)
         return p1
 
     @staticmethod
@@ -174,7 +184,10 @@ class NeRFRegTr(nn.Module):
                 xyzs.append(g[:, :3].permute(0, 3, 4, 2, 1).reshape(-1, 3)[m])
         res = tuple(grids[0].shape[-3:])
         A.set_precision(self.precision)
-        p1 = self.fpn(self.pack_grids(grids, self.act_dtype))
+        rows = None
+        if self.active_set and self.precision == "bf16":
+            rows = ops.active_sets(idxs, res, tuple((r + 1) // 2 for r in res), dev)
+        p1 = self.fpn(self.pack_grids(grids, self.act_dtype), rows)
         feats = ops.trilinear_gather(p1, torch.cat(idxs).contiguous(), torch.cat(pbatch), res)
         P = self._P()
         # A4 per pair (its stopping rule is per pair), then the whole point-set half once for all pairs

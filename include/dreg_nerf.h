@@ -62,6 +62,20 @@ int dreg_conv3d_wgrad(const void* gout, const void* in, float* dw, void* workspa
                       int B, int Di, int Hi, int Wi, int Cin, int Cin_real, int Do, int Ho, int Wo, int Cout,
                       int ksz, int stride, int pad, int accumulate, int dtype, int use_tr, void* stream);
 
+/* Active-set ("row list") forms, bf16, stride 1: only the output voxels rows[0..nrows) (ascending int32 flat indices into
+ * B*Do*Ho*Wo, device memory) are computed / reduced over; other rows of `out` are left untouched.  Used for the two FPN head
+ * convolutions, whose outputs feed only the trilinear gather at the occupied voxels (nerf_regtr.py:138-147) — identical
+ * results, work proportional to the occupied surface instead of the 64^3 volume. */
+int dreg_conv3d_igemm_rows(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
+                           const int* rows, int nrows,
+                           int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                           int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
+                           int out_f32, void* stream);
+int dreg_conv3d_wgrad_rows(const void* gout, const void* in, float* dw, void* workspace, size_t workspace_bytes,
+                           const int* rows, int nrows,
+                           int B, int Di, int Hi, int Wi, int Cin, int Cin_real, int Do, int Ho, int Wo, int Cout,
+                           int ksz, int stride, int pad, int accumulate, void* stream);
+
 /* ---------------------------------------------------------------------------------------------- FPN3D companions
  * BatchNorm3d with the reference's one-grid-per-call statistics (resnet3d.py:121,159; nerf_regtr.py:135), fused
  * residual add + ReLU (resnet3d.py:95-113). x,res,y: [B,V,C]; scale_shift, mean_rstd: fp32 [B,C,2] (saved for bwd);

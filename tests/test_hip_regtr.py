@@ -93,3 +93,31 @@ def test_e2e_eval32_bf16_close_to_fp32(golden_dir):
     assert out["src_kp"][0].shape[0] == int(g["n_src"])
     err = np.abs(out["pose"][-1].cpu().numpy() - g["pose"][-1]).max()
     assert err < 0.05, err
+
+
+def test_active_set_head_equals_dense_head():
+    """bf16: evaluating the two FPN head convolutions on the active set (rows around the occupied voxels) gives the same
+    outputs and parameter gradients as the dense 64^3 evaluation."""
+    data = synth.shell_pair(64, 1, 2, pose=synth.fixed_pose())
+    res = {}
+    for mode in (False, True):
+        m = _model("bf16", True)
+        m.active_set = mode
+        pred = m(_to(data, "cuda"))
+        loss = (pred["src_kp_warped"][0] ** 2).sum() + pred["tgt_overlap"][0].sum() + (pred["src_feats"][0][-1] ** 2).mean()
+        loss.backward()
+        named = dict(m.named_parameters())
+        res[mode] = (pred["src_kp_warped"][0].detach().cpu(), pred["pose"].cpu(),
+                     {k: named[k].grad.float().cpu() for k in ("fpn3d.feature_pyramid.upsample_transform_1.weight",
+                                                              "fpn3d.feature_pyramid.pyramid_transformation_1.weight",
+                                                              "fpn3d.feature_pyramid.pyramid_transformation_1.bias",
+                                                              "fpn3d.backbone_net.conv1.weight",
+                                                              "fpn3d.backbone_net.layer2.0.conv2.weight")})
+    assert torch.equal(res[False][0], res[True][0])       # forward: bit-identical key-point predictions
+    assert torch.equal(res[False][1], res[True][1])
+    # gradients: the head's own parameters agree to reduction-order noise; deep ResNet gradients additionally see the
+    # run-to-run noise of the fp32 atomics in the trilinear-gather backward amplified by train-mode BatchNorm (DESIGN.md §4)
+    for k in res[False][2]:
+        a, b = res[False][2][k], res[True][2][k]
+        tol = 2e-3 if "feature_pyramid" in k else 1e-1
+        assert (a - b).norm() <= tol * a.norm() + 1e-6, (k, float((a - b).norm()), float(a.norm()))
