@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-res", type=int, default=64, help="resolution of the bounded CPU sample")
     ap.add_argument("--kernel-report", default="", help="write the per-kernel/per-shape event timing table here")
+    ap.add_argument("--no-dense-reference", action="store_true", help="skip the additional dense-head measurement")
     ap.add_argument("--dense-head", action="store_true", help="evaluate the FPN head densely (BASELINE.md FLOP accounting) instead of on the active set")
     return ap.parse_args()
 
@@ -91,7 +92,6 @@ def main():
 
     torch.manual_seed(3407)
     model = NeRFRegTr(precision=args.precision).to(dev).train()
-    model.active_set = not args.dense_head
     if world > 1:  # identical initial weights on every rank
         for p in model.parameters():
             dist.broadcast(p.data, 0)
@@ -110,30 +110,44 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        ts.step(batch)
-    sync()
-    ops.PROFILER = ops.KernelTimer()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ts.step(batch)
-    sync()
-    elapsed = time.perf_counter() - t0
-    prof, ops.PROFILER = ops.PROFILER, None
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(active_set: bool):
+        model.active_set = active_set
+        for _ in range(args.warmup):
+            ts.step(batch)
+        sync()
+        ops.PROFILER = ops.KernelTimer()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ts.step(batch)
+        sync()
+        el = time.perf_counter() - t0
+        pr, ops.PROFILER = ops.PROFILER, None
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, pr
+
+    peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else 157.3
+
+    def roofline_of(pr):
+        by_name, by_label = pr.summary()
+        name, (calls, ms, flops) = max(by_name.items(), key=lambda kv: kv[1][1])
+        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                "launches": calls, "avg_launch_ms": ms / max(calls, 1), "algorithmic_flops_per_launch": flops / max(calls, 1)}, by_label
+
+    # the second, dense-head measurement keeps the BASELINE.md FLOP accounting (8.5 TFLOP per pair) comparable
+    dense = None
+    if not args.dense_head and args.precision == "bf16" and not args.no_dense_reference:
+        el_d, pr_d = timed(False)
+        if rank == 0:
+            rf_d, _ = roofline_of(pr_d)
+            dense = {"value": args.pairs * world * args.steps / el_d, "unit": "pairs/s", "ms_per_step": 1e3 * el_d / args.steps, "roofline": rf_d}
+    elapsed, prof = timed(not args.dense_head and args.precision == "bf16")
 
     if rank == 0:
-        by_name, by_label = prof.summary()
-        dom = max(by_name.items(), key=lambda kv: kv[1][1])
-        name, (calls, ms, flops) = dom
-        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else 157.3,
-                    "unit": "TFLOP/s", "frac": achieved / (MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else 157.3),
-                    "traffic": None, "launches": calls, "avg_launch_ms": ms / max(calls, 1),
-                    "algorithmic_flops_per_launch": flops / max(calls, 1)}
+        roofline, by_label = roofline_of(prof)
         if args.kernel_report:
             with open(args.kernel_report, "w") as f:
                 f.write("kernel\tshape\tcalls\ttotal_ms\tavg_ms\tTFLOP/s\n")
@@ -152,6 +166,8 @@ def main():
                        "parallelism": f"dp{world}"},
             "roofline": roofline,
         }
+        if dense is not None:
+            out["dense_head"] = dense
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_res, args.res)
         print(json.dumps(out), flush=True)
