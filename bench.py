@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--pairs", type=int, default=4, help="pairs per GPU per step (BASELINE batch = 4)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-res", type=int, default=64, help="resolution of the bounded CPU sample")
+    ap.add_argument("--cpu-res", type=int, default=0, help="resolution of the bounded CPU sample (0: 128 on hosts with >= 32 cores, else 64)")
     ap.add_argument("--kernel-report", default="", help="write the per-kernel/per-shape event timing table here")
     ap.add_argument("--no-dense-reference", action="store_true", help="skip the additional dense-head measurement")
     ap.add_argument("--dense-head", action="store_true", help="evaluate the FPN head densely (BASELINE.md FLOP accounting) instead of on the active set")
@@ -169,7 +169,8 @@ def main():
         if dense is not None:
             out["dense_head"] = dense
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_res, args.res)
+            cres = args.cpu_res or (128 if (os.cpu_count() or 1) >= 32 else 64)
+            out["cpu_baseline"] = cpu_baseline(min(cres, args.res), args.res)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
