@@ -82,6 +82,8 @@ SIGNATURES = {
     "dreg_ngp_rgb_mean_fwd": (I, [P] * 6 + [I, I, P]),
     "dreg_grid_scatter7": (I, [P] * 6 + [I, P]),
     "dreg_grid_sample_points": (I, [P, P, P, I, I, I, P, I, P]),
+    # visibility.hip
+    "dreg_surface_visibility": (I, [P] * 7 + [P] * 5 + [P, P, P] + [I] * 5 + [F, F, F, F, P]),
 }
 
 

@@ -249,10 +249,18 @@ class SampleGrid(nn.Module):
     @torch.no_grad()
     def query_radiance_and_density_from_camera(self, radiance_field, occupancy_grid, meta_data, device,
                                                density_thre: float = 0.7, cut_off: float = 0.5, jitter=None):
-        """Reference 6-tuple (sample_grid.py:343).  The ray-marched surface mask (sample_grid.py:244-318) is row N1 of
-        SURVEY.md §8(f), not built yet: every queried point is reported as surface-visible."""
+        """Reference 6-tuple (sample_grid.py:343): (world, rgb, alpha, indices, density_mask, surface_mask).
+        surface_mask: surface field >= cut_off from at least one training camera (sample_grid.py:244-318) through the fused
+        ray-march kernel (visibility.hip) when meta_data carries 'camera_poses' and 'render_step_size'; otherwise all True."""
         world, rgb, alpha, indices, density_mask = self.query_dense(radiance_field, device, density_thre, jitter)
-        surface_mask = torch.ones_like(density_mask)
+        if meta_data and "camera_poses" in meta_data and "render_step_size" in meta_data:
+            from . import visibility
+            cams = torch.as_tensor(meta_data["camera_poses"])[..., :3, 3].to(device)
+            surface_mask = visibility.surface_visibility(world, cams, radiance_field, self._binary.to(device), self._roi_aabb,
+                                                         meta_data.get("aabb", self._roi_aabb), meta_data["render_step_size"],
+                                                         cut_off, 1e-4, float(meta_data.get("alpha_thre", 0.0)))
+        else:
+            surface_mask = torch.ones_like(density_mask)
         return world, rgb, alpha, indices, density_mask, surface_mask
 
 

@@ -7,6 +7,7 @@ takes its own pairs, the flat gradient buffer is averaged with ~25 MB all-reduce
 (torch.distributed 'nccl'), the clip norm is computed on the averaged gradients, and every rank applies the
 identical update (optim.FlatAdamW: HIP grad-norm + AdamW kernels over one flat fp32 buffer).
 """
+import os
 from typing import Callable, List, Optional
 
 import torch
@@ -17,8 +18,21 @@ from . import synth
 from .optim import FlatAdamW, StepLR
 
 
+def nerf_labels(pred, data):
+    """train_nerf_regtr.py:186-199: overlap ground truth = surface-field visibility of the key points in their own NeRF block,
+    'tilde' scores = visibility of the predicted correspondences — all four through the fused ray-march kernel."""
+    from .visibility import compute_visibility_score
+    nl = pred["src_kp_warped"][0].shape[0]
+    with torch.no_grad():
+        s_gt = compute_visibility_score([pred["src_kp"][0].expand(nl, -1, -1)], data["src_nerf_path"])[0]
+        t_gt = compute_visibility_score([pred["tgt_kp"][0].expand(nl, -1, -1)], data["tgt_nerf_path"])[0]
+        s_tl = compute_visibility_score([pred["src_kp_warped"][0].detach()], data["src_nerf_path"])[0]
+        t_tl = compute_visibility_score([pred["tgt_kp_warped"][0].detach()], data["tgt_nerf_path"])[0]
+    return s_gt, t_gt, s_tl, t_tl
+
+
 def _default_labels(pred):
-    """Synthetic {0,1} visibility labels (the reference obtains them by NeRF ray marching — SURVEY §8(f) N1)."""
+    """Synthetic {0,1} visibility labels for data without NeRF blocks on disk (bench, synthetic scenes)."""
     s_kp, t_kp = pred["src_kp"][0], pred["tgt_kp"][0]
     with torch.no_grad():
         s_gt, t_gt = synth.synthetic_overlap_gt(s_kp), synth.synthetic_overlap_gt(t_kp)
@@ -54,7 +68,10 @@ class TrainStep:
         total = 0.0
         agg = {}
         for d, pred in zip(batch, preds):
-            s_gt, t_gt, s_tl, t_tl = self.label_fn(pred) if "overlap_labels" not in d else d["overlap_labels"]
+            if d.get("src_nerf_path") and os.path.exists(d["src_nerf_path"]) and os.path.exists(d.get("tgt_nerf_path", "")):
+                s_gt, t_gt, s_tl, t_tl = nerf_labels(pred, d)
+            else:
+                s_gt, t_gt, s_tl, t_tl = self.label_fn(pred)
             ls = LS.training_losses(pred, d["pose"], self.feature_loss, s_gt, t_gt, s_tl, t_tl, self.robust)
             total = total + ls["total"]
             for k, v in ls.items():

@@ -1,0 +1,74 @@
+"""Surface-field visibility labels from a NeRF block (row N1 of SURVEY.md §8f): the overlap ground truth of the training
+step (train_nerf_regtr.py:186-199 -> conerf/loss/confidence_loss.py:56-160) and the surface mask of grid extraction
+(conerf/register/sample_grid.py:244-318), both through the fused ray-march kernel of visibility.hip.
+
+The reference re-loads the block checkpoint from disk twice per call (confidence_loss.py:34-35,50); here loaded blocks are
+cached per path."""
+import ctypes
+from typing import Dict, List
+
+import torch
+
+from . import lib as L
+from . import ngp
+
+_block_cache: Dict[str, tuple] = {}
+
+
+def load_block(path: str, device):
+    """(NGPradianceField, occupancy binary [r,r,r] bool on device, meta dict) of a reference NeRF block checkpoint
+    (keys: train_ngp_nerf.py:187-209)."""
+    key = (path, str(device))
+    if key not in _block_cache:
+        ngp.install_pickle_shims()
+        state = torch.load(path, map_location="cpu", weights_only=False)
+        field = ngp.NGPradianceField(state["aabb"], unbounded=bool(state.get("unbounded", False)))
+        field.load_state_dict(state["model"], strict=False)
+        field = field.to(device).eval()
+        res = int(state.get("grid_resolution", 128))
+        occ = state["occupancy_grid"]
+        binary = (occ["_binary"] if "_binary" in occ else occ["binary"]).view(res, res, res).to(device)
+        meta = {k: state[k] for k in ("aabb", "render_step_size", "cone_angle", "alpha_thre", "camera_poses") if k in state}
+        _block_cache[key] = (field, binary, meta)
+    return _block_cache[key]
+
+
+@torch.no_grad()
+def surface_visibility(points: torch.Tensor, cam_centres: torch.Tensor, field: ngp.NGPradianceField, binary: torch.Tensor,
+                       roi_aabb, scene_aabb, render_step_size: float, cut_off: float = 0.5, early_stop_eps: float = 1e-4,
+                       alpha_thre: float = 0.0) -> torch.Tensor:
+    """points [Np,3], cam_centres [Nc,3] (device) -> bool [Np]: visible from at least one camera with surface field >= cut_off."""
+    lib = L.load()
+    base16, _ = field._prepared()
+    pts = points.reshape(-1, 3).contiguous().float()
+    cams = cam_centres.reshape(-1, 3).contiguous().float().to(pts.device)
+    label = torch.zeros(pts.shape[0], dtype=torch.int32, device=pts.device)
+    b8 = binary.to(torch.uint8).contiguous()
+    f6 = lambda v: (ctypes.c_float * 6)(*[float(t) for t in (v.tolist() if torch.is_tensor(v) else v)])
+    L.check(lib.dreg_surface_visibility(L.ptr(cams), L.ptr(pts), L.ptr(b8), L.ptr(label),
+                                        base16.data_ptr() + 3072 * 2, base16.data_ptr(), base16.data_ptr() + 2048 * 2,
+                                        *field._levels, f6(roi_aabb), f6(scene_aabb), f6(field.aabb),
+                                        b8.shape[0], b8.shape[1], b8.shape[2], cams.shape[0], pts.shape[0],
+                                        float(render_step_size), float(cut_off), float(early_stop_eps), float(alpha_thre), L.stream()),
+            "dreg_surface_visibility")
+    return label > 0
+
+
+@torch.no_grad()
+def compute_visibility_score(xyz_list: List[torch.Tensor], nerf_model_path: str, delta: float = 1e-2, cut_off: float = 0.5,
+                             score_type: str = "surface_field") -> List[torch.Tensor]:
+    """Reference signature (confidence_loss.py:56-62): list of [num_layers, N, 3] -> list of [num_layers, N, 1] float {0,1}."""
+    device = xyz_list[0].device
+    field, binary, meta = load_block(nerf_model_path, device)
+    out = []
+    for xyz in xyz_list:
+        nl, npnt = xyz.shape[0], xyz.shape[1]
+        if score_type == "density_field":
+            density, _ = field.query_raw(xyz.reshape(-1, 3))
+            out.append(torch.clip(1 - torch.exp(-delta * density), 0, 1).view(nl, npnt, 1))
+            continue
+        cams = meta["camera_poses"][..., :3, 3].to(device)
+        lab = surface_visibility(xyz.reshape(-1, 3), cams, field, binary, meta["aabb"], meta["aabb"], meta["render_step_size"],
+                                 cut_off, 1e-4, float(meta.get("alpha_thre", 0.0)))
+        out.append(lab.float().view(nl, npnt, 1))
+    return out

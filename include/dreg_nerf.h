@@ -201,6 +201,19 @@ int dreg_grid_sample_points(const int64_t* idx, const float* jitter, float* worl
 int dreg_grid_scatter7(const float* xyz, const float* rgb, const float* alpha, const int64_t* idx, const uint8_t* keep,
                        float* grid, int Np, void* stream);
 
+/* ---------------------------------------------------------------------------------------------- surface-field visibility (N1)
+ * One fused kernel for nerfacc.ray_aabb_intersect + _C.ray_marching + tcnn density + transmittance scan + scatter_max + threshold
+ * + max over cameras (conerf/utils/nerfacc_utils.py:84-222; conerf/loss/confidence_loss.py:56-160; conerf/register/sample_grid.py:244-318):
+ * label[p] |= (max over samples of alpha*T along the ray camera c -> point p, t in [t_min(scene aabb), |p - o_c|)) >= cut_off.
+ * cams fp32 [Nc,3], pts fp32 [Np,3], binary uint8 [rx,ry,rz] (occupancy grid), label int32 [Np] zeroed by the caller;
+ * table/w1/w2 = fp16 copies of mlp_base.params; level arrays and the three aabbs (grid roi, scene, model) are HOST pointers. */
+int dreg_surface_visibility(const float* cams, const float* pts, const uint8_t* binary, int* label,
+                            const void* table, const void* w1, const void* w2,
+                            const uint32_t* offset, const uint32_t* size, const uint32_t* res, const float* scale,
+                            const uint32_t* hashed, const float* roi_aabb, const float* scene_aabb, const float* model_aabb,
+                            int rx, int ry, int rz, int Nc, int Np, float render_step_size, float cut_off, float early_stop_eps,
+                            float alpha_thre, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
