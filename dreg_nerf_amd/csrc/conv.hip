@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 // buffer offset: the hardware bounds check of the raw buffer returns zeros into LDS.  Per-row tap validity is a
 // 27-bit mask computed once per block, so the K loop spends 3 VALU ops per row on addressing.
 // ------------------------------------------------------------------------------------------------
-template <typename TO, int BN>
+template <typename TO, int BM, int BN>
 __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
     const bf16_t* __restrict__ in, const bf16_t* __restrict__ wt, TO* __restrict__ out,
     const float* __restrict__ bias, const TO* __restrict__ addend, ConvGeom g,
@@ -225,9 +225,9 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
     const int* __restrict__ rowlist, uint32_t nrows)
 {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    constexpr int NW = BN == 256 ? 8 : 4, WAVES_N = BN == 256 ? 4 : 2;   // waves: 2 (M) x WAVES_N (N), 64 x (BN/WAVES_N) each
-    constexpr int BM = 128, BKe = 64, WN = BN / WAVES_N, TM = 4, TN = WN / 16;
-    constexpr int IA = 16 / NW, IBW = (BN / 8) / NW;                      // wave-instructions per wave per stage
+    constexpr int NW = BN == 256 ? 8 : 4, WAVES_N = BN == 256 ? 4 : 2;   // waves: 2 (M) x WAVES_N (N), (BM/2) x (BN/WAVES_N) each
+    constexpr int BKe = 64, WMt = BM / 2, WN = BN / WAVES_N, TM = WMt / 16, TN = WN / 16;
+    constexpr int IA = (BM / 8) / NW, IBW = (BN / 8) / NW;               // wave-instructions per wave per stage
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     constexpr uint32_t OOB = 0x7fffff00u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8_t af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sA + swz(wm * 64 + i * 16 + fr, ks * 4 + kg));
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sA + swz(wm * WMt + i * 16 + fr, ks * 4 + kg));
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(sB + swz(wn * WN + j * 16 + fr, ks * 4 + kg));
 #pragma unroll
@@ -327,57 +327,64 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
         compute(k & 1);
     }
 
-    // Epilogue through LDS: accumulators -> fp32 tile [128][BN] (16-column blocks XOR-ed with (row>>2)&1 so the two row groups
-    // of a 32-lane write phase hit different banks) -> coalesced 16-byte rows with bias / addend / ReLU applied in fp32.
-    __syncthreads();
+    // Epilogue through LDS, one pass per wave row (wm): accumulators -> fp32 tile [BM/2][BN] (16-column blocks XOR-ed with
+    // (row>>2)&1 so the two row groups of a 32-lane write phase hit different banks) -> coalesced 16-byte rows with
+    // bias / addend / ReLU applied in fp32.
     float* sC = reinterpret_cast<float*>(smem);
     const int col_l = lane & 15, rowq = (lane >> 4) * 4;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = wm * 64 + i * 16 + rowq + r;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int blk = (wn * WN + j * 16) >> 4;
-                sC[row * BN + ((blk ^ ((row >> 2) & 1)) << 4) + col_l] = acc[i][j][r];
-            }
-        }
-    __syncthreads();
     constexpr int CPR = BN / 8;                    // 8-column chunks per row
     constexpr int NTHR = BN == 256 ? 512 : 256;
-    for (int c = t; c < BM * CPR; c += NTHR) {
-        const int row = c / CPR, cc = (c - row * CPR) * 8;
-        if (m0 + row >= nrows) continue;
-        const uint32_t m = rowlist ? (uint32_t)rowlist[m0 + row] : m0 + row;
-        const float* src = sC + row * BN + ((((cc >> 4) ^ ((row >> 2) & 1)) << 4) | (cc & 8));
-        const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
-        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        const int n = n0 + cc;
-        if (bias) {
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+        if (wm == pass) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bias[n + e];
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i * 16 + rowq + r;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int blk = (wn * WN + j * 16) >> 4;
+                        sC[row * BN + ((blk ^ ((row >> 2) & 1)) << 4) + col_l] = acc[i][j][r];
+                    }
+                }
         }
-        if (addend) {
-            int b, z, y, x;
-            vox_decode(m, g, b, z, y, x);
-            const TO* ap = addend + ((size_t)((b * Da + (z >> add_shift)) * Ha + (y >> add_shift)) * Wa + (x >> add_shift)) * g.Cout + n;
+        __syncthreads();
+        for (int c = t; c < WMt * CPR; c += NTHR) {
+            const int lrow = c / CPR, cc = (c - lrow * CPR) * 8;
+            const int row = pass * WMt + lrow;
+            if (m0 + row >= nrows) continue;
+            const uint32_t m = rowlist ? (uint32_t)rowlist[m0 + row] : m0 + row;
+            const float* src = sC + lrow * BN + ((((cc >> 4) ^ ((lrow >> 2) & 1)) << 4) | (cc & 8));
+            const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const int n = n0 + cc;
+            if (bias) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += Elem<TO>::ld(ap + e);
-        }
-        if (relu) {
+                for (int e = 0; e < 8; ++e) v[e] += bias[n + e];
+            }
+            if (addend) {
+                int b, z, y, x;
+                vox_decode(m, g, b, z, y, x);
+                const TO* ap = addend + ((size_t)((b * Da + (z >> add_shift)) * Ha + (y >> add_shift)) * Wa + (x >> add_shift)) * g.Cout + n;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        TO* dst = out + (size_t)m * g.Cout + n;
-        if constexpr (sizeof(TO) == 4) {
-            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-            uint32_t w[4];
+                for (int e = 0; e < 8; ++e) v[e] += Elem<TO>::ld(ap + e);
+            }
+            if (relu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
-            *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            TO* dst = out + (size_t)m * g.Cout + n;
+            if constexpr (sizeof(TO) == 4) {
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+                uint32_t w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+                *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
         }
     }
 }
@@ -829,24 +836,19 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
     if constexpr (sizeof(T) == 2) {
         const uint64_t in_bytes = (uint64_t)g.B * g.Di * g.Hi * g.Wi * g.Cin * 2, wt_bytes = (uint64_t)g.Cout * g.Kpad * 2;
         if (g_use_glds && g.sd == 1 && g.Cin % 64 == 0 && g.ntaps <= 32 && in_bytes < 0x7fffff00ull && wt_bytes < 0x7fffff00ull) {
-            if (g.Cout % 256 == 0 && g_use_glds == 3 && tilesM >= 512) {
-                const int tilesN = g.Cout / 256;
-                static bool attr_set = false;
-                if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<TO, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 256) * 128); attr_set = true; }
-                hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, 256>), dim3(tilesM * tilesN), dim3(512), 2 * (128 + 256) * 128, st,
-                                   (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN,
-                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows);
-            } else if (g.Cout % 128 == 0) {
-                const int tilesN = g.Cout / 128;
-                hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, 128>), dim3(tilesM * tilesN), dim3(256), 2 * (128 + 128) * 128, st,
-                                   (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN,
-                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows);
-            } else if (g.Cout % 64 == 0) {
-                const int tilesN = g.Cout / 64;
-                hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, 64>), dim3(tilesM * tilesN), dim3(256), 2 * (128 + 64) * 128, st,
-                                   (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN,
-                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows);
-            } else return DREG_EINVAL;
+#define GL_LAUNCH(BMv, BNv, NT) do { \
+                const int tm_ = (nrows + BMv - 1) / BMv, tn_ = g.Cout / BNv; \
+                const size_t lds_ = (size_t)2 * (BMv + BNv) * 128; \
+                if (lds_ > 65536) (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<TO, BMv, BNv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+                hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, BMv, BNv>), dim3(tm_ * tn_), dim3(NT), lds_, st, \
+                                   (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tn_, \
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows); } while (0)
+            if (g.Cout % 256 == 0 && (g_use_glds == 1 || g_use_glds == 4) && nrows >= 65536) GL_LAUNCH(256, 256, 512);
+            else if (g.Cout % 256 == 0 && g_use_glds == 3 && nrows >= 65536) GL_LAUNCH(128, 256, 512);
+            else if (g.Cout % 128 == 0) GL_LAUNCH(128, 128, 256);
+            else if (g.Cout % 64 == 0) GL_LAUNCH(128, 64, 256);
+            else return DREG_EINVAL;
+#undef GL_LAUNCH
             DREG_LAUNCH_CHECK();
             return DREG_OK;
         }
@@ -893,8 +895,10 @@ int dreg_conv3d_igemm(const void* in, const void* wt_packed, void* out, const fl
     return launch_conv<float, float>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st);
 }
 
-// 1 (default): bf16 stride-1 convolutions use the direct-to-LDS kernel (128 x {128|64} tiles); 3: also the 8-wave 128x256
-// tile when Cout % 256 == 0 (measured equal to 128x128 in round 1); 0: always the register-staged kernel (A/B checks).
+// 1 (default): bf16 stride-1 convolutions use the direct-to-LDS kernel (8-wave 256x256 tile when Cout % 256 == 0 and the row
+// space is large, else 128 x {128|64}); 2: 128-row tiles only; 3: the 8-wave 128x256
+// tile when Cout % 256 == 0 (measured equal to 128x128 in round 1); 4: the 8-wave 256x256 tile (128x64 per wave);
+// 0: always the register-staged kernel (A/B checks).
 void dreg_conv_set_glds(int enable) { g_use_glds = enable; }
 
 // K padding of the packed weight row for (ntaps, Cin) at dtype.

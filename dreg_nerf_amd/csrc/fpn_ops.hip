@@ -30,6 +30,12 @@ template <> struct Gran<bf16_t> {
     }
 };
 
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------ BN statistics
 // partial[b][chunk][c][2] = (sum x, sum x^2) over the chunk's voxels.  grid (chunks, B, slabs), 256 threads.
 // MODE 0: plain sums of x.  MODE 1 (backward): sums of g and g*xhat with g = dy * (y > 0 if relu).
@@ -93,11 +99,6 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(
 // one wave per channel: finalise mean / biased var per grid (lanes stride over the chunk partials), update running stats
 // sequentially over the grids (reference: one grid per BatchNorm call, src then tgt — nerf_regtr.py:135), emit scale/shift
 // and (mean, rstd).
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ scale_shift, float* __restrict__ mean_rstd,
@@ -356,13 +357,14 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
         for (int i = 0; i < G; ++i) { float a = 0.f; for (int r = 0; r < rpi; ++r) a += red[r * cgs + t][i]; partial[(size_t)blockIdx.x * C + (size_t)cg * G + i] = a; }
     }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nchunks, int C, int accumulate)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nchunks, int C, int accumulate)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0.0;
-    for (int k = 0; k < nchunks; ++k) s += partial[(size_t)k * C + c];
-    out[c] = accumulate ? out[c] + (float)s : (float)s;
+    for (int k = lane; k < nchunks; k += 64) s += partial[(size_t)k * C + c];
+    s = wave_sum_d(s);
+    if (lane == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 // ------------------------------------------------------------------------------------------------ trilinear gather
@@ -444,7 +446,7 @@ static inline int nblocks(size_t total, int per = 256, int cap = 8192) {
     size_t b = (total + per - 1) / per;
     return (int)(b > (size_t)cap ? cap : (b ? b : 1));
 }
-static inline int bn_rows_per_chunk(int V) { return V >= 4096 ? 1024 : (V >= 256 ? 256 : V); }
+static inline int bn_rows_per_chunk(int V) { return V >= 262144 ? 512 : (V >= 256 ? 256 : V); }
 
 extern "C" {
 
@@ -546,7 +548,7 @@ int dreg_colsum(const void* g, float* out, float* workspace, size_t M, int C, in
     if (dtype == 0) hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3(nch, slabs), dim3(256), 0, st, (const bf16_t*)g, workspace, M, C, rpc);
     else hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(nch, slabs), dim3(256), 0, st, (const float*)g, workspace, M, C, rpc);
     DREG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 127) / 128), dim3(128), 0, st, workspace, out, nch, C, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, out, nch, C, accumulate);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

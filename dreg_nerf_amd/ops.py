@@ -113,6 +113,9 @@ def conv_igemm(x, wpk, bias, addend, out_shape, cin, cout, ksz, stride, pad, tra
     if PROFILER is not None:
         tn = "bf16" if dt == L.DT_BF16 else "f32"
         name = f"conv_igemm_kernel<{tn},{'f32' if odt == torch.float32 else 'bf16'},{128 if cout % 128 == 0 else 64}>"
+        if dt == L.DT_BF16 and stride == 1 and cin % 64 == 0:
+            bm, bn = (256, 256) if (cout % 256 == 0 and B * Do * Ho * Wo >= 65536) else (128, 128 if cout % 128 == 0 else 64)
+            name = f"conv_igemm_glds_kernel<{'f32' if odt == torch.float32 else 'bf16'},{bm},{bn}>"
         label = f"{'dgrad' if transposed else 'fwd'} B{B} {Di}x{Hi}x{Wi}x{cin}->{Do}x{Ho}x{Wo}x{cout} k{ksz}s{stride}"
         flops = 2.0 * B * Do * Ho * Wo * cout * (ksz ** 3) * (flop_cin or cin)
         if transposed and stride == 2:
@@ -262,7 +265,8 @@ def _igemm_rows(x, wpk, bias, addend, out, rows, cin, cout, ksz, pad, transposed
     ev = None
     if PROFILER is not None:
         label = f"{'dgrad' if transposed else 'fwd'}-rows B{B} {Di}x{Hi}x{Wi}x{cin}->{Do}x{Ho}x{Wo}x{cout} k{ksz} rows{rows.shape[0]}"
-        ev = PROFILER.record(f"conv_igemm_kernel<bf16,bf16,{128 if cout % 128 == 0 else 64}>", label,
+        bm, bn = (256, 256) if (cout % 256 == 0 and rows.shape[0] >= 65536) else (128, 128 if cout % 128 == 0 else 64)
+        ev = PROFILER.record(f"conv_igemm_glds_kernel<bf16,{bm},{bn}>", label,
                              2.0 * rows.shape[0] * cout * (ksz ** 3) * (flop_cin or cin))
         ev[0].record()
     L.check(lib.dreg_conv3d_igemm_rows(L.ptr(x), L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(addend), L.ptr(rows), rows.shape[0],

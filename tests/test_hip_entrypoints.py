@@ -43,12 +43,16 @@ def test_grid_extraction_from_block_checkpoint(tmp_path):
         f.mlp_base.params[3072:] = torch.randn(f.mlp_base.params.numel() - 3072, generator=g)
         f.color_mlp.params.copy_(torch.randn(7168, generator=g) * 0.2)
     binary = torch.rand(res, res, res, generator=torch.Generator().manual_seed(1)) < 0.05
+    cam_poses = torch.eye(4)[None].repeat(6, 1, 1)   # six cameras around the block, outside the aabb
+    cam_poses[:, :3, 3] = torch.tensor([[2.5, 0, 0], [-2.5, 0, 0], [0, 2.5, 0], [0, -2.5, 0], [0, 0, 2.5], [0, 0, -2.5]])
     torch.save({"step": 1, "model": f.state_dict(), "occupancy_grid": {"_binary": binary, "resolution": torch.tensor([res] * 3)},
                 "aabb": [-1.5] * 3 + [1.5] * 3, "unbounded": False, "grid_resolution": res,
                 "contraction_type": ngp.ContractionType.AABB, "render_step_size": 0.005, "alpha_thre": 0.0, "cone_angle": 0.0,
-                "camera_poses": torch.eye(4)[None], "block_id": 0}, str(d / "model.pth"))
+                "camera_poses": cam_poses, "block_id": 0}, str(d / "model.pth"))
     _run(["eval_ngp_nerf.py", "--root_dir", str(tmp_path), "--dataset", "objaverse", "--multi_blocks"])
     grid = torch.load(str(d / "voxel_grid.pt"))
     mask = torch.load(str(d / "voxel_mask.pt"))
-    assert grid.shape == (res, res, res, 7) and mask.dtype == torch.int64 and mask.numel() > 0
-    assert torch.all(binary.flatten()[mask])
+    assert grid.shape == (res, res, res, 7) and mask.dtype == torch.int64
+    assert torch.all(binary.flatten()[mask]) and torch.all(mask[1:] > mask[:-1])
+    # kept voxels = density mask AND surface-visible from a camera: a strict subset of the occupied cells here
+    assert 0 < mask.numel() < int(binary.sum())

@@ -194,3 +194,23 @@ def test_trilinear_gather():
     out.backward(gy.to(dev))
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-5)
     np.testing.assert_allclose(ncdhw(pd.grad.cpu()).numpy(), p1r.grad.numpy(), atol=2e-5)
+
+
+@pytest.mark.parametrize("mode", [3, 4])
+def test_conv_glds_large_tiles_match_default(mode):
+    """128x256 and 256x256 tile variants of the direct-to-LDS kernel == the 128x128 tile, bit for bit."""
+    from dreg_nerf_amd import lib as L
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 33, 32, 32, 256, generator=g).to(dev, torch.bfloat16)
+    w = (torch.randn(256, 256, 3, 3, 3, generator=g) * 0.02).to(dev)
+    b = torch.randn(256, generator=g).to(dev)
+    lib = L.load()
+    try:
+        lib.dreg_conv_set_glds(2)
+        ref = ops.conv3d(x, w, b, None, 1, 1)
+        lib.dreg_conv_set_glds(mode)
+        got = ops.conv3d(x, w, b, None, 1, 1)
+    finally:
+        lib.dreg_conv_set_glds(1)
+    assert torch.equal(ref, got)

@@ -24,7 +24,7 @@ for (D, cin, cout, k) in shapes:
     wp = ops.packed_weight(w, cin, False, 0)
     flops = 2.0 * B * D ** 3 * cout * cin * k ** 3
     res = {}
-    for glds in (0, 1, 3):
+    for glds in (2, 3, 4):
         lib.dreg_conv_set_glds(glds)
         ms = timeit(lambda: ops.conv_igemm(x, wp, None, None, (D, D, D), cin, cout, k, 1, k // 2, False))
         res[f"fwd_glds{glds}"] = (ms, flops / ms / 1e9)
