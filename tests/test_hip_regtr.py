@@ -121,3 +121,19 @@ def test_active_set_head_equals_dense_head():
         a, b = res[False][2][k], res[True][2][k]
         tol = 2e-3 if "feature_pyramid" in k else 1e-1
         assert (a - b).norm() <= tol * a.norm() + 1e-6, (k, float((a - b).norm()), float(a.norm()))
+
+
+def test_full_size_batch_invariance_128():
+    """BASELINE size (128^3, bf16, train-mode BatchNorm): a pair's outputs do not depend on which other pairs share the
+    step — the reference runs one grid per BatchNorm call (nerf_regtr.py:135) and the batched kernels must keep that."""
+    m = _model("bf16", True)
+    a = _to(synth.shell_pair(128, 1, 2, pose=synth.fixed_pose()), "cuda")
+    b = _to(synth.shell_pair(128, 3, 4, pose=synth.fixed_pose()), "cuda")
+    with torch.no_grad():
+        alone = m.forward_batch([a])[0]
+        both = m.forward_batch([b, a])[1]
+    assert alone["src_kp"][0].shape[0] > 1000 and alone["src_kp"][0].shape == both["src_kp"][0].shape
+    assert torch.equal(alone["src_kp"][0], both["src_kp"][0])
+    # the trilinear-gather outputs are bit-identical; the voxel means / attention see the same values in the same order
+    assert torch.equal(alone["pose"], both["pose"])
+    assert torch.equal(alone["src_overlap"][0], both["src_overlap"][0])
