@@ -334,6 +334,68 @@ def voxel_mean_downsample(points, feats, lengths, dl: float):
     return p, f, counts
 
 
+class SubsampleRound:
+    """One planned voxel-average round: everything that depends only on xyz (dreg_voxel_downsample_plan)."""
+    __slots__ = ("order", "starts", "n_out_dev", "inv_seg", "inv_cnt", "n_in", "n_out")
+
+
+def plan_voxel_downsample(points, lengths, dl: float):
+    """xyz-only half of voxel_mean_downsample: returns (round, averaged points [M,3], per-batch counts list)."""
+    lib = L.load()
+    lens = [int(v) for v in lengths]
+    dev = points.device
+    n = points.shape[0]
+    pt_batch = torch.repeat_interleave(torch.arange(len(lens), dtype=torch.int32, device=dev),
+                                       torch.tensor(lens, device=dev), output_size=n)
+    points = points.detach().contiguous()
+    r = SubsampleRound()
+    out_p = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    meta = torch.zeros(2 + len(lens), dtype=torch.int32, device=dev)  # n_out, err, counts...
+    r.inv_seg = torch.empty(n, dtype=torch.int32, device=dev)
+    r.inv_cnt = torch.empty(n, dtype=torch.float32, device=dev)
+    r.order = torch.empty(n, dtype=torch.int32, device=dev)
+    r.starts = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    nbytes = lib.dreg_voxel_downsample_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    L.check(lib.dreg_voxel_downsample_plan(L.ptr(points), L.ptr(pt_batch), L.ptr(out_p), meta.data_ptr(), meta.data_ptr() + 8,
+                                           L.ptr(r.inv_seg), L.ptr(r.inv_cnt), meta.data_ptr() + 4, L.ptr(r.order), L.ptr(r.starts),
+                                           L.ptr(ws), nbytes, n, len(lens), float(dl), L.stream()), "dreg_voxel_downsample_plan")
+    host = meta.tolist()  # the host sync of the round (the reference's .shape[0] test, grid_downsample.py:91)
+    if host[1]:
+        raise L.DregError("voxel coordinates overflow the 16-bit cell range")
+    r.n_out_dev = meta
+    r.n_in, r.n_out = n, host[0]
+    return r, out_p[:r.n_out], host[2:]
+
+
+class _SegmentMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, rnd):
+        lib = L.load()
+        feats = feats.contiguous()
+        assert feats.shape[0] == rnd.n_in and feats.dtype == torch.float32
+        c = feats.shape[1]
+        out = torch.empty(rnd.n_out, c, dtype=torch.float32, device=feats.device)
+        L.check(lib.dreg_voxel_segment_mean(L.ptr(feats), L.ptr(rnd.order), L.ptr(rnd.starts), L.ptr(rnd.n_out_dev), L.ptr(out),
+                                            rnd.n_out, c, L.stream()), "dreg_voxel_segment_mean")
+        ctx.rnd = rnd
+        return out
+
+    @staticmethod
+    def backward(ctx, gf):
+        rnd = ctx.rnd
+        lib = L.load()
+        gf = gf.contiguous()
+        gin = torch.empty(rnd.n_in, gf.shape[1], dtype=torch.float32, device=gf.device)
+        L.check(lib.dreg_voxel_downsample_bwd(L.ptr(gf), L.ptr(rnd.inv_seg), L.ptr(rnd.inv_cnt), L.ptr(gin), rnd.n_in, gf.shape[1], L.stream()),
+                "dreg_voxel_downsample_bwd")
+        return gin, None
+
+
+def segment_mean(feats, rnd: SubsampleRound):
+    return _SegmentMeanFn.apply(feats, rnd)
+
+
 def weighted_kabsch(a, b, w, eps: float = 1e-6):
     """a,b [P,N,3], w [P,N] -> [P,3,4] (no gradient: the pose enters no loss, train_nerf_regtr.py:186-228)."""
     lib = L.load()

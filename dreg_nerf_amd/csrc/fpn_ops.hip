@@ -591,3 +591,152 @@ int dreg_cast_from_f32(const float* in, void* out, size_t n, int dtype, void* st
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ active sets of the FPN head
+// S1 = coarse voxels touched by the trilinear gather (all 8 corners of every occupied fine voxel, tri_axis() above),
+// S2 = S1 dilated by the 3^3 footprint, S3 = S2 dilated again.  Output: three ascending int32 row lists (flat indices into
+// [B,d,h,w]) + their lengths, and map1[v] = rank of v in S1 (or -1).  One C call, no host round trip inside.
+__global__ void aset_mark_kernel(const int64_t* __restrict__ idx, const int* __restrict__ pt_batch, uint8_t* __restrict__ f1,
+                                 int N, int d, int h, int w, int Zr, int Xr, int Yr)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int64_t f = idx[n];
+    const int z = (int)(f % Zr), y = (int)((f / Zr) % Yr), x = (int)(f / ((int64_t)Zr * Yr));
+    const int b = pt_batch[n];
+    const TriAxis az = tri_axis(z, Zr, d), ax = tri_axis(x, Xr, h), ay = tri_axis(y, Yr, w);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int zi = (c & 4) ? az.i1 : az.i0, xi = (c & 2) ? ax.i1 : ax.i0, yi = (c & 1) ? ay.i1 : ay.i0;
+        f1[(((size_t)b * d + zi) * h + xi) * w + yi] = 1;
+    }
+}
+__global__ void aset_dilate_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int d, int h, int w)
+{
+    const size_t V = (size_t)B * d * h * w;
+    const size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const int yi = (int)(v % w), xi = (int)((v / w) % h), zi = (int)((v / ((size_t)w * h)) % d);
+    const size_t base = v - ((size_t)zi * h + xi) * w - yi;
+    uint8_t r = 0;
+    for (int dz = -1; dz <= 1; ++dz) {
+        const int zz = zi + dz;
+        if (zz < 0 || zz >= d) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = xi + dx;
+            if (xx < 0 || xx >= h) continue;
+            const uint8_t* row = in + base + ((size_t)zz * h + xx) * w;
+            r |= row[yi];
+            if (yi > 0) r |= row[yi - 1];
+            if (yi + 1 < w) r |= row[yi + 1];
+        }
+    }
+    out[v] = r;
+}
+// 3-kernel stable compaction of three flag arrays at once (blockIdx.y = which); 2048 flags per block
+constexpr int ASET_PER_BLOCK = 2048;
+__global__ __launch_bounds__(256) void aset_count_kernel(const uint8_t* __restrict__ flags, int* __restrict__ blk_counts, size_t V, int nblk)
+{
+    const uint8_t* f = flags + (size_t)blockIdx.y * V;
+    const size_t v0 = (size_t)blockIdx.x * ASET_PER_BLOCK + threadIdx.x * 8;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c += (v0 + k < V && f[v0 + k]) ? 1 : 0;
+    __shared__ int ws[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk_counts[blockIdx.y * nblk + blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ __launch_bounds__(1024) void aset_scan_kernel(int* __restrict__ blk_counts, int* __restrict__ counts, int nblk)
+{
+    // exclusive scan of blk_counts[which][0..nblk) in place; one block of 1024 threads per list, serial chunks per thread
+    int* bc = blk_counts + (size_t)blockIdx.x * nblk;
+    __shared__ int part[1024];
+    const int per = (nblk + 1023) / 1024, t = threadIdx.x;
+    const int i0 = t * per, i1 = min(i0 + per, nblk);
+    int s = 0;
+    for (int i = i0; i < i1; ++i) s += bc[i];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int i = i0; i < i1; ++i) { const int c = bc[i]; bc[i] = run; run += c; }
+    if (t == 1023) counts[blockIdx.x] = part[1023];
+}
+__global__ __launch_bounds__(256) void aset_write_kernel(const uint8_t* __restrict__ flags, const int* __restrict__ blk_counts,
+                                                         int* __restrict__ rows, int* __restrict__ map1, size_t V, int nblk)
+{
+    const int which = blockIdx.y;
+    const uint8_t* f = flags + (size_t)which * V;
+    int* out = rows + (size_t)which * V;
+    const size_t v0 = (size_t)blockIdx.x * ASET_PER_BLOCK + threadIdx.x * 8;
+    int c = 0;
+    uint8_t fl[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { fl[k] = (v0 + k < V) ? f[v0 + k] : 0; c += fl[k] ? 1 : 0; }
+    // block exclusive scan of c (256 threads)
+    __shared__ int sc[256];
+    sc[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = threadIdx.x >= o ? sc[threadIdx.x - o] : 0;
+        __syncthreads();
+        sc[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int pos = blk_counts[which * nblk + blockIdx.x] + sc[threadIdx.x] - c;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (v0 + k >= V) break;
+        if (fl[k]) {
+            out[pos] = (int)(v0 + k);
+            if (which == 0 && map1) map1[v0 + k] = pos;
+            ++pos;
+        } else if (which == 0 && map1) map1[v0 + k] = -1;
+    }
+}
+extern "C" {
+// workspace: 3*V flag bytes + 3*nblk ints (see dreg_active_sets_workspace_bytes).  rows: int32 [3][V] (list k starts at
+// rows + k*V); counts: device int32 [3]; map1: int32 [V] or NULL.
+size_t dreg_active_sets_workspace_bytes(int B, int d, int h, int w)
+{
+    const size_t V = (size_t)B * d * h * w;
+    const size_t nblk = (V + ASET_PER_BLOCK - 1) / ASET_PER_BLOCK;
+    return (3 * V + 255) / 256 * 256 + 3 * nblk * sizeof(int) + 256;
+}
+int dreg_active_sets(const int64_t* idx, const int* pt_batch, int N, int B, int Zr, int Xr, int Yr, int d, int h, int w,
+                     int* rows, int* counts, int* map1, void* workspace, size_t workspace_bytes, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const size_t V = (size_t)B * d * h * w;
+    if (V == 0 || V > 0x7fffffffull || N < 0) return DREG_EINVAL;
+    if (workspace_bytes < dreg_active_sets_workspace_bytes(B, d, h, w)) return DREG_EINVAL;
+    const int nblk = (int)((V + ASET_PER_BLOCK - 1) / ASET_PER_BLOCK);
+    uint8_t* flags = (uint8_t*)workspace;
+    int* blk = (int*)((char*)workspace + (3 * V + 255) / 256 * 256);
+    if (hipMemsetAsync(flags, 0, V, st) != hipSuccess) return DREG_ELAUNCH;
+    if (N > 0) {
+        hipLaunchKernelGGL(aset_mark_kernel, dim3((N + 255) / 256), dim3(256), 0, st, idx, pt_batch, flags, N, d, h, w, Zr, Xr, Yr);
+        DREG_LAUNCH_CHECK();
+    }
+    const unsigned nbv = (unsigned)((V + 255) / 256);
+    hipLaunchKernelGGL(aset_dilate_kernel, dim3(nbv), dim3(256), 0, st, flags, flags + V, B, d, h, w);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(aset_dilate_kernel, dim3(nbv), dim3(256), 0, st, flags + V, flags + 2 * V, B, d, h, w);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(aset_count_kernel, dim3(nblk, 3), dim3(256), 0, st, flags, blk, V, nblk);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(aset_scan_kernel, dim3(3), dim3(1024), 0, st, blk, counts, nblk);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(aset_write_kernel, dim3(nblk, 3), dim3(256), 0, st, flags, blk, rows, map1, V, nblk);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+}

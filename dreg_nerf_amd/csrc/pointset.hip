@@ -257,9 +257,19 @@ __global__ void segment_starts_kernel(const uint64_t* __restrict__ keys, const u
                                       uint32_t* __restrict__ starts, int* __restrict__ batch_counts, int* __restrict__ nseg, int N)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    if (head[i]) { starts[scan[i] - 1] = (uint32_t)i; atomicAdd(batch_counts + (int)(keys[i] >> 48), 1); }
+    const bool is_head = i < N && head[i];
+    const int b = is_head ? (int)(keys[i] >> 48) : -1;
+    if (is_head) starts[scan[i] - 1] = (uint32_t)i;
     if (i == N - 1) { *nseg = (int)scan[i]; starts[scan[i]] = (uint32_t)N; }
+    // one atomic per (wave, batch id) instead of one per segment head: keys are sorted, a wave sees very few distinct ids
+    unsigned long long todo = __ballot(is_head);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int b0 = __shfl(b, leader, 64);
+        const unsigned long long same = __ballot(is_head && b == b0);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(batch_counts + b0, (int)__popcll(same));
+        todo &= ~same;
+    }
 }
 // one wave per output row: mean over the segment's members (ascending original index = stable sort order)
 __global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restrict__ pts, const float* __restrict__ feats, const uint32_t* __restrict__ order,
@@ -271,14 +281,16 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restri
     if (seg >= *nseg) return;
     const uint32_t s0 = starts[seg], s1 = starts[seg + 1];
     const float inv = 1.f / (float)(s1 - s0);
-    for (int c0 = lane * 4; c0 < C; c0 += 256) {
-        float4 acc = make_float4(0, 0, 0, 0);
-        for (uint32_t j = s0; j < s1; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(feats + (size_t)order[j] * C + c0);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    if (feats != nullptr)
+        for (int c0 = lane * 4; c0 < C; c0 += 256) {
+            float4 acc = make_float4(0, 0, 0, 0);
+            for (uint32_t j = s0; j < s1; ++j) {
+                const float4 v = *reinterpret_cast<const float4*>(feats + (size_t)order[j] * C + c0);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            *reinterpret_cast<float4*>(out_feats + (size_t)seg * C + c0) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
         }
-        *reinterpret_cast<float4*>(out_feats + (size_t)seg * C + c0) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
-    }
+    if (pts == nullptr) return;
     if (lane < 3) {
         float acc = 0.f;
         for (uint32_t j = s0; j < s1; ++j) acc += pts[(size_t)order[j] * 3 + lane];
@@ -447,9 +459,10 @@ size_t dreg_voxel_downsample_workspace_bytes(int N)
     const size_t a = ((size_t)N * 8 + 255) / 256 * 256, b4 = ((size_t)(N + 1) * 4 + 255) / 256 * 256;
     return 2 * a + 5 * b4 + tmp + 256;
 }
-int dreg_voxel_downsample_fwd(const float* pts, const float* feats, const int* pt_batch, float* out_pts, float* out_feats,
-                              int* n_out, int* batch_counts, uint32_t* inv_seg, float* inv_cnt, int* err,
-                              void* workspace, size_t workspace_bytes, int N, int C, int nbatch, float dl, void* stream)
+static int voxel_downsample_impl(const float* pts, const float* feats, const int* pt_batch, float* out_pts, float* out_feats,
+                                 int* n_out, int* batch_counts, uint32_t* inv_seg, float* inv_cnt, int* err,
+                                 uint32_t* order_out, uint32_t* starts_out,
+                                 void* workspace, size_t workspace_bytes, int N, int C, int nbatch, float dl, void* stream)
 {
     if (N <= 0 || C % 4) return DREG_EINVAL;
     if (workspace_bytes < dreg_voxel_downsample_workspace_bytes(N)) return DREG_EINVAL;
@@ -463,6 +476,8 @@ int dreg_voxel_downsample_fwd(const float* pts, const float* feats, const int* p
     uint32_t* head = (uint32_t*)w; w += b4;
     uint32_t* scan = (uint32_t*)w; w += b4;
     uint32_t* starts = (uint32_t*)w; w += b4;
+    if (order_out) order = order_out;
+    if (starts_out) starts = starts_out;
     void* tmp = w;
     size_t tmp_bytes = workspace_bytes - (size_t)(w - (char*)workspace);
     if (hipMemsetAsync(batch_counts, 0, sizeof(int) * nbatch, st) != hipSuccess) return DREG_ELAUNCH;
@@ -479,6 +494,35 @@ int dreg_voxel_downsample_fwd(const float* pts, const float* feats, const int* p
     hipLaunchKernelGGL(segment_starts_kernel, dim3(nb), dim3(256), 0, st, keys_s, head, scan, starts, batch_counts, n_out, N);
     DREG_LAUNCH_CHECK();
     hipLaunchKernelGGL(segment_mean_kernel, dim3((N + 3) / 4), dim3(256), 0, st, pts, feats, order, starts, n_out, out_pts, out_feats, inv_seg, inv_cnt, C);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+int dreg_voxel_downsample_fwd(const float* pts, const float* feats, const int* pt_batch, float* out_pts, float* out_feats,
+                              int* n_out, int* batch_counts, uint32_t* inv_seg, float* inv_cnt, int* err,
+                              void* workspace, size_t workspace_bytes, int N, int C, int nbatch, float dl, void* stream)
+{
+    if (feats == nullptr) return DREG_EINVAL;
+    return voxel_downsample_impl(pts, feats, pt_batch, out_pts, out_feats, n_out, batch_counts, inv_seg, inv_cnt, err, nullptr, nullptr,
+                                 workspace, workspace_bytes, N, C, nbatch, dl, stream);
+}
+// The same downsample split in two, so that everything whose size is data dependent can run before the feature network:
+// plan = cells, sort, segments and averaged points (needs only xyz); order uint32 [N], starts uint32 [N+1] are kept by the caller.
+int dreg_voxel_downsample_plan(const float* pts, const int* pt_batch, float* out_pts, int* n_out, int* batch_counts,
+                               uint32_t* inv_seg, float* inv_cnt, int* err, uint32_t* order, uint32_t* starts,
+                               void* workspace, size_t workspace_bytes, int N, int nbatch, float dl, void* stream)
+{
+    if (!order || !starts) return DREG_EINVAL;
+    return voxel_downsample_impl(pts, nullptr, pt_batch, out_pts, nullptr, n_out, batch_counts, inv_seg, inv_cnt, err, order, starts,
+                                 workspace, workspace_bytes, N, 0, nbatch, dl, stream);
+}
+// apply = segment means of a feature matrix over a plan: out_feats [M,C] fp32, M = the plan's n_out (device int, rows beyond it untouched)
+int dreg_voxel_segment_mean(const float* feats, const uint32_t* order, const uint32_t* starts, const int* n_out, float* out_feats,
+                            int M, int C, void* stream)
+{
+    if (M <= 0) return DREG_OK;
+    if (C % 4) return DREG_EINVAL;
+    hipLaunchKernelGGL(segment_mean_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, feats, order, starts, n_out,
+                       (float*)nullptr, out_feats, (uint32_t*)nullptr, (float*)nullptr, C);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

@@ -51,6 +51,8 @@ SIGNATURES = {
     "dreg_trilinear_gather_fwd": (I, [P, P, P, P] + [I] * 10 + [P]),
     "dreg_trilinear_gather_bwd": (I, [P, P, P, P] + [I] * 8 + [P]),
     "dreg_cast_from_f32": (I, [P, P, Z, I, P]),
+    "dreg_active_sets_workspace_bytes": (Z, [I] * 4),
+    "dreg_active_sets": (I, [P, P] + [I] * 8 + [P, P, P, P, Z, P]),
     # attention.hip
     "dreg_mha_fwd": (I, [P] * 5 + [I] * 7 + [F, I, P]),
     "dreg_mha_bwd": (I, [P] * 10 + [I] * 7 + [F, I, P]),
@@ -73,6 +75,8 @@ SIGNATURES = {
     "dreg_voxel_downsample_workspace_bytes": (Z, [I]),
     "dreg_voxel_downsample_fwd": (I, [P] * 11 + [Z, I, I, I, F, P]),
     "dreg_voxel_downsample_bwd": (I, [P, P, P, P, I, I, P]),
+    "dreg_voxel_downsample_plan": (I, [P] * 11 + [Z, I, I, F, P]),
+    "dreg_voxel_segment_mean": (I, [P] * 5 + [I, I, P]),
     "dreg_grad_norm": (I, [P, P, P, Z, P]),
     "dreg_adamw_step": (I, [P] * 5 + [Z] + [F] * 5 + [I, F, P]),
     # ngp.hip

@@ -51,7 +51,7 @@ class InfoNCELoss(torch.nn.Module):
             ignore.scatter_(-1, i1, 0)
         logits = logits.masked_fill(ignore, -float("inf"))
         loss = -torch.gather(logits, -1, i1).squeeze(-1) + torch.logsumexp(logits, dim=-1)
-        return loss[mask].sum() / mask.sum()
+        return torch.where(mask, loss, torch.zeros_like(loss)).sum() / mask.sum()  # = loss[mask].sum() / mask.sum() without the host sync
 
 
 def training_losses(pred, pose_gt, feature_loss: InfoNCELoss, src_ov_gt, tgt_ov_gt, src_ov_tilde, tgt_ov_tilde,

@@ -337,38 +337,31 @@ def conv3d_rows(x, w, bias, addend, pad, out_rows, in_rows):
     return SparseConv3dFn.apply(x, w, bias, addend, pad, out_rows, in_rows)
 
 
-def active_sets(idx_list, fine_res, coarse_dims, device):
+def active_sets(idx_list, fine_res, coarse_dims, device, pt_batch=None, idx_cat=None):
     """Row lists for the FPN head: S1 = trilinear-gather corner voxels of the occupied fine voxels (where P1 is consumed),
     S2 = S1 dilated by 3^3 (where the lateral sum is consumed), S3 = S2 dilated (where dc1 of the head is non-zero).
     idx_list: per grid int64 flat fine indices ((x*Yr + y)*Zr + z).  Returns three ascending int32 tensors of flat indices
-    into [B, d, h, w].  The corner arithmetic repeats tri_axis() of fpn_ops.hip in float32 bit for bit."""
-    import torch.nn.functional as F
+    into [B, d, h, w] (None for dense scenes).  One C call (mark, two dilations, stable compaction) + one host read of the
+    three lengths; the corner arithmetic is tri_axis() of fpn_ops.hip itself."""
+    lib = L.load()
     Zr, Xr, Yr = fine_res
     d, h, w = coarse_dims
     B = len(idx_list)
-    flags = torch.zeros(B, d, h, w, dtype=torch.bool, device=device)
-
-    def axis(i, n_out, n_in):
-        s = (torch.tensor(float(n_in - 1), dtype=torch.float32) / torch.tensor(float(n_out - 1), dtype=torch.float32)).item() if n_out > 1 else 0.0
-        f = i.to(torch.float32) * torch.tensor(s, dtype=torch.float32, device=device)
-        i0 = f.to(torch.int64).clamp_(max=n_in - 1)
-        return i0, (i0 + 1).clamp_(max=n_in - 1)
-
-    for b, f in enumerate(idx_list):
-        z, y, x = f % Zr, (f // Zr) % Yr, f // (Zr * Yr)
-        zs, xs, ys = axis(z, Zr, d), axis(x, Xr, h), axis(y, Yr, w)
-        for zi in zs:
-            for xi in xs:
-                for yi in ys:
-                    flags[b, zi, xi, yi] = True
-    f1 = flags.float()[:, None]
-    f2 = F.max_pool3d(f1, 3, 1, 1)
-    f3 = F.max_pool3d(f2, 3, 1, 1)
-    to_rows = lambda t: torch.nonzero(t.flatten() > 0)[:, 0].to(torch.int32).contiguous()
-    s1, s2, s3 = to_rows(f1), to_rows(f2), to_rows(f3)
-    if s3.shape[0] > 0.2 * B * d * h * w:   # dense scenes: the row lists stop paying (and the wgrad slice cap applies)
+    V = B * d * h * w
+    if idx_cat is None:
+        idx_cat = torch.cat(idx_list).contiguous()
+    if pt_batch is None:
+        pt_batch = torch.cat([torch.full((f.shape[0],), b, dtype=torch.int32, device=device) for b, f in enumerate(idx_list)])
+    rows = torch.empty(3, V, dtype=torch.int32, device=device)
+    counts = torch.empty(3, dtype=torch.int32, device=device)
+    nbytes = lib.dreg_active_sets_workspace_bytes(B, d, h, w)
+    ws = _ws(nbytes, device)
+    L.check(lib.dreg_active_sets(L.ptr(idx_cat), L.ptr(pt_batch), idx_cat.shape[0], B, Zr, Xr, Yr, d, h, w,
+                                 L.ptr(rows), L.ptr(counts), None, L.ptr(ws), nbytes, L.stream()), "dreg_active_sets")
+    n1, n2, n3 = counts.tolist()
+    if n3 > 0.2 * V:   # dense scenes: the row lists stop paying (and the wgrad slice cap applies)
         return None
-    return s1, s2, s3
+    return rows[0, :n1], rows[1, :n2], rows[2, :n3]
 
 
 def linear(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = False, residual=None,

@@ -106,9 +106,20 @@ class NeRFRegTr(nn.Module):
         return torch.bfloat16 if self.precision == "bf16" else torch.float32
 
     def _P(self) -> Dict[str, torch.Tensor]:
-        d = dict(self.named_parameters(remove_duplicate=False))
-        d.update(dict(self.named_buffers(remove_duplicate=False)))
+        d = self.__dict__.get("_pdict")
+        if d is None:   # cached: walking the 772-entry module tree costs more than a millisecond of host time per call
+            d = dict(self.named_parameters(remove_duplicate=False))
+            d.update(dict(self.named_buffers(remove_duplicate=False)))
+            self.__dict__["_pdict"] = d
         return d
+
+    def _apply(self, fn, *a, **kw):  # .to() / .float() / ... may replace parameter objects
+        self.__dict__["_pdict"] = None
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self.__dict__["_pdict"] = None
+        return super().load_state_dict(*a, **kw)
 
     # ------------------------------------------------------------------ A1/A2: FPN3D over a batch of grids
     def fpn(self, x: torch.Tensor, rows=None) -> torch.Tensor:
@@ -118,10 +129,11 @@ class NeRFRegTr(nn.Module):
         P = self._P()
         train = self.training
         r = "fpn3d.backbone_net."
+        nbt = []  # num_batches_tracked buffers of the BatchNorms that ran: one fused increment at the end (B calls in the reference)
 
         def bn(t, name, res=None, relu=True):
             if train:
-                P[name + ".num_batches_tracked"] += t.shape[0]
+                nbt.append(P[name + ".num_batches_tracked"])
             return ops.batchnorm(t, P[name + ".weight"], P[name + ".bias"], P[name + ".running_mean"],
                                  P[name + ".running_var"], res=res, relu=relu, train=train)
 
@@ -157,6 +169,8 @@ class NeRFRegTr(nn.Module):
             s1, s2, s3 = rows
             lat1 = ops.conv3d_rows(c1, P[q + "pyramid_transformation_1.weight"], P[q + "pyramid_transformation_1.bias"], p2, 1, s2, s3)
             p1 = ops.conv3d_rows(lat1, P[q + "upsample_transform_1.weight"], P[q + "upsample_transform_1.bias"], None, 1, s1, s2)
+        if nbt:
+            torch._foreach_add_(nbt, x.shape[0])
         return p1
 
     @staticmethod
@@ -184,24 +198,29 @@ class NeRFRegTr(nn.Module):
                 xyzs.append(g[:, :3].permute(0, 3, 4, 2, 1).reshape(-1, 3)[m])
         res = tuple(grids[0].shape[-3:])
         A.set_precision(self.precision)
+        idx_cat, pb_cat = torch.cat(idxs).contiguous(), torch.cat(pbatch)
+        # geometry first: everything whose size depends on the data (active sets of the FPN head, the A4 voxel rounds — their
+        # stopping rule is per pair) needs only the occupied voxels' coordinates.  All host syncs of the step happen here,
+        # before the feature network is queued; from the FPN on, the host runs ahead of the GPU.
         rows = None
         if self.active_set and self.precision == "bf16":
-            rows = ops.active_sets(idxs, res, tuple((r + 1) // 2 for r in res), dev)
-        p1 = self.fpn(self.pack_grids(grids, self.act_dtype), rows)
-        feats = ops.trilinear_gather(p1, torch.cat(idxs).contiguous(), torch.cat(pbatch), res)
-        P = self._P()
-        # A4 per pair (its stopping rule is per pair), then the whole point-set half once for all pairs
-        off = 0
-        pts_l, feat_l, segs = [], [], []
-        for i, d in enumerate(batch):
+            rows = ops.active_sets(idxs, res, tuple((r + 1) // 2 for r in res), dev, pt_batch=pb_cat, idx_cat=idx_cat)
+        plans, pts_l, segs = [], [], []
+        for i in range(len(batch)):
             ns, nt = idxs[2 * i].shape[0], idxs[2 * i + 1].shape[0]
-            f = feats[off:off + ns + nt]
-            off += ns + nt
-            pts = torch.cat([xyzs[2 * i], xyzs[2 * i + 1]])
-            pts, f, lens = T.hierarchical_grid_subsample(pts, f, [ns, nt], self.num_downsample)
+            rounds, pts, lens = T.plan_hierarchical_subsample(torch.cat([xyzs[2 * i], xyzs[2 * i + 1]]), [ns, nt], self.num_downsample)
+            plans.append(rounds)
             pts_l.append(pts)
-            feat_l.append(f)
             segs.append((int(lens[0]), int(lens[1])))
+        p1 = self.fpn(self.pack_grids(grids, self.act_dtype), rows)
+        feats = ops.trilinear_gather(p1, idx_cat, pb_cat, res)
+        P = self._P()
+        off = 0
+        feat_l = []
+        for i in range(len(batch)):
+            n = idxs[2 * i].shape[0] + idxs[2 * i + 1].shape[0]
+            feat_l.append(T.apply_subsample_plan(plans[i], feats[off:off + n]))
+            off += n
         tab = A.ProblemTable(segs, dev)
         xyz_all = torch.cat(pts_l) if len(pts_l) > 1 else pts_l[0]
         cond, corr, ov = T.encode_decode_batched(P, torch.cat(feat_l) if len(feat_l) > 1 else feat_l[0], xyz_all, tab)

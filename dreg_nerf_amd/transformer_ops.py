@@ -37,6 +37,27 @@ def hierarchical_grid_subsample(points, feats, lengths, num_hierarchical=6, init
     return points, feats, lengths
 
 
+def plan_hierarchical_subsample(points, lengths, num_hierarchical=6, init_dl=0.025, radius=2.75, max_points=1500):
+    """The xyz-only half of hierarchical_grid_subsample: (rounds, subsampled points, lengths).  Every data-dependent size of
+    A4 is resolved here, so a caller can run it before the feature network and keep the rest of the step free of host syncs."""
+    radius_normal = init_dl * radius
+    rounds = []
+    for _ in range(num_hierarchical):
+        dl = 2 * radius_normal / radius
+        rnd, points, lengths = A.plan_voxel_downsample(points, lengths, dl)
+        rounds.append(rnd)
+        radius_normal *= 2
+        if points.shape[0] <= 2 * max_points:
+            break
+    return rounds, points, lengths
+
+
+def apply_subsample_plan(rounds, feats):
+    for rnd in rounds:
+        feats = A.segment_mean(feats, rnd)
+    return feats
+
+
 # --------------------------------------------------------------------------- A5
 def posenc_sine(xyz: torch.Tensor, d_model: int = 256, temperature: float = 1000.0, scale: float = 1.0):
     return A.posenc_sine(xyz, d_model, temperature, scale)

@@ -110,6 +110,14 @@ int dreg_trilinear_gather_bwd(const float* dfeat, const int64_t* idx, const int*
                               int h, int w, int C, int Zr, int Xr, int Yr, void* stream);
 int dreg_cast_from_f32(const float* in, void* out, size_t n, int dtype, void* stream);
 
+/* Active sets of the FPN head (build-side; identical results to the dense evaluation of feature_pyramid_net.py:115-127 because
+ * nerf_regtr.py:138-147 only consumes P1 at the trilinear corners of the occupied voxels): S1 = those corners, S2 = S1 dilated
+ * by 3^3, S3 = S2 dilated.  rows int32 [3][V] (V = B*d*h*w, ascending flat indices, list k at rows + k*V), counts device
+ * int32 [3], map1 int32 [V] = rank in S1 or -1 (may be NULL). */
+size_t dreg_active_sets_workspace_bytes(int B, int d, int h, int w);
+int dreg_active_sets(const int64_t* idx, const int* pt_batch, int N, int B, int Zr, int Xr, int Yr, int d, int h, int w,
+                     int* rows, int* counts, int* map1, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------- point-set half
  * Attention core of nn.MultiheadAttention (8 heads, d_head 32; transformer.py:242-281): q [Nq,ldq], k [Nk,ldk],
  * v [Nk,ldv], o [Nq,ldo], head h at column offset 32*h, lse fp32 [H,Nq].  Flash-style, nothing N x N is materialised. */
@@ -170,6 +178,14 @@ size_t dreg_voxel_downsample_workspace_bytes(int N);
 int dreg_voxel_downsample_fwd(const float* pts, const float* feats, const int* pt_batch, float* out_pts, float* out_feats,
                               int* n_out, int* batch_counts, uint32_t* inv_seg, float* inv_cnt, int* err,
                               void* workspace, size_t workspace_bytes, int N, int C, int nbatch, float dl, void* stream);
+/* The same downsample split in two, so that every data-dependent size can be resolved before the feature network runs:
+ * plan (xyz only: cells, sort, segments, averaged points; order uint32 [N] and starts uint32 [N+1] are kept by the caller),
+ * then segment means of a feature matrix over that plan (M = the plan's n_out). */
+int dreg_voxel_downsample_plan(const float* pts, const int* pt_batch, float* out_pts, int* n_out, int* batch_counts,
+                               uint32_t* inv_seg, float* inv_cnt, int* err, uint32_t* order, uint32_t* starts,
+                               void* workspace, size_t workspace_bytes, int N, int nbatch, float dl, void* stream);
+int dreg_voxel_segment_mean(const float* feats, const uint32_t* order, const uint32_t* starts, const int* n_out,
+                            float* out_feats, int M, int C, void* stream);
 int dreg_voxel_downsample_bwd(const float* gout, const uint32_t* inv_seg, const float* inv_cnt, float* gin, int N, int C,
                               void* stream);
 

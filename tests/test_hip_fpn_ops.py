@@ -214,3 +214,50 @@ def test_conv_glds_large_tiles_match_default(mode):
     finally:
         lib.dreg_conv_set_glds(1)
     assert torch.equal(ref, got)
+
+
+def _active_sets_torch(idx_list, fine_res, coarse_dims):
+    """CPU restatement of the row lists: corners of the trilinear gather (float32 arithmetic of tri_axis), two 3^3 dilations."""
+    Zr, Xr, Yr = fine_res
+    d, h, w = coarse_dims
+    B = len(idx_list)
+    flags = torch.zeros(B, d, h, w, dtype=torch.bool)
+
+    def axis(i, n_out, n_in):
+        s = (torch.tensor(float(n_in - 1), dtype=torch.float32) / torch.tensor(float(n_out - 1), dtype=torch.float32)) if n_out > 1 else torch.tensor(0.0)
+        f = i.to(torch.float32) * s
+        i0 = f.to(torch.int64).clamp_(max=n_in - 1)
+        return i0, (i0 + 1).clamp_(max=n_in - 1)
+
+    for b, f in enumerate(idx_list):
+        z, y, x = f % Zr, (f // Zr) % Yr, f // (Zr * Yr)
+        for zi in axis(z, Zr, d):
+            for xi in axis(x, Xr, h):
+                for yi in axis(y, Yr, w):
+                    flags[b, zi, xi, yi] = True
+    f1 = flags.float()[:, None]
+    f2 = F.max_pool3d(f1, 3, 1, 1)
+    f3 = F.max_pool3d(f2, 3, 1, 1)
+    return [torch.nonzero(t.flatten() > 0)[:, 0].to(torch.int32) for t in (f1, f2, f3)]
+
+
+@pytest.mark.parametrize("res,frac", [((24, 20, 28), 0.01), ((33, 31, 29), 0.003), ((16, 16, 16), 0.0)])
+def test_active_sets_match_cpu_construction(res, frac):
+    dev = _dev()
+    g = torch.Generator().manual_seed(res[0])
+    Zr, Xr, Yr = res
+    coarse = tuple((r + 1) // 2 for r in res)
+    idx = []
+    for b in range(3):
+        n = int(frac * Zr * Xr * Yr) + (0 if frac == 0.0 else b)
+        idx.append(torch.randperm(Zr * Xr * Yr, generator=g)[:n].sort().values)
+    if frac == 0.0:
+        idx[1] = torch.tensor([0, Zr * Xr * Yr - 1])  # the two extreme corners only; grids 0 and 2 empty
+    ref = _active_sets_torch(idx, res, coarse)
+    got = ops.active_sets([i.to(dev) for i in idx], res, coarse, dev)
+    V = 3 * coarse[0] * coarse[1] * coarse[2]
+    if ref[2].numel() > 0.2 * V:
+        assert got is None
+        return
+    for a, b in zip(got, ref):
+        assert a.dtype == torch.int32 and torch.equal(a.cpu(), b)

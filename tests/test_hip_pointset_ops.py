@@ -162,6 +162,25 @@ def test_voxel_downsample_vs_oracle():
     np.testing.assert_allclose(fd.grad.cpu().numpy(), fr.grad.numpy(), atol=1e-6)
 
 
+def test_subsample_plan_apply_equals_fused_path():
+    """plan (xyz only, before the feature network) + segment means == the one-call downsample, bit for bit, incl. gradients."""
+    g = torch.Generator().manual_seed(11)
+    ns, nt = 4100, 3900
+    pts = ((torch.rand(ns + nt, 3, generator=g) - 0.5) * 2.4).to(DEV)
+    feats = torch.randn(ns + nt, 256, generator=g).to(DEV)
+    f1 = feats.clone().requires_grad_(True)
+    p_a, f_a, l_a = T.hierarchical_grid_subsample(pts, f1, [ns, nt])
+    rounds, p_b, l_b = T.plan_hierarchical_subsample(pts, [ns, nt])
+    f2 = feats.clone().requires_grad_(True)
+    f_b = T.apply_subsample_plan(rounds, f2)
+    assert [int(v) for v in l_a] == [int(v) for v in l_b] and len(rounds) >= 1
+    assert torch.equal(p_a, p_b) and torch.equal(f_a, f_b)
+    go = torch.randn(f_a.shape, generator=g).to(DEV)
+    f_a.backward(go)
+    f_b.backward(go)
+    assert torch.equal(f1.grad, f2.grad)
+
+
 def test_transformer_decoder_vs_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "transformer.npz"))
     sd = {k: v.to(DEV) for k, v in params.synth_state_dict(0).items()}
