@@ -62,7 +62,8 @@ def bump_weight_generation():
 
 def packed_weight(w: torch.Tensor, cin_pad: int, for_dgrad: bool, dt: int) -> torch.Tensor:
     """w: fp32 [Cout, Cin, k, k, k] (or [Cout, Cin] for linear layers, possibly a row slice of a parameter).
-    The pack is cached against the owning parameter object (weak reference) and its in-place version counter."""
+    The pack is cached against the owning parameter object (weak reference) and its in-place version counter;
+    repack_all() refreshes every cached pack in one launch after an optimizer update."""
     base = w._base if w._base is not None else w
     key = (id(base), w.storage_offset(), tuple(w.shape), cin_pad, for_dgrad, dt)
     hit = _pack_cache.get(key)
@@ -74,17 +75,61 @@ def packed_weight(w: torch.Tensor, cin_pad: int, for_dgrad: bool, dt: int) -> to
     wd = w.detach().contiguous()
     if not for_dgrad:
         kpad = lib.dreg_conv3d_kpad(ksz, cin_pad, dt)
-        out = torch.empty(cout, kpad, dtype=L.torch_dtype(dt), device=w.device)
+        out = hit[2] if hit is not None and hit[0]() is base else torch.empty(cout, kpad, dtype=L.torch_dtype(dt), device=w.device)
     else:
         kpad = lib.dreg_conv3d_kpad(ksz, cout, dt)
-        out = torch.empty(cin_real, kpad, dtype=L.torch_dtype(dt), device=w.device)
+        out = hit[2] if hit is not None and hit[0]() is base else torch.empty(cin_real, kpad, dtype=L.torch_dtype(dt), device=w.device)
     L.check(lib.dreg_pack_conv_weight(L.ptr(wd), L.ptr(out), cout, cin_real, cin_pad, ksz, int(for_dgrad), dt, L.stream()),
             "dreg_pack_conv_weight")
     if len(_pack_cache) > 4096:  # entries of dead parameters
         for k in [k for k, v in _pack_cache.items() if v[0]() is None]:
             del _pack_cache[k]
-    _pack_cache[key] = (weakref.ref(base), (base._version, _weight_generation), out)
+    global _pack_table
+    if hit is None or hit[0]() is not base:
+        _pack_table = None
+    # (weakref, stamp, packed, contiguous?, offset of the slice inside its parameter in elements, desc fields)
+    desc = (cout, cin_real, cout if for_dgrad else cin_pad, ksz ** 3, int(for_dgrad), kpad, dt)
+    _pack_cache[key] = (weakref.ref(base), (base._version, _weight_generation), out,
+                        w.is_contiguous() and base.is_contiguous(), w.storage_offset() - base.storage_offset(), desc)
     return out
+
+
+_pack_table = None  # (device descriptor tensor, n, total_blocks, [(key, src_ptr)]) for repack_all
+
+
+def repack_all(device=None):
+    """Refresh every cached weight pack with ONE kernel launch (dreg_pack_conv_weights_batched) — called by FlatAdamW right
+    after its update, so the ~200 per-layer pack launches of a step collapse into one.  Packs of non-contiguous slices and
+    of dead parameters are skipped (they fall back to the per-call path on their next use)."""
+    global _pack_table
+    import numpy as np
+    lib = L.load()
+    live = []
+    for key, ent in _pack_cache.items():
+        base = ent[0]()
+        if base is None or not ent[3] or not base.is_cuda or (device is not None and base.device != device):
+            continue
+        live.append((key, base.data_ptr() + 4 * ent[4], base))
+    if not live:
+        return
+    sig = [(k, p) for k, p, _ in live]
+    if _pack_table is None or _pack_table[3] != sig:
+        rec = np.zeros((len(live), 12), dtype=np.int32)
+        blk = 0
+        for r, (key, src, base) in enumerate(live):
+            ent = _pack_cache[key]
+            cout, cin_real, inner, ntaps, fd, kpad, dt = ent[5]
+            rec[r, 0:2] = np.frombuffer(np.int64(src).tobytes(), dtype=np.int32)
+            rec[r, 2:4] = np.frombuffer(np.int64(ent[2].data_ptr()).tobytes(), dtype=np.int32)
+            rec[r, 4:12] = (cout, cin_real, inner, ntaps, fd, kpad, dt, blk)
+            rows = cin_real if fd else cout
+            blk += (rows * kpad + 1023) // 1024
+        _pack_table = (torch.from_numpy(rec).to(live[0][2].device), len(live), blk, sig)
+    tab, n, nblk, _ = _pack_table
+    L.check(lib.dreg_pack_conv_weights_batched(L.ptr(tab), n, nblk, L.stream()), "dreg_pack_conv_weights_batched")
+    for key, _, base in live:
+        ent = _pack_cache[key]
+        _pack_cache[key] = (ent[0], (base._version, _weight_generation)) + ent[2:]
 
 
 def _out_dim(i, k, s, p):

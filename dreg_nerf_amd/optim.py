@@ -70,6 +70,7 @@ class FlatAdamW:
                                     self.n, lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
                                     float(self.max_norm), L.stream()), "dreg_adamw_step")
         ops.bump_weight_generation()  # the kernel wrote the parameters behind torch's version counters
+        ops.repack_all(self.flat_p.device)  # every cached bf16/fp32 weight pack refreshed by one launch
 
     def grad_norm(self) -> torch.Tensor:
         return self._norm

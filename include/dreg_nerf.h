@@ -38,6 +38,10 @@ int dreg_conv3d_kpad(int ksz, int Cin, int dtype);
  * for_dgrad = 1: [Cin_real][kpad(ksz,Cout)] with K = tap*Cout + co (operand of the data-gradient pass) */
 int dreg_pack_conv_weight(const float* w, void* out, int Cout, int Cin_real, int Cin, int ksz, int for_dgrad,
                           int dtype, void* stream);
+/* Batched form (all packs of a step in one launch): descs = DEVICE array of n 48-byte records
+ * { const float* w; void* out; int Cout, Cin_real, inner (Cout for dgrad packs, padded Cin otherwise), ksz^3, for_dgrad, Kpad,
+ *   dtype, block0 } with block0 = exclusive prefix of ceil(rows*Kpad/1024), total_blocks = its sum. */
+int dreg_pack_conv_weights_batched(const void* descs, int n, int total_blocks, void* stream);
 
 /* Implicit-GEMM convolution on MFMA.
  * transposed = 0 (forward):        out[b,o,:] = sum_d in[b, o*stride - pad + d, :] . W[:, d, :]  (+bias) (+up2(addend)) (relu)
