@@ -782,36 +782,43 @@ __global__ void pack_weight_fwd_kernel(const float* __restrict__ w, T* __restric
         Elem<T>::st(out + i, v);
     }
 }
-// All weight packs of a step in ONE launch (they are re-made after every optimizer update): block -> descriptor by binary
-// search over the block prefix; 1024 elements per block.  Same element maps as the two kernels around this one.
+// All weight packs of a step in ONE launch (they are re-made after every optimizer update).  One block per packed row
+// (block -> descriptor by binary search over the row prefix): the row's fp32 source elements are staged in LDS with coalesced
+// reads (forward pack: one contiguous [Cin][taps] span; data-gradient pack: Cout spans of `taps` floats), then written as one
+// contiguous packed row.  Same element maps as the two single-layer kernels around this one.
 struct PackDesc {
     const float* w; void* out;
     int Cout, Cin_real, Cin, ntaps, for_dgrad, Kpad, dtype, block0;
 };
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDesc* __restrict__ descs, int n)
 {
+    extern __shared__ float stage[];
     int lo = 0, hi = n - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (descs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const PackDesc d = descs[lo];
-    const int rows = d.for_dgrad ? d.Cin_real : d.Cout, inner = d.for_dgrad ? d.Cout : d.Cin;
-    const size_t total = (size_t)rows * d.Kpad;
-    const size_t base = (size_t)((int)blockIdx.x - d.block0) * 1024;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const size_t i = base + j * 256 + threadIdx.x;
-        if (i >= total) return;
-        const int k = (int)(i % d.Kpad), r = (int)(i / d.Kpad);
-        const int tap = k / inner, c = k - tap * inner;
-        float v = 0.f;
-        if (tap < d.ntaps) {
-            if (d.for_dgrad) v = d.w[((size_t)c * d.Cin_real + r) * d.ntaps + tap];
-            else if (c < d.Cin_real) v = d.w[((size_t)r * d.Cin_real + c) * d.ntaps + tap];
+    const int r = (int)blockIdx.x - d.block0;            // co (forward pack) or ci (data-gradient pack)
+    const int inner = d.for_dgrad ? d.Cout : d.Cin;     // channels per tap in the packed row
+    const int nsrc = (d.for_dgrad ? d.Cout : d.Cin_real) * d.ntaps;
+    if (!d.for_dgrad) {
+        const float* src = d.w + (size_t)r * nsrc;
+        for (int i = threadIdx.x; i < nsrc; i += 256) stage[i] = src[i];
+    } else {
+        for (int i = threadIdx.x; i < nsrc; i += 256) {
+            const int co = i / d.ntaps, tap = i - co * d.ntaps;
+            stage[i] = d.w[((size_t)co * d.Cin_real + r) * d.ntaps + tap];
         }
-        if (d.dtype == 0) Elem<bf16_t>::st((bf16_t*)d.out + i, v);
-        else ((float*)d.out)[i] = v;
+    }
+    __syncthreads();
+    const int nreal = d.for_dgrad ? d.Cout : d.Cin_real;
+    for (int k = threadIdx.x; k < d.Kpad; k += 256) {
+        const int tap = k / inner, c = k - tap * inner;
+        const float v = (tap < d.ntaps && c < nreal) ? stage[c * d.ntaps + tap] : 0.f;
+        const size_t o = (size_t)r * d.Kpad + k;
+        if (d.dtype == 0) Elem<bf16_t>::st((bf16_t*)d.out + o, v);
+        else ((float*)d.out)[o] = v;
     }
 }
 // torch weight -> data-gradient pack [Cin_real][Kpad'] with K' = tap*Cout + co
@@ -964,13 +971,17 @@ int dreg_pack_conv_weight(const float* w, void* out, int Cout, int Cin_real, int
 }
 
 // Batched form of dreg_pack_conv_weight: descs = DEVICE array of n 48-byte records
-//   { const float* w; void* out; int Cout, Cin_real, Cin, ksz^3, for_dgrad, Kpad, dtype, block0 }
-// with block0 = exclusive prefix of ceil(rows*Kpad/1024) (rows = Cin_real for dgrad packs, Cout otherwise), total_blocks its sum.
-int dreg_pack_conv_weights_batched(const void* descs, int n, int total_blocks, void* stream)
+//   { const float* w; void* out; int Cout, Cin_real, inner (Cout for dgrad packs, padded Cin otherwise), ksz^3, for_dgrad, Kpad,
+//     dtype, row0 }
+// with row0 = exclusive prefix of the packed row counts (Cin_real for dgrad packs, Cout otherwise), total_rows its sum and
+// max_row_floats = max over the records of (dgrad ? Cout : Cin_real) * ksz^3 (LDS staging size).
+int dreg_pack_conv_weights_batched(const void* descs, int n, int total_rows, int max_row_floats, void* stream)
 {
     static_assert(sizeof(PackDesc) == 48, "descriptor layout is part of the ABI");
-    if (n <= 0 || total_blocks <= 0) return DREG_OK;
-    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs, n);
+    if (n <= 0 || total_rows <= 0) return DREG_OK;
+    if (max_row_floats <= 0 || (size_t)max_row_floats * 4 > 64 * 1024) return DREG_EINVAL;
+    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(total_rows), dim3(256), (size_t)max_row_floats * 4, (hipStream_t)stream,
+                       (const PackDesc*)descs, n);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

@@ -435,6 +435,72 @@ __global__ void trilinear_gather_bwd_kernel(const TG* __restrict__ dfeat, const 
     }
 }
 
+// active-set form of the gather backward: contributions are accumulated in a compact fp32 buffer [n1, C] addressed through
+// map1 (rank of a coarse voxel in S1), then written once as T rows of the (zero-filled) dense gradient.
+__global__ void trilinear_gather_bwd_rows_kernel(const float* __restrict__ dfeat, const int64_t* __restrict__ idx, const int* __restrict__ pt_batch,
+                                                 const int* __restrict__ map1, float* __restrict__ comp, int N, int d, int h, int w, int C,
+                                                 int Zr, int Xr, int Yr)
+{
+    const size_t total = (size_t)N * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C), n = (int)(i / C);
+        const int64_t f = idx[n];
+        const int z = (int)(f % Zr), y = (int)((f / Zr) % Yr), x = (int)(f / ((int64_t)Zr * Yr));
+        const int b = pt_batch[n];
+        const TriAxis az = tri_axis(z, Zr, d), ax = tri_axis(x, Xr, h), ay = tri_axis(y, Yr, w);
+        const float g = dfeat[i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int zi = (k & 4) ? az.i1 : az.i0, xi = (k & 2) ? ax.i1 : ax.i0, yi = (k & 1) ? ay.i1 : ay.i0;
+            const float wgt = ((k & 4) ? az.t : 1.f - az.t) * ((k & 2) ? ax.t : 1.f - ax.t) * ((k & 1) ? ay.t : 1.f - ay.t);
+            if (wgt != 0.f) atomicAdd(comp + (size_t)map1[(((size_t)b * d + zi) * h + xi) * w + yi] * C + c, g * wgt);
+        }
+    }
+}
+template <typename T>
+__global__ void scatter_rows_cast_kernel(const float* __restrict__ comp, const int* __restrict__ rows, T* __restrict__ out, size_t total_gran, int C)
+{
+    constexpr int G = Gran<T>::G;
+    const int CG = C / G;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total_gran; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        const size_t r = i / CG;
+        float v[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) v[k] = comp[r * C + (size_t)cg * G + k];
+        Gran<T>::st(out + (size_t)rows[r] * C + (size_t)cg * G, v);
+    }
+}
+// column sums over a row list: partial[chunk][c] = sum over rows[chunk*rpc .. ) of g[rows[i]][c]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_rows_partial_kernel(const T* __restrict__ g, const int* __restrict__ rows, float* __restrict__ partial,
+                                                                  int nrows, int C, int rows_per_chunk)
+{
+    constexpr int G = Gran<T>::G;
+    const int CG = C / G;
+    const int cgs = CG < 256 ? CG : 256, rpi = 256 / cgs;
+    const int t = threadIdx.x, cg = blockIdx.y * cgs + (t % cgs), r0 = t / cgs;
+    const int v0 = blockIdx.x * rows_per_chunk, v1 = min(v0 + rows_per_chunk, nrows);
+    float s[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) s[i] = 0.f;
+    if (r0 < rpi)
+        for (int v = v0 + r0; v < v1; v += rpi) {
+            float x[G];
+            Gran<T>::ld(g + (size_t)rows[v] * C + (size_t)cg * G, x);
+#pragma unroll
+            for (int i = 0; i < G; ++i) s[i] += x[i];
+        }
+    __shared__ float red[256][9];
+#pragma unroll
+    for (int i = 0; i < G; ++i) red[t][i] = s[i];
+    __syncthreads();
+    if (t < cgs) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) { float a = 0.f; for (int r = 0; r < rpi; ++r) a += red[r * cgs + t][i]; partial[(size_t)blockIdx.x * C + (size_t)cg * G + i] = a; }
+    }
+}
+
 // fp32 <-> T conversions (contiguous)
 template <typename T>
 __global__ void cast_from_f32_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {
@@ -446,7 +512,8 @@ static inline int nblocks(size_t total, int per = 256, int cap = 8192) {
     size_t b = (total + per - 1) / per;
     return (int)(b > (size_t)cap ? cap : (b ? b : 1));
 }
-static inline int bn_rows_per_chunk(int V) { return V >= 262144 ? 512 : (V >= 256 ? 256 : V); }
+// rows of one statistics chunk: enough chunks that B grids x chunks fill the chip even for the 8^3 / 4^3 levels of the ResNet
+static inline int bn_rows_per_chunk(int V) { return V >= 262144 ? 512 : V >= 32768 ? 256 : V >= 4096 ? 128 : V >= 512 ? 32 : (V >= 8 ? 8 : V); }
 
 extern "C" {
 
@@ -553,6 +620,22 @@ int dreg_colsum(const void* g, float* out, float* workspace, size_t M, int C, in
     return DREG_OK;
 }
 
+// out[c] (+)= sum over the row list of g[rows[i]][c]  (bias gradient of an active-set convolution).  workspace as dreg_colsum(nrows, C).
+int dreg_colsum_rows(const void* g, const int* rows, int nrows, float* out, float* workspace, int C, int accumulate, int dtype, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int G = dtype == 0 ? 8 : 4;
+    if (C % G || nrows <= 0) return DREG_EINVAL;
+    const int rpc = colsum_rows_per_chunk((size_t)nrows);
+    const int nch = (nrows + rpc - 1) / rpc;
+    const int CG = C / G, slabs = (CG + 255) / 256;
+    if (dtype == 0) hipLaunchKernelGGL(colsum_rows_partial_kernel<bf16_t>, dim3(nch, slabs), dim3(256), 0, st, (const bf16_t*)g, rows, workspace, nrows, C, rpc);
+    else hipLaunchKernelGGL(colsum_rows_partial_kernel<float>, dim3(nch, slabs), dim3(256), 0, st, (const float*)g, rows, workspace, nrows, C, rpc);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, out, nch, C, accumulate);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
 // p1: [B,d,h,w,C] (dtype), idx: int64 [N] flat fine-grid indices, pt_batch: int32 [N] grid id of every point.
 // out: [N,C] fp32 (out_f32 = 1) or dtype.
 int dreg_trilinear_gather_fwd(const void* p1, const int64_t* idx, const int* pt_batch, void* out, int N, int d, int h, int w, int C,
@@ -586,6 +669,27 @@ int dreg_cast_from_f32(const float* in, void* out, size_t n, int dtype, void* st
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0) hipLaunchKernelGGL(cast_from_f32_kernel<bf16_t>, dim3(nblocks(n)), dim3(256), 0, st, in, (bf16_t*)out, n);
     else hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, in, (float*)out, n);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// Active-set gather backward: dp1 [B,d,h,w,C] (dtype) is zero-filled here and receives the gradient on the S1 rows only.
+// rows1 / n1 / map1: list, length and inverse map from dreg_active_sets; comp: fp32 [n1, C] scratch.
+int dreg_trilinear_gather_bwd_rows(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1, const int* map1,
+                                   float* comp, void* dp1, int N, int B, int d, int h, int w, int C, int Zr, int Xr, int Yr, int dtype, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int G = dtype == 0 ? 8 : 4;
+    if (C % G) return DREG_EINVAL;
+    const size_t dense_bytes = (size_t)B * d * h * w * C * (dtype == 0 ? 2 : 4);
+    if (hipMemsetAsync(dp1, 0, dense_bytes, st) != hipSuccess) return DREG_ELAUNCH;
+    if (N == 0 || n1 == 0) return DREG_OK;
+    if (hipMemsetAsync(comp, 0, (size_t)n1 * C * sizeof(float), st) != hipSuccess) return DREG_ELAUNCH;
+    hipLaunchKernelGGL(trilinear_gather_bwd_rows_kernel, dim3(nblocks((size_t)N * C)), dim3(256), 0, st, dfeat, idx, pt_batch, map1, comp, N, d, h, w, C, Zr, Xr, Yr);
+    DREG_LAUNCH_CHECK();
+    const size_t tg = (size_t)n1 * (C / G);
+    if (dtype == 0) hipLaunchKernelGGL(scatter_rows_cast_kernel<bf16_t>, dim3(nblocks(tg)), dim3(256), 0, st, comp, rows1, (bf16_t*)dp1, tg, C);
+    else hipLaunchKernelGGL(scatter_rows_cast_kernel<float>, dim3(nblocks(tg)), dim3(256), 0, st, comp, rows1, (float*)dp1, tg, C);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

@@ -68,12 +68,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 }
 __global__ void layernorm_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ dg, float* __restrict__ db, int nblk, int accumulate)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per column (lanes stride over the block partials, fixed order -> deterministic)
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= 512) return;
     double s = 0.0;
-    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * 512 + c];
-    float* dst = c < 256 ? dg + c : db + (c - 256);
-    *dst = accumulate ? *dst + (float)s : (float)s;
+    for (int k = lane; k < nblk; k += 64) s += part[(size_t)k * 512 + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) {
+        float* dst = c < 256 ? dg + c : db + (c - 256);
+        *dst = accumulate ? *dst + (float)s : (float)s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ sine position embedding
@@ -130,11 +135,13 @@ __global__ __launch_bounds__(256) void overlap_bwd_kernel(const float* __restric
 }
 __global__ void overlap_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblk)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= 257) return;
     double s = 0.0;
-    for (int k = 0; k < nblk; ++k) s += part[(size_t)k * 257 + c];
-    if (c < 256) dw[c] = (float)s; else db[0] = (float)s;
+    for (int k = lane; k < nblk; k += 64) s += part[(size_t)k * 257 + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) { if (c < 256) dw[c] = (float)s; else db[0] = (float)s; }
 }
 
 // ------------------------------------------------------------------------------------------------ elementwise helpers
@@ -384,7 +391,7 @@ int dreg_layernorm_bwd(const float* x, const void* dy, const float* gamma, const
     if (g_dtype == 0) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, x, (const bf16_t*)dy, gamma, stats, dx, workspace, N, 64, accumulate_dx);
     else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nblk), dim3(256), 0, st, x, (const float*)dy, gamma, stats, dx, workspace, N, 64, accumulate_dx);
     DREG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3(2), dim3(256), 0, st, workspace, dgamma, dbeta, nblk, accumulate_w);
+    hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3(128), dim3(256), 0, st, workspace, dgamma, dbeta, nblk, accumulate_w);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
@@ -414,7 +421,7 @@ int dreg_overlap_bwd(const float* f, const float* w, const float* s, const float
     const int nblk = (N + 63) / 64;
     hipLaunchKernelGGL(overlap_bwd_kernel, dim3(nblk), dim3(256), 0, st, f, w, s, gy, df, workspace, N, 64);
     DREG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(overlap_bwd_final_kernel, dim3(2), dim3(256), 0, st, workspace, dw, db, nblk);
+    hipLaunchKernelGGL(overlap_bwd_final_kernel, dim3(65), dim3(256), 0, st, workspace, dw, db, nblk);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

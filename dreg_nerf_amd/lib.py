@@ -34,7 +34,7 @@ SIGNATURES = {
     "dreg_conv3d_kpad": (I, [I, I, I]),
     "dreg_conv_set_glds": (None, [I]),
     "dreg_pack_conv_weight": (I, [P, P, I, I, I, I, I, I, P]),
-    "dreg_pack_conv_weights_batched": (I, [P, I, I, P]),
+    "dreg_pack_conv_weights_batched": (I, [P, I, I, I, P]),
     "dreg_conv3d_wgrad_splits": (I, [I] * 8),
     "dreg_conv3d_wgrad_workspace_bytes": (Z, [I] * 8),
     "dreg_conv3d_wgrad": (I, [P, P, P, P, Z] + [I] * 16 + [P]),
@@ -54,6 +54,8 @@ SIGNATURES = {
     "dreg_cast_from_f32": (I, [P, P, Z, I, P]),
     "dreg_active_sets_workspace_bytes": (Z, [I] * 4),
     "dreg_active_sets": (I, [P, P] + [I] * 8 + [P, P, P, P, Z, P]),
+    "dreg_trilinear_gather_bwd_rows": (I, [P, P, P, P, I, P, P, P] + [I] * 10 + [P]),
+    "dreg_colsum_rows": (I, [P, P, I, P, P, I, I, I, P]),
     # attention.hip
     "dreg_mha_fwd": (I, [P] * 5 + [I] * 7 + [F, I, P]),
     "dreg_mha_bwd": (I, [P] * 10 + [I] * 7 + [F, I, P]),

@@ -51,7 +51,9 @@ _weight_generation = 0
 
 
 def clear_pack_cache():
+    global _pack_table
     _pack_cache.clear()
+    _pack_table = None
 
 
 def bump_weight_generation():
@@ -115,18 +117,18 @@ def repack_all(device=None):
     sig = [(k, p) for k, p, _ in live]
     if _pack_table is None or _pack_table[3] != sig:
         rec = np.zeros((len(live), 12), dtype=np.int32)
-        blk = 0
+        row0 = max_floats = 0
         for r, (key, src, base) in enumerate(live):
             ent = _pack_cache[key]
             cout, cin_real, inner, ntaps, fd, kpad, dt = ent[5]
             rec[r, 0:2] = np.frombuffer(np.int64(src).tobytes(), dtype=np.int32)
             rec[r, 2:4] = np.frombuffer(np.int64(ent[2].data_ptr()).tobytes(), dtype=np.int32)
-            rec[r, 4:12] = (cout, cin_real, inner, ntaps, fd, kpad, dt, blk)
-            rows = cin_real if fd else cout
-            blk += (rows * kpad + 1023) // 1024
-        _pack_table = (torch.from_numpy(rec).to(live[0][2].device), len(live), blk, sig)
-    tab, n, nblk, _ = _pack_table
-    L.check(lib.dreg_pack_conv_weights_batched(L.ptr(tab), n, nblk, L.stream()), "dreg_pack_conv_weights_batched")
+            rec[r, 4:12] = (cout, cin_real, inner, ntaps, fd, kpad, dt, row0)
+            row0 += cin_real if fd else cout
+            max_floats = max(max_floats, (cout if fd else cin_real) * ntaps)
+        _pack_table = (torch.from_numpy(rec).to(live[0][2].device), len(live), row0, sig, max_floats)
+    tab, n, nrows, _, max_floats = _pack_table
+    L.check(lib.dreg_pack_conv_weights_batched(L.ptr(tab), n, nrows, max_floats, L.stream()), "dreg_pack_conv_weights_batched")
     for key, _, base in live:
         ent = _pack_cache[key]
         _pack_cache[key] = (ent[0], (base._version, _weight_generation)) + ent[2:]
@@ -372,7 +374,12 @@ class SparseConv3dFn(torch.autograd.Function):
                 ev[1].record()
             gw = None if sink is not None else gw_t
         if has_bias and ctx.needs_input_grad[2]:
-            gb = colsum(gy.view(-1, cout), accumulate_into=_grad_sink(ctx.bias_ref) if ctx.bias_ref is not None else None)
+            sink = _grad_sink(ctx.bias_ref) if ctx.bias_ref is not None else None
+            gb_t = sink if sink is not None else torch.empty(cout, dtype=torch.float32, device=x.device)
+            wsb = _ws(lib.dreg_colsum_workspace_bytes(out_rows.shape[0], cout), x.device)
+            L.check(lib.dreg_colsum_rows(L.ptr(gy), L.ptr(out_rows), out_rows.shape[0], L.ptr(gb_t), L.ptr(wsb), cout, int(sink is not None),
+                                         L.dt_of(gy), L.stream()), "dreg_colsum_rows")
+            gb = None if sink is not None else gb_t
         if add_shape is not None and ctx.needs_input_grad[3]:
             ga = downsample_sum(gy, add_shape)
         return gx, gw, gb, ga, None, None, None
@@ -386,7 +393,7 @@ def active_sets(idx_list, fine_res, coarse_dims, device, pt_batch=None, idx_cat=
     """Row lists for the FPN head: S1 = trilinear-gather corner voxels of the occupied fine voxels (where P1 is consumed),
     S2 = S1 dilated by 3^3 (where the lateral sum is consumed), S3 = S2 dilated (where dc1 of the head is non-zero).
     idx_list: per grid int64 flat fine indices ((x*Yr + y)*Zr + z).  Returns three ascending int32 tensors of flat indices
-    into [B, d, h, w] (None for dense scenes).  One C call (mark, two dilations, stable compaction) + one host read of the
+    into [B, d, h, w] plus map1 (int32 [B*d*h*w]: rank of a voxel in S1, -1 outside) — None for dense scenes.  One C call (mark, two dilations, stable compaction) + one host read of the
     three lengths; the corner arithmetic is tri_axis() of fpn_ops.hip itself."""
     lib = L.load()
     Zr, Xr, Yr = fine_res
@@ -401,12 +408,13 @@ def active_sets(idx_list, fine_res, coarse_dims, device, pt_batch=None, idx_cat=
     counts = torch.empty(3, dtype=torch.int32, device=device)
     nbytes = lib.dreg_active_sets_workspace_bytes(B, d, h, w)
     ws = _ws(nbytes, device)
+    map1 = torch.empty(V, dtype=torch.int32, device=device)
     L.check(lib.dreg_active_sets(L.ptr(idx_cat), L.ptr(pt_batch), idx_cat.shape[0], B, Zr, Xr, Yr, d, h, w,
-                                 L.ptr(rows), L.ptr(counts), None, L.ptr(ws), nbytes, L.stream()), "dreg_active_sets")
+                                 L.ptr(rows), L.ptr(counts), L.ptr(map1), L.ptr(ws), nbytes, L.stream()), "dreg_active_sets")
     n1, n2, n3 = counts.tolist()
     if n3 > 0.2 * V:   # dense scenes: the row lists stop paying (and the wgrad slice cap applies)
         return None
-    return rows[0, :n1], rows[1, :n2], rows[2, :n3]
+    return rows[0, :n1], rows[1, :n2], rows[2, :n3], map1
 
 
 def linear(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = False, residual=None,
@@ -503,7 +511,7 @@ class TrilinearGatherFn(torch.autograd.Function):
     """feats[n] = trilinear(align_corners) sample of p1[batch[n]] at fine voxel idx[n]; output fp32 [N, C]."""
 
     @staticmethod
-    def forward(ctx, p1, idx, pt_batch, fine_res):
+    def forward(ctx, p1, idx, pt_batch, fine_res, rows1=None, map1=None):
         lib = L.load()
         B, d, h, w, C = p1.shape
         N = idx.shape[0]
@@ -511,26 +519,34 @@ class TrilinearGatherFn(torch.autograd.Function):
         Zr, Xr, Yr = fine_res
         L.check(lib.dreg_trilinear_gather_fwd(L.ptr(p1), L.ptr(idx), L.ptr(pt_batch), L.ptr(out), N, d, h, w, C, Zr, Xr, Yr,
                                               L.dt_of(p1), 1, L.stream()), "dreg_trilinear_gather_fwd")
-        ctx.save_for_backward(idx, pt_batch)
+        ctx.save_for_backward(idx, pt_batch, rows1, map1)
         ctx.cfg = (tuple(p1.shape), p1.dtype, fine_res)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        idx, pt_batch = ctx.saved_tensors
+        idx, pt_batch, rows1, map1 = ctx.saved_tensors
         shape, dtype, (Zr, Xr, Yr) = ctx.cfg
         lib = L.load()
         B, d, h, w, C = shape
         gout = gout.contiguous().float()
+        if rows1 is not None:  # active set: compact fp32 accumulation on S1, one cast-scatter into the zero-filled gradient
+            g = torch.empty(shape, dtype=dtype, device=gout.device)
+            comp = torch.empty(max(rows1.shape[0], 1), C, dtype=torch.float32, device=gout.device)
+            L.check(lib.dreg_trilinear_gather_bwd_rows(L.ptr(gout), L.ptr(idx), L.ptr(pt_batch), L.ptr(rows1), rows1.shape[0], L.ptr(map1),
+                                                       L.ptr(comp), L.ptr(g), idx.shape[0], B, d, h, w, C, Zr, Xr, Yr, L.dt_of(g), L.stream()),
+                    "dreg_trilinear_gather_bwd_rows")
+            return g, None, None, None, None, None
         g32 = torch.zeros(shape, dtype=torch.float32, device=gout.device)
         L.check(lib.dreg_trilinear_gather_bwd(L.ptr(gout), L.ptr(idx), L.ptr(pt_batch), L.ptr(g32), idx.shape[0], d, h, w, C,
                                               Zr, Xr, Yr, L.stream()), "dreg_trilinear_gather_bwd")
         if dtype == torch.float32:
-            return g32, None, None, None
+            return g32, None, None, None, None, None
         g = torch.empty(shape, dtype=dtype, device=gout.device)
         L.check(lib.dreg_cast_from_f32(L.ptr(g32), L.ptr(g), g32.numel(), L.dt_of(g), L.stream()), "dreg_cast_from_f32")
-        return g, None, None, None
+        return g, None, None, None, None, None
 
 
-def trilinear_gather(p1, idx, pt_batch, fine_res):
-    return TrilinearGatherFn.apply(p1, idx, pt_batch, fine_res)
+def trilinear_gather(p1, idx, pt_batch, fine_res, rows1=None, map1=None):
+    """rows1 / map1 (from active_sets): the backward then touches the S1 rows only."""
+    return TrilinearGatherFn.apply(p1, idx, pt_batch, fine_res, rows1, map1)

@@ -166,7 +166,7 @@ class NeRFRegTr(nn.Module):
         if rows is None:
             p1 = conv("upsample_transform_1", conv("pyramid_transformation_1", c1, 1, addend=p2), 1)
         else:
-            s1, s2, s3 = rows
+            s1, s2, s3 = rows[:3]
             lat1 = ops.conv3d_rows(c1, P[q + "pyramid_transformation_1.weight"], P[q + "pyramid_transformation_1.bias"], p2, 1, s2, s3)
             p1 = ops.conv3d_rows(lat1, P[q + "upsample_transform_1.weight"], P[q + "upsample_transform_1.bias"], None, 1, s1, s2)
         if nbt:
@@ -213,7 +213,7 @@ class NeRFRegTr(nn.Module):
             pts_l.append(pts)
             segs.append((int(lens[0]), int(lens[1])))
         p1 = self.fpn(self.pack_grids(grids, self.act_dtype), rows)
-        feats = ops.trilinear_gather(p1, idx_cat, pb_cat, res)
+        feats = ops.trilinear_gather(p1, idx_cat, pb_cat, res, *((rows[0], rows[3]) if rows is not None else ()))
         P = self._P()
         off = 0
         feat_l = []

@@ -40,8 +40,9 @@ int dreg_pack_conv_weight(const float* w, void* out, int Cout, int Cin_real, int
                           int dtype, void* stream);
 /* Batched form (all packs of a step in one launch): descs = DEVICE array of n 48-byte records
  * { const float* w; void* out; int Cout, Cin_real, inner (Cout for dgrad packs, padded Cin otherwise), ksz^3, for_dgrad, Kpad,
- *   dtype, block0 } with block0 = exclusive prefix of ceil(rows*Kpad/1024), total_blocks = its sum. */
-int dreg_pack_conv_weights_batched(const void* descs, int n, int total_blocks, void* stream);
+ *   dtype, row0 } with row0 = exclusive prefix of the packed row counts (Cin_real for dgrad packs, Cout otherwise),
+ * total_rows = its sum, max_row_floats = max of (dgrad ? Cout : Cin_real) * ksz^3 (LDS staging, <= 16384). */
+int dreg_pack_conv_weights_batched(const void* descs, int n, int total_rows, int max_row_floats, void* stream);
 
 /* Implicit-GEMM convolution on MFMA.
  * transposed = 0 (forward):        out[b,o,:] = sum_d in[b, o*stride - pad + d, :] . W[:, d, :]  (+bias) (+up2(addend)) (relu)
@@ -121,6 +122,13 @@ int dreg_cast_from_f32(const float* in, void* out, size_t n, int dtype, void* st
 size_t dreg_active_sets_workspace_bytes(int B, int d, int h, int w);
 int dreg_active_sets(const int64_t* idx, const int* pt_batch, int N, int B, int Zr, int Xr, int Yr, int d, int h, int w,
                      int* rows, int* counts, int* map1, void* workspace, size_t workspace_bytes, void* stream);
+/* active-set forms of the gather backward (dp1 zero-filled here, gradient on the S1 rows only; comp: fp32 [n1,C] scratch) and
+ * of the bias-gradient column sum (rows of g outside the list are known to be zero). */
+int dreg_trilinear_gather_bwd_rows(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
+                                   const int* map1, float* comp, void* dp1, int N, int B, int d, int h, int w, int C,
+                                   int Zr, int Xr, int Yr, int dtype, void* stream);
+int dreg_colsum_rows(const void* g, const int* rows, int nrows, float* out, float* workspace, int C, int accumulate,
+                     int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- point-set half
  * Attention core of nn.MultiheadAttention (8 heads, d_head 32; transformer.py:242-281): q [Nq,ldq], k [Nk,ldk],

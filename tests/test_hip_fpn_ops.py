@@ -259,5 +259,44 @@ def test_active_sets_match_cpu_construction(res, frac):
     if ref[2].numel() > 0.2 * V:
         assert got is None
         return
-    for a, b in zip(got, ref):
+    for a, b in zip(got[:3], ref):
         assert a.dtype == torch.int32 and torch.equal(a.cpu(), b)
+    map1 = got[3].cpu()
+    want = torch.full((V,), -1, dtype=torch.int32)
+    want[ref[0].long()] = torch.arange(ref[0].numel(), dtype=torch.int32)
+    assert torch.equal(map1, want)
+
+
+def test_batched_repack_equals_per_layer_pack():
+    """ops.repack_all (one launch, LDS-staged rows) == dreg_pack_conv_weight per layer, bit for bit, for both pack kinds."""
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    ws = [torch.randn(64, 4, 5, 5, 5, generator=g), torch.randn(128, 64, 3, 3, 3, generator=g), torch.randn(256, 512, 1, 1, 1, generator=g),
+          torch.randn(768, 256, generator=g), torch.randn(512, 512, 3, 3, 3, generator=g)]
+    ops.clear_pack_cache()
+    params_ = [torch.nn.Parameter(w.to(dev)) for w in ws]
+    cin_pads = [8, 64, 512, 256, 512]
+    first = []
+    for p_, cp in zip(params_, cin_pads):
+        first.append((ops.packed_weight(p_, cp, False, 0).clone(), ops.packed_weight(p_, cp, True, 0).clone() if p_.dim() == 5 and p_.shape[2] != 5 or p_.dim() == 2 else None))
+    with torch.no_grad():
+        for p_ in params_:
+            p_.mul_(1.5)   # version bump: cached packs are stale now
+    ops.repack_all(dev)
+    assert len(ops._pack_cache) == 9
+    for ent in ops._pack_cache.values():   # every cached pack was refreshed by the batched launch (no per-layer fallback below)
+        assert ent[1] == (ent[0]()._version, ops._weight_generation)
+    for p_, cp, (f0, d0) in zip(params_, cin_pads, first):
+        f1 = ops.packed_weight(p_, cp, False, 0)
+        ref = torch.empty_like(f1)
+        from dreg_nerf_amd import lib as L
+        lib = L.load()
+        ksz = p_.shape[2] if p_.dim() == 5 else 1
+        L.check(lib.dreg_pack_conv_weight(L.ptr(p_.detach()), L.ptr(ref), p_.shape[0], p_.shape[1], cp, ksz, 0, 0, L.stream()), "pack")
+        assert torch.equal(f1.view(torch.int16), ref.view(torch.int16)) and not torch.equal(f1.view(torch.int16), f0.view(torch.int16))
+        if d0 is not None:
+            d1 = ops.packed_weight(p_, cp, True, 0)
+            refd = torch.empty_like(d1)
+            L.check(lib.dreg_pack_conv_weight(L.ptr(p_.detach()), L.ptr(refd), p_.shape[0], p_.shape[1], cp, ksz, 1, 0, L.stream()), "pack")
+            assert torch.equal(d1.view(torch.int16), refd.view(torch.int16))
+    ops.clear_pack_cache()
