@@ -222,7 +222,7 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
     const bf16_t* __restrict__ in, const bf16_t* __restrict__ wt, TO* __restrict__ out,
     const float* __restrict__ bias, const TO* __restrict__ addend, ConvGeom g,
     int relu, int Da, int Ha, int Wa, int add_shift, int tilesN, uint32_t in_bytes, uint32_t wt_bytes,
-    const int* __restrict__ rowlist, uint32_t nrows)
+    const int* __restrict__ rowlist, uint32_t nrows, int ksplit)
 {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     constexpr int NW = BN == 256 ? 8 : 4, WAVES_N = BN == 256 ? 4 : 2;   // waves: 2 (M) x WAVES_N (N), (BM/2) x (BN/WAVES_N) each
@@ -319,12 +319,17 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
         }
     };
 
-    issue(0, 0);
-    for (int k = 0; k < nk; ++k) {
+    // split-K (small row spaces: blockIdx.y = K slice, raw fp32 partial tiles at out + slice*M*Cout, finished by
+    // splitk_reduce_kernel); ksplit == 1 is the plain kernel
+    const int k_begin = ksplit > 1 ? (int)((long)nk * blockIdx.y / ksplit) : 0;
+    const int k_end = ksplit > 1 ? (int)((long)nk * (blockIdx.y + 1) / ksplit) : nk;
+    if (ksplit > 1) out += (size_t)blockIdx.y * g.M * g.Cout;
+    issue(k_begin, 0);
+    for (int k = k_begin; k < k_end; ++k) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (k + 1 < nk) issue(k + 1, (k + 1) & 1);
-        compute(k & 1);
+        if (k + 1 < k_end) issue(k + 1, (k + 1 - k_begin) & 1);
+        compute((k - k_begin) & 1);
     }
 
     // Epilogue through LDS, one pass per wave row (wm): accumulators -> fp32 tile [BM/2][BN] (16-column blocks XOR-ed with
@@ -770,6 +775,40 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
 }
 
 // torch weight [Cout][Cin_real][ntaps] fp32 -> gather-form pack [Cout][Kpad] (K = tap*Cin + ci), zero padded.
+// finish of a split-K convolution: out[i] = cast([relu](sum_s part[s][i] + bias[i % Cout])), 8 channels per thread
+template <typename TO>
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, TO* __restrict__ out, const float* __restrict__ bias,
+                                     size_t total8, size_t slice, int Cout, int nsplit, int relu)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total8; i += (size_t)gridDim.x * blockDim.x) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const float4 a = *reinterpret_cast<const float4*>(part + sp * slice + i * 8), b = *reinterpret_cast<const float4*>(part + sp * slice + i * 8 + 4);
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        }
+        const int n = (int)((i * 8) % (size_t)Cout);
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bias[n + e];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if constexpr (sizeof(TO) == 4) {
+            *reinterpret_cast<float4*>(out + i * 8) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(out + i * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+            *reinterpret_cast<uint4*>(out + i * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
+
 template <typename T>
 __global__ void pack_weight_fwd_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin_real,
                                        int ntaps, int Cin, int log2Cin, int Kpad)
@@ -864,16 +903,54 @@ static int fill_geom(ConvGeom& g, int B, int Di, int Hi, int Wi, int Cin, int Do
 
 static int g_use_glds = 1;
 
+// K slices of a small bf16 stride-1-gather convolution (0/1 = no split): fill the chip when the 128-row tiling leaves most CUs idle
+static int conv_ksplit(const ConvGeom& g, bool has_addend)
+{
+    if (!g_use_glds || g_use_glds == 5 || has_addend || g.sd != 1 || g.Cin % 64 != 0 || g.ntaps > 32) return 1;
+    const int bn = g.Cout % 128 == 0 ? 128 : (g.Cout % 64 == 0 ? 64 : 0);
+    if (!bn) return 1;
+    // the slice count must not depend on how many grids share the launch (a pair's result is independent of its batch
+    // mates, bit for bit): it is derived from the per-grid voxel count at a nominal batch of 8 grids
+    const long rows_nominal = 8L * g.Do * g.Ho * g.Wo;
+    const long tiles = ((rows_nominal + 127) / 128) * (g.Cout / bn);
+    const int nk = g.ntaps * (g.Cin / 64);
+    if (tiles >= 128 || nk < 32) return 1;   // short K: the second (reduce) launch costs more than the idle CUs
+    long s = (256 + tiles - 1) / tiles;
+    if (s > nk / 4) s = nk / 4;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : (int)s;
+}
+
 template <typename T, typename TO>
 static int launch_conv(const void* in, const void* wt, void* out, const float* bias, const void* addend,
                        const ConvGeom& g, int relu, int Da, int Ha, int Wa, int add_shift, hipStream_t st,
-                       const int* rowlist = nullptr, uint32_t nrows_in = 0)
+                       const int* rowlist = nullptr, uint32_t nrows_in = 0, float* ks_ws = nullptr, size_t ks_ws_bytes = 0)
 {
     const uint32_t nrows = rowlist ? nrows_in : g.M;
     const int tilesM = (nrows + 127) / 128;
     if (rowlist && nrows == 0) return DREG_OK;
     if constexpr (sizeof(T) == 2) {
         const uint64_t in_bytes = (uint64_t)g.B * g.Di * g.Hi * g.Wi * g.Cin * 2, wt_bytes = (uint64_t)g.Cout * g.Kpad * 2;
+        const int ksplit = (ks_ws && !rowlist) ? conv_ksplit(g, addend != nullptr) : 1;
+        if (ksplit > 1 && in_bytes < 0x7fffff00ull && wt_bytes < 0x7fffff00ull) {
+            const size_t slice = (size_t)g.M * g.Cout;
+            if (ks_ws_bytes < slice * ksplit * sizeof(float)) return DREG_EINVAL;
+            const int tm_ = (g.M + 127) / 128;
+            if (g.Cout % 128 == 0)
+                hipLaunchKernelGGL((conv_igemm_glds_kernel<float, 128, 128>), dim3(tm_ * (g.Cout / 128), ksplit), dim3(256), (size_t)2 * 256 * 128, st,
+                                   (const bf16_t*)in, (const bf16_t*)wt, ks_ws, nullptr, nullptr, g, 0, 0, 0, 0, 0, g.Cout / 128,
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, nullptr, g.M, ksplit);
+            else
+                hipLaunchKernelGGL((conv_igemm_glds_kernel<float, 128, 64>), dim3(tm_ * (g.Cout / 64), ksplit), dim3(256), (size_t)2 * 192 * 128, st,
+                                   (const bf16_t*)in, (const bf16_t*)wt, ks_ws, nullptr, nullptr, g, 0, 0, 0, 0, 0, g.Cout / 64,
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, nullptr, g.M, ksplit);
+            DREG_LAUNCH_CHECK();
+            const size_t total8 = slice / 8;
+            const int nb = (int)((total8 + 255) / 256 > 2048 ? 2048 : (total8 + 255) / 256);
+            hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3(nb), dim3(256), 0, st, ks_ws, (TO*)out, bias, total8, slice, g.Cout, ksplit, relu);
+            DREG_LAUNCH_CHECK();
+            return DREG_OK;
+        }
         if (g_use_glds && g.sd == 1 && g.Cin % 64 == 0 && g.ntaps <= 32 && in_bytes < 0x7fffff00ull && wt_bytes < 0x7fffff00ull) {
 #define GL_LAUNCH(BMv, BNv, NT) do { \
                 const int tm_ = (nrows + BMv - 1) / BMv, tn_ = g.Cout / BNv; \
@@ -881,8 +958,8 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
                 if (lds_ > 65536) (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<TO, BMv, BNv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
                 hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, BMv, BNv>), dim3(tm_ * tn_), dim3(NT), lds_, st, \
                                    (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tn_, \
-                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows); } while (0)
-            if (g.Cout % 256 == 0 && (g_use_glds == 1 || g_use_glds == 4) && nrows >= 65536) GL_LAUNCH(256, 256, 512);
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows, 1); } while (0)
+            if (g.Cout % 256 == 0 && (g_use_glds == 1 || g_use_glds == 4 || g_use_glds == 5) && nrows >= 65536) GL_LAUNCH(256, 256, 512);
             else if (g.Cout % 256 == 0 && g_use_glds == 3 && nrows >= 65536) GL_LAUNCH(128, 256, 512);
             else if (g.Cout % 128 == 0) GL_LAUNCH(128, 128, 256);
             else if (g.Cout % 64 == 0) GL_LAUNCH(128, 64, 256);
@@ -915,10 +992,21 @@ extern "C" {
 // transposed = 1: out[b,i,:] = sum_d in[b, (i + pad - d)/stride, :] . W'[:, d, :]       (data gradient; "in" = dOut)
 // addend (optional, same dtype as out): [B, Da, Ha, Wa, Cout] added with nearest x2 upsampling (FPN top-down path),
 // or element-wise when add_same = 1 (residual connections of the transformer, Da,Ha,Wa = Do,Ho,Wo).
-int dreg_conv3d_igemm(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
-                      int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
-                      int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
-                      int dtype, int out_f32, void* stream)
+// workspace (optional): fp32 scratch of dreg_conv3d_igemm_workspace_bytes(...) bytes; with it, small row spaces (the 8^3 / 4^3
+// levels of the ResNet) run split-K over blockIdx.y and are finished by a reduce + bias/ReLU/cast pass.
+size_t dreg_conv3d_igemm_workspace_bytes(int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                                         int ksz, int stride, int pad, int transposed, int has_addend, int dtype)
+{
+    if (dtype != 0) return 0;
+    ConvGeom g;
+    if (fill_geom(g, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, ksz, stride, pad, transposed, 2)) return 0;
+    const int s = conv_ksplit(g, has_addend != 0);
+    return s > 1 ? (size_t)s * g.M * Cout * sizeof(float) : 0;
+}
+int dreg_conv3d_igemm_ws(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
+                         int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                         int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
+                         int dtype, int out_f32, void* workspace, size_t workspace_bytes, void* stream)
 {
     const int add_shift = add_same ? 0 : 1;
     ConvGeom g;
@@ -928,16 +1016,24 @@ int dreg_conv3d_igemm(const void* in, const void* wt_packed, void* out, const fl
     if (g.M == 0) return DREG_OK;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0) {
-        if (out_f32) return launch_conv<bf16_t, float>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st);
-        return launch_conv<bf16_t, bf16_t>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st);
+        if (out_f32) return launch_conv<bf16_t, float>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st, nullptr, 0, (float*)workspace, workspace_bytes);
+        return launch_conv<bf16_t, bf16_t>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st, nullptr, 0, (float*)workspace, workspace_bytes);
     }
     return launch_conv<float, float>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st);
+}
+int dreg_conv3d_igemm(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
+                      int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                      int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
+                      int dtype, int out_f32, void* stream)
+{
+    return dreg_conv3d_igemm_ws(in, wt_packed, out, bias, addend, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, ksz, stride, pad, transposed, relu,
+                                Da, Ha, Wa, add_same, dtype, out_f32, nullptr, 0, stream);
 }
 
 // 1 (default): bf16 stride-1 convolutions use the direct-to-LDS kernel (8-wave 256x256 tile when Cout % 256 == 0 and the row
 // space is large, else 128 x {128|64}); 2: 128-row tiles only; 3: the 8-wave 128x256
 // tile when Cout % 256 == 0 (measured equal to 128x128 in round 1); 4: the 8-wave 256x256 tile (128x64 per wave);
-// 0: always the register-staged kernel (A/B checks).
+// 5: as 1 but never split-K; 0: always the register-staged kernel (A/B checks).
 void dreg_conv_set_glds(int enable) { g_use_glds = enable; }
 
 // K padding of the packed weight row for (ntaps, Cin) at dtype.
@@ -987,15 +1083,27 @@ int dreg_pack_conv_weights_batched(const void* descs, int n, int total_rows, int
 }
 
 // number of voxel splits the weight-gradient kernel will use (pure function of the shape)
+static int g_force_wgrad_splits = 0;
+// tuning / test knob: force the number of voxel splits of the weight-gradient kernels (0 = automatic)
+void dreg_conv_set_wgrad_splits(int splits) { g_force_wgrad_splits = splits; }
 int dreg_conv3d_wgrad_splits(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int dtype) {
+    if (g_force_wgrad_splits > 0) {
+        const long Mf = (long)B * Do * Ho * Wo;
+        long f = g_force_wgrad_splits;
+        if (f > (Mf + 63) / 64) f = (Mf + 63) / 64;
+        return (int)(f > 64 ? 64 : (f < 1 ? 1 : f));
+    }
     const int es = dtype == 0 ? 2 : 4;
     const int bke = 128 / es;
     const int Kpad = ((ksz * ksz * ksz * Cin + bke - 1) / bke) * bke;
     const int bnc = (Kpad % 128 == 0) ? 128 : 64;
     const long tiles = (long)((Cout % 128 == 0) ? Cout / 128 : Cout / 64) * (Kpad / bnc);
     const long M = (long)B * Do * Ho * Wo;
-    long s = (2048 + tiles - 1) / tiles;
-    const long maxs = (M + 255) / 256;  // at least 256 voxels per split
+    long s = (3072 + tiles - 1) / tiles;
+    // enough voxels per split that the fp32 partial tile written per block (64 KB) stays small next to its MFMA work:
+    // measured optimum on MI355X is ~1024 voxels for 3^3 taps, ~512 for 1^3 (tools/bench_small_conv.py)
+    const long vmin = ksz == 1 ? 512 : 1024;
+    const long maxs = (M + vmin - 1) / vmin;
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
     if (s > 64) s = 64;

@@ -31,10 +31,13 @@ P, I, F, Z = c_void_p, c_int, c_float, c_size_t
 SIGNATURES = {
     # conv.hip
     "dreg_conv3d_igemm": (I, [P, P, P, P, P] + [I] * 18 + [I, I, P]),
+    "dreg_conv3d_igemm_workspace_bytes": (Z, [I] * 15),
+    "dreg_conv3d_igemm_ws": (I, [P, P, P, P, P] + [I] * 18 + [I, I, P, Z, P]),
     "dreg_conv3d_kpad": (I, [I, I, I]),
     "dreg_conv_set_glds": (None, [I]),
     "dreg_pack_conv_weight": (I, [P, P, I, I, I, I, I, I, P]),
     "dreg_pack_conv_weights_batched": (I, [P, I, I, I, P]),
+    "dreg_conv_set_wgrad_splits": (None, [I]),
     "dreg_conv3d_wgrad_splits": (I, [I] * 8),
     "dreg_conv3d_wgrad_workspace_bytes": (Z, [I] * 8),
     "dreg_conv3d_wgrad": (I, [P, P, P, P, Z] + [I] * 16 + [P]),

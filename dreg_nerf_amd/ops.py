@@ -169,9 +169,13 @@ def conv_igemm(x, wpk, bias, addend, out_shape, cin, cout, ksz, stride, pad, tra
             flops /= 8.0  # only 1/8 of the taps of a stride-2 data gradient are algorithmically non-zero
         ev = PROFILER.record(name, label, flops)
         ev[0].record()
-    L.check(lib.dreg_conv3d_igemm(L.ptr(x), L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(addend),
-                                  B, Di, Hi, Wi, cin, Do, Ho, Wo, cout, ksz, stride, pad, int(transposed), int(relu),
-                                  Da, Ha, Wa, int(add_same), dt, int(out_f32 and dt == L.DT_BF16), L.stream()), "dreg_conv3d_igemm")
+    nws = lib.dreg_conv3d_igemm_workspace_bytes(B, Di, Hi, Wi, cin, Do, Ho, Wo, cout, ksz, stride, pad, int(transposed),
+                                                int(addend is not None), dt) if Do * Ho * Wo < 2048 else 0
+    ws = _ws(nws, x.device) if nws else None
+    L.check(lib.dreg_conv3d_igemm_ws(L.ptr(x), L.ptr(wpk), L.ptr(out), L.ptr(bias), L.ptr(addend),
+                                     B, Di, Hi, Wi, cin, Do, Ho, Wo, cout, ksz, stride, pad, int(transposed), int(relu),
+                                     Da, Ha, Wa, int(add_same), dt, int(out_f32 and dt == L.DT_BF16), L.ptr(ws), nws, L.stream()),
+            "dreg_conv3d_igemm_ws")
     if ev is not None:
         ev[1].record()
     return out

@@ -55,12 +55,22 @@ int dreg_conv3d_igemm(const void* in, const void* wt_packed, void* out, const fl
                       int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
                       int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
                       int dtype, int out_f32, void* stream);
+/* The same with an fp32 scratch buffer (dreg_conv3d_igemm_workspace_bytes; 0 = none needed): small row spaces — the 8^3 / 4^3
+ * levels of resnet3d.py's layer3/layer4 — then run split-K and are finished by a reduce + bias/ReLU/cast pass. */
+size_t dreg_conv3d_igemm_workspace_bytes(int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                                         int ksz, int stride, int pad, int transposed, int has_addend, int dtype);
+int dreg_conv3d_igemm_ws(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
+                         int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                         int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
+                         int dtype, int out_f32, void* workspace, size_t workspace_bytes, void* stream);
 
 /* 1 (default): bf16 stride-1 convolutions stage operands with buffer_load...lds; 0: register-staged kernel (A/B checks) */
 void dreg_conv_set_glds(int enable);
 
 /* Weight gradient (split over voxels, deterministic two-stage reduction):
  * dw[Cout][Cin_real][ksz^3] (fp32, torch layout) (+)= sum_m gout[m,:]^T x in[gather(m, tap), :]. */
+/* tuning / test knob: force the number of voxel splits of the weight-gradient kernels (0 = automatic) */
+void dreg_conv_set_wgrad_splits(int splits);
 int dreg_conv3d_wgrad_splits(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int dtype);
 size_t dreg_conv3d_wgrad_workspace_bytes(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int dtype);
 int dreg_conv3d_wgrad(const void* gout, const void* in, float* dw, void* workspace, size_t workspace_bytes,
