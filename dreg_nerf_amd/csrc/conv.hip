@@ -381,6 +381,16 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
             TO* dst = out + (size_t)m * g.Cout + n;
+            if (add_shift < 0) {
+                // stride-2 data gradient as a 2^3-tap convolution over dOut with 8 x Cin "parity class" output channels:
+                // channel block p = (pz,py,px) of coarse voxel (z,y,x) is voxel (2z+pz, 2y+py, 2x+px) of the [B,Da,Ha,Wa,Cin] result
+                const int cin = -add_shift, p = n / cin, ci = n - p * cin;
+                int b, z, y, x;
+                vox_decode(m, g, b, z, y, x);
+                const int zf = 2 * z + (p >> 2), yf = 2 * y + ((p >> 1) & 1), xf = 2 * x + (p & 1);
+                if (zf >= Da || yf >= Ha || xf >= Wa) continue;
+                dst = out + ((size_t)((b * Da + zf) * Ha + yf) * Wa + xf) * cin + ci;
+            }
             if constexpr (sizeof(TO) == 4) {
                 *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -821,6 +831,30 @@ __global__ void pack_weight_fwd_kernel(const float* __restrict__ w, T* __restric
         Elem<T>::st(out + i, v);
     }
 }
+// torch weight -> "parity class" pack of the stride-2 data gradient (pad = (ksz-1)/2, ksz 1 or 3): row (p, ci), p = 4pz+2py+px,
+// K' = j*Cout + co over the 2^3 taps j = 4jz+2jy+jx (ksz 3) or the single tap (ksz 1, class 0 only);
+// element = W[co][ci][d] with d_a = p_a + pad - 2 j_a when 0 <= d_a < ksz on every axis, else 0.
+__device__ __forceinline__ int s2_class_tap(int p, int j, int ksz)
+{
+    if (ksz == 1) return (p == 0 && j == 0) ? 0 : -1;
+    const int pad = ksz >> 1;
+    const int dz = (p >> 2) + pad - 2 * (j >> 2), dy = ((p >> 1) & 1) + pad - 2 * ((j >> 1) & 1), dx = (p & 1) + pad - 2 * (j & 1);
+    if ((unsigned)dz >= (unsigned)ksz || (unsigned)dy >= (unsigned)ksz || (unsigned)dx >= (unsigned)ksz) return -1;
+    return (dz * ksz + dy) * ksz + dx;
+}
+template <typename T>
+__global__ void pack_weight_s2class_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin_real, int ksz, int Kpad)
+{
+    const int ntaps = ksz * ksz * ksz, nj = ksz == 1 ? 1 : 8, ncls = ksz == 1 ? 1 : 8;
+    const size_t total = (size_t)ncls * Cin_real * Kpad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kpad), r = (int)(i / Kpad);
+        const int p = r / Cin_real, ci = r - p * Cin_real;
+        const int j = k / Cout, co = k - j * Cout;
+        const int tap = j < nj ? s2_class_tap(p, j, ksz) : -1;
+        Elem<T>::st(out + i, tap >= 0 ? w[((size_t)co * Cin_real + ci) * ntaps + tap] : 0.f);
+    }
+}
 // All weight packs of a step in ONE launch (they are re-made after every optimizer update).  One block per packed row
 // (block -> descriptor by binary search over the row prefix): the row's fp32 source elements are staged in LDS with coalesced
 // reads (forward pack: one contiguous [Cin][taps] span; data-gradient pack: Cout spans of `taps` floats), then written as one
@@ -838,9 +872,11 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDes
         if (descs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const PackDesc d = descs[lo];
-    const int r = (int)blockIdx.x - d.block0;            // co (forward pack) or ci (data-gradient pack)
+    int r = (int)blockIdx.x - d.block0;                 // co (forward pack), ci (data-gradient pack) or (class, ci)
     const int inner = d.for_dgrad ? d.Cout : d.Cin;     // channels per tap in the packed row
     const int nsrc = (d.for_dgrad ? d.Cout : d.Cin_real) * d.ntaps;
+    const int cls = d.for_dgrad == 2 ? r / d.Cin_real : 0;
+    if (d.for_dgrad == 2) r -= cls * d.Cin_real;
     if (!d.for_dgrad) {
         const float* src = d.w + (size_t)r * nsrc;
         for (int i = threadIdx.x; i < nsrc; i += 256) stage[i] = src[i];
@@ -852,10 +888,13 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDes
     }
     __syncthreads();
     const int nreal = d.for_dgrad ? d.Cout : d.Cin_real;
+    const int ksz = d.ntaps == 1 ? 1 : (d.ntaps == 27 ? 3 : 5);
     for (int k = threadIdx.x; k < d.Kpad; k += 256) {
-        const int tap = k / inner, c = k - tap * inner;
-        const float v = (tap < d.ntaps && c < nreal) ? stage[c * d.ntaps + tap] : 0.f;
-        const size_t o = (size_t)r * d.Kpad + k;
+        int tap = k / inner;
+        const int c = k - tap * inner;
+        if (d.for_dgrad == 2) tap = tap < (ksz == 1 ? 1 : 8) ? s2_class_tap(cls, tap, ksz) : -1;
+        const float v = (tap >= 0 && tap < d.ntaps && c < nreal) ? stage[c * d.ntaps + tap] : 0.f;
+        const size_t o = ((size_t)cls * d.Cin_real + r) * d.Kpad + k;
         if (d.dtype == 0) Elem<bf16_t>::st((bf16_t*)d.out + o, v);
         else ((float*)d.out)[o] = v;
     }
@@ -883,7 +922,7 @@ static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static int fill_geom(ConvGeom& g, int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
                      int ksz, int stride, int pad, int transposed, int esize)
 {
-    if ((ksz != 1 && !is_pow2(Cin)) || (Cin * esize) % 16 != 0 || !(ksz == 1 || ksz == 3 || ksz == 5) || !(stride == 1 || stride == 2)) return DREG_EINVAL;
+    if ((ksz != 1 && !is_pow2(Cin)) || (Cin * esize) % 16 != 0 || !(ksz == 1 || ksz == 2 || ksz == 3 || ksz == 5) || !(stride == 1 || stride == 2)) return DREG_EINVAL;
     g.B = B; g.Di = Di; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.log2Cin = (ksz == 1) ? 30 : ilog2(Cin);
     g.Cmask = (1 << g.log2Cin) - 1;
     g.Do = Do; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout;
@@ -1030,11 +1069,34 @@ int dreg_conv3d_igemm(const void* in, const void* wt_packed, void* out, const fl
                                 Da, Ha, Wa, add_same, dtype, out_f32, nullptr, 0, stream);
 }
 
+// Data gradient of a stride-2 convolution (ksz 3 / pad 1 or ksz 1 / pad 0; bf16) without the 7/8 structurally-zero taps of the
+// gather form: one 2^3-tap convolution over dOut [B,Do,Ho,Wo,Cout] whose 8 x Cin output channels are the 8 parity classes
+// of dIn [B,Di,Hi,Wi,Cin] (written in place by the epilogue).  wt_class_packed: dreg_pack_conv_weight(..., for_dgrad = 2).
+int dreg_conv3d_dgrad_s2(const void* gout, const void* wt_class_packed, void* din, int B, int Di, int Hi, int Wi, int Cin,
+                         int Do, int Ho, int Wo, int Cout, int ksz, int pad, void* stream)
+{
+    if (!g_use_glds) return DREG_EINVAL;   // served by the direct-to-LDS kernel only (callers check dreg_conv_get_glds)
+    if (!((ksz == 3 && pad == 1) || (ksz == 1 && pad == 0)) || Cout % 64 != 0 || Cin % 8 != 0) return DREG_EINVAL;
+    if (Do != (Di + 2 * pad - ksz) / 2 + 1 || Ho != (Hi + 2 * pad - ksz) / 2 + 1 || Wo != (Wi + 2 * pad - ksz) / 2 + 1) return DREG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int Dc = (Di + 1) / 2, Hc = (Hi + 1) / 2, Wc = (Wi + 1) / 2;     // class lattice
+    const int ncls = ksz == 1 ? 1 : 8;
+    if ((ncls * Cin) % 64 != 0) return DREG_EINVAL;
+    ConvGeom g;
+    // class convolution: rows [B,Dc,Hc,Wc], gathered operand dOut (Cin of the geometry = Cout), taps {0,+1}^3 (or the single tap)
+    int rc = fill_geom(g, B, Do, Ho, Wo, Cout, Dc, Hc, Wc, ncls * Cin, ksz == 1 ? 1 : 2, 1, 0, 0, 2);
+    if (rc) return rc;
+    if (g.M == 0) return DREG_OK;
+    if (ksz == 1 && hipMemsetAsync(din, 0, (size_t)B * Di * Hi * Wi * Cin * 2, st) != hipSuccess) return DREG_ELAUNCH;
+    return launch_conv<bf16_t, bf16_t>(gout, wt_class_packed, din, nullptr, nullptr, g, 0, Di, Hi, Wi, -Cin, st);
+}
+
 // 1 (default): bf16 stride-1 convolutions use the direct-to-LDS kernel (8-wave 256x256 tile when Cout % 256 == 0 and the row
 // space is large, else 128 x {128|64}); 2: 128-row tiles only; 3: the 8-wave 128x256
 // tile when Cout % 256 == 0 (measured equal to 128x128 in round 1); 4: the 8-wave 256x256 tile (128x64 per wave);
 // 5: as 1 but never split-K; 0: always the register-staged kernel (A/B checks).
 void dreg_conv_set_glds(int enable) { g_use_glds = enable; }
+int dreg_conv_get_glds(void) { return g_use_glds; }
 
 // K padding of the packed weight row for (ntaps, Cin) at dtype.
 int dreg_conv3d_kpad(int ksz, int Cin, int dtype) {
@@ -1054,6 +1116,13 @@ int dreg_pack_conv_weight(const float* w, void* out, int Cout, int Cin_real, int
         const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
         if (dtype == 0) hipLaunchKernelGGL(pack_weight_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, w, (bf16_t*)out, Cout, Cin_real, ntaps, Cin, ilog2(Cin), Kpad);
         else hipLaunchKernelGGL(pack_weight_fwd_kernel<float>, dim3(blocks), dim3(256), 0, st, w, (float*)out, Cout, Cin_real, ntaps, Cin, ilog2(Cin), Kpad);
+    } else if (for_dgrad == 2) {
+        if (!(ksz == 1 || ksz == 3) || Cout % 64 != 0) return DREG_EINVAL;
+        const int Kpad = dreg_conv3d_kpad(ksz == 1 ? 1 : 2, Cout, dtype);
+        const size_t total = (size_t)(ksz == 1 ? 1 : 8) * Cin_real * Kpad;
+        const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+        if (dtype == 0) hipLaunchKernelGGL(pack_weight_s2class_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, w, (bf16_t*)out, Cout, Cin_real, ksz, Kpad);
+        else hipLaunchKernelGGL(pack_weight_s2class_kernel<float>, dim3(blocks), dim3(256), 0, st, w, (float*)out, Cout, Cin_real, ksz, Kpad);
     } else {
         if (ksz != 1 && !is_pow2(Cout)) return DREG_EINVAL;
         const int Kpad = dreg_conv3d_kpad(ksz, Cout, dtype);

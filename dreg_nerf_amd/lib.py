@@ -35,6 +35,8 @@ SIGNATURES = {
     "dreg_conv3d_igemm_ws": (I, [P, P, P, P, P] + [I] * 18 + [I, I, P, Z, P]),
     "dreg_conv3d_kpad": (I, [I, I, I]),
     "dreg_conv_set_glds": (None, [I]),
+    "dreg_conv_get_glds": (I, []),
+    "dreg_conv3d_dgrad_s2": (I, [P, P, P] + [I] * 11 + [P]),
     "dreg_pack_conv_weight": (I, [P, P, I, I, I, I, I, I, P]),
     "dreg_pack_conv_weights_batched": (I, [P, I, I, I, P]),
     "dreg_conv_set_wgrad_splits": (None, [I]),

@@ -78,6 +78,10 @@ def packed_weight(w: torch.Tensor, cin_pad: int, for_dgrad: bool, dt: int) -> to
     if not for_dgrad:
         kpad = lib.dreg_conv3d_kpad(ksz, cin_pad, dt)
         out = hit[2] if hit is not None and hit[0]() is base else torch.empty(cout, kpad, dtype=L.torch_dtype(dt), device=w.device)
+    elif for_dgrad == 2:   # parity-class pack of the stride-2 data gradient: rows (class, ci), K = (2^3 taps | 1) x Cout
+        kpad = lib.dreg_conv3d_kpad(1 if ksz == 1 else 2, cout, dt)
+        nrow = (1 if ksz == 1 else 8) * cin_real
+        out = hit[2] if hit is not None and hit[0]() is base else torch.empty(nrow, kpad, dtype=L.torch_dtype(dt), device=w.device)
     else:
         kpad = lib.dreg_conv3d_kpad(ksz, cout, dt)
         out = hit[2] if hit is not None and hit[0]() is base else torch.empty(cin_real, kpad, dtype=L.torch_dtype(dt), device=w.device)
@@ -124,7 +128,7 @@ def repack_all(device=None):
             rec[r, 0:2] = np.frombuffer(np.int64(src).tobytes(), dtype=np.int32)
             rec[r, 2:4] = np.frombuffer(np.int64(ent[2].data_ptr()).tobytes(), dtype=np.int32)
             rec[r, 4:12] = (cout, cin_real, inner, ntaps, fd, kpad, dt, row0)
-            row0 += cin_real if fd else cout
+            row0 += (cin_real * (8 if (fd == 2 and ntaps > 1) else 1)) if fd else cout
             max_floats = max(max_floats, (cout if fd else cin_real) * ntaps)
         _pack_table = (torch.from_numpy(rec).to(live[0][2].device), len(live), row0, sig, max_floats)
     tab, n, nrows, _, max_floats = _pack_table
@@ -179,6 +183,25 @@ def conv_igemm(x, wpk, bias, addend, out_shape, cin, cout, ksz, stride, pad, tra
     if ev is not None:
         ev[1].record()
     return out
+
+
+def conv_dgrad_s2(g, wpk_class, x_shape, cout, ksz, pad):
+    """Data gradient of a stride-2 convolution through the parity-class form (dreg_conv3d_dgrad_s2): g [B,Do,Ho,Wo,cout] bf16."""
+    lib = L.load()
+    B, Di, Hi, Wi, cin = x_shape
+    Do, Ho, Wo = g.shape[1:4]
+    gx = torch.empty(x_shape, dtype=g.dtype, device=g.device)
+    ev = None
+    if PROFILER is not None:
+        # algorithmic flops: the 27 (or 1) taps of the true data gradient, not the 64 of the padded class form
+        ev = PROFILER.record("conv_igemm_glds_kernel<bf16,s2-dgrad>", f"dgrad-s2 B{B} {Do}x{Ho}x{Wo}x{cout}->{Di}x{Hi}x{Wi}x{cin} k{ksz}s2",
+                             2.0 * B * Do * Ho * Wo * cout * (ksz ** 3) * cin)
+        ev[0].record()
+    L.check(lib.dreg_conv3d_dgrad_s2(L.ptr(g), L.ptr(wpk_class), L.ptr(gx), B, Di, Hi, Wi, cin, Do, Ho, Wo, cout, ksz, pad, L.stream()),
+            "dreg_conv3d_dgrad_s2")
+    if ev is not None:
+        ev[1].record()
+    return gx
 
 
 def conv_wgrad(gout, x, w_shape, cin_pad, ksz, stride, pad, use_tr=True, accumulate_into=None):
@@ -292,8 +315,12 @@ class Conv3dFn(torch.autograd.Function):
         if add_shape is not None and ctx.needs_input_grad[3] and y is not None:
             ga = g if add_same else downsample_sum(g, add_shape)
         if ctx.needs_input_grad[0]:
-            wpk = packed_weight(w, cin_pad, True, dt)
-            gx = conv_igemm(g, wpk, None, None, tuple(x.shape[1:4]), cout, w.shape[1], ksz, stride, pad, True)
+            if stride == 2 and dt == L.DT_BF16 and ((ksz == 3 and pad == 1) or (ksz == 1 and pad == 0)) and cout % 64 == 0 \
+                    and w.shape[1] % 64 == 0 and L.load().dreg_conv_get_glds():
+                gx = conv_dgrad_s2(g, packed_weight(w, cin_pad, 2, dt), tuple(x.shape), cout, ksz, pad)
+            else:
+                wpk = packed_weight(w, cin_pad, True, dt)
+                gx = conv_igemm(g, wpk, None, None, tuple(x.shape[1:4]), cout, w.shape[1], ksz, stride, pad, True)
         if ctx.needs_input_grad[1]:
             gw = conv_wgrad(g, x, tuple(w.shape), cin_pad, ksz, stride, pad, USE_TR, accumulate_into=_grad_sink(w))
         if has_bias and ctx.needs_input_grad[2]:

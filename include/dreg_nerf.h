@@ -66,6 +66,13 @@ int dreg_conv3d_igemm_ws(const void* in, const void* wt_packed, void* out, const
 
 /* 1 (default): bf16 stride-1 convolutions stage operands with buffer_load...lds; 0: register-staged kernel (A/B checks) */
 void dreg_conv_set_glds(int enable);
+int dreg_conv_get_glds(void);
+/* Data gradient of a stride-2 convolution (ksz 3 / pad 1: resnet3d.py conv2 of the first block of layer2-4; ksz 1 / pad 0: the
+ * downsample branch) without the 7/8 structurally-zero taps of the gather form: ONE 2^3-tap convolution over dOut whose
+ * 8 x Cin output channels are the 8 parity classes of dIn (scattered in place by the epilogue).  bf16 only;
+ * wt_class_packed = dreg_pack_conv_weight(..., for_dgrad = 2): rows (class, ci), K = tap*Cout + co. */
+int dreg_conv3d_dgrad_s2(const void* gout, const void* wt_class_packed, void* din, int B, int Di, int Hi, int Wi, int Cin,
+                         int Do, int Ho, int Wo, int Cout, int ksz, int pad, void* stream);
 
 /* Weight gradient (split over voxels, deterministic two-stage reduction):
  * dw[Cout][Cin_real][ksz^3] (fp32, torch layout) (+)= sum_m gout[m,:]^T x in[gather(m, tap), :]. */

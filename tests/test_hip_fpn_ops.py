@@ -33,6 +33,8 @@ CONV_CASES = [
     (1, (16, 14, 12), 4, 8, 64, 5, 2, 2),
     (1, (6, 6, 6), 256, 256, 256, 3, 1, 1),
     (1, (1, 1, 300), 256, 256, 768, 1, 1, 0),
+    (2, (10, 12, 8), 64, 64, 256, 3, 2, 1),     # stride-2 data gradient through the parity-class form, even dims
+    (1, (5, 6, 7), 512, 512, 64, 1, 2, 0),
 ]
 
 
