@@ -130,8 +130,9 @@ class ProblemTable:
         for (s0, ns, t0, nt) in starts:
             self_p += [[s0, ns, s0, ns], [t0, nt, t0, nt]]
             cross_p += [[s0, ns, t0, nt], [t0, nt, s0, ns]]
-        self.self_probs = torch.tensor(self_p, dtype=torch.int32, device=device)
-        self.cross_probs = torch.tensor(cross_p, dtype=torch.int32, device=device)
+        device = torch.device(device)
+        self.self_probs = L.to_device_async(self_p, torch.int32, device)   # no pageable H2D copy: that would drain the stream
+        self.cross_probs = L.to_device_async(cross_p, torch.int32, device)
         self.max_len = max(max(ns, nt) for ns, nt in seg_lengths)
         self.nprob = len(self_p)
 
@@ -329,7 +330,7 @@ def voxel_mean_downsample(points, feats, lengths, dl: float):
     lens = [int(v) for v in lengths]
     dev = feats.device
     pt_batch = torch.repeat_interleave(torch.arange(len(lens), dtype=torch.int32, device=dev),
-                                       torch.tensor(lens, device=dev))
+                                       L.to_device_async(lens, torch.int64, dev))
     p, f, counts = _VoxelMeanFn.apply(points, feats, pt_batch, len(lens), dl)
     return p, f, counts
 
@@ -346,7 +347,7 @@ def plan_voxel_downsample(points, lengths, dl: float):
     dev = points.device
     n = points.shape[0]
     pt_batch = torch.repeat_interleave(torch.arange(len(lens), dtype=torch.int32, device=dev),
-                                       torch.tensor(lens, device=dev), output_size=n)
+                                       L.to_device_async(lens, torch.int64, dev), output_size=n)
     points = points.detach().contiguous()
     r = SubsampleRound()
     out_p = torch.empty(n, 3, dtype=torch.float32, device=dev)

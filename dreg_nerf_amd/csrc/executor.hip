@@ -1,0 +1,402 @@
+// Native executor of the FPN3D trunk (forward + backward) on gfx950: a recorded op program — convolutions, per-grid
+// BatchNorm (+residual, +ReLU), max-pool and the active-set head convolutions — is issued from C++ in one call per pass,
+// so a training step spends ~1 ms of host time on the ~900 kernel launches of the feature network instead of one Python
+// autograd node per layer.  The program is recorded once per (batch, resolution) by dreg_nerf_amd/trunk_exec.py from the
+// same Python description of the network that drives the per-op path (regtr.NeRFRegTr.fpn), and both paths call the same
+// kernels in the same order: forward results are bit-identical.
+//
+// Reference call sites of the network this executes: conerf/model/resnet3d.py:86-161 (Bottleneck / ResNet forward),
+// conerf/model/feature_pyramid_net.py:97-127 (FeaturePyramid.forward), conerf/register/nerf_regtr.py:131-137.
+//
+// Memory: the caller owns one arena (dreg_exec_arena_bytes) holding every activation (kept for the backward pass), the
+// BatchNorm statistics, the activation gradients and the kernels' scratch; weight gradients are accumulated in place into
+// the caller's fp32 gradient buffers (FlatAdamW's flat buffer), packed bf16 weights live in a second caller-owned buffer
+// refreshed by dreg_exec_repack (one launch) after every optimizer update.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "../../include/dreg_nerf.h"
+#ifndef DREG_ELAUNCH
+#define DREG_ELAUNCH (-2)
+#endif
+
+namespace {
+
+enum { OP_CONV = 0, OP_BN = 1, OP_MAXPOOL = 2, OP_CONV_ROWS = 3 };
+constexpr int OP_INTS = 16;      // ints per op record
+constexpr int TENSOR_INTS = 5;   // B, D, H, W, C
+constexpr int PARAM_I64 = 5;     // value ptr, grad ptr, d0, d1, ksz  (conv weight: [d0=Cout][d1=Cin][ksz^3]; vectors: d0 = length)
+
+struct Tensor { int B, D, H, W, C; size_t bytes, off, goff; };
+struct Param {
+    float* val; float* grad; int d0, d1, ksz;
+    size_t pk_fwd = SIZE_MAX, pk_dgrad = SIZE_MAX, pk_cls = SIZE_MAX;   // offsets in the pack buffer
+    int cin_pad = 0;
+};
+struct Op {
+    int kind, in, out, in2, w, b, p2, p3, p4, ksz, stride, pad, relu, add_same, rows_out, rows_in;
+    size_t aux0 = 0, aux1 = 0;   // BN: scale_shift / mean_rstd; max-pool: argmax
+};
+struct PackRec { const float* w; void* out; int Cout, Cin_real, inner, ntaps, for_dgrad, Kpad, dtype, row0; };
+static_assert(sizeof(PackRec) == 48, "matches PackDesc of conv.hip");
+
+struct TimedLaunch { hipEvent_t e0, e1; int op, kind; };
+
+struct Exec {
+    std::vector<Tensor> t;
+    std::vector<Op> ops;
+    std::vector<Param> prm;
+    std::vector<char> needs_grad;          // per tensor: some parameter lies upstream
+    size_t act_bytes = 0, arena_bytes = 0, pack_bytes = 0;
+    size_t off_bn_ws = 0, off_coef = 0, off_ks = 0, off_wg = 0, off_cs = 0, off_tmp = 0;
+    size_t sz_ks = 0, sz_wg = 0;
+    std::vector<PackRec> packs;            // with out = offset (patched on export)
+    int pack_rows = 0, pack_max_floats = 0;
+    int out_slot = -1;
+    bool timing = false;
+    std::vector<TimedLaunch> timed;
+    size_t timed_used = 0;
+};
+
+inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+inline int out_dim(int i, int k, int s, int p) { return (i + 2 * p - k) / s + 1; }
+
+struct Scope {   // optional HIP-event bracket of one launch group
+    Exec* e; hipStream_t st; TimedLaunch* tl = nullptr;
+    Scope(Exec* ex, hipStream_t s, int op, int kind) : e(ex), st(s) {
+        if (!e->timing) return;
+        if (e->timed_used == e->timed.size()) {
+            TimedLaunch n{}; n.op = op; n.kind = kind;
+            if (hipEventCreate(&n.e0) != hipSuccess || hipEventCreate(&n.e1) != hipSuccess) return;
+            e->timed.push_back(n);
+        }
+        tl = &e->timed[e->timed_used++];
+        tl->op = op; tl->kind = kind;
+        (void)hipEventRecord(tl->e0, st);
+    }
+    ~Scope() { if (tl) (void)hipEventRecord(tl->e1, st); }
+};
+
+#define CK(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
+bool s2_class_ok(const Param& p, int ksz, int stride, int pad)
+{
+    return stride == 2 && ((ksz == 3 && pad == 1) || (ksz == 1 && pad == 0)) && p.d0 % 64 == 0 && p.d1 % 64 == 0 && dreg_conv_get_glds();
+}
+
+}  // namespace
+
+extern "C" {
+
+// tensors: int32 [nt][5] (B,D,H,W,C; bf16 NDHWC; tensor 0 is the external input), ops: int32 [nops][16]
+//   { kind, in, out, in2 (addend / residual, -1), w, b, p2, p3, p4 (BN: gamma=w, beta=b, running_mean, running_var), ksz, stride,
+//     pad, relu, add_same, rows_out, rows_in (row-list ids of OP_CONV_ROWS) },
+// params: int64 [np][5] { fp32 value ptr, fp32 grad ptr (0 = frozen), d0, d1, ksz }.  The last op's output is the result.
+void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, const int64_t* params, int np)
+{
+    Exec* e = new Exec();
+    e->t.resize(nt);
+    for (int i = 0; i < nt; ++i) {
+        Tensor& t = e->t[i];
+        t.B = tensors[i * TENSOR_INTS]; t.D = tensors[i * TENSOR_INTS + 1]; t.H = tensors[i * TENSOR_INTS + 2];
+        t.W = tensors[i * TENSOR_INTS + 3]; t.C = tensors[i * TENSOR_INTS + 4];
+        t.bytes = align256((size_t)t.B * t.D * t.H * t.W * t.C * 2);
+    }
+    e->prm.resize(np);
+    for (int i = 0; i < np; ++i) {
+        Param& p = e->prm[i];
+        p.val = (float*)params[i * PARAM_I64]; p.grad = (float*)params[i * PARAM_I64 + 1];
+        p.d0 = (int)params[i * PARAM_I64 + 2]; p.d1 = (int)params[i * PARAM_I64 + 3]; p.ksz = (int)params[i * PARAM_I64 + 4];
+    }
+    e->ops.resize(nops);
+    for (int i = 0; i < nops; ++i) {
+        const int* r = ops + i * OP_INTS;
+        Op& o = e->ops[i];
+        o.kind = r[0]; o.in = r[1]; o.out = r[2]; o.in2 = r[3]; o.w = r[4]; o.b = r[5]; o.p2 = r[6]; o.p3 = r[7]; o.p4 = r[8];
+        o.ksz = r[9]; o.stride = r[10]; o.pad = r[11]; o.relu = r[12]; o.add_same = r[13]; o.rows_out = r[14]; o.rows_in = r[15];
+        if (o.in < 0 || o.in >= nt || o.out <= 0 || o.out >= nt || o.in2 >= nt) { delete e; return nullptr; }
+    }
+    e->out_slot = nops ? e->ops.back().out : -1;
+
+    // which tensors carry a gradient: everything downstream of a trainable parameter
+    e->needs_grad.assign(nt, 0);
+    for (const Op& o : e->ops) {
+        bool g = e->needs_grad[o.in] || (o.in2 >= 0 && e->needs_grad[o.in2]);
+        if (o.kind == OP_CONV || o.kind == OP_CONV_ROWS) g = g || e->prm[o.w].grad || (o.b >= 0 && e->prm[o.b].grad);
+        if (o.kind == OP_BN) g = g || e->prm[o.w].grad || e->prm[o.b].grad;
+        e->needs_grad[o.out] = g;
+    }
+
+    // arena: activations | BN statistics / argmax | gradients | scratch
+    size_t off = 0;
+    for (int i = 1; i < nt; ++i) { e->t[i].off = off; off += e->t[i].bytes; }
+    size_t max_tensor = 0, bn_ws = 0, coef = 0, cs = 0;
+    for (Op& o : e->ops) {
+        const Tensor& x = e->t[o.in];
+        if (o.kind == OP_BN) {
+            const size_t sb = align256((size_t)x.B * x.C * 2 * sizeof(float));
+            o.aux0 = off; off += sb; o.aux1 = off; off += sb;
+            const size_t V = (size_t)x.D * x.H * x.W;
+            const size_t w = (size_t)x.B * dreg_bn_num_chunks((int)V) * x.C * 2 * sizeof(float);
+            if (w > bn_ws) bn_ws = w;
+            if (sb > coef) coef = sb;
+        } else if (o.kind == OP_MAXPOOL) {
+            const Tensor& y = e->t[o.out];
+            o.aux0 = off; off += align256((size_t)y.B * y.D * y.H * y.W * y.C);
+        } else {
+            const Param& w = e->prm[o.w];
+            const Tensor& y = e->t[o.out];
+            const size_t k1 = dreg_conv3d_igemm_workspace_bytes(x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0, o.ksz, o.stride, o.pad, 0, o.in2 >= 0, 0);
+            const size_t k2 = dreg_conv3d_igemm_workspace_bytes(x.B, y.D, y.H, y.W, w.d0, x.D, x.H, x.W, w.d1, o.ksz, o.stride, o.pad, 1, 0, 0);
+            if (k1 > e->sz_ks) e->sz_ks = k1;
+            if (k2 > e->sz_ks) e->sz_ks = k2;
+            const size_t g = dreg_conv3d_wgrad_workspace_bytes(x.B, y.D, y.H, y.W, x.C, w.d0, o.ksz, 0);
+            if (g > e->sz_wg) e->sz_wg = g;
+            const size_t c = dreg_colsum_workspace_bytes((size_t)y.B * y.D * y.H * y.W, w.d0);
+            if (c > cs) cs = c;
+        }
+    }
+    e->act_bytes = off;
+    for (int i = 1; i < nt; ++i) {
+        if (e->t[i].bytes > max_tensor) max_tensor = e->t[i].bytes;
+        if (e->needs_grad[i] && i != e->out_slot) { e->t[i].goff = off; off += e->t[i].bytes; } else e->t[i].goff = SIZE_MAX;
+    }
+    e->off_bn_ws = off; off += align256(bn_ws);
+    e->off_coef = off; off += align256(coef);
+    e->off_ks = off; off += align256(e->sz_ks);
+    e->off_wg = off; off += align256(e->sz_wg);
+    e->off_cs = off; off += align256(cs);
+    e->off_tmp = off; off += max_tensor;
+    e->arena_bytes = off + 256;
+
+    // weight packs: forward for every convolution; data-gradient (gather or stride-2 class form) where the input carries a gradient
+    size_t poff = 0;
+    auto add_pack = [&](Param& p, int kind, int cin_pad) {
+        PackRec r{};
+        const int ntaps = p.ksz * p.ksz * p.ksz;
+        r.w = p.val; r.Cout = p.d0; r.Cin_real = p.d1; r.ntaps = ntaps; r.for_dgrad = kind; r.dtype = 0; r.row0 = e->pack_rows;
+        int rows;
+        if (kind == 0) { r.inner = cin_pad; r.Kpad = dreg_conv3d_kpad(p.ksz, cin_pad, 0); rows = p.d0; }
+        else if (kind == 1) { r.inner = p.d0; r.Kpad = dreg_conv3d_kpad(p.ksz, p.d0, 0); rows = p.d1; }
+        else { r.inner = p.d0; r.Kpad = dreg_conv3d_kpad(p.ksz == 1 ? 1 : 2, p.d0, 0); rows = (p.ksz == 1 ? 1 : 8) * p.d1; }
+        r.out = (void*)poff;
+        const size_t o = poff;
+        poff += align256((size_t)rows * r.Kpad * 2);
+        e->pack_rows += rows;
+        const int fl = (kind ? p.d0 : p.d1) * ntaps;
+        if (fl > e->pack_max_floats) e->pack_max_floats = fl;
+        e->packs.push_back(r);
+        return o;
+    };
+    for (const Op& o : e->ops) {
+        if (o.kind != OP_CONV && o.kind != OP_CONV_ROWS) continue;
+        Param& p = e->prm[o.w];
+        const Tensor& x = e->t[o.in];
+        if (p.pk_fwd == SIZE_MAX) { p.cin_pad = x.C; p.pk_fwd = add_pack(p, 0, x.C); }
+        if (e->needs_grad[o.in]) {
+            if (o.kind == OP_CONV && s2_class_ok(p, o.ksz, o.stride, o.pad)) { if (p.pk_cls == SIZE_MAX) p.pk_cls = add_pack(p, 2, x.C); }
+            else if (p.pk_dgrad == SIZE_MAX) p.pk_dgrad = add_pack(p, 1, x.C);
+        }
+    }
+    e->pack_bytes = poff + 256;
+    return e;
+}
+
+void dreg_exec_destroy(void* h)
+{
+    Exec* e = (Exec*)h;
+    if (!e) return;
+    for (auto& t : e->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
+    delete e;
+}
+
+size_t dreg_exec_arena_bytes(void* h) { return ((Exec*)h)->arena_bytes; }
+size_t dreg_exec_pack_bytes(void* h) { return ((Exec*)h)->pack_bytes; }
+int dreg_exec_num_packs(void* h) { return (int)((Exec*)h)->packs.size(); }
+// byte offset of tensor `slot` in the arena (activation) — slot 0 is external
+size_t dreg_exec_tensor_offset(void* h, int slot) { return ((Exec*)h)->t[slot].off; }
+int dreg_exec_output_slot(void* h) { return ((Exec*)h)->out_slot; }
+
+// Write the 48-byte pack descriptors (dreg_pack_conv_weights_batched) for a pack buffer at device address pack_base into host memory.
+int dreg_exec_export_pack_table(void* h, void* host_out, void* pack_base)
+{
+    Exec* e = (Exec*)h;
+    PackRec* o = (PackRec*)host_out;
+    for (size_t i = 0; i < e->packs.size(); ++i) { o[i] = e->packs[i]; o[i].out = (char*)pack_base + (size_t)e->packs[i].out; }
+    return DREG_OK;
+}
+// descs_dev: the exported table copied to the device by the caller
+int dreg_exec_repack(void* h, const void* descs_dev, void* stream)
+{
+    Exec* e = (Exec*)h;
+    return dreg_pack_conv_weights_batched(descs_dev, (int)e->packs.size(), e->pack_rows, e->pack_max_floats, stream);
+}
+
+void dreg_exec_set_timing(void* h, int enable) { Exec* e = (Exec*)h; e->timing = enable != 0; e->timed_used = 0; }
+// After a stream synchronisation: elapsed ms of the bracketed launches since the last set_timing; records are (op, kind, ms)
+// with kind 0 forward, 1 data gradient, 2 weight gradient (+reduce).  Returns the number written (<= max) and restarts.
+int dreg_exec_read_timings(void* h, int* op_kind, float* ms, int max)
+{
+    Exec* e = (Exec*)h;
+    int n = 0;
+    for (size_t i = 0; i < e->timed_used && n < max; ++i) {
+        float v = 0.f;
+        if (hipEventElapsedTime(&v, e->timed[i].e0, e->timed[i].e1) != hipSuccess) continue;
+        op_kind[2 * n] = e->timed[i].op; op_kind[2 * n + 1] = e->timed[i].kind; ms[n] = v; ++n;
+    }
+    e->timed_used = 0;
+    return n;
+}
+
+// rowlists: int64 [nlists][2] = (device int32* rows, count).  x: tensor 0.  The result lands at dreg_exec_tensor_offset(output slot).
+int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack_base, const void* x_in,
+                      const int64_t* rowlists, int nlists, int train, void* stream)
+{
+    Exec* e = (Exec*)h;
+    if (arena_bytes < e->arena_bytes) return DREG_EINVAL;
+    char* A = (char*)arena;
+    const char* PK = (const char*)pack_base;
+    hipStream_t st = (hipStream_t)stream;
+    auto act = [&](int s) -> void* { return s == 0 ? (void*)x_in : (void*)(A + e->t[s].off); };
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+        const Op& o = e->ops[i];
+        const Tensor& x = e->t[o.in];
+        const Tensor& y = e->t[o.out];
+        if (o.kind == OP_CONV) {
+            const Param& w = e->prm[o.w];
+            const float* bias = o.b >= 0 ? e->prm[o.b].val : nullptr;
+            const void* add = o.in2 >= 0 ? act(o.in2) : nullptr;
+            const Tensor* ta = o.in2 >= 0 ? &e->t[o.in2] : nullptr;
+            Scope sc(e, st, (int)i, 0);
+            CK(dreg_conv3d_igemm_ws(act(o.in), PK + w.pk_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0,
+                                    o.ksz, o.stride, o.pad, 0, o.relu, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0, o.add_same, 0, 0,
+                                    A + e->off_ks, e->sz_ks, stream));
+        } else if (o.kind == OP_CONV_ROWS) {
+            const Param& w = e->prm[o.w];
+            if (o.rows_out < 0 || o.rows_out >= nlists) return DREG_EINVAL;
+            const float* bias = o.b >= 0 ? e->prm[o.b].val : nullptr;
+            const void* add = o.in2 >= 0 ? act(o.in2) : nullptr;
+            const Tensor* ta = o.in2 >= 0 ? &e->t[o.in2] : nullptr;
+            Scope sc(e, st, (int)i, 0);
+            CK(dreg_conv3d_igemm_rows(act(o.in), PK + w.pk_fwd, act(o.out), bias, add, (const int*)rowlists[2 * o.rows_out], (int)rowlists[2 * o.rows_out + 1],
+                                      x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0, o.ksz, 1, o.pad, 0, 0, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0,
+                                      0, 0, stream));
+        } else if (o.kind == OP_BN) {
+            const int V = x.D * x.H * x.W;
+            CK(dreg_bn3d_fwd(act(o.in), o.in2 >= 0 ? act(o.in2) : nullptr, act(o.out), e->prm[o.w].val, e->prm[o.b].val, e->prm[o.p2].val, e->prm[o.p3].val,
+                             (float*)(A + o.aux0), (float*)(A + o.aux1), (float*)(A + e->off_bn_ws), x.B, V, x.C, 1e-5f, 0.1f, train, o.relu, 0, stream));
+        } else if (o.kind == OP_MAXPOOL) {
+            CK(dreg_maxpool3d_fwd(act(o.in), act(o.out), (uint8_t*)(A + o.aux0), x.B, x.D, x.H, x.W, y.D, y.H, y.W, x.C, 0, stream));
+        } else return DREG_EINVAL;
+    }
+    return DREG_OK;
+}
+
+// grad_out: gradient of the result tensor (bf16, same shape).  Weight / bias / BatchNorm gradients are ACCUMULATED into the
+// parameters' grad pointers; nothing is returned for the input tensor 0.
+int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pack_base, const void* x_in, const void* grad_out,
+                       const int64_t* rowlists, int nlists, void* stream)
+{
+    Exec* e = (Exec*)h;
+    if (arena_bytes < e->arena_bytes) return DREG_EINVAL;
+    char* A = (char*)arena;
+    const char* PK = (const char*)pack_base;
+    hipStream_t st = (hipStream_t)stream;
+    auto act = [&](int s) -> void* { return s == 0 ? (void*)x_in : (void*)(A + e->t[s].off); };
+    std::vector<char> written(e->t.size(), 0);
+    auto grad = [&](int s) -> void* { return s == e->out_slot ? (void*)grad_out : (void*)(A + e->t[s].goff); };
+    // destination for a new contribution to tensor s: its gradient buffer the first time, the temporary afterwards (then add)
+    auto dst_for = [&](int s) -> void* { return written[s] ? (void*)(A + e->off_tmp) : grad(s); };
+    auto commit = [&](int s) -> int {
+        if (written[s]) {
+            const Tensor& t = e->t[s];
+            return dreg_add_inplace(grad(s), A + e->off_tmp, (size_t)t.B * t.D * t.H * t.W * t.C, 0, stream);
+        }
+        written[s] = 1;
+        return DREG_OK;
+    };
+    written[e->out_slot] = 1;
+    for (int i = (int)e->ops.size() - 1; i >= 0; --i) {
+        const Op& o = e->ops[i];
+        const Tensor& x = e->t[o.in];
+        const Tensor& y = e->t[o.out];
+        if (!e->needs_grad[o.out] || !written[o.out]) continue;   // nothing flows back through this op
+        const void* gy = grad(o.out);
+        if (o.kind == OP_CONV || o.kind == OP_CONV_ROWS) {
+            const Param& w = e->prm[o.w];
+            const bool rows = o.kind == OP_CONV_ROWS;
+            const int* r_out = rows ? (const int*)rowlists[2 * o.rows_out] : nullptr;
+            const int n_out = rows ? (int)rowlists[2 * o.rows_out + 1] : 0;
+            if (o.in2 >= 0 && e->needs_grad[o.in2]) {
+                const Tensor& ta = e->t[o.in2];
+                if (o.add_same) { CK(hipMemcpyAsync(dst_for(o.in2), gy, (size_t)y.B * y.D * y.H * y.W * y.C * 2, hipMemcpyDeviceToDevice, st) == hipSuccess ? 0 : DREG_ELAUNCH); }
+                else CK(dreg_downsample_sum(gy, dst_for(o.in2), y.B, y.D, y.H, y.W, ta.D, ta.H, ta.W, y.C, 0, stream));
+                CK(commit(o.in2));
+            }
+            if (e->needs_grad[o.in]) {
+                void* gx = dst_for(o.in);
+                Scope sc(e, st, i, 1);
+                if (rows) {
+                    if (o.rows_in < 0 || o.rows_in >= nlists) return DREG_EINVAL;
+                    if (hipMemsetAsync(gx, 0, (size_t)x.B * x.D * x.H * x.W * x.C * 2, st) != hipSuccess) return DREG_ELAUNCH;
+                    CK(dreg_conv3d_igemm_rows(gy, PK + w.pk_dgrad, gx, nullptr, nullptr, (const int*)rowlists[2 * o.rows_in], (int)rowlists[2 * o.rows_in + 1],
+                                              x.B, y.D, y.H, y.W, w.d0, x.D, x.H, x.W, x.C, o.ksz, 1, o.pad, 1, 0, 0, 0, 0, 0, 0, stream));
+                } else if (w.pk_cls != SIZE_MAX && s2_class_ok(w, o.ksz, o.stride, o.pad)) {
+                    CK(dreg_conv3d_dgrad_s2(gy, PK + w.pk_cls, gx, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0, o.ksz, o.pad, stream));
+                } else {
+                    if (w.pk_dgrad == SIZE_MAX) return DREG_EINVAL;
+                    CK(dreg_conv3d_igemm_ws(gy, PK + w.pk_dgrad, gx, nullptr, nullptr, x.B, y.D, y.H, y.W, w.d0, x.D, x.H, x.W, w.d1,
+                                            o.ksz, o.stride, o.pad, 1, 0, 0, 0, 0, 0, 0, 0, A + e->off_ks, e->sz_ks, stream));
+                }
+            }
+            if (e->needs_grad[o.in]) CK(commit(o.in));
+            if (w.grad) {
+                Scope sc(e, st, i, 2);
+                if (rows) CK(dreg_conv3d_wgrad_rows(gy, act(o.in), w.grad, A + e->off_wg, e->sz_wg, r_out, n_out, x.B, x.D, x.H, x.W, x.C, w.d1,
+                                                    y.D, y.H, y.W, w.d0, o.ksz, 1, o.pad, 1, stream));
+                else CK(dreg_conv3d_wgrad(gy, act(o.in), w.grad, A + e->off_wg, e->sz_wg, x.B, x.D, x.H, x.W, x.C, w.d1, y.D, y.H, y.W, w.d0,
+                                          o.ksz, o.stride, o.pad, 1, 0, 1, stream));
+            }
+            if (o.b >= 0 && e->prm[o.b].grad) {
+                if (rows) CK(dreg_colsum_rows(gy, r_out, n_out, e->prm[o.b].grad, (float*)(A + e->off_cs), w.d0, 1, 0, stream));
+                else CK(dreg_colsum(gy, e->prm[o.b].grad, (float*)(A + e->off_cs), (size_t)y.B * y.D * y.H * y.W, w.d0, 1, 0, stream));
+            }
+        } else if (o.kind == OP_BN) {
+            const int V = x.D * x.H * x.W;
+            const bool res_g = o.in2 >= 0 && e->needs_grad[o.in2];
+            // dx goes to its own buffer or the temporary; a second temporary is never needed: the residual's contribution is
+            // written first (into a fresh buffer or, when one exists already, via the temporary + add) only if dx takes the direct path
+            void* dx = dst_for(o.in);
+            void* dres = nullptr;
+            bool res_via_copy = false;
+            if (res_g) {
+                if (!written[o.in2]) dres = grad(o.in2);
+                else if (dx != (void*)(A + e->off_tmp)) dres = A + e->off_tmp;
+                else res_via_copy = true;   // both want the temporary: run dx first, then recompute-free path below
+            }
+            if (!e->prm[o.w].grad || !e->prm[o.b].grad) return DREG_EINVAL;
+            if (res_via_copy) {
+                // rare (never in ResNet-50/FPN): produce dres = masked gy through a second pass after dx has been folded in
+                CK(dreg_bn3d_bwd(act(o.in), gy, act(o.out), (float*)(A + o.aux0), (float*)(A + o.aux1), dx, nullptr, e->prm[o.w].grad, e->prm[o.b].grad,
+                                 (float*)(A + e->off_coef), (float*)(A + e->off_bn_ws), x.B, V, x.C, o.relu, 1, 0, stream));
+                CK(commit(o.in));
+                if (o.relu) CK(dreg_relu_bwd(act(o.out), gy, A + e->off_tmp, (size_t)x.B * V * x.C, 0, 0, 0, stream));
+                else if (hipMemcpyAsync(A + e->off_tmp, gy, (size_t)x.B * V * x.C * 2, hipMemcpyDeviceToDevice, st) != hipSuccess) return DREG_ELAUNCH;
+                CK(commit(o.in2));
+            } else {
+                CK(dreg_bn3d_bwd(act(o.in), gy, act(o.out), (float*)(A + o.aux0), (float*)(A + o.aux1), dx, dres, e->prm[o.w].grad, e->prm[o.b].grad,
+                                 (float*)(A + e->off_coef), (float*)(A + e->off_bn_ws), x.B, V, x.C, o.relu, 1, 0, stream));
+                if (res_g && dres == (void*)(A + e->off_tmp)) { CK(commit(o.in2)); CK(commit(o.in)); }
+                else { CK(commit(o.in)); if (res_g) CK(commit(o.in2)); }
+            }
+        } else if (o.kind == OP_MAXPOOL) {
+            if (!e->needs_grad[o.in]) continue;
+            CK(dreg_maxpool3d_bwd(gy, (const uint8_t*)(A + o.aux0), dst_for(o.in), x.B, x.D, x.H, x.W, y.D, y.H, y.W, x.C, 0, stream));
+            CK(commit(o.in));
+        }
+    }
+    return DREG_OK;
+}
+
+}  // extern "C"

@@ -501,6 +501,20 @@ __global__ __launch_bounds__(256) void colsum_rows_partial_kernel(const T* __res
     }
 }
 
+// dst += src (gradient accumulation where a tensor feeds two consumers); fp32 add, one rounding — what torch's add does
+template <typename T>
+__global__ void add_inplace_kernel(T* __restrict__ dst, const T* __restrict__ src, size_t total_gran)
+{
+    constexpr int G = Gran<T>::G;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total_gran; i += (size_t)gridDim.x * blockDim.x) {
+        float a[G], b[G];
+        Gran<T>::ld(dst + i * G, a);
+        Gran<T>::ld(src + i * G, b);
+#pragma unroll
+        for (int k = 0; k < G; ++k) a[k] += b[k];
+        Gran<T>::st(dst + i * G, a);
+    }
+}
 // fp32 <-> T conversions (contiguous)
 template <typename T>
 __global__ void cast_from_f32_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {
@@ -673,6 +687,17 @@ int dreg_cast_from_f32(const float* in, void* out, size_t n, int dtype, void* st
     return DREG_OK;
 }
 
+// dst += src, n elements (n % 8 == 0 for bf16, % 4 for fp32)
+int dreg_add_inplace(void* dst, const void* src, size_t n, int dtype, void* stream)
+{
+    const int G = dtype == 0 ? 8 : 4;
+    if (n % G) return DREG_EINVAL;
+    if (n == 0) return DREG_OK;
+    if (dtype == 0) hipLaunchKernelGGL(add_inplace_kernel<bf16_t>, dim3(nblocks(n / G)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dst, (const bf16_t*)src, n / G);
+    else hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(nblocks(n / G)), dim3(256), 0, (hipStream_t)stream, (float*)dst, (const float*)src, n / G);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
 // Active-set gather backward: dp1 [B,d,h,w,C] (dtype) is zero-filled here and receives the gradient on the S1 rows only.
 // rows1 / n1 / map1: list, length and inverse map from dreg_active_sets; comp: fp32 [n1, C] scratch.
 int dreg_trilinear_gather_bwd_rows(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1, const int* map1,

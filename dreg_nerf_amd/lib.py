@@ -61,6 +61,21 @@ SIGNATURES = {
     "dreg_active_sets": (I, [P, P] + [I] * 8 + [P, P, P, P, Z, P]),
     "dreg_trilinear_gather_bwd_rows": (I, [P, P, P, P, I, P, P, P] + [I] * 10 + [P]),
     "dreg_colsum_rows": (I, [P, P, I, P, P, I, I, I, P]),
+    "dreg_add_inplace": (I, [P, P, Z, I, P]),
+    # executor.hip
+    "dreg_exec_create": (P, [P, I, P, I, P, I]),
+    "dreg_exec_destroy": (None, [P]),
+    "dreg_exec_arena_bytes": (Z, [P]),
+    "dreg_exec_pack_bytes": (Z, [P]),
+    "dreg_exec_num_packs": (I, [P]),
+    "dreg_exec_tensor_offset": (Z, [P, I]),
+    "dreg_exec_output_slot": (I, [P]),
+    "dreg_exec_export_pack_table": (I, [P, P, P]),
+    "dreg_exec_repack": (I, [P, P, P]),
+    "dreg_exec_set_timing": (None, [P, I]),
+    "dreg_exec_read_timings": (I, [P, P, P, I]),
+    "dreg_exec_forward": (I, [P, P, Z, P, P, P, I, I, P]),
+    "dreg_exec_backward": (I, [P, P, Z, P, P, P, P, I, P]),
     # attention.hip
     "dreg_mha_fwd": (I, [P] * 5 + [I] * 7 + [F, I, P]),
     "dreg_mha_bwd": (I, [P] * 10 + [I] * 7 + [F, I, P]),
@@ -158,3 +173,12 @@ def dt_of(t: torch.Tensor) -> int:
 
 def torch_dtype(dt: int):
     return torch.bfloat16 if dt == DT_BF16 else torch.float32
+
+
+def to_device_async(data, dtype, device):
+    """Small host list -> device tensor without stalling the stream: pinned staging + non-blocking copy.  (On ROCm a copy from
+    pageable memory — torch.tensor(list, device=...) — blocks the host until ALL previously queued work has finished.)"""
+    t = torch.tensor(data, dtype=dtype)
+    if device.type != "cuda":
+        return t
+    return t.pin_memory().to(device, non_blocking=True)

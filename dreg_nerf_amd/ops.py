@@ -20,6 +20,7 @@ class KernelTimer:
 
     def __init__(self):
         self.entries = []
+        self.measured = []
 
     def record(self, name, label, flops):
         start = torch.cuda.Event(enable_timing=True)
@@ -27,9 +28,19 @@ class KernelTimer:
         self.entries.append((name, label, flops, start, end))
         return start, end
 
+    def add_measured(self, name, label, flops, ms):
+        """A launch timed elsewhere (the native trunk executor's own HIP events)."""
+        self.measured.append((name, label, flops, ms))
+
     def summary(self):
         torch.cuda.synchronize()
         by_name, by_label = {}, {}
+        for name, label, flops, ms in self.measured:
+            for d, k in ((by_name, name), (by_label, (name, label))):
+                a = d.setdefault(k, [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += ms
+                a[2] += flops
         for name, label, flops, s, e in self.entries:
             ms = s.elapsed_time(e)
             for d, k in ((by_name, name), (by_label, (name, label))):

@@ -96,6 +96,8 @@ class NeRFRegTr(nn.Module):
         # Evaluate the two FPN head convolutions only where their outputs are consumed (around the occupied voxels):
         # identical results, a fraction of the FLOPs.  False = dense 64^3 evaluation (the BASELINE.md FLOP accounting).
         self.active_set = True
+        # Issue the FPN3D forward / backward from the C++ executor (csrc/executor.hip) instead of one autograd node per layer
+        self.native_trunk = True
         self._spec = params.regtr_spec()
         _build_tree(self, self._spec)
         _reset_parameters(self, self._spec)
@@ -122,33 +124,30 @@ class NeRFRegTr(nn.Module):
         return super().load_state_dict(*a, **kw)
 
     # ------------------------------------------------------------------ A1/A2: FPN3D over a batch of grids
-    def fpn(self, x: torch.Tensor, rows=None) -> torch.Tensor:
-        """x: [B, D, H, W, 8] (rgba + 4 zero channels), activation dtype.  Returns P1 [B, D/2, H/2, W/2, 256].
-        rows = (S1, S2, S3) from ops.active_sets: the two head convolutions are evaluated on the active set only
-        (P1 is then defined on S1, which is all the trilinear gather reads)."""
+    def _fpn_program(self, O, x, rows, nbt, train: bool = True):
+        """The feature network written against an op provider O: dreg_nerf_amd.ops (eager, one autograd node per layer) or
+        trunk_exec._Recorder (records the op program of the native executor).  rows = (S1, S2, S3[, map1]) or None."""
         P = self._P()
-        train = self.training
         r = "fpn3d.backbone_net."
-        nbt = []  # num_batches_tracked buffers of the BatchNorms that ran: one fused increment at the end (B calls in the reference)
 
         def bn(t, name, res=None, relu=True):
             if train:
                 nbt.append(P[name + ".num_batches_tracked"])
-            return ops.batchnorm(t, P[name + ".weight"], P[name + ".bias"], P[name + ".running_mean"],
-                                 P[name + ".running_var"], res=res, relu=relu, train=train)
+            return O.batchnorm(t, P[name + ".weight"], P[name + ".bias"], P[name + ".running_mean"],
+                               P[name + ".running_var"], res=res, relu=relu, train=train)
 
-        c1 = bn(ops.conv3d(x, P[r + "conv1.weight"], stride=2, pad=2), r + "bn1")
-        h = ops.maxpool3d(c1)
+        c1 = bn(O.conv3d(x, P[r + "conv1.weight"], stride=2, pad=2), r + "bn1")
+        h = O.maxpool3d(c1)
         feats = [c1]
         for li, nblk in enumerate(params.RESNET50_BLOCKS):
             for b in range(nblk):
                 p = f"{r}layer{li + 1}.{b}"
                 stride = 2 if (b == 0 and li > 0) else 1
-                o = bn(ops.conv3d(h, P[p + ".conv1.weight"]), p + ".bn1")
-                o = bn(ops.conv3d(o, P[p + ".conv2.weight"], stride=stride, pad=1), p + ".bn2")
-                o = ops.conv3d(o, P[p + ".conv3.weight"])
+                o = bn(O.conv3d(h, P[p + ".conv1.weight"]), p + ".bn1")
+                o = bn(O.conv3d(o, P[p + ".conv2.weight"], stride=stride, pad=1), p + ".bn2")
+                o = O.conv3d(o, P[p + ".conv3.weight"])
                 if (p + ".downsample.0.weight") in P:
-                    res = bn(ops.conv3d(h, P[p + ".downsample.0.weight"], stride=stride), p + ".downsample.1", relu=False)
+                    res = bn(O.conv3d(h, P[p + ".downsample.0.weight"], stride=stride), p + ".downsample.1", relu=False)
                 else:
                     res = h
                 h = bn(o, p + ".bn3", res=res, relu=True)
@@ -157,7 +156,7 @@ class NeRFRegTr(nn.Module):
         q = "fpn3d.feature_pyramid."
 
         def conv(name, t, pad, addend=None):
-            return ops.conv3d(t, P[q + name + ".weight"], P[q + name + ".bias"], addend=addend, pad=pad)
+            return O.conv3d(t, P[q + name + ".weight"], P[q + name + ".bias"], addend=addend, pad=pad)
 
         p5 = conv("pyramid_transformation_5", c5, 0)
         p4 = conv("upsample_transform_4", conv("pyramid_transformation_4", c4, 0, addend=p5), 1)
@@ -167,11 +166,55 @@ class NeRFRegTr(nn.Module):
             p1 = conv("upsample_transform_1", conv("pyramid_transformation_1", c1, 1, addend=p2), 1)
         else:
             s1, s2, s3 = rows[:3]
-            lat1 = ops.conv3d_rows(c1, P[q + "pyramid_transformation_1.weight"], P[q + "pyramid_transformation_1.bias"], p2, 1, s2, s3)
-            p1 = ops.conv3d_rows(lat1, P[q + "upsample_transform_1.weight"], P[q + "upsample_transform_1.bias"], None, 1, s1, s2)
+            lat1 = O.conv3d_rows(c1, P[q + "pyramid_transformation_1.weight"], P[q + "pyramid_transformation_1.bias"], p2, 1, s2, s3)
+            p1 = O.conv3d_rows(lat1, P[q + "upsample_transform_1.weight"], P[q + "upsample_transform_1.bias"], None, 1, s1, s2)
+        return p1
+
+    def _trunk_executor(self, x, rows):
+        """The native executor for this (batch, resolution, head mode, grad mode), or None when it does not apply: fp32 parity
+        mode, or training without preallocated gradient buffers (the executor accumulates straight into FlatAdamW's)."""
+        if not self.native_trunk or self.precision != "bf16":
+            return None
+        from . import trunk_exec
+        with_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.fpn3d.parameters())
+        if with_grad and any(p.requires_grad and (p.grad is None or not p.grad.is_contiguous()) for p in self.fpn3d.parameters()):
+            return None
+        key = (tuple(x.shape), rows is not None, with_grad)
+        cache = self.__dict__.setdefault("_trunk_cache", {})
+        ex = cache.get(key)
+        if ex is not None and not ex.still_valid():
+            ex = None
+        if ex is None:
+            cache.clear()   # one live program: its arena holds every activation of the network
+            ex = trunk_exec.TrunkExecutor(self, tuple(x.shape), rows is not None, with_grad)
+            cache[key] = ex
+        return ex
+
+    def fpn(self, x: torch.Tensor, rows=None) -> torch.Tensor:
+        """x: [B, D, H, W, 8] (rgba + 4 zero channels), activation dtype.  Returns P1 [B, D/2, H/2, W/2, 256].
+        rows = (S1, S2, S3) from ops.active_sets: the two head convolutions are evaluated on the active set only
+        (P1 is then defined on S1, which is all the trilinear gather reads)."""
+        train = self.training
+        ex = self._trunk_executor(x, rows)
+        if ex is not None:
+            from . import trunk_exec
+            p1 = trunk_exec.run_trunk(ex, x, self.fpn3d.backbone_net.conv1.weight, rows, train)
+            if train and ex.nbt:
+                torch._foreach_add_(ex.nbt, x.shape[0])
+            return p1
+        nbt = []  # num_batches_tracked buffers of the BatchNorms that ran: one fused increment at the end (B calls in the reference)
+        p1 = self._fpn_program(ops, x, rows, nbt, train)
         if nbt:
             torch._foreach_add_(nbt, x.shape[0])
         return p1
+
+    def drain_trunk_timings(self, profiler):
+        """Move the native executor's HIP-event records (one per convolution launch) into `profiler` and stop timing."""
+        for ex in self.__dict__.get("_trunk_cache", {}).values():
+            if ex._timing:
+                torch.cuda.synchronize()
+                ex.drain_timings(profiler)
+                ex.set_timing(False)
 
     @staticmethod
     def pack_grids(grids: List[torch.Tensor], dtype) -> torch.Tensor:

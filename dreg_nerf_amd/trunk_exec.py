@@ -1,0 +1,242 @@
+"""Native (C++) execution of the FPN3D feature network: the per-op description in ``regtr.NeRFRegTr.fpn`` is recorded once
+per (batch, resolution, head mode) into an op program and handed to ``csrc/executor.hip``; afterwards a training step issues
+the whole forward (and the whole backward) of the network with ONE C call each.
+
+Reference network: conerf/model/resnet3d.py:86-161, conerf/model/feature_pyramid_net.py:97-127 (see regtr.py for the
+name-by-name mapping).  The per-op Python path stays the description of record (and the fp32 parity path); this module only
+changes who issues the launches, and tests/test_hip_trunk_exec.py checks the two bit for bit.
+"""
+import ctypes
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import ops
+
+OP_CONV, OP_BN, OP_MAXPOOL, OP_CONV_ROWS = 0, 1, 2, 3
+KIND_NAMES = {0: "fwd", 1: "dgrad", 2: "wgrad"}
+
+
+class _Recorder:
+    """Stands in for dreg_nerf_amd.ops while regtr.fpn() runs once on shape placeholders."""
+
+    def __init__(self, P: Dict[str, torch.Tensor], x_shape):
+        self.P = P
+        self.tensors = [tuple(x_shape)]
+        self.ops = []
+        self.params = []        # list of torch tensors (parameters / buffers)
+        self.pindex = {}
+
+    class T:  # shape placeholder
+        def __init__(self, slot, shape):
+            self.slot, self.shape = slot, tuple(shape)
+
+    def _new(self, shape):
+        self.tensors.append(tuple(shape))
+        return _Recorder.T(len(self.tensors) - 1, shape)
+
+    def _p(self, t: Optional[torch.Tensor]) -> int:
+        if t is None:
+            return -1
+        k = id(t)
+        if k not in self.pindex:
+            self.pindex[k] = len(self.params)
+            self.params.append(t)
+        return self.pindex[k]
+
+    def conv3d(self, x, w, bias=None, addend=None, stride=1, pad=0):
+        B, D, H, W, _ = x.shape
+        k = w.shape[2]
+        od = tuple((d + 2 * pad - k) // stride + 1 for d in (D, H, W))
+        y = self._new((B,) + od + (w.shape[0],))
+        self.ops.append([OP_CONV, x.slot, y.slot, addend.slot if addend is not None else -1, self._p(w), self._p(bias), -1, -1, -1,
+                         k, stride, pad, 0, 0, -1, -1])
+        return y
+
+    def conv3d_rows(self, x, w, bias, addend, pad, out_rows: int, in_rows: int):
+        y = self._new(x.shape[:4] + (w.shape[0],))
+        self.ops.append([OP_CONV_ROWS, x.slot, y.slot, addend.slot if addend is not None else -1, self._p(w), self._p(bias), -1, -1, -1,
+                         w.shape[2], 1, pad, 0, 0, out_rows, in_rows])
+        return y
+
+    def batchnorm(self, x, gamma, beta, running_mean, running_var, res=None, relu=True, train=True):
+        y = self._new(x.shape)
+        self.ops.append([OP_BN, x.slot, y.slot, res.slot if res is not None else -1, self._p(gamma), self._p(beta),
+                         self._p(running_mean), self._p(running_var), -1, 0, 0, 0, int(relu), 0, -1, -1])
+        return y
+
+    def maxpool3d(self, x):
+        B, D, H, W, C = x.shape
+        y = self._new((B,) + tuple((d + 2 - 3) // 2 + 1 for d in (D, H, W)) + (C,))
+        self.ops.append([OP_MAXPOOL, x.slot, y.slot, -1, -1, -1, -1, -1, -1, 3, 2, 1, 0, 0, -1, -1])
+        return y
+
+
+class TrunkExecutor:
+    """One recorded program + its arena and packed-weight buffer."""
+
+    def __init__(self, model, x_shape, sparse_head: bool, with_grad: bool = True):
+        self.lib = L.load()
+        P = model._P()
+        rec = _Recorder(P, x_shape)
+        x0 = _Recorder.T(0, x_shape)
+        self.nbt = []
+        out = model._fpn_program(rec, x0, (0, 1, 2) if sparse_head else None, self.nbt, True)
+        self.out_shape = out.shape
+        self.rec = rec
+        dev = next(model.parameters()).device
+        self.device = dev
+        tens = np.asarray(rec.tensors, dtype=np.int32)
+        opsa = np.asarray(rec.ops, dtype=np.int32)
+        prm = np.zeros((len(rec.params), 5), dtype=np.int64)
+        self._param_refs = rec.params
+        self._sig = []
+        for i, t in enumerate(rec.params):
+            assert t.is_contiguous() and t.dtype == torch.float32, "the executor reads fp32 master parameters in place"
+            g = t.grad if (with_grad and isinstance(t, torch.nn.Parameter) and t.requires_grad) else None
+            if g is not None:
+                assert g.is_contiguous() and g.dtype == torch.float32
+            elif with_grad and isinstance(t, torch.nn.Parameter) and t.requires_grad:
+                raise L.DregError("TrunkExecutor needs preallocated .grad buffers (FlatAdamW) on every trainable parameter")
+            prm[i, 0] = t.data_ptr()
+            prm[i, 1] = g.data_ptr() if g is not None else 0
+            prm[i, 2] = t.shape[0]
+            prm[i, 3] = t.shape[1] if t.dim() > 1 else 1
+            prm[i, 4] = t.shape[2] if t.dim() == 5 else 1
+            self._sig.append((t.data_ptr(), prm[i, 1]))
+        self.h = self.lib.dreg_exec_create(tens.ctypes.data, len(rec.tensors), opsa.ctypes.data, len(rec.ops), prm.ctypes.data, len(rec.params))
+        if not self.h:
+            raise L.DregError("dreg_exec_create rejected the op program")
+        self.arena_bytes = self.lib.dreg_exec_arena_bytes(self.h)
+        self.arena = torch.empty(self.arena_bytes, dtype=torch.uint8, device=dev)
+        self.pack = torch.empty(self.lib.dreg_exec_pack_bytes(self.h), dtype=torch.uint8, device=dev)
+        n = self.lib.dreg_exec_num_packs(self.h)
+        host = np.zeros((n, 12), dtype=np.int32)
+        L.check(self.lib.dreg_exec_export_pack_table(self.h, host.ctypes.data, self.pack.data_ptr()), "dreg_exec_export_pack_table")
+        self.pack_table = torch.from_numpy(host).to(dev)
+        self.out_slot = self.lib.dreg_exec_output_slot(self.h)
+        self.out_off = self.lib.dreg_exec_tensor_offset(self.h, self.out_slot)
+        self.pack_stamp = None
+        self._timing = False
+        self.last_row_counts = []
+        self.sparse_head = sparse_head
+        self.with_grad = with_grad
+        self.labels = self._labels()
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.dreg_exec_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def still_valid(self) -> bool:
+        """Parameter / gradient storage unchanged since the program was recorded?"""
+        for t, (vp, gp) in zip(self._param_refs, self._sig):
+            g = t.grad if (self.with_grad and isinstance(t, torch.nn.Parameter) and t.requires_grad) else None
+            if t.data_ptr() != vp or (g.data_ptr() if g is not None else 0) != gp:
+                return False
+        return True
+
+    def _labels(self):
+        """(name, label, flops) per (op index, kind) for the HIP-event timing records."""
+        out = {}
+        for i, o in enumerate(self.rec.ops):
+            if o[0] not in (OP_CONV, OP_CONV_ROWS):
+                continue
+            x, y = self.rec.tensors[o[1]], self.rec.tensors[o[2]]
+            w = self.rec.params[o[4]]
+            B = x[0]
+            k, s = o[9], o[10]
+            cout, cin = w.shape[0], w.shape[1]
+            M = B * y[1] * y[2] * y[3]
+            big = cout % 256 == 0 and M >= 65536
+            fname = f"conv_igemm_glds_kernel<bf16,{256 if big else 128},{256 if big else (128 if cout % 128 == 0 else 64)}>" \
+                if (x[4] % 64 == 0) else f"conv_igemm_kernel<bf16,bf16,{128 if cout % 128 == 0 else 64}>"
+            bigd = cin % 256 == 0 and B * x[1] * x[2] * x[3] >= 65536
+            dname = "conv_igemm_glds_kernel<bf16,s2-dgrad>" if s == 2 else \
+                f"conv_igemm_glds_kernel<bf16,{256 if bigd else 128},{256 if bigd else (128 if cin % 128 == 0 else 64)}>"
+            rows = "-rows" if o[0] == OP_CONV_ROWS else ""
+            fl = 2.0 * M * cout * k ** 3 * cin
+            # active-set launches: flops per row, scaled by the step's row count (list id) when the records are drained
+            per_row = 2.0 * cout * k ** 3 * cin
+            lo, li = (o[14], o[15]) if rows else (-1, -1)
+            out[(i, 0)] = (fname, f"fwd{rows} B{B} {x[1]}x{x[2]}x{x[3]}x{x[4]}->{y[1]}x{y[2]}x{y[3]}x{cout} k{k}s{s}", fl, lo, per_row)
+            out[(i, 1)] = (dname, f"dgrad{rows} B{B} {y[1]}x{y[2]}x{y[3]}x{cout}->{x[1]}x{x[2]}x{x[3]}x{cin} k{k}s{s}", fl, li, per_row)
+            out[(i, 2)] = ("conv_wgrad_kernel<bf16>+reduce", f"wgrad{rows} B{B} {x[1]}x{x[2]}x{x[3]}x{x[4]} g{y[1]}x{y[2]}x{y[3]}x{cout} k{k}s{s}", fl, lo, per_row)
+        return out
+
+    # ------------------------------------------------------------------ per-step calls
+    def repack_if_stale(self):
+        stamp = ops._weight_generation
+        if self.pack_stamp != stamp:
+            L.check(self.lib.dreg_exec_repack(self.h, L.ptr(self.pack_table), L.stream()), "dreg_exec_repack")
+            self.pack_stamp = stamp
+
+    @staticmethod
+    def _rowlist_array(rows):
+        if rows is None:
+            return None, 0
+        a = (ctypes.c_int64 * 6)()
+        for i in range(3):
+            a[2 * i] = rows[i].data_ptr()
+            a[2 * i + 1] = rows[i].shape[0]
+        return a, 3
+
+    def forward(self, x: torch.Tensor, rows, train: bool) -> torch.Tensor:
+        self.repack_if_stale()
+        if ops.PROFILER is not None and not self._timing:
+            self.set_timing(True)
+        self.last_row_counts = [int(r.shape[0]) for r in rows[:3]] if rows is not None else []
+        ra, n = self._rowlist_array(rows)
+        L.check(self.lib.dreg_exec_forward(self.h, L.ptr(self.arena), self.arena_bytes, L.ptr(self.pack), L.ptr(x),
+                                           ctypes.addressof(ra) if ra is not None else None, n, int(train), L.stream()), "dreg_exec_forward")
+        nbytes = int(np.prod(self.out_shape)) * 2
+        return self.arena[self.out_off:self.out_off + nbytes].view(torch.bfloat16).view(self.out_shape)
+
+    def backward(self, x: torch.Tensor, rows, grad_out: torch.Tensor):
+        ra, n = self._rowlist_array(rows)
+        L.check(self.lib.dreg_exec_backward(self.h, L.ptr(self.arena), self.arena_bytes, L.ptr(self.pack), L.ptr(x), L.ptr(grad_out),
+                                            ctypes.addressof(ra) if ra is not None else None, n, L.stream()), "dreg_exec_backward")
+
+    # ------------------------------------------------------------------ timing (bench.py's roofline line)
+    def set_timing(self, on: bool):
+        self._timing = bool(on)
+        self.lib.dreg_exec_set_timing(self.h, int(on))
+
+    def drain_timings(self, profiler: "ops.KernelTimer"):
+        """After a device synchronisation: move the executor's HIP-event records into a KernelTimer-compatible store."""
+        cap = 65536
+        ok = (ctypes.c_int * (2 * cap))()
+        ms = (ctypes.c_float * cap)()
+        n = self.lib.dreg_exec_read_timings(self.h, ok, ms, cap)
+        for i in range(n):
+            name, label, fl, lid, per_row = self.labels[(ok[2 * i], ok[2 * i + 1])]
+            if lid >= 0:   # active-set launch: algorithmic flops follow the (last) step's row count
+                nr = self.last_row_counts[lid]
+                fl, label = per_row * nr, f"{label} rows{nr}"
+            profiler.add_measured(name, label, fl, ms[i])
+
+
+class _TrunkFn(torch.autograd.Function):
+    """P1 = FPN3D(x) through the native executor.  `anchor` is any trainable parameter: it only keeps this node in the autograd
+    graph (the executor accumulates every parameter gradient itself, straight into the .grad buffers)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, ex: TrunkExecutor, rows, train: bool):
+        ctx.ex, ctx.rows = ex, rows
+        ctx.save_for_backward(x)
+        return ex.forward(x, rows, train)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        ctx.ex.backward(x, ctx.rows, g.contiguous())
+        return None, None, None, None, None
+
+
+def run_trunk(ex: TrunkExecutor, x, anchor, rows, train):
+    return _TrunkFn.apply(x, anchor, ex, rows, train)

@@ -131,6 +131,7 @@ int dreg_trilinear_gather_fwd(const void* p1, const int64_t* idx, const int* pt_
 int dreg_trilinear_gather_bwd(const float* dfeat, const int64_t* idx, const int* pt_batch, float* dp1_f32, int N, int d,
                               int h, int w, int C, int Zr, int Xr, int Yr, void* stream);
 int dreg_cast_from_f32(const float* in, void* out, size_t n, int dtype, void* stream);
+int dreg_add_inplace(void* dst, const void* src, size_t n, int dtype, void* stream);   /* dst += src */
 
 /* Active sets of the FPN head (build-side; identical results to the dense evaluation of feature_pyramid_net.py:115-127 because
  * nerf_regtr.py:138-147 only consumes P1 at the trilinear corners of the occupied voxels): S1 = those corners, S2 = S1 dilated
@@ -146,6 +147,30 @@ int dreg_trilinear_gather_bwd_rows(const float* dfeat, const int64_t* idx, const
                                    int Zr, int Xr, int Yr, int dtype, void* stream);
 int dreg_colsum_rows(const void* g, const int* rows, int nrows, float* out, float* workspace, int C, int accumulate,
                      int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- trunk executor
+ * The FPN3D forward/backward (resnet3d.py:86-161, feature_pyramid_net.py:97-127) as a recorded op program issued from C++:
+ * one call per pass instead of one host round trip per layer.  tensors int32 [nt][5] (B,D,H,W,C; bf16 NDHWC; tensor 0 = the
+ * external input), ops int32 [nops][16] { kind (0 conv, 1 batchnorm, 2 maxpool 3/2/1, 3 active-set conv), in, out,
+ * in2 (addend / residual or -1), w, b, p2, p3, p4 (BN: gamma, beta, running_mean, running_var), ksz, stride, pad, relu,
+ * add_same, rows_out, rows_in }, params int64 [np][5] { fp32 value ptr, fp32 grad ptr (0 = frozen), d0, d1, ksz }.
+ * The caller owns the arena (activations kept for backward, statistics, activation gradients, scratch) and the packed-weight
+ * buffer; weight / bias / BatchNorm gradients are ACCUMULATED into the grad pointers.  One forward may be outstanding. */
+void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, const int64_t* params, int np);
+void dreg_exec_destroy(void* h);
+size_t dreg_exec_arena_bytes(void* h);
+size_t dreg_exec_pack_bytes(void* h);
+int dreg_exec_num_packs(void* h);
+size_t dreg_exec_tensor_offset(void* h, int slot);
+int dreg_exec_output_slot(void* h);
+int dreg_exec_export_pack_table(void* h, void* host_out, void* pack_base);   /* 48-byte records of dreg_pack_conv_weights_batched */
+int dreg_exec_repack(void* h, const void* descs_dev, void* stream);
+void dreg_exec_set_timing(void* h, int enable);                              /* HIP events around every convolution launch */
+int dreg_exec_read_timings(void* h, int* op_kind, float* ms, int max);       /* (op, kind 0 fwd / 1 dgrad / 2 wgrad), ms */
+int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack_base, const void* x_in,
+                      const int64_t* rowlists, int nlists, int train, void* stream);
+int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pack_base, const void* x_in,
+                       const void* grad_out, const int64_t* rowlists, int nlists, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- point-set half
  * Attention core of nn.MultiheadAttention (8 heads, d_head 32; transformer.py:242-281): q [Nq,ldq], k [Nk,ldk],
