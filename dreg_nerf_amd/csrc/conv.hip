@@ -856,48 +856,121 @@ __global__ void pack_weight_s2class_kernel(const float* __restrict__ w, T* __res
     }
 }
 // All weight packs of a step in ONE launch (they are re-made after every optimizer update).  One block per packed row
-// (block -> descriptor by binary search over the row prefix): the row's fp32 source elements are staged in LDS with coalesced
-// reads (forward pack: one contiguous [Cin][taps] span; data-gradient pack: Cout spans of `taps` floats), then written as one
-// contiguous packed row.  Same element maps as the two single-layer kernels around this one.
+// (block -> descriptor by binary search over the row prefix).  bf16 packs take one of three coalesced routes:
+//   1^3 forward pack      : the row is a contiguous fp32 span -> 8 elements per thread, 16-byte stores;
+//   1^3 data-gradient pack: a [Cout][Cin] -> [Cin][Cout] transpose; the first block of every 32 rows moves the band through
+//                           64x32 LDS tiles (the other 31 blocks exit);
+//   k^3 packs             : 64 channels x taps at a time through LDS (coalesced reads: one contiguous span for the forward
+//                           pack, Cout spans of `taps` floats for the data-gradient / stride-2 class packs), then one
+//                           16-byte store per (tap, 8 channels).
+// fp32 packs (exact-f32 parity mode) read global memory element by element.  Same element maps as the single-layer kernels.
 struct PackDesc {
     const float* w; void* out;
     int Cout, Cin_real, Cin, ntaps, for_dgrad, Kpad, dtype, block0;
 };
-__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDesc* __restrict__ descs, int n)
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDesc* __restrict__ descs, int n, const int* __restrict__ row_desc)
 {
     extern __shared__ float stage[];
+    __shared__ float tile[64][33];
     int lo = 0, hi = n - 1;
-    while (lo < hi) {
+    if (row_desc) lo = row_desc[blockIdx.x];             // one load instead of a chain of log2(n) dependent ones
+    else while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (descs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const PackDesc d = descs[lo];
     int r = (int)blockIdx.x - d.block0;                 // co (forward pack), ci (data-gradient pack) or (class, ci)
+    const int t = threadIdx.x;
     const int inner = d.for_dgrad ? d.Cout : d.Cin;     // channels per tap in the packed row
-    const int nsrc = (d.for_dgrad ? d.Cout : d.Cin_real) * d.ntaps;
-    const int cls = d.for_dgrad == 2 ? r / d.Cin_real : 0;
-    if (d.for_dgrad == 2) r -= cls * d.Cin_real;
-    if (!d.for_dgrad) {
-        const float* src = d.w + (size_t)r * nsrc;
-        for (int i = threadIdx.x; i < nsrc; i += 256) stage[i] = src[i];
-    } else {
-        for (int i = threadIdx.x; i < nsrc; i += 256) {
-            const int co = i / d.ntaps, tap = i - co * d.ntaps;
-            stage[i] = d.w[((size_t)co * d.Cin_real + r) * d.ntaps + tap];
-        }
-    }
-    __syncthreads();
     const int nreal = d.for_dgrad ? d.Cout : d.Cin_real;
     const int ksz = d.ntaps == 1 ? 1 : (d.ntaps == 27 ? 3 : 5);
-    for (int k = threadIdx.x; k < d.Kpad; k += 256) {
-        int tap = k / inner;
-        const int c = k - tap * inner;
-        if (d.for_dgrad == 2) tap = tap < (ksz == 1 ? 1 : 8) ? s2_class_tap(cls, tap, ksz) : -1;
-        const float v = (tap >= 0 && tap < d.ntaps && c < nreal) ? stage[c * d.ntaps + tap] : 0.f;
-        const size_t o = ((size_t)cls * d.Cin_real + r) * d.Kpad + k;
-        if (d.dtype == 0) Elem<bf16_t>::st((bf16_t*)d.out + o, v);
-        else ((float*)d.out)[o] = v;
+    if (d.dtype != 0 || (inner & 7)) {                   // generic route
+        const int cls = d.for_dgrad == 2 ? r / d.Cin_real : 0;
+        if (d.for_dgrad == 2) r -= cls * d.Cin_real;
+        const size_t row_o = ((size_t)cls * d.Cin_real + r) * d.Kpad;
+        for (int k = t; k < d.Kpad; k += 256) {
+            int tap = k / inner;
+            const int c = k - tap * inner;
+            if (d.for_dgrad == 2) tap = tap < (ksz == 1 ? 1 : 8) ? s2_class_tap(cls, tap, ksz) : -1;
+            float v = 0.f;
+            if (tap >= 0 && tap < d.ntaps && c < nreal)
+                v = d.for_dgrad ? d.w[((size_t)c * d.Cin_real + r) * d.ntaps + tap] : d.w[((size_t)r * d.Cin_real + c) * d.ntaps + tap];
+            if (d.dtype == 0) Elem<bf16_t>::st((bf16_t*)d.out + row_o + k, v);
+            else ((float*)d.out)[row_o + k] = v;
+        }
+        return;
     }
+    bf16_t* out = (bf16_t*)d.out;
+    if (d.ntaps == 1 && !d.for_dgrad) {                  // contiguous fp32 row -> bf16 row
+        const float* src = d.w + (size_t)r * d.Cin_real;
+        for (int k = t * 8; k < d.Kpad; k += 2048) {
+            uint32_t pk[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v0 = k + 2 * e < d.Cin_real ? src[k + 2 * e] : 0.f, v1 = k + 2 * e + 1 < d.Cin_real ? src[k + 2 * e + 1] : 0.f;
+                pk[e] = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+            }
+            *reinterpret_cast<uint4*>(out + (size_t)r * d.Kpad + k) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
+        return;
+    }
+    if (d.ntaps == 1) {                                  // [Cout][Cin] -> [Cin][Kpad] (data-gradient pack and class-0 pack)
+        if (r & 31) return;
+        const int ci_l = t & 31, ci_w = t >> 3, cg = t & 7;
+        for (int co0 = 0; co0 < d.Kpad; co0 += 64) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int co = co0 + (t >> 5) + 8 * it;
+                tile[(t >> 5) + 8 * it][ci_l] = (co < d.Cout && r + ci_l < d.Cin_real) ? d.w[(size_t)co * d.Cin_real + r + ci_l] : 0.f;
+            }
+            __syncthreads();
+            if (r + ci_w < d.Cin_real) {
+                uint32_t pk[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    pk[e] = (uint32_t)f2bf(tile[cg * 8 + 2 * e][ci_w]) | ((uint32_t)f2bf(tile[cg * 8 + 2 * e + 1][ci_w]) << 16);
+                *reinterpret_cast<uint4*>(out + (size_t)(r + ci_w) * d.Kpad + co0 + cg * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    // k^3 packs: 64 channels x taps per pass
+    const int cls = d.for_dgrad == 2 ? r / d.Cin_real : 0;
+    if (d.for_dgrad == 2) r -= cls * d.Cin_real;
+    const size_t row_o = ((size_t)cls * d.Cin_real + r) * d.Kpad;
+    const int ntd = d.for_dgrad == 2 ? 8 : d.ntaps;     // taps of the packed row
+    for (int c0 = 0; c0 < inner; c0 += 64) {
+        const int nc = min(64, nreal - c0);              // real channels in this chunk (<= 0: padding only)
+        if (nc > 0) {
+            if (!d.for_dgrad) {
+                const float* src = d.w + ((size_t)r * d.Cin_real + c0) * d.ntaps;
+                for (int i = t; i < nc * d.ntaps; i += 256) stage[i] = src[i];
+            } else {
+                for (int cl = t >> 5; cl < nc; cl += 8)
+                    for (int tap = t & 31; tap < d.ntaps; tap += 32)
+                        stage[cl * d.ntaps + tap] = d.w[((size_t)(c0 + cl) * d.Cin_real + r) * d.ntaps + tap];
+            }
+        }
+        __syncthreads();
+        const int g = t & 7;
+        if (c0 + g * 8 < inner) {
+            for (int tp = t >> 3; tp < ntd; tp += 32) {
+                const int tap = d.for_dgrad == 2 ? s2_class_tap(cls, tp, ksz) : tp;
+                uint32_t pk[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int cl = g * 8 + 2 * e;
+                    const float v0 = (tap >= 0 && cl < nc) ? stage[cl * d.ntaps + tap] : 0.f;
+                    const float v1 = (tap >= 0 && cl + 1 < nc) ? stage[(cl + 1) * d.ntaps + tap] : 0.f;
+                    pk[e] = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+                }
+                *reinterpret_cast<uint4*>(out + row_o + (size_t)tp * inner + c0 + g * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            }
+        }
+        __syncthreads();
+    }
+    for (int k = ntd * inner + t * 8; k < d.Kpad; k += 2048) *reinterpret_cast<uint4*>(out + row_o + k) = make_uint4(0, 0, 0, 0);
 }
 // torch weight -> data-gradient pack [Cin_real][Kpad'] with K' = tap*Cout + co
 template <typename T>
@@ -1138,15 +1211,16 @@ int dreg_pack_conv_weight(const float* w, void* out, int Cout, int Cin_real, int
 // Batched form of dreg_pack_conv_weight: descs = DEVICE array of n 48-byte records
 //   { const float* w; void* out; int Cout, Cin_real, inner (Cout for dgrad packs, padded Cin otherwise), ksz^3, for_dgrad, Kpad,
 //     dtype, row0 }
-// with row0 = exclusive prefix of the packed row counts (Cin_real for dgrad packs, Cout otherwise), total_rows its sum and
-// max_row_floats = max over the records of (dgrad ? Cout : Cin_real) * ksz^3 (LDS staging size).
-int dreg_pack_conv_weights_batched(const void* descs, int n, int total_rows, int max_row_floats, void* stream)
+// with row0 = exclusive prefix of the packed row counts (Cin_real [x8 for 3^3 class packs] for dgrad packs, Cout otherwise),
+// total_rows its sum and stage_floats = max over the bf16 records with ksz > 1 of min(channels, 64) * ksz^3 (LDS staging).
+// row_desc (optional, device int32 [total_rows]): record index of every packed row — saves the per-block binary search.
+int dreg_pack_conv_weights_batched(const void* descs, int n, int total_rows, int stage_floats, const int* row_desc, void* stream)
 {
     static_assert(sizeof(PackDesc) == 48, "descriptor layout is part of the ABI");
     if (n <= 0 || total_rows <= 0) return DREG_OK;
-    if (max_row_floats <= 0 || (size_t)max_row_floats * 4 > 64 * 1024) return DREG_EINVAL;
-    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(total_rows), dim3(256), (size_t)max_row_floats * 4, (hipStream_t)stream,
-                       (const PackDesc*)descs, n);
+    if (stage_floats < 0 || (size_t)stage_floats * 4 > 48 * 1024) return DREG_EINVAL;
+    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(total_rows), dim3(256), (size_t)(stage_floats > 0 ? stage_floats : 1) * 4, (hipStream_t)stream,
+                       (const PackDesc*)descs, n, row_desc);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

@@ -184,7 +184,8 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
         const size_t o = poff;
         poff += align256((size_t)rows * r.Kpad * 2);
         e->pack_rows += rows;
-        const int fl = (kind ? p.d0 : p.d1) * ntaps;
+        const int ch = kind ? p.d0 : p.d1;
+        const int fl = ntaps > 1 ? (ch < 64 ? ch : 64) * ntaps : 0;   // LDS staging of the k^3 route of the batched pack kernel
         if (fl > e->pack_max_floats) e->pack_max_floats = fl;
         e->packs.push_back(r);
         return o;
@@ -219,18 +220,24 @@ size_t dreg_exec_tensor_offset(void* h, int slot) { return ((Exec*)h)->t[slot].o
 int dreg_exec_output_slot(void* h) { return ((Exec*)h)->out_slot; }
 
 // Write the 48-byte pack descriptors (dreg_pack_conv_weights_batched) for a pack buffer at device address pack_base into host memory.
-int dreg_exec_export_pack_table(void* h, void* host_out, void* pack_base)
+int dreg_exec_pack_rows(void* h) { return ((Exec*)h)->pack_rows; }
+// host_row_desc: int32 [dreg_exec_pack_rows] receives the record index of every packed row
+int dreg_exec_export_pack_table(void* h, void* host_out, int* host_row_desc, void* pack_base)
 {
     Exec* e = (Exec*)h;
     PackRec* o = (PackRec*)host_out;
-    for (size_t i = 0; i < e->packs.size(); ++i) { o[i] = e->packs[i]; o[i].out = (char*)pack_base + (size_t)e->packs[i].out; }
+    for (size_t i = 0; i < e->packs.size(); ++i) {
+        o[i] = e->packs[i]; o[i].out = (char*)pack_base + (size_t)e->packs[i].out;
+        const int end = i + 1 < e->packs.size() ? e->packs[i + 1].row0 : e->pack_rows;
+        for (int r = e->packs[i].row0; r < end; ++r) host_row_desc[r] = (int)i;
+    }
     return DREG_OK;
 }
-// descs_dev: the exported table copied to the device by the caller
-int dreg_exec_repack(void* h, const void* descs_dev, void* stream)
+// descs_dev / row_desc_dev: the exported tables copied to the device by the caller
+int dreg_exec_repack(void* h, const void* descs_dev, const int* row_desc_dev, void* stream)
 {
     Exec* e = (Exec*)h;
-    return dreg_pack_conv_weights_batched(descs_dev, (int)e->packs.size(), e->pack_rows, e->pack_max_floats, stream);
+    return dreg_pack_conv_weights_batched(descs_dev, (int)e->packs.size(), e->pack_rows, e->pack_max_floats, row_desc_dev, stream);
 }
 
 void dreg_exec_set_timing(void* h, int enable) { Exec* e = (Exec*)h; e->timing = enable != 0; e->timed_used = 0; }

@@ -457,6 +457,64 @@ __global__ void trilinear_gather_bwd_rows_kernel(const float* __restrict__ dfeat
         }
     }
 }
+// Deterministic (atomic-free) form: one wave per S1 voxel gathers the contributions of the occupied fine voxels whose
+// trilinear corner set contains it.  fine_map[b][idx] = point index or -1.  Candidates per axis: the <= 6 fine coordinates with
+// i*s in (c-1, c+1), each tested with tri_axis() itself, so the weights are the forward's bit for bit.
+__global__ void fine_map_fill_kernel(const int64_t* __restrict__ idx, const int* __restrict__ pt_batch, int* __restrict__ fine_map, int N, size_t Vf)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) fine_map[(size_t)pt_batch[n] * Vf + (size_t)idx[n]] = n;
+}
+__device__ __forceinline__ void tri_range(int c, int n_out, int n_in, int& lo, int& hi) {
+    if (n_out <= 1 || n_in <= 1) { lo = 0; hi = n_out - 1; return; }
+    const float inv = (float)(n_out - 1) / (float)(n_in - 1);
+    lo = max(0, (int)floorf((float)(c - 1) * inv) - 1);
+    hi = min(n_out - 1, (int)ceilf((float)(c + 1) * inv) + 1);
+}
+__device__ __forceinline__ float tri_weight(int i, int c, int n_out, int n_in) {
+    const TriAxis a = tri_axis(i, n_out, n_in);
+    return (a.i0 == c ? 1.f - a.t : 0.f) + (a.i1 == c ? a.t : 0.f);
+}
+template <typename T, int CPL>
+__global__ __launch_bounds__(256) void trilinear_gather_bwd_gather_kernel(const float* __restrict__ dfeat, const int* __restrict__ fine_map,
+                                                                          const int* __restrict__ rows1, int n1, T* __restrict__ dp1,
+                                                                          int d, int h, int w, int Zr, int Xr, int Yr)
+{
+    constexpr int C = CPL * 64;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wv >= n1) return;
+    const int v = rows1[wv];
+    const int yc = v % w, xc = (v / w) % h, zc = (v / (w * h)) % d, b = v / (w * h * d);
+    int zlo, zhi, xlo, xhi, ylo, yhi;
+    tri_range(zc, Zr, d, zlo, zhi); tri_range(xc, Xr, h, xlo, xhi); tri_range(yc, Yr, w, ylo, yhi);
+    const int nz = zhi - zlo + 1, nx = xhi - xlo + 1, ny = yhi - ylo + 1, total = nz * nx * ny;
+    const size_t Vf = (size_t)Zr * Xr * Yr;
+    float acc[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) acc[k] = 0.f;
+    for (int base = 0; base < total; base += 64) {
+        const int j = base + lane;
+        int n = -1;
+        float wgt = 0.f;
+        if (j < total) {
+            const int jy = j % ny, jx = (j / ny) % nx, jz = j / (ny * nx);
+            const int z = zlo + jz, x = xlo + jx, y = ylo + jy;
+            wgt = tri_weight(z, zc, Zr, d) * tri_weight(x, xc, Xr, h) * tri_weight(y, yc, Yr, w);
+            if (wgt != 0.f) n = fine_map[(size_t)b * Vf + ((size_t)x * Yr + y) * Zr + z];
+        }
+        unsigned long long m = __ballot(n >= 0);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int nn = __shfl(n, l, 64);
+            const float ww = __shfl(wgt, l, 64);
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) acc[k] += dfeat[(size_t)nn * C + lane + 64 * k] * ww;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) Elem<T>::st(dp1 + (size_t)v * C + lane + 64 * k, acc[k]);
+}
 template <typename T>
 __global__ void scatter_rows_cast_kernel(const float* __restrict__ comp, const int* __restrict__ rows, T* __restrict__ out, size_t total_gran, int C)
 {
@@ -715,6 +773,30 @@ int dreg_trilinear_gather_bwd_rows(const float* dfeat, const int64_t* idx, const
     const size_t tg = (size_t)n1 * (C / G);
     if (dtype == 0) hipLaunchKernelGGL(scatter_rows_cast_kernel<bf16_t>, dim3(nblocks(tg)), dim3(256), 0, st, comp, rows1, (bf16_t*)dp1, tg, C);
     else hipLaunchKernelGGL(scatter_rows_cast_kernel<float>, dim3(nblocks(tg)), dim3(256), 0, st, comp, rows1, (float*)dp1, tg, C);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// Deterministic variant (no atomics): fine_map int32 [B*Zr*Xr*Yr] scratch.  C must be 64, 128, 192 or 256.
+int dreg_trilinear_gather_bwd_gather(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
+                                     int* fine_map, void* dp1, int N, int B, int d, int h, int w, int C, int Zr, int Xr, int Yr,
+                                     int dtype, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (C % 64 || C > 256) return DREG_EINVAL;
+    const size_t dense_bytes = (size_t)B * d * h * w * C * (dtype == 0 ? 2 : 4);
+    if (hipMemsetAsync(dp1, 0, dense_bytes, st) != hipSuccess) return DREG_ELAUNCH;
+    if (N == 0 || n1 == 0) return DREG_OK;
+    const size_t Vf = (size_t)Zr * Xr * Yr;
+    if (hipMemsetAsync(fine_map, 0xff, (size_t)B * Vf * sizeof(int), st) != hipSuccess) return DREG_ELAUNCH;
+    hipLaunchKernelGGL(fine_map_fill_kernel, dim3((N + 255) / 256), dim3(256), 0, st, idx, pt_batch, fine_map, N, Vf);
+    DREG_LAUNCH_CHECK();
+    const dim3 grid((n1 + 3) / 4);
+#define TG_LAUNCH(T, CPL) hipLaunchKernelGGL((trilinear_gather_bwd_gather_kernel<T, CPL>), grid, dim3(256), 0, st, dfeat, fine_map, rows1, n1, (T*)dp1, d, h, w, Zr, Xr, Yr)
+    const int cpl = C / 64;
+    if (dtype == 0) { if (cpl == 1) TG_LAUNCH(bf16_t, 1); else if (cpl == 2) TG_LAUNCH(bf16_t, 2); else if (cpl == 3) TG_LAUNCH(bf16_t, 3); else TG_LAUNCH(bf16_t, 4); }
+    else { if (cpl == 1) TG_LAUNCH(float, 1); else if (cpl == 2) TG_LAUNCH(float, 2); else if (cpl == 3) TG_LAUNCH(float, 3); else TG_LAUNCH(float, 4); }
+#undef TG_LAUNCH
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

@@ -38,7 +38,7 @@ SIGNATURES = {
     "dreg_conv_get_glds": (I, []),
     "dreg_conv3d_dgrad_s2": (I, [P, P, P] + [I] * 11 + [P]),
     "dreg_pack_conv_weight": (I, [P, P, I, I, I, I, I, I, P]),
-    "dreg_pack_conv_weights_batched": (I, [P, I, I, I, P]),
+    "dreg_pack_conv_weights_batched": (I, [P, I, I, I, P, P]),
     "dreg_conv_set_wgrad_splits": (None, [I]),
     "dreg_conv3d_wgrad_splits": (I, [I] * 8),
     "dreg_conv3d_wgrad_workspace_bytes": (Z, [I] * 8),
@@ -61,6 +61,7 @@ SIGNATURES = {
     "dreg_active_sets": (I, [P, P] + [I] * 8 + [P, P, P, P, Z, P]),
     "dreg_trilinear_gather_bwd_rows": (I, [P, P, P, P, I, P, P, P] + [I] * 10 + [P]),
     "dreg_colsum_rows": (I, [P, P, I, P, P, I, I, I, P]),
+    "dreg_trilinear_gather_bwd_gather": (I, [P, P, P, P, I, P, P] + [I] * 10 + [P]),
     "dreg_add_inplace": (I, [P, P, Z, I, P]),
     # executor.hip
     "dreg_exec_create": (P, [P, I, P, I, P, I]),
@@ -70,8 +71,9 @@ SIGNATURES = {
     "dreg_exec_num_packs": (I, [P]),
     "dreg_exec_tensor_offset": (Z, [P, I]),
     "dreg_exec_output_slot": (I, [P]),
-    "dreg_exec_export_pack_table": (I, [P, P, P]),
-    "dreg_exec_repack": (I, [P, P, P]),
+    "dreg_exec_pack_rows": (I, [P]),
+    "dreg_exec_export_pack_table": (I, [P, P, P, P]),
+    "dreg_exec_repack": (I, [P, P, P, P]),
     "dreg_exec_set_timing": (None, [P, I]),
     "dreg_exec_read_timings": (I, [P, P, P, I]),
     "dreg_exec_forward": (I, [P, P, Z, P, P, P, I, I, P]),

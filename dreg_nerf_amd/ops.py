@@ -133,17 +133,22 @@ def repack_all(device=None):
     if _pack_table is None or _pack_table[3] != sig:
         rec = np.zeros((len(live), 12), dtype=np.int32)
         row0 = max_floats = 0
+        rowmap = []
         for r, (key, src, base) in enumerate(live):
             ent = _pack_cache[key]
             cout, cin_real, inner, ntaps, fd, kpad, dt = ent[5]
             rec[r, 0:2] = np.frombuffer(np.int64(src).tobytes(), dtype=np.int32)
             rec[r, 2:4] = np.frombuffer(np.int64(ent[2].data_ptr()).tobytes(), dtype=np.int32)
             rec[r, 4:12] = (cout, cin_real, inner, ntaps, fd, kpad, dt, row0)
-            row0 += (cin_real * (8 if (fd == 2 and ntaps > 1) else 1)) if fd else cout
-            max_floats = max(max_floats, (cout if fd else cin_real) * ntaps)
-        _pack_table = (torch.from_numpy(rec).to(live[0][2].device), len(live), row0, sig, max_floats)
-    tab, n, nrows, _, max_floats = _pack_table
-    L.check(lib.dreg_pack_conv_weights_batched(L.ptr(tab), n, nrows, max_floats, L.stream()), "dreg_pack_conv_weights_batched")
+            nrow = (cin_real * (8 if (fd == 2 and ntaps > 1) else 1)) if fd else cout
+            rowmap.append(np.full(nrow, r, dtype=np.int32))
+            row0 += nrow
+            if ntaps > 1 and dt == 0:
+                max_floats = max(max_floats, min(cout if fd else cin_real, 64) * ntaps)
+        dev_ = live[0][2].device
+        _pack_table = (torch.from_numpy(rec).to(dev_), len(live), row0, sig, max_floats, torch.from_numpy(np.concatenate(rowmap)).to(dev_))
+    tab, n, nrows, _, max_floats, rmap = _pack_table
+    L.check(lib.dreg_pack_conv_weights_batched(L.ptr(tab), n, nrows, max_floats, L.ptr(rmap), L.stream()), "dreg_pack_conv_weights_batched")
     for key, _, base in live:
         ent = _pack_cache[key]
         _pack_cache[key] = (ent[0], (base._version, _weight_generation)) + ent[2:]
@@ -431,7 +436,7 @@ def conv3d_rows(x, w, bias, addend, pad, out_rows, in_rows):
     return SparseConv3dFn.apply(x, w, bias, addend, pad, out_rows, in_rows)
 
 
-def active_sets(idx_list, fine_res, coarse_dims, device, pt_batch=None, idx_cat=None):
+def active_sets(idx_list, fine_res, coarse_dims, device, pt_batch=None, idx_cat=None, density_cap: float = 0.2):
     """Row lists for the FPN head: S1 = trilinear-gather corner voxels of the occupied fine voxels (where P1 is consumed),
     S2 = S1 dilated by 3^3 (where the lateral sum is consumed), S3 = S2 dilated (where dc1 of the head is non-zero).
     idx_list: per grid int64 flat fine indices ((x*Yr + y)*Zr + z).  Returns three ascending int32 tensors of flat indices
@@ -454,7 +459,7 @@ def active_sets(idx_list, fine_res, coarse_dims, device, pt_batch=None, idx_cat=
     L.check(lib.dreg_active_sets(L.ptr(idx_cat), L.ptr(pt_batch), idx_cat.shape[0], B, Zr, Xr, Yr, d, h, w,
                                  L.ptr(rows), L.ptr(counts), L.ptr(map1), L.ptr(ws), nbytes, L.stream()), "dreg_active_sets")
     n1, n2, n3 = counts.tolist()
-    if n3 > 0.2 * V:   # dense scenes: the row lists stop paying (and the wgrad slice cap applies)
+    if n3 > density_cap * V:   # dense scenes: the row lists stop paying (and the wgrad slice cap applies)
         return None
     return rows[0, :n1], rows[1, :n2], rows[2, :n3], map1
 
@@ -574,6 +579,12 @@ class TrilinearGatherFn(torch.autograd.Function):
         gout = gout.contiguous().float()
         if rows1 is not None:  # active set: compact fp32 accumulation on S1, one cast-scatter into the zero-filled gradient
             g = torch.empty(shape, dtype=dtype, device=gout.device)
+            if C % 64 == 0 and C <= 256:   # atomic-free gather per S1 voxel: deterministic
+                fmap = torch.empty(B * Zr * Xr * Yr, dtype=torch.int32, device=gout.device)
+                L.check(lib.dreg_trilinear_gather_bwd_gather(L.ptr(gout), L.ptr(idx), L.ptr(pt_batch), L.ptr(rows1), rows1.shape[0], L.ptr(fmap),
+                                                             L.ptr(g), idx.shape[0], B, d, h, w, C, Zr, Xr, Yr, L.dt_of(g), L.stream()),
+                        "dreg_trilinear_gather_bwd_gather")
+                return g, None, None, None, None, None
             comp = torch.empty(max(rows1.shape[0], 1), C, dtype=torch.float32, device=gout.device)
             L.check(lib.dreg_trilinear_gather_bwd_rows(L.ptr(gout), L.ptr(idx), L.ptr(pt_batch), L.ptr(rows1), rows1.shape[0], L.ptr(map1),
                                                        L.ptr(comp), L.ptr(g), idx.shape[0], B, d, h, w, C, Zr, Xr, Yr, L.dt_of(g), L.stream()),

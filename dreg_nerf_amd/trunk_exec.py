@@ -114,8 +114,10 @@ class TrunkExecutor:
         self.pack = torch.empty(self.lib.dreg_exec_pack_bytes(self.h), dtype=torch.uint8, device=dev)
         n = self.lib.dreg_exec_num_packs(self.h)
         host = np.zeros((n, 12), dtype=np.int32)
-        L.check(self.lib.dreg_exec_export_pack_table(self.h, host.ctypes.data, self.pack.data_ptr()), "dreg_exec_export_pack_table")
+        rowmap = np.zeros(self.lib.dreg_exec_pack_rows(self.h), dtype=np.int32)
+        L.check(self.lib.dreg_exec_export_pack_table(self.h, host.ctypes.data, rowmap.ctypes.data, self.pack.data_ptr()), "dreg_exec_export_pack_table")
         self.pack_table = torch.from_numpy(host).to(dev)
+        self.pack_rowmap = torch.from_numpy(rowmap).to(dev)
         self.out_slot = self.lib.dreg_exec_output_slot(self.h)
         self.out_off = self.lib.dreg_exec_tensor_offset(self.h, self.out_slot)
         self.pack_stamp = None
@@ -173,7 +175,7 @@ class TrunkExecutor:
     def repack_if_stale(self):
         stamp = ops._weight_generation
         if self.pack_stamp != stamp:
-            L.check(self.lib.dreg_exec_repack(self.h, L.ptr(self.pack_table), L.stream()), "dreg_exec_repack")
+            L.check(self.lib.dreg_exec_repack(self.h, L.ptr(self.pack_table), L.ptr(self.pack_rowmap), L.stream()), "dreg_exec_repack")
             self.pack_stamp = stamp
 
     @staticmethod

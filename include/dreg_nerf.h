@@ -40,9 +40,11 @@ int dreg_pack_conv_weight(const float* w, void* out, int Cout, int Cin_real, int
                           int dtype, void* stream);
 /* Batched form (all packs of a step in one launch): descs = DEVICE array of n 48-byte records
  * { const float* w; void* out; int Cout, Cin_real, inner (Cout for dgrad packs, padded Cin otherwise), ksz^3, for_dgrad, Kpad,
- *   dtype, row0 } with row0 = exclusive prefix of the packed row counts (Cin_real for dgrad packs, Cout otherwise),
- * total_rows = its sum, max_row_floats = max of (dgrad ? Cout : Cin_real) * ksz^3 (LDS staging, <= 16384). */
-int dreg_pack_conv_weights_batched(const void* descs, int n, int total_rows, int max_row_floats, void* stream);
+ *   dtype, row0 } with row0 = exclusive prefix of the packed row counts (Cin_real [x8 for 3^3 class packs] for dgrad packs,
+ * Cout otherwise), total_rows = its sum, stage_floats = max over bf16 records with ksz > 1 of min(channels, 64) * ksz^3,
+ * row_desc (optional device int32 [total_rows]) = record index of every packed row. */
+int dreg_pack_conv_weights_batched(const void* descs, int n, int total_rows, int stage_floats, const int* row_desc,
+                                   void* stream);
 
 /* Implicit-GEMM convolution on MFMA.
  * transposed = 0 (forward):        out[b,o,:] = sum_d in[b, o*stride - pad + d, :] . W[:, d, :]  (+bias) (+up2(addend)) (relu)
@@ -145,6 +147,11 @@ int dreg_active_sets(const int64_t* idx, const int* pt_batch, int N, int B, int 
 int dreg_trilinear_gather_bwd_rows(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
                                    const int* map1, float* comp, void* dp1, int N, int B, int d, int h, int w, int C,
                                    int Zr, int Xr, int Yr, int dtype, void* stream);
+/* deterministic (atomic-free) gather backward: one wave per S1 voxel collects the occupied fine voxels whose corner set
+ * contains it; fine_map int32 [B*Zr*Xr*Yr] scratch; C in {64,128,192,256}. */
+int dreg_trilinear_gather_bwd_gather(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
+                                     int* fine_map, void* dp1, int N, int B, int d, int h, int w, int C, int Zr, int Xr,
+                                     int Yr, int dtype, void* stream);
 int dreg_colsum_rows(const void* g, const int* rows, int nrows, float* out, float* workspace, int C, int accumulate,
                      int dtype, void* stream);
 
@@ -163,8 +170,9 @@ size_t dreg_exec_pack_bytes(void* h);
 int dreg_exec_num_packs(void* h);
 size_t dreg_exec_tensor_offset(void* h, int slot);
 int dreg_exec_output_slot(void* h);
-int dreg_exec_export_pack_table(void* h, void* host_out, void* pack_base);   /* 48-byte records of dreg_pack_conv_weights_batched */
-int dreg_exec_repack(void* h, const void* descs_dev, void* stream);
+int dreg_exec_pack_rows(void* h);
+int dreg_exec_export_pack_table(void* h, void* host_out, int* host_row_desc, void* pack_base);   /* 48-byte records + row->record map */
+int dreg_exec_repack(void* h, const void* descs_dev, const int* row_desc_dev, void* stream);
 void dreg_exec_set_timing(void* h, int enable);                              /* HIP events around every convolution launch */
 int dreg_exec_read_timings(void* h, int* op_kind, float* ms, int max);       /* (op, kind 0 fwd / 1 dgrad / 2 wgrad), ms */
 int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack_base, const void* x_in,

@@ -198,6 +198,35 @@ def test_trilinear_gather():
     np.testing.assert_allclose(ncdhw(pd.grad.cpu()).numpy(), p1r.grad.numpy(), atol=2e-5)
 
 
+@pytest.mark.parametrize("res,coarse", [((10, 12, 14), (5, 6, 7)), ((17, 15, 13), (9, 8, 7))])
+def test_trilinear_gather_backward_on_active_set_is_exact_and_deterministic(res, coarse):
+    """Atomic-free gather form of the backward (one wave per S1 voxel) == the fp32 CPU gradient of the oracle's upsample+gather,
+    run twice bit-identically (the dense form accumulates with fp32 atomics)."""
+    dev = _dev()
+    from oracle import regtr_oracle as O
+    g = torch.Generator().manual_seed(res[0])
+    B, C = 3, 256
+    p1 = torch.randn(B, C, *coarse, generator=g)
+    n = res[0] * res[1] * res[2]
+    masks = [torch.randperm(n, generator=g)[:40 + 7 * b].sort().values for b in range(B)]
+    masks[1] = torch.cat([masks[1], torch.tensor([0, n - 1])]).unique()   # the clamped corners
+    p1r = p1.clone().requires_grad_(True)
+    ref = torch.cat([O.upsample_gather(p1r[b:b + 1], torch.zeros(1, 3, *res), masks[b])[1] for b in range(B)])
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    idx = torch.cat(masks).to(dev)
+    pb = torch.cat([torch.full((m.numel(),), b, dtype=torch.int32) for b, m in enumerate(masks)]).to(dev)
+    rows = ops.active_sets([m.to(dev) for m in masks], res, coarse, dev, pt_batch=pb, idx_cat=idx, density_cap=1.0)
+    grads = []
+    for _ in range(2):
+        pd = ndhwc(p1).to(dev).requires_grad_(True)
+        out = ops.trilinear_gather(pd, idx, pb, res, rows[0], rows[3])
+        out.backward(gy.to(dev))
+        grads.append(pd.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    np.testing.assert_allclose(ncdhw(grads[0].cpu()).numpy(), p1r.grad.numpy(), atol=2e-5)
+
+
 @pytest.mark.parametrize("mode", [3, 4])
 def test_conv_glds_large_tiles_match_default(mode):
     """128x256 and 256x256 tile variants of the direct-to-LDS kernel == the 128x128 tile, bit for bit."""
