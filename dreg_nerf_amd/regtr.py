@@ -98,6 +98,8 @@ class NeRFRegTr(nn.Module):
         self.active_set = True
         # Issue the FPN3D forward / backward from the C++ executor (csrc/executor.hip) instead of one autograd node per layer
         self.native_trunk = True
+        # Run the data-dependent geometry phase of forward_batch on its own high-priority stream (see forward_batch)
+        self.async_geometry = True
         self._spec = params.regtr_spec()
         _build_tree(self, self._spec)
         _reset_parameters(self, self._spec)
@@ -223,9 +225,10 @@ class NeRFRegTr(nn.Module):
         return F.pad(rgba, (0, 4)).to(dtype).contiguous()
 
     # ------------------------------------------------------------------ A3..A9 for a batch of pairs
-    def forward_batch(self, batch: List[dict]) -> List[dict]:
-        """Each element: the reference's ``data`` dict for one pair.  Returns one output dict per pair."""
-        dev = self.fpn3d.backbone_net.conv1.weight.device
+    def _geometry(self, batch: List[dict], dev):
+        """Everything whose size depends on the data — point coordinates, the active sets of the FPN head, the A4 voxel rounds
+        (their stopping rule is per pair) — needs only the occupied voxels' coordinates, not the feature network.  All host
+        syncs of a step happen here."""
         grids, idxs, pbatch, xyzs = [], [], [], []
         for i, d in enumerate(batch):
             for j, side in enumerate(("src", "tgt")):
@@ -240,11 +243,7 @@ class NeRFRegTr(nn.Module):
                 pbatch.append(torch.full((m.shape[0],), 2 * i + j, dtype=torch.int32, device=dev))
                 xyzs.append(g[:, :3].permute(0, 3, 4, 2, 1).reshape(-1, 3)[m])
         res = tuple(grids[0].shape[-3:])
-        A.set_precision(self.precision)
         idx_cat, pb_cat = torch.cat(idxs).contiguous(), torch.cat(pbatch)
-        # geometry first: everything whose size depends on the data (active sets of the FPN head, the A4 voxel rounds — their
-        # stopping rule is per pair) needs only the occupied voxels' coordinates.  All host syncs of the step happen here,
-        # before the feature network is queued; from the FPN on, the host runs ahead of the GPU.
         rows = None
         if self.active_set and self.precision == "bf16":
             rows = ops.active_sets(idxs, res, tuple((r + 1) // 2 for r in res), dev, pt_batch=pb_cat, idx_cat=idx_cat)
@@ -255,6 +254,36 @@ class NeRFRegTr(nn.Module):
             plans.append(rounds)
             pts_l.append(pts)
             segs.append((int(lens[0]), int(lens[1])))
+        return grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs
+
+    def forward_batch(self, batch: List[dict]) -> List[dict]:
+        """Each element: the reference's ``data`` dict for one pair.  Returns one output dict per pair.
+        The geometry phase runs on a high-priority side stream (async_geometry): its host syncs then wait for that stream only,
+        so the host can prepare step n+1 while the GPU still works on step n.  The input tensors must be materialised when
+        this is called (true for synchronous uploads); otherwise pass the upload's event as data['ready_event']."""
+        dev = self.fpn3d.backbone_net.conv1.weight.device
+        A.set_precision(self.precision)
+        if self.async_geometry and dev.type == "cuda":
+            main = torch.cuda.current_stream(dev)
+            side = self.__dict__.get("_geo_stream")
+            if side is None or side.device != dev:
+                side = self.__dict__["_geo_stream"] = torch.cuda.Stream(device=dev, priority=-1)
+            for d in batch:
+                if d.get("ready_event") is not None:
+                    side.wait_event(d["ready_event"])
+            with torch.cuda.stream(side):
+                geo = self._geometry(batch, dev)
+            main.wait_stream(side)
+            grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs = geo
+            # these were allocated on the side stream and are consumed on the main one
+            keep = [idx_cat, pb_cat] + list(pts_l) + ([rows[0], rows[3]] if rows is not None else [])
+            for rounds in plans:
+                for rnd in rounds:
+                    keep += [rnd.order, rnd.starts, rnd.n_out_dev, rnd.inv_seg, rnd.inv_cnt]
+            for t in keep:
+                t.record_stream(main)
+        else:
+            grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs = self._geometry(batch, dev)
         p1 = self.fpn(self.pack_grids(grids, self.act_dtype), rows)
         feats = ops.trilinear_gather(p1, idx_cat, pb_cat, res, *((rows[0], rows[3]) if rows is not None else ()))
         P = self._P()
