@@ -134,6 +134,18 @@ class ProblemTable:
         self.self_probs = L.to_device_async(self_p, torch.int32, device)   # no pageable H2D copy: that would drain the stream
         self.cross_probs = L.to_device_async(cross_p, torch.int32, device)
         self.max_len = max(max(ns, nt) for ns, nt in seg_lengths)
+        # per-pair tables of the batched Kabsch / loss kernels: (s0, ns, t0, nt); source-row and logits-block offsets
+        self.pair_probs = L.to_device_async([list(sg) for sg in starts], torch.int32, device)
+        so, lo, a, b = [], [], 0, 0
+        for (s0, ns, t0, nt) in starts:
+            so.append(a)
+            lo.append(b)
+            a += ns
+            b += ns * nt
+        self.total_src, self.total_logits = a, b
+        self.logit_off_host = lo
+        self.src_off = L.to_device_async(so, torch.int32, device)
+        self.logit_off = L.to_device_async(lo, torch.int64, device)
         self.nprob = len(self_p)
 
 
@@ -404,4 +416,16 @@ def weighted_kabsch(a, b, w, eps: float = 1e-6):
     out = torch.empty(a.shape[0], 3, 4, dtype=torch.float32, device=a.device)
     L.check(lib.dreg_weighted_kabsch(L.ptr(a), L.ptr(b), L.ptr(w), L.ptr(out), a.shape[0], a.shape[1], eps, L.stream()),
             "dreg_weighted_kabsch")
+    return out
+
+
+def weighted_kabsch_pairs(xyz, corr, ov, tab: "ProblemTable", eps: float = 1e-6):
+    """All (pair, layer) solves of a step in one launch: xyz [R,3], corr [L,R,3], ov [L,R(,1)] -> [P,L,3,4] (no gradient)."""
+    lib = L.load()
+    xyz, corr = xyz.detach().contiguous().float(), corr.detach().contiguous().float()
+    ov = ov.detach().reshape(corr.shape[0], -1).contiguous().float()
+    P_, Ln, R = len(tab.segs), corr.shape[0], xyz.shape[0]
+    out = torch.empty(P_, Ln, 3, 4, dtype=torch.float32, device=xyz.device)
+    L.check(lib.dreg_weighted_kabsch_pairs(L.ptr(xyz), L.ptr(corr), L.ptr(ov), L.ptr(tab.pair_probs), L.ptr(out), P_, Ln, R, eps, L.stream()),
+            "dreg_weighted_kabsch_pairs")
     return out

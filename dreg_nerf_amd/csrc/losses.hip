@@ -1,0 +1,256 @@
+// Training losses of the registration network for all pairs of a step at once (gfx950): the overlap BCE, the label
+// consistency smooth-L1, the correspondence L1 and the InfoNCE feature loss, with their input gradients.
+//
+// Reference: train_nerf_regtr.py:186-229 (assembly; last decoder layer only; weights 1 / 1 / 0.1 / 1),
+// conerf/loss/correspondence_loss.py:16-51, conerf/loss/feature_loss.py:24-73.  The reference's quirks are kept:
+// BCEWithLogits(input = labels, target = prediction), and the [nl,N,1] x [N] broadcast of the correspondence loss, which
+// makes it sum_j err_j * (sum w / max(sum w, eps)).
+//
+// Row space: R rows = every pair's (src | tgt) key points; probs int32 [P][4] = (s0, ns, t0, nt).  All reductions run in
+// a fixed order inside one block per segment: results are deterministic.
+#include "common.h"
+
+__device__ __forceinline__ double block_sum_d(double v, double* red)
+{
+    const int t = threadIdx.x;
+    red[t] = v; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
+    const double r = red[0]; __syncthreads();
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ point losses
+// grid = 2P blocks: block (p, side).  gt, tilde: [L,R] labels; ov: [R] last-layer overlap prediction; corr: [R,3] last-layer
+// correspondences; xyz [R,3]; pose [P,4,4].  partial [2P][4] = (bce sum, smooth-l1 sum, err sum, label sum).
+// d_ov [R], d_corr [R,3]: gradients of the MEAN-over-pairs total (weights folded in).
+__global__ __launch_bounds__(256) void reg_point_losses_kernel(
+    const float* __restrict__ gt, const float* __restrict__ tilde, const float* __restrict__ ov, const float* __restrict__ corr,
+    const float* __restrict__ xyz, const float* __restrict__ pose, const int* __restrict__ probs,
+    float* __restrict__ partial, float* __restrict__ d_ov, float* __restrict__ d_corr,
+    int L, int R, int P, int robust, float eps, float w_overlap, float w_corr)
+{
+    __shared__ double red[256];
+    const int p = blockIdx.x >> 1, side = blockIdx.x & 1, t = threadIdx.x;
+    const int s0 = probs[p * 4], ns = probs[p * 4 + 1], t0 = probs[p * 4 + 2], nt = probs[p * 4 + 3];
+    const int r0 = side ? t0 : s0, n = side ? nt : ns;
+    // rigid map of this side: src uses the pose, tgt its inverse (R^T, -R^T t)
+    float Rm[3][3], tv[3];
+    const float* Pm = pose + (size_t)p * 16;
+    if (!side) {
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Rm[i][j] = Pm[i * 4 + j]; tv[i] = Pm[i * 4 + 3]; }
+    } else {
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) Rm[i][j] = Pm[j * 4 + i];
+            tv[i] = -(Pm[0 * 4 + i] * Pm[0 * 4 + 3] + Pm[1 * 4 + i] * Pm[1 * 4 + 3] + Pm[2 * 4 + i] * Pm[2 * 4 + 3]);
+        }
+    }
+    double bce = 0.0, sl1 = 0.0, err = 0.0, wsum = 0.0;
+    const float inv_n = 1.f / (float)(ns + nt);
+    for (int i = t; i < n; i += 256) {
+        const int row = r0 + i;
+        const float x = gt[(size_t)(L - 1) * R + row], tt = ov[row];
+        bce += (double)(fmaxf(x, 0.f) - x * tt + log1pf(expf(-fabsf(x))));
+        d_ov[row] = -x * inv_n * w_overlap / (float)P;
+        for (int l = 0; l < L; ++l) {
+            const float g = gt[(size_t)l * R + row], d = g - tilde[(size_t)l * R + row], a = fabsf(d);
+            sl1 += (double)(a < 1.f ? 0.5f * d * d : a - 0.5f);
+            wsum += (double)g;
+        }
+        float e = 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const float tx = xyz[(size_t)row * 3] * Rm[c][0] + xyz[(size_t)row * 3 + 1] * Rm[c][1] + xyz[(size_t)row * 3 + 2] * Rm[c][2] + tv[c];
+            float d = corr[(size_t)row * 3 + c] - tx;
+            if (robust) d = sqrtf((d / 0.5f) * (d / 0.5f) + 1.f) - 1.f;
+            e += fabsf(d);
+        }
+        err += (double)e;
+    }
+    bce = block_sum_d(bce, red); sl1 = block_sum_d(sl1, red); err = block_sum_d(err, red); wsum = block_sum_d(wsum, red);
+    if (t == 0) {
+        float* o = partial + (size_t)blockIdx.x * 4;
+        o[0] = (float)bce; o[1] = (float)sl1; o[2] = (float)err; o[3] = (float)wsum;
+    }
+    const float factor = (float)wsum / fmaxf((float)wsum, eps) * w_corr / (float)P;
+    for (int i = t; i < n; i += 256) {
+        const int row = r0 + i;
+        for (int c = 0; c < 3; ++c) {
+            const float tx = xyz[(size_t)row * 3] * Rm[c][0] + xyz[(size_t)row * 3 + 1] * Rm[c][1] + xyz[(size_t)row * 3 + 2] * Rm[c][2] + tv[c];
+            const float d = corr[(size_t)row * 3 + c] - tx;
+            float g;
+            if (robust) {
+                // |ph(d)| with ph(d) = sqrt((d/0.5)^2 + 1) - 1 >= 0: derivative (d / 0.25) / sqrt((d/0.5)^2 + 1)
+                g = (d / 0.25f) / sqrtf((d / 0.5f) * (d / 0.5f) + 1.f);
+            } else g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            d_corr[(size_t)row * 3 + c] = g * factor;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ InfoNCE
+// pass 1 (needs only coordinates): nearest target of every transformed source point, its distance test, the pair's positive
+// count (atomic adds of 0/1: exact in fp32, order independent).  One wave per source row.  nn [Rs] (index inside the pair's
+// target set; the lowest index on ties), mask [Rs] (0/1), count [P] (zeroed by the caller); rows indexed by their position in
+// the concatenated SOURCE row list (src_off[p] = sum of ns of earlier pairs).
+__global__ __launch_bounds__(256) void infonce_nn_kernel(const float* __restrict__ xyz, const float* __restrict__ pose, const int* __restrict__ probs,
+                                                         const int* __restrict__ src_off, int* __restrict__ nn, float* __restrict__ mask,
+                                                         float* __restrict__ count, int P, int total_src, float r_p)
+{
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wv >= total_src) return;
+    int p = 0;
+    while (p + 1 < P && src_off[p + 1] <= wv) ++p;
+    const int i = wv - src_off[p];
+    const int s0 = probs[p * 4], t0 = probs[p * 4 + 2], nt = probs[p * 4 + 3];
+    const float* Pm = pose + (size_t)p * 16;
+    const float* s = xyz + (size_t)(s0 + i) * 3;
+    float a[3];
+    for (int c = 0; c < 3; ++c) a[c] = s[0] * Pm[c * 4] + s[1] * Pm[c * 4 + 1] + s[2] * Pm[c * 4 + 2] + Pm[c * 4 + 3];
+    float best = 3.4e38f; int bj = 0x7fffffff;
+    for (int j = lane; j < nt; j += 64) {
+        const float* q = xyz + (size_t)(t0 + j) * 3;
+        const float dx = a[0] - q[0], dy = a[1] - q[1], dz = a[2] - q[2];
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        if (d2 < best) { best = d2; bj = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float b2 = __shfl_xor(best, o, 64);
+        const int j2 = __shfl_xor(bj, o, 64);
+        if (b2 < best || (b2 == best && j2 < bj)) { best = b2; bj = j2; }
+    }
+    if (lane == 0) {
+        nn[wv] = bj;
+        const float m = sqrtf(best) < r_p ? 1.f : 0.f;
+        mask[wv] = m;
+        if (m > 0.f) atomicAdd(count + p, 1.f);
+    }
+}
+
+// pass 2: one wave per source row over the pair's logits block (row-major [ns][nt] at logit_off[p]).  Included columns:
+// dist >= r_n, plus the nearest neighbour.  loss_row = -logit[nn] + logsumexp(included); dlogits (in place) =
+// mask/count * (softmax(included) - onehot(nn)) * scale.
+__global__ __launch_bounds__(256) void infonce_rows_kernel(float* __restrict__ logits, const float* __restrict__ xyz, const float* __restrict__ pose,
+                                                           const int* __restrict__ probs, const int* __restrict__ src_off, const long long* __restrict__ logit_off,
+                                                           const int* __restrict__ nn, const float* __restrict__ mask, const float* __restrict__ count,
+                                                           float* __restrict__ loss_row, int P, int total_src, float r_n, float scale, int write_grad)
+{
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wv >= total_src) return;
+    int p = 0;
+    while (p + 1 < P && src_off[p + 1] <= wv) ++p;
+    const int i = wv - src_off[p];
+    const int s0 = probs[p * 4], t0 = probs[p * 4 + 2], nt = probs[p * 4 + 3];
+    const float* Pm = pose + (size_t)p * 16;
+    const float* s = xyz + (size_t)(s0 + i) * 3;
+    float a[3];
+    for (int c = 0; c < 3; ++c) a[c] = s[0] * Pm[c * 4] + s[1] * Pm[c * 4 + 1] + s[2] * Pm[c * 4 + 2] + Pm[c * 4 + 3];
+    float* lg = logits + logit_off[p] + (size_t)i * nt;
+    const int jn = nn[wv];
+    // online logsumexp over the included columns
+    float mx = -3.4e38f, se = 0.f;
+    for (int j = lane; j < nt; j += 64) {
+        const float* q = xyz + (size_t)(t0 + j) * 3;
+        const float dx = a[0] - q[0], dy = a[1] - q[1], dz = a[2] - q[2];
+        const bool inc = (j == jn) || !(sqrtf(dx * dx + dy * dy + dz * dz) < r_n);
+        if (inc) {
+            const float v = lg[j];
+            if (v > mx) { se = se * expf(mx - v) + 1.f; mx = v; } else se += expf(v - mx);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(mx, o, 64), s2 = __shfl_xor(se, o, 64);
+        const float mm = fmaxf(mx, m2);
+        se = se * expf(mx - mm) + s2 * expf(m2 - mm);
+        mx = mm;
+    }
+    const float lse = mx + logf(se);
+    const float lnn = lg[jn];
+    if (lane == 0) loss_row[wv] = mask[wv] * (lse - lnn);
+    if (!write_grad) return;
+    const float cnt = count[p];
+    const float k = (mask[wv] > 0.f && cnt > 0.f) ? scale / cnt : 0.f;
+    for (int j = lane; j < nt; j += 64) {
+        const float* q = xyz + (size_t)(t0 + j) * 3;
+        const float dx = a[0] - q[0], dy = a[1] - q[1], dz = a[2] - q[2];
+        const bool inc = (j == jn) || !(sqrtf(dx * dx + dy * dy + dz * dz) < r_n);
+        float g = inc ? expf(lg[j] - lse) : 0.f;
+        if (j == jn) g -= 1.f;
+        lg[j] = g * k;
+    }
+}
+
+// final: out[5] = mean over pairs of (overlap, nerf_cont, feature, corr, total)
+__global__ __launch_bounds__(256) void reg_losses_final_kernel(const float* __restrict__ partial, const float* __restrict__ loss_row, const float* __restrict__ count,
+                                                               const int* __restrict__ probs, const int* __restrict__ src_off, float* __restrict__ out,
+                                                               int P, int L, float eps, float w_overlap, float w_cont, float w_feat, float w_corr)
+{
+    __shared__ double red[256];
+    const int t = threadIdx.x;
+    double acc[4] = {0, 0, 0, 0};
+    for (int p = 0; p < P; ++p) {
+        const int ns = probs[p * 4 + 1], nt = probs[p * 4 + 3];
+        double f = 0.0;
+        for (int i = t; i < ns; i += 256) f += (double)loss_row[src_off[p] + i];
+        f = block_sum_d(f, red);
+        if (t == 0) {
+            const float* a = partial + (size_t)(2 * p) * 4;
+            const float* b = a + 4;
+            const double n = (double)(ns + nt);
+            acc[0] += ((double)a[0] + (double)b[0]) / n;
+            acc[1] += ((double)a[1] + (double)b[1]) / (n * L);
+            acc[2] += f / (double)count[p];           // 0/0 -> nan, as loss[mask].sum() / mask.sum() of the reference
+            acc[3] += (double)a[2] * ((double)a[3] / fmax((double)a[3], (double)eps)) + (double)b[2] * ((double)b[3] / fmax((double)b[3], (double)eps));
+        }
+    }
+    if (t == 0) {
+        for (int k = 0; k < 4; ++k) out[k] = (float)(acc[k] / P);
+        out[4] = w_overlap * out[0] + w_cont * out[1] + w_feat * out[2] + w_corr * out[3];
+    }
+}
+
+extern "C" {
+
+int dreg_reg_point_losses(const float* gt, const float* tilde, const float* ov, const float* corr, const float* xyz, const float* pose,
+                          const int* probs, float* partial, float* d_ov, float* d_corr, int L, int R, int P, int robust, float eps,
+                          float w_overlap, float w_corr, void* stream)
+{
+    if (P <= 0) return DREG_OK;
+    hipLaunchKernelGGL(reg_point_losses_kernel, dim3(2 * P), dim3(256), 0, (hipStream_t)stream, gt, tilde, ov, corr, xyz, pose, probs, partial, d_ov, d_corr,
+                       L, R, P, robust, eps, w_overlap, w_corr);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+int dreg_infonce_nn(const float* xyz, const float* pose, const int* probs, const int* src_off, int* nn, float* mask, float* count, int P,
+                    int total_src, float r_p, void* stream)
+{
+    if (P <= 0 || total_src <= 0) return DREG_OK;
+    if (hipMemsetAsync(count, 0, sizeof(float) * P, (hipStream_t)stream) != hipSuccess) return DREG_ELAUNCH;
+    hipLaunchKernelGGL(infonce_nn_kernel, dim3((total_src + 3) / 4), dim3(256), 0, (hipStream_t)stream, xyz, pose, probs, src_off, nn, mask, count,
+                       P, total_src, r_p);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// logits: every pair's [ns][nt] block at element offset logit_off[p]; overwritten by the gradient when write_grad.
+// scale: weight of the feature loss in the mean-over-pairs total (w_feat / P).
+int dreg_infonce_rows(float* logits, const float* xyz, const float* pose, const int* probs, const int* src_off, const long long* logit_off,
+                      const int* nn, const float* mask, const float* count, float* loss_row, int P, int total_src, float r_n, float scale,
+                      int write_grad, void* stream)
+{
+    if (P <= 0 || total_src <= 0) return DREG_OK;
+    hipLaunchKernelGGL(infonce_rows_kernel, dim3((total_src + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, xyz, pose, probs, src_off, logit_off,
+                       nn, mask, count, loss_row, P, total_src, r_n, scale, write_grad);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+int dreg_reg_losses_final(const float* partial, const float* loss_row, const float* count, const int* probs, const int* src_off, float* out,
+                          int P, int L, float eps, float w_overlap, float w_cont, float w_feat, float w_corr, void* stream)
+{
+    if (P <= 0) return DREG_OK;
+    hipLaunchKernelGGL(reg_losses_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, loss_row, count, probs, src_off, out, P, L, eps,
+                       w_overlap, w_cont, w_feat, w_corr);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+}  // extern "C"

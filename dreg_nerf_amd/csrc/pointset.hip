@@ -174,13 +174,39 @@ __device__ void jacobi_eig3(double A[3][3], double V[3][3])
             }
     }
 }
+// row accessors of one Kabsch problem: dense [N,3] arrays, or the (src | tgt) rows of a pair inside the shared row space
+struct KabschDense {
+    const float* A; const float* Bp; const float* Wp;
+    __device__ __forceinline__ float a(int i, int c) const { return A[i * 3 + c]; }
+    __device__ __forceinline__ float b(int i, int c) const { return Bp[i * 3 + c]; }
+    __device__ __forceinline__ float w(int i) const { return Wp[i]; }
+};
+struct KabschPair {   // a = cat[src_xyz, tgt_corr], b = cat[src_corr, tgt_xyz], w = cat[src_ov, tgt_ov]  (nerf_regtr.py:226-236)
+    const float* xyz; const float* corr; const float* ov; int s0, ns, t0;
+    __device__ __forceinline__ float a(int i, int c) const { return i < ns ? xyz[(size_t)(s0 + i) * 3 + c] : corr[(size_t)(t0 + i - ns) * 3 + c]; }
+    __device__ __forceinline__ float b(int i, int c) const { return i < ns ? corr[(size_t)(s0 + i) * 3 + c] : xyz[(size_t)(t0 + i - ns) * 3 + c]; }
+    __device__ __forceinline__ float w(int i) const { return i < ns ? ov[s0 + i] : ov[t0 + i - ns]; }
+};
+template <typename Acc> __device__ void kabsch_body(const Acc& X, int N, float* __restrict__ o, float eps);
 __global__ __launch_bounds__(256) void kabsch_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ w,
                                                      float* __restrict__ out, int N, float eps)
 {
-    const int p = blockIdx.x, t = threadIdx.x;
-    const float* A = a + (size_t)p * N * 3;
-    const float* Bp = b + (size_t)p * N * 3;
-    const float* W = w + (size_t)p * N;
+    const int p = blockIdx.x;
+    KabschDense X{a + (size_t)p * N * 3, b + (size_t)p * N * 3, w + (size_t)p * N};
+    kabsch_body(X, N, out + (size_t)p * 12, eps);
+}
+// one block per (pair, layer): probs int32 [P][4] = (s0, ns, t0, nt) rows of the shared row space; corr [L,R,3], ov [L,R]
+__global__ __launch_bounds__(256) void kabsch_pairs_kernel(const float* __restrict__ xyz, const float* __restrict__ corr, const float* __restrict__ ov,
+                                                           const int* __restrict__ probs, float* __restrict__ out, int L, int R, float eps)
+{
+    const int p = blockIdx.x / L, l = blockIdx.x % L;
+    const int* pr = probs + p * 4;
+    KabschPair X{xyz, corr + (size_t)l * R * 3, ov + (size_t)l * R, pr[0], pr[1], pr[2]};
+    kabsch_body(X, pr[1] + pr[3], out + (size_t)blockIdx.x * 12, eps);
+}
+template <typename Acc> __device__ void kabsch_body(const Acc& X, int N, float* __restrict__ o, float eps)
+{
+    const int t = threadIdx.x;
     __shared__ double red[256];
     __shared__ double acc[16];
     auto block_sum = [&](double v) -> double {
@@ -189,19 +215,19 @@ __global__ __launch_bounds__(256) void kabsch_kernel(const float* __restrict__ a
         const double r = red[0]; __syncthreads(); return r;
     };
     double sw = 0.0;
-    for (int i = t; i < N; i += 256) sw += W[i];
+    for (int i = t; i < N; i += 256) sw += X.w(i);
     sw = block_sum(sw);
     const double norm = fmax(sw, (double)eps);
     double ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
     for (int i = t; i < N; i += 256) {
-        const double wn = W[i] / norm;
-        for (int c = 0; c < 3; ++c) { ca[c] += wn * A[i * 3 + c]; cb[c] += wn * Bp[i * 3 + c]; }
+        const double wn = X.w(i) / norm;
+        for (int c = 0; c < 3; ++c) { ca[c] += wn * X.a(i, c); cb[c] += wn * X.b(i, c); }
     }
     for (int c = 0; c < 3; ++c) { ca[c] = block_sum(ca[c]); cb[c] = block_sum(cb[c]); }
     double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     for (int i = t; i < N; i += 256) {
-        const double wn = W[i] / norm;
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r][c] += (A[i * 3 + r] - ca[r]) * (Bp[i * 3 + c] - cb[c]) * wn;
+        const double wn = X.w(i) / norm;
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r][c] += (X.a(i, r) - ca[r]) * (X.b(i, c) - cb[c]) * wn;
     }
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r][c] = block_sum(H[r][c]);
     if (t == 0) {
@@ -227,7 +253,6 @@ __global__ __launch_bounds__(256) void kabsch_kernel(const float* __restrict__ a
         // which is exactly the reference's "flip the last column of V when det(V U^T) < 0" rule (se3.py:128-134).
         double R[3][3];
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i][j] = Vs[i][0] * U[j][0] + Vs[i][1] * U[j][1] + v2[i] * u2[j];
-        float* o = out + (size_t)p * 12;
         for (int i = 0; i < 3; ++i) {
             double tr = cb[i];
             for (int j = 0; j < 3; ++j) { o[i * 4 + j] = (float)R[i][j]; tr -= R[i][j] * ca[j]; }
@@ -449,6 +474,18 @@ int dreg_weighted_kabsch(const float* a, const float* b, const float* w, float* 
 {
     if (P == 0) return DREG_OK;
     hipLaunchKernelGGL(kabsch_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, a, b, w, out, N, eps);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// The same solve for every (pair, decoder layer) of a step in one launch, reading the shared row space directly:
+// a = cat[src_xyz, tgt_corr], b = cat[src_corr, tgt_xyz], w = cat[src_ov, tgt_ov] (nerf_regtr.py:226-236) without the copies.
+// xyz [R,3], corr [L,R,3], ov [L,R], probs int32 [P][4] = (s0, ns, t0, nt); out [P,L,3,4].
+int dreg_weighted_kabsch_pairs(const float* xyz, const float* corr, const float* ov, const int* probs, float* out, int P, int L, int R,
+                               float eps, void* stream)
+{
+    if (P == 0 || L == 0) return DREG_OK;
+    hipLaunchKernelGGL(kabsch_pairs_kernel, dim3(P * L), dim3(256), 0, (hipStream_t)stream, xyz, corr, ov, probs, out, L, R, eps);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

@@ -97,6 +97,12 @@ SIGNATURES = {
     "dreg_overlap_bwd": (I, [P] * 8 + [I, P]),
     "dreg_relu_bwd": (I, [P, P, P, Z, I, I, I, P]),
     "dreg_weighted_kabsch": (I, [P, P, P, P, I, I, F, P]),
+    "dreg_weighted_kabsch_pairs": (I, [P, P, P, P, P, I, I, I, F, P]),
+    # losses.hip
+    "dreg_reg_point_losses": (I, [P] * 10 + [I, I, I, I, F, F, F, P]),
+    "dreg_infonce_nn": (I, [P] * 7 + [I, I, F, P]),
+    "dreg_infonce_rows": (I, [P] * 10 + [I, I, F, F, I, P]),
+    "dreg_reg_losses_final": (I, [P] * 6 + [I, I, F, F, F, F, F, P]),
     "dreg_voxel_downsample_workspace_bytes": (Z, [I]),
     "dreg_voxel_downsample_fwd": (I, [P] * 11 + [Z, I, I, I, F, P]),
     "dreg_voxel_downsample_bwd": (I, [P, P, P, P, I, I, P]),

@@ -297,16 +297,15 @@ class NeRFRegTr(nn.Module):
         xyz_all = torch.cat(pts_l) if len(pts_l) > 1 else pts_l[0]
         cond, corr, ov = T.encode_decode_batched(P, torch.cat(feat_l) if len(feat_l) > 1 else feat_l[0], xyz_all, tab)
         outs = []
-        for (s0, ns, t0, nt) in tab.segs:
+        poses = A.weighted_kabsch_pairs(xyz_all, corr, ov, tab)   # [P,6,3,4]: every (pair, layer) solve in one launch
+        # the batched view of the same results (row space of all pairs) for the fused training losses
+        self.last_batched = {"cond": cond, "corr": corr, "ov": ov, "xyz": xyz_all, "tab": tab}
+        for pi, (s0, ns, t0, nt) in enumerate(tab.segs):
             s_xyz, t_xyz = xyz_all[s0:s0 + ns], xyz_all[t0:t0 + nt]
             s_c, t_c = cond[:, s0:s0 + ns], cond[:, t0:t0 + nt]
             s_corr, t_corr = corr[:, s0:s0 + ns], corr[:, t0:t0 + nt]
             s_ov, t_ov = ov[:, s0:s0 + ns], ov[:, t0:t0 + nt]
-            nl = s_c.shape[0]
-            a = torch.cat([s_xyz.expand(nl, -1, -1), t_corr], dim=1)
-            b = torch.cat([s_corr, t_xyz.expand(nl, -1, -1)], dim=1)
-            w = torch.cat([s_ov[..., 0], t_ov[..., 0]], dim=1)
-            pose = T.weighted_kabsch(a.detach(), b.detach(), w.detach())[:, None]
+            pose = poses[pi][:, None]
             outs.append({
                 "src_feats": [s_c], "tgt_feats": [t_c],
                 "src_kp": [s_xyz], "src_kp_warped": [s_corr],

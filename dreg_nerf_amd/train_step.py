@@ -13,6 +13,7 @@ from typing import Callable, List, Optional
 import torch
 import torch.distributed as dist
 
+from . import fused_losses as FL
 from . import losses as LS
 from . import synth
 from .optim import FlatAdamW, StepLR
@@ -45,7 +46,7 @@ def _default_labels(pred):
 class TrainStep:
     def __init__(self, model, lr: float = 1e-4, weight_decay: float = 1e-4, grad_clip: float = 0.1,
                  robust_loss: bool = False, step_lr: int = 34000, gamma: float = 0.5, finetune: bool = False,
-                 label_fn: Optional[Callable] = None):
+                 label_fn: Optional[Callable] = None, fused_losses: bool = True):
         self.model = model
         dev = next(model.parameters()).device
         self.feature_loss = LS.InfoNCELoss(256, 0.2, 0.4).to(dev)
@@ -56,6 +57,7 @@ class TrainStep:
         self.robust = robust_loss
         self.finetune = finetune
         self.label_fn = label_fn or _default_labels
+        self.fused_losses = fused_losses
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.last_losses = None
         self.last_preds = None
@@ -65,18 +67,39 @@ class TrainStep:
         if self.feature_loss.W.grad is not None:
             self.feature_loss.W.grad = None
         preds = self.model.forward_batch(batch)
-        total = 0.0
-        agg = {}
-        for d, pred in zip(batch, preds):
-            if d.get("src_nerf_path") and os.path.exists(d["src_nerf_path"]) and os.path.exists(d.get("tgt_nerf_path", "")):
-                s_gt, t_gt, s_tl, t_tl = nerf_labels(pred, d)
+        if self.fused_losses:
+            # all pairs at once through csrc/losses.hip: labels in the shared row space [6,R], one autograd node
+            bt = self.model.last_batched
+            have_nerf = [bool(d.get("src_nerf_path")) and os.path.exists(d["src_nerf_path"]) and os.path.exists(d.get("tgt_nerf_path", ""))
+                         for d in batch]
+            if not any(have_nerf) and self.label_fn is _default_labels:
+                with torch.no_grad():
+                    gt = synth.synthetic_overlap_gt(bt["xyz"])[..., 0]
+                    tilde = (bt["corr"][..., 0] + 0.31 * bt["corr"][..., 1] - 0.17 * bt["corr"][..., 2] > 0.0123).float()
             else:
-                s_gt, t_gt, s_tl, t_tl = self.label_fn(pred)
-            ls = LS.training_losses(pred, d["pose"], self.feature_loss, s_gt, t_gt, s_tl, t_tl, self.robust)
-            total = total + ls["total"]
-            for k, v in ls.items():
-                agg[k] = agg.get(k, 0.0) + v.detach()
-        total = total / len(batch)
+                gts, tls = [], []
+                for d, pred, hn in zip(batch, preds, have_nerf):
+                    s_gt, t_gt, s_tl, t_tl = nerf_labels(pred, d) if hn else self.label_fn(pred)
+                    gts += [s_gt[..., 0], t_gt[..., 0]]
+                    tls += [s_tl[..., 0], t_tl[..., 0]]
+                gt, tilde = torch.cat(gts, dim=1), torch.cat(tls, dim=1)
+            poses = torch.cat([d["pose"].reshape(1, 4, 4) for d in batch]).float()
+            ls = FL.regtr_losses(bt, poses, self.feature_loss, gt, tilde, self.robust)
+            total = ls["total"]
+            agg = {k: v.detach() * len(batch) for k, v in ls.items()}
+        else:
+            total = 0.0
+            agg = {}
+            for d, pred in zip(batch, preds):
+                if d.get("src_nerf_path") and os.path.exists(d["src_nerf_path"]) and os.path.exists(d.get("tgt_nerf_path", "")):
+                    s_gt, t_gt, s_tl, t_tl = nerf_labels(pred, d)
+                else:
+                    s_gt, t_gt, s_tl, t_tl = self.label_fn(pred)
+                ls = LS.training_losses(pred, d["pose"], self.feature_loss, s_gt, t_gt, s_tl, t_tl, self.robust)
+                total = total + ls["total"]
+                for k, v in ls.items():
+                    agg[k] = agg.get(k, 0.0) + v.detach()
+            total = total / len(batch)
         total.backward()
         if self.world > 1:
             self.optimizer.all_reduce_mean(self.world)

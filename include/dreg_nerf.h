@@ -232,6 +232,27 @@ int dreg_relu_bwd(const void* y, const void* g, void* out, size_t n, int y_dtype
 
 /* compute_rigid_transform (se3.py:89-140): a,b fp32 [P,N,3], w fp32 [P,N] -> out fp32 [P,3,4]; 3x3 SVD on device. */
 int dreg_weighted_kabsch(const float* a, const float* b, const float* w, float* out, int P, int N, float eps, void* stream);
+/* every (pair, decoder layer) of a step in one launch, reading the shared row space (nerf_regtr.py:226-236 without the cats):
+ * xyz [R,3], corr [L,R,3], ov [L,R], probs int32 [P][4] = (s0, ns, t0, nt) -> out [P,L,3,4] */
+int dreg_weighted_kabsch_pairs(const float* xyz, const float* corr, const float* ov, const int* probs, float* out, int P, int L,
+                               int R, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- training losses
+ * train_nerf_regtr.py:186-229 for all P pairs of a step (rows = every pair's (src | tgt) key points, probs as above):
+ * overlap BCE (input = labels, target = prediction: the reference's argument order), label smooth-L1, correspondence L1
+ * (conerf/loss/correspondence_loss.py:16-51, incl. its [nl,N,1] x [N] broadcast) and InfoNCE (conerf/loss/feature_loss.py:
+ * 24-73) on precomputed fp32 logits.  d_ov / d_corr / the in-place logits gradient are those of the mean-over-pairs total. */
+int dreg_reg_point_losses(const float* gt, const float* tilde, const float* ov, const float* corr, const float* xyz,
+                          const float* pose, const int* probs, float* partial, float* d_ov, float* d_corr, int L, int R, int P,
+                          int robust, float eps, float w_overlap, float w_corr, void* stream);
+int dreg_infonce_nn(const float* xyz, const float* pose, const int* probs, const int* src_off, int* nn, float* mask,
+                    float* count, int P, int total_src, float r_p, void* stream);
+int dreg_infonce_rows(float* logits, const float* xyz, const float* pose, const int* probs, const int* src_off,
+                      const long long* logit_off, const int* nn, const float* mask, const float* count, float* loss_row, int P,
+                      int total_src, float r_n, float scale, int write_grad, void* stream);
+int dreg_reg_losses_final(const float* partial, const float* loss_row, const float* count, const int* probs, const int* src_off,
+                          float* out, int P, int L, float eps, float w_overlap, float w_cont, float w_feat, float w_corr,
+                          void* stream);
 
 /* batched_grid_subsample (grid_downsample.py:6-44; MinkowskiEngine UNWEIGHTED_AVERAGE): mean of (xyz | feat) over rows
  * sharing (batch, floor(p/dl)); rows out ordered by (batch, ix, iy, iz).  Outputs sized for N rows; n_out / batch_counts

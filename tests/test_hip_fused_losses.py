@@ -1,0 +1,85 @@
+"""GPU: the fused all-pairs loss node (csrc/losses.hip) against the per-pair torch formulation of dreg_nerf_amd/losses.py (which
+tests/test_oracle_golden.py pins to the reference through the oracle): values and input gradients; the batched Kabsch against
+the per-pair kernel."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from dreg_nerf_amd import attn_ops as A, fused_losses as FL, losses as LS, synth  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _case(seed, segs, robust):
+    g = torch.Generator().manual_seed(seed)
+    R = sum(a + b for a, b in segs)
+    tab = A.ProblemTable(segs, torch.device(DEV))
+    xyz = (torch.rand(R, 3, generator=g) - 0.5) * 1.6
+    cond = torch.randn(6, R, 256, generator=g) * 0.3
+    corr = xyz[None] + 0.1 * torch.randn(6, R, 3, generator=g)
+    ov = torch.sigmoid(torch.randn(6, R, 1, generator=g))
+    gt = (torch.rand(R, generator=g) > 0.4).float()[None].expand(6, -1).contiguous()
+    tilde = (torch.rand(6, R, generator=g) > 0.5).float()
+    poses = []
+    for p in range(len(segs)):
+        q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+        if torch.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        T = torch.eye(4)
+        T[:3, :3] = 0.1 * q + 0.9 * torch.eye(3)   # not orthonormal on purpose: the losses only apply the 3x4 map (and R^T for the inverse)
+        T[:3, :3] = q
+        T[:3, 3] = 0.05 * torch.randn(3, generator=g)
+        poses.append(T)
+    return tab, xyz, cond, corr, ov, gt, tilde, torch.stack(poses)
+
+
+@pytest.mark.parametrize("robust", [False, True])
+def test_fused_losses_match_per_pair_torch(robust):
+    segs = [(310, 277), (150, 401)]
+    tab, xyz, cond, corr, ov, gt, tilde, poses = _case(3, segs, robust)
+    fl = LS.InfoNCELoss(256, 0.2, 0.4)
+    torch.manual_seed(0)
+    torch.nn.init.normal_(fl.W, std=0.1)
+    # reference: per pair on the CPU in fp32
+    c_r, k_r, o_r = cond.clone().requires_grad_(True), corr.clone().requires_grad_(True), ov.clone().requires_grad_(True)
+    tot, per = 0.0, {k: 0.0 for k in FL.NAMES}
+    for p, (s0, ns, t0, nt) in enumerate(tab.segs):
+        pred = {"src_feats": [c_r[:, s0:s0 + ns]], "tgt_feats": [c_r[:, t0:t0 + nt]], "src_kp": [xyz[s0:s0 + ns]], "tgt_kp": [xyz[t0:t0 + nt]],
+                "src_kp_warped": [k_r[:, s0:s0 + ns]], "tgt_kp_warped": [k_r[:, t0:t0 + nt]],
+                "src_overlap": [o_r[:, s0:s0 + ns]], "tgt_overlap": [o_r[:, t0:t0 + nt]]}
+        ls = LS.training_losses(pred, poses[p][None], fl, gt[:, s0:s0 + ns, None], gt[:, t0:t0 + nt, None],
+                                tilde[:, s0:s0 + ns, None], tilde[:, t0:t0 + nt, None], robust)
+        tot = tot + ls["total"]
+        for k in FL.NAMES:
+            per[k] += float(ls[k])
+    tot = tot / len(segs)
+    tot.backward()
+    # fused
+    fd = LS.InfoNCELoss(256, 0.2, 0.4).to(DEV)
+    with torch.no_grad():
+        fd.W.copy_(fl.W)
+    c_d, k_d, o_d = (t.to(DEV).requires_grad_(True) for t in (cond, corr, ov))
+    bt = {"cond": c_d, "corr": k_d, "ov": o_d, "xyz": xyz.to(DEV), "tab": tab}
+    out = FL.regtr_losses(bt, poses.to(DEV), fd, gt.to(DEV), tilde.to(DEV), robust)
+    out["total"].backward()
+    for k in FL.NAMES:
+        assert abs(float(out[k]) - per[k] / len(segs)) <= 2e-5 * max(1.0, abs(per[k])), (k, float(out[k]), per[k] / len(segs))
+    np.testing.assert_allclose(o_d.grad.cpu().numpy(), o_r.grad.numpy(), atol=1e-7)
+    np.testing.assert_allclose(k_d.grad.cpu().numpy(), k_r.grad.numpy(), rtol=2e-6, atol=1e-7)
+    gc, gr = c_d.grad.cpu(), c_r.grad
+    assert float((gc - gr).abs().max()) <= 2e-5 * float(gr.abs().max()) + 1e-9
+
+
+def test_kabsch_pairs_equals_per_pair_kernel():
+    segs = [(310, 277), (150, 401), (64, 64)]
+    tab, xyz, cond, corr, ov, gt, tilde, poses = _case(5, segs, False)
+    xyz_d, corr_d, ov_d = xyz.to(DEV), corr.to(DEV), ov.to(DEV)
+    got = A.weighted_kabsch_pairs(xyz_d, corr_d, ov_d, tab)
+    for p, (s0, ns, t0, nt) in enumerate(tab.segs):
+        a = torch.cat([xyz_d[s0:s0 + ns].expand(6, -1, -1), corr_d[:, t0:t0 + nt]], dim=1)
+        b = torch.cat([corr_d[:, s0:s0 + ns], xyz_d[t0:t0 + nt].expand(6, -1, -1)], dim=1)
+        w = torch.cat([ov_d[:, s0:s0 + ns, 0], ov_d[:, t0:t0 + nt, 0]], dim=1)
+        ref = A.weighted_kabsch(a, b, w)
+        assert torch.equal(got[p], ref)
