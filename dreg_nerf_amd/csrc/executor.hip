@@ -392,7 +392,8 @@ int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pac
                 else if (hipMemcpyAsync(A + e->off_tmp, gy, (size_t)x.B * V * x.C * 2, hipMemcpyDeviceToDevice, st) != hipSuccess) return DREG_ELAUNCH;
                 CK(commit(o.in2));
             } else {
-                CK(dreg_bn3d_bwd(act(o.in), gy, act(o.out), (float*)(A + o.aux0), (float*)(A + o.aux1), dx, dres, e->prm[o.w].grad, e->prm[o.b].grad,
+                // without a residual the ReLU mask is recomputed from x: y is not read
+                CK(dreg_bn3d_bwd(act(o.in), gy, o.in2 >= 0 ? act(o.out) : nullptr, (float*)(A + o.aux0), (float*)(A + o.aux1), dx, dres, e->prm[o.w].grad, e->prm[o.b].grad,
                                  (float*)(A + e->off_coef), (float*)(A + e->off_bn_ws), x.B, V, x.C, o.relu, 1, 0, stream));
                 if (res_g && dres == (void*)(A + e->off_tmp)) { CK(commit(o.in2)); CK(commit(o.in)); }
                 else { CK(commit(o.in)); if (res_g) CK(commit(o.in2)); }

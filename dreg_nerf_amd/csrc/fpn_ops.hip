@@ -42,7 +42,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y, const float* __restrict__ mean_rstd,
-    float* __restrict__ partial, int V, int C, int rows_per_chunk, int relu)
+    float* __restrict__ partial, int V, int C, int rows_per_chunk, int relu, const float* __restrict__ scale_shift = nullptr)
 {
     constexpr int G = Gran<T>::G;
     const int CG = C / G;
@@ -60,6 +60,13 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(
 #pragma unroll
         for (int i = 0; i < G; ++i) { mu[i] = mean_rstd[((size_t)b * C + cg * G + i) * 2]; rs[i] = mean_rstd[((size_t)b * C + cg * G + i) * 2 + 1]; }
     }
+    // ReLU mask without reading y (y == nullptr; BatchNorms without a residual): y > 0  <=>  x*scale + shift > 0
+    float sc[G], sh[G];
+    const bool remask = MODE == 1 && relu && y == nullptr;
+    if (remask) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) { sc[i] = scale_shift[((size_t)b * C + cg * G + i) * 2]; sh[i] = scale_shift[((size_t)b * C + cg * G + i) * 2 + 1]; }
+    }
     if (r0 < rpi) {
         for (int v = v0 + r0; v < v1; v += rpi) {
             const size_t off = ((size_t)b * V + v) * C + (size_t)cg * G;
@@ -71,7 +78,10 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(
             } else {
                 float gv[G], yv[G];
                 Gran<T>::ld(dy + off, gv);
-                if (relu) { Gran<T>::ld(y + off, yv);
+                if (remask) {
+#pragma unroll
+                    for (int i = 0; i < G; ++i) gv[i] = (xv[i] * sc[i] + sh[i]) > 0.f ? gv[i] : 0.f;
+                } else if (relu) { Gran<T>::ld(y + off, yv);
 #pragma unroll
                     for (int i = 0; i < G; ++i) gv[i] = yv[i] > 0.f ? gv[i] : 0.f; }
 #pragma unroll
@@ -207,11 +217,14 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
         float xv[G], gv[G], yv[G];
         Gran<T>::ld(x + i * G, xv);
         Gran<T>::ld(dy + i * G, gv);
-        if (relu) { Gran<T>::ld(y + i * G, yv);
+        const size_t pc = ((size_t)b * C + (size_t)cg * G) * 2;
+        if (relu && y == nullptr) {
+#pragma unroll
+            for (int k = 0; k < G; ++k) gv[k] = (xv[k] * scale_shift[pc + 2 * k] + scale_shift[pc + 2 * k + 1]) > 0.f ? gv[k] : 0.f;
+        } else if (relu) { Gran<T>::ld(y + i * G, yv);
 #pragma unroll
             for (int k = 0; k < G; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f; }
         if (dres) Gran<T>::st(dres + i * G, gv);
-        const size_t pc = ((size_t)b * C + (size_t)cg * G) * 2;
 #pragma unroll
         for (int k = 0; k < G; ++k) {
             const float xh = (xv[k] - mean_rstd[pc + 2 * k]) * mean_rstd[pc + 2 * k + 1];
@@ -573,6 +586,37 @@ __global__ void add_inplace_kernel(T* __restrict__ dst, const T* __restrict__ sr
         Gran<T>::st(dst + i * G, a);
     }
 }
+// ------------------------------------------------------------------------------------------------ input staging
+// grids: B device pointers to fp32 [7, Z, X, Y] voxel grids (xyz | rgb | alpha, the reference's voxel_grid.pt layout).
+// out [B, Z, X, Y, 8] (T): channels 0..3 = rgba (grid channels 3..6), 4..7 = 0  — the NDHWC input of the stem convolution
+// (nerf_regtr.py:131-135 feeds grid[:, 3:]).
+template <typename T>
+__global__ void pack_rgba_kernel(const float* const* __restrict__ grids, T* __restrict__ out, size_t V, int B)
+{
+    const size_t total = V * B;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / V);
+        const size_t v = i - (size_t)b * V;
+        const float* g = grids[b] + 3 * V + v;
+        float c[8] = {g[0], g[V], g[2 * V], g[3 * V], 0.f, 0.f, 0.f, 0.f};
+        if constexpr (sizeof(T) == 2) Gran<bf16_t>::st(reinterpret_cast<bf16_t*>(out) + i * 8, c);
+        else { float lo[4] = {c[0], c[1], c[2], c[3]}, hi[4] = {0.f, 0.f, 0.f, 0.f}; Gran<float>::st(reinterpret_cast<float*>(out) + i * 8, lo); Gran<float>::st(reinterpret_cast<float*>(out) + i * 8 + 4, hi); }
+    }
+}
+// xyz[n, c] = grids[pt_batch[n]][c, z, x, y] with (x, y, z) decoded from idx[n] = (x*Yr + y)*Zr + z  (nerf_regtr.py:144-147:
+// grid[:3].permute(X, Y, Z)[mask])
+__global__ void gather_xyz_kernel(const float* const* __restrict__ grids, const int64_t* __restrict__ idx, const int* __restrict__ pt_batch,
+                                  float* __restrict__ xyz, int N, int Zr, int Xr, int Yr)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int64_t f = idx[n];
+    const int z = (int)(f % Zr), y = (int)((f / Zr) % Yr), x = (int)(f / ((int64_t)Zr * Yr));
+    const size_t V = (size_t)Zr * Xr * Yr, o = ((size_t)z * Xr + x) * Yr + y;
+    const float* g = grids[pt_batch[n]];
+    xyz[(size_t)n * 3] = g[o]; xyz[(size_t)n * 3 + 1] = g[V + o]; xyz[(size_t)n * 3 + 2] = g[2 * V + o];
+}
+
 // fp32 <-> T conversions (contiguous)
 template <typename T>
 __global__ void cast_from_f32_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {
@@ -620,6 +664,8 @@ int dreg_bn3d_fwd(const void* x, const void* res, void* y, const float* gamma, c
 }
 
 // Backward of y = [relu](bn(x) [+ res]) in training mode.  dres may be null.  coef: fp32 [B,C,2] scratch.
+// y may be null when the forward had NO residual: the ReLU mask is then recomputed from x (x*scale + shift > 0), one tensor
+// read less in both passes.
 int dreg_bn3d_bwd(const void* x, const void* dy, const void* y, const float* scale_shift, const float* mean_rstd,
                   void* dx, void* dres, float* dgamma, float* dbeta, float* coef, float* workspace,
                   int B, int V, int C, int relu, int accumulate, int dtype, void* stream)
@@ -630,8 +676,8 @@ int dreg_bn3d_bwd(const void* x, const void* dy, const void* y, const float* sca
     const int rpc = bn_rows_per_chunk(V), nch = (V + rpc - 1) / rpc;
     const int CG = C / G, slabs = (CG + 255) / 256;
     dim3 grid(nch, B, slabs);
-    if (dtype == 0) hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean_rstd, workspace, V, C, rpc, relu);
-    else hipLaunchKernelGGL((bn_partial_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y, mean_rstd, workspace, V, C, rpc, relu);
+    if (dtype == 0) hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean_rstd, workspace, V, C, rpc, relu, scale_shift);
+    else hipLaunchKernelGGL((bn_partial_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y, mean_rstd, workspace, V, C, rpc, relu, scale_shift);
     DREG_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, coef, dgamma, dbeta, B, nch, C, V, accumulate);
     DREG_LAUNCH_CHECK();
@@ -745,6 +791,24 @@ int dreg_cast_from_f32(const float* in, void* out, size_t n, int dtype, void* st
     return DREG_OK;
 }
 
+// grids: DEVICE array of B pointers to fp32 [7,Z,X,Y] grids -> out [B,Z,X,Y,8] (dtype): rgba + 4 zero channels
+int dreg_pack_rgba_grids(const void* grids, void* out, int B, int Z, int X, int Y, int dtype, void* stream)
+{
+    const size_t V = (size_t)Z * X * Y;
+    if (B <= 0 || V == 0) return DREG_OK;
+    if (dtype == 0) hipLaunchKernelGGL(pack_rgba_kernel<bf16_t>, dim3(nblocks(V * B)), dim3(256), 0, (hipStream_t)stream, (const float* const*)grids, (bf16_t*)out, V, B);
+    else hipLaunchKernelGGL(pack_rgba_kernel<float>, dim3(nblocks(V * B)), dim3(256), 0, (hipStream_t)stream, (const float* const*)grids, (float*)out, V, B);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// xyz fp32 [N,3] of the occupied voxels: idx int64 [N] flat (x*Yr + y)*Zr + z, pt_batch int32 [N] grid ids
+int dreg_gather_grid_xyz(const void* grids, const int64_t* idx, const int* pt_batch, float* xyz, int N, int Zr, int Xr, int Yr, void* stream)
+{
+    if (N <= 0) return DREG_OK;
+    hipLaunchKernelGGL(gather_xyz_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float* const*)grids, idx, pt_batch, xyz, N, Zr, Xr, Yr);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
 // dst += src, n elements (n % 8 == 0 for bf16, % 4 for fp32)
 int dreg_add_inplace(void* dst, const void* src, size_t n, int dtype, void* stream)
 {

@@ -511,7 +511,7 @@ class BatchNormFn(torch.autograd.Function):
         dres = torch.empty_like(x) if has_res else None
         dg = torch.empty(C, dtype=torch.float32, device=x.device)
         db = torch.empty(C, dtype=torch.float32, device=x.device)
-        L.check(lib.dreg_bn3d_bwd(L.ptr(x), L.ptr(gy), L.ptr(y), L.ptr(ss), L.ptr(mr), L.ptr(dx), L.ptr(dres),
+        L.check(lib.dreg_bn3d_bwd(L.ptr(x), L.ptr(gy), L.ptr(y) if has_res else None, L.ptr(ss), L.ptr(mr), L.ptr(dx), L.ptr(dres),
                                   L.ptr(dg), L.ptr(db), L.ptr(coef), L.ptr(ws), B, V, C, int(relu), 0, dt, L.stream()),
                 "dreg_bn3d_bwd")
         return dx, dg, db, None, None, dres, None, None, None, None

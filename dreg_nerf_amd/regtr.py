@@ -219,8 +219,21 @@ class NeRFRegTr(nn.Module):
                 ex.set_timing(False)
 
     @staticmethod
-    def pack_grids(grids: List[torch.Tensor], dtype) -> torch.Tensor:
+    def _grid_table(grids: List[torch.Tensor]):
+        """Device pointer table of the (contiguous fp32 [1,7,Z,X,Y]) grids for the staging kernels, or None."""
+        if not all(g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.shape[-4] == 7 for g in grids):
+            return None
+        return L.to_device_async([g.data_ptr() for g in grids], torch.int64, grids[0].device)
+
+    @staticmethod
+    def pack_grids(grids: List[torch.Tensor], dtype, table=None) -> torch.Tensor:
         """List of [1,7,Z,X,Y] fp32 grids -> NDHWC [B,Z,X,Y,8]: rgba (channels 3:7) + 4 zero pad channels."""
+        table = table if table is not None else NeRFRegTr._grid_table(grids)
+        if table is not None:
+            Z, X, Y = grids[0].shape[-3:]
+            out = torch.empty(len(grids), Z, X, Y, 8, dtype=dtype, device=grids[0].device)
+            L.check(L.load().dreg_pack_rgba_grids(L.ptr(table), L.ptr(out), len(grids), Z, X, Y, L.dt_of(out), L.stream()), "dreg_pack_rgba_grids")
+            return out
         rgba = torch.cat([g[:, 3:] for g in grids], dim=0).permute(0, 2, 3, 4, 1)
         return F.pad(rgba, (0, 4)).to(dtype).contiguous()
 
@@ -229,7 +242,7 @@ class NeRFRegTr(nn.Module):
         """Everything whose size depends on the data — point coordinates, the active sets of the FPN head, the A4 voxel rounds
         (their stopping rule is per pair) — needs only the occupied voxels' coordinates, not the feature network.  All host
         syncs of a step happen here."""
-        grids, idxs, pbatch, xyzs = [], [], [], []
+        grids, idxs = [], []
         for i, d in enumerate(batch):
             for j, side in enumerate(("src", "tgt")):
                 g = d[side + "_xyz_rgba"]
@@ -240,21 +253,32 @@ class NeRFRegTr(nn.Module):
                     m = m.squeeze(0)
                 grids.append(g)
                 idxs.append(m)
-                pbatch.append(torch.full((m.shape[0],), 2 * i + j, dtype=torch.int32, device=dev))
-                xyzs.append(g[:, :3].permute(0, 3, 4, 2, 1).reshape(-1, 3)[m])
         res = tuple(grids[0].shape[-3:])
-        idx_cat, pb_cat = torch.cat(idxs).contiguous(), torch.cat(pbatch)
+        counts = [int(m.shape[0]) for m in idxs]
+        idx_cat = torch.cat(idxs).contiguous()
+        pb_cat = torch.repeat_interleave(torch.arange(len(idxs), dtype=torch.int32, device=dev), L.to_device_async(counts, torch.int64, dev),
+                                         output_size=sum(counts))
+        table = self._grid_table(grids)
+        if table is not None:   # one gather launch for all grids
+            xyz_cat = torch.empty(idx_cat.shape[0], 3, dtype=torch.float32, device=dev)
+            L.check(L.load().dreg_gather_grid_xyz(L.ptr(table), L.ptr(idx_cat), L.ptr(pb_cat), L.ptr(xyz_cat), idx_cat.shape[0], *res, L.stream()),
+                    "dreg_gather_grid_xyz")
+        else:
+            xyz_cat = torch.cat([g[:, :3].permute(0, 3, 4, 2, 1).reshape(-1, 3)[m] for g, m in zip(grids, idxs)])
+        offs = [0]
+        for c in counts:
+            offs.append(offs[-1] + c)
         rows = None
         if self.active_set and self.precision == "bf16":
             rows = ops.active_sets(idxs, res, tuple((r + 1) // 2 for r in res), dev, pt_batch=pb_cat, idx_cat=idx_cat)
         plans, pts_l, segs = [], [], []
         for i in range(len(batch)):
             ns, nt = idxs[2 * i].shape[0], idxs[2 * i + 1].shape[0]
-            rounds, pts, lens = T.plan_hierarchical_subsample(torch.cat([xyzs[2 * i], xyzs[2 * i + 1]]), [ns, nt], self.num_downsample)
+            rounds, pts, lens = T.plan_hierarchical_subsample(xyz_cat[offs[2 * i]:offs[2 * i + 2]], [ns, nt], self.num_downsample)
             plans.append(rounds)
             pts_l.append(pts)
             segs.append((int(lens[0]), int(lens[1])))
-        return grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs
+        return grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs, table
 
     def forward_batch(self, batch: List[dict]) -> List[dict]:
         """Each element: the reference's ``data`` dict for one pair.  Returns one output dict per pair.
@@ -274,17 +298,17 @@ class NeRFRegTr(nn.Module):
             with torch.cuda.stream(side):
                 geo = self._geometry(batch, dev)
             main.wait_stream(side)
-            grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs = geo
+            grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs, table = geo
             # these were allocated on the side stream and are consumed on the main one
-            keep = [idx_cat, pb_cat] + list(pts_l) + ([rows[0], rows[3]] if rows is not None else [])
+            keep = [idx_cat, pb_cat] + list(pts_l) + ([rows[0], rows[3]] if rows is not None else []) + ([table] if table is not None else [])
             for rounds in plans:
                 for rnd in rounds:
                     keep += [rnd.order, rnd.starts, rnd.n_out_dev, rnd.inv_seg, rnd.inv_cnt]
             for t in keep:
                 t.record_stream(main)
         else:
-            grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs = self._geometry(batch, dev)
-        p1 = self.fpn(self.pack_grids(grids, self.act_dtype), rows)
+            grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs, table = self._geometry(batch, dev)
+        p1 = self.fpn(self.pack_grids(grids, self.act_dtype, table), rows)
         feats = ops.trilinear_gather(p1, idx_cat, pb_cat, res, *((rows[0], rows[3]) if rows is not None else ()))
         P = self._P()
         off = 0

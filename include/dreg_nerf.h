@@ -108,6 +108,7 @@ int dreg_bn_num_chunks(int V);
 int dreg_bn3d_fwd(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                   float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
                   int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, void* stream);
+/* y may be NULL when the forward had no residual: the ReLU mask is then recomputed as x*scale + shift > 0 (one read less). */
 int dreg_bn3d_bwd(const void* x, const void* dy, const void* y, const float* scale_shift, const float* mean_rstd,
                   void* dx, void* dres, float* dgamma, float* dbeta, float* coef, float* workspace,
                   int B, int V, int C, int relu, int accumulate, int dtype, void* stream);
@@ -134,6 +135,12 @@ int dreg_trilinear_gather_bwd(const float* dfeat, const int64_t* idx, const int*
                               int h, int w, int C, int Zr, int Xr, int Yr, void* stream);
 int dreg_cast_from_f32(const float* in, void* out, size_t n, int dtype, void* stream);
 int dreg_add_inplace(void* dst, const void* src, size_t n, int dtype, void* stream);   /* dst += src */
+/* Input staging (nerf_regtr.py:131-147): grids = DEVICE array of B pointers to fp32 [7,Z,X,Y] voxel grids (xyz | rgb | alpha).
+ * pack: -> [B,Z,X,Y,8] (dtype) = rgba + 4 zero channels, the NDHWC stem input.  gather: xyz fp32 [N,3] of the occupied voxels
+ * (idx int64 [N] = (x*Yr + y)*Zr + z, pt_batch int32 [N]). */
+int dreg_pack_rgba_grids(const void* grids, void* out, int B, int Z, int X, int Y, int dtype, void* stream);
+int dreg_gather_grid_xyz(const void* grids, const int64_t* idx, const int* pt_batch, float* xyz, int N, int Zr, int Xr, int Yr,
+                         void* stream);
 
 /* Active sets of the FPN head (build-side; identical results to the dense evaluation of feature_pyramid_net.py:115-127 because
  * nerf_regtr.py:138-147 only consumes P1 at the trilinear corners of the occupied voxels): S1 = those corners, S2 = S1 dilated
