@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-res", type=int, default=0, help="resolution of the bounded CPU sample (0: 128 on hosts with >= 32 cores, else 64)")
+    ap.add_argument("--event-steps", type=int, default=2, help="timed steps whose conv launches are bracketed by HIP events (roofline line)")
     ap.add_argument("--kernel-report", default="", help="write the per-kernel/per-shape event timing table here")
     ap.add_argument("--no-dense-reference", action="store_true", help="skip the additional dense-head measurement")
     ap.add_argument("--dense-head", action="store_true", help="evaluate the FPN head densely (BASELINE.md FLOP accounting) instead of on the active set")
@@ -117,7 +118,9 @@ def main():
         sync()
         ops.PROFILER = ops.KernelTimer()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for i in range(args.steps):
+            if i == args.event_steps:      # HIP-event brackets on the first steps of the timed region only (they cost host time)
+                ops.PROFILER.enabled = False
             ts.step(batch)
         sync()
         el = time.perf_counter() - t0
@@ -139,7 +142,8 @@ def main():
         name, (calls, ms, flops) = max(single.items(), key=lambda kv: kv[1][1])
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         return {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                "launches": calls, "avg_launch_ms": ms / max(calls, 1), "algorithmic_flops_per_launch": flops / max(calls, 1)}, by_label
+                "launches": calls, "avg_launch_ms": ms / max(calls, 1), "algorithmic_flops_per_launch": flops / max(calls, 1),
+                "event_steps": min(args.event_steps, args.steps), "empty_bracket_ms_subtracted": pr.bracket_overhead_ms()}, by_label
 
     # the second, dense-head measurement keeps the BASELINE.md FLOP accounting (8.5 TFLOP per pair) comparable
     dense = None

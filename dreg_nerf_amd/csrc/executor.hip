@@ -240,7 +240,7 @@ int dreg_exec_repack(void* h, const void* descs_dev, const int* row_desc_dev, vo
     return dreg_pack_conv_weights_batched(descs_dev, (int)e->packs.size(), e->pack_rows, e->pack_max_floats, row_desc_dev, stream);
 }
 
-void dreg_exec_set_timing(void* h, int enable) { Exec* e = (Exec*)h; e->timing = enable != 0; e->timed_used = 0; }
+void dreg_exec_set_timing(void* h, int enable) { ((Exec*)h)->timing = enable != 0; }   // records are kept until read
 // After a stream synchronisation: elapsed ms of the bracketed launches since the last set_timing; records are (op, kind, ms)
 // with kind 0 forward, 1 data gradient, 2 weight gradient (+reduce).  Returns the number written (<= max) and restarts.
 int dreg_exec_read_timings(void* h, int* op_kind, float* ms, int max)

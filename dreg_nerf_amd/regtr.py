@@ -213,10 +213,9 @@ class NeRFRegTr(nn.Module):
     def drain_trunk_timings(self, profiler):
         """Move the native executor's HIP-event records (one per convolution launch) into `profiler` and stop timing."""
         for ex in self.__dict__.get("_trunk_cache", {}).values():
-            if ex._timing:
-                torch.cuda.synchronize()
-                ex.drain_timings(profiler)
-                ex.set_timing(False)
+            torch.cuda.synchronize()
+            ex.drain_timings(profiler)
+            ex.set_timing(False)
 
     @staticmethod
     def _grid_table(grids: List[torch.Tensor]):

@@ -190,8 +190,9 @@ class TrunkExecutor:
 
     def forward(self, x: torch.Tensor, rows, train: bool) -> torch.Tensor:
         self.repack_if_stale()
-        if ops.PROFILER is not None and not self._timing:
-            self.set_timing(True)
+        want = ops.PROFILER is not None and ops.PROFILER.enabled
+        if want != self._timing:
+            self.set_timing(want)
         self.last_row_counts = [int(r.shape[0]) for r in rows[:3]] if rows is not None else []
         ra, n = self._rowlist_array(rows)
         L.check(self.lib.dreg_exec_forward(self.h, L.ptr(self.arena), self.arena_bytes, L.ptr(self.pack), L.ptr(x),
