@@ -977,6 +977,20 @@ __global__ __launch_bounds__(256) void aset_write_kernel(const uint8_t* __restri
         } else if (which == 0 && map1) map1[v0 + k] = -1;
     }
 }
+// level-2 flags: a coarse voxel of the next pyramid level is active when any of its (<= 8) children is
+__global__ void aset_parent_kernel(const uint8_t* __restrict__ child, uint8_t* __restrict__ parent, int B, int d, int h, int w, int d2, int h2, int w2)
+{
+    const size_t V2 = (size_t)B * d2 * h2 * w2;
+    const size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (v >= V2) return;
+    const int y = (int)(v % w2), x = (int)((v / w2) % h2), z = (int)((v / ((size_t)w2 * h2)) % d2), b = (int)(v / ((size_t)w2 * h2 * d2));
+    uint8_t r = 0;
+    for (int dz = 0; dz < 2; ++dz) for (int dx = 0; dx < 2; ++dx) for (int dy = 0; dy < 2; ++dy) {
+        const int zz = 2 * z + dz, xx = 2 * x + dx, yy = 2 * y + dy;
+        if (zz < d && xx < h && yy < w) r |= child[(((size_t)b * d + zz) * h + xx) * w + yy];
+    }
+    parent[v] = r;
+}
 extern "C" {
 // workspace: 3*V flag bytes + 3*nblk ints (see dreg_active_sets_workspace_bytes).  rows: int32 [3][V] (list k starts at
 // rows + k*V); counts: device int32 [3]; map1: int32 [V] or NULL.
@@ -1011,6 +1025,38 @@ int dreg_active_sets(const int64_t* idx, const int* pt_batch, int N, int B, int 
     hipLaunchKernelGGL(aset_scan_kernel, dim3(3), dim3(1024), 0, st, blk, counts, nblk);
     DREG_LAUNCH_CHECK();
     hipLaunchKernelGGL(aset_write_kernel, dim3(nblk, 3), dim3(256), 0, st, flags, blk, rows, map1, V, nblk);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// Second pyramid level of the active sets: child_flags = the S2 flags of dreg_active_sets (bytes [V, 2V) of ITS workspace, on
+// [B,d,h,w]); A = parents of S2 on [B,d2,h2,w2] (where the next-coarser FPN map P2 is consumed by the nearest-x2 upsample-add),
+// A2 = A dilated by 3^3 (where its lateral sum is consumed).  rows2 int32 [2][V2], counts2 device int32 [2].
+size_t dreg_active_sets_level2_workspace_bytes(int B, int d2, int h2, int w2)
+{
+    const size_t V2 = (size_t)B * d2 * h2 * w2;
+    const size_t nblk = (V2 + ASET_PER_BLOCK - 1) / ASET_PER_BLOCK;
+    return (2 * V2 + 255) / 256 * 256 + 2 * nblk * sizeof(int) + 256;
+}
+int dreg_active_sets_level2(const uint8_t* child_flags, int B, int d, int h, int w, int d2, int h2, int w2, int* rows2, int* counts2,
+                            void* workspace, size_t workspace_bytes, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const size_t V2 = (size_t)B * d2 * h2 * w2;
+    if (V2 == 0 || V2 > 0x7fffffffull || d2 != (d + 1) / 2 || h2 != (h + 1) / 2 || w2 != (w + 1) / 2) return DREG_EINVAL;
+    if (workspace_bytes < dreg_active_sets_level2_workspace_bytes(B, d2, h2, w2)) return DREG_EINVAL;
+    const int nblk = (int)((V2 + ASET_PER_BLOCK - 1) / ASET_PER_BLOCK);
+    uint8_t* flags = (uint8_t*)workspace;
+    int* blk = (int*)((char*)workspace + (2 * V2 + 255) / 256 * 256);
+    const unsigned nbv = (unsigned)((V2 + 255) / 256);
+    hipLaunchKernelGGL(aset_parent_kernel, dim3(nbv), dim3(256), 0, st, child_flags, flags, B, d, h, w, d2, h2, w2);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(aset_dilate_kernel, dim3(nbv), dim3(256), 0, st, flags, flags + V2, B, d2, h2, w2);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(aset_count_kernel, dim3(nblk, 2), dim3(256), 0, st, flags, blk, V2, nblk);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(aset_scan_kernel, dim3(2), dim3(1024), 0, st, blk, counts2, nblk);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(aset_write_kernel, dim3(nblk, 2), dim3(256), 0, st, flags, blk, rows2, (int*)nullptr, V2, nblk);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

@@ -463,11 +463,13 @@ def conv3d_rows(x, w, bias, addend, pad, out_rows, in_rows):
     return SparseConv3dFn.apply(x, w, bias, addend, pad, out_rows, in_rows)
 
 
-def active_sets(idx_list, fine_res, coarse_dims, device, pt_batch=None, idx_cat=None, density_cap: float = 0.2):
+def active_sets(idx_list, fine_res, coarse_dims, device, pt_batch=None, idx_cat=None, density_cap: float = 0.2,
+                level2: bool = True, level2_cap: float = 0.5):
     """Row lists for the FPN head: S1 = trilinear-gather corner voxels of the occupied fine voxels (where P1 is consumed),
     S2 = S1 dilated by 3^3 (where the lateral sum is consumed), S3 = S2 dilated (where dc1 of the head is non-zero).
     idx_list: per grid int64 flat fine indices ((x*Yr + y)*Zr + z).  Returns three ascending int32 tensors of flat indices
-    into [B, d, h, w] plus map1 (int32 [B*d*h*w]: rank of a voxel in S1, -1 outside) — None for dense scenes.  One C call (mark, two dilations, stable compaction) + one host read of the
+    into [B, d, h, w] plus map1 (int32 [B*d*h*w]: rank of a voxel in S1, -1 outside) — None for dense scenes — and, when the
+    next pyramid level is sparse enough as well, A / A2 (row lists on [B, ceil(d/2), ...]: parents of S2, dilated).  One C call (mark, two dilations, stable compaction) + one host read of the
     three lengths; the corner arithmetic is tri_axis() of fpn_ops.hip itself."""
     lib = L.load()
     Zr, Xr, Yr = fine_res
@@ -485,10 +487,25 @@ def active_sets(idx_list, fine_res, coarse_dims, device, pt_batch=None, idx_cat=
     map1 = torch.empty(V, dtype=torch.int32, device=device)
     L.check(lib.dreg_active_sets(L.ptr(idx_cat), L.ptr(pt_batch), idx_cat.shape[0], B, Zr, Xr, Yr, d, h, w,
                                  L.ptr(rows), L.ptr(counts), L.ptr(map1), L.ptr(ws), nbytes, L.stream()), "dreg_active_sets")
-    n1, n2, n3 = counts.tolist()
+    # second pyramid level (P2 at half the resolution is only consumed at the parents of S2): A = parents(S2), A2 = dilate(A)
+    d2, h2, w2 = (d + 1) // 2, (h + 1) // 2, (w + 1) // 2
+    V2 = B * d2 * h2 * w2
+    rows2 = torch.empty(2, V2, dtype=torch.int32, device=device)
+    counts2 = torch.empty(2, dtype=torch.int32, device=device)
+    if level2:
+        nb2 = lib.dreg_active_sets_level2_workspace_bytes(B, d2, h2, w2)
+        ws2 = _ws(nb2, device)
+        L.check(lib.dreg_active_sets_level2(ws.data_ptr() + V, B, d, h, w, d2, h2, w2, L.ptr(rows2), L.ptr(counts2), L.ptr(ws2), nb2, L.stream()),
+                "dreg_active_sets_level2")
+        n1, n2, n3, m1, m2 = torch.cat([counts, counts2]).tolist()
+    else:
+        (n1, n2, n3), m1, m2 = counts.tolist(), 0, V2
     if n3 > density_cap * V:   # dense scenes: the row lists stop paying (and the wgrad slice cap applies)
         return None
-    return rows[0, :n1], rows[1, :n2], rows[2, :n3], map1
+    out = (rows[0, :n1], rows[1, :n2], rows[2, :n3], map1)
+    if level2 and m2 <= level2_cap * V2:
+        out = out + (rows2[0, :m1], rows2[1, :m2])
+    return out
 
 
 def linear(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = False, residual=None,

@@ -163,7 +163,14 @@ class NeRFRegTr(nn.Module):
         p5 = conv("pyramid_transformation_5", c5, 0)
         p4 = conv("upsample_transform_4", conv("pyramid_transformation_4", c4, 0, addend=p5), 1)
         p3 = conv("upsample_transform_3", conv("pyramid_transformation_3", c3, 0, addend=p4), 1)
-        p2 = conv("upsample_transform_2", conv("pyramid_transformation_2", c2, 0, addend=p3), 1)
+        if rows is not None and len(rows) >= 6:
+            # P2 is only consumed (by the nearest-x2 upsample-add of the head's lateral sum on S2) at A = parents(S2); its own
+            # lateral sum only on A2 = A dilated by 3^3: both level-2 convolutions run on row lists as well
+            a1, a2 = rows[4], rows[5]
+            lat2 = O.conv3d_rows(c2, P[q + "pyramid_transformation_2.weight"], P[q + "pyramid_transformation_2.bias"], p3, 0, a2, a2)
+            p2 = O.conv3d_rows(lat2, P[q + "upsample_transform_2.weight"], P[q + "upsample_transform_2.bias"], None, 1, a1, a2)
+        else:
+            p2 = conv("upsample_transform_2", conv("pyramid_transformation_2", c2, 0, addend=p3), 1)
         if rows is None:
             p1 = conv("upsample_transform_1", conv("pyramid_transformation_1", c1, 1, addend=p2), 1)
         else:
@@ -181,14 +188,15 @@ class NeRFRegTr(nn.Module):
         with_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.fpn3d.parameters())
         if with_grad and any(p.requires_grad and (p.grad is None or not p.grad.is_contiguous()) for p in self.fpn3d.parameters()):
             return None
-        key = (tuple(x.shape), rows is not None, with_grad)
+        sparse_level = 0 if rows is None else (2 if len(rows) >= 6 else 1)
+        key = (tuple(x.shape), sparse_level, with_grad)
         cache = self.__dict__.setdefault("_trunk_cache", {})
         ex = cache.get(key)
         if ex is not None and not ex.still_valid():
             ex = None
         if ex is None:
             cache.clear()   # one live program: its arena holds every activation of the network
-            ex = trunk_exec.TrunkExecutor(self, tuple(x.shape), rows is not None, with_grad)
+            ex = trunk_exec.TrunkExecutor(self, tuple(x.shape), sparse_level, with_grad)
             cache[key] = ex
         return ex
 
@@ -300,6 +308,8 @@ class NeRFRegTr(nn.Module):
             grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs, table = geo
             # these were allocated on the side stream and are consumed on the main one
             keep = [idx_cat, pb_cat] + list(pts_l) + ([rows[0], rows[3]] if rows is not None else []) + ([table] if table is not None else [])
+            if rows is not None and len(rows) >= 6:
+                keep.append(rows[4])
             for rounds in plans:
                 for rnd in rounds:
                     keep += [rnd.order, rnd.starts, rnd.n_out_dev, rnd.inv_seg, rnd.inv_cnt]

@@ -77,13 +77,15 @@ class _Recorder:
 class TrunkExecutor:
     """One recorded program + its arena and packed-weight buffer."""
 
-    def __init__(self, model, x_shape, sparse_head: bool, with_grad: bool = True):
+    def __init__(self, model, x_shape, sparse_head: int, with_grad: bool = True):
         self.lib = L.load()
         P = model._P()
         rec = _Recorder(P, x_shape)
         x0 = _Recorder.T(0, x_shape)
         self.nbt = []
-        out = model._fpn_program(rec, x0, (0, 1, 2) if sparse_head else None, self.nbt, True)
+        # row-list ids: 0..2 = S1, S2, S3 (head), 4, 5 = A, A2 (second pyramid level) — positions in ops.active_sets' tuple
+        rl = None if not sparse_head else ((0, 1, 2, None) if sparse_head == 1 else (0, 1, 2, None, 4, 5))
+        out = model._fpn_program(rec, x0, rl, self.nbt, True)
         self.out_shape = out.shape
         self.rec = rec
         dev = next(model.parameters()).device
@@ -182,18 +184,21 @@ class TrunkExecutor:
     def _rowlist_array(rows):
         if rows is None:
             return None, 0
-        a = (ctypes.c_int64 * 6)()
-        for i in range(3):
+        n = len(rows)
+        a = (ctypes.c_int64 * (2 * n))()
+        for i in range(n):
+            if i == 3 or rows[i] is None:   # slot 3 is map1 (not a row list)
+                continue
             a[2 * i] = rows[i].data_ptr()
             a[2 * i + 1] = rows[i].shape[0]
-        return a, 3
+        return a, n
 
     def forward(self, x: torch.Tensor, rows, train: bool) -> torch.Tensor:
         self.repack_if_stale()
         want = ops.PROFILER is not None and ops.PROFILER.enabled
         if want != self._timing:
             self.set_timing(want)
-        self.last_row_counts = [int(r.shape[0]) for r in rows[:3]] if rows is not None else []
+        self.last_row_counts = [int(r.shape[0]) if (r is not None and i != 3) else 0 for i, r in enumerate(rows)] if rows is not None else []
         ra, n = self._rowlist_array(rows)
         L.check(self.lib.dreg_exec_forward(self.h, L.ptr(self.arena), self.arena_bytes, L.ptr(self.pack), L.ptr(x),
                                            ctypes.addressof(ra) if ra is not None else None, n, int(train), L.stream()), "dreg_exec_forward")

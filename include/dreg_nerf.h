@@ -149,6 +149,12 @@ int dreg_gather_grid_xyz(const void* grids, const int64_t* idx, const int* pt_ba
 size_t dreg_active_sets_workspace_bytes(int B, int d, int h, int w);
 int dreg_active_sets(const int64_t* idx, const int* pt_batch, int N, int B, int Zr, int Xr, int Yr, int d, int h, int w,
                      int* rows, int* counts, int* map1, void* workspace, size_t workspace_bytes, void* stream);
+/* Second pyramid level: child_flags = the S2 flags of dreg_active_sets (bytes [V, 2V) of its workspace); A = parents of S2 on
+ * [B,d2,h2,w2] (where P2 is consumed by the nearest-x2 upsample-add of feature_pyramid_net.py:58-61), A2 = A dilated by 3^3.
+ * rows2 int32 [2][V2], counts2 device int32 [2]. */
+size_t dreg_active_sets_level2_workspace_bytes(int B, int d2, int h2, int w2);
+int dreg_active_sets_level2(const uint8_t* child_flags, int B, int d, int h, int w, int d2, int h2, int w2, int* rows2,
+                            int* counts2, void* workspace, size_t workspace_bytes, void* stream);
 /* active-set forms of the gather backward (dp1 zero-filled here, gradient on the S1 rows only; comp: fp32 [n1,C] scratch) and
  * of the bias-gradient column sum (rows of g outside the list are known to be zero). */
 int dreg_trilinear_gather_bwd_rows(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,

@@ -269,7 +269,9 @@ def _active_sets_torch(idx_list, fine_res, coarse_dims):
     f1 = flags.float()[:, None]
     f2 = F.max_pool3d(f1, 3, 1, 1)
     f3 = F.max_pool3d(f2, 3, 1, 1)
-    return [torch.nonzero(t.flatten() > 0)[:, 0].to(torch.int32) for t in (f1, f2, f3)]
+    fa = F.max_pool3d(f2, 2, 2, ceil_mode=True)          # parents of S2 on the next pyramid level
+    fa2 = F.max_pool3d(fa, 3, 1, 1)
+    return [torch.nonzero(t.flatten() > 0)[:, 0].to(torch.int32) for t in (f1, f2, f3, fa, fa2)]
 
 
 @pytest.mark.parametrize("res,frac", [((24, 20, 28), 0.01), ((33, 31, 29), 0.003), ((16, 16, 16), 0.0)])
@@ -285,12 +287,15 @@ def test_active_sets_match_cpu_construction(res, frac):
     if frac == 0.0:
         idx[1] = torch.tensor([0, Zr * Xr * Yr - 1])  # the two extreme corners only; grids 0 and 2 empty
     ref = _active_sets_torch(idx, res, coarse)
-    got = ops.active_sets([i.to(dev) for i in idx], res, coarse, dev)
+    got = ops.active_sets([i.to(dev) for i in idx], res, coarse, dev, level2_cap=1.0)
     V = 3 * coarse[0] * coarse[1] * coarse[2]
     if ref[2].numel() > 0.2 * V:
         assert got is None
         return
-    for a, b in zip(got[:3], ref):
+    for a, b in zip(got[:3], ref[:3]):
+        assert a.dtype == torch.int32 and torch.equal(a.cpu(), b)
+    assert len(got) == 6
+    for a, b in zip(got[4:], ref[3:]):
         assert a.dtype == torch.int32 and torch.equal(a.cpu(), b)
     map1 = got[3].cpu()
     want = torch.full((V,), -1, dtype=torch.int32)
