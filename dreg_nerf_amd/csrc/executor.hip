@@ -57,6 +57,11 @@ struct Exec {
     bool timing = false;
     std::vector<TimedLaunch> timed;
     size_t timed_used = 0;
+    // weight / bias gradients run on a second stream next to the data-gradient chain (they only share their input gy)
+    hipStream_t aux = nullptr;
+    std::vector<hipEvent_t> ev;            // per op: "gy of this op is complete" (recorded on the caller's stream)
+    hipEvent_t ev_done = nullptr;
+    bool use_aux = true;
 };
 
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -209,6 +214,9 @@ void dreg_exec_destroy(void* h)
     Exec* e = (Exec*)h;
     if (!e) return;
     for (auto& t : e->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
+    for (auto& v : e->ev) if (v) (void)hipEventDestroy(v);
+    if (e->ev_done) (void)hipEventDestroy(e->ev_done);
+    if (e->aux) (void)hipStreamDestroy(e->aux);
     delete e;
 }
 
@@ -240,6 +248,8 @@ int dreg_exec_repack(void* h, const void* descs_dev, const int* row_desc_dev, vo
     return dreg_pack_conv_weights_batched(descs_dev, (int)e->packs.size(), e->pack_rows, e->pack_max_floats, row_desc_dev, stream);
 }
 
+// 1 (default): weight / bias gradients on the executor's own second stream, overlapping the data-gradient chain; 0: one stream
+void dreg_exec_set_overlap(void* h, int enable) { ((Exec*)h)->use_aux = enable != 0; }
 void dreg_exec_set_timing(void* h, int enable) { ((Exec*)h)->timing = enable != 0; }   // records are kept until read
 // After a stream synchronisation: elapsed ms of the bracketed launches since the last set_timing; records are (op, kind, ms)
 // with kind 0 forward, 1 data gradient, 2 weight gradient (+reduce).  Returns the number written (<= max) and restarts.
@@ -324,6 +334,15 @@ int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pac
         return DREG_OK;
     };
     written[e->out_slot] = 1;
+    bool aux_on = e->use_aux;
+    if (aux_on && !e->aux) {
+        if (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess) { e->aux = nullptr; aux_on = false; }
+        else {
+            e->ev.assign(e->ops.size(), nullptr);
+            if (hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) != hipSuccess) aux_on = false;
+        }
+    }
+    bool aux_used = false;
     for (int i = (int)e->ops.size() - 1; i >= 0; --i) {
         const Op& o = e->ops[i];
         const Tensor& x = e->t[o.in];
@@ -335,6 +354,29 @@ int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pac
             const bool rows = o.kind == OP_CONV_ROWS;
             const int* r_out = rows ? (const int*)rowlists[2 * o.rows_out] : nullptr;
             const int n_out = rows ? (int)rowlists[2 * o.rows_out + 1] : 0;
+            // parameter gradients first, on the second stream: gy is complete here (every consumer of this op's output has been
+            // processed), and nothing below modifies gy or the op's input activation
+            const bool pg = w.grad || (o.b >= 0 && e->prm[o.b].grad);
+            if (pg) {
+                hipStream_t ws = st;
+                if (aux_on) {
+                    if (!e->ev[i] && hipEventCreateWithFlags(&e->ev[i], hipEventDisableTiming) != hipSuccess) return DREG_ELAUNCH;
+                    if (hipEventRecord(e->ev[i], st) != hipSuccess || hipStreamWaitEvent(e->aux, e->ev[i], 0) != hipSuccess) return DREG_ELAUNCH;
+                    ws = e->aux;
+                    aux_used = true;
+                }
+                if (w.grad) {
+                    Scope sc(e, ws, i, 2);
+                    if (rows) CK(dreg_conv3d_wgrad_rows(gy, act(o.in), w.grad, A + e->off_wg, e->sz_wg, r_out, n_out, x.B, x.D, x.H, x.W, x.C, w.d1,
+                                                        y.D, y.H, y.W, w.d0, o.ksz, 1, o.pad, 1, (void*)ws));
+                    else CK(dreg_conv3d_wgrad(gy, act(o.in), w.grad, A + e->off_wg, e->sz_wg, x.B, x.D, x.H, x.W, x.C, w.d1, y.D, y.H, y.W, w.d0,
+                                              o.ksz, o.stride, o.pad, 1, 0, 1, (void*)ws));
+                }
+                if (o.b >= 0 && e->prm[o.b].grad) {
+                    if (rows) CK(dreg_colsum_rows(gy, r_out, n_out, e->prm[o.b].grad, (float*)(A + e->off_cs), w.d0, 1, 0, (void*)ws));
+                    else CK(dreg_colsum(gy, e->prm[o.b].grad, (float*)(A + e->off_cs), (size_t)y.B * y.D * y.H * y.W, w.d0, 1, 0, (void*)ws));
+                }
+            }
             if (o.in2 >= 0 && e->needs_grad[o.in2]) {
                 const Tensor& ta = e->t[o.in2];
                 if (o.add_same) { CK(hipMemcpyAsync(dst_for(o.in2), gy, (size_t)y.B * y.D * y.H * y.W * y.C * 2, hipMemcpyDeviceToDevice, st) == hipSuccess ? 0 : DREG_ELAUNCH); }
@@ -358,17 +400,6 @@ int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pac
                 }
             }
             if (e->needs_grad[o.in]) CK(commit(o.in));
-            if (w.grad) {
-                Scope sc(e, st, i, 2);
-                if (rows) CK(dreg_conv3d_wgrad_rows(gy, act(o.in), w.grad, A + e->off_wg, e->sz_wg, r_out, n_out, x.B, x.D, x.H, x.W, x.C, w.d1,
-                                                    y.D, y.H, y.W, w.d0, o.ksz, 1, o.pad, 1, stream));
-                else CK(dreg_conv3d_wgrad(gy, act(o.in), w.grad, A + e->off_wg, e->sz_wg, x.B, x.D, x.H, x.W, x.C, w.d1, y.D, y.H, y.W, w.d0,
-                                          o.ksz, o.stride, o.pad, 1, 0, 1, stream));
-            }
-            if (o.b >= 0 && e->prm[o.b].grad) {
-                if (rows) CK(dreg_colsum_rows(gy, r_out, n_out, e->prm[o.b].grad, (float*)(A + e->off_cs), w.d0, 1, 0, stream));
-                else CK(dreg_colsum(gy, e->prm[o.b].grad, (float*)(A + e->off_cs), (size_t)y.B * y.D * y.H * y.W, w.d0, 1, 0, stream));
-            }
         } else if (o.kind == OP_BN) {
             const int V = x.D * x.H * x.W;
             const bool res_g = o.in2 >= 0 && e->needs_grad[o.in2];
@@ -403,6 +434,9 @@ int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pac
             CK(dreg_maxpool3d_bwd(gy, (const uint8_t*)(A + o.aux0), dst_for(o.in), x.B, x.D, x.H, x.W, y.D, y.H, y.W, x.C, 0, stream));
             CK(commit(o.in));
         }
+    }
+    if (aux_used) {   // the caller's stream continues (optimizer) only after every parameter gradient has landed
+        if (hipEventRecord(e->ev_done, e->aux) != hipSuccess || hipStreamWaitEvent(st, e->ev_done, 0) != hipSuccess) return DREG_ELAUNCH;
     }
     return DREG_OK;
 }

@@ -78,6 +78,7 @@ SIGNATURES = {
     "dreg_exec_pack_rows": (I, [P]),
     "dreg_exec_export_pack_table": (I, [P, P, P, P]),
     "dreg_exec_repack": (I, [P, P, P, P]),
+    "dreg_exec_set_overlap": (None, [P, I]),
     "dreg_exec_set_timing": (None, [P, I]),
     "dreg_exec_read_timings": (I, [P, P, P, I]),
     "dreg_exec_forward": (I, [P, P, Z, P, P, P, I, I, P]),
