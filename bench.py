@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md chip table
+HBM_PEAK_GBPS = 8000.0          # HBM3E, same table
 
 
 def parse():
@@ -35,7 +36,7 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-res", type=int, default=0, help="resolution of the bounded CPU sample (0: 128 on hosts with >= 32 cores, else 64)")
-    ap.add_argument("--event-steps", type=int, default=2, help="timed steps whose conv launches are bracketed by HIP events (roofline line)")
+    ap.add_argument("--event-steps", type=int, default=1, help="timed steps whose conv launches are bracketed by HIP events (roofline line)")
     ap.add_argument("--kernel-report", default="", help="write the per-kernel/per-shape event timing table here")
     ap.add_argument("--no-dense-reference", action="store_true", help="skip the additional dense-head measurement")
     ap.add_argument("--dense-head", action="store_true", help="evaluate the FPN head densely (BASELINE.md FLOP accounting) instead of on the active set")
@@ -134,6 +135,19 @@ def main():
 
     peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else 157.3
 
+    def label_bytes(label):
+        """Compulsory HBM bytes of one conv launch from its shape label: every input voxel, weight and output element once
+        (bf16 operands; fp32 for the f32-output variant is ignored: < 1 % of the launches' bytes)."""
+        import re
+        m = re.match(r"(\S+) B(\d+) (\d+)x(\d+)x(\d+)x(\d+)->(\d+)x(\d+)x(\d+)x(\d+) k(\d+)s(\d+)(?: rows(\d+))?", label)
+        if not m:
+            return 0.0
+        B, di, hi, wi, cin, do, ho, wo, cout, k = (int(m.group(i)) for i in range(2, 12))
+        rows = m.group(13)
+        n_in = int(rows) if rows else B * di * hi * wi
+        n_out = int(rows) if rows else B * do * ho * wo
+        return 2.0 * (n_in * cin + n_out * cout + cout * cin * k ** 3)
+
     def roofline_of(pr):
         by_name, by_label = pr.summary()
         # the dominant SINGLE kernel: "...+reduce" entries bracket two launches (weight gradient + its split reduce) and have no
@@ -141,9 +155,17 @@ def main():
         single = {k: v for k, v in by_name.items() if "+" not in k}
         name, (calls, ms, flops) = max(single.items(), key=lambda kv: kv[1][1])
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        return {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                "launches": calls, "avg_launch_ms": ms / max(calls, 1), "algorithmic_flops_per_launch": flops / max(calls, 1),
-                "event_steps": min(args.event_steps, args.steps), "empty_bracket_ms_subtracted": pr.bracket_overhead_ms()}, by_label
+        nbytes = sum(label_bytes(l) * c for (n, l), (c, _, _) in by_label.items() if n == name)
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        rf = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+              "launches": calls, "avg_launch_ms": ms / max(calls, 1), "algorithmic_flops_per_launch": flops / max(calls, 1),
+              "event_steps": min(args.event_steps, args.steps), "empty_bracket_ms_subtracted": pr.bracket_overhead_ms(),
+              # the same launches against the other roof: compulsory bytes (inputs, weights, outputs once) / time vs 8 TB/s
+              "compulsory_bytes_per_launch": nbytes / max(calls, 1), "hbm_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBPS}
+        if rf["hbm_frac"] > rf["frac"]:   # a family of small / 1x1x1 convolutions sits closer to the HBM roof than to the MFMA roof
+            rf.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBPS,
+                       "mfma_TFLOPs": ach, "mfma_frac": ach / peak})
+        return rf, by_label
 
     # the second, dense-head measurement keeps the BASELINE.md FLOP accounting (8.5 TFLOP per pair) comparable
     dense = None

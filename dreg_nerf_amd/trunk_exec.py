@@ -212,8 +212,11 @@ class TrunkExecutor:
 
     # ------------------------------------------------------------------ timing (bench.py's roofline line)
     def set_timing(self, on: bool):
+        """HIP-event brackets around every convolution launch.  While they are on, the weight-gradient launches stay on the
+        caller's stream (no second stream), so a bracket measures its kernel alone rather than two kernels sharing the CUs."""
         self._timing = bool(on)
         self.lib.dreg_exec_set_timing(self.h, int(on))
+        self.lib.dreg_exec_set_overlap(self.h, int(not on))
 
     def drain_timings(self, profiler: "ops.KernelTimer"):
         """After a device synchronisation: move the executor's HIP-event records into a KernelTimer-compatible store."""
