@@ -216,7 +216,6 @@ void dreg_exec_destroy(void* h)
     for (auto& t : e->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
     for (auto& v : e->ev) if (v) (void)hipEventDestroy(v);
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
-    if (e->aux) (void)hipStreamDestroy(e->aux);
     delete e;
 }
 
@@ -311,9 +310,10 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
 }
 
 // grad_out: gradient of the result tensor (bf16, same shape).  Weight / bias / BatchNorm gradients are ACCUMULATED into the
-// parameters' grad pointers; nothing is returned for the input tensor 0.
+// parameters' grad pointers; nothing is returned for the input tensor 0.  aux_stream (optional): a second stream of the caller's
+// for the weight / bias gradient launches; `stream` waits for it before this call's work is considered complete.
 int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pack_base, const void* x_in, const void* grad_out,
-                       const int64_t* rowlists, int nlists, void* stream)
+                       const int64_t* rowlists, int nlists, void* stream, void* aux_stream)
 {
     Exec* e = (Exec*)h;
     if (arena_bytes < e->arena_bytes) return DREG_EINVAL;
@@ -334,13 +334,13 @@ int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pac
         return DREG_OK;
     };
     written[e->out_slot] = 1;
-    bool aux_on = e->use_aux;
-    if (aux_on && !e->aux) {
-        if (hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) != hipSuccess) { e->aux = nullptr; aux_on = false; }
-        else {
-            e->ev.assign(e->ops.size(), nullptr);
-            if (hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) != hipSuccess) aux_on = false;
-        }
+    // the second stream is the caller's (one per process/device: HIP maps streams onto a handful of hardware queues, and a
+    // stream created per executor can land on the queue of the main stream, which serialises instead of overlapping)
+    bool aux_on = e->use_aux && aux_stream != nullptr && aux_stream != stream;
+    e->aux = (hipStream_t)aux_stream;
+    if (aux_on && e->ev.empty()) {
+        e->ev.assign(e->ops.size(), nullptr);
+        if (hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) != hipSuccess) aux_on = false;
     }
     bool aux_used = false;
     for (int i = (int)e->ops.size() - 1; i >= 0; --i) {

@@ -290,6 +290,9 @@ def _grad_sink(p):
 
 
 DIRECT_GRAD_ACCUMULATE = True
+# torch.cuda.Stream for the weight / bias gradient launches of Conv3dFn.backward while a caller that joins it afterwards is
+# running the backward pass (train_step.TrainStep); None = everything on the current stream
+PARAM_GRAD_STREAM = None
 
 
 def downsample_sum(g, coarse_shape):
@@ -362,10 +365,27 @@ class Conv3dFn(torch.autograd.Function):
             else:
                 wpk = packed_weight(w, cin_pad, True, dt)
                 gx = conv_igemm(g, wpk, None, None, tuple(x.shape[1:4]), cout, w.shape[1], ksz, stride, pad, True)
+        wsink = _grad_sink(w) if ctx.needs_input_grad[1] else None
+        bsink = _grad_sink(ctx.bias_ref) if (has_bias and ctx.needs_input_grad[2] and ctx.bias_ref is not None) else None
+        want_b = has_bias and ctx.needs_input_grad[2]
+        if PARAM_GRAD_STREAM is not None and wsink is not None and (not want_b or bsink is not None) \
+                and (PROFILER is None or not PROFILER.enabled):
+            # both parameter gradients accumulate in place: run them on the side stream next to the data-gradient chain
+            # (train_step.TrainStep joins the stream before the optimizer reads the gradients)
+            ev = torch.cuda.Event()
+            ev.record()
+            PARAM_GRAD_STREAM.wait_event(ev)
+            with torch.cuda.stream(PARAM_GRAD_STREAM):
+                conv_wgrad(g, x, tuple(w.shape), cin_pad, ksz, stride, pad, USE_TR, accumulate_into=wsink)
+                if want_b:
+                    colsum(g.view(-1, cout), accumulate_into=bsink)
+            g.record_stream(PARAM_GRAD_STREAM)
+            x.record_stream(PARAM_GRAD_STREAM)
+            return gx, None, None, ga, None, None, None, None, None
         if ctx.needs_input_grad[1]:
-            gw = conv_wgrad(g, x, tuple(w.shape), cin_pad, ksz, stride, pad, USE_TR, accumulate_into=_grad_sink(w))
-        if has_bias and ctx.needs_input_grad[2]:
-            gb = colsum(g.view(-1, cout), accumulate_into=_grad_sink(ctx.bias_ref) if ctx.bias_ref is not None else None)
+            gw = conv_wgrad(g, x, tuple(w.shape), cin_pad, ksz, stride, pad, USE_TR, accumulate_into=wsink)
+        if want_b:
+            gb = colsum(g.view(-1, cout), accumulate_into=bsink)
         return gx, gw, gb, ga, None, None, None, None, None
 
 

@@ -15,6 +15,7 @@ import torch.distributed as dist
 
 from . import fused_losses as FL
 from . import losses as LS
+from . import ops
 from . import synth
 from .optim import FlatAdamW, StepLR
 
@@ -58,6 +59,8 @@ class TrainStep:
         self.finetune = finetune
         self.label_fn = label_fn or _default_labels
         self.fused_losses = fused_losses
+        self.overlap_param_grads = True
+        self._pg_stream = None
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.last_losses = None
         self.last_preds = None
@@ -100,7 +103,20 @@ class TrainStep:
                 for k, v in ls.items():
                     agg[k] = agg.get(k, 0.0) + v.detach()
             total = total / len(batch)
-        total.backward()
+        dev = next(self.model.parameters()).device
+        if self.overlap_param_grads and dev.type == "cuda":
+            # weight / bias gradients of the point-set half's linear layers on a side stream, next to the data-gradient chain
+            if self._pg_stream is None:
+                from .trunk_exec import aux_stream
+                self._pg_stream = aux_stream(dev)      # the same second stream the trunk executor uses
+            ops.PARAM_GRAD_STREAM = self._pg_stream
+            try:
+                total.backward()
+            finally:
+                ops.PARAM_GRAD_STREAM = None
+            torch.cuda.current_stream(dev).wait_stream(self._pg_stream)
+        else:
+            total.backward()
         if self.world > 1:
             self.optimizer.all_reduce_mean(self.world)
         self.optimizer.step()          # clip_grad_norm_(grad_clip) folded into the AdamW kernel

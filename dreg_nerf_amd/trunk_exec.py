@@ -208,7 +208,8 @@ class TrunkExecutor:
     def backward(self, x: torch.Tensor, rows, grad_out: torch.Tensor):
         ra, n = self._rowlist_array(rows)
         L.check(self.lib.dreg_exec_backward(self.h, L.ptr(self.arena), self.arena_bytes, L.ptr(self.pack), L.ptr(x), L.ptr(grad_out),
-                                            ctypes.addressof(ra) if ra is not None else None, n, L.stream()), "dreg_exec_backward")
+                                            ctypes.addressof(ra) if ra is not None else None, n, L.stream(), aux_stream(self.device).cuda_stream),
+                "dreg_exec_backward")
 
     # ------------------------------------------------------------------ timing (bench.py's roofline line)
     def set_timing(self, on: bool):
@@ -230,6 +231,19 @@ class TrunkExecutor:
                 nr = self.last_row_counts[lid]
                 fl, label = per_row * nr, f"{label} rows{nr}"
             profiler.add_measured(name, label, fl, ms[i])
+
+
+_AUX = {}
+
+
+def aux_stream(device) -> "torch.cuda.Stream":
+    """The process-wide second stream (per device) for parameter-gradient launches: shared by every executor and by
+    train_step's point-set half, created once so that its hardware queue never changes."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _AUX.get(key)
+    if st is None:
+        st = _AUX[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 class _TrunkFn(torch.autograd.Function):

@@ -186,13 +186,13 @@ int dreg_exec_output_slot(void* h);
 int dreg_exec_pack_rows(void* h);
 int dreg_exec_export_pack_table(void* h, void* host_out, int* host_row_desc, void* pack_base);   /* 48-byte records + row->record map */
 int dreg_exec_repack(void* h, const void* descs_dev, const int* row_desc_dev, void* stream);
-void dreg_exec_set_overlap(void* h, int enable);                             /* 1 (default): weight gradients on a second stream */
+void dreg_exec_set_overlap(void* h, int enable);                             /* 1 (default): weight gradients on aux_stream */
 void dreg_exec_set_timing(void* h, int enable);                              /* HIP events around every convolution launch */
 int dreg_exec_read_timings(void* h, int* op_kind, float* ms, int max);       /* (op, kind 0 fwd / 1 dgrad / 2 wgrad), ms */
 int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack_base, const void* x_in,
                       const int64_t* rowlists, int nlists, int train, void* stream);
 int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pack_base, const void* x_in,
-                       const void* grad_out, const int64_t* rowlists, int nlists, void* stream);
+                       const void* grad_out, const int64_t* rowlists, int nlists, void* stream, void* aux_stream);
 
 /* ---------------------------------------------------------------------------------------------- point-set half
  * Attention core of nn.MultiheadAttention (8 heads, d_head 32; transformer.py:242-281): q [Nq,ldq], k [Nk,ldk],
