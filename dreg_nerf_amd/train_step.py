@@ -59,7 +59,7 @@ class TrainStep:
         self.finetune = finetune
         self.label_fn = label_fn or _default_labels
         self.fused_losses = fused_losses
-        self.overlap_param_grads = True
+        self.overlap_param_grads = not bool(int(os.environ.get("DREG_SERIAL_STREAMS", "0")))
         self._pg_stream = None
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.last_losses = None

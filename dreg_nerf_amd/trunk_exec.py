@@ -16,6 +16,8 @@ from . import lib as L
 from . import ops
 
 OP_CONV, OP_BN, OP_MAXPOOL, OP_CONV_ROWS = 0, 1, 2, 3
+# DREG_SERIAL_STREAMS=1: no second stream for parameter gradients (every kernel alone on the GPU: what a per-kernel profile wants)
+SERIAL_STREAMS = bool(int(__import__("os").environ.get("DREG_SERIAL_STREAMS", "0")))
 KIND_NAMES = {0: "fwd", 1: "dgrad", 2: "wgrad"}
 
 
@@ -128,6 +130,8 @@ class TrunkExecutor:
         self.sparse_head = sparse_head
         self.with_grad = with_grad
         self.labels = self._labels()
+        if SERIAL_STREAMS:
+            self.lib.dreg_exec_set_overlap(self.h, 0)
 
     def __del__(self):
         try:
@@ -217,7 +221,7 @@ class TrunkExecutor:
         caller's stream (no second stream), so a bracket measures its kernel alone rather than two kernels sharing the CUs."""
         self._timing = bool(on)
         self.lib.dreg_exec_set_timing(self.h, int(on))
-        self.lib.dreg_exec_set_overlap(self.h, int(not on))
+        self.lib.dreg_exec_set_overlap(self.h, int(not on and not SERIAL_STREAMS))
 
     def drain_timings(self, profiler: "ops.KernelTimer"):
         """After a device synchronisation: move the executor's HIP-event records into a KernelTimer-compatible store."""
