@@ -1227,6 +1227,9 @@ int dreg_pack_conv_weights_batched(const void* descs, int n, int total_rows, int
 
 // number of voxel splits the weight-gradient kernel will use (pure function of the shape)
 static int g_force_wgrad_splits = 0;
+static int g_wgrad_target_blocks = 3072;
+// tuning knob: workgroups the automatic voxel-split choice of the weight-gradient kernels aims for
+void dreg_conv_set_wgrad_target_blocks(int blocks) { g_wgrad_target_blocks = blocks > 0 ? blocks : 3072; }
 // tuning / test knob: force the number of voxel splits of the weight-gradient kernels (0 = automatic)
 void dreg_conv_set_wgrad_splits(int splits) { g_force_wgrad_splits = splits; }
 int dreg_conv3d_wgrad_splits(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int dtype) {
@@ -1242,7 +1245,7 @@ int dreg_conv3d_wgrad_splits(int B, int Do, int Ho, int Wo, int Cin, int Cout, i
     const int bnc = (Kpad % 128 == 0) ? 128 : 64;
     const long tiles = (long)((Cout % 128 == 0) ? Cout / 128 : Cout / 64) * (Kpad / bnc);
     const long M = (long)B * Do * Ho * Wo;
-    long s = (3072 + tiles - 1) / tiles;
+    long s = (g_wgrad_target_blocks + tiles - 1) / tiles;
     // enough voxels per split that the fp32 partial tile written per block (64 KB) stays small next to its MFMA work:
     // measured optimum on MI355X is ~1024 voxels for 3^3 taps, ~512 for 1^3 (tools/bench_small_conv.py)
     const long vmin = ksz == 1 ? 512 : 1024;

@@ -23,6 +23,9 @@ def run(n):
     torch.cuda.synchronize()
     return 1e3 * (time.perf_counter() - t0) / n
 seq = sys.argv[1] if len(sys.argv) > 1 else "ADAD"
+from dreg_nerf_amd import lib as L
+if len(sys.argv) > 2:
+    L.load().dreg_conv_set_wgrad_target_blocks(int(sys.argv[2]))
 for c in seq:
     if c == "E":
         torch.cuda.empty_cache(); print("empty_cache"); continue
