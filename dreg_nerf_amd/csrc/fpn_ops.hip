@@ -603,6 +603,23 @@ __global__ void pack_rgba_kernel(const float* const* __restrict__ grids, T* __re
         else { float lo[4] = {c[0], c[1], c[2], c[3]}, hi[4] = {0.f, 0.f, 0.f, 0.f}; Gran<float>::st(reinterpret_cast<float*>(out) + i * 8, lo); Gran<float>::st(reinterpret_cast<float*>(out) + i * 8 + 4, hi); }
     }
 }
+// sparse form of the same staging: vals fp32 [N,7] (xyz | rgb | alpha) of the occupied voxels idx[n] (flat (x*Yr + y)*Zr + z) of
+// grid pt_batch[n]; out [B,Z,X,Y,8] must be zero-filled by the caller (the reference's voxel_grid.pt is zero outside the mask,
+// eval_ngp_nerf.py:397-405)
+template <typename T>
+__global__ void scatter_rgba_kernel(const float* __restrict__ vals, const int64_t* __restrict__ idx, const int* __restrict__ pt_batch,
+                                    T* __restrict__ out, int N, int Zr, int Xr, int Yr)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int64_t f = idx[n];
+    const int z = (int)(f % Zr), y = (int)((f / Zr) % Yr), x = (int)(f / ((int64_t)Zr * Yr));
+    const size_t V = (size_t)Zr * Xr * Yr, o = ((size_t)pt_batch[n] * V + ((size_t)z * Xr + x) * Yr + y) * 8;
+    const float* v = vals + (size_t)n * 7 + 3;
+    float c[8] = {v[0], v[1], v[2], v[3], 0.f, 0.f, 0.f, 0.f};
+    if constexpr (sizeof(T) == 2) Gran<bf16_t>::st(reinterpret_cast<bf16_t*>(out) + o, c);
+    else { float lo[4] = {c[0], c[1], c[2], c[3]}, hi[4] = {0.f, 0.f, 0.f, 0.f}; Gran<float>::st(reinterpret_cast<float*>(out) + o, lo); Gran<float>::st(reinterpret_cast<float*>(out) + o + 4, hi); }
+}
 // xyz[n, c] = grids[pt_batch[n]][c, z, x, y] with (x, y, z) decoded from idx[n] = (x*Yr + y)*Zr + z  (nerf_regtr.py:144-147:
 // grid[:3].permute(X, Y, Z)[mask])
 __global__ void gather_xyz_kernel(const float* const* __restrict__ grids, const int64_t* __restrict__ idx, const int* __restrict__ pt_batch,
@@ -798,6 +815,20 @@ int dreg_pack_rgba_grids(const void* grids, void* out, int B, int Z, int X, int 
     if (B <= 0 || V == 0) return DREG_OK;
     if (dtype == 0) hipLaunchKernelGGL(pack_rgba_kernel<bf16_t>, dim3(nblocks(V * B)), dim3(256), 0, (hipStream_t)stream, (const float* const*)grids, (bf16_t*)out, V, B);
     else hipLaunchKernelGGL(pack_rgba_kernel<float>, dim3(nblocks(V * B)), dim3(256), 0, (hipStream_t)stream, (const float* const*)grids, (float*)out, V, B);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// Sparse staging: out [B,Z,X,Y,8] (dtype) = zeros + rgba of the occupied voxels (vals fp32 [N,7], idx int64 [N], pt_batch int32 [N])
+int dreg_pack_rgba_sparse(const float* vals, const int64_t* idx, const int* pt_batch, void* out, int N, int B, int Z, int X, int Y,
+                          int dtype, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = (size_t)B * Z * X * Y * 8 * (dtype == 0 ? 2 : 4);
+    if (bytes == 0) return DREG_OK;
+    if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) return DREG_ELAUNCH;
+    if (N <= 0) return DREG_OK;
+    if (dtype == 0) hipLaunchKernelGGL(scatter_rgba_kernel<bf16_t>, dim3((N + 255) / 256), dim3(256), 0, st, vals, idx, pt_batch, (bf16_t*)out, N, Z, X, Y);
+    else hipLaunchKernelGGL(scatter_rgba_kernel<float>, dim3((N + 255) / 256), dim3(256), 0, st, vals, idx, pt_batch, (float*)out, N, Z, X, Y);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

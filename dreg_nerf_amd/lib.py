@@ -67,6 +67,7 @@ SIGNATURES = {
     "dreg_trilinear_gather_bwd_gather": (I, [P, P, P, P, I, P, P] + [I] * 10 + [P]),
     "dreg_add_inplace": (I, [P, P, Z, I, P]),
     "dreg_pack_rgba_grids": (I, [P, P, I, I, I, I, I, P]),
+    "dreg_pack_rgba_sparse": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "dreg_gather_grid_xyz": (I, [P, P, P, P, I, I, I, I, P]),
     # executor.hip
     "dreg_exec_create": (P, [P, I, P, I, P, I]),

@@ -233,6 +233,15 @@ class NeRFRegTr(nn.Module):
         return L.to_device_async([g.data_ptr() for g in grids], torch.int64, grids[0].device)
 
     @staticmethod
+    def pack_sparse(vals_cat, idx_cat, pb_cat, n_grids: int, res, dtype) -> torch.Tensor:
+        """Sparse blocks -> the same NDHWC [B,Z,X,Y,8] stem input (zero fill + scatter of the occupied voxels' rgba)."""
+        Z, X, Y = res
+        out = torch.empty(n_grids, Z, X, Y, 8, dtype=dtype, device=vals_cat.device)
+        L.check(L.load().dreg_pack_rgba_sparse(L.ptr(vals_cat), L.ptr(idx_cat), L.ptr(pb_cat), L.ptr(out), idx_cat.shape[0], n_grids, Z, X, Y,
+                                               L.dt_of(out), L.stream()), "dreg_pack_rgba_sparse")
+        return out
+
+    @staticmethod
     def pack_grids(grids: List[torch.Tensor], dtype, table=None) -> torch.Tensor:
         """List of [1,7,Z,X,Y] fp32 grids -> NDHWC [B,Z,X,Y,8]: rgba (channels 3:7) + 4 zero pad channels."""
         table = table if table is not None else NeRFRegTr._grid_table(grids)
@@ -249,9 +258,16 @@ class NeRFRegTr(nn.Module):
         """Everything whose size depends on the data — point coordinates, the active sets of the FPN head, the A4 voxel rounds
         (their stopping rule is per pair) — needs only the occupied voxels' coordinates, not the feature network.  All host
         syncs of a step happen here."""
-        grids, idxs = [], []
+        grids, idxs, vals = [], [], []
+        sparse = all((s + "_sparse") in d for d in batch for s in ("src", "tgt"))
         for i, d in enumerate(batch):
             for j, side in enumerate(("src", "tgt")):
+                if sparse:   # dataset.SparseBlock: (idx int64 [N], vals fp32 [N,7], (Z,X,Y)) — the dense grid is zero elsewhere
+                    sb = d[side + "_sparse"]
+                    idxs.append(sb.idx)
+                    vals.append(sb.vals)
+                    grids.append(sb.res)
+                    continue
                 g = d[side + "_xyz_rgba"]
                 if g.dim() == 6:
                     g = g.squeeze(0)
@@ -260,13 +276,17 @@ class NeRFRegTr(nn.Module):
                     m = m.squeeze(0)
                 grids.append(g)
                 idxs.append(m)
-        res = tuple(grids[0].shape[-3:])
+        res = tuple(grids[0]) if sparse else tuple(grids[0].shape[-3:])
         counts = [int(m.shape[0]) for m in idxs]
         idx_cat = torch.cat(idxs).contiguous()
         pb_cat = torch.repeat_interleave(torch.arange(len(idxs), dtype=torch.int32, device=dev), L.to_device_async(counts, torch.int64, dev),
                                          output_size=sum(counts))
-        table = self._grid_table(grids)
-        if table is not None:   # one gather launch for all grids
+        table = None if sparse else self._grid_table(grids)
+        if sparse:
+            vals_cat = torch.cat(vals).contiguous().float()
+            xyz_cat = vals_cat[:, :3].contiguous()
+            grids = (vals_cat, len(idxs))     # what pack_grids needs in the sparse form
+        elif table is not None:   # one gather launch for all grids
             xyz_cat = torch.empty(idx_cat.shape[0], 3, dtype=torch.float32, device=dev)
             L.check(L.load().dreg_gather_grid_xyz(L.ptr(table), L.ptr(idx_cat), L.ptr(pb_cat), L.ptr(xyz_cat), idx_cat.shape[0], *res, L.stream()),
                     "dreg_gather_grid_xyz")
@@ -308,6 +328,8 @@ class NeRFRegTr(nn.Module):
             grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs, table = geo
             # these were allocated on the side stream and are consumed on the main one
             keep = [idx_cat, pb_cat] + list(pts_l) + ([rows[0], rows[3]] if rows is not None else []) + ([table] if table is not None else [])
+            if isinstance(grids, tuple):
+                keep.append(grids[0])
             if rows is not None and len(rows) >= 6:
                 keep.append(rows[4])
             for rounds in plans:
@@ -317,7 +339,11 @@ class NeRFRegTr(nn.Module):
                 t.record_stream(main)
         else:
             grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs, table = self._geometry(batch, dev)
-        p1 = self.fpn(self.pack_grids(grids, self.act_dtype, table), rows)
+        if isinstance(grids, tuple):   # sparse input form
+            x_in = self.pack_sparse(grids[0], idx_cat, pb_cat, grids[1], res, self.act_dtype)
+        else:
+            x_in = self.pack_grids(grids, self.act_dtype, table)
+        p1 = self.fpn(x_in, rows)
         feats = ops.trilinear_gather(p1, idx_cat, pb_cat, res, *((rows[0], rows[3]) if rows is not None else ()))
         P = self._P()
         off = 0

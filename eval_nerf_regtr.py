@@ -28,7 +28,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     split = "test"
     ds = SyntheticRegDataset(cfg.synthetic, cfg.synthetic_res, split) if cfg.synthetic > 0 else \
-        NeRFRegDataset(cfg.root_dir, cfg.json_dir, cfg.dataset, split)
+        NeRFRegDataset(cfg.root_dir, cfg.json_dir, cfg.dataset, split, sparse=True, device=dev)
     model = NeRFRegTr(cfg.position_embedding_type, cfg.position_embedding_dim, cfg.position_embedding_scaling,
                       cfg.num_downsample, precision=cfg.precision).to(dev).eval()
     ckpt_path = cfg.ckpt_path or os.path.join(cfg.root_dir, "out", cfg.expname, "model.pth")

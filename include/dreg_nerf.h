@@ -140,6 +140,10 @@ int dreg_add_inplace(void* dst, const void* src, size_t n, int dtype, void* stre
  * pack: -> [B,Z,X,Y,8] (dtype) = rgba + 4 zero channels, the NDHWC stem input.  gather: xyz fp32 [N,3] of the occupied voxels
  * (idx int64 [N] = (x*Yr + y)*Zr + z, pt_batch int32 [N]). */
 int dreg_pack_rgba_grids(const void* grids, void* out, int B, int Z, int X, int Y, int dtype, void* stream);
+/* sparse form (conerf/datasets/register/dataset.py:221-331 keeps dense 58.7 MB grids; they are zero outside voxel_mask.pt):
+ * vals fp32 [N,7] of the occupied voxels idx[n] of grid pt_batch[n] -> zero-filled [B,Z,X,Y,8] + their rgba */
+int dreg_pack_rgba_sparse(const float* vals, const int64_t* idx, const int* pt_batch, void* out, int N, int B, int Z, int X,
+                          int Y, int dtype, void* stream);
 int dreg_gather_grid_xyz(const void* grids, const int64_t* idx, const int* pt_batch, float* xyz, int N, int Zr, int Xr, int Yr,
                          void* stream);
 

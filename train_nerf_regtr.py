@@ -56,8 +56,8 @@ def main():
     if cfg.synthetic > 0:
         train_ds, val_ds = SyntheticRegDataset(cfg.synthetic, cfg.synthetic_res, "train"), SyntheticRegDataset(max(2, cfg.synthetic // 4), cfg.synthetic_res, "test")
     else:
-        train_ds = NeRFRegDataset(cfg.root_dir, cfg.json_dir, cfg.dataset, "train")
-        val_ds = NeRFRegDataset(cfg.root_dir, cfg.json_dir, cfg.dataset, "test")
+        train_ds = NeRFRegDataset(cfg.root_dir, cfg.json_dir, cfg.dataset, "train", sparse=True, device=dev)
+        val_ds = NeRFRegDataset(cfg.root_dir, cfg.json_dir, cfg.dataset, "test", sparse=True, device=dev)
     model = NeRFRegTr(cfg.position_embedding_type, cfg.position_embedding_dim, cfg.position_embedding_scaling,
                       cfg.num_downsample, precision=cfg.precision).to(dev).train()
     if world > 1:
