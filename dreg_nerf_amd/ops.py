@@ -3,6 +3,7 @@
 Activations are NDHWC tensors ``[B, D, H, W, C]`` in bf16 (production) or fp32 (exact-f32 MFMA parity
 mode).  Master weights stay fp32 in torch layout; the kernels consume per-step packed copies.
 """
+import os
 from typing import Optional
 
 import torch
@@ -641,7 +642,7 @@ class TrilinearGatherFn(torch.autograd.Function):
         lib = L.load()
         B, d, h, w, C = shape
         gout = gout.contiguous().float()
-        if rows1 is not None:  # active set: compact fp32 accumulation on S1, one cast-scatter into the zero-filled gradient
+        if rows1 is not None and ((C % 64 == 0 and C <= 256) or map1 is not None):  # per consumed coarse voxel (S1): gather form, else compact atomics
             g = torch.empty(shape, dtype=dtype, device=gout.device)
             if C % 64 == 0 and C <= 256:   # atomic-free gather per S1 voxel: deterministic
                 fmap = torch.empty(B * Zr * Xr * Yr, dtype=torch.int32, device=gout.device)

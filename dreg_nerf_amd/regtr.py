@@ -298,6 +298,9 @@ class NeRFRegTr(nn.Module):
         rows = None
         if self.active_set and self.precision == "bf16":
             rows = ops.active_sets(idxs, res, tuple((r + 1) // 2 for r in res), dev, pt_batch=pb_cat, idx_cat=idx_cat)
+        # the gather backward is evaluated per consumed coarse voxel (S1) in every mode: atomic-free, deterministic
+        s1_rows = rows[0] if rows is not None else \
+            ops.active_sets(idxs, res, tuple((r + 1) // 2 for r in res), dev, pt_batch=pb_cat, idx_cat=idx_cat, density_cap=1.0, level2=False)[0]
         plans, pts_l, segs = [], [], []
         for i in range(len(batch)):
             ns, nt = idxs[2 * i].shape[0], idxs[2 * i + 1].shape[0]
@@ -305,7 +308,7 @@ class NeRFRegTr(nn.Module):
             plans.append(rounds)
             pts_l.append(pts)
             segs.append((int(lens[0]), int(lens[1])))
-        return grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs, table
+        return grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs, table, s1_rows
 
     def forward_batch(self, batch: List[dict]) -> List[dict]:
         """Each element: the reference's ``data`` dict for one pair.  Returns one output dict per pair.
@@ -325,9 +328,9 @@ class NeRFRegTr(nn.Module):
             with torch.cuda.stream(side):
                 geo = self._geometry(batch, dev)
             main.wait_stream(side)
-            grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs, table = geo
+            grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs, table, s1_rows = geo
             # these were allocated on the side stream and are consumed on the main one
-            keep = [idx_cat, pb_cat] + list(pts_l) + ([rows[0], rows[3]] if rows is not None else []) + ([table] if table is not None else [])
+            keep = [idx_cat, pb_cat, s1_rows] + list(pts_l) + ([rows[0], rows[3]] if rows is not None else []) + ([table] if table is not None else [])
             if isinstance(grids, tuple):
                 keep.append(grids[0])
             if rows is not None and len(rows) >= 6:
@@ -338,13 +341,13 @@ class NeRFRegTr(nn.Module):
             for t in keep:
                 t.record_stream(main)
         else:
-            grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs, table = self._geometry(batch, dev)
+            grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs, table, s1_rows = self._geometry(batch, dev)
         if isinstance(grids, tuple):   # sparse input form
             x_in = self.pack_sparse(grids[0], idx_cat, pb_cat, grids[1], res, self.act_dtype)
         else:
             x_in = self.pack_grids(grids, self.act_dtype, table)
         p1 = self.fpn(x_in, rows)
-        feats = ops.trilinear_gather(p1, idx_cat, pb_cat, res, *((rows[0], rows[3]) if rows is not None else ()))
+        feats = ops.trilinear_gather(p1, idx_cat, pb_cat, res, s1_rows, rows[3] if rows is not None else None)
         P = self._P()
         off = 0
         feat_l = []

@@ -87,3 +87,33 @@ def test_executor_eval_mode_and_no_grad():
         m.native_trunk = True
         b = m.fpn(x, None).clone()
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shell", [(0.3, 0.34), (0.55, 0.8)], ids=["active-set", "dense-head"])
+def test_training_steps_are_bitwise_reproducible(shell):
+    """Two runs of the same three optimizer steps (executor, geometry stream, second stream for the parameter gradients, fused
+    losses — every reduction is deterministic) end in bit-identical parameters; a stream-ordering bug would show up here."""
+    from dreg_nerf_amd.train_step import TrainStep
+
+    def run():
+        torch.manual_seed(7)
+        m = NeRFRegTr(precision="bf16").to(DEV).train()
+        ts = TrainStep(m)
+        batch = []
+        for i in range(2):
+            d = {"pose": synth.fixed_pose()[None].clone(), "src_nerf_path": "", "tgt_nerf_path": ""}
+            for j, side in enumerate(("src", "tgt")):
+                g, mk = synth.shell_grid(64, 20 + 2 * i + j, *shell)
+                d[side + "_xyz_rgba"], d[side + "_mask"] = g.permute(3, 2, 0, 1).unsqueeze(0).contiguous(), mk
+            batch.append({k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in d.items()})
+        losses = []
+        for _ in range(3):
+            out = ts.step(batch)
+            losses.append(float(out["losses"]["total"]))
+        torch.cuda.synchronize()
+        return ts.optimizer.flat_p.clone(), losses
+
+    p1, l1 = run()
+    p2, l2 = run()
+    assert all(np.isfinite(l1)) and l1 == l2
+    assert torch.equal(p1, p2)
