@@ -7,7 +7,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdreg_nerf_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+# -fno-slp-vectorize / -fno-vectorize: keep packed-fp32 VALU instructions (v_pk_{add,mul,fma}_f32) out of the device code.  On this
+# hardware a v_pk_*_f32 in one wave returned a wrong low element in lanes 48..63 while the implicit-GEMM kernels ran on a second
+# stream of the same CU (tools/hw_probe, DESIGN.md "co-execution"); every kernel here may share a CU with the executor's
+# weight-gradient stream, so none of them may contain one.  tests/test_abi_and_ddp.py checks the built code objects.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-vectorize"]
 
 
 def sources():
@@ -37,6 +41,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     return LIB
+
+
+def device_disassembly(obj: str) -> str:
+    """Disassembly of the gfx950 code object bundled in one compiled .o (used by the packed-fp32 check)."""
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    with tempfile.TemporaryDirectory() as td:
+        import shutil
+        local = os.path.join(td, "unit.o")
+        shutil.copy(obj, local)
+        subprocess.check_output([os.path.join(llvm, "llvm-objdump"), "--offloading", local], stderr=subprocess.STDOUT)   # extracts next to it
+        co = [f for f in os.listdir(td) if "amdgcn" in f]
+        if not co:
+            return ""                                        # host-only translation unit (executor.hip)
+        return subprocess.check_output([os.path.join(llvm, "llvm-objdump"), "-d", os.path.join(td, co[0])], text=True)
 
 
 if __name__ == "__main__":

@@ -59,11 +59,10 @@ class TrainStep:
         self.finetune = finetune
         self.label_fn = label_fn or _default_labels
         self.fused_losses = fused_losses
-        # Second stream for the weight / bias gradients of the point-set half's linear layers (Conv3dFn.backward).  OFF by default:
-        # it is worth ~1 ms per step, but runs of the same steps then end in parameters that differ in the last bits (the
-        # trunk executor's second stream does not show this; tools/nondet_steps.py bisects it to a linear layer's weight gradient
-        # overlapping the LayerNorm backward that follows it — root cause not found in round 1).  DREG_PG_STREAM=1 enables it.
-        self.overlap_param_grads = bool(int(os.environ.get("DREG_PG_STREAM", "0"))) and not bool(int(os.environ.get("DREG_SERIAL_STREAMS", "0")))
+        # Second stream for the weight / bias gradients of the point-set half's linear layers (Conv3dFn.backward), ~1.3 ms per step.
+        # (It exposed the packed-fp32 co-execution fault described in DESIGN.md; the library is built without those instructions
+        # and steps are bitwise reproducible with it: tests/test_hip_trunk_exec.py.)  DREG_PG_STREAM=0 turns it off.
+        self.overlap_param_grads = bool(int(os.environ.get("DREG_PG_STREAM", "1"))) and not bool(int(os.environ.get("DREG_SERIAL_STREAMS", "0")))
         self._pg_stream = None
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.last_losses = None

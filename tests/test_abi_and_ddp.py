@@ -36,6 +36,23 @@ def test_library_exports_every_declared_symbol():
     assert set(lib.declared_symbols()) == syms
 
 
+def test_device_code_has_no_packed_fp32_instructions():
+    """v_pk_*_f32 returned wrong lanes next to the implicit-GEMM kernels of a second stream (DESIGN.md "co-execution",
+    tools/hw_probe); the build flags keep them out of every code object and this pins it."""
+    from dreg_nerf_amd import build
+    build.build(verbose=False)
+    checked = 0
+    for src in build.sources():
+        asm = build.device_disassembly(src[:-4] + ".o")
+        if not asm:
+            continue                                         # host-only translation unit
+        assert "s_endpgm" in asm, src
+        checked += 1
+        hits = re.findall(r"v_pk_(?:add|mul|fma|mov)_f32", asm)
+        assert not hits, f"{os.path.basename(src)}: {len(hits)} packed-fp32 instructions"
+    assert checked >= 7
+
+
 def test_product_path_fails_loudly_without_library(monkeypatch):
     from dreg_nerf_amd import lib
     monkeypatch.setattr(lib, "_lib", None)
