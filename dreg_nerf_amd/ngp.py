@@ -186,6 +186,57 @@ def sh4(d: torch.Tensor) -> torch.Tensor:
         0.59004358992664352 * x * (-x2 + 3.0 * y2)], dim=-1)
 
 
+class OccupancyGrid(nn.Module):
+    """State holder for a nerfacc 0.3.5 ``OccupancyGrid`` (the 'occupancy_grid' entry of a NeRF block checkpoint,
+    train_ngp_nerf.py:196; constructed as in conerf/loss/confidence_loss.py:42-46).  Persistent buffers of the original: _roi_aabb
+    fp32 [6], resolution int32 [3], occs fp32 [res^3] (the EMA densities), _binary bool [res,res,res].  Training the grid
+    (every_n_step) belongs to NeRF training, which is out of scope; the registration path only reads ``binary``."""
+    NUM_DIM = 3
+    _NON_PERSISTENT = ("grid_coords", "grid_indices")   # written by some nerfacc builds, rebuilt on construction there
+
+    def __init__(self, roi_aabb, resolution=128, contraction_type=ContractionType.AABB):
+        super().__init__()
+        if isinstance(resolution, int):
+            resolution = [resolution] * 3
+        resolution = torch.as_tensor(resolution, dtype=torch.int32).clone()
+        roi_aabb = torch.as_tensor(roi_aabb, dtype=torch.float32).clone()
+        assert resolution.shape == (3,), f"Invalid shape: {resolution.shape}"
+        assert roi_aabb.shape == (6,), f"Invalid shape: {roi_aabb.shape}"
+        self.num_cells = int(resolution.prod().item())
+        self.register_buffer("_roi_aabb", roi_aabb)
+        self.register_buffer("resolution", resolution)
+        self.register_buffer("occs", torch.zeros(self.num_cells))
+        self.register_buffer("_binary", torch.zeros(resolution.tolist(), dtype=torch.bool))
+        self._contraction_type = contraction_type
+
+    @property
+    def roi_aabb(self):
+        return self._roi_aabb
+
+    @property
+    def binary(self):
+        return self._binary
+
+    @property
+    def contraction_type(self):
+        return self._contraction_type
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        sd = {k: v for k, v in state_dict.items() if k not in self._NON_PERSISTENT}
+        return super().load_state_dict(sd, strict=strict)
+
+    @torch.no_grad()
+    def query_occ(self, samples: torch.Tensor) -> torch.Tensor:
+        """Occupancy of world points [N,3] (False outside the aabb): nerfacc's grid query for ContractionType.AABB."""
+        lo, hi = self._roi_aabb[:3], self._roi_aabb[3:]
+        u = (samples - lo) / (hi - lo)
+        inside = ((u >= 0) & (u < 1)).all(dim=-1)
+        res = self.resolution.to(samples.device)
+        ijk = (u * res).long().clamp_(min=torch.zeros_like(res, dtype=torch.long), max=(res - 1).long())
+        flat = (ijk[:, 0] * res[1] + ijk[:, 1]) * res[2] + ijk[:, 2]
+        return self._binary.reshape(-1)[flat] & inside
+
+
 class SampleGrid(nn.Module):
     NUM_DIM = 3
 

@@ -7,6 +7,8 @@ cached per path."""
 import ctypes
 from typing import Dict, List
 
+import os
+
 import torch
 
 from . import lib as L
@@ -20,16 +22,19 @@ def load_block(path: str, device):
     (keys: train_ngp_nerf.py:187-209)."""
     key = (path, str(device))
     if key not in _block_cache:
-        ngp.install_pickle_shims()
-        state = torch.load(path, map_location="cpu", weights_only=False)
-        field = ngp.NGPradianceField(state["aabb"], unbounded=bool(state.get("unbounded", False)))
-        field.load_state_dict(state["model"], strict=False)
+        from .checkpoint import CheckPointManager
+        # the reference's two-pass load (conerf/loss/confidence_loss.py:25-50): meta data first, then the modules built from it
+        meta = {k: None for k in ("aabb", "unbounded", "grid_resolution", "contraction_type", "render_step_size", "alpha_thre",
+                                  "cone_angle", "camera_poses")}
+        mgr = CheckPointManager(verbose=False)
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        mgr.load_no_config(ckpt_path=path, meta_data=meta, map_location="cpu")
+        field = ngp.NGPradianceField(meta["aabb"], unbounded=bool(meta["unbounded"]))
+        occ = ngp.OccupancyGrid(meta["aabb"], meta["grid_resolution"], meta["contraction_type"])
+        mgr.load_no_config(ckpt_path=path, models={"model": field, "occupancy_grid": occ}, map_location="cpu")
         field = field.to(device).eval()
-        res = int(state.get("grid_resolution", 128))
-        occ = state["occupancy_grid"]
-        binary = (occ["_binary"] if "_binary" in occ else occ["binary"]).view(res, res, res).to(device)
-        meta = {k: state[k] for k in ("aabb", "render_step_size", "cone_angle", "alpha_thre", "camera_poses") if k in state}
-        _block_cache[key] = (field, binary, meta)
+        _block_cache[key] = (field, occ.binary.to(device), {k: meta[k] for k in ("aabb", "render_step_size", "cone_angle", "alpha_thre", "camera_poses")})
     return _block_cache[key]
 
 

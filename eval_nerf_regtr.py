@@ -32,7 +32,8 @@ def main():
     model = NeRFRegTr(cfg.position_embedding_type, cfg.position_embedding_dim, cfg.position_embedding_scaling,
                       cfg.num_downsample, precision=cfg.precision).to(dev).eval()
     ckpt_path = cfg.ckpt_path or os.path.join(cfg.root_dir, "out", cfg.expname, "model.pth")
-    CheckPointManager(verbose=rank == 0).load(ckpt_path, models={"model": model}, map_location=dev)
+    if CheckPointManager(verbose=rank == 0).load_no_config(ckpt_path, models={"model": model}, map_location=dev) == 0 and not os.path.exists(ckpt_path):
+        print(f"[WARNING] no checkpoint at {ckpt_path}: evaluating random-init weights", flush=True)
     rows = {}
     with torch.no_grad():
         for i in range(rank, len(ds), world):

@@ -8,21 +8,25 @@ import os
 import torch
 
 from dreg_nerf_amd import ngp
+from dreg_nerf_amd.checkpoint import CheckPointManager
 from dreg_nerf_amd.config import config_parser
 
 
 @torch.no_grad()
 def extract_block(ckpt_path: str, dev, density_thre: float = 0.7):
-    ngp.install_pickle_shims()
-    state = torch.load(ckpt_path, map_location="cpu", weights_only=False)
-    field = ngp.NGPradianceField(state["aabb"], unbounded=bool(state.get("unbounded", False)))
-    field.load_state_dict(state["model"], strict=False)
+    # the reference's two-pass load (eval_ngp_nerf.py:63-115): meta data, then the modules constructed from it
+    meta = {k: None for k in ("aabb", "unbounded", "grid_resolution", "contraction_type", "near_plane", "far_plane",
+                              "render_step_size", "alpha_thre", "cone_angle", "camera_poses")}
+    mgr = CheckPointManager(verbose=False)
+    mgr.load_no_config(ckpt_path, meta_data=meta, map_location="cpu")
+    field = ngp.NGPradianceField(meta["aabb"], unbounded=bool(meta["unbounded"]))
+    occ = ngp.OccupancyGrid(meta["aabb"], meta["grid_resolution"], meta["contraction_type"])
+    mgr.load_no_config(ckpt_path, models={"model": field, "occupancy_grid": occ}, map_location="cpu")
     field = field.to(dev).eval()
-    res = int(state.get("grid_resolution", 128))
-    occ = state["occupancy_grid"]
-    binary = occ["_binary"] if "_binary" in occ else occ["binary"]
-    sg = ngp.SampleGrid(state["aabb"], res, state.get("contraction_type", ngp.ContractionType.AABB)).to(dev)
-    sg.set_binary_fields(binary.to(dev).view(res, res, res))
+    sg = ngp.SampleGrid(meta["aabb"], meta["grid_resolution"], meta["contraction_type"]).to(dev)
+    sg.set_binary_fields(occ.binary.to(dev))
+    res = int(sg.resolution[0])
+    state = meta
     world, rgb, alpha, idx, dmask, smask = sg.query_radiance_and_density_from_camera(field, None, state, dev, density_thre)
     grid, mask = ngp.build_voxel_grid(world, rgb, alpha, idx, dmask & smask, res)
     ngp.save_voxel_grid(os.path.dirname(ckpt_path), grid, mask)

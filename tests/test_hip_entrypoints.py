@@ -31,6 +31,12 @@ def test_train_then_eval_synthetic(tmp_path):
     assert "R_mean" in m and "t_mean" in m and "shell_0000" in m and set(m["shell_0000"]) == {"R_mean", "t_mean", "R_med", "t_med", "time"}
 
 
+def _occ_state(ngp, binary, res):
+    occ = ngp.OccupancyGrid([-1.5] * 3 + [1.5] * 3, res)      # the four persistent buffers a nerfacc 0.3.5 grid stores
+    occ._binary.copy_(binary)
+    return occ.state_dict()
+
+
 def test_grid_extraction_from_block_checkpoint(tmp_path):
     from dreg_nerf_amd import ngp
     res = 32
@@ -45,7 +51,7 @@ def test_grid_extraction_from_block_checkpoint(tmp_path):
     binary = torch.rand(res, res, res, generator=torch.Generator().manual_seed(1)) < 0.05
     cam_poses = torch.eye(4)[None].repeat(6, 1, 1)   # six cameras around the block, outside the aabb
     cam_poses[:, :3, 3] = torch.tensor([[2.5, 0, 0], [-2.5, 0, 0], [0, 2.5, 0], [0, -2.5, 0], [0, 0, 2.5], [0, 0, -2.5]])
-    torch.save({"step": 1, "model": f.state_dict(), "occupancy_grid": {"_binary": binary, "resolution": torch.tensor([res] * 3)},
+    torch.save({"step": 1, "model": f.state_dict(), "occupancy_grid": _occ_state(ngp, binary, res),
                 "aabb": [-1.5] * 3 + [1.5] * 3, "unbounded": False, "grid_resolution": res,
                 "contraction_type": ngp.ContractionType.AABB, "render_step_size": 0.005, "alpha_thre": 0.0, "cone_angle": 0.0,
                 "camera_poses": cam_poses, "block_id": 0}, str(d / "model.pth"))

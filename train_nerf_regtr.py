@@ -69,10 +69,11 @@ def main():
     if rank == 0:
         os.makedirs(save_dir, exist_ok=True)
     models = {"model": model, "feature_loss": ts.feature_loss}
-    start = CheckPointManager(save_dir, verbose=rank == 0).load(
-        cfg.ckpt_path or None, models=models,
-        optimizers=None if cfg.no_load_opt else {"optimizer": ts.optimizer},
-        schedulers=None if cfg.no_load_scheduler else {"scheduler": ts.scheduler}, map_location=dev)
+    loader = CheckPointManager(verbose=rank == 0)     # every rank reads; only rank 0 owns the index file and writes
+    loader.set_save_path(save_dir)
+    start = loader.load(cfg, models=models,
+                        optimizers=None if cfg.no_load_opt else {"optimizer": ts.optimizer},
+                        schedulers=None if cfg.no_load_scheduler else {"scheduler": ts.scheduler}, map_location=dev)
     iteration = 0 if cfg.finetune else start
     per_step = cfg.pairs_per_step
     log = open(os.path.join(save_dir, "log.txt"), "a") if rank == 0 else None
@@ -96,11 +97,11 @@ def main():
                 score, r, t = validate(model, val_ds, dev)
                 print(f"val it {iteration}: R_mean={r:.3f} t_mean={t:.4f}", flush=True)
             if iteration % cfg.n_checkpoint == 0 and rank == 0:
-                ckpt.save(iteration, models=models, optimizers={"optimizer": ts.optimizer}, schedulers={"scheduler": ts.scheduler}, score=score)
+                ckpt.save(models, {"optimizer": ts.optimizer}, iteration, schedulers={"scheduler": ts.scheduler}, score=score)
     if rank == 0:
         score, r, t = validate(model, val_ds, dev)
         print(f"final val: R_mean={r:.3f} t_mean={t:.4f}", flush=True)
-        ckpt.save(iteration, models=models, optimizers={"optimizer": ts.optimizer}, schedulers={"scheduler": ts.scheduler}, score=score)
+        ckpt.save(models, {"optimizer": ts.optimizer}, iteration, schedulers={"scheduler": ts.scheduler}, score=score)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
