@@ -15,7 +15,7 @@ from dreg_nerf_amd.config import config_parser
 @torch.no_grad()
 def extract_block(ckpt_path: str, dev, density_thre: float = 0.7):
     # the reference's two-pass load (eval_ngp_nerf.py:63-115): meta data, then the modules constructed from it
-    meta = {k: None for k in ("aabb", "unbounded", "grid_resolution", "contraction_type", "near_plane", "far_plane",
+    meta = {k: None for k in ("aabb", "unbounded", "grid_resolution", "contraction_type",
                               "render_step_size", "alpha_thre", "cone_angle", "camera_poses")}
     mgr = CheckPointManager(verbose=False)
     mgr.load_no_config(ckpt_path, meta_data=meta, map_location="cpu")

@@ -52,7 +52,7 @@ def test_grid_extraction_from_block_checkpoint(tmp_path):
     cam_poses = torch.eye(4)[None].repeat(6, 1, 1)   # six cameras around the block, outside the aabb
     cam_poses[:, :3, 3] = torch.tensor([[2.5, 0, 0], [-2.5, 0, 0], [0, 2.5, 0], [0, -2.5, 0], [0, 0, 2.5], [0, 0, -2.5]])
     torch.save({"step": 1, "model": f.state_dict(), "occupancy_grid": _occ_state(ngp, binary, res),
-                "aabb": [-1.5] * 3 + [1.5] * 3, "unbounded": False, "grid_resolution": res,
+                "aabb": [-1.5] * 3 + [1.5] * 3, "unbounded": False, "near_plane": None, "far_plane": None, "grid_resolution": res,
                 "contraction_type": ngp.ContractionType.AABB, "render_step_size": 0.005, "alpha_thre": 0.0, "cone_angle": 0.0,
                 "camera_poses": cam_poses, "block_id": 0}, str(d / "model.pth"))
     _run(["eval_ngp_nerf.py", "--root_dir", str(tmp_path), "--dataset", "objaverse", "--multi_blocks"])

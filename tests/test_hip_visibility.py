@@ -50,7 +50,7 @@ def test_compute_visibility_score_from_checkpoint(tmp_path):
     path = str(tmp_path / "model.pth")
     occ = ngp.OccupancyGrid(AABB, res)
     occ._binary.copy_(binary)
-    torch.save({"step": 1, "model": f.state_dict(), "occupancy_grid": occ.state_dict(), "aabb": AABB, "unbounded": False,
+    torch.save({"step": 1, "model": f.state_dict(), "occupancy_grid": occ.state_dict(), "aabb": AABB, "unbounded": False, "near_plane": None, "far_plane": None,
                 "grid_resolution": res, "contraction_type": ngp.ContractionType.AABB, "render_step_size": 0.02,
                 "alpha_thre": 0.0, "cone_angle": 0.0, "camera_poses": poses, "block_id": 0}, path)
     xyz = (torch.rand(6, 50, 3, generator=g) - 0.5).to(DEV) * 2
