@@ -106,20 +106,20 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(
     }
 }
 
-// one wave per channel: finalise mean / biased var per grid (lanes stride over the chunk partials), update running stats
-// sequentially over the grids (reference: one grid per BatchNorm call, src then tgt — nerf_regtr.py:135), emit scale/shift
-// and (mean, rstd).
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma, const float* __restrict__ beta,
+// one block per channel, one wave per grid: finalise mean / biased var (lanes stride over the chunk partials, all loads of a
+// wave in flight at once), emit scale/shift and (mean, rstd); thread 0 then updates the running stats sequentially over the grids
+// (reference: one grid per BatchNorm call, src then tgt — nerf_regtr.py:135).
+constexpr int BN_MAX_GRIDS = 256;
+__global__ __launch_bounds__(512) void bn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ scale_shift, float* __restrict__ mean_rstd,
                                    int B, int nchunks, int C, int V, float eps, float momentum, int train)
 {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (c >= C) return;
+    const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const float ga = gamma[c], be = beta[c];
     if (!train) {
         const float rstd = 1.0f / sqrtf(running_var[c] + eps);
-        for (int b = lane; b < B; b += 64) {
+        for (int b = threadIdx.x; b < B; b += blockDim.x) {
             scale_shift[((size_t)b * C + c) * 2] = ga * rstd;
             scale_shift[((size_t)b * C + c) * 2 + 1] = be - running_mean[c] * ga * rstd;
             mean_rstd[((size_t)b * C + c) * 2] = running_mean[c];
@@ -127,29 +127,38 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         }
         return;
     }
-    float rm = running_mean[c], rv = running_var[c];
-    for (int b = 0; b < B; ++b) {
+    __shared__ double stat[BN_MAX_GRIDS][2];
+    for (int b = wave; b < B; b += nw) {
         double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
         for (int k = lane; k < nchunks; k += 64) {
-            const float* p = partial + (((size_t)b * nchunks + k) * C + c) * 2;
-            s1 += p[0]; s2 += p[1];
+            const float2 p = *reinterpret_cast<const float2*>(partial + (((size_t)b * nchunks + k) * C + c) * 2);
+            s1 += p.x; s2 += p.y;
         }
         s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
         const double mean = s1 / V;
         double var = s2 / V - mean * mean;
         if (var < 0) var = 0;
-        const float rstd = 1.0f / sqrtf((float)var + eps);
         if (lane == 0) {
+            const float rstd = 1.0f / sqrtf((float)var + eps);
             scale_shift[((size_t)b * C + c) * 2] = ga * rstd;
             scale_shift[((size_t)b * C + c) * 2 + 1] = be - (float)mean * ga * rstd;
             mean_rstd[((size_t)b * C + c) * 2] = (float)mean;
             mean_rstd[((size_t)b * C + c) * 2 + 1] = rstd;
+            stat[b][0] = mean; stat[b][1] = var;
         }
-        const float unbiased = V > 1 ? (float)(var * V / (V - 1)) : (float)var;
-        rm = (1.f - momentum) * rm + momentum * (float)mean;
-        rv = (1.f - momentum) * rv + momentum * unbiased;
     }
-    if (lane == 0) { running_mean[c] = rm; running_var[c] = rv; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float rm = running_mean[c], rv = running_var[c];
+        for (int b = 0; b < B; ++b) {
+            const double mean = stat[b][0], var = stat[b][1];
+            const float unbiased = V > 1 ? (float)(var * V / (V - 1)) : (float)var;
+            rm = (1.f - momentum) * rm + momentum * (float)mean;
+            rv = (1.f - momentum) * rv + momentum * unbiased;
+        }
+        running_mean[c] = rm; running_var[c] = rv;
+    }
 }
 
 // y = [relu]( x * scale[b,c] + shift[b,c] [+ res] )
@@ -176,27 +185,31 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
     }
 }
 
-// backward finalize (one wave per channel): per (b,c) coefficients c1 = sum(g)/V, c2 = sum(g*xhat)/V; dgamma/dbeta summed over grids.
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ coef, float* __restrict__ dgamma,
+// backward finalize (one block per channel, one wave per grid): per (b,c) coefficients c1 = sum(g)/V, c2 = sum(g*xhat)/V;
+// dgamma/dbeta summed over the grids in order by thread 0.
+__global__ __launch_bounds__(512) void bn_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ coef, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, int B, int nchunks, int C, int V, int accumulate)
 {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (c >= C) return;
-    double dg = 0.0, db = 0.0;
-    for (int b = 0; b < B; ++b) {
+    const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    __shared__ double stat[BN_MAX_GRIDS][2];
+    for (int b = wave; b < B; b += nw) {
         double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
         for (int k = lane; k < nchunks; k += 64) {
-            const float* p = partial + (((size_t)b * nchunks + k) * C + c) * 2;
-            s1 += p[0]; s2 += p[1];
+            const float2 p = *reinterpret_cast<const float2*>(partial + (((size_t)b * nchunks + k) * C + c) * 2);
+            s1 += p.x; s2 += p.y;
         }
         s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
         if (lane == 0) {
             coef[((size_t)b * C + c) * 2] = (float)(s1 / V);
             coef[((size_t)b * C + c) * 2 + 1] = (float)(s2 / V);
+            stat[b][0] = s1; stat[b][1] = s2;
         }
-        db += s1; dg += s2;
     }
-    if (lane == 0) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double dg = 0.0, db = 0.0;
+        for (int b = 0; b < B; ++b) { db += stat[b][0]; dg += stat[b][1]; }
         dgamma[c] = accumulate ? dgamma[c] + (float)dg : (float)dg;
         dbeta[c] = accumulate ? dbeta[c] + (float)db : (float)db;
     }
@@ -231,6 +244,93 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
             xv[k] = scale_shift[pc + 2 * k] * (gv[k] - coef[pc + 2 * k] - xh * coef[pc + 2 * k + 1]);
         }
         Gran<T>::st(dx + i * G, xv);
+    }
+}
+
+// Column-fixed forms of the two apply kernels (grid (chunks, B, slabs) like bn_partial_kernel): a thread keeps ONE channel granule,
+// holds that granule's per-channel parameters in registers and walks down the rows of its chunk, UN rows in flight.  (The flat
+// forms above re-load 2-6 parameter floats per element on every iteration, which made them instruction- rather than HBM-bound.)
+template <typename T, int UN>
+__global__ __launch_bounds__(256) void bn_apply_cols_kernel(const T* __restrict__ x, const float* __restrict__ scale_shift, const T* __restrict__ res,
+                                                            T* __restrict__ y, int V, int C, int rows_per_chunk, int relu)
+{
+    constexpr int G = Gran<T>::G;
+    const int CG = C / G, cgs = CG < 256 ? CG : 256, rpi = 256 / cgs;
+    const int t = threadIdx.x, cg = blockIdx.z * cgs + (t % cgs), r0 = t / cgs, b = blockIdx.y;
+    if (r0 >= rpi || cg >= CG) return;
+    const int v0 = blockIdx.x * rows_per_chunk, v1 = min(v0 + rows_per_chunk, V);
+    float sc[G], sh[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) { sc[i] = scale_shift[((size_t)b * C + cg * G + i) * 2]; sh[i] = scale_shift[((size_t)b * C + cg * G + i) * 2 + 1]; }
+    for (int v = v0 + r0; v < v1; v += rpi * UN) {
+        float xv[UN][G], rv[UN][G];
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (v + u * rpi < v1) {
+                const size_t off = ((size_t)b * V + v + u * rpi) * C + (size_t)cg * G;
+                Gran<T>::ld(x + off, xv[u]);
+                if (res) Gran<T>::ld(res + off, rv[u]);
+            }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (v + u * rpi < v1) {
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    float o = xv[u][k] * sc[k] + sh[k];
+                    if (res) o += rv[u][k];
+                    xv[u][k] = relu ? fmaxf(o, 0.f) : o;
+                }
+                Gran<T>::st(y + ((size_t)b * V + v + u * rpi) * C + (size_t)cg * G, xv[u]);
+            }
+    }
+}
+template <typename T, int UN>
+__global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
+                                                                const float* __restrict__ mean_rstd, const float* __restrict__ scale_shift,
+                                                                const float* __restrict__ coef, T* __restrict__ dx, T* __restrict__ dres,
+                                                                int V, int C, int rows_per_chunk, int relu)
+{
+    constexpr int G = Gran<T>::G;
+    const int CG = C / G, cgs = CG < 256 ? CG : 256, rpi = 256 / cgs;
+    const int t = threadIdx.x, cg = blockIdx.z * cgs + (t % cgs), r0 = t / cgs, b = blockIdx.y;
+    if (r0 >= rpi || cg >= CG) return;
+    const int v0 = blockIdx.x * rows_per_chunk, v1 = min(v0 + rows_per_chunk, V);
+    float mu[G], rs[G], sc[G], sh[G], c1[G], c2[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const size_t pc = ((size_t)b * C + cg * G + i) * 2;
+        mu[i] = mean_rstd[pc]; rs[i] = mean_rstd[pc + 1]; sc[i] = scale_shift[pc]; sh[i] = scale_shift[pc + 1]; c1[i] = coef[pc]; c2[i] = coef[pc + 1];
+    }
+    const bool remask = relu && y == nullptr;
+    for (int v = v0 + r0; v < v1; v += rpi * UN) {
+        float xv[UN][G], gv[UN][G], yv[UN][G];
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (v + u * rpi < v1) {
+                const size_t off = ((size_t)b * V + v + u * rpi) * C + (size_t)cg * G;
+                Gran<T>::ld(x + off, xv[u]);
+                Gran<T>::ld(dy + off, gv[u]);
+                if (relu && !remask) Gran<T>::ld(y + off, yv[u]);
+            }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (v + u * rpi < v1) {
+                const size_t off = ((size_t)b * V + v + u * rpi) * C + (size_t)cg * G;
+                if (remask) {
+#pragma unroll
+                    for (int k = 0; k < G; ++k) gv[u][k] = (xv[u][k] * sc[k] + sh[k]) > 0.f ? gv[u][k] : 0.f;
+                } else if (relu) {
+#pragma unroll
+                    for (int k = 0; k < G; ++k) gv[u][k] = yv[u][k] > 0.f ? gv[u][k] : 0.f;
+                }
+                if (dres) Gran<T>::st(dres + off, gv[u]);
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const float xh = (xv[u][k] - mu[k]) * rs[k];
+                    xv[u][k] = sc[k] * (gv[u][k] - c1[k] - xh * c2[k]);
+                }
+                Gran<T>::st(dx + off, xv[u]);
+            }
     }
 }
 
@@ -670,12 +770,15 @@ int dreg_bn3d_fwd(const void* x, const void* res, void* y, const float* gamma, c
         else hipLaunchKernelGGL((bn_partial_kernel<float, 0>), grid, dim3(256), 0, st, (const float*)x, nullptr, nullptr, nullptr, workspace, V, C, rpc, 0);
         DREG_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, gamma, beta, running_mean, running_var,
+    if (B > BN_MAX_GRIDS) return DREG_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64 * (B < 8 ? B : 8)), 0, st, workspace, gamma, beta, running_mean, running_var,
                        scale_shift, mean_rstd, B, nch, C, V, eps, momentum, train);
     DREG_LAUNCH_CHECK();
     const size_t tg = (size_t)B * V * CG;
-    if (dtype == 0) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(nblocks(tg)), dim3(256), 0, st, (const bf16_t*)x, scale_shift, (const bf16_t*)res, (bf16_t*)y, tg, V, C, relu);
-    else hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(nblocks(tg)), dim3(256), 0, st, (const float*)x, scale_shift, (const float*)res, (float*)y, tg, V, C, relu);
+    (void)tg;
+    const dim3 agrid(nch, B, slabs);
+    if (dtype == 0) hipLaunchKernelGGL((bn_apply_cols_kernel<bf16_t, 4>), agrid, dim3(256), 0, st, (const bf16_t*)x, scale_shift, (const bf16_t*)res, (bf16_t*)y, V, C, rpc, relu);
+    else hipLaunchKernelGGL((bn_apply_cols_kernel<float, 4>), agrid, dim3(256), 0, st, (const float*)x, scale_shift, (const float*)res, (float*)y, V, C, rpc, relu);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
@@ -696,11 +799,13 @@ int dreg_bn3d_bwd(const void* x, const void* dy, const void* y, const float* sca
     if (dtype == 0) hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean_rstd, workspace, V, C, rpc, relu, scale_shift);
     else hipLaunchKernelGGL((bn_partial_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y, mean_rstd, workspace, V, C, rpc, relu, scale_shift);
     DREG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, coef, dgamma, dbeta, B, nch, C, V, accumulate);
+    if (B > BN_MAX_GRIDS) return DREG_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64 * (B < 8 ? B : 8)), 0, st, workspace, coef, dgamma, dbeta, B, nch, C, V, accumulate);
     DREG_LAUNCH_CHECK();
     const size_t tg = (size_t)B * V * CG;
-    if (dtype == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(nblocks(tg)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean_rstd, scale_shift, coef, (bf16_t*)dx, (bf16_t*)dres, tg, V, C, relu);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(nblocks(tg)), dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y, mean_rstd, scale_shift, coef, (float*)dx, (float*)dres, tg, V, C, relu);
+    (void)tg;
+    if (dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean_rstd, scale_shift, coef, (bf16_t*)dx, (bf16_t*)dres, V, C, rpc, relu);
+    else hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y, mean_rstd, scale_shift, coef, (float*)dx, (float*)dres, V, C, rpc, relu);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
