@@ -65,14 +65,25 @@ __device__ __forceinline__ Frag<float> frag_col(const char* base, int rs, int kb
     for (int e = 0; e < 8; ++e) f.v[e] = *reinterpret_cast<const float*>(base + (kb + e) * rs + (cb + fi) * 4);
     return f;
 }
+// Reductions over the 16 lanes of a DPP row (= the 16 key columns of an MFMA C tile) on the VALU's data-parallel-primitive
+// path instead of ds_bpermute (LDS crossbar round trips): xor 1, xor 2 by quad_perm, then row_half_mirror, then row_mirror — each
+// step pairs disjoint halves, so all 16 lanes end with the full result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float group16_max(float v) {
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = fmaxf(v, dpp_f<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_f<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_f<0x141>(v));   // row_half_mirror
+    v = fmaxf(v, dpp_f<0x140>(v));   // row_mirror
     return v;
 }
 __device__ __forceinline__ float group16_sum(float v) {
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    v += dpp_f<0x140>(v);
     return v;
 }
 
@@ -111,6 +122,35 @@ __device__ __forceinline__ void load_tile(char* dst, int rs, const T* src, long 
     }
 }
 
+// Register-staged variant: fetch the NEXT tile's granules into registers while the current tile (already in LDS) is being consumed,
+// store them after the block has finished reading the current one — the global-memory latency of a tile hides behind a tile of MFMAs.
+template <typename T, int D>
+struct TileRegs {
+    static constexpr int GPR = D * sizeof(T) / 16, NL = (64 * GPR + 255) / 256;
+    uint4 v[NL];
+    __device__ __forceinline__ void fetch(const T* src, long ld, int row0, int nrows_valid, int tid) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int q = tid + i * 256, r = q / GPR, g = q % GPR;
+            v[i] = make_uint4(0, 0, 0, 0);
+            if (q < 64 * GPR && row0 + r < nrows_valid) v[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(src + (long)(row0 + r) * ld) + g * 16);
+        }
+    }
+    __device__ __forceinline__ void store(char* dst, int rs, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int q = tid + i * 256, r = q / GPR, g = q % GPR;
+            if (q < 64 * GPR) *reinterpret_cast<uint4*>(dst + r * rs + g * 16) = v[i];
+        }
+    }
+};
+// the probability scratch tiles are private to a wave: LDS operations of one wave complete in order, so a wave-level fence is enough
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <typename T, int D, bool XYZ>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a)
@@ -142,20 +182,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a)
     for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; o3[r][0] = o3[r][1] = o3[r][2] = 0.f; }
     o[0] = o[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    TileRegs<T, D> rk;
+    TileRegs<T, DV> rv;
+    float4 rx = make_float4(0, 0, 0, 0);
+    const T* Vp = XYZ ? nullptr : (const T*)a.v + h * a.hv + pb.k0 * a.ldv;
+    auto fetch = [&](int k0) {
+        rk.fetch(K, a.ldk, k0, pb.Nk, tid);
+        if constexpr (XYZ) {
+            const float* x = (const float*)a.v + pb.k0 * 3;
+            rx = make_float4(0, 0, 0, 0);
+            if (tid < 64 && k0 + tid < pb.Nk) rx = make_float4(x[(long)(k0 + tid) * 3], x[(long)(k0 + tid) * 3 + 1], x[(long)(k0 + tid) * 3 + 2], 0.f);
+        } else {
+            rv.fetch(Vp, a.ldv, k0, pb.Nk, tid);
+        }
+    };
+    fetch(0);
     for (int k0 = 0; k0 < pb.Nk; k0 += 64) {
         __syncthreads();
-        load_tile<T, D>(sK, KRS, K, a.ldk, k0, pb.Nk, tid);
-        if constexpr (XYZ) {
-            if (tid < 64) {
-                const float* x = (const float*)a.v + pb.k0 * 3;
-                float4 val = make_float4(0, 0, 0, 0);
-                if (k0 + tid < pb.Nk) val = make_float4(x[(long)(k0 + tid) * 3], x[(long)(k0 + tid) * 3 + 1], x[(long)(k0 + tid) * 3 + 2], 0.f);
-                *reinterpret_cast<float4*>(sV + tid * 16) = val;
-            }
-        } else {
-            load_tile<T, DV>(sV, VRS, (const T*)a.v + h * a.hv + pb.k0 * a.ldv, a.ldv, k0, pb.Nk, tid);
-        }
+        rk.store(sK, KRS, tid);
+        if constexpr (XYZ) { if (tid < 64) *reinterpret_cast<float4*>(sV + tid * 16) = rx; }
+        else rv.store(sV, VRS, tid);
         __syncthreads();
+        if (k0 + 64 < pb.Nk) fetch(k0 + 64);
         f32x4_t s[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -200,7 +248,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a)
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Elem<T>::st(reinterpret_cast<T*>(myP + (kg * 4 + r) * PRS) + t * 16 + fr, s[t][r]);
-            __syncthreads();
+            wave_lds_sync();
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 Frag<T> pf = frag_row(myP, PRS, fr, ks * 32 + kg * 8, T());
@@ -292,20 +340,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a)
 #pragma unroll
     for (int u = 0; u < D / 16; ++u) dq[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    TileRegs<T, D> rk;
+    TileRegs<T, DV> rv;
+    float4 rx = make_float4(0, 0, 0, 0);
+    const T* Vp = XYZ ? nullptr : (const T*)a.v + h * a.hv + pb.k0 * a.ldv;
+    auto fetch = [&](int k0) {
+        rk.fetch(K, a.ldk, k0, pb.Nk, tid);
+        if constexpr (XYZ) {
+            const float* x = (const float*)a.v + pb.k0 * 3;
+            rx = make_float4(0, 0, 0, 0);
+            if (tid < 64 && k0 + tid < pb.Nk) rx = make_float4(x[(long)(k0 + tid) * 3], x[(long)(k0 + tid) * 3 + 1], x[(long)(k0 + tid) * 3 + 2], 0.f);
+        } else {
+            rv.fetch(Vp, a.ldv, k0, pb.Nk, tid);
+        }
+    };
+    fetch(0);
     for (int k0 = 0; k0 < pb.Nk; k0 += 64) {
         __syncthreads();
-        load_tile<T, D>(sK, KRS, K, a.ldk, k0, pb.Nk, tid);
-        if constexpr (XYZ) {
-            if (tid < 64) {
-                const float* x = (const float*)a.v + pb.k0 * 3;
-                float4 val = make_float4(0, 0, 0, 0);
-                if (k0 + tid < pb.Nk) val = make_float4(x[(long)(k0 + tid) * 3], x[(long)(k0 + tid) * 3 + 1], x[(long)(k0 + tid) * 3 + 2], 0.f);
-                *reinterpret_cast<float4*>(sV + tid * 16) = val;
-            }
-        } else {
-            load_tile<T, DV>(sV, VRS, (const T*)a.v + h * a.hv + pb.k0 * a.ldv, a.ldv, k0, pb.Nk, tid);
-        }
+        rk.store(sK, KRS, tid);
+        if constexpr (XYZ) { if (tid < 64) *reinterpret_cast<float4*>(sV + tid * 16) = rx; }
+        else rv.store(sV, VRS, tid);
         __syncthreads();
+        if (k0 + 64 < pb.Nk) fetch(k0 + 64);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -324,7 +380,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a)
                 Elem<T>::st(reinterpret_cast<T*>(myP + (kg * 4 + r) * PRS) + t * 16 + fr, p * (dpv - dv_[r]) * a.scale);
             }
         }
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             Frag<T> df = frag_row(myP, PRS, fr, ks * 32 + kg * 8, T());
@@ -383,24 +439,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a)
     for (int u = 0; u < D / 16; ++u) dk[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     dvv[0] = dvv[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    for (int q0 = 0; q0 < pb.Nq; q0 += 64) {
-        __syncthreads();
-        load_tile<T, D>(sQ, QRS, Q, a.ldq, q0, pb.Nq, tid);
+    TileRegs<T, D> rq;
+    TileRegs<T, DV> ro;
+    float4 rg = make_float4(0, 0, 0, 0);
+    float rl = 0.f, rd = 0.f;
+    const T* dOp = XYZ ? nullptr : (const T*)a.dout + h * a.ho + pb.q0 * a.ldo;
+    auto fetch = [&](int q0) {
+        rq.fetch(Q, a.ldq, q0, pb.Nq, tid);
         if constexpr (XYZ) {
-            if (tid < 64) {
+            rg = make_float4(0, 0, 0, 0);
+            if (tid < 64 && q0 + tid < pb.Nq) {
                 const float* g = (const float*)a.dout + ((long)h * a.Rq + pb.q0 + q0 + tid) * 3;
-                float4 val = make_float4(0, 0, 0, 0);
-                if (q0 + tid < pb.Nq) val = make_float4(g[0], g[1], g[2], 0.f);
-                *reinterpret_cast<float4*>(sO + tid * 16) = val;
+                rg = make_float4(g[0], g[1], g[2], 0.f);
             }
         } else {
-            load_tile<T, DV>(sO, ORS, (const T*)a.dout + h * a.ho + pb.q0 * a.ldo, a.ldo, q0, pb.Nq, tid);
+            ro.fetch(dOp, a.ldo, q0, pb.Nq, tid);
         }
-        if (tid < 64) {
-            sL[tid] = q0 + tid < pb.Nq ? a.lse[(long)h * a.Rq + pb.q0 + q0 + tid] : 0.f;
-            sL[64 + tid] = q0 + tid < pb.Nq ? a.dvec[(long)h * a.Rq + pb.q0 + q0 + tid] : 0.f;
-        }
+        rl = rd = 0.f;
+        if (tid < 64 && q0 + tid < pb.Nq) { rl = a.lse[(long)h * a.Rq + pb.q0 + q0 + tid]; rd = a.dvec[(long)h * a.Rq + pb.q0 + q0 + tid]; }
+    };
+    fetch(0);
+    for (int q0 = 0; q0 < pb.Nq; q0 += 64) {
         __syncthreads();
+        rq.store(sQ, QRS, tid);
+        if constexpr (XYZ) { if (tid < 64) *reinterpret_cast<float4*>(sO + tid * 16) = rg; }
+        else ro.store(sO, ORS, tid);
+        if (tid < 64) { sL[tid] = rl; sL[64 + tid] = rd; }
+        __syncthreads();
+        if (q0 + 64 < pb.Nq) fetch(q0 + 64);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             // S^T[key][q] : rows = keys (this wave's 16), cols = queries t*16 + fr
@@ -424,7 +490,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a)
                 Elem<T>::st(reinterpret_cast<T*>(myS + (kg * 4 + r) * PRS) + qc, p * (dpv - dvec) * a.scale);
             }
         }
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             Frag<T> sf = frag_row(myS, PRS, fr, ks * 32 + kg * 8, T());

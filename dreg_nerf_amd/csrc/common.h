@@ -14,11 +14,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
-    return (bf16_t)(u >> 16);
+// fp32 -> bf16, round to nearest even: gfx950's v_cvt_pk_bf16_f32 (one instruction per PAIR) instead of five integer VALU
+// instructions per value — the elementwise kernels (BatchNorm apply, softmax probabilities, conv epilogues) are VALU-bound
+// on exactly this.  Same results as the integer formula for every finite value and infinity; NaN stays (quiet) NaN.
+typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 hw_bf16x2_t;
+typedef __attribute__((__vector_size__(2 * sizeof(float)))) float hw_f32x2_t;
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {
+    const hw_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_bf16x2_t));
 }
 
 template <typename T> struct Elem;

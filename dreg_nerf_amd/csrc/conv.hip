@@ -397,7 +397,7 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
             } else {
                 uint32_t w[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) w[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+                for (int e = 0; e < 4; ++e) w[e] = f2bf2(v[2 * e], v[2 * e + 1]);
                 *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
             }
         }
@@ -813,7 +813,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, TO* __restr
         } else {
             uint32_t w[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+            for (int e = 0; e < 4; ++e) w[e] = f2bf2(v[2 * e], v[2 * e + 1]);
             *reinterpret_cast<uint4*>(out + i * 8) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
@@ -908,7 +908,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDes
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float v0 = k + 2 * e < d.Cin_real ? src[k + 2 * e] : 0.f, v1 = k + 2 * e + 1 < d.Cin_real ? src[k + 2 * e + 1] : 0.f;
-                pk[e] = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+                pk[e] = f2bf2(v0, v1);
             }
             *reinterpret_cast<uint4*>(out + (size_t)r * d.Kpad + k) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         }
@@ -928,7 +928,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDes
                 uint32_t pk[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    pk[e] = (uint32_t)f2bf(tile[cg * 8 + 2 * e][ci_w]) | ((uint32_t)f2bf(tile[cg * 8 + 2 * e + 1][ci_w]) << 16);
+                    pk[e] = f2bf2(tile[cg * 8 + 2 * e][ci_w], tile[cg * 8 + 2 * e + 1][ci_w]);
                 *reinterpret_cast<uint4*>(out + (size_t)(r + ci_w) * d.Kpad + co0 + cg * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             }
             __syncthreads();
@@ -963,7 +963,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDes
                     const int cl = g * 8 + 2 * e;
                     const float v0 = (tap >= 0 && cl < nc) ? stage[cl * d.ntaps + tap] : 0.f;
                     const float v1 = (tap >= 0 && cl + 1 < nc) ? stage[(cl + 1) * d.ntaps + tap] : 0.f;
-                    pk[e] = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+                    pk[e] = f2bf2(v0, v1);
                 }
                 *reinterpret_cast<uint4*>(out + row_o + (size_t)tp * inner + c0 + g * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             }

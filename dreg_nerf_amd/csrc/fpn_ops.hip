@@ -25,7 +25,7 @@ template <> struct Gran<bf16_t> {
     static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {
         uint32_t w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = f2bf2(v[2 * i], v[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
@@ -68,25 +68,37 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(
         for (int i = 0; i < G; ++i) { sc[i] = scale_shift[((size_t)b * C + cg * G + i) * 2]; sh[i] = scale_shift[((size_t)b * C + cg * G + i) * 2 + 1]; }
     }
     if (r0 < rpi) {
-        for (int v = v0 + r0; v < v1; v += rpi) {
-            const size_t off = ((size_t)b * V + v) * C + (size_t)cg * G;
-            float xv[G];
-            Gran<T>::ld(x + off, xv);
-            if (MODE == 0) {
+        constexpr int UN = 4;                            // rows in flight per thread (sums stay in row order: bit-identical to UN = 1)
+        for (int v = v0 + r0; v < v1; v += rpi * UN) {
+            float xv[UN][G], gv[UN][G], yv[UN][G];
 #pragma unroll
-                for (int i = 0; i < G; ++i) { s1[i] += xv[i]; s2[i] += xv[i] * xv[i]; }
-            } else {
-                float gv[G], yv[G];
-                Gran<T>::ld(dy + off, gv);
-                if (remask) {
+            for (int u = 0; u < UN; ++u)
+                if (v + u * rpi < v1) {
+                    const size_t off = ((size_t)b * V + v + u * rpi) * C + (size_t)cg * G;
+                    Gran<T>::ld(x + off, xv[u]);
+                    if (MODE == 1) {
+                        Gran<T>::ld(dy + off, gv[u]);
+                        if (relu && !remask) Gran<T>::ld(y + off, yv[u]);
+                    }
+                }
 #pragma unroll
-                    for (int i = 0; i < G; ++i) gv[i] = (xv[i] * sc[i] + sh[i]) > 0.f ? gv[i] : 0.f;
-                } else if (relu) { Gran<T>::ld(y + off, yv);
+            for (int u = 0; u < UN; ++u)
+                if (v + u * rpi < v1) {
+                    if (MODE == 0) {
 #pragma unroll
-                    for (int i = 0; i < G; ++i) gv[i] = yv[i] > 0.f ? gv[i] : 0.f; }
+                        for (int i = 0; i < G; ++i) { s1[i] += xv[u][i]; s2[i] += xv[u][i] * xv[u][i]; }
+                    } else {
+                        if (remask) {
 #pragma unroll
-                for (int i = 0; i < G; ++i) { s1[i] += gv[i]; s2[i] += gv[i] * (xv[i] - mu[i]) * rs[i]; }
-            }
+                            for (int i = 0; i < G; ++i) gv[u][i] = (xv[u][i] * sc[i] + sh[i]) > 0.f ? gv[u][i] : 0.f;
+                        } else if (relu) {
+#pragma unroll
+                            for (int i = 0; i < G; ++i) gv[u][i] = yv[u][i] > 0.f ? gv[u][i] : 0.f;
+                        }
+#pragma unroll
+                        for (int i = 0; i < G; ++i) { s1[i] += gv[u][i]; s2[i] += gv[u][i] * (xv[u][i] - mu[i]) * rs[i]; }
+                    }
+                }
         }
     }
     __shared__ float red[256][2 * 8 + 1];
