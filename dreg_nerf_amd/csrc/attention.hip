@@ -151,16 +151,57 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ------------------------------------------------------------------------------------------------ transposed formulation
+// All three kernels compute the score tile TRANSPOSED with respect to the operand they stream, so that the MFMA C layout of the
+// scores (lane (fr, kg) holds rows kg*4..kg*4+3 of column fr) IS the B-operand layout of the second product (lane (fr, kg) holds
+// eight k-slots of column fr): two C tiles are converted in registers and fed straight back — no LDS round trip for the
+// probabilities, and every softmax quantity (running max, sum, lse, D) is one value per lane instead of four.  The eight k-slots
+// of lane group kg are rows kg*4..kg*4+3 of the first 16-row tile and of the second; the other operand of the second product is
+// read with the same row permutation (frag_colp).
+__device__ __forceinline__ Frag<bf16_t> frag_regs(const float (&v)[8], bf16_t) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+    const u32x4_t w = {f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7])};
+    Frag<bf16_t> f; f.v = __builtin_bit_cast(bf16x8_t, w); return f;
+}
+__device__ __forceinline__ Frag<float> frag_regs(const float (&v)[8], float) {
+    Frag<float> f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f.v[e] = v[e];
+    return f;
+}
+// element j of the result = tile[j < 4 ? row_lo + j : row_hi + j - 4][cb + (lane & 15)]   (row_lo / row_hi already per lane group)
+__device__ __forceinline__ Frag<bf16_t> frag_colp(const char* base, int rs, int row_lo, int row_hi, int cb, int lane, bf16_t) {
+    typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
+    const int fi = lane & 15;
+    const int off = (fi >> 2) * rs + (cb + (fi & 3) * 4) * 2;
+    bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(base + row_lo * rs + off));
+    bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(base + row_hi * rs + off));
+    Frag<bf16_t> f; f.v = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return f;
+}
+__device__ __forceinline__ Frag<float> frag_colp(const char* base, int rs, int row_lo, int row_hi, int cb, int lane, float) {
+    const int fi = lane & 15;
+    Frag<float> f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f.v[e] = *reinterpret_cast<const float*>(base + (e < 4 ? row_lo + e : row_hi + e - 4) * rs + (cb + fi) * 4);
+    return f;
+}
+__device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) { *reinterpret_cast<uint2*>(p) = make_uint2(f2bf2(a, b), f2bf2(c, d)); }
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
+__device__ __forceinline__ float group4x_sum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }   // over the 4 lane groups
+__device__ __forceinline__ float group4x_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
 // ------------------------------------------------------------------------------------------------ forward
+// wave = 16 queries (lane's query: q0 + fr); S^T = K Q^T per 16-key tile, O^T = V^T P^T.
 template <typename T, int D, bool XYZ>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a)
 {
     constexpr int DV = 32;
-    constexpr int KRS = D * sizeof(T) + 16, VRS = XYZ ? 16 : DV * sizeof(T) + 16, PRS = 64 * sizeof(T) + 16;
+    constexpr int KRS = D * sizeof(T) + 16, VRS = XYZ ? 16 : DV * sizeof(T) + 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;
     char* sV = sK + 64 * KRS;
-    char* sP = sV + 64 * VRS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.y;
     const Prob pb = get_prob(a);
@@ -169,17 +210,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a)
     const T* Q = (const T*)a.q + h * a.hq + pb.q0 * a.ldq;
     const T* K = (const T*)a.k + h * a.hk + pb.k0 * a.ldk;
     const int fr = lane & 15, kg = lane >> 4;
-    char* myP = sP + wave * 16 * PRS;
 
-    Frag<T> qf[D / 32];
+    Frag<T> qf[D / 32];       // B operand Q^T: column q = fr, k-slots kg*8..
 #pragma unroll
     for (int kk = 0; kk < D / 32; ++kk) qf[kk] = frag_glob(Q + (long)(q0 + fr) * a.ldq + kk * 32 + kg * 8, q0 + fr < pb.Nq);
-
-    float m[4], l[4];
-    f32x4_t o[2];
-    float o3[4][3];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; o3[r][0] = o3[r][1] = o3[r][2] = 0.f; }
+    const float c2 = a.scale * LOG2E;          // scores in the log2 domain
+    float m = -INFINITY, l = 0.f;              // running max / this lane's share of the running sum, query q0 + fr
+    f32x4_t o[2];                              // O^T[dv = u*16 + kg*4 + r][q = fr]
+    float o3[3] = {0.f, 0.f, 0.f};
     o[0] = o[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     TileRegs<T, D> rk;
@@ -204,88 +242,83 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a)
         else rv.store(sV, VRS, tid);
         __syncthreads();
         if (k0 + 64 < pb.Nk) fetch(k0 + 64);
-        f32x4_t s[4];
+        f32x4_t s[4];          // s[t][r] = score(q = fr, key = k0 + t*16 + kg*4 + r)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < D / 32; ++kk) s[t] = mma(qf[kk], frag_row(sK, KRS, t * 16 + fr, kk * 32 + kg * 8, T()), s[t]);
+            for (int kk = 0; kk < D / 32; ++kk) s[t] = mma(frag_row(sK, KRS, t * 16 + fr, kk * 32 + kg * 8, T()), qf[kk], s[t]);
         }
-        float alpha[4];
+        const bool ragged = k0 + 64 > pb.Nk;
+        float mx = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                s[t][r] = (k0 + t * 16 + fr < pb.Nk) ? s[t][r] * a.scale : -INFINITY;
-                mx = fmaxf(mx, s[t][r]);
-            }
-            mx = group16_max(mx);
-            const float mn = fmaxf(m[r], mx);
-            alpha[r] = __expf(m[r] - mn);
-            float sum = 0.f;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { s[t][r] = __expf(s[t][r] - mn); sum += s[t][r]; }
-            sum = group16_sum(sum);
-            l[r] = l[r] * alpha[r] + sum;
-            m[r] = mn;
-        }
-        if constexpr (XYZ) {
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) o3[r][c] *= alpha[r];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float4 x = *reinterpret_cast<const float4*>(sV + (t * 16 + fr) * 16);
-                    o3[r][0] += s[t][r] * x.x; o3[r][1] += s[t][r] * x.y; o3[r][2] += s[t][r] * x.z;
-                }
+                float v = s[t][r] * c2;
+                if (ragged && k0 + t * 16 + kg * 4 + r >= pb.Nk) v = -INFINITY;
+                s[t][r] = v;
+                mx = fmaxf(mx, v);
             }
-        } else {
+        mx = group4x_max(mx);
+        const float mn = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { o[0][r] *= alpha[r]; o[1][r] *= alpha[r]; }
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - mn); sum += s[t][r]; }
+        l = l * alpha + sum;
+        m = mn;
+        if constexpr (XYZ) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o3[c] *= alpha;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Elem<T>::st(reinterpret_cast<T*>(myP + (kg * 4 + r) * PRS) + t * 16 + fr, s[t][r]);
-            wave_lds_sync();
+                for (int r = 0; r < 4; ++r) {
+                    const float4 x = *reinterpret_cast<const float4*>(sV + (t * 16 + kg * 4 + r) * 16);
+                    o3[0] += s[t][r] * x.x; o3[1] += s[t][r] * x.y; o3[2] += s[t][r] * x.z;
+                }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                Frag<T> pf = frag_row(myP, PRS, fr, ks * 32 + kg * 8, T());
+                const float pv[8] = {s[2 * ks][0], s[2 * ks][1], s[2 * ks][2], s[2 * ks][3], s[2 * ks + 1][0], s[2 * ks + 1][1], s[2 * ks + 1][2], s[2 * ks + 1][3]};
+                const Frag<T> pf = frag_regs(pv, T());
 #pragma unroll
-                for (int u = 0; u < 2; ++u) o[u] = mma(pf, frag_col(sV, VRS, ks * 32, u * 16, lane, T()), o[u]);
+                for (int u = 0; u < 2; ++u) o[u] = mma(frag_colp(sV, VRS, ks * 32 + kg * 4, ks * 32 + 16 + kg * 4, u * 16, lane, T()), pf, o[u]);
             }
         }
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qr = q0 + kg * 4 + r;
-        const float inv = 1.f / l[r];
-        if constexpr (XYZ) {
-            float x = group16_sum(o3[r][0]), y = group16_sum(o3[r][1]), z = group16_sum(o3[r][2]);
-            if (fr == 0 && qr < pb.Nq) {
-                float* op = (float*)a.o + ((long)h * a.Rq + pb.q0 + qr) * 3;
-                op[0] = x * inv; op[1] = y * inv; op[2] = z * inv;
-            }
-        } else if (qr < pb.Nq) {
-            T* op = (T*)a.o + h * a.ho + (pb.q0 + qr) * a.ldo;
-            Elem<T>::st(op + fr, o[0][r] * inv);
-            Elem<T>::st(op + 16 + fr, o[1][r] * inv);
+    l = group4x_sum(l);
+    const float inv = 1.f / l;
+    const int qr = q0 + fr;
+    if constexpr (XYZ) {
+        const float x = group4x_sum(o3[0]), y = group4x_sum(o3[1]), z = group4x_sum(o3[2]);
+        if (kg == 0 && qr < pb.Nq) {
+            float* op = (float*)a.o + ((long)h * a.Rq + pb.q0 + qr) * 3;
+            op[0] = x * inv; op[1] = y * inv; op[2] = z * inv;
         }
-        if (fr == 0 && qr < pb.Nq) a.lse[(long)h * a.Rq + pb.q0 + qr] = m[r] + __logf(l[r]);
+    } else if (qr < pb.Nq) {
+        T* op = (T*)a.o + h * a.ho + (pb.q0 + qr) * a.ldo + kg * 4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) store4(op + u * 16, o[u][0] * inv, o[u][1] * inv, o[u][2] * inv, o[u][3] * inv);
     }
+    if (kg == 0 && qr < pb.Nq) a.lse[(long)h * a.Rq + pb.q0 + qr] = (m + __log2f(l)) * LN2;
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
+// wave = 16 queries; S^T and dP^T per 16-key tile, dQ^T = K^T dS^T.
 template <typename T, int D, bool XYZ>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a)
+__global__ __launch_bounds__(256, (D > 32 ? 2 : 1)) void attn_bwd_dq_kernel(AttnArgs a)
 {
     constexpr int DV = 32;
-    constexpr int KRS = D * sizeof(T) + 16, VRS = XYZ ? 16 : DV * sizeof(T) + 16, PRS = 64 * sizeof(T) + 16;
+    constexpr int KRS = D * sizeof(T) + 16, VRS = XYZ ? 16 : DV * sizeof(T) + 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;
     char* sV = sK + 64 * KRS;
-    char* sP = sV + 64 * VRS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.y;
     const Prob pb = get_prob(a);
@@ -294,20 +327,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a)
     const T* Q = (const T*)a.q + h * a.hq + pb.q0 * a.ldq;
     const T* K = (const T*)a.k + h * a.hk + pb.k0 * a.ldk;
     const int fr = lane & 15, kg = lane >> 4;
-    char* myP = sP + wave * 16 * PRS;
+    const int qr = q0 + fr;
+    const bool qv = qr < pb.Nq;
 
     Frag<T> qf[D / 32];
 #pragma unroll
-    for (int kk = 0; kk < D / 32; ++kk) qf[kk] = frag_glob(Q + (long)(q0 + fr) * a.ldq + kk * 32 + kg * 8, q0 + fr < pb.Nq);
-    // per-row quantities in the C layout rows (kg*4 + r)
-    float lse[4], dv_[4], do3[4][3];
-    Frag<T> dof;  // dO as A operand (rows q = fr)
+    for (int kk = 0; kk < D / 32; ++kk) qf[kk] = frag_glob(Q + (long)qr * a.ldq + kk * 32 + kg * 8, qv);
+    // per-lane quantities of query qr: lse (log2 domain), D = rowsum(dO * O), dO
+    const float lse2 = qv ? a.lse[(long)h * a.Rq + pb.q0 + qr] * LOG2E : 0.f;
+    float dvec, do3[3] = {0.f, 0.f, 0.f};
+    Frag<T> dof;  // dO^T as B operand (column q = fr)
     if constexpr (!XYZ) {
         const T* dO = (const T*)a.dout + h * a.ho + pb.q0 * a.ldo;
         const T* O = (const T*)a.o + h * a.ho + pb.q0 * a.ldo;
-        dof = frag_glob(dO + (long)(q0 + fr) * a.ldo + kg * 8, q0 + fr < pb.Nq);
-        // D[q] = sum_dv dO*O : each lane sums its 8 columns of row fr, then the 4 lane groups are combined
-        Frag<T> of = frag_glob(O + (long)(q0 + fr) * a.ldo + kg * 8, q0 + fr < pb.Nq);
+        dof = frag_glob(dO + (long)qr * a.ldo + kg * 8, qv);
+        const Frag<T> of = frag_glob(O + (long)qr * a.ldo + kg * 8, qv);
         float part = 0.f;
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -316,27 +350,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a)
 #pragma unroll
             for (int e = 0; e < 8; ++e) part += dof.v[e] * of.v[e];
         }
-        part += __shfl_xor(part, 16, 64);
-        part += __shfl_xor(part, 32, 64);   // every lane with the same fr now holds D[row fr]
+        dvec = group4x_sum(part);
+    } else {
+        const float* dO = (const float*)a.dout + ((long)h * a.Rq + pb.q0 + qr) * 3;
+        const float* O = (const float*)a.o + ((long)h * a.Rq + pb.q0 + qr) * 3;
+        dvec = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dv_[r] = __shfl(part, kg * 4 + r, 64);
-        if (kg == 0 && q0 + fr < pb.Nq) a.dvec[(long)h * a.Rq + pb.q0 + q0 + fr] = part;
+        for (int c = 0; c < 3; ++c) { do3[c] = qv ? dO[c] : 0.f; dvec += do3[c] * (qv ? O[c] : 0.f); }
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qr = q0 + kg * 4 + r;
-        lse[r] = qr < pb.Nq ? a.lse[(long)h * a.Rq + pb.q0 + qr] : 0.f;
-        if constexpr (XYZ) {
-            const float* dO = (const float*)a.dout + ((long)h * a.Rq + pb.q0 + qr) * 3;
-            const float* O = (const float*)a.o + ((long)h * a.Rq + pb.q0 + qr) * 3;
-            float d = 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { do3[r][c] = qr < pb.Nq ? dO[c] : 0.f; d += do3[r][c] * (qr < pb.Nq ? O[c] : 0.f); }
-            dv_[r] = d;
-            if (fr == 0 && qr < pb.Nq) a.dvec[(long)h * a.Rq + pb.q0 + qr] = d;
-        }
-    }
-    f32x4_t dq[D / 16];
+    if (kg == 0 && qv) a.dvec[(long)h * a.Rq + pb.q0 + qr] = dvec;
+    const float c2 = a.scale * LOG2E;
+    f32x4_t dq[D / 16];        // dQ^T[d = u*16 + kg*4 + r][q = fr]
 #pragma unroll
     for (int u = 0; u < D / 16; ++u) dq[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
@@ -363,52 +387,55 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a)
         __syncthreads();
         if (k0 + 64 < pb.Nk) fetch(k0 + 64);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < 2; ++ks) {
+            float dsv[8];
 #pragma unroll
-            for (int kk = 0; kk < D / 32; ++kk) s = mma(qf[kk], frag_row(sK, KRS, t * 16 + fr, kk * 32 + kg * 8, T()), s);
-            f32x4_t dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            if constexpr (!XYZ) dp = mma(dof, frag_row(sV, VRS, t * 16 + fr, kg * 8, T()), dp);
-            const bool kv = k0 + t * 16 + fr < pb.Nk;
-            float4 x = make_float4(0, 0, 0, 0);
-            if constexpr (XYZ) x = *reinterpret_cast<const float4*>(sV + (t * 16 + fr) * 16);
+            for (int tt = 0; tt < 2; ++tt) {
+                const int t = 2 * ks + tt;
+                f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = kv ? __expf(s[r] * a.scale - lse[r]) : 0.f;
-                float dpv = dp[r];
-                if constexpr (XYZ) dpv = do3[r][0] * x.x + do3[r][1] * x.y + do3[r][2] * x.z;
-                Elem<T>::st(reinterpret_cast<T*>(myP + (kg * 4 + r) * PRS) + t * 16 + fr, p * (dpv - dv_[r]) * a.scale);
+                for (int kk = 0; kk < D / 32; ++kk) s = mma(frag_row(sK, KRS, t * 16 + fr, kk * 32 + kg * 8, T()), qf[kk], s);
+                f32x4_t dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                if constexpr (!XYZ) dp = mma(frag_row(sV, VRS, t * 16 + fr, kg * 8, T()), dof, dp);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kr = t * 16 + kg * 4 + r;
+                    // keys past Nk need no mask: their K (and V / xyz) rows are zero in LDS, so whatever dS they get multiplies zero
+                    const float p = __builtin_amdgcn_exp2f(s[r] * c2 - lse2);
+                    float dpv = dp[r];
+                    if constexpr (XYZ) {
+                        const float4 x = *reinterpret_cast<const float4*>(sV + kr * 16);
+                        dpv = do3[0] * x.x + do3[1] * x.y + do3[2] * x.z;
+                    }
+                    dsv[tt * 4 + r] = p * (dpv - dvec);      // the softmax scale is applied once, to dQ
+                }
+            }
+            const Frag<T> df = frag_regs(dsv, T());
+#pragma unroll
+            for (int u = 0; u < D / 16; ++u) {
+                dq[u] = mma(frag_colp(sK, KRS, ks * 32 + kg * 4, ks * 32 + 16 + kg * 4, u * 16, lane, T()), df, dq[u]);
+                if (D > 32 && (u & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep at most four operand fragments in flight (registers)
             }
         }
-        wave_lds_sync();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            Frag<T> df = frag_row(myP, PRS, fr, ks * 32 + kg * 8, T());
-#pragma unroll
-            for (int u = 0; u < D / 16; ++u) dq[u] = mma(df, frag_col(sK, KRS, ks * 32, u * 16, lane, T()), dq[u]);
-        }
     }
-    T* dQ = (T*)a.dq + h * a.hq + pb.q0 * a.ldq;
+    if (qv) {
+        T* dQ = (T*)a.dq + h * a.hq + (pb.q0 + qr) * a.ldq + kg * 4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qr = q0 + kg * 4 + r;
-        if (qr < pb.Nq)
-#pragma unroll
-            for (int u = 0; u < D / 16; ++u) Elem<T>::st(dQ + (long)qr * a.ldq + u * 16 + fr, dq[u][r]);
+        for (int u = 0; u < D / 16; ++u) store4(dQ + u * 16, dq[u][0] * a.scale, dq[u][1] * a.scale, dq[u][2] * a.scale, dq[u][3] * a.scale);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
+// wave = 16 keys (lane's key: key0 + fr); S and dP per 16-query tile, dK^T = Q^T dS, dV^T = dO^T P.
 template <typename T, int D, bool XYZ>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a)
+__global__ __launch_bounds__(256, (D > 32 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnArgs a)
 {
     constexpr int DV = 32;
-    constexpr int QRS = D * sizeof(T) + 16, ORS = XYZ ? 16 : DV * sizeof(T) + 16, PRS = 64 * sizeof(T) + 16;
+    constexpr int QRS = D * sizeof(T) + 16, ORS = XYZ ? 16 : DV * sizeof(T) + 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sQ = smem;
     char* sO = sQ + 64 * QRS;             // dO tile
-    char* sP = sO + 64 * ORS;             // two scratch tiles per wave: p^T and dS^T
-    float* sL = reinterpret_cast<float*>(sP + 4 * 2 * 16 * PRS);  // lse[64], dvec[64]
+    float* sL = reinterpret_cast<float*>(sO + 64 * ORS);  // lse * log2(e) [64], dvec [64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.y;
     const Prob pb = get_prob(a);
@@ -417,24 +444,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a)
     const T* Q = (const T*)a.q + h * a.hq + pb.q0 * a.ldq;
     const T* K = (const T*)a.k + h * a.hk + pb.k0 * a.ldk;
     const int fr = lane & 15, kg = lane >> 4;
-    char* myP = sP + wave * 2 * 16 * PRS;
-    char* myS = myP + 16 * PRS;
+    const int kr = key0 + fr;
+    const bool kv = kr < pb.Nk;
 
-    Frag<T> kf[D / 32], vf;
+    Frag<T> kf[D / 32], vf;     // B operands K^T / V^T: column key = fr
 #pragma unroll
-    for (int kk = 0; kk < D / 32; ++kk) kf[kk] = frag_glob(K + (long)(key0 + fr) * a.ldk + kk * 32 + kg * 8, key0 + fr < pb.Nk);
-    float x3[4][3];
+    for (int kk = 0; kk < D / 32; ++kk) kf[kk] = frag_glob(K + (long)kr * a.ldk + kk * 32 + kg * 8, kv);
+    float x3[3] = {0.f, 0.f, 0.f};
     if constexpr (!XYZ) {
-        vf = frag_glob((const T*)a.v + h * a.hv + pb.k0 * a.ldv + (long)(key0 + fr) * a.ldv + kg * 8, key0 + fr < pb.Nk);
+        vf = frag_glob((const T*)a.v + h * a.hv + (pb.k0 + (long)kr) * a.ldv + kg * 8, kv);
     } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int kr = key0 + kg * 4 + r;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) x3[r][c] = kr < pb.Nk ? ((const float*)a.v)[(pb.k0 + kr) * 3 + c] : 0.f;
-        }
+        for (int c = 0; c < 3; ++c) x3[c] = kv ? ((const float*)a.v)[(pb.k0 + kr) * 3 + c] : 0.f;
     }
-    f32x4_t dk[D / 16], dvv[2];
+    const float c2 = a.scale * LOG2E;
+    f32x4_t dk[D / 16], dvv[2];   // dK^T[d = u*16 + kg*4 + r][key = fr], dV^T likewise
 #pragma unroll
     for (int u = 0; u < D / 16; ++u) dk[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     dvv[0] = dvv[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -456,7 +480,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a)
             ro.fetch(dOp, a.ldo, q0, pb.Nq, tid);
         }
         rl = rd = 0.f;
-        if (tid < 64 && q0 + tid < pb.Nq) { rl = a.lse[(long)h * a.Rq + pb.q0 + q0 + tid]; rd = a.dvec[(long)h * a.Rq + pb.q0 + q0 + tid]; }
+        if (tid < 64 && q0 + tid < pb.Nq) { rl = a.lse[(long)h * a.Rq + pb.q0 + q0 + tid] * LOG2E; rd = a.dvec[(long)h * a.Rq + pb.q0 + q0 + tid]; }
     };
     fetch(0);
     for (int q0 = 0; q0 < pb.Nq; q0 += 64) {
@@ -468,53 +492,55 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a)
         __syncthreads();
         if (q0 + 64 < pb.Nq) fetch(q0 + 64);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            // S^T[key][q] : rows = keys (this wave's 16), cols = queries t*16 + fr
-            f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < D / 32; ++kk) s = mma(kf[kk], frag_row(sQ, QRS, t * 16 + fr, kk * 32 + kg * 8, T()), s);
-            f32x4_t dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            if constexpr (!XYZ) dp = mma(vf, frag_row(sO, ORS, t * 16 + fr, kg * 8, T()), dp);
-            const int qc = t * 16 + fr;
-            const bool qv = q0 + qc < pb.Nq;
-            const float lse = sL[qc], dvec = sL[64 + qc];
-            float4 g = make_float4(0, 0, 0, 0);
-            if constexpr (XYZ) g = *reinterpret_cast<const float4*>(sO + qc * 16);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool kv = key0 + kg * 4 + r < pb.Nk;
-                const float p = (qv && kv) ? __expf(s[r] * a.scale - lse) : 0.f;
-                float dpv = dp[r];
-                if constexpr (XYZ) dpv = x3[r][0] * g.x + x3[r][1] * g.y + x3[r][2] * g.z;
-                if constexpr (!XYZ) Elem<T>::st(reinterpret_cast<T*>(myP + (kg * 4 + r) * PRS) + qc, p);
-                Elem<T>::st(reinterpret_cast<T*>(myS + (kg * 4 + r) * PRS) + qc, p * (dpv - dvec) * a.scale);
-            }
-        }
-        wave_lds_sync();
-#pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            Frag<T> sf = frag_row(myS, PRS, fr, ks * 32 + kg * 8, T());
+            float pv[8], dsv[8];
 #pragma unroll
-            for (int u = 0; u < D / 16; ++u) dk[u] = mma(sf, frag_col(sQ, QRS, ks * 32, u * 16, lane, T()), dk[u]);
+            for (int tt = 0; tt < 2; ++tt) {
+                const int t = 2 * ks + tt;
+                // S[q][key] : rows = queries t*16 + kg*4 + r, column = this lane's key
+                f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < D / 32; ++kk) s = mma(frag_row(sQ, QRS, t * 16 + fr, kk * 32 + kg * 8, T()), kf[kk], s);
+                f32x4_t dp = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                if constexpr (!XYZ) dp = mma(frag_row(sO, ORS, t * 16 + fr, kg * 8, T()), vf, dp);
+                const float4 l4 = *reinterpret_cast<const float4*>(sL + t * 16 + kg * 4);
+                const float4 d4 = *reinterpret_cast<const float4*>(sL + 64 + t * 16 + kg * 4);
+                const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq_[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ql = t * 16 + kg * 4 + r;
+                    // no masks: query rows past Nq are zero in LDS (Q, dO, lse, D), so their p multiplies zero; key columns past Nk are not stored
+                    const float p = __builtin_amdgcn_exp2f(s[r] * c2 - lq[r]);
+                    float dpv = dp[r];
+                    if constexpr (XYZ) {
+                        const float4 g = *reinterpret_cast<const float4*>(sO + ql * 16);
+                        dpv = x3[0] * g.x + x3[1] * g.y + x3[2] * g.z;
+                    }
+                    pv[tt * 4 + r] = p;
+                    dsv[tt * 4 + r] = p * (dpv - dq_[r]);    // the softmax scale is applied once, to dK
+                }
+            }
+            const Frag<T> sf = frag_regs(dsv, T());
+#pragma unroll
+            for (int u = 0; u < D / 16; ++u) {
+                dk[u] = mma(frag_colp(sQ, QRS, ks * 32 + kg * 4, ks * 32 + 16 + kg * 4, u * 16, lane, T()), sf, dk[u]);
+                if (D > 32 && (u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
             if constexpr (!XYZ) {
-                Frag<T> pf = frag_row(myP, PRS, fr, ks * 32 + kg * 8, T());
+                const Frag<T> pf = frag_regs(pv, T());
 #pragma unroll
-                for (int u = 0; u < 2; ++u) dvv[u] = mma(pf, frag_col(sO, ORS, ks * 32, u * 16, lane, T()), dvv[u]);
+                for (int u = 0; u < 2; ++u) dvv[u] = mma(frag_colp(sO, ORS, ks * 32 + kg * 4, ks * 32 + 16 + kg * 4, u * 16, lane, T()), pf, dvv[u]);
             }
         }
     }
-    T* dK = (T*)a.dk + h * a.hk + pb.k0 * a.ldk;
+    if (kv) {
+        T* dK = (T*)a.dk + h * a.hk + (pb.k0 + (long)kr) * a.ldk + kg * 4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int kr = key0 + kg * 4 + r;
-        if (kr < pb.Nk) {
-#pragma unroll
-            for (int u = 0; u < D / 16; ++u) Elem<T>::st(dK + (long)kr * a.ldk + u * 16 + fr, dk[u][r]);
-            if constexpr (!XYZ) {
-                T* dV = (T*)a.dv + h * a.hv + (pb.k0 + kr) * a.ldv;
-                Elem<T>::st(dV + fr, dvv[0][r]);
-                Elem<T>::st(dV + 16 + fr, dvv[1][r]);
-            }
+        for (int u = 0; u < D / 16; ++u) store4(dK + u * 16, dk[u][0] * a.scale, dk[u][1] * a.scale, dk[u][2] * a.scale, dk[u][3] * a.scale);
+        if constexpr (!XYZ) {
+            T* dV = (T*)a.dv + h * a.hv + (pb.k0 + (long)kr) * a.ldv + kg * 4;
+            store4(dV, dvv[0][0], dvv[0][1], dvv[0][2], dvv[0][3]);
+            store4(dV + 16, dvv[1][0], dvv[1][1], dvv[1][2], dvv[1][3]);
         }
     }
 }
@@ -525,17 +551,17 @@ static int launch_attn(const AttnArgs& a, int H, int mode, hipStream_t st, int n
 {
     const int gq = ((a.probs ? maxq : a.Nq) + 63) / 64, gk = ((a.probs ? maxk : a.Nk) + 63) / 64;
     constexpr int DV = 32;
-    const size_t krs = D * sizeof(T) + 16, vrs = XYZ ? 16 : DV * sizeof(T) + 16, prs = 64 * sizeof(T) + 16;
+    const size_t krs = D * sizeof(T) + 16, vrs = XYZ ? 16 : DV * sizeof(T) + 16;
     if (mode == 0) {
-        const size_t lds = 64 * krs + 64 * vrs + 4 * 16 * prs;
+        const size_t lds = 64 * krs + 64 * vrs;
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, XYZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((attn_fwd_kernel<T, D, XYZ>), dim3(gq, H, nprob), dim3(256), lds, st, a);
     } else if (mode == 1) {
-        const size_t lds = 64 * krs + 64 * vrs + 4 * 16 * prs;
+        const size_t lds = 64 * krs + 64 * vrs;
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<T, D, XYZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, XYZ>), dim3(gq, H, nprob), dim3(256), lds, st, a);
     } else {
-        const size_t lds = 64 * krs + 64 * vrs + 4 * 2 * 16 * prs + 128 * sizeof(float);
+        const size_t lds = 64 * krs + 64 * vrs + 128 * sizeof(float);
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, D, XYZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, XYZ>), dim3(gk, H, nprob), dim3(256), lds, st, a);
     }
