@@ -383,10 +383,17 @@ int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pac
                 else CK(dreg_downsample_sum(gy, dst_for(o.in2), y.B, y.D, y.H, y.W, ta.D, ta.H, ta.W, y.C, 0, stream));
                 CK(commit(o.in2));
             }
+            bool fused_add = false;
             if (e->needs_grad[o.in]) {
-                void* gx = dst_for(o.in);
+                // a second contribution to an existing gradient: the plain data-gradient convolution adds it in its epilogue (fp32,
+                // in place, one rounding) instead of going through the temporary and a separate add
+                fused_add = written[o.in] && !rows && !(w.pk_cls != SIZE_MAX && s2_class_ok(w, o.ksz, o.stride, o.pad)) && w.pk_dgrad != SIZE_MAX;
+                void* gx = fused_add ? grad(o.in) : dst_for(o.in);
                 Scope sc(e, st, i, 1);
-                if (rows) {
+                if (fused_add) {
+                    CK(dreg_conv3d_igemm_ws(gy, PK + w.pk_dgrad, gx, nullptr, gx, x.B, y.D, y.H, y.W, w.d0, x.D, x.H, x.W, w.d1,
+                                            o.ksz, o.stride, o.pad, 1, 0, x.D, x.H, x.W, 1, 0, 0, A + e->off_ks, e->sz_ks, stream));
+                } else if (rows) {
                     if (o.rows_in < 0 || o.rows_in >= nlists) return DREG_EINVAL;
                     if (hipMemsetAsync(gx, 0, (size_t)x.B * x.D * x.H * x.W * x.C * 2, st) != hipSuccess) return DREG_ELAUNCH;
                     CK(dreg_conv3d_igemm_rows(gy, PK + w.pk_dgrad, gx, nullptr, nullptr, (const int*)rowlists[2 * o.rows_in], (int)rowlists[2 * o.rows_in + 1],
@@ -399,7 +406,7 @@ int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pac
                                             o.ksz, o.stride, o.pad, 1, 0, 0, 0, 0, 0, 0, 0, A + e->off_ks, e->sz_ks, stream));
                 }
             }
-            if (e->needs_grad[o.in]) CK(commit(o.in));
+            if (e->needs_grad[o.in] && !fused_add) CK(commit(o.in));
         } else if (o.kind == OP_BN) {
             const int V = x.D * x.H * x.W;
             const bool res_g = o.in2 >= 0 && e->needs_grad[o.in2];
