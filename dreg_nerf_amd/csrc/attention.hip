@@ -6,11 +6,11 @@
 //   D = 32  : 8-head attention, V is [Nk, 32] per head, output in the operand dtype.
 //   D = 256 : single-head correspondence attention over the 6 stacked layer outputs, V = xyz (3 fp32 columns,
 //             accumulated on the VALU in fp32 so key-point coordinates never round to bf16).
-// One workgroup = 4 waves = 64 query (or key) rows of one head; each wave owns 16 rows; the other operand is
-// streamed through LDS in 64-row tiles.  S = Q K^T uses one 16x16x32 MFMA per 32 channels; probabilities are
-// re-laid out to the A-operand layout through a per-wave LDS scratch; strided B operands (V, K, Q, dO as
-// [row][channel]) are read with ds_read_b64_tr_b16 (bf16) or gathered (fp32).  fp32 operands use the exact
-// 16x16x4 f32 MFMA with the k-permutation "lane group g owns k = 8g..8g+7".
+// One workgroup = 4 waves = 64 query (or key) rows of one head; each wave owns 16 rows (one per lane column); the other operand is
+// streamed through LDS in 64-row tiles (next tile prefetched into registers).  Score tiles are computed transposed (one 16x16x32
+// MFMA per 32 channels) so that their C layout is the B-operand layout of the second product: probabilities never touch LDS (see
+// "transposed formulation" below).  Strided operands (V, K, Q, dO as [row][channel]) are read with ds_read_b64_tr_b16 (bf16) or
+// gathered (fp32).  fp32 operands use the exact 16x16x4 f32 MFMA with the k-permutation "lane group g owns k = 8g..8g+7".
 #include "common.h"
 
 template <typename T> struct Frag;
@@ -48,45 +48,6 @@ __device__ __forceinline__ Frag<float> frag_glob(const float* p, bool valid) {
     for (int e = 0; e < 8; ++e) f.v[e] = valid ? p[e] : 0.f;
     return f;
 }
-// B operand from a [k][col] row-major tile: element j = tile[k0 + j][col], col = cb + (lane & 15), k0 = kb0 + (lane>>4)*8
-__device__ __forceinline__ Frag<bf16_t> frag_col(const char* base, int rs, int kb0, int cb, int lane, bf16_t) {
-    typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
-    const int fi = lane & 15, kb = kb0 + (lane >> 4) * 8;
-    const char* p0 = base + (kb + (fi >> 2)) * rs + (cb + (fi & 3) * 4) * 2;
-    bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0));
-    bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(p0 + 4 * rs));
-    Frag<bf16_t> f; f.v = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return f;
-}
-__device__ __forceinline__ Frag<float> frag_col(const char* base, int rs, int kb0, int cb, int lane, float) {
-    const int fi = lane & 15, kb = kb0 + (lane >> 4) * 8;
-    Frag<float> f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) f.v[e] = *reinterpret_cast<const float*>(base + (kb + e) * rs + (cb + fi) * 4);
-    return f;
-}
-// Reductions over the 16 lanes of a DPP row (= the 16 key columns of an MFMA C tile) on the VALU's data-parallel-primitive
-// path instead of ds_bpermute (LDS crossbar round trips): xor 1, xor 2 by quad_perm, then row_half_mirror, then row_mirror — each
-// step pairs disjoint halves, so all 16 lanes end with the full result.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float group16_max(float v) {
-    v = fmaxf(v, dpp_f<0xB1>(v));    // quad_perm [1,0,3,2]
-    v = fmaxf(v, dpp_f<0x4E>(v));    // quad_perm [2,3,0,1]
-    v = fmaxf(v, dpp_f<0x141>(v));   // row_half_mirror
-    v = fmaxf(v, dpp_f<0x140>(v));   // row_mirror
-    return v;
-}
-__device__ __forceinline__ float group16_sum(float v) {
-    v += dpp_f<0xB1>(v);
-    v += dpp_f<0x4E>(v);
-    v += dpp_f<0x141>(v);
-    v += dpp_f<0x140>(v);
-    return v;
-}
-
 struct AttnArgs {
     const void *q, *k, *v;     // operand type T;  v = fp32 xyz [Nk,3] when XYZ
     void* o;                   // T [Nq, ...] or fp32 [H, Nq, 3] when XYZ
@@ -111,18 +72,7 @@ __device__ __forceinline__ Prob get_prob(const AttnArgs& a) {
     return p;
 }
 
-template <typename T, int D>
-__device__ __forceinline__ void load_tile(char* dst, int rs, const T* src, long ld, int row0, int nrows_valid, int tid) {
-    constexpr int GPR = D * sizeof(T) / 16;  // 16-byte granules per row
-    for (int q = tid; q < 64 * GPR; q += 256) {
-        const int r = q / GPR, g = q % GPR;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (row0 + r < nrows_valid) val = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(src + (long)(row0 + r) * ld) + g * 16);
-        *reinterpret_cast<uint4*>(dst + r * rs + g * 16) = val;
-    }
-}
-
-// Register-staged variant: fetch the NEXT tile's granules into registers while the current tile (already in LDS) is being consumed,
+// Tiles are register-staged: fetch the NEXT tile's granules into registers while the current tile (already in LDS) is being consumed,
 // store them after the block has finished reading the current one — the global-memory latency of a tile hides behind a tile of MFMAs.
 template <typename T, int D>
 struct TileRegs {
@@ -144,13 +94,6 @@ struct TileRegs {
         }
     }
 };
-// the probability scratch tiles are private to a wave: LDS operations of one wave complete in order, so a wave-level fence is enough
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // ------------------------------------------------------------------------------------------------ transposed formulation
 // All three kernels compute the score tile TRANSPOSED with respect to the operand they stream, so that the MFMA C layout of the
 // scores (lane (fr, kg) holds rows kg*4..kg*4+3 of column fr) IS the B-operand layout of the second product (lane (fr, kg) holds
