@@ -222,7 +222,7 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
     const bf16_t* __restrict__ in, const bf16_t* __restrict__ wt, TO* __restrict__ out,
     const float* __restrict__ bias, const TO* __restrict__ addend, ConvGeom g,
     int relu, int Da, int Ha, int Wa, int add_shift, int tilesN, uint32_t in_bytes, uint32_t wt_bytes,
-    const int* __restrict__ rowlist, uint32_t nrows, int ksplit)
+    const int* __restrict__ rowlist, uint32_t nrows, int ksplit, int nstage)
 {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     constexpr int NW = BN == 256 ? 8 : 4, WAVES_N = BN == 256 ? 4 : 2;   // waves: 2 (M) x WAVES_N (N), (BM/2) x (BN/WAVES_N) each
@@ -324,12 +324,21 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
     const int k_begin = ksplit > 1 ? (int)((long)nk * blockIdx.y / ksplit) : 0;
     const int k_end = ksplit > 1 ? (int)((long)nk * (blockIdx.y + 1) / ksplit) : nk;
     if (ksplit > 1) out += (size_t)blockIdx.y * g.M * g.Cout;
-    issue(k_begin, 0);
+    // ring of nstage (2..4) LDS stages: stage k is consumed while the loads of up to nstage-1 later stages are in flight
+    constexpr int LPS = IA + IBW;                      // direct-to-LDS loads per wave per stage (vmcnt retires them in order)
+    for (int s = 0; s < nstage - 1; ++s)
+        if (k_begin + s < k_end) issue(k_begin + s, s);
+    int cbuf = 0, ibuf = nstage - 1;                   // stage being consumed / stage the next issue goes to
     for (int k = k_begin; k < k_end; ++k) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (k + 1 < k_end) issue(k + 1, (k + 1 - k_begin) & 1);
-        compute((k - k_begin) & 1);
+        const int ahead = min(nstage - 2, k_end - 1 - k);   // later stages already issued
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // stage k landed for every wave; everyone is done with stage k-1
+        if (k + nstage - 1 < k_end) issue(k + nstage - 1, ibuf);
+        compute(cbuf);
+        cbuf = cbuf + 1 == nstage ? 0 : cbuf + 1;
+        ibuf = ibuf + 1 == nstage ? 0 : ibuf + 1;
     }
 
     // Epilogue through LDS, one pass per wave row (wm): accumulators -> fp32 tile [BM/2][BN] (16-column blocks XOR-ed with
@@ -1033,6 +1042,13 @@ static int conv_ksplit(const ConvGeom& g, bool has_addend)
     return s < 2 ? 1 : (int)s;
 }
 
+// LDS stages of the direct-to-LDS kernel.  Measured (tools/bench_small_conv.py): a deeper ring (3-4 stages) does not help even when a
+// launch leaves one block per CU — a 128x128 block moves 96 KB through LDS per K step (64 KB of fragment reads + 32 KB of DMA
+// writes, ~750 cycles at 128 B/clk) against 512 cycles of MFMA, so the K loop sits on the LDS-bandwidth roof, not on load latency.
+// The default therefore stays 2 (two blocks per CU where the grid allows); dreg_conv_set_glds_stages forces 2..4 for experiments.
+static int g_glds_stages = 0;
+static inline int glds_stages(long blocks) { (void)blocks; return g_glds_stages ? g_glds_stages : 2; }
+
 template <typename T, typename TO>
 static int launch_conv(const void* in, const void* wt, void* out, const float* bias, const void* addend,
                        const ConvGeom& g, int relu, int Da, int Ha, int Wa, int add_shift, hipStream_t st,
@@ -1048,14 +1064,19 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
             const size_t slice = (size_t)g.M * g.Cout;
             if (ks_ws_bytes < slice * ksplit * sizeof(float)) return DREG_EINVAL;
             const int tm_ = (g.M + 127) / 128;
-            if (g.Cout % 128 == 0)
-                hipLaunchKernelGGL((conv_igemm_glds_kernel<float, 128, 128>), dim3(tm_ * (g.Cout / 128), ksplit), dim3(256), (size_t)2 * 256 * 128, st,
+            if (g.Cout % 128 == 0) {
+                const int ns = glds_stages(tm_ * (g.Cout / 128) * ksplit);
+                if (ns > 2) (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<float, 128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, ns * 256 * 128);
+                hipLaunchKernelGGL((conv_igemm_glds_kernel<float, 128, 128>), dim3(tm_ * (g.Cout / 128), ksplit), dim3(256), (size_t)ns * 256 * 128, st,
                                    (const bf16_t*)in, (const bf16_t*)wt, ks_ws, nullptr, nullptr, g, 0, 0, 0, 0, 0, g.Cout / 128,
-                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, nullptr, g.M, ksplit);
-            else
-                hipLaunchKernelGGL((conv_igemm_glds_kernel<float, 128, 64>), dim3(tm_ * (g.Cout / 64), ksplit), dim3(256), (size_t)2 * 192 * 128, st,
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, nullptr, g.M, ksplit, ns);
+            } else {
+                const int ns = glds_stages(tm_ * (g.Cout / 64) * ksplit);
+                if (ns > 2) (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<float, 128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, ns * 192 * 128);
+                hipLaunchKernelGGL((conv_igemm_glds_kernel<float, 128, 64>), dim3(tm_ * (g.Cout / 64), ksplit), dim3(256), (size_t)ns * 192 * 128, st,
                                    (const bf16_t*)in, (const bf16_t*)wt, ks_ws, nullptr, nullptr, g, 0, 0, 0, 0, 0, g.Cout / 64,
-                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, nullptr, g.M, ksplit);
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, nullptr, g.M, ksplit, ns);
+            }
             DREG_LAUNCH_CHECK();
             const size_t total8 = slice / 8;
             const int nb = (int)((total8 + 255) / 256 > 2048 ? 2048 : (total8 + 255) / 256);
@@ -1066,11 +1087,12 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
         if (g_use_glds && g.sd == 1 && g.Cin % 64 == 0 && g.ntaps <= 32 && in_bytes < 0x7fffff00ull && wt_bytes < 0x7fffff00ull) {
 #define GL_LAUNCH(BMv, BNv, NT) do { \
                 const int tm_ = (nrows + BMv - 1) / BMv, tn_ = g.Cout / BNv; \
-                const size_t lds_ = (size_t)2 * (BMv + BNv) * 128; \
+                const int ns_ = BNv == 256 ? 2 : glds_stages(tm_ * tn_); \
+                const size_t lds_ = (size_t)ns_ * (BMv + BNv) * 128; \
                 if (lds_ > 65536) (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<TO, BMv, BNv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
                 hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, BMv, BNv>), dim3(tm_ * tn_), dim3(NT), lds_, st, \
                                    (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tn_, \
-                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows, 1); } while (0)
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows, 1, ns_); } while (0)
             if (g.Cout % 256 == 0 && (g_use_glds == 1 || g_use_glds == 4 || g_use_glds == 5) && nrows >= 65536) GL_LAUNCH(256, 256, 512);
             else if (g.Cout % 256 == 0 && g_use_glds == 3 && nrows >= 65536) GL_LAUNCH(128, 256, 512);
             else if (g.Cout % 128 == 0) GL_LAUNCH(128, 128, 256);
@@ -1229,6 +1251,7 @@ int dreg_pack_conv_weights_batched(const void* descs, int n, int total_rows, int
 static int g_force_wgrad_splits = 0;
 static int g_wgrad_target_blocks = 3072;
 // tuning knob: workgroups the automatic voxel-split choice of the weight-gradient kernels aims for
+void dreg_conv_set_glds_stages(int stages) { g_glds_stages = (stages >= 2 && stages <= 4) ? stages : 0; }
 void dreg_conv_set_wgrad_target_blocks(int blocks) { g_wgrad_target_blocks = blocks > 0 ? blocks : 3072; }
 // tuning / test knob: force the number of voxel splits of the weight-gradient kernels (0 = automatic)
 void dreg_conv_set_wgrad_splits(int splits) { g_force_wgrad_splits = splits; }

@@ -80,6 +80,7 @@ int dreg_conv3d_dgrad_s2(const void* gout, const void* wt_class_packed, void* di
  * dw[Cout][Cin_real][ksz^3] (fp32, torch layout) (+)= sum_m gout[m,:]^T x in[gather(m, tap), :]. */
 /* tuning / test knob: force the number of voxel splits of the weight-gradient kernels (0 = automatic) */
 void dreg_conv_set_wgrad_splits(int splits);
+void dreg_conv_set_glds_stages(int stages);          /* LDS pipeline stages of the direct-to-LDS convolution: 0 = default (2), 2..4 forces; results do not depend on it */
 void dreg_conv_set_wgrad_target_blocks(int blocks);   /* workgroups the automatic split choice aims for (default 3072) */
 int dreg_conv3d_wgrad_splits(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int dtype);
 size_t dreg_conv3d_wgrad_workspace_bytes(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int dtype);

@@ -21,14 +21,16 @@ for (D, cin, cout, k) in shapes:
     wp = ops.packed_weight(w, cin, False, 0)
     flops = 2.0 * B * D ** 3 * cout * cin * k ** 3
     out = {}
-    for mode in (5, 1):
-        lib.dreg_conv_set_glds(mode)
+    for mode in (5, 1, 12, 14):      # 5 = no split-K; 1 = default; 12 / 14 = default with 2 / 4 LDS stages forced
+        lib.dreg_conv_set_glds(1 if mode > 5 else mode)
+        lib.dreg_conv_set_glds_stages(mode - 10 if mode > 5 else 0)
         y = ops.conv_igemm(x, wp, None, None, (D, D, D), cin, cout, k, 1, k // 2, False)
         out[mode] = y.float()
         ms = timeit(lambda: ops.conv_igemm(x, wp, None, None, (D, D, D), cin, cout, k, 1, k // 2, False))
         print(f"B{B} {D}^3 {cin}->{cout} k{k} mode{mode}: fwd {ms*1e3:.1f} us {flops/ms/1e9:.0f} TF", end="   ")
-    err = (out[5] - out[1]).abs().max().item() / out[5].abs().max().item()
-    lib.dreg_conv_set_glds(1)
+    err = max((out[5] - out[1]).abs().max().item(), (out[12] - out[14]).abs().max().item()) / out[5].abs().max().item()
+    assert torch.equal(out[12], out[14]) and torch.equal(out[1], out[14])
+    lib.dreg_conv_set_glds(1); lib.dreg_conv_set_glds_stages(0)
     print(f"relerr {err:.1e}  wgrad:", end=" ")
     for f in (0, 1, 2, 4, 8, 16, 32):
         lib.dreg_conv_set_wgrad_splits(f)
