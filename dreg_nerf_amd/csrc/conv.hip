@@ -1043,9 +1043,8 @@ static int conv_ksplit(const ConvGeom& g, bool has_addend)
 }
 
 // LDS stages of the direct-to-LDS kernel.  Measured (tools/bench_small_conv.py): a deeper ring (3-4 stages) does not help even when a
-// launch leaves one block per CU — a 128x128 block moves 96 KB through LDS per K step (64 KB of fragment reads + 32 KB of DMA
-// writes, ~750 cycles at 128 B/clk) against 512 cycles of MFMA, so the K loop sits on the LDS-bandwidth roof, not on load latency.
-// The default therefore stays 2 (two blocks per CU where the grid allows); dreg_conv_set_glds_stages forces 2..4 for experiments.
+// launch leaves one block per CU — the K step (~1,000 cycles for 32 MFMAs per wave) is bound by the issue cost of its 8 direct-to-LDS
+// pieces per wave, not by their latency.  The default stays 2; dreg_conv_set_glds_stages forces 2..4 for experiments.
 static int g_glds_stages = 0;
 static inline int glds_stages(long blocks) { (void)blocks; return g_glds_stages ? g_glds_stages : 2; }
 
