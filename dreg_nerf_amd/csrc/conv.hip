@@ -1032,7 +1032,8 @@ static int conv_ksplit(const ConvGeom& g, bool has_addend)
     if (!bn) return 1;
     // the slice count must not depend on how many grids share the launch (a pair's result is independent of its batch
     // mates, bit for bit): it is derived from the per-grid voxel count at a nominal batch of 8 grids
-    const long rows_nominal = 8L * g.Do * g.Ho * g.Wo;
+    const long vox = (long)g.Do * g.Ho * g.Wo;
+    const long rows_nominal = vox == 1 ? (long)g.M : 8L * vox;   // 1x1x1 volumes = linear layers: rows are the batch dimension
     const long tiles = ((rows_nominal + 127) / 128) * (g.Cout / bn);
     const int nk = g.ntaps * (g.Cin / 64);
     if (tiles >= 128 || nk < 32) return 1;   // short K: the second (reduce) launch costs more than the idle CUs

@@ -533,8 +533,10 @@ def linear(x2d: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], rel
            out_f32: bool = False) -> torch.Tensor:
     """[N, Cin] x [Cout, Cin]^T (+bias) (+residual) (relu) through the 1x1x1 path of the same kernels."""
     n, cin = x2d.shape
-    res = residual.view(1, 1, 1, n, w.shape[0]) if residual is not None else None
-    y = Conv3dFn.apply(x2d.view(1, 1, 1, n, cin), w, bias, res, 1, 0, relu, out_f32, residual is not None)
+    # rows as the batch dimension of 1x1x1 "volumes": the kernels' row decode (magic division by the volume extents) then has no
+    # size limit — as one x-row of n voxels it needs n^2 < 2^32, which 6 stacked layers of ~11k points already exceed
+    res = residual.view(n, 1, 1, 1, w.shape[0]) if residual is not None else None
+    y = Conv3dFn.apply(x2d.view(n, 1, 1, 1, cin), w, bias, res, 1, 0, relu, out_f32, residual is not None)
     return y.view(n, w.shape[0])
 
 

@@ -278,6 +278,8 @@ class NeRFRegTr(nn.Module):
                 idxs.append(m)
         res = tuple(grids[0]) if sparse else tuple(grids[0].shape[-3:])
         counts = [int(m.shape[0]) for m in idxs]
+        if min(counts) == 0:
+            raise ValueError("a block has no occupied voxel (empty voxel_mask): nothing to register")
         idx_cat = torch.cat(idxs).contiguous()
         pb_cat = torch.repeat_interleave(torch.arange(len(idxs), dtype=torch.int32, device=dev), L.to_device_async(counts, torch.int64, dev),
                                          output_size=sum(counts))

@@ -336,3 +336,27 @@ def test_batched_repack_equals_per_layer_pack():
             L.check(lib.dreg_pack_conv_weight(L.ptr(p_.detach()), L.ptr(refd), p_.shape[0], p_.shape[1], cp, ksz, 1, 0, L.stream()), "pack")
             assert torch.equal(d1.view(torch.int16), refd.view(torch.int16))
     ops.clear_pack_cache()
+
+
+@pytest.mark.parametrize("n", [70001, 131072])
+def test_linear_with_many_rows(n):
+    """Linear layers run as 1x1x1 convolutions with the ROWS as the batch dimension: six stacked decoder inputs of a step with
+    > 10,922 points each (6R >= 65,536 rows) used to fail the geometry check of the kernels' magic row decode (n^2 >= 2^32)."""
+    DEV = _dev()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, 256, generator=g).to(DEV).bfloat16().requires_grad_(True)
+    w = (torch.randn(128, 256, generator=g) * 0.05).to(DEV).requires_grad_(True)
+    b = torch.randn(128, generator=g).to(DEV).requires_grad_(True)
+    y = ops.linear(x, w, b, relu=True)
+    ref = F.relu(x.detach().float() @ w.detach().t() + b.detach())
+    assert y.shape == (n, 128)
+    tol = 2e-2 * float(ref.abs().max())
+    assert float((y.float() - ref).abs().max()) <= tol
+    gy = torch.randn(n, 128, generator=g).to(DEV).bfloat16()
+    ops.linear(x, w, b).backward(gy)      # no ReLU here: its mask flips where bf16 and fp32 pre-activations straddle zero
+    xr = x.detach().float().requires_grad_(True); wr = w.detach().clone().requires_grad_(True)
+    (xr @ wr.t() + b.detach()).backward(gy.float())
+    assert float((x.grad.float() - xr.grad).abs().max()) <= 2e-2 * float(xr.grad.abs().max())
+    assert float((w.grad - wr.grad).abs().max()) <= 2e-2 * float(wr.grad.abs().max())
+    # the last row is computed (ragged tile) and distinct from its neighbours
+    assert torch.isfinite(y[-1]).all() and not torch.equal(y[-1], y[-2])
