@@ -13,15 +13,24 @@ model = NeRFRegTr(precision="bf16").to(dev).train()
 ts = TrainStep(model, lr=1e-4)
 pose = synth.fixed_pose()
 pool = []
-for i in range(12):      # 12 different pairs (different shell radii -> different row counts), cycled in groups of 4
+def make(i, j, r0, r1):
+    g, mk = synth.shell_grid(128, 1 + 2 * i + j, r0, r1)
+    return g.permute(3, 2, 0, 1).unsqueeze(0).contiguous(), mk
+EDGE = os.environ.get("SOAK_EDGE")
+for i in range(12):      # 12 different pairs (different shell radii -> different row counts), cycled in groups
     d = {"pose": pose[None].clone(), "src_nerf_path": "", "tgt_nerf_path": ""}
     for j, side in enumerate(("src", "tgt")):
-        g, mk = synth.shell_grid(128, 1 + 2 * i + j, 0.76 + 0.01 * (i % 5), 0.81 + 0.012 * ((i + j) % 4))
-        d[side + "_xyz_rgba"], d[side + "_mask"] = g.permute(3, 2, 0, 1).unsqueeze(0).contiguous(), mk
+        r0, r1 = 0.76 + 0.01 * (i % 5), 0.81 + 0.012 * ((i + j) % 4)
+        if EDGE and i % 6 == 1:
+            r0, r1 = 0.3, 1.2          # a thick shell: > 20 % of the volume occupied -> the dense head path for that step
+        if EDGE and i % 6 == 4:
+            r0, r1 = 0.20, 0.215       # a tiny shell: a few hundred voxels, fewer points than one attention tile after the voxel rounds
+        d[side + "_xyz_rgba"], d[side + "_mask"] = make(i, j, r0, r1)
     pool.append({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()})
 losses, t0 = [], time.perf_counter()
 for s in range(steps):
-    batch = [pool[(4 * s + j) % len(pool)] for j in range(4)]
+    nb = (1 + s % 4) if EDGE else 4          # 1..4 pairs per step in the edge-case run
+    batch = [pool[(4 * s + j) % len(pool)] for j in range(nb)]
     out = ts.step(batch)
     losses.append(out["losses"]["total"])
     if os.environ.get("SOAK_SYNC"):
