@@ -55,7 +55,7 @@ template <typename T, typename TO, int BN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const T* __restrict__ in, const T* __restrict__ wt, TO* __restrict__ out,
     const float* __restrict__ bias, const TO* __restrict__ addend, ConvGeom g,
-    int relu, int Da, int Ha, int Wa, int add_shift, int tilesN)
+    int relu, int Da, int Ha, int Wa, int add_shift, int tilesN, const uint8_t* __restrict__ rowocc = nullptr)
 {
     constexpr int BM = 128;
     constexpr int G = 16 / sizeof(T);
@@ -74,6 +74,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int gq = t & 7, rbase = t >> 3;
+
+    // rowocc (host guarantees: forward gather, no bias / addend, BM % Wo == 0): byte per output W-row, 0 = its whole receptive field
+    // is zero, so the result is exactly zero: tiles made of such rows are zero-filled without touching the operands
+    if (rowocc) {
+        const uint32_t nrow = BM / (uint32_t)g.Wo, row0 = m0 / (uint32_t)g.Wo, rows_total = g.M / (uint32_t)g.Wo;
+        bool any = false;
+        for (uint32_t r = 0; r < nrow; ++r) any = any || (row0 + r < rows_total && rowocc[row0 + r] != 0);
+        if (!any) {
+            const size_t base = (size_t)m0 * g.Cout + n0;
+            for (int i = t; i < BM * (BN / G); i += 256) {
+                const int r = i / (BN / G), c = (i - r * (BN / G)) * G;
+                if (m0 + r < g.M) {
+                    if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint4*>(out + base + (size_t)r * g.Cout + c) = make_uint4(0, 0, 0, 0);
+                    else { for (int e = 0; e < G; ++e) out[base + (size_t)r * g.Cout + c + e] = (TO)0; }
+                }
+            }
+            return;
+        }
+    }
 
     int zb[4], yb[4], xb[4];
     uint32_t vb[4];
@@ -422,7 +441,7 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
 template <typename T, int BM, int BNC, bool TR>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const T* __restrict__ gout, const T* __restrict__ in, float* __restrict__ part,
-    ConvGeom g, int tilesCol, uint32_t vox_per_split)
+    ConvGeom g, int tilesCol, uint32_t vox_per_split, const uint8_t* __restrict__ rowocc = nullptr)
 {
     constexpr int KV = 32;
     constexpr int G = 16 / sizeof(T);
@@ -559,14 +578,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 
     if (v_begin < v_end) {
         const int nk = (int)((v_end - v_begin + KV - 1) / KV);
-        load_g(v_begin);
-        store_l(0);
+        // rowocc (host guarantees Wo % KV == 0 and vox_per_split % KV == 0): a 32-voxel step lies in one output W-row; rows flagged 0
+        // gather only zeros, so their products add exactly nothing and the step is skipped
+        auto next = [&](int k) {
+            if (rowocc)
+                while (k < nk && rowocc[(v_begin + (uint32_t)k * KV) / (uint32_t)g.Wo] == 0) ++k;
+            return k;
+        };
+        int k = next(0), buf = 0;
+        if (k < nk) {
+            load_g(v_begin + (uint32_t)k * KV);
+            store_l(0);
+        }
         __syncthreads();
-        for (int k = 0; k < nk; ++k) {
-            if (k + 1 < nk) load_g(v_begin + (uint32_t)(k + 1) * KV);
-            compute(k & 1);
-            if (k + 1 < nk) store_l((k + 1) & 1);
+        while (k < nk) {
+            const int kn = next(k + 1);
+            if (kn < nk) load_g(v_begin + (uint32_t)kn * KV);
+            compute(buf);
+            if (kn < nk) store_l(buf ^ 1);
             __syncthreads();
+            k = kn; buf ^= 1;
         }
     }
     float* dst = part + (size_t)blockIdx.y * g.Cout * g.Kpad;
@@ -596,7 +627,7 @@ template <int BM, int BNC, bool ROWS>
 __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(
     const bf16_t* __restrict__ gout, const bf16_t* __restrict__ in, float* __restrict__ part,
     ConvGeom g, int tilesCol, int tiles, int nsplit, uint32_t vox_per_split, uint32_t gout_bytes, uint32_t in_bytes,
-    const int* __restrict__ rowlist, uint32_t nrows)
+    const int* __restrict__ rowlist, uint32_t nrows, const uint8_t* __restrict__ rowocc = nullptr)
 {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
@@ -751,6 +782,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(
         // NS-deep LDS ring, loads issued 3 stages ahead; stage k is consumed after a COUNTED wait (the two younger stages stay
         // in flight across the barrier) + a raw s_barrier (a __syncthreads() here would drain the DMA queue with vmcnt(0)).
         const int nk = (int)((v_end - v_begin + KV - 1) / KV);
+        if (rowocc) {
+            // rowocc (dense launches with Wo % KV == 0): a 64-voxel stage lies in one output W-row; a row flagged 0 gathers only
+            // zeros, its products add exactly nothing, and the stage is skipped.  The flags of this block's stages go to LDS first
+            // (a global load inside the K loop would drain the DMA queue).
+            uint8_t* socc = reinterpret_cast<uint8_t*>(smem + NS * STAGE);
+            for (int i = t; i < nk; i += 256) socc[i] = rowocc[(v_begin + (uint32_t)i * KV) / (uint32_t)g.Wo];
+            __syncthreads();
+            auto next = [&](int k) { while (k < nk && socc[k] == 0) ++k; return k; };
+            int k = next(0), buf = 0;
+            if (k < nk) issue(v_begin + (uint32_t)k * KV, 0);
+            while (k < nk) {
+                const int kn = next(k + 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (kn < nk) issue(v_begin + (uint32_t)kn * KV, buf ^ 1);
+                compute(buf);
+                k = kn; buf ^= 1;
+            }
+        } else {
         for (int p = 0; p < NS - 1 && p < nk; ++p) issue(v_begin + (uint32_t)p * KV, p);
         for (int k = 0; k < nk; ++k) {
             const int ahead = min(nk - 1 - k, NS - 2);   // stages issued after stage k that may stay in flight
@@ -760,6 +810,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(
             __builtin_amdgcn_s_barrier();
             if (k + NS - 1 < nk) issue(v_begin + (uint32_t)(k + NS - 1) * KV, (k + NS - 1) % NS);
             compute(k % NS);
+        }
         }
     }
     float* dst = part + (size_t)split * g.Cout * g.Kpad;
@@ -1052,8 +1103,11 @@ static inline int glds_stages(long blocks) { (void)blocks; return g_glds_stages 
 template <typename T, typename TO>
 static int launch_conv(const void* in, const void* wt, void* out, const float* bias, const void* addend,
                        const ConvGeom& g, int relu, int Da, int Ha, int Wa, int add_shift, hipStream_t st,
-                       const int* rowlist = nullptr, uint32_t nrows_in = 0, float* ks_ws = nullptr, size_t ks_ws_bytes = 0)
+                       const int* rowlist = nullptr, uint32_t nrows_in = 0, float* ks_ws = nullptr, size_t ks_ws_bytes = 0,
+                       const uint8_t* rowocc = nullptr)
 {
+    // output-row occupancy is honoured by the register-staged kernel for plain forward gathers whose tiles are whole W-rows
+    if (rowocc && (rowlist || bias || addend || relu || g.dsign != 1 || g.sd != 1 || g.Wo <= 0 || 128 % g.Wo != 0 || g.M % (uint32_t)g.Wo != 0)) rowocc = nullptr;
     const uint32_t nrows = rowlist ? nrows_in : g.M;
     const int tilesM = (nrows + 127) / 128;
     if (rowlist && nrows == 0) return DREG_OK;
@@ -1108,18 +1162,23 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
         const int tilesN = g.Cout / 128;
         const size_t lds = 2 * (128 + 128) * 128;
         hipLaunchKernelGGL((conv_igemm_kernel<T, TO, 128>), dim3(tilesM * tilesN), dim3(256), lds, st,
-                           (const T*)in, (const T*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN);
+                           (const T*)in, (const T*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN, rowocc);
     } else if (g.Cout % 64 == 0) {
         const int tilesN = g.Cout / 64;
         const size_t lds = 2 * (128 + 64) * 128;
         hipLaunchKernelGGL((conv_igemm_kernel<T, TO, 64>), dim3(tilesM * tilesN), dim3(256), lds, st,
-                           (const T*)in, (const T*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN);
+                           (const T*)in, (const T*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN, rowocc);
     } else return DREG_EINVAL;
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
 
 extern "C" {
+
+int dreg_conv3d_igemm_occ(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
+                          int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                          int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
+                          int dtype, int out_f32, void* workspace, size_t workspace_bytes, const uint8_t* rowocc, void* stream);
 
 // dtype: 0 = bf16 activations/weights (fp32 accumulate), 1 = fp32 (exact-f32 MFMA).  out_f32: bf16 inputs, fp32 output.
 // transposed = 0: out[b,o,:] = sum_d in[b, o*stride - pad + d, :] . W[:, d, :]           (forward)
@@ -1142,6 +1201,16 @@ int dreg_conv3d_igemm_ws(const void* in, const void* wt_packed, void* out, const
                          int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
                          int dtype, int out_f32, void* workspace, size_t workspace_bytes, void* stream)
 {
+    return dreg_conv3d_igemm_occ(in, wt_packed, out, bias, addend, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, ksz, stride, pad, transposed, relu,
+                                 Da, Ha, Wa, add_same, dtype, out_f32, workspace, workspace_bytes, nullptr, stream);
+}
+// the same with output-row occupancy flags rowocc byte [B, Do, Ho] (dreg_conv_row_occupancy; may be null): W-rows flagged 0 have an
+// all-zero receptive field and are written as zeros without being computed (forward, no bias / addend / ReLU) — same result.
+int dreg_conv3d_igemm_occ(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
+                          int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                          int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
+                          int dtype, int out_f32, void* workspace, size_t workspace_bytes, const uint8_t* rowocc, void* stream)
+{
     const int add_shift = add_same ? 0 : 1;
     ConvGeom g;
     const int es = dtype == 0 ? 2 : 4;
@@ -1150,10 +1219,10 @@ int dreg_conv3d_igemm_ws(const void* in, const void* wt_packed, void* out, const
     if (g.M == 0) return DREG_OK;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0) {
-        if (out_f32) return launch_conv<bf16_t, float>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st, nullptr, 0, (float*)workspace, workspace_bytes);
-        return launch_conv<bf16_t, bf16_t>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st, nullptr, 0, (float*)workspace, workspace_bytes);
+        if (out_f32) return launch_conv<bf16_t, float>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st, nullptr, 0, (float*)workspace, workspace_bytes, rowocc);
+        return launch_conv<bf16_t, bf16_t>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st, nullptr, 0, (float*)workspace, workspace_bytes, rowocc);
     }
-    return launch_conv<float, float>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st);
+    return launch_conv<float, float>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st, nullptr, 0, nullptr, 0, rowocc);
 }
 int dreg_conv3d_igemm(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
                       int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
@@ -1291,7 +1360,7 @@ size_t dreg_conv3d_wgrad_workspace_bytes(int B, int Do, int Ho, int Wo, int Cin,
 static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspace, size_t workspace_bytes,
                       int B, int Di, int Hi, int Wi, int Cin, int Cin_real, int Do, int Ho, int Wo, int Cout,
                       int ksz, int stride, int pad, int accumulate, int dtype, int use_tr, void* stream,
-                      const int* rowlist, uint32_t nrows_list)
+                      const int* rowlist, uint32_t nrows_list, const uint8_t* rowocc = nullptr)
 {
     ConvGeom g;
     const int es = dtype == 0 ? 2 : 4;
@@ -1313,7 +1382,8 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
     dim3 grid(tilesRow * tilesCol, nsplit);
     const size_t lds = (size_t)2 * 32 * (bm + bnc) * es;
     float* part = (float*)workspace;
-#define WG_LAUNCH(T, BMv, BNv, TRv) hipLaunchKernelGGL((conv_wgrad_kernel<T, BMv, BNv, TRv>), grid, dim3(256), lds, st, (const T*)gout, (const T*)in, part, g, tilesCol, vps)
+    if (rowocc && (rowlist || Wo % 64 != 0)) rowocc = nullptr;   // the flags are per output W-row: stages must not straddle rows
+#define WG_LAUNCH(T, BMv, BNv, TRv) hipLaunchKernelGGL((conv_wgrad_kernel<T, BMv, BNv, TRv>), grid, dim3(256), lds, st, (const T*)gout, (const T*)in, part, g, tilesCol, vps, rowocc)
 #define WG_DISPATCH(T, TRv) do { \
         if (bm == 128 && bnc == 128) WG_LAUNCH(T, 128, 128, TRv); \
         else if (bm == 128 && bnc == 64) WG_LAUNCH(T, 128, 64, TRv); \
@@ -1322,7 +1392,7 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
     const uint64_t gbytes = (uint64_t)g.M * Cout * 2, ibytes = (uint64_t)B * Di * Hi * Wi * Cin * 2;
     if (dtype == 0 && use_tr && g_use_glds && gbytes < 0x7fffff00ull && ibytes < 0x7fffff00ull) {
 #define WGG(BMv, BNv) do { if (rowlist) hipLaunchKernelGGL((conv_wgrad_glds_kernel<BMv, BNv, true>), dim3(tilesRow * tilesCol * nsplit), dim3(256), (size_t)2 * 64 * (bm + bnc) * 2 + (size_t)vps * 4, st, (const bf16_t*)gout, (const bf16_t*)in, part, g, tilesCol, tilesRow * tilesCol, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows); \
-        else hipLaunchKernelGGL((conv_wgrad_glds_kernel<BMv, BNv, false>), dim3(tilesRow * tilesCol * nsplit), dim3(256), (size_t)2 * 64 * (bm + bnc) * 2, st, (const bf16_t*)gout, (const bf16_t*)in, part, g, tilesCol, tilesRow * tilesCol, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows); } while (0)
+        else hipLaunchKernelGGL((conv_wgrad_glds_kernel<BMv, BNv, false>), dim3(tilesRow * tilesCol * nsplit), dim3(256), (size_t)2 * 64 * (bm + bnc) * 2 + (rowocc ? (size_t)(vps / 64 + 16) : 0), st, (const bf16_t*)gout, (const bf16_t*)in, part, g, tilesCol, tilesRow * tilesCol, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, rowocc); } while (0)
         if (rowlist && vps > 20480) return DREG_EINVAL;   // the row-list slice must fit in LDS behind the stages (caller falls back to dense)
         if (rowlist) {
             const int ldsr = 2 * 64 * (bm + bnc) * 2 + (int)vps * 4;
@@ -1354,6 +1424,15 @@ int dreg_conv3d_wgrad(const void* gout, const void* in, float* dw, void* workspa
 {
     return wgrad_impl(gout, in, dw, workspace, workspace_bytes, B, Di, Hi, Wi, Cin, Cin_real, Do, Ho, Wo, Cout, ksz, stride, pad,
                       accumulate, dtype, use_tr, stream, nullptr, 0);
+}
+// the same with output-row occupancy flags (dreg_conv_row_occupancy): output W-rows flagged 0 have an all-zero receptive field in
+// `in`, so they are left out of the reduction — same result, bit for bit.  rowocc may be null.
+int dreg_conv3d_wgrad_occ(const void* gout, const void* in, float* dw, void* workspace, size_t workspace_bytes,
+                          int B, int Di, int Hi, int Wi, int Cin, int Cin_real, int Do, int Ho, int Wo, int Cout,
+                          int ksz, int stride, int pad, int accumulate, int dtype, int use_tr, const uint8_t* rowocc, void* stream)
+{
+    return wgrad_impl(gout, in, dw, workspace, workspace_bytes, B, Di, Hi, Wi, Cin, Cin_real, Do, Ho, Wo, Cout, ksz, stride, pad,
+                      accumulate, dtype, use_tr, stream, nullptr, 0, rowocc);
 }
 
 // ---- active-set ("row list") forms, bf16, stride 1: only the output voxels rows[0..nrows) (ascending int32 flat indices

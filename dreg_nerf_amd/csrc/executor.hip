@@ -62,6 +62,7 @@ struct Exec {
     std::vector<hipEvent_t> ev;            // per op: "gy of this op is complete" (recorded on the caller's stream)
     hipEvent_t ev_done = nullptr;
     bool use_aux = true;
+    const uint8_t* in_rowocc = nullptr;   // output-row occupancy of the convolution that reads the network input (may be null)
 };
 
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -249,6 +250,9 @@ int dreg_exec_repack(void* h, const void* descs_dev, const int* row_desc_dev, vo
 
 // 1 (default): weight / bias gradients on the executor's own second stream, overlapping the data-gradient chain; 0: one stream
 void dreg_exec_set_overlap(void* h, int enable) { ((Exec*)h)->use_aux = enable != 0; }
+// Output-row occupancy flags (dreg_conv_row_occupancy) of the convolution that reads the network input x_in — the stem: byte
+// [B, Do, Ho], 0 = the row's receptive field in x_in is all zero.  Used by the next forward / backward calls; null = none.
+void dreg_exec_set_input_row_occupancy(void* h, const uint8_t* rowocc) { ((Exec*)h)->in_rowocc = rowocc; }
 void dreg_exec_set_timing(void* h, int enable) { ((Exec*)h)->timing = enable != 0; }   // records are kept until read
 // After a stream synchronisation: elapsed ms of the bracketed launches since the last set_timing; records are (op, kind, ms)
 // with kind 0 forward, 1 data gradient, 2 weight gradient (+reduce).  Returns the number written (<= max) and restarts.
@@ -285,9 +289,9 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
             const void* add = o.in2 >= 0 ? act(o.in2) : nullptr;
             const Tensor* ta = o.in2 >= 0 ? &e->t[o.in2] : nullptr;
             Scope sc(e, st, (int)i, 0);
-            CK(dreg_conv3d_igemm_ws(act(o.in), PK + w.pk_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0,
-                                    o.ksz, o.stride, o.pad, 0, o.relu, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0, o.add_same, 0, 0,
-                                    A + e->off_ks, e->sz_ks, stream));
+            CK(dreg_conv3d_igemm_occ(act(o.in), PK + w.pk_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0,
+                                     o.ksz, o.stride, o.pad, 0, o.relu, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0, o.add_same, 0, 0,
+                                     A + e->off_ks, e->sz_ks, o.in == 0 ? e->in_rowocc : nullptr, stream));
         } else if (o.kind == OP_CONV_ROWS) {
             const Param& w = e->prm[o.w];
             if (o.rows_out < 0 || o.rows_out >= nlists) return DREG_EINVAL;
@@ -369,8 +373,8 @@ int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pac
                     Scope sc(e, ws, i, 2);
                     if (rows) CK(dreg_conv3d_wgrad_rows(gy, act(o.in), w.grad, A + e->off_wg, e->sz_wg, r_out, n_out, x.B, x.D, x.H, x.W, x.C, w.d1,
                                                         y.D, y.H, y.W, w.d0, o.ksz, 1, o.pad, 1, (void*)ws));
-                    else CK(dreg_conv3d_wgrad(gy, act(o.in), w.grad, A + e->off_wg, e->sz_wg, x.B, x.D, x.H, x.W, x.C, w.d1, y.D, y.H, y.W, w.d0,
-                                              o.ksz, o.stride, o.pad, 1, 0, 1, (void*)ws));
+                    else CK(dreg_conv3d_wgrad_occ(gy, act(o.in), w.grad, A + e->off_wg, e->sz_wg, x.B, x.D, x.H, x.W, x.C, w.d1, y.D, y.H, y.W, w.d0,
+                                                  o.ksz, o.stride, o.pad, 1, 0, 1, o.in == 0 ? e->in_rowocc : nullptr, (void*)ws));
                 }
                 if (o.b >= 0 && e->prm[o.b].grad) {
                     if (rows) CK(dreg_colsum_rows(gy, r_out, n_out, e->prm[o.b].grad, (float*)(A + e->off_cs), w.d0, 1, 0, (void*)ws));

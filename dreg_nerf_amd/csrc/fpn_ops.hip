@@ -702,8 +702,10 @@ __global__ void add_inplace_kernel(T* __restrict__ dst, const T* __restrict__ sr
 // grids: B device pointers to fp32 [7, Z, X, Y] voxel grids (xyz | rgb | alpha, the reference's voxel_grid.pt layout).
 // out [B, Z, X, Y, 8] (T): channels 0..3 = rgba (grid channels 3..6), 4..7 = 0  — the NDHWC input of the stem convolution
 // (nerf_regtr.py:131-135 feeds grid[:, 3:]).
+// inocc (optional, zero-filled by the caller): byte [B, Z, X] = 1 where the Y-row (b, z, x) holds any non-zero rgba value — the
+// stem convolution skips output rows whose whole receptive field is flagged empty (dreg_conv_row_occupancy).
 template <typename T>
-__global__ void pack_rgba_kernel(const float* const* __restrict__ grids, T* __restrict__ out, size_t V, int B)
+__global__ void pack_rgba_kernel(const float* const* __restrict__ grids, T* __restrict__ out, size_t V, int B, uint8_t* __restrict__ inocc, int Yr)
 {
     const size_t total = V * B;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -711,6 +713,7 @@ __global__ void pack_rgba_kernel(const float* const* __restrict__ grids, T* __re
         const size_t v = i - (size_t)b * V;
         const float* g = grids[b] + 3 * V + v;
         float c[8] = {g[0], g[V], g[2 * V], g[3 * V], 0.f, 0.f, 0.f, 0.f};
+        if (inocc && (c[0] != 0.f || c[1] != 0.f || c[2] != 0.f || c[3] != 0.f)) inocc[i / Yr] = 1;
         if constexpr (sizeof(T) == 2) Gran<bf16_t>::st(reinterpret_cast<bf16_t*>(out) + i * 8, c);
         else { float lo[4] = {c[0], c[1], c[2], c[3]}, hi[4] = {0.f, 0.f, 0.f, 0.f}; Gran<float>::st(reinterpret_cast<float*>(out) + i * 8, lo); Gran<float>::st(reinterpret_cast<float*>(out) + i * 8 + 4, hi); }
     }
@@ -720,13 +723,14 @@ __global__ void pack_rgba_kernel(const float* const* __restrict__ grids, T* __re
 // eval_ngp_nerf.py:397-405)
 template <typename T>
 __global__ void scatter_rgba_kernel(const float* __restrict__ vals, const int64_t* __restrict__ idx, const int* __restrict__ pt_batch,
-                                    T* __restrict__ out, int N, int Zr, int Xr, int Yr)
+                                    T* __restrict__ out, int N, int Zr, int Xr, int Yr, uint8_t* __restrict__ inocc)
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const int64_t f = idx[n];
     const int z = (int)(f % Zr), y = (int)((f / Zr) % Yr), x = (int)(f / ((int64_t)Zr * Yr));
     const size_t V = (size_t)Zr * Xr * Yr, o = ((size_t)pt_batch[n] * V + ((size_t)z * Xr + x) * Yr + y) * 8;
+    if (inocc) inocc[((size_t)pt_batch[n] * Zr + z) * Xr + x] = 1;
     const float* v = vals + (size_t)n * 7 + 3;
     float c[8] = {v[0], v[1], v[2], v[3], 0.f, 0.f, 0.f, 0.f};
     if constexpr (sizeof(T) == 2) Gran<bf16_t>::st(reinterpret_cast<bf16_t*>(out) + o, c);
@@ -744,6 +748,25 @@ __global__ void gather_xyz_kernel(const float* const* __restrict__ grids, const 
     const size_t V = (size_t)Zr * Xr * Yr, o = ((size_t)z * Xr + x) * Yr + y;
     const float* g = grids[pt_batch[n]];
     xyz[(size_t)n * 3] = g[o]; xyz[(size_t)n * 3 + 1] = g[V + o]; xyz[(size_t)n * 3 + 2] = g[2 * V + o];
+}
+
+// rowocc[b, zo, ho] = any inocc[b, zi, hi] inside the kernel window of output row (zo, ho, *):  zi = zo*stride - pad + d, d < ksz
+__global__ void conv_row_occupancy_kernel(const uint8_t* __restrict__ inocc, uint8_t* __restrict__ rowocc, int B, int Di, int Hi, int Do, int Ho,
+                                          int ksz, int stride, int pad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Do * Ho) return;
+    const int ho = i % Ho, zo = (i / Ho) % Do, b = i / (Ho * Do);
+    uint8_t any = 0;
+    for (int dz = 0; dz < ksz; ++dz) {
+        const int zi = zo * stride - pad + dz;
+        if ((unsigned)zi >= (unsigned)Di) continue;
+        for (int dh = 0; dh < ksz; ++dh) {
+            const int hi = ho * stride - pad + dh;
+            if ((unsigned)hi < (unsigned)Hi) any |= inocc[((size_t)b * Di + zi) * Hi + hi];
+        }
+    }
+    rowocc[i] = any;
 }
 
 // fp32 <-> T conversions (contiguous)
@@ -925,29 +948,51 @@ int dreg_cast_from_f32(const float* in, void* out, size_t n, int dtype, void* st
     return DREG_OK;
 }
 
-// grids: DEVICE array of B pointers to fp32 [7,Z,X,Y] grids -> out [B,Z,X,Y,8] (dtype): rgba + 4 zero channels
-int dreg_pack_rgba_grids(const void* grids, void* out, int B, int Z, int X, int Y, int dtype, void* stream)
+// grids: DEVICE array of B pointers to fp32 [7,Z,X,Y] grids -> out [B,Z,X,Y,8] (dtype): rgba + 4 zero channels.
+// _occ: also inocc byte [B,Z,X] (may be null) = 1 for every Y-row with a non-zero value.
+int dreg_pack_rgba_grids_occ(const void* grids, void* out, uint8_t* inocc, int B, int Z, int X, int Y, int dtype, void* stream)
 {
     const size_t V = (size_t)Z * X * Y;
     if (B <= 0 || V == 0) return DREG_OK;
-    if (dtype == 0) hipLaunchKernelGGL(pack_rgba_kernel<bf16_t>, dim3(nblocks(V * B)), dim3(256), 0, (hipStream_t)stream, (const float* const*)grids, (bf16_t*)out, V, B);
-    else hipLaunchKernelGGL(pack_rgba_kernel<float>, dim3(nblocks(V * B)), dim3(256), 0, (hipStream_t)stream, (const float* const*)grids, (float*)out, V, B);
+    if (inocc && hipMemsetAsync(inocc, 0, (size_t)B * Z * X, (hipStream_t)stream) != hipSuccess) return DREG_ELAUNCH;
+    if (dtype == 0) hipLaunchKernelGGL(pack_rgba_kernel<bf16_t>, dim3(nblocks(V * B)), dim3(256), 0, (hipStream_t)stream, (const float* const*)grids, (bf16_t*)out, V, B, inocc, Y);
+    else hipLaunchKernelGGL(pack_rgba_kernel<float>, dim3(nblocks(V * B)), dim3(256), 0, (hipStream_t)stream, (const float* const*)grids, (float*)out, V, B, inocc, Y);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+int dreg_pack_rgba_grids(const void* grids, void* out, int B, int Z, int X, int Y, int dtype, void* stream)
+{
+    return dreg_pack_rgba_grids_occ(grids, out, nullptr, B, Z, X, Y, dtype, stream);
+}
+// Output-row occupancy of a convolution over a volume whose non-empty input rows are flagged in inocc (byte [B, Di, Hi]):
+// rowocc byte [B, Do, Ho].  dreg_conv3d_igemm_occ / dreg_conv3d_wgrad_occ skip the rows flagged 0 (their result is exactly zero).
+int dreg_conv_row_occupancy(const uint8_t* inocc, uint8_t* rowocc, int B, int Di, int Hi, int Do, int Ho, int ksz, int stride, int pad, void* stream)
+{
+    const int n = B * Do * Ho;
+    if (n <= 0) return DREG_OK;
+    hipLaunchKernelGGL(conv_row_occupancy_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, inocc, rowocc, B, Di, Hi, Do, Ho, ksz, stride, pad);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
 // Sparse staging: out [B,Z,X,Y,8] (dtype) = zeros + rgba of the occupied voxels (vals fp32 [N,7], idx int64 [N], pt_batch int32 [N])
-int dreg_pack_rgba_sparse(const float* vals, const int64_t* idx, const int* pt_batch, void* out, int N, int B, int Z, int X, int Y,
-                          int dtype, void* stream)
+int dreg_pack_rgba_sparse_occ(const float* vals, const int64_t* idx, const int* pt_batch, void* out, uint8_t* inocc, int N, int B, int Z, int X, int Y,
+                              int dtype, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = (size_t)B * Z * X * Y * 8 * (dtype == 0 ? 2 : 4);
     if (bytes == 0) return DREG_OK;
     if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) return DREG_ELAUNCH;
+    if (inocc && hipMemsetAsync(inocc, 0, (size_t)B * Z * X, st) != hipSuccess) return DREG_ELAUNCH;
     if (N <= 0) return DREG_OK;
-    if (dtype == 0) hipLaunchKernelGGL(scatter_rgba_kernel<bf16_t>, dim3((N + 255) / 256), dim3(256), 0, st, vals, idx, pt_batch, (bf16_t*)out, N, Z, X, Y);
-    else hipLaunchKernelGGL(scatter_rgba_kernel<float>, dim3((N + 255) / 256), dim3(256), 0, st, vals, idx, pt_batch, (float*)out, N, Z, X, Y);
+    if (dtype == 0) hipLaunchKernelGGL(scatter_rgba_kernel<bf16_t>, dim3((N + 255) / 256), dim3(256), 0, st, vals, idx, pt_batch, (bf16_t*)out, N, Z, X, Y, inocc);
+    else hipLaunchKernelGGL(scatter_rgba_kernel<float>, dim3((N + 255) / 256), dim3(256), 0, st, vals, idx, pt_batch, (float*)out, N, Z, X, Y, inocc);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
+}
+int dreg_pack_rgba_sparse(const float* vals, const int64_t* idx, const int* pt_batch, void* out, int N, int B, int Z, int X, int Y,
+                          int dtype, void* stream)
+{
+    return dreg_pack_rgba_sparse_occ(vals, idx, pt_batch, out, nullptr, N, B, Z, X, Y, dtype, stream);
 }
 // xyz fp32 [N,3] of the occupied voxels: idx int64 [N] flat (x*Yr + y)*Zr + z, pt_batch int32 [N] grid ids
 int dreg_gather_grid_xyz(const void* grids, const int64_t* idx, const int* pt_batch, float* xyz, int N, int Zr, int Xr, int Yr, void* stream)

@@ -33,6 +33,7 @@ SIGNATURES = {
     "dreg_conv3d_igemm": (I, [P, P, P, P, P] + [I] * 18 + [I, I, P]),
     "dreg_conv3d_igemm_workspace_bytes": (Z, [I] * 15),
     "dreg_conv3d_igemm_ws": (I, [P, P, P, P, P] + [I] * 18 + [I, I, P, Z, P]),
+    "dreg_conv3d_igemm_occ": (I, [P, P, P, P, P] + [I] * 18 + [I, I, P, Z, P, P]),
     "dreg_conv3d_kpad": (I, [I, I, I]),
     "dreg_conv_set_glds": (None, [I]),
     "dreg_conv_get_glds": (I, []),
@@ -45,6 +46,7 @@ SIGNATURES = {
     "dreg_conv3d_wgrad_splits": (I, [I] * 8),
     "dreg_conv3d_wgrad_workspace_bytes": (Z, [I] * 8),
     "dreg_conv3d_wgrad": (I, [P, P, P, P, Z] + [I] * 16 + [P]),
+    "dreg_conv3d_wgrad_occ": (I, [P, P, P, P, Z] + [I] * 16 + [P, P]),
     "dreg_conv3d_igemm_rows": (I, [P] * 5 + [P, I] + [I] * 18 + [I, P]),
     "dreg_conv3d_wgrad_rows": (I, [P, P, P, P, Z] + [P, I] + [I] * 14 + [P]),
     # fpn_ops.hip
@@ -68,7 +70,10 @@ SIGNATURES = {
     "dreg_trilinear_gather_bwd_gather": (I, [P, P, P, P, I, P, P] + [I] * 10 + [P]),
     "dreg_add_inplace": (I, [P, P, Z, I, P]),
     "dreg_pack_rgba_grids": (I, [P, P, I, I, I, I, I, P]),
+    "dreg_pack_rgba_grids_occ": (I, [P, P, P, I, I, I, I, I, P]),
     "dreg_pack_rgba_sparse": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "dreg_pack_rgba_sparse_occ": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
+    "dreg_conv_row_occupancy": (I, [P, P, I, I, I, I, I, I, I, I, P]),
     "dreg_gather_grid_xyz": (I, [P, P, P, P, I, I, I, I, P]),
     # executor.hip
     "dreg_exec_create": (P, [P, I, P, I, P, I]),
@@ -82,6 +87,7 @@ SIGNATURES = {
     "dreg_exec_export_pack_table": (I, [P, P, P, P]),
     "dreg_exec_repack": (I, [P, P, P, P]),
     "dreg_exec_set_overlap": (None, [P, I]),
+    "dreg_exec_set_input_row_occupancy": (None, [P, P]),
     "dreg_exec_set_timing": (None, [P, I]),
     "dreg_exec_read_timings": (I, [P, P, P, I]),
     "dreg_exec_forward": (I, [P, P, Z, P, P, P, I, I, P]),

@@ -100,6 +100,7 @@ class NeRFRegTr(nn.Module):
         self.native_trunk = True
         # Run the data-dependent geometry phase of forward_batch on its own high-priority stream (see forward_batch)
         self.async_geometry = True
+        self.skip_empty_stem_rows = True   # stem output rows whose receptive field is all zero are written as zeros, not computed
         self._spec = params.regtr_spec()
         _build_tree(self, self._spec)
         _reset_parameters(self, self._spec)
@@ -200,14 +201,17 @@ class NeRFRegTr(nn.Module):
             cache[key] = ex
         return ex
 
-    def fpn(self, x: torch.Tensor, rows=None) -> torch.Tensor:
+    def fpn(self, x: torch.Tensor, rows=None, row_occ=None) -> torch.Tensor:
         """x: [B, D, H, W, 8] (rgba + 4 zero channels), activation dtype.  Returns P1 [B, D/2, H/2, W/2, 256].
         rows = (S1, S2, S3) from ops.active_sets: the two head convolutions are evaluated on the active set only
-        (P1 is then defined on S1, which is all the trilinear gather reads)."""
+        (P1 is then defined on S1, which is all the trilinear gather reads).  row_occ (uint8 [B, D/2, H/2], from the packers
+        with occupancy=True): output rows of the stem whose receptive field in x is all zero; the native executor skips them
+        (their result is exactly zero) — same output bit for bit."""
         train = self.training
         ex = self._trunk_executor(x, rows)
         if ex is not None:
             from . import trunk_exec
+            ex.set_input_row_occupancy(row_occ)
             p1 = trunk_exec.run_trunk(ex, x, self.fpn3d.backbone_net.conv1.weight, rows, train)
             if train and ex.nbt:
                 torch._foreach_add_(ex.nbt, x.shape[0])
@@ -233,25 +237,40 @@ class NeRFRegTr(nn.Module):
         return L.to_device_async([g.data_ptr() for g in grids], torch.int64, grids[0].device)
 
     @staticmethod
-    def pack_sparse(vals_cat, idx_cat, pb_cat, n_grids: int, res, dtype) -> torch.Tensor:
-        """Sparse blocks -> the same NDHWC [B,Z,X,Y,8] stem input (zero fill + scatter of the occupied voxels' rgba)."""
+    def pack_sparse(vals_cat, idx_cat, pb_cat, n_grids: int, res, dtype, occupancy: bool = False):
+        """Sparse blocks -> the same NDHWC [B,Z,X,Y,8] stem input (zero fill + scatter of the occupied voxels' rgba).
+        occupancy=True: returns (x, row_occ) with the stem's output-row occupancy flags (see fpn)."""
         Z, X, Y = res
         out = torch.empty(n_grids, Z, X, Y, 8, dtype=dtype, device=vals_cat.device)
-        L.check(L.load().dreg_pack_rgba_sparse(L.ptr(vals_cat), L.ptr(idx_cat), L.ptr(pb_cat), L.ptr(out), idx_cat.shape[0], n_grids, Z, X, Y,
-                                               L.dt_of(out), L.stream()), "dreg_pack_rgba_sparse")
-        return out
+        inocc = torch.empty(n_grids, Z, X, dtype=torch.uint8, device=vals_cat.device) if occupancy else None
+        L.check(L.load().dreg_pack_rgba_sparse_occ(L.ptr(vals_cat), L.ptr(idx_cat), L.ptr(pb_cat), L.ptr(out), L.ptr(inocc), idx_cat.shape[0], n_grids,
+                                                   Z, X, Y, L.dt_of(out), L.stream()), "dreg_pack_rgba_sparse_occ")
+        return (out, NeRFRegTr._stem_row_occupancy(inocc)) if occupancy else out
 
     @staticmethod
-    def pack_grids(grids: List[torch.Tensor], dtype, table=None) -> torch.Tensor:
-        """List of [1,7,Z,X,Y] fp32 grids -> NDHWC [B,Z,X,Y,8]: rgba (channels 3:7) + 4 zero pad channels."""
+    def _stem_row_occupancy(inocc: torch.Tensor) -> torch.Tensor:
+        """Input-row flags [B,Z,X] -> output-row flags [B,Z/2,X/2] of the stem (conv1: 5^3, stride 2, pad 2; conerf/model/resnet3d.py:118)."""
+        B, Z, X = inocc.shape
+        Zo, Xo = (Z + 4 - 5) // 2 + 1, (X + 4 - 5) // 2 + 1
+        occ = torch.empty(B, Zo, Xo, dtype=torch.uint8, device=inocc.device)
+        L.check(L.load().dreg_conv_row_occupancy(L.ptr(inocc), L.ptr(occ), B, Z, X, Zo, Xo, 5, 2, 2, L.stream()), "dreg_conv_row_occupancy")
+        return occ
+
+    @staticmethod
+    def pack_grids(grids: List[torch.Tensor], dtype, table=None, occupancy: bool = False):
+        """List of [1,7,Z,X,Y] fp32 grids -> NDHWC [B,Z,X,Y,8]: rgba (channels 3:7) + 4 zero pad channels.
+        occupancy=True: returns (x, row_occ or None) — flags from the VALUES (a row is empty only if all its rgba are zero)."""
         table = table if table is not None else NeRFRegTr._grid_table(grids)
         if table is not None:
             Z, X, Y = grids[0].shape[-3:]
             out = torch.empty(len(grids), Z, X, Y, 8, dtype=dtype, device=grids[0].device)
-            L.check(L.load().dreg_pack_rgba_grids(L.ptr(table), L.ptr(out), len(grids), Z, X, Y, L.dt_of(out), L.stream()), "dreg_pack_rgba_grids")
-            return out
+            inocc = torch.empty(len(grids), Z, X, dtype=torch.uint8, device=out.device) if occupancy else None
+            L.check(L.load().dreg_pack_rgba_grids_occ(L.ptr(table), L.ptr(out), L.ptr(inocc), len(grids), Z, X, Y, L.dt_of(out), L.stream()),
+                    "dreg_pack_rgba_grids_occ")
+            return (out, NeRFRegTr._stem_row_occupancy(inocc)) if occupancy else out
         rgba = torch.cat([g[:, 3:] for g in grids], dim=0).permute(0, 2, 3, 4, 1)
-        return F.pad(rgba, (0, 4)).to(dtype).contiguous()
+        out = F.pad(rgba, (0, 4)).to(dtype).contiguous()
+        return (out, None) if occupancy else out
 
     # ------------------------------------------------------------------ A3..A9 for a batch of pairs
     def _geometry(self, batch: List[dict], dev):
@@ -345,10 +364,10 @@ class NeRFRegTr(nn.Module):
         else:
             grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs, table, s1_rows = self._geometry(batch, dev)
         if isinstance(grids, tuple):   # sparse input form
-            x_in = self.pack_sparse(grids[0], idx_cat, pb_cat, grids[1], res, self.act_dtype)
+            x_in, row_occ = self.pack_sparse(grids[0], idx_cat, pb_cat, grids[1], res, self.act_dtype, occupancy=True)
         else:
-            x_in = self.pack_grids(grids, self.act_dtype, table)
-        p1 = self.fpn(x_in, rows)
+            x_in, row_occ = self.pack_grids(grids, self.act_dtype, table, occupancy=True)
+        p1 = self.fpn(x_in, rows, row_occ if self.skip_empty_stem_rows else None)
         feats = ops.trilinear_gather(p1, idx_cat, pb_cat, res, s1_rows, rows[3] if rows is not None else None)
         P = self._P()
         off = 0

@@ -216,6 +216,12 @@ class TrunkExecutor:
                 "dreg_exec_backward")
 
     # ------------------------------------------------------------------ timing (bench.py's roofline line)
+    def set_input_row_occupancy(self, row_occ):
+        """uint8 [B, D/2, H/2] output-row flags of the stem for the next forward / backward (None = compute every row).  The tensor
+        is kept alive here until it is replaced: the weight gradient on the second stream reads it during backward."""
+        self._row_occ = row_occ
+        self.lib.dreg_exec_set_input_row_occupancy(self.h, L.ptr(row_occ) if row_occ is not None else None)
+
     def set_timing(self, on: bool):
         """HIP-event brackets around every convolution launch.  While they are on, the weight-gradient launches stay on the
         caller's stream (no second stream), so a bracket measures its kernel alone rather than two kernels sharing the CUs."""

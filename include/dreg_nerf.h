@@ -65,6 +65,10 @@ int dreg_conv3d_igemm_ws(const void* in, const void* wt_packed, void* out, const
                          int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
                          int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
                          int dtype, int out_f32, void* workspace, size_t workspace_bytes, void* stream);
+int dreg_conv3d_igemm_occ(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
+                          int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                          int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
+                          int dtype, int out_f32, void* workspace, size_t workspace_bytes, const uint8_t* rowocc, void* stream);
 
 /* 1 (default): bf16 stride-1 convolutions stage operands with buffer_load...lds; 0: register-staged kernel (A/B checks) */
 void dreg_conv_set_glds(int enable);
@@ -87,6 +91,9 @@ size_t dreg_conv3d_wgrad_workspace_bytes(int B, int Do, int Ho, int Wo, int Cin,
 int dreg_conv3d_wgrad(const void* gout, const void* in, float* dw, void* workspace, size_t workspace_bytes,
                       int B, int Di, int Hi, int Wi, int Cin, int Cin_real, int Do, int Ho, int Wo, int Cout,
                       int ksz, int stride, int pad, int accumulate, int dtype, int use_tr, void* stream);
+int dreg_conv3d_wgrad_occ(const void* gout, const void* in, float* dw, void* workspace, size_t workspace_bytes,
+                          int B, int Di, int Hi, int Wi, int Cin, int Cin_real, int Do, int Ho, int Wo, int Cout,
+                          int ksz, int stride, int pad, int accumulate, int dtype, int use_tr, const uint8_t* rowocc, void* stream);
 
 /* Active-set ("row list") forms, bf16, stride 1: only the output voxels rows[0..nrows) (ascending int32 flat indices into
  * B*Do*Ho*Wo, device memory) are computed / reduced over; other rows of `out` are left untouched.  Used for the two FPN head
@@ -141,10 +148,18 @@ int dreg_add_inplace(void* dst, const void* src, size_t n, int dtype, void* stre
  * pack: -> [B,Z,X,Y,8] (dtype) = rgba + 4 zero channels, the NDHWC stem input.  gather: xyz fp32 [N,3] of the occupied voxels
  * (idx int64 [N] = (x*Yr + y)*Zr + z, pt_batch int32 [N]). */
 int dreg_pack_rgba_grids(const void* grids, void* out, int B, int Z, int X, int Y, int dtype, void* stream);
+/* the same + inocc byte [B,Z,X] (null ok): 1 for every Y-row of the input volume that holds a non-zero value */
+int dreg_pack_rgba_grids_occ(const void* grids, void* out, uint8_t* inocc, int B, int Z, int X, int Y, int dtype, void* stream);
 /* sparse form (conerf/datasets/register/dataset.py:221-331 keeps dense 58.7 MB grids; they are zero outside voxel_mask.pt):
  * vals fp32 [N,7] of the occupied voxels idx[n] of grid pt_batch[n] -> zero-filled [B,Z,X,Y,8] + their rgba */
 int dreg_pack_rgba_sparse(const float* vals, const int64_t* idx, const int* pt_batch, void* out, int N, int B, int Z, int X,
                           int Y, int dtype, void* stream);
+int dreg_pack_rgba_sparse_occ(const float* vals, const int64_t* idx, const int* pt_batch, void* out, uint8_t* inocc, int N, int B, int Z, int X,
+                              int Y, int dtype, void* stream);
+/* rowocc byte [B,Do,Ho] = any inocc [B,Di,Hi] inside the window of output row (zo, ho, *) of a ksz^3 / stride / pad convolution; the _occ
+   convolution entry points skip rows flagged 0 (their result is exactly zero).  Reference: conv1 of conerf/model/resnet3d.py:118-121 on the
+   voxel grids of eval_ngp_nerf.py:397-405, which are zero outside voxel_mask. */
+int dreg_conv_row_occupancy(const uint8_t* inocc, uint8_t* rowocc, int B, int Di, int Hi, int Do, int Ho, int ksz, int stride, int pad, void* stream);
 int dreg_gather_grid_xyz(const void* grids, const int64_t* idx, const int* pt_batch, float* xyz, int N, int Zr, int Xr, int Yr,
                          void* stream);
 
@@ -192,7 +207,8 @@ int dreg_exec_output_slot(void* h);
 int dreg_exec_pack_rows(void* h);
 int dreg_exec_export_pack_table(void* h, void* host_out, int* host_row_desc, void* pack_base);   /* 48-byte records + row->record map */
 int dreg_exec_repack(void* h, const void* descs_dev, const int* row_desc_dev, void* stream);
-void dreg_exec_set_overlap(void* h, int enable);                             /* 1 (default): weight gradients on aux_stream */
+void dreg_exec_set_overlap(void* h, int enable);
+void dreg_exec_set_input_row_occupancy(void* h, const uint8_t* rowocc);   /* flags for the convolution that reads x_in (the stem); null = none */                             /* 1 (default): weight gradients on aux_stream */
 void dreg_exec_set_timing(void* h, int enable);                              /* HIP events around every convolution launch */
 int dreg_exec_read_timings(void* h, int* op_kind, float* ms, int max);       /* (op, kind 0 fwd / 1 dgrad / 2 wgrad), ms */
 int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack_base, const void* x_in,

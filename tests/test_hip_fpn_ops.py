@@ -360,3 +360,53 @@ def test_linear_with_many_rows(n):
     assert float((w.grad - wr.grad).abs().max()) <= 2e-2 * float(wr.grad.abs().max())
     # the last row is computed (ragged tile) and distinct from its neighbours
     assert torch.isfinite(y[-1]).all() and not torch.equal(y[-1], y[-2])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_stem_row_occupancy_skips_only_empty_rows(dtype):
+    """Stem convolution (5^3, stride 2, pad 2, 8 input channels) on a volume that is zero outside a small blob: with the output-row
+    occupancy flags the forward result and the weight gradient are the same BIT FOR BIT as without them; the flags come from the packer
+    (values, not masks) and mark exactly the rows whose window touches a non-zero input row."""
+    from dreg_nerf_amd import lib as L
+    from dreg_nerf_amd.regtr import NeRFRegTr
+    dev = _dev()
+    lib = L.load()
+    g = torch.Generator().manual_seed(11)
+    B, R = 2, 64
+    grids = []
+    for b in range(B):
+        v = torch.zeros(1, 7, R, R, R)
+        z0, x0 = 10 + 20 * b, 30
+        v[:, 3:, z0:z0 + 6, x0:x0 + 9, 5:50] = torch.rand(1, 4, 6, 9, 45, generator=g)
+        grids.append(v.to(dev))
+    x, occ = NeRFRegTr.pack_grids(grids, dtype, occupancy=True)
+    x0_ = NeRFRegTr.pack_grids(grids, dtype)
+    assert torch.equal(x, x0_) and occ.shape == (B, R // 2, R // 2) and occ.dtype == torch.uint8
+    # reference flags on the host: output row (zo, xo) is live iff some input row (z, x) in [2zo-2, 2zo+2] x [2xo-2, 2xo+2] is non-zero
+    nz = (torch.stack([gg[0, 3:].abs().sum(dim=(0, 3)) for gg in grids]) > 0).cpu()       # [B, Z, X]
+    want = torch.zeros(B, R // 2, R // 2, dtype=torch.bool)
+    for b, z, xx in nz.nonzero().tolist():
+        want[b, max(0, (z - 2 + 1) // 2):min(R // 2, (z + 2) // 2 + 1), max(0, (xx - 2 + 1) // 2):min(R // 2, (xx + 2) // 2 + 1)] = True
+    assert torch.equal(occ.cpu().bool(), want) and 0 < int(want.sum()) < want.numel() // 4
+    w = (torch.randn(64, 4, 5, 5, 5, generator=g) * 0.1).to(dev)
+    dt = L.dt_of(x)
+    wpk = ops.packed_weight(w, 8, False, dt)
+    Do = R // 2
+    outs = []
+    for flags in (None, occ):
+        y = torch.full((B, Do, Do, Do, 64), 7.0, dtype=dtype, device=dev)       # poisoned: skipped tiles must be written
+        L.check(lib.dreg_conv3d_igemm_occ(L.ptr(x), L.ptr(wpk), L.ptr(y), None, None, B, R, R, R, 8, Do, Do, Do, 64, 5, 2, 2, 0, 0, 0, 0, 0, 0,
+                                          dt, 0, None, 0, L.ptr(flags), L.stream()), "dreg_conv3d_igemm_occ")
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    assert float(outs[0].float().abs().max()) > 0 and float((outs[0].float().abs().sum(dim=(3, 4)) > 0).float().mean()) < 0.3
+    gy = torch.randn(B, Do, Do, Do, 64, generator=g).to(dev).to(dtype)
+    nbytes = lib.dreg_conv3d_wgrad_workspace_bytes(B, Do, Do, Do, 8, 64, 5, dt)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dws = []
+    for flags in (None, occ):
+        dw = torch.empty(64, 4, 5, 5, 5, dtype=torch.float32, device=dev)
+        L.check(lib.dreg_conv3d_wgrad_occ(L.ptr(gy), L.ptr(x), L.ptr(dw), L.ptr(ws), nbytes, B, R, R, R, 8, 4, Do, Do, Do, 64, 5, 2, 2, 0, dt,
+                                          int(dtype == torch.bfloat16), L.ptr(flags), L.stream()), "dreg_conv3d_wgrad_occ")
+        dws.append(dw)
+    assert torch.equal(dws[0], dws[1]) and float(dws[0].abs().max()) > 0

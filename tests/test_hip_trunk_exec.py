@@ -117,3 +117,25 @@ def test_training_steps_are_bitwise_reproducible(shell):
     p2, l2 = run()
     assert all(np.isfinite(l1)) and l1 == l2
     assert torch.equal(p1, p2)
+
+
+def test_stem_row_skipping_does_not_change_a_training_step():
+    """Three optimizer steps with and without the stem's empty-row skipping end in identical parameters and losses."""
+    from dreg_nerf_amd.train_step import TrainStep
+    res = []
+    for skip in (True, False):
+        torch.manual_seed(5)
+        m = NeRFRegTr(precision="bf16").to(DEV).train()
+        m.skip_empty_stem_rows = skip
+        ts = TrainStep(m)
+        batch = []
+        for i in range(2):
+            d = {"pose": synth.fixed_pose()[None].clone(), "src_nerf_path": "", "tgt_nerf_path": ""}
+            for j, side in enumerate(("src", "tgt")):
+                g, mk = synth.shell_grid(64, 30 + 2 * i + j, 0.3, 0.34)
+                d[side + "_xyz_rgba"], d[side + "_mask"] = g.permute(3, 2, 0, 1).unsqueeze(0).contiguous(), mk
+            batch.append({k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in d.items()})
+        ls = [float(ts.step(batch)["losses"]["total"]) for _ in range(3)]
+        torch.cuda.synchronize()
+        res.append((ls, ts.optimizer.flat_p.clone()))
+    assert all(np.isfinite(res[0][0])) and res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
