@@ -152,14 +152,14 @@ def main():
         """HBM bytes per launch of kernel `name` from the committed rocprofv3 PMC passes (tools/collect_pmc.sh: separate
         FETCH_SIZE / WRITE_SIZE runs of this bench at this workload, --pmc with --kernel-trace only).  Both counters are in KB;
         FETCH_SIZE is doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 bytes: MI355X_MICROARCH.md, HBM)."""
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_i_pmc_hbm_per_launch.json")
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_j_pmc_hbm_per_launch.json")
         if args.res != 128 or args.pairs != 4 or args.precision != "bf16" or not os.path.exists(path):
             return None, None
         norm = lambda k: k.replace("void ", "").split("(")[0].replace("unsigned short", "bf16").replace("float", "f32").replace(" ", "")
         for k, e in json.load(open(path)).get(head, {}).items():
             if norm(k) == name.replace(" ", "") and "FETCH_SIZE" in e and "WRITE_SIZE" in e:
                 return (2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0, \
-                    f"profiles/r01_i_pmc_hbm_per_launch.json [{head}]: 2 x FETCH_SIZE + WRITE_SIZE, mean of {e['launches_FETCH_SIZE']} launches"
+                    f"profiles/r01_j_pmc_hbm_per_launch.json [{head}]: 2 x FETCH_SIZE + WRITE_SIZE, mean of {e['launches_FETCH_SIZE']} launches"
         return None, None
 
     def roofline_of(pr, head):
