@@ -10,11 +10,23 @@ import time
 import torch
 import torch.distributed as dist
 
+from dreg_nerf_amd import fgr
 from dreg_nerf_amd import losses as LS
 from dreg_nerf_amd.checkpoint import CheckPointManager
 from dreg_nerf_amd.config import config_parser
 from dreg_nerf_amd.dataset import NeRFRegDataset, SyntheticRegDataset
 from dreg_nerf_amd.regtr import NeRFRegTr
+
+
+def _points(data, side):
+    """World coordinates of the occupied voxels of one block = the voxel point cloud the reference reads from its PLY."""
+    if side + "_sparse" in data:
+        return data[side + "_sparse"].vals[:, :3].float()
+    g = data[side + "_xyz_rgba"]
+    g = g.squeeze(0) if g.dim() == 6 else g
+    m = data[side + "_mask"]
+    m = m.squeeze(0) if m.dim() == 2 else m
+    return g[:, :3].permute(0, 3, 4, 2, 1).reshape(-1, 3)[m].float()      # same flattening as nerf_regtr.py:144-147
 
 
 def main():
@@ -34,7 +46,7 @@ def main():
     ckpt_path = cfg.ckpt_path or os.path.join(cfg.root_dir, "out", cfg.expname, "model.pth")
     if CheckPointManager(verbose=rank == 0).load_no_config(ckpt_path, models={"model": model}, map_location=dev) == 0 and not os.path.exists(ckpt_path):
         print(f"[WARNING] no checkpoint at {ckpt_path}: evaluating random-init weights", flush=True)
-    rows = {}
+    rows, fgr_rows = {}, {}
     with torch.no_grad():
         for i in range(rank, len(ds), world):
             data = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in ds[i].items()}
@@ -46,10 +58,17 @@ def main():
             err = LS.evaluate_camera_alignment(pred["pose"][-1], data["pose"])
             rows[data["scene"]] = {"R_mean": float(err["R_error_mean"]), "t_mean": float(err["t_error_mean"]),
                                    "R_med": float(err["R_error_med"]), "t_med": float(err["t_error_med"]), "time": dt}
+            if cfg.fgr_baseline:   # the reference's baseline on the two voxel point clouds (global_registration.py:96-116)
+                T, sec = fgr.run_registration(_points(data, "src"), _points(data, "tgt"))
+                e = LS.evaluate_camera_alignment(T[None].float(), data["pose"])
+                fgr_rows[data["scene"]] = {"R_mean": float(e["R_error_mean"]), "t_mean": float(e["t_error_mean"]),
+                                           "R_med": float(e["R_error_med"]), "t_med": float(e["t_error_med"]), "time": sec}
     if world > 1:
         gathered = [None] * world
         dist.all_gather_object(gathered, rows)
         rows = {k: v for g in gathered for k, v in g.items()}
+        dist.all_gather_object(gathered, fgr_rows)
+        fgr_rows = {k: v for g in gathered for k, v in g.items()}
     if rank == 0:
         out = dict(rows)
         out["R_mean"] = sum(r["R_mean"] for r in rows.values()) / max(len(rows), 1)
@@ -59,6 +78,13 @@ def main():
         with open(os.path.join(d, f"metrics_{split}.json"), "w") as f:
             json.dump(out, f, indent=2)
         print(f"{len(rows)} scenes: R_mean={out['R_mean']:.3f} deg, t_mean={out['t_mean']:.4f} -> {d}/metrics_{split}.json", flush=True)
+        if fgr_rows:
+            fo = dict(fgr_rows)
+            fo["R_mean"] = sum(r["R_mean"] for r in fgr_rows.values()) / len(fgr_rows)
+            fo["t_mean"] = sum(r["t_mean"] for r in fgr_rows.values()) / len(fgr_rows)
+            with open(os.path.join(d, f"fgr_metrics_{split}.json"), "w") as f:
+                json.dump(fo, f, indent=4)
+            print(f"FGR baseline: R_mean={fo['R_mean']:.3f} deg, t_mean={fo['t_mean']:.4f} -> {d}/fgr_metrics_{split}.json", flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

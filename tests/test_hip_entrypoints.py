@@ -26,9 +26,12 @@ def test_train_then_eval_synthetic(tmp_path):
     assert set(["step", "model", "feature_loss", "optimizer", "scheduler"]) <= set(ck.keys())
     assert len(ck["model"]) == 772 and ck["feature_loss"]["W"].shape == (256, 256)
     assert os.path.exists(os.path.join(root, "out", "t", "model_best.pth")) and os.path.exists(os.path.join(root, "out", "t", "checkpoints.txt"))
-    out = _run(["eval_nerf_regtr.py", "--synthetic", "2", "--synthetic_res", "64", "--root_dir", root, "--expname", "t"])
+    out = _run(["eval_nerf_regtr.py", "--synthetic", "2", "--synthetic_res", "64", "--root_dir", root, "--expname", "t", "--fgr_baseline"])
     m = json.load(open(os.path.join(root, "eval", "t", "synthetic", "metrics_test.json")))
     assert "R_mean" in m and "t_mean" in m and "shell_0000" in m and set(m["shell_0000"]) == {"R_mean", "t_mean", "R_med", "t_med", "time"}
+    # the FGR baseline file of the reference (eval_nerf_regtr.py:261-273), same schema (a sphere shell has no unique pose: only the format is checked)
+    fm = json.load(open(os.path.join(root, "eval", "t", "synthetic", "fgr_metrics_test.json")))
+    assert set(fm) == set(m) and set(fm["shell_0000"]) == {"R_mean", "t_mean", "R_med", "t_med", "time"}
 
 
 def _occ_state(ngp, binary, res):
