@@ -40,6 +40,7 @@ class LayerNormFn(torch.autograd.Function):
         L.check(lib.dreg_layernorm_fwd(L.ptr(x), L.ptr(g.detach()), L.ptr(b.detach()), L.ptr(pe), L.ptr(y), L.ptr(stats),
                                        n, 256, 1e-5, L.dt_of(y), L.stream()), "dreg_layernorm_fwd")
         ctx.save_for_backward(x, g, stats)
+        ctx.b_ref = b if b.is_leaf else None
         return y
 
     @staticmethod
@@ -49,12 +50,16 @@ class LayerNormFn(torch.autograd.Function):
         gy = gy.contiguous()
         n = x.shape[0]
         dx = torch.empty_like(x)
-        dg = torch.empty(256, dtype=torch.float32, device=x.device)
-        db = torch.empty(256, dtype=torch.float32, device=x.device)
+        # gamma / beta gradients straight into the preallocated .grad buffers when both exist (one [256] add_ launch less per
+        # parameter and LayerNorm call: 40 per step); otherwise fresh tensors for autograd to accumulate
+        gs, bs = ops._grad_sink(g), (ops._grad_sink(ctx.b_ref) if ctx.b_ref is not None else None)
+        direct = gs is not None and bs is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+        dg = gs if direct else torch.empty(256, dtype=torch.float32, device=x.device)
+        db = bs if direct else torch.empty(256, dtype=torch.float32, device=x.device)
         ws = torch.empty(lib.dreg_layernorm_bwd_workspace_bytes(n) // 4 + 4, dtype=torch.float32, device=x.device)
         L.check(lib.dreg_layernorm_bwd(L.ptr(x), L.ptr(gy), L.ptr(g.detach()), L.ptr(stats), L.ptr(dx), L.ptr(dg), L.ptr(db),
-                                       L.ptr(ws), n, 256, L.dt_of(gy), 0, 0, L.stream()), "dreg_layernorm_bwd")
-        return dx, dg, db, None, None
+                                       L.ptr(ws), n, 256, L.dt_of(gy), 0, int(direct), L.stream()), "dreg_layernorm_bwd")
+        return dx, (None if direct else dg), (None if direct else db), None, None
 
 
 def layer_norm(x, w, b, pe=None, out_dtype=None):

@@ -370,12 +370,10 @@ class NeRFRegTr(nn.Module):
         p1 = self.fpn(x_in, rows, row_occ if self.skip_empty_stem_rows else None)
         feats = ops.trilinear_gather(p1, idx_cat, pb_cat, res, s1_rows, rows[3] if rows is not None else None)
         P = self._P()
-        off = 0
-        feat_l = []
-        for i in range(len(batch)):
-            n = idxs[2 * i].shape[0] + idxs[2 * i + 1].shape[0]
-            feat_l.append(T.apply_subsample_plan(plans[i], feats[off:off + n]))
-            off += n
+        # one split (backward: one concatenation) instead of per-pair slices: autograd turns every slice of the [N_mask_total, 256]
+        # feature tensor into a zero-filled full-size gradient plus an add (2.3 GB of traffic per step at 4 pairs)
+        sizes = [idxs[2 * i].shape[0] + idxs[2 * i + 1].shape[0] for i in range(len(batch))]
+        feat_l = [T.apply_subsample_plan(plans[i], f) for i, f in enumerate(feats.split(sizes))]
         tab = A.ProblemTable(segs, dev)
         xyz_all = torch.cat(pts_l) if len(pts_l) > 1 else pts_l[0]
         cond, corr, ov = T.encode_decode_batched(P, torch.cat(feat_l) if len(feat_l) > 1 else feat_l[0], xyz_all, tab)
