@@ -30,8 +30,12 @@ def linear(x, w, b, relu: bool = False, residual=None, out_f32: bool = False):
 
 # --------------------------------------------------------------------------- LayerNorm (+pe)
 class LayerNormFn(torch.autograd.Function):
+    """y = LN(x)*g + b (+pe).  with_residual: also returns x itself as a second output for the residual branch that by-passes the
+    LayerNorm (x -> LN -> sublayer -> + x, transformer.py:238-293); its gradient then arrives HERE and is added inside the LayerNorm
+    backward kernel instead of by a separate autograd accumulation launch."""
+
     @staticmethod
-    def forward(ctx, x, g, b, pe, out_dtype):
+    def forward(ctx, x, g, b, pe, out_dtype, with_residual=False):
         lib = L.load()
         x = x.contiguous()
         n = x.shape[0]
@@ -41,14 +45,19 @@ class LayerNormFn(torch.autograd.Function):
                                        n, 256, 1e-5, L.dt_of(y), L.stream()), "dreg_layernorm_fwd")
         ctx.save_for_backward(x, g, stats)
         ctx.b_ref = b if b.is_leaf else None
-        return y
+        ctx.set_materialize_grads(False)
+        return (y, x.view_as(x)) if with_residual else y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gres=None):
         x, g, stats = ctx.saved_tensors
         lib = L.load()
-        gy = gy.contiguous()
         n = x.shape[0]
+        if gy is None:                      # only the residual branch carried a gradient
+            return gres, None, None, None, None, None
+        gy = gy.contiguous()
+        if gres is not None:
+            gres = gres.contiguous().float()
         dx = torch.empty_like(x)
         # gamma / beta gradients straight into the preallocated .grad buffers when both exist (one [256] add_ launch less per
         # parameter and LayerNorm call: 40 per step); otherwise fresh tensors for autograd to accumulate
@@ -57,14 +66,19 @@ class LayerNormFn(torch.autograd.Function):
         dg = gs if direct else torch.empty(256, dtype=torch.float32, device=x.device)
         db = bs if direct else torch.empty(256, dtype=torch.float32, device=x.device)
         ws = torch.empty(lib.dreg_layernorm_bwd_workspace_bytes(n) // 4 + 4, dtype=torch.float32, device=x.device)
-        L.check(lib.dreg_layernorm_bwd(L.ptr(x), L.ptr(gy), L.ptr(g.detach()), L.ptr(stats), L.ptr(dx), L.ptr(dg), L.ptr(db),
-                                       L.ptr(ws), n, 256, L.dt_of(gy), 0, int(direct), L.stream()), "dreg_layernorm_bwd")
-        return dx, (None if direct else dg), (None if direct else db), None, None
+        L.check(lib.dreg_layernorm_bwd_add(L.ptr(x), L.ptr(gy), L.ptr(g.detach()), L.ptr(stats), L.ptr(dx), L.ptr(gres), L.ptr(dg), L.ptr(db),
+                                           L.ptr(ws), n, 256, L.dt_of(gy), int(direct), L.stream()), "dreg_layernorm_bwd_add")
+        return dx, (None if direct else dg), (None if direct else db), None, None, None
 
 
 def layer_norm(x, w, b, pe=None, out_dtype=None):
     """x fp32 [N,256] -> LN(x)*w + b (+pe) in out_dtype (default: the compute dtype)."""
     return LayerNormFn.apply(x, w, b, pe, out_dtype or _COMPUTE_DTYPE)
+
+
+def layer_norm_residual(x, w, b, pe=None, out_dtype=None):
+    """(LN(x)*w + b (+pe), x): the second output is x for the residual add that follows the sublayer (see LayerNormFn)."""
+    return LayerNormFn.apply(x, w, b, pe, out_dtype or _COMPUTE_DTYPE, True)
 
 
 # --------------------------------------------------------------------------- multi-head attention core

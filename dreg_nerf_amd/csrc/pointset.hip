@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 template <typename TG>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const TG* __restrict__ dy, const float* __restrict__ g,
                                                             const float* __restrict__ stats, float* __restrict__ dx, float* __restrict__ part,
-                                                            int N, int rows_per_block, int accumulate_dx)
+                                                            int N, int rows_per_block, const float* dx_add)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4);
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = rstd * (d[i] * gv[i] - s1 - xh[i] * s2);
         float* p = dx + (size_t)row * 256 + lane * 4;
-        if (accumulate_dx) { const float4 old = *reinterpret_cast<const float4*>(p); o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w; }
+        if (dx_add) { const float4 old = *reinterpret_cast<const float4*>(dx_add + (size_t)row * 256 + lane * 4); o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w; }
         *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
     }
     __shared__ float red[4][512];
@@ -404,17 +404,26 @@ int dreg_layernorm_fwd(const float* x, const float* gamma, const float* beta, co
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
+int dreg_layernorm_bwd_add(const float* x, const void* dy, const float* gamma, const float* stats, float* dx, const float* dx_add, float* dgamma,
+                           float* dbeta, float* workspace, int N, int C, int g_dtype, int accumulate_w, void* stream);
 size_t dreg_layernorm_bwd_workspace_bytes(int N) { return (size_t)((N + 63) / 64) * 512 * sizeof(float); }
 // dy in g_dtype (0 bf16 / 1 fp32); dx fp32 (accumulated into when accumulate_dx); dgamma/dbeta fp32 (accumulated when accumulate_w)
 int dreg_layernorm_bwd(const float* x, const void* dy, const float* gamma, const float* stats, float* dx, float* dgamma, float* dbeta,
                        float* workspace, int N, int C, int g_dtype, int accumulate_dx, int accumulate_w, void* stream)
 {
+    return dreg_layernorm_bwd_add(x, dy, gamma, stats, dx, accumulate_dx ? dx : nullptr, dgamma, dbeta, workspace, N, C, g_dtype, accumulate_w, stream);
+}
+// the same with an explicit addend: dx = LayerNorm-backward(dy) + dx_add  (dx_add fp32 [N,256] or null; may be dx itself).  Folds the
+// gradient of a residual branch that by-passes the LayerNorm (transformer.py:238-293: x -> LN -> ... + x) into this launch.
+int dreg_layernorm_bwd_add(const float* x, const void* dy, const float* gamma, const float* stats, float* dx, const float* dx_add, float* dgamma,
+                           float* dbeta, float* workspace, int N, int C, int g_dtype, int accumulate_w, void* stream)
+{
     if (C != 256) return DREG_EINVAL;
     if (N == 0) return DREG_OK;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = (N + 63) / 64;
-    if (g_dtype == 0) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, x, (const bf16_t*)dy, gamma, stats, dx, workspace, N, 64, accumulate_dx);
-    else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nblk), dim3(256), 0, st, x, (const float*)dy, gamma, stats, dx, workspace, N, 64, accumulate_dx);
+    if (g_dtype == 0) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, x, (const bf16_t*)dy, gamma, stats, dx, workspace, N, 64, dx_add);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nblk), dim3(256), 0, st, x, (const float*)dy, gamma, stats, dx, workspace, N, 64, dx_add);
     DREG_LAUNCH_CHECK();
     hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3(128), dim3(256), 0, st, workspace, dgamma, dbeta, nblk, accumulate_w);
     DREG_LAUNCH_CHECK();

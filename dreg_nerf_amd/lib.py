@@ -105,6 +105,7 @@ SIGNATURES = {
     "dreg_layernorm_fwd": (I, [P] * 6 + [I, I, F, I, P]),
     "dreg_layernorm_bwd_workspace_bytes": (Z, [I]),
     "dreg_layernorm_bwd": (I, [P] * 8 + [I] * 5 + [P]),
+    "dreg_layernorm_bwd_add": (I, [P] * 9 + [I] * 4 + [P]),
     "dreg_posenc_sine": (I, [P, P, I, F, F, P]),
     "dreg_overlap_fwd": (I, [P, P, P, P, I, P]),
     "dreg_overlap_bwd_workspace_bytes": (Z, [I]),

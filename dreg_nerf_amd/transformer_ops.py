@@ -122,17 +122,17 @@ def corr_decoder(P, src_f, tgt_f, src_xyz, tgt_xyz, src_pe, tgt_pe):
 def encoder_layer_batched(P, p, x, pe, tab):
     """x fp32 [R,256]: rows of every pair's (src | tgt) point sets; tab: attn_ops.ProblemTable."""
     sc = 1.0 / math.sqrt(256 // N_HEADS)
-    h = A.layer_norm(x, P[p + ".norm1.weight"], P[p + ".norm1.bias"], pe)
+    h, xr = A.layer_norm_residual(x, P[p + ".norm1.weight"], P[p + ".norm1.bias"], pe)
     qkv = A.linear(h, P[p + ".self_attn.in_proj_weight"], P[p + ".self_attn.in_proj_bias"])
     o = A.mha_varlen(qkv, tab.self_probs, tab.nprob, tab.max_len, N_HEADS, sc)
-    x = A.linear(o, P[p + ".self_attn.out_proj.weight"], P[p + ".self_attn.out_proj.bias"], residual=x, out_f32=True)
-    h = A.layer_norm(x, P[p + ".norm2.weight"], P[p + ".norm2.bias"], pe)
+    x = A.linear(o, P[p + ".self_attn.out_proj.weight"], P[p + ".self_attn.out_proj.bias"], residual=xr, out_f32=True)
+    h, xr = A.layer_norm_residual(x, P[p + ".norm2.weight"], P[p + ".norm2.bias"], pe)
     qkv = A.linear(h, P[p + ".cross_attn.in_proj_weight"], P[p + ".cross_attn.in_proj_bias"])
     o = A.mha_varlen(qkv, tab.cross_probs, tab.nprob, tab.max_len, N_HEADS, sc)
-    x = A.linear(o, P[p + ".cross_attn.out_proj.weight"], P[p + ".cross_attn.out_proj.bias"], residual=x, out_f32=True)
-    h = A.layer_norm(x, P[p + ".norm3.weight"], P[p + ".norm3.bias"])
+    x = A.linear(o, P[p + ".cross_attn.out_proj.weight"], P[p + ".cross_attn.out_proj.bias"], residual=xr, out_f32=True)
+    h, xr = A.layer_norm_residual(x, P[p + ".norm3.weight"], P[p + ".norm3.bias"])
     h = A.linear(h, P[p + ".linear1.weight"], P[p + ".linear1.bias"], relu=True)
-    return A.linear(h, P[p + ".linear2.weight"], P[p + ".linear2.bias"], residual=x, out_f32=True)
+    return A.linear(h, P[p + ".linear2.weight"], P[p + ".linear2.bias"], residual=xr, out_f32=True)
 
 
 def encode_decode_batched(P, feats, xyz, tab):

@@ -253,6 +253,9 @@ size_t dreg_layernorm_bwd_workspace_bytes(int N);
 int dreg_layernorm_bwd(const float* x, const void* dy, const float* gamma, const float* stats, float* dx, float* dgamma,
                        float* dbeta, float* workspace, int N, int C, int g_dtype, int accumulate_dx, int accumulate_w,
                        void* stream);
+/* dx = LayerNorm-backward(dy) + dx_add (fp32 [N,256], null ok, may alias dx): the by-passing residual branch's gradient folded in */
+int dreg_layernorm_bwd_add(const float* x, const void* dy, const float* gamma, const float* stats, float* dx, const float* dx_add, float* dgamma,
+                           float* dbeta, float* workspace, int N, int C, int g_dtype, int accumulate_w, void* stream);
 
 /* PositionEmbeddingCoordsSine.forward (position_embedding.py:30-53): xyz fp32 [N,3] -> pe fp32 [N,256]. */
 int dreg_posenc_sine(const float* xyz, float* pe, int N, float scale, float temperature, void* stream);
