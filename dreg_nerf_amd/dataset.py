@@ -20,17 +20,35 @@ import torch
 from . import synth
 
 
+def se3_from_draws(phi: float, cos_theta: float, theta_n: float, trans_n, std: float) -> torch.Tensor:
+    """The reference's small rigid perturbation as a function of its random draws (dataset.py:13-33,71-91): rotation axis uniform
+    on the sphere (phi ~ U(0, 2 pi), cos(theta) ~ U(-1, 1)), angle = theta_n * std * pi / sqrt(3) with theta_n ~ N(0,1) (first-order
+    Taylor form when the angle is ~0), translation = trans_n * std / sqrt(3) with trans_n ~ N(0,1)^3.  fp64 like the reference's numpy."""
+    th = math.acos(max(-1.0, min(1.0, float(cos_theta))))
+    ax = torch.tensor([math.sin(th) * math.cos(phi), math.sin(th) * math.sin(phi), math.cos(th)], dtype=torch.float64)
+    omega = ax * (float(theta_n) * std * math.pi / math.sqrt(3.0))
+
+    def hat(v):
+        return torch.tensor([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]], dtype=torch.float64)
+
+    ang = float(omega.norm())
+    if abs(ang) <= 1e-8:                      # np.isclose(theta, 0.) -> I + hat(omega)
+        R = torch.eye(3, dtype=torch.float64) + hat(omega)
+    else:
+        K = hat(omega / ang)
+        R = torch.eye(3, dtype=torch.float64) + math.sin(ang) * K + (1.0 - math.cos(ang)) * (K @ K)
+    T = torch.eye(4, dtype=torch.float64)
+    T[:3, :3] = R
+    T[:3, 3] = torch.as_tensor(trans_n, dtype=torch.float64).reshape(3) * (std / math.sqrt(3.0))
+    return T.float()
+
+
 def _small_se3(std: float, gen=None) -> torch.Tensor:
-    """Random small rigid transform: rotation vector ~ N(0, std), translation ~ N(0, std) (dataset.py:24-33)."""
-    v = torch.randn(6, generator=gen) * std
-    w, t = v[:3], v[3:]
-    th = w.norm().clamp_min(1e-12)
-    k = w / th
-    K = torch.tensor([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
-    R = torch.eye(3) + torch.sin(th) * K + (1 - torch.cos(th)) * (K @ K)
-    T = torch.eye(4)
-    T[:3, :3], T[:3, 3] = R, t
-    return T
+    """Random small rigid transform with the reference's distribution (_sample_se3_small, dataset.py:71-91); draws from torch's RNG
+    (the reference uses numpy's) in the reference's order: phi, cos(theta), angle, translation."""
+    u = torch.rand(2, generator=gen, dtype=torch.float64)
+    n = torch.randn(4, generator=gen, dtype=torch.float64)
+    return se3_from_draws(float(u[0]) * 2.0 * math.pi, float(u[1]) * 2.0 - 1.0, float(n[0]), n[1:], std)
 
 
 class SparseBlock:
@@ -142,6 +160,25 @@ def augment(data: dict, jitter: float = 0.005, std: float = 0.1) -> dict:
     return data
 
 
+def load_split(json_dir: str, dataset: str) -> dict:
+    """{'train': [scene names], 'test': [...]} of `dataset` from the reference's split files (dataset.py:194-216): objaverse.json is
+    {dataset: {split: [ids]}}; for the 'objaverse' entry the ids are object uids that obj_id_names.json maps to scene directory
+    names.  A file that is directly {split: [names]} (single-dataset form) is accepted as well."""
+    path = os.path.join(json_dir, "objaverse.json")
+    if not os.path.exists(path):
+        path = os.path.join(json_dir, f"{dataset}.json")
+    splits = json.load(open(path))
+    if dataset in splits and isinstance(splits[dataset], dict):
+        split = splits[dataset]
+        if dataset == "objaverse":
+            id2name = json.load(open(os.path.join(json_dir, "obj_id_names.json")))
+            split = {sp: [id2name[i] for i in ids] for sp, ids in split.items()}
+        return split
+    if all(k in splits for k in ("train", "test")):
+        return splits
+    raise KeyError(f"dataset '{dataset}' not in {path} (has: {sorted(splits)})")
+
+
 class NeRFRegDataset:
     def __init__(self, root_fp: str, json_dir: str, dataset: str = "objaverse", split: str = "train", model_dir: str = "nerf_models",
                  sparse: bool = False, device=None):
@@ -150,11 +187,12 @@ class NeRFRegDataset:
         self.mode = split
         self.sparse, self.device = sparse, device
         self.meta = []
-        names = json.load(open(os.path.join(json_dir, f"{dataset}.json")))
-        scenes = names[split] if isinstance(names, dict) else names
+        scenes = load_split(json_dir, dataset)[split]
+        skipped = []
         for scene in scenes:
             tf = os.path.join(root_fp, dataset, "images", scene, "world_frame_transforms.json")
             if not os.path.exists(tf):
+                skipped.append(scene)
                 continue
             transforms = {int(k): torch.tensor(v, dtype=torch.float32) for k, v in json.load(open(tf)).items()}
             blocks = {}
@@ -164,6 +202,15 @@ class NeRFRegDataset:
                     blocks[k] = {"dir": d, "transform": transforms[k]}
             if len(blocks) >= 2:
                 self.meta.append({"scene": scene, "dataset": dataset, "blocks": blocks})
+            else:
+                skipped.append(scene)
+        if skipped:
+            print(f"[WARNING] {len(skipped)} of {len(scenes)} {split} scenes of '{dataset}' have no usable blocks under {root_fp} "
+                  f"(first: {skipped[0]})", flush=True)
+        if not self.meta:
+            raise FileNotFoundError(f"no {split} scene of '{dataset}' found under {os.path.join(root_fp, dataset)} "
+                                    f"({len(scenes)} listed in {json_dir})")
+        print(f"Loaded {len(self.meta)} {split} scenes.", flush=True)
 
     def __len__(self):
         return len(self.meta)

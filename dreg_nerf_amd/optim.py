@@ -15,25 +15,33 @@ from . import ops
 
 class FlatAdamW:
     def __init__(self, params: List[torch.nn.Parameter], lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 1e-4, max_norm: float = 0.1):
+                 weight_decay: float = 1e-4, max_norm: float = 0.1, never_used=()):
+        """never_used: parameters that take no part in the forward pass (the reference's correspondence_decoder.q_norm,
+        nerf_regtr.py:266): torch.optim.AdamW skips a parameter whose .grad is None — no moment update and NO weight decay — so they
+        sit behind the updated range of the flat buffers and the kernels never touch them."""
         self.params = [p for p in params]
         dev = self.params[0].device
         n = sum(p.numel() for p in self.params)
         self.n = n
+        skip = {id(p) for p in never_used}
+        self.n_active = n - sum(p.numel() for p in self.params if id(p) in skip)
         self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.offsets = []
+        self.offsets = [0] * len(self.params)
         off = 0
         with torch.no_grad():
-            for p in self.params:
-                k = p.numel()
-                self.flat_p[off:off + k].copy_(p.data.reshape(-1))
-                p.data = self.flat_p[off:off + k].view(p.shape)
-                p.grad = self.flat_g[off:off + k].view(p.shape)
-                self.offsets.append(off)
-                off += k
+            for active in (True, False):
+                for i, p in enumerate(self.params):
+                    if (id(p) not in skip) != active:
+                        continue
+                    k = p.numel()
+                    self.flat_p[off:off + k].copy_(p.data.reshape(-1))
+                    p.data = self.flat_p[off:off + k].view(p.shape)
+                    p.grad = self.flat_g[off:off + k].view(p.shape)
+                    self.offsets[i] = off
+                    off += k
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, betas, eps, weight_decay, max_norm
         self.step_count = 0
         self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -65,9 +73,9 @@ class FlatAdamW:
         self.step_count += 1
         lr = self.param_groups[0]["lr"]
         if self.max_norm > 0:
-            L.check(lib.dreg_grad_norm(L.ptr(self.flat_g), L.ptr(self._norm), L.ptr(self._ws), self.n, L.stream()), "dreg_grad_norm")
+            L.check(lib.dreg_grad_norm(L.ptr(self.flat_g), L.ptr(self._norm), L.ptr(self._ws), self.n_active, L.stream()), "dreg_grad_norm")
         L.check(lib.dreg_adamw_step(L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), L.ptr(self._norm),
-                                    self.n, lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
+                                    self.n_active, lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
                                     float(self.max_norm), L.stream()), "dreg_adamw_step")
         ops.bump_weight_generation()  # the kernel wrote the parameters behind torch's version counters
         ops.repack_all(self.flat_p.device)  # every cached bf16/fp32 weight pack refreshed by one launch

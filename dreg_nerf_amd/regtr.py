@@ -124,7 +124,9 @@ class NeRFRegTr(nn.Module):
 
     def load_state_dict(self, *a, **kw):
         self.__dict__["_pdict"] = None
-        return super().load_state_dict(*a, **kw)
+        out = super().load_state_dict(*a, **kw)
+        ops.bump_weight_generation()   # in-place copies keep data_ptr(): cached bf16 weight packs (ops, trunk executor) are stale now
+        return out
 
     # ------------------------------------------------------------------ A1/A2: FPN3D over a batch of grids
     def _fpn_program(self, O, x, rows, nbt, train: bool = True):

@@ -52,7 +52,8 @@ class TrainStep:
         dev = next(model.parameters()).device
         self.feature_loss = LS.InfoNCELoss(256, 0.2, 0.4).to(dev)
         self.params = [p for p in model.parameters()]
-        self.optimizer = FlatAdamW(self.params, lr=lr, weight_decay=weight_decay, max_norm=grad_clip)
+        never_used = [p for n, p in model.named_parameters() if n.startswith("correspondence_decoder.q_norm.")]   # nerf_regtr.py:266
+        self.optimizer = FlatAdamW(self.params, lr=lr, weight_decay=weight_decay, max_norm=grad_clip, never_used=never_used)
         self.scheduler = StepLR(self.optimizer, step_size=step_lr, gamma=gamma)
         self.grad_clip = grad_clip
         self.robust = robust_loss

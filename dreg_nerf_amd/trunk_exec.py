@@ -179,7 +179,9 @@ class TrunkExecutor:
 
     # ------------------------------------------------------------------ per-step calls
     def repack_if_stale(self):
-        stamp = ops._weight_generation
+        # FlatAdamW / load_state_dict bump the generation; torch's own in-place writes (dist.broadcast, p.data.copy_, manual edits)
+        # move the parameters' version counters
+        stamp = (ops._weight_generation, sum(t._version for t in self._param_refs))
         if self.pack_stamp != stamp:
             L.check(self.lib.dreg_exec_repack(self.h, L.ptr(self.pack_table), L.ptr(self.pack_rowmap), L.stream()), "dreg_exec_repack")
             self.pack_stamp = stamp

@@ -4,6 +4,7 @@ step (train_nerf_regtr.py:186-199 -> conerf/loss/confidence_loss.py:56-160) and 
 
 The reference re-loads the block checkpoint from disk twice per call (confidence_loss.py:34-35,50); here loaded blocks are
 cached per path."""
+import collections
 import ctypes
 from typing import Dict, List
 
@@ -14,28 +15,54 @@ import torch
 from . import lib as L
 from . import ngp
 
-_block_cache: Dict[str, tuple] = {}
+# Loaded blocks, least recently used first; bounded by device bytes (a block = 12.6 M hash-grid parameters in fp32 + the fp16
+# inference copy + the occupancy grid, ~80 MB: an Objaverse epoch touches 3,284 of them, the reference reloads from disk every call).
+_block_cache: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
+_block_cache_bytes = 0
+BLOCK_CACHE_MAX_BYTES = int(os.environ.get("DREG_BLOCK_CACHE_MB", "2048")) << 20
+
+
+def _block_bytes(field, binary) -> int:
+    """fp32 parameters + the fp16 inference copy NGPradianceField._prepared() makes on first use + the occupancy grid."""
+    n_par = sum(p.numel() for p in field.parameters())
+    return n_par * 4 + n_par * 2 + sum(b.numel() * b.element_size() for b in field.buffers()) + binary.numel() * binary.element_size()
+
+
+def clear_block_cache():
+    global _block_cache_bytes
+    _block_cache.clear()
+    _block_cache_bytes = 0
 
 
 def load_block(path: str, device):
     """(NGPradianceField, occupancy binary [r,r,r] bool on device, meta dict) of a reference NeRF block checkpoint
-    (keys: train_ngp_nerf.py:187-209)."""
+    (keys: train_ngp_nerf.py:187-209), through a byte-bounded LRU cache."""
+    global _block_cache_bytes
     key = (path, str(device))
-    if key not in _block_cache:
-        from .checkpoint import CheckPointManager
-        # the reference's two-pass load (conerf/loss/confidence_loss.py:25-50): meta data first, then the modules built from it
-        meta = {k: None for k in ("aabb", "unbounded", "grid_resolution", "contraction_type", "render_step_size", "alpha_thre",
-                                  "cone_angle", "camera_poses")}
-        mgr = CheckPointManager(verbose=False)
-        if not os.path.exists(path):
-            raise FileNotFoundError(path)
-        mgr.load_no_config(ckpt_path=path, meta_data=meta, map_location="cpu")
-        field = ngp.NGPradianceField(meta["aabb"], unbounded=bool(meta["unbounded"]))
-        occ = ngp.OccupancyGrid(meta["aabb"], meta["grid_resolution"], meta["contraction_type"])
-        mgr.load_no_config(ckpt_path=path, models={"model": field, "occupancy_grid": occ}, map_location="cpu")
-        field = field.to(device).eval()
-        _block_cache[key] = (field, occ.binary.to(device), {k: meta[k] for k in ("aabb", "render_step_size", "cone_angle", "alpha_thre", "camera_poses")})
-    return _block_cache[key]
+    hit = _block_cache.get(key)
+    if hit is not None:
+        _block_cache.move_to_end(key)
+        return hit[:3]
+    from .checkpoint import CheckPointManager
+    # the reference's two-pass load (conerf/loss/confidence_loss.py:25-50): meta data first, then the modules built from it
+    meta = {k: None for k in ("aabb", "unbounded", "grid_resolution", "contraction_type", "render_step_size", "alpha_thre",
+                              "cone_angle", "camera_poses")}
+    mgr = CheckPointManager(verbose=False)
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    mgr.load_no_config(ckpt_path=path, meta_data=meta, map_location="cpu")
+    field = ngp.NGPradianceField(meta["aabb"], unbounded=bool(meta["unbounded"]))
+    occ = ngp.OccupancyGrid(meta["aabb"], meta["grid_resolution"], meta["contraction_type"])
+    mgr.load_no_config(ckpt_path=path, models={"model": field, "occupancy_grid": occ}, map_location="cpu")
+    field = field.to(device).eval()
+    binary = occ.binary.to(device)
+    nbytes = _block_bytes(field, binary)
+    while _block_cache and _block_cache_bytes + nbytes > BLOCK_CACHE_MAX_BYTES:
+        _, old = _block_cache.popitem(last=False)
+        _block_cache_bytes -= old[3]
+    _block_cache[key] = (field, binary, {k: meta[k] for k in ("aabb", "render_step_size", "cone_angle", "alpha_thre", "camera_poses")}, nbytes)
+    _block_cache_bytes += nbytes
+    return _block_cache[key][:3]
 
 
 @torch.no_grad()

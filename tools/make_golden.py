@@ -145,9 +145,22 @@ def main():
              rre=rr.numpy(), rte=rt.numpy())
     print("e2e_eval32 done; N =", out["src_kp"][0].shape[0], out["tgt_kp"][0].shape[0])
 
-    # ---------------------------------------------------------------- training step, 64^3, train-mode BN
+    want = set(sys.argv[1:]) or {"small", "train64", "train128"}
+    if "train64" in want:
+        train_golden(nr, sd, 64, "train64")
+    if "train128" in want:
+        # BASELINE size: two A4 rounds, split-K thresholds and 32-bit index ranges of the 128^3 path (reference fwd+bwd: ~2 min on
+        # 8 cores; the fp64 oracle pass needs ~40 GB and ~20 min: DREG_GOLDEN_FP64_128=0 skips it)
+        train_golden(nr, sd, 128, "train128", with_fp64=bool(int(os.environ.get("DREG_GOLDEN_FP64_128", "1"))))
+
+
+def train_golden(nr, sd, res: int, name: str, with_fp64: bool = True):
+    """One training step of the REFERENCE (train-mode BatchNorm, its own loss code, clip_grad_norm_ + AdamW) on
+    shell_pair(res, 1, 2): losses, pose, per-module gradient norms, gradient probes (+ their fp64 truth from the
+    reference-pinned oracle), clip norm and the per-module parameter delta of the optimizer step."""
+    from conerf.loss.feature_loss import InfoNCELoss
     m = ref_model(nr, sd).train()
-    data = synth.shell_pair(64, 1, 2, pose=synth.fixed_pose())
+    data = synth.shell_pair(res, 1, 2, pose=synth.fixed_pose())
     feature_loss = InfoNCELoss(d_embed=256, r_p=0.2, r_n=0.4)
     gW = torch.Generator().manual_seed(5)
     with torch.no_grad():
@@ -197,31 +210,33 @@ def main():
         idx = sample_idx(gr.numel(), 64, 31)
         gp["gidx/" + k] = idx
         gp["gval/" + k] = gr[idx].numpy()
-    # fp64 ground truth of the same probes from the (reference-pinned) oracle: train-mode BatchNorm over the 8 voxels
-    # of layer4 makes fp32 gradients of the ResNet noisy at the 1e-2 level, so GPU tests bound their error relative
-    # to the fp32 reference's own distance from this truth.
-    sd64 = {}
-    for k, v in params.synth_state_dict(0).items():
-        if k.startswith(params.ALIAS_DST):
-            sd64[k] = sd64[params.ALIAS_SRC + k[len(params.ALIAS_DST):]]
-        else:
-            sd64[k] = v.double() if v.is_floating_point() else v.clone()
-    for k, (shape, kind) in params.regtr_spec().items():
-        if not params.is_buffer(kind) and not k.startswith(params.ALIAS_DST):
-            sd64[k].requires_grad_(True)
-    d64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in data.items()}
-    p64 = O.regtr_forward(sd64, d64, train=True)
-    s_gt64, t_gt64 = synth.synthetic_overlap_gt(p64["src_kp"][0]), synth.synthetic_overlap_gt(p64["tgt_kp"][0])
-    assert torch.equal(s_gt64.float(), s_gt) and torch.equal(t_gt64.float(), t_gt)
-    l64 = O.training_losses(p64, d64["pose"], feature_loss.W.detach().double(), s_gt64, t_gt64, s_tl.double(), t_tl.double())
-    l64["total"].backward()
-    for k in probes:
-        gp["gval64/" + k] = sd64[k].grad.flatten()[gp["gidx/" + k]].numpy()
-    gnorm64 = {}
-    for gname, pref in groups.items():
-        gnorm64[gname] = float(sum(float(v.grad.pow(2).sum()) for k, v in sd64.items()
-                                   if k.startswith(pref) and not k.startswith(params.ALIAS_DST) and v.grad is not None) ** 0.5)
-    print("fp64 losses", {k: float(v) for k, v in l64.items()}, gnorm64)
+    gnorm64, l64 = {}, {}
+    if with_fp64:
+        # fp64 ground truth of the same probes from the (reference-pinned) oracle: train-mode BatchNorm over the 8 voxels
+        # of layer4 makes fp32 gradients of the ResNet noisy at the 1e-2 level, so GPU tests bound their error relative
+        # to the fp32 reference's own distance from this truth.
+        sd64 = {}
+        for k, v in params.synth_state_dict(0).items():
+            if k.startswith(params.ALIAS_DST):
+                sd64[k] = sd64[params.ALIAS_SRC + k[len(params.ALIAS_DST):]]
+            else:
+                sd64[k] = v.double() if v.is_floating_point() else v.clone()
+        for k, (shape, kind) in params.regtr_spec().items():
+            if not params.is_buffer(kind) and not k.startswith(params.ALIAS_DST):
+                sd64[k].requires_grad_(True)
+        d64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in data.items()}
+        p64 = O.regtr_forward(sd64, d64, train=True)
+        s_gt64, t_gt64 = synth.synthetic_overlap_gt(p64["src_kp"][0]), synth.synthetic_overlap_gt(p64["tgt_kp"][0])
+        assert torch.equal(s_gt64.float(), s_gt) and torch.equal(t_gt64.float(), t_gt)
+        l64 = O.training_losses(p64, d64["pose"], feature_loss.W.detach().double(), s_gt64, t_gt64, s_tl.double(), t_tl.double())
+        l64["total"].backward()
+        for k in probes:
+            gp["gval64/" + k] = sd64[k].grad.flatten()[gp["gidx/" + k]].numpy()
+        gnorm64 = {}
+        for gname, pref in groups.items():
+            gnorm64[gname] = float(sum(float(v.grad.pow(2).sum()) for k, v in sd64.items()
+                                       if k.startswith(pref) and not k.startswith(params.ALIAS_DST) and v.grad is not None) ** 0.5)
+        print("fp64 losses", {k: float(v) for k, v in l64.items()}, gnorm64)
     total_norm = float(torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=0.1))
     opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=1e-4)
     before = {k: p.detach().clone() for k, p in named.items()}
@@ -231,7 +246,7 @@ def main():
              for gname, pref in groups.items()}
     bn_probe = m.state_dict()["fpn3d.backbone_net.layer3.1.bn2.running_var"][:16].numpy()
     bn_probe_m = m.state_dict()["fpn3d.backbone_net.bn1.running_mean"][:16].numpy()
-    np.savez(os.path.join(OUT, "train64.npz"),
+    np.savez(os.path.join(OUT, name + ".npz"),
              n_src=s_kp.shape[0], n_tgt=t_kp.shape[0],
              pose=pred["pose"].detach().numpy(),
              **{"loss_" + k: float(v) for k, v in losses.items()},
@@ -241,7 +256,7 @@ def main():
              **{"dnorm_" + k: v for k, v in dnorm.items()},
              total_grad_norm=total_norm, bn_running_var_probe=bn_probe, bn_running_mean_probe=bn_probe_m,
              W_seed=5, **gp)
-    print("train64 done", {k: float(v) for k, v in losses.items()}, gnorm, total_norm)
+    print(name, "done", {k: float(v) for k, v in losses.items()}, gnorm, total_norm)
 
 
 if __name__ == "__main__":

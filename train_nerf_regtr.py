@@ -81,7 +81,12 @@ def main():
     for epoch in range(cfg.epochs):
         ids = list(range(len(train_ds)))
         random.Random(cfg.seed + epoch).shuffle(ids)
-        ids = ids[rank::world]
+        # every rank must run the same number of steps (each step ends in a blocking gradient all-reduce, and the step count drives
+        # StepLR and the checkpoint cadence): keep a multiple of world * pairs_per_step scenes of this epoch's permutation
+        usable = (len(ids) // (world * per_step)) * world * per_step
+        if usable == 0:
+            raise SystemExit(f"{len(ids)} training scenes < world ({world}) x pairs_per_step ({per_step}): nothing to train on")
+        ids = ids[:usable][rank::world]
         for b in range(0, len(ids) - per_step + 1, per_step):
             batch = [to_device(train_ds[i], dev) for i in ids[b:b + per_step]]
             out = ts.step(batch)
