@@ -1,0 +1,366 @@
+// Dense 3x3x3 / stride-1 / pad-1 convolution (forward and, with the flipped-tap weight pack, its data gradient) for bf16 NDHWC
+// activations with Cout = 256: the two dominant layers of the reference's FeaturePyramid_v1 head, upsample_transform_1
+// (256 -> 256 at 64^3: 67 % of the network's FLOPs) and pyramid_transformation_1 (64 -> 256)
+// (conerf/model/feature_pyramid_net.py:47-56,97-103; cuDNN conv3d in the reference).
+//
+// Why a second convolution kernel: the implicit-GEMM kernel of conv.hip re-gathers the A tile (256 voxels x 64 channels) from
+// L2 for every one of the 27 taps — 64 KB of direct-to-LDS pieces per K step and workgroup, whose ISSUE alone costs what the
+// step's MFMAs cost (0.41 of the MFMA roof, 5x the compulsory HBM bytes; profiles/r01_j).  Here a workgroup owns a
+// 4 x 8 x 8 box of output voxels and stages its 6 x 10 x 10 input halo ONCE per 32-channel chunk (37.5 KB); all 27 taps read
+// it through shifted ds_read_b128 windows.  Only the weights stream per tap (16 KB per unit = one tap x 32 channels x 256
+// output channels, contiguous in the [chunk][tap][cout][32] pack).  Direct-to-LDS traffic per unit drops from 32 KB to ~17 KB.
+//
+// Schedule (8 waves = 2 (M: two z-planes each) x 4 (N: 64 output channels each), v_mfma_f32_32x32x16_bf16, 16 per wave and unit):
+// the two wave groups (waves 0-3 / 4-7; wave w and w+4 share a SIMD) run in ANTI-PHASE, one barrier apart: while one group
+// issues its 12 fragment reads and its direct-to-LDS pieces for a later unit, the other runs its 16 MFMAs at raised priority,
+// then they swap (the guide's 8-phase idea with a unit as the phase).  Counted vmcnt only: the weight ring is RING units deep,
+// a unit is issued AHEAD units before it is read, waited for one unit before it is read and never drained.
+//
+// LDS (143,360 B): two halo buffers of 38 KiB (chunk parity) | weight ring 4 x 16 KiB (re-used by the epilogue as the fp32
+// staging tile).  Both images are written lane-linearly by the DMA, the 16-byte-slot XOR swizzles sit on the SOURCE address:
+//   halo voxel hv = (hz*10 + hy)*10 + hx, 64 B each: slot s of voxel hv holds channel granule s ^ (hy & 3)
+//   weight row co (64 B):                               slot s holds granule s ^ ((co >> 2) & 3)
+// which makes every ds_read_b128 of a 32-row MFMA fragment conflict free for all 27 window shifts (tools/lds_conflicts.py).
+#include "common.h"
+
+namespace halo {
+constexpr int TZ = 4, TY = 8, TX = 8;
+constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HVOX = HZ * HY * HX;   // 600
+constexpr int CK = 32;                                  // channels per unit
+constexpr int HPIECES = (HVOX + 15) / 16;               // 38 DMA pieces of 16 voxels x 64 B
+constexpr int HBUF = HPIECES * 1024;                    // 38,912 B
+constexpr int UNIT = 256 * CK * 2;                      // 16,384 B of weights per (chunk, tap)
+constexpr uint32_t OOB = 0x7fffff00u;                   // out-of-range buffer offset: the DMA writes zeros
+}
+
+struct HaloGeom {
+    int B, D, H, W, Cin, nchunks;
+    int tilesY, tilesX, tilesPerGrid;        // tiles along y, x; tiles per grid
+    int Da, Ha, Wa, add_shift;               // addend geometry (nearest x2 when add_shift = 1, same size when 0)
+};
+
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+
+__device__ __forceinline__ uint32_t halo_xcd_remap(uint32_t bid, uint32_t nblk) {
+    const uint32_t xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vmcnt_n(int n) {
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        case 5: wait_vmcnt<5>(); break;
+        default: wait_vmcnt<6>(); break;
+    }
+}
+
+#define HALO_DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+
+// ABL (timing experiments only, wrong results): 1 = no DMA inside the loop, 2 = no fragment reads, 4 = no MFMAs
+template <typename TO, int AHEAD, int RING, bool STAGGER, int ABL = 0, bool SPLITDS = true>
+__global__ __launch_bounds__(512) void conv3_halo_kernel(
+    const bf16_t* __restrict__ in, const bf16_t* __restrict__ wpk, TO* __restrict__ out,
+    const float* __restrict__ bias, const TO* __restrict__ addend, HaloGeom g, uint32_t in_bytes, uint32_t wt_bytes)
+{
+    using namespace halo;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    static_assert(RING >= AHEAD + 2 && AHEAD >= 2 && AHEAD <= 3, "a unit may be overwritten two units after it was read (anti-phase groups)");
+    constexpr int RING_OFF = 2 * HBUF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const uint32_t tile = halo_xcd_remap(blockIdx.x, gridDim.x);
+    const int b = tile / g.tilesPerGrid;
+    int rem = tile - b * g.tilesPerGrid;
+    const int tz = rem / (g.tilesY * g.tilesX);
+    rem -= tz * (g.tilesY * g.tilesX);
+    const int ty = rem / g.tilesX, tx = rem - ty * g.tilesX;
+    const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, wt_bytes, 0x00020000);
+
+    // ---- halo staging roles: this wave moves pieces wave, wave+8, ... (16 halo voxels each; lane -> voxel lane>>2, slot lane&3)
+    uint32_t hoff[5];
+    const int npw = (HPIECES - wave + 7) >> 3;            // 5 pieces for waves 0..5, 4 for waves 6, 7
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int hv = (wave + 8 * j) * 16 + (lane >> 2);
+        const int hz = hv / (HY * HX), r2 = hv - hz * (HY * HX), hy = r2 / HX, hx = r2 - hy * HX;
+        const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool v = hv < HVOX && (unsigned)gz < (unsigned)g.D && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+        const uint32_t vox = (uint32_t)(((b * g.D + gz) * g.H + gy) * g.W + gx);
+        hoff[j] = v ? vox * (uint32_t)(g.Cin * 2) + (uint32_t)((((lane & 3) ^ (hy & 3))) << 4) : OOB;
+    }
+    // ---- weight staging role: pieces 2*wave, 2*wave+1 of every unit (rows 32*wave .. +31); lane -> row lane>>2, slot lane&3
+    const uint32_t wlane = (uint32_t)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+
+    // ---- fragment read roles (32x32x16: lane -> row lane&31, k-half lane>>5)
+    const int fr = lane & 31, fq = lane >> 5;
+    const int fx = fr & 7, fy = fr >> 3;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t a_lane = lds0 + (uint32_t)((((2 * wm) * HY + fy) * HX + fx) * 64);
+    const uint32_t b_sw0 = (uint32_t)((fq ^ ((fr >> 2) & 3)) << 4);
+    const uint32_t b_lane0 = lds0 + RING_OFF + (uint32_t)((wn * 64 + fr) * 64) + b_sw0;
+    const uint32_t b_lane1 = lds0 + RING_OFF + (uint32_t)((wn * 64 + fr) * 64) + (b_sw0 ^ 32u);
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int U = g.nchunks * 27;
+    auto issue_halo = [&](int chunk, int j) {
+        const uint32_t vo = j == 0 ? hoff[0] : j == 1 ? hoff[1] : j == 2 ? hoff[2] : j == 3 ? hoff[3] : hoff[4];
+        char* dst = smem + (chunk & 1) * HBUF + (wave + 8 * j) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)dst, 16, (int)vo, chunk * (CK * 2), 0, 0);
+    };
+    auto issue_unit = [&](int u) {
+        char* dst = smem + RING_OFF + (u % RING) * UNIT + wave * 2048;
+        const int so = u * UNIT + wave * 2048;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, (lds_ptr_t)dst, 16, (int)wlane, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, (lds_ptr_t)(dst + 1024), 16, (int)wlane, so + 1024, 0, 0);
+    };
+
+    // ---- prologue: halo of chunk 0, units 0 .. AHEAD-1
+    for (int j = 0; j < npw; ++j) issue_halo(0, j);
+#pragma unroll
+    for (int u = 0; u < AHEAD; ++u)
+        if (u < U) issue_unit(u);
+    // unit 0 and the halo have landed for this wave once at most 2*(AHEAD-1) younger pieces are outstanding
+    wait_vmcnt_n(2 * (min(AHEAD, U) - 1));
+    __builtin_amdgcn_s_barrier();
+    if (STAGGER && wm == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one barrier behind group 0
+
+    int nh_prev = 0;                                             // halo pieces this wave issued in the previous unit's load half
+    int c = 0, tap = 0, dz = 0, dy = 0, dx = 0;
+    for (int u = 0; u < U; ++u) {
+        // ================= load half: fragments of unit u (k-half 0; SPLITDS: k-half 1 follows inside the compute half), direct-to-LDS
+        // pieces of later units (issued HERE, under the other group's MFMAs: between this wave's own MFMAs each piece stalls its
+        // in-order instruction stream for ~100 cycles and the matrix pipe runs dry — measured 6 % slower)
+        const uint32_t sw0 = (uint32_t)((fq ^ ((fy + dy) & 3)) << 4);
+        const uint32_t s_a = (uint32_t)((c & 1) * HBUF + ((dz * HY + dy) * HX + dx) * 64);
+        const uint32_t aA0 = a_lane + s_a + sw0, aA1 = a_lane + s_a + (sw0 ^ 32u);
+        const uint32_t s_b = (uint32_t)((u % RING) * UNIT);
+        const uint32_t aB0 = b_lane0 + s_b, aB1 = b_lane1 + s_b;
+        i32x4_t a00, a01, a10, a11, a20, a21, a30, a31, b00, b01, b10, b11;   // [tile][k-half]
+        if (!(ABL & 2)) {
+            HALO_DSR(b00, aB0, 0);    HALO_DSR(b10, aB0, 2048);
+            HALO_DSR(a00, aA0, 0);    HALO_DSR(a10, aA0, 2560);  HALO_DSR(a20, aA0, 6400);  HALO_DSR(a30, aA0, 8960);
+            if (!SPLITDS) {
+                HALO_DSR(b01, aB1, 0);    HALO_DSR(b11, aB1, 2048);
+                HALO_DSR(a01, aA1, 0);    HALO_DSR(a11, aA1, 2560);  HALO_DSR(a21, aA1, 6400);  HALO_DSR(a31, aA1, 8960);
+            }
+        } else {
+            asm volatile("" : "=v"(a00), "=v"(a01), "=v"(a10), "=v"(a11), "=v"(a20), "=v"(a21), "=v"(a30), "=v"(a31), "=v"(b00), "=v"(b01), "=v"(b10), "=v"(b11)
+                         : "v"(aA0), "v"(aA1), "v"(aB0), "v"(aB1));
+        }
+        int nh = 0;
+        if (!(ABL & 1) && tap >= 1 && tap <= npw && c + 1 < g.nchunks) { issue_halo(c + 1, tap - 1); nh = 1; }
+        int nb = 0;
+        if (!(ABL & 1) && u + AHEAD < U) { issue_unit(u + AHEAD); nb = 2; }
+        if (u + 1 < U) {
+            // unit u+1 was issued AHEAD-1 units ago; everything issued after it may stay in flight
+            int n = nh + nb;
+            if (AHEAD >= 3) n += nh_prev + (u + 2 < U ? 2 : 0);
+            wait_vmcnt_n(n);
+        }
+        nh_prev = nh;
+        // next unit's coordinates (scalar work kept out of the compute half)
+        if (++dx == 3) { dx = 0; if (++dy == 3) { dy = 0; ++dz; } }
+        if (++tap == 27) { tap = 0; dz = 0; ++c; }
+        __builtin_amdgcn_s_barrier();
+        if (SPLITDS && !(ABL & 2))
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a00), "+v"(a10), "+v"(a20), "+v"(a30), "+v"(b00), "+v"(b10));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11), "+v"(a20), "+v"(a21), "+v"(a30), "+v"(a31),
+                           "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11));
+        __builtin_amdgcn_sched_barrier(0);
+        // ================= compute half
+        __builtin_amdgcn_s_setprio(1);
+#define HALO_MM(i, j, A, Bv) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A), __builtin_bit_cast(bf16x8_t, Bv), acc[i][j], 0, 0, 0)
+#define HALO_SB() __builtin_amdgcn_sched_barrier(0)
+        if (ABL & 4) {
+            asm volatile("" :: "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(a20), "v"(a21), "v"(a30), "v"(a31), "v"(b00), "v"(b01), "v"(b10), "v"(b11));
+        } else if (SPLITDS && !(ABL & 2)) {
+            // the second k-half's six fragment reads ride in the issue gaps of the first eight MFMAs (an MFMA occupies the matrix
+            // pipe for 32 cycles, a ds_read_b128 the wave's issue slot for a few)
+            HALO_MM(0, 0, a00, b00); HALO_SB(); HALO_DSR(b01, aB1, 0);    HALO_SB();
+            HALO_MM(1, 0, a10, b00); HALO_SB(); HALO_DSR(b11, aB1, 2048); HALO_SB();
+            HALO_MM(2, 0, a20, b00); HALO_SB(); HALO_DSR(a01, aA1, 0);    HALO_SB();
+            HALO_MM(3, 0, a30, b00); HALO_SB(); HALO_DSR(a11, aA1, 2560); HALO_SB();
+            HALO_MM(0, 1, a00, b10); HALO_SB(); HALO_DSR(a21, aA1, 6400); HALO_SB();
+            HALO_MM(1, 1, a10, b10); HALO_SB(); HALO_DSR(a31, aA1, 8960); HALO_SB();
+            HALO_MM(2, 1, a20, b10); HALO_MM(3, 1, a30, b10);
+            HALO_SB();
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a01), "+v"(a11), "+v"(a21), "+v"(a31), "+v"(b01), "+v"(b11));
+            HALO_SB();
+            HALO_MM(0, 0, a01, b01); HALO_MM(1, 0, a11, b01); HALO_MM(2, 0, a21, b01); HALO_MM(3, 0, a31, b01);
+            HALO_MM(0, 1, a01, b11); HALO_MM(1, 1, a11, b11); HALO_MM(2, 1, a21, b11); HALO_MM(3, 1, a31, b11);
+        } else {
+            HALO_MM(0, 0, a00, b00); HALO_MM(1, 0, a10, b00); HALO_MM(2, 0, a20, b00); HALO_MM(3, 0, a30, b00);
+            HALO_MM(0, 1, a00, b10); HALO_MM(1, 1, a10, b10); HALO_MM(2, 1, a20, b10); HALO_MM(3, 1, a30, b10);
+            HALO_MM(0, 0, a01, b01); HALO_MM(1, 0, a11, b01); HALO_MM(2, 0, a21, b01); HALO_MM(3, 0, a31, b01);
+            HALO_MM(0, 1, a01, b11); HALO_MM(1, 1, a11, b11); HALO_MM(2, 1, a21, b11); HALO_MM(3, 1, a31, b11);
+        }
+#undef HALO_MM
+#undef HALO_SB
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();      // pairs with group 1's last barrier
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue: one z-plane (64 voxels x 256 channels, fp32) at a time through the weight ring, then coalesced rows with
+    // bias / addend applied in fp32
+    float* sC = reinterpret_cast<float*>(smem + RING_OFF);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {            // unrolled: the accumulator tiles are indexed at compile time
+        if (wm == (p >> 1)) {
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih) {
+                const int i = 2 * (p & 1) + ih;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = ih * 32 + (e & 3) + 8 * (e >> 2) + 4 * fq;
+                        sC[row * 256 + wn * 64 + j * 32 + fr] = acc[i][j][e];
+                    }
+            }
+        }
+        __syncthreads();
+        const int z = z0 + p;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int cidx = t + 512 * it;
+            const int row = cidx >> 5, c8 = (cidx & 31) * 8;
+            const int y = y0 + (row >> 3), x = x0 + (row & 7);
+            const float4 lo = *reinterpret_cast<const float4*>(sC + row * 256 + c8), hi = *reinterpret_cast<const float4*>(sC + row * 256 + c8 + 4);
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            if (bias) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bias[c8 + e];
+            }
+            if (addend) {
+                const TO* ap = addend + ((size_t)((b * g.Da + (z >> g.add_shift)) * g.Ha + (y >> g.add_shift)) * g.Wa + (x >> g.add_shift)) * 256 + c8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += Elem<TO>::ld(ap + e);
+            }
+            TO* dst = out + ((size_t)((b * g.D + z) * g.H + y) * g.W + x) * 256 + c8;
+            if constexpr (sizeof(TO) == 4) {
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+                uint32_t w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = f2bf2(v[2 * e], v[2 * e + 1]);
+                *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// torch weight [Cout][Cin][3][3][3] fp32 -> [Cin/32][27][256 rows][32] bf16.
+//   forward      : row = co,  column = ci within the chunk, tap as stored:            pack[c][t][co][k] = W[co][32c+k][t]
+//   data gradient: row = ci,  column = co within the chunk, tap flipped (26 - t):     pack[c][t][ci][k] = W[32c+k][ci][26-t]
+// (dIn[v][ci] = sum_{t,co} dOut[v + 1 - d(t)][co] W[co][ci][t] = sum_{t'} sum_co dOut[v - 1 + d(t')][co] W[co][ci][26-t'])
+__global__ __launch_bounds__(256) void pack_weight_halo_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int transposed)
+{
+    const int rows = transposed ? Cin : Cout, red = transposed ? Cout : Cin;   // rows must be 256
+    const int unit = blockIdx.x;                 // (chunk, tap)
+    const int c = unit / 27, tp = unit - c * 27;
+    for (int i = threadIdx.x; i < rows * 4; i += 256) {
+        const int row = i >> 2, k8 = (i & 3) * 8;
+        uint32_t pk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = c * 32 + k8 + 2 * e + h;
+                v[h] = k < red ? (transposed ? w[((size_t)k * Cin + row) * 27 + (26 - tp)] : w[((size_t)row * Cin + k) * 27 + tp]) : 0.f;
+            }
+            pk[e] = f2bf2(v[0], v[1]);
+        }
+        *reinterpret_cast<uint4*>(out + ((size_t)unit * rows + row) * 32 + k8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+}
+
+static int g_halo_variant = 0;   // experiments only (tools/bench_conv_halo.py): 0 = anti-phase groups, weights 2 units ahead / ring 4; 1 = lockstep; 2 = 3 ahead / ring 5; 1x = ablations
+
+extern "C" {
+
+void dreg_conv3_halo_set_variant(int v) { g_halo_variant = v; }
+
+// 1 when (shape) is served by the halo kernel: 3^3 / stride 1 / pad 1, 256 output channels, Cin % 32 == 0, volume divisible by the
+// 4 x 8 x 8 box, operands below 2 GiB (32-bit buffer offsets)
+int dreg_conv3_halo_supported(int B, int D, int H, int W, int Cin, int Cout)
+{
+    if (Cout != 256 || Cin % 32 != 0 || Cin < 32 || D % halo::TZ || H % halo::TY || W % halo::TX) return 0;
+    if ((uint64_t)B * D * H * W * (Cin > 256 ? Cin : 256) * 2 >= 0x7fffff00ull) return 0;
+    return 1;
+}
+
+size_t dreg_conv3_halo_pack_bytes(int Cin_red) { return (size_t)(Cin_red / 32) * 27 * halo::UNIT; }
+
+// w: torch layout fp32 [Cout][Cin][27]; transposed = 0: forward pack (Cout must be 256), 1: data-gradient pack (Cin must be 256)
+int dreg_pack_conv_weight_halo(const float* w, void* out, int Cout, int Cin, int transposed, void* stream)
+{
+    const int rows = transposed ? Cin : Cout, red = transposed ? Cout : Cin;
+    if (rows != 256 || red % 32 != 0) return DREG_EINVAL;
+    hipLaunchKernelGGL(pack_weight_halo_kernel, dim3((red / 32) * 27), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)out, Cout, Cin, transposed);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// out[b,z,y,x,:] = bias + addend(...) + sum_{d in 3^3} in[b, (z,y,x) - 1 + d, :] . pack[., d, :, .]     (bf16 in/out, fp32 accumulate)
+// in [B,D,H,W,Cin] bf16, wpk from dreg_pack_conv_weight_halo, out [B,D,H,W,256] bf16 (out_f32: fp32), bias fp32 [256] or null,
+// addend [B,Da,Ha,Wa,256] (same dtype as out) added with nearest x2 upsampling (add_same = 0) or element-wise (add_same = 1), or null.
+int dreg_conv3_halo(const void* in, const void* wpk, void* out, const float* bias, const void* addend,
+                    int B, int D, int H, int W, int Cin, int Da, int Ha, int Wa, int add_same, int out_f32, void* stream)
+{
+    using namespace halo;
+    if (!dreg_conv3_halo_supported(B, D, H, W, Cin, 256)) return DREG_EINVAL;
+    HaloGeom g;
+    g.B = B; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.nchunks = Cin / CK;
+    g.tilesY = H / TY; g.tilesX = W / TX; g.tilesPerGrid = (D / TZ) * g.tilesY * g.tilesX;
+    g.Da = Da; g.Ha = Ha; g.Wa = Wa; g.add_shift = add_same ? 0 : 1;
+    const uint32_t ntiles = (uint32_t)B * g.tilesPerGrid;
+    if (ntiles == 0) return DREG_OK;
+    const uint32_t in_bytes = (uint32_t)((uint64_t)B * D * H * W * Cin * 2), wt_bytes = (uint32_t)dreg_conv3_halo_pack_bytes(Cin);
+    hipStream_t st = (hipStream_t)stream;
+#define HALO_LAUNCH(TOt, AH, RG, SG, AB, SD) do { \
+        const int lds_ = 2 * HBUF + RG * UNIT; \
+        (void)hipFuncSetAttribute((const void*)conv3_halo_kernel<TOt, AH, RG, SG, AB, SD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); \
+        hipLaunchKernelGGL((conv3_halo_kernel<TOt, AH, RG, SG, AB, SD>), dim3(ntiles), dim3(512), lds_, st, (const bf16_t*)in, (const bf16_t*)wpk, (TOt*)out, \
+                           bias, (const TOt*)addend, g, in_bytes, wt_bytes); } while (0)
+    if (out_f32) HALO_LAUNCH(float, 2, 4, true, 0, true);
+    else if (g_halo_variant == 1) HALO_LAUNCH(bf16_t, 2, 4, false, 0, true);
+    else if (g_halo_variant == 2) HALO_LAUNCH(bf16_t, 3, 5, true, 0, true);
+    else if (g_halo_variant == 3) HALO_LAUNCH(bf16_t, 2, 4, true, 0, false);
+    else if (g_halo_variant == 11) HALO_LAUNCH(bf16_t, 2, 4, true, 1, true);
+    else if (g_halo_variant == 12) HALO_LAUNCH(bf16_t, 2, 4, true, 2, true);
+    else if (g_halo_variant == 13) HALO_LAUNCH(bf16_t, 2, 4, true, 3, true);
+    else if (g_halo_variant == 14) HALO_LAUNCH(bf16_t, 2, 4, true, 4, true);
+    else HALO_LAUNCH(bf16_t, 2, 4, true, 0, true);
+#undef HALO_LAUNCH
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+}  // extern "C"

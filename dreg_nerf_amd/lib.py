@@ -49,6 +49,12 @@ SIGNATURES = {
     "dreg_conv3d_wgrad_occ": (I, [P, P, P, P, Z] + [I] * 16 + [P, P]),
     "dreg_conv3d_igemm_rows": (I, [P] * 5 + [P, I] + [I] * 18 + [I, P]),
     "dreg_conv3d_wgrad_rows": (I, [P, P, P, P, Z] + [P, I] + [I] * 14 + [P]),
+    # conv_halo.hip
+    "dreg_conv3_halo_supported": (I, [I] * 6),
+    "dreg_conv3_halo_pack_bytes": (Z, [I]),
+    "dreg_pack_conv_weight_halo": (I, [P, P, I, I, I, P]),
+    "dreg_conv3_halo": (I, [P, P, P, P, P] + [I] * 10 + [P]),
+    "dreg_conv3_halo_set_variant": (None, [I]),
     # fpn_ops.hip
     "dreg_bn_num_chunks": (I, [I]),
     "dreg_bn3d_fwd": (I, [P] * 10 + [I, I, I, F, F, I, I, I, P]),

@@ -70,6 +70,23 @@ int dreg_conv3d_igemm_occ(const void* in, const void* wt_packed, void* out, cons
                           int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
                           int dtype, int out_f32, void* workspace, size_t workspace_bytes, const uint8_t* rowocc, void* stream);
 
+/* ---- dense 3^3 / stride 1 / pad 1 convolution with 256 output channels on an LDS-resident input halo (csrc/conv_halo.hip):
+ * the FeaturePyramid_v1 head's upsample_transform_* / pyramid_transformation_1 layers (conerf/model/feature_pyramid_net.py:47-56,
+ * 97-103; cuDNN conv3d in the reference) and their data gradients.  A workgroup owns a 4 x 8 x 8 box of output voxels, stages its
+ * 6 x 10 x 10 input halo once per 32-channel chunk and runs all 27 taps out of LDS; only the weights stream per tap.
+ * dreg_conv3_halo_supported: 1 when the shape qualifies (Cout == 256, Cin % 32 == 0, D % 4 == H % 8 == W % 8 == 0, operands < 2 GiB).
+ * dreg_pack_conv_weight_halo: torch weight fp32 [Cout][Cin][27] -> bf16 [Cin'/32][27][256][32] (dreg_conv3_halo_pack_bytes(Cin') bytes);
+ *   transposed = 0: forward pack (Cout must be 256, Cin' = Cin); 1: data-gradient pack (Cin must be 256, Cin' = Cout, taps flipped).
+ * dreg_conv3_halo: out[b,v,:] = bias + addend + sum_d in[b, v - 1 + d, :] . W[:, d, :]; in [B,D,H,W,Cin] bf16, out [B,D,H,W,256] bf16
+ *   (fp32 when out_f32), addend [B,Da,Ha,Wa,256] of out's dtype added with nearest x2 upsampling (add_same = 0) or element-wise (1). */
+int dreg_conv3_halo_supported(int B, int D, int H, int W, int Cin, int Cout);
+size_t dreg_conv3_halo_pack_bytes(int Cin_reduced);
+int dreg_pack_conv_weight_halo(const float* w, void* out, int Cout, int Cin, int transposed, void* stream);
+int dreg_conv3_halo(const void* in, const void* wpk, void* out, const float* bias, const void* addend,
+                    int B, int D, int H, int W, int Cin, int Da, int Ha, int Wa, int add_same, int out_f32, void* stream);
+/* experiments (tools/bench_conv_halo.py): 0 = anti-phase wave groups, weights 2 units ahead (default); 1 = lockstep; 2 = 3 units ahead */
+void dreg_conv3_halo_set_variant(int variant);
+
 /* 1 (default): bf16 stride-1 convolutions stage operands with buffer_load...lds; 0: register-staged kernel (A/B checks) */
 void dreg_conv_set_glds(int enable);
 int dreg_conv_get_glds(void);
