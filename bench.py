@@ -40,39 +40,144 @@ def parse():
     ap.add_argument("--kernel-report", default="", help="write the per-kernel/per-shape event timing table here")
     ap.add_argument("--no-dense-reference", action="store_true", help="skip the additional dense-head measurement")
     ap.add_argument("--dense-head", action="store_true", help="evaluate the FPN head densely (BASELINE.md FLOP accounting) instead of on the active set")
+    ap.add_argument("--cpu-samples", type=int, default=3, help="timed samples of the CPU baseline (after one warm-up)")
+    ap.add_argument("--occupancy-sweep", action="store_true", help="also time the step on shells of 1e4 .. 1e5 occupied voxels per side (active-set head)")
+    ap.add_argument("--ngp", action="store_true", help="BASELINE.json configs[3] instead: NGP grid extraction of 128^3 NeRF blocks (dense hash-MLP query)")
+    ap.add_argument("--ngp-radius", type=float, default=1.0, help="--ngp: occupied cells = ball of this radius in the [-1.5,1.5]^3 block")
     return ap.parse_args()
 
 
-def cpu_baseline(res: int, target_res: int):
+def cpu_baseline(res: int, target_res: int, samples: int = 3):
     """Oracle (kind 'port': CPU restatement pinned to the reference by tests/golden) fwd+bwd of ONE pair at `res`,
-    train mode, fp32, all host cores.  Converted to pairs/s at `target_res` by the conv FLOP ratio (res^3)."""
+    train mode, fp32, all host cores: one warm-up, then `samples` timed runs (median reported, all listed).
+    Converted to pairs/s at `target_res` by the conv FLOP ratio (res^3) when the sample resolution is smaller."""
     from dreg_nerf_amd import params, synth
     from oracle import regtr_oracle as O
     cores = min(os.cpu_count() or 1, 16)  # more threads than this slow torch's CPU conv3d down at batch 1
     torch.set_num_threads(cores)
-    sd = params.synth_state_dict(0)
-    for k, (shape, kind) in params.regtr_spec().items():
-        if not params.is_buffer(kind) and not k.startswith(params.ALIAS_DST):
-            sd[k].requires_grad_(True)
     data = synth.shell_pair(res, 1, 2, pose=synth.fixed_pose())
     W = 0.1 * torch.randn(256, 256, generator=torch.Generator().manual_seed(5))
-    t0 = time.time()
-    pred = O.regtr_forward(sd, data, train=True)
-    s_kp, t_kp = pred["src_kp"][0], pred["tgt_kp"][0]
-    s_gt, t_gt = synth.synthetic_overlap_gt(s_kp), synth.synthetic_overlap_gt(t_kp)
-    with torch.no_grad():
-        s_tl = torch.stack([synth.synthetic_overlap_gt(pred["src_kp_warped"][0][l], 1)[0] for l in range(6)])
-        t_tl = torch.stack([synth.synthetic_overlap_gt(pred["tgt_kp_warped"][0][l], 1)[0] for l in range(6)])
-    losses = O.training_losses(pred, data["pose"], W, s_gt, t_gt, s_tl, t_tl)
-    losses["total"].backward()
-    dt = time.time() - t0
+
+    def one():
+        sd = params.synth_state_dict(0)
+        for k, (shape, kind) in params.regtr_spec().items():
+            if not params.is_buffer(kind) and not k.startswith(params.ALIAS_DST):
+                sd[k].requires_grad_(True)
+        t0 = time.time()
+        pred = O.regtr_forward(sd, data, train=True)
+        s_kp, t_kp = pred["src_kp"][0], pred["tgt_kp"][0]
+        s_gt, t_gt = synth.synthetic_overlap_gt(s_kp), synth.synthetic_overlap_gt(t_kp)
+        with torch.no_grad():
+            s_tl = torch.stack([synth.synthetic_overlap_gt(pred["src_kp_warped"][0][l], 1)[0] for l in range(6)])
+            t_tl = torch.stack([synth.synthetic_overlap_gt(pred["tgt_kp_warped"][0][l], 1)[0] for l in range(6)])
+        losses = O.training_losses(pred, data["pose"], W, s_gt, t_gt, s_tl, t_tl)
+        losses["total"].backward()
+        return time.time() - t0
+
+    warm = one()
+    ts = sorted(one() for _ in range(max(samples, 1)))
+    dt = ts[len(ts) // 2]
     scale = (target_res / res) ** 3
     return {
         "value": 1.0 / (dt * scale), "unit": "pairs/s", "cores": cores, "kind": "port",
-        "sample": f"oracle (PyTorch-CPU fp32 restatement) fwd+bwd of 1 shell-R pair at {res}^3 in {dt:.1f}s, "
-                  f"scaled x{scale:.0f} (conv FLOPs ~ res^3) to {target_res}^3",
-        "measured_seconds": dt,
+        "sample": f"oracle (PyTorch-CPU fp32 restatement of the reference) fwd+bwd of 1 shell-R pair at {res}^3: warm-up {warm:.1f}s, then "
+                  f"{len(ts)} timed runs, median {dt:.1f}s" + (f", scaled x{scale:.0f} (conv FLOPs ~ res^3) to {target_res}^3" if scale != 1 else ""),
+        "measured_seconds": ts,
     }
+
+
+def kernel_source_sha():
+    """sha256 over the HIP sources: PMC traffic numbers are only valid for the kernels they were collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "dreg_nerf_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def ngp_bench(args, rank, world, dev):
+    """BASELINE.json configs[3]: one 128^3 NeRF block = Np occupied cells -> world samples -> density (hash grid + MLP) -> colour x 18
+    directions -> alpha / masks -> voxel_grid + voxel_mask (eval_ngp_nerf.py:336-412 without the surface ray march, which needs the
+    block's training cameras).  Every rank extracts its own blocks (replicas only, no collective).  A "step" = one block."""
+    from dreg_nerf_amd import ngp
+    res = 128
+    aabb = [-1.5] * 3 + [1.5] * 3
+    g = torch.Generator().manual_seed(100 + rank)
+    f = ngp.NGPradianceField(aabb)
+    with torch.no_grad():   # generated weights (no checkpoints without network access): tcnn's default-ish scales
+        f.mlp_base.params[:3072] = torch.randn(3072, generator=g) * 0.4
+        f.mlp_base.params[3072:] = torch.randn(f.mlp_base.params.numel() - 3072, generator=g)
+        f.color_mlp.params.copy_(torch.randn(7168, generator=g) * 0.2)
+    f = f.to(dev)
+    c = (torch.arange(res, dtype=torch.float32) + 0.5) / res * 3 - 1.5
+    X, Y, Z = torch.meshgrid(c, c, c, indexing="ij")
+    binary = (torch.stack([X, Y, Z], -1).norm(dim=-1) < args.ngp_radius).to(dev)
+    sg = ngp.SampleGrid(aabb, res).to(dev)
+    sg.set_binary_fields(binary)
+    npts = int(binary.sum())
+    jitter = torch.rand(npts, 3, generator=g).to(dev)
+    dirs = sg._viewdirs.to(dev)
+
+    def block():
+        w, rgb, a, idx, dm = sg.query_dense(f, dev, jitter=jitter)
+        return ngp.build_voxel_grid(w, rgb, a, idx, dm, res)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        block()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        block()
+    sync()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    if rank != 0:
+        return
+    # per-kernel times (events on the launch stream = torch's current stream), same inputs
+    world_pts = sg.query_dense(f, dev, jitter=jitter)[0]
+
+    def ev_time(fn, n=5):
+        fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(n):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / n
+
+    ms_d = ev_time(lambda: f.query_raw(world_pts))
+    raw = f.query_raw(world_pts)[1]
+    ms_c = ev_time(lambda: f.query_rgb_mean(raw, dirs))
+    fl_c = npts * (18 * (64 * 64 + 16 * 64) + 64 * 32) * 2.0        # colour net x 18 directions (geometry half of layer 1 once)
+    fl_d = npts * 3072 * 2.0
+    gather = npts * 512.0                                             # 16 levels x 8 corners x 2 fp16
+    rf = {"bound": "mfma", "kernel": "ngp_rgb_kernel", "achieved": fl_c / ms_c / 1e9, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+          "frac": fl_c / ms_c / 1e9 / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms_c, "algorithmic_flops_per_launch": fl_c,
+          "note": "fp16 MFMA (same dense peak as bf16); HIP events on the launch stream, 5 launches",
+          "density_kernel": {"kernel": "ngp_density_kernel", "avg_launch_ms": ms_d, "Gpts_per_s": npts / ms_d / 1e6,
+                             "gather_TBps": gather / ms_d / 1e9, "gather_frac_of_hbm_peak": gather / ms_d / 1e9 / (HBM_PEAK_GBPS / 1e3),
+                             "mlp_TFLOPs": fl_d / ms_d / 1e9,
+                             "note": "512 B gathered per point from the 25.2 MB fp16 table (Infinity-Cache resident, so above-HBM rates are possible)"}}
+    print(json.dumps({
+        "metric": "ngp_grid_extraction_blocks_per_sec_128", "value": args.steps * world / el, "unit": "blocks/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"NGP occupancy-grid extraction, one 128^3 block per step: {npts} occupied cells (ball r={args.ngp_radius}) -> density + "
+                               f"18-direction colour + voxel_grid writer; generated hash-grid / MLP weights", "points_per_block": npts,
+                   "parallelism": f"replicas x{world}"},
+        "points_per_sec": npts * args.steps * world / el, "roofline": rf}), flush=True)
 
 
 def main():
@@ -87,6 +192,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    if args.ngp:
+        ngp_bench(args, rank, world, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from dreg_nerf_amd import ops, synth
     from dreg_nerf_amd.regtr import NeRFRegTr
@@ -151,19 +263,27 @@ def main():
     def pmc_traffic(name, head):
         """HBM bytes per launch of kernel `name` from the committed rocprofv3 PMC passes (tools/collect_pmc.sh: separate
         FETCH_SIZE / WRITE_SIZE runs of this bench at this workload, --pmc with --kernel-trace only).  Both counters are in KB;
-        FETCH_SIZE is doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 bytes: MI355X_MICROARCH.md, HBM)."""
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_j_pmc_hbm_per_launch.json")
+        FETCH_SIZE is doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 bytes: MI355X_MICROARCH.md, HBM).
+        The file records the sha of the kernel sources it was collected on: a stale file yields no traffic figure."""
+        path = os.path.join(ROOT, "profiles", "pmc_hbm_per_launch.json")
         if args.res != 128 or args.pairs != 4 or args.precision != "bf16" or not os.path.exists(path):
             return None, None
+        db = json.load(open(path))
+        if db.get("kernel_source_sha") != kernel_source_sha():
+            return None, f"profiles/pmc_hbm_per_launch.json is stale (collected on kernel sources {db.get('kernel_source_sha')}, now {kernel_source_sha()}): re-run tools/collect_pmc.sh"
         norm = lambda k: k.replace("void ", "").split("(")[0].replace("unsigned short", "bf16").replace("float", "f32").replace(" ", "")
-        for k, e in json.load(open(path)).get(head, {}).items():
-            if norm(k) == name.replace(" ", "") and "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+        want = name.replace(" ", "")
+        for k, e in db.get(head, {}).items():
+            kn = norm(k)
+            if (kn == want or kn.startswith(want.rstrip(">") + ",")) and "FETCH_SIZE" in e and "WRITE_SIZE" in e:
                 return (2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0, \
-                    f"profiles/r01_j_pmc_hbm_per_launch.json [{head}]: 2 x FETCH_SIZE + WRITE_SIZE, mean of {e['launches_FETCH_SIZE']} launches"
+                    f"profiles/pmc_hbm_per_launch.json [{head}] {k.split('(')[0][:80]}: 2 x FETCH_SIZE + WRITE_SIZE, mean of {e['launches_FETCH_SIZE']} launches"
         return None, None
 
     def roofline_of(pr, head):
-        by_name, by_label = pr.summary()
+        # HIP-event brackets as measured: nothing is subtracted (an empty bracket reads ~6 us, but with a kernel inside the events add
+        # ~2 us to its duration: the round-1 subtraction over-corrected and put `frac` above what profiles/'s rocprofv3 CSV gives)
+        by_name, by_label = pr.summary(subtract_overhead=False)
         # the dominant SINGLE kernel: "...+reduce" entries bracket two launches (weight gradient + its split reduce) and have no
         # one rocprofv3 row to be checked against; they stay in the --kernel-report table
         single = {k: v for k, v in by_name.items() if "+" not in k}
@@ -173,12 +293,13 @@ def main():
         gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         rf = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
               "launches": calls, "avg_launch_ms": ms / max(calls, 1), "algorithmic_flops_per_launch": flops / max(calls, 1),
-              "event_steps": min(args.event_steps, args.steps), "empty_bracket_ms_subtracted": pr.bracket_overhead_ms(),
+              "event_steps": min(args.event_steps, args.steps), "empty_bracket_ms_not_subtracted": pr.bracket_overhead_ms(),
               # the same launches against the other roof: compulsory bytes (inputs, weights, outputs once) / time vs 8 TB/s
               "compulsory_bytes_per_launch": nbytes / max(calls, 1), "hbm_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBPS}
         rf["traffic"], src = pmc_traffic(name, head)
         if src:
             rf["traffic_source"] = src
+        if rf["traffic"]:
             rf["traffic_over_compulsory"] = rf["traffic"] / max(rf["compulsory_bytes_per_launch"], 1.0)
         if rf["hbm_frac"] > rf["frac"]:   # a family of small / 1x1x1 convolutions sits closer to the HBM roof than to the MFMA roof
             rf.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBPS,
@@ -194,6 +315,32 @@ def main():
             dense = {"value": args.pairs * world * args.steps / el_d, "unit": "pairs/s", "ms_per_step": 1e3 * el_d / args.steps, "roofline": rf_d}
     elapsed, prof = timed(not args.dense_head and args.precision == "bf16")
 
+    # the active-set head's work follows the occupied surface: the same step on shells of 1e4 .. 1e5 occupied voxels per side
+    sweep = None
+    if args.occupancy_sweep and world == 1 and args.precision == "bf16":
+        sweep = []
+        for r1 in (0.815, 0.83, 0.86, 0.90, 0.96):
+            b2 = []
+            for i in range(args.pairs):
+                sd_ = 1 + 2 * i
+                gs, ms_ = synth.shell_grid(args.res, sd_, 0.8, r1)
+                gt, mt_ = synth.shell_grid(args.res, sd_ + 1, 0.8, r1, pose=pose)
+                b2.append({"src_xyz_rgba": gs.permute(3, 2, 0, 1).unsqueeze(0).contiguous().to(dev), "tgt_xyz_rgba": gt.permute(3, 2, 0, 1).unsqueeze(0).contiguous().to(dev),
+                           "src_mask": ms_.to(dev), "tgt_mask": mt_.to(dev), "pose": pose[None].clone().to(dev), "src_nerf_path": "", "tgt_nerf_path": ""})
+            model.active_set = True
+            for _ in range(2):
+                ts.step(b2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                ts.step(b2)
+            torch.cuda.synchronize()
+            el_ = (time.perf_counter() - t0) / 4
+            rc = []
+            for ex in model.__dict__.get("_trunk_cache", {}).values():
+                rc = list(ex.last_row_counts)
+            sweep.append({"shell_r1": r1, "n_mask_per_side": int(b2[0]["src_mask"].shape[0]), "pairs_per_s": args.pairs / el_, "ms_per_step": 1e3 * el_,
+                          "active_rows": rc, "head": "active-set" if rc else "dense fallback"})
     if rank == 0:
         roofline, by_label = roofline_of(prof, "dense_head" if args.dense_head else "active_set")
         if args.kernel_report:
@@ -216,9 +363,11 @@ def main():
         }
         if dense is not None:
             out["dense_head"] = dense
+        if sweep is not None:
+            out["occupancy_sweep"] = sweep
         if world == 1 and not args.no_cpu_baseline:
             cres = args.cpu_res or (128 if (os.cpu_count() or 1) >= 32 else 64)
-            out["cpu_baseline"] = cpu_baseline(min(cres, args.res), args.res)
+            out["cpu_baseline"] = cpu_baseline(min(cres, args.res), args.res, args.cpu_samples)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

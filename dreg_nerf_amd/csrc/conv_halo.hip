@@ -16,19 +16,20 @@
 // then they swap (the guide's 8-phase idea with a unit as the phase).  Counted vmcnt only: the weight ring is RING units deep,
 // a unit is issued AHEAD units before it is read, waited for one unit before it is read and never drained.
 //
-// LDS (143,360 B): two halo buffers of 38 KiB (chunk parity) | weight ring 4 x 16 KiB (re-used by the epilogue as the fp32
+// LDS (147,456 B): two halo buffers of 40 KiB (chunk parity) | weight ring 4 x 16 KiB (re-used by the epilogue as the fp32
 // staging tile).  Both images are written lane-linearly by the DMA, the 16-byte-slot XOR swizzles sit on the SOURCE address:
 //   halo voxel hv = (hz*10 + hy)*10 + hx, 64 B each: slot s of voxel hv holds channel granule s ^ (hy & 3)
 //   weight row co (64 B):                               slot s holds granule s ^ ((co >> 2) & 3)
 // which makes every ds_read_b128 of a 32-row MFMA fragment conflict free for all 27 window shifts (tools/lds_conflicts.py).
 #include "common.h"
+#include <utility>
 
 namespace halo {
 constexpr int TZ = 4, TY = 8, TX = 8;
 constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2, HVOX = HZ * HY * HX;   // 600
 constexpr int CK = 32;                                  // channels per unit
-constexpr int HPIECES = (HVOX + 15) / 16;               // 38 DMA pieces of 16 voxels x 64 B
-constexpr int HBUF = HPIECES * 1024;                    // 38,912 B
+constexpr int HPW = 5;                                  // DMA pieces of 16 voxels x 64 B per wave: 40 >= ceil(600 / 16) = 38
+constexpr int HBUF = 8 * HPW * 1024;                    // 40,960 B
 constexpr int UNIT = 256 * CK * 2;                      // 16,384 B of weights per (chunk, tap)
 constexpr uint32_t OOB = 0x7fffff00u;                   // out-of-range buffer offset: the DMA writes zeros
 }
@@ -47,29 +48,23 @@ __device__ __forceinline__ uint32_t halo_xcd_remap(uint32_t bid, uint32_t nblk) 
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void wait_vmcnt_n(int n) {
-    switch (n) {
-        case 0: wait_vmcnt<0>(); break;
-        case 1: wait_vmcnt<1>(); break;
-        case 2: wait_vmcnt<2>(); break;
-        case 3: wait_vmcnt<3>(); break;
-        case 4: wait_vmcnt<4>(); break;
-        case 5: wait_vmcnt<5>(); break;
-        default: wait_vmcnt<6>(); break;
-    }
-}
+template <int... I, typename F> __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
 #define HALO_DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
 
+// The 27 taps of a chunk are unrolled: every LDS offset, the halo-issue slot and every vmcnt count is an immediate and the load half
+// is straight-line code (a first version looped over the units with scalar branches for the tap coordinates, the piece selection and
+// the wait count: ~300 of its ~1,000 load-half cycles per unit were control flow).
 // ABL (timing experiments only, wrong results): 1 = no DMA inside the loop, 2 = no fragment reads, 4 = no MFMAs
-template <typename TO, int AHEAD, int RING, bool STAGGER, int ABL = 0, bool SPLITDS = true>
+template <typename TO, bool STAGGER, int ABL = 0, bool SPLITDS = true, bool PROF = false>
 __global__ __launch_bounds__(512) void conv3_halo_kernel(
     const bf16_t* __restrict__ in, const bf16_t* __restrict__ wpk, TO* __restrict__ out,
-    const float* __restrict__ bias, const TO* __restrict__ addend, HaloGeom g, uint32_t in_bytes, uint32_t wt_bytes)
+    const float* __restrict__ bias, const TO* __restrict__ addend, HaloGeom g, uint32_t in_bytes, uint32_t wt_bytes,
+    unsigned long long* __restrict__ prof = nullptr)
 {
     using namespace halo;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    static_assert(RING >= AHEAD + 2 && AHEAD >= 2 && AHEAD <= 3, "a unit may be overwritten two units after it was read (anti-phase groups)");
+    constexpr int AHEAD = 2, RING = 4;       // unit u+AHEAD is issued in the load half of unit u into the slot unit u-2 was read from
     constexpr int RING_OFF = 2 * HBUF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -87,11 +82,11 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, wt_bytes, 0x00020000);
 
-    // ---- halo staging roles: this wave moves pieces wave, wave+8, ... (16 halo voxels each; lane -> voxel lane>>2, slot lane&3)
-    uint32_t hoff[5];
-    const int npw = (HPIECES - wave + 7) >> 3;            // 5 pieces for waves 0..5, 4 for waves 6, 7
+    // ---- halo staging roles: this wave moves pieces wave, wave+8, ..., wave+32 (16 halo voxels each; lane -> voxel lane>>2, slot
+    // lane&3); pieces 38, 39 and the voxels past 600 exist only as zero-filled padding of the buffer
+    uint32_t hoff[HPW];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < HPW; ++j) {
         const int hv = (wave + 8 * j) * 16 + (lane >> 2);
         const int hz = hv / (HY * HX), r2 = hv - hz * (HY * HX), hy = r2 / HX, hx = r2 - hy * HX;
         const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
@@ -99,14 +94,18 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(
         const uint32_t vox = (uint32_t)(((b * g.D + gz) * g.H + gy) * g.W + gx);
         hoff[j] = v ? vox * (uint32_t)(g.Cin * 2) + (uint32_t)((((lane & 3) ^ (hy & 3))) << 4) : OOB;
     }
-    // ---- weight staging role: pieces 2*wave, 2*wave+1 of every unit (rows 32*wave .. +31); lane -> row lane>>2, slot lane&3
-    const uint32_t wlane = (uint32_t)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+    // ---- weight staging role: pieces 2*wave, 2*wave+1 of every unit (rows 32*wave .. +31); lane -> row lane>>2, slot lane&3.
+    // The unit's byte offset goes into the VGPR offset (the buffer bounds check covers it: units past the pack read as zeros).
+    const uint32_t wlane = (uint32_t)(wave * 2048 + (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
 
     // ---- fragment read roles (32x32x16: lane -> row lane&31, k-half lane>>5)
     const int fr = lane & 31, fq = lane >> 5;
     const int fx = fr & 7, fy = fr >> 3;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const uint32_t a_lane = lds0 + (uint32_t)((((2 * wm) * HY + fy) * HX + fx) * 64);
+    uint32_t a_sw[3];                                     // per dy: lane base + swizzled slot of k-half 0 (k-half 1: ^ 32)
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) a_sw[dy] = (uint32_t)((fq ^ ((fy + dy) & 3)) << 4);
     const uint32_t b_sw0 = (uint32_t)((fq ^ ((fr >> 2) & 3)) << 4);
     const uint32_t b_lane0 = lds0 + RING_OFF + (uint32_t)((wn * 64 + fr) * 64) + b_sw0;
     const uint32_t b_lane1 = lds0 + RING_OFF + (uint32_t)((wn * 64 + fr) * 64) + (b_sw0 ^ 32u);
@@ -119,106 +118,128 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int U = g.nchunks * 27;
-    auto issue_halo = [&](int chunk, int j) {
-        const uint32_t vo = j == 0 ? hoff[0] : j == 1 ? hoff[1] : j == 2 ? hoff[2] : j == 3 ? hoff[3] : hoff[4];
-        char* dst = smem + (chunk & 1) * HBUF + (wave + 8 * j) * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)dst, 16, (int)vo, chunk * (CK * 2), 0, 0);
+    auto issue_halo = [&](int chunk, bool real) {
+        char* dst = smem + (chunk & 1) * HBUF + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < HPW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(dst + j * 8192), 16, (int)(real ? hoff[j] : OOB), chunk * (CK * 2), 0, 0);
     };
-    auto issue_unit = [&](int u) {
-        char* dst = smem + RING_OFF + (u % RING) * UNIT + wave * 2048;
-        const int so = u * UNIT + wave * 2048;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, (lds_ptr_t)dst, 16, (int)wlane, so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, (lds_ptr_t)(dst + 1024), 16, (int)wlane, so + 1024, 0, 0);
+    auto issue_unit = [&](int ring_w, int src_off) {       // ring_w: byte offset of the destination slot, src_off: byte offset of the unit
+        char* dst = smem + RING_OFF + ring_w + wave * 2048;
+        const int vo = (int)(wlane + (uint32_t)src_off);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, (lds_ptr_t)dst, 16, vo, 0, 0, 0);
+        // the instruction offset of an LDS-DMA load is added to the memory address AND to the LDS address (M0 base + offset + 16 * lane)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, (lds_ptr_t)dst, 16, vo, 0, 1024, 0);
     };
 
-    // ---- prologue: halo of chunk 0, units 0 .. AHEAD-1
-    for (int j = 0; j < npw; ++j) issue_halo(0, j);
-#pragma unroll
-    for (int u = 0; u < AHEAD; ++u)
-        if (u < U) issue_unit(u);
-    // unit 0 and the halo have landed for this wave once at most 2*(AHEAD-1) younger pieces are outstanding
-    wait_vmcnt_n(2 * (min(AHEAD, U) - 1));
+    // ---- prologue: halo of chunk 0, units 0 and 1; unit 0 and the halo have landed for this wave once only unit 1 is outstanding
+    issue_halo(0, true);
+    issue_unit(0, 0);
+    issue_unit(UNIT, UNIT);
+    wait_vmcnt<2>();
     __builtin_amdgcn_s_barrier();
     if (STAGGER && wm == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one barrier behind group 0
 
-    int nh_prev = 0;                                             // halo pieces this wave issued in the previous unit's load half
-    int c = 0, tap = 0, dz = 0, dy = 0, dx = 0;
-    for (int u = 0; u < U; ++u) {
-        // ================= load half: fragments of unit u (k-half 0; SPLITDS: k-half 1 follows inside the compute half), direct-to-LDS
-        // pieces of later units (issued HERE, under the other group's MFMAs: between this wave's own MFMAs each piece stalls its
-        // in-order instruction stream for ~100 cycles and the matrix pipe runs dry — measured 6 % slower)
-        const uint32_t sw0 = (uint32_t)((fq ^ ((fy + dy) & 3)) << 4);
-        const uint32_t s_a = (uint32_t)((c & 1) * HBUF + ((dz * HY + dy) * HX + dx) * 64);
-        const uint32_t aA0 = a_lane + s_a + sw0, aA1 = a_lane + s_a + (sw0 ^ 32u);
-        const uint32_t s_b = (uint32_t)((u % RING) * UNIT);
-        const uint32_t aB0 = b_lane0 + s_b, aB1 = b_lane1 + s_b;
-        i32x4_t a00, a01, a10, a11, a20, a21, a30, a31, b00, b01, b10, b11;   // [tile][k-half]
-        if (!(ABL & 2)) {
-            HALO_DSR(b00, aB0, 0);    HALO_DSR(b10, aB0, 2048);
-            HALO_DSR(a00, aA0, 0);    HALO_DSR(a10, aA0, 2560);  HALO_DSR(a20, aA0, 6400);  HALO_DSR(a30, aA0, 8960);
-            if (!SPLITDS) {
-                HALO_DSR(b01, aB1, 0);    HALO_DSR(b11, aB1, 2048);
-                HALO_DSR(a01, aA1, 0);    HALO_DSR(a11, aA1, 2560);  HALO_DSR(a21, aA1, 6400);  HALO_DSR(a31, aA1, 8960);
+    unsigned long long pt[5] = {0, 0, 0, 0, 0}, tprev = 0;     // PROF: shader-clock sums per wave (tools/bench_conv_halo.py --prof)
+    auto stamp = [&](int k) {
+        if constexpr (PROF) {
+            unsigned long long tnow;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow) :: "memory");
+            if (k >= 0) pt[k] += tnow - tprev;
+            tprev = tnow;
+        }
+    };
+    stamp(-1);
+
+    int ring_r = 0;                       // slot (byte offset) unit u is read from; unit u+2 goes to ring_r + 2 slots
+    int src_off = 2 * UNIT;               // byte offset of unit u+2 in the pack
+#pragma unroll 1
+    for (int c = 0; c < g.nchunks; ++c) {
+        const uint32_t hbase = (uint32_t)((c & 1) * HBUF);
+        const bool next_real = c + 1 < g.nchunks;
+        static_for(std::make_integer_sequence<int, 27>{}, [&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+            constexpr int dz = T / 9, dy = (T / 3) % 3, dx = T % 3;
+            constexpr int OA = ((dz * HY + dy) * HX + dx) * 64;           // window shift of this tap inside the halo
+            // ================= load half: fragments of unit u (k-half 0; SPLITDS: k-half 1 rides in the compute half), then the
+            // direct-to-LDS pieces of unit u+2 — issued HERE, under the other group's MFMAs (between this wave's own MFMAs each piece
+            // stalls its in-order instruction stream for ~100 cycles and the matrix pipe runs dry: measured 6 % slower)
+            const uint32_t aA0 = a_lane + hbase + a_sw[dy], aA1 = a_lane + hbase + (a_sw[dy] ^ 32u);
+            const uint32_t aB0 = b_lane0 + (uint32_t)ring_r, aB1 = b_lane1 + (uint32_t)ring_r;
+            i32x4_t a00, a01, a10, a11, a20, a21, a30, a31, b00, b01, b10, b11;   // [tile][k-half]
+            if (!(ABL & 2)) {
+                HALO_DSR(b00, aB0, 0);         HALO_DSR(b10, aB0, 2048);
+                HALO_DSR(a00, aA0, OA);        HALO_DSR(a10, aA0, OA + 2560);  HALO_DSR(a20, aA0, OA + 6400);  HALO_DSR(a30, aA0, OA + 8960);
+                if (!SPLITDS) {
+                    HALO_DSR(b01, aB1, 0);     HALO_DSR(b11, aB1, 2048);
+                    HALO_DSR(a01, aA1, OA);    HALO_DSR(a11, aA1, OA + 2560);  HALO_DSR(a21, aA1, OA + 6400);  HALO_DSR(a31, aA1, OA + 8960);
+                }
+            } else {
+                asm volatile("" : "=v"(a00), "=v"(a01), "=v"(a10), "=v"(a11), "=v"(a20), "=v"(a21), "=v"(a30), "=v"(a31), "=v"(b00), "=v"(b01), "=v"(b10), "=v"(b11)
+                             : "v"(aA0), "v"(aA1), "v"(aB0), "v"(aB1));
             }
-        } else {
-            asm volatile("" : "=v"(a00), "=v"(a01), "=v"(a10), "=v"(a11), "=v"(a20), "=v"(a21), "=v"(a30), "=v"(a31), "=v"(b00), "=v"(b01), "=v"(b10), "=v"(b11)
-                         : "v"(aA0), "v"(aA1), "v"(aB0), "v"(aB1));
-        }
-        int nh = 0;
-        if (!(ABL & 1) && tap >= 1 && tap <= npw && c + 1 < g.nchunks) { issue_halo(c + 1, tap - 1); nh = 1; }
-        int nb = 0;
-        if (!(ABL & 1) && u + AHEAD < U) { issue_unit(u + AHEAD); nb = 2; }
-        if (u + 1 < U) {
-            // unit u+1 was issued AHEAD-1 units ago; everything issued after it may stay in flight
-            int n = nh + nb;
-            if (AHEAD >= 3) n += nh_prev + (u + 2 < U ? 2 : 0);
-            wait_vmcnt_n(n);
-        }
-        nh_prev = nh;
-        // next unit's coordinates (scalar work kept out of the compute half)
-        if (++dx == 3) { dx = 0; if (++dy == 3) { dy = 0; ++dz; } }
-        if (++tap == 27) { tap = 0; dz = 0; ++c; }
-        __builtin_amdgcn_s_barrier();
-        if (SPLITDS && !(ABL & 2))
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a00), "+v"(a10), "+v"(a20), "+v"(a30), "+v"(b00), "+v"(b10));
-        else
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11), "+v"(a20), "+v"(a21), "+v"(a30), "+v"(a31),
-                           "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11));
-        __builtin_amdgcn_sched_barrier(0);
-        // ================= compute half
-        __builtin_amdgcn_s_setprio(1);
+            // vmcnt retires loads IN ORDER, so a wait for a weight unit also waits for every older piece.  The halo pieces of the next
+            // chunk are mostly HBM misses; issued AFTER this half's weight pieces (tap 1: the other halo buffer's last reader finished
+            // a barrier ago) they are only older than the units issued from the next load half on, i.e. they have two units to land
+            // (and in the last chunk they are turned into zero fills so that the counts below stay constants).
+            if (!(ABL & 1)) {
+                issue_unit((ring_r + 2 * UNIT) & (RING * UNIT - 1), src_off);
+                if (T == 1) issue_halo(c + 1, next_real);
+            }
+            if (PROF) stamp(0);
+            // unit u+1 (issued one load half ago) has landed for this wave when only the pieces issued after it are outstanding
+            if (!(ABL & 1)) wait_vmcnt<2 + (T == 1 ? HPW : 0) + (T == 2 ? HPW : 0)>();
+            if (PROF) stamp(1);
+            ring_r = (ring_r + UNIT) & (RING * UNIT - 1);
+            src_off += UNIT;
+            __builtin_amdgcn_s_barrier();
+            if (SPLITDS && !(ABL & 2))
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a00), "+v"(a10), "+v"(a20), "+v"(a30), "+v"(b00), "+v"(b10));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11), "+v"(a20), "+v"(a21), "+v"(a30), "+v"(a31),
+                               "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11));
+            __builtin_amdgcn_sched_barrier(0);
+            if (PROF) stamp(2);
+            // ================= compute half
+            __builtin_amdgcn_s_setprio(1);
 #define HALO_MM(i, j, A, Bv) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A), __builtin_bit_cast(bf16x8_t, Bv), acc[i][j], 0, 0, 0)
 #define HALO_SB() __builtin_amdgcn_sched_barrier(0)
-        if (ABL & 4) {
-            asm volatile("" :: "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(a20), "v"(a21), "v"(a30), "v"(a31), "v"(b00), "v"(b01), "v"(b10), "v"(b11));
-        } else if (SPLITDS && !(ABL & 2)) {
-            // the second k-half's six fragment reads ride in the issue gaps of the first eight MFMAs (an MFMA occupies the matrix
-            // pipe for 32 cycles, a ds_read_b128 the wave's issue slot for a few)
-            HALO_MM(0, 0, a00, b00); HALO_SB(); HALO_DSR(b01, aB1, 0);    HALO_SB();
-            HALO_MM(1, 0, a10, b00); HALO_SB(); HALO_DSR(b11, aB1, 2048); HALO_SB();
-            HALO_MM(2, 0, a20, b00); HALO_SB(); HALO_DSR(a01, aA1, 0);    HALO_SB();
-            HALO_MM(3, 0, a30, b00); HALO_SB(); HALO_DSR(a11, aA1, 2560); HALO_SB();
-            HALO_MM(0, 1, a00, b10); HALO_SB(); HALO_DSR(a21, aA1, 6400); HALO_SB();
-            HALO_MM(1, 1, a10, b10); HALO_SB(); HALO_DSR(a31, aA1, 8960); HALO_SB();
-            HALO_MM(2, 1, a20, b10); HALO_MM(3, 1, a30, b10);
-            HALO_SB();
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a01), "+v"(a11), "+v"(a21), "+v"(a31), "+v"(b01), "+v"(b11));
-            HALO_SB();
-            HALO_MM(0, 0, a01, b01); HALO_MM(1, 0, a11, b01); HALO_MM(2, 0, a21, b01); HALO_MM(3, 0, a31, b01);
-            HALO_MM(0, 1, a01, b11); HALO_MM(1, 1, a11, b11); HALO_MM(2, 1, a21, b11); HALO_MM(3, 1, a31, b11);
-        } else {
-            HALO_MM(0, 0, a00, b00); HALO_MM(1, 0, a10, b00); HALO_MM(2, 0, a20, b00); HALO_MM(3, 0, a30, b00);
-            HALO_MM(0, 1, a00, b10); HALO_MM(1, 1, a10, b10); HALO_MM(2, 1, a20, b10); HALO_MM(3, 1, a30, b10);
-            HALO_MM(0, 0, a01, b01); HALO_MM(1, 0, a11, b01); HALO_MM(2, 0, a21, b01); HALO_MM(3, 0, a31, b01);
-            HALO_MM(0, 1, a01, b11); HALO_MM(1, 1, a11, b11); HALO_MM(2, 1, a21, b11); HALO_MM(3, 1, a31, b11);
-        }
+            if (ABL & 4) {
+                asm volatile("" :: "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(a20), "v"(a21), "v"(a30), "v"(a31), "v"(b00), "v"(b01), "v"(b10), "v"(b11));
+            } else if (SPLITDS && !(ABL & 2)) {
+                // the second k-half's six fragment reads ride in the issue gaps of the first eight MFMAs (an MFMA occupies the matrix
+                // pipe for 32 cycles, a ds_read_b128 the wave's issue slot for a few)
+                HALO_MM(0, 0, a00, b00); HALO_SB(); HALO_DSR(b01, aB1, 0);         HALO_SB();
+                HALO_MM(1, 0, a10, b00); HALO_SB(); HALO_DSR(b11, aB1, 2048);      HALO_SB();
+                HALO_MM(2, 0, a20, b00); HALO_SB(); HALO_DSR(a01, aA1, OA);        HALO_SB();
+                HALO_MM(3, 0, a30, b00); HALO_SB(); HALO_DSR(a11, aA1, OA + 2560); HALO_SB();
+                HALO_MM(0, 1, a00, b10); HALO_SB(); HALO_DSR(a21, aA1, OA + 6400); HALO_SB();
+                HALO_MM(1, 1, a10, b10); HALO_SB(); HALO_DSR(a31, aA1, OA + 8960); HALO_SB();
+                HALO_MM(2, 1, a20, b10); HALO_MM(3, 1, a30, b10);
+                HALO_SB();
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a01), "+v"(a11), "+v"(a21), "+v"(a31), "+v"(b01), "+v"(b11));
+                HALO_SB();
+                HALO_MM(0, 0, a01, b01); HALO_MM(1, 0, a11, b01); HALO_MM(2, 0, a21, b01); HALO_MM(3, 0, a31, b01);
+                HALO_MM(0, 1, a01, b11); HALO_MM(1, 1, a11, b11); HALO_MM(2, 1, a21, b11); HALO_MM(3, 1, a31, b11);
+            } else {
+                HALO_MM(0, 0, a00, b00); HALO_MM(1, 0, a10, b00); HALO_MM(2, 0, a20, b00); HALO_MM(3, 0, a30, b00);
+                HALO_MM(0, 1, a00, b10); HALO_MM(1, 1, a10, b10); HALO_MM(2, 1, a20, b10); HALO_MM(3, 1, a30, b10);
+                HALO_MM(0, 0, a01, b01); HALO_MM(1, 0, a11, b01); HALO_MM(2, 0, a21, b01); HALO_MM(3, 0, a31, b01);
+                HALO_MM(0, 1, a01, b11); HALO_MM(1, 1, a11, b11); HALO_MM(2, 1, a21, b11); HALO_MM(3, 1, a31, b11);
+            }
 #undef HALO_MM
 #undef HALO_SB
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (PROF) stamp(3);
+            __builtin_amdgcn_s_barrier();
+            if (PROF) stamp(4);
+        });
+    }
+    if constexpr (PROF) {
+        if (prof && blockIdx.x < 64 && lane == 0)
+            for (int k = 0; k < 5; ++k) prof[(blockIdx.x * 8 + wave) * 5 + k] = pt[k];
     }
     if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();      // pairs with group 1's last barrier
     wait_vmcnt<0>();
@@ -303,9 +324,12 @@ __global__ __launch_bounds__(256) void pack_weight_halo_kernel(const float* __re
 
 static int g_halo_variant = 0;   // experiments only (tools/bench_conv_halo.py): 0 = anti-phase groups, weights 2 units ahead / ring 4; 1 = lockstep; 2 = 3 ahead / ring 5; 1x = ablations
 
+static unsigned long long* g_halo_prof = nullptr;
+
 extern "C" {
 
 void dreg_conv3_halo_set_variant(int v) { g_halo_variant = v; }
+void dreg_conv3_halo_set_prof(void* buf) { g_halo_prof = (unsigned long long*)buf; }   // 64 blocks x 8 waves x 5 u64 (variant 5)
 
 // 1 when (shape) is served by the halo kernel: 3^3 / stride 1 / pad 1, 256 output channels, Cin % 32 == 0, volume divisible by the
 // 4 x 8 x 8 box, operands below 2 GiB (32-bit buffer offsets)
@@ -314,6 +338,15 @@ int dreg_conv3_halo_supported(int B, int D, int H, int W, int Cin, int Cout)
     if (Cout != 256 || Cin % 32 != 0 || Cin < 32 || D % halo::TZ || H % halo::TY || W % halo::TX) return 0;
     if ((uint64_t)B * D * H * W * (Cin > 256 ? Cin : 256) * 2 >= 0x7fffff00ull) return 0;
     return 1;
+}
+
+// 1 when a bf16 convolution (ksz, stride, pad; Cin -> Cout over [B,D,H,W]) should run on the halo kernel: supported shape and enough
+// 4 x 8 x 8 boxes to fill the chip (a box keeps a CU busy for ~100 us; small volumes are better served by the split-K implicit GEMM).
+// The decision depends on the per-grid shape only, never on B: a pair's result does not depend on its batch mates.
+int dreg_conv3_halo_use(int B, int D, int H, int W, int Cin, int Cout, int ksz, int stride, int pad)
+{
+    if (ksz != 3 || stride != 1 || pad != 1 || !dreg_conv3_halo_supported(B, D, H, W, Cin, Cout)) return 0;
+    return (D / halo::TZ) * (H / halo::TY) * (W / halo::TX) >= 128;      // >= 32^3 per grid
 }
 
 size_t dreg_conv3_halo_pack_bytes(int Cin_red) { return (size_t)(Cin_red / 32) * 27 * halo::UNIT; }
@@ -344,20 +377,21 @@ int dreg_conv3_halo(const void* in, const void* wpk, void* out, const float* bia
     if (ntiles == 0) return DREG_OK;
     const uint32_t in_bytes = (uint32_t)((uint64_t)B * D * H * W * Cin * 2), wt_bytes = (uint32_t)dreg_conv3_halo_pack_bytes(Cin);
     hipStream_t st = (hipStream_t)stream;
-#define HALO_LAUNCH(TOt, AH, RG, SG, AB, SD) do { \
-        const int lds_ = 2 * HBUF + RG * UNIT; \
-        (void)hipFuncSetAttribute((const void*)conv3_halo_kernel<TOt, AH, RG, SG, AB, SD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); \
-        hipLaunchKernelGGL((conv3_halo_kernel<TOt, AH, RG, SG, AB, SD>), dim3(ntiles), dim3(512), lds_, st, (const bf16_t*)in, (const bf16_t*)wpk, (TOt*)out, \
-                           bias, (const TOt*)addend, g, in_bytes, wt_bytes); } while (0)
-    if (out_f32) HALO_LAUNCH(float, 2, 4, true, 0, true);
-    else if (g_halo_variant == 1) HALO_LAUNCH(bf16_t, 2, 4, false, 0, true);
-    else if (g_halo_variant == 2) HALO_LAUNCH(bf16_t, 3, 5, true, 0, true);
-    else if (g_halo_variant == 3) HALO_LAUNCH(bf16_t, 2, 4, true, 0, false);
-    else if (g_halo_variant == 11) HALO_LAUNCH(bf16_t, 2, 4, true, 1, true);
-    else if (g_halo_variant == 12) HALO_LAUNCH(bf16_t, 2, 4, true, 2, true);
-    else if (g_halo_variant == 13) HALO_LAUNCH(bf16_t, 2, 4, true, 3, true);
-    else if (g_halo_variant == 14) HALO_LAUNCH(bf16_t, 2, 4, true, 4, true);
-    else HALO_LAUNCH(bf16_t, 2, 4, true, 0, true);
+#define HALO_LAUNCH(TOt, SG, AB, SD, PR) do { \
+        const int lds_ = 2 * HBUF + 4 * UNIT; \
+        (void)hipFuncSetAttribute((const void*)conv3_halo_kernel<TOt, SG, AB, SD, PR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); \
+        hipLaunchKernelGGL((conv3_halo_kernel<TOt, SG, AB, SD, PR>), dim3(ntiles), dim3(512), lds_, st, (const bf16_t*)in, (const bf16_t*)wpk, (TOt*)out, \
+                           bias, (const TOt*)addend, g, in_bytes, wt_bytes, g_halo_prof); } while (0)
+    if (out_f32) HALO_LAUNCH(float, true, 0, true, false);
+    else if (g_halo_variant == 1) HALO_LAUNCH(bf16_t, false, 0, true, false);
+    else if (g_halo_variant == 3) HALO_LAUNCH(bf16_t, true, 0, false, false);
+    else if (g_halo_variant == 5) HALO_LAUNCH(bf16_t, true, 0, false, true);
+    else if (g_halo_variant == 11) HALO_LAUNCH(bf16_t, true, 1, true, false);
+    else if (g_halo_variant == 12) HALO_LAUNCH(bf16_t, true, 2, true, false);
+    else if (g_halo_variant == 13) HALO_LAUNCH(bf16_t, true, 3, true, false);
+    else if (g_halo_variant == 14) HALO_LAUNCH(bf16_t, true, 4, true, false);
+    else if (g_halo_variant == 16) HALO_LAUNCH(bf16_t, true, 6, true, false);
+    else HALO_LAUNCH(bf16_t, true, 0, true, false);
 #undef HALO_LAUNCH
     DREG_LAUNCH_CHECK();
     return DREG_OK;

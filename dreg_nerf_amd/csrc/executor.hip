@@ -32,12 +32,15 @@ struct Tensor { int B, D, H, W, C; size_t bytes, off, goff; };
 struct Param {
     float* val; float* grad; int d0, d1, ksz;
     size_t pk_fwd = SIZE_MAX, pk_dgrad = SIZE_MAX, pk_cls = SIZE_MAX;   // offsets in the pack buffer
+    size_t pk_halo_fwd = SIZE_MAX, pk_halo_dgrad = SIZE_MAX;            // halo-kernel packs (conv_halo.hip)
     int cin_pad = 0;
 };
 struct Op {
     int kind, in, out, in2, w, b, p2, p3, p4, ksz, stride, pad, relu, add_same, rows_out, rows_in;
     size_t aux0 = 0, aux1 = 0;   // BN: scale_shift / mean_rstd; max-pool: argmax
+    int halo = 0;                // OP_CONV: bit 0 = forward, bit 1 = data gradient run on the halo kernel
 };
+struct HaloPack { const float* w; size_t off; int Cout, Cin, transposed; };
 struct PackRec { const float* w; void* out; int Cout, Cin_real, inner, ntaps, for_dgrad, Kpad, dtype, row0; };
 static_assert(sizeof(PackRec) == 48, "matches PackDesc of conv.hip");
 
@@ -52,6 +55,7 @@ struct Exec {
     size_t off_bn_ws = 0, off_coef = 0, off_ks = 0, off_wg = 0, off_cs = 0, off_tmp = 0;
     size_t sz_ks = 0, sz_wg = 0;
     std::vector<PackRec> packs;            // with out = offset (patched on export)
+    std::vector<HaloPack> halo_packs;      // refreshed by dreg_exec_repack next to the batched pack launch
     int pack_rows = 0, pack_max_floats = 0;
     int out_slot = -1;
     bool timing = false;
@@ -63,6 +67,7 @@ struct Exec {
     hipEvent_t ev_done = nullptr;
     bool use_aux = true;
     const uint8_t* in_rowocc = nullptr;   // output-row occupancy of the convolution that reads the network input (may be null)
+    char* pack_base = nullptr;            // device address of the pack buffer (dreg_exec_export_pack_table)
 };
 
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -196,13 +201,27 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
         e->packs.push_back(r);
         return o;
     };
-    for (const Op& o : e->ops) {
+    auto add_halo_pack = [&](Param& p, int transposed) {
+        HaloPack hp{p.val, poff, p.d0, p.d1, transposed};
+        poff += align256(dreg_conv3_halo_pack_bytes(transposed ? p.d0 : p.d1));
+        e->halo_packs.push_back(hp);
+        return hp.off;
+    };
+    for (Op& o : e->ops) {
         if (o.kind != OP_CONV && o.kind != OP_CONV_ROWS) continue;
         Param& p = e->prm[o.w];
         const Tensor& x = e->t[o.in];
-        if (p.pk_fwd == SIZE_MAX) { p.cin_pad = x.C; p.pk_fwd = add_pack(p, 0, x.C); }
+        const Tensor& y = e->t[o.out];
+        if (o.kind == OP_CONV && !o.relu) {
+            // dense 3^3 convolutions with 256 output channels on large volumes: forward x -> y, data gradient gy -> gx (needs 256 INPUT channels)
+            if (dreg_conv3_halo_use(x.B, x.D, x.H, x.W, x.C, p.d0, o.ksz, o.stride, o.pad) && p.d1 == x.C) o.halo |= 1;
+            if (e->needs_grad[o.in] && dreg_conv3_halo_use(y.B, y.D, y.H, y.W, p.d0, p.d1, o.ksz, o.stride, o.pad) && p.d0 % 32 == 0) o.halo |= 2;
+        }
+        if (o.halo & 1) { if (p.pk_halo_fwd == SIZE_MAX) p.pk_halo_fwd = add_halo_pack(p, 0); }
+        else if (p.pk_fwd == SIZE_MAX) { p.cin_pad = x.C; p.pk_fwd = add_pack(p, 0, x.C); }
         if (e->needs_grad[o.in]) {
-            if (o.kind == OP_CONV && s2_class_ok(p, o.ksz, o.stride, o.pad)) { if (p.pk_cls == SIZE_MAX) p.pk_cls = add_pack(p, 2, x.C); }
+            if (o.halo & 2) { if (p.pk_halo_dgrad == SIZE_MAX) p.pk_halo_dgrad = add_halo_pack(p, 1); }
+            else if (o.kind == OP_CONV && s2_class_ok(p, o.ksz, o.stride, o.pad)) { if (p.pk_cls == SIZE_MAX) p.pk_cls = add_pack(p, 2, x.C); }
             else if (p.pk_dgrad == SIZE_MAX) p.pk_dgrad = add_pack(p, 1, x.C);
         }
     }
@@ -233,6 +252,7 @@ int dreg_exec_pack_rows(void* h) { return ((Exec*)h)->pack_rows; }
 int dreg_exec_export_pack_table(void* h, void* host_out, int* host_row_desc, void* pack_base)
 {
     Exec* e = (Exec*)h;
+    e->pack_base = (char*)pack_base;
     PackRec* o = (PackRec*)host_out;
     for (size_t i = 0; i < e->packs.size(); ++i) {
         o[i] = e->packs[i]; o[i].out = (char*)pack_base + (size_t)e->packs[i].out;
@@ -245,8 +265,13 @@ int dreg_exec_export_pack_table(void* h, void* host_out, int* host_row_desc, voi
 int dreg_exec_repack(void* h, const void* descs_dev, const int* row_desc_dev, void* stream)
 {
     Exec* e = (Exec*)h;
-    return dreg_pack_conv_weights_batched(descs_dev, (int)e->packs.size(), e->pack_rows, e->pack_max_floats, row_desc_dev, stream);
+    CK(dreg_pack_conv_weights_batched(descs_dev, (int)e->packs.size(), e->pack_rows, e->pack_max_floats, row_desc_dev, stream));
+    for (const HaloPack& hp : e->halo_packs)
+        CK(dreg_pack_conv_weight_halo(hp.w, e->pack_base + hp.off, hp.Cout, hp.Cin, hp.transposed, stream));
+    return DREG_OK;
 }
+// bit 0 / bit 1: the forward / data gradient of op `op` runs on the halo kernel (labels of the HIP-event timing records)
+int dreg_exec_op_halo(void* h, int op) { Exec* e = (Exec*)h; return op >= 0 && op < (int)e->ops.size() ? e->ops[op].halo : 0; }
 
 // 1 (default): weight / bias gradients on the executor's own second stream, overlapping the data-gradient chain; 0: one stream
 void dreg_exec_set_overlap(void* h, int enable) { ((Exec*)h)->use_aux = enable != 0; }
@@ -289,6 +314,11 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
             const void* add = o.in2 >= 0 ? act(o.in2) : nullptr;
             const Tensor* ta = o.in2 >= 0 ? &e->t[o.in2] : nullptr;
             Scope sc(e, st, (int)i, 0);
+            if (o.halo & 1) {
+                CK(dreg_conv3_halo(act(o.in), PK + w.pk_halo_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0,
+                                   o.add_same, 0, stream));
+                continue;
+            }
             CK(dreg_conv3d_igemm_occ(act(o.in), PK + w.pk_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0,
                                      o.ksz, o.stride, o.pad, 0, o.relu, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0, o.add_same, 0, 0,
                                      A + e->off_ks, e->sz_ks, o.in == 0 ? e->in_rowocc : nullptr, stream));
@@ -391,10 +421,15 @@ int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pac
             if (e->needs_grad[o.in]) {
                 // a second contribution to an existing gradient: the plain data-gradient convolution adds it in its epilogue (fp32,
                 // in place, one rounding) instead of going through the temporary and a separate add
-                fused_add = written[o.in] && !rows && !(w.pk_cls != SIZE_MAX && s2_class_ok(w, o.ksz, o.stride, o.pad)) && w.pk_dgrad != SIZE_MAX;
+                const bool halo_d = (o.halo & 2) != 0;
+                fused_add = written[o.in] && !rows && (halo_d || (!(w.pk_cls != SIZE_MAX && s2_class_ok(w, o.ksz, o.stride, o.pad)) && w.pk_dgrad != SIZE_MAX));
                 void* gx = fused_add ? grad(o.in) : dst_for(o.in);
                 Scope sc(e, st, i, 1);
-                if (fused_add) {
+                if (halo_d) {
+                    // gx = [gx +] conv(gy, flipped-tap pack): the halo kernel's same-size addend is the in-place accumulation
+                    CK(dreg_conv3_halo(gy, PK + w.pk_halo_dgrad, gx, nullptr, fused_add ? gx : nullptr, y.B, y.D, y.H, y.W, w.d0,
+                                       fused_add ? x.D : 0, fused_add ? x.H : 0, fused_add ? x.W : 0, 1, 0, stream));
+                } else if (fused_add) {
                     CK(dreg_conv3d_igemm_ws(gy, PK + w.pk_dgrad, gx, nullptr, gx, x.B, y.D, y.H, y.W, w.d0, x.D, x.H, x.W, w.d1,
                                             o.ksz, o.stride, o.pad, 1, 0, x.D, x.H, x.W, 1, 0, 0, A + e->off_ks, e->sz_ks, stream));
                 } else if (rows) {

@@ -132,15 +132,17 @@ def augment_sparse(data: dict, jitter: float = 0.005, std: float = 0.1, gen=None
     return data
 
 
-def augment(data: dict, jitter: float = 0.005, std: float = 0.1) -> dict:
-    """dataset.py:277-331 on whatever device the tensors live on."""
+def augment(data: dict, jitter: float = 0.005, std: float = 0.1, draws=None) -> dict:
+    """dataset.py:277-331 on whatever device the tensors live on (dense grids).  draws: as augment_sparse (tests)."""
+    draws = draws or {}
     for side in ("src", "tgt"):
         g, m = data[side + "_xyz_rgba"], data[side + "_mask"]
         flat = g[0, :3].permute(2, 3, 1, 0).reshape(-1, 3)
-        flat[m] = flat[m] + torch.randn(m.shape[0], 3, device=g.device) * jitter
+        noise = draws["noise_" + side].to(g.device) if ("noise_" + side) in draws else torch.randn(m.shape[0], 3, device=g.device) * jitter
+        flat[m] = flat[m] + noise
         g[0, :3] = flat.view(g.shape[3], g.shape[4], g.shape[2], 3).permute(3, 2, 0, 1)
-    perturb = _small_se3(std).to(data["pose"].device)
-    side = "src" if random.random() > 0.5 else "tgt"
+    perturb = (draws["perturb"] if "perturb" in draws else _small_se3(std)).to(data["pose"].device)
+    side = "src" if (draws["perturb_source"] if "perturb_source" in draws else random.random() > 0.5) else "tgt"
     g, m = data[side + "_xyz_rgba"], data[side + "_mask"]
     flat = g[0, :3].permute(2, 3, 1, 0).reshape(-1, 3)
     c = flat.mean(dim=0)  # the reference centres on the mean over ALL voxels (zeros included), dataset.py:305-306
@@ -153,7 +155,7 @@ def augment(data: dict, jitter: float = 0.005, std: float = 0.1) -> dict:
         data["pose"] = data["pose"] @ torch.linalg.inv(P)
     else:
         data["pose"] = P @ data["pose"]
-    if random.random() > 0.5:
+    if (draws["swap"] if "swap" in draws else random.random() > 0.5):
         for a, b in (("src_xyz_rgba", "tgt_xyz_rgba"), ("src_mask", "tgt_mask"), ("src_nerf_path", "tgt_nerf_path")):
             data[a], data[b] = data[b], data[a]
         data["pose"] = torch.linalg.inv(data["pose"])

@@ -51,10 +51,12 @@ SIGNATURES = {
     "dreg_conv3d_wgrad_rows": (I, [P, P, P, P, Z] + [P, I] + [I] * 14 + [P]),
     # conv_halo.hip
     "dreg_conv3_halo_supported": (I, [I] * 6),
+    "dreg_conv3_halo_use": (I, [I] * 9),
     "dreg_conv3_halo_pack_bytes": (Z, [I]),
     "dreg_pack_conv_weight_halo": (I, [P, P, I, I, I, P]),
     "dreg_conv3_halo": (I, [P, P, P, P, P] + [I] * 10 + [P]),
     "dreg_conv3_halo_set_variant": (None, [I]),
+    "dreg_conv3_halo_set_prof": (None, [P]),
     # fpn_ops.hip
     "dreg_bn_num_chunks": (I, [I]),
     "dreg_bn3d_fwd": (I, [P] * 10 + [I, I, I, F, F, I, I, I, P]),
@@ -84,6 +86,7 @@ SIGNATURES = {
     # executor.hip
     "dreg_exec_create": (P, [P, I, P, I, P, I]),
     "dreg_exec_destroy": (None, [P]),
+    "dreg_exec_op_halo": (I, [P, I]),
     "dreg_exec_arena_bytes": (Z, [P]),
     "dreg_exec_pack_bytes": (Z, [P]),
     "dreg_exec_num_packs": (I, [P]),

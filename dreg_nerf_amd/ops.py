@@ -53,9 +53,9 @@ class KernelTimer:
             self._overhead = v[len(v) // 2]
         return self._overhead
 
-    def summary(self):
+    def summary(self, subtract_overhead: bool = True):
         torch.cuda.synchronize()
-        oh = self.bracket_overhead_ms()
+        oh = self.bracket_overhead_ms() if subtract_overhead else 0.0
         by_name, by_label = {}, {}
         for name, label, flops, ms in self.measured:
             ms = max(ms - oh, 0.0)
@@ -87,6 +87,7 @@ _weight_generation = 0
 def clear_pack_cache():
     global _pack_table
     _pack_cache.clear()
+    _halo_cache.clear()
     _pack_table = None
 
 
@@ -225,6 +226,58 @@ def conv_igemm(x, wpk, bias, addend, out_shape, cin, cout, ksz, stride, pad, tra
     return out
 
 
+_halo_cache = {}
+
+
+def halo_packed_weight(w: torch.Tensor, transposed: bool) -> torch.Tensor:
+    """bf16 [chunk][tap][256][32] pack of a 3^3 weight for the halo kernel (forward, or the flipped-tap data-gradient form), cached
+    against the parameter's version / the optimizer generation like packed_weight()."""
+    base = w._base if w._base is not None else w
+    key = (id(base), w.storage_offset(), tuple(w.shape), bool(transposed))
+    hit = _halo_cache.get(key)
+    stamp = (base._version, _weight_generation)
+    if hit is not None and hit[0]() is base and hit[1] == stamp:
+        return hit[2]
+    lib = L.load()
+    cout, cin = w.shape[0], w.shape[1]
+    out = hit[2] if hit is not None and hit[0]() is base else \
+        torch.empty(lib.dreg_conv3_halo_pack_bytes(cout if transposed else cin) // 2, dtype=torch.bfloat16, device=w.device)
+    L.check(lib.dreg_pack_conv_weight_halo(L.ptr(w.detach().contiguous()), L.ptr(out), cout, cin, int(transposed), L.stream()), "dreg_pack_conv_weight_halo")
+    if len(_halo_cache) > 64:
+        for k in [k for k, v in _halo_cache.items() if v[0]() is None]:
+            del _halo_cache[k]
+    _halo_cache[key] = (weakref.ref(base), stamp, out)
+    return out
+
+
+def halo_applies(x_shape, cin, cout, ksz, stride, pad, dt) -> bool:
+    """The dense 3^3 / 256-output-channel convolutions of large volumes run on the halo kernel (csrc/conv_halo.hip) — the same
+    predicate the native trunk executor uses."""
+    return dt == L.DT_BF16 and bool(L.load().dreg_conv3_halo_use(x_shape[0], x_shape[1], x_shape[2], x_shape[3], cin, cout, ksz, stride, pad))
+
+
+def conv_halo(x, w, bias, addend, transposed: bool, add_same: bool = False, out_f32: bool = False):
+    """x [B,D,H,W,C] bf16 -> [B,D,H,W,256]: 3^3 / stride 1 / pad 1 with w [Cout,Cin,3,3,3] (transposed: the data gradient, x = dOut)."""
+    lib = L.load()
+    B, D, H, W, C = x.shape
+    out = torch.empty(B, D, H, W, 256, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    Da = Ha = Wa = 0
+    if addend is not None:
+        assert addend.dtype == out.dtype and addend.shape[0] == B and addend.shape[4] == 256
+        Da, Ha, Wa = addend.shape[1:4]
+    ev = None
+    if PROFILER is not None:
+        label = f"{'dgrad' if transposed else 'fwd'} B{B} {D}x{H}x{W}x{C}->{D}x{H}x{W}x256 k3s1"
+        ev = PROFILER.record("conv3_halo_kernel<bf16>", label, 2.0 * B * D * H * W * 256 * 27 * C)
+        if ev is not None:
+            ev[0].record()
+    L.check(lib.dreg_conv3_halo(L.ptr(x), L.ptr(halo_packed_weight(w, transposed)), L.ptr(out), L.ptr(bias), L.ptr(addend), B, D, H, W, C,
+                                Da, Ha, Wa, int(add_same), int(out_f32), L.stream()), "dreg_conv3_halo")
+    if ev is not None:
+        ev[1].record()
+    return out
+
+
 def conv_dgrad_s2(g, wpk_class, x_shape, cout, ksz, pad):
     """Data gradient of a stride-2 convolution through the parity-class form (dreg_conv3d_dgrad_s2): g [B,Do,Ho,Wo,cout] bf16."""
     lib = L.load()
@@ -337,10 +390,13 @@ class Conv3dFn(torch.autograd.Function):
         cout = w.shape[0]
         ksz = w.shape[2] if w.dim() == 5 else 1
         out_shape = tuple(_out_dim(x.shape[i + 1], ksz, stride, pad) for i in range(3))
-        wpk = packed_weight(w, cin_pad, False, dt)
         b32 = bias.detach().float().contiguous() if bias is not None else None
-        y = conv_igemm(x, wpk, b32, addend, out_shape, cin_pad, cout, ksz, stride, pad, False, relu=relu, out_f32=out_f32,
-                       flop_cin=w.shape[1], add_same=add_same)
+        if not relu and w.dim() == 5 and w.shape[1] == cin_pad and halo_applies(x.shape, cin_pad, cout, ksz, stride, pad, dt):
+            y = conv_halo(x, w, b32, addend, False, add_same=add_same, out_f32=out_f32)
+        else:
+            wpk = packed_weight(w, cin_pad, False, dt)
+            y = conv_igemm(x, wpk, b32, addend, out_shape, cin_pad, cout, ksz, stride, pad, False, relu=relu, out_f32=out_f32,
+                           flop_cin=w.shape[1], add_same=add_same)
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.bias_ref = bias if (bias is not None and bias.is_leaf) else None
         ctx.cfg = (stride, pad, ksz, cin_pad, bias is not None, None if addend is None else tuple(addend.shape[1:4]), add_same)
@@ -363,6 +419,8 @@ class Conv3dFn(torch.autograd.Function):
             if stride == 2 and dt == L.DT_BF16 and ((ksz == 3 and pad == 1) or (ksz == 1 and pad == 0)) and cout % 64 == 0 \
                     and w.shape[1] % 64 == 0 and L.load().dreg_conv_get_glds():
                 gx = conv_dgrad_s2(g, packed_weight(w, cin_pad, 2, dt), tuple(x.shape), cout, ksz, pad)
+            elif y is None and w.dim() == 5 and halo_applies(g.shape, cout, w.shape[1], ksz, stride, pad, dt):
+                gx = conv_halo(g, w, None, None, True)          # flipped-tap pack: dIn = conv(dOut, W^T)
             else:
                 wpk = packed_weight(w, cin_pad, True, dt)
                 gx = conv_igemm(g, wpk, None, None, tuple(x.shape[1:4]), cout, w.shape[1], ksz, stride, pad, True)

@@ -167,6 +167,11 @@ class TrunkExecutor:
             bigd = cin % 256 == 0 and B * x[1] * x[2] * x[3] >= 65536
             dname = "conv_igemm_glds_kernel<bf16,s2-dgrad>" if s == 2 else \
                 f"conv_igemm_glds_kernel<bf16,{256 if bigd else 128},{256 if bigd else (128 if cin % 128 == 0 else 64)}>"
+            halo = self.lib.dreg_exec_op_halo(self.h, i)
+            if halo & 1:
+                fname = "conv3_halo_kernel<bf16>"
+            if halo & 2:
+                dname = "conv3_halo_kernel<bf16>"
             rows = "-rows" if o[0] == OP_CONV_ROWS else ""
             fl = 2.0 * M * cout * k ** 3 * cin
             # active-set launches: flops per row, scaled by the step's row count (list id) when the records are drained

@@ -80,12 +80,15 @@ int dreg_conv3d_igemm_occ(const void* in, const void* wt_packed, void* out, cons
  * dreg_conv3_halo: out[b,v,:] = bias + addend + sum_d in[b, v - 1 + d, :] . W[:, d, :]; in [B,D,H,W,Cin] bf16, out [B,D,H,W,256] bf16
  *   (fp32 when out_f32), addend [B,Da,Ha,Wa,256] of out's dtype added with nearest x2 upsampling (add_same = 0) or element-wise (1). */
 int dreg_conv3_halo_supported(int B, int D, int H, int W, int Cin, int Cout);
+/* supported AND large enough per grid (>= 128 boxes, i.e. 32^3) to beat the split-K implicit GEMM; independent of B */
+int dreg_conv3_halo_use(int B, int D, int H, int W, int Cin, int Cout, int ksz, int stride, int pad);
 size_t dreg_conv3_halo_pack_bytes(int Cin_reduced);
 int dreg_pack_conv_weight_halo(const float* w, void* out, int Cout, int Cin, int transposed, void* stream);
 int dreg_conv3_halo(const void* in, const void* wpk, void* out, const float* bias, const void* addend,
                     int B, int D, int H, int W, int Cin, int Da, int Ha, int Wa, int add_same, int out_f32, void* stream);
 /* experiments (tools/bench_conv_halo.py): 0 = anti-phase wave groups, weights 2 units ahead (default); 1 = lockstep; 2 = 3 units ahead */
 void dreg_conv3_halo_set_variant(int variant);
+void dreg_conv3_halo_set_prof(void* u64_buf_64x8x5);   /* variant 5: per-wave shader-clock breakdown of the first 64 workgroups */
 
 /* 1 (default): bf16 stride-1 convolutions stage operands with buffer_load...lds; 0: register-staged kernel (A/B checks) */
 void dreg_conv_set_glds(int enable);
@@ -224,6 +227,7 @@ int dreg_exec_output_slot(void* h);
 int dreg_exec_pack_rows(void* h);
 int dreg_exec_export_pack_table(void* h, void* host_out, int* host_row_desc, void* pack_base);   /* 48-byte records + row->record map */
 int dreg_exec_repack(void* h, const void* descs_dev, const int* row_desc_dev, void* stream);
+int dreg_exec_op_halo(void* h, int op);   /* bit 0 / 1: forward / data gradient of convolution `op` runs on the halo kernel (dreg_conv3_halo_use) */
 void dreg_exec_set_overlap(void* h, int enable);
 void dreg_exec_set_input_row_occupancy(void* h, const uint8_t* rowocc);   /* flags for the convolution that reads x_in (the stem); null = none */                             /* 1 (default): weight gradients on aux_stream */
 void dreg_exec_set_timing(void* h, int enable);                              /* HIP events around every convolution launch */

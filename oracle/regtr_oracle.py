@@ -42,6 +42,42 @@ N_LAYERS = 6
 D_MODEL = 256
 
 
+# --------------------------------------------------------------------------- operand-precision emulation (a yardstick, not a path)
+# EMULATE = "bf16": every GEMM-shaped operand (convolution / linear inputs and weights, attention q, k, v and probabilities) and every
+# stored activation of the FPN3D half is rounded to bfloat16 (round-to-nearest-even) on the way forward, and the gradient flowing back
+# through the same point is rounded as well — where the bf16 build keeps bf16 tensors.  Accumulation stays in the tensors' own
+# precision.  The network at a random initialisation is badly conditioned (train-mode BatchNorm over 8..64 voxels in layer4: the
+# fp32 reference itself is only within 1e-2 of an fp64 evaluation for the early-layer gradients), so "how far does bf16 rounding
+# ALONE move the reference's results" is the scale the bf16 build is judged against (tests/test_hip_pinned_step.py).
+EMULATE = None
+
+
+class _RoundBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def _q(x: torch.Tensor) -> torch.Tensor:
+    return _RoundBF16.apply(x) if EMULATE == "bf16" else x
+
+
+def _conv(x, w, b=None, stride=1, padding=0, addend=None):
+    """F.conv3d with the emulated operand rounding; the addend joins before the result is stored."""
+    y = F.conv3d(_q(x), _q(w), b, stride=stride, padding=padding)
+    if addend is not None:
+        y = y + addend
+    return _q(y)
+
+
+def _linear(x, w, b=None):
+    return F.linear(_q(x), _q(w), b)
+
+
 # --------------------------------------------------------------------------- A1 / A2
 def _bn(sd: SD, p: str, x: torch.Tensor, train: bool) -> torch.Tensor:
     """BatchNorm3d, reference semantics = one grid per call (resnet3d.py:121,159).
@@ -53,26 +89,26 @@ def _bn(sd: SD, p: str, x: torch.Tensor, train: bool) -> torch.Tensor:
         sd[p + ".num_batches_tracked"] += 1
     return F.batch_norm(
         x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
-        training=train, momentum=BN_MOMENTUM, eps=BN_EPS)
+        training=train, momentum=BN_MOMENTUM, eps=BN_EPS)      # callers round the stored result (after the residual / ReLU)
 
 
 def _bottleneck(sd: SD, p: str, x: torch.Tensor, stride: int, train: bool) -> torch.Tensor:
     """resnet3d.py:95-113 — 1x1x1 -> 3x3x3(stride) -> 1x1x1, BN after each, residual, ReLU."""
-    out = F.relu(_bn(sd, p + ".bn1", F.conv3d(x, sd[p + ".conv1.weight"]), train))
-    out = F.relu(_bn(sd, p + ".bn2",
-                     F.conv3d(out, sd[p + ".conv2.weight"], stride=stride, padding=1), train))
-    out = _bn(sd, p + ".bn3", F.conv3d(out, sd[p + ".conv3.weight"]), train)
+    out = _q(F.relu(_bn(sd, p + ".bn1", _conv(x, sd[p + ".conv1.weight"]), train)))
+    out = _q(F.relu(_bn(sd, p + ".bn2",
+                        _conv(out, sd[p + ".conv2.weight"], stride=stride, padding=1), train)))
+    out = _bn(sd, p + ".bn3", _conv(out, sd[p + ".conv3.weight"]), train)
     if (p + ".downsample.0.weight") in sd:
-        res = _bn(sd, p + ".downsample.1",
-                  F.conv3d(x, sd[p + ".downsample.0.weight"], stride=stride), train)
+        res = _q(_bn(sd, p + ".downsample.1",
+                     _conv(x, sd[p + ".downsample.0.weight"], stride=stride), train))
     else:
         res = x
-    return F.relu(out + res)
+    return _q(F.relu(out + res))
 
 
 def resnet3d_forward(sd: SD, x: torch.Tensor, train: bool, p: str = "fpn3d.backbone_net"):
     """resnet3d.py:157-172.  x [1,4,D,H,W] -> (c1..c5)."""
-    c1 = F.relu(_bn(sd, p + ".bn1", F.conv3d(x, sd[p + ".conv1.weight"], stride=2, padding=2), train))
+    c1 = _q(F.relu(_bn(sd, p + ".bn1", _conv(x, sd[p + ".conv1.weight"], stride=2, padding=2), train)))
     h = F.max_pool3d(c1, kernel_size=3, stride=2, padding=1)
     feats = [c1]
     for li, nblk in enumerate(RESNET50_BLOCKS):
@@ -94,14 +130,14 @@ def fpn_forward(sd: SD, x: torch.Tensor, train: bool) -> torch.Tensor:
     c1, c2, c3, c4, c5 = resnet3d_forward(sd, x, train)
     q = "fpn3d.feature_pyramid."
 
-    def conv(name, t, pad):
-        return F.conv3d(t, sd[q + name + ".weight"], sd[q + name + ".bias"], padding=pad)
+    def conv(name, t, pad, addend=None):
+        return _conv(t, sd[q + name + ".weight"], sd[q + name + ".bias"], padding=pad, addend=addend)
 
     p5 = conv("pyramid_transformation_5", c5, 0)
-    p4 = conv("upsample_transform_4", _up_crop(p5, c4) + conv("pyramid_transformation_4", c4, 0), 1)
-    p3 = conv("upsample_transform_3", _up_crop(p4, c3) + conv("pyramid_transformation_3", c3, 0), 1)
-    p2 = conv("upsample_transform_2", _up_crop(p3, c2) + conv("pyramid_transformation_2", c2, 0), 1)
-    p1 = conv("upsample_transform_1", _up_crop(p2, c1) + conv("pyramid_transformation_1", c1, 1), 1)
+    p4 = conv("upsample_transform_4", conv("pyramid_transformation_4", c4, 0, _up_crop(p5, c4)), 1)
+    p3 = conv("upsample_transform_3", conv("pyramid_transformation_3", c3, 0, _up_crop(p4, c3)), 1)
+    p2 = conv("upsample_transform_2", conv("pyramid_transformation_2", c2, 0, _up_crop(p3, c2)), 1)
+    p1 = conv("upsample_transform_1", conv("pyramid_transformation_1", c1, 1, _up_crop(p2, c1)), 1)
     return p1
 
 
@@ -205,12 +241,12 @@ def _mha(sd: SD, p: str, q_in, k_in, v_in) -> torch.Tensor:
     w, b = sd[p + ".in_proj_weight"], sd[p + ".in_proj_bias"]
     e = w.shape[1]
     dh = e // N_HEADS
-    q = F.linear(q_in, w[:e], b[:e]).view(-1, N_HEADS, dh).transpose(0, 1)
-    k = F.linear(k_in, w[e:2 * e], b[e:2 * e]).view(-1, N_HEADS, dh).transpose(0, 1)
-    v = F.linear(v_in, w[2 * e:], b[2 * e:]).view(-1, N_HEADS, dh).transpose(0, 1)
+    q = _q(_linear(q_in, w[:e], b[:e])).view(-1, N_HEADS, dh).transpose(0, 1)
+    k = _q(_linear(k_in, w[e:2 * e], b[e:2 * e])).view(-1, N_HEADS, dh).transpose(0, 1)
+    v = _q(_linear(v_in, w[2 * e:], b[2 * e:])).view(-1, N_HEADS, dh).transpose(0, 1)
     att = torch.softmax((q * (1.0 / math.sqrt(dh))) @ k.transpose(1, 2), dim=-1)
-    o = (att @ v).transpose(0, 1).reshape(-1, e)
-    return F.linear(o, sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
+    o = (_q(att) @ v).transpose(0, 1).reshape(-1, e)
+    return _linear(o, sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
 
 
 def encoder_layer(sd: SD, p: str, src, tgt, src_pe, tgt_pe):
@@ -228,8 +264,8 @@ def encoder_layer(sd: SD, p: str, src, tgt, src_pe, tgt_pe):
 
     def ffn(x):
         h = _ln(sd, p + ".norm3", x)
-        return F.linear(F.relu(F.linear(h, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
-                        sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
+        return _linear(F.relu(_linear(h, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])),
+                       sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
 
     return src + ffn(src), tgt + ffn(tgt)
 
@@ -250,9 +286,9 @@ def corr_decoder(sd: SD, src_f, tgt_f, src_xyz, tgt_xyz, src_pe, tgt_pe):
     p = "correspondence_decoder"
 
     def attend(qf, kf, val):
-        q = F.linear(qf, sd[p + ".q_proj.weight"], sd[p + ".q_proj.bias"]) / math.sqrt(qf.shape[-1])
-        k = F.linear(kf, sd[p + ".k_proj.weight"], sd[p + ".k_proj.bias"])
-        return torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ val
+        q = _q(_linear(qf, sd[p + ".q_proj.weight"], sd[p + ".q_proj.bias"]) / math.sqrt(qf.shape[-1]))
+        k = _q(_linear(kf, sd[p + ".k_proj.weight"], sd[p + ".k_proj.bias"]))
+        return torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ val      # V = xyz: fp32 on the VALU in the build
 
     s2, t2 = src_f + src_pe, tgt_f + tgt_pe
     src_corr = attend(s2, t2, tgt_xyz)

@@ -1,0 +1,96 @@
+"""CPU: the dataset's training augmentation and split loading against the REFERENCE's own dataset class
+(conerf/datasets/register/dataset.py:24-91,194-216,277-331).  tests/golden/augment.npz holds, for the four (perturb source?, swap?)
+outcomes, the random draws the reference consumed and its outputs (tools/make_golden.py augment_golden)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dreg_nerf_amd import dataset as DS, synth
+
+
+def _case(g, c):
+    pre = f"c{c}/"
+    return {k[len(pre):]: g[k] for k in g.files if k.startswith(pre)}
+
+
+def _inputs(case):
+    res, seed = int(case["res"]), int(case["grid_seed"])
+    gs, ms = synth.shell_grid(res, seed, 0.5, 0.9)
+    gt, mt = synth.shell_grid(res, seed + 1, 0.5, 0.9, pose=synth.fixed_pose())
+    return gs, ms, gt, mt, synth.fixed_pose() @ torch.linalg.inv(torch.eye(4))
+
+
+def _draws(case):
+    return {"noise_src": torch.from_numpy(case["noise_src"]), "noise_tgt": torch.from_numpy(case["noise_tgt"]),
+            "perturb": DS.se3_from_draws(float(case["phi"]), float(case["cos_theta"]), float(case["theta_n"]), case["trans_n"], 0.1),
+            "perturb_source": bool(case["perturb_source"]), "swap": bool(case["swap"])}
+
+
+def test_small_se3_is_the_references_function_of_its_draws(golden_dir):
+    g = np.load(os.path.join(golden_dir, "augment.npz"))
+    for c in range(int(g["n_cases"])):
+        case = _case(g, c)
+        T = DS.se3_from_draws(float(case["phi"]), float(case["cos_theta"]), float(case["theta_n"]), case["trans_n"], 0.1)
+        np.testing.assert_allclose(T.numpy(), case["perturb"], atol=1e-6)
+
+
+@pytest.mark.parametrize("sparse", [True, False])
+def test_augmentation_matches_reference_outputs(golden_dir, sparse):
+    g = np.load(os.path.join(golden_dir, "augment.npz"))
+    assert int(g["n_cases"]) == 4
+    seen = set()
+    for c in range(4):
+        case = _case(g, c)
+        seen.add((bool(case["perturb_source"]), bool(case["swap"])))
+        gs, ms, gt, mt, pose = _inputs(case)
+        if sparse:
+            data = {"src_sparse": DS.SparseBlock.from_dense(gs, ms), "tgt_sparse": DS.SparseBlock.from_dense(gt, mt), "pose": pose,
+                    "src_nerf_path": "s", "tgt_nerf_path": "t"}
+            out = DS.augment_sparse(data, draws=_draws(case))
+            src_xyz, tgt_xyz = out["src_sparse"].vals[:, :3], out["tgt_sparse"].vals[:, :3]
+            src_mask, tgt_mask = out["src_sparse"].idx, out["tgt_sparse"].idx
+            # everything but xyz rides along unchanged
+            ref_rgba = (gt if case["swap"] else gs).reshape(-1, 7)[src_mask][:, 3:]
+            assert torch.equal(out["src_sparse"].vals[:, 3:], ref_rgba)
+        else:
+            data = {"src_xyz_rgba": gs.permute(3, 2, 0, 1).unsqueeze(0).clone(), "tgt_xyz_rgba": gt.permute(3, 2, 0, 1).unsqueeze(0).clone(),
+                    "src_mask": ms, "tgt_mask": mt, "pose": pose[None].clone(), "src_nerf_path": "s", "tgt_nerf_path": "t"}
+            out = DS.augment(data, draws=_draws(case))
+            flat = lambda t: t[0, :3].permute(2, 3, 1, 0).reshape(-1, 3)
+            src_mask, tgt_mask = out["src_mask"], out["tgt_mask"]
+            src_xyz, tgt_xyz = flat(out["src_xyz_rgba"])[src_mask], flat(out["tgt_xyz_rgba"])[tgt_mask]
+        assert torch.equal(src_mask, torch.from_numpy(case["src_mask"])) and torch.equal(tgt_mask, torch.from_numpy(case["tgt_mask"]))
+        np.testing.assert_allclose(out["pose"].reshape(4, 4).numpy(), case["pose"].reshape(4, 4), atol=2e-6)
+        np.testing.assert_allclose(src_xyz.numpy(), case["src_xyz"], atol=2e-6)
+        np.testing.assert_allclose(tgt_xyz.numpy(), case["tgt_xyz"], atol=2e-6)
+        assert out["src_nerf_path"] == str(case["src_path"])
+    assert len(seen) == 4
+
+
+def test_small_se3_distribution_moments():
+    """_small_se3 draws the reference's distribution: angle ~ N(0, (std pi / sqrt 3)^2), translation ~ N(0, (std / sqrt 3)^2) per axis."""
+    gen = torch.Generator().manual_seed(0)
+    std = 0.1
+    Ts = torch.stack([DS._small_se3(std, gen) for _ in range(4000)])
+    tr = Ts[:, 0, 0] + Ts[:, 1, 1] + Ts[:, 2, 2]
+    ang = torch.acos(((tr - 1) / 2).clamp(-1, 1))
+    assert abs(float(ang.pow(2).mean().sqrt()) - std * np.pi / np.sqrt(3)) < 0.01
+    assert abs(float(Ts[:, :3, 3].std()) - std / np.sqrt(3)) < 0.003
+
+
+def test_load_split_reads_the_reference_file_format(tmp_path):
+    """objaverse.json is {dataset: {split: [ids]}}; the 'objaverse' entry holds object uids that obj_id_names.json maps to scene
+    directory names (dataset.py:194-216)."""
+    json.dump({"objaverse": {"train": ["uid_a", "uid_b"], "test": ["uid_c"]}, "scannerf": {"train": ["airplane1"], "test": ["airplane2"]}},
+              open(tmp_path / "objaverse.json", "w"))
+    json.dump({"uid_a": "Scene_A", "uid_b": "Scene_B", "uid_c": "Scene_C", "unused": "X"}, open(tmp_path / "obj_id_names.json", "w"))
+    assert DS.load_split(str(tmp_path), "objaverse") == {"train": ["Scene_A", "Scene_B"], "test": ["Scene_C"]}
+    assert DS.load_split(str(tmp_path), "scannerf") == {"train": ["airplane1"], "test": ["airplane2"]}
+    with pytest.raises(KeyError):
+        DS.load_split(str(tmp_path), "nope")
+    # a dataset whose directories are missing is an error, not an empty loader
+    with pytest.raises(FileNotFoundError):
+        DS.NeRFRegDataset(str(tmp_path), str(tmp_path), "objaverse", "train")

@@ -39,7 +39,7 @@ def _ref(x, w, bias=None, addend=None, add_same=False):
     return y.permute(0, 2, 3, 4, 1).float()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 3])
 @pytest.mark.parametrize("cin,shape", [(256, (2, 8, 16, 16)), (64, (1, 4, 8, 24)), (32, (3, 12, 8, 8))])
 def test_halo_forward_matches_fp32_reference(cin, shape, variant):
     g = torch.Generator().manual_seed(7)

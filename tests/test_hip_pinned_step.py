@@ -63,44 +63,72 @@ def _product_step(g, res, active_set=True, native_trunk=True):
     return m, ts, out, pred, grads, delta
 
 
-def _check_against_golden(g, tag, out, pred, grads, delta, m, tol):
-    """Every pinned quantity is measured first and written to the report; the assertions follow."""
+def _check_against_golden(g, tag, out, pred, grads, delta, m, tol, emu=None):
+    """Every pinned quantity is measured first and written to the report; the assertions follow.
+    emu (bf16 runs): the reference-pinned oracle evaluated with bf16 operand rounding on the same step (tools/make_golden.py
+    bf16_yardstick).  The network at this random initialisation is badly conditioned — the fp32 reference itself is only within 1e-2 of
+    the fp64 truth for early-layer gradients — so pose and gradients of a bf16 evaluation are bounded RELATIVE to that yardstick:
+    distance(build, truth) <= K x distance(emulated reference, truth) + a small floor.  Losses, the optimizer's parameter delta and the
+    BatchNorm statistics are well conditioned and bounded directly."""
     rec, bad = {}, []
+    K = tol.get("K", 3.0)
 
-    def close(name, got, ref, rtol):
-        rec[name] = [float(got), float(ref)]
-        if not abs(float(got) - float(ref)) <= rtol * abs(float(ref)):
-            bad.append((name, float(got), float(ref), rtol))
+    def close(name, got, ref, rtol, emu_val=None):
+        got, ref = float(got), float(ref)
+        rec[name] = [got, ref] + ([float(emu_val)] if emu_val is not None else [])
+        bound = rtol * abs(ref)
+        if emu_val is not None:
+            bound = max(bound, K * abs(float(emu_val) - ref))
+        if not abs(got - ref) <= bound:
+            bad.append((name, got, ref, bound))
+
+    def norm_close(name, got, truth, rtol, emu_val=None):
+        """A gradient NORM under rounding noise grows like sqrt(truth^2 + noise^2): compare the implied relative noise
+        sqrt(|got^2 - truth^2|) / truth with K x the yardstick's, not the difference of the norms."""
+        got, truth = float(got), float(truth)
+        noise = lambda v: abs(v * v - truth * truth) ** 0.5 / truth
+        bound = noise(truth * (1.0 + rtol))
+        if emu_val is not None:
+            bound = max(bound, K * noise(float(emu_val)))
+        rec[name] = {"got": got, "truth": truth, "emulated_reference": None if emu_val is None else float(emu_val), "noise": noise(got), "noise_bound": bound}
+        if not noise(got) <= bound:
+            bad.append((name, got, truth, noise(got), bound))
 
     assert pred["src_kp"][0].shape[0] == int(g["n_src"]) and pred["tgt_kp"][0].shape[0] == int(g["n_tgt"])
     # ---- losses (the reference's own loss code on the reference's fp32 forward)
     for k in ("overlap", "nerf_cont", "feature", "corr", "total"):
-        close("loss_" + k, out["losses"][k], g["loss_" + k], tol["loss_feature"] if k == "feature" else tol["loss"])
-    rec["pose_maxabs"] = float(np.abs(pred["pose"].detach().cpu().numpy() - g["pose"]).max())
-    if not rec["pose_maxabs"] < tol["pose"]:
-        bad.append(("pose", rec["pose_maxabs"], tol["pose"]))
-    # ---- per-module gradient norms against the fp64 truth of the same step (fp32 reference where the fixture has no fp64 pass)
+        close("loss_" + k, out["losses"][k], g["loss_" + k], tol["loss_feature"] if k == "feature" else tol["loss"],
+              emu["loss_" + k] if emu is not None else None)
+    pose_err = float(np.abs(pred["pose"].detach().cpu().numpy() - g["pose"]).max())
+    pose_bound = tol["pose"] + (K * float(np.abs(emu["pose"] - g["pose"]).max()) if emu is not None else 0.0)
+    rec["pose_maxabs"] = [pose_err, pose_bound]
+    if not pose_err <= pose_bound:
+        bad.append(("pose", pose_err, pose_bound))
+    # ---- per-module gradient norms against the fp64 truth of the same step
     for name, pref in GROUPS.items():
         sq = sum(float(v.double().pow(2).sum()) for k, v in grads.items() if k.startswith(pref))
-        ref = float(g["gnorm64_" + name]) if ("gnorm64_" + name) in g.files else float(g["gnorm_" + name])
-        close("gnorm_" + name, sq ** 0.5, ref, tol["gnorm"])
-    # ---- gradient probes: direction (cosine) and relative distance to the truth
-    cos_min = 1.0
+        norm_close("gnorm_" + name, sq ** 0.5, g["gnorm64_" + name], tol["gnorm"], emu["gnorm_" + name] if emu is not None else None)
+    # ---- gradient probes: relative distance to the truth (and the cosine, reported)
     for key in g.files:
         if not key.startswith("gidx/"):
             continue
         k = key[5:]
         got = grads[k].flatten()[g[key]].double().numpy()
-        ref = g["gval64/" + k] if ("gval64/" + k) in g.files else g["gval/" + k].astype(np.float64)
+        ref = g["gval64/" + k]
         cos = float(np.dot(got, ref) / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-300))
         rel = float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-300))
-        rec["probe/" + k] = [cos, rel]
-        cos_min = min(cos_min, cos)
-        if not cos >= tol["cos"]:
-            bad.append(("probe " + k, cos, rel))
-    rec["cos_min"] = cos_min
+        bound = tol["probe"]
+        rel_emu = None
+        if emu is not None:
+            rel_emu = float(np.linalg.norm(emu["gval/" + k].astype(np.float64) - ref) / (np.linalg.norm(ref) + 1e-300))
+            bound = max(bound, K * rel_emu)
+        else:   # fp32: of the order of the fp32 reference's own distance to the truth
+            bound = max(bound, 4 * float(np.linalg.norm(g["gval/" + k].astype(np.float64) - ref) / (np.linalg.norm(ref) + 1e-300)))
+        rec["probe/" + k] = {"cos": cos, "rel": rel, "rel_emulated_reference": rel_emu, "bound": bound}
+        if not rel <= bound:
+            bad.append(("probe " + k, rel, bound))
     # ---- clip norm (clip_grad_norm_(0.1) sees the norm over ALL parameters) and the parameter delta of the optimizer step
-    close("total_grad_norm", out["grad_norm"], g["total_grad_norm"], tol["gnorm"])
+    norm_close("total_grad_norm", out["grad_norm"], g["total_grad_norm"], tol["gnorm"], emu["total_grad_norm"] if emu is not None else None)
     for name, pref in GROUPS.items():
         dn = sum(float(v.pow(2).sum()) for k, v in delta.items() if k.startswith(pref)) ** 0.5
         close("dnorm_" + name, dn, g["dnorm_" + name], tol["dnorm"])
@@ -119,30 +147,36 @@ def _check_against_golden(g, tag, out, pred, grads, delta, m, tol):
     return rec
 
 
-# bf16 operands (8 mantissa bits) through 53 convolutions with train-mode BatchNorm: measured distances are recorded in
-# gpurun_out/pinned_step_report.json; the bounds below leave ~2x headroom over them
-TOL_BF16 = {"loss": 2e-2, "loss_feature": 5e-2, "pose": 5e-2, "gnorm": 5e-2, "cos": 0.99, "dnorm": 2e-2, "bn": 2e-2}
-TOL_FP32 = {"loss": 1e-3, "loss_feature": 5e-3, "pose": 5e-4, "gnorm": 2e-2, "cos": 0.999, "dnorm": 5e-3, "bn": 1e-3}
+def _emu(golden_dir, name):
+    p = os.path.join(golden_dir, name + "_bf16emu.npz")
+    assert os.path.exists(p), f"{p} missing: python tools/make_golden.py bf16emu64 bf16emu128"
+    return np.load(p)
+
+
+# bf16: direct bounds for the well-conditioned quantities (measured: losses <= 1.1 %, parameter delta <= 0.2 %, BatchNorm statistics
+# <= 0.2 %), yardstick-relative bounds (K = 3) with these floors for pose and gradients.  fp32: direct bounds.
+TOL_BF16 = {"loss": 2e-2, "loss_feature": 4e-2, "pose": 2e-3, "gnorm": 2e-2, "probe": 2e-2, "dnorm": 1e-2, "bn": 1e-2, "K": 3.0}
+TOL_FP32 = {"loss": 1e-3, "loss_feature": 5e-3, "pose": 5e-4, "gnorm": 2e-2, "probe": 2e-3, "dnorm": 5e-3, "bn": 1e-3}
 
 
 def test_bf16_product_step_matches_reference_golden_64(golden_dir):
     g = np.load(os.path.join(golden_dir, "train64.npz"))
     m, ts, out, pred, grads, delta = _product_step(g, 64)
     assert m.__dict__.get("_trunk_cache"), "the native trunk executor did not run"
-    _check_against_golden(g, "bf16_64_active_exec", out, pred, grads, delta, m, TOL_BF16)
+    _check_against_golden(g, "bf16_64_active_exec", out, pred, grads, delta, m, TOL_BF16, _emu(golden_dir, "train64"))
 
 
 def test_bf16_dense_head_step_matches_reference_golden_64(golden_dir):
     g = np.load(os.path.join(golden_dir, "train64.npz"))
     m, ts, out, pred, grads, delta = _product_step(g, 64, active_set=False)
-    _check_against_golden(g, "bf16_64_dense_exec", out, pred, grads, delta, m, TOL_BF16)
+    _check_against_golden(g, "bf16_64_dense_exec", out, pred, grads, delta, m, TOL_BF16, _emu(golden_dir, "train64"))
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "train128.npz")), reason="train128.npz not generated")
 def test_bf16_product_step_matches_reference_golden_128(golden_dir):
     g = np.load(os.path.join(golden_dir, "train128.npz"))
     m, ts, out, pred, grads, delta = _product_step(g, 128)
-    _check_against_golden(g, "bf16_128_active_exec", out, pred, grads, delta, m, TOL_BF16)
+    _check_against_golden(g, "bf16_128_active_exec", out, pred, grads, delta, m, TOL_BF16, _emu(golden_dir, "train128"))
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "train128.npz")), reason="train128.npz not generated")

@@ -27,11 +27,23 @@ def main():
         lib.dreg_conv3_halo_set_variant(v)
         L.check(lib.dreg_conv3_halo(L.ptr(x), L.ptr(pk), L.ptr(out), L.ptr(bias), None, B, R, R, R, cin, 0, 0, 0, 0, 0, L.stream()), "halo")
 
-    arms = {"igemm256": lambda: ops.conv3d(x, w, bias, pad=1), "halo": lambda: halo(0), "halo_lockstep": lambda: halo(1), "halo_a3r5": lambda: halo(2), "halo_nosplit": lambda: halo(3)}
+    arms = {"igemm256": lambda: ops.conv3d(x, w, bias, pad=1), "halo": lambda: halo(0), "halo_lockstep": lambda: halo(1), "halo_nosplit": lambda: halo(3)}
     if "--only-halo" in sys.argv:
         arms = {"halo": lambda: halo(0), "igemm256": arms["igemm256"]}
     if "--ablate" in sys.argv:
-        arms.update({"abl_noDMA": lambda: halo(11), "abl_noDSread": lambda: halo(12), "abl_noDMA_noDS": lambda: halo(13), "abl_noMFMA": lambda: halo(14)})
+        arms.update({"abl_noDMA": lambda: halo(11), "abl_noDSread": lambda: halo(12), "abl_noDMA_noDS": lambda: halo(13), "abl_noMFMA": lambda: halo(14), "abl_DMAonly": lambda: halo(16)})
+    if "--prof" in sys.argv:
+        buf = torch.zeros(64 * 8 * 5, dtype=torch.int64, device=dev)
+        lib.dreg_conv3_halo_set_prof(L.ptr(buf))
+        halo(5)
+        torch.cuda.synchronize()
+        lib.dreg_conv3_halo_set_prof(None)
+        p = buf.view(64, 8, 5).double().cpu()
+        nu = (cin // 32) * 27
+        names = ["issue(reads+DMA)", "vmcnt wait", "barrier1+lgkm", "MFMA half", "barrier2"]
+        for grp, sl in (("group0 (waves 0-3)", slice(0, 4)), ("group1 (waves 4-7)", slice(4, 8))):
+            m = p[:, sl].mean(dim=(0, 1)) / nu
+            print(grp, " ".join(f"{n}={v:.0f}" for n, v in zip(names, m.tolist())), f"sum={m.sum():.0f} cycles/unit (s_memtime ticks)")
     for f in arms.values():
         f()
     torch.cuda.synchronize()

@@ -75,6 +75,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if sys.argv[1:] and all(a.startswith("bf16emu") for a in sys.argv[1:]):     # oracle-only products: the reference is not needed
+        for a in sys.argv[1:]:
+            bf16_yardstick(int(a[7:]), "train" + a[7:])
+        return
     nr = import_reference()
     from conerf.register.se3 import compute_rigid_transform
     from conerf.register.position_embedding import PositionEmbeddingCoordsSine
@@ -145,13 +149,118 @@ def main():
              rre=rr.numpy(), rte=rt.numpy())
     print("e2e_eval32 done; N =", out["src_kp"][0].shape[0], out["tgt_kp"][0].shape[0])
 
-    want = set(sys.argv[1:]) or {"small", "train64", "train128"}
+    want = set(sys.argv[1:]) or {"small", "augment", "train64", "train128", "bf16emu64", "bf16emu128"}
+    if "augment" in want:
+        augment_golden()
     if "train64" in want:
         train_golden(nr, sd, 64, "train64")
     if "train128" in want:
         # BASELINE size: two A4 rounds, split-K thresholds and 32-bit index ranges of the 128^3 path (reference fwd+bwd: ~2 min on
         # 8 cores; the fp64 oracle pass needs ~40 GB and ~20 min: DREG_GOLDEN_FP64_128=0 skips it)
         train_golden(nr, sd, 128, "train128", with_fp64=bool(int(os.environ.get("DREG_GOLDEN_FP64_128", "1"))))
+    if "bf16emu64" in want:
+        bf16_yardstick(64, "train64")
+    if "bf16emu128" in want:
+        bf16_yardstick(128, "train128")
+
+
+def augment_golden():
+    """Training-time augmentation of the REFERENCE's dataset class (conerf/datasets/register/dataset.py:277-331: points_jitter,
+    rigid_perturb, random_swap, in __getitem__'s order) on small shell grids, with the random draws it consumed (torch.randn for the
+    jitter, numpy for the SE(3) perturbation, random.random for the two coin flips) recorded next to its outputs."""
+    import random
+    import types as _types
+    import conerf.datasets.register.dataset as RD
+    out, seen = {}, set()
+    case = 0
+    for seed in range(3, 60):
+        random.seed(seed)
+        r1, r2 = random.random(), random.random()
+        combo = (r1 > 0.5, r2 > 0.5)
+        if combo in seen:
+            continue
+        seen.add(combo)
+        res = 16
+        gs, ms = synth.shell_grid(res, 2 * seed + 1, 0.5, 0.9)
+        gt, mt = synth.shell_grid(res, 2 * seed + 2, 0.5, 0.9, pose=synth.fixed_pose())
+        Ts, Tt = torch.eye(4), synth.fixed_pose()
+        self = _types.SimpleNamespace(scale=0.005, clip=0.05, std=0.1)
+        random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+        src = gs.permute(3, 2, 0, 1).unsqueeze(0).clone()
+        tgt = gt.permute(3, 2, 0, 1).unsqueeze(0).clone()
+        src[:, :3] = RD.NeRFRegDataset.points_jitter(self, src[:, :3], ms)
+        tgt[:, :3] = RD.NeRFRegDataset.points_jitter(self, tgt[:, :3], mt)
+        data = {"src_xyz_rgba": src, "tgt_xyz_rgba": tgt, "src_mask": ms, "tgt_mask": mt, "src_nerf_path": "s", "tgt_nerf_path": "t",
+                "pose": Tt @ torch.linalg.inv(Ts)}
+        data = RD.NeRFRegDataset.rigid_perturb(self, data)
+        data = RD.NeRFRegDataset.random_swap(self, data)
+        # the draws, replayed
+        torch.manual_seed(seed)
+        noise_src = torch.randn(ms.shape[0], 3) * 0.005
+        noise_tgt = torch.randn(mt.shape[0], 3) * 0.005
+        np.random.seed(seed)
+        phi, cos_theta = np.random.uniform(0.0, 2 * np.pi), np.random.uniform(-1.0, 1.0)
+        theta_n, trans_n = np.random.randn(), np.random.randn(3, 1)
+        np.random.seed(seed)
+        perturb = RD._sample_se3_small(0.1)
+        flat = lambda g_: g_[0, :3].permute(2, 3, 1, 0).reshape(-1, 3)
+        pre = f"c{case}/"
+        out.update({pre + "grid_seed": 2 * seed + 1, pre + "res": res, pre + "noise_src": noise_src.numpy(), pre + "noise_tgt": noise_tgt.numpy(),
+                    pre + "phi": phi, pre + "cos_theta": cos_theta, pre + "theta_n": theta_n, pre + "trans_n": trans_n[:, 0],
+                    pre + "perturb": perturb, pre + "perturb_source": bool(r1 > 0.5), pre + "swap": bool(r2 > 0.5),
+                    pre + "pose": data["pose"].numpy(), pre + "src_mask": data["src_mask"].numpy(), pre + "tgt_mask": data["tgt_mask"].numpy(),
+                    pre + "src_xyz": flat(data["src_xyz_rgba"])[data["src_mask"]].numpy(), pre + "tgt_xyz": flat(data["tgt_xyz_rgba"])[data["tgt_mask"]].numpy(),
+                    pre + "src_path": data["src_nerf_path"]})
+        case += 1
+        if len(seen) == 4:
+            break
+    out["n_cases"] = case
+    np.savez(os.path.join(OUT, "augment.npz"), **out)
+    print("augment done:", case, "cases", sorted(seen))
+
+
+def bf16_yardstick(res: int, name: str):
+    """The reference-pinned oracle evaluated with bf16 operand rounding (oracle.regtr_oracle.EMULATE = "bf16") on the same step as
+    `name`.npz: how far bf16 rounding ALONE moves losses / pose / gradient probes / gradient norms / the optimizer's parameter delta.
+    Written to `name`_bf16emu.npz; tests/test_hip_pinned_step.py bounds the bf16 build's distance to the truth by this distance."""
+    base = np.load(os.path.join(OUT, name + ".npz"))
+    sd = params.synth_state_dict(0)
+    leaves = {}
+    for k, (shape, kind) in params.regtr_spec().items():
+        if not params.is_buffer(kind) and not k.startswith(params.ALIAS_DST):
+            sd[k].requires_grad_(True)
+            leaves[k] = sd[k]
+    data = synth.shell_pair(res, 1, 2, pose=synth.fixed_pose())
+    W = 0.1 * torch.randn(256, 256, generator=torch.Generator().manual_seed(int(base["W_seed"])))
+    O.EMULATE = "bf16"
+    try:
+        pred = O.regtr_forward(sd, data, train=True)
+        s_gt, t_gt = synth.synthetic_overlap_gt(pred["src_kp"][0]), synth.synthetic_overlap_gt(pred["tgt_kp"][0])
+        with torch.no_grad():
+            s_tl = torch.stack([synth.synthetic_overlap_gt(pred["src_kp_warped"][0][l], 1)[0] for l in range(6)])
+            t_tl = torch.stack([synth.synthetic_overlap_gt(pred["tgt_kp_warped"][0][l], 1)[0] for l in range(6)])
+        losses = O.training_losses(pred, data["pose"], W, s_gt, t_gt, s_tl, t_tl)
+        losses["total"].backward()
+    finally:
+        O.EMULATE = None
+    groups = {"resnet": "fpn3d.backbone_net.", "fpn_head": "fpn3d.feature_pyramid.",
+              "transformer": "transformer_encoder.", "decoder": "correspondence_decoder."}
+    out = {"n_src": pred["src_kp"][0].shape[0], "n_tgt": pred["tgt_kp"][0].shape[0], "pose": pred["pose"].detach().numpy()}
+    for k, v in losses.items():
+        out["loss_" + k] = float(v)
+    for gname, pref in groups.items():
+        out["gnorm_" + gname] = float(sum(float(v.grad.double().pow(2).sum()) for k, v in leaves.items() if k.startswith(pref) and v.grad is not None) ** 0.5)
+    for key in base.files:
+        if key.startswith("gidx/"):
+            out["gval/" + key[5:]] = leaves[key[5:]].grad.flatten()[base[key]].numpy()
+    plist = [v for v in leaves.values() if v.grad is not None]
+    out["total_grad_norm"] = float(torch.nn.utils.clip_grad_norm_(plist, max_norm=0.1))
+    before = {k: v.detach().clone() for k, v in leaves.items()}
+    torch.optim.AdamW(plist, lr=1e-4, weight_decay=1e-4).step()
+    for gname, pref in groups.items():
+        out["dnorm_" + gname] = float(sum((leaves[k].detach() - before[k]).double().pow(2).sum() for k in leaves if k.startswith(pref)) ** 0.5)
+    np.savez(os.path.join(OUT, name + "_bf16emu.npz"), **out)
+    print(name + "_bf16emu done", {k: v for k, v in out.items() if k.startswith(("loss_", "gnorm_", "total"))})
 
 
 def train_golden(nr, sd, res: int, name: str, with_fp64: bool = True):

@@ -14,8 +14,17 @@ for arg in sys.argv[2:]:
         for (kn, cn), (_, tot, disp) in acc.items():
             e = out.setdefault(label, {}).setdefault(kn, {})
             e[cn] = tot / len(disp); e["launches_" + cn] = len(disp)
+import hashlib
+_h = hashlib.sha256()
+_d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dreg_nerf_amd", "csrc")
+for _f in sorted(os.listdir(_d)):
+    if _f.endswith((".hip", ".h")):
+        _h.update(open(os.path.join(_d, _f), "rb").read())
+out["kernel_source_sha"] = _h.hexdigest()[:16]      # bench.py refuses the traffic numbers once the kernels change
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 for label, ks in out.items():
+    if not isinstance(ks, dict):
+        continue
     top = sorted(ks.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", 0) * kv[1].get("launches_FETCH_SIZE", 0))[:8]
     for kn, e in top:
         print(label, kn[:70], {k: (round(v, 1) if isinstance(v, float) else v) for k, v in e.items()})
