@@ -1,0 +1,109 @@
+"""GPU: BASELINE.json configs[4] as one chain on a synthetic stand-in split (the Objaverse blocks and the trained checkpoint are external
+downloads): generated NGP blocks -> eval_ngp_nerf.py (grid extraction) -> eval_nerf_regtr.py (registration + RRE/RTE) over a split
+described by the REFERENCE's split files (objaverse.json + obj_id_names.json), then every row of metrics_test.json is re-derived on the
+CPU by the reference-pinned oracle from the extracted voxel_grid.pt / voxel_mask.pt and the ground-truth block transforms.
+Reference flow: eval_ngp_nerf.py:336-451 -> eval_nerf_regtr.py:224-301 (metrics: :24-65)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from dreg_nerf_amd import ngp, params, synth  # noqa: E402
+from dreg_nerf_amd.dataset import _small_se3  # noqa: E402
+from oracle import regtr_oracle as O  # noqa: E402
+
+RES = 32
+AABB = [-1.5] * 3 + [1.5] * 3
+
+
+def _run(args, timeout=900):
+    r = subprocess.run([sys.executable] + args, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def _make_block(path, seed):
+    """A NeRF block checkpoint in the reference's format (train_ngp_nerf.py:187-209) with generated weights: a thick occupancy shell,
+    a random hash grid / MLP (density = exp(h0 - 1) crosses the 0.7 threshold on ~1/4 of the cells), six cameras around the block."""
+    g = torch.Generator().manual_seed(seed)
+    f = ngp.NGPradianceField(AABB)
+    with torch.no_grad():
+        f.mlp_base.params[:3072] = torch.randn(3072, generator=g) * 0.4
+        f.mlp_base.params[3072:] = torch.randn(f.mlp_base.params.numel() - 3072, generator=g)
+        f.color_mlp.params.copy_(torch.randn(7168, generator=g) * 0.2)
+    c = (torch.arange(RES, dtype=torch.float32) + 0.5) / RES * 3 - 1.5
+    X, Y, Z = torch.meshgrid(c, c, c, indexing="ij")
+    rad = torch.stack([X, Y, Z], -1).norm(dim=-1)
+    binary = (rad > 0.55) & (rad < 1.05)
+    occ = ngp.OccupancyGrid(AABB, RES)
+    occ._binary.copy_(binary)
+    cams = torch.eye(4)[None].repeat(6, 1, 1)
+    cams[:, :3, 3] = torch.tensor([[2.5, 0, 0], [-2.5, 0, 0], [0, 2.5, 0], [0, -2.5, 0], [0, 0, 2.5], [0, 0, -2.5]])
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save({"step": 1, "model": f.state_dict(), "occupancy_grid": occ.state_dict(), "aabb": AABB, "unbounded": False,
+                "near_plane": None, "far_plane": None, "grid_resolution": RES, "contraction_type": ngp.ContractionType.AABB,
+                "render_step_size": 0.005, "alpha_thre": 0.0, "cone_angle": 0.0, "camera_poses": cams, "block_id": 0}, path)
+    return int(binary.sum())
+
+
+def test_extract_then_register_split_matches_oracle(tmp_path):
+    root, jdir = tmp_path / "root", tmp_path / "json"
+    jdir.mkdir()
+    scenes = {f"uid{i:02d}": f"Scene_{i:02d}" for i in range(4)}
+    # the reference's split files: object uids per split, uid -> scene directory name (dataset.py:194-216)
+    json.dump({"objaverse": {"train": [], "test": list(scenes)}}, open(jdir / "objaverse.json", "w"))
+    json.dump(scenes, open(jdir / "obj_id_names.json", "w"))
+    gt = {}
+    for i, name in enumerate(scenes.values()):
+        (root / "objaverse" / "images" / name).mkdir(parents=True)
+        tf = {}
+        for k in range(2):
+            n_occ = _make_block(str(root / "objaverse" / "nerf_models" / name / f"block_{k}" / "model.pth"), 100 * i + k)
+            assert n_occ > 3000
+            tf[str(k)] = _small_se3(0.2, torch.Generator().manual_seed(7 * i + k)).tolist()
+        json.dump(tf, open(root / "objaverse" / "images" / name / "world_frame_transforms.json", "w"))
+        gt[name] = {int(k): torch.tensor(v) for k, v in tf.items()}
+    # stage 1: grid extraction for all 8 blocks
+    out = _run(["eval_ngp_nerf.py", "--root_dir", str(root), "--dataset", "objaverse", "--multi_blocks"])
+    assert out.count("voxels kept") == 8
+    # stage 2: registration over the test split with a fixed checkpoint in the reference's format
+    sd = params.synth_state_dict(0)
+    os.makedirs(root / "out" / "chain", exist_ok=True)
+    torch.save({"step": 1, "model": sd}, str(root / "out" / "chain" / "model.pth"))
+    _run(["eval_nerf_regtr.py", "--root_dir", str(root), "--json_dir", str(jdir), "--dataset", "objaverse", "--expname", "chain",
+          "--precision", "fp32"])
+    m = json.load(open(root / "eval" / "chain" / "objaverse" / "metrics_test.json"))
+    assert set(m) == set(scenes.values()) | {"R_mean", "t_mean"}
+    # stage 3: every row re-derived by the oracle (CPU, fp32, eval-mode BatchNorm) from the files stage 1 wrote
+    r_all, t_all = [], []
+    for name in scenes.values():
+        blocks = {}
+        for k in range(2):
+            d = root / "objaverse" / "nerf_models" / name / f"block_{k}"
+            grid, mask = torch.load(str(d / "voxel_grid.pt")), torch.load(str(d / "voxel_mask.pt"))
+            assert grid.shape == (RES, RES, RES, 7) and mask.dtype == torch.int64 and mask.numel() > 50
+            assert torch.all(mask[1:] > mask[:-1]) and torch.count_nonzero(grid.reshape(-1, 7)[mask][:, :3]) > 0
+            blocks[k] = (grid.permute(3, 2, 0, 1).unsqueeze(0).contiguous(), mask)          # loader layout (dataset.py:244-248)
+        cands = []
+        for s, t in ((0, 1), (1, 0)):       # the dataset shuffles which block is the source (quirk Q15): either order is legitimate
+            pose = (gt[name][t] @ torch.linalg.inv(gt[name][s]))[None]
+            data = {"src_xyz_rgba": blocks[s][0], "tgt_xyz_rgba": blocks[t][0], "src_mask": blocks[s][1], "tgt_mask": blocks[t][1], "pose": pose}
+            with torch.no_grad():
+                pred = O.regtr_forward(params.clone_state_dict(sd), data, train=False)
+            rre, rte = O.rre_rte(pred["pose"][-1], pose)
+            cands.append((float(rre[0]), float(rte[0])))
+        row = m[name]
+        assert set(row) == {"R_mean", "t_mean", "R_med", "t_med", "time"}
+        err = min(abs(row["R_mean"] - r) / max(r, 1.0) + abs(row["t_mean"] - t) / max(t, 1e-2) for r, t in cands)
+        assert err < 2e-3, (name, row, cands)       # RRE in degrees / RTE of the HIP chain vs the oracle on the same grids
+        assert row["R_med"] == pytest.approx(row["R_mean"]) and row["time"] > 0
+        r_all.append(row["R_mean"])
+        t_all.append(row["t_mean"])
+    assert m["R_mean"] == pytest.approx(float(np.mean(r_all)), rel=1e-6) and m["t_mean"] == pytest.approx(float(np.mean(t_all)), rel=1e-6)
