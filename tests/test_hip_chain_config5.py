@@ -31,11 +31,11 @@ def _run(args, timeout=900):
 
 def _make_block(path, seed):
     """A NeRF block checkpoint in the reference's format (train_ngp_nerf.py:187-209) with generated weights: a thick occupancy shell,
-    a random hash grid / MLP (density = exp(h0 - 1) crosses the 0.7 threshold on ~1/4 of the cells), six cameras around the block."""
+    a random hash grid / MLP (density = exp(h0 - 1) with a heavy tail: some cells opaque enough to be surfaces), six cameras around the block."""
     g = torch.Generator().manual_seed(seed)
     f = ngp.NGPradianceField(AABB)
     with torch.no_grad():
-        f.mlp_base.params[:3072] = torch.randn(3072, generator=g) * 0.4
+        f.mlp_base.params[:3072] = torch.randn(3072, generator=g) * 1.0     # |h0| large enough that every block keeps ~1e3 voxels
         f.mlp_base.params[3072:] = torch.randn(f.mlp_base.params.numel() - 3072, generator=g)
         f.color_mlp.params.copy_(torch.randn(7168, generator=g) * 0.2)
     c = (torch.arange(RES, dtype=torch.float32) + 0.5) / RES * 3 - 1.5
