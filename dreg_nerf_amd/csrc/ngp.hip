@@ -36,7 +36,8 @@ __device__ __forceinline__ f16x8_t ldsfrag(const char* base, int rs, int row, in
 __global__ __launch_bounds__(256) void ngp_density_kernel(const float* __restrict__ x, const _Float16* __restrict__ table,
                                                           const _Float16* __restrict__ w1, const _Float16* __restrict__ w2,
                                                           float* __restrict__ density, _Float16* __restrict__ raw,
-                                                          NgpLevels lv, float lo0, float lo1, float lo2, float hi0, float hi1, float hi2, int Np)
+                                                          NgpLevels lv, float lo0, float lo1, float lo2, float hi0, float hi1, float hi2, int Np,
+                                                          int contract)
 {
     constexpr int XRS = 32 * 2 + 16, HRS = 64 * 2 + 16;
     __shared__ __attribute__((aligned(16))) char smem[4 * (64 * XRS + 64 * HRS + 64 * 4)];
@@ -52,8 +53,24 @@ __global__ __launch_bounds__(256) void ngp_density_kernel(const float* __restric
         const float lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
         inside = true;
 #pragma unroll
+        for (int c = 0; c < 3; ++c) u[c] = (x[(size_t)p * 3 + c] - lo[c]) / (hi[c] - lo[c]);
+        if (contract) {
+            // contract_to_unisphere (conerf/radiance_fields/ngp.py:41-63): the aabb maps to [-1,1]^3, points of norm > 1 are pulled
+            // onto the shell (2 - 1/|x|) x/|x| of radius < 2, and [-2,2]^3 maps to [0,1]^3
+            float v[3], m2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { v[c] = u[c] * 2.f - 1.f; m2 += v[c] * v[c]; }
+            const float mag = sqrtf(m2);
+            if (mag > 1.f) {
+                const float sc = (2.f - 1.f / mag) / mag;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[c] *= sc;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) u[c] = v[c] / 4.f + 0.5f;
+        }
+#pragma unroll
         for (int c = 0; c < 3; ++c) {
-            u[c] = (x[(size_t)p * 3 + c] - lo[c]) / (hi[c] - lo[c]);
             inside = inside && (u[c] > 0.f) && (u[c] < 1.f);
             u[c] = fminf(fmaxf(u[c], 0.f), 1.f);
         }
@@ -128,7 +145,7 @@ __global__ __launch_bounds__(256) void ngp_density_kernel(const float* __restric
 // w1 fp16 [64][32], w2 fp16 [64][64], w3 fp16 [16][64]; dirbias fp32 [ndir][64] = W1[:, :16] . fp16(sh_k)
 __global__ __launch_bounds__(256) void ngp_rgb_kernel(const _Float16* __restrict__ raw, const _Float16* __restrict__ w1, const _Float16* __restrict__ w2,
                                                       const _Float16* __restrict__ w3, const float* __restrict__ dirbias,
-                                                      float* __restrict__ rgb, int ndir, int Np)
+                                                      float* __restrict__ rgb, int ndir, int Np, const float* __restrict__ dirs = nullptr)
 {
     constexpr int XRS = 32 * 2 + 16, HRS = 64 * 2 + 16;
     __shared__ __attribute__((aligned(16))) char smem[4 * (64 * XRS + 2 * 64 * HRS)];
@@ -138,8 +155,22 @@ __global__ __launch_bounds__(256) void ngp_rgb_kernel(const _Float16* __restrict
     char* sH2 = sH1 + 64 * HRS;
     const int p0 = (blockIdx.x * 4 + wave) * 64;
     const int p = p0 + lane;
-    {   // X = (0 x16 | feat[1..15] | 1)
+    {   // X = (0 x16 | feat[1..15] | 1); with per-point directions (dirs != null, ndir == 1) the first 16 columns carry fp16(SH4(dir))
+        // and the first layer is the full 32-wide product instead of "geometry half + per-direction bias"
         _Float16* xr = reinterpret_cast<_Float16*>(sX + lane * XRS);
+        if (dirs && p < Np) {
+            const float x = dirs[(size_t)p * 3], y = dirs[(size_t)p * 3 + 1], z = dirs[(size_t)p * 3 + 2];
+            const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+            const float sh[16] = {0.28209479177387814f, -0.48860251190291987f * y, 0.48860251190291987f * z, -0.48860251190291987f * x,
+                                  1.0925484305920792f * xy, -1.0925484305920792f * yz, 0.94617469575755997f * z2 - 0.31539156525251999f,
+                                  -1.0925484305920792f * xz, 0.54627421529603959f * x2 - 0.54627421529603959f * y2,
+                                  0.59004358992664352f * y * (-3.0f * x2 + y2), 2.8906114426405538f * xy * z,
+                                  0.45704579946446572f * y * (1.0f - 5.0f * z2), 0.3731763325901154f * z * (5.0f * z2 - 3.0f),
+                                  0.45704579946446572f * x * (1.0f - 5.0f * z2), 1.4453057213202769f * z * (x2 - y2),
+                                  0.59004358992664352f * x * (-x2 + 3.0f * y2)};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) xr[j] = (_Float16)sh[j];
+        } else
 #pragma unroll
         for (int j = 0; j < 16; ++j) xr[j] = (_Float16)0.f;
 #pragma unroll
@@ -173,7 +204,7 @@ __global__ __launch_bounds__(256) void ngp_rgb_kernel(const _Float16* __restrict
     for (int k = 0; k < ndir; ++k) {
         float cb_[4];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) cb_[cb] = dirbias[k * 64 + cb * 16 + fr];
+        for (int cb = 0; cb < 4; ++cb) cb_[cb] = dirs ? 0.f : dirbias[k * 64 + cb * 16 + fr];
         __syncthreads();
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
@@ -297,7 +328,32 @@ int dreg_ngp_density_fwd(const float* x, const void* table, const void* w1, cons
     for (int l = 0; l < 16; ++l) { lv.offset[l] = offset[l]; lv.size[l] = size[l]; lv.res[l] = res[l]; lv.scale[l] = scale[l]; lv.hashed[l] = hashed[l]; }
     hipLaunchKernelGGL(ngp_density_kernel, dim3((Np + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)table,
                        (const _Float16*)w1, (const _Float16*)w2, density, (_Float16*)raw, lv,
-                       aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np);
+                       aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np, 0);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// the same for an unbounded scene (NGPradianceField(unbounded=True), conerf/radiance_fields/ngp.py:41-63,163-167): positions go through
+// the unisphere contraction of the aabb before the hash grid; contract = 0 is dreg_ngp_density_fwd.
+int dreg_ngp_density_fwd_contract(const float* x, const void* table, const void* w1, const void* w2, float* density, void* raw,
+                                  const uint32_t* offset, const uint32_t* size, const uint32_t* res, const float* scale, const uint32_t* hashed,
+                                  const float* aabb, int Np, int contract, void* stream)
+{
+    if (Np == 0) return DREG_OK;
+    NgpLevels lv;
+    for (int l = 0; l < 16; ++l) { lv.offset[l] = offset[l]; lv.size[l] = size[l]; lv.res[l] = res[l]; lv.scale[l] = scale[l]; lv.hashed[l] = hashed[l]; }
+    hipLaunchKernelGGL(ngp_density_kernel, dim3((Np + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)table,
+                       (const _Float16*)w1, (const _Float16*)w2, density, (_Float16*)raw, lv,
+                       aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np, contract);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// colour for ONE viewing direction per point (NGPradianceField.query_rgb(dir, embedding) / forward(positions, directions),
+// conerf/radiance_fields/ngp.py:178-208): dirs fp32 [Np,3] as passed to query_rgb, raw fp16 [Np,16] -> rgb fp32 [Np,3].
+int dreg_ngp_rgb_dir_fwd(const void* raw, const void* w1, const void* w2, const void* w3, const float* dirs, float* rgb, int Np, void* stream)
+{
+    if (Np == 0) return DREG_OK;
+    hipLaunchKernelGGL(ngp_rgb_kernel, dim3((Np + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const _Float16*)raw,
+                       (const _Float16*)w1, (const _Float16*)w2, (const _Float16*)w3, (const float*)nullptr, rgb, 1, Np, dirs);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

@@ -68,8 +68,6 @@ class NGPradianceField(nn.Module):
     def __init__(self, aabb: Union[torch.Tensor, List[float]], num_dim: int = 3, use_viewdirs: bool = True,
                  unbounded: bool = False, geo_feat_dim: int = 15, n_levels: int = 16, log2_hashmap_size: int = 19):
         super().__init__()
-        if unbounded:
-            raise NotImplementedError("unbounded scenes (contract_to_unisphere) are outside the registration path")
         if not isinstance(aabb, torch.Tensor):
             aabb = torch.tensor(aabb, dtype=torch.float32)
         assert n_levels == 16 and geo_feat_dim == 15 and num_dim == 3 and use_viewdirs
@@ -125,8 +123,10 @@ class NGPradianceField(nn.Module):
         density = torch.empty(n, dtype=torch.float32, device=x.device)
         raw = torch.empty(n, 16, dtype=torch.float16, device=x.device)
         aabb = (ctypes.c_float * 6)(*[float(v) for v in self.aabb.tolist()])
-        L.check(lib.dreg_ngp_density_fwd(L.ptr(x), base16.data_ptr() + 3072 * 2, base16.data_ptr(), base16.data_ptr() + 2048 * 2,
-                                         L.ptr(density), L.ptr(raw), *self._levels, aabb, n, L.stream()), "dreg_ngp_density_fwd")
+        # unbounded: contract_to_unisphere(x, aabb) before the hash grid (ngp.py:41-63,163-164)
+        L.check(lib.dreg_ngp_density_fwd_contract(L.ptr(x), base16.data_ptr() + 3072 * 2, base16.data_ptr(), base16.data_ptr() + 2048 * 2,
+                                                  L.ptr(density), L.ptr(raw), *self._levels, aabb, n, int(bool(self.unbounded)), L.stream()),
+                "dreg_ngp_density_fwd_contract")
         return density, raw
 
     @torch.no_grad()
@@ -159,15 +159,24 @@ class NGPradianceField(nn.Module):
 
     @torch.no_grad()
     def query_rgb(self, dir, embedding):
-        """Reference signature: one direction per point.  Implemented for the dense-query use (a single direction
-        repeated for all points, sample_grid.py:332-337); per-point directions belong to rendering (out of scope)."""
-        d = dir.reshape(-1, 3)
-        if not torch.allclose(d, d[:1].expand_as(d)):
-            raise NotImplementedError("per-point viewing directions (volume rendering) are outside the registration path")
-        raw = torch.cat([torch.zeros(embedding.reshape(-1, 15).shape[0], 1, device=embedding.device), embedding.reshape(-1, 15)], dim=1).half()
-        return self.query_rgb_mean(raw, d[:1]).view(*embedding.shape[:-1], 3)
+        """Reference signature (ngp.py:178-193): one viewing direction per point, `embedding` = the 15 geometry features
+        (query_density(..., return_feat=True)) -> rgb [..., 3].  A single direction shared by all points takes the mean-kernel's
+        folded-bias route (the dense query's 18 passes, sample_grid.py:332-337); distinct directions evaluate SH per point."""
+        lib = L.load()
+        d = dir.reshape(-1, 3).float().contiguous()
+        feat = embedding.reshape(-1, self.geo_feat_dim)
+        raw = torch.cat([torch.zeros(feat.shape[0], 1, device=feat.device, dtype=feat.dtype), feat], dim=1).half().contiguous()
+        _, col16 = self._prepared()
+        n = raw.shape[0]
+        assert d.shape[0] == n, f"{tuple(dir.shape)} v.s. {tuple(embedding.shape)}"
+        rgb = torch.empty(n, 3, dtype=torch.float32, device=raw.device)
+        L.check(lib.dreg_ngp_rgb_dir_fwd(L.ptr(raw), col16.data_ptr(), col16.data_ptr() + 2048 * 2, col16.data_ptr() + 6144 * 2, L.ptr(d.to(raw.device)),
+                                         L.ptr(rgb), n, L.stream()), "dreg_ngp_rgb_dir_fwd")
+        return rgb.view(*embedding.shape[:-1], 3).to(embedding.dtype)
 
     def forward(self, positions, directions=None):
+        """ngp.py:195-208: (rgb, density) of points seen from per-point directions."""
+        assert directions is not None and positions.shape == directions.shape, f"{positions.shape} v.s. {None if directions is None else directions.shape}"
         density, feat = self.query_density(positions, return_feat=True)
         return self.query_rgb(directions, feat), density
 

@@ -353,6 +353,12 @@ int dreg_ngp_density_fwd(const float* x, const void* table, const void* w1, cons
 /* mean over ndir fixed viewing directions of the colour net: dirbias fp32 [ndir,64] = W1[:, :16] . sh4(dir_k) */
 int dreg_ngp_rgb_mean_fwd(const void* raw, const void* w1, const void* w2, const void* w3, const float* dirbias, float* rgb,
                           int ndir, int Np, void* stream);
+/* unbounded scenes: positions pass through contract_to_unisphere (conerf/radiance_fields/ngp.py:41-63) before the hash grid */
+int dreg_ngp_density_fwd_contract(const float* x, const void* table, const void* w1, const void* w2, float* density, void* raw,
+                                  const uint32_t* offset, const uint32_t* size, const uint32_t* res, const float* scale, const uint32_t* hashed,
+                                  const float* aabb, int Np, int contract, void* stream);
+/* one viewing direction per point: NGPradianceField.query_rgb(dir, embedding) / forward (conerf/radiance_fields/ngp.py:178-208) */
+int dreg_ngp_rgb_dir_fwd(const void* raw, const void* w1, const void* w2, const void* w3, const float* dirs, float* rgb, int Np, void* stream);
 /* jittered sample of every occupied cell mapped to world space (sample_grid.py:226-242, AABB contraction) */
 int dreg_grid_sample_points(const int64_t* idx, const float* jitter, float* world, int rx, int ry, int rz, const float* aabb,
                             int Np, void* stream);

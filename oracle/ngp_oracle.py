@@ -87,10 +87,19 @@ def split_color_params(params: torch.Tensor):
     return params[:2048].view(64, 32), params[2048:6144].view(64, 64), params[6144:].view(16, 64)
 
 
-def query_density(x: torch.Tensor, aabb: torch.Tensor, mlp_base_params: torch.Tensor):
+def contract_to_unisphere(x: torch.Tensor, aabb: torch.Tensor) -> torch.Tensor:
+    """conerf/radiance_fields/ngp.py:41-63 (non-derivative branch): aabb -> [-1,1]^3, |x| > 1 -> (2 - 1/|x|) x/|x|, then /4 + 0.5."""
+    lo, hi = aabb[:3], aabb[3:]
+    v = (x - lo) / (hi - lo) * 2 - 1
+    mag = v.norm(dim=-1, keepdim=True)
+    v = torch.where(mag > 1, (2 - 1 / mag) * (v / mag), v)
+    return v / 4 + 0.5
+
+
+def query_density(x: torch.Tensor, aabb: torch.Tensor, mlp_base_params: torch.Tensor, unbounded: bool = False):
     """Returns (density [N] fp32, raw [N,16] fp16-valued: pre-activation density | 15 features)."""
     lo, hi = aabb[:3], aabb[3:]
-    u = (x - lo) / (hi - lo)
+    u = contract_to_unisphere(x, aabb) if unbounded else (x - lo) / (hi - lo)
     selector = ((u > 0.0) & (u < 1.0)).all(dim=-1)
     w1, w2, table = split_density_params(mlp_base_params)
     enc = hash_encode(u, f16(table))

@@ -98,3 +98,40 @@ def test_dense_query_and_grid_writer(tmp_path):
     assert float(flat[untouched].abs().sum()) == 0.0
     ngp.save_voxel_grid(str(tmp_path), grid, mask)
     assert torch.load(str(tmp_path / "voxel_grid.pt")).shape == (res, res, res, 7)
+
+
+def test_unbounded_contraction_and_per_point_directions_vs_oracle():
+    """NGPradianceField(unbounded=True).query_density and query_rgb / forward with one direction per point
+    (conerf/radiance_fields/ngp.py:41-63,163-167,178-208)."""
+    f = ngp.NGPradianceField(AABB, unbounded=True)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        p = f.mlp_base.params
+        p[:3072] = torch.randn(3072, generator=g) * 0.25
+        p[3072:] = torch.randn(p.numel() - 3072, generator=g) * 0.5
+        f.color_mlp.params.copy_(torch.randn(7168, generator=g) * 0.2)
+    params_b, params_c = f.mlp_base.params.detach().clone(), f.color_mlp.params.detach().clone()
+    f = f.to(DEV)
+    x = (torch.rand(5000, 3, generator=g) - 0.5) * 20.0          # far outside the aabb: the contraction keeps them inside (0,1)^3
+    x[:500] = (torch.rand(500, 3, generator=g) - 0.5) * 2.0
+    d_ref, raw_ref = N.query_density(x, torch.tensor(AABB), params_b, unbounded=True)
+    assert float((d_ref > 0).float().mean()) > 0.99             # the selector passes (almost) everything in an unbounded scene
+    dens, feat = f.query_density(x.to(DEV), return_feat=True)
+    scale = float(raw_ref.abs().max())
+    assert (feat.cpu() - raw_ref[:, 1:]).abs().max() <= 4e-3 * scale
+    ok = (raw_ref[:, 0] - 1.0).abs() < 8                          # exp() of huge logits amplifies the fp16 ulp
+    np.testing.assert_allclose(dens[:, 0].cpu()[ok].numpy(), d_ref[ok].numpy(), rtol=2e-2, atol=1e-6)
+    # one direction per point
+    dirs = torch.nn.functional.normalize(torch.randn(5000, 3, generator=g), dim=1)
+    rgb_ref = N.query_rgb(dirs, raw_ref, params_c)
+    rgb = f.query_rgb(dirs.to(DEV), feat)
+    assert (rgb.cpu() - N.query_rgb(dirs, torch.cat([raw_ref[:, :1], feat.cpu()], 1), params_c)).abs().max() < 4e-3
+    assert (rgb.cpu() - rgb_ref).abs().max() < 2e-2
+    rgb2, dens2 = f(x.to(DEV), dirs.to(DEV))
+    assert torch.equal(rgb2, rgb) and torch.equal(dens2, dens)
+    # a single shared direction agrees with the dense query's folded-bias kernel
+    one = dirs[:1].expand(5000, 3).contiguous()
+    raw16 = torch.cat([torch.zeros(5000, 1, device=DEV), feat], 1).half()
+    a = f.query_rgb(one.to(DEV), feat)
+    b = f.query_rgb_mean(raw16, one[:1].to(DEV))
+    assert (a - b).abs().max() < 4e-3
