@@ -68,6 +68,8 @@ struct Exec {
     bool use_aux = true;
     const uint8_t* in_rowocc = nullptr;   // output-row occupancy of the convolution that reads the network input (may be null)
     char* pack_base = nullptr;            // device address of the pack buffer (dreg_exec_export_pack_table)
+    std::vector<char> written;            // backward pass state, kept across the segments of dreg_exec_backward_range
+    bool aux_used = false;
 };
 
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -346,16 +348,30 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
 // grad_out: gradient of the result tensor (bf16, same shape).  Weight / bias / BatchNorm gradients are ACCUMULATED into the
 // parameters' grad pointers; nothing is returned for the input tensor 0.  aux_stream (optional): a second stream of the caller's
 // for the weight / bias gradient launches; `stream` waits for it before this call's work is considered complete.
+int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const void* pack_base, const void* x_in, const void* grad_out,
+                             const int64_t* rowlists, int nlists, void* stream, void* aux_stream, int op_begin, int op_end, int flags);
 int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pack_base, const void* x_in, const void* grad_out,
                        const int64_t* rowlists, int nlists, void* stream, void* aux_stream)
 {
+    return dreg_exec_backward_range(h, arena, arena_bytes, pack_base, x_in, grad_out, rowlists, nlists, stream, aux_stream,
+                                    0, (int)((Exec*)h)->ops.size(), 3);
+}
+// The same in segments: ops [op_begin, op_end) are processed in reverse order; flags bit 0 = first segment of a pass (the one that
+// contains the last op), bit 1 = last segment (the caller's stream then joins the parameter-gradient stream).  Between two segments
+// the caller may record events on both streams: every parameter gradient of the ops processed so far has been enqueued — the
+// data-parallel step launches the all-reduce of finished gradient buckets there (dreg_nerf_amd/optim.py GradSync).
+int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const void* pack_base, const void* x_in, const void* grad_out,
+                             const int64_t* rowlists, int nlists, void* stream, void* aux_stream, int op_begin, int op_end, int flags)
+{
     Exec* e = (Exec*)h;
-    if (arena_bytes < e->arena_bytes) return DREG_EINVAL;
+    if (arena_bytes < e->arena_bytes || op_begin < 0 || op_end > (int)e->ops.size() || op_begin > op_end) return DREG_EINVAL;
     char* A = (char*)arena;
     const char* PK = (const char*)pack_base;
     hipStream_t st = (hipStream_t)stream;
     auto act = [&](int s) -> void* { return s == 0 ? (void*)x_in : (void*)(A + e->t[s].off); };
-    std::vector<char> written(e->t.size(), 0);
+    if (flags & 1) { e->written.assign(e->t.size(), 0); e->aux_used = false; }
+    if (e->written.size() != e->t.size()) return DREG_EINVAL;
+    std::vector<char>& written = e->written;
     auto grad = [&](int s) -> void* { return s == e->out_slot ? (void*)grad_out : (void*)(A + e->t[s].goff); };
     // destination for a new contribution to tensor s: its gradient buffer the first time, the temporary afterwards (then add)
     auto dst_for = [&](int s) -> void* { return written[s] ? (void*)(A + e->off_tmp) : grad(s); };
@@ -376,8 +392,8 @@ int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pac
         e->ev.assign(e->ops.size(), nullptr);
         if (hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) != hipSuccess) aux_on = false;
     }
-    bool aux_used = false;
-    for (int i = (int)e->ops.size() - 1; i >= 0; --i) {
+    bool& aux_used = e->aux_used;
+    for (int i = op_end - 1; i >= op_begin; --i) {
         const Op& o = e->ops[i];
         const Tensor& x = e->t[o.in];
         const Tensor& y = e->t[o.out];
@@ -481,7 +497,7 @@ int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pac
             CK(commit(o.in));
         }
     }
-    if (aux_used) {   // the caller's stream continues (optimizer) only after every parameter gradient has landed
+    if ((flags & 2) && aux_used) {   // the caller's stream continues (optimizer) only after every parameter gradient has landed
         if (hipEventRecord(e->ev_done, e->aux) != hipSuccess || hipStreamWaitEvent(st, e->ev_done, 0) != hipSuccess) return DREG_ELAUNCH;
     }
     return DREG_OK;

@@ -101,6 +101,7 @@ SIGNATURES = {
     "dreg_exec_read_timings": (I, [P, P, P, I]),
     "dreg_exec_forward": (I, [P, P, Z, P, P, P, I, I, P]),
     "dreg_exec_backward": (I, [P, P, Z, P, P, P, P, I, P, P]),
+    "dreg_exec_backward_range": (I, [P, P, Z, P, P, P, P, I, P, P, I, I, I]),
     # attention.hip
     "dreg_mha_fwd": (I, [P] * 5 + [I] * 7 + [F, I, P]),
     "dreg_mha_bwd": (I, [P] * 10 + [I] * 7 + [F, I, P]),

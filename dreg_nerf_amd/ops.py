@@ -347,6 +347,8 @@ DIRECT_GRAD_ACCUMULATE = True
 # torch.cuda.Stream for the weight / bias gradient launches of Conv3dFn.backward while a caller that joins it afterwards is
 # running the backward pass (train_step.TrainStep); None = everything on the current stream
 PARAM_GRAD_STREAM = None
+# optim.GradSync of a data-parallel step while its backward pass runs (the native trunk executor reports finished gradient ranges to it)
+GRAD_SYNC = None
 
 
 def downsample_sum(g, coarse_shape):

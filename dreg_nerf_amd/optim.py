@@ -55,6 +55,11 @@ class FlatAdamW:
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + off * 4:
                 p.grad = self.flat_g[off:off + p.numel()].view(p.shape)
 
+    def offset_of(self, grad_ptr: int) -> int:
+        """Element offset inside the flat gradient buffer of a .grad view's data pointer (-1: not one of ours)."""
+        d = grad_ptr - self.flat_g.data_ptr()
+        return d // 4 if 0 <= d < self.n * 4 else -1
+
     def all_reduce_mean(self, world: int, bucket_elems: int = (25 << 20) // 4):
         """Average gradients over the ranks: async all-reduce of ~25 MB slices issued from the END of the buffer
         (decoder/transformer/FPN-head gradients, which backward produces first, sit at the highest offsets)."""
@@ -132,3 +137,65 @@ class StepLR:
         self.last_epoch = sd.get("last_epoch", 0)
         self.base_lr = sd.get("base_lrs", [self.base_lr])[0]
         self.opt.param_groups[0]["lr"] = self.base_lr * self.gamma ** (self.last_epoch // self.step_size)
+
+
+class GradSync:
+    """Gradient averaging of a data-parallel step OVERLAPPED with the backward pass: the flat gradient buffer is cut
+    into ~25 MB buckets from its END (decoder / transformer / FPN head: what backward finishes first); whoever drives backward calls
+    ready(lo) as soon as every gradient at element offsets >= lo has been ENQUEUED (on the main stream and the parameter-gradient
+    stream); every whole bucket above `lo` is then all-reduced on the collective's own stream behind events of both streams, while
+    backward continues.  finish() launches what is left and makes the current stream wait for all of it.
+    Averaging: ReduceOp.AVG on RCCL ('nccl'); SUM + one division on backends without AVG (gloo)."""
+
+    def __init__(self, opt: FlatAdamW, world: int, bucket_bytes: int = 25 << 20, streams=(), reduce_fn=None):
+        self.opt, self.world = opt, world
+        be = max(bucket_bytes // 4, 1)
+        self.buckets = []                      # (lo, hi) from the end of the UPDATED range (never-used parameters have no gradient)
+        hi = opt.n_active
+        while hi > 0:
+            lo = max(0, hi - be)
+            self.buckets.append((lo, hi))
+            hi = lo
+        self.extra_streams = list(streams)     # streams besides the current one that produce gradients (parameter-gradient stream)
+        self.reduce_fn = reduce_fn             # tests: called instead of torch.distributed with (lo, hi)
+        self._use_avg = reduce_fn is None and world > 1 and dist.get_backend() == "nccl"
+        self._side = None
+        self.begin()
+
+    def begin(self):
+        self.next, self.handles, self.launched = 0, [], []
+
+    def _launch(self, lo, hi):
+        self.launched.append((lo, hi))
+        if self.reduce_fn is not None:
+            self.reduce_fn(lo, hi)
+            return
+        g = self.opt.flat_g[lo:hi]
+        if g.is_cuda:
+            cur = torch.cuda.current_stream(g.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=g.device)
+            self._side.wait_stream(cur)        # events, not host waits: the collective starts when both producers reach this point
+            for s in self.extra_streams:
+                self._side.wait_stream(s)
+            with torch.cuda.stream(self._side):
+                h = dist.all_reduce(g, op=dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM, async_op=True)
+            g.record_stream(self._side)
+        else:
+            h = dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True)
+        self.handles.append(h)
+
+    def ready(self, lo: int):
+        """All gradients at offsets >= lo are enqueued: launch every not-yet-launched bucket that lies entirely above lo."""
+        while self.next < len(self.buckets) and self.buckets[self.next][0] >= lo:
+            self._launch(*self.buckets[self.next])
+            self.next += 1
+
+    def finish(self):
+        self.ready(0)
+        for h in self.handles:
+            h.wait()                           # the current stream waits for the collective (no host block on 'nccl')
+        if self.reduce_fn is None and not self._use_avg and self.world > 1:
+            self.opt.flat_g[:self.opt.n_active].div_(self.world)
+        if self._side is not None:
+            torch.cuda.current_stream(self.opt.flat_g.device).wait_stream(self._side)

@@ -17,7 +17,7 @@ from . import fused_losses as FL
 from . import losses as LS
 from . import ops
 from . import synth
-from .optim import FlatAdamW, StepLR
+from .optim import FlatAdamW, GradSync, StepLR
 
 
 def nerf_labels(pred, data):
@@ -66,6 +66,7 @@ class TrainStep:
         self.overlap_param_grads = bool(int(os.environ.get("DREG_PG_STREAM", "1"))) and not bool(int(os.environ.get("DREG_SERIAL_STREAMS", "0")))
         self._pg_stream = None
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self._sync = None
         self.last_losses = None
         self.last_preds = None
 
@@ -108,6 +109,31 @@ class TrainStep:
                     agg[k] = agg.get(k, 0.0) + v.detach()
             total = total / len(batch)
         dev = next(self.model.parameters()).device
+        sync = None
+        if self.world > 1:
+            # gradient averaging overlapped with backward: buckets of the flat gradient buffer are all-reduced as soon as backward
+            # has produced them (optim.GradSync; the trunk executor reports progress between its segments)
+            if self._sync is None:
+                from .trunk_exec import aux_stream
+                self._sync = GradSync(self.optimizer, self.world, streams=[aux_stream(dev)] if dev.type == "cuda" else [])
+            sync = self._sync
+            sync.begin()
+            ops.GRAD_SYNC = sync
+        try:
+            self._backward(total, dev)
+        finally:
+            ops.GRAD_SYNC = None
+        if sync is not None:
+            sync.finish()
+        self.optimizer.step()          # clip_grad_norm_(grad_clip) folded into the AdamW kernel
+        gnorm = self.optimizer.grad_norm()
+        if not self.finetune:
+            self.scheduler.step()
+        self.last_losses = {k: v / len(batch) for k, v in agg.items()}
+        self.last_preds = preds
+        return {"losses": self.last_losses, "grad_norm": gnorm}
+
+    def _backward(self, total, dev):
         if self.overlap_param_grads and dev.type == "cuda":
             # weight / bias gradients of the point-set half's linear layers on a side stream, next to the data-gradient chain
             if self._pg_stream is None:
@@ -121,12 +147,3 @@ class TrainStep:
             torch.cuda.current_stream(dev).wait_stream(self._pg_stream)
         else:
             total.backward()
-        if self.world > 1:
-            self.optimizer.all_reduce_mean(self.world)
-        self.optimizer.step()          # clip_grad_norm_(grad_clip) folded into the AdamW kernel
-        gnorm = self.optimizer.grad_norm()
-        if not self.finetune:
-            self.scheduler.step()
-        self.last_losses = {k: v / len(batch) for k, v in agg.items()}
-        self.last_preds = preds
-        return {"losses": self.last_losses, "grad_norm": gnorm}

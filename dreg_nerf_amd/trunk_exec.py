@@ -218,9 +218,51 @@ class TrunkExecutor:
 
     def backward(self, x: torch.Tensor, rows, grad_out: torch.Tensor):
         ra, n = self._rowlist_array(rows)
-        L.check(self.lib.dreg_exec_backward(self.h, L.ptr(self.arena), self.arena_bytes, L.ptr(self.pack), L.ptr(x), L.ptr(grad_out),
-                                            ctypes.addressof(ra) if ra is not None else None, n, L.stream(), aux_stream(self.device).cuda_stream),
-                "dreg_exec_backward")
+        sync = ops.GRAD_SYNC
+        if sync is None:
+            L.check(self.lib.dreg_exec_backward(self.h, L.ptr(self.arena), self.arena_bytes, L.ptr(self.pack), L.ptr(x), L.ptr(grad_out),
+                                                ctypes.addressof(ra) if ra is not None else None, n, L.stream(), aux_stream(self.device).cuda_stream),
+                    "dreg_exec_backward")
+            return
+        # data-parallel step: backward in segments; after each, the gradient buckets it completed start their all-reduce
+        plan = self._sync_plan(sync)
+        sync.ready(plan["above"])              # everything past the trunk's parameters (transformer, decoder) was produced before this call
+        hi = len(self.rec.ops)
+        for k, (lo_op, done_from) in enumerate(plan["cuts"]):
+            flags = (1 if k == 0 else 0) | (2 if k == len(plan["cuts"]) - 1 else 0)
+            L.check(self.lib.dreg_exec_backward_range(self.h, L.ptr(self.arena), self.arena_bytes, L.ptr(self.pack), L.ptr(x), L.ptr(grad_out),
+                                                      ctypes.addressof(ra) if ra is not None else None, n, L.stream(), aux_stream(self.device).cuda_stream,
+                                                      lo_op, hi, flags), "dreg_exec_backward_range")
+            hi = lo_op
+            sync.ready(done_from)
+
+    def _sync_plan(self, sync):
+        """Segments of the backward pass for GradSync: ops are processed last to first; after the segment ending at op `lo_op` every
+        parameter at flat-gradient offsets >= done_from is final.  Cuts are placed where done_from crosses a bucket boundary."""
+        key = (id(sync.opt), tuple(sync.buckets))
+        if getattr(self, "_plan_key", None) == key:
+            return self._plan
+        spans = {}                                      # parameter index -> (offset, numel) in the flat gradient buffer
+        for i, t in enumerate(self.rec.params):
+            g = t.grad if (isinstance(t, torch.nn.Parameter) and t.requires_grad) else None
+            off = sync.opt.offset_of(g.data_ptr()) if g is not None else -1
+            if off >= 0:
+                spans[i] = (off, t.numel())
+        touched = [[p for p in (o[4], o[5]) if p in spans] for o in self.rec.ops]          # conv: w, b; BatchNorm: gamma, beta
+        above = max((off + n for off, n in spans.values()), default=0)
+        pending = dict(spans)
+        bounds = sorted({lo for lo, _ in sync.buckets}, reverse=True)
+        cuts, last_done = [], above
+        for i in range(len(self.rec.ops) - 1, -1, -1):
+            for p in touched[i]:
+                pending.pop(p, None)
+            done_from = max((off + n for off, n in pending.values()), default=0)          # everything above the highest unfinished parameter
+            crossed = [b for b in bounds if done_from <= b < last_done]
+            if crossed or i == 0:
+                cuts.append((i, done_from))
+                last_done = done_from
+        self._plan_key, self._plan = key, {"above": above, "cuts": cuts}
+        return self._plan
 
     # ------------------------------------------------------------------ timing (bench.py's roofline line)
     def set_input_row_occupancy(self, row_occ):

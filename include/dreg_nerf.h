@@ -236,6 +236,10 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
                       const int64_t* rowlists, int nlists, int train, void* stream);
 int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pack_base, const void* x_in,
                        const void* grad_out, const int64_t* rowlists, int nlists, void* stream, void* aux_stream);
+/* the same in segments (ops [op_begin, op_end) in reverse order; flags bit 0 = first segment of the pass, bit 1 = last): between two
+ * segments every parameter gradient of the ops processed so far has been enqueued on `stream` / `aux_stream` */
+int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const void* pack_base, const void* x_in, const void* grad_out,
+                             const int64_t* rowlists, int nlists, void* stream, void* aux_stream, int op_begin, int op_end, int flags);
 
 /* ---------------------------------------------------------------------------------------------- point-set half
  * Attention core of nn.MultiheadAttention (8 heads, d_head 32; transformer.py:242-281): q [Nq,ldq], k [Nk,ldk],

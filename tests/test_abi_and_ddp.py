@@ -94,3 +94,55 @@ def test_grad_buckets_gloo_world2():
         exp = (1.0 * (i + 1) + (0.0 if i == 2 else 2.0 * (i + 1))) / 2
         for r in range(2):
             assert all(abs(v - exp) < 1e-6 for v in res[r][i])
+
+
+def _sync_worker(rank, world, port, q):
+    """GradSync (the overlapped gradient averaging of train_step.TrainStep) over gloo: rank r holds the gradient of 'its' pair; after
+    the bucketed all-reduce — launched in pieces while 'backward' reports progress — both ranks hold the gradient of the 1-rank step on
+    the concatenated batch [pair a, pair b] (loss = mean over pairs), bit for bit the same on both."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dreg_nerf_amd.optim import FlatAdamW, GradSync
+    sizes = (7, 300, 5, 1000, 64, 129)
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in sizes]
+    opt = FlatAdamW(ps, never_used=[ps[2]])                     # one parameter takes no part in the forward pass: it sits past n_active
+    assert opt.n_active == sum(sizes) - 5 and opt.offsets[2] == opt.n_active
+    opt.zero_grad()
+    g = torch.Generator().manual_seed(100 + rank)               # this rank's pair
+    mine = torch.randn(opt.n_active, generator=g)
+    opt.flat_g[:opt.n_active].copy_(mine)
+    sync = GradSync(opt, world, bucket_bytes=256 * 4)
+    # backward produces the buffer from its end: progress reports at arbitrary offsets, finish() sweeps the rest
+    order = []
+    for lo in (1400, 1100, 1100, 700, 123):
+        sync.ready(lo)
+        order.append(len(sync.launched))
+    sync.finish()
+    q.put((rank, mine.tolist(), opt.flat_g.tolist(), sync.launched, order, sync.buckets))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_sync_two_ranks_equal_one_rank_on_concatenated_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29811 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=120) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_active = len(res[0][0])
+    want = ((torch.tensor(res[0][0]) + torch.tensor(res[1][0])) / 2).tolist()        # d/dtheta of mean(loss_a, loss_b)
+    for r in range(2):
+        mine, flat, launched, order, buckets = res[r]
+        assert flat[:n_active] == want and all(v == 0.0 for v in flat[n_active:])     # never-used tail untouched
+        # buckets: launched from the END of the buffer, each exactly once, covering [0, n_active)
+        assert launched == buckets and launched[0][1] == n_active and launched[-1][0] == 0
+        assert all(a[0] == b[1] for a, b in zip(launched, launched[1:]))
+        # a bucket starts only once everything above its lower bound was reported ready
+        assert order == sorted(order) and order[0] == sum(1 for lo, _ in buckets if lo >= 1400) and order[-1] == sum(1 for lo, _ in buckets if lo >= 123)
+    assert res[0][1] == res[1][1]

@@ -139,3 +139,53 @@ def test_stem_row_skipping_does_not_change_a_training_step():
         torch.cuda.synchronize()
         res.append((ls, ts.optimizer.flat_p.clone()))
     assert all(np.isfinite(res[0][0])) and res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+
+
+def test_segmented_backward_reports_gradient_buckets_in_order_and_changes_nothing():
+    """Data-parallel overlap (optim.GradSync): with a sync object installed, the executor runs its backward pass in segments and reports
+    finished gradient ranges between them.  Same launches in the same order: every gradient is bitwise what the one-call backward
+    gives; the buckets are launched from the end of the flat buffer, each once, the first ones BEFORE the last segment was issued."""
+    from dreg_nerf_amd.optim import GradSync
+    from dreg_nerf_amd.train_step import TrainStep
+    data = synth.shell_pair(64, 1, 2, pose=synth.fixed_pose())
+    data = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in data.items()}
+    grads = []
+    for use_sync in (False, True):
+        torch.manual_seed(0)
+        m = NeRFRegTr(precision="bf16").to(DEV).train()
+        ts = TrainStep(m)
+        log = []
+        if use_sync:
+            ts.world = 2                                          # drive the data-parallel code path with a recording stand-in for the collective
+            ts._sync = GradSync(ts.optimizer, 2, bucket_bytes=25 << 20, reduce_fn=lambda lo, hi: log.append(("reduce", lo, hi)))
+            ex_backward = None
+        ts.optimizer.max_norm = 0.0                              # keep the raw gradients in the buffer (no in-place clipping)
+        if use_sync:
+            from dreg_nerf_amd import trunk_exec
+            orig = trunk_exec.TrunkExecutor.backward
+
+            def spy(self, x, rows, g):
+                plan = self._sync_plan(ops.GRAD_SYNC)
+                log.append(("plan", len(plan["cuts"]), plan["above"]))
+                return orig(self, x, rows, g)
+            trunk_exec.TrunkExecutor.backward = spy
+            try:
+                ts.step([data])
+            finally:
+                trunk_exec.TrunkExecutor.backward = orig
+        else:
+            ts.step([data])
+        torch.cuda.synchronize()
+        grads.append(ts.optimizer.flat_g.clone())
+        if use_sync:
+            sync = ts._sync
+            plans = [e for e in log if e[0] == "plan"]
+            reduces = [(lo, hi) for tag, lo, hi in (e for e in log if e[0] == "reduce")]
+            assert plans and plans[0][1] >= 4, plans              # 244 MB of fp32 gradients in 25 MB buckets: several segments
+            assert reduces == sync.buckets and reduces[0][1] == ts.optimizer.n_active and reduces[-1][0] == 0
+            # transformer + decoder buckets (everything above the trunk's parameters) are launched before the trunk's backward starts
+            first_plan = log.index(plans[0])
+            assert any(e[0] == "reduce" for e in log[:first_plan + 1]) or plans[0][2] >= sync.buckets[0][0]
+            n_before_last = sum(1 for e in log if e[0] == "reduce")
+            assert n_before_last == len(sync.buckets)
+    assert torch.equal(grads[0], grads[1])
