@@ -346,8 +346,14 @@ class NeRFRegTr(nn.Module):
             if side is None or side.device != dev:
                 side = self.__dict__["_geo_stream"] = torch.cuda.Stream(device=dev, priority=-1)
             for d in batch:
-                if d.get("ready_event") is not None:
-                    side.wait_event(d["ready_event"])
+                if d.get("ready_event") is not None:      # produced on a loader stream (dataset.PrefetchLoader): wait on the GPU and tell
+                    side.wait_event(d["ready_event"])     # the allocator that these streams read the sample's tensors
+                    main.wait_event(d["ready_event"])
+                    for v in d.values():
+                        for t in ((v.idx, v.vals) if hasattr(v, "vals") else (v,)):
+                            if torch.is_tensor(t) and t.is_cuda:
+                                t.record_stream(side)
+                                t.record_stream(main)
             with torch.cuda.stream(side):
                 geo = self._geometry(batch, dev)
             main.wait_stream(side)

@@ -8,6 +8,7 @@ No data:     python train_nerf_regtr.py --synthetic 16 --synthetic_res 128 --epo
 """
 import os
 import random
+import time
 
 import torch
 import torch.distributed as dist
@@ -15,7 +16,7 @@ import torch.distributed as dist
 from dreg_nerf_amd import losses as LS
 from dreg_nerf_amd.checkpoint import CheckPointManager
 from dreg_nerf_amd.config import config_parser
-from dreg_nerf_amd.dataset import NeRFRegDataset, SyntheticRegDataset
+from dreg_nerf_amd.dataset import NeRFRegDataset, PrefetchLoader, SyntheticRegDataset
 from dreg_nerf_amd.regtr import NeRFRegTr
 from dreg_nerf_amd.train_step import TrainStep
 
@@ -87,10 +88,14 @@ def main():
         if usable == 0:
             raise SystemExit(f"{len(ids)} training scenes < world ({world}) x pairs_per_step ({per_step}): nothing to train on")
         ids = ids[:usable][rank::world]
+        # on-disk data: samples are read, uploaded and augmented two steps ahead on a loader thread / stream
+        loader = PrefetchLoader(train_ds, ids, dev, depth=2 * per_step) if cfg.synthetic == 0 else None
+        t_epoch, n_pairs = time.time(), 0
         for b in range(0, len(ids) - per_step + 1, per_step):
-            batch = [to_device(train_ds[i], dev) for i in ids[b:b + per_step]]
+            batch = [next(loader) for _ in range(per_step)] if loader is not None else [to_device(train_ds[i], dev) for i in ids[b:b + per_step]]
             out = ts.step(batch)
             iteration += 1
+            n_pairs += per_step
             if rank == 0 and iteration % cfg.n_tensorboard == 0:
                 pred, data = ts.last_preds[0], batch[0]
                 err = LS.evaluate_camera_alignment(pred["pose"][-1].detach(), data["pose"])
@@ -103,6 +108,12 @@ def main():
                 print(f"val it {iteration}: R_mean={r:.3f} t_mean={t:.4f}", flush=True)
             if iteration % cfg.n_checkpoint == 0 and rank == 0:
                 ckpt.save(models, {"optimizer": ts.optimizer}, iteration, schedulers={"scheduler": ts.scheduler}, score=score)
+        torch.cuda.synchronize()
+        if rank == 0:
+            dt = time.time() - t_epoch
+            msg = f"epoch {epoch}: {n_pairs} pairs on this rank in {dt:.2f}s = {n_pairs * world / dt:.1f} pairs/s over {world} GPU(s), input pipeline included"
+            print(msg, flush=True)
+            log.write(msg + "\n"); log.flush()
     if rank == 0:
         score, r, t = validate(model, val_ds, dev)
         print(f"final val: R_mean={r:.3f} t_mean={t:.4f}", flush=True)
