@@ -17,6 +17,7 @@
 #include <cstring>
 #include <vector>
 #include "../../include/dreg_nerf.h"
+#include "../../include/dreg_nerf_tuning.h"   // dreg_conv_get_glds (read only)
 #ifndef DREG_ELAUNCH
 #define DREG_ELAUNCH (-2)
 #endif

@@ -86,13 +86,7 @@ size_t dreg_conv3_halo_pack_bytes(int Cin_reduced);
 int dreg_pack_conv_weight_halo(const float* w, void* out, int Cout, int Cin, int transposed, void* stream);
 int dreg_conv3_halo(const void* in, const void* wpk, void* out, const float* bias, const void* addend,
                     int B, int D, int H, int W, int Cin, int Da, int Ha, int Wa, int add_same, int out_f32, void* stream);
-/* experiments (tools/bench_conv_halo.py): 0 = anti-phase wave groups, weights 2 units ahead (default); 1 = lockstep; 2 = 3 units ahead */
-void dreg_conv3_halo_set_variant(int variant);
-void dreg_conv3_halo_set_prof(void* u64_buf_64x8x5);   /* variant 5: per-wave shader-clock breakdown of the first 64 workgroups */
 
-/* 1 (default): bf16 stride-1 convolutions stage operands with buffer_load...lds; 0: register-staged kernel (A/B checks) */
-void dreg_conv_set_glds(int enable);
-int dreg_conv_get_glds(void);
 /* Data gradient of a stride-2 convolution (ksz 3 / pad 1: resnet3d.py conv2 of the first block of layer2-4; ksz 1 / pad 0: the
  * downsample branch) without the 7/8 structurally-zero taps of the gather form: ONE 2^3-tap convolution over dOut whose
  * 8 x Cin output channels are the 8 parity classes of dIn (scattered in place by the epilogue).  bf16 only;
@@ -102,10 +96,6 @@ int dreg_conv3d_dgrad_s2(const void* gout, const void* wt_class_packed, void* di
 
 /* Weight gradient (split over voxels, deterministic two-stage reduction):
  * dw[Cout][Cin_real][ksz^3] (fp32, torch layout) (+)= sum_m gout[m,:]^T x in[gather(m, tap), :]. */
-/* tuning / test knob: force the number of voxel splits of the weight-gradient kernels (0 = automatic) */
-void dreg_conv_set_wgrad_splits(int splits);
-void dreg_conv_set_glds_stages(int stages);          /* LDS pipeline stages of the direct-to-LDS convolution: 0 = default (2), 2..4 forces; results do not depend on it */
-void dreg_conv_set_wgrad_target_blocks(int blocks);   /* workgroups the automatic split choice aims for (default 3072) */
 int dreg_conv3d_wgrad_splits(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int dtype);
 size_t dreg_conv3d_wgrad_workspace_bytes(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int dtype);
 int dreg_conv3d_wgrad(const void* gout, const void* in, float* dw, void* workspace, size_t workspace_bytes,

@@ -1,0 +1,27 @@
+/* Tuning / experiment switches of libdreg_nerf_hip.so — NOT part of the drop-in boundary (include/dreg_nerf.h).
+ *
+ * These are process-global knobs used by the A/B tools under tools/ and by a few tests to force a kernel variant; the product path
+ * (dreg_nerf_amd/, the entry points, bench.py's timed region) never calls a setter (it reads dreg_conv_get_glds), and every entry point of dreg_nerf.h gives the same
+ * results whatever they are set to (variants differ in speed only, except the halo kernel's ablation variants >= 11, which are
+ * timing experiments with wrong results and are reachable from tools/bench_conv_halo.py only). */
+#ifndef DREG_NERF_TUNING_H
+#define DREG_NERF_TUNING_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* experiments (tools/bench_conv_halo.py): 0 = anti-phase wave groups, weights 2 units ahead (default); 1 = lockstep; 2 = 3 units ahead */
+void dreg_conv3_halo_set_variant(int variant);
+void dreg_conv3_halo_set_prof(void* u64_buf_64x8x5);   /* variant 5: per-wave shader-clock breakdown of the first 64 workgroups */
+/* 1 (default): bf16 stride-1 convolutions stage operands with buffer_load...lds; 0: register-staged kernel (A/B checks) */
+void dreg_conv_set_glds(int enable);
+int dreg_conv_get_glds(void);
+/* tuning / test knob: force the number of voxel splits of the weight-gradient kernels (0 = automatic) */
+void dreg_conv_set_wgrad_splits(int splits);
+void dreg_conv_set_glds_stages(int stages);          /* LDS pipeline stages of the direct-to-LDS convolution: 0 = default (2), 2..4 forces; results do not depend on it */
+void dreg_conv_set_wgrad_target_blocks(int blocks);   /* workgroups the automatic split choice aims for (default 3072) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
