@@ -346,6 +346,190 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(const T* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ small volumes: fused passes
+// The 16^3 / 8^3 / 4^3 levels of the ResNet (layer2-4: 42 of the 53 BatchNorms, V = 4096 / 512 / 64 voxels per grid) are launch
+// latency in the three-kernel form (statistics, finalize, apply: ~25 us for a few us of traffic).  Statistics are per GRID and per
+// channel, so a workgroup that owns (grid b, 4 channel granules = 64 bytes of every row) needs nobody else for the normalisation:
+// statistics of its rows (fp32 per thread, xor-shuffle tree over the 16 row lanes of a wave, the four waves summed in fp64 in a
+// fixed order), scale / shift, then the apply pass over the same rows (L2-warm) — ONE launch instead of two, no cross-workgroup
+// coupling.  What does couple the grids — the running statistics (sequential over the grids, as the reference's one-grid-per-call
+// updates: nerf_regtr.py:135) and dgamma / dbeta (sum over the grids) — is a second, tiny launch over the per-grid results.
+// (A "last block arrives" single launch was measured 3x slower than three launches: the agent-scope fence writes the L2 back; a
+// single launch that walks the grids in sequence starves the chip: 8-64 workgroups with 8 dependent passes each.)
+constexpr int BNS_COLS = 4, BNS_ROWS = 64;      // 256 threads = 4 granule columns x 64 row lanes
+template <int G> __device__ __forceinline__ void bns_reduce(float (&s1)[G], float (&s2)[G], float (*red)[BNS_COLS][16], int t)
+{
+    // lanes of a wave: col = lane & 3, row lane = lane >> 2 (16 per wave): xor over lane bits 2..5
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1)
+#pragma unroll
+        for (int i = 0; i < G; ++i) { s1[i] += __shfl_xor(s1[i], o, 64); s2[i] += __shfl_xor(s2[i], o, 64); }
+    const int lane = t & 63, wave = t >> 6;
+    if (lane < BNS_COLS) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) { red[wave][lane][i] = s1[i]; red[wave][lane][8 + i] = s2[i]; }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ scale_shift, float* __restrict__ mean_rstd, float* __restrict__ var_out,
+                                                           int V, int C, float eps, int relu)
+{
+    constexpr int G = Gran<T>::G;
+    const int t = threadIdx.x, col = t & (BNS_COLS - 1), rl = t >> 2, b = blockIdx.y;
+    const int c0 = (blockIdx.x * BNS_COLS + col) * G;               // first channel of this thread's granule
+    __shared__ float red[4][BNS_COLS][16];
+    __shared__ float s_sc[BNS_COLS * 8], s_sh[BNS_COLS * 8];
+    float s1[G], s2[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) s1[i] = s2[i] = 0.f;
+#pragma unroll 4
+    for (int v = rl; v < V; v += BNS_ROWS) {
+        float xv[G];
+        Gran<T>::ld(x + ((size_t)b * V + v) * C + c0, xv);
+#pragma unroll
+        for (int i = 0; i < G; ++i) { s1[i] += xv[i]; s2[i] += xv[i] * xv[i]; }
+    }
+    bns_reduce<G>(s1, s2, red, t);
+    __syncthreads();
+    if (t < BNS_COLS * G) {
+        const int cc = t / G, ci = t % G, myc = blockIdx.x * BNS_COLS * G + t;
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a1 += red[w][cc][ci]; a2 += red[w][cc][8 + ci]; }
+        const double mean = a1 / V;
+        double var = a2 / V - mean * mean;
+        if (var < 0) var = 0;
+        const float rstd = 1.0f / sqrtf((float)var + eps);
+        const float ga = gamma[myc], be = beta[myc];
+        const float sc = ga * rstd, sh = be - (float)mean * ga * rstd;
+        scale_shift[((size_t)b * C + myc) * 2] = sc;
+        scale_shift[((size_t)b * C + myc) * 2 + 1] = sh;
+        mean_rstd[((size_t)b * C + myc) * 2] = (float)mean;
+        mean_rstd[((size_t)b * C + myc) * 2 + 1] = rstd;
+        var_out[(size_t)b * C + myc] = (float)var;
+        s_sc[t] = sc; s_sh[t] = sh;
+    }
+    __syncthreads();
+    float sc[G], sh[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) { sc[i] = s_sc[col * G + i]; sh[i] = s_sh[col * G + i]; }
+#pragma unroll 4
+    for (int v = rl; v < V; v += BNS_ROWS) {
+        const size_t off = ((size_t)b * V + v) * C + c0;
+        float xv[G], rvv[G];
+        Gran<T>::ld(x + off, xv);
+        if (res) Gran<T>::ld(res + off, rvv);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            float o = xv[i] * sc[i] + sh[i];
+            if (res) o += rvv[i];
+            xv[i] = relu ? fmaxf(o, 0.f) : o;
+        }
+        Gran<T>::st(y + off, xv);
+    }
+}
+// running statistics from the per-grid (mean, biased variance), sequentially over the grids: one thread per channel
+__global__ void bn_running_update_kernel(const float* __restrict__ mean_rstd, const float* __restrict__ var, float* __restrict__ running_mean,
+                                         float* __restrict__ running_var, int B, int V, int C, float momentum)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float rm = running_mean[c], rv = running_var[c];
+    for (int b = 0; b < B; ++b) {
+        const float mean = mean_rstd[((size_t)b * C + c) * 2], vb = var[(size_t)b * C + c];
+        const float unbiased = V > 1 ? (float)((double)vb * V / (V - 1)) : vb;
+        rm = (1.f - momentum) * rm + momentum * mean;
+        rv = (1.f - momentum) * rv + momentum * unbiased;
+    }
+    running_mean[c] = rm; running_var[c] = rv;
+}
+
+// backward of the same: per grid c1 = sum(g)/V, c2 = sum(g xhat)/V, dx = gamma rstd (g - c1 - xhat c2), dres = g; the per-grid sums go to
+// sums[b][c][2] and a second tiny launch adds them over the grids in order into dgamma / dbeta
+template <typename T>
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
+                                                           const float* __restrict__ scale_shift, const float* __restrict__ mean_rstd,
+                                                           T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ sums,
+                                                           int V, int C, int relu)
+{
+    constexpr int G = Gran<T>::G;
+    const int t = threadIdx.x, col = t & (BNS_COLS - 1), rl = t >> 2, b = blockIdx.y;
+    const int c0 = (blockIdx.x * BNS_COLS + col) * G;
+    __shared__ float red[4][BNS_COLS][16];
+    __shared__ float s_c1[BNS_COLS * 8], s_c2[BNS_COLS * 8];
+    const bool remask = relu && y == nullptr;
+    float mu[G], rs[G], sc[G], sh[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const size_t pc = ((size_t)b * C + c0 + i) * 2;
+        mu[i] = mean_rstd[pc]; rs[i] = mean_rstd[pc + 1]; sc[i] = scale_shift[pc]; sh[i] = scale_shift[pc + 1];
+    }
+    float s1[G], s2[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) s1[i] = s2[i] = 0.f;
+#pragma unroll 4
+    for (int v = rl; v < V; v += BNS_ROWS) {
+        const size_t off = ((size_t)b * V + v) * C + c0;
+        float xv[G], gv[G], yv[G];
+        Gran<T>::ld(x + off, xv);
+        Gran<T>::ld(dy + off, gv);
+        if (relu && !remask) Gran<T>::ld(y + off, yv);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            if (remask) gv[i] = (xv[i] * sc[i] + sh[i]) > 0.f ? gv[i] : 0.f;
+            else if (relu) gv[i] = yv[i] > 0.f ? gv[i] : 0.f;
+            s1[i] += gv[i]; s2[i] += gv[i] * (xv[i] - mu[i]) * rs[i];
+        }
+    }
+    bns_reduce<G>(s1, s2, red, t);
+    __syncthreads();
+    if (t < BNS_COLS * G) {
+        const int cc = t / G, ci = t % G, myc = blockIdx.x * BNS_COLS * G + t;
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a1 += red[w][cc][ci]; a2 += red[w][cc][8 + ci]; }
+        s_c1[t] = (float)(a1 / V); s_c2[t] = (float)(a2 / V);
+        sums[((size_t)b * C + myc) * 2] = (float)a1; sums[((size_t)b * C + myc) * 2 + 1] = (float)a2;
+    }
+    __syncthreads();
+    float c1[G], c2[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) { c1[i] = s_c1[col * G + i]; c2[i] = s_c2[col * G + i]; }
+#pragma unroll 4
+    for (int v = rl; v < V; v += BNS_ROWS) {
+        const size_t off = ((size_t)b * V + v) * C + c0;
+        float xv[G], gv[G], yv[G];
+        Gran<T>::ld(x + off, xv);
+        Gran<T>::ld(dy + off, gv);
+        if (relu && !remask) Gran<T>::ld(y + off, yv);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            if (remask) gv[i] = (xv[i] * sc[i] + sh[i]) > 0.f ? gv[i] : 0.f;
+            else if (relu) gv[i] = yv[i] > 0.f ? gv[i] : 0.f;
+        }
+        if (dres) Gran<T>::st(dres + off, gv);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const float xh = (xv[i] - mu[i]) * rs[i];
+            xv[i] = sc[i] * (gv[i] - c1[i] - xh * c2[i]);
+        }
+        Gran<T>::st(dx + off, xv);
+    }
+}
+__global__ void bn_param_grad_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C, int accumulate)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double db = 0.0, dg = 0.0;
+    for (int b = 0; b < B; ++b) { db += sums[((size_t)b * C + c) * 2]; dg += sums[((size_t)b * C + c) * 2 + 1]; }
+    dgamma[c] = accumulate ? dgamma[c] + (float)dg : (float)dg;
+    dbeta[c] = accumulate ? dbeta[c] + (float)db : (float)db;
+}
+static int g_bn_small_maxv = 512;    // tuning (include/dreg_nerf_tuning.h): largest per-grid volume served by the fused kernels, 0 = never
+static inline bool bn_small_ok(int B, int V, int C, int G) { return V >= 2 && V <= g_bn_small_maxv && C % (BNS_COLS * G) == 0 && B >= 1; }
+
 // ------------------------------------------------------------------------------------------------ max-pool 3^3 s2 p1
 template <typename T>
 __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ arg,
@@ -785,6 +969,7 @@ static inline int bn_rows_per_chunk(int V) { return V >= 262144 ? 512 : V >= 327
 
 extern "C" {
 
+void dreg_bn_set_small_max_voxels(int v) { g_bn_small_maxv = v; }
 int dreg_bn_num_chunks(int V) { const int r = bn_rows_per_chunk(V); return (V + r - 1) / r; }
 
 // Forward BatchNorm3d over B independent grids (per-grid statistics).  x,y,res: [B,V,C] (dtype 0 bf16 / 1 fp32).
@@ -798,6 +983,18 @@ int dreg_bn3d_fwd(const void* x, const void* res, void* y, const float* gamma, c
     if (C % G) return DREG_EINVAL;
     const int rpc = bn_rows_per_chunk(V), nch = (V + rpc - 1) / rpc;
     const int CG = C / G, slabs = (CG + 255) / 256;
+    if (train && bn_small_ok(B, V, C, G)) {      // 16^3 / 8^3 / 4^3 levels: statistics + apply in one launch, running statistics in a tiny second one
+        const dim3 g1(CG / BNS_COLS, B);
+        float* var = workspace;                   // [B][C] biased variances (the workspace holds >= B * chunks * C * 2 floats)
+        if (dtype == 0) hipLaunchKernelGGL(bn_small_fwd_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y, gamma, beta,
+                                           scale_shift, mean_rstd, var, V, C, eps, relu);
+        else hipLaunchKernelGGL(bn_small_fwd_kernel<float>, g1, dim3(256), 0, st, (const float*)x, (const float*)res, (float*)y, gamma, beta,
+                                scale_shift, mean_rstd, var, V, C, eps, relu);
+        DREG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, st, mean_rstd, var, running_mean, running_var, B, V, C, momentum);
+        DREG_LAUNCH_CHECK();
+        return DREG_OK;
+    }
     if (train) {
         if (train && V < 2) return DREG_EINVAL;  // torch raises for one value per channel
         dim3 grid(nch, B, slabs);
@@ -830,6 +1027,18 @@ int dreg_bn3d_bwd(const void* x, const void* dy, const void* y, const float* sca
     if (C % G) return DREG_EINVAL;
     const int rpc = bn_rows_per_chunk(V), nch = (V + rpc - 1) / rpc;
     const int CG = C / G, slabs = (CG + 255) / 256;
+    if (bn_small_ok(B, V, C, G)) {
+        const dim3 g1(CG / BNS_COLS, B);
+        float* sums = coef;                        // [B][C][2]: per-grid (sum g, sum g xhat)
+        if (dtype == 0) hipLaunchKernelGGL(bn_small_bwd_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, scale_shift, mean_rstd,
+                                           (bf16_t*)dx, (bf16_t*)dres, sums, V, C, relu);
+        else hipLaunchKernelGGL(bn_small_bwd_kernel<float>, g1, dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y, scale_shift, mean_rstd,
+                                (float*)dx, (float*)dres, sums, V, C, relu);
+        DREG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, dgamma, dbeta, B, C, accumulate);
+        DREG_LAUNCH_CHECK();
+        return DREG_OK;
+    }
     dim3 grid(nch, B, slabs);
     if (dtype == 0) hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean_rstd, workspace, V, C, rpc, relu, scale_shift);
     else hipLaunchKernelGGL((bn_partial_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y, mean_rstd, workspace, V, C, rpc, relu, scale_shift);

@@ -59,6 +59,7 @@ SIGNATURES = {
     "dreg_conv3_halo_set_prof": (None, [P]),
     # fpn_ops.hip
     "dreg_bn_num_chunks": (I, [I]),
+    "dreg_bn_set_small_max_voxels": (None, [I]),
     "dreg_bn3d_fwd": (I, [P] * 10 + [I, I, I, F, F, I, I, I, P]),
     "dreg_bn3d_bwd": (I, [P] * 11 + [I, I, I, I, I, I, P]),
     "dreg_maxpool3d_fwd": (I, [P, P, P] + [I] * 9 + [P]),
