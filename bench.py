@@ -319,7 +319,7 @@ def main():
     sweep = None
     if args.occupancy_sweep and world == 1 and args.precision == "bf16":
         sweep = []
-        for r1 in (0.815, 0.83, 0.86, 0.90, 0.96):
+        for r1 in (0.815, 0.83, 0.86, 0.90, 0.96, 1.02, 1.1):
             b2 = []
             for i in range(args.pairs):
                 sd_ = 1 + 2 * i

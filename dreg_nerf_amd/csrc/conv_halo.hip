@@ -300,6 +300,10 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(
 //   forward      : row = co,  column = ci within the chunk, tap as stored:            pack[c][t][co][k] = W[co][32c+k][t]
 //   data gradient: row = ci,  column = co within the chunk, tap flipped (26 - t):     pack[c][t][ci][k] = W[32c+k][ci][26-t]
 // (dIn[v][ci] = sum_{t,co} dOut[v + 1 - d(t)][co] W[co][ci][t] = sum_{t'} sum_co dOut[v - 1 + d(t')][co] W[co][ci][26-t'])
+// experiments only (include/dreg_nerf_tuning.h): 0 = anti-phase groups (default); 1 = lockstep; 3 = all 12 fragment reads in the load half;
+// 5 = profiled; 1x = ablations; -1 = dreg_conv3_halo_use() answers 0 (the implicit-GEMM kernel serves every shape: A/B tests)
+static int g_halo_variant = 0;
+
 __global__ __launch_bounds__(256) void pack_weight_halo_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int transposed)
 {
     const int rows = transposed ? Cin : Cout, red = transposed ? Cout : Cin;   // rows must be 256
@@ -322,7 +326,6 @@ __global__ __launch_bounds__(256) void pack_weight_halo_kernel(const float* __re
     }
 }
 
-static int g_halo_variant = 0;   // experiments only (tools/bench_conv_halo.py): 0 = anti-phase groups, weights 2 units ahead / ring 4; 1 = lockstep; 2 = 3 ahead / ring 5; 1x = ablations
 
 static unsigned long long* g_halo_prof = nullptr;
 
@@ -345,7 +348,7 @@ int dreg_conv3_halo_supported(int B, int D, int H, int W, int Cin, int Cout)
 // The decision depends on the per-grid shape only, never on B: a pair's result does not depend on its batch mates.
 int dreg_conv3_halo_use(int B, int D, int H, int W, int Cin, int Cout, int ksz, int stride, int pad)
 {
-    if (ksz != 3 || stride != 1 || pad != 1 || !dreg_conv3_halo_supported(B, D, H, W, Cin, Cout)) return 0;
+    if (g_halo_variant < 0 || ksz != 3 || stride != 1 || pad != 1 || !dreg_conv3_halo_supported(B, D, H, W, Cin, Cout)) return 0;
     return (D / halo::TZ) * (H / halo::TY) * (W / halo::TX) >= 128;      // >= 32^3 per grid
 }
 

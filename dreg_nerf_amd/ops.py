@@ -544,7 +544,7 @@ def conv3d_rows(x, w, bias, addend, pad, out_rows, in_rows):
     return SparseConv3dFn.apply(x, w, bias, addend, pad, out_rows, in_rows)
 
 
-def active_sets(idx_list, fine_res, coarse_dims, device, pt_batch=None, idx_cat=None, density_cap: float = 0.2,
+def active_sets(idx_list, fine_res, coarse_dims, device, pt_batch=None, idx_cat=None, density_cap: float = 0.3,
                 level2: bool = True, level2_cap: float = 0.5):
     """Row lists for the FPN head: S1 = trilinear-gather corner voxels of the occupied fine voxels (where P1 is consumed),
     S2 = S1 dilated by 3^3 (where the lateral sum is consumed), S3 = S2 dilated (where dc1 of the head is non-zero).
