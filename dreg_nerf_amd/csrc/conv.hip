@@ -619,12 +619,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 // XOR of the 16-byte granule index with f(row), applied on the SOURCE side of the DMA and on the read address:
 // 256-byte rows: f = ((row&3) + 4*((row>>3)&1)) * 2;  128-byte rows: f = (((row>>1)&1) + 2*((row>>3)&1)) * 2.
 // (ds_read_b64_tr_b16 services a 32-lane half-wave per cycle: voxel rows r..r+3 and r+8..r+11 must land on disjoint banks)
-template <int GP> __device__ __forceinline__ int wg_swz(int row) {
-    return GP == 16 ? (((row & 3) + 4 * ((row >> 3) & 1)) << 1) : ((((row >> 1) & 1) + 2 * ((row >> 3) & 1)) << 1);
+template <int GP> __device__ __forceinline__ int wg_swz(int row) {   // rows of >= 256 bytes (GP >= 16): the XOR acts on the low four granule bits
+    return GP >= 16 ? (((row & 3) + 4 * ((row >> 3) & 1)) << 1) : ((((row >> 1) & 1) + 2 * ((row >> 3) & 1)) << 1);
 }
 
-template <int BM, int BNC, bool ROWS>
-__global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(
+// NW = 4: 2 x 2 waves (128 x 128 / 128 x 64 / 64 x 128 / 64 x 64 tiles).  NW = 8: 2 x 4 waves on a 256 x 256 tile — per 64-voxel stage it
+// moves 64 KB for 8.4 MFLOP instead of 32 KB for 2.1 MFLOP: the 128-square tile needs ~62 B/clk of direct-to-LDS traffic at the MFMA
+// roof, which is the whole L2 -> LDS path of a CU (tools/hw_probe/l2_stream.hip: 129 GB/s per CU) and the reason it stops at 0.7 PFLOP/s.
+template <int BM, int BNC, bool ROWS, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
     const bf16_t* __restrict__ gout, const bf16_t* __restrict__ in, float* __restrict__ part,
     ConvGeom g, int tilesCol, int tiles, int nsplit, uint32_t vox_per_split, uint32_t gout_bytes, uint32_t in_bytes,
     const int* __restrict__ rowlist, uint32_t nrows, const uint8_t* __restrict__ rowocc = nullptr)
@@ -635,17 +638,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(
     constexpr int RSA = BM * 2, RSB = BNC * 2;
     constexpr int GPA = RSA / 16, GPB = RSB / 16;          // granules per row (16 or 8)
     constexpr int A_BYTES = KV * RSA, B_BYTES = KV * RSB, STAGE = A_BYTES + B_BYTES;
-    constexpr int IA = A_BYTES / 1024 / 4, IB = B_BYTES / 1024 / 4;   // wave-instructions per wave per tile
+    constexpr int IA = A_BYTES / 1024 / NW, IB = B_BYTES / 1024 / NW;   // wave-instructions per wave per tile
     constexpr int LPS = IA + IB;                           // DMA instructions per wave per stage (for counted vmcnt)
-    static_assert(IA >= 1 && IB >= 1, "stage too small for 4 waves");
+    static_assert(IA >= 1 && IB >= 1, "stage too small for the wave count");
     constexpr int RPA = 64 / GPA, RPB = 64 / GPB;          // rows per wave-instruction
-    constexpr int WN = BNC / 2, WM = BM / 2, TM = WM / 16, TN = WN / 16;
+    constexpr int WAVES_N = NW / 2;                       // waves: 2 (rows of the tile) x WAVES_N (columns)
+    constexpr int WN = BNC / WAVES_N, WM = BM / 2, TM = WM / 16, TN = WN / 16;
     constexpr uint32_t OOB = 0x7fffff00u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     // XCD-aware placement (block b runs on XCD b % 8): every XCD owns the voxel splits s == xcd (mod 8) and runs all
     // (co, n) tiles of a split back to back, so both streamed operands are fetched from HBM by ONE L2 and re-used there.
     uint32_t split, tile;
@@ -660,7 +664,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(
     const int* srow = reinterpret_cast<const int*>(smem + NS * STAGE);
     if constexpr (ROWS) {
         int* w_ = reinterpret_cast<int*>(smem + NS * STAGE);
-        for (uint32_t i = v_begin + t; i < v_end; i += 256) w_[i - v_begin] = rowlist[i];
+        for (uint32_t i = v_begin + t; i < v_end; i += NW * 64) w_[i - v_begin] = rowlist[i];
         __syncthreads();
     }
     const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)gout, 0, gout_bytes, 0x00020000);
@@ -787,7 +791,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_glds_kernel(
             // zeros, its products add exactly nothing, and the stage is skipped.  The flags of this block's stages go to LDS first
             // (a global load inside the K loop would drain the DMA queue).
             uint8_t* socc = reinterpret_cast<uint8_t*>(smem + NS * STAGE);
-            for (int i = t; i < nk; i += 256) socc[i] = rowocc[(v_begin + (uint32_t)i * KV) / (uint32_t)g.Wo];
+            for (int i = t; i < nk; i += NW * 64) socc[i] = rowocc[(v_begin + (uint32_t)i * KV) / (uint32_t)g.Wo];
             __syncthreads();
             auto next = [&](int k) { while (k < nk && socc[k] == 0) ++k; return k; };
             int k = next(0), buf = 0;
@@ -1074,6 +1078,7 @@ static int fill_geom(ConvGeom& g, int B, int Di, int Hi, int Wi, int Cin, int Do
 }
 
 static int g_use_glds = 1;
+static int g_wgrad_big = 1;     // tuning (include/dreg_nerf_tuning.h): 8-wave 256 x 256 weight-gradient tile for large dense layers
 
 // K slices of a small bf16 stride-1-gather convolution (0/1 = no split): fill the chip when the 128-row tiling leaves most CUs idle
 static int conv_ksplit(const ConvGeom& g, bool has_addend)
@@ -1260,6 +1265,7 @@ int dreg_conv3d_dgrad_s2(const void* gout, const void* wt_class_packed, void* di
 // tile when Cout % 256 == 0 (measured equal to 128x128 in round 1); 4: the 8-wave 256x256 tile (128x64 per wave);
 // 5: as 1 but never split-K; 0: always the register-staged kernel (A/B checks).
 void dreg_conv_set_glds(int enable) { g_use_glds = enable; }
+void dreg_conv_set_wgrad_big(int enable) { g_wgrad_big = enable; }
 int dreg_conv_get_glds(void) { return g_use_glds; }
 
 // K padding of the packed weight row for (ntaps, Cin) at dtype.
@@ -1402,6 +1408,13 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
             (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<64, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)ldsr;
         }
+        if (!rowlist && !rowocc && g_wgrad_big && Cout % 256 == 0 && g.Kpad % 256 == 0 && nrows >= 65536) {
+            // large dense layers: the 8-wave 256 x 256 tile
+            const int tiles256 = (Cout / 256) * (g.Kpad / 256);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 * 2);
+            hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, false, 8>), dim3(tiles256 * nsplit), dim3(512), (size_t)2 * 64 * 512 * 2, st, (const bf16_t*)gout,
+                               (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, rowocc);
+        } else
         if (bm == 128 && bnc == 128) WGG(128, 128); else if (bm == 128 && bnc == 64) WGG(128, 64);
         else if (bm == 64 && bnc == 128) WGG(64, 128); else WGG(64, 64);
 #undef WGG

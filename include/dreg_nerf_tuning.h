@@ -18,6 +18,7 @@ void dreg_conv_set_glds(int enable);
 int dreg_conv_get_glds(void);
 /* tuning / test knob: force the number of voxel splits of the weight-gradient kernels (0 = automatic) */
 void dreg_conv_set_wgrad_splits(int splits);
+void dreg_conv_set_wgrad_big(int enable);           /* 1 (default): large dense layers use the 8-wave 256 x 256 weight-gradient tile */
 void dreg_conv_set_glds_stages(int stages);          /* LDS pipeline stages of the direct-to-LDS convolution: 0 = default (2), 2..4 forces; results do not depend on it */
 void dreg_conv_set_wgrad_target_blocks(int blocks);   /* workgroups the automatic split choice aims for (default 3072) */
 /* largest per-grid volume (voxels) whose BatchNorm runs the fused statistics+apply kernels (default 512 = the 8^3 level; 16^3 measured slower fused); 0 = never */
