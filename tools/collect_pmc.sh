@@ -1,5 +1,6 @@
 # HBM traffic counters of the bench's kernels (separate passes per the guide: FETCH_SIZE and WRITE_SIZE do not fit one TCC pass;
-# --pmc only with --kernel-trace).  Writes gpurun_out/pmc/hbm_per_launch.json.
+# --pmc only with --kernel-trace).  Writes gpurun_out/pmc/hbm_per_launch.json (copy it to profiles/pmc_hbm_per_launch.json: bench.py
+# reads it from there and checks the recorded kernel-source sha against the tree it runs in).
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc
