@@ -848,6 +848,85 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
     }
 }
 
+// Batched form: the partials of MANY layers (each in its own workspace) are summed by one launch.  A workgroup owns (layer, co,
+// 64 input channels): it sums the splits of the [ntaps][64] patch of the packed row (256-byte runs per tap), turns it through LDS
+// and writes 64 * ntaps CONTIGUOUS floats of the torch-layout row (the element-wise kernel above scatters 4-byte words at a stride
+// of ntaps floats).  1^3 layers need no transposition: 2,048 contiguous elements per workgroup.
+struct WgradReduceDesc {
+    const float* part; float* dw;
+    int nsplit, Cout, Kpad, ntaps, Cin, Cin_real, accumulate, block0;
+};
+static_assert(sizeof(WgradReduceDesc) == 48, "descriptor layout is part of the ABI");
+static inline int wgrad_reduce_blocks(int Cout, int Cin_real, int ntaps)
+{
+    if (ntaps == 1) return (int)(((size_t)Cout * Cin_real + 2047) / 2048);
+    return Cout * ((Cin_real + 63) / 64);
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgradReduceDesc* __restrict__ descs, int n, int block_base)
+{
+    __shared__ float stage[64 * 125 + 64];
+    const int blk = (int)blockIdx.x + block_base;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block0 <= blk) lo = mid; else hi = mid - 1;
+    }
+    const WgradReduceDesc d = descs[lo];
+    const int r = blk - d.block0, t = threadIdx.x;
+    const size_t slab = (size_t)d.Cout * d.Kpad;
+    if (d.ntaps == 1) {
+        const size_t total = (size_t)d.Cout * d.Cin_real;
+        const size_t i0 = (size_t)r * 2048 + (size_t)t * 4;
+        if ((d.Cin_real & 3) == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const size_t i = i0 + (size_t)h * 1024;
+                if (i >= total) break;
+                const int co = (int)(i / d.Cin_real), ci = (int)(i - (size_t)co * d.Cin_real);
+                const float* src = d.part + (size_t)co * d.Kpad + ci;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = 0; k < d.nsplit; ++k) {
+                    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)k * slab);
+                    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                }
+                float4* o = reinterpret_cast<float4*>(d.dw + i);
+                if (d.accumulate) { const float4 p = *o; a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w; }
+                *o = a;
+            }
+        } else {
+            for (int e = 0; e < 8; ++e) {
+                const size_t i = (size_t)r * 2048 + (size_t)e * 256 + t;
+                if (i >= total) break;
+                const int co = (int)(i / d.Cin_real), ci = (int)(i - (size_t)co * d.Cin_real);
+                float a = 0.f;
+                for (int k = 0; k < d.nsplit; ++k) a += d.part[(size_t)k * slab + (size_t)co * d.Kpad + ci];
+                d.dw[i] = d.accumulate ? d.dw[i] + a : a;
+            }
+        }
+        return;
+    }
+    const int nchunk = (d.Cin_real + 63) / 64;
+    const int co = r / nchunk, ci0 = (r - co * nchunk) * 64;
+    const int nci = min(64, d.Cin_real - ci0);
+    const int chp = d.Cin < 64 ? d.Cin : 64;                  // padded channels of the patch row (a power of two for k > 1)
+    const int sh = 31 - __builtin_clz(chp);
+    const float* src = d.part + (size_t)co * d.Kpad + ci0;
+    const int ne = d.ntaps << sh;
+    for (int e = t; e < ne; e += 256) {
+        const int tap = e >> sh, cl = e & (chp - 1);
+        if (cl < nci) {
+            const float* p = src + (size_t)tap * d.Cin + cl;
+            float a = 0.f;
+            for (int k = 0; k < d.nsplit; ++k) a += p[(size_t)k * slab];
+            stage[cl * d.ntaps + tap] = a;                     // lanes walk cl: stride ntaps (odd) floats, conflict-free
+        }
+    }
+    __syncthreads();
+    float* o = d.dw + ((size_t)co * d.Cin_real + ci0) * d.ntaps;
+    const int no = nci * d.ntaps;
+    for (int j = t; j < no; j += 256) o[j] = d.accumulate ? o[j] + stage[j] : stage[j];
+}
+
 // torch weight [Cout][Cin_real][ntaps] fp32 -> gather-form pack [Cout][Kpad] (K = tap*Cin + ci), zero padded.
 // finish of a split-K convolution: out[i] = cast([relu](sum_s part[s][i] + bias[i % Cout])), 8 channels per thread
 template <typename TO>
@@ -934,7 +1013,7 @@ struct PackDesc {
 };
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDesc* __restrict__ descs, int n, const int* __restrict__ row_desc)
 {
-    extern __shared__ float stage[];
+    extern __shared__ __align__(16) float stage[];
     __shared__ float tile[64][33];
     int lo = 0, hi = n - 1;
     if (row_desc) lo = row_desc[blockIdx.x];             // one load instead of a chain of log2(n) dependent ones
@@ -979,9 +1058,13 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDes
         return;
     }
     if (d.ntaps == 1) {                                  // [Cout][Cin] -> [Cin][Kpad] (data-gradient pack and class-0 pack)
-        if (r & 31) return;
+        // the 32 workgroups of a 32-row group share its 64-column chunks (one chunk each for Cout = 2,048) instead of one of them
+        // walking all of them: the pack is latency-bound, so what counts is how many 8 KB tiles are in flight
+        const int sub = r & 31;
+        r -= sub;
+        const int nb = min(32, d.Cin_real - r);          // workgroups of this group (a ragged last group has fewer)
         const int ci_l = t & 31, ci_w = t >> 3, cg = t & 7;
-        for (int co0 = 0; co0 < d.Kpad; co0 += 64) {
+        for (int co0 = sub * 64; co0 < d.Kpad; co0 += nb * 64) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int co = co0 + (t >> 5) + 8 * it;
@@ -999,17 +1082,25 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDes
         }
         return;
     }
-    // k^3 packs: 64 channels x taps per pass
+    // k^3 packs: CH channels x taps per pass (256 for 3^3: 27 KB of the fp32 row in flight per workgroup and pass — the pack is
+    // latency-bound — 64 for the 5^3 stem)
     const int cls = d.for_dgrad == 2 ? r / d.Cin_real : 0;
     if (d.for_dgrad == 2) r -= cls * d.Cin_real;
     const size_t row_o = ((size_t)cls * d.Cin_real + r) * d.Kpad;
     const int ntd = d.for_dgrad == 2 ? 8 : d.ntaps;     // taps of the packed row
-    for (int c0 = 0; c0 < inner; c0 += 64) {
-        const int nc = min(64, nreal - c0);              // real channels in this chunk (<= 0: padding only)
+    const int CH = d.ntaps <= 27 ? 256 : 64;
+    const int ngr = CH >> 3;                             // 8-channel granules per pass
+    for (int c0 = 0; c0 < inner; c0 += CH) {
+        const int nc = min(CH, nreal - c0);              // real channels in this chunk (<= 0: padding only)
         if (nc > 0) {
             if (!d.for_dgrad) {
                 const float* src = d.w + ((size_t)r * d.Cin_real + c0) * d.ntaps;
-                for (int i = t; i < nc * d.ntaps; i += 256) stage[i] = src[i];
+                const int n = nc * d.ntaps;
+                if (((size_t)src & 15) == 0) {
+                    for (int i = t * 4; i + 3 < n; i += 1024) *reinterpret_cast<float4*>(stage + i) = *reinterpret_cast<const float4*>(src + i);
+                    for (int i = (n & ~3) + t; i < n; i += 256) stage[i] = src[i];
+                } else
+                    for (int i = t; i < n; i += 256) stage[i] = src[i];
             } else {
                 for (int cl = t >> 5; cl < nc; cl += 8)
                     for (int tap = t & 31; tap < d.ntaps; tap += 32)
@@ -1017,20 +1108,19 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDes
             }
         }
         __syncthreads();
-        const int g = t & 7;
-        if (c0 + g * 8 < inner) {
-            for (int tp = t >> 3; tp < ntd; tp += 32) {
-                const int tap = d.for_dgrad == 2 ? s2_class_tap(cls, tp, ksz) : tp;
-                uint32_t pk[4];
+        for (int it = t; it < ngr * ntd; it += 256) {
+            const int g = it % ngr, tp = it / ngr;
+            if (c0 + g * 8 >= inner) continue;
+            const int tap = d.for_dgrad == 2 ? s2_class_tap(cls, tp, ksz) : tp;
+            uint32_t pk[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int cl = g * 8 + 2 * e;
-                    const float v0 = (tap >= 0 && cl < nc) ? stage[cl * d.ntaps + tap] : 0.f;
-                    const float v1 = (tap >= 0 && cl + 1 < nc) ? stage[(cl + 1) * d.ntaps + tap] : 0.f;
-                    pk[e] = f2bf2(v0, v1);
-                }
-                *reinterpret_cast<uint4*>(out + row_o + (size_t)tp * inner + c0 + g * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            for (int e = 0; e < 4; ++e) {
+                const int cl = g * 8 + 2 * e;
+                const float v0 = (tap >= 0 && cl < nc) ? stage[cl * d.ntaps + tap] : 0.f;
+                const float v1 = (tap >= 0 && cl + 1 < nc) ? stage[(cl + 1) * d.ntaps + tap] : 0.f;
+                pk[e] = f2bf2(v0, v1);
             }
+            *reinterpret_cast<uint4*>(out + row_o + (size_t)tp * inner + c0 + g * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         }
         __syncthreads();
     }
@@ -1316,7 +1406,8 @@ int dreg_pack_conv_weights_batched(const void* descs, int n, int total_rows, int
     static_assert(sizeof(PackDesc) == 48, "descriptor layout is part of the ABI");
     if (n <= 0 || total_rows <= 0) return DREG_OK;
     if (stage_floats < 0 || (size_t)stage_floats * 4 > 48 * 1024) return DREG_EINVAL;
-    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(total_rows), dim3(256), (size_t)(stage_floats > 0 ? stage_floats : 1) * 4, (hipStream_t)stream,
+    // stage_floats > 0 says "k^3 packs present": the kernel stages 256 channels x 27 taps (or 64 x 125) per pass
+    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(total_rows), dim3(256), (size_t)(stage_floats > 0 ? 64 * 125 : 1) * 4, (hipStream_t)stream,
                        (const PackDesc*)descs, n, row_desc);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
@@ -1350,7 +1441,10 @@ int dreg_conv3d_wgrad_splits(int B, int Do, int Ho, int Wo, int Cin, int Cout, i
     const long maxs = (M + vmin - 1) / vmin;
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
-    if (s > 64) s = 64;
+    // layers with a handful of weight tiles (the 1^3 convolutions of the 32^3 level: 1-2 tiles, 262,144 voxels to stream) need more
+    // than 64 splits to occupy the chip at all: up to 512 while the launch stays under 1,024 workgroups (partials <= 34 MB)
+    const long cap = (tiles * 64 >= 1024 || dtype != 0) ? 64 : ((1024 + tiles - 1) / tiles > 512 ? 512 : (1024 + tiles - 1) / tiles);
+    if (s > cap) s = cap;
     if (s > 8) s = (s + 7) / 8 * 8;   // whole multiples of the 8 XCDs (see the block placement of the glds kernel)
     return (int)s;
 }
@@ -1366,7 +1460,7 @@ size_t dreg_conv3d_wgrad_workspace_bytes(int B, int Do, int Ho, int Wo, int Cin,
 static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspace, size_t workspace_bytes,
                       int B, int Di, int Hi, int Wi, int Cin, int Cin_real, int Do, int Ho, int Wo, int Cout,
                       int ksz, int stride, int pad, int accumulate, int dtype, int use_tr, void* stream,
-                      const int* rowlist, uint32_t nrows_list, const uint8_t* rowocc = nullptr)
+                      const int* rowlist, uint32_t nrows_list, const uint8_t* rowocc = nullptr, bool defer_reduce = false)
 {
     ConvGeom g;
     const int es = dtype == 0 ? 2 : 4;
@@ -1424,6 +1518,7 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
 #undef WG_DISPATCH
 #undef WG_LAUNCH
     DREG_LAUNCH_CHECK();
+    if (defer_reduce) return DREG_OK;    // the caller sums the splits later (dreg_wgrad_reduce_batched)
     const size_t total = (size_t)Cout * g.ntaps * Cin_real;
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, part, dw, nsplit, Cout, g.Kpad, g.ntaps, Cin, g.log2Cin, Cin_real, accumulate);
@@ -1465,6 +1560,28 @@ int dreg_conv3d_igemm_rows(const void* in, const void* wt_packed, void* out, con
     hipStream_t st = (hipStream_t)stream;
     if (out_f32) return launch_conv<bf16_t, float>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st, rows, (uint32_t)nrows);
     return launch_conv<bf16_t, bf16_t>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st, rows, (uint32_t)nrows);
+}
+// Deferred form: only the split partials are written ([nsplit][Cout][Kpad] fp32 in `workspace`, which the caller keeps until it has
+// run dreg_wgrad_reduce_batched over it).  rows / rowocc as in the _rows / _occ forms (both may be null).
+int dreg_conv3d_wgrad_partials(const void* gout, const void* in, void* workspace, size_t workspace_bytes, const int* rows, int nrows,
+                               int B, int Di, int Hi, int Wi, int Cin, int Cin_real, int Do, int Ho, int Wo, int Cout,
+                               int ksz, int stride, int pad, const uint8_t* rowocc, void* stream)
+{
+    if (rows && nrows < 0) return DREG_EINVAL;
+    return wgrad_impl(gout, in, nullptr, workspace, workspace_bytes, B, Di, Hi, Wi, Cin, Cin_real, Do, Ho, Wo, Cout, ksz, stride, pad,
+                      0, 0, 1, stream, rows, rows ? (uint32_t)nrows : 0, rows ? nullptr : rowocc, true);
+}
+// Workgroups the batched reduce spends on one layer: descriptor i starts at block0 = sum of the counts of the descriptors before it.
+int dreg_wgrad_reduce_blocks(int Cout, int Cin_real, int ksz) { return wgrad_reduce_blocks(Cout, Cin_real, ksz * ksz * ksz); }
+// descs_dev: n descriptors {part, dw, nsplit, Cout, Kpad, ntaps, Cin, Cin_real, accumulate, block0} (48 bytes each, device memory,
+// ascending block0); blocks [block_base, block_base + nblocks) are launched, so a sub-range of a long table can be reduced on its own.
+int dreg_wgrad_reduce_batched(const void* descs_dev, int n, int block_base, int nblocks, void* stream)
+{
+    if (n <= 0 || nblocks <= 0) return DREG_OK;
+    if (!descs_dev || block_base < 0) return DREG_EINVAL;
+    hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const WgradReduceDesc*)descs_dev, n, block_base);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
 }
 int dreg_conv3d_wgrad_rows(const void* gout, const void* in, float* dw, void* workspace, size_t workspace_bytes,
                            const int* rows, int nrows,

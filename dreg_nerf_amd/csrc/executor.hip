@@ -39,11 +39,16 @@ struct Param {
 struct Op {
     int kind, in, out, in2, w, b, p2, p3, p4, ksz, stride, pad, relu, add_same, rows_out, rows_in;
     size_t aux0 = 0, aux1 = 0;   // BN: scale_shift / mean_rstd; max-pool: argmax
+    size_t wg_off = 0, wg_bytes = 0;   // OP_CONV*: this layer's weight-gradient split partials (kept until the batched reduce)
+    int rd = -1;                 // index of its record in the reduce table
     int halo = 0;                // OP_CONV: bit 0 = forward, bit 1 = data gradient run on the halo kernel
 };
 struct HaloPack { const float* w; size_t off; int Cout, Cin, transposed; };
 struct PackRec { const float* w; void* out; int Cout, Cin_real, inner, ntaps, for_dgrad, Kpad, dtype, row0; };
 static_assert(sizeof(PackRec) == 48, "matches PackDesc of conv.hip");
+
+struct ReduceRec { const float* part; float* dw; int nsplit, Cout, Kpad, ntaps, Cin, Cin_real, accumulate, block0; };
+static_assert(sizeof(ReduceRec) == 48, "matches WgradReduceDesc of conv.hip");
 
 struct TimedLaunch { hipEvent_t e0, e1; int op, kind; };
 
@@ -53,8 +58,12 @@ struct Exec {
     std::vector<Param> prm;
     std::vector<char> needs_grad;          // per tensor: some parameter lies upstream
     size_t act_bytes = 0, arena_bytes = 0, pack_bytes = 0;
-    size_t off_bn_ws = 0, off_coef = 0, off_ks = 0, off_wg = 0, off_cs = 0, off_tmp = 0;
-    size_t sz_ks = 0, sz_wg = 0;
+    size_t off_bn_ws = 0, off_coef = 0, off_ks = 0, off_rd = 0, off_cs = 0, off_tmp = 0;
+    size_t sz_ks = 0;
+    std::vector<ReduceRec> reduce;         // one per convolution with a weight gradient, in op order; part = arena offset
+    std::vector<ReduceRec> reduce_abs;     // the same with absolute addresses for the arena it was last uploaded to
+    int reduce_blocks = 0;
+    const void* reduce_arena = nullptr;
     std::vector<PackRec> packs;            // with out = offset (patched on export)
     std::vector<HaloPack> halo_packs;      // refreshed by dreg_exec_repack next to the batched pack launch
     int pack_rows = 0, pack_max_floats = 0;
@@ -165,8 +174,22 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
             const size_t k2 = dreg_conv3d_igemm_workspace_bytes(x.B, y.D, y.H, y.W, w.d0, x.D, x.H, x.W, w.d1, o.ksz, o.stride, o.pad, 1, 0, 0);
             if (k1 > e->sz_ks) e->sz_ks = k1;
             if (k2 > e->sz_ks) e->sz_ks = k2;
-            const size_t g = dreg_conv3d_wgrad_workspace_bytes(x.B, y.D, y.H, y.W, x.C, w.d0, o.ksz, 0);
-            if (g > e->sz_wg) e->sz_wg = g;
+            if (w.grad) {
+                // every layer keeps its own split partials: the splits of a whole backward segment are summed by ONE launch
+                o.wg_bytes = dreg_conv3d_wgrad_workspace_bytes(x.B, y.D, y.H, y.W, x.C, w.d0, o.ksz, 0);
+                bool shared = false;      // a parameter used by two layers: the later one sums its splits with its own launch
+                for (const ReduceRec& q : e->reduce) shared = shared || q.dw == w.grad;
+                if (shared) o.rd = -2;
+                else {
+                    ReduceRec r{};
+                    r.dw = w.grad; r.nsplit = dreg_conv3d_wgrad_splits(x.B, y.D, y.H, y.W, x.C, w.d0, o.ksz, 0);
+                    r.Cout = w.d0; r.Kpad = dreg_conv3d_kpad(o.ksz, x.C, 0); r.ntaps = o.ksz * o.ksz * o.ksz; r.Cin = x.C; r.Cin_real = w.d1;
+                    r.accumulate = 1; r.block0 = e->reduce_blocks;
+                    e->reduce_blocks += dreg_wgrad_reduce_blocks(w.d0, w.d1, o.ksz);
+                    o.rd = (int)e->reduce.size();
+                    e->reduce.push_back(r);
+                }
+            }
             const size_t c = dreg_colsum_workspace_bytes((size_t)y.B * y.D * y.H * y.W, w.d0);
             if (c > cs) cs = c;
         }
@@ -179,7 +202,8 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
     e->off_bn_ws = off; off += align256(bn_ws);
     e->off_coef = off; off += align256(coef);
     e->off_ks = off; off += align256(e->sz_ks);
-    e->off_wg = off; off += align256(e->sz_wg);
+    for (Op& o : e->ops) if (o.rd != -1) { o.wg_off = off; off += align256(o.wg_bytes); if (o.rd >= 0) e->reduce[o.rd].part = (const float*)o.wg_off; }
+    e->off_rd = off; off += align256(e->reduce.size() * sizeof(ReduceRec) + 16);
     e->off_cs = off; off += align256(cs);
     e->off_tmp = off; off += max_tensor;
     e->arena_bytes = off + 256;
@@ -394,6 +418,16 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
         if (hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) != hipSuccess) aux_on = false;
     }
     bool& aux_used = e->aux_used;
+    if (e->reduce_arena != arena && !e->reduce.empty()) {
+        // the reduce table lives in the arena (addresses of this arena's partials); uploaded once per arena
+        e->reduce_abs = e->reduce;
+        for (ReduceRec& r : e->reduce_abs) r.part = (const float*)(A + (size_t)r.part);
+        if (hipMemcpyAsync(A + e->off_rd, e->reduce_abs.data(), e->reduce_abs.size() * sizeof(ReduceRec), hipMemcpyHostToDevice, st) != hipSuccess) return DREG_ELAUNCH;
+        if (hipStreamSynchronize(st) != hipSuccess) return DREG_ELAUNCH;
+        e->reduce_arena = arena;
+    }
+    std::vector<char> rd_done(e->reduce.size(), 0);   // records whose partials this call produced
+    hipStream_t rd_stream = st;
     for (int i = op_end - 1; i >= op_begin; --i) {
         const Op& o = e->ops[i];
         const Tensor& x = e->t[o.in];
@@ -418,10 +452,18 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                 }
                 if (w.grad) {
                     Scope sc(e, ws, i, 2);
-                    if (rows) CK(dreg_conv3d_wgrad_rows(gy, act(o.in), w.grad, A + e->off_wg, e->sz_wg, r_out, n_out, x.B, x.D, x.H, x.W, x.C, w.d1,
-                                                        y.D, y.H, y.W, w.d0, o.ksz, 1, o.pad, 1, (void*)ws));
-                    else CK(dreg_conv3d_wgrad_occ(gy, act(o.in), w.grad, A + e->off_wg, e->sz_wg, x.B, x.D, x.H, x.W, x.C, w.d1, y.D, y.H, y.W, w.d0,
-                                                  o.ksz, o.stride, o.pad, 1, 0, 1, o.in == 0 ? e->in_rowocc : nullptr, (void*)ws));
+                    if (o.rd >= 0) {
+                        CK(dreg_conv3d_wgrad_partials(gy, act(o.in), A + o.wg_off, o.wg_bytes, rows ? r_out : nullptr, n_out, x.B, x.D, x.H, x.W, x.C, w.d1,
+                                                      y.D, y.H, y.W, w.d0, o.ksz, rows ? 1 : o.stride, o.pad, (!rows && o.in == 0) ? e->in_rowocc : nullptr, (void*)ws));
+                        rd_done[o.rd] = 1;
+                        rd_stream = ws;
+                    } else if (rows) {
+                        CK(dreg_conv3d_wgrad_rows(gy, act(o.in), w.grad, A + o.wg_off, o.wg_bytes, r_out, n_out, x.B, x.D, x.H, x.W, x.C, w.d1,
+                                                  y.D, y.H, y.W, w.d0, o.ksz, 1, o.pad, 1, (void*)ws));
+                    } else {
+                        CK(dreg_conv3d_wgrad_occ(gy, act(o.in), w.grad, A + o.wg_off, o.wg_bytes, x.B, x.D, x.H, x.W, x.C, w.d1, y.D, y.H, y.W, w.d0,
+                                                 o.ksz, o.stride, o.pad, 1, 0, 1, o.in == 0 ? e->in_rowocc : nullptr, (void*)ws));
+                    }
                 }
                 if (o.b >= 0 && e->prm[o.b].grad) {
                     if (rows) CK(dreg_colsum_rows(gy, r_out, n_out, e->prm[o.b].grad, (float*)(A + e->off_cs), w.d0, 1, 0, (void*)ws));
@@ -497,6 +539,19 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
             CK(dreg_maxpool3d_bwd(gy, (const uint8_t*)(A + o.aux0), dst_for(o.in), x.B, x.D, x.H, x.W, y.D, y.H, y.W, x.C, 0, stream));
             CK(commit(o.in));
         }
+    }
+    // one launch sums the splits of every layer of this range into the torch-layout gradients (on the stream the partials were
+    // produced on: all of them the second stream, or all of them the caller's); layers no gradient reached are left out, so a
+    // range is one launch per run of consecutive records
+    for (int lo = 0, nrec = (int)rd_done.size(); lo < nrec;) {
+        if (!rd_done[lo]) { ++lo; continue; }
+        int hi = lo;
+        while (hi + 1 < nrec && rd_done[hi + 1]) ++hi;
+        Scope sc(e, rd_stream, -1, 3);
+        const int b0 = e->reduce[lo].block0;
+        const int b1 = hi + 1 < nrec ? e->reduce[hi + 1].block0 : e->reduce_blocks;
+        CK(dreg_wgrad_reduce_batched((const ReduceRec*)(A + e->off_rd) + lo, hi - lo + 1, b0, b1 - b0, (void*)rd_stream));
+        lo = hi + 1;
     }
     if ((flags & 2) && aux_used) {   // the caller's stream continues (optimizer) only after every parameter gradient has landed
         if (hipEventRecord(e->ev_done, e->aux) != hipSuccess || hipStreamWaitEvent(st, e->ev_done, 0) != hipSuccess) return DREG_ELAUNCH;

@@ -6,6 +6,7 @@ mode).  Master weights stay fp32 in torch layout; the kernels consume per-step p
 import os
 from typing import Optional
 
+import numpy as np
 import torch
 
 from . import lib as L
@@ -91,6 +92,41 @@ def clear_pack_cache():
     _pack_table = None
 
 
+PACK_STREAM = None        # side stream for the repack that follows an optimizer update (train_step sets it; None = current stream)
+_PACK_EVENTS = []
+
+
+class pack_region:
+    """`with pack_region():` — pack launches inside run on PACK_STREAM (after everything already enqueued on the current stream:
+    the optimizer update) and the first consumer of a pack waits for them (wait_packs).  The repack is latency-bound (~0.5 ms at
+    ~1 TB/s); on the side stream it runs under the input staging of the next step instead of in front of its first convolution."""
+
+    def __enter__(self):
+        self.side = PACK_STREAM if (PACK_STREAM is not None and torch.cuda.is_available()) else None
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream(self.side.device))
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            _PACK_EVENTS.append(ev)
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def wait_packs():
+    """Called in front of every consumer of a weight pack: the current stream waits for the side-stream repacks."""
+    if _PACK_EVENTS:
+        st = torch.cuda.current_stream()
+        for ev in _PACK_EVENTS:
+            st.wait_event(ev)
+        _PACK_EVENTS.clear()
+
+
 def bump_weight_generation():
     """Called by optimizers that update parameters behind torch's version counters (FlatAdamW)."""
     global _weight_generation
@@ -101,6 +137,7 @@ def packed_weight(w: torch.Tensor, cin_pad: int, for_dgrad: bool, dt: int) -> to
     """w: fp32 [Cout, Cin, k, k, k] (or [Cout, Cin] for linear layers, possibly a row slice of a parameter).
     The pack is cached against the owning parameter object (weak reference) and its in-place version counter;
     repack_all() refreshes every cached pack in one launch after an optimizer update."""
+    wait_packs()
     base = w._base if w._base is not None else w
     key = (id(base), w.storage_offset(), tuple(w.shape), cin_pad, for_dgrad, dt)
     hit = _pack_cache.get(key)
@@ -298,9 +335,48 @@ def conv_dgrad_s2(g, wpk_class, x_shape, cout, ksz, pad):
     return gx
 
 
-def conv_wgrad(gout, x, w_shape, cin_pad, ksz, stride, pad, use_tr=True, accumulate_into=None):
+_PENDING_REDUCE = []      # (workspace tensor, record) of the deferred weight-gradient launches since the last flush
+_REDUCE_DT = np.dtype([("part", "<u8"), ("dw", "<u8"), ("nsplit", "<i4"), ("Cout", "<i4"), ("Kpad", "<i4"), ("ntaps", "<i4"),
+                       ("Cin", "<i4"), ("Cin_real", "<i4"), ("accumulate", "<i4"), ("block0", "<i4")])
+
+
+def flush_wgrad_reduce():
+    """Sum the split partials of every deferred weight gradient (conv_wgrad(..., defer=True)) into their gradient tensors: one
+    launch (dreg_wgrad_reduce_batched) on the current stream, which must be the stream the partials were produced on."""
+    if not _PENDING_REDUCE:
+        return
+    lib = L.load()
+    # a gradient that received several contributions (a layer applied twice) is summed by successive launches, in call order:
+    # within one launch every record owns its destination
+    rounds = []
+    for rec in _PENDING_REDUCE:
+        key = rec[1].data_ptr()
+        for seen, lst in rounds:
+            if key not in seen:
+                seen.add(key); lst.append(rec)
+                break
+        else:
+            rounds.append(({key}, [rec]))
+    dev = _PENDING_REDUCE[0][0].device
+    st = torch.cuda.current_stream(dev)
+    for _, lst in rounds:
+        recs = np.zeros(len(lst), dtype=_REDUCE_DT)
+        blocks = 0
+        for i, (ws, dw, nsplit, cout, kpad, ntaps, cin, cin_real, ksz) in enumerate(lst):
+            recs[i] = (ws.data_ptr(), dw.data_ptr(), nsplit, cout, kpad, ntaps, cin, cin_real, 1, blocks)
+            blocks += lib.dreg_wgrad_reduce_blocks(cout, cin_real, ksz)
+        table = torch.from_numpy(recs.view(np.uint8)).pin_memory().to(dev, non_blocking=True)
+        L.check(lib.dreg_wgrad_reduce_batched(L.ptr(table), len(lst), 0, blocks, L.stream()), "dreg_wgrad_reduce_batched")
+        table.record_stream(st)
+    for ws, *_ in _PENDING_REDUCE:
+        ws.record_stream(st)
+    _PENDING_REDUCE.clear()
+
+
+def conv_wgrad(gout, x, w_shape, cin_pad, ksz, stride, pad, use_tr=True, accumulate_into=None, defer=False):
     """accumulate_into: an existing fp32 gradient tensor of w_shape (e.g. a view of the flat gradient buffer) that the
-    reduce kernel adds into; the function then returns None."""
+    reduce kernel adds into; the function then returns None.  defer (bf16, with accumulate_into): only the split partials are
+    produced now; flush_wgrad_reduce() adds the sums of all deferred layers with one launch."""
     lib = L.load()
     dt = L.dt_of(x)
     B, Di, Hi, Wi = x.shape[:4]
@@ -308,6 +384,12 @@ def conv_wgrad(gout, x, w_shape, cin_pad, ksz, stride, pad, use_tr=True, accumul
     cin_real = w_shape[1]
     nbytes = lib.dreg_conv3d_wgrad_workspace_bytes(B, Do, Ho, Wo, cin_pad, cout, ksz, dt)
     ws = _ws(nbytes, x.device)
+    if defer and accumulate_into is not None and dt == L.DT_BF16 and use_tr and accumulate_into.is_contiguous():
+        L.check(lib.dreg_conv3d_wgrad_partials(L.ptr(gout), L.ptr(x), L.ptr(ws), nbytes, None, 0, B, Di, Hi, Wi, cin_pad, cin_real,
+                                               Do, Ho, Wo, cout, ksz, stride, pad, None, L.stream()), "dreg_conv3d_wgrad_partials")
+        _PENDING_REDUCE.append((ws, accumulate_into, lib.dreg_conv3d_wgrad_splits(B, Do, Ho, Wo, cin_pad, cout, ksz, dt), cout,
+                                lib.dreg_conv3d_kpad(ksz, cin_pad, dt), ksz ** 3, cin_pad, cin_real, ksz))
+        return None
     dw = accumulate_into if accumulate_into is not None else torch.empty(w_shape, dtype=torch.float32, device=x.device)
     ev = None
     if PROFILER is not None:
@@ -437,7 +519,7 @@ class Conv3dFn(torch.autograd.Function):
             ev.record()
             PARAM_GRAD_STREAM.wait_event(ev)
             with torch.cuda.stream(PARAM_GRAD_STREAM):
-                conv_wgrad(g, x, tuple(w.shape), cin_pad, ksz, stride, pad, USE_TR, accumulate_into=wsink)
+                conv_wgrad(g, x, tuple(w.shape), cin_pad, ksz, stride, pad, USE_TR, accumulate_into=wsink, defer=True)
                 if want_b:
                     colsum(g.view(-1, cout), accumulate_into=bsink)
             g.record_stream(PARAM_GRAD_STREAM)

@@ -83,7 +83,8 @@ class FlatAdamW:
                                     self.n_active, lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
                                     float(self.max_norm), L.stream()), "dreg_adamw_step")
         ops.bump_weight_generation()  # the kernel wrote the parameters behind torch's version counters
-        ops.repack_all(self.flat_p.device)  # every cached bf16/fp32 weight pack refreshed by one launch
+        with ops.pack_region():             # on ops.PACK_STREAM when train_step set one: next to the next step's input staging
+            ops.repack_all(self.flat_p.device)  # every cached bf16/fp32 weight pack refreshed by one launch
 
     def grad_norm(self) -> torch.Tensor:
         return self._norm

@@ -125,7 +125,16 @@ class TrainStep:
             ops.GRAD_SYNC = None
         if sync is not None:
             sync.finish()
-        self.optimizer.step()          # clip_grad_norm_(grad_clip) folded into the AdamW kernel
+        if self.overlap_param_grads and dev.type == "cuda":
+            from .trunk_exec import aux_stream
+            ops.PACK_STREAM = aux_stream(dev)
+        try:
+            self.optimizer.step()          # clip_grad_norm_(grad_clip) folded into the AdamW kernel; weight packs refreshed
+            for ex in getattr(self.model, "_trunk_cache", {}).values():
+                if ex.with_grad and ex.still_valid():
+                    ex.repack_after_update()
+        finally:
+            ops.PACK_STREAM = None
         gnorm = self.optimizer.grad_norm()
         if not self.finetune:
             self.scheduler.step()
@@ -142,8 +151,11 @@ class TrainStep:
             ops.PARAM_GRAD_STREAM = self._pg_stream
             try:
                 total.backward()
+                with torch.cuda.stream(self._pg_stream):
+                    ops.flush_wgrad_reduce()       # deferred split sums nobody flushed yet (no trunk executor in the graph)
             finally:
                 ops.PARAM_GRAD_STREAM = None
+                ops._PENDING_REDUCE.clear()
             torch.cuda.current_stream(dev).wait_stream(self._pg_stream)
         else:
             total.backward()

@@ -179,7 +179,8 @@ class TrunkExecutor:
             lo, li = (o[14], o[15]) if rows else (-1, -1)
             out[(i, 0)] = (fname, f"fwd{rows} B{B} {x[1]}x{x[2]}x{x[3]}x{x[4]}->{y[1]}x{y[2]}x{y[3]}x{cout} k{k}s{s}", fl, lo, per_row)
             out[(i, 1)] = (dname, f"dgrad{rows} B{B} {y[1]}x{y[2]}x{y[3]}x{cout}->{x[1]}x{x[2]}x{x[3]}x{cin} k{k}s{s}", fl, li, per_row)
-            out[(i, 2)] = ("conv_wgrad_kernel<bf16>+reduce", f"wgrad{rows} B{B} {x[1]}x{x[2]}x{x[3]}x{x[4]} g{y[1]}x{y[2]}x{y[3]}x{cout} k{k}s{s}", fl, lo, per_row)
+            out[(i, 2)] = ("conv_wgrad_kernel<bf16>", f"wgrad{rows} B{B} {x[1]}x{x[2]}x{x[3]}x{x[4]} g{y[1]}x{y[2]}x{y[3]}x{cout} k{k}s{s}", fl, lo, per_row)
+        out[(-1, 3)] = ("wgrad_reduce_batched_kernel", "split sums of a backward range -> torch-layout gradients", 0.0, -1, 0.0)
         return out
 
     # ------------------------------------------------------------------ per-step calls
@@ -190,6 +191,12 @@ class TrunkExecutor:
         if self.pack_stamp != stamp:
             L.check(self.lib.dreg_exec_repack(self.h, L.ptr(self.pack_table), L.ptr(self.pack_rowmap), L.stream()), "dreg_exec_repack")
             self.pack_stamp = stamp
+
+    def repack_after_update(self):
+        """Right after an optimizer update (train_step): refresh the packs inside ops.pack_region() — on the side stream, under the
+        next step's input staging; forward() waits for it (ops.wait_packs) instead of repacking in front of its first convolution."""
+        with ops.pack_region():
+            self.repack_if_stale()
 
     @staticmethod
     def _rowlist_array(rows):
@@ -205,6 +212,7 @@ class TrunkExecutor:
         return a, n
 
     def forward(self, x: torch.Tensor, rows, train: bool) -> torch.Tensor:
+        ops.wait_packs()
         self.repack_if_stale()
         want = ops.PROFILER is not None and ops.PROFILER.enabled
         if want != self._timing:
@@ -219,6 +227,7 @@ class TrunkExecutor:
     def backward(self, x: torch.Tensor, rows, grad_out: torch.Tensor):
         ra, n = self._rowlist_array(rows)
         sync = ops.GRAD_SYNC
+        self._flush_deferred()
         if sync is None:
             L.check(self.lib.dreg_exec_backward(self.h, L.ptr(self.arena), self.arena_bytes, L.ptr(self.pack), L.ptr(x), L.ptr(grad_out),
                                                 ctypes.addressof(ra) if ra is not None else None, n, L.stream(), aux_stream(self.device).cuda_stream),
@@ -235,6 +244,13 @@ class TrunkExecutor:
                                                       lo_op, hi, flags), "dreg_exec_backward_range")
             hi = lo_op
             sync.ready(done_from)
+
+    def _flush_deferred(self):
+        """The point-set half's deferred weight-gradient sums (ops.conv_wgrad(defer=True)) are all enqueued when the trunk's backward
+        starts: one launch on the stream they were produced on adds them to the gradients."""
+        if ops._PENDING_REDUCE:
+            with torch.cuda.stream(aux_stream(self.device)):
+                ops.flush_wgrad_reduce()
 
     def _sync_plan(self, sync):
         """Segments of the backward pass for GradSync: ops are processed last to first; after the segment ending at op `lo_op` every

@@ -118,6 +118,17 @@ int dreg_conv3d_wgrad_rows(const void* gout, const void* in, float* dw, void* wo
                            const int* rows, int nrows,
                            int B, int Di, int Hi, int Wi, int Cin, int Cin_real, int Do, int Ho, int Wo, int Cout,
                            int ksz, int stride, int pad, int accumulate, void* stream);
+/* loss.backward() produces ~100 weight gradients per step (train_nerf_regtr.py:232): the deferred form writes only the split
+ * partials of one layer ([dreg_conv3d_wgrad_splits][Cout][Kpad] fp32 into a workspace the caller keeps; rows / rowocc as in the
+ * _rows / _occ forms, both may be null), and dreg_wgrad_reduce_batched sums the partials of many layers into their torch-layout
+ * gradients [Cout][Cin_real][k^3] with ONE launch.  descs_dev: n records of 48 bytes in device memory
+ *   { const float* part; float* dw; int nsplit, Cout, Kpad, ntaps, Cin, Cin_real, accumulate, block0; }
+ * with block0 = sum of dreg_wgrad_reduce_blocks(...) of the records before it; workgroups [block_base, block_base + nblocks) run. */
+int dreg_conv3d_wgrad_partials(const void* gout, const void* in, void* workspace, size_t workspace_bytes, const int* rows, int nrows,
+                               int B, int Di, int Hi, int Wi, int Cin, int Cin_real, int Do, int Ho, int Wo, int Cout,
+                               int ksz, int stride, int pad, const uint8_t* rowocc, void* stream);
+int dreg_wgrad_reduce_blocks(int Cout, int Cin_real, int ksz);
+int dreg_wgrad_reduce_batched(const void* descs_dev, int n, int block_base, int nblocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- FPN3D companions
  * BatchNorm3d with the reference's one-grid-per-call statistics (resnet3d.py:121,159; nerf_regtr.py:135), fused

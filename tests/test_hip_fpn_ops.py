@@ -87,6 +87,46 @@ def test_wgrad_transpose_read_matches_gather_path():
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("shape", [
+    (2, 9, 10, 11, 128, 256, 3),       # 3^3: LDS-transposed rows of 64 input channels
+    (1, 40, 33, 17, 64, 64, 3),        # many splits
+    (3, 5, 6, 7, 256, 128, 1),         # 1^3, float4 route
+    (700, 1, 1, 1, 256, 768, 1),       # a transformer linear over 700 key points
+    (2, 12, 12, 12, 8, 64, 5),         # the stem: 4 real input channels padded to 8, 125 taps
+])
+def test_deferred_wgrad_batched_reduce_is_bit_identical(shape):
+    """dreg_conv3d_wgrad_partials + ONE dreg_wgrad_reduce_batched over several layers == the per-layer weight gradient + its own
+    reduce launch, bit for bit (same split order, same accumulation into an existing gradient)."""
+    dev = _dev()
+    B, D, H, W, cin, cout, k = shape
+    g = torch.Generator().manual_seed(11)
+    cin_real = 4 if cin == 8 else cin
+    x = torch.randn(B, D, H, W, cin, generator=g).to(dev, torch.bfloat16)
+    if cin_real != cin:
+        x[..., cin_real:] = 0
+    stride, pad = (2, 2) if k == 5 else (1, k // 2)
+    Do = (D + 2 * pad - k) // stride + 1
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    gy = torch.randn(B, Do, Ho, Wo, cout, generator=g).to(dev, torch.bfloat16)
+    wshape = (cout, cin_real, k, k, k)
+    base = torch.randn(wshape, generator=g).to(dev)
+    a1, a2 = base.clone(), base.clone()
+    ops.conv_wgrad(gy, x, wshape, cin, k, stride, pad, accumulate_into=a1)
+    ops.conv_wgrad(gy, x, wshape, cin, k, stride, pad, accumulate_into=a1)
+    # three deferred launches over two layers (one layer applied twice: its gradient accumulates twice, in two successive reduce
+    # launches; the other layer shares the first launch)
+    ops.conv_wgrad(gy, x, wshape, cin, k, stride, pad, accumulate_into=a2, defer=True)
+    b2 = torch.zeros(64, 64, 1, 1, 1, device=dev)
+    xo = torch.randn(3, 4, 4, 4, 64, generator=g).to(dev, torch.bfloat16)
+    ops.conv_wgrad(xo, xo, (64, 64, 1, 1, 1), 64, 1, 1, 0, accumulate_into=b2, defer=True)
+    ops.conv_wgrad(gy, x, wshape, cin, k, stride, pad, accumulate_into=a2, defer=True)
+    assert len(ops._PENDING_REDUCE) == 3
+    ops.flush_wgrad_reduce()
+    assert not ops._PENDING_REDUCE
+    assert torch.equal(a1, a2)
+    assert torch.equal(b2, ops.conv_wgrad(xo, xo, (64, 64, 1, 1, 1), 64, 1, 1, 0))
+
+
 def test_conv_upsample_add_epilogue():
     dev = _dev()
     g = torch.Generator().manual_seed(7)
