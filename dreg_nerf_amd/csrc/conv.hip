@@ -830,41 +830,107 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
         }
 }
 
-// sum the split partials and scatter into the torch layout [Cout][Cin_real][ntaps] (fp32), optionally accumulating
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nsplit, int Cout,
-                                    int Kpad, int ntaps, int Cin, int log2Cin, int Cin_real, int accumulate)
-{
-    const size_t total = (size_t)Cout * ntaps * Cin_real;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        // iterate in packed order for coalesced reads: i -> (co, tap, ci)
-        const int ci = (int)(i % Cin_real);
-        const size_t r = i / Cin_real;
-        const int tap = (int)(r % ntaps), co = (int)(r / ntaps);
-        const size_t src = (size_t)co * Kpad + (size_t)tap * Cin + ci;
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * Cout * Kpad + src];
-        const size_t d = ((size_t)co * Cin_real + ci) * ntaps + tap;
-        dw[d] = accumulate ? dw[d] + s : s;
-    }
-}
-
-// Batched form: the partials of MANY layers (each in its own workspace) are summed by one launch.  A workgroup owns (layer, co,
-// 64 input channels): it sums the splits of the [ntaps][64] patch of the packed row (256-byte runs per tap), turns it through LDS
-// and writes 64 * ntaps CONTIGUOUS floats of the torch-layout row (the element-wise kernel above scatters 4-byte words at a stride
-// of ntaps floats).  1^3 layers need no transposition: 2,048 contiguous elements per workgroup.
+// Sum the split partials [nsplit][Cout][Kpad] (K = tap*Cin + ci) into the torch-layout gradient [Cout][Cin_real][ntaps] (fp32),
+// optionally accumulating.  One kernel body serves a single layer (descriptor by value) and the batched form (descriptor table:
+// the partials of MANY layers, each in its own workspace, summed by one launch).
+//  * k^3 layers: a workgroup owns (co, a chunk of input channels): it sums the splits of the [ntaps][chunk] patch of the packed row
+//    (contiguous runs per tap), turns it through LDS and writes chunk * ntaps CONTIGUOUS floats of the torch-layout row;
+//  * 1^3 layers need no transposition: contiguous elements, float4 lanes;
+//  * the sum over the splits is what takes the time for the layers with few weights and hundreds of splits (a handful of
+//    workgroups walking 512 partials each): there the workgroup covers fewer elements and its threads form KG groups that take
+//    every KG-th split, combined through LDS in group order — the result does not depend on the launch shape, only on nsplit.
 struct WgradReduceDesc {
     const float* part; float* dw;
     int nsplit, Cout, Kpad, ntaps, Cin, Cin_real, accumulate, block0;
 };
 static_assert(sizeof(WgradReduceDesc) == 48, "descriptor layout is part of the ABI");
-static inline int wgrad_reduce_blocks(int Cout, int Cin_real, int ntaps)
+constexpr int WR_STAGE = 8192;                              // floats of LDS behind one workgroup
+__host__ __device__ static inline int wr_epb(int nsplit) { return nsplit < 8 ? 2048 : (nsplit < 64 ? 512 : 128); }   // 1^3: elements per workgroup
+__host__ __device__ static inline int wr_chunk(int nsplit) { return nsplit < 32 ? 64 : 16; }                          // k^3: input channels per workgroup
+static inline int wgrad_reduce_blocks(int Cout, int Cin_real, int ntaps, int nsplit)
 {
-    if (ntaps == 1) return (int)(((size_t)Cout * Cin_real + 2047) / 2048);
-    return Cout * ((Cin_real + 63) / 64);
+    if (ntaps == 1) return (int)(((size_t)Cout * Cin_real + wr_epb(nsplit) - 1) / wr_epb(nsplit));
+    return Cout * ((Cin_real + wr_chunk(nsplit) - 1) / wr_chunk(nsplit));
+}
+__device__ __forceinline__ float wr_sum(const float* p, size_t slab, int k0, int kstep, int nsplit)
+{
+    float a = 0.f;
+#pragma unroll 4
+    for (int k = k0; k < nsplit; k += kstep) a += p[(size_t)k * slab];
+    return a;
+}
+__device__ __forceinline__ void wgrad_reduce_block(const WgradReduceDesc& d, int r, float* stage)
+{
+    const int t = threadIdx.x;
+    const size_t slab = (size_t)d.Cout * d.Kpad;
+    if (d.ntaps == 1) {
+        const int epb = wr_epb(d.nsplit), KG = 2048 / epb, EL = 256 / KG, g = t / EL, l = t - g * EL;
+        const size_t total = (size_t)d.Cout * d.Cin_real;
+        const bool vec = (d.Cin_real & 3) == 0;
+        const int per = vec ? 4 : 1, passes = epb / (EL * per);
+        for (int ps = 0; ps < passes; ++ps) {
+            const size_t i = (size_t)r * epb + (size_t)(ps * EL + l) * per;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < total) {
+                const int co = (int)(i / d.Cin_real), ci = (int)(i - (size_t)co * d.Cin_real);
+                const float* src = d.part + (size_t)co * d.Kpad + ci;
+                if (vec) {
+#pragma unroll 4
+                    for (int k = g; k < d.nsplit; k += KG) {
+                        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)k * slab);
+                        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                    }
+                } else a.x = wr_sum(src, slab, g, KG, d.nsplit);
+            }
+            if (KG > 1) {
+                __syncthreads();
+                reinterpret_cast<float4*>(stage)[g * EL + l] = a;
+                __syncthreads();
+                if (g == 0) {
+                    a = reinterpret_cast<float4*>(stage)[l];
+                    for (int q = 1; q < KG; ++q) { const float4 v = reinterpret_cast<float4*>(stage)[q * EL + l]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+                }
+            }
+            if (g == 0 && i < total) {
+                if (vec) {
+                    float4* o = reinterpret_cast<float4*>(d.dw + i);
+                    if (d.accumulate) { const float4 q = *o; a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; }
+                    *o = a;
+                } else d.dw[i] = d.accumulate ? d.dw[i] + a.x : a.x;
+            }
+        }
+        return;
+    }
+    const int cc = wr_chunk(d.nsplit);
+    const int nchunk = (d.Cin_real + cc - 1) / cc;
+    const int co = r / nchunk, ci0 = (r - co * nchunk) * cc;
+    const int nci = min(cc, d.Cin_real - ci0);
+    const int chp = d.Cin < cc ? d.Cin : cc;                  // padded channels of the patch row (a power of two for k > 1)
+    const int sh = 31 - __builtin_clz(chp);
+    const int ne = d.ntaps << sh;                             // patch elements, ordered (tap, channel)
+    const int no = nci * d.ntaps;                             // output elements, ordered (channel, tap)
+    const int KG = (d.nsplit >= 8 && 4 * no <= WR_STAGE) ? 4 : 1, EL = 256 / KG, g = t / EL, l = t - g * EL;
+    const float* src = d.part + (size_t)co * d.Kpad + ci0;
+    for (int e = l; e < ne; e += EL) {
+        const int tap = e >> sh, cl = e & (chp - 1);
+        if (cl < nci) stage[g * no + cl * d.ntaps + tap] = wr_sum(src + (size_t)tap * d.Cin + cl, slab, g, KG, d.nsplit);   // lanes walk cl: stride ntaps (odd)
+    }
+    __syncthreads();
+    float* o = d.dw + ((size_t)co * d.Cin_real + ci0) * d.ntaps;
+    for (int j = t; j < no; j += 256) {
+        float a = stage[j];
+        for (int q = 1; q < KG; ++q) a += stage[q * no + j];
+        o[j] = d.accumulate ? o[j] + a : a;
+    }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceDesc d)
+{
+    __shared__ __align__(16) float stage[WR_STAGE];
+    wgrad_reduce_block(d, (int)blockIdx.x, stage);
 }
 __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgradReduceDesc* __restrict__ descs, int n, int block_base)
 {
-    __shared__ float stage[64 * 125 + 64];
+    __shared__ __align__(16) float stage[WR_STAGE];
     const int blk = (int)blockIdx.x + block_base;
     int lo = 0, hi = n - 1;
     while (lo < hi) {
@@ -872,59 +938,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgradRe
         if (descs[mid].block0 <= blk) lo = mid; else hi = mid - 1;
     }
     const WgradReduceDesc d = descs[lo];
-    const int r = blk - d.block0, t = threadIdx.x;
-    const size_t slab = (size_t)d.Cout * d.Kpad;
-    if (d.ntaps == 1) {
-        const size_t total = (size_t)d.Cout * d.Cin_real;
-        const size_t i0 = (size_t)r * 2048 + (size_t)t * 4;
-        if ((d.Cin_real & 3) == 0) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const size_t i = i0 + (size_t)h * 1024;
-                if (i >= total) break;
-                const int co = (int)(i / d.Cin_real), ci = (int)(i - (size_t)co * d.Cin_real);
-                const float* src = d.part + (size_t)co * d.Kpad + ci;
-                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int k = 0; k < d.nsplit; ++k) {
-                    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)k * slab);
-                    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-                }
-                float4* o = reinterpret_cast<float4*>(d.dw + i);
-                if (d.accumulate) { const float4 p = *o; a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w; }
-                *o = a;
-            }
-        } else {
-            for (int e = 0; e < 8; ++e) {
-                const size_t i = (size_t)r * 2048 + (size_t)e * 256 + t;
-                if (i >= total) break;
-                const int co = (int)(i / d.Cin_real), ci = (int)(i - (size_t)co * d.Cin_real);
-                float a = 0.f;
-                for (int k = 0; k < d.nsplit; ++k) a += d.part[(size_t)k * slab + (size_t)co * d.Kpad + ci];
-                d.dw[i] = d.accumulate ? d.dw[i] + a : a;
-            }
-        }
-        return;
-    }
-    const int nchunk = (d.Cin_real + 63) / 64;
-    const int co = r / nchunk, ci0 = (r - co * nchunk) * 64;
-    const int nci = min(64, d.Cin_real - ci0);
-    const int chp = d.Cin < 64 ? d.Cin : 64;                  // padded channels of the patch row (a power of two for k > 1)
-    const int sh = 31 - __builtin_clz(chp);
-    const float* src = d.part + (size_t)co * d.Kpad + ci0;
-    const int ne = d.ntaps << sh;
-    for (int e = t; e < ne; e += 256) {
-        const int tap = e >> sh, cl = e & (chp - 1);
-        if (cl < nci) {
-            const float* p = src + (size_t)tap * d.Cin + cl;
-            float a = 0.f;
-            for (int k = 0; k < d.nsplit; ++k) a += p[(size_t)k * slab];
-            stage[cl * d.ntaps + tap] = a;                     // lanes walk cl: stride ntaps (odd) floats, conflict-free
-        }
-    }
-    __syncthreads();
-    float* o = d.dw + ((size_t)co * d.Cin_real + ci0) * d.ntaps;
-    const int no = nci * d.ntaps;
-    for (int j = t; j < no; j += 256) o[j] = d.accumulate ? o[j] + stage[j] : stage[j];
+    wgrad_reduce_block(d, blk - d.block0, stage);
 }
 
 // torch weight [Cout][Cin_real][ntaps] fp32 -> gather-form pack [Cout][Kpad] (K = tap*Cin + ci), zero padded.
@@ -1519,9 +1533,9 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
 #undef WG_LAUNCH
     DREG_LAUNCH_CHECK();
     if (defer_reduce) return DREG_OK;    // the caller sums the splits later (dreg_wgrad_reduce_batched)
-    const size_t total = (size_t)Cout * g.ntaps * Cin_real;
-    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, part, dw, nsplit, Cout, g.Kpad, g.ntaps, Cin, g.log2Cin, Cin_real, accumulate);
+    if (g.ntaps > 1 && (size_t)g.ntaps * (Cin < 64 ? Cin : 64) > (size_t)WR_STAGE) return DREG_EINVAL;
+    WgradReduceDesc rd{part, dw, nsplit, Cout, g.Kpad, g.ntaps, Cin, Cin_real, accumulate, 0};
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_blocks(Cout, Cin_real, g.ntaps, nsplit)), dim3(256), 0, st, rd);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
@@ -1572,7 +1586,7 @@ int dreg_conv3d_wgrad_partials(const void* gout, const void* in, void* workspace
                       0, 0, 1, stream, rows, rows ? (uint32_t)nrows : 0, rows ? nullptr : rowocc, true);
 }
 // Workgroups the batched reduce spends on one layer: descriptor i starts at block0 = sum of the counts of the descriptors before it.
-int dreg_wgrad_reduce_blocks(int Cout, int Cin_real, int ksz) { return wgrad_reduce_blocks(Cout, Cin_real, ksz * ksz * ksz); }
+int dreg_wgrad_reduce_blocks(int Cout, int Cin_real, int ksz, int nsplit) { return wgrad_reduce_blocks(Cout, Cin_real, ksz * ksz * ksz, nsplit); }
 // descs_dev: n descriptors {part, dw, nsplit, Cout, Kpad, ntaps, Cin, Cin_real, accumulate, block0} (48 bytes each, device memory,
 // ascending block0); blocks [block_base, block_base + nblocks) are launched, so a sub-range of a long table can be reduced on its own.
 int dreg_wgrad_reduce_batched(const void* descs_dev, int n, int block_base, int nblocks, void* stream)

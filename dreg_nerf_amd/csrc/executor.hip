@@ -185,7 +185,7 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
                     r.dw = w.grad; r.nsplit = dreg_conv3d_wgrad_splits(x.B, y.D, y.H, y.W, x.C, w.d0, o.ksz, 0);
                     r.Cout = w.d0; r.Kpad = dreg_conv3d_kpad(o.ksz, x.C, 0); r.ntaps = o.ksz * o.ksz * o.ksz; r.Cin = x.C; r.Cin_real = w.d1;
                     r.accumulate = 1; r.block0 = e->reduce_blocks;
-                    e->reduce_blocks += dreg_wgrad_reduce_blocks(w.d0, w.d1, o.ksz);
+                    e->reduce_blocks += dreg_wgrad_reduce_blocks(w.d0, w.d1, o.ksz, r.nsplit);
                     o.rd = (int)e->reduce.size();
                     e->reduce.push_back(r);
                 }
@@ -426,8 +426,27 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
         if (hipStreamSynchronize(st) != hipSuccess) return DREG_ELAUNCH;
         e->reduce_arena = arena;
     }
-    std::vector<char> rd_done(e->reduce.size(), 0);   // records whose partials this call produced
+    std::vector<char> rd_done(e->reduce.size(), 0);   // records whose partials this call produced and nobody summed yet
     hipStream_t rd_stream = st;
+    size_t rd_pending = 0;
+    // One launch sums the splits of every pending layer into the torch-layout gradients (on the stream the partials were produced
+    // on: all of them the second stream, or all of them the caller's); layers no gradient reached are left out, so a flush is one
+    // launch per run of consecutive records.  Flushed every ~192 MB of partials: the deep layers' sums then run next to the rest
+    // of the backward pass, and only the last few layers' are left for the end.
+    auto flush_reduce = [&]() -> int {
+        for (int lo = 0, nrec = (int)rd_done.size(); lo < nrec;) {
+            if (!rd_done[lo]) { ++lo; continue; }
+            int hi = lo;
+            while (hi + 1 < nrec && rd_done[hi + 1]) ++hi;
+            Scope sc(e, rd_stream, -1, 3);
+            const int b0 = e->reduce[lo].block0;
+            const int b1 = hi + 1 < nrec ? e->reduce[hi + 1].block0 : e->reduce_blocks;
+            CK(dreg_wgrad_reduce_batched((const ReduceRec*)(A + e->off_rd) + lo, hi - lo + 1, b0, b1 - b0, (void*)rd_stream));
+            for (int q = lo; q <= hi; ++q) rd_done[q] = 0;
+            lo = hi + 1;
+        }
+        return DREG_OK;
+    };
     for (int i = op_end - 1; i >= op_begin; --i) {
         const Op& o = e->ops[i];
         const Tensor& x = e->t[o.in];
@@ -457,6 +476,8 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                                                       y.D, y.H, y.W, w.d0, o.ksz, rows ? 1 : o.stride, o.pad, (!rows && o.in == 0) ? e->in_rowocc : nullptr, (void*)ws));
                         rd_done[o.rd] = 1;
                         rd_stream = ws;
+                        rd_pending += o.wg_bytes;
+                        if (rd_pending >= ((size_t)192 << 20)) { CK(flush_reduce()); rd_pending = 0; }
                     } else if (rows) {
                         CK(dreg_conv3d_wgrad_rows(gy, act(o.in), w.grad, A + o.wg_off, o.wg_bytes, r_out, n_out, x.B, x.D, x.H, x.W, x.C, w.d1,
                                                   y.D, y.H, y.W, w.d0, o.ksz, 1, o.pad, 1, (void*)ws));
@@ -540,19 +561,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
             CK(commit(o.in));
         }
     }
-    // one launch sums the splits of every layer of this range into the torch-layout gradients (on the stream the partials were
-    // produced on: all of them the second stream, or all of them the caller's); layers no gradient reached are left out, so a
-    // range is one launch per run of consecutive records
-    for (int lo = 0, nrec = (int)rd_done.size(); lo < nrec;) {
-        if (!rd_done[lo]) { ++lo; continue; }
-        int hi = lo;
-        while (hi + 1 < nrec && rd_done[hi + 1]) ++hi;
-        Scope sc(e, rd_stream, -1, 3);
-        const int b0 = e->reduce[lo].block0;
-        const int b1 = hi + 1 < nrec ? e->reduce[hi + 1].block0 : e->reduce_blocks;
-        CK(dreg_wgrad_reduce_batched((const ReduceRec*)(A + e->off_rd) + lo, hi - lo + 1, b0, b1 - b0, (void*)rd_stream));
-        lo = hi + 1;
-    }
+    CK(flush_reduce());
     if ((flags & 2) && aux_used) {   // the caller's stream continues (optimizer) only after every parameter gradient has landed
         if (hipEventRecord(e->ev_done, e->aux) != hipSuccess || hipStreamWaitEvent(st, e->ev_done, 0) != hipSuccess) return DREG_ELAUNCH;
     }

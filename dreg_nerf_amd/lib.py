@@ -51,7 +51,7 @@ SIGNATURES = {
     "dreg_conv3d_igemm_rows": (I, [P] * 5 + [P, I] + [I] * 18 + [I, P]),
     "dreg_conv3d_wgrad_rows": (I, [P, P, P, P, Z] + [P, I] + [I] * 14 + [P]),
     "dreg_conv3d_wgrad_partials": (I, [P, P, P, Z, P, I] + [I] * 13 + [P, P]),
-    "dreg_wgrad_reduce_blocks": (I, [I, I, I]),
+    "dreg_wgrad_reduce_blocks": (I, [I, I, I, I]),
     "dreg_wgrad_reduce_batched": (I, [P, I, I, I, P]),
     # conv_halo.hip
     "dreg_conv3_halo_supported": (I, [I] * 6),

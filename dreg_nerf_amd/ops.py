@@ -364,7 +364,7 @@ def flush_wgrad_reduce():
         blocks = 0
         for i, (ws, dw, nsplit, cout, kpad, ntaps, cin, cin_real, ksz) in enumerate(lst):
             recs[i] = (ws.data_ptr(), dw.data_ptr(), nsplit, cout, kpad, ntaps, cin, cin_real, 1, blocks)
-            blocks += lib.dreg_wgrad_reduce_blocks(cout, cin_real, ksz)
+            blocks += lib.dreg_wgrad_reduce_blocks(cout, cin_real, ksz, nsplit)
         table = torch.from_numpy(recs.view(np.uint8)).pin_memory().to(dev, non_blocking=True)
         L.check(lib.dreg_wgrad_reduce_batched(L.ptr(table), len(lst), 0, blocks, L.stream()), "dreg_wgrad_reduce_batched")
         table.record_stream(st)

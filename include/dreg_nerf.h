@@ -127,7 +127,7 @@ int dreg_conv3d_wgrad_rows(const void* gout, const void* in, float* dw, void* wo
 int dreg_conv3d_wgrad_partials(const void* gout, const void* in, void* workspace, size_t workspace_bytes, const int* rows, int nrows,
                                int B, int Di, int Hi, int Wi, int Cin, int Cin_real, int Do, int Ho, int Wo, int Cout,
                                int ksz, int stride, int pad, const uint8_t* rowocc, void* stream);
-int dreg_wgrad_reduce_blocks(int Cout, int Cin_real, int ksz);
+int dreg_wgrad_reduce_blocks(int Cout, int Cin_real, int ksz, int nsplit);
 int dreg_wgrad_reduce_batched(const void* descs_dev, int n, int block_base, int nblocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- FPN3D companions

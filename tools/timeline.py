@@ -62,3 +62,12 @@ for g, c, a, b in gaps:
 print("gap time by (previous kernel, next kernel):")
 for (a, b), t in pairs.most_common(25):
     print(f"  {1e-6 * t:6.3f} ms  {a} -> {b}")
+print("kernel time by queue (this step):")
+for q, rs in sorted(byq.items(), key=lambda kv: -len(kv[1])):
+    agg = collections.Counter(); n = collections.Counter()
+    for r in rs:
+        k = r["Kernel_Name"].split("(")[0][:90]
+        agg[k] += r["e"] - r["s"]; n[k] += 1
+    print(f" queue {q}:")
+    for k, t in agg.most_common(int(sys.argv[3]) if len(sys.argv) > 3 else 28):
+        print(f"   {1e-6 * t:7.3f} ms  n={n[k]:4d}  avg {1e-3 * t / n[k]:7.1f} us  {k}")
