@@ -29,8 +29,8 @@ HBM_PEAK_GBPS = 8000.0          # HBM3E, same table
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--res", type=int, default=128)
     ap.add_argument("--pairs", type=int, default=4, help="pairs per GPU per step (BASELINE batch = 4)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])

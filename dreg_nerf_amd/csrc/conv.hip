@@ -1209,6 +1209,7 @@ static int conv_ksplit(const ConvGeom& g, bool has_addend)
 static int g_glds_stages = 0;
 static inline int glds_stages(long blocks) { (void)blocks; return g_glds_stages ? g_glds_stages : 2; }
 
+static int g_narrow_small = 2;        // tuning (include/dreg_nerf_tuning.h): 128 x 64 tiles for launches of < 224 128 x 128 tiles
 template <typename T, typename TO>
 static int launch_conv(const void* in, const void* wt, void* out, const float* bias, const void* addend,
                        const ConvGeom& g, int relu, int Da, int Ha, int Wa, int add_shift, hipStream_t st,
@@ -1258,7 +1259,9 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
                                    (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows, 1, ns_); } while (0)
             if (g.Cout % 256 == 0 && (g_use_glds == 1 || g_use_glds == 4 || g_use_glds == 5) && nrows >= 65536) GL_LAUNCH(256, 256, 512);
             else if (g.Cout % 256 == 0 && g_use_glds == 3 && nrows >= 65536) GL_LAUNCH(128, 256, 512);
-            else if (g.Cout % 128 == 0) GL_LAUNCH(128, 128, 256);
+            // fewer 128 x 128 tiles than CUs (the point-set half's linear layers: ~77 row tiles x 2): half-width tiles put twice as
+            // many workgroups on the chip
+            else if (g.Cout % 128 == 0 && !(g_narrow_small && ((nrows + 127) / 128) * (g.Cout / 128) < 224)) GL_LAUNCH(128, 128, 256);
             else if (g.Cout % 64 == 0) GL_LAUNCH(128, 64, 256);
             else return DREG_EINVAL;
 #undef GL_LAUNCH
@@ -1428,6 +1431,7 @@ int dreg_pack_conv_weights_batched(const void* descs, int n, int total_rows, int
 }
 
 // number of voxel splits the weight-gradient kernel will use (pure function of the shape)
+void dreg_conv_set_narrow_small(int on) { g_narrow_small = on; }   // 0 off, 1 forward / data gradient only, 2 weight gradients too
 static int g_force_wgrad_splits = 0;
 static int g_wgrad_target_blocks = 3072;
 // tuning knob: workgroups the automatic voxel-split choice of the weight-gradient kernels aims for
@@ -1489,9 +1493,15 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
     uint32_t vps = (uint32_t)((nrows + nsplit - 1) / nsplit);
     vps = ((vps + 63) / 64) * 64;
     if (vps == 0) vps = 64;
-    const int bm = (Cout % 128 == 0) ? 128 : 64;
+    int bm = (Cout % 128 == 0) ? 128 : 64;
+    int bnc = (g.Kpad % 128 == 0) ? 128 : 64;
+    // launches that leave most CUs empty (the point-set half's linear layers: 4 weight tiles x 16 splits) take 64-wide tiles: up to
+    // four times the workgroups, the same per-element accumulation order
+    if (g_narrow_small >= 2 && dtype == 0 && (Cout / bm) * (g.Kpad / bnc) * nsplit < 224) {
+        if (bnc == 128) bnc = 64;
+        if (bm == 128 && (Cout / bm) * (g.Kpad / bnc) * nsplit < 224) bm = 64;
+    }
     const int tilesRow = Cout / bm;
-    const int bnc = (g.Kpad % 128 == 0) ? 128 : 64;
     const int tilesCol = g.Kpad / bnc;
     dim3 grid(tilesRow * tilesCol, nsplit);
     const size_t lds = (size_t)2 * 32 * (bm + bnc) * es;

@@ -59,6 +59,7 @@ SIGNATURES = {
     "dreg_conv3_halo_pack_bytes": (Z, [I]),
     "dreg_pack_conv_weight_halo": (I, [P, P, I, I, I, P]),
     "dreg_conv3_halo": (I, [P, P, P, P, P] + [I] * 10 + [P]),
+    "dreg_conv_set_narrow_small": (None, [I]),
     "dreg_conv3_halo_set_variant": (None, [I]),
     "dreg_conv3_halo_set_prof": (None, [P]),
     # fpn_ops.hip

@@ -127,6 +127,38 @@ def test_deferred_wgrad_batched_reduce_is_bit_identical(shape):
     assert torch.equal(b2, ops.conv_wgrad(xo, xo, (64, 64, 1, 1, 1), 64, 1, 1, 0))
 
 
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_narrow_tiles_for_small_launches_are_bit_identical(out_f32):
+    """Launches with fewer 128 x 128 tiles than CUs run 128 x 64 tiles (include/dreg_nerf_tuning.h: dreg_conv_set_narrow_small): every
+    output element is the same K-ordered MFMA accumulation, so which tile shape a batch size lands on cannot change a result."""
+    from dreg_nerf_amd import lib as L
+    dev = _dev()
+    lib = L.load()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(1, 1, 1, 2400, 256, generator=g).to(dev, torch.bfloat16)
+    w = (torch.randn(256, 256, generator=g) / 16).to(dev)
+    b = torch.randn(256, generator=g).to(dev)
+    wpk = ops.packed_weight(w, 256, False, 0)
+    outs = []
+    try:
+        for on in (1, 0):
+            lib.dreg_conv_set_narrow_small(on)
+            outs.append(ops.conv_igemm(x, wpk, b, None, (1, 1, 2400), 256, 256, 1, 1, 0, False, relu=True, out_f32=out_f32))
+    finally:
+        lib.dreg_conv_set_narrow_small(1)
+    assert torch.equal(outs[0], outs[1])
+    # the weight gradient of the same layer: 4 tiles x 8 splits of 128 x 128 -> 64 x 64 tiles
+    gy = torch.randn(1, 1, 1, 2400, 256, generator=g).to(dev, torch.bfloat16)
+    wg = []
+    try:
+        for on in (1, 0):
+            lib.dreg_conv_set_narrow_small(on)
+            wg.append(ops.conv_wgrad(gy, x, (256, 256), 256, 1, 1, 0))
+    finally:
+        lib.dreg_conv_set_narrow_small(1)
+    assert torch.equal(wg[0], wg[1])
+
+
 def test_conv_upsample_add_epilogue():
     dev = _dev()
     g = torch.Generator().manual_seed(7)
