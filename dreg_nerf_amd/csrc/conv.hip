@@ -825,8 +825,10 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
         for (int r = 0; r < 4; ++r) {
             const int co = co0 + wm * WM + i * 16 + rowq + r;
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                dst[(size_t)co * g.Kpad + n0 + wn * WN + j * 16 + col_l] = acc[i][j][r];
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WN + j * 16 + col_l;
+                if (n < g.Kpad) dst[(size_t)co * g.Kpad + n] = acc[i][j][r];    // the last column tile may be ragged (Kpad = 27 * 64)
+            }
         }
 }
 
@@ -1449,8 +1451,8 @@ int dreg_conv3d_wgrad_splits(int B, int Do, int Ho, int Wo, int Cin, int Cout, i
     const int es = dtype == 0 ? 2 : 4;
     const int bke = 128 / es;
     const int Kpad = ((ksz * ksz * ksz * Cin + bke - 1) / bke) * bke;
-    const int bnc = (Kpad % 128 == 0) ? 128 : 64;
-    const long tiles = (long)((Cout % 128 == 0) ? Cout / 128 : Cout / 64) * (Kpad / bnc);
+    const int bnc = (Kpad % 128 == 0 || (dtype == 0 && Kpad > 128)) ? 128 : 64;
+    const long tiles = (long)((Cout % 128 == 0) ? Cout / 128 : Cout / 64) * ((Kpad + bnc - 1) / bnc);
     const long M = (long)B * Do * Ho * Wo;
     long s = (g_wgrad_target_blocks + tiles - 1) / tiles;
     // enough voxels per split that the fp32 partial tile written per block (64 KB) stays small next to its MFMA work:
@@ -1494,15 +1496,19 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
     vps = ((vps + 63) / 64) * 64;
     if (vps == 0) vps = 64;
     int bm = (Cout % 128 == 0) ? 128 : 64;
-    int bnc = (g.Kpad % 128 == 0) ? 128 : 64;
+    const uint64_t gbytes = (uint64_t)g.M * Cout * 2, ibytes = (uint64_t)B * Di * Hi * Wi * Cin * 2;
+    const bool glds_path = dtype == 0 && use_tr && g_use_glds && gbytes < 0x7fffff00ull && ibytes < 0x7fffff00ull;
+    // 128 columns per tile also when Kpad is an odd multiple of 64 (3^3 taps x 64 channels = 1,728): the direct-to-LDS kernel
+    // masks the ragged last tile (columns >= Kpad gather zeros and are not stored); the older kernels need exact tiles
+    int bnc = (g.Kpad % 128 == 0 || (glds_path && g.Kpad > 128)) ? 128 : 64;
     // launches that leave most CUs empty (the point-set half's linear layers: 4 weight tiles x 16 splits) take 64-wide tiles: up to
     // four times the workgroups, the same per-element accumulation order
-    if (g_narrow_small >= 2 && dtype == 0 && (Cout / bm) * (g.Kpad / bnc) * nsplit < 224) {
+    if (g_narrow_small >= 2 && dtype == 0 && (Cout / bm) * ((g.Kpad + bnc - 1) / bnc) * nsplit < 224) {
         if (bnc == 128) bnc = 64;
         if (bm == 128 && (Cout / bm) * (g.Kpad / bnc) * nsplit < 224) bm = 64;
     }
     const int tilesRow = Cout / bm;
-    const int tilesCol = g.Kpad / bnc;
+    const int tilesCol = (g.Kpad + bnc - 1) / bnc;
     dim3 grid(tilesRow * tilesCol, nsplit);
     const size_t lds = (size_t)2 * 32 * (bm + bnc) * es;
     float* part = (float*)workspace;
@@ -1513,8 +1519,7 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
         else if (bm == 128 && bnc == 64) WG_LAUNCH(T, 128, 64, TRv); \
         else if (bm == 64 && bnc == 128) WG_LAUNCH(T, 64, 128, TRv); \
         else WG_LAUNCH(T, 64, 64, TRv); } while (0)
-    const uint64_t gbytes = (uint64_t)g.M * Cout * 2, ibytes = (uint64_t)B * Di * Hi * Wi * Cin * 2;
-    if (dtype == 0 && use_tr && g_use_glds && gbytes < 0x7fffff00ull && ibytes < 0x7fffff00ull) {
+    if (glds_path) {
 #define WGG(BMv, BNv) do { if (rowlist) hipLaunchKernelGGL((conv_wgrad_glds_kernel<BMv, BNv, true>), dim3(tilesRow * tilesCol * nsplit), dim3(256), (size_t)2 * 64 * (bm + bnc) * 2 + (size_t)vps * 4, st, (const bf16_t*)gout, (const bf16_t*)in, part, g, tilesCol, tilesRow * tilesCol, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows); \
         else hipLaunchKernelGGL((conv_wgrad_glds_kernel<BMv, BNv, false>), dim3(tilesRow * tilesCol * nsplit), dim3(256), (size_t)2 * 64 * (bm + bnc) * 2 + (rowocc ? (size_t)(vps / 64 + 16) : 0), st, (const bf16_t*)gout, (const bf16_t*)in, part, g, tilesCol, tilesRow * tilesCol, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, rowocc); } while (0)
         if (rowlist && vps > 20480) return DREG_EINVAL;   // the row-list slice must fit in LDS behind the stages (caller falls back to dense)

@@ -41,6 +41,7 @@ struct Op {
     size_t aux0 = 0, aux1 = 0;   // BN: scale_shift / mean_rstd; max-pool: argmax
     size_t wg_off = 0, wg_bytes = 0;   // OP_CONV*: this layer's weight-gradient split partials (kept until the batched reduce)
     int rd = -1;                 // index of its record in the reduce table
+    int pool = -1;               // OP_BN: index of the max-pool op fused behind it; OP_MAXPOOL: index of the BatchNorm it is fused into
     int halo = 0;                // OP_CONV: bit 0 = forward, bit 1 = data gradient run on the halo kernel
 };
 struct HaloPack { const float* w; size_t off; int Cout, Cin, transposed; };
@@ -103,6 +104,8 @@ struct Scope {   // optional HIP-event bracket of one launch group
 
 #define CK(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 
+int g_fuse_stem = 1;      // tuning (include/dreg_nerf_tuning.h): BatchNorm + ReLU + max-pool of the stem in one pass
+
 bool s2_class_ok(const Param& p, int ksz, int stride, int pad)
 {
     return stride == 2 && ((ksz == 3 && pad == 1) || (ksz == 1 && pad == 0)) && p.d0 % 64 == 0 && p.d1 % 64 == 0 && dreg_conv_get_glds();
@@ -149,6 +152,19 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
         if (o.kind == OP_CONV || o.kind == OP_CONV_ROWS) g = g || e->prm[o.w].grad || (o.b >= 0 && e->prm[o.b].grad);
         if (o.kind == OP_BN) g = g || e->prm[o.w].grad || e->prm[o.b].grad;
         e->needs_grad[o.out] = g;
+    }
+
+    // stem: a ReLU BatchNorm without residual whose output only feeds a 3^3/2 max-pool runs fused with it (fpn_ops.hip): the
+    // full-resolution activation between them is never written
+    for (size_t i = 0; i + 1 < e->ops.size(); ++i) {
+        Op& o = e->ops[i];
+        if (o.kind != OP_BN || o.in2 >= 0 || o.out == e->out_slot) continue;
+        int users = 0, pool = -1;
+        for (size_t j = 0; j < e->ops.size(); ++j) {
+            const Op& q = e->ops[j];
+            if (q.in == o.out || q.in2 == o.out) { ++users; if (q.kind == OP_MAXPOOL && q.in == o.out && j > i) pool = (int)j; }
+        }
+        if (users == 1 && pool >= 0 && e->t[o.out].C % 8 == 0 && g_fuse_stem) { o.pool = pool; e->ops[pool].pool = (int)i; }
     }
 
     // arena: activations | BN statistics / argmax | gradients | scratch
@@ -305,6 +321,7 @@ void dreg_exec_set_overlap(void* h, int enable) { ((Exec*)h)->use_aux = enable !
 // Output-row occupancy flags (dreg_conv_row_occupancy) of the convolution that reads the network input x_in — the stem: byte
 // [B, Do, Ho], 0 = the row's receptive field in x_in is all zero.  Used by the next forward / backward calls; null = none.
 void dreg_exec_set_input_row_occupancy(void* h, const uint8_t* rowocc) { ((Exec*)h)->in_rowocc = rowocc; }
+void dreg_exec_set_fuse_stem(int on) { g_fuse_stem = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_timing(void* h, int enable) { ((Exec*)h)->timing = enable != 0; }   // records are kept until read
 // After a stream synchronisation: elapsed ms of the bracketed launches since the last set_timing; records are (op, kind, ms)
 // with kind 0 forward, 1 data gradient, 2 weight gradient (+reduce).  Returns the number written (<= max) and restarts.
@@ -359,6 +376,14 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
             CK(dreg_conv3d_igemm_rows(act(o.in), PK + w.pk_fwd, act(o.out), bias, add, (const int*)rowlists[2 * o.rows_out], (int)rowlists[2 * o.rows_out + 1],
                                       x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0, o.ksz, 1, o.pad, 0, 0, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0,
                                       0, 0, stream));
+        } else if (o.kind == OP_BN && o.pool >= 0) {
+            const Op& q = e->ops[o.pool];
+            const Tensor& p = e->t[q.out];
+            CK(dreg_bn_relu_maxpool_fwd(act(o.in), act(q.out), (uint8_t*)(A + q.aux0), e->prm[o.w].val, e->prm[o.b].val, e->prm[o.p2].val, e->prm[o.p3].val,
+                                        (float*)(A + o.aux0), (float*)(A + o.aux1), (float*)(A + e->off_bn_ws), x.B, x.D, x.H, x.W, p.D, p.H, p.W, x.C,
+                                        1e-5f, 0.1f, train, o.relu, stream));
+        } else if (o.kind == OP_MAXPOOL && o.pool >= 0) {
+            // done by the BatchNorm in front of it
         } else if (o.kind == OP_BN) {
             const int V = x.D * x.H * x.W;
             CK(dreg_bn3d_fwd(act(o.in), o.in2 >= 0 ? act(o.in2) : nullptr, act(o.out), e->prm[o.w].val, e->prm[o.b].val, e->prm[o.p2].val, e->prm[o.p3].val,
@@ -451,6 +476,18 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
         const Op& o = e->ops[i];
         const Tensor& x = e->t[o.in];
         const Tensor& y = e->t[o.out];
+        if (o.kind == OP_MAXPOOL && o.pool >= 0) continue;          // un-pooled inside the fused BatchNorm backward below
+        if (o.kind == OP_BN && o.pool >= 0) {
+            const Op& q = e->ops[o.pool];
+            const Tensor& p = e->t[q.out];
+            if (!e->needs_grad[q.out] || !written[q.out]) continue;
+            if (!e->prm[o.w].grad || !e->prm[o.b].grad) return DREG_EINVAL;
+            CK(dreg_bn_relu_maxpool_bwd(act(o.in), grad(q.out), (const uint8_t*)(A + q.aux0), (float*)(A + o.aux0), (float*)(A + o.aux1), dst_for(o.in),
+                                        e->prm[o.w].grad, e->prm[o.b].grad, (float*)(A + e->off_coef), (float*)(A + e->off_bn_ws),
+                                        x.B, x.D, x.H, x.W, p.D, p.H, p.W, x.C, o.relu, 1, stream));
+            CK(commit(o.in));
+            continue;
+        }
         if (!e->needs_grad[o.out] || !written[o.out]) continue;   // nothing flows back through this op
         const void* gy = grad(o.out);
         if (o.kind == OP_CONV || o.kind == OP_CONV_ROWS) {
@@ -557,8 +594,9 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
             }
         } else if (o.kind == OP_MAXPOOL) {
             if (!e->needs_grad[o.in]) continue;
-            CK(dreg_maxpool3d_bwd(gy, (const uint8_t*)(A + o.aux0), dst_for(o.in), x.B, x.D, x.H, x.W, y.D, y.H, y.W, x.C, 0, stream));
-            CK(commit(o.in));
+            // a second contribution (the stem activation also feeds the FPN's finest lateral): added in place, no temporary + add
+            CK(dreg_maxpool3d_bwd_acc(gy, (const uint8_t*)(A + o.aux0), grad(o.in), x.B, x.D, x.H, x.W, y.D, y.H, y.W, x.C, written[o.in] ? 1 : 0, 0, stream));
+            written[o.in] = 1;
         }
     }
     CK(flush_reduce());

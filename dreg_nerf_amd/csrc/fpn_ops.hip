@@ -527,6 +527,7 @@ __global__ void bn_param_grad_kernel(const float* __restrict__ sums, float* __re
     dgamma[c] = accumulate ? dgamma[c] + (float)dg : (float)dg;
     dbeta[c] = accumulate ? dbeta[c] + (float)db : (float)db;
 }
+static int g_bn_debug_skip = 0;      // measurement only (tools/ab_step.py): bit 0 / bit 1 leave out the forward / backward statistics pass (stale statistics)
 static int g_bn_small_maxv = 512;    // tuning (include/dreg_nerf_tuning.h): largest per-grid volume served by the fused kernels, 0 = never
 static inline bool bn_small_ok(int B, int V, int C, int G) { return V >= 2 && V <= g_bn_small_maxv && C % (BNS_COLS * G) == 0 && B >= 1; }
 
@@ -572,7 +573,7 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, u
 // gather-form backward: every input voxel sums the dy of the windows whose arg-max tap points at it
 template <typename T>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ arg, T* __restrict__ dx,
-                                   int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C)
+                                   int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int accumulate)
 {
     constexpr int G = Gran<T>::G;
     const int CG = C / G;
@@ -602,7 +603,150 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __re
                 }
             }
         }
+        if (accumulate) {       // a second contribution to an existing gradient (the FPN lateral's): one read-modify-write, no temporary
+            float prev[G];
+            Gran<T>::ld(dx + i * G, prev);
+#pragma unroll
+            for (int k = 0; k < G; ++k) acc[k] += prev[k];
+        }
         Gran<T>::st(dx + i * G, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ stem: BatchNorm + ReLU + max-pool in one pass
+// resnet3d.py:118-123 runs conv1 -> bn1 -> relu -> maxpool; the full-resolution activation between them (8 x 64^3 x 64 bf16 =
+// 268 MB) is only ever read by the pool.  Forward: the pool kernel normalises on the fly (y rounded to the activation dtype exactly as
+// the unfused pair stores it, same tap order, same strict comparison: pooled values and arg-max taps are bit-identical) and the
+// 268 MB write + read disappear.  Backward: the pooled gradient is un-pooled on the fly (gather form: every input voxel sums the
+// windows whose arg-max points at it) inside the statistics pass and again inside the apply pass — the dense dy is never written.
+template <typename T>
+__global__ void bn_relu_maxpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale_shift, T* __restrict__ y, uint8_t* __restrict__ arg,
+                                           int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int relu)
+{
+    constexpr int G = Gran<T>::G;
+    const int CG = C / G;
+    const size_t total = (size_t)B * Do * Ho * Wo * CG;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        size_t r = i / CG;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho); r /= Ho;
+        const int oz = (int)(r % Do);
+        const int b = (int)(r / Do);
+        float sc[G], sh[G], best[G];
+        int bi[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            sc[k] = scale_shift[((size_t)b * C + cg * G + k) * 2]; sh[k] = scale_shift[((size_t)b * C + cg * G + k) * 2 + 1];
+            best[k] = -INFINITY; bi[k] = 0;
+        }
+        for (int dz = 0; dz < 3; ++dz) {
+            const int z = oz * 2 - 1 + dz; if ((unsigned)z >= (unsigned)Di) continue;
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yy = oy * 2 - 1 + dy; if ((unsigned)yy >= (unsigned)Hi) continue;
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int xx = ox * 2 - 1 + dx; if ((unsigned)xx >= (unsigned)Wi) continue;
+                    float v[G];
+                    Gran<T>::ld(x + ((((size_t)b * Di + z) * Hi + yy) * Wi + xx) * C + (size_t)cg * G, v);
+                    const int tap = (dz * 3 + dy) * 3 + dx;
+#pragma unroll
+                    for (int k = 0; k < G; ++k) {
+                        float o = v[k] * sc[k] + sh[k];
+                        o = relu ? fmaxf(o, 0.f) : o;
+                        if constexpr (sizeof(T) == 2) o = bf2f(f2bf(o));         // what the unfused BatchNorm stores
+                        if (o > best[k]) { best[k] = o; bi[k] = tap; }
+                    }
+                }
+            }
+        }
+        Gran<T>::st(y + i * G, best);
+#pragma unroll
+        for (int k = 0; k < G; ++k) arg[i * G + k] = (uint8_t)bi[k];
+    }
+}
+// g[k] = (sum of the pooled gradients whose arg-max is this input voxel) masked by the ReLU (x*scale + shift > 0)
+template <typename T>
+__device__ __forceinline__ void unpool_gather(const T* __restrict__ dp, const uint8_t* __restrict__ arg, int b, int iz, int iy, int ix,
+                                              int Do, int Ho, int Wo, int C, int c0, float (&acc)[Gran<T>::G])
+{
+    constexpr int G = Gran<T>::G;
+#pragma unroll
+    for (int k = 0; k < G; ++k) acc[k] = 0.f;
+    for (int oz = max(0, iz / 2); oz <= min(Do - 1, (iz + 1) / 2); ++oz) {
+        const int dz = iz - 2 * oz + 1; if (dz < 0 || dz > 2) continue;
+        for (int oy = max(0, iy / 2); oy <= min(Ho - 1, (iy + 1) / 2); ++oy) {
+            const int dyy = iy - 2 * oy + 1; if (dyy < 0 || dyy > 2) continue;
+            for (int ox = max(0, ix / 2); ox <= min(Wo - 1, (ix + 1) / 2); ++ox) {
+                const int dxx = ix - 2 * ox + 1; if (dxx < 0 || dxx > 2) continue;
+                const int tap = (dz * 3 + dyy) * 3 + dxx;
+                const size_t o = ((((size_t)b * Do + oz) * Ho + oy) * Wo + ox) * C + (size_t)c0;
+                float g[G];
+                Gran<T>::ld(dp + o, g);
+                const uint2 a8 = *reinterpret_cast<const uint2*>(arg + o);      // G <= 8 arg-max bytes
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const uint32_t a = ((k < 4 ? a8.x : a8.y) >> (8 * (k & 3))) & 0xffu;
+                    if ((int)a == tap) acc[k] += g[k];
+                }
+            }
+        }
+    }
+}
+// MODE 0: partial[b][chunk][c][2] = (sum g, sum g*xhat) over the chunk's input voxels (grid as bn_partial_kernel);
+// MODE 1: dx = scale * (g - c1 - xhat*c2)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dp, const uint8_t* __restrict__ arg,
+                                                          const float* __restrict__ mean_rstd, const float* __restrict__ scale_shift,
+                                                          const float* __restrict__ coef, float* __restrict__ partial, T* __restrict__ dx,
+                                                          int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int rows_per_chunk, int relu)
+{
+    constexpr int G = Gran<T>::G;
+    static_assert(G == 8, "arg-max bytes are read eight at a time");
+    const int V = Di * Hi * Wi;
+    const int CG = C / G, cgs = CG < 256 ? CG : 256, rpi = 256 / cgs;
+    const int t = threadIdx.x, cg = blockIdx.z * cgs + (t % cgs), r0 = t / cgs, b = blockIdx.y;
+    const int chunk = blockIdx.x, nchunks = gridDim.x;
+    const int v0 = chunk * rows_per_chunk, v1 = min(v0 + rows_per_chunk, V);
+    float mu[G], rs[G], sc[G], sh[G], c1[G], c2[G], s1[G], s2[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const size_t pc = ((size_t)b * C + cg * G + i) * 2;
+        mu[i] = mean_rstd[pc]; rs[i] = mean_rstd[pc + 1]; sc[i] = scale_shift[pc]; sh[i] = scale_shift[pc + 1];
+        if (MODE == 1) { c1[i] = coef[pc]; c2[i] = coef[pc + 1]; }
+        s1[i] = s2[i] = 0.f;
+    }
+    if (r0 < rpi && cg < CG)
+        for (int v = v0 + r0; v < v1; v += rpi) {
+            const int ix = v % Wi, iy = (v / Wi) % Hi, iz = v / (Wi * Hi);
+            float xv[G], g[G];
+            const size_t off = ((size_t)b * V + v) * C + (size_t)cg * G;
+            Gran<T>::ld(x + off, xv);
+            unpool_gather<T>(dp, arg, b, iz, iy, ix, Do, Ho, Wo, C, cg * G, g);
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                if (relu && !((xv[k] * sc[k] + sh[k]) > 0.f)) g[k] = 0.f;
+                const float xh = (xv[k] - mu[k]) * rs[k];
+                if (MODE == 0) { s1[k] += g[k]; s2[k] += g[k] * xh; }
+                else xv[k] = sc[k] * (g[k] - c1[k] - xh * c2[k]);
+            }
+            if (MODE == 1) Gran<T>::st(dx + off, xv);
+        }
+    if (MODE == 0) {
+        __shared__ float red[256][2 * 8 + 1];
+#pragma unroll
+        for (int i = 0; i < G; ++i) { red[t][i] = s1[i]; red[t][G + i] = s2[i]; }
+        __syncthreads();
+        if (t < cgs) {
+            float a1[G], a2[G];
+#pragma unroll
+            for (int i = 0; i < G; ++i) { a1[i] = 0.f; a2[i] = 0.f; }
+            for (int r = 0; r < rpi; ++r)
+#pragma unroll
+                for (int i = 0; i < G; ++i) { a1[i] += red[r * cgs + t][i]; a2[i] += red[r * cgs + t][G + i]; }
+            float* dst = partial + (((size_t)b * nchunks + chunk) * C + (size_t)cg * G) * 2;
+#pragma unroll
+            for (int i = 0; i < G; ++i) { dst[2 * i] = a1[i]; dst[2 * i + 1] = a2[i]; }
+        }
     }
 }
 
@@ -969,6 +1113,7 @@ static inline int bn_rows_per_chunk(int V) { return V >= 262144 ? 512 : V >= 327
 
 extern "C" {
 
+void dreg_bn_set_debug_skip(int mask) { g_bn_debug_skip = mask; }
 void dreg_bn_set_small_max_voxels(int v) { g_bn_small_maxv = v; }
 int dreg_bn_num_chunks(int V) { const int r = bn_rows_per_chunk(V); return (V + r - 1) / r; }
 
@@ -995,7 +1140,7 @@ int dreg_bn3d_fwd(const void* x, const void* res, void* y, const float* gamma, c
         DREG_LAUNCH_CHECK();
         return DREG_OK;
     }
-    if (train) {
+    if (train && !(g_bn_debug_skip & 1)) {
         if (train && V < 2) return DREG_EINVAL;  // torch raises for one value per channel
         dim3 grid(nch, B, slabs);
         if (dtype == 0) hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 0>), grid, dim3(256), 0, st, (const bf16_t*)x, nullptr, nullptr, nullptr, workspace, V, C, rpc, 0);
@@ -1040,7 +1185,8 @@ int dreg_bn3d_bwd(const void* x, const void* dy, const void* y, const float* sca
         return DREG_OK;
     }
     dim3 grid(nch, B, slabs);
-    if (dtype == 0) hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean_rstd, workspace, V, C, rpc, relu, scale_shift);
+    if (g_bn_debug_skip & 2) {}
+    else if (dtype == 0) hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean_rstd, workspace, V, C, rpc, relu, scale_shift);
     else hipLaunchKernelGGL((bn_partial_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y, mean_rstd, workspace, V, C, rpc, relu, scale_shift);
     DREG_LAUNCH_CHECK();
     if (B > BN_MAX_GRIDS) return DREG_EINVAL;
@@ -1050,6 +1196,53 @@ int dreg_bn3d_bwd(const void* x, const void* dy, const void* y, const float* sca
     (void)tg;
     if (dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean_rstd, scale_shift, coef, (bf16_t*)dx, (bf16_t*)dres, V, C, rpc, relu);
     else hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y, mean_rstd, scale_shift, coef, (float*)dx, (float*)dres, V, C, rpc, relu);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// Fused stem (bf16): statistics + finalize of dreg_bn3d_fwd, then pooled = maxpool3(relu(bn(x))) without the full-resolution
+// activation in between.  x: [B,Di,Hi,Wi,C]; pooled: [B,Do,Ho,Wo,C]; argmax: uint8 per pooled element; no residual.
+int dreg_bn_relu_maxpool_fwd(const void* x, void* pooled, uint8_t* argmax, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
+                             int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, float eps, float momentum, int train, int relu, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int V = Di * Hi * Wi;
+    if (C % 8 || B > BN_MAX_GRIDS || (train && V < 2)) return DREG_EINVAL;
+    const int rpc = bn_rows_per_chunk(V), nch = (V + rpc - 1) / rpc;
+    const int CG = C / 8, slabs = (CG + 255) / 256;
+    if (train) {
+        hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 0>), dim3(nch, B, slabs), dim3(256), 0, st, (const bf16_t*)x, nullptr, nullptr, nullptr, workspace, V, C, rpc, 0);
+        DREG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64 * (B < 8 ? B : 8)), 0, st, workspace, gamma, beta, running_mean, running_var,
+                       scale_shift, mean_rstd, B, nch, C, V, eps, momentum, train);
+    DREG_LAUNCH_CHECK();
+    const size_t total = (size_t)B * Do * Ho * Wo * CG;
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, st, (const bf16_t*)x, scale_shift, (bf16_t*)pooled, argmax,
+                       B, Di, Hi, Wi, Do, Ho, Wo, C, relu);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// Its backward: dx = d(loss)/dx from the POOLED gradient dp; dgamma / dbeta as dreg_bn3d_bwd.  coef: fp32 [B,C,2] scratch,
+// workspace as dreg_bn3d_fwd.
+int dreg_bn_relu_maxpool_bwd(const void* x, const void* dp, const uint8_t* argmax, const float* scale_shift, const float* mean_rstd,
+                             void* dx, float* dgamma, float* dbeta, float* coef, float* workspace,
+                             int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int relu, int accumulate, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int V = Di * Hi * Wi;
+    if (C % 8 || B > BN_MAX_GRIDS) return DREG_EINVAL;
+    const int rpc = bn_rows_per_chunk(V), nch = (V + rpc - 1) / rpc;
+    const int CG = C / 8, slabs = (CG + 255) / 256;
+    const dim3 grid(nch, B, slabs);
+    hipLaunchKernelGGL((bn_pool_bwd_kernel<bf16_t, 0>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dp, argmax, mean_rstd, scale_shift, nullptr, workspace,
+                       (bf16_t*)nullptr, Di, Hi, Wi, Do, Ho, Wo, C, rpc, relu);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64 * (B < 8 ? B : 8)), 0, st, workspace, coef, dgamma, dbeta, B, nch, C, V, accumulate);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL((bn_pool_bwd_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dp, argmax, mean_rstd, scale_shift, coef, nullptr,
+                       (bf16_t*)dx, Di, Hi, Wi, Do, Ho, Wo, C, rpc, relu);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
@@ -1064,15 +1257,21 @@ int dreg_maxpool3d_fwd(const void* x, void* y, uint8_t* argmax, int B, int Di, i
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
-int dreg_maxpool3d_bwd(const void* dy, const uint8_t* argmax, void* dx, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int dtype, void* stream)
+// accumulate: dx += the un-pooled gradient (dx already holds another contribution: fp32 sum, one rounding)
+int dreg_maxpool3d_bwd_acc(const void* dy, const uint8_t* argmax, void* dx, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int accumulate,
+                           int dtype, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
     const int G = dtype == 0 ? 8 : 4;
     const size_t total = (size_t)B * Di * Hi * Wi * (C / G);
-    if (dtype == 0) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, B, Di, Hi, Wi, Do, Ho, Wo, C);
-    else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(nblocks(total)), dim3(256), 0, st, (const float*)dy, argmax, (float*)dx, B, Di, Hi, Wi, Do, Ho, Wo, C);
+    if (dtype == 0) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, B, Di, Hi, Wi, Do, Ho, Wo, C, accumulate);
+    else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(nblocks(total)), dim3(256), 0, st, (const float*)dy, argmax, (float*)dx, B, Di, Hi, Wi, Do, Ho, Wo, C, accumulate);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
+}
+int dreg_maxpool3d_bwd(const void* dy, const uint8_t* argmax, void* dx, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int dtype, void* stream)
+{
+    return dreg_maxpool3d_bwd_acc(dy, argmax, dx, B, Di, Hi, Wi, Do, Ho, Wo, C, 0, dtype, stream);
 }
 
 int dreg_downsample_sum(const void* g, void* out, int B, int Df, int Hf, int Wf, int Dc, int Hc, int Wc, int C, int dtype, void* stream)

@@ -60,15 +60,20 @@ SIGNATURES = {
     "dreg_pack_conv_weight_halo": (I, [P, P, I, I, I, P]),
     "dreg_conv3_halo": (I, [P, P, P, P, P] + [I] * 10 + [P]),
     "dreg_conv_set_narrow_small": (None, [I]),
+    "dreg_bn_set_debug_skip": (None, [I]),
+    "dreg_exec_set_fuse_stem": (None, [I]),
     "dreg_conv3_halo_set_variant": (None, [I]),
     "dreg_conv3_halo_set_prof": (None, [P]),
     # fpn_ops.hip
     "dreg_bn_num_chunks": (I, [I]),
     "dreg_bn_set_small_max_voxels": (None, [I]),
+    "dreg_bn_relu_maxpool_fwd": (I, [P] * 10 + [I] * 8 + [F, F, I, I, P]),
+    "dreg_bn_relu_maxpool_bwd": (I, [P] * 10 + [I] * 10 + [P]),
     "dreg_bn3d_fwd": (I, [P] * 10 + [I, I, I, F, F, I, I, I, P]),
     "dreg_bn3d_bwd": (I, [P] * 11 + [I, I, I, I, I, I, P]),
     "dreg_maxpool3d_fwd": (I, [P, P, P] + [I] * 9 + [P]),
     "dreg_maxpool3d_bwd": (I, [P, P, P] + [I] * 9 + [P]),
+    "dreg_maxpool3d_bwd_acc": (I, [P, P, P] + [I] * 10 + [P]),
     "dreg_downsample_sum": (I, [P, P] + [I] * 9 + [P]),
     "dreg_colsum_workspace_bytes": (Z, [Z, I]),
     "dreg_colsum": (I, [P, P, P, Z, I, I, I, P]),

@@ -143,11 +143,22 @@ int dreg_bn3d_bwd(const void* x, const void* dy, const void* y, const float* sca
                   void* dx, void* dres, float* dgamma, float* dbeta, float* coef, float* workspace,
                   int B, int V, int C, int relu, int accumulate, int dtype, void* stream);
 
+/* Stem fused (resnet3d.py:118-123: conv1 -> bn1 -> relu -> maxpool, bf16): pooled = maxpool3(relu(bn(x))) and its backward without the
+ * full-resolution activation / gradient in between; pooled values and arg-max taps are bit-identical to dreg_bn3d_fwd + dreg_maxpool3d_fwd. */
+int dreg_bn_relu_maxpool_fwd(const void* x, void* pooled, uint8_t* argmax, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
+                             int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, float eps, float momentum, int train, int relu, void* stream);
+int dreg_bn_relu_maxpool_bwd(const void* x, const void* dp, const uint8_t* argmax, const float* scale_shift, const float* mean_rstd,
+                             void* dx, float* dgamma, float* dbeta, float* coef, float* workspace,
+                             int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int relu, int accumulate, void* stream);
 /* nn.MaxPool3d(3, 2, 1) (resnet3d.py:123,161); argmax: uint8 [B,Do,Ho,Wo,C] tap index for the backward pass. */
 int dreg_maxpool3d_fwd(const void* x, void* y, uint8_t* argmax, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                        int C, int dtype, void* stream);
 int dreg_maxpool3d_bwd(const void* dy, const uint8_t* argmax, void* dx, int B, int Di, int Hi, int Wi, int Do, int Ho,
                        int Wo, int C, int dtype, void* stream);
+/* the same adding into an existing dx (accumulate = 1): a tensor with a second consumer gets its gradient in one read-modify-write */
+int dreg_maxpool3d_bwd_acc(const void* dy, const uint8_t* argmax, void* dx, int B, int Di, int Hi, int Wi, int Do, int Ho,
+                           int Wo, int C, int accumulate, int dtype, void* stream);
 
 /* backward of the nearest x2 upsample + crop: out[b,z,y,x,:] = sum of the in-range 2x2x2 children of g */
 int dreg_downsample_sum(const void* g, void* out, int B, int Df, int Hf, int Wf, int Dc, int Hc, int Wc, int C,

@@ -159,6 +159,53 @@ def test_narrow_tiles_for_small_launches_are_bit_identical(out_f32):
     assert torch.equal(wg[0], wg[1])
 
 
+@pytest.mark.parametrize("shape", [(2, 12, 10, 14, 64), (1, 9, 11, 7, 16)])
+def test_fused_stem_bn_relu_maxpool_matches_the_unfused_pair(shape):
+    """dreg_bn_relu_maxpool_fwd / _bwd (what the trunk executor runs for conv1 -> bn1 -> relu -> maxpool) against dreg_bn3d_fwd +
+    dreg_maxpool3d_fwd and their backwards: pooled values, arg-max taps, statistics and running statistics bit-identical; the input
+    gradient agrees to bf16 round-off (the unfused chain rounds the un-pooled gradient to bf16 in between, the fused one does not)."""
+    from dreg_nerf_amd import lib as L
+    dev = _dev()
+    lib = L.load()
+    B, D, H, W, C = shape
+    Do, Ho, Wo = (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
+    g = torch.Generator().manual_seed(17)
+    x = (torch.randn(B, D, H, W, C, generator=g) * 2 + 0.3).to(dev, torch.bfloat16)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.3).to(dev)
+    dp = torch.randn(B, Do, Ho, Wo, C, generator=g).to(dev, torch.bfloat16)
+    V = D * H * W
+    nws = B * lib.dreg_bn_num_chunks(V) * C * 2
+
+    def buffers():
+        return dict(rm=torch.zeros(C, device=dev), rv=torch.ones(C, device=dev), ss=torch.zeros(B, C, 2, device=dev), mr=torch.zeros(B, C, 2, device=dev),
+                    ws=torch.zeros(nws, device=dev), coef=torch.zeros(B, C, 2, device=dev), dg=torch.zeros(C, device=dev), db=torch.zeros(C, device=dev),
+                    p=torch.empty(B, Do, Ho, Wo, C, dtype=torch.bfloat16, device=dev), arg=torch.empty(B, Do, Ho, Wo, C, dtype=torch.uint8, device=dev),
+                    dx=torch.empty_like(x))
+    a, b = buffers(), buffers()
+    st = L.stream()
+    # unfused
+    y = torch.empty_like(x)
+    L.check(lib.dreg_bn3d_fwd(L.ptr(x), None, L.ptr(y), L.ptr(gamma), L.ptr(beta), L.ptr(a["rm"]), L.ptr(a["rv"]), L.ptr(a["ss"]), L.ptr(a["mr"]), L.ptr(a["ws"]),
+                              B, V, C, 1e-5, 0.1, 1, 1, 0, st), "bn fwd")
+    L.check(lib.dreg_maxpool3d_fwd(L.ptr(y), L.ptr(a["p"]), L.ptr(a["arg"]), B, D, H, W, Do, Ho, Wo, C, 0, st), "pool fwd")
+    dy = torch.empty_like(x)
+    L.check(lib.dreg_maxpool3d_bwd(L.ptr(dp), L.ptr(a["arg"]), L.ptr(dy), B, D, H, W, Do, Ho, Wo, C, 0, st), "pool bwd")
+    L.check(lib.dreg_bn3d_bwd(L.ptr(x), L.ptr(dy), None, L.ptr(a["ss"]), L.ptr(a["mr"]), L.ptr(a["dx"]), None, L.ptr(a["dg"]), L.ptr(a["db"]), L.ptr(a["coef"]),
+                              L.ptr(a["ws"]), B, V, C, 1, 0, 0, st), "bn bwd")
+    # fused
+    L.check(lib.dreg_bn_relu_maxpool_fwd(L.ptr(x), L.ptr(b["p"]), L.ptr(b["arg"]), L.ptr(gamma), L.ptr(beta), L.ptr(b["rm"]), L.ptr(b["rv"]), L.ptr(b["ss"]),
+                                         L.ptr(b["mr"]), L.ptr(b["ws"]), B, D, H, W, Do, Ho, Wo, C, 1e-5, 0.1, 1, 1, st), "fused fwd")
+    L.check(lib.dreg_bn_relu_maxpool_bwd(L.ptr(x), L.ptr(dp), L.ptr(b["arg"]), L.ptr(b["ss"]), L.ptr(b["mr"]), L.ptr(b["dx"]), L.ptr(b["dg"]), L.ptr(b["db"]),
+                                         L.ptr(b["coef"]), L.ptr(b["ws"]), B, D, H, W, Do, Ho, Wo, C, 1, 0, st), "fused bwd")
+    torch.cuda.synchronize()
+    for k in ("p", "arg", "ss", "mr", "rm", "rv"):
+        assert torch.equal(a[k], b[k]), k
+    for k in ("dg", "db"):
+        np.testing.assert_allclose(b[k].cpu().numpy(), a[k].cpu().numpy(), rtol=2e-2, atol=2e-2 * float(a[k].abs().max()))
+    d = (a["dx"].float() - b["dx"].float()).abs().max().item()
+    assert d <= 2e-2 * a["dx"].float().abs().max().item(), d
+
+
 def test_conv_upsample_add_epilogue():
     dev = _dev()
     g = torch.Generator().manual_seed(7)

@@ -11,7 +11,10 @@ dense = "--dense" in args
 rounds = int(args[args.index("--rounds") + 1]) if "--rounds" in args else 3
 steps = int(args[args.index("--steps") + 1]) if "--steps" in args else 12
 setter = args[0]
-vals = [int(a) for a in args[1:] if a.lstrip("-").isdigit() and args[args.index(a) - 1] not in ("--rounds", "--steps")]
+vals = []
+for i, a in enumerate(args[1:], 1):
+    if a.lstrip("-").isdigit() and args[i - 1] not in ("--rounds", "--steps"):
+        vals.append(int(a))
 lib = L.load()
 fn = getattr(lib, setter)
 dev = torch.device("cuda", 0)
@@ -28,6 +31,7 @@ res = {v: [] for v in vals}
 for r in range(rounds):
     for v in (vals if r % 2 == 0 else vals[::-1]):
         fn(v)
+        model.__dict__.pop('_trunk_cache', None)      # setters read at executor creation take effect
         for _ in range(2): ts.step(batch)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(steps): ts.step(batch)
