@@ -41,6 +41,9 @@ struct Op {
     size_t aux0 = 0, aux1 = 0;   // BN: scale_shift / mean_rstd; max-pool: argmax
     size_t wg_off = 0, wg_bytes = 0;   // OP_CONV*: this layer's weight-gradient split partials (kept until the batched reduce)
     int rd = -1;                 // index of its record in the reduce table
+    int sparse_gx = 0;           // OP_CONV_ROWS: the input's gradient buffer has no other writer: kept zero outside the rows of the last step
+    size_t cl_off = 0;           //   arena copy of the row list that was written (cleared at the start of the next backward)
+    int cl_count = 0;
     int pool = -1;               // OP_BN: index of the max-pool op fused behind it; OP_MAXPOOL: index of the BatchNorm it is fused into
     int halo = 0;                // OP_CONV: bit 0 = forward, bit 1 = data gradient run on the halo kernel
 };
@@ -62,6 +65,7 @@ struct Exec {
     size_t off_bn_ws = 0, off_coef = 0, off_ks = 0, off_rd = 0, off_cs = 0, off_tmp = 0;
     size_t sz_ks = 0;
     std::vector<ReduceRec> reduce;         // one per convolution with a weight gradient, in op order; part = arena offset
+    const void* sparse_arena = nullptr;     // arena whose sparse gradient buffers are in the all-zero state
     std::vector<ReduceRec> reduce_abs;     // the same with absolute addresses for the arena it was last uploaded to
     int reduce_blocks = 0;
     const void* reduce_arena = nullptr;
@@ -104,6 +108,7 @@ struct Scope {   // optional HIP-event bracket of one launch group
 
 #define CK(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 
+int g_sparse_grads = 1;   // tuning (include/dreg_nerf_tuning.h): row-cleared instead of memset gradient buffers in front of the active-set convolutions
 int g_fuse_stem = 1;      // tuning (include/dreg_nerf_tuning.h): BatchNorm + ReLU + max-pool of the stem in one pass
 
 bool s2_class_ok(const Param& p, int ksz, int stride, int pad)
@@ -215,6 +220,17 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
         if (e->t[i].bytes > max_tensor) max_tensor = e->t[i].bytes;
         if (e->needs_grad[i] && i != e->out_slot) { e->t[i].goff = off; off += e->t[i].bytes; } else e->t[i].goff = SIZE_MAX;
     }
+    // gradient buffers written by exactly one active-set convolution (the lateral sums in front of the head's 3^3 convolutions,
+    // 1 GB at 8 x 64^3 x 256): instead of a dense memset per step they are kept zero outside the rows of the step before, and
+    // those rows (a copy of the row list lives in the arena) are cleared when the next backward starts
+    for (Op& o : e->ops) {
+        if (o.kind != OP_CONV_ROWS || !e->needs_grad[o.in] || o.in == 0 || e->t[o.in].goff == SIZE_MAX) continue;
+        int writers = 0;
+        for (const Op& q : e->ops) if ((q.in == o.in || q.in2 == o.in) && e->needs_grad[q.out]) ++writers;
+        if (writers != 1 || !g_sparse_grads) continue;
+        const Tensor& x = e->t[o.in];
+        o.sparse_gx = 1; o.cl_off = off; off += align256((size_t)x.B * x.D * x.H * x.W * sizeof(int));
+    }
     e->off_bn_ws = off; off += align256(bn_ws);
     e->off_coef = off; off += align256(coef);
     e->off_ks = off; off += align256(e->sz_ks);
@@ -321,6 +337,7 @@ void dreg_exec_set_overlap(void* h, int enable) { ((Exec*)h)->use_aux = enable !
 // Output-row occupancy flags (dreg_conv_row_occupancy) of the convolution that reads the network input x_in — the stem: byte
 // [B, Do, Ho], 0 = the row's receptive field in x_in is all zero.  Used by the next forward / backward calls; null = none.
 void dreg_exec_set_input_row_occupancy(void* h, const uint8_t* rowocc) { ((Exec*)h)->in_rowocc = rowocc; }
+void dreg_exec_set_sparse_grads(int on) { g_sparse_grads = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_fuse_stem(int on) { g_fuse_stem = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_timing(void* h, int enable) { ((Exec*)h)->timing = enable != 0; }   // records are kept until read
 // After a stream synchronisation: elapsed ms of the bracketed launches since the last set_timing; records are (op, kind, ms)
@@ -451,6 +468,18 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
         if (hipStreamSynchronize(st) != hipSuccess) return DREG_ELAUNCH;
         e->reduce_arena = arena;
     }
+    if (flags & 1) {
+        // sparse gradient buffers back to all-zero: a dense memset the first time this arena is seen, the rows of the last step after that
+        const bool fresh = e->sparse_arena != arena;
+        for (Op& o : e->ops) {
+            if (!o.sparse_gx) continue;
+            const Tensor& x = e->t[o.in];
+            if (fresh) { if (hipMemsetAsync(A + x.goff, 0, (size_t)x.B * x.D * x.H * x.W * x.C * 2, st) != hipSuccess) return DREG_ELAUNCH; }
+            else if (o.cl_count > 0) CK(dreg_zero_rows(A + x.goff, (const int*)(A + o.cl_off), o.cl_count, x.C, 0, stream));
+            o.cl_count = 0;
+        }
+        e->sparse_arena = arena;
+    }
     std::vector<char> rd_done(e->reduce.size(), 0);   // records whose partials this call produced and nobody summed yet
     hipStream_t rd_stream = st;
     size_t rd_pending = 0;
@@ -551,7 +580,13 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                                             o.ksz, o.stride, o.pad, 1, 0, x.D, x.H, x.W, 1, 0, 0, A + e->off_ks, e->sz_ks, stream));
                 } else if (rows) {
                     if (o.rows_in < 0 || o.rows_in >= nlists) return DREG_EINVAL;
-                    if (hipMemsetAsync(gx, 0, (size_t)x.B * x.D * x.H * x.W * x.C * 2, st) != hipSuccess) return DREG_ELAUNCH;
+                    const int* r_in = (const int*)rowlists[2 * o.rows_in];
+                    const int n_in = (int)rowlists[2 * o.rows_in + 1];
+                    if (o.sparse_gx && gx == grad(o.in)) {
+                        // the buffer is zero everywhere (see the start of this call); remember which rows this step writes
+                        if (n_in > 0 && hipMemcpyAsync(A + o.cl_off, r_in, (size_t)n_in * sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess) return DREG_ELAUNCH;
+                        const_cast<Op&>(o).cl_count = n_in;
+                    } else if (hipMemsetAsync(gx, 0, (size_t)x.B * x.D * x.H * x.W * x.C * 2, st) != hipSuccess) return DREG_ELAUNCH;
                     CK(dreg_conv3d_igemm_rows(gy, PK + w.pk_dgrad, gx, nullptr, nullptr, (const int*)rowlists[2 * o.rows_in], (int)rowlists[2 * o.rows_in + 1],
                                               x.B, y.D, y.H, y.W, w.d0, x.D, x.H, x.W, x.C, o.ksz, 1, o.pad, 1, 0, 0, 0, 0, 0, 0, stream));
                 } else if (w.pk_cls != SIZE_MAX && s2_class_ok(w, o.ksz, o.stride, o.pad)) {

@@ -982,6 +982,20 @@ __global__ void scatter_rows_cast_kernel(const float* __restrict__ comp, const i
         Gran<T>::st(out + (size_t)rows[r] * C + (size_t)cg * G, v);
     }
 }
+// out[rows[r]][:] = 0: returns a dense buffer that only ever holds values on a row list to the all-zero state (the gradient
+// buffers in front of the active-set convolutions: 1 GB each at 8 x 64^3 x 256 — zeroing the ~5 % of rows that were written instead
+// of the whole buffer every step)
+template <typename T>
+__global__ void zero_rows_kernel(const int* __restrict__ rows, T* __restrict__ out, size_t total_gran, int C)
+{
+    constexpr int G = Gran<T>::G;
+    const int CG = C / G;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total_gran; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        const size_t r = i / CG;
+        *reinterpret_cast<uint4*>(out + (size_t)rows[r] * C + (size_t)cg * G) = make_uint4(0, 0, 0, 0);
+    }
+}
 // column sums over a row list: partial[chunk][c] = sum over rows[chunk*rpc .. ) of g[rows[i]][c]
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_rows_partial_kernel(const T* __restrict__ g, const int* __restrict__ rows, float* __restrict__ partial,
@@ -1442,15 +1456,39 @@ int dreg_trilinear_gather_bwd_rows(const float* dfeat, const int64_t* idx, const
     return DREG_OK;
 }
 
+int dreg_zero_rows(void* buf, const int* rows, int nrows, int C, int dtype, void* stream)
+{
+    const int G = dtype == 0 ? 8 : 4;
+    if (C % G || nrows < 0) return DREG_EINVAL;
+    if (nrows == 0) return DREG_OK;
+    const size_t tg = (size_t)nrows * (C / G);
+    if (dtype == 0) hipLaunchKernelGGL(zero_rows_kernel<bf16_t>, dim3(nblocks(tg)), dim3(256), 0, (hipStream_t)stream, rows, (bf16_t*)buf, tg, C);
+    else hipLaunchKernelGGL(zero_rows_kernel<float>, dim3(nblocks(tg)), dim3(256), 0, (hipStream_t)stream, rows, (float*)buf, tg, C);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
 // Deterministic variant (no atomics): fine_map int32 [B*Zr*Xr*Yr] scratch.  C must be 64, 128, 192 or 256.
+// zero_dense = 0: dp1 is already zero outside rows1 (a persistent buffer the caller cleans with dreg_zero_rows); only rows1 are written.
+static int tri_bwd_gather(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
+                          int* fine_map, void* dp1, int N, int B, int d, int h, int w, int C, int Zr, int Xr, int Yr,
+                          int dtype, int zero_dense, void* stream);
 int dreg_trilinear_gather_bwd_gather(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
                                      int* fine_map, void* dp1, int N, int B, int d, int h, int w, int C, int Zr, int Xr, int Yr,
                                      int dtype, void* stream)
+{ return tri_bwd_gather(dfeat, idx, pt_batch, rows1, n1, fine_map, dp1, N, B, d, h, w, C, Zr, Xr, Yr, dtype, 1, stream); }
+int dreg_trilinear_gather_bwd_gather_rows_only(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
+                                               int* fine_map, void* dp1, int N, int B, int d, int h, int w, int C, int Zr, int Xr, int Yr,
+                                               int dtype, void* stream)
+{ return tri_bwd_gather(dfeat, idx, pt_batch, rows1, n1, fine_map, dp1, N, B, d, h, w, C, Zr, Xr, Yr, dtype, 0, stream); }
+static int tri_bwd_gather(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
+                          int* fine_map, void* dp1, int N, int B, int d, int h, int w, int C, int Zr, int Xr, int Yr,
+                          int dtype, int zero_dense, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (C % 64 || C > 256) return DREG_EINVAL;
     const size_t dense_bytes = (size_t)B * d * h * w * C * (dtype == 0 ? 2 : 4);
-    if (hipMemsetAsync(dp1, 0, dense_bytes, st) != hipSuccess) return DREG_ELAUNCH;
+    if (zero_dense && hipMemsetAsync(dp1, 0, dense_bytes, st) != hipSuccess) return DREG_ELAUNCH;
     if (N == 0 || n1 == 0) return DREG_OK;
     const size_t Vf = (size_t)Zr * Xr * Yr;
     if (hipMemsetAsync(fine_map, 0xff, (size_t)B * Vf * sizeof(int), st) != hipSuccess) return DREG_ELAUNCH;

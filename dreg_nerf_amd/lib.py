@@ -62,6 +62,7 @@ SIGNATURES = {
     "dreg_conv_set_narrow_small": (None, [I]),
     "dreg_bn_set_debug_skip": (None, [I]),
     "dreg_exec_set_fuse_stem": (None, [I]),
+    "dreg_exec_set_sparse_grads": (None, [I]),
     "dreg_conv3_halo_set_variant": (None, [I]),
     "dreg_conv3_halo_set_prof": (None, [P]),
     # fpn_ops.hip
@@ -87,6 +88,8 @@ SIGNATURES = {
     "dreg_trilinear_gather_bwd_rows": (I, [P, P, P, P, I, P, P, P] + [I] * 10 + [P]),
     "dreg_colsum_rows": (I, [P, P, I, P, P, I, I, I, P]),
     "dreg_trilinear_gather_bwd_gather": (I, [P, P, P, P, I, P, P] + [I] * 10 + [P]),
+    "dreg_trilinear_gather_bwd_gather_rows_only": (I, [P, P, P, P, I, P, P] + [I] * 10 + [P]),
+    "dreg_zero_rows": (I, [P, P, I, I, I, P]),
     "dreg_add_inplace": (I, [P, P, Z, I, P]),
     "dreg_pack_rgba_grids": (I, [P, P, I, I, I, I, I, P]),
     "dreg_pack_rgba_grids_occ": (I, [P, P, P, I, I, I, I, I, P]),

@@ -87,6 +87,7 @@ _weight_generation = 0
 
 def clear_pack_cache():
     global _pack_table
+    _DP1_CACHE.clear()
     _pack_cache.clear()
     _halo_cache.clear()
     _pack_table = None
@@ -763,6 +764,10 @@ def maxpool3d(x):
 
 
 # --------------------------------------------------------------------------- fused trilinear upsample + gather
+PERSISTENT_GRAD_BUFFERS = False     # train_step.TrainStep sets it around backward
+_DP1_CACHE = {}
+
+
 class TrilinearGatherFn(torch.autograd.Function):
     """feats[n] = trilinear(align_corners) sample of p1[batch[n]] at fine voxel idx[n]; output fp32 [N, C]."""
 
@@ -788,6 +793,23 @@ class TrilinearGatherFn(torch.autograd.Function):
         gout = gout.contiguous().float()
         if rows1 is not None and ((C % 64 == 0 and C <= 256) or map1 is not None):  # per consumed coarse voxel (S1): gather form, else compact atomics
             g = torch.empty(shape, dtype=dtype, device=gout.device)
+            if C % 64 == 0 and C <= 256 and PERSISTENT_GRAD_BUFFERS:
+                # one dense buffer per shape, kept across steps: zero outside the rows of the step that wrote it, so only those
+                # rows are cleared (a 1 GB memset per step at 8 x 64^3 x 256 otherwise).  train_step turns this on around its
+                # backward: the consumer (the trunk's backward) has read the buffer before the next step reuses it.
+                key = (shape, dtype, gout.device)
+                ent = _DP1_CACHE.get(key)
+                if ent is None:
+                    ent = _DP1_CACHE[key] = [torch.zeros(shape, dtype=dtype, device=gout.device), None]
+                g, dirty = ent
+                if dirty is not None:
+                    L.check(lib.dreg_zero_rows(L.ptr(g), L.ptr(dirty), dirty.shape[0], C, L.dt_of(g), L.stream()), "dreg_zero_rows")
+                fmap = torch.empty(B * Zr * Xr * Yr, dtype=torch.int32, device=gout.device)
+                L.check(lib.dreg_trilinear_gather_bwd_gather_rows_only(L.ptr(gout), L.ptr(idx), L.ptr(pt_batch), L.ptr(rows1), rows1.shape[0], L.ptr(fmap),
+                                                                       L.ptr(g), idx.shape[0], B, d, h, w, C, Zr, Xr, Yr, L.dt_of(g), L.stream()),
+                        "dreg_trilinear_gather_bwd_gather_rows_only")
+                ent[1] = rows1
+                return g, None, None, None, None, None
             if C % 64 == 0 and C <= 256:   # atomic-free gather per S1 voxel: deterministic
                 fmap = torch.empty(B * Zr * Xr * Yr, dtype=torch.int32, device=gout.device)
                 L.check(lib.dreg_trilinear_gather_bwd_gather(L.ptr(gout), L.ptr(idx), L.ptr(pt_batch), L.ptr(rows1), rows1.shape[0], L.ptr(fmap),

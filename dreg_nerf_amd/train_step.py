@@ -63,6 +63,7 @@ class TrainStep:
         # Second stream for the weight / bias gradients of the point-set half's linear layers (Conv3dFn.backward), ~1.3 ms per step.
         # (It exposed the packed-fp32 co-execution fault described in DESIGN.md; the library is built without those instructions
         # and steps are bitwise reproducible with it: tests/test_hip_trunk_exec.py.)  DREG_PG_STREAM=0 turns it off.
+        self.persistent_grad_buffers = True     # dense gradient buffers of the active-set head kept zero by clearing rows (ops.TrilinearGatherFn)
         self.overlap_param_grads = bool(int(os.environ.get("DREG_PG_STREAM", "1"))) and not bool(int(os.environ.get("DREG_SERIAL_STREAMS", "0")))
         self._pg_stream = None
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -119,10 +120,12 @@ class TrainStep:
             sync = self._sync
             sync.begin()
             ops.GRAD_SYNC = sync
+        ops.PERSISTENT_GRAD_BUFFERS = dev.type == "cuda" and self.persistent_grad_buffers
         try:
             self._backward(total, dev)
         finally:
             ops.GRAD_SYNC = None
+            ops.PERSISTENT_GRAD_BUFFERS = False
         if sync is not None:
             sync.finish()
         if self.overlap_param_grads and dev.type == "cuda":

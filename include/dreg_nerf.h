@@ -218,6 +218,13 @@ int dreg_trilinear_gather_bwd_rows(const float* dfeat, const int64_t* idx, const
 int dreg_trilinear_gather_bwd_gather(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
                                      int* fine_map, void* dp1, int N, int B, int d, int h, int w, int C, int Zr, int Xr,
                                      int Yr, int dtype, void* stream);
+/* The dense gradient buffers in front of the active-set convolutions only ever hold values on a row list.  Kept across steps they stay
+ * zero elsewhere: _rows_only writes rows1 without the dense memset (dp1 must be zero outside rows1), and dreg_zero_rows returns the
+ * rows written by the previous step to zero (buf: [*, C] in dtype, rows: int32 flat row indices). */
+int dreg_trilinear_gather_bwd_gather_rows_only(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
+                                               int* fine_map, void* dp1, int N, int B, int d, int h, int w, int C, int Zr, int Xr, int Yr,
+                                               int dtype, void* stream);
+int dreg_zero_rows(void* buf, const int* rows, int nrows, int C, int dtype, void* stream);
 int dreg_colsum_rows(const void* g, const int* rows, int nrows, float* out, float* workspace, int C, int accumulate,
                      int dtype, void* stream);
 

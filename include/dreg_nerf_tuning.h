@@ -23,6 +23,7 @@ void dreg_conv_set_glds_stages(int stages);          /* LDS pipeline stages of t
 void dreg_conv_set_wgrad_target_blocks(int blocks);   /* workgroups the automatic split choice aims for (default 3072) */
 /* largest per-grid volume (voxels) whose BatchNorm runs the fused statistics+apply kernels (default 512 = the 8^3 level; 16^3 measured slower fused); 0 = never */
 void dreg_bn_set_small_max_voxels(int v);
+void dreg_exec_set_sparse_grads(int on);              /* 1 (default): executors created from now on keep the single-writer gradient buffers of the active-set head zero by clearing rows */
 void dreg_exec_set_fuse_stem(int on);                 /* 1 (default): executors created from now on fuse the stem's BatchNorm + ReLU + max-pool (fpn_ops.hip) */
 void dreg_bn_set_debug_skip(int mask);                /* MEASUREMENT ONLY (wrong results): bit 0 / 1 leave out the forward / backward statistics pass of the large BatchNorms */
 void dreg_conv_set_narrow_small(int on);              /* 1 (default): launches of < 224 128 x 128 tiles use 128 x 64 tiles (twice the workgroups) */

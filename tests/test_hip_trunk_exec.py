@@ -189,3 +189,40 @@ def test_segmented_backward_reports_gradient_buckets_in_order_and_changes_nothin
             n_before_last = sum(1 for e in log if e[0] == "reduce")
             assert n_before_last == len(sync.buckets)
     assert torch.equal(grads[0], grads[1])
+
+
+def test_row_cleared_gradient_buffers_equal_memset_ones_over_changing_active_sets():
+    """The dense gradient buffers in front of the active-set convolutions (dP1 from the trilinear gather, the lateral sums inside the
+    executor) are kept zero across steps by clearing the rows the last step wrote instead of a dense memset per step.  Three optimizer
+    steps over pairs whose active sets grow and shrink end in bit-identical parameters with the feature on and off."""
+    from dreg_nerf_amd import lib as L, synth
+    from dreg_nerf_amd.train_step import TrainStep
+    lib = L.load()
+    dev = torch.device("cuda")
+
+    def run(sparse: bool):
+        lib.dreg_exec_set_sparse_grads(int(sparse))
+        try:
+            torch.manual_seed(7)
+            m = NeRFRegTr(precision="bf16").to(dev).train()
+            ts = TrainStep(m)
+            ts.persistent_grad_buffers = sparse
+            pose = synth.fixed_pose()
+            for step, radii in enumerate((((0.8, 0.9), (0.6, 0.66)), ((0.45, 0.5), (0.9, 1.05)), ((0.7, 0.74), (0.3, 0.45)))):
+                batch = []
+                for i, (ra, rb) in enumerate(radii):     # shells of different radius / thickness: the active sets move, grow and shrink
+                    gs, ms = synth.shell_grid(64, 11 + 2 * i + step, ra, rb)
+                    gt, mt = synth.shell_grid(64, 12 + 2 * i + step, ra, rb, pose=pose)
+                    batch.append({"src_xyz_rgba": gs.permute(3, 2, 0, 1).unsqueeze(0).contiguous().to(dev),
+                                  "tgt_xyz_rgba": gt.permute(3, 2, 0, 1).unsqueeze(0).contiguous().to(dev),
+                                  "src_mask": ms.to(dev), "tgt_mask": mt.to(dev), "pose": pose[None].clone().to(dev),
+                                  "src_nerf_path": "", "tgt_nerf_path": ""})
+                ts.step(batch)
+            torch.cuda.synchronize()
+            return {k: v.detach().clone() for k, v in m.state_dict().items()}
+        finally:
+            lib.dreg_exec_set_sparse_grads(1)
+
+    a, b = run(True), run(False)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
