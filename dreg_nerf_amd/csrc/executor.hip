@@ -41,6 +41,7 @@ struct Op {
     size_t aux0 = 0, aux1 = 0;   // BN: scale_shift / mean_rstd; max-pool: argmax
     size_t wg_off = 0, wg_bytes = 0;   // OP_CONV*: this layer's weight-gradient split partials (kept until the batched reduce)
     int rd = -1;                 // index of its record in the reduce table
+    int ds_rows = -1;            // OP_CONV_ROWS with an upsampled addend produced by another active-set convolution: that one's output row list
     int sparse_gx = 0;           // OP_CONV_ROWS: the input's gradient buffer has no other writer: kept zero outside the rows of the last step
     size_t cl_off = 0;           //   arena copy of the row list that was written (cleared at the start of the next backward)
     int cl_count = 0;
@@ -219,6 +220,12 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
     for (int i = 1; i < nt; ++i) {
         if (e->t[i].bytes > max_tensor) max_tensor = e->t[i].bytes;
         if (e->needs_grad[i] && i != e->out_slot) { e->t[i].goff = off; off += e->t[i].bytes; } else e->t[i].goff = SIZE_MAX;
+    }
+    // the gradient of an upsample-add inside the active-set head is zero off the parents of the fine active set, which is the output
+    // row list of the coarse convolution that produced the addend: sum the children there only
+    for (Op& o : e->ops) {
+        if (o.kind != OP_CONV_ROWS || o.in2 < 0 || o.add_same || !e->needs_grad[o.in2] || !g_sparse_grads) continue;
+        for (const Op& q : e->ops) if (q.out == o.in2 && q.kind == OP_CONV_ROWS) o.ds_rows = q.rows_out;
     }
     // gradient buffers written by exactly one active-set convolution (the lateral sums in front of the head's 3^3 convolutions,
     // 1 GB at 8 x 64^3 x 256): instead of a dense memset per step they are kept zero outside the rows of the step before, and
@@ -560,6 +567,12 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
             if (o.in2 >= 0 && e->needs_grad[o.in2]) {
                 const Tensor& ta = e->t[o.in2];
                 if (o.add_same) { CK(hipMemcpyAsync(dst_for(o.in2), gy, (size_t)y.B * y.D * y.H * y.W * y.C * 2, hipMemcpyDeviceToDevice, st) == hipSuccess ? 0 : DREG_ELAUNCH); }
+                else if (rows && o.ds_rows >= 0 && o.ds_rows < nlists) {
+                    void* dst = dst_for(o.in2);
+                    if (hipMemsetAsync(dst, 0, (size_t)ta.B * ta.D * ta.H * ta.W * ta.C * 2, st) != hipSuccess) return DREG_ELAUNCH;
+                    CK(dreg_downsample_sum_rows(gy, dst, (const int*)rowlists[2 * o.ds_rows], (int)rowlists[2 * o.ds_rows + 1],
+                                                y.D, y.H, y.W, ta.D, ta.H, ta.W, y.C, 0, stream));
+                }
                 else CK(dreg_downsample_sum(gy, dst_for(o.in2), y.B, y.D, y.H, y.W, ta.D, ta.H, ta.W, y.C, 0, stream));
                 CK(commit(o.in2));
             }

@@ -752,6 +752,38 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const T* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------ 2x downsample-sum
 // out[b,z,y,x,:] = sum over the (cropped) 2x2x2 children of g  (backward of nearest x2 upsample + crop)
+// the same over a list of coarse voxels (ascending flat indices into [B,Dc,Hc,Wc]): the other rows of `out` are not touched
+template <typename T>
+__global__ void downsample_sum_rows_kernel(const T* __restrict__ g, T* __restrict__ out, const int* __restrict__ rows, int nrows,
+                                           int Df, int Hf, int Wf, int Dc, int Hc, int Wc, int C)
+{
+    constexpr int G = Gran<T>::G;
+    const int CG = C / G;
+    const size_t total = (size_t)nrows * CG;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        size_t r = (size_t)rows[i / CG];
+        const size_t orow = r;
+        const int x = (int)(r % Wc); r /= Wc;
+        const int y = (int)(r % Hc); r /= Hc;
+        const int z = (int)(r % Dc);
+        const int b = (int)(r / Dc);
+        float acc[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) acc[k] = 0.f;
+        for (int a = 0; a < 2; ++a) { const int zz = 2 * z + a; if (zz >= Df) continue;
+            for (int c = 0; c < 2; ++c) { const int yy = 2 * y + c; if (yy >= Hf) continue;
+                for (int d = 0; d < 2; ++d) { const int xx = 2 * x + d; if (xx >= Wf) continue;
+                    float v[G];
+                    Gran<T>::ld(g + ((((size_t)b * Df + zz) * Hf + yy) * Wf + xx) * C + (size_t)cg * G, v);
+#pragma unroll
+                    for (int k = 0; k < G; ++k) acc[k] += v[k];
+                }
+            }
+        }
+        Gran<T>::st(out + orow * C + (size_t)cg * G, acc);
+    }
+}
 template <typename T>
 __global__ void downsample_sum_kernel(const T* __restrict__ g, T* __restrict__ out, int B, int Df, int Hf, int Wf,
                                       int Dc, int Hc, int Wc, int C)
@@ -1288,6 +1320,20 @@ int dreg_maxpool3d_bwd(const void* dy, const uint8_t* argmax, void* dx, int B, i
     return dreg_maxpool3d_bwd_acc(dy, argmax, dx, B, Di, Hi, Wi, Do, Ho, Wo, C, 0, dtype, stream);
 }
 
+// Row-list form: out[rows] = sums of the 2^3 children in g; `out` elsewhere is left as it is (the caller keeps it zero: the gradient
+// of an upsample-add whose fine side only holds values on an active set is zero off the parents of that set).
+int dreg_downsample_sum_rows(const void* g, void* out, const int* rows, int nrows, int Df, int Hf, int Wf, int Dc, int Hc, int Wc, int C, int dtype, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int G = dtype == 0 ? 8 : 4;
+    if (C % G || nrows < 0) return DREG_EINVAL;
+    if (nrows == 0) return DREG_OK;
+    const size_t total = (size_t)nrows * (C / G);
+    if (dtype == 0) hipLaunchKernelGGL(downsample_sum_rows_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, st, (const bf16_t*)g, (bf16_t*)out, rows, nrows, Df, Hf, Wf, Dc, Hc, Wc, C);
+    else hipLaunchKernelGGL(downsample_sum_rows_kernel<float>, dim3(nblocks(total)), dim3(256), 0, st, (const float*)g, (float*)out, rows, nrows, Df, Hf, Wf, Dc, Hc, Wc, C);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
 int dreg_downsample_sum(const void* g, void* out, int B, int Df, int Hf, int Wf, int Dc, int Hc, int Wc, int C, int dtype, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;

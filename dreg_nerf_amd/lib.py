@@ -76,6 +76,7 @@ SIGNATURES = {
     "dreg_maxpool3d_bwd": (I, [P, P, P] + [I] * 9 + [P]),
     "dreg_maxpool3d_bwd_acc": (I, [P, P, P] + [I] * 10 + [P]),
     "dreg_downsample_sum": (I, [P, P] + [I] * 9 + [P]),
+    "dreg_downsample_sum_rows": (I, [P, P, P] + [I] * 9 + [P]),
     "dreg_colsum_workspace_bytes": (Z, [Z, I]),
     "dreg_colsum": (I, [P, P, P, Z, I, I, I, P]),
     "dreg_trilinear_gather_fwd": (I, [P, P, P, P] + [I] * 10 + [P]),

@@ -163,6 +163,9 @@ int dreg_maxpool3d_bwd_acc(const void* dy, const uint8_t* argmax, void* dx, int 
 /* backward of the nearest x2 upsample + crop: out[b,z,y,x,:] = sum of the in-range 2x2x2 children of g */
 int dreg_downsample_sum(const void* g, void* out, int B, int Df, int Hf, int Wf, int Dc, int Hc, int Wc, int C,
                         int dtype, void* stream);
+/* the same over a list of coarse voxels only (out is left untouched elsewhere; used when the fine gradient lives on an active set) */
+int dreg_downsample_sum_rows(const void* g, void* out, const int* rows, int nrows, int Df, int Hf, int Wf, int Dc, int Hc, int Wc,
+                             int C, int dtype, void* stream);
 
 /* out[c] (+)= sum_m g[m][c]  (bias gradients) */
 size_t dreg_colsum_workspace_bytes(size_t M, int C);
