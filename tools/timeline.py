@@ -64,10 +64,11 @@ for (a, b), t in pairs.most_common(25):
     print(f"  {1e-6 * t:6.3f} ms  {a} -> {b}")
 print("kernel time by queue (this step):")
 for q, rs in sorted(byq.items(), key=lambda kv: -len(kv[1])):
-    agg = collections.Counter(); n = collections.Counter()
+    agg = collections.Counter(); n = collections.Counter(); wgs = collections.Counter()
     for r in rs:
         k = r["Kernel_Name"].split("(")[0][:90]
         agg[k] += r["e"] - r["s"]; n[k] += 1
+        wgs[k] += (int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)) * (int(r["Grid_Size_Y"]) // max(int(r["Workgroup_Size_Y"]), 1)) * (int(r["Grid_Size_Z"]) // max(int(r["Workgroup_Size_Z"]), 1))
     print(f" queue {q}:")
     for k, t in agg.most_common(int(sys.argv[3]) if len(sys.argv) > 3 else 28):
-        print(f"   {1e-6 * t:7.3f} ms  n={n[k]:4d}  avg {1e-3 * t / n[k]:7.1f} us  {k}")
+        print(f"   {1e-6 * t:7.3f} ms  n={n[k]:4d}  avg {1e-3 * t / n[k]:7.1f} us  avg workgroups {wgs[k] // n[k]:6d}  {k}")
