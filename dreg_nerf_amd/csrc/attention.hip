@@ -192,25 +192,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a)
 #pragma unroll
             for (int kk = 0; kk < D / 32; ++kk) s[t] = mma(frag_row(sK, KRS, t * 16 + fr, kk * 32 + kg * 8, T()), qf[kk], s[t]);
         }
-        const bool ragged = k0 + 64 > pb.Nk;
+        // The loop is VALU-bound (16 scores per lane and tile): the key mask runs in the last tile only (a wave-uniform branch), the
+        // maximum is taken over the raw scores (c2 > 0) and the scale folds into the exponent's fused multiply-add.
+        if (k0 + 64 > pb.Nk) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (k0 + t * 16 + kg * 4 + r >= pb.Nk) s[t][r] = -INFINITY;
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = s[t][r] * c2;
-                if (ragged && k0 + t * 16 + kg * 4 + r >= pb.Nk) v = -INFINITY;
-                s[t][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = group4x_max(mx);
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
+        mx = group4x_max(mx) * c2;                // every tile holds at least one real key: finite
         const float mn = fmaxf(m, mx);
         const float alpha = __builtin_amdgcn_exp2f(m - mn);
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - mn); sum += s[t][r]; }
+            for (int r = 0; r < 4; ++r) { s[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], c2, -mn)); sum += s[t][r]; }
         l = l * alpha + sum;
         m = mn;
         if constexpr (XYZ) {
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(256, (D > 32 ? 2 : 1)) void attn_bwd_dq_kernel(Attn
                 for (int r = 0; r < 4; ++r) {
                     const int kr = t * 16 + kg * 4 + r;
                     // keys past Nk need no mask: their K (and V / xyz) rows are zero in LDS, so whatever dS they get multiplies zero
-                    const float p = __builtin_amdgcn_exp2f(s[r] * c2 - lse2);
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -lse2));
                     float dpv = dp[r];
                     if constexpr (XYZ) {
                         const float4 x = *reinterpret_cast<const float4*>(sV + kr * 16);
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(256, (D > 32 ? 2 : 1)) void attn_bwd_dkv_kernel(Att
                 for (int r = 0; r < 4; ++r) {
                     const int ql = t * 16 + kg * 4 + r;
                     // no masks: query rows past Nq are zero in LDS (Q, dO, lse, D), so their p multiplies zero; key columns past Nk are not stored
-                    const float p = __builtin_amdgcn_exp2f(s[r] * c2 - lq[r]);
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -lq[r]));
                     float dpv = dp[r];
                     if constexpr (XYZ) {
                         const float4 g = *reinterpret_cast<const float4*>(sO + ql * 16);
