@@ -626,7 +626,8 @@ template <int GP> __device__ __forceinline__ int wg_swz(int row) {   // rows of 
 // NW = 4: 2 x 2 waves (128 x 128 / 128 x 64 / 64 x 128 / 64 x 64 tiles).  NW = 8: 2 x 4 waves on a 256 x 256 tile — per 64-voxel stage it
 // moves 64 KB for 8.4 MFLOP instead of 32 KB for 2.1 MFLOP: the 128-square tile needs ~62 B/clk of direct-to-LDS traffic at the MFMA
 // roof, which is the whole L2 -> LDS path of a CU (tools/hw_probe/l2_stream.hip: 129 GB/s per CU) and the reason it stops at 0.7 PFLOP/s.
-template <int BM, int BNC, bool ROWS, int NW = 4>
+// ABL (tools/bench_wgrad.py --ablate, wrong results): 1 no MFMA, 2 no fragment reads, 3 no direct-to-LDS loads — what bounds the loop
+template <int BM, int BNC, bool ROWS, int NW = 4, int ABL = 0>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
     const bf16_t* __restrict__ gout, const bf16_t* __restrict__ in, float* __restrict__ part,
     ConvGeom g, int tilesCol, int tiles, int nsplit, uint32_t vox_per_split, uint32_t gout_bytes, uint32_t in_bytes,
@@ -697,6 +698,32 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    // Row-aligned stages (dense stride-1 launches whose 64-voxel stages are whole x-rows of the volume: 64 % Wo == 0, Ho * Wo % 64 == 0 —
+    // every layer of the 64^3 / 32^3 / 16^3 levels): the stage fixes (b, z, y0) for the whole workgroup, and what a lane adds — its
+    // row inside the stage, its tap — never changes.  The gather address of a lane is then  uniform stage base + lane constant, and
+    // only the bounds test needs the stage's z / y: ~8 VALU instructions per load instead of a voxel decode with carries (~30).  The
+    // address arithmetic of the general path was a third of the kernel's time (tools/bench_wgrad_ablate.py).
+    const bool aligned = !ROWS && g.sn == 1 && g.sd == 1 && g.dsign == 1 && (KV % g.Wo) == 0 && ((g.Ho * g.Wo) % KV) == 0 &&
+                         (uint64_t)g.B * g.Di * g.Hi * g.Wi * g.Cin * 2 < 0x7fffff00ull;
+    int al_dz[IB], al_dy[IB];
+    uint32_t al_off[IB];
+    bool al_ok[IB];
+    uint32_t al_l[IB];
+    if (aligned) {
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            const int l = (wave * IB + i) * RPB + rb;              // voxel of this lane inside a stage
+            const int ly = l / g.Wo, lx = l - ly * g.Wo;
+            const int xin = lx + g.off + b_dx[i];
+            al_l[i] = (uint32_t)l;
+            al_dz[i] = g.off + b_dz[i];
+            al_dy[i] = ly + g.off + b_dy[i];
+            al_ok[i] = b_tv[i] && (unsigned)xin < (unsigned)g.Wi;
+            // bytes relative to the stage's (b, z, y0) row of the gathered operand; may be negative: added modulo 2^32 to the base
+            al_off[i] = (uint32_t)((((al_dz[i] * g.Hi + al_dy[i]) * g.Wi + xin) * g.Cin + b_ci[i]) * 2);
+        }
+    }
+
     auto issue = [&](uint32_t v0, int buf) {
         char* sA = smem + buf * STAGE;
         char* sB = sA + A_BYTES;
@@ -707,7 +734,23 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
             uint32_t m = vi;
             if constexpr (ROWS) m = vi < v_end ? (uint32_t)srow[vi - v_begin] : 0u;
             const uint32_t voff = (vi < v_end) ? m * (uint32_t)(g.Cout * 2) + a_col[i] : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(sA + j * 1024), 16, (int)voff, 0, 0, 0);
+            if constexpr (ABL != 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(sA + j * 1024), 16, (int)voff, 0, 0, 0);
+            else asm volatile("" :: "v"(voff));
+        }
+        if (aligned) {
+            int sb, sz, sy, sx;
+            vox_decode(v0, g, sb, sz, sy, sx);                       // wave-uniform: v0 is the first voxel of an x-row
+            const uint32_t base = (uint32_t)(((sb * g.Di + sz) * g.Hi + sy) * g.Wi) * (uint32_t)(g.Cin * 2);
+            const uint32_t left = v_end - v0;
+#pragma unroll
+            for (int i = 0; i < IB; ++i) {
+                const int j = wave * IB + i;
+                const bool v = al_ok[i] && al_l[i] < left && (unsigned)(sz + al_dz[i]) < (unsigned)g.Di && (unsigned)(sy + al_dy[i]) < (unsigned)g.Hi;
+                const uint32_t voff = v ? base + al_off[i] : OOB;
+                if constexpr (ABL != 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sB + j * 1024), 16, (int)voff, 0, 0, 0);
+                else asm volatile("" :: "v"(voff));
+            }
+            return;
         }
         // one full voxel decode per K step (row of instruction 0); the wave's other rows are +RPB, +2*RPB ... voxels
         // further along x with at most one carry when Wo >= IB*RPB (else every row is decoded in full)
@@ -733,7 +776,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
             v = v && (unsigned)z < (unsigned)g.Di && (unsigned)y < (unsigned)g.Hi && (unsigned)x < (unsigned)g.Wi;
             const uint32_t vox = (uint32_t)b * (uint32_t)(g.Di * g.Hi * g.Wi) + (uint32_t)((z * g.Hi + y) * g.Wi + x);
             const uint32_t voff = v ? (vox * (uint32_t)g.Cin + (uint32_t)b_ci[i]) * 2u : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sB + j * 1024), 16, (int)voff, 0, 0, 0);
+            if constexpr (ABL != 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sB + j * 1024), 16, (int)voff, 0, 0, 0);
+            else asm volatile("" :: "v"(voff));
         }
     };
     // The transpose reads go through inline asm: hipcc otherwise orders ds_read_b64_tr_b16 behind every pending LDS-DMA with an
@@ -742,7 +786,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
     typedef __attribute__((ext_vector_type(2))) int i32x2_t;
     auto tr_read = [&](uint32_t addr) -> i32x2_t {
         i32x2_t v;
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+        if constexpr (ABL != 2) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+        else { v = (i32x2_t){(int)addr, (int)addr}; asm volatile("" : "+v"(v)); }
         return v;
     };
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -777,8 +822,10 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (ABL != 1) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    else asm volatile("" :: "v"(af[i]), "v"(bf[j]));
+                }
         }
     };
 
@@ -1535,6 +1582,14 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
             // large dense layers: the 8-wave 256 x 256 tile
             const int tiles256 = (Cout / 256) * (g.Kpad / 256);
             (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 * 2);
+            if (g_wgrad_big >= 11 && g_wgrad_big <= 13) {   // ablations of the 8-wave kernel
+                const size_t l_ = (size_t)2 * 64 * 512 * 2;
+#define WG_ABL(A) do { (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, false, 8, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_); \
+                hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, false, 8, A>), dim3(tiles256 * nsplit), dim3(512), l_, st, (const bf16_t*)gout, \
+                                   (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, rowocc); } while (0)
+                if (g_wgrad_big == 11) WG_ABL(1); else if (g_wgrad_big == 12) WG_ABL(2); else WG_ABL(3);
+#undef WG_ABL
+            } else
             hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, false, 8>), dim3(tiles256 * nsplit), dim3(512), (size_t)2 * 64 * 512 * 2, st, (const bf16_t*)gout,
                                (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, rowocc);
         } else
@@ -1611,6 +1666,22 @@ int dreg_wgrad_reduce_batched(const void* descs_dev, int n, int block_base, int 
     hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const WgradReduceDesc*)descs_dev, n, block_base);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
+}
+// Which bf16 weight-gradient kernel a launch of this shape runs (the same rules as wgrad_impl; for the profiler's labels):
+// returns BM * 1000 + BNC (256256 = the 8-wave 256 x 256 tile).  rows: row-list launch; occ: launch with output-row occupancy flags.
+int dreg_conv3d_wgrad_variant(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int rows, int nrows, int occ)
+{
+    const int Kpad = dreg_conv3d_kpad(ksz, Cin, 0);
+    const int nsplit = dreg_conv3d_wgrad_splits(B, Do, Ho, Wo, Cin, Cout, ksz, 0);
+    const long M = (long)B * Do * Ho * Wo;
+    if (!rows && !occ && g_wgrad_big && Cout % 256 == 0 && Kpad % 256 == 0 && (rows ? nrows : M) >= 65536) return 256256;
+    int bm = (Cout % 128 == 0) ? 128 : 64;
+    int bnc = (Kpad % 128 == 0 || Kpad > 128) ? 128 : 64;
+    if (g_narrow_small >= 2 && (Cout / bm) * ((Kpad + bnc - 1) / bnc) * nsplit < 224) {
+        if (bnc == 128) bnc = 64;
+        if (bm == 128 && (Cout / bm) * (Kpad / bnc) * nsplit < 224) bm = 64;
+    }
+    return bm * 1000 + bnc;
 }
 int dreg_conv3d_wgrad_rows(const void* gout, const void* in, float* dw, void* workspace, size_t workspace_bytes,
                            const int* rows, int nrows,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "dreg_pack_conv_weight_halo": (I, [P, P, I, I, I, P]),
     "dreg_conv3_halo": (I, [P, P, P, P, P] + [I] * 10 + [P]),
     "dreg_conv_set_narrow_small": (None, [I]),
+    "dreg_conv3d_wgrad_variant": (I, [I] * 10),
     "dreg_bn_set_debug_skip": (None, [I]),
     "dreg_exec_set_fuse_stem": (None, [I]),
     "dreg_exec_set_sparse_grads": (None, [I]),

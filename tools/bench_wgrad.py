@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Weight-gradient kernels on the dominant dense layers: 4-wave 128x128 tile vs 8-wave 256x256 tile (interleaved rounds, random data)."""
+"""Weight-gradient kernels on the dominant dense layers: 4-wave 128x128 tile vs 8-wave 256x256 tile; interleaved rounds, random data."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,4 +32,4 @@ for (D, cin, cout) in ((64, 256, 256), (32, 256, 256), (64, 64, 256)):
             ts[big].append(e0.elapsed_time(e1) / 3)
     lib.dreg_conv_set_wgrad_big(1)
     m = {k: sorted(v)[len(v) // 2] for k, v in ts.items()}
-    print(f"B{B} {D}^3 {cin}->{cout}: 128x128 {m[0]:.3f} ms {flops / m[0] / 1e9:.0f} TF | 256x256 {m[1]:.3f} ms {flops / m[1] / 1e9:.0f} TF | rel diff {d:.2e}", flush=True)
+    print(f"B{B} {D}^3 {cin}->{cout}: 128x128 {m[0]:.3f} ms {flops / m[0] / 1e9:.0f} TF | 256x256 8 waves {m[1]:.3f} ms {flops / m[1] / 1e9:.0f} TF | rel diff {d:.2e}", flush=True)
