@@ -645,7 +645,7 @@ template <int GP> __device__ __forceinline__ int wg_swz(int row) {   // rows of 
 // moves 64 KB for 8.4 MFLOP instead of 32 KB for 2.1 MFLOP: the 128-square tile needs ~62 B/clk of direct-to-LDS traffic at the MFMA
 // roof, which is the whole L2 -> LDS path of a CU (tools/hw_probe/l2_stream.hip: 129 GB/s per CU) and the reason it stops at 0.7 PFLOP/s.
 // ABL (tools/bench_wgrad.py --ablate, wrong results): 1 no MFMA, 2 no fragment reads, 3 no direct-to-LDS loads — what bounds the loop
-template <int BM, int BNC, bool ROWS, int NW = 4, int ABL = 0>
+template <int BM, int BNC, bool ROWS, int NW = 4, int ABL = 0, int KV_ = 64>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
     const bf16_t* __restrict__ gout, const bf16_t* __restrict__ in, float* __restrict__ part,
     ConvGeom g, int tilesCol, int tiles, int nsplit, uint32_t vox_per_split, uint32_t gout_bytes, uint32_t in_bytes,
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
 {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
-    constexpr int KV = 64, NS = 2;                        // voxels per stage, LDS ring depth (prefetch distance NS-1)
+    constexpr int KV = KV_, NS = 2;                       // voxels per stage, LDS ring depth (prefetch distance NS-1)
     constexpr int RSA = BM * 2, RSB = BNC * 2;
     constexpr int GPA = RSA / 16, GPB = RSB / 16;          // granules per row (16 or 8)
     constexpr int A_BYTES = KV * RSA, B_BYTES = KV * RSB, STAGE = A_BYTES + B_BYTES;
@@ -721,24 +721,25 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
     // row inside the stage, its tap — never changes.  The gather address of a lane is then  uniform stage base + lane constant, and
     // only the bounds test needs the stage's z / y: ~8 VALU instructions per load instead of a voxel decode with carries (~30).  The
     // address arithmetic of the general path was a third of the kernel's time (tools/bench_wgrad_ablate.py).
-    const bool aligned = !ROWS && g.sn == 1 && g.sd == 1 && g.dsign == 1 && (KV % g.Wo) == 0 && ((g.Ho * g.Wo) % KV) == 0 &&
+    // (a stage may also be a PART of an x-row — Wo a multiple of the stage length: then the stage's first x joins the base and the
+    // x bounds test moves into the loop)
+    const bool aligned = !ROWS && g.sn == 1 && g.sd == 1 && g.dsign == 1 &&
+                         (((KV % g.Wo) == 0 && ((g.Ho * g.Wo) % KV) == 0) || (g.Wo % KV) == 0) &&
                          (uint64_t)g.B * g.Di * g.Hi * g.Wi * g.Cin * 2 < 0x7fffff00ull;
-    int al_dz[IB], al_dy[IB];
+    int al_dz[IB], al_dy[IB], al_x[IB];
     uint32_t al_off[IB];
-    bool al_ok[IB];
     uint32_t al_l[IB];
     if (aligned) {
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
             const int l = (wave * IB + i) * RPB + rb;              // voxel of this lane inside a stage
             const int ly = l / g.Wo, lx = l - ly * g.Wo;
-            const int xin = lx + g.off + b_dx[i];
-            al_l[i] = (uint32_t)l;
+            al_l[i] = b_tv[i] ? (uint32_t)l : 0x7fffffffu;         // an invalid column (K padding) never passes the "inside the split" test
             al_dz[i] = g.off + b_dz[i];
             al_dy[i] = ly + g.off + b_dy[i];
-            al_ok[i] = b_tv[i] && (unsigned)xin < (unsigned)g.Wi;
-            // bytes relative to the stage's (b, z, y0) row of the gathered operand; may be negative: added modulo 2^32 to the base
-            al_off[i] = (uint32_t)((((al_dz[i] * g.Hi + al_dy[i]) * g.Wi + xin) * g.Cin + b_ci[i]) * 2);
+            al_x[i] = lx + g.off + b_dx[i];
+            // bytes relative to the stage's first voxel (b, z, y0, x0) of the gathered operand; may be negative: added modulo 2^32
+            al_off[i] = (uint32_t)((((al_dz[i] * g.Hi + al_dy[i]) * g.Wi + al_x[i]) * g.Cin + b_ci[i]) * 2);
         }
     }
 
@@ -757,13 +758,14 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
         }
         if (aligned) {
             int sb, sz, sy, sx;
-            vox_decode(v0, g, sb, sz, sy, sx);                       // wave-uniform: v0 is the first voxel of an x-row
-            const uint32_t base = (uint32_t)(((sb * g.Di + sz) * g.Hi + sy) * g.Wi) * (uint32_t)(g.Cin * 2);
+            vox_decode(v0, g, sb, sz, sy, sx);                       // wave-uniform: v0 starts an x-row or a KV-aligned part of one
+            const uint32_t base = (uint32_t)(((sb * g.Di + sz) * g.Hi + sy) * g.Wi + sx) * (uint32_t)(g.Cin * 2);
             const uint32_t left = v_end - v0;
 #pragma unroll
             for (int i = 0; i < IB; ++i) {
                 const int j = wave * IB + i;
-                const bool v = al_ok[i] && al_l[i] < left && (unsigned)(sz + al_dz[i]) < (unsigned)g.Di && (unsigned)(sy + al_dy[i]) < (unsigned)g.Hi;
+                const bool v = al_l[i] < left && (unsigned)(sz + al_dz[i]) < (unsigned)g.Di && (unsigned)(sy + al_dy[i]) < (unsigned)g.Hi &&
+                               (unsigned)(sx + al_x[i]) < (unsigned)g.Wi;
                 const uint32_t voff = v ? base + al_off[i] : OOB;
                 if constexpr (ABL != 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sB + j * 1024), 16, (int)voff, 0, 0, 0);
                 else asm volatile("" :: "v"(voff));
@@ -1249,7 +1251,7 @@ static int fill_geom(ConvGeom& g, int B, int Di, int Hi, int Wi, int Cin, int Do
 }
 
 static int g_use_glds = 1;
-static int g_wgrad_big = 1;     // tuning (include/dreg_nerf_tuning.h): 8-wave 256 x 256 weight-gradient tile for large dense layers
+static int g_wgrad_big = 3;     // tuning (include/dreg_nerf_tuning.h): 256-row weight-gradient tiles for large dense layers (1: 256 x 128 / 4 waves, 3: 256 x 256 / 8 waves)
 
 // K slices of a small bf16 stride-1-gather convolution (0/1 = no split): fill the chip when the 128-row tiling leaves most CUs idle
 static int conv_ksplit(const ConvGeom& g, bool has_addend)
@@ -1597,10 +1599,19 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
             (void)ldsr;
         }
         if (!rowlist && !rowocc && g_wgrad_big && Cout % 256 == 0 && g.Kpad % 256 == 0 && nrows >= 65536) {
+            // large dense layers: 256-row tiles.  Default (3): the 8-wave 256 x 256 tile (0.90 PFLOP/s on 256 -> 256 @64^3 alone); 1: 4
+            // waves on 256 x 128 with 32-voxel stages — 48 KB of LDS, two independent workgroups per CU: 0.93 alone, but no faster
+            // inside the step, where the data-gradient stream shares the CUs (tools/ab_step.py: 43.25 vs 43.16 ms, dense head)
             // large dense layers: the 8-wave 256 x 256 tile
             const int tiles256 = (Cout / 256) * (g.Kpad / 256);
             (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 * 2);
-            if (g_wgrad_big >= 11 && g_wgrad_big <= 13) {   // ablations of the 8-wave kernel
+            if (g_wgrad_big == 1) {
+                const int t2 = (Cout / 256) * (g.Kpad / 128);
+                const size_t l_ = (size_t)2 * 32 * 384 * 2;
+                uint32_t vps2 = ((vps + 31) / 32) * 32;
+                hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 128, false, 4, 0, 32>), dim3(t2 * nsplit), dim3(256), l_, st, (const bf16_t*)gout,
+                                   (const bf16_t*)in, part, g, g.Kpad / 128, t2, nsplit, vps2, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr);
+            } else if (g_wgrad_big >= 11 && g_wgrad_big <= 13) {   // ablations of the 8-wave kernel
                 const size_t l_ = (size_t)2 * 64 * 512 * 2;
 #define WG_ABL(A) do { (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, false, 8, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_); \
                 hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, false, 8, A>), dim3(tiles256 * nsplit), dim3(512), l_, st, (const bf16_t*)gout, \
@@ -1692,7 +1703,7 @@ int dreg_conv3d_wgrad_variant(int B, int Do, int Ho, int Wo, int Cin, int Cout, 
     const int Kpad = dreg_conv3d_kpad(ksz, Cin, 0);
     const int nsplit = dreg_conv3d_wgrad_splits(B, Do, Ho, Wo, Cin, Cout, ksz, 0);
     const long M = (long)B * Do * Ho * Wo;
-    if (!rows && !occ && g_wgrad_big && Cout % 256 == 0 && Kpad % 256 == 0 && (rows ? nrows : M) >= 65536) return 256256;
+    if (!rows && !occ && g_wgrad_big && Cout % 256 == 0 && Kpad % 256 == 0 && (rows ? nrows : M) >= 65536) return g_wgrad_big == 1 ? 256128 : 256256;
     int bm = (Cout % 128 == 0) ? 128 : 64;
     int bnc = (Kpad % 128 == 0 || Kpad > 128) ? 128 : 64;
     if (g_narrow_small >= 2 && (Cout / bm) * ((Kpad + bnc - 1) / bnc) * nsplit < 224) {

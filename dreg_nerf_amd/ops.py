@@ -398,7 +398,7 @@ def conv_wgrad(gout, x, w_shape, cin_pad, ksz, stride, pad, use_tr=True, accumul
         label = f"wgrad B{B} {Di}x{Hi}x{Wi}x{cin_pad} g{Do}x{Ho}x{Wo}x{cout} k{ksz}s{stride}"
         if dt == L.DT_BF16 and use_tr:
             var = lib.dreg_conv3d_wgrad_variant(B, Do, Ho, Wo, cin_pad, cout, ksz, 0, 0, 0)
-            wname = "conv_wgrad_glds_kernel<256,256,false,8>+reduce" if var == 256256 else f"conv_wgrad_glds_kernel<{var // 1000},{var % 1000},false,4>+reduce"
+            wname = "conv_wgrad_glds_kernel<256,256,false,8>+reduce" if var == 256256 else f"conv_wgrad_glds_kernel<{var // 1000},{var % 1000},false,4>+reduce"   # 256128 -> <256,128,...>
         else:
             wname = f"conv_wgrad_kernel<{tn}>+reduce"
         ev = PROFILER.record(wname, label, 2.0 * B * Do * Ho * Wo * cout * (ksz ** 3) * cin_real)

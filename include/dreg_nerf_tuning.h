@@ -18,7 +18,7 @@ void dreg_conv_set_glds(int enable);
 int dreg_conv_get_glds(void);
 /* tuning / test knob: force the number of voxel splits of the weight-gradient kernels (0 = automatic) */
 void dreg_conv_set_wgrad_splits(int splits);
-void dreg_conv_set_wgrad_big(int enable);           /* 1 (default): large dense layers use the 8-wave 256 x 256 weight-gradient tile */
+void dreg_conv_set_wgrad_big(int mode);             /* large dense layers: 3 (default) the 8-wave 256 x 256 tile, 1 four waves on 256 x 128 with 32-voxel stages, 11-13 ablations of the 8-wave tile, 0 neither */
 void dreg_conv_set_glds_stages(int stages);          /* LDS pipeline stages of the direct-to-LDS convolution: 0 = default (2), 2..4 forces; results do not depend on it */
 void dreg_conv_set_wgrad_target_blocks(int blocks);   /* workgroups the automatic split choice aims for (default 3072) */
 /* largest per-grid volume (voxels) whose BatchNorm runs the fused statistics+apply kernels (default 512 = the 8^3 level; 16^3 measured slower fused); 0 = never */
@@ -26,7 +26,7 @@ void dreg_bn_set_small_max_voxels(int v);
 void dreg_exec_set_sparse_grads(int on);              /* 1 (default): executors created from now on keep the single-writer gradient buffers of the active-set head zero by clearing rows */
 void dreg_exec_set_fuse_stem(int on);                 /* 1 (default): executors created from now on fuse the stem's BatchNorm + ReLU + max-pool (fpn_ops.hip) */
 void dreg_bn_set_debug_skip(int mask);                /* MEASUREMENT ONLY (wrong results): bit 0 / 1 leave out the forward / backward statistics pass of the large BatchNorms */
-/* which bf16 weight-gradient kernel a launch of this shape runs: BM * 1000 + BNC (256256 = the 8-wave tile); for profiler labels */
+/* which bf16 weight-gradient kernel a launch of this shape runs: BM * 1000 + BNC (256256 = the 8-wave tile, 256128 = 4 waves / 32-voxel stages); for profiler labels */
 int dreg_conv3d_wgrad_variant(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int rows, int nrows, int occ);
 void dreg_conv_set_narrow_small(int on);              /* 1 (default): launches of < 224 128 x 128 tiles use 128 x 64 tiles (twice the workgroups) */
 

@@ -206,6 +206,29 @@ def test_fused_stem_bn_relu_maxpool_matches_the_unfused_pair(shape):
     assert d <= 2e-2 * a["dx"].float().abs().max().item(), d
 
 
+def test_large_layer_weight_gradient_tiles_are_bit_identical():
+    """The 256-row weight-gradient tiles of large dense layers (include/dreg_nerf_tuning.h: dreg_conv_set_wgrad_big — 1: 4 waves on
+    256 x 128 with 32-voxel stages; 3: 8 waves on 256 x 256, the default) against the 128 x 128 tile: the same per-element accumulation
+    order, so the same bits."""
+    from dreg_nerf_amd import lib as L
+    dev = _dev()
+    lib = L.load()
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 32, 32, 32, 256, generator=g).to(dev, torch.bfloat16)
+    gy = torch.randn(2, 32, 32, 32, 256, generator=g).to(dev, torch.bfloat16)
+    out = {}
+    try:
+        for mode in (0, 1, 3):
+            lib.dreg_conv_set_wgrad_big(mode)
+            out[mode] = ops.conv_wgrad(gy, x, (256, 256, 3, 3, 3), 256, 3, 1, 1)
+    finally:
+        lib.dreg_conv_set_wgrad_big(3)
+    assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[3])
+    ref = torch.zeros(256, 256, 3, 3, 3, device=dev, requires_grad=True)
+    F.conv3d(x.float().permute(0, 4, 1, 2, 3), ref, padding=1).backward(gy.float().permute(0, 4, 1, 2, 3))
+    assert float((out[1] - ref.grad).abs().max()) <= 2e-3 * float(ref.grad.abs().max())
+
+
 def test_conv_upsample_add_epilogue():
     dev = _dev()
     g = torch.Generator().manual_seed(7)
