@@ -352,7 +352,7 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);   // C^T: a lane holds 4 consecutive channels of one row
         }
     };
 
@@ -378,28 +378,28 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
         ibuf = ibuf + 1 == nstage ? 0 : ibuf + 1;
     }
 
-    // Epilogue through LDS, one pass per wave row (wm): accumulators -> fp32 tile [BM/2][BN] (16-column blocks XOR-ed with
-    // (row>>2)&1 so the two row groups of a 32-lane write phase hit different banks) -> coalesced 16-byte rows with
-    // bias / addend / ReLU applied in fp32.
+    // Epilogue through LDS, one pass per wave row (wm): accumulators -> fp32 tile [BM/2][BN] -> coalesced 16-byte rows with bias /
+    // addend / ReLU applied in fp32.  The products are formed transposed (weights as the MFMA's first operand), so a lane holds FOUR
+    // CONSECUTIVE CHANNELS of one output row per MFMA tile: one ds_write_b128 per tile instead of four ds_write_b32 (16 instead of 64
+    // LDS writes per lane and pass — the epilogue is a third of a short 1^3-convolution workgroup's life).  16-byte granules are XOR-ed
+    // with the row's low four bits: the 16 lanes of a write phase (16 rows, same channels) land in 16 different granules.
     float* sC = reinterpret_cast<float*>(smem);
-    const int col_l = lane & 15, rowq = (lane >> 4) * 4;
     constexpr int CPR = BN / 8;                    // 8-column chunks per row
     constexpr int NTHR = BN == 256 ? 512 : 256;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();
         if (wm == pass) {
+            const int rl = lane & 15, gq = lane >> 4;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                const int row = i * 16 + rl;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = i * 16 + rowq + r;
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const int blk = (wn * WN + j * 16) >> 4;
-                        sC[row * BN + ((blk ^ ((row >> 2) & 1)) << 4) + col_l] = acc[i][j][r];
-                    }
+                for (int j = 0; j < TN; ++j) {
+                    const int gr = ((wn * WN + j * 16) >> 2) + gq;
+                    *reinterpret_cast<f32x4_t*>(sC + row * BN + ((gr ^ rl) << 2)) = acc[i][j];
                 }
+            }
         }
         __syncthreads();
         for (int c = t; c < WMt * CPR; c += NTHR) {
@@ -407,8 +407,9 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
             const int row = pass * WMt + lrow;
             if (m0 + row >= nrows) continue;
             const uint32_t m = rowlist ? (uint32_t)rowlist[m0 + row] : m0 + row;
-            const float* src = sC + lrow * BN + ((((cc >> 4) ^ ((lrow >> 2) & 1)) << 4) | (cc & 8));
-            const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+            const int g0 = cc >> 2, sw = lrow & 15;
+            const float4 lo = *reinterpret_cast<const float4*>(sC + lrow * BN + ((g0 ^ sw) << 2));
+            const float4 hi = *reinterpret_cast<const float4*>(sC + lrow * BN + (((g0 + 1) ^ sw) << 2));
             float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             const int n = n0 + cc;
             if (bias) {
