@@ -1279,6 +1279,7 @@ static int conv_ksplit(const ConvGeom& g, bool has_addend)
 static int g_glds_stages = 0;
 static inline int glds_stages(long blocks) { (void)blocks; return g_glds_stages ? g_glds_stages : 2; }
 
+static int g_narrow_thr = 224;        // tile count below which a launch takes the narrower tiles
 static int g_narrow_small = 2;        // tuning (include/dreg_nerf_tuning.h): 128 x 64 tiles for launches of < 224 128 x 128 tiles
 template <typename T, typename TO>
 static int launch_conv(const void* in, const void* wt, void* out, const float* bias, const void* addend,
@@ -1331,7 +1332,7 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
             else if (g.Cout % 256 == 0 && g_use_glds == 3 && nrows >= 65536) GL_LAUNCH(128, 256, 512);
             // fewer 128 x 128 tiles than CUs (the point-set half's linear layers: ~77 row tiles x 2): half-width tiles put twice as
             // many workgroups on the chip
-            else if (g.Cout % 128 == 0 && !(g_narrow_small && ((nrows + 127) / 128) * (g.Cout / 128) < 224)) GL_LAUNCH(128, 128, 256);
+            else if (g.Cout % 128 == 0 && !(g_narrow_small && ((nrows + 127) / 128) * (g.Cout / 128) < g_narrow_thr)) GL_LAUNCH(128, 128, 256);
             else if (g.Cout % 64 == 0) GL_LAUNCH(128, 64, 256);
             else return DREG_EINVAL;
 #undef GL_LAUNCH
@@ -1501,7 +1502,7 @@ int dreg_pack_conv_weights_batched(const void* descs, int n, int total_rows, int
 }
 
 // number of voxel splits the weight-gradient kernel will use (pure function of the shape)
-void dreg_conv_set_narrow_small(int on) { g_narrow_small = on; }   // 0 off, 1 forward / data gradient only, 2 weight gradients too
+void dreg_conv_set_narrow_small(int on) { if (on >= 10) { g_narrow_small = 2; g_narrow_thr = on; } else { g_narrow_small = on; g_narrow_thr = 224; } }   // 0 off, 1 forward / data gradient only, 2 weight gradients too; >= 10: mode 2 with this tile-count threshold
 static int g_force_wgrad_splits = 0;
 static int g_wgrad_target_blocks = 3072;
 // tuning knob: workgroups the automatic voxel-split choice of the weight-gradient kernels aims for
@@ -1571,9 +1572,9 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
     int bnc = (g.Kpad % 128 == 0 || (glds_path && g.Kpad > 128)) ? 128 : 64;
     // launches that leave most CUs empty (the point-set half's linear layers: 4 weight tiles x 16 splits) take 64-wide tiles: up to
     // four times the workgroups, the same per-element accumulation order
-    if (g_narrow_small >= 2 && dtype == 0 && (Cout / bm) * ((g.Kpad + bnc - 1) / bnc) * nsplit < 224) {
+    if (g_narrow_small >= 2 && dtype == 0 && (Cout / bm) * ((g.Kpad + bnc - 1) / bnc) * nsplit < g_narrow_thr) {
         if (bnc == 128) bnc = 64;
-        if (bm == 128 && (Cout / bm) * (g.Kpad / bnc) * nsplit < 224) bm = 64;
+        if (bm == 128 && (Cout / bm) * (g.Kpad / bnc) * nsplit < g_narrow_thr) bm = 64;
     }
     const int tilesRow = Cout / bm;
     const int tilesCol = (g.Kpad + bnc - 1) / bnc;
@@ -1707,9 +1708,9 @@ int dreg_conv3d_wgrad_variant(int B, int Do, int Ho, int Wo, int Cin, int Cout, 
     if (!rows && !occ && g_wgrad_big && Cout % 256 == 0 && Kpad % 256 == 0 && (rows ? nrows : M) >= 65536) return g_wgrad_big == 1 ? 256128 : 256256;
     int bm = (Cout % 128 == 0) ? 128 : 64;
     int bnc = (Kpad % 128 == 0 || Kpad > 128) ? 128 : 64;
-    if (g_narrow_small >= 2 && (Cout / bm) * ((Kpad + bnc - 1) / bnc) * nsplit < 224) {
+    if (g_narrow_small >= 2 && (Cout / bm) * ((Kpad + bnc - 1) / bnc) * nsplit < g_narrow_thr) {
         if (bnc == 128) bnc = 64;
-        if (bm == 128 && (Cout / bm) * (Kpad / bnc) * nsplit < 224) bm = 64;
+        if (bm == 128 && (Cout / bm) * (Kpad / bnc) * nsplit < g_narrow_thr) bm = 64;
     }
     return bm * 1000 + bnc;
 }
