@@ -187,7 +187,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL over xGMI ("nccl" is RCCL on ROCm).  DREG_BENCH_BACKEND=gloo with DREG_BENCH_ONE_GPU=1 is a test hook: several ranks on the
+        # one GPU of a test box exercise this script's multi-rank path (tests/test_hip_ddp_gpu.py); never a measurement.
+        backend = os.environ.get("DREG_BENCH_BACKEND", "nccl")
+        if os.environ.get("DREG_BENCH_ONE_GPU") == "1":
+            local_rank = 0
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
     torch.cuda.set_device(local_rank)

@@ -79,3 +79,23 @@ def test_two_ranks_average_equals_one_rank_with_both_pairs():
             seen += 1
     assert seen > 100 and worst < 5e-2, (seen, worst)
     assert float((single.double() - g0.double()).norm()) < 5e-3 * float(single.double().norm())
+
+
+def test_bench_script_runs_with_two_ranks():
+    """bench.py's multi-rank path (rank-0 broadcast of the weights, barrier + max-over-ranks timing, one JSON line from rank 0 with the
+    whole-job rate) with two ranks on this box's one GPU over gloo (DREG_BENCH_BACKEND / DREG_BENCH_ONE_GPU test hooks)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DREG_BENCH_BACKEND="gloo", DREG_BENCH_ONE_GPU="1")
+    port = 29700 + (os.getpid() % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--res", "64", "--pairs", "1", "--no-cpu-baseline", "--no-dense-reference"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 2 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # whole-job pairs/s = ranks x pairs / step time
