@@ -271,6 +271,12 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
         const uint32_t ri = m0 + r;            // row of the (possibly sparse) row space
         const bool rv = ri < nrows;
         const uint32_t m = rowlist ? (rv ? (uint32_t)rowlist[ri] : 0u) : ri;   // output voxel
+        if (g.ksz == 1 && g.sn == 1 && g.sd == 1 && g.off == 0) {
+            // 1^3 stride 1 (the linear layers, two of three bottleneck convolutions): the gathered voxel IS the output voxel
+            amask[i] = rv ? 1u : 0u;
+            abase[i] = m * (uint32_t)(g.Cin * 2) + (uint32_t)(gl * 16);
+            continue;
+        }
         int b, z, y, x;
         vox_decode(rv ? m : 0, g, b, z, y, x);
         const int zb = z * g.sn + g.off, yb = y * g.sn + g.off, xb = x * g.sn + g.off;
@@ -358,8 +364,9 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
 
     // split-K (small row spaces: blockIdx.y = K slice, raw fp32 partial tiles at out + slice*M*Cout, finished by
     // splitk_reduce_kernel); ksplit == 1 is the plain kernel
-    const int k_begin = ksplit > 1 ? (int)((long)nk * blockIdx.y / ksplit) : 0;
-    const int k_end = ksplit > 1 ? (int)((long)nk * (blockIdx.y + 1) / ksplit) : nk;
+    // (32-bit: nk <= 27 * 32 K steps, <= 16 slices; a 64-bit division by a run-time value is ~150 scalar instructions, twice per workgroup)
+    const int k_begin = ksplit > 1 ? (int)((uint32_t)nk * blockIdx.y / (uint32_t)ksplit) : 0;
+    const int k_end = ksplit > 1 ? (int)((uint32_t)nk * (blockIdx.y + 1) / (uint32_t)ksplit) : nk;
     if (ksplit > 1) out += (size_t)blockIdx.y * g.M * g.Cout;
     // ring of nstage (2..4) LDS stages: stage k is consumed while the loads of up to nstage-1 later stages are in flight
     constexpr int LPS = IA + IBW;                      // direct-to-LDS loads per wave per stage (vmcnt retires them in order)

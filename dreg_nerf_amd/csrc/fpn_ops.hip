@@ -30,6 +30,24 @@ template <> struct Gran<bf16_t> {
     }
 };
 
+// flat element index -> (channel granule, x, y, z, batch).  The grids here have < 2^32 granules: 32-bit divisions (~25 instructions each)
+// instead of the 64-bit ones the size_t loop index would drag in (~120 each, four per element: the pooling kernels were instruction-bound)
+__device__ __forceinline__ void decode_gxyzb(size_t i, int CG, int W, int H, int D, int& cg, int& x, int& y, int& z, int& b)
+{
+    if ((i >> 32) == 0) {
+        uint32_t r = (uint32_t)i;
+        uint32_t q = r / (uint32_t)CG; cg = (int)(r - q * (uint32_t)CG); r = q;
+        q = r / (uint32_t)W; x = (int)(r - q * (uint32_t)W); r = q;
+        q = r / (uint32_t)H; y = (int)(r - q * (uint32_t)H); r = q;
+        q = r / (uint32_t)D; z = (int)(r - q * (uint32_t)D); b = (int)q;
+    } else {
+        size_t r = i;
+        cg = (int)(r % CG); r /= CG;
+        x = (int)(r % W); r /= W;
+        y = (int)(r % H); r /= H;
+        z = (int)(r % D); b = (int)(r / D);
+    }
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -540,12 +558,8 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, u
     const int CG = C / G;
     const size_t total = (size_t)B * Do * Ho * Wo * CG;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % CG);
-        size_t r = i / CG;
-        const int ox = (int)(r % Wo); r /= Wo;
-        const int oy = (int)(r % Ho); r /= Ho;
-        const int oz = (int)(r % Do);
-        const int b = (int)(r / Do);
+        int cg, ox, oy, oz, b;
+        decode_gxyzb(i, CG, Wo, Ho, Do, cg, ox, oy, oz, b);
         float best[G];
         int bi[G];
 #pragma unroll
@@ -579,12 +593,8 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __re
     const int CG = C / G;
     const size_t total = (size_t)B * Di * Hi * Wi * CG;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % CG);
-        size_t r = i / CG;
-        const int ix = (int)(r % Wi); r /= Wi;
-        const int iy = (int)(r % Hi); r /= Hi;
-        const int iz = (int)(r % Di);
-        const int b = (int)(r / Di);
+        int cg, ix, iy, iz, b;
+        decode_gxyzb(i, CG, Wi, Hi, Di, cg, ix, iy, iz, b);
         float acc[G];
 #pragma unroll
         for (int k = 0; k < G; ++k) acc[k] = 0.f;
@@ -627,12 +637,8 @@ __global__ void bn_relu_maxpool_fwd_kernel(const T* __restrict__ x, const float*
     const int CG = C / G;
     const size_t total = (size_t)B * Do * Ho * Wo * CG;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % CG);
-        size_t r = i / CG;
-        const int ox = (int)(r % Wo); r /= Wo;
-        const int oy = (int)(r % Ho); r /= Ho;
-        const int oz = (int)(r % Do);
-        const int b = (int)(r / Do);
+        int cg, ox, oy, oz, b;
+        decode_gxyzb(i, CG, Wo, Ho, Do, cg, ox, oy, oz, b);
         float sc[G], sh[G], best[G];
         int bi[G];
 #pragma unroll
@@ -761,13 +767,11 @@ __global__ void downsample_sum_rows_kernel(const T* __restrict__ g, T* __restric
     const int CG = C / G;
     const size_t total = (size_t)nrows * CG;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % CG);
-        size_t r = (size_t)rows[i / CG];
-        const size_t orow = r;
-        const int x = (int)(r % Wc); r /= Wc;
-        const int y = (int)(r % Hc); r /= Hc;
-        const int z = (int)(r % Dc);
-        const int b = (int)(r / Dc);
+        const uint32_t ri = (uint32_t)(i / (uint32_t)CG);       // total < 2^32 granules
+        const int cg = (int)((uint32_t)i - ri * (uint32_t)CG);
+        const size_t orow = (size_t)rows[ri];
+        int cg0, x, y, z, b;
+        decode_gxyzb(orow, 1, Wc, Hc, Dc, cg0, x, y, z, b);
         float acc[G];
 #pragma unroll
         for (int k = 0; k < G; ++k) acc[k] = 0.f;
@@ -792,12 +796,8 @@ __global__ void downsample_sum_kernel(const T* __restrict__ g, T* __restrict__ o
     const int CG = C / G;
     const size_t total = (size_t)B * Dc * Hc * Wc * CG;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % CG);
-        size_t r = i / CG;
-        const int x = (int)(r % Wc); r /= Wc;
-        const int y = (int)(r % Hc); r /= Hc;
-        const int z = (int)(r % Dc);
-        const int b = (int)(r / Dc);
+        int cg, x, y, z, b;
+        decode_gxyzb(i, CG, Wc, Hc, Dc, cg, x, y, z, b);
         float acc[G];
 #pragma unroll
         for (int k = 0; k < G; ++k) acc[k] = 0.f;
@@ -1006,8 +1006,8 @@ __global__ void scatter_rows_cast_kernel(const float* __restrict__ comp, const i
     constexpr int G = Gran<T>::G;
     const int CG = C / G;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total_gran; i += (size_t)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % CG);
-        const size_t r = i / CG;
+        const size_t r = (i >> 32) == 0 ? (size_t)((uint32_t)i / (uint32_t)CG) : i / CG;
+        const int cg = (int)(i - r * CG);
         float v[G];
 #pragma unroll
         for (int k = 0; k < G; ++k) v[k] = comp[r * C + (size_t)cg * G + k];
@@ -1023,8 +1023,8 @@ __global__ void zero_rows_kernel(const int* __restrict__ rows, T* __restrict__ o
     constexpr int G = Gran<T>::G;
     const int CG = C / G;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total_gran; i += (size_t)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % CG);
-        const size_t r = i / CG;
+        const size_t r = (i >> 32) == 0 ? (size_t)((uint32_t)i / (uint32_t)CG) : i / CG;
+        const int cg = (int)(i - r * CG);
         *reinterpret_cast<uint4*>(out + (size_t)rows[r] * C + (size_t)cg * G) = make_uint4(0, 0, 0, 0);
     }
 }
