@@ -805,6 +805,8 @@ class TrilinearGatherFn(torch.autograd.Function):
                 key = (shape, dtype, gout.device)
                 ent = _DP1_CACHE.get(key)
                 if ent is None:
+                    while len(_DP1_CACHE) >= 2:            # one buffer per (shape, dtype, device): 1 GB at 8 x 64^3 x 256 — keep two
+                        _DP1_CACHE.pop(next(iter(_DP1_CACHE)))
                     ent = _DP1_CACHE[key] = [torch.zeros(shape, dtype=dtype, device=gout.device), None]
                 g, dirty = ent
                 if dirty is not None:
