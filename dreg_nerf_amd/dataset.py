@@ -275,7 +275,7 @@ class PrefetchLoader:
         import threading
         self.ds, self.indices, self.device = dataset, list(indices), device
         self.q = queue.Queue(maxsize=max(depth, 1))
-        self.stream = torch.cuda.Stream(device=device) if (device is not None and torch.device(device).type == "cuda") else None
+        self.stream = torch.cuda.Stream(device=device, priority=-1) if (device is not None and torch.device(device).type == "cuda") else None   # high priority: its few small kernels must not queue behind a saturated training stream
         self._err = None
         self._rng_state = random.getstate()     # the thread draws the block order / augmentation from the caller's Python RNG stream
         self.thread = threading.Thread(target=self._run, daemon=True)

@@ -2,7 +2,7 @@
 """End-to-end training throughput of train_nerf_regtr.py on ON-DISK blocks in the reference's directory layout (input pipeline
 included: disk -> sparse block -> H2D -> on-device augmentation through dataset.PrefetchLoader), next to bench.py's synthetic,
 HBM-resident number.  8 real shell-R scenes (2 blocks of 128^3, dense voxel_grid.pt = 58.7 MB each as the reference writes them) are
-exposed under 64 scene names (symlinks); epoch 0 builds the voxel_sparse.pt caches, later epochs are the steady state."""
+exposed under 256 scene names (symlinks; IO_NAMES); epoch 0 builds the voxel_sparse.pt caches, later epochs are the steady state."""
 import json
 import os
 import re
@@ -20,7 +20,7 @@ from dreg_nerf_amd.dataset import _small_se3  # noqa: E402
 
 
 def main():
-    res, n_real, n_names, per_step = 128, 8, 64, 4
+    res, n_real, n_names, per_step = 128, 8, int(os.environ.get("IO_NAMES", "256")), 4
     root = tempfile.mkdtemp(prefix="dreg_io_")
     jdir = os.path.join(root, "json")
     os.makedirs(jdir)

@@ -38,6 +38,25 @@ for s in range(steps):
         print("step", s, "ok", [(int(b["src_mask"].shape[-1]), int(b["tgt_mask"].shape[-1])) for b in batch], {k: round(float(v), 4) for k, v in out["losses"].items()}, flush=True)
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
+if os.environ.get("SOAK_ALLOC"):
+    # steady-state check: a second pass over the same pool — how many device allocations (hipMalloc: synchronises) does a step with
+    # CHANGING row counts still trigger, and what does it cost next to a fixed batch?
+    st0 = torch.cuda.memory_stats()
+    t1 = time.perf_counter()
+    for s in range(steps):
+        ts.step([pool[(4 * s + j) % len(pool)] for j in range(4)])
+    torch.cuda.synchronize()
+    dt_var = (time.perf_counter() - t1) / steps
+    st1 = torch.cuda.memory_stats()
+    t1 = time.perf_counter()
+    for s in range(steps):
+        ts.step(pool[:4])
+    torch.cuda.synchronize()
+    dt_fix = (time.perf_counter() - t1) / steps
+    st2 = torch.cuda.memory_stats()
+    k = "num_device_alloc"
+    print(f"changing pairs: {1e3 * dt_var:.2f} ms/step, {st1[k] - st0[k]} device allocations, {st1['num_alloc_retries'] - st0['num_alloc_retries']} retries; "
+          f"fixed batch: {1e3 * dt_fix:.2f} ms/step, {st2[k] - st1[k]} device allocations")
 ls = [float(x) for x in losses]
 assert all(l == l and abs(l) < 1e9 for l in ls), "non-finite loss"
 k = max(1, steps // 10)

@@ -42,6 +42,10 @@ def validate(model, dataset, dev, frac=0.2):
 
 
 def main():
+    # The loader thread (dataset.PrefetchLoader) and this thread share the interpreter lock; with CPython's default 5 ms switch
+    # interval the launching thread can sit out several milliseconds per hand-over while the GPU runs dry.
+    import sys
+    sys.setswitchinterval(float(os.environ.get("DREG_SWITCH_INTERVAL", "0.0005")))
     cfg = config_parser()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
