@@ -229,6 +229,48 @@ def test_large_layer_weight_gradient_tiles_are_bit_identical():
     assert float((out[1] - ref.grad).abs().max()) <= 2e-3 * float(ref.grad.abs().max())
 
 
+def test_row_list_helpers_of_the_active_set_backward():
+    """dreg_zero_rows, dreg_downsample_sum_rows and dreg_maxpool3d_bwd_acc against plain torch."""
+    from dreg_nerf_amd import lib as L
+    dev = _dev()
+    lib = L.load()
+    g = torch.Generator().manual_seed(41)
+    st = L.stream()
+    # zero_rows: only the listed rows change
+    buf = torch.randn(500, 64, generator=g).to(dev, torch.bfloat16)
+    rows = torch.tensor(sorted(torch.randperm(500, generator=g)[:77].tolist()), dtype=torch.int32, device=dev)
+    want = buf.clone(); want[rows.long()] = 0
+    L.check(lib.dreg_zero_rows(L.ptr(buf), L.ptr(rows), rows.shape[0], 64, 0, st), "zero_rows")
+    assert torch.equal(buf, want)
+    # downsample_sum_rows: out[rows] = sum of the 2^3 children (odd fine extents: cropped), other rows untouched
+    B, Df, Hf, Wf, C = 2, 7, 6, 5, 32
+    Dc, Hc, Wc = 4, 3, 3
+    fine = torch.randn(B, Df, Hf, Wf, C, generator=g).to(dev, torch.bfloat16)
+    out = torch.full((B, Dc, Hc, Wc, C), 7.0, dtype=torch.bfloat16, device=dev)
+    crow = torch.tensor(sorted(torch.randperm(B * Dc * Hc * Wc, generator=g)[:31].tolist()), dtype=torch.int32, device=dev)
+    L.check(lib.dreg_downsample_sum_rows(L.ptr(fine), L.ptr(out), L.ptr(crow), crow.shape[0], Df, Hf, Wf, Dc, Hc, Wc, C, 0, st), "ds rows")
+    pad = torch.zeros(B, 2 * Dc, 2 * Hc, 2 * Wc, C, device=dev)
+    pad[:, :Df, :Hf, :Wf] = fine.float()
+    ref = pad.view(B, Dc, 2, Hc, 2, Wc, 2, C).sum(dim=(2, 4, 6)).to(torch.bfloat16)
+    flat_out, flat_ref = out.view(-1, C), ref.view(-1, C)
+    sel = torch.zeros(flat_out.shape[0], dtype=torch.bool, device=dev); sel[crow.long()] = True
+    assert torch.allclose(flat_out[sel].float(), flat_ref[sel].float(), atol=2e-2, rtol=2e-2) and bool((flat_out[~sel] == 7.0).all())
+    # maxpool3d_bwd_acc: dx += unpool(dy)
+    x = torch.randn(1, 6, 6, 6, 16, generator=g).to(dev, torch.bfloat16)
+    y = torch.empty(1, 3, 3, 3, 16, dtype=torch.bfloat16, device=dev); arg = torch.empty(1, 3, 3, 3, 16, dtype=torch.uint8, device=dev)
+    L.check(lib.dreg_maxpool3d_fwd(L.ptr(x), L.ptr(y), L.ptr(arg), 1, 6, 6, 6, 3, 3, 3, 16, 0, st), "pool fwd")
+    dy = torch.randn(1, 3, 3, 3, 16, generator=g).to(dev, torch.bfloat16)
+    plain = torch.empty_like(x)
+    L.check(lib.dreg_maxpool3d_bwd(L.ptr(dy), L.ptr(arg), L.ptr(plain), 1, 6, 6, 6, 3, 3, 3, 16, 0, st), "pool bwd")
+    base = torch.randn(1, 6, 6, 6, 16, generator=g).to(dev, torch.bfloat16)
+    acc = base.clone()
+    L.check(lib.dreg_maxpool3d_bwd_acc(L.ptr(dy), L.ptr(arg), L.ptr(acc), 1, 6, 6, 6, 3, 3, 3, 16, 1, 0, st), "pool bwd acc")
+    xr = x.float().permute(0, 4, 1, 2, 3).requires_grad_(True)
+    F.max_pool3d(xr, 3, 2, 1).backward(dy.float().permute(0, 4, 1, 2, 3))
+    assert torch.allclose(plain.float(), xr.grad.permute(0, 2, 3, 4, 1), atol=1e-2)
+    assert torch.allclose(acc.float(), base.float() + plain.float(), atol=2e-2, rtol=2e-2)
+
+
 def test_conv_upsample_add_epilogue():
     dev = _dev()
     g = torch.Generator().manual_seed(7)
