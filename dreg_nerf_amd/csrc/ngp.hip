@@ -31,6 +31,21 @@ __device__ __forceinline__ f16x8_t ldsfrag(const char* base, int rs, int row, in
     return *reinterpret_cast<const f16x8_t*>(base + row * rs + k0 * 2);
 }
 
+// Every wave owns its 64 points and its own slice of LDS (sX / sH of wave w): what one layer writes is read back by the SAME wave.  LDS
+// instructions of a wave execute in issue order, so no workgroup barrier is needed between the layers — only the compiler must not
+// move the reads above the writes.  (Six __syncthreads per direction kept the four waves of a workgroup in lockstep.)
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// Hidden activations go back to LDS between the layers.  The products are formed TRANSPOSED (weights as the MFMA's first operand), so a
+// lane holds four consecutive hidden units of one point: one 8-byte LDS write of four fp16 instead of four 2-byte writes (the layers
+// are 16-64 MFMAs each; 64 scalar LDS writes per lane and layer were most of the kernel).  Same products, same sums: bit-identical.
+__device__ __forceinline__ void store_relu4(char* sH, int row_stride, int point, int hidden, const f32x4_t& v, float b0 = 0.f, float b1 = 0.f, float b2 = 0.f, float b3 = 0.f)
+{
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+    const f16x4_t h = {(_Float16)fmaxf(v[0] + b0, 0.f), (_Float16)fmaxf(v[1] + b1, 0.f), (_Float16)fmaxf(v[2] + b2, 0.f), (_Float16)fmaxf(v[3] + b3, 0.f)};
+    *reinterpret_cast<f16x4_t*>(sH + point * row_stride + hidden * 2) = h;
+}
+
 // ------------------------------------------------------------------------------------------------ density
 // x world [Np,3] fp32 -> density fp32 [Np] (= exp(h0 - 1) * inside), raw fp16 [Np,16] (h0 | 15 geometry features)
 __global__ __launch_bounds__(256) void ngp_density_kernel(const float* __restrict__ x, const _Float16* __restrict__ table,
@@ -40,10 +55,12 @@ __global__ __launch_bounds__(256) void ngp_density_kernel(const float* __restric
                                                           int contract)
 {
     constexpr int XRS = 32 * 2 + 16, HRS = 64 * 2 + 16;
-    __shared__ __attribute__((aligned(16))) char smem[4 * (64 * XRS + 64 * HRS + 64 * 4)];
+    // per wave: ONE 64 x 64 fp16 tile (the encoded input X lives in its first 5 KB until the first layer has read it) + 64 flags:
+    // 9.5 KB per wave, 38 KB per workgroup -> four workgroups per CU (the gathers of the 16 levels are latency: occupancy hides them)
+    __shared__ __attribute__((aligned(16))) char smem[4 * (64 * HRS + 64 * 4)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    char* sX = smem + wave * (64 * XRS + 64 * HRS + 64 * 4);
-    char* sH = sX + 64 * XRS;
+    char* sH = smem + wave * (64 * HRS + 64 * 4);
+    char* sX = sH;
     float* sSel = reinterpret_cast<float*>(sH + 64 * HRS);
     const int p0 = (blockIdx.x * 4 + wave) * 64;
     const int p = p0 + lane;
@@ -98,7 +115,7 @@ __global__ __launch_bounds__(256) void ngp_density_kernel(const float* __restric
         _Float16* xr = reinterpret_cast<_Float16*>(sX + lane * XRS);
         xr[2 * l] = (_Float16)f0; xr[2 * l + 1] = (_Float16)f1;
     }
-    __syncthreads();
+    wave_sync();
     const int fr = lane & 15, kg = lane >> 4;
     f32x4_t acc[4][4];
     {
@@ -109,17 +126,14 @@ __global__ __launch_bounds__(256) void ngp_density_kernel(const float* __restric
         for (int rb = 0; rb < 4; ++rb) {
             const f16x8_t af = ldsfrag(sX, XRS, rb * 16 + fr, kg * 8);
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[cb], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            for (int cb = 0; cb < 4; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[cb], af, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
     }
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                reinterpret_cast<_Float16*>(sH + (rb * 16 + kg * 4 + r) * HRS)[cb * 16 + fr] = (_Float16)fmaxf(acc[rb][cb][r], 0.f);
-    __syncthreads();
+        for (int cb = 0; cb < 4; ++cb) store_relu4(sH, HRS, rb * 16 + fr, cb * 16 + kg * 4, acc[rb][cb]);
+    wave_sync();
     f16x8_t w2f[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) w2f[kb] = *reinterpret_cast<const f16x8_t*>(w2 + fr * 64 + kb * 32 + kg * 8);
@@ -143,16 +157,19 @@ __global__ __launch_bounds__(256) void ngp_density_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------ colour, 18 directions
 // raw fp16 [Np,16] (col 0 ignored, cols 1..15 geometry features) -> rgb fp32 [Np,3] = mean_k sigmoid(net(sh_k | feat | 1))
 // w1 fp16 [64][32], w2 fp16 [64][64], w3 fp16 [16][64]; dirbias fp32 [ndir][64] = W1[:, :16] . fp16(sh_k)
-__global__ __launch_bounds__(256) void ngp_rgb_kernel(const _Float16* __restrict__ raw, const _Float16* __restrict__ w1, const _Float16* __restrict__ w2,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ngp_rgb_kernel(const _Float16* __restrict__ raw, const _Float16* __restrict__ w1, const _Float16* __restrict__ w2,
                                                       const _Float16* __restrict__ w3, const float* __restrict__ dirbias,
                                                       float* __restrict__ rgb, int ndir, int Np, const float* __restrict__ dirs = nullptr)
 {
     constexpr int XRS = 32 * 2 + 16, HRS = 64 * 2 + 16;
-    __shared__ __attribute__((aligned(16))) char smem[4 * (64 * XRS + 2 * 64 * HRS)];
+    // per wave ONE 64 x 64 fp16 tile: X (prologue only) aliases it, and the second layer overwrites the first layer's activations in
+    // place — a 16-row block is read into registers in full before its outputs are written.  9 KB per wave instead of 23.5 KB: four
+    // workgroups per CU instead of one (one wave per SIMD had nothing to hide the LDS round trips and MFMA dependency chains with).
+    __shared__ __attribute__((aligned(16))) char smem[4 * 64 * HRS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    char* sX = smem + wave * (64 * XRS + 2 * 64 * HRS);
-    char* sH1 = sX + 64 * XRS;
-    char* sH2 = sH1 + 64 * HRS;
+    char* sH1 = smem + wave * 64 * HRS;
+    char* sH2 = sH1;
+    char* sX = sH1;
     const int p0 = (blockIdx.x * 4 + wave) * 64;
     const int p = p0 + lane;
     {   // X = (0 x16 | feat[1..15] | 1); with per-point directions (dirs != null, ndir == 1) the first 16 columns carry fp16(SH4(dir))
@@ -177,7 +194,7 @@ __global__ __launch_bounds__(256) void ngp_rgb_kernel(const _Float16* __restrict
         for (int j = 0; j < 15; ++j) xr[16 + j] = p < Np ? raw[(size_t)p * 16 + 1 + j] : (_Float16)0.f;
         xr[31] = (_Float16)1.f;
     }
-    __syncthreads();
+    wave_sync();
     const int fr = lane & 15, kg = lane >> 4;
     f32x4_t base[4][4];
     {
@@ -188,7 +205,7 @@ __global__ __launch_bounds__(256) void ngp_rgb_kernel(const _Float16* __restrict
         for (int rb = 0; rb < 4; ++rb) {
             const f16x8_t af = ldsfrag(sX, XRS, rb * 16 + fr, kg * 8);
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) base[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[cb], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            for (int cb = 0; cb < 4; ++cb) base[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[cb], af, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
     }
     f16x8_t w3f[2];
@@ -202,18 +219,15 @@ __global__ __launch_bounds__(256) void ngp_rgb_kernel(const _Float16* __restrict
 
 #pragma unroll 1
     for (int k = 0; k < ndir; ++k) {
-        float cb_[4];
+        float4 cb_[4];       // the direction's bias for this lane's four hidden units of every 16-column block
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) cb_[cb] = dirs ? 0.f : dirbias[k * 64 + cb * 16 + fr];
-        __syncthreads();
+        for (int cb = 0; cb < 4; ++cb) cb_[cb] = dirs ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(dirbias + k * 64 + cb * 16 + kg * 4);
+        wave_sync();
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    reinterpret_cast<_Float16*>(sH1 + (rb * 16 + kg * 4 + r) * HRS)[cb * 16 + fr] = (_Float16)fmaxf(base[rb][cb][r] + cb_[cb], 0.f);
-        __syncthreads();
+            for (int cb = 0; cb < 4; ++cb) store_relu4(sH1, HRS, rb * 16 + fr, cb * 16 + kg * 4, base[rb][cb], cb_[cb].x, cb_[cb].y, cb_[cb].z, cb_[cb].w);
+        wave_sync();
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
             f16x8_t af[2];
@@ -224,13 +238,11 @@ __global__ __launch_bounds__(256) void ngp_rgb_kernel(const _Float16* __restrict
                 f32x4_t h = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
-                    h = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kb], *reinterpret_cast<const f16x8_t*>(w2 + (cb * 16 + fr) * 64 + kb * 32 + kg * 8), h, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    reinterpret_cast<_Float16*>(sH2 + (rb * 16 + kg * 4 + r) * HRS)[cb * 16 + fr] = (_Float16)fmaxf(h[r], 0.f);
+                    h = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8_t*>(w2 + (cb * 16 + fr) * 64 + kb * 32 + kg * 8), af[kb], h, 0, 0, 0);
+                store_relu4(sH2, HRS, rb * 16 + fr, cb * 16 + kg * 4, h);
             }
         }
-        __syncthreads();
+        wave_sync();
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
             f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -239,7 +251,8 @@ __global__ __launch_bounds__(256) void ngp_rgb_kernel(const _Float16* __restrict
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float hv = (float)(_Float16)o[r];
-                sum[rb][r] += (float)(_Float16)(1.f / (1.f + __expf(-hv)));
+                // v_rcp_f32 (1 ulp) instead of the 12-instruction IEEE division: the result is rounded to fp16 right after
+                sum[rb][r] += (float)(_Float16)__builtin_amdgcn_rcpf(1.f + __expf(-hv));
             }
         }
     }
