@@ -48,7 +48,9 @@ __device__ __forceinline__ void store_relu4(char* sH, int row_stride, int point,
 
 // ------------------------------------------------------------------------------------------------ density
 // x world [Np,3] fp32 -> density fp32 [Np] (= exp(h0 - 1) * inside), raw fp16 [Np,16] (h0 | 15 geometry features)
-__global__ __launch_bounds__(256) void ngp_density_kernel(const float* __restrict__ x, const _Float16* __restrict__ table,
+// one wave per workgroup: the waves are independent (no workgroup barrier), and 5,081 small workgroups for a 325 k-point block fill
+// the chip evenly where 1,270 four-wave ones left a quarter-full second round
+__global__ __launch_bounds__(64) void ngp_density_kernel(const float* __restrict__ x, const _Float16* __restrict__ table,
                                                           const _Float16* __restrict__ w1, const _Float16* __restrict__ w2,
                                                           float* __restrict__ density, _Float16* __restrict__ raw,
                                                           NgpLevels lv, float lo0, float lo1, float lo2, float hi0, float hi1, float hi2, int Np,
@@ -57,12 +59,12 @@ __global__ __launch_bounds__(256) void ngp_density_kernel(const float* __restric
     constexpr int XRS = 32 * 2 + 16, HRS = 64 * 2 + 16;
     // per wave: ONE 64 x 64 fp16 tile (the encoded input X lives in its first 5 KB until the first layer has read it) + 64 flags:
     // 9.5 KB per wave, 38 KB per workgroup -> four workgroups per CU (the gathers of the 16 levels are latency: occupancy hides them)
-    __shared__ __attribute__((aligned(16))) char smem[4 * (64 * HRS + 64 * 4)];
+    __shared__ __attribute__((aligned(16))) char smem[64 * HRS + 64 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    char* sH = smem + wave * (64 * HRS + 64 * 4);
+    char* sH = smem;
     char* sX = sH;
     float* sSel = reinterpret_cast<float*>(sH + 64 * HRS);
-    const int p0 = (blockIdx.x * 4 + wave) * 64;
+    const int p0 = (int)blockIdx.x * 64;
     const int p = p0 + lane;
     float u[3] = {0.f, 0.f, 0.f};
     bool inside = false;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void ngp_density_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------ colour, 18 directions
 // raw fp16 [Np,16] (col 0 ignored, cols 1..15 geometry features) -> rgb fp32 [Np,3] = mean_k sigmoid(net(sh_k | feat | 1))
 // w1 fp16 [64][32], w2 fp16 [64][64], w3 fp16 [16][64]; dirbias fp32 [ndir][64] = W1[:, :16] . fp16(sh_k)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ngp_rgb_kernel(const _Float16* __restrict__ raw, const _Float16* __restrict__ w1, const _Float16* __restrict__ w2,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void ngp_rgb_kernel(const _Float16* __restrict__ raw, const _Float16* __restrict__ w1, const _Float16* __restrict__ w2,
                                                       const _Float16* __restrict__ w3, const float* __restrict__ dirbias,
                                                       float* __restrict__ rgb, int ndir, int Np, const float* __restrict__ dirs = nullptr)
 {
@@ -165,12 +167,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // per wave ONE 64 x 64 fp16 tile: X (prologue only) aliases it, and the second layer overwrites the first layer's activations in
     // place — a 16-row block is read into registers in full before its outputs are written.  9 KB per wave instead of 23.5 KB: four
     // workgroups per CU instead of one (one wave per SIMD had nothing to hide the LDS round trips and MFMA dependency chains with).
-    __shared__ __attribute__((aligned(16))) char smem[4 * 64 * HRS];
+    __shared__ __attribute__((aligned(16))) char smem[64 * HRS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    char* sH1 = smem + wave * 64 * HRS;
+    char* sH1 = smem;
     char* sH2 = sH1;
     char* sX = sH1;
-    const int p0 = (blockIdx.x * 4 + wave) * 64;
+    const int p0 = (int)blockIdx.x * 64;
     const int p = p0 + lane;
     {   // X = (0 x16 | feat[1..15] | 1); with per-point directions (dirs != null, ndir == 1) the first 16 columns carry fp16(SH4(dir))
         // and the first layer is the full 32-wide product instead of "geometry half + per-direction bias"
@@ -339,7 +341,7 @@ int dreg_ngp_density_fwd(const float* x, const void* table, const void* w1, cons
     if (Np == 0) return DREG_OK;
     NgpLevels lv;
     for (int l = 0; l < 16; ++l) { lv.offset[l] = offset[l]; lv.size[l] = size[l]; lv.res[l] = res[l]; lv.scale[l] = scale[l]; lv.hashed[l] = hashed[l]; }
-    hipLaunchKernelGGL(ngp_density_kernel, dim3((Np + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)table,
+    hipLaunchKernelGGL(ngp_density_kernel, dim3((Np + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, (const _Float16*)table,
                        (const _Float16*)w1, (const _Float16*)w2, density, (_Float16*)raw, lv,
                        aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np, 0);
     DREG_LAUNCH_CHECK();
@@ -354,7 +356,7 @@ int dreg_ngp_density_fwd_contract(const float* x, const void* table, const void*
     if (Np == 0) return DREG_OK;
     NgpLevels lv;
     for (int l = 0; l < 16; ++l) { lv.offset[l] = offset[l]; lv.size[l] = size[l]; lv.res[l] = res[l]; lv.scale[l] = scale[l]; lv.hashed[l] = hashed[l]; }
-    hipLaunchKernelGGL(ngp_density_kernel, dim3((Np + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, (const _Float16*)table,
+    hipLaunchKernelGGL(ngp_density_kernel, dim3((Np + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, (const _Float16*)table,
                        (const _Float16*)w1, (const _Float16*)w2, density, (_Float16*)raw, lv,
                        aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np, contract);
     DREG_LAUNCH_CHECK();
@@ -365,7 +367,7 @@ int dreg_ngp_density_fwd_contract(const float* x, const void* table, const void*
 int dreg_ngp_rgb_dir_fwd(const void* raw, const void* w1, const void* w2, const void* w3, const float* dirs, float* rgb, int Np, void* stream)
 {
     if (Np == 0) return DREG_OK;
-    hipLaunchKernelGGL(ngp_rgb_kernel, dim3((Np + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const _Float16*)raw,
+    hipLaunchKernelGGL(ngp_rgb_kernel, dim3((Np + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const _Float16*)raw,
                        (const _Float16*)w1, (const _Float16*)w2, (const _Float16*)w3, (const float*)nullptr, rgb, 1, Np, dirs);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
@@ -376,7 +378,7 @@ int dreg_ngp_rgb_mean_fwd(const void* raw, const void* w1, const void* w2, const
                           int ndir, int Np, void* stream)
 {
     if (Np == 0) return DREG_OK;
-    hipLaunchKernelGGL(ngp_rgb_kernel, dim3((Np + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const _Float16*)raw,
+    hipLaunchKernelGGL(ngp_rgb_kernel, dim3((Np + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const _Float16*)raw,
                        (const _Float16*)w1, (const _Float16*)w2, (const _Float16*)w3, dirbias, rgb, ndir, Np);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
