@@ -374,6 +374,49 @@ int dreg_ngp_rgb_dir_fwd(const void* raw, const void* w1, const void* w2, const 
 }
 
 // raw fp16 [Np,16] -> rgb fp32 [Np,3], mean over ndir directions; dirbias fp32 [ndir,64] on the device.
+// c[k][j] = sum_i fp16(W1[j][i]) * fp16(SH4(dir_k)[i]), i < 16: the direction half of the colour net's first layer for K shared viewing
+// directions (sample_grid.py:332-337 evaluates the field from 18 of them) — one launch instead of ~30 elementwise torch launches.
+__global__ void ngp_dir_bias_kernel(const float* __restrict__ dirs, const _Float16* __restrict__ w1, float* __restrict__ out, int K)
+{
+    const int k = blockIdx.x, j = threadIdx.x;       // 64 threads: one output unit each
+    if (k >= K || j >= 64) return;
+    const float x = dirs[k * 3], y = dirs[k * 3 + 1], z = dirs[k * 3 + 2];
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    const float sh[16] = {0.28209479177387814f, -0.48860251190291987f * y, 0.48860251190291987f * z, -0.48860251190291987f * x,
+                          1.0925484305920792f * xy, -1.0925484305920792f * yz, 0.94617469575755997f * z2 - 0.31539156525251999f,
+                          -1.0925484305920792f * xz, 0.54627421529603959f * x2 - 0.54627421529603959f * y2,
+                          0.59004358992664352f * y * (-3.0f * x2 + y2), 2.8906114426405538f * xy * z,
+                          0.45704579946446572f * y * (1.0f - 5.0f * z2), 0.3731763325901154f * z * (5.0f * z2 - 3.0f),
+                          0.45704579946446572f * x * (1.0f - 5.0f * z2), 1.4453057213202769f * z * (x2 - y2),
+                          0.59004358992664352f * x * (-x2 + 3.0f * y2)};
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += (float)w1[j * 32 + i] * (float)(_Float16)sh[i];
+    out[k * 64 + j] = acc;
+}
+int dreg_ngp_dir_bias(const float* dirs, const void* w1, float* out, int K, void* stream)
+{
+    if (K <= 0) return DREG_OK;
+    hipLaunchKernelGGL(ngp_dir_bias_kernel, dim3(K), dim3(64), 0, (hipStream_t)stream, dirs, (const _Float16*)w1, out, K);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// alpha[n] = clip(1 - exp(-delta * density[n]), 0, 1), keep[n] = density[n] > threshold (sample_grid.py:338-341) in one pass
+__global__ void ngp_alpha_keep_kernel(const float* __restrict__ density, float* __restrict__ alpha, uint8_t* __restrict__ keep, int N, float delta, float thre)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float d = density[n];
+    alpha[n] = fminf(fmaxf(1.f - __expf(-delta * d), 0.f), 1.f);
+    keep[n] = d > thre ? 1 : 0;
+}
+int dreg_ngp_alpha_keep(const float* density, float* alpha, uint8_t* keep, int N, float delta, float threshold, void* stream)
+{
+    if (N <= 0) return DREG_OK;
+    hipLaunchKernelGGL(ngp_alpha_keep_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, density, alpha, keep, N, delta, threshold);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
 int dreg_ngp_rgb_mean_fwd(const void* raw, const void* w1, const void* w2, const void* w3, const float* dirbias, float* rgb,
                           int ndir, int Np, void* stream)
 {

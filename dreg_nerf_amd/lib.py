@@ -156,6 +156,8 @@ SIGNATURES = {
     "dreg_f32_to_f16": (I, [P, P, Z, P]),
     "dreg_ngp_density_fwd": (I, [P] * 6 + [P] * 5 + [P, I, P]),
     "dreg_ngp_rgb_mean_fwd": (I, [P] * 6 + [I, I, P]),
+    "dreg_ngp_dir_bias": (I, [P, P, P, I, P]),
+    "dreg_ngp_alpha_keep": (I, [P, P, P, I, F, F, P]),
     "dreg_ngp_density_fwd_contract": (I, [P] * 6 + [P] * 5 + [P, I, I, P]),
     "dreg_ngp_rgb_dir_fwd": (I, [P] * 6 + [I, P]),
     "dreg_grid_scatter7": (I, [P] * 6 + [I, P]),

@@ -113,6 +113,13 @@ class NGPradianceField(nn.Module):
         return self._prep[1], self._prep[2]
 
     @torch.no_grad()
+    def _aabb_host(self):
+        """The six aabb floats on the host, cached against the buffer's version: `.tolist()` of a device tensor is a host sync."""
+        c = self.__dict__.get("_aabb_cache")
+        if c is None or c[0] != (self.aabb.data_ptr(), self.aabb._version):
+            c = self.__dict__["_aabb_cache"] = ((self.aabb.data_ptr(), self.aabb._version), [float(v) for v in self.aabb.tolist()])
+        return c[1]
+
     def query_raw(self, x: torch.Tensor):
         """x [N,3] world -> (density fp32 [N], raw fp16 [N,16])."""
         lib = L.load()
@@ -122,7 +129,7 @@ class NGPradianceField(nn.Module):
         n = x.shape[0]
         density = torch.empty(n, dtype=torch.float32, device=x.device)
         raw = torch.empty(n, 16, dtype=torch.float16, device=x.device)
-        aabb = (ctypes.c_float * 6)(*[float(v) for v in self.aabb.tolist()])
+        aabb = (ctypes.c_float * 6)(*self._aabb_host())
         # unbounded: contract_to_unisphere(x, aabb) before the hash grid (ngp.py:41-63,163-164)
         L.check(lib.dreg_ngp_density_fwd_contract(L.ptr(x), base16.data_ptr() + 3072 * 2, base16.data_ptr(), base16.data_ptr() + 2048 * 2,
                                                   L.ptr(density), L.ptr(raw), *self._levels, aabb, n, int(bool(self.unbounded)), L.stream()),
@@ -141,6 +148,11 @@ class NGPradianceField(nn.Module):
     def dir_bias(self, dirs: torch.Tensor) -> torch.Tensor:
         """c_k = fp16(W1[:, :16]) . fp16(SH4(dir_k))  for the colour net's first layer: [ndir, 64] fp32."""
         _, col16 = self._prepared()
+        if col16.is_cuda:      # one launch (csrc/ngp.hip) instead of ~30 elementwise ones: the dense query is host-bound on its glue
+            d = dirs.to(col16.device).float().contiguous()
+            out = torch.empty(d.shape[0], 64, dtype=torch.float32, device=col16.device)
+            L.check(L.load().dreg_ngp_dir_bias(L.ptr(d), col16.data_ptr(), L.ptr(out), d.shape[0], L.stream()), "dreg_ngp_dir_bias")
+            return out
         w1 = col16[:2048].view(64, 32)[:, :16].float()
         sh = sh4(dirs.to(w1.device)).half().float()
         return (sh @ w1.T).contiguous()
@@ -298,13 +310,19 @@ class SampleGrid(nn.Module):
             jitter = torch.rand(n, 3, dtype=torch.float32, device=device)
         jitter = jitter.to(device).contiguous()
         world = torch.empty(n, 3, dtype=torch.float32, device=device)
-        rx, ry, rz = [int(v) for v in self.resolution.tolist()]
-        aabb = (ctypes.c_float * 6)(*[float(v) for v in self._roi_aabb.tolist()])
+        hc = self.__dict__.get("_host_consts")      # resolution / aabb on the host, cached: .tolist() of device buffers is a sync each
+        key = (self.resolution.data_ptr(), self.resolution._version, self._roi_aabb.data_ptr(), self._roi_aabb._version)
+        if hc is None or hc[0] != key:
+            hc = self.__dict__["_host_consts"] = (key, [int(v) for v in self.resolution.tolist()], [float(v) for v in self._roi_aabb.tolist()])
+        rx, ry, rz = hc[1]
+        aabb = (ctypes.c_float * 6)(*hc[2])
         L.check(lib.dreg_grid_sample_points(L.ptr(indices), L.ptr(jitter), L.ptr(world), rx, ry, rz, aabb, n, L.stream()), "dreg_grid_sample_points")
         density, raw = radiance_field.query_raw(world)
         rgb = radiance_field.query_rgb_mean(raw, self._viewdirs.to(device))
-        alpha = torch.clip(1 - torch.exp(-self._delta * density), 0, 1)
-        return world, rgb, alpha[:, None], indices, density > density_thre
+        alpha = torch.empty(n, dtype=torch.float32, device=device)
+        keep = torch.empty(n, dtype=torch.uint8, device=device)
+        L.check(lib.dreg_ngp_alpha_keep(L.ptr(density), L.ptr(alpha), L.ptr(keep), n, float(self._delta), float(density_thre), L.stream()), "dreg_ngp_alpha_keep")
+        return world, rgb, alpha[:, None], indices, keep.view(torch.bool)
 
     @torch.no_grad()
     def query_radiance_and_density_from_camera(self, radiance_field, occupancy_grid, meta_data, device,

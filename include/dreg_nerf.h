@@ -376,6 +376,11 @@ int dreg_f32_to_f16(const float* in, void* out, size_t n, void* stream);
 int dreg_ngp_density_fwd(const float* x, const void* table, const void* w1, const void* w2, float* density, void* raw,
                          const uint32_t* offset, const uint32_t* size, const uint32_t* res, const float* scale,
                          const uint32_t* hashed, const float* aabb, int Np, void* stream);
+/* The per-block glue of the dense query as kernels: the direction half of the colour net's first layer for K shared directions
+ * (out fp32 [K][64]; what ngp.NGPradianceField.dir_bias computed with ~30 torch launches), and alpha / density mask
+ * (sample_grid.py:338-341: alpha = clip(1 - exp(-delta * density), 0, 1), keep = density > threshold). */
+int dreg_ngp_dir_bias(const float* dirs, const void* w1_f16, float* out, int K, void* stream);
+int dreg_ngp_alpha_keep(const float* density, float* alpha, uint8_t* keep, int N, float delta, float threshold, void* stream);
 /* mean over ndir fixed viewing directions of the colour net: dirbias fp32 [ndir,64] = W1[:, :16] . sh4(dir_k) */
 int dreg_ngp_rgb_mean_fwd(const void* raw, const void* w1, const void* w2, const void* w3, const float* dirbias, float* rgb,
                           int ndir, int Np, void* stream);
