@@ -47,6 +47,8 @@ struct Op {
     int cl_count = 0;
     int pool = -1;               // OP_BN: index of the max-pool op fused behind it; OP_MAXPOOL: index of the BatchNorm it is fused into
     int halo = 0;                // OP_CONV: bit 0 = forward, bit 1 = data gradient run on the halo kernel
+    int bt = -1;                 // OP_BN on the one-launch small path: index of its record in the two BatchNorm tail tables
+    size_t keep_var = 0, keep_sums = 0;   //   per-grid variances [B][C] / gradient sums [B][C][2] kept until the batched tail launch
 };
 struct HaloPack { const float* w; size_t off; int Cout, Cin, transposed; };
 struct PackRec { const float* w; void* out; int Cout, Cin_real, inner, ntaps, for_dgrad, Kpad, dtype, row0; };
@@ -54,6 +56,9 @@ static_assert(sizeof(PackRec) == 48, "matches PackDesc of conv.hip");
 
 struct ReduceRec { const float* part; float* dw; int nsplit, Cout, Kpad, ntaps, Cin, Cin_real, accumulate, block0; };
 static_assert(sizeof(ReduceRec) == 48, "matches WgradReduceDesc of conv.hip");
+
+struct BnTailRec { const float* a; const float* b; float* o0; float* o1; int B, V, C, block0; };
+static_assert(sizeof(BnTailRec) == 48, "matches BnTailDesc of fpn_ops.hip");
 
 struct TimedLaunch { hipEvent_t e0, e1; int op, kind; };
 
@@ -70,6 +75,10 @@ struct Exec {
     std::vector<ReduceRec> reduce_abs;     // the same with absolute addresses for the arena it was last uploaded to
     int reduce_blocks = 0;
     const void* reduce_arena = nullptr;
+    // small BatchNorms: running-statistics update (forward) and dgamma / dbeta (backward) of all layers of a pass in one launch each
+    std::vector<BnTailRec> bn_fwd, bn_bwd; // a / b = arena offsets until uploaded
+    size_t off_bnf = 0, off_bnb = 0;
+    int bn_blocks = 0;
     std::vector<PackRec> packs;            // with out = offset (patched on export)
     std::vector<HaloPack> halo_packs;      // refreshed by dreg_exec_repack next to the batched pack launch
     int pack_rows = 0, pack_max_floats = 0;
@@ -110,6 +119,7 @@ struct Scope {   // optional HIP-event bracket of one launch group
 #define CK(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 
 int g_sparse_grads = 1;   // tuning (include/dreg_nerf_tuning.h): row-cleared instead of memset gradient buffers in front of the active-set convolutions
+int g_bn_batch_tails = 1; // tuning (include/dreg_nerf_tuning.h): the small BatchNorms' running-statistics / parameter-gradient launches batched per pass
 int g_fuse_stem = 1;      // tuning (include/dreg_nerf_tuning.h): BatchNorm + ReLU + max-pool of the stem in one pass
 
 bool s2_class_ok(const Param& p, int ksz, int stride, int pad)
@@ -186,6 +196,19 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
             const size_t w = (size_t)x.B * dreg_bn_num_chunks((int)V) * x.C * 2 * sizeof(float);
             if (w > bn_ws) bn_ws = w;
             if (sb > coef) coef = sb;
+            bool shared = false;          // parameters used by two layers: both keep their own tail launches
+            for (const Op& q : e->ops) shared = shared || (&q != &o && q.kind == OP_BN && (q.w == o.w || q.b == o.b || q.p2 == o.p2 || q.p3 == o.p3));
+            if (g_bn_batch_tails && o.pool < 0 && !shared && dreg_bn_small(x.B, (int)V, x.C, 0)) {
+                o.keep_var = off; off += align256((size_t)x.B * x.C * sizeof(float));
+                o.keep_sums = off; off += sb;
+                BnTailRec f{}, b{};
+                f.a = (const float*)o.aux1; f.b = (const float*)o.keep_var; f.o0 = e->prm[o.p2].val; f.o1 = e->prm[o.p3].val;
+                b.a = (const float*)o.keep_sums; b.b = nullptr; b.o0 = e->prm[o.w].grad; b.o1 = e->prm[o.b].grad;
+                f.B = b.B = x.B; f.V = b.V = (int)V; f.C = b.C = x.C; f.block0 = b.block0 = e->bn_blocks;
+                e->bn_blocks += (x.C + 255) / 256;
+                o.bt = (int)e->bn_fwd.size();
+                e->bn_fwd.push_back(f); e->bn_bwd.push_back(b);
+            }
         } else if (o.kind == OP_MAXPOOL) {
             const Tensor& y = e->t[o.out];
             o.aux0 = off; off += align256((size_t)y.B * y.D * y.H * y.W * y.C);
@@ -243,6 +266,8 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
     e->off_ks = off; off += align256(e->sz_ks);
     for (Op& o : e->ops) if (o.rd != -1) { o.wg_off = off; off += align256(o.wg_bytes); if (o.rd >= 0) e->reduce[o.rd].part = (const float*)o.wg_off; }
     e->off_rd = off; off += align256(e->reduce.size() * sizeof(ReduceRec) + 16);
+    e->off_bnf = off; off += align256(e->bn_fwd.size() * sizeof(BnTailRec) + 16);
+    e->off_bnb = off; off += align256(e->bn_bwd.size() * sizeof(BnTailRec) + 16);
     e->off_cs = off; off += align256(cs);
     e->off_tmp = off; off += max_tensor;
     e->arena_bytes = off + 256;
@@ -345,6 +370,7 @@ void dreg_exec_set_overlap(void* h, int enable) { ((Exec*)h)->use_aux = enable !
 // [B, Do, Ho], 0 = the row's receptive field in x_in is all zero.  Used by the next forward / backward calls; null = none.
 void dreg_exec_set_input_row_occupancy(void* h, const uint8_t* rowocc) { ((Exec*)h)->in_rowocc = rowocc; }
 void dreg_exec_set_sparse_grads(int on) { g_sparse_grads = on ? 1 : 0; }   // read when an executor is created
+void dreg_exec_set_bn_batch_tails(int on) { g_bn_batch_tails = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_fuse_stem(int on) { g_fuse_stem = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_timing(void* h, int enable) { ((Exec*)h)->timing = enable != 0; }   // records are kept until read
 // After a stream synchronisation: elapsed ms of the bracketed launches since the last set_timing; records are (op, kind, ms)
@@ -362,6 +388,40 @@ int dreg_exec_read_timings(void* h, int* op_kind, float* ms, int max)
     return n;
 }
 
+// The descriptor tables of the batched launches live in the arena (they hold addresses of this arena's buffers): uploaded once per arena.
+static int upload_tables(Exec* e, char* A, hipStream_t st)
+{
+    if (e->reduce_arena == (const void*)A) return DREG_OK;
+    e->reduce_abs = e->reduce;
+    for (ReduceRec& r : e->reduce_abs) r.part = (const float*)(A + (size_t)r.part);
+    std::vector<BnTailRec> f = e->bn_fwd, b = e->bn_bwd;
+    for (BnTailRec& r : f) { r.a = (const float*)(A + (size_t)r.a); r.b = (const float*)(A + (size_t)r.b); }
+    for (BnTailRec& r : b) r.a = (const float*)(A + (size_t)r.a);
+    if (!e->reduce_abs.empty() && hipMemcpyAsync(A + e->off_rd, e->reduce_abs.data(), e->reduce_abs.size() * sizeof(ReduceRec), hipMemcpyHostToDevice, st) != hipSuccess) return DREG_ELAUNCH;
+    if (!f.empty() && (hipMemcpyAsync(A + e->off_bnf, f.data(), f.size() * sizeof(BnTailRec), hipMemcpyHostToDevice, st) != hipSuccess ||
+                       hipMemcpyAsync(A + e->off_bnb, b.data(), b.size() * sizeof(BnTailRec), hipMemcpyHostToDevice, st) != hipSuccess)) return DREG_ELAUNCH;
+    if (hipStreamSynchronize(st) != hipSuccess) return DREG_ELAUNCH;   // the host copies above are locals
+    e->reduce_arena = A;
+    return DREG_OK;
+}
+// One launch per run of consecutive flagged records of a BatchNorm tail table (what: 0 running statistics, 1 parameter gradients).
+static int flush_bn_tails(Exec* e, char* A, std::vector<char>& done, int what, hipStream_t st)
+{
+    for (int lo = 0, nrec = (int)done.size(); lo < nrec;) {
+        if (!done[lo]) { ++lo; continue; }
+        int hi = lo;
+        while (hi + 1 < nrec && done[hi + 1]) ++hi;
+        Scope sc(e, st, -1, 4 + what);
+        const int b0 = e->bn_fwd[lo].block0;
+        const int b1 = hi + 1 < nrec ? e->bn_fwd[hi + 1].block0 : e->bn_blocks;
+        if (what == 0) CK(dreg_bn_running_update_batched((const BnTailRec*)(A + e->off_bnf) + lo, hi - lo + 1, b0, b1 - b0, 0.1f, (void*)st));
+        else CK(dreg_bn_param_grad_batched((const BnTailRec*)(A + e->off_bnb) + lo, hi - lo + 1, b0, b1 - b0, 1, (void*)st));
+        for (int q = lo; q <= hi; ++q) done[q] = 0;
+        lo = hi + 1;
+    }
+    return DREG_OK;
+}
+
 // rowlists: int64 [nlists][2] = (device int32* rows, count).  x: tensor 0.  The result lands at dreg_exec_tensor_offset(output slot).
 int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack_base, const void* x_in,
                       const int64_t* rowlists, int nlists, int train, void* stream)
@@ -371,6 +431,8 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
     char* A = (char*)arena;
     const char* PK = (const char*)pack_base;
     hipStream_t st = (hipStream_t)stream;
+    CK(upload_tables(e, (char*)arena, st));
+    std::vector<char> bn_done(e->bn_fwd.size(), 0);
     auto act = [&](int s) -> void* { return s == 0 ? (void*)x_in : (void*)(A + e->t[s].off); };
     for (size_t i = 0; i < e->ops.size(); ++i) {
         const Op& o = e->ops[i];
@@ -410,12 +472,16 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
             // done by the BatchNorm in front of it
         } else if (o.kind == OP_BN) {
             const int V = x.D * x.H * x.W;
-            CK(dreg_bn3d_fwd(act(o.in), o.in2 >= 0 ? act(o.in2) : nullptr, act(o.out), e->prm[o.w].val, e->prm[o.b].val, e->prm[o.p2].val, e->prm[o.p3].val,
-                             (float*)(A + o.aux0), (float*)(A + o.aux1), (float*)(A + e->off_bn_ws), x.B, V, x.C, 1e-5f, 0.1f, train, o.relu, 0, stream));
+            int deferred = 0;
+            CK(dreg_bn3d_fwd_defer_update(act(o.in), o.in2 >= 0 ? act(o.in2) : nullptr, act(o.out), e->prm[o.w].val, e->prm[o.b].val, e->prm[o.p2].val, e->prm[o.p3].val,
+                                          (float*)(A + o.aux0), (float*)(A + o.aux1), (float*)(A + e->off_bn_ws), x.B, V, x.C, 1e-5f, 0.1f, train, o.relu, 0,
+                                          o.bt >= 0 ? (float*)(A + o.keep_var) : nullptr, &deferred, stream));
+            if (deferred) bn_done[o.bt] = 1;
         } else if (o.kind == OP_MAXPOOL) {
             CK(dreg_maxpool3d_fwd(act(o.in), act(o.out), (uint8_t*)(A + o.aux0), x.B, x.D, x.H, x.W, y.D, y.H, y.W, x.C, 0, stream));
         } else return DREG_EINVAL;
     }
+    CK(flush_bn_tails(e, A, bn_done, 0, st));
     return DREG_OK;
 }
 
@@ -467,14 +533,8 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
         if (hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming) != hipSuccess) aux_on = false;
     }
     bool& aux_used = e->aux_used;
-    if (e->reduce_arena != arena && !e->reduce.empty()) {
-        // the reduce table lives in the arena (addresses of this arena's partials); uploaded once per arena
-        e->reduce_abs = e->reduce;
-        for (ReduceRec& r : e->reduce_abs) r.part = (const float*)(A + (size_t)r.part);
-        if (hipMemcpyAsync(A + e->off_rd, e->reduce_abs.data(), e->reduce_abs.size() * sizeof(ReduceRec), hipMemcpyHostToDevice, st) != hipSuccess) return DREG_ELAUNCH;
-        if (hipStreamSynchronize(st) != hipSuccess) return DREG_ELAUNCH;
-        e->reduce_arena = arena;
-    }
+    CK(upload_tables(e, A, st));
+    std::vector<char> bn_done(e->bn_bwd.size(), 0);
     if (flags & 1) {
         // sparse gradient buffers back to all-zero: a dense memset the first time this arena is seen, the rows of the last step after that
         const bool fresh = e->sparse_arena != arena;
@@ -625,18 +685,23 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                 else res_via_copy = true;   // both want the temporary: run dx first, then recompute-free path below
             }
             if (!e->prm[o.w].grad || !e->prm[o.b].grad) return DREG_EINVAL;
+            int deferred = 0;
             if (res_via_copy) {
                 // rare (never in ResNet-50/FPN): produce dres = masked gy through a second pass after dx has been folded in
-                CK(dreg_bn3d_bwd(act(o.in), gy, act(o.out), (float*)(A + o.aux0), (float*)(A + o.aux1), dx, nullptr, e->prm[o.w].grad, e->prm[o.b].grad,
-                                 (float*)(A + e->off_coef), (float*)(A + e->off_bn_ws), x.B, V, x.C, o.relu, 1, 0, stream));
+                CK(dreg_bn3d_bwd_defer_params(act(o.in), gy, act(o.out), (float*)(A + o.aux0), (float*)(A + o.aux1), dx, nullptr, e->prm[o.w].grad, e->prm[o.b].grad,
+                                              (float*)(A + e->off_coef), (float*)(A + e->off_bn_ws), x.B, V, x.C, o.relu, 1, 0,
+                                              o.bt >= 0 ? (float*)(A + o.keep_sums) : nullptr, &deferred, stream));
+                if (deferred) bn_done[o.bt] = 1;
                 CK(commit(o.in));
                 if (o.relu) CK(dreg_relu_bwd(act(o.out), gy, A + e->off_tmp, (size_t)x.B * V * x.C, 0, 0, 0, stream));
                 else if (hipMemcpyAsync(A + e->off_tmp, gy, (size_t)x.B * V * x.C * 2, hipMemcpyDeviceToDevice, st) != hipSuccess) return DREG_ELAUNCH;
                 CK(commit(o.in2));
             } else {
                 // without a residual the ReLU mask is recomputed from x: y is not read
-                CK(dreg_bn3d_bwd(act(o.in), gy, o.in2 >= 0 ? act(o.out) : nullptr, (float*)(A + o.aux0), (float*)(A + o.aux1), dx, dres, e->prm[o.w].grad, e->prm[o.b].grad,
-                                 (float*)(A + e->off_coef), (float*)(A + e->off_bn_ws), x.B, V, x.C, o.relu, 1, 0, stream));
+                CK(dreg_bn3d_bwd_defer_params(act(o.in), gy, o.in2 >= 0 ? act(o.out) : nullptr, (float*)(A + o.aux0), (float*)(A + o.aux1), dx, dres, e->prm[o.w].grad, e->prm[o.b].grad,
+                                              (float*)(A + e->off_coef), (float*)(A + e->off_bn_ws), x.B, V, x.C, o.relu, 1, 0,
+                                              o.bt >= 0 ? (float*)(A + o.keep_sums) : nullptr, &deferred, stream));
+                if (deferred) bn_done[o.bt] = 1;
                 if (res_g && dres == (void*)(A + e->off_tmp)) { CK(commit(o.in2)); CK(commit(o.in)); }
                 else { CK(commit(o.in)); if (res_g) CK(commit(o.in2)); }
             }
@@ -648,6 +713,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
         }
     }
     CK(flush_reduce());
+    CK(flush_bn_tails(e, A, bn_done, 1, st));
     if ((flags & 2) && aux_used) {   // the caller's stream continues (optimizer) only after every parameter gradient has landed
         if (hipEventRecord(e->ev_done, e->aux) != hipSuccess || hipStreamWaitEvent(st, e->ev_done, 0) != hipSuccess) return DREG_ELAUNCH;
     }

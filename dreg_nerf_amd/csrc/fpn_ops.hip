@@ -545,6 +545,43 @@ __global__ void bn_param_grad_kernel(const float* __restrict__ sums, float* __re
     dgamma[c] = accumulate ? dgamma[c] + (float)dg : (float)dg;
     dbeta[c] = accumulate ? dbeta[c] + (float)db : (float)db;
 }
+// The two tiny cross-grid launches of every small BatchNorm (42 of the 53 layers: running statistics in the forward pass, dgamma / dbeta
+// in the backward pass) batched over the layers of a pass: one launch each instead of 28.  Same arithmetic per channel.
+struct BnTailDesc {              // 48 bytes
+    const float* a;              // running update: mean_rstd [B][C][2];   parameter gradients: sums [B][C][2]
+    const float* b;              // running update: var [B][C];            parameter gradients: unused
+    float* o0; float* o1;        // running update: running_mean / running_var;   parameter gradients: dgamma / dbeta
+    int B, V, C, block0;         // block0: first workgroup (256 channels each) of this layer in the batched launch
+};
+static_assert(sizeof(BnTailDesc) == 48, "descriptor layout is part of the ABI");
+template <int WHAT>
+__global__ void bn_tail_batched_kernel(const BnTailDesc* __restrict__ descs, int n, int block_base, float momentum, int accumulate)
+{
+    const int blk = (int)blockIdx.x + block_base;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block0 <= blk) lo = mid; else hi = mid - 1;
+    }
+    const BnTailDesc d = descs[lo];
+    const int c = (blk - d.block0) * blockDim.x + threadIdx.x;
+    if (c >= d.C) return;
+    if (WHAT == 0) {
+        float rm = d.o0[c], rv = d.o1[c];
+        for (int b = 0; b < d.B; ++b) {
+            const float mean = d.a[((size_t)b * d.C + c) * 2], vb = d.b[(size_t)b * d.C + c];
+            const float unbiased = d.V > 1 ? (float)((double)vb * d.V / (d.V - 1)) : vb;
+            rm = (1.f - momentum) * rm + momentum * mean;
+            rv = (1.f - momentum) * rv + momentum * unbiased;
+        }
+        d.o0[c] = rm; d.o1[c] = rv;
+    } else {
+        double db = 0.0, dg = 0.0;
+        for (int b = 0; b < d.B; ++b) { db += d.a[((size_t)b * d.C + c) * 2]; dg += d.a[((size_t)b * d.C + c) * 2 + 1]; }
+        d.o0[c] = accumulate ? d.o0[c] + (float)dg : (float)dg;
+        d.o1[c] = accumulate ? d.o1[c] + (float)db : (float)db;
+    }
+}
 static int g_bn_debug_skip = 0;      // measurement only (tools/ab_step.py): bit 0 / bit 1 leave out the forward / backward statistics pass (stale statistics)
 static int g_bn_small_maxv = 512;    // tuning (include/dreg_nerf_tuning.h): largest per-grid volume served by the fused kernels, 0 = never
 static inline bool bn_small_ok(int B, int V, int C, int G) { return V >= 2 && V <= g_bn_small_maxv && C % (BNS_COLS * G) == 0 && B >= 1; }
@@ -1165,23 +1202,61 @@ int dreg_bn_num_chunks(int V) { const int r = bn_rows_per_chunk(V); return (V + 
 
 // Forward BatchNorm3d over B independent grids (per-grid statistics).  x,y,res: [B,V,C] (dtype 0 bf16 / 1 fp32).
 // workspace: fp32 [B * chunks * C * 2].  scale_shift, mean_rstd: fp32 [B,C,2] outputs (saved for backward).
+static int bn3d_fwd_impl(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
+                         int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, void* stream, float* var_keep, int* deferred);
 int dreg_bn3d_fwd(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                   float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
                   int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, void* stream)
 {
+    return bn3d_fwd_impl(x, res, y, gamma, beta, running_mean, running_var, scale_shift, mean_rstd, workspace, B, V, C, eps, momentum, train, relu, dtype, stream, nullptr, nullptr);
+}
+// The same with the running-statistics update of a SMALL training-mode layer left to the caller: the per-grid variances go to var_keep
+// ([B][C] floats the caller keeps) and *deferred = 1; the caller later runs dreg_bn_running_update_batched over all such layers.
+// Large layers (their finalize kernel updates the running statistics itself) and eval mode run as dreg_bn3d_fwd: *deferred = 0.
+int dreg_bn3d_fwd_defer_update(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
+                               int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, float* var_keep, int* deferred, void* stream)
+{
+    return bn3d_fwd_impl(x, res, y, gamma, beta, running_mean, running_var, scale_shift, mean_rstd, workspace, B, V, C, eps, momentum, train, relu, dtype, stream, var_keep, deferred);
+}
+int dreg_bn_small(int B, int V, int C, int dtype) { return bn_small_ok(B, V, C, dtype == 0 ? 8 : 4) ? 1 : 0; }
+// descs_dev: n records of 48 bytes { const float* mean_rstd; const float* var; float* running_mean; float* running_var; int B, V, C, block0; }
+// with block0 = sum of ceil(C / 256) of the records before; workgroups [block_base, block_base + nblocks) run.
+int dreg_bn_running_update_batched(const void* descs_dev, int n, int block_base, int nblocks, float momentum, void* stream)
+{
+    if (n <= 0 || nblocks <= 0) return DREG_OK;
+    hipLaunchKernelGGL(bn_tail_batched_kernel<0>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const BnTailDesc*)descs_dev, n, block_base, momentum, 0);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// the same table layout with { const float* sums; unused; float* dgamma; float* dbeta; ... }
+int dreg_bn_param_grad_batched(const void* descs_dev, int n, int block_base, int nblocks, int accumulate, void* stream)
+{
+    if (n <= 0 || nblocks <= 0) return DREG_OK;
+    hipLaunchKernelGGL(bn_tail_batched_kernel<1>, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const BnTailDesc*)descs_dev, n, block_base, 0.f, accumulate);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+static int bn3d_fwd_impl(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
+                         int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, void* stream, float* var_keep, int* deferred)
+{
     hipStream_t st = (hipStream_t)stream;
+    if (deferred) *deferred = 0;
     const int G = dtype == 0 ? 8 : 4;
     if (C % G) return DREG_EINVAL;
     const int rpc = bn_rows_per_chunk(V), nch = (V + rpc - 1) / rpc;
     const int CG = C / G, slabs = (CG + 255) / 256;
     if (train && bn_small_ok(B, V, C, G)) {      // 16^3 / 8^3 / 4^3 levels: statistics + apply in one launch, running statistics in a tiny second one
         const dim3 g1(CG / BNS_COLS, B);
-        float* var = workspace;                   // [B][C] biased variances (the workspace holds >= B * chunks * C * 2 floats)
+        float* var = var_keep ? var_keep : workspace;   // [B][C] biased variances (the workspace holds >= B * chunks * C * 2 floats)
         if (dtype == 0) hipLaunchKernelGGL(bn_small_fwd_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y, gamma, beta,
                                            scale_shift, mean_rstd, var, V, C, eps, relu);
         else hipLaunchKernelGGL(bn_small_fwd_kernel<float>, g1, dim3(256), 0, st, (const float*)x, (const float*)res, (float*)y, gamma, beta,
                                 scale_shift, mean_rstd, var, V, C, eps, relu);
         DREG_LAUNCH_CHECK();
+        if (var_keep && deferred) { *deferred = 1; return DREG_OK; }
         hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, st, mean_rstd, var, running_mean, running_var, B, V, C, momentum);
         DREG_LAUNCH_CHECK();
         return DREG_OK;
@@ -1209,23 +1284,42 @@ int dreg_bn3d_fwd(const void* x, const void* res, void* y, const float* gamma, c
 // Backward of y = [relu](bn(x) [+ res]) in training mode.  dres may be null.  coef: fp32 [B,C,2] scratch.
 // y may be null when the forward had NO residual: the ReLU mask is then recomputed from x (x*scale + shift > 0), one tensor
 // read less in both passes.
+static int bn3d_bwd_impl(const void* x, const void* dy, const void* y, const float* scale_shift, const float* mean_rstd,
+                         void* dx, void* dres, float* dgamma, float* dbeta, float* coef, float* workspace,
+                         int B, int V, int C, int relu, int accumulate, int dtype, void* stream, float* sums_keep, int* deferred);
 int dreg_bn3d_bwd(const void* x, const void* dy, const void* y, const float* scale_shift, const float* mean_rstd,
                   void* dx, void* dres, float* dgamma, float* dbeta, float* coef, float* workspace,
                   int B, int V, int C, int relu, int accumulate, int dtype, void* stream)
 {
+    return bn3d_bwd_impl(x, dy, y, scale_shift, mean_rstd, dx, dres, dgamma, dbeta, coef, workspace, B, V, C, relu, accumulate, dtype, stream, nullptr, nullptr);
+}
+// The same with dgamma / dbeta of a SMALL layer left to the caller: the per-grid sums go to sums_keep ([B][C][2] floats) and
+// *deferred = 1 (dreg_bn_param_grad_batched finishes them); large layers run as dreg_bn3d_bwd: *deferred = 0.
+int dreg_bn3d_bwd_defer_params(const void* x, const void* dy, const void* y, const float* scale_shift, const float* mean_rstd,
+                               void* dx, void* dres, float* dgamma, float* dbeta, float* coef, float* workspace,
+                               int B, int V, int C, int relu, int accumulate, int dtype, float* sums_keep, int* deferred, void* stream)
+{
+    return bn3d_bwd_impl(x, dy, y, scale_shift, mean_rstd, dx, dres, dgamma, dbeta, coef, workspace, B, V, C, relu, accumulate, dtype, stream, sums_keep, deferred);
+}
+static int bn3d_bwd_impl(const void* x, const void* dy, const void* y, const float* scale_shift, const float* mean_rstd,
+                         void* dx, void* dres, float* dgamma, float* dbeta, float* coef, float* workspace,
+                         int B, int V, int C, int relu, int accumulate, int dtype, void* stream, float* sums_keep, int* deferred)
+{
     hipStream_t st = (hipStream_t)stream;
+    if (deferred) *deferred = 0;
     const int G = dtype == 0 ? 8 : 4;
     if (C % G) return DREG_EINVAL;
     const int rpc = bn_rows_per_chunk(V), nch = (V + rpc - 1) / rpc;
     const int CG = C / G, slabs = (CG + 255) / 256;
     if (bn_small_ok(B, V, C, G)) {
         const dim3 g1(CG / BNS_COLS, B);
-        float* sums = coef;                        // [B][C][2]: per-grid (sum g, sum g xhat)
+        float* sums = sums_keep ? sums_keep : coef;   // [B][C][2]: per-grid (sum g, sum g xhat)
         if (dtype == 0) hipLaunchKernelGGL(bn_small_bwd_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, scale_shift, mean_rstd,
                                            (bf16_t*)dx, (bf16_t*)dres, sums, V, C, relu);
         else hipLaunchKernelGGL(bn_small_bwd_kernel<float>, g1, dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y, scale_shift, mean_rstd,
                                 (float*)dx, (float*)dres, sums, V, C, relu);
         DREG_LAUNCH_CHECK();
+        if (sums_keep && deferred) { *deferred = 1; return DREG_OK; }
         hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, dgamma, dbeta, B, C, accumulate);
         DREG_LAUNCH_CHECK();
         return DREG_OK;

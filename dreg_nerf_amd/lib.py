@@ -63,6 +63,7 @@ SIGNATURES = {
     "dreg_conv3d_wgrad_variant": (I, [I] * 10),
     "dreg_bn_set_debug_skip": (None, [I]),
     "dreg_exec_set_fuse_stem": (None, [I]),
+    "dreg_exec_set_bn_batch_tails": (None, [I]),
     "dreg_exec_set_sparse_grads": (None, [I]),
     "dreg_conv3_halo_set_variant": (None, [I]),
     "dreg_conv3_halo_set_prof": (None, [P]),
@@ -73,6 +74,11 @@ SIGNATURES = {
     "dreg_bn_relu_maxpool_bwd": (I, [P] * 10 + [I] * 10 + [P]),
     "dreg_bn3d_fwd": (I, [P] * 10 + [I, I, I, F, F, I, I, I, P]),
     "dreg_bn3d_bwd": (I, [P] * 11 + [I, I, I, I, I, I, P]),
+    "dreg_bn_small": (I, [I, I, I, I]),
+    "dreg_bn3d_fwd_defer_update": (I, [P] * 10 + [I, I, I, F, F, I, I, I, P, P, P]),
+    "dreg_bn3d_bwd_defer_params": (I, [P] * 11 + [I, I, I, I, I, I, P, P, P]),
+    "dreg_bn_running_update_batched": (I, [P, I, I, I, F, P]),
+    "dreg_bn_param_grad_batched": (I, [P, I, I, I, I, P]),
     "dreg_maxpool3d_fwd": (I, [P, P, P] + [I] * 9 + [P]),
     "dreg_maxpool3d_bwd": (I, [P, P, P] + [I] * 9 + [P]),
     "dreg_maxpool3d_bwd_acc": (I, [P, P, P] + [I] * 10 + [P]),

@@ -184,6 +184,8 @@ class TrunkExecutor:
                 f"conv_wgrad_glds_kernel<{var // 1000},{var % 1000},{'true' if rows else 'false'},4>"     # the template arguments rocprofv3 prints
             out[(i, 2)] = (wname, f"wgrad{rows} B{B} {x[1]}x{x[2]}x{x[3]}x{x[4]} g{y[1]}x{y[2]}x{y[3]}x{cout} k{k}s{s}", fl, lo, per_row)
         out[(-1, 3)] = ("wgrad_reduce_batched_kernel", "split sums of a backward range -> torch-layout gradients", 0.0, -1, 0.0)
+        out[(-1, 4)] = ("bn_tail_batched_kernel<0>", "running statistics of the small BatchNorms of a forward pass", 0.0, -1, 0.0)
+        out[(-1, 5)] = ("bn_tail_batched_kernel<1>", "dgamma / dbeta of the small BatchNorms of a backward range", 0.0, -1, 0.0)
         return out
 
     # ------------------------------------------------------------------ per-step calls

@@ -142,6 +142,23 @@ int dreg_bn3d_fwd(const void* x, const void* res, void* y, const float* gamma, c
 int dreg_bn3d_bwd(const void* x, const void* dy, const void* y, const float* scale_shift, const float* mean_rstd,
                   void* dx, void* dres, float* dgamma, float* dbeta, float* coef, float* workspace,
                   int B, int V, int C, int relu, int accumulate, int dtype, void* stream);
+/* The two launches of a SMALL BatchNorm (one grid's column slab per workgroup; dreg_bn_small says which shapes) with the tiny cross-grid
+ * tail left to the caller, who batches it over the layers of a pass: the forward keeps the per-grid variances in var_keep [B][C], the
+ * backward the per-grid sums in sums_keep [B][C][2], and *deferred = 1.  For other shapes (and eval mode) they run as dreg_bn3d_fwd /
+ * dreg_bn3d_bwd and *deferred = 0.  The tables are n records of 48 bytes
+ *   { const float* a; const float* b; float* o0; float* o1; int B, V, C, block0; }
+ * (running update: a = mean_rstd, b = var_keep, o0 / o1 = running_mean / running_var;  parameter gradients: a = sums_keep, b unused,
+ * o0 / o1 = dgamma / dbeta) in device memory, block0 = sum of ceil(C / 256) over the records before; workgroups
+ * [block_base, block_base + nblocks) of the table run.  Same arithmetic per channel as the unbatched launches (results bit-identical). */
+int dreg_bn_small(int B, int V, int C, int dtype);
+int dreg_bn3d_fwd_defer_update(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
+                               int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, float* var_keep, int* deferred, void* stream);
+int dreg_bn3d_bwd_defer_params(const void* x, const void* dy, const void* y, const float* scale_shift, const float* mean_rstd,
+                               void* dx, void* dres, float* dgamma, float* dbeta, float* coef, float* workspace,
+                               int B, int V, int C, int relu, int accumulate, int dtype, float* sums_keep, int* deferred, void* stream);
+int dreg_bn_running_update_batched(const void* descs_dev, int n, int block_base, int nblocks, float momentum, void* stream);
+int dreg_bn_param_grad_batched(const void* descs_dev, int n, int block_base, int nblocks, int accumulate, void* stream);
 
 /* Stem fused (resnet3d.py:118-123: conv1 -> bn1 -> relu -> maxpool, bf16): pooled = maxpool3(relu(bn(x))) and its backward without the
  * full-resolution activation / gradient in between; pooled values and arg-max taps are bit-identical to dreg_bn3d_fwd + dreg_maxpool3d_fwd. */

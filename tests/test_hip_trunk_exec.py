@@ -226,3 +226,39 @@ def test_row_cleared_gradient_buffers_equal_memset_ones_over_changing_active_set
     a, b = run(True), run(False)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_batched_batchnorm_tails_change_nothing():
+    """The running-statistics / dgamma-dbeta launches of the small BatchNorms batched per pass (one launch each) against one launch
+    per layer: same arithmetic per channel, so gradients and running statistics are bit-identical."""
+    from dreg_nerf_amd import lib as L
+    lib = L.load()
+    m, opt = _model(2)
+    res = 64
+    grids, _ = _grids(res, 2)
+    x = NeRFRegTr.pack_grids(grids, torch.bfloat16)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    go = None
+    got = []
+    try:
+        for batched in (0, 1):
+            lib.dreg_exec_set_bn_batch_tails(batched)
+            m.__dict__.pop("_trunk_cache", None)       # read when an executor is created
+            m.load_state_dict(sd0)
+            ops.bump_weight_generation()
+            m.native_trunk = True
+            for _ in range(2):                          # the second pass accumulates on top of the first
+                if _ == 0:
+                    opt.zero_grad()
+                p1 = m.fpn(x, None)
+                if go is None:
+                    go = torch.randn(p1.shape, generator=torch.Generator().manual_seed(4)).to(DEV).bfloat16()
+                p1.backward(go)
+            got.append((opt.flat_g.clone(), {k: v.clone() for k, v in m.state_dict().items() if "running" in k}))
+    finally:
+        lib.dreg_exec_set_bn_batch_tails(1)
+        m.__dict__.pop("_trunk_cache", None)
+    assert torch.isfinite(got[1][0]).all() and got[1][0].abs().sum() > 0
+    assert torch.equal(got[0][0], got[1][0])
+    for k in got[0][1]:
+        assert torch.equal(got[0][1][k], got[1][1][k]), k
