@@ -45,6 +45,7 @@ class LayerNormFn(torch.autograd.Function):
                                        n, 256, 1e-5, L.dt_of(y), L.stream()), "dreg_layernorm_fwd")
         ctx.save_for_backward(x, g, stats)
         ctx.b_ref = b if b.is_leaf else None
+        ctx.pe_dtype = pe.dtype if (pe is not None and pe.requires_grad) else None   # learned position embedding: d pe = gy
         ctx.set_materialize_grads(False)
         return (y, x.view_as(x)) if with_residual else y
 
@@ -56,6 +57,7 @@ class LayerNormFn(torch.autograd.Function):
         if gy is None:                      # only the residual branch carried a gradient
             return gres, None, None, None, None, None
         gy = gy.contiguous()
+        gpe = gy.to(ctx.pe_dtype) if ctx.pe_dtype is not None else None
         if gres is not None:
             gres = gres.contiguous().float()
         dx = torch.empty_like(x)
@@ -68,7 +70,7 @@ class LayerNormFn(torch.autograd.Function):
         ws = torch.empty(lib.dreg_layernorm_bwd_workspace_bytes(n) // 4 + 4, dtype=torch.float32, device=x.device)
         L.check(lib.dreg_layernorm_bwd_add(L.ptr(x), L.ptr(gy), L.ptr(g.detach()), L.ptr(stats), L.ptr(dx), L.ptr(gres), L.ptr(dg), L.ptr(db),
                                            L.ptr(ws), n, 256, L.dt_of(gy), int(direct), L.stream()), "dreg_layernorm_bwd_add")
-        return dx, (None if direct else dg), (None if direct else db), None, None, None
+        return dx, (None if direct else dg), (None if direct else db), gpe, None, None
 
 
 def layer_norm(x, w, b, pe=None, out_dtype=None):

@@ -47,8 +47,22 @@ def resnet_spec(prefix: str = ALIAS_SRC) -> "OrderedDict[str, Tuple[tuple, str]]
     return spec
 
 
-def regtr_spec() -> "OrderedDict[str, Tuple[tuple, str]]":
-    """key -> (shape, kind) in reference state_dict order (both ResNet aliases listed)."""
+POS_EMBED_ALIAS = "correspondence_decoder.pos_embed."   # the decoder holds the model's pos_embed module (nerf_regtr.py:110,265)
+POS_EMBED_MLP = (3, 32, 64, 128, 256)                    # PositionEmbeddingLearned (position_embedding.py:60-74): Linear+ReLU x4, Linear
+
+
+def _pos_embed_spec(prefix: str, d_model: int):
+    out = OrderedDict()
+    dims = POS_EMBED_MLP + (d_model,)
+    for i in range(5):
+        out[prefix + f"mlp.{2 * i}.weight"] = ((dims[i + 1], dims[i]), "linear")
+        out[prefix + f"mlp.{2 * i}.bias"] = ((dims[i + 1],), "bias")
+    return out
+
+
+def regtr_spec(pos_emb_type: str = "sine") -> "OrderedDict[str, Tuple[tuple, str]]":
+    """key -> (shape, kind) in reference state_dict order (both ResNet aliases listed; with the learned position embedding also
+    both names of its MLP, nerf_regtr.py:87-90,110)."""
     spec = OrderedDict()
     spec.update(resnet_spec(ALIAS_SRC))
     spec.update(resnet_spec(ALIAS_DST))
@@ -61,6 +75,8 @@ def regtr_spec() -> "OrderedDict[str, Tuple[tuple, str]]":
     for i in (1, 2, 3, 4):
         spec[q + f"upsample_transform_{i}.weight"] = ((256, 256, 3, 3, 3), "conv")
         spec[q + f"upsample_transform_{i}.bias"] = ((256,), "bias")
+    if pos_emb_type != "sine":
+        spec.update(_pos_embed_spec("pos_embed.", 256))
     for l in range(6):
         p = f"transformer_encoder.layers.{l}."
         for att in ("self_attn", "cross_attn"):
@@ -78,6 +94,8 @@ def regtr_spec() -> "OrderedDict[str, Tuple[tuple, str]]":
     spec["transformer_encoder.norm.weight"] = ((256,), "ln_weight")
     spec["transformer_encoder.norm.bias"] = ((256,), "bias")
     p = "correspondence_decoder."
+    if pos_emb_type != "sine":
+        spec.update(_pos_embed_spec(POS_EMBED_ALIAS, 256))
     spec[p + "q_norm.weight"] = ((256,), "ln_weight")
     spec[p + "q_norm.bias"] = ((256,), "bias")
     spec[p + "q_proj.weight"] = ((256, 256), "linear")
@@ -110,13 +128,15 @@ def _fill(key: str, shape: tuple, kind: str, seed: int) -> torch.Tensor:
     return 0.05 * n  # biases, bn_mean
 
 
-def synth_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
-    """Deterministic, key-seeded fill of every entry (fp32, CPU).  Both ResNet aliases point
-    at the same tensors, as in the reference module."""
+def synth_state_dict(seed: int = 0, pos_emb_type: str = "sine") -> Dict[str, torch.Tensor]:
+    """Deterministic, key-seeded fill of every entry (fp32, CPU).  Both ResNet aliases (and both names of a learned position
+    embedding) point at the same tensors, as in the reference module."""
     sd = OrderedDict()
-    for key, (shape, kind) in regtr_spec().items():
+    for key, (shape, kind) in regtr_spec(pos_emb_type).items():
         if key.startswith(ALIAS_DST):
             sd[key] = sd[ALIAS_SRC + key[len(ALIAS_DST):]]
+        elif key.startswith(POS_EMBED_ALIAS):
+            sd[key] = sd["pos_embed." + key[len(POS_EMBED_ALIAS):]]
         else:
             sd[key] = _fill(key, shape, kind, seed)
     return sd
@@ -128,6 +148,8 @@ def clone_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     for key, v in sd.items():
         if key.startswith(ALIAS_DST):
             out[key] = out[ALIAS_SRC + key[len(ALIAS_DST):]]
+        elif key.startswith(POS_EMBED_ALIAS):
+            out[key] = out["pos_embed." + key[len(POS_EMBED_ALIAS):]]
         else:
             out[key] = v.clone()
     return out

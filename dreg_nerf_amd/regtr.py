@@ -26,7 +26,7 @@ class _Node(nn.Module):
 def _build_tree(root: nn.Module, spec, init_from=None):
     made = {}
     for key, (shape, kind) in spec.items():
-        if key.startswith(params.ALIAS_DST):
+        if key.startswith(params.ALIAS_DST) or key.startswith(params.POS_EMBED_ALIAS):
             continue
         parts = key.split(".")
         mod = root
@@ -48,6 +48,9 @@ def _build_tree(root: nn.Module, spec, init_from=None):
     reordered = {"resnet": mods["resnet"]}
     reordered.update({k: v for k, v in mods.items() if k != "resnet"})
     fp._modules = reordered
+    if hasattr(root, "pos_embed"):   # learned embedding: the decoder's first member is the same module object (nerf_regtr.py:110,265)
+        cd = root.correspondence_decoder
+        cd._modules = {"pos_embed": root.pos_embed, **cd._modules}
 
 
 def _reset_parameters(model: nn.Module, spec):
@@ -58,7 +61,7 @@ def _reset_parameters(model: nn.Module, spec):
     bufs = dict(model.named_buffers())
     with torch.no_grad():
         for key, (shape, kind) in spec.items():
-            if key.startswith(params.ALIAS_DST):
+            if key.startswith(params.ALIAS_DST) or key.startswith(params.POS_EMBED_ALIAS):
                 continue
             if kind == "conv":
                 nn.init.xavier_normal_(sd[key])
@@ -88,8 +91,10 @@ class NeRFRegTr(nn.Module):
     def __init__(self, pos_emb_type: str = "sine", pos_emb_dim: int = 256, pos_emb_scaling: float = 1.0,
                  num_downsample: int = 6, precision: str = "bf16"):
         super().__init__()
-        if pos_emb_type != "sine" or pos_emb_dim != 256:
-            raise NotImplementedError("only the reference default (sine, 256) position embedding is built")
+        if pos_emb_dim != 256:
+            raise NotImplementedError("the attention / LayerNorm kernels are built for the reference's model width 256")
+        # 'sine' (default) or anything else = the learned MLP, as the reference's constructor decides (nerf_regtr.py:87-90)
+        self.pos_emb_type = "sine" if pos_emb_type == "sine" else "learned"
         self.num_downsample = num_downsample
         self.pos_emb_scaling = pos_emb_scaling
         self.precision = precision
@@ -101,7 +106,7 @@ class NeRFRegTr(nn.Module):
         # Run the data-dependent geometry phase of forward_batch on its own high-priority stream (see forward_batch)
         self.async_geometry = True
         self.skip_empty_stem_rows = True   # stem output rows whose receptive field is all zero are written as zeros, not computed
-        self._spec = params.regtr_spec()
+        self._spec = params.regtr_spec(self.pos_emb_type)
         _build_tree(self, self._spec)
         _reset_parameters(self, self._spec)
 
@@ -127,6 +132,21 @@ class NeRFRegTr(nn.Module):
         out = super().load_state_dict(*a, **kw)
         ops.bump_weight_generation()   # in-place copies keep data_ptr(): cached bf16 weight packs (ops, trunk executor) are stale now
         return out
+
+    # ------------------------------------------------------------------ A5: position embedding of the point coordinates
+    def position_embedding(self, xyz: torch.Tensor) -> torch.Tensor:
+        """fp32 [R,3] -> fp32 [R,256] (nerf_regtr.py:170): the sine embedding with the configured coordinate scale
+        (position_embedding.py:24-53), or the learned MLP 3-32-64-128-256-256 (position_embedding.py:56-76; five small plain GEMMs:
+        rocBLAS through torch, its gradient arrives through the LayerNorm / decoder additions)."""
+        if self.pos_emb_type == "sine":
+            return A.posenc_sine(xyz, 256, 1000.0, self.pos_emb_scaling)
+        P = self._P()
+        h = xyz.float()
+        for i in range(5):
+            h = F.linear(h, P[f"pos_embed.mlp.{2 * i}.weight"], P[f"pos_embed.mlp.{2 * i}.bias"])
+            if i < 4:
+                h = torch.relu(h)
+        return h
 
     # ------------------------------------------------------------------ A1/A2: FPN3D over a batch of grids
     def _fpn_program(self, O, x, rows, nbt, train: bool = True):
@@ -384,7 +404,7 @@ class NeRFRegTr(nn.Module):
         feat_l = [T.apply_subsample_plan(plans[i], f) for i, f in enumerate(feats.split(sizes))]
         tab = A.ProblemTable(segs, dev)
         xyz_all = torch.cat(pts_l) if len(pts_l) > 1 else pts_l[0]
-        cond, corr, ov = T.encode_decode_batched(P, torch.cat(feat_l) if len(feat_l) > 1 else feat_l[0], xyz_all, tab)
+        cond, corr, ov = T.encode_decode_batched(P, torch.cat(feat_l) if len(feat_l) > 1 else feat_l[0], xyz_all, tab, self.position_embedding)
         outs = []
         poses = A.weighted_kabsch_pairs(xyz_all, corr, ov, tab)   # [P,6,3,4]: every (pair, layer) solve in one launch
         # the batched view of the same results (row space of all pairs) for the fused training losses

@@ -135,12 +135,12 @@ def encoder_layer_batched(P, p, x, pe, tab):
     return A.linear(h, P[p + ".linear2.weight"], P[p + ".linear2.bias"], residual=xr, out_f32=True)
 
 
-def encode_decode_batched(P, feats, xyz, tab):
+def encode_decode_batched(P, feats, xyz, tab, pos_embed=None):
     """feats fp32 [R,256], xyz fp32 [R,3] (rows ordered pair by pair, src then tgt), tab: ProblemTable.
     Returns (cond fp32 [6,R,256], corr fp32 [6,R,3], overlap fp32 [6,R,1])."""
     x = feats.float().contiguous()
     xyz = xyz.contiguous()
-    pe = A.posenc_sine(xyz)
+    pe = A.posenc_sine(xyz) if pos_embed is None else pos_embed(xyz).contiguous()   # NeRFRegTr.position_embedding
     outs = []
     for l in range(N_LAYERS):
         x = encoder_layer_batched(P, f"transformer_encoder.layers.{l}", x, pe, tab)

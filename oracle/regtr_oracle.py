@@ -230,6 +230,16 @@ def posenc_sine(xyz: torch.Tensor, d_model: int = D_MODEL, temperature: float = 
     return F.pad(emb, (0, d_model - npf * n_dim))
 
 
+def posenc_learned(sd: SD, xyz: torch.Tensor, p: str = "pos_embed") -> torch.Tensor:
+    """position_embedding.py:56-76: Linear(3,32) ReLU Linear(32,64) ReLU Linear(64,128) ReLU Linear(128,256) ReLU Linear(256,d)."""
+    h = xyz
+    for i in range(5):
+        h = _linear(h, sd[f"{p}.mlp.{2 * i}.weight"], sd[f"{p}.mlp.{2 * i}.bias"])
+        if i < 4:
+            h = torch.relu(h)
+    return h
+
+
 # --------------------------------------------------------------------------- A6
 def _ln(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
     return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], LN_EPS)

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from dreg_nerf_amd import attn_ops as A, lib as L, params  # noqa: E402
+from dreg_nerf_amd import attn_ops as A, lib as L, ops, params  # noqa: E402
 from dreg_nerf_amd import transformer_ops as T  # noqa: E402
 from oracle import regtr_oracle as O  # noqa: E402
 
@@ -195,6 +195,42 @@ def test_transformer_decoder_vs_golden(golden_dir):
     np.testing.assert_allclose(s_corr.cpu().numpy(), g["s_corr"], atol=1e-4)
     np.testing.assert_allclose(t_corr.cpu().numpy(), g["t_corr"], atol=1e-4)
     np.testing.assert_allclose(s_ov.cpu().numpy(), g["s_ov"], atol=1e-5)
+
+
+def test_learned_position_embedding_vs_golden(golden_dir):
+    """NeRFRegTr(pos_emb_type != 'sine') (nerf_regtr.py:87-90): the learned MLP embedding through the batched encoder + decoder,
+    forward and the gradients that reach its parameters through the LayerNorm(+pe) kernels, against the reference's vectors; and
+    the coordinate scale of the sine embedding (position_embedding.py:28,43)."""
+    from dreg_nerf_amd.regtr import NeRFRegTr
+    g = np.load(os.path.join(golden_dir, "pos_embed.npz"))
+    m = NeRFRegTr("learned", 256, 1.0, precision="fp32")
+    assert list(m.state_dict().keys()) == list(params.regtr_spec("learned").keys())
+    m.load_state_dict(params.synth_state_dict(0, "learned"))
+    m = m.to(DEV).train()
+    A.set_precision("fp32")
+    s_xyz, t_xyz = torch.from_numpy(g["s_xyz"]).to(DEV), torch.from_numpy(g["t_xyz"]).to(DEV)
+    ns, nt = s_xyz.shape[0], t_xyz.shape[0]
+    half = NeRFRegTr("sine", 256, 0.5, precision="fp32")
+    np.testing.assert_allclose(half.position_embedding(s_xyz).cpu().numpy(), g["sine_scale_half"], atol=2e-5)
+    xyz = torch.cat([s_xyz, t_xyz])
+    np.testing.assert_allclose(m.position_embedding(xyz)[:ns].detach().cpu().numpy(), g["s_pe"], atol=1e-5)
+    feats = torch.cat([torch.from_numpy(g["s_f"]), torch.from_numpy(g["t_f"])]).to(DEV)
+    tab = A.ProblemTable([(ns, nt)], DEV)
+    cond, corr, ov = T.encode_decode_batched(m._P(), feats, xyz, tab, m.position_embedding)
+    np.testing.assert_allclose(cond[:, :ns].detach().cpu().numpy(), g["s_cond"], atol=1e-4)
+    np.testing.assert_allclose(cond[:, ns:].detach().cpu().numpy(), g["t_cond"], atol=1e-4)
+    np.testing.assert_allclose(corr.detach().cpu().numpy(), g["corr"], atol=1e-4)
+    np.testing.assert_allclose(ov.detach().cpu().numpy(), g["ov"], atol=1e-5)
+    loss = (corr * torch.from_numpy(g["w_corr"]).to(DEV)).sum() + (ov * torch.from_numpy(g["w_ov"]).to(DEV)).sum()
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), atol=2e-3)
+    loss.backward()
+    ops.flush_wgrad_reduce()
+    torch.cuda.synchronize()
+    P = dict(m.named_parameters())
+    for i in range(5):
+        for kind, key in (("weight", f"g_w{i}"), ("bias", f"g_b{i}")):
+            got = P[f"pos_embed.mlp.{2 * i}.{kind}"].grad.cpu().numpy()
+            np.testing.assert_allclose(got, g[key], atol=1e-3 * max(1.0, float(np.abs(g[key]).max())))
 
 
 def test_adamw_and_grad_norm_match_torch():

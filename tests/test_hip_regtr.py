@@ -165,3 +165,24 @@ def test_full_size_batch_invariance_128():
     # the trilinear-gather outputs are bit-identical; the voxel means / attention see the same values in the same order
     assert torch.equal(alone["pose"], both["pose"])
     assert torch.equal(alone["src_overlap"][0], both["src_overlap"][0])
+
+
+def test_training_step_with_learned_position_embedding():
+    """The non-default embedding (nerf_regtr.py:89-90) in the benchmarked configuration (bf16, executor, fused losses, flat AdamW):
+    its parameters are part of the flat buffers, get gradients through the LayerNorm(+pe) kernels and move."""
+    from dreg_nerf_amd.train_step import TrainStep
+    torch.manual_seed(5)
+    m = NeRFRegTr("learned", 256, 1.0, precision="bf16").to("cuda").train()
+    ts = TrainStep(m)
+    d = synth.shell_pair(64, 1, 2, pose=synth.fixed_pose())
+    batch = [{k: (v.to("cuda") if torch.is_tensor(v) else v) for k, v in d.items()}]
+    w0 = {k: v.detach().clone() for k, v in m.named_parameters() if k.startswith("pos_embed.")}
+    assert len(w0) == 10
+    losses = [float(ts.step(batch)["losses"]["total"]) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)), losses
+    for k, v in m.named_parameters():
+        if k.startswith("pos_embed."):
+            assert torch.isfinite(v).all() and not torch.equal(v.detach(), w0[k]), k
+    sd = m.state_dict()
+    assert sd["correspondence_decoder.pos_embed.mlp.0.weight"].data_ptr() == sd["pos_embed.mlp.0.weight"].data_ptr()

@@ -50,6 +50,35 @@ def test_transformer_decoder(golden_dir):
     np.testing.assert_allclose(t_ov.numpy(), g["t_ov"], atol=2e-6)
 
 
+def test_non_default_position_embeddings(golden_dir):
+    """nerf_regtr.py:87-90: the learned MLP embedding (through encoder + decoder, with the gradients of its parameters) and the
+    sine embedding with a coordinate scale, against vectors of the reference (tools/make_golden.py pos_embed)."""
+    g = _load(golden_dir, "pos_embed.npz")
+    spec = params.regtr_spec("learned")
+    assert [k for k in spec if "pos_embed" in k][:2] == ["pos_embed.mlp.0.weight", "pos_embed.mlp.0.bias"]
+    sd = params.synth_state_dict(0, "learned")
+    assert sd["correspondence_decoder.pos_embed.mlp.8.weight"] is sd["pos_embed.mlp.8.weight"]
+    for i in range(5):
+        sd[f"pos_embed.mlp.{2 * i}.weight"].requires_grad_(True)
+        sd[f"pos_embed.mlp.{2 * i}.bias"].requires_grad_(True)
+    s_xyz, t_xyz = torch.from_numpy(g["s_xyz"]), torch.from_numpy(g["t_xyz"])
+    np.testing.assert_allclose(O.posenc_sine(s_xyz, scale=0.5).numpy(), g["sine_scale_half"], atol=2e-6)
+    s_pe, t_pe = O.posenc_learned(sd, s_xyz), O.posenc_learned(sd, t_xyz)
+    np.testing.assert_allclose(s_pe.detach().numpy(), g["s_pe"], atol=1e-6)
+    sc, tc = O.cross_encoder(sd, torch.from_numpy(g["s_f"]), torch.from_numpy(g["t_f"]), s_pe, t_pe)
+    s_corr, t_corr, s_ov, t_ov = O.corr_decoder(sd, sc, tc, s_xyz, t_xyz, s_pe, t_pe)
+    corr, ov = torch.cat([s_corr, t_corr], dim=1), torch.cat([s_ov, t_ov], dim=1)
+    np.testing.assert_allclose(sc.detach().numpy(), g["s_cond"], atol=2e-5)
+    np.testing.assert_allclose(corr.detach().numpy(), g["corr"], atol=2e-5)
+    np.testing.assert_allclose(ov.detach().numpy(), g["ov"], atol=2e-6)
+    loss = (corr * torch.from_numpy(g["w_corr"])).sum() + (ov * torch.from_numpy(g["w_ov"])).sum()
+    loss.backward()
+    for i in range(5):
+        gw = sd[f"pos_embed.mlp.{2 * i}.weight"].grad.numpy()
+        np.testing.assert_allclose(gw, g[f"g_w{i}"], atol=2e-4 * max(1.0, float(np.abs(g[f"g_w{i}"]).max())))
+        np.testing.assert_allclose(sd[f"pos_embed.mlp.{2 * i}.bias"].grad.numpy(), g[f"g_b{i}"], atol=2e-4 * max(1.0, float(np.abs(g[f"g_b{i}"]).max())))
+
+
 def test_trilinear_gather_direct_matches_interpolate():
     g = torch.Generator().manual_seed(3)
     p1 = torch.randn(1, 8, 5, 6, 7, generator=g)

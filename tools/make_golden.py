@@ -368,5 +368,55 @@ def train_golden(nr, sd, res: int, name: str, with_fp64: bool = True):
     print(name, "done", {k: float(v) for k, v in losses.items()}, gnorm, total_norm)
 
 
+def pos_embed_golden():
+    """Non-default position embeddings (nerf_regtr.py:87-90): the learned MLP through the whole transformer + decoder, forward
+    and the gradients of its parameters, and the sine embedding with a coordinate scale != 1.
+    usage: python tools/make_golden.py pos_embed"""
+    nr = import_reference()
+    from conerf.register.position_embedding import PositionEmbeddingCoordsSine
+    sd = params.synth_state_dict(0, "learned")
+    m = nr.NeRFRegTr("learned", 256, 1.0)
+    spec = params.regtr_spec("learned")
+    assert list(m.state_dict().keys()) == list(spec.keys()), "state_dict key order differs from params.regtr_spec('learned')"
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == spec[k][0], k
+    m.load_state_dict(params.clone_state_dict(sd), strict=True)
+    m.eval()
+    g = torch.Generator().manual_seed(31)
+    ns, nt = 70, 55
+    s_xyz = (torch.rand(ns, 3, generator=g) - 0.5) * 2
+    t_xyz = (torch.rand(nt, 3, generator=g) - 0.5) * 2
+    s_f = torch.randn(ns, 256, generator=g)
+    t_f = torch.randn(nt, 256, generator=g)
+    w_corr = torch.randn(6, ns + nt, 3, generator=g)
+    w_ov = torch.randn(6, ns + nt, 1, generator=g)
+    s_pe, t_pe = m.pos_embed(s_xyz), m.pos_embed(t_xyz)
+    sc, tc = m.transformer_encoder(
+        src=s_f[:, None], tgt=t_f[:, None],
+        src_key_padding_mask=torch.zeros(1, ns, dtype=torch.bool),
+        tgt_key_padding_mask=torch.zeros(1, nt, dtype=torch.bool),
+        src_pos=s_pe[:, None], tgt_pos=t_pe[:, None])
+    scl, tcl, sol, tol = m.correspondence_decoder(sc, tc, [s_xyz], [t_xyz])
+    corr = torch.cat([scl[0], tcl[0]], dim=1)      # [6, ns+nt, 3]
+    ov = torch.cat([sol[0], tol[0]], dim=1)        # [6, ns+nt, 1]
+    loss = (corr * w_corr).sum() + (ov * w_ov).sum()
+    loss.backward()
+    out = dict(s_xyz=s_xyz.numpy(), t_xyz=t_xyz.numpy(), s_f=s_f.numpy(), t_f=t_f.numpy(), w_corr=w_corr.numpy(), w_ov=w_ov.numpy(),
+               s_pe=s_pe.detach().numpy(), t_pe=t_pe.detach().numpy(),
+               s_cond=sc[:, :, 0].detach().numpy(), t_cond=tc[:, :, 0].detach().numpy(),
+               corr=corr.detach().numpy(), ov=ov.detach().numpy(), loss=loss.detach().numpy())
+    for i in range(5):
+        out[f"g_w{i}"] = m.pos_embed.mlp[2 * i].weight.grad.numpy()
+        out[f"g_b{i}"] = m.pos_embed.mlp[2 * i].bias.grad.numpy()
+    with torch.no_grad():
+        out["sine_scale_half"] = PositionEmbeddingCoordsSine(3, 256, scale=0.5)(s_xyz).numpy()
+    np.savez(os.path.join(OUT, "pos_embed.npz"), **out)
+    print("pos_embed done", float(loss))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "pos_embed":
+        pos_embed_golden()
+    else:
+        main()
+        pos_embed_golden()
