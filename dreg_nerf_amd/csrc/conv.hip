@@ -653,15 +653,20 @@ template <int GP> __device__ __forceinline__ int wg_swz(int row) {   // rows of 
 // moves 64 KB for 8.4 MFLOP instead of 32 KB for 2.1 MFLOP: the 128-square tile needs ~62 B/clk of direct-to-LDS traffic at the MFMA
 // roof, which is the whole L2 -> LDS path of a CU (tools/hw_probe/l2_stream.hip: 129 GB/s per CU) and the reason it stops at 0.7 PFLOP/s.
 // ABL (tools/bench_wgrad.py --ablate, wrong results): 1 no MFMA, 2 no fragment reads, 3 no direct-to-LDS loads — what bounds the loop
-template <int BM, int BNC, bool ROWS, int NW = 4, int ABL = 0, int KV_ = 64>
+// KV_ / NS_: voxels per stage and LDS ring depth.  The loop is bound by what the ring keeps in flight (a stage is requested one
+// iteration before it is consumed; the L2 / HBM gather latency is ~2 us under load): (NS-1) stages x workgroups per CU.  64-voxel
+// stages x 2 keep 64 KB per CU in flight for either tile; 32-voxel stages x 4 or 5 keep 96 / 128 KB in the same LDS footprint.
+// PIPE: the fragment reads of the next group of MFMAs are issued before the current group's MFMAs (two register slots per operand),
+// so the LDS read phase of a wave runs under its own MFMAs instead of in front of them; same products, same accumulation order.
+template <int BM, int BNC, bool ROWS, int NW = 4, int ABL = 0, int KV_ = 64, int NS_ = 2, int PIPE = 0>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
     const bf16_t* __restrict__ gout, const bf16_t* __restrict__ in, float* __restrict__ part,
     ConvGeom g, int tilesCol, int tiles, int nsplit, uint32_t vox_per_split, uint32_t gout_bytes, uint32_t in_bytes,
-    const int* __restrict__ rowlist, uint32_t nrows, const uint8_t* __restrict__ rowocc = nullptr)
+    const int* __restrict__ rowlist, uint32_t nrows, const uint8_t* __restrict__ rowocc = nullptr, int rows_fast = 0)
 {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
-    constexpr int KV = KV_, NS = 2;                       // voxels per stage, LDS ring depth (prefetch distance NS-1)
+    constexpr int KV = KV_, NS = NS_;                     // voxels per stage, LDS ring depth (prefetch distance NS-1)
     constexpr int RSA = BM * 2, RSB = BNC * 2;
     constexpr int GPA = RSA / 16, GPB = RSB / 16;          // granules per row (16 or 8)
     constexpr int A_BYTES = KV * RSA, B_BYTES = KV * RSB, STAGE = A_BYTES + B_BYTES;
@@ -688,10 +693,23 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
     const uint32_t v_end = min(v_begin + vox_per_split, nrows);   // positions in the row space (dense: voxels; sparse: list entries)
     // ROWS: this block's slice of the row list is copied to LDS up front (plain loads inside the K loop would make hipcc
     // drain the DMA queue with vmcnt(0) every step); it sits behind the NS stages.
+    // rows_fast (stride 1, output volume = input volume: the two head convolutions): the slice also keeps every row's (z, y, x) packed
+    // in 30 bits.  The gathered voxel of output voxel m at tap d is m + a lane constant, and the bounds test reads the packed
+    // coordinates: no voxel decode (three magic divisions) per load in the K loop — a third of the loop's VALU work.
     const int* srow = reinterpret_cast<const int*>(smem + NS * STAGE);
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+    const u32x2_t* srow2 = reinterpret_cast<const u32x2_t*>(smem + NS * STAGE);   // rows_fast: (row, packed z|y|x) pairs
     if constexpr (ROWS) {
         int* w_ = reinterpret_cast<int*>(smem + NS * STAGE);
-        for (uint32_t i = v_begin + t; i < v_end; i += NW * 64) w_[i - v_begin] = rowlist[i];
+        u32x2_t* w2_ = reinterpret_cast<u32x2_t*>(smem + NS * STAGE);
+        for (uint32_t i = v_begin + t; i < v_end; i += NW * 64) {
+            const int m = rowlist[i];
+            if (rows_fast) {
+                int b, z, y, x;
+                vox_decode((uint32_t)m, g, b, z, y, x);
+                w2_[i - v_begin] = (u32x2_t){(uint32_t)m, ((uint32_t)z << 20) | ((uint32_t)y << 10) | (uint32_t)x};
+            } else w_[i - v_begin] = m;
+        }
         __syncthreads();
     }
     const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)gout, 0, gout_bytes, 0x00020000);
@@ -737,6 +755,13 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
     int al_dz[IB], al_dy[IB], al_x[IB];
     uint32_t al_off[IB];
     uint32_t al_l[IB];
+    if (ROWS && rows_fast) {
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {    // the same registers: tap offsets per axis and the byte offset of the tap relative to the output voxel
+            al_dz[i] = g.off + b_dz[i]; al_dy[i] = g.off + b_dy[i]; al_x[i] = g.off + b_dx[i];
+            al_off[i] = (uint32_t)((((al_dz[i] * g.Hi + al_dy[i]) * g.Wi + al_x[i]) * g.Cin + b_ci[i]) * 2);
+        }
+    }
     if (aligned) {
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
@@ -754,6 +779,38 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
     auto issue = [&](uint32_t v0, int buf) {
         char* sA = smem + buf * STAGE;
         char* sB = sA + A_BYTES;
+        if constexpr (ROWS) {
+            if (rows_fast) {
+                // every LDS read of the stage first (clamped index: no branch), then the direct-to-LDS loads: the reads' latency is paid
+                // once per stage, not once per load (the compiler keeps an LDS read behind every direct-to-LDS load issued before it)
+                uint32_t am[IA];
+                u32x2_t bm[IB];
+                const uint32_t last = v_end - 1 - v_begin;
+#pragma unroll
+                for (int i = 0; i < IA; ++i) am[i] = srow2[min(v0 + (wave * IA + i) * RPA + ra - v_begin, last)][0];
+#pragma unroll
+                for (int i = 0; i < IB; ++i) bm[i] = srow2[min(v0 + ((wave * IB) + i) * RPB + rb - v_begin, last)];
+#pragma unroll
+                for (int i = 0; i < IA; ++i) {
+                    const int j = wave * IA + i;
+                    const uint32_t vi = v0 + j * RPA + ra;
+                    const uint32_t voff = (vi < v_end) ? am[i] * (uint32_t)(g.Cout * 2) + a_col[i] : OOB;
+                    if constexpr (ABL != 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(sA + j * 1024), 16, (int)voff, 0, 0, 0);
+                    else asm volatile("" :: "v"(voff));
+                }
+#pragma unroll
+                for (int i = 0; i < IB; ++i) {
+                    const int j = wave * IB + i;
+                    const uint32_t vi = v0 + j * RPB + rb, p = bm[i][1];
+                    const bool v = vi < v_end && b_tv[i] && (unsigned)((int)(p >> 20) + al_dz[i]) < (unsigned)g.Di &&
+                                   (unsigned)((int)((p >> 10) & 1023u) + al_dy[i]) < (unsigned)g.Hi && (unsigned)((int)(p & 1023u) + al_x[i]) < (unsigned)g.Wi;
+                    const uint32_t voff = v ? bm[i][0] * (uint32_t)(g.Cin * 2) + al_off[i] : OOB;
+                    if constexpr (ABL != 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sB + j * 1024), 16, (int)voff, 0, 0, 0);
+                    else asm volatile("" :: "v"(voff));
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
             const int j = wave * IA + i;
@@ -780,9 +837,9 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
             }
             return;
         }
+        const uint32_t mb = v0 + (wave * IB) * RPB + rb;
         // one full voxel decode per K step (row of instruction 0); the wave's other rows are +RPB, +2*RPB ... voxels
         // further along x with at most one carry when Wo >= IB*RPB (else every row is decoded in full)
-        const uint32_t mb = v0 + (wave * IB) * RPB + rb;
         int b0, z0, y0, x0;
         vox_decode((!ROWS && mb < g.M) ? mb : 0, g, b0, z0, y0, x0);
         const bool fast = !ROWS && g.Wo >= IB * RPB;
@@ -823,6 +880,54 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
         const uint32_t sA = lds_base + buf * STAGE;
         const uint32_t sB = sA + A_BYTES;
         const int fi = lane & 15;
+        if constexpr (PIPE) {
+            typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+            constexpr int G = TM >= 4 ? 2 : 1, NG = TM / G, KS = KV / 32;
+            i32x2_t alo[2][G], ahi[2][G], blo[2][TN], bhi[2][TN];
+            auto rdA = [&](int ks, int grp, int slot) {
+                const int kb = ks * 32 + (lane >> 4) * 8, r0 = kb + (fi >> 2), r1 = r0 + 4;
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    const int gi = (wm * WM + (grp * G + i) * 16) / 8 + ((fi & 3) >> 1), o8 = (fi & 1) * 8;
+                    alo[slot][i] = tr_read(sA + r0 * RSA + ((gi ^ wg_swz<GPA>(r0)) << 4) + o8);
+                    ahi[slot][i] = tr_read(sA + r1 * RSA + ((gi ^ wg_swz<GPA>(r1)) << 4) + o8);
+                }
+            };
+            auto rdB = [&](int ks, int slot) {
+                const int kb = ks * 32 + (lane >> 4) * 8, r0 = kb + (fi >> 2), r1 = r0 + 4;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int gi = (wn * WN + j * 16) / 8 + ((fi & 3) >> 1), o8 = (fi & 1) * 8;
+                    blo[slot][j] = tr_read(sB + r0 * RSB + ((gi ^ wg_swz<GPB>(r0)) << 4) + o8);
+                    bhi[slot][j] = tr_read(sB + r1 * RSB + ((gi ^ wg_swz<GPB>(r1)) << 4) + o8);
+                }
+            };
+            rdB(0, 0); rdA(0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int grp = 0; grp < NG; ++grp) {
+                    const int as = (ks * NG + grp) & 1, bs = ks & 1;
+                    if (grp + 1 < NG) rdA(ks, grp + 1, as ^ 1);
+                    else if (ks + 1 < KS) { rdB(ks + 1, bs ^ 1); rdA(ks + 1, 0, as ^ 1); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    bf16x8_t af[G], bf[TN];
+#pragma unroll
+                    for (int i = 0; i < G; ++i) { i32x4_t t4 = {alo[as][i][0], alo[as][i][1], ahi[as][i][0], ahi[as][i][1]}; af[i] = __builtin_bit_cast(bf16x8_t, t4); }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) { i32x4_t t4 = {blo[bs][j][0], blo[bs][j][1], bhi[bs][j][0], bhi[bs][j][1]}; bf[j] = __builtin_bit_cast(bf16x8_t, t4); }
+#pragma unroll
+                    for (int i = 0; i < G; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[grp * G + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[grp * G + i][j], 0, 0, 0);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < KV / 32; ++ks) {
             const int kb = ks * 32 + (lane >> 4) * 8;
@@ -880,15 +985,20 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
                 k = kn; buf ^= 1;
             }
         } else {
+        static_assert(NS >= 2 && NS <= 5 && 3 * LPS <= 63, "ring depth / counted wait range");
         for (int p = 0; p < NS - 1 && p < nk; ++p) issue(v_begin + (uint32_t)p * KV, p);
+        int cur = 0, nxt = NS - 1;                       // ring positions of stage k and of stage k + NS - 1
         for (int k = 0; k < nk; ++k) {
             const int ahead = min(nk - 1 - k, NS - 2);   // stages issued after stage k that may stay in flight
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+            if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
+            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (k + NS - 1 < nk) issue(v_begin + (uint32_t)(k + NS - 1) * KV, (k + NS - 1) % NS);
-            compute(k % NS);
+            if (k + NS - 1 < nk) issue(v_begin + (uint32_t)(k + NS - 1) * KV, nxt);
+            compute(cur);
+            cur = cur + 1 == NS ? 0 : cur + 1;
+            nxt = nxt + 1 == NS ? 0 : nxt + 1;
         }
         }
     }
@@ -1259,6 +1369,9 @@ static int fill_geom(ConvGeom& g, int B, int Di, int Hi, int Wi, int Cin, int Do
 }
 
 static int g_use_glds = 1;
+static int g_wgrad_pipe = 0;    // tuning (include/dreg_nerf_tuning.h): the dense 8-wave weight-gradient tile reads its fragments one MFMA group ahead (measured: no gain)
+static int g_wgrad_ring = 0;    // tuning (include/dreg_nerf_tuning.h): LDS ring of the dense 8-wave weight-gradient tile: 0 two 64-voxel stages, 1 four / 2 five 32-voxel stages (measured: no gain)
+static int g_rows_fast = 1;     // tuning (include/dreg_nerf_tuning.h): row-list weight gradients keep packed coordinates in LDS (no voxel decode per load) and use the 8-wave tile
 static int g_wgrad_big = 3;     // tuning (include/dreg_nerf_tuning.h): 256-row weight-gradient tiles for large dense layers (1: 256 x 128 / 4 waves, 3: 256 x 256 / 8 waves)
 
 // K slices of a small bf16 stride-1-gather convolution (0/1 = no split): fill the chip when the 128-row tiling leaves most CUs idle
@@ -1451,6 +1564,9 @@ int dreg_conv3d_dgrad_s2(const void* gout, const void* wt_class_packed, void* di
 // 5: as 1 but never split-K; 0: always the register-staged kernel (A/B checks).
 void dreg_conv_set_glds(int enable) { g_use_glds = enable; }
 void dreg_conv_set_wgrad_big(int enable) { g_wgrad_big = enable; }
+void dreg_conv_set_wgrad_rows_fast(int enable) { g_rows_fast = enable ? 1 : 0; }
+void dreg_conv_set_wgrad_ring(int mode) { g_wgrad_ring = mode; }
+void dreg_conv_set_wgrad_pipe(int enable) { g_wgrad_pipe = enable ? 1 : 0; }
 int dreg_conv_get_glds(void) { return g_use_glds; }
 
 // K padding of the packed weight row for (ntaps, Cin) at dtype.
@@ -1596,17 +1712,32 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
         else if (bm == 64 && bnc == 128) WG_LAUNCH(T, 64, 128, TRv); \
         else WG_LAUNCH(T, 64, 64, TRv); } while (0)
     if (glds_path) {
-#define WGG(BMv, BNv) do { if (rowlist) hipLaunchKernelGGL((conv_wgrad_glds_kernel<BMv, BNv, true>), dim3(tilesRow * tilesCol * nsplit), dim3(256), (size_t)2 * 64 * (bm + bnc) * 2 + (size_t)vps * 4, st, (const bf16_t*)gout, (const bf16_t*)in, part, g, tilesCol, tilesRow * tilesCol, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows); \
-        else hipLaunchKernelGGL((conv_wgrad_glds_kernel<BMv, BNv, false>), dim3(tilesRow * tilesCol * nsplit), dim3(256), (size_t)2 * 64 * (bm + bnc) * 2 + (rowocc ? (size_t)(vps / 64 + 16) : 0), st, (const bf16_t*)gout, (const bf16_t*)in, part, g, tilesCol, tilesRow * tilesCol, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, rowocc); } while (0)
+#define WGG_(BMv, BNv, KVv, NSv, PPv) do { if (rowlist) hipLaunchKernelGGL((conv_wgrad_glds_kernel<BMv, BNv, true, 4, 0, KVv, NSv, PPv>), dim3(tilesRow * tilesCol * nsplit), dim3(256), (size_t)2 * 64 * (bm + bnc) * 2 + (size_t)vps * (rows_fast ? 8 : 4), st, (const bf16_t*)gout, (const bf16_t*)in, part, g, tilesCol, tilesRow * tilesCol, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr, rows_fast); \
+        else hipLaunchKernelGGL((conv_wgrad_glds_kernel<BMv, BNv, false, 4, 0, KVv, NSv, PPv>), dim3(tilesRow * tilesCol * nsplit), dim3(256), (size_t)2 * 64 * (bm + bnc) * 2 + (rowocc ? (size_t)(vps / KVv + 16) : 0), st, (const bf16_t*)gout, (const bf16_t*)in, part, g, tilesCol, tilesRow * tilesCol, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, rowocc); } while (0)
+#define WGG(BMv, BNv) WGG_(BMv, BNv, 64, 2, 0)
         if (rowlist && vps > 20480) return DREG_EINVAL;   // the row-list slice must fit in LDS behind the stages (caller falls back to dense)
+        // row lists over a stride-1 same-size volume (what the active-set head launches): 8 bytes per row in LDS (index + packed
+        // coordinates) when that fits, and the 8-wave 256 x 256 tile for the 256 -> 256 layers
+        const bool same_vol = g.sn == 1 && g.sd == 1 && g.dsign == 1 && Di == Do && Hi == Ho && Wi == Wo && Do < 1024 && Ho < 1024 && Wo < 1024;
+        const bool rows256 = rowlist && same_vol && g_rows_fast && g_wgrad_big == 3 && Cout % 256 == 0 && g.Kpad % 256 == 0 && nrows >= 65536 &&
+                             (size_t)2 * 64 * 512 * 2 + (size_t)vps * 8 <= (size_t)160 * 1024;
+        const int rows_fast = (rowlist && same_vol && g_rows_fast && (rows256 || (size_t)2 * 64 * (bm + bnc) * 2 + (size_t)vps * 8 <= (size_t)160 * 1024)) ? 1 : 0;
         if (rowlist) {
             const int ldsr = 2 * 64 * (bm + bnc) * 2 + (int)vps * 4;
             (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<128, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<64, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<64, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+
             (void)ldsr;
         }
+        if (rows256) {
+            const int tiles256 = (Cout / 256) * (g.Kpad / 256);
+            const size_t l_ = (size_t)2 * 64 * 512 * 2 + (size_t)vps * 8;
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, true, 8>), dim3(tiles256 * nsplit), dim3(512), l_, st, (const bf16_t*)gout,
+                               (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr, 1);
+        } else
         if (!rowlist && !rowocc && g_wgrad_big && Cout % 256 == 0 && g.Kpad % 256 == 0 && nrows >= 65536) {
             // large dense layers: 256-row tiles.  Default (3): the 8-wave 256 x 256 tile (0.90 PFLOP/s on 256 -> 256 @64^3 alone); 1: 4
             // waves on 256 x 128 with 32-voxel stages — 48 KB of LDS, two independent workgroups per CU: 0.93 alone, but no faster
@@ -1627,6 +1758,18 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
                                    (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, rowocc); } while (0)
                 if (g_wgrad_big == 11) WG_ABL(1); else if (g_wgrad_big == 12) WG_ABL(2); else WG_ABL(3);
 #undef WG_ABL
+            } else if (g_wgrad_pipe && !g_wgrad_ring) {
+                (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, false, 8, 0, 64, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, false, 8, 0, 64, 2, 1>), dim3(tiles256 * nsplit), dim3(512), (size_t)2 * 64 * 512 * 2 + (rowocc ? (size_t)(vps / 64 + 16) : 0), st, (const bf16_t*)gout,
+                                   (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, rowocc);
+            } else if (g_wgrad_ring == 2) {   // five 32-voxel stages: the whole 160 KB of LDS, four stages in flight
+                (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, false, 8, 0, 32, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, false, 8, 0, 32, 5>), dim3(tiles256 * nsplit), dim3(512), (size_t)5 * 32 * 512 * 2, st, (const bf16_t*)gout,
+                                   (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr);
+            } else if (g_wgrad_ring == 1) {
+                (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, false, 8, 0, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, false, 8, 0, 32, 4>), dim3(tiles256 * nsplit), dim3(512), (size_t)4 * 32 * 512 * 2, st, (const bf16_t*)gout,
+                                   (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr);
             } else
             hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, false, 8>), dim3(tiles256 * nsplit), dim3(512), (size_t)2 * 64 * 512 * 2, st, (const bf16_t*)gout,
                                (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, rowocc);
@@ -1713,6 +1856,11 @@ int dreg_conv3d_wgrad_variant(int B, int Do, int Ho, int Wo, int Cin, int Cout, 
     const int nsplit = dreg_conv3d_wgrad_splits(B, Do, Ho, Wo, Cin, Cout, ksz, 0);
     const long M = (long)B * Do * Ho * Wo;
     if (!rows && !occ && g_wgrad_big && Cout % 256 == 0 && Kpad % 256 == 0 && (rows ? nrows : M) >= 65536) return g_wgrad_big == 1 ? 256128 : 256256;
+    if (rows && g_rows_fast && g_wgrad_big == 3 && ksz == 3 && Cout % 256 == 0 && Kpad % 256 == 0 && nrows >= 65536) {   // stride 1, same-size volume assumed
+        uint32_t vps = (uint32_t)((nrows + nsplit - 1) / nsplit);
+        vps = ((vps + 63) / 64) * 64;
+        if ((size_t)2 * 64 * 512 * 2 + (size_t)vps * 8 <= (size_t)160 * 1024) return 256256;
+    }
     int bm = (Cout % 128 == 0) ? 128 : 64;
     int bnc = (Kpad % 128 == 0 || Kpad > 128) ? 128 : 64;
     if (g_narrow_small >= 2 && (Cout / bm) * ((Kpad + bnc - 1) / bnc) * nsplit < g_narrow_thr) {

@@ -42,6 +42,9 @@ SIGNATURES = {
     "dreg_pack_conv_weights_batched": (I, [P, I, I, I, P, P]),
     "dreg_conv_set_wgrad_splits": (None, [I]),
     "dreg_conv_set_wgrad_big": (None, [I]),
+    "dreg_conv_set_wgrad_pipe": (None, [I]),
+    "dreg_conv_set_wgrad_ring": (None, [I]),
+    "dreg_conv_set_wgrad_rows_fast": (None, [I]),
     "dreg_conv_set_glds_stages": (None, [I]),
     "dreg_conv_set_wgrad_target_blocks": (None, [I]),
     "dreg_conv3d_wgrad_splits": (I, [I] * 8),

@@ -229,6 +229,44 @@ def test_large_layer_weight_gradient_tiles_are_bit_identical():
     assert float((out[1] - ref.grad).abs().max()) <= 2e-3 * float(ref.grad.abs().max())
 
 
+@pytest.mark.parametrize("cin,cout,D", [(256, 256, 48), (64, 256, 32), (128, 128, 16)])
+def test_row_list_weight_gradient_fast_path_is_bit_identical(cin, cout, D):
+    """Row-list weight gradient with (row, packed z|y|x) pairs in LDS read once per stage — and, for 256 -> 256 layers with >= 65,536
+    rows, the 8-wave 256 x 256 tile — against the loop that decodes the voxel per load: same products in the same order."""
+    from dreg_nerf_amd import lib as L
+    lib = L.load()
+    DEV = _dev()
+    B = 8
+    g = torch.Generator().manual_seed(cin + D)
+    keep = torch.rand(B * D ** 3, generator=g) < (0.1 if D == 48 else 0.3)   # 48^3: 88 k rows, 2.8 k per split: the slice fits behind the 8-wave tile's stages
+    keep[:3] = True; keep[-2:] = True                   # first / last voxels: every bounds test of the taps
+    rows = keep.nonzero().flatten().int().to(DEV)
+    n = rows.shape[0]
+    x = torch.randn(B, D, D, D, cin, generator=g).to(DEV).bfloat16()
+    gy = torch.randn(B, D, D, D, cout, generator=g).to(DEV).bfloat16()
+    nbytes = lib.dreg_conv3d_wgrad_workspace_bytes(B, D, D, D, cin, cout, 3, 0)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    out = []
+    try:
+        for fast in (0, 1):
+            lib.dreg_conv_set_wgrad_rows_fast(fast)
+            dw = torch.empty(cout, cin, 3, 3, 3, dtype=torch.float32, device=DEV)
+            L.check(lib.dreg_conv3d_wgrad_rows(L.ptr(gy), L.ptr(x), L.ptr(dw), L.ptr(ws), nbytes, L.ptr(rows), n, B, D, D, D, cin, cin, D, D, D, cout, 3, 1, 1, 0,
+                                               L.stream()), "dreg_conv3d_wgrad_rows")
+            out.append(dw)
+    finally:
+        lib.dreg_conv_set_wgrad_rows_fast(1)
+    if D == 48:
+        assert lib.dreg_conv3d_wgrad_variant(B, D, D, D, cin, cout, 3, 1, n, 0) == 256256
+    assert torch.isfinite(out[1]).all() and out[1].abs().max() > 0
+    assert torch.equal(out[0], out[1])
+    # and against the dense kernel on a gradient that is zero off the rows
+    gz = torch.zeros_like(gy).view(-1, cout)
+    gz[rows.long()] = gy.view(-1, cout)[rows.long()]
+    ref = ops.conv_wgrad(gz.view_as(gy), x, (cout, cin, 3, 3, 3), cin, 3, 1, 1, True)
+    assert (out[1] - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
 def test_row_list_helpers_of_the_active_set_backward():
     """dreg_zero_rows, dreg_downsample_sum_rows and dreg_maxpool3d_bwd_acc against plain torch."""
     from dreg_nerf_amd import lib as L

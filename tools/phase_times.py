@@ -19,8 +19,8 @@ def mark(name):
     e = torch.cuda.Event(enable_timing=True); e.record(); marks.append((name, e))
 # monkeypatch phase boundaries
 orig_fpn = model.fpn
-def fpn(x, rows=None):
-    mark("fpn_fwd_start"); y = orig_fpn(x, rows); mark("fpn_fwd_end"); return y
+def fpn(x, rows=None, *a, **kw):
+    mark("fpn_fwd_start"); y = orig_fpn(x, rows, *a, **kw); mark("fpn_fwd_end"); return y
 model.fpn = fpn
 from dreg_nerf_amd import trunk_exec
 orig_bwd = trunk_exec.TrunkExecutor.backward
@@ -47,3 +47,5 @@ for _ in range(N):
     for (n1, e1) in marks[1:]:
         acc[("step_start", n1)] = acc.get(("step_start", n1), 0.0) + base.elapsed_time(e1)
 for k, v in acc.items(): print(f"{k[0]:20s} -> {k[1]:20s} {v/N:7.2f} ms")
+# fwd trunk = fpn_fwd_end - fpn_fwd_start; point-set half fwd + losses + its backward = fpn_bwd_start - fpn_fwd_end;
+# trunk backward = fpn_bwd_end - fpn_bwd_start; reduce join + clip + AdamW + repack = step_end - fpn_bwd_end
