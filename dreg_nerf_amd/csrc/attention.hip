@@ -74,6 +74,12 @@ __device__ __forceinline__ Prob get_prob(const AttnArgs& a) {
 
 // Tiles are register-staged: fetch the NEXT tile's granules into registers while the current tile (already in LDS) is being consumed,
 // store them after the block has finished reading the current one — the global-memory latency of a tile hides behind a tile of MFMAs.
+// Row padding of the LDS tiles.  bf16: 32 bytes — rows then start 32 bytes apart modulo 256, so the eight consecutive rows x 32 bytes a
+// half-wave of ds_read_b64_tr_b16 touches tile the 64 banks exactly (with 16 bytes of padding the 4th row wrapped onto the 1st and the
+// 5th overlapped the 2nd: SQ_LDS_BANK_CONFLICT was 46 % of the LDS cycles); the 16-byte row reads stay conflict-free.
+template <typename T> __host__ __device__ constexpr int row_pad() { return sizeof(T) == 2 ? 32 : 16; }
+// Two LDS buffers per operand and ONE barrier per tile: after the barrier of tile k (everyone has finished tile k-1) the registers holding
+// tile k+1 are stored into the other buffer and tile k+2 is requested; tile k is then consumed from its buffer.
 template <typename T, int D>
 struct TileRegs {
     static constexpr int GPR = D * sizeof(T) / 16, NL = (64 * GPR + 255) / 256;
@@ -141,10 +147,9 @@ template <typename T, int D, bool XYZ>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a)
 {
     constexpr int DV = 32;
-    constexpr int KRS = D * sizeof(T) + 16, VRS = XYZ ? 16 : DV * sizeof(T) + 16;
+    constexpr int KRS = D * sizeof(T) + row_pad<T>(), VRS = XYZ ? 16 : DV * sizeof(T) + row_pad<T>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;
-    char* sV = sK + 64 * KRS;
+    constexpr int BUF = 64 * KRS + 64 * VRS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.y;
     const Prob pb = get_prob(a);
@@ -177,14 +182,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a)
             rv.fetch(Vp, a.ldv, k0, pb.Nk, tid);
         }
     };
+    auto stage = [&](int buf) {
+        char* dK = smem + buf * BUF;
+        rk.store(dK, KRS, tid);
+        if constexpr (XYZ) { if (tid < 64) *reinterpret_cast<float4*>(dK + 64 * KRS + tid * 16) = rx; }
+        else rv.store(dK + 64 * KRS, VRS, tid);
+    };
     fetch(0);
-    for (int k0 = 0; k0 < pb.Nk; k0 += 64) {
+    stage(0);
+    if (64 < pb.Nk) fetch(64);
+    for (int k0 = 0, buf = 0; k0 < pb.Nk; k0 += 64, buf ^= 1) {
         __syncthreads();
-        rk.store(sK, KRS, tid);
-        if constexpr (XYZ) { if (tid < 64) *reinterpret_cast<float4*>(sV + tid * 16) = rx; }
-        else rv.store(sV, VRS, tid);
-        __syncthreads();
-        if (k0 + 64 < pb.Nk) fetch(k0 + 64);
+        if (k0 + 64 < pb.Nk) { stage(buf ^ 1); if (k0 + 128 < pb.Nk) fetch(k0 + 128); }
+        const char* sK = smem + buf * BUF;
+        const char* sV = sK + 64 * KRS;
         f32x4_t s[4];          // s[t][r] = score(q = fr, key = k0 + t*16 + kg*4 + r)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -261,10 +272,9 @@ template <typename T, int D, bool XYZ>
 __global__ __launch_bounds__(256, (D > 32 ? 2 : 1)) void attn_bwd_dq_kernel(AttnArgs a)
 {
     constexpr int DV = 32;
-    constexpr int KRS = D * sizeof(T) + 16, VRS = XYZ ? 16 : DV * sizeof(T) + 16;
+    constexpr int KRS = D * sizeof(T) + row_pad<T>(), VRS = XYZ ? 16 : DV * sizeof(T) + row_pad<T>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;
-    char* sV = sK + 64 * KRS;
+    constexpr int BUF = 64 * KRS + 64 * VRS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.y;
     const Prob pb = get_prob(a);
@@ -324,14 +334,20 @@ __global__ __launch_bounds__(256, (D > 32 ? 2 : 1)) void attn_bwd_dq_kernel(Attn
             rv.fetch(Vp, a.ldv, k0, pb.Nk, tid);
         }
     };
+    auto stage = [&](int buf) {
+        char* dK = smem + buf * BUF;
+        rk.store(dK, KRS, tid);
+        if constexpr (XYZ) { if (tid < 64) *reinterpret_cast<float4*>(dK + 64 * KRS + tid * 16) = rx; }
+        else rv.store(dK + 64 * KRS, VRS, tid);
+    };
     fetch(0);
-    for (int k0 = 0; k0 < pb.Nk; k0 += 64) {
+    stage(0);
+    if (64 < pb.Nk) fetch(64);
+    for (int k0 = 0, buf = 0; k0 < pb.Nk; k0 += 64, buf ^= 1) {
         __syncthreads();
-        rk.store(sK, KRS, tid);
-        if constexpr (XYZ) { if (tid < 64) *reinterpret_cast<float4*>(sV + tid * 16) = rx; }
-        else rv.store(sV, VRS, tid);
-        __syncthreads();
-        if (k0 + 64 < pb.Nk) fetch(k0 + 64);
+        if (k0 + 64 < pb.Nk) { stage(buf ^ 1); if (k0 + 128 < pb.Nk) fetch(k0 + 128); }
+        const char* sK = smem + buf * BUF;
+        const char* sV = sK + 64 * KRS;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             float dsv[8];
@@ -377,11 +393,9 @@ template <typename T, int D, bool XYZ>
 __global__ __launch_bounds__(256, (D > 32 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnArgs a)
 {
     constexpr int DV = 32;
-    constexpr int QRS = D * sizeof(T) + 16, ORS = XYZ ? 16 : DV * sizeof(T) + 16;
+    constexpr int QRS = D * sizeof(T) + row_pad<T>(), ORS = XYZ ? 16 : DV * sizeof(T) + row_pad<T>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sQ = smem;
-    char* sO = sQ + 64 * QRS;             // dO tile
-    float* sL = reinterpret_cast<float*>(sO + 64 * ORS);  // lse * log2(e) [64], dvec [64]
+    constexpr int BUF = 64 * QRS + 64 * ORS + 128 * (int)sizeof(float);   // Q tile | dO tile | lse * log2(e) [64], dvec [64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.y;
     const Prob pb = get_prob(a);
@@ -428,15 +442,23 @@ __global__ __launch_bounds__(256, (D > 32 ? 2 : 1)) void attn_bwd_dkv_kernel(Att
         rl = rd = 0.f;
         if (tid < 64 && q0 + tid < pb.Nq) { rl = a.lse[(long)h * a.Rq + pb.q0 + q0 + tid] * LOG2E; rd = a.dvec[(long)h * a.Rq + pb.q0 + q0 + tid]; }
     };
+    auto stage = [&](int buf) {
+        char* dQ = smem + buf * BUF;
+        rq.store(dQ, QRS, tid);
+        if constexpr (XYZ) { if (tid < 64) *reinterpret_cast<float4*>(dQ + 64 * QRS + tid * 16) = rg; }
+        else ro.store(dQ + 64 * QRS, ORS, tid);
+        float* dL = reinterpret_cast<float*>(dQ + 64 * QRS + 64 * ORS);
+        if (tid < 64) { dL[tid] = rl; dL[64 + tid] = rd; }
+    };
     fetch(0);
-    for (int q0 = 0; q0 < pb.Nq; q0 += 64) {
+    stage(0);
+    if (64 < pb.Nq) fetch(64);
+    for (int q0 = 0, buf = 0; q0 < pb.Nq; q0 += 64, buf ^= 1) {
         __syncthreads();
-        rq.store(sQ, QRS, tid);
-        if constexpr (XYZ) { if (tid < 64) *reinterpret_cast<float4*>(sO + tid * 16) = rg; }
-        else ro.store(sO, ORS, tid);
-        if (tid < 64) { sL[tid] = rl; sL[64 + tid] = rd; }
-        __syncthreads();
-        if (q0 + 64 < pb.Nq) fetch(q0 + 64);
+        if (q0 + 64 < pb.Nq) { stage(buf ^ 1); if (q0 + 128 < pb.Nq) fetch(q0 + 128); }
+        const char* sQ = smem + buf * BUF;
+        const char* sO = sQ + 64 * QRS;
+        const float* sL = reinterpret_cast<const float*>(sO + 64 * ORS);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             float pv[8], dsv[8];
@@ -497,17 +519,17 @@ static int launch_attn(const AttnArgs& a, int H, int mode, hipStream_t st, int n
 {
     const int gq = ((a.probs ? maxq : a.Nq) + 63) / 64, gk = ((a.probs ? maxk : a.Nk) + 63) / 64;
     constexpr int DV = 32;
-    const size_t krs = D * sizeof(T) + 16, vrs = XYZ ? 16 : DV * sizeof(T) + 16;
+    const size_t krs = D * sizeof(T) + row_pad<T>(), vrs = XYZ ? 16 : DV * sizeof(T) + row_pad<T>();
     if (mode == 0) {
-        const size_t lds = 64 * krs + 64 * vrs;
+        const size_t lds = 2 * (64 * krs + 64 * vrs);
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, D, XYZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((attn_fwd_kernel<T, D, XYZ>), dim3(gq, H, nprob), dim3(256), lds, st, a);
     } else if (mode == 1) {
-        const size_t lds = 64 * krs + 64 * vrs;
+        const size_t lds = 2 * (64 * krs + 64 * vrs);
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<T, D, XYZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, XYZ>), dim3(gq, H, nprob), dim3(256), lds, st, a);
     } else {
-        const size_t lds = 64 * krs + 64 * vrs + 128 * sizeof(float);
+        const size_t lds = 2 * (64 * krs + 64 * vrs + 128 * sizeof(float));
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, D, XYZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, XYZ>), dim3(gk, H, nprob), dim3(256), lds, st, a);
     }
