@@ -152,11 +152,8 @@ class ProblemTable:
             self_p += [[s0, ns, s0, ns], [t0, nt, t0, nt]]
             cross_p += [[s0, ns, t0, nt], [t0, nt, s0, ns]]
         device = torch.device(device)
-        self.self_probs = L.to_device_async(self_p, torch.int32, device)   # no pageable H2D copy: that would drain the stream
-        self.cross_probs = L.to_device_async(cross_p, torch.int32, device)
         self.max_len = max(max(ns, nt) for ns, nt in seg_lengths)
         # per-pair tables of the batched Kabsch / loss kernels: (s0, ns, t0, nt); source-row and logits-block offsets
-        self.pair_probs = L.to_device_async([list(sg) for sg in starts], torch.int32, device)
         so, lo, a, b = [], [], 0, 0
         for (s0, ns, t0, nt) in starts:
             so.append(a)
@@ -165,8 +162,22 @@ class ProblemTable:
             b += ns * nt
         self.total_src, self.total_logits = a, b
         self.logit_off_host = lo
-        self.src_off = L.to_device_async(so, torch.int32, device)
-        self.logit_off = L.to_device_async(lo, torch.int64, device)
+        # ONE upload for the five tables (each was its own small copy in front of the transformer): int64 offsets first (alignment),
+        # then the int32 tables; no pageable H2D copy: that would drain the stream
+        P, n4 = len(starts), 4 * len(self_p)
+        flat = []
+        for v in lo:
+            flat += [v & 0xFFFFFFFF, v >> 32]
+        flat += [x for row in self_p for x in row] + [x for row in cross_p for x in row] + [x for sg in starts for x in sg] + so
+        flat = [x - (1 << 32) if x >= (1 << 31) else x for x in flat]
+        buf = L.to_device_async(flat, torch.int32, device)
+        self.buffer = buf
+        o = 2 * P
+        self.logit_off = buf[:o].view(torch.int64)
+        self.self_probs = buf[o:o + n4].view(-1, 4)
+        self.cross_probs = buf[o + n4:o + 2 * n4].view(-1, 4)
+        self.pair_probs = buf[o + 2 * n4:o + 2 * n4 + 4 * P].view(-1, 4)
+        self.src_off = buf[o + 2 * n4 + 4 * P:]
         self.nprob = len(self_p)
 
 

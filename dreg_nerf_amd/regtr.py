@@ -376,10 +376,11 @@ class NeRFRegTr(nn.Module):
                                 t.record_stream(main)
             with torch.cuda.stream(side):
                 geo = self._geometry(batch, dev)
+                tab = A.ProblemTable(geo[8], dev)      # the attention / Kabsch / loss tables: uploaded next to the geometry, not in front of the transformer
             main.wait_stream(side)
             grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs, table, s1_rows = geo
             # these were allocated on the side stream and are consumed on the main one
-            keep = [idx_cat, pb_cat, s1_rows] + list(pts_l) + ([rows[0], rows[3]] if rows is not None else []) + ([table] if table is not None else [])
+            keep = [idx_cat, pb_cat, s1_rows, tab.buffer] + list(pts_l) + ([rows[0], rows[3]] if rows is not None else []) + ([table] if table is not None else [])
             if isinstance(grids, tuple):
                 keep.append(grids[0])
             if rows is not None and len(rows) >= 6:
@@ -391,6 +392,7 @@ class NeRFRegTr(nn.Module):
                 t.record_stream(main)
         else:
             grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs, table, s1_rows = self._geometry(batch, dev)
+            tab = A.ProblemTable(segs, dev)
         if isinstance(grids, tuple):   # sparse input form
             x_in, row_occ = self.pack_sparse(grids[0], idx_cat, pb_cat, grids[1], res, self.act_dtype, occupancy=True)
         else:
@@ -402,7 +404,6 @@ class NeRFRegTr(nn.Module):
         # feature tensor into a zero-filled full-size gradient plus an add (2.3 GB of traffic per step at 4 pairs)
         sizes = [idxs[2 * i].shape[0] + idxs[2 * i + 1].shape[0] for i in range(len(batch))]
         feat_l = [T.apply_subsample_plan(plans[i], f) for i, f in enumerate(feats.split(sizes))]
-        tab = A.ProblemTable(segs, dev)
         xyz_all = torch.cat(pts_l) if len(pts_l) > 1 else pts_l[0]
         cond, corr, ov = T.encode_decode_batched(P, torch.cat(feat_l) if len(feat_l) > 1 else feat_l[0], xyz_all, tab, self.position_embedding)
         outs = []

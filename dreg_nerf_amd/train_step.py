@@ -95,7 +95,8 @@ class TrainStep:
             poses = torch.cat([d["pose"].reshape(1, 4, 4) for d in batch]).float()
             ls = FL.regtr_losses(bt, poses, self.feature_loss, gt, tilde, self.robust)
             total = ls["total"]
-            agg = {k: v.detach() * len(batch) for k, v in ls.items()}
+            agg = None                       # the fused losses are batch means already (no x len / len round trip: ten tiny launches)
+            means = {k: v.detach() for k, v in ls.items()}
         else:
             total = 0.0
             agg = {}
@@ -141,7 +142,7 @@ class TrainStep:
         gnorm = self.optimizer.grad_norm()
         if not self.finetune:
             self.scheduler.step()
-        self.last_losses = {k: v / len(batch) for k, v in agg.items()}
+        self.last_losses = means if agg is None else {k: v / len(batch) for k, v in agg.items()}
         self.last_preds = preds
         return {"losses": self.last_losses, "grad_norm": gnorm}
 
