@@ -60,7 +60,8 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y, const float* __restrict__ mean_rstd,
-    float* __restrict__ partial, int V, int C, int rows_per_chunk, int relu, const float* __restrict__ scale_shift = nullptr)
+    float* __restrict__ partial, int V, int C, int rows_per_chunk, int relu, const float* __restrict__ scale_shift = nullptr,
+    T* __restrict__ gout = nullptr)   // MODE 1: the masked gradient g is also stored (it IS the residual branch's gradient; the apply pass then reads it instead of dy and y)
 {
     constexpr int G = Gran<T>::G;
     const int CG = C / G;
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(
 #pragma unroll
                             for (int i = 0; i < G; ++i) gv[u][i] = yv[u][i] > 0.f ? gv[u][i] : 0.f;
                         }
+                        if (gout) Gran<T>::st(gout + ((size_t)b * V + v + u * rpi) * C + (size_t)cg * G, gv[u]);
 #pragma unroll
                         for (int i = 0; i < G; ++i) { s1[i] += gv[u][i]; s2[i] += gv[u][i] * (xv[u][i] - mu[i]) * rs[i]; }
                     }
@@ -315,15 +317,16 @@ __global__ __launch_bounds__(256) void bn_apply_cols_kernel(const T* __restrict_
     }
 }
 template <typename T, int UN>
-__global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
+__global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(const T* __restrict__ x, const T* dy, const T* __restrict__ y,
                                                                 const float* __restrict__ mean_rstd, const float* __restrict__ scale_shift,
-                                                                const float* __restrict__ coef, T* __restrict__ dx, T* __restrict__ dres,
-                                                                int V, int C, int rows_per_chunk, int relu)
+                                                                const float* __restrict__ coef, T* __restrict__ dx, T* dres,
+                                                                int V, int C, int rows_per_chunk, int relu, int g_stored = 0)
 {
     constexpr int G = Gran<T>::G;
     const int CG = C / G, cgs = CG < 256 ? CG : 256, rpi = 256 / cgs;
     const int t = threadIdx.x, cg = blockIdx.z * cgs + (t % cgs), r0 = t / cgs, b = blockIdx.y;
     if (r0 >= rpi || cg >= CG) return;
+    if (g_stored) { dy = dres; dres = nullptr; relu = 0; }     // the statistics pass stored the masked gradient in dres: one tensor read less
     const int v0 = blockIdx.x * rows_per_chunk, v1 = min(v0 + rows_per_chunk, V);
     float mu[G], rs[G], sc[G], sh[G], c1[G], c2[G];
 #pragma unroll
@@ -582,6 +585,7 @@ __global__ void bn_tail_batched_kernel(const BnTailDesc* __restrict__ descs, int
         d.o1[c] = accumulate ? d.o1[c] + (float)db : (float)db;
     }
 }
+static int g_bn_store_g = 1;     // tuning (include/dreg_nerf_tuning.h): residual BatchNorm backward stores the masked gradient in the statistics pass
 static int g_bn_debug_skip = 0;      // measurement only (tools/ab_step.py): bit 0 / bit 1 leave out the forward / backward statistics pass (stale statistics)
 static int g_bn_small_maxv = 512;    // tuning (include/dreg_nerf_tuning.h): largest per-grid volume served by the fused kernels, 0 = never
 static inline bool bn_small_ok(int B, int V, int C, int G) { return V >= 2 && V <= g_bn_small_maxv && C % (BNS_COLS * G) == 0 && B >= 1; }
@@ -1197,6 +1201,7 @@ static inline int bn_rows_per_chunk(int V) { return V >= 262144 ? 512 : V >= 327
 extern "C" {
 
 void dreg_bn_set_debug_skip(int mask) { g_bn_debug_skip = mask; }
+void dreg_bn_set_store_g(int enable) { g_bn_store_g = enable ? 1 : 0; }
 void dreg_bn_set_small_max_voxels(int v) { g_bn_small_maxv = v; }
 int dreg_bn_num_chunks(int V) { const int r = bn_rows_per_chunk(V); return (V + r - 1) / r; }
 
@@ -1325,17 +1330,20 @@ static int bn3d_bwd_impl(const void* x, const void* dy, const void* y, const flo
         return DREG_OK;
     }
     dim3 grid(nch, B, slabs);
+    // residual + ReLU layers (the last BatchNorm of a bottleneck): the masked gradient the statistics pass forms IS the residual branch's
+    // gradient — it is stored there, and the apply pass reads it back instead of dy and y (one activation-sized read less, same values)
+    const int g_stored = (dres && relu && y && dres != dy && dres != dx && g_bn_store_g && !(g_bn_debug_skip & 2)) ? 1 : 0;
     if (g_bn_debug_skip & 2) {}
-    else if (dtype == 0) hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean_rstd, workspace, V, C, rpc, relu, scale_shift);
-    else hipLaunchKernelGGL((bn_partial_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y, mean_rstd, workspace, V, C, rpc, relu, scale_shift);
+    else if (dtype == 0) hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean_rstd, workspace, V, C, rpc, relu, scale_shift, g_stored ? (bf16_t*)dres : nullptr);
+    else hipLaunchKernelGGL((bn_partial_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y, mean_rstd, workspace, V, C, rpc, relu, scale_shift, g_stored ? (float*)dres : nullptr);
     DREG_LAUNCH_CHECK();
     if (B > BN_MAX_GRIDS) return DREG_EINVAL;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64 * (B < 8 ? B : 8)), 0, st, workspace, coef, dgamma, dbeta, B, nch, C, V, accumulate);
     DREG_LAUNCH_CHECK();
     const size_t tg = (size_t)B * V * CG;
     (void)tg;
-    if (dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean_rstd, scale_shift, coef, (bf16_t*)dx, (bf16_t*)dres, V, C, rpc, relu);
-    else hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y, mean_rstd, scale_shift, coef, (float*)dx, (float*)dres, V, C, rpc, relu);
+    if (dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, mean_rstd, scale_shift, coef, (bf16_t*)dx, (bf16_t*)dres, V, C, rpc, relu, g_stored);
+    else hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y, mean_rstd, scale_shift, coef, (float*)dx, (float*)dres, V, C, rpc, relu, g_stored);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

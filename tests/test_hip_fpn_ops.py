@@ -374,6 +374,35 @@ def test_batchnorm_train_fwd_bwd(shape, dtype, with_res):
     np.testing.assert_allclose(bd.grad.cpu().numpy(), br.grad.numpy(), atol=tol * float(br.grad.abs().max()) * 2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batchnorm_backward_with_the_masked_gradient_stored_once_is_bit_identical(dtype):
+    """Residual + ReLU BatchNorm, three-kernel form (dreg_bn_set_store_g): the statistics pass stores g = dy * (y > 0) as the residual
+    branch's gradient and the apply pass reads it back, against both passes reading dy and y."""
+    from dreg_nerf_amd import lib as L
+    dev = _dev()
+    lib = L.load()
+    g = torch.Generator().manual_seed(17)
+    B, D, C = 3, 20, 128
+    x = torch.randn(B, D, D, D, C, generator=g).to(dev, dtype)
+    res = torch.randn(B, D, D, D, C, generator=g).to(dev, dtype)
+    gy = torch.randn(B, D, D, D, C, generator=g).to(dev, dtype)
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+    got = []
+    try:
+        for on in (1, 0):
+            lib.dreg_bn_set_store_g(on)
+            xd, rd = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+            gd, bd = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+            y = ops.batchnorm(xd, gd, bd, torch.zeros(C, device=dev), torch.ones(C, device=dev), res=rd, relu=True, train=True)
+            y.backward(gy)
+            got.append((xd.grad, rd.grad, gd.grad, bd.grad))
+    finally:
+        lib.dreg_bn_set_store_g(1)
+    for a, c in zip(got[0], got[1]):
+        assert torch.isfinite(a.float()).all() and a.float().abs().max() > 0
+        assert torch.equal(a, c)
+
+
 def test_batchnorm_eval():
     dev = _dev()
     g = torch.Generator().manual_seed(3)
