@@ -13,6 +13,9 @@ template <> struct Gran<float> {
     static constexpr int G = 4;
     static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) { float4 q = *reinterpret_cast<const float4*>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
     static __device__ __forceinline__ void st(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+    // the 16-byte granule as it lies in memory (kept in registers between two phases of a kernel)
+    static __device__ __forceinline__ void unpack(const uint4& q, float (&v)[4]) { v[0] = __uint_as_float(q.x); v[1] = __uint_as_float(q.y); v[2] = __uint_as_float(q.z); v[3] = __uint_as_float(q.w); }
+    static __device__ __forceinline__ uint4 pack(const float (&v)[4]) { return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])); }
 };
 template <> struct Gran<bf16_t> {
     static constexpr int G = 8;
@@ -27,6 +30,17 @@ template <> struct Gran<bf16_t> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] = f2bf2(v[2 * i], v[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    static __device__ __forceinline__ void unpack(const uint4& q, float (&v)[8]) {
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ uint4 pack(const float (&v)[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = f2bf2(v[2 * i], v[2 * i + 1]);
+        return make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
 
@@ -391,7 +405,10 @@ template <int G> __device__ __forceinline__ void bns_reduce(float (&s1)[G], floa
         for (int i = 0; i < G; ++i) { red[wave][lane][i] = s1[i]; red[wave][lane][8 + i] = s2[i]; }
     }
 }
-template <typename T>
+// NR > 0 (V == NR * 64 rows per grid: 8^3 -> 8, 4^3 -> 1): a thread's rows are loaded ONCE, all loads in flight together, and stay in
+// registers between the statistics and the apply phase (the general form, NR = 0, walks the rows twice, four loads in flight): the
+// kernels are short enough that the second walk and the exposed latencies were most of their time.  Same sums in the same order.
+template <typename T, int NR = 0>
 __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ scale_shift, float* __restrict__ mean_rstd, float* __restrict__ var_out,
@@ -405,12 +422,30 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const T* __restrict__
     float s1[G], s2[G];
 #pragma unroll
     for (int i = 0; i < G; ++i) s1[i] = s2[i] = 0.f;
+    constexpr int NRR = NR > 0 ? NR : 1;
+    uint4 xr[NRR], rr[NRR];
+    if constexpr (NR > 0) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const size_t off = ((size_t)b * V + rl + j * BNS_ROWS) * C + c0;
+            xr[j] = *reinterpret_cast<const uint4*>(x + off);
+            if (res) rr[j] = *reinterpret_cast<const uint4*>(res + off);
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            float xv[G];
+            Gran<T>::unpack(xr[j], xv);
+#pragma unroll
+            for (int i = 0; i < G; ++i) { s1[i] += xv[i]; s2[i] += xv[i] * xv[i]; }
+        }
+    } else {
 #pragma unroll 4
     for (int v = rl; v < V; v += BNS_ROWS) {
         float xv[G];
         Gran<T>::ld(x + ((size_t)b * V + v) * C + c0, xv);
 #pragma unroll
         for (int i = 0; i < G; ++i) { s1[i] += xv[i]; s2[i] += xv[i] * xv[i]; }
+    }
     }
     bns_reduce<G>(s1, s2, red, t);
     __syncthreads();
@@ -436,6 +471,23 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const T* __restrict__
     float sc[G], sh[G];
 #pragma unroll
     for (int i = 0; i < G; ++i) { sc[i] = s_sc[col * G + i]; sh[i] = s_sh[col * G + i]; }
+    if constexpr (NR > 0) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const size_t off = ((size_t)b * V + rl + j * BNS_ROWS) * C + c0;
+            float xv[G], rvv[G];
+            Gran<T>::unpack(xr[j], xv);
+            if (res) Gran<T>::unpack(rr[j], rvv);
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                float o = xv[i] * sc[i] + sh[i];
+                if (res) o += rvv[i];
+                xv[i] = relu ? fmaxf(o, 0.f) : o;
+            }
+            Gran<T>::st(y + off, xv);
+        }
+        return;
+    }
 #pragma unroll 4
     for (int v = rl; v < V; v += BNS_ROWS) {
         const size_t off = ((size_t)b * V + v) * C + c0;
@@ -469,7 +521,7 @@ __global__ void bn_running_update_kernel(const float* __restrict__ mean_rstd, co
 
 // backward of the same: per grid c1 = sum(g)/V, c2 = sum(g xhat)/V, dx = gamma rstd (g - c1 - xhat c2), dres = g; the per-grid sums go to
 // sums[b][c][2] and a second tiny launch adds them over the grids in order into dgamma / dbeta
-template <typename T>
+template <typename T, int NR = 0>
 __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                                            const float* __restrict__ scale_shift, const float* __restrict__ mean_rstd,
                                                            T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ sums,
@@ -490,6 +542,32 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const T* __restrict__
     float s1[G], s2[G];
 #pragma unroll
     for (int i = 0; i < G; ++i) s1[i] = s2[i] = 0.f;
+    constexpr int NRR = NR > 0 ? NR : 1;
+    uint4 xr[NRR], gr[NRR];                       // NR > 0: this thread's rows of x and of the MASKED gradient, as they lie in memory
+    if constexpr (NR > 0) {
+        uint4 yr[NRR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const size_t off = ((size_t)b * V + rl + j * BNS_ROWS) * C + c0;
+            xr[j] = *reinterpret_cast<const uint4*>(x + off);
+            gr[j] = *reinterpret_cast<const uint4*>(dy + off);
+            if (relu && !remask) yr[j] = *reinterpret_cast<const uint4*>(y + off);
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            float xv[G], gv[G], yv[G];
+            Gran<T>::unpack(xr[j], xv);
+            Gran<T>::unpack(gr[j], gv);
+            if (relu && !remask) Gran<T>::unpack(yr[j], yv);
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                if (remask) gv[i] = (xv[i] * sc[i] + sh[i]) > 0.f ? gv[i] : 0.f;
+                else if (relu) gv[i] = yv[i] > 0.f ? gv[i] : 0.f;
+                s1[i] += gv[i]; s2[i] += gv[i] * (xv[i] - mu[i]) * rs[i];
+            }
+            if (relu) gr[j] = Gran<T>::pack(gv);      // exact: every element is the stored value or zero
+        }
+    } else {
 #pragma unroll 4
     for (int v = rl; v < V; v += BNS_ROWS) {
         const size_t off = ((size_t)b * V + v) * C + c0;
@@ -503,6 +581,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const T* __restrict__
             else if (relu) gv[i] = yv[i] > 0.f ? gv[i] : 0.f;
             s1[i] += gv[i]; s2[i] += gv[i] * (xv[i] - mu[i]) * rs[i];
         }
+    }
     }
     bns_reduce<G>(s1, s2, red, t);
     __syncthreads();
@@ -518,6 +597,23 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const T* __restrict__
     float c1[G], c2[G];
 #pragma unroll
     for (int i = 0; i < G; ++i) { c1[i] = s_c1[col * G + i]; c2[i] = s_c2[col * G + i]; }
+    if constexpr (NR > 0) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const size_t off = ((size_t)b * V + rl + j * BNS_ROWS) * C + c0;
+            float xv[G], gv[G];
+            Gran<T>::unpack(xr[j], xv);
+            Gran<T>::unpack(gr[j], gv);
+            if (dres) *reinterpret_cast<uint4*>(dres + off) = gr[j];
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const float xh = (xv[i] - mu[i]) * rs[i];
+                xv[i] = sc[i] * (gv[i] - c1[i] - xh * c2[i]);
+            }
+            Gran<T>::st(dx + off, xv);
+        }
+        return;
+    }
 #pragma unroll 4
     for (int v = rl; v < V; v += BNS_ROWS) {
         const size_t off = ((size_t)b * V + v) * C + c0;
@@ -585,6 +681,7 @@ __global__ void bn_tail_batched_kernel(const BnTailDesc* __restrict__ descs, int
         d.o1[c] = accumulate ? d.o1[c] + (float)db : (float)db;
     }
 }
+static int g_bn_small_regs = 1;  // tuning (include/dreg_nerf_tuning.h): the small BatchNorms keep their rows in registers between the two phases (8^3 / 4^3 volumes)
 static int g_bn_store_g = 1;     // tuning (include/dreg_nerf_tuning.h): residual BatchNorm backward stores the masked gradient in the statistics pass
 static int g_bn_debug_skip = 0;      // measurement only (tools/ab_step.py): bit 0 / bit 1 leave out the forward / backward statistics pass (stale statistics)
 static int g_bn_small_maxv = 512;    // tuning (include/dreg_nerf_tuning.h): largest per-grid volume served by the fused kernels, 0 = never
@@ -1202,6 +1299,7 @@ extern "C" {
 
 void dreg_bn_set_debug_skip(int mask) { g_bn_debug_skip = mask; }
 void dreg_bn_set_store_g(int enable) { g_bn_store_g = enable ? 1 : 0; }
+void dreg_bn_set_small_regs(int enable) { g_bn_small_regs = enable ? 1 : 0; }
 void dreg_bn_set_small_max_voxels(int v) { g_bn_small_maxv = v; }
 int dreg_bn_num_chunks(int V) { const int r = bn_rows_per_chunk(V); return (V + r - 1) / r; }
 
@@ -1256,10 +1354,12 @@ static int bn3d_fwd_impl(const void* x, const void* res, void* y, const float* g
     if (train && bn_small_ok(B, V, C, G)) {      // 16^3 / 8^3 / 4^3 levels: statistics + apply in one launch, running statistics in a tiny second one
         const dim3 g1(CG / BNS_COLS, B);
         float* var = var_keep ? var_keep : workspace;   // [B][C] biased variances (the workspace holds >= B * chunks * C * 2 floats)
-        if (dtype == 0) hipLaunchKernelGGL(bn_small_fwd_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y, gamma, beta,
-                                           scale_shift, mean_rstd, var, V, C, eps, relu);
-        else hipLaunchKernelGGL(bn_small_fwd_kernel<float>, g1, dim3(256), 0, st, (const float*)x, (const float*)res, (float*)y, gamma, beta,
-                                scale_shift, mean_rstd, var, V, C, eps, relu);
+#define BNS_FWD(Tt, NRv) hipLaunchKernelGGL((bn_small_fwd_kernel<Tt, NRv>), g1, dim3(256), 0, st, (const Tt*)x, (const Tt*)res, (Tt*)y, gamma, beta, \
+                                            scale_shift, mean_rstd, var, V, C, eps, relu)
+        const int nr = !g_bn_small_regs ? 0 : (V == 8 * BNS_ROWS ? 8 : (V == BNS_ROWS ? 1 : 0));
+        if (dtype == 0) { if (nr == 8) BNS_FWD(bf16_t, 8); else if (nr == 1) BNS_FWD(bf16_t, 1); else BNS_FWD(bf16_t, 0); }
+        else { if (nr == 8) BNS_FWD(float, 8); else if (nr == 1) BNS_FWD(float, 1); else BNS_FWD(float, 0); }
+#undef BNS_FWD
         DREG_LAUNCH_CHECK();
         if (var_keep && deferred) { *deferred = 1; return DREG_OK; }
         hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, st, mean_rstd, var, running_mean, running_var, B, V, C, momentum);
@@ -1319,10 +1419,12 @@ static int bn3d_bwd_impl(const void* x, const void* dy, const void* y, const flo
     if (bn_small_ok(B, V, C, G)) {
         const dim3 g1(CG / BNS_COLS, B);
         float* sums = sums_keep ? sums_keep : coef;   // [B][C][2]: per-grid (sum g, sum g xhat)
-        if (dtype == 0) hipLaunchKernelGGL(bn_small_bwd_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)y, scale_shift, mean_rstd,
-                                           (bf16_t*)dx, (bf16_t*)dres, sums, V, C, relu);
-        else hipLaunchKernelGGL(bn_small_bwd_kernel<float>, g1, dim3(256), 0, st, (const float*)x, (const float*)dy, (const float*)y, scale_shift, mean_rstd,
-                                (float*)dx, (float*)dres, sums, V, C, relu);
+#define BNS_BWD(Tt, NRv) hipLaunchKernelGGL((bn_small_bwd_kernel<Tt, NRv>), g1, dim3(256), 0, st, (const Tt*)x, (const Tt*)dy, (const Tt*)y, scale_shift, mean_rstd, \
+                                            (Tt*)dx, (Tt*)dres, sums, V, C, relu)
+        const int nr = !g_bn_small_regs ? 0 : (V == 8 * BNS_ROWS ? 8 : (V == BNS_ROWS ? 1 : 0));
+        if (dtype == 0) { if (nr == 8) BNS_BWD(bf16_t, 8); else if (nr == 1) BNS_BWD(bf16_t, 1); else BNS_BWD(bf16_t, 0); }
+        else { if (nr == 8) BNS_BWD(float, 8); else if (nr == 1) BNS_BWD(float, 1); else BNS_BWD(float, 0); }
+#undef BNS_BWD
         DREG_LAUNCH_CHECK();
         if (sums_keep && deferred) { *deferred = 1; return DREG_OK; }
         hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, dgamma, dbeta, B, C, accumulate);

@@ -66,6 +66,7 @@ SIGNATURES = {
     "dreg_conv3d_wgrad_variant": (I, [I] * 10),
     "dreg_bn_set_debug_skip": (None, [I]),
     "dreg_bn_set_store_g": (None, [I]),
+    "dreg_bn_set_small_regs": (None, [I]),
     "dreg_exec_set_fuse_stem": (None, [I]),
     "dreg_exec_set_bn_batch_tails": (None, [I]),
     "dreg_exec_set_sparse_grads": (None, [I]),

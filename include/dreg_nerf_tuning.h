@@ -30,6 +30,7 @@ void dreg_exec_set_sparse_grads(int on);              /* 1 (default): executors 
 void dreg_exec_set_bn_batch_tails(int on);            /* 1 (default): executors created from now on batch the small BatchNorms' running-statistics / dgamma-dbeta launches per pass */
 void dreg_exec_set_fuse_stem(int on);                 /* 1 (default): executors created from now on fuse the stem's BatchNorm + ReLU + max-pool (fpn_ops.hip) */
 void dreg_bn_set_store_g(int enable);                /* 1 (default): the backward of a residual + ReLU BatchNorm stores the masked gradient (= the residual gradient) in its statistics pass; the apply pass reads it instead of dy and y */
+void dreg_bn_set_small_regs(int enable);             /* 1 (default): the one-launch BatchNorms of the 8^3 / 4^3 volumes load their rows once and keep them in registers between statistics and apply */
 void dreg_bn_set_debug_skip(int mask);                /* MEASUREMENT ONLY (wrong results): bit 0 / 1 leave out the forward / backward statistics pass of the large BatchNorms */
 /* which bf16 weight-gradient kernel a launch of this shape runs: BM * 1000 + BNC (256256 = the 8-wave tile, 256128 = 4 waves / 32-voxel stages); for profiler labels */
 int dreg_conv3d_wgrad_variant(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int rows, int nrows, int occ);

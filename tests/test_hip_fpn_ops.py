@@ -403,6 +403,38 @@ def test_batchnorm_backward_with_the_masked_gradient_stored_once_is_bit_identica
         assert torch.equal(a, c)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_res", [True, False])
+@pytest.mark.parametrize("D,C", [(8, 256), (4, 512)])
+def test_small_batchnorm_with_rows_in_registers_is_bit_identical(D, C, with_res, dtype):
+    """8^3 / 4^3 volumes (dreg_bn_set_small_regs): rows loaded once and kept in registers between the statistics and the apply phase
+    against the form that walks them twice — forward output, running statistics and every gradient."""
+    from dreg_nerf_amd import lib as L
+    dev = _dev()
+    lib = L.load()
+    g = torch.Generator().manual_seed(D * C)
+    B = 8
+    x = (torch.randn(B, D, D, D, C, generator=g) * 2 + 0.5).to(dev, dtype)
+    res = torch.randn(B, D, D, D, C, generator=g).to(dev, dtype)
+    gy = torch.randn(B, D, D, D, C, generator=g).to(dev, dtype)
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+    got = []
+    try:
+        for on in (1, 0):
+            lib.dreg_bn_set_small_regs(on)
+            xd, rd = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+            gd, bd = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+            rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+            y = ops.batchnorm(xd, gd, bd, rm, rv, res=rd if with_res else None, relu=True, train=True)
+            y.backward(gy)
+            got.append([y.detach(), rm, rv, xd.grad, gd.grad, bd.grad] + ([rd.grad] if with_res else []))
+    finally:
+        lib.dreg_bn_set_small_regs(1)
+    for a, c in zip(got[0], got[1]):
+        assert torch.isfinite(a.float()).all() and a.float().abs().max() > 0
+        assert torch.equal(a, c)
+
+
 def test_batchnorm_eval():
     dev = _dev()
     g = torch.Generator().manual_seed(3)
