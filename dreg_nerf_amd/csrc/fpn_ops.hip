@@ -736,24 +736,43 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __re
         float acc[G];
 #pragma unroll
         for (int k = 0; k < G; ++k) acc[k] = 0.f;
-        for (int oz = max(0, iz / 2); oz <= min(Do - 1, (iz + 1) / 2); ++oz) {
-            const int dz = iz - 2 * oz + 1; if (dz < 0 || dz > 2) continue;
-            for (int oy = max(0, iy / 2); oy <= min(Ho - 1, (iy + 1) / 2); ++oy) {
-                const int dyy = iy - 2 * oy + 1; if (dyy < 0 || dyy > 2) continue;
-                for (int ox = max(0, ix / 2); ox <= min(Wo - 1, (ix + 1) / 2); ++ox) {
-                    const int dxx = ix - 2 * ox + 1; if (dxx < 0 || dxx > 2) continue;
-                    const int tap = (dz * 3 + dyy) * 3 + dxx;
-                    const size_t o = ((((size_t)b * Do + oz) * Ho + oy) * Wo + ox) * C + (size_t)cg * G;
-                    float g[G];
-                    Gran<T>::ld(dy + o, g);
+        // The windows that contain input voxel i: per axis the one starting at floor(i/2) and, for odd i, the next one — at most eight.
+        // They are enumerated statically (same z, y, x ascending order as a loop nest), so all their loads — gradient granule and the
+        // G arg-max bytes as ONE word — are in flight together instead of one dependent pair per loop iteration.
+        const int oz0 = iz >> 1, oy0 = iy >> 1, ox0 = ix >> 1;
+        uint4 gq[8];
+        uint2 aq[8];
+        bool ok[8];
+        int tp[8];
 #pragma unroll
-                    for (int k = 0; k < G; ++k) if (arg[o + k] == tap) acc[k] += g[k];
-                }
+        for (int u = 0; u < 8; ++u) {
+            const int uz = u >> 2, uy = (u >> 1) & 1, ux = u & 1;
+            const int oz = oz0 + uz, oy = oy0 + uy, ox = ox0 + ux;
+            ok[u] = (!uz || (iz & 1)) && (!uy || (iy & 1)) && (!ux || (ix & 1)) && oz < Do && oy < Ho && ox < Wo;
+            tp[u] = ((iz - 2 * oz + 1) * 3 + (iy - 2 * oy + 1)) * 3 + (ix - 2 * ox + 1);
+            if (ok[u]) {
+                const size_t o = ((((size_t)b * Do + oz) * Ho + oy) * Wo + ox) * C + (size_t)cg * G;
+                gq[u] = *reinterpret_cast<const uint4*>(dy + o);
+                if constexpr (G == 8) aq[u] = *reinterpret_cast<const uint2*>(arg + o);
+                else aq[u] = make_uint2(*reinterpret_cast<const uint32_t*>(arg + o), 0u);
             }
         }
+        uint4 pq = make_uint4(0, 0, 0, 0);
+        if (accumulate) pq = *reinterpret_cast<const uint4*>(dx + i * G);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (ok[u]) {
+                float g[G];
+                Gran<T>::unpack(gq[u], g);
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const uint32_t a = ((k < 4 ? aq[u].x : aq[u].y) >> (8 * (k & 3))) & 0xffu;
+                    if ((int)a == tp[u]) acc[k] += g[k];
+                }
+            }
         if (accumulate) {       // a second contribution to an existing gradient (the FPN lateral's): one read-modify-write, no temporary
             float prev[G];
-            Gran<T>::ld(dx + i * G, prev);
+            Gran<T>::unpack(pq, prev);
 #pragma unroll
             for (int k = 0; k < G; ++k) acc[k] += prev[k];
         }
@@ -1126,13 +1145,33 @@ __global__ __launch_bounds__(256) void trilinear_gather_bwd_gather_kernel(const 
             if (wgt != 0.f) n = fine_map[(size_t)b * Vf + ((size_t)x * Yr + y) * Zr + z];
         }
         unsigned long long m = __ballot(n >= 0);
+        // four contributing points per round: their rows are requested together and added in the same (ascending) order — one row in
+        // flight per wave made the kernel a chain of ~20 memory round trips per coarse voxel
         while (m) {
-            const int l = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int nn = __shfl(n, l, 64);
-            const float ww = __shfl(wgt, l, 64);
+            constexpr int U = 4;
+            int nn[U];
+            float ww[U], r[U][CPL];
+            bool ok[U];
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) acc[k] += dfeat[(size_t)nn * C + lane + 64 * k] * ww;
+            for (int u = 0; u < U; ++u) {
+                ok[u] = m != 0;                                   // wave-uniform
+                const int l = ok[u] ? __ffsll((long long)m) - 1 : 0;
+                if (ok[u]) m &= m - 1;
+                nn[u] = __shfl(n, l, 64);
+                ww[u] = __shfl(wgt, l, 64);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (ok[u]) {
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) r[u][k] = dfeat[(size_t)nn[u] * C + lane + 64 * k];
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (ok[u]) {
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) acc[k] += r[u][k] * ww[u];
+                }
         }
     }
 #pragma unroll
