@@ -983,13 +983,23 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     float s[G];
 #pragma unroll
     for (int i = 0; i < G; ++i) s[i] = 0.f;
-    if (r0 < rpi)
-        for (size_t v = v0 + r0; v < v1; v += rpi) {
-            float x[G];
-            Gran<T>::ld(g + v * C + (size_t)cg * G, x);
+    if (r0 < rpi) {
+        constexpr int UN = 4;                      // rows in flight per thread; added in row order (bit-identical to one at a time)
+        for (size_t v = v0 + r0; v < v1; v += (size_t)rpi * UN) {
+            uint4 q[UN];
 #pragma unroll
-            for (int i = 0; i < G; ++i) s[i] += x[i];
+            for (int u = 0; u < UN; ++u)
+                if (v + (size_t)u * rpi < v1) q[u] = *reinterpret_cast<const uint4*>(g + (v + (size_t)u * rpi) * C + (size_t)cg * G);
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (v + (size_t)u * rpi < v1) {
+                    float x[G];
+                    Gran<T>::unpack(q[u], x);
+#pragma unroll
+                    for (int i = 0; i < G; ++i) s[i] += x[i];
+                }
         }
+    }
     __shared__ float red[256][9];
 #pragma unroll
     for (int i = 0; i < G; ++i) red[t][i] = s[i];
@@ -1218,13 +1228,26 @@ __global__ __launch_bounds__(256) void colsum_rows_partial_kernel(const T* __res
     float s[G];
 #pragma unroll
     for (int i = 0; i < G; ++i) s[i] = 0.f;
-    if (r0 < rpi)
-        for (int v = v0 + r0; v < v1; v += rpi) {
-            float x[G];
-            Gran<T>::ld(g + (size_t)rows[v] * C + (size_t)cg * G, x);
+    if (r0 < rpi) {
+        constexpr int UN = 4;                      // rows in flight per thread; added in list order
+        for (int v = v0 + r0; v < v1; v += rpi * UN) {
+            int rw[UN];
+            uint4 q[UN];
 #pragma unroll
-            for (int i = 0; i < G; ++i) s[i] += x[i];
+            for (int u = 0; u < UN; ++u) rw[u] = v + u * rpi < v1 ? rows[v + u * rpi] : -1;
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (rw[u] >= 0) q[u] = *reinterpret_cast<const uint4*>(g + (size_t)rw[u] * C + (size_t)cg * G);
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (rw[u] >= 0) {
+                    float x[G];
+                    Gran<T>::unpack(q[u], x);
+#pragma unroll
+                    for (int i = 0; i < G; ++i) s[i] += x[i];
+                }
         }
+    }
     __shared__ float red[256][9];
 #pragma unroll
     for (int i = 0; i < G; ++i) red[t][i] = s[i];

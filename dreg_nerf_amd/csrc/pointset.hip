@@ -13,6 +13,14 @@
 
 // ------------------------------------------------------------------------------------------------ LayerNorm (C = 256)
 // y = LN(x) * g + b [+ pe]; one wave per row, 4 channels per lane.  Saves (mean, rstd) per row.
+// four consecutive elements as ONE load / store (8 bytes of bf16, 16 of fp32)
+__device__ __forceinline__ void ld4(const float* p, float (&v)[4]) { const float4 q = *reinterpret_cast<const float4*>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+__device__ __forceinline__ void ld4(const bf16_t* p, float (&v)[4]) {
+    const uint2 q = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u); v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+}
+__device__ __forceinline__ void st4(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void st4(bf16_t* p, const float (&v)[4]) { *reinterpret_cast<uint2*>(p) = make_uint2(f2bf2(v[0], v[1]), f2bf2(v[2], v[3])); }
 template <typename TO>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
                                                             const float* __restrict__ pe, TO* __restrict__ y, float* __restrict__ stats, int N, float eps)
@@ -27,8 +35,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4), bb = *reinterpret_cast<const float4*>(b + lane * 4);
     float o[4] = {d0 * rstd * gg.x + bb.x, d1 * rstd * gg.y + bb.y, d2 * rstd * gg.z + bb.z, d3 * rstd * gg.w + bb.w};
     if (pe) { const float4 p = *reinterpret_cast<const float4*>(pe + (size_t)row * 256 + lane * 4); o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) Elem<TO>::st(y + (size_t)row * 256 + lane * 4 + i, o[i]);
+    st4(y + (size_t)row * 256 + lane * 4, o);
     if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
 // dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  partial dgamma/dbeta per block of rows
@@ -41,24 +48,40 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4);
     float dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
     const int r0 = blockIdx.x * rows_per_block;
-    for (int row = r0 + wave; row < min(r0 + rows_per_block, N); row += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * 256 + lane * 4);
-        float d[4];
+    // a wave's rows four at a time: every load of the four rows is issued before the first row's reductions (the rows were a chain of
+    // load -> two wave reductions -> store, one row's loads in flight); per-lane dgamma / dbeta sums stay in row order
+    const int rend = min(r0 + rows_per_block, N);
+    const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
+    for (int rb = r0 + wave; rb < rend; rb += 16) {
+        constexpr int U = 4;
+        float4 v[U], old[U];
+        float d[U][4], mean[U], rstd[U];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) d[i] = Elem<TG>::ld(dy + (size_t)row * 256 + lane * 4 + i);
-        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-        const float xh[4] = {(v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd};
-        const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
-        float s1 = 0.f, s2 = 0.f;
+        for (int u = 0; u < U; ++u) {
+            const int row = rb + 4 * u;
+            if (row < rend) {
+                v[u] = *reinterpret_cast<const float4*>(x + (size_t)row * 256 + lane * 4);
+                ld4(dy + (size_t)row * 256 + lane * 4, d[u]);
+                mean[u] = stats[2 * row]; rstd[u] = stats[2 * row + 1];
+                if (dx_add) old[u] = *reinterpret_cast<const float4*>(dx_add + (size_t)row * 256 + lane * 4);
+            }
+        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { s1 += d[i] * gv[i]; s2 += d[i] * gv[i] * xh[i]; dg[i] += d[i] * xh[i]; db[i] += d[i]; }
-        s1 = wave_sum(s1) * (1.f / 256.f); s2 = wave_sum(s2) * (1.f / 256.f);
-        float o[4];
+        for (int u = 0; u < U; ++u) {
+            const int row = rb + 4 * u;
+            if (row < rend) {
+                const float xh[4] = {(v[u].x - mean[u]) * rstd[u], (v[u].y - mean[u]) * rstd[u], (v[u].z - mean[u]) * rstd[u], (v[u].w - mean[u]) * rstd[u]};
+                float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = rstd * (d[i] * gv[i] - s1 - xh[i] * s2);
-        float* p = dx + (size_t)row * 256 + lane * 4;
-        if (dx_add) { const float4 old = *reinterpret_cast<const float4*>(dx_add + (size_t)row * 256 + lane * 4); o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w; }
-        *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+                for (int i = 0; i < 4; ++i) { s1 += d[u][i] * gv[i]; s2 += d[u][i] * gv[i] * xh[i]; dg[i] += d[u][i] * xh[i]; db[i] += d[u][i]; }
+                s1 = wave_sum(s1) * (1.f / 256.f); s2 = wave_sum(s2) * (1.f / 256.f);
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = rstd[u] * (d[u][i] * gv[i] - s1 - xh[i] * s2);
+                if (dx_add) { o[0] += old[u].x; o[1] += old[u].y; o[2] += old[u].z; o[3] += old[u].w; }
+                *reinterpret_cast<float4*>(dx + (size_t)row * 256 + lane * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
     }
     __shared__ float red[4][512];
 #pragma unroll
