@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void infonce_nn_kernel(const float* __restrict
     float a[3];
     for (int c = 0; c < 3; ++c) a[c] = s[0] * Pm[c * 4] + s[1] * Pm[c * 4 + 1] + s[2] * Pm[c * 4 + 2] + Pm[c * 4 + 3];
     float best = 3.4e38f; int bj = 0x7fffffff;
+#pragma unroll 4                                     // the four iterations' coordinate loads are independent: in flight together
     for (int j = lane; j < nt; j += 64) {
         const float* q = xyz + (size_t)(t0 + j) * 3;
         const float dx = a[0] - q[0], dy = a[1] - q[1], dz = a[2] - q[2];
@@ -148,12 +149,13 @@ __global__ __launch_bounds__(256) void infonce_rows_kernel(float* __restrict__ l
     const int jn = nn[wv];
     // online logsumexp over the included columns
     float mx = -3.4e38f, se = 0.f;
+#pragma unroll 4
     for (int j = lane; j < nt; j += 64) {
         const float* q = xyz + (size_t)(t0 + j) * 3;
         const float dx = a[0] - q[0], dy = a[1] - q[1], dz = a[2] - q[2];
         const bool inc = (j == jn) || !(sqrtf(dx * dx + dy * dy + dz * dz) < r_n);
+        const float v = lg[j];                       // unconditional: the load does not wait for the distance test
         if (inc) {
-            const float v = lg[j];
             if (v > mx) { se = se * expf(mx - v) + 1.f; mx = v; } else se += expf(v - mx);
         }
     }
@@ -170,11 +172,13 @@ __global__ __launch_bounds__(256) void infonce_rows_kernel(float* __restrict__ l
     if (!write_grad) return;
     const float cnt = count[p];
     const float k = (mask[wv] > 0.f && cnt > 0.f) ? scale / cnt : 0.f;
+#pragma unroll 4
     for (int j = lane; j < nt; j += 64) {
         const float* q = xyz + (size_t)(t0 + j) * 3;
         const float dx = a[0] - q[0], dy = a[1] - q[1], dz = a[2] - q[2];
         const bool inc = (j == jn) || !(sqrtf(dx * dx + dy * dy + dz * dz) < r_n);
-        float g = inc ? expf(lg[j] - lse) : 0.f;
+        const float v = lg[j];
+        float g = inc ? expf(v - lse) : 0.f;
         if (j == jn) g -= 1.f;
         lg[j] = g * k;
     }
