@@ -1138,6 +1138,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, TO* __restr
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = 0.f;
+#pragma unroll 4                                 // the slices' loads are independent: four slices in flight, added in slice order
         for (int sp = 0; sp < nsplit; ++sp) {
             const float4 a = *reinterpret_cast<const float4*>(part + sp * slice + i * 8), b = *reinterpret_cast<const float4*>(part + sp * slice + i * 8 + 4);
             v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;

@@ -1014,6 +1014,7 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0.0;
+#pragma unroll 4
     for (int k = lane; k < nchunks; k += 64) s += partial[(size_t)k * C + c];
     s = wave_sum_d(s);
     if (lane == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;

@@ -95,6 +95,7 @@ __global__ void layernorm_bwd_final_kernel(const float* __restrict__ part, float
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= 512) return;
     double s = 0.0;
+#pragma unroll 8                                     // ~10 partials per lane: all in flight, added in order
     for (int k = lane; k < nblk; k += 64) s += part[(size_t)k * 512 + c];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -238,16 +239,19 @@ template <typename Acc> __device__ void kabsch_body(const Acc& X, int N, float* 
         const double r = red[0]; __syncthreads(); return r;
     };
     double sw = 0.0;
+#pragma unroll 4
     for (int i = t; i < N; i += 256) sw += X.w(i);
     sw = block_sum(sw);
     const double norm = fmax(sw, (double)eps);
     double ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
+#pragma unroll 2
     for (int i = t; i < N; i += 256) {
         const double wn = X.w(i) / norm;
         for (int c = 0; c < 3; ++c) { ca[c] += wn * X.a(i, c); cb[c] += wn * X.b(i, c); }
     }
     for (int c = 0; c < 3; ++c) { ca[c] = block_sum(ca[c]); cb[c] = block_sum(cb[c]); }
     double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll 2
     for (int i = t; i < N; i += 256) {
         const double wn = X.w(i) / norm;
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r][c] += (X.a(i, r) - ca[r]) * (X.b(i, c) - cb[c]) * wn;
@@ -339,6 +343,7 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restri
     if (feats != nullptr)
         for (int c0 = lane * 4; c0 < C; c0 += 256) {
             float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll 4
             for (uint32_t j = s0; j < s1; ++j) {
                 const float4 v = *reinterpret_cast<const float4*>(feats + (size_t)order[j] * C + c0);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
