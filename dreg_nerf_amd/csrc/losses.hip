@@ -88,16 +88,27 @@ __global__ __launch_bounds__(256) void reg_point_losses_kernel(
 
 // ------------------------------------------------------------------------------------------------ InfoNCE
 // pass 1 (needs only coordinates): nearest target of every transformed source point, its distance test, the pair's positive
-// count (atomic adds of 0/1: exact in fp32, order independent).  One wave per source row.  nn [Rs] (index inside the pair's
+// count (a sum of 0/1: exact in fp32, order independent; formed by a second tiny launch).  One wave per source row.  nn [Rs] (index inside the pair's
 // target set; the lowest index on ties), mask [Rs] (0/1), count [P] (zeroed by the caller); rows indexed by their position in
 // the concatenated SOURCE row list (src_off[p] = sum of ns of earlier pairs).
+constexpr int INFONCE_LDS_PTS = 2048;     // target points staged per workgroup (24 KB); larger sets are read from global memory
 __global__ __launch_bounds__(256) void infonce_nn_kernel(const float* __restrict__ xyz, const float* __restrict__ pose, const int* __restrict__ probs,
                                                          const int* __restrict__ src_off, int* __restrict__ nn, float* __restrict__ mask,
                                                          float* __restrict__ count, int P, int total_src, float r_p)
 {
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // the target points of the workgroup's pair once into LDS (its four source rows almost always share the pair): the loop below
+    // was a chain of ~19 L2 round trips per wave (95 % of the wave cycles parked)
+    __shared__ float sx[INFONCE_LDS_PTS * 3];
+    int p0 = 0;
+    while (p0 + 1 < P && src_off[p0 + 1] <= (int)blockIdx.x * 4) ++p0;
+    const int t00 = probs[p0 * 4 + 2], nt0 = probs[p0 * 4 + 3];
+    const bool staged = nt0 <= INFONCE_LDS_PTS;
+    if (staged)
+        for (int k = threadIdx.x; k < nt0 * 3; k += 256) sx[k] = xyz[(size_t)t00 * 3 + k];
+    __syncthreads();
     if (wv >= total_src) return;
-    int p = 0;
+    int p = p0;
     while (p + 1 < P && src_off[p + 1] <= wv) ++p;
     const int i = wv - src_off[p];
     const int s0 = probs[p * 4], t0 = probs[p * 4 + 2], nt = probs[p * 4 + 3];
@@ -106,9 +117,10 @@ __global__ __launch_bounds__(256) void infonce_nn_kernel(const float* __restrict
     float a[3];
     for (int c = 0; c < 3; ++c) a[c] = s[0] * Pm[c * 4] + s[1] * Pm[c * 4 + 1] + s[2] * Pm[c * 4 + 2] + Pm[c * 4 + 3];
     float best = 3.4e38f; int bj = 0x7fffffff;
+    const float* tb = (staged && p == p0) ? sx : xyz + (size_t)t0 * 3;      // same values either way
 #pragma unroll 4                                     // the four iterations' coordinate loads are independent: in flight together
     for (int j = lane; j < nt; j += 64) {
-        const float* q = xyz + (size_t)(t0 + j) * 3;
+        const float* q = tb + (size_t)j * 3;
         const float dx = a[0] - q[0], dy = a[1] - q[1], dz = a[2] - q[2];
         const float d2 = dx * dx + dy * dy + dz * dz;
         if (d2 < best) { best = d2; bj = j; }
@@ -123,7 +135,7 @@ __global__ __launch_bounds__(256) void infonce_nn_kernel(const float* __restrict
         nn[wv] = bj;
         const float m = sqrtf(best) < r_p ? 1.f : 0.f;
         mask[wv] = m;
-        if (m > 0.f) atomicAdd(count + p, 1.f);
+        // the pair's positive count is summed by infonce_count_kernel: 4,876 float atomics on four addresses were most of this kernel
     }
 }
 
@@ -136,8 +148,16 @@ __global__ __launch_bounds__(256) void infonce_rows_kernel(float* __restrict__ l
                                                            float* __restrict__ loss_row, int P, int total_src, float r_n, float scale, int write_grad)
 {
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    __shared__ float sx[INFONCE_LDS_PTS * 3];          // as in infonce_nn_kernel
+    int p0 = 0;
+    while (p0 + 1 < P && src_off[p0 + 1] <= (int)blockIdx.x * 4) ++p0;
+    const int t00 = probs[p0 * 4 + 2], nt0 = probs[p0 * 4 + 3];
+    const bool staged = nt0 <= INFONCE_LDS_PTS;
+    if (staged)
+        for (int k = threadIdx.x; k < nt0 * 3; k += 256) sx[k] = xyz[(size_t)t00 * 3 + k];
+    __syncthreads();
     if (wv >= total_src) return;
-    int p = 0;
+    int p = p0;
     while (p + 1 < P && src_off[p + 1] <= wv) ++p;
     const int i = wv - src_off[p];
     const int s0 = probs[p * 4], t0 = probs[p * 4 + 2], nt = probs[p * 4 + 3];
@@ -145,13 +165,14 @@ __global__ __launch_bounds__(256) void infonce_rows_kernel(float* __restrict__ l
     const float* s = xyz + (size_t)(s0 + i) * 3;
     float a[3];
     for (int c = 0; c < 3; ++c) a[c] = s[0] * Pm[c * 4] + s[1] * Pm[c * 4 + 1] + s[2] * Pm[c * 4 + 2] + Pm[c * 4 + 3];
+    const float* tb = (staged && p == p0) ? sx : xyz + (size_t)t0 * 3;
     float* lg = logits + logit_off[p] + (size_t)i * nt;
     const int jn = nn[wv];
     // online logsumexp over the included columns
     float mx = -3.4e38f, se = 0.f;
 #pragma unroll 4
     for (int j = lane; j < nt; j += 64) {
-        const float* q = xyz + (size_t)(t0 + j) * 3;
+        const float* q = tb + (size_t)j * 3;
         const float dx = a[0] - q[0], dy = a[1] - q[1], dz = a[2] - q[2];
         const bool inc = (j == jn) || !(sqrtf(dx * dx + dy * dy + dz * dz) < r_n);
         const float v = lg[j];                       // unconditional: the load does not wait for the distance test
@@ -174,7 +195,7 @@ __global__ __launch_bounds__(256) void infonce_rows_kernel(float* __restrict__ l
     const float k = (mask[wv] > 0.f && cnt > 0.f) ? scale / cnt : 0.f;
 #pragma unroll 4
     for (int j = lane; j < nt; j += 64) {
-        const float* q = xyz + (size_t)(t0 + j) * 3;
+        const float* q = tb + (size_t)j * 3;
         const float dx = a[0] - q[0], dy = a[1] - q[1], dz = a[2] - q[2];
         const bool inc = (j == jn) || !(sqrtf(dx * dx + dy * dy + dz * dz) < r_n);
         const float v = lg[j];
@@ -225,13 +246,28 @@ int dreg_reg_point_losses(const float* gt, const float* tilde, const float* ov, 
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
+// count[p] = number of positives of pair p (sum of its 0/1 mask entries: exact in fp32 in any order); one workgroup per pair
+__global__ __launch_bounds__(256) void infonce_count_kernel(const float* __restrict__ mask, const int* __restrict__ probs, const int* __restrict__ src_off,
+                                                            float* __restrict__ count)
+{
+    __shared__ float red[256];
+    const int p = blockIdx.x, t = threadIdx.x, ns = probs[p * 4 + 1];
+    float c = 0.f;
+#pragma unroll 4
+    for (int i = t; i < ns; i += 256) c += mask[src_off[p] + i];
+    red[t] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
+    if (t == 0) count[p] = red[0];
+}
 int dreg_infonce_nn(const float* xyz, const float* pose, const int* probs, const int* src_off, int* nn, float* mask, float* count, int P,
                     int total_src, float r_p, void* stream)
 {
     if (P <= 0 || total_src <= 0) return DREG_OK;
-    if (hipMemsetAsync(count, 0, sizeof(float) * P, (hipStream_t)stream) != hipSuccess) return DREG_ELAUNCH;
     hipLaunchKernelGGL(infonce_nn_kernel, dim3((total_src + 3) / 4), dim3(256), 0, (hipStream_t)stream, xyz, pose, probs, src_off, nn, mask, count,
                        P, total_src, r_p);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(infonce_count_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, mask, probs, src_off, count);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
