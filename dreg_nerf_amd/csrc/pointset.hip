@@ -231,17 +231,29 @@ __global__ __launch_bounds__(256) void kabsch_pairs_kernel(const float* __restri
 template <typename Acc> __device__ void kabsch_body(const Acc& X, int N, float* __restrict__ o, float eps)
 {
     const int t = threadIdx.x;
-    __shared__ double red[256];
-    __shared__ double acc[16];
-    auto block_sum = [&](double v) -> double {
-        red[t] = v; __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) { if (t < s) red[t] += red[t + s]; __syncthreads(); }
-        const double r = red[0]; __syncthreads(); return r;
+    __shared__ double red[9][256];
+    __shared__ double tot[9];
+    // Sums of NV quantities over the 256 threads with TWO barriers: the additions are exactly those of a halving tree over red[0..255]
+    // (s = 128, 64 across the waves: (a + c) + (b + d); s = 32 .. 1 inside wave 0 as shuffles), which took nine barriers per quantity.
+    auto block_sums = [&](double* v, int NV) {
+        for (int q = 0; q < NV; ++q) red[q][t] = v[q];
+        __syncthreads();
+        if (t < 64) {
+            for (int q = 0; q < NV; ++q) {
+                double a = (red[q][t] + red[q][t + 128]) + (red[q][t + 64] + red[q][t + 192]);
+#pragma unroll
+                for (int s = 32; s > 0; s >>= 1) a += __shfl_down(a, s, 64);
+                if (t == 0) tot[q] = a;
+            }
+        }
+        __syncthreads();
+        for (int q = 0; q < NV; ++q) v[q] = tot[q];
+        __syncthreads();
     };
     double sw = 0.0;
 #pragma unroll 4
     for (int i = t; i < N; i += 256) sw += X.w(i);
-    sw = block_sum(sw);
+    block_sums(&sw, 1);
     const double norm = fmax(sw, (double)eps);
     double ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
 #pragma unroll 2
@@ -249,14 +261,18 @@ template <typename Acc> __device__ void kabsch_body(const Acc& X, int N, float* 
         const double wn = X.w(i) / norm;
         for (int c = 0; c < 3; ++c) { ca[c] += wn * X.a(i, c); cb[c] += wn * X.b(i, c); }
     }
-    for (int c = 0; c < 3; ++c) { ca[c] = block_sum(ca[c]); cb[c] = block_sum(cb[c]); }
+    {
+        double v6[6] = {ca[0], ca[1], ca[2], cb[0], cb[1], cb[2]};
+        block_sums(v6, 6);
+        for (int c = 0; c < 3; ++c) { ca[c] = v6[c]; cb[c] = v6[3 + c]; }
+    }
     double H[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #pragma unroll 2
     for (int i = t; i < N; i += 256) {
         const double wn = X.w(i) / norm;
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r][c] += (X.a(i, r) - ca[r]) * (X.b(i, c) - cb[c]) * wn;
     }
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r][c] = block_sum(H[r][c]);
+    block_sums(&H[0][0], 9);
     if (t == 0) {
         // H = U S V^T.  Eigen-decompose H^T H = V S^2 V^T, sort descending, U = H V S^-1 (last column by cross product).
         double HtH[3][3], V[3][3];
@@ -286,7 +302,6 @@ template <typename Acc> __device__ void kabsch_body(const Acc& X, int N, float* 
             o[i * 4 + 3] = (float)tr;
         }
     }
-    (void)acc;
 }
 
 // ------------------------------------------------------------------------------------------------ voxel-average downsample
