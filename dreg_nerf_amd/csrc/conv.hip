@@ -317,6 +317,13 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
         const int gl = (lane & 7) ^ ((r >> 1) & 7);
         bbase[i] = (uint32_t)(n0 + r) * (uint32_t)(g.Kpad * 2) + (uint32_t)(gl * 16);
     }
+    // keep the per-lane bases as VALUES in registers: left alone, the compiler re-derives each abase from its factors inside the K loop
+    // (a v_mul_lo_u32 and three more VALU operations per direct-to-LDS load in front of the select; the issue phase is ~40 % of a K step
+    // of an under-filled launch: tools/igemm_phase_probe.py)
+#pragma unroll
+    for (int i = 0; i < IA; ++i) asm volatile("" : "+v"(abase[i]), "+v"(amask[i]));
+#pragma unroll
+    for (int i = 0; i < IBW; ++i) asm volatile("" : "+v"(bbase[i]));
     const int chunks = g.Cin / BKe;            // K steps per tap
     const int nk = g.ntaps * chunks;
 
