@@ -236,7 +236,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 // buffer offset: the hardware bounds check of the raw buffer returns zeros into LDS.  Per-row tap validity is a
 // 27-bit mask computed once per block, so the K loop spends 3 VALU ops per row on addressing.
 // ------------------------------------------------------------------------------------------------
-template <typename TO, int BM, int BN>
+// DBG (tools/igemm_phase_probe.py, measurement only): s_memtime stamps around the four phases of a K step, summed per wave into g_igemm_dbg
+__device__ unsigned long long g_igemm_dbg[8];
+__device__ __forceinline__ unsigned long long dbg_now() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
+template <typename TO, int BM, int BN, int DBG = 0>
 __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
     const bf16_t* __restrict__ in, const bf16_t* __restrict__ wt, TO* __restrict__ out,
     const float* __restrict__ bias, const TO* __restrict__ addend, ConvGeom g,
@@ -380,16 +383,29 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
     for (int s = 0; s < nstage - 1; ++s)
         if (k_begin + s < k_end) issue(k_begin + s, s);
     int cbuf = 0, ibuf = nstage - 1;                   // stage being consumed / stage the next issue goes to
+    unsigned long long dsum[4] = {0, 0, 0, 0}, dt0 = 0;
     for (int k = k_begin; k < k_end; ++k) {
         const int ahead = min(nstage - 2, k_end - 1 - k);   // later stages already issued
+        if constexpr (DBG) dt0 = dbg_now();
         if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (DBG) { const unsigned long long t_ = dbg_now(); dsum[0] += t_ - dt0; dt0 = t_; }
         __syncthreads();                               // stage k landed for every wave; everyone is done with stage k-1
+        if constexpr (DBG) { const unsigned long long t_ = dbg_now(); dsum[1] += t_ - dt0; dt0 = t_; }
         if (k + nstage - 1 < k_end) issue(k + nstage - 1, ibuf);
+        if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = dbg_now(); dsum[2] += t_ - dt0; dt0 = t_; }
         compute(cbuf);
+        if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = dbg_now(); dsum[3] += t_ - dt0; }
         cbuf = cbuf + 1 == nstage ? 0 : cbuf + 1;
         ibuf = ibuf + 1 == nstage ? 0 : ibuf + 1;
+    }
+    if constexpr (DBG) {
+        if (lane == 0) {
+            for (int q = 0; q < 4; ++q) atomicAdd(&g_igemm_dbg[q], dsum[q]);
+            atomicAdd(&g_igemm_dbg[4], (unsigned long long)(k_end - k_begin));   // K steps x waves
+            atomicAdd(&g_igemm_dbg[5], 1ull);                                    // waves
+        }
     }
 
     // Epilogue through LDS, one pass per wave row (wm): accumulators -> fp32 tile [BM/2][BN] -> coalesced 16-byte rows with bias /
@@ -1407,6 +1423,7 @@ static int conv_ksplit(const ConvGeom& g, bool has_addend)
 static int g_glds_stages = 0;
 static inline int glds_stages(long blocks) { (void)blocks; return g_glds_stages ? g_glds_stages : 2; }
 
+static int g_igemm_probe = 0;         // measurement only (tools/igemm_phase_probe.py): the 128 x 128 kernel with s_memtime stamps
 static int g_narrow_thr = 224;        // tile count below which a launch takes the narrower tiles
 static int g_narrow_small = 2;        // tuning (include/dreg_nerf_tuning.h): 128 x 64 tiles for launches of < 224 128 x 128 tiles
 template <typename T, typename TO>
@@ -1460,6 +1477,12 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
             else if (g.Cout % 256 == 0 && g_use_glds == 3 && nrows >= 65536) GL_LAUNCH(128, 256, 512);
             // fewer 128 x 128 tiles than CUs (the point-set half's linear layers: ~77 row tiles x 2): half-width tiles put twice as
             // many workgroups on the chip
+            else if (g_igemm_probe && g.Cout % 128 == 0 && sizeof(TO) == 2) {
+                const int tm_ = (nrows + 127) / 128, tn_ = g.Cout / 128;
+                hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, 128, 128, 1>), dim3(tm_ * tn_), dim3(256), (size_t)2 * 256 * 128, st,
+                                   (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tn_,
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows, 1, 2);
+            }
             else if (g.Cout % 128 == 0 && !(g_narrow_small && ((nrows + 127) / 128) * (g.Cout / 128) < g_narrow_thr)) GL_LAUNCH(128, 128, 256);
             else if (g.Cout % 64 == 0) GL_LAUNCH(128, 64, 256);
             else return DREG_EINVAL;
@@ -1572,6 +1595,17 @@ int dreg_conv3d_dgrad_s2(const void* gout, const void* wt_class_packed, void* di
 // 5: as 1 but never split-K; 0: always the register-staged kernel (A/B checks).
 void dreg_conv_set_glds(int enable) { g_use_glds = enable; }
 void dreg_conv_set_wgrad_big(int enable) { g_wgrad_big = enable; }
+// measurement only: enable = 1 routes bf16 launches with Cout % 128 == 0 to the instrumented 128 x 128 kernel; read returns
+// { cycles waiting for the stage's loads, in the barrier, issuing the next stage, in fragment reads + MFMAs; K steps x waves; waves } and clears them
+void dreg_conv_igemm_probe(int enable) { g_igemm_probe = enable; }
+int dreg_conv_igemm_probe_read(unsigned long long* out6)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return DREG_ELAUNCH;
+    if (hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_igemm_dbg), 6 * sizeof(unsigned long long)) != hipSuccess) return DREG_ELAUNCH;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_dbg), z, sizeof(z)) != hipSuccess) return DREG_ELAUNCH;
+    return DREG_OK;
+}
 void dreg_conv_set_wgrad_rows_fast(int enable) { g_rows_fast = enable ? 1 : 0; }
 void dreg_conv_set_wgrad_ring(int mode) { g_wgrad_ring = mode; }
 void dreg_conv_set_wgrad_pipe(int enable) { g_wgrad_pipe = enable ? 1 : 0; }

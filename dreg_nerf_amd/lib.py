@@ -42,6 +42,8 @@ SIGNATURES = {
     "dreg_pack_conv_weights_batched": (I, [P, I, I, I, P, P]),
     "dreg_conv_set_wgrad_splits": (None, [I]),
     "dreg_conv_set_wgrad_big": (None, [I]),
+    "dreg_conv_igemm_probe": (None, [I]),
+    "dreg_conv_igemm_probe_read": (I, [P]),
     "dreg_conv_set_wgrad_pipe": (None, [I]),
     "dreg_conv_set_wgrad_ring": (None, [I]),
     "dreg_conv_set_wgrad_rows_fast": (None, [I]),

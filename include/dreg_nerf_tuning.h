@@ -21,6 +21,8 @@ void dreg_conv_set_wgrad_splits(int splits);
 void dreg_conv_set_wgrad_rows_fast(int enable);      /* 1 (default): row-list weight gradients keep packed voxel coordinates in LDS (no decode per load) and take the 8-wave 256 x 256 tile for 256 -> 256 layers */
 void dreg_conv_set_wgrad_ring(int mode);             /* LDS ring of the dense 8-wave weight-gradient tile: 0 (default) two 64-voxel stages (one in flight), 1 four / 2 five 32-voxel stages (three / four in flight; measured no gain) */
 void dreg_conv_set_wgrad_pipe(int enable);           /* 1: the dense 8-wave weight-gradient tile reads the fragments of the next MFMA group while the current group runs (default 0: measured no gain) */
+void dreg_conv_igemm_probe(int enable);               /* MEASUREMENT ONLY: bf16 launches with Cout % 128 == 0 run the 128 x 128 implicit-GEMM kernel with s_memtime stamps around the phases of a K step */
+int dreg_conv_igemm_probe_read(unsigned long long* out6); /* { wait-for-loads, barrier, issue, compute cycles; K steps x waves; waves }, summed over the waves since the last read */
 void dreg_conv_set_wgrad_big(int mode);             /* large dense layers: 3 (default) the 8-wave 256 x 256 tile, 1 four waves on 256 x 128 with 32-voxel stages, 11-13 ablations of the 8-wave tile, 0 neither */
 void dreg_conv_set_glds_stages(int stages);          /* LDS pipeline stages of the direct-to-LDS convolution: 0 = default (2), 2..4 forces; results do not depend on it */
 void dreg_conv_set_wgrad_target_blocks(int blocks);   /* workgroups the automatic split choice aims for (default 3072) */

@@ -39,7 +39,7 @@ for name, B, D, cin, cout, k in shapes:
     probed = e0.elapsed_time(e1) * 50
     lib.dreg_conv_igemm_probe_read(ctypes.cast(buf, ctypes.c_void_p))
     lib.dreg_conv_igemm_probe(0)
-    wait, bar, issue, comp, ksteps, waves, loop = [int(buf[i]) for i in range(7)]
+    wait, bar, issue, comp, ksteps, waves = [int(buf[i]) for i in range(6)]
     tiles = ((B * D ** 3 + 127) // 128) * (cout // 128)
     print(f"{name:28s} {tiles:5d} workgroups, {ksteps // max(waves, 1):3d} K steps: per K step and wave  wait for loads {wait / ksteps:6.0f}  barrier {bar / ksteps:6.0f}  "
-          f"issue {issue / ksteps:5.0f}  reads + MFMA {comp / ksteps:6.0f}  (K loop {loop / max(waves, 1):7.0f} cycles per wave; launch {plain:.1f} us, instrumented {probed:.1f} us)", flush=True)
+          f"issue {issue / ksteps:5.0f}  reads + MFMA {comp / ksteps:6.0f}  (launch {plain:.1f} us; instrumented {probed:.1f} us: the stamps and the final atomics)", flush=True)
