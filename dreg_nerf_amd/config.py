@@ -43,6 +43,8 @@ def config_parser(argv=None):
     p.add_argument("--pairs_per_step", type=int, default=1, help="pairs per optimizer step and GPU (reference: 1)")
     p.add_argument("--synthetic", type=int, default=0, help="use N synthetic shell-R scenes instead of a dataset on disk")
     p.add_argument("--synthetic_res", type=int, default=128)
+    p.add_argument("--dump_outputs", action="store_true",
+                   help="eval: per scene, transformation_est.json and the registration's point clouds as PLY files (eval_nerf_regtr.py:313-438)")
     p.add_argument("--fgr_baseline", action="store_true",
                    help="also run the Fast Global Registration baseline on every pair and write fgr_metrics_{split}.json (eval_nerf_regtr.py:303-311 of the reference)")
     args, _unknown = p.parse_known_args(argv)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Evaluate NeRF registration on MI355X — drop-in for the metric part of the reference's eval_nerf_regtr.py
-(:224-301): per-scene RRE/RTE + forward time (with a device sync, unlike the reference — quirk Q13) written to
+(:224-301; with --dump_outputs also its per-scene transformation_est.json and PLY point clouds, :313-438): per-scene RRE/RTE + forward time (with a device sync, unlike the reference — quirk Q13) written to
 <root>/eval/<expname>/<dataset>/metrics_<split>.json with the reference's schema.  Scenes are sharded over ranks
 when launched with torch.distributed.run (replicas only, results gathered on rank 0)."""
 import json
@@ -10,7 +10,7 @@ import time
 import torch
 import torch.distributed as dist
 
-from dreg_nerf_amd import fgr
+from dreg_nerf_amd import fgr, vis_dump
 from dreg_nerf_amd import losses as LS
 from dreg_nerf_amd.checkpoint import CheckPointManager
 from dreg_nerf_amd.config import config_parser
@@ -58,6 +58,8 @@ def main():
             err = LS.evaluate_camera_alignment(pred["pose"][-1], data["pose"])
             rows[data["scene"]] = {"R_mean": float(err["R_error_mean"]), "t_mean": float(err["t_error_mean"]),
                                    "R_med": float(err["R_error_med"]), "t_med": float(err["t_error_med"]), "time": dt}
+            if cfg.dump_outputs:   # the reference's per-scene files (eval_nerf_regtr.py:313-321, 369-438; no videos / camera-pose dumps)
+                vis_dump.dump_scene_outputs(os.path.join(cfg.root_dir, "eval", cfg.expname, cfg.dataset or "synthetic", str(data["scene"])), pred, data["pose"])
             if cfg.fgr_baseline:   # the reference's baseline on the two voxel point clouds (global_registration.py:96-116)
                 T, sec = fgr.run_registration(_points(data, "src"), _points(data, "tgt"))
                 e = LS.evaluate_camera_alignment(T[None].float(), data["pose"])

@@ -78,9 +78,21 @@ def test_extract_then_register_split_matches_oracle(tmp_path):
     os.makedirs(root / "out" / "chain", exist_ok=True)
     torch.save({"step": 1, "model": sd}, str(root / "out" / "chain" / "model.pth"))
     _run(["eval_nerf_regtr.py", "--root_dir", str(root), "--json_dir", str(jdir), "--dataset", "objaverse", "--expname", "chain",
-          "--precision", "fp32"])
+          "--precision", "fp32", "--dump_outputs"])
     m = json.load(open(root / "eval" / "chain" / "objaverse" / "metrics_test.json"))
     assert set(m) == set(scenes.values()) | {"R_mean", "t_mean"}
+    # the reference's per-scene files (eval_nerf_regtr.py:313-321, 369-438): estimated transformation + registration point clouds
+    from dreg_nerf_amd import vis_dump
+    for name in scenes.values():
+        sdir = root / "eval" / "chain" / "objaverse" / name
+        T = np.array(json.load(open(sdir / "transformation_est.json"))["transformation"])
+        assert T.shape == (4, 4) and np.allclose(T[3], [0, 0, 0, 1]) and abs(np.linalg.det(T[:3, :3]) - 1.0) < 1e-3
+        xyz, rgb = vis_dump.read_ply(str(sdir / "noisy_point_cloud_pred.ply"))
+        ns = vis_dump.read_ply(str(sdir / "src_xyz.ply"))[0].shape[0]
+        nt = vis_dump.read_ply(str(sdir / "tgt_xyz.ply"))[0].shape[0]
+        assert xyz.shape == (ns + nt, 3) and (rgb[:ns] == [255, 0, 0]).all() and (rgb[ns:] == [0, 255, 0]).all()
+        src = vis_dump.read_ply(str(sdir / "src_xyz.ply"))[0]
+        assert np.allclose(xyz[:ns], src @ T[:3, :3].T + T[:3, 3], atol=1e-5)
     # stage 3: every row re-derived by the oracle (CPU, fp32, eval-mode BatchNorm) from the files stage 1 wrote
     r_all, t_all = [], []
     for name in scenes.values():
