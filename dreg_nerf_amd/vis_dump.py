@@ -1,8 +1,9 @@
 """Per-scene outputs of the reference's evaluation besides the metrics (eval_nerf_regtr.py:313-438): the estimated transformation as
 JSON and the point clouds of the registration as PLY files with the reference's names and colours.  The reference writes them with
 open3d.io.write_point_cloud (absent here); the files below use the layout open3d's writer produces for a point cloud — binary
-little-endian, double x / y / z, uchar red / green / blue when coloured — so the same viewers and scripts read them.  The rendered
-videos and the camera-pose dumps of the reference need its NeRF renderer and are not produced."""
+little-endian, double x / y / z, uchar red / green / blue when coloured — so the same viewers and scripts read them.  The camera-pose
+dumps (:330-343) are written when the blocks' NeRF checkpoints (their camera_poses meta data) are on disk; the rendered videos need the
+reference's NeRF renderer and are not produced."""
 import json
 import os
 
@@ -50,11 +51,23 @@ def _se3(pose, xyz):
     return xyz @ pose[:3, :3].T + pose[:3, 3]
 
 
-def dump_scene_outputs(out_dir: str, pred: dict, pose_gt: torch.Tensor) -> None:
-    """pred: the model's output dict for ONE pair (List(B=1) members, pose [6,1,3,4]); pose_gt [1,4,4]."""
+def dump_camera_poses(out_dir: str, pose4: torch.Tensor, pose_gt4: torch.Tensor, src_cams: torch.Tensor, tgt_cams: torch.Tensor) -> None:
+    """eval_nerf_regtr.py:330-343: the two blocks' training cameras [N,4,4] unaligned, aligned by the ground-truth and by the estimated
+    transformation (source cameras moved into the target frame)."""
+    src_cams, tgt_cams = src_cams.float().cpu(), tgt_cams.float().cpu()
+    torch.save(torch.cat([src_cams, tgt_cams], dim=0), os.path.join(out_dir, "unaligned_poses.pt"))
+    torch.save(torch.cat([pose_gt4.float().cpu() @ src_cams, tgt_cams], dim=0), os.path.join(out_dir, "aligned_poses_gt.pt"))
+    torch.save(torch.cat([pose4.float().cpu() @ src_cams, tgt_cams], dim=0), os.path.join(out_dir, "aligned_poses_pred.pt"))
+
+
+def dump_scene_outputs(out_dir: str, pred: dict, pose_gt: torch.Tensor, src_cams=None, tgt_cams=None) -> None:
+    """pred: the model's output dict for ONE pair (List(B=1) members, pose [6,1,3,4]); pose_gt [1,4,4]; src_cams / tgt_cams: the blocks'
+    camera_poses meta data [N,4,4] when their NeRF checkpoints are on disk (then the three pose files are written too)."""
     os.makedirs(out_dir, exist_ok=True)
     pred_pose = pred["pose"][-1][0].detach().float().cpu()            # [3,4]
     pose4 = torch.cat([pred_pose, torch.tensor([[0.0, 0.0, 0.0, 1.0]])])
+    if src_cams is not None and tgt_cams is not None:
+        dump_camera_poses(out_dir, pose4, pose_gt[0].detach(), torch.as_tensor(src_cams), torch.as_tensor(tgt_cams))
     with open(os.path.join(out_dir, "transformation_est.json"), "w") as f:
         f.write(json.dumps({"transformation": pose4.numpy().tolist()}, indent=4))
     red, green = np.array([[1.0, 0.0, 0.0]]), np.array([[0.0, 1.0, 0.0]])

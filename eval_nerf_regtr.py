@@ -59,7 +59,13 @@ def main():
             rows[data["scene"]] = {"R_mean": float(err["R_error_mean"]), "t_mean": float(err["t_error_mean"]),
                                    "R_med": float(err["R_error_med"]), "t_med": float(err["t_error_med"]), "time": dt}
             if cfg.dump_outputs:   # the reference's per-scene files (eval_nerf_regtr.py:313-321, 369-438; no videos / camera-pose dumps)
-                vis_dump.dump_scene_outputs(os.path.join(cfg.root_dir, "eval", cfg.expname, cfg.dataset or "synthetic", str(data["scene"])), pred, data["pose"])
+                cams = [None, None]
+                sp, tp = data.get("src_nerf_path", ""), data.get("tgt_nerf_path", "")
+                if sp and tp and os.path.exists(sp) and os.path.exists(tp):       # camera_poses of the two NeRF blocks (train_ngp_nerf.py:187-209)
+                    from dreg_nerf_amd.visibility import load_block
+                    cams = [load_block(q, dev)[2]["camera_poses"] for q in (sp, tp)]
+                vis_dump.dump_scene_outputs(os.path.join(cfg.root_dir, "eval", cfg.expname, cfg.dataset or "synthetic", str(data["scene"])), pred, data["pose"],
+                                            cams[0], cams[1])
             if cfg.fgr_baseline:   # the reference's baseline on the two voxel point clouds (global_registration.py:96-116)
                 T, sec = fgr.run_registration(_points(data, "src"), _points(data, "tgt"))
                 e = LS.evaluate_camera_alignment(T[None].float(), data["pose"])

@@ -93,6 +93,10 @@ def test_extract_then_register_split_matches_oracle(tmp_path):
         assert xyz.shape == (ns + nt, 3) and (rgb[:ns] == [255, 0, 0]).all() and (rgb[ns:] == [0, 255, 0]).all()
         src = vis_dump.read_ply(str(sdir / "src_xyz.ply"))[0]
         assert np.allclose(xyz[:ns], src @ T[:3, :3].T + T[:3, 3], atol=1e-5)
+        # the blocks' NeRF checkpoints are on disk here: the camera-pose dumps (eval_nerf_regtr.py:330-343) are written too
+        un, al = torch.load(str(sdir / "unaligned_poses.pt")), torch.load(str(sdir / "aligned_poses_pred.pt"))
+        assert un.shape == al.shape and un.shape[1:] == (4, 4) and (sdir / "aligned_poses_gt.pt").exists()
+        assert torch.allclose(al[0], torch.from_numpy(T).float() @ un[0], atol=1e-5)
     # stage 3: every row re-derived by the oracle (CPU, fp32, eval-mode BatchNorm) from the files stage 1 wrote
     r_all, t_all = [], []
     for name in scenes.values():

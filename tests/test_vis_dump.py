@@ -23,7 +23,12 @@ def test_scene_outputs(tmp_path):
             "src_kp_warped": [torch.randn(6, ns, 3, generator=g)], "tgt_kp_warped": [torch.randn(6, nt, 3, generator=g)],
             "src_overlap": [ov_s], "tgt_overlap": [ov_t]}
     d = str(tmp_path / "scene0")
-    vis_dump.dump_scene_outputs(d, pred, pose[None])
+    cs, ct = torch.randn(5, 4, 4, generator=g), torch.randn(3, 4, 4, generator=g)
+    vis_dump.dump_scene_outputs(d, pred, pose[None], cs, ct)
+    for f_, T_ in (("unaligned_poses.pt", torch.eye(4)), ("aligned_poses_gt.pt", pose), ("aligned_poses_pred.pt", torch.cat([pred_pose, torch.tensor([[0.0, 0, 0, 1]])]))):
+        P = torch.load(os.path.join(d, f_))
+        assert P.shape == (8, 4, 4) and torch.allclose(P[:5], T_ @ cs, atol=1e-6) and torch.equal(P[5:], ct)
+        os.remove(os.path.join(d, f_))
     names = {"transformation_est.json", "src_xyz.ply", "tgt_xyz.ply", "src_kp_warped.ply", "tgt_kp_warped.ply", "all_src_xyz.ply", "all_tgt_xyz.ply",
              "noisy_point_cloud_pred.ply", "point_cloud_pred.ply", "noisy_point_cloud_gt.ply", "point_cloud_gt.ply"}
     assert set(os.listdir(d)) == names
