@@ -180,11 +180,35 @@ def ngp_bench(args, rank, world, dev):
         "points_per_sec": npts * args.steps * world / el, "roofline": rf}), flush=True)
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): re-execute this script under torch.distributed.run with one
+    rank per GPU (the reference's own multi-GPU form is one process per GPU from the shell, scripts/train/train_nerf_regtr.sh:14-16).
+    Never a silent fallback: fewer visible GPUs than N is an error."""
+    import socket
+    import subprocess
+    one_gpu_hook = os.environ.get("DREG_BENCH_ONE_GPU") == "1"      # test hook: N ranks on the one GPU of a test box (gloo)
+    have = torch.cuda.device_count()
+    if have < args.gpus and not one_gpu_hook:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible; refusing to run fewer ranks than asked")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL over xGMI ("nccl" is RCCL on ROCm).  DREG_BENCH_BACKEND=gloo with DREG_BENCH_ONE_GPU=1 is a test hook: several ranks on the
@@ -193,6 +217,8 @@ def main():
         if os.environ.get("DREG_BENCH_ONE_GPU") == "1":
             local_rank = 0
         if backend == "nccl":
+            if local_rank >= torch.cuda.device_count():
+                raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
@@ -362,7 +388,8 @@ def main():
         pairs = args.pairs * world * args.steps
         out = {
             "metric": "nerf_pairs_per_sec_regtr_fwd_bwd_128", "value": pairs / elapsed, "unit": "pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "n_gpus": dist.get_world_size() if world > 1 else 1, "rccl_ranks": (dist.get_world_size() if backend == "nccl" else 0),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"RegTR fwd+bwd+AdamW, shell-R synthetic pairs, {args.res}^3 grids, "

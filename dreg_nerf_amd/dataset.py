@@ -96,11 +96,14 @@ def load_block_sparse(block_dir: str) -> SparseBlock:
     return sb
 
 
-def augment_sparse(data: dict, jitter: float = 0.005, std: float = 0.1, gen=None, draws=None) -> dict:
+def augment_sparse(data: dict, jitter: float = 0.005, std: float = 0.1, gen=None, draws=None, rng=None, cpu_gen=None) -> dict:
     """dataset.py:277-331 on sparse blocks, on whatever device they live on: jitter of the occupied voxels' xyz, a small SE(3)
     perturbation centred on the mean over ALL voxels of the grid (zeros included, as the reference does), random swap.
-    draws (tests): dict with 'noise_src', 'noise_tgt', 'perturb' (4x4), 'perturb_source' (bool), 'swap' (bool)."""
+    draws (tests): dict with 'noise_src', 'noise_tgt', 'perturb' (4x4), 'perturb_source' (bool), 'swap' (bool).
+    gen: torch.Generator on the blocks' device (jitter); cpu_gen: CPU generator (SE(3) draws); rng: a random.Random for the two coin
+    flips — a loader thread passes its own three so that it never touches the process-global generators (PrefetchLoader)."""
     draws = draws or {}
+    rng = rng or random
     for side in ("src", "tgt"):
         sb = data[side + "_sparse"]
         noise = draws.get("noise_" + side)
@@ -109,8 +112,8 @@ def augment_sparse(data: dict, jitter: float = 0.005, std: float = 0.1, gen=None
         vals = sb.vals.clone()
         vals[:, :3] += noise.to(vals.device)
         data[side + "_sparse"] = SparseBlock(sb.idx, vals, sb.res)
-    perturb = draws["perturb"] if "perturb" in draws else _small_se3(std)
-    psrc = draws["perturb_source"] if "perturb_source" in draws else (random.random() > 0.5)
+    perturb = draws["perturb"] if "perturb" in draws else _small_se3(std, cpu_gen)
+    psrc = draws["perturb_source"] if "perturb_source" in draws else (rng.random() > 0.5)
     side = "src" if psrc else "tgt"
     sb = data[side + "_sparse"]
     dev = sb.vals.device
@@ -123,7 +126,7 @@ def augment_sparse(data: dict, jitter: float = 0.005, std: float = 0.1, gen=None
     data[side + "_sparse"] = SparseBlock(sb.idx, vals, sb.res)
     pose = data["pose"].to(dev)
     data["pose"] = pose @ torch.linalg.inv(P) if psrc else P @ pose
-    swap = draws["swap"] if "swap" in draws else (random.random() > 0.5)
+    swap = draws["swap"] if "swap" in draws else (rng.random() > 0.5)
     if swap:
         data["src_sparse"], data["tgt_sparse"] = data["tgt_sparse"], data["src_sparse"]
         if "src_nerf_path" in data:
@@ -218,9 +221,14 @@ class NeRFRegDataset:
         return len(self.meta)
 
     def __getitem__(self, index):
+        return self.get(index)
+
+    def get(self, index, rng=None, gen=None, cpu_gen=None):
+        """rng / gen / cpu_gen: the caller's own random.Random, device and CPU torch.Generator (PrefetchLoader's thread); default = the
+        process-global generators, as the reference's dataset uses them."""
         sm = self.meta[index]
         ids = list(sm["blocks"].keys())
-        random.shuffle(ids)  # also in test mode, as the reference (quirk Q15)
+        (rng or random).shuffle(ids)  # also in test mode, as the reference (quirk Q15)
         s, t = sm["blocks"][ids[0]], sm["blocks"][ids[1]]
         if self.sparse:
             data = {"src_sparse": load_block_sparse(s["dir"]), "tgt_sparse": load_block_sparse(t["dir"]),
@@ -232,7 +240,7 @@ class NeRFRegDataset:
                 data["pose"] = data["pose"].to(self.device)
             if self.mode == "train":
                 data["pose"] = data["pose"][0]
-                data = augment_sparse(data)
+                data = augment_sparse(data, gen=gen, rng=rng, cpu_gen=cpu_gen)
                 data["pose"] = data["pose"][None]
             return data
         data = {
@@ -277,23 +285,29 @@ class PrefetchLoader:
         self.q = queue.Queue(maxsize=max(depth, 1))
         self.stream = torch.cuda.Stream(device=device, priority=-1) if (device is not None and torch.device(device).type == "cuda") else None   # high priority: its few small kernels must not queue behind a saturated training stream
         self._err = None
-        self._rng_state = random.getstate()     # the thread draws the block order / augmentation from the caller's Python RNG stream
+        # The thread owns its generators (seeded from ONE draw of the caller's Python RNG at construction, on the caller's thread): the
+        # block order / augmentation are reproducible for a fixed seed and never interleave with the main thread's draws.
+        seed = random.getrandbits(62)
+        self._rng = random.Random(seed)
+        self._cpu_gen = torch.Generator().manual_seed(seed)
+        self._gen = torch.Generator(device=device).manual_seed(seed) if self.stream is not None else self._cpu_gen
+        self._own_rng = hasattr(dataset, "get")
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.thread.start()
 
     def _run(self):
         try:
-            random.setstate(self._rng_state)
+            fetch = (lambda i: self.ds.get(i, rng=self._rng, gen=self._gen, cpu_gen=self._cpu_gen)) if self._own_rng else (lambda i: self.ds[i])
             for i in self.indices:
                 if self.stream is not None:
                     with torch.cuda.stream(self.stream):
-                        sample = self.ds[i]
+                        sample = fetch(i)
                         ev = torch.cuda.Event()
                         ev.record(self.stream)
                     sample["ready_event"] = ev
                     sample["_loader_stream"] = self.stream
                 else:
-                    sample = self.ds[i]
+                    sample = fetch(i)
                 self.q.put(sample)
         except BaseException as e:   # surfaced on the consumer side
             self._err = e

@@ -112,7 +112,6 @@ class NGPradianceField(nn.Module):
             self._prep = (key, base16, col16)
         return self._prep[1], self._prep[2]
 
-    @torch.no_grad()
     def _aabb_host(self):
         """The six aabb floats on the host, cached against the buffer's version: `.tolist()` of a device tensor is a host sync."""
         c = self.__dict__.get("_aabb_cache")
@@ -120,6 +119,7 @@ class NGPradianceField(nn.Module):
             c = self.__dict__["_aabb_cache"] = ((self.aabb.data_ptr(), self.aabb._version), [float(v) for v in self.aabb.tolist()])
         return c[1]
 
+    @torch.no_grad()
     def query_raw(self, x: torch.Tensor):
         """x [N,3] world -> (density fp32 [N], raw fp16 [N,16])."""
         lib = L.load()

@@ -94,7 +94,9 @@ def clear_pack_cache():
 
 
 PACK_STREAM = None        # side stream for the repack that follows an optimizer update (train_step sets it; None = current stream)
-_PACK_EVENTS = []
+_PACK_EVENTS = []         # events of the repacks since the last optimizer update; kept until the NEXT update's repack replaces them
+_PACK_WAITED = set()      # streams that already wait behind every event in _PACK_EVENTS
+_PACK_EPOCH = [0, -1]     # [optimizer updates seen, update the events in _PACK_EVENTS belong to]
 
 
 class pack_region:
@@ -114,24 +116,33 @@ class pack_region:
         if self.side is not None:
             ev = torch.cuda.Event()
             ev.record(self.side)
+            if _PACK_EPOCH[1] != _PACK_EPOCH[0]:        # first repack after an optimizer update: the older events are all behind it
+                _PACK_EVENTS.clear()                    # (same side stream, in order)
+                _PACK_EPOCH[1] = _PACK_EPOCH[0]
             _PACK_EVENTS.append(ev)
+            _PACK_WAITED.clear()
             self.ctx.__exit__(*exc)
         return False
 
 
 def wait_packs():
-    """Called in front of every consumer of a weight pack: the current stream waits for the side-stream repacks."""
+    """Called in front of every consumer of a weight pack (and by TrainStep.step before any work): the CURRENT stream waits for the
+    side-stream repacks.  The events stay until the next update's repack replaces them, so a consumer on any other stream (the
+    parameter-gradient stream, the geometry stream, a loader thread) waits too — once per stream and repack."""
     if _PACK_EVENTS:
         st = torch.cuda.current_stream()
-        for ev in _PACK_EVENTS:
-            st.wait_event(ev)
-        _PACK_EVENTS.clear()
+        key = (st.device.index, st.cuda_stream)
+        if key not in _PACK_WAITED:
+            for ev in _PACK_EVENTS:
+                st.wait_event(ev)
+            _PACK_WAITED.add(key)
 
 
 def bump_weight_generation():
     """Called by optimizers that update parameters behind torch's version counters (FlatAdamW)."""
     global _weight_generation
     _weight_generation += 1
+    _PACK_EPOCH[0] += 1
 
 
 def packed_weight(w: torch.Tensor, cin_pad: int, for_dgrad: bool, dt: int) -> torch.Tensor:
@@ -270,6 +281,7 @@ _halo_cache = {}
 def halo_packed_weight(w: torch.Tensor, transposed: bool) -> torch.Tensor:
     """bf16 [chunk][tap][256][32] pack of a 3^3 weight for the halo kernel (forward, or the flipped-tap data-gradient form), cached
     against the parameter's version / the optimizer generation like packed_weight()."""
+    wait_packs()
     base = w._base if w._base is not None else w
     key = (id(base), w.storage_offset(), tuple(w.shape), bool(transposed))
     hit = _halo_cache.get(key)
@@ -770,7 +782,16 @@ def maxpool3d(x):
 
 # --------------------------------------------------------------------------- fused trilinear upsample + gather
 PERSISTENT_GRAD_BUFFERS = False     # train_step.TrainStep sets it around backward
-_DP1_CACHE = {}
+_DP1_CACHE = {}                     # (shape, dtype, device) -> [buffer, rows the last writer dirtied, in use by an unconsumed gradient]
+
+
+def release_grad_buffers(free: bool = False):
+    """TrainStep calls this after its backward: the cached dense gradient buffers may be handed out again (their consumer, the trunk's
+    backward, is enqueued behind the writer on the same stream).  free=True drops them (up to 2 x ~1 GB at 8 x 64^3 x 256)."""
+    for ent in _DP1_CACHE.values():
+        ent[2] = False
+    if free:
+        _DP1_CACHE.clear()
 
 
 class TrilinearGatherFn(torch.autograd.Function):
@@ -802,13 +823,18 @@ class TrilinearGatherFn(torch.autograd.Function):
                 # one dense buffer per shape, kept across steps: zero outside the rows of the step that wrote it, so only those
                 # rows are cleared (a 1 GB memset per step at 8 x 64^3 x 256 otherwise).  train_step turns this on around its
                 # backward: the consumer (the trunk's backward) has read the buffer before the next step reuses it.
+                # A second gather node of the same shape inside ONE backward (per-pair forwards summed into one loss) must not get the
+                # buffer whose gradient has not been consumed yet: it takes a fresh zero-filled one.
                 key = (shape, dtype, gout.device)
                 ent = _DP1_CACHE.get(key)
-                if ent is None:
+                if ent is not None and ent[2]:
+                    ent = [torch.zeros(shape, dtype=dtype, device=gout.device), None, True]
+                elif ent is None:
                     while len(_DP1_CACHE) >= 2:            # one buffer per (shape, dtype, device): 1 GB at 8 x 64^3 x 256 — keep two
                         _DP1_CACHE.pop(next(iter(_DP1_CACHE)))
-                    ent = _DP1_CACHE[key] = [torch.zeros(shape, dtype=dtype, device=gout.device), None]
-                g, dirty = ent
+                    ent = _DP1_CACHE[key] = [torch.zeros(shape, dtype=dtype, device=gout.device), None, False]
+                ent[2] = True
+                g, dirty = ent[0], ent[1]
                 if dirty is not None:
                     L.check(lib.dreg_zero_rows(L.ptr(g), L.ptr(dirty), dirty.shape[0], C, L.dt_of(g), L.stream()), "dreg_zero_rows")
                 fmap = torch.empty(B * Zr * Xr * Yr, dtype=torch.int32, device=gout.device)

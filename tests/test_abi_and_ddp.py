@@ -146,3 +146,22 @@ def test_grad_sync_two_ranks_equal_one_rank_on_concatenated_batch():
         # a bucket starts only once everything above its lower bound was reported ready
         assert order == sorted(order) and order[0] == sum(1 for lo, _ in buckets if lo >= 1400) and order[-1] == sum(1 for lo, _ in buckets if lo >= 123)
     assert res[0][1] == res[1][1]
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus 2` on a box with fewer GPUs must fail loudly, never run fewer ranks (here: no GPU at all)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DREG_BENCH_ONE_GPU")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "refusing to run fewer ranks" in (out.stderr + out.stdout)
+    # a launcher whose rank count disagrees with --gpus is an error too
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "must agree" in (out.stderr + out.stdout)

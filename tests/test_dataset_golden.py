@@ -94,3 +94,49 @@ def test_load_split_reads_the_reference_file_format(tmp_path):
     # a dataset whose directories are missing is an error, not an empty loader
     with pytest.raises(FileNotFoundError):
         DS.NeRFRegDataset(str(tmp_path), str(tmp_path), "objaverse", "train")
+
+
+def _tiny_on_disk_dataset(root, n_scenes=3, res=8):
+    """Three scenes x two blocks in the reference's directory layout (dataset.py:100-134), 8^3 grids."""
+    jd = os.path.join(root, "json")
+    os.makedirs(jd)
+    names = [f"scene{i}" for i in range(n_scenes)]
+    json.dump({"toy": {"train": names, "test": names}}, open(os.path.join(jd, "objaverse.json"), "w"))
+    g = torch.Generator().manual_seed(0)
+    for sc in names:
+        d = os.path.join(root, "toy", "images", sc)
+        os.makedirs(d)
+        json.dump({str(k): (torch.eye(4) + 0.01 * k).tolist() for k in range(2)}, open(os.path.join(d, "world_frame_transforms.json"), "w"))
+        for k in range(2):
+            b = os.path.join(root, "toy", "nerf_models", sc, f"block_{k}")
+            os.makedirs(b)
+            mask = torch.randperm(res ** 3, generator=g)[:40].sort().values
+            grid = torch.zeros(res ** 3, 7)
+            grid[mask] = torch.rand(40, 7, generator=g)
+            torch.save(grid.view(res, res, res, 7), os.path.join(b, "voxel_grid.pt"))
+            torch.save(mask, os.path.join(b, "voxel_mask.pt"))
+    return jd
+
+
+def test_prefetch_loader_owns_its_random_streams(tmp_path):
+    """The loader thread draws block order / augmentation from its OWN generators (seeded by one draw of the caller's RNG at
+    construction): same seed -> same samples, and the process-global Python / torch generators are not advanced or rewound by it."""
+    import random
+    jd = _tiny_on_disk_dataset(str(tmp_path))
+    ds = DS.NeRFRegDataset(str(tmp_path), jd, "toy", "train", sparse=True)
+
+    def run(seed):
+        random.seed(seed)
+        torch.manual_seed(seed)
+        ld = DS.PrefetchLoader(ds, [0, 1, 2, 0, 1, 2], None, depth=2)
+        py_state, t_state = random.getstate(), torch.get_rng_state()
+        out = [(s["block_list"], s["pose"].clone(), s["src_sparse"].vals.clone()) for s in ld]
+        ld.thread.join()
+        assert random.getstate() == py_state and torch.equal(torch.get_rng_state(), t_state)     # the thread left the global streams alone
+        return out
+
+    a, b, c = run(7), run(7), run(8)
+    assert len(a) == 6
+    for (bl0, p0, v0), (bl1, p1, v1) in zip(a, b):
+        assert bl0 == bl1 and torch.equal(p0, p1) and torch.equal(v0, v1)
+    assert any(not torch.equal(p0, p2) for (_, p0, _), (_, p2, _) in zip(a, c))

@@ -99,3 +99,28 @@ def test_bench_script_runs_with_two_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] - 2 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # whole-job pairs/s = ranks x pairs / step time
+
+
+def test_bench_script_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher and WORLD_SIZE unset (the driver's form) must itself start two ranks, one JSON
+    line from rank 0 with n_gpus = the process group's world size.  On this one-GPU box the two ranks share the GPU over gloo
+    (test hooks); on a node the same path is one RCCL rank per GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(DREG_BENCH_BACKEND="gloo", DREG_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--res", "64", "--pairs", "1",
+           "--no-cpu-baseline", "--no-dense-reference"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 0 and d["config"]["parallelism"] == "dp2"      # gloo hook: not an RCCL measurement
+    # without the one-GPU hook the same command must refuse (one visible GPU < 2), not run one rank
+    env.pop("DREG_BENCH_ONE_GPU")
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and "refusing" in (out.stderr + out.stdout)

@@ -26,18 +26,23 @@ def to_device(d, dev):
 
 
 @torch.no_grad()
-def validate(model, dataset, dev, frac=0.2):
-    """train_nerf_regtr.py:258-291: RRE/RTE on the first 20 % of the validation scenes; score = n / sum(R_mean)."""
+def validate(model, dataset, dev, frac=0.2, rank=0, world=1):
+    """train_nerf_regtr.py:258-291: RRE/RTE on the first 20 % of the validation scenes; score = n / sum(R_mean).
+    With several ranks EVERY rank calls this at the same iteration and evaluates scenes rank, rank + world, ...; the two error sums
+    are added over the ranks (one small all-reduce), so no rank waits in the next step's gradient exchange while rank 0 validates."""
     model.eval()
     n = max(1, int(len(dataset) * frac))
-    r_sum = t_sum = 0.0
-    for i in range(n):
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    for i in range(rank, n, world):
         data = to_device(dataset[i], dev)
         pred = model(data)
         err = LS.evaluate_camera_alignment(pred["pose"][-1], data["pose"])
-        r_sum += float(err["R_error_mean"])
-        t_sum += float(err["t_error_mean"])
+        sums[0] += err["R_error_mean"].double()
+        sums[1] += err["t_error_mean"].double()
+    if world > 1:
+        dist.all_reduce(sums)
     model.train()
+    r_sum, t_sum = (float(v) for v in sums.tolist())
     return n / max(r_sum, 1e-9), r_sum / n, t_sum / n
 
 
@@ -107,9 +112,10 @@ def main():
                       f" R={float(err['R_error_mean']):.3f}deg t={float(err['t_error_mean']):.4f} lr={ts.scheduler.get_last_lr()[0]:.2e}"
                 print(msg, flush=True)
                 log.write(msg + "\n"); log.flush()
-            if iteration % cfg.n_validation == 0 and rank == 0:
-                score, r, t = validate(model, val_ds, dev)
-                print(f"val it {iteration}: R_mean={r:.3f} t_mean={t:.4f}", flush=True)
+            if iteration % cfg.n_validation == 0:
+                score, r, t = validate(model, val_ds, dev, rank=rank, world=world)
+                if rank == 0:
+                    print(f"val it {iteration}: R_mean={r:.3f} t_mean={t:.4f}", flush=True)
             if iteration % cfg.n_checkpoint == 0 and rank == 0:
                 ckpt.save(models, {"optimizer": ts.optimizer}, iteration, schedulers={"scheduler": ts.scheduler}, score=score)
         torch.cuda.synchronize()
@@ -118,8 +124,8 @@ def main():
             msg = f"epoch {epoch}: {n_pairs} pairs on this rank in {dt:.2f}s = {n_pairs * world / dt:.1f} pairs/s over {world} GPU(s), input pipeline included"
             print(msg, flush=True)
             log.write(msg + "\n"); log.flush()
+    score, r, t = validate(model, val_ds, dev, rank=rank, world=world)
     if rank == 0:
-        score, r, t = validate(model, val_ds, dev)
         print(f"final val: R_mean={r:.3f} t_mean={t:.4f}", flush=True)
         ckpt.save(models, {"optimizer": ts.optimizer}, iteration, schedulers={"scheduler": ts.scheduler}, score=score)
     if world > 1:
