@@ -1,18 +1,22 @@
-"""Checkpoint manager with the reference's interface and on-disk layout (conerf/base/checkpoint_manager.py:13-222).
+"""Checkpoint files of the registration / NeRF-block trainers: same public calls and the same files on disk as the reference's
+manager (behaviour pinned by tests/golden/checkpoint_manager.json, recorded from the reference), own implementation.
 
-Files under ``save_path``:
-  model/model_{step:06d}.pth   torch.save({'step', <model names>: state_dict, <optimizer names>, <scheduler names>, <meta keys>})
-  model.pth                    copy of the most recent one            (:84)
-  model_best.pth               copy of the best one by ``score``      (:88-91; score may be a vector: all components >=)
-  checkpoints.txt              basenames of the kept files, one per line, then ``Best step: N``   (:109-115)
-Retention (:98-107, the tf.Saver rule): at most ``max_to_keep`` recent files; a file that falls out of that window is kept
-for good when it is newer than the next "keep every n hours" mark, deleted otherwise.
+What a run directory holds after ``save``:
 
-Both kinds of reference checkpoint go through ``load_no_config``: RegTR training states (train_nerf_regtr.py) and NeRF block
-states (train_ngp_nerf.py:192-209: 'model' = NGPradianceField, 'occupancy_grid' = nerfacc OccupancyGrid, plus aabb / unbounded /
-grid_resolution / contraction_type / render_step_size / alpha_thre / cone_angle / camera_poses [/ block_id]).  The nerfacc enum
-pickled into the latter is resolved by ngp.install_pickle_shims(); ngp.NGPradianceField and ngp.OccupancyGrid take the
-tiny-cuda-nn flat parameter vectors and the nerfacc buffers as they are."""
+    <dir>/model/model_000123.pth    one torch-pickled dict per saved step: 'step', then one entry per model / optimizer /
+                                    scheduler name (their state_dict()) and per meta key (the value as given)
+    <dir>/model.pth                 the newest of them
+    <dir>/model_best.pth            the one with the best score so far (a later equal score wins; vector scores: every
+                                    component must be at least as good)
+    <dir>/checkpoints.txt           the step files still on disk, oldest first, one name per line, last line 'Best step: N'
+
+Pruning keeps a sliding window of ``max_to_keep`` step files.  A file leaving the window survives only as a periodic
+"milestone": the first one always does, afterwards one per ``keep_checkpoint_every_n_hours`` of wall-clock time.
+
+Both kinds of reference checkpoint are read back through ``load_no_config``: RegTR training states and NeRF block states
+(train_ngp_nerf.py:192-209: 'model', 'occupancy_grid' and the aabb / unbounded / grid_resolution / contraction_type / ... meta
+keys).  The nerfacc enum pickled into the latter is resolved by ngp.install_pickle_shims()."""
+import collections
 import os
 import shutil
 import time
@@ -20,121 +24,133 @@ import time
 import numpy as np
 import torch
 
+_StepFile = collections.namedtuple("_StepFile", "path written_at")
+
 
 def de_parallel(model):
-    """The wrapped module of a DistributedDataParallel-style wrapper (checkpoint_manager.py:9-10)."""
-    return model.module if hasattr(model, "module") else model
+    """Unwrap a data-parallel style wrapper (anything that carries the real network as ``.module``)."""
+    inner = getattr(model, "module", None)
+    return model if inner is None else inner
+
+
+def _at_least_as_good(score, incumbent) -> bool:
+    return incumbent is None or bool(np.all(np.asarray(score) >= np.asarray(incumbent)))
+
+
+class _Window:
+    """Which step files stay on disk: the newest `size` of them plus the milestones."""
+
+    def __init__(self, size: int, milestone_hours: float):
+        self.size = size
+        self.period_s = milestone_hours * 3600.0
+        self.recent = collections.deque()
+        self.milestones = []
+        self.milestone_due = time.time()          # anything written after this moment qualifies as the next milestone
+
+    def admit(self, path: str):
+        self.recent.append(_StepFile(path, time.time()))
+        while len(self.recent) > self.size:
+            old = self.recent.popleft()
+            if old.written_at > self.milestone_due:
+                self.milestones.append(old)
+                self.milestone_due = old.written_at + self.period_s
+            else:
+                os.remove(old.path)
+
+    def names(self):
+        return [os.path.basename(f.path) for f in (*self.milestones, *self.recent)]
 
 
 class CheckPointManager(object):
     def __init__(self, save_path: str = None, max_to_keep: int = 5, keep_checkpoint_every_n_hours: float = 10000.0,
                  verbose: bool = True) -> None:
-        if max_to_keep <= 0:
-            raise ValueError("max_to_keep must be at least 1")
-        self._max_to_keep = max_to_keep
-        self._keep_checkpoint_every_n_hours = keep_checkpoint_every_n_hours
-        self._verbose = verbose
-        self._checkpoints_permanent = []   # (path, time) never deleted
-        self._checkpoints_buffer = []      # (path, time) the max_to_keep most recent
-        self._next_save_time = time.time()
-        self._best_score = None
-        self._best_step = None
-        self._save_path = save_path
-        self._checkpoints_fname = None
+        if max_to_keep < 1:
+            raise ValueError(f"a checkpoint window of {max_to_keep} files keeps nothing: max_to_keep has to be 1 or more")
+        self.verbose = verbose
+        self.window = _Window(max_to_keep, keep_checkpoint_every_n_hours)
+        self.best = {"score": None, "step": None}
+        self.root = save_path
         if save_path is not None:
             os.makedirs(save_path, exist_ok=True)
-            self._checkpoints_fname = os.path.join(save_path, "checkpoints.txt")
-            self._update_checkpoints_file()
+            self._write_index()
 
     def set_save_path(self, path: str):
-        self._save_path = path
+        self.root = path
 
-    # ------------------------------------------------------------------ save
-    def _update_checkpoints_file(self):
-        names = [os.path.basename(c[0]) for c in self._checkpoints_permanent + self._checkpoints_buffer]
-        with open(self._checkpoints_fname, "w") as fid:
-            fid.write("\n".join(names))
-            fid.write("\nBest step: {}".format(self._best_step))
+    def _say(self, text: str):
+        if self.verbose:
+            print(text, flush=True)
 
-    def _remove_old_checkpoints(self):
-        while len(self._checkpoints_buffer) > self._max_to_keep:
-            path, stamp = self._checkpoints_buffer.pop(0)
-            if stamp > self._next_save_time:
-                self._checkpoints_permanent.append((path, stamp))
-                self._next_save_time = stamp + self._keep_checkpoint_every_n_hours * 3600
-            else:
-                os.remove(path)
+    # ------------------------------------------------------------------ writing
+    def _write_index(self):
+        lines = self.window.names() + [f"Best step: {self.best['step']}"]
+        if len(lines) == 1:
+            lines.insert(0, "")               # an empty run still has its (empty) name line in front of the best-step line
+        with open(os.path.join(self.root, "checkpoints.txt"), "w") as f:
+            f.write("\n".join(lines))
+
+    @staticmethod
+    def _snapshot(step, models, optimizers, schedulers, meta_data) -> dict:
+        snap = {"step": step}
+        snap.update({name: de_parallel(net).state_dict() for name, net in models.items()})
+        for group in (optimizers, schedulers):
+            snap.update({name: obj.state_dict() for name, obj in (group or {}).items()})
+        snap.update(meta_data or {})
+        return snap
 
     def save(self, models: dict, optimizers: dict, step: int, schedulers: dict = None, meta_data: dict = None, score=0.0):
-        if self._save_path is None:
-            raise AssertionError("Checkpoint manager must be initialized with save path for save().")
-        os.makedirs(os.path.join(self._save_path, "model"), exist_ok=True)
-        name = os.path.join(self._save_path, "model", "model_{:06d}.pth".format(step))
-        state = {"step": step}
-        for key, m in models.items():
-            state[key] = de_parallel(m).state_dict()
-        for key, o in optimizers.items():
-            state[key] = o.state_dict()
-        for key, s in (schedulers or {}).items():
-            state[key] = s.state_dict()
-        for key, v in (meta_data or {}).items():
-            state[key] = v
-        if self._verbose:
-            print(f"Saving checkpoint: {name}")
-        torch.save(state, name)
-        shutil.copy(name, os.path.join(self._save_path, "model.pth"))
-        self._checkpoints_buffer.append((name, time.time()))
-        if self._best_score is None or np.all(np.array(score) >= np.array(self._best_score)):
-            shutil.copyfile(name, os.path.join(self._save_path, "model_best.pth"))
-            self._best_score, self._best_step = score, step
-            if self._verbose:
-                print("Checkpoint is current best, score={}".format(np.array_str(np.array(score), precision=3)))
-        self._remove_old_checkpoints()
-        if self._checkpoints_fname is None:
-            self._checkpoints_fname = os.path.join(self._save_path, "checkpoints.txt")
-        self._update_checkpoints_file()
+        assert self.root is not None, "save() needs a directory: construct the manager with save_path or call set_save_path()"
+        step_dir = os.path.join(self.root, "model")
+        os.makedirs(step_dir, exist_ok=True)
+        target = os.path.join(step_dir, f"model_{step:06d}.pth")
+        torch.save(self._snapshot(step, models, optimizers, schedulers, meta_data), target)
+        self._say(f"checkpoint written: {target}")
+        shutil.copyfile(target, os.path.join(self.root, "model.pth"))
+        if _at_least_as_good(score, self.best["score"]):
+            shutil.copyfile(target, os.path.join(self.root, "model_best.pth"))
+            self.best = {"score": score, "step": step}
+            self._say(f"  new best at step {step}: score {np.array2string(np.asarray(score), precision=3)}")
+        self.window.admit(target)
+        self._write_index()
 
-    # ------------------------------------------------------------------ load
+    # ------------------------------------------------------------------ reading
+    def _locate(self, ckpt_path: str):
+        """The file to resume from: the explicit path when it exists, else the run directory's newest checkpoint."""
+        if ckpt_path and os.path.exists(ckpt_path):
+            return ckpt_path, "checkpoint"
+        if self.root is not None and os.path.isdir(self.root):
+            return os.path.join(self.root, "model.pth"), "latest checkpoint"
+        return None, ""
+
     def load_no_config(self, ckpt_path: str, distributed: bool = False, local_rank: int = 0, models: dict = None,
                        optimizers: dict = None, schedulers: dict = None, meta_data: dict = None, map_location=None) -> int:
-        """Restores whatever is passed from ``ckpt_path`` (or, when that does not exist, from save_path/model.pth) and returns
-        the stored step; 0 when there is no checkpoint.  A name that is asked for but not in the file is a KeyError, a
-        state_dict mismatch raises from load_state_dict (strict) — as in the reference.  ``map_location`` is an addition
-        (default: cuda:{local_rank} when distributed, else the device the tensors were saved from, CPU if that is absent)."""
-        name = None
-        if ckpt_path and os.path.exists(ckpt_path):
-            name = ckpt_path
-            if self._verbose:
-                print(f"[INFO] Resuming from checkpoint {name}...")
-        elif self._save_path is not None and os.path.isdir(self._save_path):
-            name = os.path.join(self._save_path, "model.pth")
-            if self._verbose:
-                print(f"[INFO] Resuming from latest checkpoint {name}...")
-        if name is None or not os.path.exists(name):
-            if self._verbose:
-                print(f"[WARNING] Checkpoint {name} does not exist, training from scratch!")
+        """Restores every object passed in from ``ckpt_path`` (or, when that does not exist, from <save_path>/model.pth) and returns
+        the stored step; 0 when there is nothing to resume from.  Asking for a name the file does not hold is a KeyError, a
+        state_dict that does not fit raises from load_state_dict (strict).  ``meta_data``: its keys are looked up in the file and
+        the values filled in.  ``map_location`` (an addition; default: cuda:{local_rank} when distributed, else wherever the tensors
+        were saved from, CPU on a box without a GPU)."""
+        source, kind = self._locate(ckpt_path)
+        if source is None or not os.path.exists(source):
+            self._say(f"nothing to resume from ({source or ckpt_path or 'no path'}): starting at step 0")
             return 0
+        self._say(f"resuming from {kind} {source}")
         from .ngp import install_pickle_shims
         install_pickle_shims()
         if map_location is None:
             map_location = f"cuda:{local_rank}" if distributed else (None if torch.cuda.is_available() else "cpu")
-        state = torch.load(name, map_location=map_location, weights_only=False)
-        step = state["step"] if "step" in state else 0
-        for key, m in (models or {}).items():
-            de_parallel(m).load_state_dict(state[key])
-        for key, o in (optimizers or {}).items():
-            o.load_state_dict(state[key])
-        for key, s in (schedulers or {}).items():
-            s.load_state_dict(state[key])
+        snap = torch.load(source, map_location=map_location, weights_only=False)
+        for name, net in (models or {}).items():
+            de_parallel(net).load_state_dict(snap[name])
+        for group in (optimizers, schedulers):
+            for name, obj in (group or {}).items():
+                obj.load_state_dict(snap[name])
         if meta_data is not None:
-            for key in meta_data.keys():
-                meta_data[key] = state[key]
-        if self._verbose:
-            print(f"[INFO] Loaded models from {name}")
-        return step
+            meta_data.update({key: snap[key] for key in list(meta_data)})
+        self._say(f"restored {sorted((models or {}).keys())} at step {snap.get('step', 0)}")
+        return snap.get("step", 0)
 
     def load(self, config, models: dict = None, optimizers: dict = None, schedulers: dict = None, meta_data: dict = None,
              map_location=None) -> int:
-        """config carries ckpt_path / distributed / local_rank (conerf/utils/config.py; checkpoint_manager.py:198-222)."""
+        """``config``: the parsed flags (ckpt_path, distributed, local_rank of dreg_nerf_amd/config.py)."""
         return self.load_no_config(getattr(config, "ckpt_path", "") or "", bool(getattr(config, "distributed", False)),
                                    int(getattr(config, "local_rank", 0)), models, optimizers, schedulers, meta_data, map_location)

@@ -355,7 +355,13 @@ def build_voxel_grid(world, rgb, alpha, indices, keep, resolution: int):
     return grid.view(resolution, resolution, resolution, 7), indices[keep]
 
 
-def save_voxel_grid(out_dir: str, voxel_grid: torch.Tensor, voxel_mask: torch.Tensor, prefix: str = "voxel"):
+def save_voxel_grid(out_dir: str, voxel_grid: torch.Tensor, voxel_mask: torch.Tensor, prefix: str = "voxel", points=None, colors=None):
+    """<prefix>_grid.pt / <prefix>_mask.pt and, when the kept samples are passed, <prefix>_point_cloud.ply (positions + colours of
+    the kept samples, the layout open3d writes: eval_ngp_nerf.py:357-362,388-394).  prefix 'voxel' = surface AND density mask (what
+    the registration dataset reads), 'density_voxel' = density mask only (:350-381)."""
     os.makedirs(out_dir, exist_ok=True)
     torch.save(voxel_grid.cpu(), os.path.join(out_dir, f"{prefix}_grid.pt"))
     torch.save(voxel_mask.cpu(), os.path.join(out_dir, f"{prefix}_mask.pt"))
+    if points is not None:
+        from .vis_dump import write_ply
+        write_ply(os.path.join(out_dir, f"{prefix}_point_cloud.ply"), points.float().cpu(), None if colors is None else colors.float().cpu())

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Voxel-grid extraction from trained NeRF blocks on MI355X — drop-in for the `sample_points` part of the reference's
 eval_ngp_nerf.py (:336-451, `--multi_blocks`): for every <root>/<dataset>/nerf_models/<scene>/block_k/model.pth write
-voxel_grid.pt / voxel_mask.pt next to it.  Blocks are independent: ranks take blocks round-robin (replicas only)."""
+voxel_grid.pt / voxel_mask.pt / voxel_point_cloud.ply and their density_voxel_* twins next to it.  Blocks are independent: ranks take blocks round-robin (replicas only)."""
 import glob
 import os
 
@@ -28,8 +28,13 @@ def extract_block(ckpt_path: str, dev, density_thre: float = 0.7):
     res = int(sg.resolution[0])
     state = meta
     world, rgb, alpha, idx, dmask, smask = sg.query_radiance_and_density_from_camera(field, None, state, dev, density_thre)
-    grid, mask = ngp.build_voxel_grid(world, rgb, alpha, idx, dmask & smask, res)
-    ngp.save_voxel_grid(os.path.dirname(ckpt_path), grid, mask)
+    out_dir = os.path.dirname(ckpt_path)
+    # the density-field twins first (eval_ngp_nerf.py:350-381), then the surface AND density set the registration dataset reads (:383-412)
+    dgrid, dmask_idx = ngp.build_voxel_grid(world, rgb, alpha, idx, dmask, res)
+    ngp.save_voxel_grid(out_dir, dgrid, dmask_idx, prefix="density_voxel", points=world[dmask], colors=rgb[dmask])
+    keep = dmask & smask
+    grid, mask = ngp.build_voxel_grid(world, rgb, alpha, idx, keep, res)
+    ngp.save_voxel_grid(out_dir, grid, mask, points=world[keep], colors=rgb[keep])
     return int(mask.shape[0])
 
 

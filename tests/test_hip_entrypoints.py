@@ -65,3 +65,18 @@ def test_grid_extraction_from_block_checkpoint(tmp_path):
     assert torch.all(binary.flatten()[mask]) and torch.all(mask[1:] > mask[:-1])
     # kept voxels = density mask AND surface-visible from a camera: a strict subset of the occupied cells here
     assert 0 < mask.numel() < int(binary.sum())
+    # the reference's other outputs of sample_points (eval_ngp_nerf.py:350-394): the density-mask twins and both point clouds
+    from dreg_nerf_amd.vis_dump import read_ply
+    dgrid, dmask = torch.load(str(d / "density_voxel_grid.pt")), torch.load(str(d / "density_voxel_mask.pt"))
+    assert dgrid.shape == grid.shape and dmask.dtype == torch.int64 and torch.all(dmask[1:] > dmask[:-1])
+    assert set(mask.tolist()) <= set(dmask.tolist()) and torch.all(binary.flatten()[dmask])       # surface AND density is a subset of density
+    assert torch.equal(dgrid.reshape(-1, 7)[mask], grid.reshape(-1, 7)[mask])                        # same samples where both keep a voxel
+    others = torch.ones(res ** 3, dtype=torch.bool)
+    others[dmask] = False
+    assert float(dgrid.reshape(-1, 7)[others].abs().max()) == 0.0
+    for name, g7, m in (("voxel_point_cloud.ply", grid, mask), ("density_voxel_point_cloud.ply", dgrid, dmask)):
+        xyz, rgb = read_ply(str(d / name))
+        rows = g7.reshape(-1, 7)[m]
+        assert xyz.shape == (m.numel(), 3) and rgb.shape == (m.numel(), 3)
+        assert torch.allclose(torch.from_numpy(xyz).float(), rows[:, :3], atol=1e-6)
+        assert torch.equal(torch.from_numpy(rgb).long(), torch.clamp(torch.round(rows[:, 3:6].double() * 255.0), 0, 255).long())
