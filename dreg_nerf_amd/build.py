@@ -43,7 +43,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
-    if force or procs or not os.path.exists(LIB):
+    if force or procs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)

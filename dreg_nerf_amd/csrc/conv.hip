@@ -668,6 +668,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 // XOR of the 16-byte granule index with f(row), applied on the SOURCE side of the DMA and on the read address:
 // 256-byte rows: f = ((row&3) + 4*((row>>3)&1)) * 2;  128-byte rows: f = (((row>>1)&1) + 2*((row>>3)&1)) * 2.
 // (ds_read_b64_tr_b16 services a 32-lane half-wave per cycle: voxel rows r..r+3 and r+8..r+11 must land on disjoint banks)
+__device__ unsigned long long g_wgrad_dbg[8];   // AP == 2 (tools/wgrad_phase_probe.py, measurement only): cycles per phase, summed over waves
 template <int GP> __device__ __forceinline__ int wg_swz(int row) {   // rows of >= 256 bytes (GP >= 16): the XOR acts on the low four granule bits
     return GP >= 16 ? (((row & 3) + 4 * ((row >> 3) & 1)) << 1) : ((((row >> 1) & 1) + 2 * ((row >> 3) & 1)) << 1);
 }
@@ -681,7 +682,12 @@ template <int GP> __device__ __forceinline__ int wg_swz(int row) {   // rows of 
 // stages x 2 keep 64 KB per CU in flight for either tile; 32-voxel stages x 4 or 5 keep 96 / 128 KB in the same LDS footprint.
 // PIPE: the fragment reads of the next group of MFMAs are issued before the current group's MFMAs (two register slots per operand),
 // so the LDS read phase of a wave runs under its own MFMAs instead of in front of them; same products, same accumulation order.
-template <int BM, int BNC, bool ROWS, int NW = 4, int ABL = 0, int KV_ = 64, int NS_ = 2, int PIPE = 0>
+// AP (round 3, NW = 8, KV = 32, NS = 4): ANTI-PHASE wave groups.  Waves 0-3 and 4-7 (wave w and w + 4 share a SIMD) run one barrier
+// apart over 32-voxel units: in every phase one group issues its 4 direct-to-LDS pieces for the unit three ahead and reads the 24
+// transposed fragments of its next unit, while the other group runs the 32 MFMAs of the unit it read one phase earlier at raised
+// priority; then they swap.  Same products in the same order as the lockstep loop (bit-identical), but a SIMD's matrix pipe always
+// has one of its two waves in the MFMA half instead of both loading, then both multiplying behind one barrier per stage.
+template <int BM, int BNC, bool ROWS, int NW = 4, int ABL = 0, int KV_ = 64, int NS_ = 2, int PIPE = 0, int AP = 0>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
     const bf16_t* __restrict__ gout, const bf16_t* __restrict__ in, float* __restrict__ part,
     ConvGeom g, int tilesCol, int tiles, int nsplit, uint32_t vox_per_split, uint32_t gout_bytes, uint32_t in_bytes,
@@ -834,6 +840,38 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
                 return;
             }
         }
+        if (AP && aligned) {
+            // anti-phase loop: every address of the unit first (independent chains the scheduler can interleave), then the pieces back to
+            // back — with an address chain in front of each piece a piece cost ~200 cycles of the load half (tools/wgrad_phase_probe.py)
+            uint32_t voa[IA], vob[IB];
+#pragma unroll
+            for (int i = 0; i < IA; ++i) {
+                const uint32_t vi = v0 + (wave * IA + i) * RPA + ra;
+                voa[i] = (vi < v_end) ? vi * (uint32_t)(g.Cout * 2) + a_col[i] : OOB;
+            }
+            int sb, sz, sy, sx;
+            vox_decode(v0, g, sb, sz, sy, sx);
+            const uint32_t base = (uint32_t)(((sb * g.Di + sz) * g.Hi + sy) * g.Wi + sx) * (uint32_t)(g.Cin * 2);
+            const uint32_t left = v_end - v0;
+#pragma unroll
+            for (int i = 0; i < IB; ++i) {
+                const bool v = al_l[i] < left && (unsigned)(sz + al_dz[i]) < (unsigned)g.Di && (unsigned)(sy + al_dy[i]) < (unsigned)g.Hi &&
+                               (unsigned)(sx + al_x[i]) < (unsigned)g.Wi;
+                vob[i] = v ? base + al_off[i] : OOB;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < IA; ++i) {
+                if constexpr (ABL != 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(sA + (wave * IA + i) * 1024), 16, (int)voa[i], 0, 0, 0);
+                else asm volatile("" :: "v"(voa[i]));
+            }
+#pragma unroll
+            for (int i = 0; i < IB; ++i) {
+                if constexpr (ABL != 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sB + (wave * IB + i) * 1024), 16, (int)vob[i], 0, 0, 0);
+                else asm volatile("" :: "v"(vob[i]));
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
             const int j = wave * IA + i;
@@ -985,6 +1023,213 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
         }
     };
 
+    if constexpr (AP) {
+        // AP: 1 general anti-phase loop, 3 FAST dense form; 2 / 4 = the same with s_memtime stamps (tools/wgrad_phase_probe.py).
+        // What the probe showed: a wave issues roughly one instruction per 5 cycles, whatever the instruction is — the load half of the
+        // first anti-phase version took ~1,400 cycles per unit for 24 fragment reads + 4 pieces because it was ~200 INSTRUCTIONS long
+        // (an address add in front of every read, a voxel decode and three compares per piece), against 620 cycles for the 32 MFMAs
+        // of the other group.  FAST (dense stride-1 same-volume layers whose 32-voxel units are parts of one x-row; host-checked):
+        //  * fragment-read addresses live in 24 registers for the whole kernel; the ring slot is an immediate offset (0 / 32 KB) plus
+        //    one +-64 KB step of those registers every second unit (the unit loop is unrolled by four);
+        //  * a piece's source offset is  uniform unit base + lane constant,  its bounds test  (lane mask & unit mask) == 0  with the
+        //    unit's (z, y, x-phase) border flags in one scalar mask advanced incrementally — no decode, no per-axis compare.
+        constexpr bool FAST = AP >= 3, STAMP = (AP == 2 || AP == 4);
+        static_assert(NW == 8 && KV == 32 && NS == 4 && PIPE == 0 && LPS <= 15, "anti-phase loop: 8 waves, four 32-voxel units in the ring");
+        static_assert(!FAST || !ROWS, "the fast form is dense");
+        if (v_begin < v_end) {
+            const int nk = (int)((v_end - v_begin + KV - 1) / KV);
+            const int grp = wave >> 2;
+            const int fi = lane & 15;
+            i32x2_t alo[TM], ahi[TM], blo[TN], bhi[TN];
+            // ---- fragment reads
+            uint32_t fa[2 * TM + 2 * TN];                  // FAST: LDS byte addresses of this lane's 24 reads in ring slot 0 (or 2)
+            if constexpr (FAST) {
+                const int kb = (lane >> 4) * 8;
+                const int r0 = kb + (fi >> 2), r1 = r0 + 4;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int gi = (wm * WM + i * 16) / 8 + ((fi & 3) >> 1), o8 = (fi & 1) * 8;
+                    fa[2 * i] = lds_base + r0 * RSA + ((gi ^ wg_swz<GPA>(r0)) << 4) + o8;
+                    fa[2 * i + 1] = lds_base + r1 * RSA + ((gi ^ wg_swz<GPA>(r1)) << 4) + o8;
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int gi = (wn * WN + j * 16) / 8 + ((fi & 3) >> 1), o8 = (fi & 1) * 8;
+                    fa[2 * TM + 2 * j] = lds_base + A_BYTES + r0 * RSB + ((gi ^ wg_swz<GPB>(r0)) << 4) + o8;
+                    fa[2 * TM + 2 * j + 1] = lds_base + A_BYTES + r1 * RSB + ((gi ^ wg_swz<GPB>(r1)) << 4) + o8;
+                }
+            }
+            auto tr_read_hi = [&](uint32_t addr) -> i32x2_t {    // the same read 32 KB further (odd ring slots)
+                i32x2_t v;
+                if constexpr (ABL != 2) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:32768" : "=v"(v) : "v"(addr));
+                else { v = (i32x2_t){(int)addr, (int)addr}; asm volatile("" : "+v"(v)); }
+                return v;
+            };
+            auto rd = [&](int buf) {
+                if constexpr (FAST) {
+                    if (buf & 1) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) { alo[i] = tr_read_hi(fa[2 * i]); ahi[i] = tr_read_hi(fa[2 * i + 1]); }
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) { blo[j] = tr_read_hi(fa[2 * TM + 2 * j]); bhi[j] = tr_read_hi(fa[2 * TM + 2 * j + 1]); }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) { alo[i] = tr_read(fa[2 * i]); ahi[i] = tr_read(fa[2 * i + 1]); }
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) { blo[j] = tr_read(fa[2 * TM + 2 * j]); bhi[j] = tr_read(fa[2 * TM + 2 * j + 1]); }
+                    }
+                    return;
+                }
+                const uint32_t sA = lds_base + buf * STAGE;
+                const uint32_t sB = sA + A_BYTES;
+                const int kb = (lane >> 4) * 8;
+                const int r0 = kb + (fi >> 2), r1 = r0 + 4;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int gi = (wm * WM + i * 16) / 8 + ((fi & 3) >> 1), o8 = (fi & 1) * 8;
+                    alo[i] = tr_read(sA + r0 * RSA + ((gi ^ wg_swz<GPA>(r0)) << 4) + o8);
+                    ahi[i] = tr_read(sA + r1 * RSA + ((gi ^ wg_swz<GPA>(r1)) << 4) + o8);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int gi = (wn * WN + j * 16) / 8 + ((fi & 3) >> 1), o8 = (fi & 1) * 8;
+                    blo[j] = tr_read(sB + r0 * RSB + ((gi ^ wg_swz<GPB>(r0)) << 4) + o8);
+                    bhi[j] = tr_read(sB + r1 * RSB + ((gi ^ wg_swz<GPB>(r1)) << 4) + o8);
+                }
+            };
+            auto mm = [&]() {
+                typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+                bf16x8_t af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) { i32x4_t t4 = {alo[i][0], alo[i][1], ahi[i][0], ahi[i][1]}; af[i] = __builtin_bit_cast(bf16x8_t, t4); }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { i32x4_t t4 = {blo[j][0], blo[j][1], bhi[j][0], bhi[j][1]}; bf[j] = __builtin_bit_cast(bf16x8_t, t4); }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (ABL != 1) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                        else asm volatile("" :: "v"(af[i]), "v"(bf[j]));
+                    }
+            };
+            // ---- pieces.  FAST: lane constants + an incrementally advanced scalar cursor (the NEXT unit to request)
+            uint32_t pa_off[IA], pb_off[IB], pb_m[IB];
+            uint32_t cur_v = v_begin;                      // first voxel of the next unit to request
+            int cz = 0, cy = 0, cx = 0;
+            if constexpr (FAST) {
+#pragma unroll
+                for (int i = 0; i < IA; ++i) pa_off[i] = (uint32_t)((wave * IA + i) * RPA + ra) * (uint32_t)(g.Cout * 2) + a_col[i];
+#pragma unroll
+                for (int i = 0; i < IB; ++i) {
+                    const int l = (wave * IB + i) * RPB + rb;              // voxel of this lane inside a unit = its x offset in the row part
+                    const int dz = g.off + b_dz[i], dy = g.off + b_dy[i], dx = g.off + b_dx[i];
+                    pb_off[i] = (uint32_t)((((dz * g.Hi + dy) * g.Wi + (l + dx)) * g.Cin + b_ci[i]) * 2);   // relative to the unit's first voxel, mod 2^32
+                    pb_m[i] = (dz < 0 ? 1u : 0u) | (dz > 0 ? 2u : 0u) | (dy < 0 ? 4u : 0u) | (dy > 0 ? 8u : 0u) |
+                              (l + dx < 0 ? 16u : 0u) | (l + dx >= KV ? 32u : 0u) | (b_tv[i] ? 0u : 64u);
+                }
+                int cb;
+                vox_decode(v_begin, g, cb, cz, cy, cx);
+            }
+            // the source offsets of the NEXT request are computed one half earlier (prep_fast: inside the MFMA half, where the wave has
+            // ~70 idle issue slots between its 32 MFMAs) and only handed to the direct-to-LDS instructions in the load half
+            uint32_t voa[IA], vob[IB];
+            auto prep_fast = [&]() {
+                const uint32_t smask = (cz == 0 ? 1u : 0u) | (cz == g.Do - 1 ? 2u : 0u) | (cy == 0 ? 4u : 0u) | (cy == g.Ho - 1 ? 8u : 0u) |
+                                       (cx == 0 ? 16u : 0u) | (cx + KV == g.Wo ? 32u : 0u) | 64u;
+                const uint32_t ab = cur_v * (uint32_t)(g.Cout * 2), bb = cur_v * (uint32_t)(g.Cin * 2);
+#pragma unroll
+                for (int i = 0; i < IA; ++i) voa[i] = ab + pa_off[i];
+#pragma unroll
+                for (int i = 0; i < IB; ++i) vob[i] = (pb_m[i] & smask) == 0u ? bb + pb_off[i] : OOB;
+                cur_v += KV; cx += KV;
+                if (cx == g.Wo) { cx = 0; if (++cy == g.Ho) { cy = 0; if (++cz == g.Do) cz = 0; } }
+            };
+            auto issue_fast = [&](int buf) {
+                char* sA = smem + buf * STAGE;
+                char* sB = sA + A_BYTES;
+#pragma unroll
+                for (int i = 0; i < IA; ++i) {
+                    if constexpr (ABL != 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(sA + (wave * IA + i) * 1024), 16, (int)voa[i], 0, 0, 0);
+                    else asm volatile("" :: "v"(voa[i]));
+                }
+#pragma unroll
+                for (int i = 0; i < IB; ++i) {
+                    if constexpr (ABL != 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sB + (wave * IB + i) * 1024), 16, (int)vob[i], 0, 0, 0);
+                    else asm volatile("" :: "v"(vob[i]));
+                }
+            };
+            auto request = [&](int u) {                    // unit u -> ring slot u & 3 (units are requested in order)
+                if constexpr (FAST) issue_fast(u & 3);
+                else issue(v_begin + (uint32_t)u * KV, u & 3);
+            };
+            // prologue: units 0..2 requested; unit 0 has landed (own pieces: counted wait; the others': the barrier)
+            for (int p = 0; p < 3 && p < nk; ++p) { if constexpr (FAST) prep_fast(); request(p); }
+            if constexpr (FAST) prep_fast();                 // offsets of unit 3, requested in the first load half
+            if (nk >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+            else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (grp) __builtin_amdgcn_s_barrier();           // the second group runs one phase behind
+            unsigned long long dsum[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+            auto stamp = [&](int q) {
+                if constexpr (STAMP) {
+                    unsigned long long tnow;
+                    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow) :: "memory");
+                    if (q >= 0) dsum[q] += tnow - tprev;
+                    tprev = tnow;
+                }
+            };
+            stamp(-1);
+            auto unit = [&](int u, int slot) {
+                // ---- load half: fragment reads of unit u, then unit u + 3 into the ring slot of unit u - 1 (both groups have read it)
+                rd(slot);
+                stamp(0);
+                if (u + 3 < nk) request(u + 3);
+                stamp(1);
+                // this wave's pieces of unit u + 1 must have landed before the barrier that closes this phase
+                const int younger = min(nk - 1, u + 3) - (u + 1);
+                if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                stamp(2);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                stamp(3);
+                // ---- MFMA half
+                if (!(rows_fast & 2)) __builtin_amdgcn_s_setprio(1);   // (rows_fast bit 1: experiment, no priority raise)
+                if constexpr (FAST) prep_fast();            // offsets of unit u + 4 (scalar cursor + ~12 VALU): scheduled among the MFMAs
+                mm();
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                stamp(4);
+                __builtin_amdgcn_s_barrier();
+                stamp(5);
+            };
+            if constexpr (FAST) {
+                for (int u = 0; u < nk; u += 4) {
+                    unit(u, 0);
+                    if (u + 1 < nk) unit(u + 1, 1);
+#pragma unroll
+                    for (int k = 0; k < 2 * TM + 2 * TN; ++k) fa[k] += 2u * STAGE;
+                    if (u + 2 < nk) unit(u + 2, 2);
+                    if (u + 3 < nk) unit(u + 3, 3);
+#pragma unroll
+                    for (int k = 0; k < 2 * TM + 2 * TN; ++k) fa[k] -= 2u * STAGE;
+                }
+            } else {
+                for (int u = 0; u < nk; ++u) unit(u, u & 3);
+            }
+            if (!grp) __builtin_amdgcn_s_barrier();
+            if constexpr (STAMP) {
+                if (lane == 0) {
+                    for (int q = 0; q < 6; ++q) atomicAdd(&g_wgrad_dbg[q], dsum[q]);
+                    atomicAdd(&g_wgrad_dbg[6], (unsigned long long)nk);
+                    atomicAdd(&g_wgrad_dbg[7], 1ull);
+                }
+            }
+        }
+    } else
     if (v_begin < v_end) {
         // NS-deep LDS ring, loads issued 3 stages ahead; stage k is consumed after a COUNTED wait (the two younger stages stay
         // in flight across the barrier) + a raw s_barrier (a __syncthreads() here would drain the DMA queue with vmcnt(0)).
@@ -1606,6 +1851,14 @@ int dreg_conv_igemm_probe_read(unsigned long long* out6)
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_dbg), z, sizeof(z)) != hipSuccess) return DREG_ELAUNCH;
     return DREG_OK;
 }
+int dreg_conv_wgrad_probe_read(unsigned long long* out8)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return DREG_ELAUNCH;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wgrad_dbg), 8 * sizeof(unsigned long long)) != hipSuccess) return DREG_ELAUNCH;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_dbg), z, sizeof(z)) != hipSuccess) return DREG_ELAUNCH;
+    return DREG_OK;
+}
 void dreg_conv_set_wgrad_rows_fast(int enable) { g_rows_fast = enable ? 1 : 0; }
 void dreg_conv_set_wgrad_ring(int mode) { g_wgrad_ring = mode; }
 void dreg_conv_set_wgrad_pipe(int enable) { g_wgrad_pipe = enable ? 1 : 0; }
@@ -1808,6 +2061,22 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
                 (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, false, 8, 0, 32, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, false, 8, 0, 32, 5>), dim3(tiles256 * nsplit), dim3(512), (size_t)5 * 32 * 512 * 2, st, (const bf16_t*)gout,
                                    (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr);
+            } else if (g_wgrad_ring >= 3 && g_wgrad_ring <= 8) {
+                // anti-phase wave groups over a ring of four 32-voxel units.  3: product form (FAST when the layer qualifies, else the general
+                // loop); 8: the general loop; 4..7 measurement only: FAST with s_memtime stamps, 5..7 (wrong results) without fragment
+                // reads / without pieces / without MFMAs
+                const bool fast_ok = ksz <= 3 && g.sn == 1 && g.sd == 1 && g.dsign == 1 && Di == Do && Hi == Ho && Wi == Wo && (Wo % 32) == 0 &&
+                                     (g.M % 32u) == 0 && (vps % 32u) == 0;
+#define WG_AP(A, APv) do { (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, false, 8, A, 32, 4, 0, APv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, false, 8, A, 32, 4, 0, APv>), dim3(tiles256 * nsplit), dim3(512), (size_t)4 * 32 * 512 * 2, st, (const bf16_t*)gout, \
+                                   (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr, g_wgrad_pipe ? 2 : 0); } while (0)
+                if (g_wgrad_ring == 8 || !fast_ok) WG_AP(0, 1);
+                else if (g_wgrad_ring == 3) WG_AP(0, 3);
+                else if (g_wgrad_ring == 4) WG_AP(0, 4);
+                else if (g_wgrad_ring == 5) WG_AP(2, 4);
+                else if (g_wgrad_ring == 6) WG_AP(3, 4);
+                else WG_AP(1, 4);
+#undef WG_AP
             } else if (g_wgrad_ring == 1) {
                 (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, false, 8, 0, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, false, 8, 0, 32, 4>), dim3(tiles256 * nsplit), dim3(512), (size_t)4 * 32 * 512 * 2, st, (const bf16_t*)gout,

@@ -45,6 +45,7 @@ SIGNATURES = {
     "dreg_conv_igemm_probe": (None, [I]),
     "dreg_conv_igemm_probe_read": (I, [P]),
     "dreg_conv_set_wgrad_pipe": (None, [I]),
+    "dreg_conv_wgrad_probe_read": (I, [P]),
     "dreg_conv_set_wgrad_ring": (None, [I]),
     "dreg_conv_set_wgrad_rows_fast": (None, [I]),
     "dreg_conv_set_glds_stages": (None, [I]),

@@ -111,26 +111,65 @@ def is_buffer(kind: str) -> bool:
     return kind in ("bn_mean", "bn_var", "bn_count")
 
 
-def _fill(key: str, shape: tuple, kind: str, seed: int) -> torch.Tensor:
+# Weight profiles (all generated from (key, seed); nothing stored).
+#   "default": the reference's own initialisation scheme (Xavier-normal convolutions / linears, BatchNorm / LayerNorm gains ~ 1).  At
+#       B = 1 with train-mode BatchNorm over 8..64 voxels this network is chaotic: the gradient norm grows from 1.5e3 at the decoder to
+#       3e5 at the ResNet and bf16 operand rounding alone moves early-layer gradients by O(1) (profiles/r02_pinned_step_report.json).
+#   "wc": a WELL-CONDITIONED point of the same parameter space, for tests that bound the bf16 build in absolute terms
+#       (tests/test_hip_pinned_step.py): the last BatchNorm gain of every bottleneck ~ 0.15 (near-identity residual blocks, as in
+#       zero-init-residual training), output projections of the transformer's attention / FFN branches scaled by 0.3, the shared final
+#       LayerNorm gain ~ 0.1 and the correspondence decoder's key projection EQUAL to its query projection with gain 1.5 — so the
+#       decoder's logits are a positive-definite kernel dominated by the position embedding, the soft correspondences are peaked on
+#       nearby points and the weighted-Kabsch problem is full rank instead of collapsing to the centroids; the FPN laterals of the three
+#       deepest levels (c3..c5: train-mode BatchNorm over 8..512 voxels per grid) scaled by 0.03, so their rounding noise does not
+#       drown the early layers' gradients (the deep layers still run forward and backward; their own gradients are compared by
+#       cosine, which is scale-free).  tools/wc_profile_sweep.py shows what each knob buys.
+PROFILES = {
+    "default": {},
+    "wc": {"bn3_gain": 0.15, "branch_out_gain": 0.3, "final_ln_gain": 0.1, "qk_shared_gain": 1.5, "deep_lateral_gain": 0.03},
+}
+_BRANCH_OUT = ("self_attn.out_proj.weight", "cross_attn.out_proj.weight", "linear2.weight")
+
+
+def _fill(key: str, shape: tuple, kind: str, seed: int, knobs: dict = None) -> torch.Tensor:
+    knobs = knobs or {}
+    if knobs.get("qk_shared_gain") and key == "correspondence_decoder.k_proj.weight":
+        key = "correspondence_decoder.q_proj.weight"            # same generator stream -> the same matrix
     g = torch.Generator().manual_seed((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
     if kind == "bn_count":
         return torch.zeros((), dtype=torch.int64)
     n = torch.randn(shape, generator=g, dtype=torch.float32)
     if kind == "conv":
         rf = shape[2] * shape[3] * shape[4]
-        return n * math.sqrt(2.0 / ((shape[0] + shape[1]) * rf))
+        gain = 1.0
+        if knobs.get("deep_lateral_gain") and key.endswith(("pyramid_transformation_3.weight", "pyramid_transformation_4.weight", "pyramid_transformation_5.weight")):
+            gain = float(knobs["deep_lateral_gain"])
+        return n * (gain * math.sqrt(2.0 / ((shape[0] + shape[1]) * rf)))
     if kind == "linear":
-        return n * math.sqrt(2.0 / (shape[0] + shape[1]))
+        gain = 1.0
+        if knobs.get("qk_shared_gain") and key == "correspondence_decoder.q_proj.weight":
+            gain = float(knobs["qk_shared_gain"])
+        if knobs.get("branch_out_gain") and key.endswith(_BRANCH_OUT):
+            gain = float(knobs["branch_out_gain"])
+        return n * (gain * math.sqrt(2.0 / (shape[0] + shape[1])))
     if kind in ("bn_weight", "ln_weight"):
-        return 1.0 + 0.1 * n
+        gain = 1.0
+        if knobs.get("bn3_gain") and key.endswith(".bn3.weight"):
+            gain = float(knobs["bn3_gain"])
+        if knobs.get("final_ln_gain") and key == "transformer_encoder.norm.weight":
+            gain = float(knobs["final_ln_gain"])
+        return gain * (1.0 + 0.1 * n)
     if kind == "bn_var":
         return 1.0 + 0.1 * n.abs()
+    if kind == "bn_bias" and knobs.get("bn_bias_gain"):
+        return float(knobs["bn_bias_gain"]) * n
     return 0.05 * n  # biases, bn_mean
 
 
-def synth_state_dict(seed: int = 0, pos_emb_type: str = "sine") -> Dict[str, torch.Tensor]:
+def synth_state_dict(seed: int = 0, pos_emb_type: str = "sine", profile="default") -> Dict[str, torch.Tensor]:
     """Deterministic, key-seeded fill of every entry (fp32, CPU).  Both ResNet aliases (and both names of a learned position
-    embedding) point at the same tensors, as in the reference module."""
+    embedding) point at the same tensors, as in the reference module.  profile: a name in PROFILES or a dict of its knobs."""
+    knobs = PROFILES[profile] if isinstance(profile, str) else dict(profile)
     sd = OrderedDict()
     for key, (shape, kind) in regtr_spec(pos_emb_type).items():
         if key.startswith(ALIAS_DST):
@@ -138,7 +177,7 @@ def synth_state_dict(seed: int = 0, pos_emb_type: str = "sine") -> Dict[str, tor
         elif key.startswith(POS_EMBED_ALIAS):
             sd[key] = sd["pos_embed." + key[len(POS_EMBED_ALIAS):]]
         else:
-            sd[key] = _fill(key, shape, kind, seed)
+            sd[key] = _fill(key, shape, kind, seed, knobs)
     return sd
 
 
