@@ -1042,42 +1042,42 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
             const int fi = lane & 15;
             i32x2_t alo[TM], ahi[TM], blo[TN], bhi[TN];
             // ---- fragment reads
-            uint32_t fa[2 * TM + 2 * TN];                  // FAST: LDS byte addresses of this lane's 24 reads in ring slot 0 (or 2)
+            // FAST: LDS byte addresses of this lane's reads of fragment row r0 in ring slot 0 (or 2).  Row r1 = r0 + 4 has the same
+            // swizzle (r0 and r0 + 4 agree in row & 3 and in row >> 3), so its read is the same address + 4 rows as an immediate offset,
+            // and the odd ring slots are + 32 KB as an immediate as well: 12 address registers serve all 24 reads of every unit.
+            uint32_t fa[TM + TN];
             if constexpr (FAST) {
+                static_assert(RSA == RSB, "one row stride for both operands");
                 const int kb = (lane >> 4) * 8;
-                const int r0 = kb + (fi >> 2), r1 = r0 + 4;
+                const int r0 = kb + (fi >> 2);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int gi = (wm * WM + i * 16) / 8 + ((fi & 3) >> 1), o8 = (fi & 1) * 8;
-                    fa[2 * i] = lds_base + r0 * RSA + ((gi ^ wg_swz<GPA>(r0)) << 4) + o8;
-                    fa[2 * i + 1] = lds_base + r1 * RSA + ((gi ^ wg_swz<GPA>(r1)) << 4) + o8;
+                    fa[i] = lds_base + r0 * RSA + ((gi ^ wg_swz<GPA>(r0)) << 4) + o8;
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int gi = (wn * WN + j * 16) / 8 + ((fi & 3) >> 1), o8 = (fi & 1) * 8;
-                    fa[2 * TM + 2 * j] = lds_base + A_BYTES + r0 * RSB + ((gi ^ wg_swz<GPB>(r0)) << 4) + o8;
-                    fa[2 * TM + 2 * j + 1] = lds_base + A_BYTES + r1 * RSB + ((gi ^ wg_swz<GPB>(r1)) << 4) + o8;
+                    fa[TM + j] = lds_base + A_BYTES + r0 * RSB + ((gi ^ wg_swz<GPB>(r0)) << 4) + o8;
                 }
             }
-            auto tr_read_hi = [&](uint32_t addr) -> i32x2_t {    // the same read 32 KB further (odd ring slots)
+            auto tr_read_o = [&](uint32_t addr, int which) -> i32x2_t {   // which: 0 r0 / even slot, 1 r1 / even, 2 r0 / odd, 3 r1 / odd (constant after inlining)
                 i32x2_t v;
-                if constexpr (ABL != 2) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:32768" : "=v"(v) : "v"(addr));
-                else { v = (i32x2_t){(int)addr, (int)addr}; asm volatile("" : "+v"(v)); }
+                if constexpr (ABL != 2) {
+                    if (which == 0) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+                    else if (which == 1) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(4 * RSA));
+                    else if (which == 2) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(STAGE));
+                    else asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(STAGE + 4 * RSA));
+                } else { v = (i32x2_t){(int)addr, (int)addr}; asm volatile("" : "+v"(v)); }
                 return v;
             };
             auto rd = [&](int buf) {
                 if constexpr (FAST) {
-                    if (buf & 1) {
+                    const int odd = (buf & 1) * 2;
 #pragma unroll
-                        for (int i = 0; i < TM; ++i) { alo[i] = tr_read_hi(fa[2 * i]); ahi[i] = tr_read_hi(fa[2 * i + 1]); }
+                    for (int i = 0; i < TM; ++i) { alo[i] = tr_read_o(fa[i], odd); ahi[i] = tr_read_o(fa[i], odd + 1); }
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) { blo[j] = tr_read_hi(fa[2 * TM + 2 * j]); bhi[j] = tr_read_hi(fa[2 * TM + 2 * j + 1]); }
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) { alo[i] = tr_read(fa[2 * i]); ahi[i] = tr_read(fa[2 * i + 1]); }
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) { blo[j] = tr_read(fa[2 * TM + 2 * j]); bhi[j] = tr_read(fa[2 * TM + 2 * j + 1]); }
-                    }
+                    for (int j = 0; j < TN; ++j) { blo[j] = tr_read_o(fa[TM + j], odd); bhi[j] = tr_read_o(fa[TM + j], odd + 1); }
                     return;
                 }
                 const uint32_t sA = lds_base + buf * STAGE;
@@ -1114,7 +1114,6 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
             };
             // ---- pieces.  FAST: lane constants + an incrementally advanced scalar cursor (the NEXT unit to request)
             uint32_t pa_off[IA], pb_off[IB], pb_m[IB];
-            uint32_t cur_v = v_begin;                      // first voxel of the next unit to request
             int cz = 0, cy = 0, cx = 0;
             if constexpr (FAST) {
 #pragma unroll
@@ -1133,16 +1132,26 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
             // the source offsets of the NEXT request are computed one half earlier (prep_fast: inside the MFMA half, where the wave has
             // ~70 idle issue slots between its 32 MFMAs) and only handed to the direct-to-LDS instructions in the load half
             uint32_t voa[IA], vob[IB];
+            uint32_t cur_a = v_begin * (uint32_t)(g.Cout * 2), cur_b = v_begin * (uint32_t)(g.Cin * 2);   // byte offsets of the cursor's first voxel
+            uint32_t m_zy = 0;                             // border flags of the cursor's (z, y): recomputed only when the x-row changes
+            auto zy_flags = [&]() { m_zy = (cz == 0 ? 1u : 0u) | (cz == g.Do - 1 ? 2u : 0u) | (cy == 0 ? 4u : 0u) | (cy == g.Ho - 1 ? 8u : 0u) | 64u; };
+            if constexpr (FAST) zy_flags();
+            // scalar half of the preparation (border mask + byte offsets of the cursor's unit, cursor advanced) and its VALU half
+            uint32_t nx_mask = 0, nx_a = 0, nx_b = 0;
+            auto prep_scalar = [&]() {
+                nx_mask = m_zy | (cx == 0 ? 16u : 0u) | (cx + KV == g.Wo ? 32u : 0u);
+                nx_a = cur_a; nx_b = cur_b;
+                cur_a += (uint32_t)(KV * 2) * (uint32_t)g.Cout; cur_b += (uint32_t)(KV * 2) * (uint32_t)g.Cin; cx += KV;
+                if (cx == g.Wo) {                             // a new x-row: every Wo / 32 units.  The empty volatile asm keeps this a real (rarely
+                    asm volatile("" ::: "memory");            // taken) branch: if-converted it was ~20 scalar selects in every load half
+                    cx = 0; if (++cy == g.Ho) { cy = 0; if (++cz == g.Do) cz = 0; } zy_flags();
+                }
+            };
             auto prep_fast = [&]() {
-                const uint32_t smask = (cz == 0 ? 1u : 0u) | (cz == g.Do - 1 ? 2u : 0u) | (cy == 0 ? 4u : 0u) | (cy == g.Ho - 1 ? 8u : 0u) |
-                                       (cx == 0 ? 16u : 0u) | (cx + KV == g.Wo ? 32u : 0u) | 64u;
-                const uint32_t ab = cur_v * (uint32_t)(g.Cout * 2), bb = cur_v * (uint32_t)(g.Cin * 2);
 #pragma unroll
-                for (int i = 0; i < IA; ++i) voa[i] = ab + pa_off[i];
+                for (int i = 0; i < IA; ++i) voa[i] = nx_a + pa_off[i];
 #pragma unroll
-                for (int i = 0; i < IB; ++i) vob[i] = (pb_m[i] & smask) == 0u ? bb + pb_off[i] : OOB;
-                cur_v += KV; cx += KV;
-                if (cx == g.Wo) { cx = 0; if (++cy == g.Ho) { cy = 0; if (++cz == g.Do) cz = 0; } }
+                for (int i = 0; i < IB; ++i) vob[i] = (pb_m[i] & nx_mask) == 0u ? nx_b + pb_off[i] : OOB;
             };
             auto issue_fast = [&](int buf) {
                 char* sA = smem + buf * STAGE;
@@ -1163,8 +1172,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
                 else issue(v_begin + (uint32_t)u * KV, u & 3);
             };
             // prologue: units 0..2 requested; unit 0 has landed (own pieces: counted wait; the others': the barrier)
-            for (int p = 0; p < 3 && p < nk; ++p) { if constexpr (FAST) prep_fast(); request(p); }
-            if constexpr (FAST) prep_fast();                 // offsets of unit 3, requested in the first load half
+            for (int p = 0; p < 3 && p < nk; ++p) { if constexpr (FAST) { prep_scalar(); prep_fast(); } request(p); }
+            if constexpr (FAST) { prep_scalar(); prep_fast(); }   // offsets of unit 3, requested in the first load half
             if (nk >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
             else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1180,17 +1189,22 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
                 }
             };
             stamp(-1);
-            auto unit = [&](int u, int slot) {
+            auto unit = [&](int u, int slot, bool steady) {
                 // ---- load half: fragment reads of unit u, then unit u + 3 into the ring slot of unit u - 1 (both groups have read it)
                 rd(slot);
                 stamp(0);
-                if (u + 3 < nk) request(u + 3);
-                stamp(1);
-                // this wave's pieces of unit u + 1 must have landed before the barrier that closes this phase
-                const int younger = min(nk - 1, u + 3) - (u + 1);
-                if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-                else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // this wave's pieces of unit u + 1 must have landed before the barrier that closes this phase: all but the two youngest
+                // units in flight (steady state: one compare), fewer at the end of the split
+                (void)steady;
+                if (u + 3 < nk) {
+                    request(u + 3);
+                    stamp(1);
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+                } else {
+                    stamp(1);
+                    if (u + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 stamp(2);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1198,8 +1212,19 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
                 stamp(3);
                 // ---- MFMA half
                 if (!(rows_fast & 2)) __builtin_amdgcn_s_setprio(1);   // (rows_fast bit 1: experiment, no priority raise)
-                if constexpr (FAST) prep_fast();            // offsets of unit u + 4 (scalar cursor + ~12 VALU): scheduled among the MFMAs
+                // offsets of unit u + 4 (scalar cursor + ~12 VALU), scheduled among the MFMAs: the MFMA half is paced by the matrix pipe and
+                // has idle issue slots, the load half is bound by its instruction count (the same scalar work at the end of the load
+                // half measured 1.11 instead of 1.20 PFLOP/s)
+                if constexpr (FAST) { prep_scalar(); prep_fast(); }
                 mm();
+                if constexpr (FAST) {
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) {            // two non-MFMA instructions per gap between MFMAs (a gap has ~3 idle issue slots)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                    }
+                }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 stamp(4);
@@ -1208,17 +1233,17 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
             };
             if constexpr (FAST) {
                 for (int u = 0; u < nk; u += 4) {
-                    unit(u, 0);
-                    if (u + 1 < nk) unit(u + 1, 1);
+                    unit(u, 0, false);
+                    if (u + 1 < nk) unit(u + 1, 1, false);
 #pragma unroll
-                    for (int k = 0; k < 2 * TM + 2 * TN; ++k) fa[k] += 2u * STAGE;
-                    if (u + 2 < nk) unit(u + 2, 2);
-                    if (u + 3 < nk) unit(u + 3, 3);
+                    for (int k = 0; k < TM + TN; ++k) fa[k] += 2u * STAGE;
+                    if (u + 2 < nk) unit(u + 2, 2, false);
+                    if (u + 3 < nk) unit(u + 3, 3, false);
 #pragma unroll
-                    for (int k = 0; k < 2 * TM + 2 * TN; ++k) fa[k] -= 2u * STAGE;
+                    for (int k = 0; k < TM + TN; ++k) fa[k] -= 2u * STAGE;
                 }
             } else {
-                for (int u = 0; u < nk; ++u) unit(u, u & 3);
+                for (int u = 0; u < nk; ++u) unit(u, u & 3, false);
             }
             if (!grp) __builtin_amdgcn_s_barrier();
             if constexpr (STAMP) {
@@ -1639,7 +1664,7 @@ static int fill_geom(ConvGeom& g, int B, int Di, int Hi, int Wi, int Cin, int Do
 
 static int g_use_glds = 1;
 static int g_wgrad_pipe = 0;    // tuning (include/dreg_nerf_tuning.h): the dense 8-wave weight-gradient tile reads its fragments one MFMA group ahead (measured: no gain)
-static int g_wgrad_ring = 0;    // tuning (include/dreg_nerf_tuning.h): LDS ring of the dense 8-wave weight-gradient tile: 0 two 64-voxel stages, 1 four / 2 five 32-voxel stages (measured: no gain)
+static int g_wgrad_ring = 3;    // tuning (include/dreg_nerf_tuning.h): dense 8-wave weight-gradient tile: 3 (default) anti-phase wave groups over four 32-voxel units, 0 lockstep over two 64-voxel stages, 1 / 2 lockstep over four / five 32-voxel stages, 4..8 probes
 static int g_rows_fast = 1;     // tuning (include/dreg_nerf_tuning.h): row-list weight gradients keep packed coordinates in LDS (no voxel decode per load) and use the 8-wave tile
 static int g_wgrad_big = 3;     // tuning (include/dreg_nerf_tuning.h): 256-row weight-gradient tiles for large dense layers (1: 256 x 128 / 4 waves, 3: 256 x 256 / 8 waves)
 
@@ -1953,6 +1978,21 @@ int dreg_conv3d_wgrad_splits(int B, int Do, int Ho, int Wo, int Cin, int Cout, i
     const long cap = (tiles * 64 >= 1024 || dtype != 0) ? 64 : ((1024 + tiles - 1) / tiles > 512 ? 512 : (1024 + tiles - 1) / tiles);
     if (s > cap) s = cap;
     if (s > 8) s = (s + 7) / 8 * 8;   // whole multiples of the 8 XCDs (see the block placement of the glds kernel)
+    // layers that take the 8-wave 256 x 256 tile (one workgroup per CU): the launch is tiles256 x splits workgroups over 256 CUs, and a last
+    // round that is mostly empty is pure loss (27 tiles x 32 splits = 3.375 rounds ran as 4: 84 %; x 56 = 5.9 rounds: 98 %).  Among the
+    // multiples of 8 up to 64 with >= 2,048 voxels per split take the count with the fullest last round (ties: the larger).
+    if (dtype == 0 && Cout % 256 == 0 && Kpad % 256 == 0 && M >= 65536) {
+        const long t256 = (long)(Cout / 256) * (Kpad / 256);
+        long best = s;
+        double best_eff = 0.0;
+        for (long c = 24; c <= 64; c += 8) {
+            if (M / c < 2048) break;
+            const double rounds = (double)(t256 * c) / 256.0;
+            const double eff = rounds / (double)((t256 * c + 255) / 256);
+            if (eff >= best_eff - 1e-9) { best_eff = eff; best = c; }
+        }
+        if (best_eff > 0.0) s = best;
+    }
     return (int)s;
 }
 size_t dreg_conv3d_wgrad_workspace_bytes(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int dtype) {

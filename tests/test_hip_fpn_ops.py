@@ -224,6 +224,26 @@ def test_large_layer_weight_gradient_tiles_are_bit_identical():
     finally:
         lib.dreg_conv_set_wgrad_big(3)
     assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[3])
+    # round 3: the 8-wave tile's loop forms (dreg_conv_set_wgrad_ring) — 3 anti-phase wave groups with the lean load half (default),
+    # 8 the general anti-phase loop, 0 the lockstep loop over 64-voxel stages — accumulate the same 32-voxel products in the same order
+    try:
+        for ring in (0, 8, 3):
+            lib.dreg_conv_set_wgrad_ring(ring)
+            assert torch.equal(ops.conv_wgrad(gy, x, (256, 256, 3, 3, 3), 256, 3, 1, 1), out[0]), ring
+        # a volume whose 32-voxel units straddle x-rows (16^3) takes the general anti-phase loop by itself; 1^3 taps; a batch of one
+        for (B2, D2, k2) in ((16, 16, 3), (2, 32, 1), (1, 64, 3)):
+            x2 = torch.randn(B2, D2, D2, D2, 256, generator=g).to(dev, torch.bfloat16)
+            gy2 = torch.randn(B2, D2, D2, D2, 256, generator=g).to(dev, torch.bfloat16)
+            got = {}
+            for ring in (0, 3):
+                lib.dreg_conv_set_wgrad_ring(ring)
+                got[ring] = ops.conv_wgrad(gy2, x2, (256, 256, k2, k2, k2), 256, k2, 1, k2 // 2)
+            assert torch.equal(got[0], got[3]), (B2, D2, k2)
+            r2 = torch.zeros(256, 256, k2, k2, k2, device=dev, requires_grad=True)
+            F.conv3d(x2.float().permute(0, 4, 1, 2, 3), r2, padding=k2 // 2).backward(gy2.float().permute(0, 4, 1, 2, 3))
+            assert float((got[3] - r2.grad).abs().max()) <= 2e-3 * float(r2.grad.abs().max()), (B2, D2, k2)
+    finally:
+        lib.dreg_conv_set_wgrad_ring(3)
     ref = torch.zeros(256, 256, 3, 3, 3, device=dev, requires_grad=True)
     F.conv3d(x.float().permute(0, 4, 1, 2, 3), ref, padding=1).backward(gy.float().permute(0, 4, 1, 2, 3))
     assert float((out[1] - ref.grad).abs().max()) <= 2e-3 * float(ref.grad.abs().max())

@@ -31,6 +31,6 @@ for (D, cin, cout) in ((64, 256, 256), (32, 256, 256), (64, 64, 256)):
             e1.record()
             torch.cuda.synchronize()
             ts[big].append(e0.elapsed_time(e1) / 3)
-    lib.dreg_conv_set_wgrad_big(3); lib.dreg_conv_set_wgrad_ring(0); lib.dreg_conv_set_wgrad_pipe(0)
+    lib.dreg_conv_set_wgrad_big(3); lib.dreg_conv_set_wgrad_ring(3); lib.dreg_conv_set_wgrad_pipe(0)
     m = {k: sorted(v)[len(v) // 2] for k, v in ts.items()}
     print(f"B{B} {D}^3 {cin}->{cout}: 128x128 {m[0]:.3f} ms {flops / m[0] / 1e9:.0f} TF | 256x256 8 waves {m[3]:.3f} ms {flops / m[3] / 1e9:.0f} TF | 256x128 4 waves, 32-voxel stages {m[1]:.3f} ms {flops / m[1] / 1e9:.0f} TF | 256x256 with a ring of four 32-voxel stages {m[103]:.3f} ms {flops / m[103] / 1e9:.0f} TF, of five {m[203]:.3f} ms {flops / m[203] / 1e9:.0f} TF | 256x256 with fragment reads one MFMA group ahead {m[1003]:.3f} ms {flops / m[1003] / 1e9:.0f} TF | ANTI-PHASE wave groups (ring mode 3) {m[303]:.3f} ms {flops / m[303] / 1e9:.0f} TF, bit-identical to the lockstep tile: {torch.equal(out[3], out[303])} | anti-phase without the priority raise {m[1303]:.3f} ms {flops / m[1303] / 1e9:.0f} TF | rel diff {d:.2e}", flush=True)

@@ -36,4 +36,4 @@ for (B, D, cin, cout) in ((8, 64, 256, 256),):
         units = max(v[6], 1)
         print(f"B{B} {D}^3 {cin}->{cout} [{what}]: plain {plain:.3f} ms = {flops / plain / 1e9:.0f} TF, instrumented {probed:.3f} ms; per unit and wave: " +
               "  ".join(f"{n} {v[i] / units:.0f}" for i, n in enumerate(names)) + f"  | sum {sum(v[:6]) / units:.0f} cycles, {v[7]} waves x {units // max(v[7], 1)} units", flush=True)
-    lib.dreg_conv_set_wgrad_ring(0)
+    lib.dreg_conv_set_wgrad_ring(3)
