@@ -77,7 +77,9 @@ def main():
     torch.set_num_threads(8)
     if sys.argv[1:] and all(a.startswith("bf16emu") for a in sys.argv[1:]):     # oracle-only products: the reference is not needed
         for a in sys.argv[1:]:
-            bf16_yardstick(int(a[7:]), "train" + a[7:])
+            wc = a.endswith("_wc")
+            r = a[7:-3] if wc else a[7:]
+            bf16_yardstick(int(r), "train" + r + ("_wc" if wc else ""), "wc" if wc else "default")
         return
     nr = import_reference()
     from conerf.register.se3 import compute_rigid_transform
@@ -149,7 +151,7 @@ def main():
              rre=rr.numpy(), rte=rt.numpy())
     print("e2e_eval32 done; N =", out["src_kp"][0].shape[0], out["tgt_kp"][0].shape[0])
 
-    want = set(sys.argv[1:]) or {"small", "augment", "train64", "train128", "bf16emu64", "bf16emu128"}
+    want = set(sys.argv[1:]) or {"small", "augment", "train64", "train128", "bf16emu64", "bf16emu128", "train64_wc", "train128_wc", "bf16emu64_wc", "bf16emu128_wc"}
     if "augment" in want:
         augment_golden()
     if "train64" in want:
@@ -158,6 +160,17 @@ def main():
         # BASELINE size: two A4 rounds, split-K thresholds and 32-bit index ranges of the 128^3 path (reference fwd+bwd: ~2 min on
         # 8 cores; the fp64 oracle pass needs ~40 GB and ~20 min: DREG_GOLDEN_FP64_128=0 skips it)
         train_golden(nr, sd, 128, "train128", with_fp64=bool(int(os.environ.get("DREG_GOLDEN_FP64_128", "1"))))
+    # the same step on the WELL-CONDITIONED weight profile (params.PROFILES["wc"], tools/wc_profile_sweep.py): the fixtures the bf16
+    # build is bounded against in absolute terms
+    sd_wc = params.synth_state_dict(seed=0, profile="wc")
+    if "train64_wc" in want:
+        train_golden(nr, sd_wc, 64, "train64_wc", profile="wc")
+    if "train128_wc" in want:
+        train_golden(nr, sd_wc, 128, "train128_wc", with_fp64=bool(int(os.environ.get("DREG_GOLDEN_FP64_128", "1"))), profile="wc")
+    if "bf16emu64_wc" in want:
+        bf16_yardstick(64, "train64_wc", "wc")
+    if "bf16emu128_wc" in want:
+        bf16_yardstick(128, "train128_wc", "wc")
     if "bf16emu64" in want:
         bf16_yardstick(64, "train64")
     if "bf16emu128" in want:
@@ -219,12 +232,12 @@ def augment_golden():
     print("augment done:", case, "cases", sorted(seen))
 
 
-def bf16_yardstick(res: int, name: str):
+def bf16_yardstick(res: int, name: str, profile="default"):
     """The reference-pinned oracle evaluated with bf16 operand rounding (oracle.regtr_oracle.EMULATE = "bf16") on the same step as
     `name`.npz: how far bf16 rounding ALONE moves losses / pose / gradient probes / gradient norms / the optimizer's parameter delta.
     Written to `name`_bf16emu.npz; tests/test_hip_pinned_step.py bounds the bf16 build's distance to the truth by this distance."""
     base = np.load(os.path.join(OUT, name + ".npz"))
-    sd = params.synth_state_dict(0)
+    sd = params.synth_state_dict(0, profile=profile)
     leaves = {}
     for k, (shape, kind) in params.regtr_spec().items():
         if not params.is_buffer(kind) and not k.startswith(params.ALIAS_DST):
@@ -245,6 +258,8 @@ def bf16_yardstick(res: int, name: str):
         O.EMULATE = None
     groups = {"resnet": "fpn3d.backbone_net.", "fpn_head": "fpn3d.feature_pyramid.",
               "transformer": "transformer_encoder.", "decoder": "correspondence_decoder."}
+    if profile != "default":
+        groups.update(EXTRA_GROUPS)
     out = {"n_src": pred["src_kp"][0].shape[0], "n_tgt": pred["tgt_kp"][0].shape[0], "pose": pred["pose"].detach().numpy()}
     for k, v in losses.items():
         out["loss_" + k] = float(v)
@@ -263,7 +278,14 @@ def bf16_yardstick(res: int, name: str):
     print(name + "_bf16emu done", {k: v for k, v in out.items() if k.startswith(("loss_", "gnorm_", "total"))})
 
 
-def train_golden(nr, sd, res: int, name: str, with_fp64: bool = True):
+EXTRA_PROBES = ["fpn3d.backbone_net.layer2.1.conv1.weight", "fpn3d.backbone_net.layer2.0.downsample.0.weight", "fpn3d.backbone_net.layer3.2.conv2.weight",
+                "fpn3d.backbone_net.layer3.5.bn1.weight", "fpn3d.backbone_net.layer4.0.downsample.0.weight", "fpn3d.backbone_net.layer4.1.conv2.weight",
+                "fpn3d.feature_pyramid.upsample_transform_2.weight", "fpn3d.feature_pyramid.pyramid_transformation_4.weight"]
+EXTRA_GROUPS = {"stem": "fpn3d.backbone_net.conv1.", "layer1": "fpn3d.backbone_net.layer1.", "layer2": "fpn3d.backbone_net.layer2.",
+                "layer3": "fpn3d.backbone_net.layer3.", "layer4": "fpn3d.backbone_net.layer4."}
+
+
+def train_golden(nr, sd, res: int, name: str, with_fp64: bool = True, profile="default"):
     """One training step of the REFERENCE (train-mode BatchNorm, its own loss code, clip_grad_norm_ + AdamW) on
     shell_pair(res, 1, 2): losses, pose, per-module gradient norms, gradient probes (+ their fp64 truth from the
     reference-pinned oracle), clip norm and the per-module parameter delta of the optimizer step."""
@@ -302,6 +324,8 @@ def train_golden(nr, sd, res: int, name: str, with_fp64: bool = True):
     named = dict(m.named_parameters())
     groups = {"resnet": "fpn3d.backbone_net.", "fpn_head": "fpn3d.feature_pyramid.",
               "transformer": "transformer_encoder.", "decoder": "correspondence_decoder."}
+    if profile != "default":
+        groups.update(EXTRA_GROUPS)      # the well-conditioned fixtures also pin the ResNet stage by stage
     for gname, pref in groups.items():
         sq = 0.0
         for k, p in named.items():
@@ -313,6 +337,8 @@ def train_golden(nr, sd, res: int, name: str, with_fp64: bool = True):
               "fpn3d.feature_pyramid.pyramid_transformation_1.bias",
               "transformer_encoder.layers.0.self_attn.in_proj_weight",
               "transformer_encoder.layers.5.linear2.weight", "correspondence_decoder.q_proj.weight"]
+    if profile != "default":
+        probes = probes + EXTRA_PROBES
     gp = {}
     for k in probes:
         gr = named[k].grad.flatten()
@@ -325,7 +351,7 @@ def train_golden(nr, sd, res: int, name: str, with_fp64: bool = True):
         # of layer4 makes fp32 gradients of the ResNet noisy at the 1e-2 level, so GPU tests bound their error relative
         # to the fp32 reference's own distance from this truth.
         sd64 = {}
-        for k, v in params.synth_state_dict(0).items():
+        for k, v in params.synth_state_dict(0, profile=profile).items():
             if k.startswith(params.ALIAS_DST):
                 sd64[k] = sd64[params.ALIAS_SRC + k[len(params.ALIAS_DST):]]
             else:
@@ -364,7 +390,7 @@ def train_golden(nr, sd, res: int, name: str, with_fp64: bool = True):
              **{"loss64_" + k: float(v) for k, v in l64.items()},
              **{"dnorm_" + k: v for k, v in dnorm.items()},
              total_grad_norm=total_norm, bn_running_var_probe=bn_probe, bn_running_mean_probe=bn_probe_m,
-             W_seed=5, **gp)
+             W_seed=5, profile=str(profile), **gp)
     print(name, "done", {k: float(v) for k, v in losses.items()}, gnorm, total_norm)
 
 
