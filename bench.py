@@ -97,6 +97,56 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def pmc_traffic(name, head, applies=True):
+    """HBM bytes per launch of kernel `name` from the committed rocprofv3 PMC passes (tools/collect_pmc.sh: separate
+    FETCH_SIZE / WRITE_SIZE runs of this bench at this workload, --pmc with --kernel-trace only).  Both counters are in KB;
+    FETCH_SIZE is doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 bytes: MI355X_MICROARCH.md, HBM).
+    The file records the sha of the kernel sources it was collected on: a stale file yields no traffic figure."""
+    path = os.path.join(ROOT, "profiles", "pmc_hbm_per_launch.json")
+    if not applies or not os.path.exists(path):
+        return None, None
+    db = json.load(open(path))
+    if db.get("kernel_source_sha") != kernel_source_sha():
+        return None, f"profiles/pmc_hbm_per_launch.json is stale (collected on kernel sources {db.get('kernel_source_sha')}, now {kernel_source_sha()}): re-run tools/collect_pmc.sh"
+    norm = lambda k: k.replace("void ", "").split("(")[0].replace("unsigned short", "bf16").replace("float", "f32").replace(" ", "")
+    want = name.replace(" ", "")
+    for k, e in db.get(head, {}).items():
+        kn = norm(k)
+        if (kn == want or kn.startswith(want.rstrip(">") + ",")) and "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+            return (2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0, \
+                f"profiles/pmc_hbm_per_launch.json [{head}] {k.split('(')[0][:80]}: 2 x FETCH_SIZE + WRITE_SIZE, mean of {e['launches_FETCH_SIZE']} launches"
+    return None, None
+
+
+def ngp_cpu_baseline(npts_block: int, cores: int):
+    """oracle/ngp_oracle.dense_query (kind 'port': the published Instant-NGP algorithm restated on the CPU; tiny-cuda-nn itself is not in
+    the reference tree) on a BOUNDED sample of the same workload — a ball of ~9 k occupied cells of a 128^3 block, same generated
+    weights — timed on this box's host cores, scaled to the block's point count (the work is per point)."""
+    from oracle import ngp_oracle as N
+    torch.set_num_threads(cores)
+    res = 128
+    g = torch.Generator().manual_seed(100)
+    base = torch.cat([torch.randn(3072, generator=g) * 0.4, torch.randn(N.n_grid_params(), generator=g)])
+    col = torch.randn(7168, generator=g) * 0.2
+    c = (torch.arange(res, dtype=torch.float32) + 0.5) / res * 3 - 1.5
+    X, Y, Z = torch.meshgrid(c, c, c, indexing="ij")
+    binary = torch.stack([X, Y, Z], -1).norm(dim=-1) < 0.3
+    n = int(binary.sum())
+    jitter = torch.rand(n, 3, generator=g)
+    aabb = torch.tensor([-1.5] * 3 + [1.5] * 3)
+    ts = []
+    for i in range(4):          # one warm-up, three timed
+        t0 = time.time()
+        N.dense_query(binary, jitter, aabb, aabb, base, col)
+        ts.append(time.time() - t0)
+    warm, ts = ts[0], sorted(ts[1:])
+    dt = ts[1] * npts_block / n
+    return {"value": 1.0 / dt, "unit": "blocks/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/ngp_oracle.dense_query (hash grid + density MLP + 18-direction colour MLP, fp16-emulating torch CPU) on {n} occupied cells "
+                      f"of a 128^3 block: warm-up {warm:.2f}s, 3 timed runs, median {ts[1]:.2f}s, scaled x{npts_block / n:.1f} to the block's {npts_block} cells",
+            "measured_seconds": ts}
+
+
 def ngp_bench(args, rank, world, dev):
     """BASELINE.json configs[3]: one 128^3 NeRF block = Np occupied cells -> world samples -> density (hash grid + MLP) -> colour x 18
     directions -> alpha / masks -> voxel_grid + voxel_mask (eval_ngp_nerf.py:336-412 without the surface ray march, which needs the
@@ -169,7 +219,20 @@ def ngp_bench(args, rank, world, dev):
           "density_kernel": {"kernel": "ngp_density_kernel", "avg_launch_ms": ms_d, "Gpts_per_s": npts / ms_d / 1e6,
                              "gather_TBps": gather / ms_d / 1e9, "gather_frac_of_hbm_peak": gather / ms_d / 1e9 / (HBM_PEAK_GBPS / 1e3),
                              "mlp_TFLOPs": fl_d / ms_d / 1e9,
-                             "note": "512 B gathered per point from the 25.2 MB fp16 table (Infinity-Cache resident, so above-HBM rates are possible)"}}
+                             "note": "512 B gathered per point from the 25.2 MB fp16 table: it lives in the 256 MB Infinity Cache (and its five dense levels in the 4 MB L2s), so the gather rate is a cache rate, not an HBM rate; `traffic` (PMC) is what reached the memory side"}}
+    rf["traffic"], src = pmc_traffic("ngp_rgb_kernel", "ngp", args.ngp_radius == 1.0)
+    if src:
+        rf["traffic_source"] = src
+    dt_, dsrc = pmc_traffic("ngp_density_kernel", "ngp", args.ngp_radius == 1.0)
+    rf["density_kernel"]["traffic"] = dt_
+    if dsrc:
+        rf["density_kernel"]["traffic_source"] = dsrc
+    if dt_:   # what actually reached HBM per launch vs what the lanes gathered: the table is cache resident
+        rf["density_kernel"]["hbm_GBps"] = dt_ / ms_d / 1e6
+        rf["density_kernel"]["gathered_over_hbm_bytes"] = gather / dt_
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = ngp_cpu_baseline(npts, min(os.cpu_count() or 1, 16))
     print(json.dumps({
         "metric": "ngp_grid_extraction_blocks_per_sec_128", "value": args.steps * world / el, "unit": "blocks/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -177,7 +240,7 @@ def ngp_bench(args, rank, world, dev):
         "config": {"workload": f"NGP occupancy-grid extraction, one 128^3 block per step: {npts} occupied cells (ball r={args.ngp_radius}) -> density + "
                                f"18-direction colour + voxel_grid writer; generated hash-grid / MLP weights", "points_per_block": npts,
                    "parallelism": f"replicas x{world}"},
-        "points_per_sec": npts * args.steps * world / el, "roofline": rf}), flush=True)
+        "points_per_sec": npts * args.steps * world / el, "roofline": rf, **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
 
 
 def spawn_ranks(args):
@@ -294,26 +357,6 @@ def main():
         n_out = int(rows) if rows else B * do * ho * wo
         return 2.0 * (n_in * cin + n_out * cout + cout * cin * k ** 3)
 
-    def pmc_traffic(name, head):
-        """HBM bytes per launch of kernel `name` from the committed rocprofv3 PMC passes (tools/collect_pmc.sh: separate
-        FETCH_SIZE / WRITE_SIZE runs of this bench at this workload, --pmc with --kernel-trace only).  Both counters are in KB;
-        FETCH_SIZE is doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 bytes: MI355X_MICROARCH.md, HBM).
-        The file records the sha of the kernel sources it was collected on: a stale file yields no traffic figure."""
-        path = os.path.join(ROOT, "profiles", "pmc_hbm_per_launch.json")
-        if args.res != 128 or args.pairs != 4 or args.precision != "bf16" or not os.path.exists(path):
-            return None, None
-        db = json.load(open(path))
-        if db.get("kernel_source_sha") != kernel_source_sha():
-            return None, f"profiles/pmc_hbm_per_launch.json is stale (collected on kernel sources {db.get('kernel_source_sha')}, now {kernel_source_sha()}): re-run tools/collect_pmc.sh"
-        norm = lambda k: k.replace("void ", "").split("(")[0].replace("unsigned short", "bf16").replace("float", "f32").replace(" ", "")
-        want = name.replace(" ", "")
-        for k, e in db.get(head, {}).items():
-            kn = norm(k)
-            if (kn == want or kn.startswith(want.rstrip(">") + ",")) and "FETCH_SIZE" in e and "WRITE_SIZE" in e:
-                return (2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0, \
-                    f"profiles/pmc_hbm_per_launch.json [{head}] {k.split('(')[0][:80]}: 2 x FETCH_SIZE + WRITE_SIZE, mean of {e['launches_FETCH_SIZE']} launches"
-        return None, None
-
     def roofline_of(pr, head):
         # HIP-event brackets as measured: nothing is subtracted (an empty bracket reads ~6 us, but with a kernel inside the events add
         # ~2 us to its duration: the round-1 subtraction over-corrected and put `frac` above what profiles/'s rocprofv3 CSV gives)
@@ -330,7 +373,7 @@ def main():
               "event_steps": min(args.event_steps, args.steps), "empty_bracket_ms_not_subtracted": pr.bracket_overhead_ms(),
               # the same launches against the other roof: compulsory bytes (inputs, weights, outputs once) / time vs 8 TB/s
               "compulsory_bytes_per_launch": nbytes / max(calls, 1), "hbm_GBps": gbs, "hbm_frac": gbs / HBM_PEAK_GBPS}
-        rf["traffic"], src = pmc_traffic(name, head)
+        rf["traffic"], src = pmc_traffic(name, head, args.res == 128 and args.pairs == 4 and args.precision == "bf16")
         if src:
             rf["traffic_source"] = src
         if rf["traffic"]:

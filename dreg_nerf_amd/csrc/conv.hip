@@ -239,15 +239,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 // DBG (tools/igemm_phase_probe.py, measurement only): s_memtime stamps around the four phases of a K step, summed per wave into g_igemm_dbg
 __device__ unsigned long long g_igemm_dbg[8];
 __device__ __forceinline__ unsigned long long dbg_now() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
-template <typename TO, int BM, int BN, int DBG = 0>
-__global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
+// AP (round 3): the 128-row tiles on EIGHT waves in two anti-phase groups, for launches that put at most one or two workgroups on a CU
+// (layer2-4 of the ResNet, the point-set half's linear layers: ~150 launches per training step).  With four waves and one workgroup
+// per CU nothing overlaps: per 64-channel K step a wave waits for the stage, issues 8 direct-to-LDS pieces (~600 cycles), reads 16
+// fragments and only then runs its 32 MFMAs (512 cycles of a ~1,700-cycle step: tools/igemm_phase_probe.py).  Here waves 0-3 and 4-7
+// (w and w + 4 share a SIMD) each own a 64 x (BN/4) quarter-strip of the SAME tile and run one barrier apart over a ring of four
+// stages: while one group reads its fragments of stage k and issues its half of the pieces of stage k + 3, the other runs its MFMAs
+// of the stage it read a phase earlier.  Every accumulator still sums the K steps in order: results are bit-identical to the
+// four-wave kernel, so the choice may depend on the launch size.
+template <typename TO, int BM, int BN, int DBG = 0, int AP = 0>
+__global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds_kernel(
     const bf16_t* __restrict__ in, const bf16_t* __restrict__ wt, TO* __restrict__ out,
     const float* __restrict__ bias, const TO* __restrict__ addend, ConvGeom g,
     int relu, int Da, int Ha, int Wa, int add_shift, int tilesN, uint32_t in_bytes, uint32_t wt_bytes,
     const int* __restrict__ rowlist, uint32_t nrows, int ksplit, int nstage)
 {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    constexpr int NW = BN == 256 ? 8 : 4, WAVES_N = BN == 256 ? 4 : 2;   // waves: 2 (M) x WAVES_N (N), (BM/2) x (BN/WAVES_N) each
+    constexpr int NW = (BN == 256 || AP) ? 8 : 4, WAVES_N = NW / 2;      // waves: 2 (M) x WAVES_N (N), (BM/2) x (BN/WAVES_N) each
     constexpr int BKe = 64, WMt = BM / 2, WN = BN / WAVES_N, TM = WMt / 16, TN = WN / 16;
     constexpr int IA = (BM / 8) / NW, IBW = (BN / 8) / NW;               // wave-instructions per wave per stage
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -380,6 +388,95 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
     if (ksplit > 1) out += (size_t)blockIdx.y * g.M * g.Cout;
     // ring of nstage (2..4) LDS stages: stage k is consumed while the loads of up to nstage-1 later stages are in flight
     constexpr int LPS = IA + IBW;                      // direct-to-LDS loads per wave per stage (vmcnt retires them in order)
+    if constexpr (AP) {
+        static_assert(BM == 128 && (BN == 128 || BN == 64) && !DBG && STAGE <= 65535, "anti-phase form: 128-row tiles");
+        const int nku = k_end - k_begin;
+        if (nku > 0) {
+            const int grp = wave >> 2;
+            const int fr = lane & 15, kg = lane >> 4;
+            const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+            // fragment addresses in ring slot 0 (or 2): fixed per lane; the odd slots are + STAGE as an immediate offset
+            uint32_t fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[ks][i] = lds0 + swz(wm * WMt + i * 16 + fr, ks * 4 + kg);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[ks][j] = lds0 + A_BYTES + swz(wn * WN + j * 16 + fr, ks * 4 + kg);
+            }
+            typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+            i32x4_t af[2][TM], bf[2][TN];
+            auto rd1 = [&](uint32_t addr, int odd) -> i32x4_t {
+                i32x4_t v;
+                if (odd) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(STAGE));
+                else asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+                return v;
+            };
+            auto rd = [&](int odd) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[ks][i] = rd1(fa[ks][i], odd);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[ks][j] = rd1(fb[ks][j], odd);
+                }
+            };
+            auto mm = [&]() {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bf[ks][j]), __builtin_bit_cast(bf16x8_t, af[ks][i]), acc[i][j], 0, 0, 0);
+            };
+            // prologue: stages 0..2 requested; stage 0 landed (own pieces: counted wait; the other waves': the barrier)
+            for (int p = 0; p < 3 && p < nku; ++p) issue(k_begin + p, p);
+            if (nku >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+            else if (nku == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (grp) __builtin_amdgcn_s_barrier();           // the second group runs one phase behind
+            auto unit = [&](int u, int slot) {
+                // load half: fragments of stage u, then stage u + 3 into the ring slot of stage u - 1 (read by both groups two barriers ago)
+                rd(slot & 1);
+                if (u + 3 < nku) {
+                    issue(k_begin + u + 3, (slot + 3) & 3);
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");   // this wave's pieces of stage u + 1 have landed
+                } else {
+                    if (u + 2 < nku) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                // MFMA half
+                __builtin_amdgcn_s_setprio(1);
+                mm();
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            };
+            auto shift = [&](uint32_t d) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[ks][i] += d;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[ks][j] += d;
+                }
+            };
+            for (int u = 0; u < nku; u += 4) {
+                unit(u, 0);
+                if (u + 1 < nku) unit(u + 1, 1);
+                shift(2u * STAGE);
+                if (u + 2 < nku) unit(u + 2, 2);
+                if (u + 3 < nku) unit(u + 3, 3);
+                shift(0u - 2u * STAGE);
+            }
+            if (!grp) __builtin_amdgcn_s_barrier();
+        }
+    } else {
     for (int s = 0; s < nstage - 1; ++s)
         if (k_begin + s < k_end) issue(k_begin + s, s);
     int cbuf = 0, ibuf = nstage - 1;                   // stage being consumed / stage the next issue goes to
@@ -407,6 +504,7 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
             atomicAdd(&g_igemm_dbg[5], 1ull);                                    // waves
         }
     }
+    }   // !AP
 
     // Epilogue through LDS, one pass per wave row (wm): accumulators -> fp32 tile [BM/2][BN] -> coalesced 16-byte rows with bias /
     // addend / ReLU applied in fp32.  The products are formed transposed (weights as the MFMA's first operand), so a lane holds FOUR
@@ -415,7 +513,7 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256) void conv_igemm_glds_kernel(
     // with the row's low four bits: the 16 lanes of a write phase (16 rows, same channels) land in 16 different granules.
     float* sC = reinterpret_cast<float*>(smem);
     constexpr int CPR = BN / 8;                    // 8-column chunks per row
-    constexpr int NTHR = BN == 256 ? 512 : 256;
+    constexpr int NTHR = NW * 64;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();
@@ -1695,7 +1793,41 @@ static inline int glds_stages(long blocks) { (void)blocks; return g_glds_stages 
 
 static int g_igemm_probe = 0;         // measurement only (tools/igemm_phase_probe.py): the 128 x 128 kernel with s_memtime stamps
 static int g_narrow_thr = 224;        // tile count below which a launch takes the narrower tiles
+static int g_igemm_ap = 256;          // tuning (include/dreg_nerf_tuning.h): launches of at most this many 128-row tiles take the eight-wave anti-phase form (0: never)
 static int g_narrow_small = 2;        // tuning (include/dreg_nerf_tuning.h): 128 x 64 tiles for launches of < 224 128 x 128 tiles
+// Which kernel instantiation a bf16 / fp32 convolution launch runs (ONE rule set: launch_conv dispatches on it and
+// dreg_conv3d_igemm_variant reports it, so profiler labels name the launched template arguments — the row rocprofv3 prints).
+struct IgemmChoice { int kind, bm, bn, ap, ksplit; };   // kind 0: direct-to-LDS kernel, 1: register-staged kernel, -1: unsupported
+static IgemmChoice igemm_choose(const ConvGeom& g, uint32_t nrows, bool rowlist, bool has_ws, bool has_addend, int esize)
+{
+    IgemmChoice c{1, 128, g.Cout % 128 == 0 ? 128 : 64, 0, 1};
+    if (esize == 2) {
+        const uint64_t in_bytes = (uint64_t)g.B * g.Di * g.Hi * g.Wi * g.Cin * 2, wt_bytes = (uint64_t)g.Cout * g.Kpad * 2;
+        const bool fits = in_bytes < 0x7fffff00ull && wt_bytes < 0x7fffff00ull;
+        const int ksplit = (has_ws && !rowlist) ? conv_ksplit(g, has_addend) : 1;
+        if (ksplit > 1 && fits) {
+            const int tm_ = (g.M + 127) / 128;
+            c.kind = 0; c.ksplit = ksplit; c.bn = g.Cout % 128 == 0 ? 128 : 64;
+            c.ap = (g_igemm_ap && tm_ * (g.Cout / c.bn) * ksplit <= g_igemm_ap) ? 1 : 0;
+            return c;
+        }
+        if (g_use_glds && g.sd == 1 && g.Cin % 64 == 0 && g.ntaps <= 32 && fits) {
+            c.kind = 0;
+            const uint32_t tm_ = (nrows + 127) / 128;
+            if (g.Cout % 256 == 0 && (g_use_glds == 1 || g_use_glds == 4 || g_use_glds == 5) && nrows >= 65536) { c.bm = 256; c.bn = 256; }
+            else if (g.Cout % 256 == 0 && g_use_glds == 3 && nrows >= 65536) { c.bm = 128; c.bn = 256; }
+            else if (g_igemm_ap && g.Cout % 128 == 0 && tm_ * (g.Cout / 128) <= (uint32_t)g_igemm_ap) { c.bn = 128; c.ap = 1; }
+            else if (g_igemm_ap && g.Cout % 128 != 0 && g.Cout % 64 == 0 && tm_ * (g.Cout / 64) <= (uint32_t)g_igemm_ap) { c.bn = 64; c.ap = 1; }
+            else if (g.Cout % 128 == 0 && !(g_narrow_small && tm_ * (g.Cout / 128) < (uint32_t)g_narrow_thr)) c.bn = 128;
+            else if (g.Cout % 64 == 0) c.bn = 64;
+            else c.kind = -1;
+            return c;
+        }
+    }
+    if (rowlist || (g.Cout % 128 != 0 && g.Cout % 64 != 0)) c.kind = -1;
+    return c;
+}
+
 template <typename T, typename TO>
 static int launch_conv(const void* in, const void* wt, void* out, const float* bias, const void* addend,
                        const ConvGeom& g, int relu, int Da, int Ha, int Wa, int add_shift, hipStream_t st,
@@ -1714,6 +1846,17 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
             const size_t slice = (size_t)g.M * g.Cout;
             if (ks_ws_bytes < slice * ksplit * sizeof(float)) return DREG_EINVAL;
             const int tm_ = (g.M + 127) / 128;
+            if (g.Cout % 128 == 0 && g_igemm_ap && tm_ * (g.Cout / 128) * ksplit <= g_igemm_ap) {
+                (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<float, 128, 128, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128);
+                hipLaunchKernelGGL((conv_igemm_glds_kernel<float, 128, 128, 0, 1>), dim3(tm_ * (g.Cout / 128), ksplit), dim3(512), (size_t)4 * 256 * 128, st,
+                                   (const bf16_t*)in, (const bf16_t*)wt, ks_ws, nullptr, nullptr, g, 0, 0, 0, 0, 0, g.Cout / 128,
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, nullptr, g.M, ksplit, 4);
+            } else if (g.Cout % 128 != 0 && g_igemm_ap && tm_ * (g.Cout / 64) * ksplit <= g_igemm_ap) {
+                (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<float, 128, 64, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 192 * 128);
+                hipLaunchKernelGGL((conv_igemm_glds_kernel<float, 128, 64, 0, 1>), dim3(tm_ * (g.Cout / 64), ksplit), dim3(512), (size_t)4 * 192 * 128, st,
+                                   (const bf16_t*)in, (const bf16_t*)wt, ks_ws, nullptr, nullptr, g, 0, 0, 0, 0, 0, g.Cout / 64,
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, nullptr, g.M, ksplit, 4);
+            } else
             if (g.Cout % 128 == 0) {
                 const int ns = glds_stages(tm_ * (g.Cout / 128) * ksplit);
                 if (ns > 2) (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<float, 128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, ns * 256 * 128);
@@ -1743,8 +1886,9 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
                 hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, BMv, BNv>), dim3(tm_ * tn_), dim3(NT), lds_, st, \
                                    (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tn_, \
                                    (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows, 1, ns_); } while (0)
-            if (g.Cout % 256 == 0 && (g_use_glds == 1 || g_use_glds == 4 || g_use_glds == 5) && nrows >= 65536) GL_LAUNCH(256, 256, 512);
-            else if (g.Cout % 256 == 0 && g_use_glds == 3 && nrows >= 65536) GL_LAUNCH(128, 256, 512);
+            const IgemmChoice ch = igemm_choose(g, nrows, rowlist != nullptr, false, addend != nullptr, 2);
+            if (ch.bm == 256) GL_LAUNCH(256, 256, 512);
+            else if (ch.bn == 256) GL_LAUNCH(128, 256, 512);
             // fewer 128 x 128 tiles than CUs (the point-set half's linear layers: ~77 row tiles x 2): half-width tiles put twice as
             // many workgroups on the chip
             else if (g_igemm_probe && g.Cout % 128 == 0 && sizeof(TO) == 2) {
@@ -1753,10 +1897,21 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
                                    (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tn_,
                                    (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows, 1, 2);
             }
-            else if (g.Cout % 128 == 0 && !(g_narrow_small && ((nrows + 127) / 128) * (g.Cout / 128) < g_narrow_thr)) GL_LAUNCH(128, 128, 256);
-            else if (g.Cout % 64 == 0) GL_LAUNCH(128, 64, 256);
+#define GL_LAUNCH_AP(BNv) do { \
+                const int tm_ = (nrows + 127) / 128, tn_ = g.Cout / BNv; \
+                const size_t lds_ = (size_t)4 * (128 + BNv) * 128; \
+                (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<TO, 128, BNv, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
+                hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, 128, BNv, 0, 1>), dim3(tm_ * tn_), dim3(512), lds_, st, \
+                                   (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tn_, \
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows, 1, 4); } while (0)
+            // launches that put at most one or two workgroups on a CU: the eight-wave anti-phase form of the same tile (bit-identical)
+            else if (ch.kind == 0 && ch.ap && ch.bn == 128) GL_LAUNCH_AP(128);
+            else if (ch.kind == 0 && ch.ap && ch.bn == 64) GL_LAUNCH_AP(64);
+            else if (ch.kind == 0 && ch.bn == 128) GL_LAUNCH(128, 128, 256);
+            else if (ch.kind == 0 && ch.bn == 64) GL_LAUNCH(128, 64, 256);
             else return DREG_EINVAL;
 #undef GL_LAUNCH
+#undef GL_LAUNCH_AP
             DREG_LAUNCH_CHECK();
             return DREG_OK;
         }
@@ -1867,7 +2022,20 @@ void dreg_conv_set_glds(int enable) { g_use_glds = enable; }
 void dreg_conv_set_wgrad_big(int enable) { g_wgrad_big = enable; }
 // measurement only: enable = 1 routes bf16 launches with Cout % 128 == 0 to the instrumented 128 x 128 kernel; read returns
 // { cycles waiting for the stage's loads, in the barrier, issuing the next stage, in fragment reads + MFMAs; K steps x waves; waves } and clears them
+// Which kernel a convolution launch of this shape runs (the rules launch_conv applies; for profiler labels):
+//   kind * 100000000 + BM * 100000 + BN * 100 + AP * 10 + (split-K ? 1 : 0);   kind 0 = conv_igemm_glds_kernel, 1 = conv_igemm_kernel, negative = unsupported.
+// nrows: 0 = dense, else the row-list length; has_ws: the caller passes a split-K workspace (dreg_conv3d_igemm_ws); dtype 0 bf16, 1 fp32.
+int dreg_conv3d_igemm_variant(int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksz, int stride, int pad,
+                              int transposed, int nrows, int has_ws, int has_addend, int dtype)
+{
+    ConvGeom g;
+    if (fill_geom(g, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, ksz, stride, pad, transposed, dtype == 0 ? 2 : 4)) return -1;
+    const IgemmChoice c = igemm_choose(g, nrows > 0 ? (uint32_t)nrows : g.M, nrows > 0, has_ws != 0, has_addend != 0, dtype == 0 ? 2 : 4);
+    if (c.kind < 0) return -1;
+    return c.kind * 100000000 + c.bm * 100000 + c.bn * 100 + c.ap * 10 + (c.ksplit > 1 ? 1 : 0);
+}
 void dreg_conv_igemm_probe(int enable) { g_igemm_probe = enable; }
+void dreg_conv_set_igemm_ap(int max_tiles) { g_igemm_ap = max_tiles > 0 ? max_tiles : 0; }
 int dreg_conv_igemm_probe_read(unsigned long long* out6)
 {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};

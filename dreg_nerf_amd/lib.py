@@ -43,6 +43,7 @@ SIGNATURES = {
     "dreg_conv_set_wgrad_splits": (None, [I]),
     "dreg_conv_set_wgrad_big": (None, [I]),
     "dreg_conv_igemm_probe": (None, [I]),
+    "dreg_conv_set_igemm_ap": (None, [I]),
     "dreg_conv_igemm_probe_read": (I, [P]),
     "dreg_conv_set_wgrad_pipe": (None, [I]),
     "dreg_conv_wgrad_probe_read": (I, [P]),
@@ -67,6 +68,7 @@ SIGNATURES = {
     "dreg_conv3_halo": (I, [P, P, P, P, P] + [I] * 10 + [P]),
     "dreg_conv_set_narrow_small": (None, [I]),
     "dreg_conv3d_wgrad_variant": (I, [I] * 10),
+    "dreg_conv3d_igemm_variant": (I, [I] * 17),
     "dreg_bn_set_debug_skip": (None, [I]),
     "dreg_bn_set_store_g": (None, [I]),
     "dreg_bn_set_small_regs": (None, [I]),

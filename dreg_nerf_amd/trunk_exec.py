@@ -161,12 +161,13 @@ class TrunkExecutor:
             k, s = o[9], o[10]
             cout, cin = w.shape[0], w.shape[1]
             M = B * y[1] * y[2] * y[3]
-            big = cout % 256 == 0 and M >= 65536
-            fname = f"conv_igemm_glds_kernel<bf16,{256 if big else 128},{256 if big else (128 if cout % 128 == 0 else 64)}>" \
-                if (x[4] % 64 == 0) else f"conv_igemm_kernel<bf16,bf16,{128 if cout % 128 == 0 else 64}>"
-            bigd = cin % 256 == 0 and B * x[1] * x[2] * x[3] >= 65536
+            # names of the launched instantiations (dreg_conv3d_igemm_variant: the library's own rules).  Active-set launches: the row
+            # count changes per step, so the variant is queried for a list long enough for the large tile (their lists are) — the label says "-rows"
+            pd = o[11] if len(o) > 11 else k // 2
+            nr = 1 << 20 if o[0] == OP_CONV_ROWS else 0
+            fname = ops.igemm_kernel_name(self.lib, B, x[1], x[2], x[3], x[4], y[1], y[2], y[3], cout, k, s, pd, 0, nr, 0 if nr else 1, False, L.DT_BF16, False)
             dname = "conv_igemm_glds_kernel<bf16,s2-dgrad>" if s == 2 else \
-                f"conv_igemm_glds_kernel<bf16,{256 if bigd else 128},{256 if bigd else (128 if cin % 128 == 0 else 64)}>"
+                ops.igemm_kernel_name(self.lib, B, y[1], y[2], y[3], cout, x[1], x[2], x[3], x[4], k, 1, pd, 1, nr, 0 if nr else 1, False, L.DT_BF16, False)
             halo = self.lib.dreg_exec_op_halo(self.h, i)
             if halo & 1:
                 fname = "conv3_halo_kernel<bf16>"

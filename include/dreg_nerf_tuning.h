@@ -22,6 +22,7 @@ void dreg_conv_set_wgrad_rows_fast(int enable);      /* 1 (default): row-list we
 void dreg_conv_set_wgrad_ring(int mode);             /* dense 8-wave weight-gradient tile: 3 (default) anti-phase wave groups over a ring of four 32-voxel units (lean load half for stride-1 same-volume layers, general loop otherwise), 8 the general anti-phase loop, 0 lockstep over two 64-voxel stages, 1 / 2 lockstep over four / five 32-voxel stages (measured no gain), 4 = 3 with s_memtime stamps, 5..7 stamped ablations (wrong results) */
 int dreg_conv_wgrad_probe_read(unsigned long long* out8); /* ring mode 4 (measurement only): { issue, fragment reads, wait for loads, barrier, MFMAs, barrier cycles; units x waves; waves } since the last read */
 void dreg_conv_set_wgrad_pipe(int enable);           /* 1: the dense 8-wave weight-gradient tile reads the fragments of the next MFMA group while the current group runs (default 0: measured no gain) */
+void dreg_conv_set_igemm_ap(int max_tiles);          /* bf16 implicit-GEMM launches of at most this many 128-row tiles run the eight-wave anti-phase form of the tile (default 256 = one workgroup per CU; 0: never); bit-identical results */
 void dreg_conv_igemm_probe(int enable);               /* MEASUREMENT ONLY: bf16 launches with Cout % 128 == 0 run the 128 x 128 implicit-GEMM kernel with s_memtime stamps around the phases of a K step */
 int dreg_conv_igemm_probe_read(unsigned long long* out6); /* { wait-for-loads, barrier, issue, compute cycles; K steps x waves; waves }, summed over the waves since the last read */
 void dreg_conv_set_wgrad_big(int mode);             /* large dense layers: 3 (default) the 8-wave 256 x 256 tile, 1 four waves on 256 x 128 with 32-voxel stages, 11-13 ablations of the 8-wave tile, 0 neither */
@@ -36,6 +37,9 @@ void dreg_bn_set_store_g(int enable);                /* 1 (default): the backwar
 void dreg_bn_set_small_regs(int enable);             /* 1 (default): the one-launch BatchNorms of the 8^3 / 4^3 volumes load their rows once and keep them in registers between statistics and apply */
 void dreg_bn_set_debug_skip(int mask);                /* MEASUREMENT ONLY (wrong results): bit 0 / 1 leave out the forward / backward statistics pass of the large BatchNorms */
 /* which bf16 weight-gradient kernel a launch of this shape runs: BM * 1000 + BNC (256256 = the 8-wave tile, 256128 = 4 waves / 32-voxel stages); for profiler labels */
+/* which kernel a convolution launch of this shape runs: kind * 1e8 + BM * 1e5 + BN * 100 + AP * 10 + splitK (kind 0 conv_igemm_glds_kernel, 1 conv_igemm_kernel; < 0 unsupported); nrows 0 = dense */
+int dreg_conv3d_igemm_variant(int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksz, int stride, int pad,
+                              int transposed, int nrows, int has_ws, int has_addend, int dtype);
 int dreg_conv3d_wgrad_variant(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int rows, int nrows, int occ);
 void dreg_conv_set_narrow_small(int on);              /* 1 (default): launches of < 224 128 x 128 tiles use 128 x 64 tiles (twice the workgroups) */
 
