@@ -826,6 +826,26 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
     const int* srow = reinterpret_cast<const int*>(smem + NS * STAGE);
     typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
     const u32x2_t* srow2 = reinterpret_cast<const u32x2_t*>(smem + NS * STAGE);   // rows_fast: (row, packed z|y|x) pairs
+    if constexpr (ROWS && AP >= 3) {
+        // anti-phase row-list form: (row index, border flags) pairs — z == 0: 1, z == D-1: 2, y == 0: 4, y == H-1: 8, x == 0: 16, x == W-1: 32,
+        // every real row: 256 — padded with sentinel entries (flag 128, an out-of-range row) to whole 32-row units plus the four units the
+        // preparation runs ahead: the K loop tests  (lane's tap mask & row flags) == 0  and never decodes a voxel or compares a count
+        u32x2_t* w2_ = reinterpret_cast<u32x2_t*>(smem + NS * STAGE);
+        const uint32_t nreal = v_begin < v_end ? v_end - v_begin : 0u;
+        const uint32_t npad = ((nreal + KV - 1) / KV + 4) * KV;
+        const uint32_t m_sent = 0x7fffff00u / (uint32_t)((g.Cout > g.Cin ? g.Cout : g.Cin) * 2) + 1u;
+        for (uint32_t i = t; i < npad; i += NW * 64) {
+            if (i < nreal) {
+                const int m = rowlist[v_begin + i];
+                int b, z, y, x;
+                vox_decode((uint32_t)m, g, b, z, y, x);
+                const uint32_t fl = (z == 0 ? 1u : 0u) | (z == g.Do - 1 ? 2u : 0u) | (y == 0 ? 4u : 0u) | (y == g.Ho - 1 ? 8u : 0u) |
+                                    (x == 0 ? 16u : 0u) | (x == g.Wo - 1 ? 32u : 0u) | 256u;
+                w2_[i] = (u32x2_t){(uint32_t)m, fl};
+            } else w2_[i] = (u32x2_t){m_sent, 128u};
+        }
+        __syncthreads();
+    } else
     if constexpr (ROWS) {
         int* w_ = reinterpret_cast<int*>(smem + NS * STAGE);
         u32x2_t* w2_ = reinterpret_cast<u32x2_t*>(smem + NS * STAGE);
@@ -1133,7 +1153,6 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
         //    unit's (z, y, x-phase) border flags in one scalar mask advanced incrementally — no decode, no per-axis compare.
         constexpr bool FAST = AP >= 3, STAMP = (AP == 2 || AP == 4);
         static_assert(NW == 8 && KV == 32 && NS == 4 && PIPE == 0 && LPS <= 15, "anti-phase loop: 8 waves, four 32-voxel units in the ring");
-        static_assert(!FAST || !ROWS, "the fast form is dense");
         if (v_begin < v_end) {
             const int nk = (int)((v_end - v_begin + KV - 1) / KV);
             const int grp = wave >> 2;
@@ -1213,6 +1232,21 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
             // ---- pieces.  FAST: lane constants + an incrementally advanced scalar cursor (the NEXT unit to request)
             uint32_t pa_off[IA], pb_off[IB], pb_m[IB];
             int cz = 0, cy = 0, cx = 0;
+            uint32_t lp = 0;                               // row-list form: LDS address of this lane's first (row, flags) pair of the cursor's unit
+            u32x2_t lm[IA];
+            if constexpr (FAST && ROWS) {
+                static_assert(IA == IB && RPA == RPB, "one row per lane for both operands");
+                lp = lds_base + NS * STAGE + (uint32_t)(wave * IA * RPA + ra) * 8u;
+#pragma unroll
+                for (int i = 0; i < IA; ++i) pa_off[i] = a_col[i];
+#pragma unroll
+                for (int i = 0; i < IB; ++i) {
+                    const int dz = g.off + b_dz[i], dy = g.off + b_dy[i], dx = g.off + b_dx[i];
+                    pb_off[i] = (uint32_t)((((dz * g.Hi + dy) * g.Wi + dx) * g.Cin + b_ci[i]) * 2);   // relative to the row's own voxel, mod 2^32
+                    pb_m[i] = (dz < 0 ? 1u : 0u) | (dz > 0 ? 2u : 0u) | (dy < 0 ? 4u : 0u) | (dy > 0 ? 8u : 0u) |
+                              (dx < 0 ? 16u : 0u) | (dx > 0 ? 32u : 0u) | 128u | (b_tv[i] ? 0u : 256u);
+                }
+            } else
             if constexpr (FAST) {
 #pragma unroll
                 for (int i = 0; i < IA; ++i) pa_off[i] = (uint32_t)((wave * IA + i) * RPA + ra) * (uint32_t)(g.Cout * 2) + a_col[i];
@@ -1251,6 +1285,21 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
 #pragma unroll
                 for (int i = 0; i < IB; ++i) vob[i] = (pb_m[i] & nx_mask) == 0u ? nx_b + pb_off[i] : OOB;
             };
+            auto list_read = [&]() {                       // (row, flags) of this lane's rows in the cursor's unit; cursor -> next unit
+#pragma unroll
+                for (int i = 0; i < IA; ++i) {
+                    if (i == 0) asm volatile("ds_read_b64 %0, %1" : "=v"(lm[i]) : "v"(lp));
+                    else asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(lm[i]) : "v"(lp), "n"(RPA * 8));
+                }
+                static_assert(IA <= 2, "list_read: two rows per lane");
+                lp += (uint32_t)KV * 8u;
+            };
+            auto prep_rows = [&]() {
+#pragma unroll
+                for (int i = 0; i < IA; ++i) voa[i] = __umul24(lm[i][0], (uint32_t)(g.Cout * 2)) + pa_off[i];
+#pragma unroll
+                for (int i = 0; i < IB; ++i) vob[i] = (pb_m[i] & lm[i][1]) == 0u ? __umul24(lm[i][0], (uint32_t)(g.Cin * 2)) + pb_off[i] : OOB;
+            };
             auto issue_fast = [&](int buf) {
                 char* sA = smem + buf * STAGE;
                 char* sB = sA + A_BYTES;
@@ -1270,8 +1319,15 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
                 else issue(v_begin + (uint32_t)u * KV, u & 3);
             };
             // prologue: units 0..2 requested; unit 0 has landed (own pieces: counted wait; the others': the barrier)
-            for (int p = 0; p < 3 && p < nk; ++p) { if constexpr (FAST) { prep_scalar(); prep_fast(); } request(p); }
-            if constexpr (FAST) { prep_scalar(); prep_fast(); }   // offsets of unit 3, requested in the first load half
+            for (int p = 0; p < 3 && p < nk; ++p) {
+                if constexpr (FAST && ROWS) { list_read(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); prep_rows(); }
+                else if constexpr (FAST) { prep_scalar(); prep_fast(); }
+                request(p);
+            }
+            if constexpr (FAST && ROWS) {
+                for (int p = nk < 3 ? nk : 3; p < 3; ++p) list_read();     // a split of fewer than three units: keep the cursor in step
+                list_read(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); prep_rows();   // offsets of unit 3
+            } else if constexpr (FAST) { prep_scalar(); prep_fast(); }   // offsets of unit 3, requested in the first load half
             if (nk >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
             else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1290,6 +1346,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
             auto unit = [&](int u, int slot, bool steady) {
                 // ---- load half: fragment reads of unit u, then unit u + 3 into the ring slot of unit u - 1 (both groups have read it)
                 rd(slot);
+                if constexpr (FAST && ROWS) list_read();    // rows of unit u + 4: back with the fragments, consumed in the MFMA half
                 stamp(0);
                 // this wave's pieces of unit u + 1 must have landed before the barrier that closes this phase: all but the two youngest
                 // units in flight (steady state: one compare), fewer at the end of the split
@@ -1313,7 +1370,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
                 // offsets of unit u + 4 (scalar cursor + ~12 VALU), scheduled among the MFMAs: the MFMA half is paced by the matrix pipe and
                 // has idle issue slots, the load half is bound by its instruction count (the same scalar work at the end of the load
                 // half measured 1.11 instead of 1.20 PFLOP/s)
-                if constexpr (FAST) { prep_scalar(); prep_fast(); }
+                if constexpr (FAST && ROWS) prep_rows();
+                else if constexpr (FAST) { prep_scalar(); prep_fast(); }
                 mm();
                 if constexpr (FAST) {
 #pragma unroll
@@ -2149,8 +2207,8 @@ int dreg_conv3d_wgrad_splits(int B, int Do, int Ho, int Wo, int Cin, int Cout, i
     // layers that take the 8-wave 256 x 256 tile (one workgroup per CU): the launch is tiles256 x splits workgroups over 256 CUs, and a last
     // round that is mostly empty is pure loss (27 tiles x 32 splits = 3.375 rounds ran as 4: 84 %; x 56 = 5.9 rounds: 98 %).  Among the
     // multiples of 8 up to 64 with >= 2,048 voxels per split take the count with the fullest last round (ties: the larger).
-    if (dtype == 0 && Cout % 256 == 0 && Kpad % 256 == 0 && M >= 65536) {
-        const long t256 = (long)(Cout / 256) * (Kpad / 256);
+    if (dtype == 0 && Cout % 256 == 0 && (Kpad % 256 == 0 || Kpad >= 1024) && M >= 65536) {
+        const long t256 = (long)(Cout / 256) * ((Kpad + 255) / 256);
         long best = s;
         double best_eff = 0.0;
         for (long c = 24; c <= 64; c += 8) {
@@ -2234,6 +2292,14 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
 
             (void)ldsr;
         }
+        if (rows256 && g_wgrad_ring == 3 && ksz <= 3 && (size_t)4 * 32 * 512 * 2 + ((size_t)vps + 5 * 32) * 8 <= (size_t)160 * 1024) {
+            // anti-phase wave groups on the row list ((row, border flags) pairs in LDS; lean load half as in the dense form)
+            const int tiles256 = (Cout / 256) * (g.Kpad / 256);
+            const size_t l_ = (size_t)4 * 32 * 512 * 2 + ((size_t)vps + 5 * 32) * 8;
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, true, 8, 0, 32, 4, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, true, 8, 0, 32, 4, 0, 3>), dim3(tiles256 * nsplit), dim3(512), l_, st, (const bf16_t*)gout,
+                               (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr, 1);
+        } else
         if (rows256) {
             const int tiles256 = (Cout / 256) * (g.Kpad / 256);
             const size_t l_ = (size_t)2 * 64 * 512 * 2 + (size_t)vps * 8;
@@ -2241,12 +2307,14 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
             hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, true, 8>), dim3(tiles256 * nsplit), dim3(512), l_, st, (const bf16_t*)gout,
                                (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr, 1);
         } else
-        if (!rowlist && !rowocc && g_wgrad_big && Cout % 256 == 0 && g.Kpad % 256 == 0 && nrows >= 65536) {
+        // (a K extent that is not a multiple of 256 — 27 taps x 64 channels = 1,728 — takes a ragged last column tile: its columns >= Kpad
+        //  gather zeros and are not stored)
+        if (!rowlist && !rowocc && g_wgrad_big && Cout % 256 == 0 && (g.Kpad % 256 == 0 || (g.Kpad >= 1024 && g_wgrad_big == 3 && g_wgrad_ring >= 3 && !g_wgrad_pipe)) && nrows >= 65536) {
             // large dense layers: 256-row tiles.  Default (3): the 8-wave 256 x 256 tile (0.90 PFLOP/s on 256 -> 256 @64^3 alone); 1: 4
             // waves on 256 x 128 with 32-voxel stages — 48 KB of LDS, two independent workgroups per CU: 0.93 alone, but no faster
             // inside the step, where the data-gradient stream shares the CUs (tools/ab_step.py: 43.25 vs 43.16 ms, dense head)
             // large dense layers: the 8-wave 256 x 256 tile
-            const int tiles256 = (Cout / 256) * (g.Kpad / 256);
+            const int tiles256 = (Cout / 256) * ((g.Kpad + 255) / 256);
             (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * 512 * 2);
             if (g_wgrad_big == 1) {
                 const int t2 = (Cout / 256) * (g.Kpad / 128);
@@ -2258,17 +2326,17 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
                 const size_t l_ = (size_t)2 * 64 * 512 * 2;
 #define WG_ABL(A) do { (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, false, 8, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_); \
                 hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, false, 8, A>), dim3(tiles256 * nsplit), dim3(512), l_, st, (const bf16_t*)gout, \
-                                   (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, rowocc); } while (0)
+                                   (const bf16_t*)in, part, g, (g.Kpad + 255) / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, rowocc); } while (0)
                 if (g_wgrad_big == 11) WG_ABL(1); else if (g_wgrad_big == 12) WG_ABL(2); else WG_ABL(3);
 #undef WG_ABL
             } else if (g_wgrad_pipe && !g_wgrad_ring) {
                 (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, false, 8, 0, 64, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, false, 8, 0, 64, 2, 1>), dim3(tiles256 * nsplit), dim3(512), (size_t)2 * 64 * 512 * 2 + (rowocc ? (size_t)(vps / 64 + 16) : 0), st, (const bf16_t*)gout,
-                                   (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, rowocc);
+                                   (const bf16_t*)in, part, g, (g.Kpad + 255) / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, rowocc);
             } else if (g_wgrad_ring == 2) {   // five 32-voxel stages: the whole 160 KB of LDS, four stages in flight
                 (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, false, 8, 0, 32, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, false, 8, 0, 32, 5>), dim3(tiles256 * nsplit), dim3(512), (size_t)5 * 32 * 512 * 2, st, (const bf16_t*)gout,
-                                   (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr);
+                                   (const bf16_t*)in, part, g, (g.Kpad + 255) / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr);
             } else if (g_wgrad_ring >= 3 && g_wgrad_ring <= 8) {
                 // anti-phase wave groups over a ring of four 32-voxel units.  3: product form (FAST when the layer qualifies, else the general
                 // loop); 8: the general loop; 4..7 measurement only: FAST with s_memtime stamps, 5..7 (wrong results) without fragment
@@ -2277,7 +2345,7 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
                                      (g.M % 32u) == 0 && (vps % 32u) == 0;
 #define WG_AP(A, APv) do { (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, false, 8, A, 32, 4, 0, APv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
                 hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, false, 8, A, 32, 4, 0, APv>), dim3(tiles256 * nsplit), dim3(512), (size_t)4 * 32 * 512 * 2, st, (const bf16_t*)gout, \
-                                   (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr, g_wgrad_pipe ? 2 : 0); } while (0)
+                                   (const bf16_t*)in, part, g, (g.Kpad + 255) / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr, g_wgrad_pipe ? 2 : 0); } while (0)
                 if (g_wgrad_ring == 8 || !fast_ok) WG_AP(0, 1);
                 else if (g_wgrad_ring == 3) WG_AP(0, 3);
                 else if (g_wgrad_ring == 4) WG_AP(0, 4);
@@ -2288,10 +2356,10 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
             } else if (g_wgrad_ring == 1) {
                 (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, false, 8, 0, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, false, 8, 0, 32, 4>), dim3(tiles256 * nsplit), dim3(512), (size_t)4 * 32 * 512 * 2, st, (const bf16_t*)gout,
-                                   (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr);
+                                   (const bf16_t*)in, part, g, (g.Kpad + 255) / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr);
             } else
             hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, false, 8>), dim3(tiles256 * nsplit), dim3(512), (size_t)2 * 64 * 512 * 2, st, (const bf16_t*)gout,
-                               (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, rowocc);
+                               (const bf16_t*)in, part, g, (g.Kpad + 255) / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, rowocc);
         } else
         if (bm == 128 && bnc == 128) WGG(128, 128); else if (bm == 128 && bnc == 64) WGG(128, 64);
         else if (bm == 64 && bnc == 128) WGG(64, 128); else WGG(64, 64);
@@ -2374,7 +2442,7 @@ int dreg_conv3d_wgrad_variant(int B, int Do, int Ho, int Wo, int Cin, int Cout, 
     const int Kpad = dreg_conv3d_kpad(ksz, Cin, 0);
     const int nsplit = dreg_conv3d_wgrad_splits(B, Do, Ho, Wo, Cin, Cout, ksz, 0);
     const long M = (long)B * Do * Ho * Wo;
-    if (!rows && !occ && g_wgrad_big && Cout % 256 == 0 && Kpad % 256 == 0 && (rows ? nrows : M) >= 65536) return g_wgrad_big == 1 ? 256128 : 256256;
+    if (!rows && !occ && g_wgrad_big && Cout % 256 == 0 && (Kpad % 256 == 0 || (Kpad >= 1024 && g_wgrad_big == 3 && g_wgrad_ring >= 3 && !g_wgrad_pipe)) && (rows ? nrows : M) >= 65536) return g_wgrad_big == 1 ? 256128 : 256256;
     if (rows && g_rows_fast && g_wgrad_big == 3 && ksz == 3 && Cout % 256 == 0 && Kpad % 256 == 0 && nrows >= 65536) {   // stride 1, same-size volume assumed
         uint32_t vps = (uint32_t)((nrows + nsplit - 1) / nsplit);
         vps = ((vps + 63) / 64) * 64;

@@ -366,6 +366,21 @@ int dreg_exec_op_halo(void* h, int op) { Exec* e = (Exec*)h; return op >= 0 && o
 
 // 1 (default): weight / bias gradients on the executor's own second stream, overlapping the data-gradient chain; 0: one stream
 void dreg_exec_set_overlap(void* h, int enable) { ((Exec*)h)->use_aux = enable != 0; }
+// Experiment (include/dreg_nerf_tuning.h): the weight-gradient launches of a backward pass rotate over n streams (the caller's second
+// stream + n - 1 process-wide extra ones) instead of queueing on one: most of them are under-filled (64 - 256 workgroups), so several
+// can share the chip.  1 = one second stream (default).
+static int g_aux_streams = 1;
+static hipStream_t g_extra_stream[3] = {nullptr, nullptr, nullptr};
+static hipEvent_t g_extra_event[3] = {nullptr, nullptr, nullptr};
+void dreg_exec_set_aux_streams(int n) { g_aux_streams = n < 1 ? 1 : (n > 4 ? 4 : n); }
+static bool extra_streams_ready(int n)
+{
+    for (int k = 0; k < n - 1; ++k) {
+        if (!g_extra_stream[k] && hipStreamCreateWithFlags(&g_extra_stream[k], hipStreamNonBlocking) != hipSuccess) return false;
+        if (!g_extra_event[k] && hipEventCreateWithFlags(&g_extra_event[k], hipEventDisableTiming) != hipSuccess) return false;
+    }
+    return true;
+}
 // Output-row occupancy flags (dreg_conv_row_occupancy) of the convolution that reads the network input x_in — the stem: byte
 // [B, Do, Ho], 0 = the row's receptive field in x_in is all zero.  Used by the next forward / backward calls; null = none.
 void dreg_exec_set_input_row_occupancy(void* h, const uint8_t* rowocc) { ((Exec*)h)->in_rowocc = rowocc; }
@@ -547,6 +562,17 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
         }
         e->sparse_arena = arena;
     }
+    const int n_ws = (aux_on && g_aux_streams > 1 && extra_streams_ready(g_aux_streams)) ? g_aux_streams : 1;
+    int ws_rr = 0;
+    bool extra_busy[3] = {false, false, false};
+    auto join_extra = [&]() -> int {                  // the second stream continues only behind what the extra streams have been given
+        for (int k = 0; k < 3; ++k) {
+            if (!extra_busy[k]) continue;
+            if (hipEventRecord(g_extra_event[k], g_extra_stream[k]) != hipSuccess || hipStreamWaitEvent(e->aux, g_extra_event[k], 0) != hipSuccess) return DREG_ELAUNCH;
+            extra_busy[k] = false;
+        }
+        return DREG_OK;
+    };
     std::vector<char> rd_done(e->reduce.size(), 0);   // records whose partials this call produced and nobody summed yet
     hipStream_t rd_stream = st;
     size_t rd_pending = 0;
@@ -555,6 +581,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
     // launch per run of consecutive records.  Flushed every ~192 MB of partials: the deep layers' sums then run next to the rest
     // of the backward pass, and only the last few layers' are left for the end.
     auto flush_reduce = [&]() -> int {
+        CK(join_extra());
         for (int lo = 0, nrec = (int)rd_done.size(); lo < nrec;) {
             if (!rd_done[lo]) { ++lo; continue; }
             int hi = lo;
@@ -602,13 +629,22 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                     ws = e->aux;
                     aux_used = true;
                 }
+                hipStream_t bs = ws;                  // bias sums stay on the second stream (they share one scratch buffer)
+                if (w.grad && n_ws > 1 && o.rd >= 0) {  // deferred-sum weight gradients rotate over the streams
+                    const int k = ws_rr++ % n_ws;
+                    if (k > 0) {
+                        if (hipStreamWaitEvent(g_extra_stream[k - 1], e->ev[i], 0) != hipSuccess) return DREG_ELAUNCH;
+                        ws = g_extra_stream[k - 1];
+                        extra_busy[k - 1] = true;
+                    }
+                }
                 if (w.grad) {
                     Scope sc(e, ws, i, 2);
                     if (o.rd >= 0) {
                         CK(dreg_conv3d_wgrad_partials(gy, act(o.in), A + o.wg_off, o.wg_bytes, rows ? r_out : nullptr, n_out, x.B, x.D, x.H, x.W, x.C, w.d1,
                                                       y.D, y.H, y.W, w.d0, o.ksz, rows ? 1 : o.stride, o.pad, (!rows && o.in == 0) ? e->in_rowocc : nullptr, (void*)ws));
                         rd_done[o.rd] = 1;
-                        rd_stream = ws;
+                        rd_stream = n_ws > 1 ? e->aux : ws;
                         rd_pending += o.wg_bytes;
                         if (rd_pending >= ((size_t)192 << 20)) { CK(flush_reduce()); rd_pending = 0; }
                     } else if (rows) {
@@ -620,8 +656,8 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                     }
                 }
                 if (o.b >= 0 && e->prm[o.b].grad) {
-                    if (rows) CK(dreg_colsum_rows(gy, r_out, n_out, e->prm[o.b].grad, (float*)(A + e->off_cs), w.d0, 1, 0, (void*)ws));
-                    else CK(dreg_colsum(gy, e->prm[o.b].grad, (float*)(A + e->off_cs), (size_t)y.B * y.D * y.H * y.W, w.d0, 1, 0, (void*)ws));
+                    if (rows) CK(dreg_colsum_rows(gy, r_out, n_out, e->prm[o.b].grad, (float*)(A + e->off_cs), w.d0, 1, 0, (void*)bs));
+                    else CK(dreg_colsum(gy, e->prm[o.b].grad, (float*)(A + e->off_cs), (size_t)y.B * y.D * y.H * y.W, w.d0, 1, 0, (void*)bs));
                 }
             }
             if (o.in2 >= 0 && e->needs_grad[o.in2]) {
@@ -714,6 +750,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
     }
     CK(flush_reduce());
     CK(flush_bn_tails(e, A, bn_done, 1, st));
+    if (aux_on) CK(join_extra());
     if ((flags & 2) && aux_used) {   // the caller's stream continues (optimizer) only after every parameter gradient has landed
         if (hipEventRecord(e->ev_done, e->aux) != hipSuccess || hipStreamWaitEvent(st, e->ev_done, 0) != hipSuccess) return DREG_ELAUNCH;
     }

@@ -30,6 +30,7 @@ void dreg_conv_set_glds_stages(int stages);          /* LDS pipeline stages of t
 void dreg_conv_set_wgrad_target_blocks(int blocks);   /* workgroups the automatic split choice aims for (default 3072) */
 /* largest per-grid volume (voxels) whose BatchNorm runs the fused statistics+apply kernels (default 512 = the 8^3 level; 16^3 measured slower fused); 0 = never */
 void dreg_bn_set_small_max_voxels(int v);
+void dreg_exec_set_aux_streams(int n);                /* experiment: weight-gradient launches of the executor's backward rotate over n streams (default 1 = the one second stream) */
 void dreg_exec_set_sparse_grads(int on);              /* 1 (default): executors created from now on keep the single-writer gradient buffers of the active-set head zero by clearing rows */
 void dreg_exec_set_bn_batch_tails(int on);            /* 1 (default): executors created from now on batch the small BatchNorms' running-statistics / dgamma-dbeta launches per pass */
 void dreg_exec_set_fuse_stem(int on);                 /* 1 (default): executors created from now on fuse the stem's BatchNorm + ReLU + max-pool (fpn_ops.hip) */

@@ -204,9 +204,12 @@ def test_fp32_mode_step_matches_reference_golden_128(golden_dir):
 # emulation.  train64_wc / train128_wc are the SAME step of the REFERENCE on the well-conditioned weight profile params.PROFILES["wc"]
 # (tools/wc_profile_sweep.py: what each knob buys; the bf16-emulated oracle itself reaches pose 6e-5, primary probes cos >= 0.997, deep
 # ResNet probes cos >= 0.96, every gradient norm within 0.6 % at 128^3).  Here the bf16 build is bounded in ABSOLUTE terms:
-#   pose max-abs <= 2e-2, the eight primary gradient probes cos >= 0.99, the eight deeper probes (layer2..4, the second head level)
-#   cos >= 0.9 (a sign flip reads -1), every per-module AND per-ResNet-stage gradient norm within 5 % of the fp64 truth.
-PRIMARY = ["fpn3d.backbone_net.conv1.weight", "fpn3d.backbone_net.layer1.0.conv2.weight", "fpn3d.backbone_net.layer4.2.bn3.weight",
+#   pose max-abs <= 2e-2; gradient probes (64 sampled elements each, against the fp64 truth): cos >= 0.99 for the stem, layer1, both head
+#   levels, the transformer and the decoder; cos >= 0.9 at 128^3 / >= 0.8 at 64^3 for the probes inside layer2..4, whose BatchNorms
+#   see 8..512 voxels per grid (the bf16-EMULATED REFERENCE itself reads 0.83-0.98 there at 64^3; a sign flip reads -1);
+#   every per-module AND per-ResNet-stage gradient norm within 5 % of the fp64 truth (measured <= 1.3 %).
+PRIMARY = ["fpn3d.backbone_net.conv1.weight", "fpn3d.backbone_net.layer1.0.conv2.weight",
+           "fpn3d.feature_pyramid.upsample_transform_2.weight", "fpn3d.feature_pyramid.pyramid_transformation_4.weight",
            "fpn3d.feature_pyramid.upsample_transform_1.weight", "fpn3d.feature_pyramid.pyramid_transformation_1.bias",
            "transformer_encoder.layers.0.self_attn.in_proj_weight", "transformer_encoder.layers.5.linear2.weight", "correspondence_decoder.q_proj.weight"]
 STAGES = {"stem": "fpn3d.backbone_net.conv1.", "layer1": "fpn3d.backbone_net.layer1.", "layer2": "fpn3d.backbone_net.layer2.",
@@ -285,7 +288,7 @@ def test_bf16_product_step_absolute_bounds_wc_64(golden_dir, active_set):
     g, emu = _wc(golden_dir, "train64_wc")
     m, ts, out, pred, grads, delta = _product_step(g, 64, active_set=active_set, profile="wc")
     assert m.__dict__.get("_trunk_cache"), "the native trunk executor did not run"
-    _check_absolute(g, "wc_bf16_64_" + ("active" if active_set else "dense"), out, pred, grads, delta, m, emu)
+    _check_absolute(g, "wc_bf16_64_" + ("active" if active_set else "dense"), out, pred, grads, delta, m, emu, cos_deep=0.8)
 
 
 def test_bf16_product_step_absolute_bounds_wc_128(golden_dir):
@@ -301,10 +304,14 @@ def test_sign_flip_in_a_weight_gradient_is_caught(golden_dir):
     broken = dict(grads)
     broken["fpn3d.backbone_net.layer1.0.conv2.weight"] = -grads["fpn3d.backbone_net.layer1.0.conv2.weight"]
     with pytest.raises(AssertionError):
-        _check_absolute(g, "wc_sign_flip_must_fail", out, pred, broken, delta, m, emu)
+        _check_absolute(g, "wc_sign_flip_must_fail", out, pred, broken, delta, m, emu, cos_deep=0.8)
+    broken = dict(grads)                                  # ... also for a probe inside the deep stages
+    broken["fpn3d.backbone_net.layer3.2.conv2.weight"] = -grads["fpn3d.backbone_net.layer3.2.conv2.weight"]
+    with pytest.raises(AssertionError):
+        _check_absolute(g, "wc_sign_flip_deep_must_fail", out, pred, broken, delta, m, emu, cos_deep=0.8)
     half = dict(grads)                                    # and a dropped contribution (gradient scaled by 0.8) fails the stage norm
     for k in list(half):
         if k.startswith("fpn3d.backbone_net.layer3."):
             half[k] = 0.8 * grads[k]
     with pytest.raises(AssertionError):
-        _check_absolute(g, "wc_scaled_stage_must_fail", out, pred, half, delta, m, emu)
+        _check_absolute(g, "wc_scaled_stage_must_fail", out, pred, half, delta, m, emu, cos_deep=0.8)
