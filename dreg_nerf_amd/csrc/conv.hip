@@ -256,9 +256,14 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
 {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     constexpr int NW = (BN == 256 || AP) ? 8 : 4, WAVES_N = NW / 2;      // waves: 2 (M) x WAVES_N (N), (BM/2) x (BN/WAVES_N) each
-    constexpr int BKe = 64, WMt = BM / 2, WN = BN / WAVES_N, TM = WMt / 16, TN = WN / 16;
-    constexpr int IA = (BM / 8) / NW, IBW = (BN / 8) / NW;               // wave-instructions per wave per stage
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    // AP with the 256 x 256 tile: stages of 32 channels (64-byte rows, 16 rows per direct-to-LDS piece) so that a ring of four fits LDS
+    constexpr bool AP256 = AP && BM == 256;
+    constexpr int BKe = AP256 ? 32 : 64, WMt = BM / 2, WN = BN / WAVES_N, TM = WMt / 16, TN = WN / 16;
+    constexpr int RPP = AP256 ? 16 : 8, GPR = 64 / RPP;                  // rows per piece, 16-byte granules per row
+    constexpr int LOGK = AP256 ? 5 : 6;
+    constexpr int IA = (BM / RPP) / NW, IBW = (BN / RPP) / NW;           // wave-instructions per wave per stage
+    constexpr int A_BYTES = BM * BKe * 2, B_BYTES = BN * BKe * 2, STAGE = A_BYTES + B_BYTES;
+    auto gswz = [](int r) -> int { return AP256 ? (((r >> 3) & 1) * 3) : ((r >> 1) & 7); };   // granule XOR of LDS row r (see the fragment reads)
     constexpr uint32_t OOB = 0x7fffff00u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -270,15 +275,14 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)wt, 0, wt_bytes, 0x00020000);
 
     // staging roles: wave-instruction i of this wave covers tile rows (wave*IA + i)*8 + (lane>>3), physical slot lane&7
     uint32_t abase[IA], amask[IA];
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-        const int r = (wave * IA + i) * 8 + (lane >> 3);
-        const int gl = (lane & 7) ^ ((r >> 1) & 7);
+        const int r = (wave * IA + i) * RPP + lane / GPR;
+        const int gl = (lane % GPR) ^ gswz(r);
         const uint32_t ri = m0 + r;            // row of the (possibly sparse) row space
         const bool rv = ri < nrows;
         const uint32_t m = rowlist ? (rv ? (uint32_t)rowlist[ri] : 0u) : ri;   // output voxel
@@ -324,8 +328,8 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
     uint32_t bbase[IBW];
 #pragma unroll
     for (int i = 0; i < IBW; ++i) {
-        const int r = (wave * IBW + i) * 8 + (lane >> 3);
-        const int gl = (lane & 7) ^ ((r >> 1) & 7);
+        const int r = (wave * IBW + i) * RPP + lane / GPR;
+        const int gl = (lane % GPR) ^ gswz(r);
         bbase[i] = (uint32_t)(n0 + r) * (uint32_t)(g.Kpad * 2) + (uint32_t)(gl * 16);
     }
     // keep the per-lane bases as VALUES in registers: left alone, the compiler re-derives each abase from its factors inside the K loop
@@ -344,22 +348,54 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    // ---- requests.  K steps are requested IN ORDER, so the gather address of a piece is kept as  per-lane offset (fixed for a tap) +
+    // scalar offset (tap offset + channel chunk, the instruction's soffset operand):  a K step costs its 2 x (IA + IBW) M0 / load
+    // instructions and two scalar adds; the tap decode and the per-row validity select (4 VALU per piece) run once per tap, behind a real
+    // branch.  (The issue phase was ~600 of ~1,700 cycles of a K step: a wave issues about one instruction per 5 cycles whatever it is.)
+    // Offsets are biased so that both operands of the hardware's address sum are non-negative: the descriptor starts X + Y bytes before
+    // the tensor, the lane offset carries + X (the d = 0 corner of a row may lie up to X bytes before it: forward padding), the scalar
+    // offset + Y (data-gradient taps walk backwards); a valid lane's sum is inside the tensor, an invalid lane's offset is out of range.
+    const int pneg = g.off < 0 ? -g.off : 0;
+    const uint32_t biasX = (uint32_t)(((pneg * g.Hi + pneg) * g.Wi + pneg) * g.Cin * 2);
+    const uint32_t biasY = g.dsign < 0 ? (uint32_t)(((g.ksz - 1) * ((g.Hi + 1) * g.Wi + 1)) * g.Cin * 2) : 0u;
+    const __amdgpu_buffer_rsrc_t rs_inb = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)in - (biasX + biasY)), 0, in_bytes + biasX + biasY, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < IA; ++i) { abase[i] += biasX; asm volatile("" : "+v"(abase[i])); }
+    const int step_x = g.dsign * g.Cin * 2, step_y = step_x * (g.Wi - (g.ksz - 1)), step_z = step_x * ((g.Hi - (g.ksz - 1)) * g.Wi - (g.ksz - 1));
+    int ck = 0, cc = 0, ctap = 0, cdx = 0, cdy = 0, cdz = 0;    // cursor: next K step, its channel chunk, tap and tap coordinates
+    uint32_t ctoff = 0;                                         // biased byte offset of the cursor's tap
+    uint32_t voffA[IA];
+    auto tap_select = [&]() {
+#pragma unroll
+        for (int i = 0; i < IA; ++i) voffA[i] = ((amask[i] >> ctap) & 1u) ? abase[i] : OOB;
+    };
+    auto cursor_init = [&](int k) {
+        ck = k;
+        ctap = g.ksz == 1 ? 0 : (k >> (g.log2Cin - LOGK));      // k^3 layers have power-of-two channel counts (fill_geom): a shift
+        cc = k - ctap * chunks;
+        tap_decode(ctap, g.ksz, cdz, cdy, cdx);
+        ctoff = (uint32_t)(((cdz * g.Hi + cdy) * g.Wi + cdx) * step_x) + biasY;
+        tap_select();
+    };
     auto issue = [&](int k, int buf) {
-        // k^3 layers have power-of-two channel counts (fill_geom): the tap of K step k is a shift, not a division
-        const int tap = g.ksz == 1 ? 0 : (k >> (g.log2Cin - 6)), c = k - tap * chunks;
-        int dz, dy, dx;
-        tap_decode(tap, g.ksz, dz, dy, dx);
-        const int toff = (((dz * g.Hi + dy) * g.Wi + dx) * g.dsign * g.Cin + c * BKe) * 2;
+        (void)k;                                                // == ck: requests are sequential
         char* sA = smem + buf * STAGE + wave * IA * 1024;
         char* sB = smem + buf * STAGE + A_BYTES + wave * IBW * 1024;
+        const uint32_t soA = ctoff + (uint32_t)(cc * BKe * 2), soB = (uint32_t)(ck * BKe * 2);
 #pragma unroll
-        for (int i = 0; i < IA; ++i) {
-            const uint32_t voff = ((amask[i] >> tap) & 1u) ? abase[i] + (uint32_t)toff : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(sA + i * 1024), 16, (int)voff, 0, 0, 0);
-        }
+        for (int i = 0; i < IA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_inb, (lds_ptr_t)(sA + i * 1024), 16, (int)voffA[i], (int)soA, 0, 0);
 #pragma unroll
         for (int i = 0; i < IBW; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, (lds_ptr_t)(sB + i * 1024), 16, (int)(bbase[i] + (uint32_t)(k * BKe * 2)), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, (lds_ptr_t)(sB + i * 1024), 16, (int)bbase[i], (int)soB, 0, 0);
+        ++ck;
+        if (++cc == chunks) {                                   // next tap (the empty volatile asm keeps this a real branch)
+            asm volatile("" ::: "memory");
+            cc = 0; ++ctap;
+            if (++cdx < g.ksz) ctoff += (uint32_t)step_x;
+            else { cdx = 0; if (++cdy < g.ksz) ctoff += (uint32_t)step_y; else { cdy = 0; ++cdz; ctoff += (uint32_t)step_z; } }
+            tap_select();
+        }
     };
     auto compute = [&](int buf) {
         const char* sA = smem + buf * STAGE;
@@ -388,24 +424,33 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
     if (ksplit > 1) out += (size_t)blockIdx.y * g.M * g.Cout;
     // ring of nstage (2..4) LDS stages: stage k is consumed while the loads of up to nstage-1 later stages are in flight
     constexpr int LPS = IA + IBW;                      // direct-to-LDS loads per wave per stage (vmcnt retires them in order)
+    cursor_init(k_begin);
     if constexpr (AP) {
-        static_assert(BM == 128 && (BN == 128 || BN == 64) && !DBG && STAGE <= 65535, "anti-phase form: 128-row tiles");
+        static_assert(((BM == 128 && (BN == 128 || BN == 64)) || (BM == 256 && BN == 256)) && !DBG && STAGE <= 65535, "anti-phase form: 128-row tiles, or 256 x 256 with 32-channel stages");
+        constexpr int KS = AP256 ? 1 : 2;            // 32-channel fragment groups per stage
         const int nku = k_end - k_begin;
         if (nku > 0) {
             const int grp = wave >> 2;
             const int fr = lane & 15, kg = lane >> 4;
             const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
             // fragment addresses in ring slot 0 (or 2): fixed per lane; the odd slots are + STAGE as an immediate offset
-            uint32_t fa[2][TM], fb[2][TN];
+            // 64-byte rows (AP256): slot = granule ^ 3 * ((row >> 3) & 1) — a ds_read_b128 is served in four groups of 16 lanes
+            // ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... : fragment rows q, q+4, q+8, q+12 of a 16-row block meet in one group with
+            // K granules (g, g^1, g^1, g)), and with this XOR the 16 lanes of every group touch 16 different 16-byte slots of a 256-byte line
+            auto fswz = [&](int row, int slot) -> uint32_t {
+                if constexpr (AP256) return (uint32_t)row * 64u + (uint32_t)((slot ^ gswz(row)) << 4);
+                else return swz(row, slot);
+            };
+            uint32_t fa[KS][TM], fb[KS][TN];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[ks][i] = lds0 + swz(wm * WMt + i * 16 + fr, ks * 4 + kg);
+                for (int i = 0; i < TM; ++i) fa[ks][i] = lds0 + fswz(wm * WMt + i * 16 + fr, ks * 4 + kg);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[ks][j] = lds0 + A_BYTES + swz(wn * WN + j * 16 + fr, ks * 4 + kg);
+                for (int j = 0; j < TN; ++j) fb[ks][j] = lds0 + A_BYTES + fswz(wn * WN + j * 16 + fr, ks * 4 + kg);
             }
             typedef __attribute__((ext_vector_type(4))) int i32x4_t;
-            i32x4_t af[2][TM], bf[2][TN];
+            i32x4_t af[KS][TM], bf[KS][TN];
             auto rd1 = [&](uint32_t addr, int odd) -> i32x4_t {
                 i32x4_t v;
                 if (odd) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(STAGE));
@@ -414,7 +459,7 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
             };
             auto rd = [&](int odd) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
+                for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) af[ks][i] = rd1(fa[ks][i], odd);
 #pragma unroll
@@ -423,7 +468,7 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
             };
             auto mm = [&]() {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -459,7 +504,7 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
             };
             auto shift = [&](uint32_t d) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
+                for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) fa[ks][i] += d;
 #pragma unroll
@@ -1851,6 +1896,7 @@ static inline int glds_stages(long blocks) { (void)blocks; return g_glds_stages 
 
 static int g_igemm_probe = 0;         // measurement only (tools/igemm_phase_probe.py): the 128 x 128 kernel with s_memtime stamps
 static int g_narrow_thr = 224;        // tile count below which a launch takes the narrower tiles
+static int g_igemm_ap256 = 1;         // tuning (include/dreg_nerf_tuning.h): the 256 x 256 tile of large launches runs in its anti-phase form (32-channel stages)
 static int g_igemm_ap = 256;          // tuning (include/dreg_nerf_tuning.h): launches of at most this many 128-row tiles take the eight-wave anti-phase form (0: never)
 static int g_narrow_small = 2;        // tuning (include/dreg_nerf_tuning.h): 128 x 64 tiles for launches of < 224 128 x 128 tiles
 // Which kernel instantiation a bf16 / fp32 convolution launch runs (ONE rule set: launch_conv dispatches on it and
@@ -1872,7 +1918,7 @@ static IgemmChoice igemm_choose(const ConvGeom& g, uint32_t nrows, bool rowlist,
         if (g_use_glds && g.sd == 1 && g.Cin % 64 == 0 && g.ntaps <= 32 && fits) {
             c.kind = 0;
             const uint32_t tm_ = (nrows + 127) / 128;
-            if (g.Cout % 256 == 0 && (g_use_glds == 1 || g_use_glds == 4 || g_use_glds == 5) && nrows >= 65536) { c.bm = 256; c.bn = 256; }
+            if (g.Cout % 256 == 0 && (g_use_glds == 1 || g_use_glds == 4 || g_use_glds == 5) && nrows >= 65536) { c.bm = 256; c.bn = 256; c.ap = g_igemm_ap256 ? 1 : 0; }
             else if (g.Cout % 256 == 0 && g_use_glds == 3 && nrows >= 65536) { c.bm = 128; c.bn = 256; }
             else if (g_igemm_ap && g.Cout % 128 == 0 && tm_ * (g.Cout / 128) <= (uint32_t)g_igemm_ap) { c.bn = 128; c.ap = 1; }
             else if (g_igemm_ap && g.Cout % 128 != 0 && g.Cout % 64 == 0 && tm_ * (g.Cout / 64) <= (uint32_t)g_igemm_ap) { c.bn = 64; c.ap = 1; }
@@ -1945,7 +1991,15 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
                                    (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tn_, \
                                    (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows, 1, ns_); } while (0)
             const IgemmChoice ch = igemm_choose(g, nrows, rowlist != nullptr, false, addend != nullptr, 2);
-            if (ch.bm == 256) GL_LAUNCH(256, 256, 512);
+            if (ch.bm == 256 && ch.ap) {
+                const int tm_ = (nrows + 255) / 256, tn_ = g.Cout / 256;
+                const size_t lds_ = (size_t)4 * (256 + 256) * 64;
+                (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<TO, 256, 256, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);
+                hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, 256, 256, 0, 1>), dim3(tm_ * tn_), dim3(512), lds_, st,
+                                   (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tn_,
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows, 1, 4);
+            }
+            else if (ch.bm == 256) GL_LAUNCH(256, 256, 512);
             else if (ch.bn == 256) GL_LAUNCH(128, 256, 512);
             // fewer 128 x 128 tiles than CUs (the point-set half's linear layers: ~77 row tiles x 2): half-width tiles put twice as
             // many workgroups on the chip
@@ -2094,6 +2148,7 @@ int dreg_conv3d_igemm_variant(int B, int Di, int Hi, int Wi, int Cin, int Do, in
 }
 void dreg_conv_igemm_probe(int enable) { g_igemm_probe = enable; }
 void dreg_conv_set_igemm_ap(int max_tiles) { g_igemm_ap = max_tiles > 0 ? max_tiles : 0; }
+void dreg_conv_set_igemm_ap256(int on) { g_igemm_ap256 = on ? 1 : 0; }
 int dreg_conv_igemm_probe_read(unsigned long long* out6)
 {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -44,6 +44,7 @@ SIGNATURES = {
     "dreg_conv_set_wgrad_big": (None, [I]),
     "dreg_conv_igemm_probe": (None, [I]),
     "dreg_conv_set_igemm_ap": (None, [I]),
+    "dreg_conv_set_igemm_ap256": (None, [I]),
     "dreg_exec_set_aux_streams": (None, [I]),
     "dreg_conv_igemm_probe_read": (I, [P]),
     "dreg_conv_set_wgrad_pipe": (None, [I]),

@@ -46,3 +46,44 @@ for name, B, D, cin, cout, k in shapes:
     print(f"{name:28s} four waves {a:7.1f} us ({fl / a / 1e6:6.0f} TF)   anti-phase {b:7.1f} us ({fl / b / 1e6:6.0f} TF)   x{a / b:.2f}   bit-identical {torch.equal(res[0], res[512])}", flush=True)
 lib.dreg_conv_set_igemm_ap(512)
 print(f"sum {tot[0]:.1f} -> {tot[1]:.1f} us")
+
+# ---- the 256 x 256 tile of large launches: anti-phase form over 32-channel stages (dreg_conv_set_igemm_ap256) vs the lockstep form
+print("256 x 256 tile:")
+big = [("64^3 x 8  256 -> 256 k3", 8, 64, 256, 256, 3), ("32^3 x 8  256 -> 256 k3", 8, 32, 256, 256, 3), ("64^3 x 8  64 -> 256 k3", 8, 64, 64, 256, 3),
+       ("32^3 x 8  64 -> 256 k1", 8, 32, 64, 256, 1), ("32^3 x 8  512 -> 256 k1", 8, 32, 512, 256, 1)]
+for name, B, D, cin, cout, k in big:
+    x = torch.randn(B, D, D, D, cin, device=dev).bfloat16()
+    w = torch.randn(cout, cin, k, k, k, device=dev) * 0.05
+    bias = torch.randn(cout, device=dev)
+    wp = ops.packed_weight(w, cin, False, 0)
+    out = torch.empty(B, D, D, D, cout, dtype=torch.bfloat16, device=dev)
+    keep = torch.rand(B * D ** 3, device=dev) < 0.4
+    keep[:5] = True; keep[-5:] = True
+    rows = keep.nonzero().flatten().int()
+    out_r = torch.zeros_like(out)
+
+    def dense():
+        L.check(lib.dreg_conv3d_igemm(L.ptr(x), L.ptr(wp), L.ptr(out), L.ptr(bias), None, B, D, D, D, cin, D, D, D, cout, k, 1, k // 2, 0, 1, 0, 0, 0, 0, 0, 0, L.stream()), "igemm")
+
+    def sparse():
+        L.check(lib.dreg_conv3d_igemm_rows(L.ptr(x), L.ptr(wp), L.ptr(out_r), L.ptr(bias), None, L.ptr(rows), rows.shape[0], B, D, D, D, cin, D, D, D, cout, k, 1, k // 2, 0, 1, 0, 0, 0, 0, 0, L.stream()), "igemm_rows")
+
+    res, ms = {}, {}
+    for ap in (0, 1):
+        lib.dreg_conv_set_igemm_ap256(ap)
+        dense(); out_r.zero_(); sparse(); torch.cuda.synchronize()
+        res[ap] = (out.clone(), out_r.clone())
+    for rnd in range(3):
+        for ap in (0, 1):
+            lib.dreg_conv_set_igemm_ap256(ap)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5): dense()
+            e1.record(); torch.cuda.synchronize()
+            ms.setdefault(ap, []).append(e0.elapsed_time(e1) / 5)
+    a, b = sorted(ms[0])[1], sorted(ms[1])[1]
+    fl = 2.0 * B * D ** 3 * cin * cout * k ** 3
+    same = torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    rows_ok = torch.equal(res[1][1].view(-1, cout)[rows.long()], res[1][0].view(-1, cout)[rows.long()])
+    print(f"{name:28s} lockstep {a:7.3f} ms ({fl / a / 1e9:6.0f} TF)   anti-phase {b:7.3f} ms ({fl / b / 1e9:6.0f} TF)   x{a / b:.2f}   bit-identical {same}   row-list == dense rows {rows_ok}", flush=True)
+lib.dreg_conv_set_igemm_ap256(1)
