@@ -135,3 +135,47 @@ def test_unbounded_contraction_and_per_point_directions_vs_oracle():
     a = f.query_rgb(one.to(DEV), feat)
     b = f.query_rgb_mean(raw16, one[:1].to(DEV))
     assert (a - b).abs().max() < 4e-3
+
+
+def test_dense_query_at_the_baseline_size_128():
+    """BASELINE config 4's size: a 128^3 block with ~325 k occupied cells (a ball of radius 1 in the [-1.5, 1.5]^3 block).  The oracle
+    cannot walk 3e5 points in test time, so: (1) the occupied-cell enumeration (indices) is compared bit for bit with the oracle's
+    enumeration of the same binary field, and world positions with its formula; (2) two launches give identical outputs; (3) density /
+    colour / alpha of 4,096 sampled points against the oracle on exactly those points; (4) the grid writer's masks are the keep set."""
+    res = 128
+    f = _field(9, table_scale=1.0)
+    params_b, params_c = f.mlp_base.params.detach().clone(), f.color_mlp.params.detach().clone()
+    f = f.to(DEV)
+    c = (torch.arange(res, dtype=torch.float32) + 0.5) / res * 3 - 1.5
+    X, Y, Z = torch.meshgrid(c, c, c, indexing="ij")
+    binary = torch.stack([X, Y, Z], -1).norm(dim=-1) < 1.0
+    n = int(binary.sum())
+    assert n > 300000
+    g = torch.Generator().manual_seed(6)
+    jitter = torch.rand(n, 3, generator=g)
+    sg = ngp.SampleGrid(AABB, res).to(DEV)
+    sg.set_binary_fields(binary.to(DEV))
+    world, rgb, alpha, indices, dmask = sg.query_dense(f, DEV, jitter=jitter.to(DEV))
+    world2, rgb2, alpha2, indices2, dmask2 = sg.query_dense(f, DEV, jitter=jitter.to(DEV))
+    assert torch.equal(world, world2) and torch.equal(rgb, rgb2) and torch.equal(alpha, alpha2) and torch.equal(indices, indices2) and torch.equal(dmask, dmask2)
+    idx_ref = torch.nonzero(binary.flatten())[:, 0]
+    assert torch.equal(indices.cpu(), idx_ref)                                     # bit-exact enumeration, ascending
+    coords = torch.stack([idx_ref // (res * res), (idx_ref // res) % res, idx_ref % res], dim=1).float()
+    w_ref = (coords + jitter) / res * 3.0 - 1.5
+    np.testing.assert_allclose(world.cpu().numpy(), w_ref.numpy(), atol=2e-6)
+    pick = torch.randperm(n, generator=g)[:4096]
+    aabb = torch.tensor(AABB)
+    d_ref, raw_ref = N.query_density(world.cpu()[pick], aabb, params_b)
+    dirs = N.fixed_viewdirs()
+    rgb_ref = torch.stack([N.query_rgb(dirs[k].expand(pick.shape[0], 3), raw_ref, params_c) for k in range(dirs.shape[0])]).mean(0)
+    alpha_ref = torch.clip(1 - torch.exp(-1e-2 * d_ref), 0, 1)
+    np.testing.assert_allclose(alpha.cpu().numpy()[pick, 0], alpha_ref.numpy().reshape(-1), rtol=2e-2, atol=1e-5)
+    np.testing.assert_allclose(rgb.cpu().numpy()[pick], rgb_ref.numpy(), atol=5e-3)
+    dm_ref = (d_ref.reshape(-1) > 0.7)
+    away = (d_ref.reshape(-1) - 0.7).abs() > 0.02 * 0.7                             # bit-exact away from the threshold (fp16 network output)
+    assert torch.equal(dmask.cpu()[pick][away], dm_ref[away]) and float(away.float().mean()) > 0.9
+    grid, mask = ngp.build_voxel_grid(world, rgb, alpha, indices, dmask, res)
+    assert torch.equal(mask.cpu(), idx_ref[dmask.cpu()]) and torch.all(mask[1:] > mask[:-1])
+    flat = grid.view(-1, 7)
+    assert torch.equal(flat[mask, :3], world[dmask]) and torch.equal(flat[mask, 6], alpha[dmask].reshape(-1))
+    assert int((flat.abs().sum(dim=1) > 0).sum()) <= int(dmask.sum())

@@ -56,3 +56,32 @@ def test_compute_visibility_score_from_checkpoint(tmp_path):
     xyz = (torch.rand(6, 50, 3, generator=g) - 0.5).to(DEV) * 2
     out = visibility.compute_visibility_score([xyz], path)
     assert out[0].shape == (6, 50, 1) and set(out[0].unique().tolist()) <= {0.0, 1.0}
+
+
+def test_surface_visibility_at_block_scale():
+    """3.2e5 points x 4 cameras through a 128^3 occupancy field (the size of one block's extraction / a training step's labels): two launches
+    agree bit for bit, and a sample of 400 points agrees with the oracle's march wherever the surface field is not within 2 % of the cut-off."""
+    res = 128
+    g = torch.Generator().manual_seed(3)
+    f = ngp.NGPradianceField(AABB)
+    with torch.no_grad():
+        f.mlp_base.params[:3072] = torch.randn(3072, generator=g) * 0.5
+        f.mlp_base.params[3072:] = torch.randn(f.mlp_base.params.numel() - 3072, generator=g) * 2.0
+    params_b = f.mlp_base.params.detach().clone()
+    f = f.to(DEV)
+    c = (torch.arange(res, dtype=torch.float32) + 0.5) / res * 3 - 1.5
+    X, Y, Z = torch.meshgrid(c, c, c, indexing="ij")
+    rad = torch.stack([X, Y, Z], -1).norm(dim=-1)
+    binary = (rad > 0.55) & (rad < 0.95)
+    pts = (torch.rand(320000, 3, generator=g) - 0.5) * 2.2
+    cams = torch.tensor([[2.5, 0.3, 0.1], [-0.4, -2.2, 0.9], [0.2, 0.1, 0.05], [0.1, 2.4, -0.6]])
+    dt = 3 * 3 ** 0.5 / 1024
+    lab = visibility.surface_visibility(pts.to(DEV), cams.to(DEV), f, binary.to(DEV), AABB, AABB, dt)
+    lab2 = visibility.surface_visibility(pts.to(DEV), cams.to(DEV), f, binary.to(DEV), AABB, AABB, dt)
+    assert torch.equal(lab, lab2) and lab.shape[0] == 320000
+    pick = torch.randperm(320000, generator=g)[:400]
+    lab_ref, best = VO.surface_visibility(cams, pts[pick], binary, torch.tensor(AABB), torch.tensor(AABB), torch.tensor(AABB), params_b, dt)
+    decided = ((best - 0.5).abs() > 0.02).all(dim=0)
+    assert decided.float().mean() > 0.8
+    assert torch.equal(lab.cpu().int()[pick][decided], lab_ref[decided])
+    assert 0 < int(lab.sum()) < 320000
