@@ -77,8 +77,14 @@ def test_two_ranks_average_equals_one_rank_with_both_pairs():
         if float(a.norm()) > 1e-6 * float(single.double().norm()):
             worst = max(worst, float((a - b).norm()) / float(a.norm()))
             seen += 1
-    assert seen > 100 and worst < 5e-2, (seen, worst)
-    assert float((single.double() - g0.double()).norm()) < 5e-3 * float(single.double().norm())
+    print(f"two ranks vs one rank: worst per-parameter relative distance {worst:.3e} over {seen} tensors, whole buffer "
+          f"{float((single.double() - g0.double()).norm()) / float(single.double().norm()):.3e}")
+    # What differs between the two: the weight gradients' voxel splits (their boundaries follow B x D^3, so one process with two pairs
+    # cuts the voxel range differently from two processes with one pair each), the bias column sums' partial groups, and the
+    # all-reduce's own (a + b) / 2 — fp32 summation order only.  Measured 4.5e-7 per parameter tensor, 9e-8 over the buffer; a dropped
+    # or doubled bucket, a missing 1 / world or a stale gradient would read >= 1e-2.
+    assert seen > 100 and worst < 2e-5, (seen, worst)
+    assert float((single.double() - g0.double()).norm()) < 2e-6 * float(single.double().norm())
 
 
 def test_bench_script_runs_with_two_ranks():
