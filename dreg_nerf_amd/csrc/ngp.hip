@@ -46,6 +46,21 @@ __device__ __forceinline__ void store_relu4(char* sH, int row_stride, int point,
     *reinterpret_cast<f16x4_t*>(sH + point * row_stride + hidden * 2) = h;
 }
 
+// The same with the ReLU on the packed-half VALU: round the four sums to fp16 first (round-to-nearest, as the plain cast), then ONE
+// v_pk_max_f16 per pair — relu(rn(x)) == rn(relu(x)), so the stored bits are those of store_relu4.  (The library is built without
+// packed-fp32 VALU instructions; packed fp16 ones are not affected: DESIGN.md, co-execution fault.)
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_relu4_pk(char* sH, int row_stride, int point, int hidden, const f32x4_t& v)
+{
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+    const f16x2_t z = {(_Float16)0.f, (_Float16)0.f};
+    f16x2_t a = {(_Float16)v[0], (_Float16)v[1]}, b = {(_Float16)v[2], (_Float16)v[3]};
+    a = __builtin_elementwise_max(a, z);
+    b = __builtin_elementwise_max(b, z);
+    const f16x4_t h = {a[0], a[1], b[0], b[1]};
+    *reinterpret_cast<f16x4_t*>(sH + point * row_stride + hidden * 2) = h;
+}
+
 // ------------------------------------------------------------------------------------------------ density
 // x world [Np,3] fp32 -> density fp32 [Np] (= exp(h0 - 1) * inside), raw fp16 [Np,16] (h0 | 15 geometry features)
 // one wave per workgroup: the waves are independent (no workgroup barrier), and 5,081 small workgroups for a 325 k-point block fill
@@ -213,22 +228,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     f16x8_t w3f[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) w3f[kb] = *reinterpret_cast<const f16x8_t*>(w3 + fr * 64 + kb * 32 + kg * 8);
-    float sum[4][4];
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sum[rb][r] = 0.f;
+    // Round 3: the loop was VALU-bound (~480 VALU instructions against 40 MFMAs per direction).  Three changes, same arithmetic:
+    //  * the direction's bias joins on the MATRIX pipe:  base + c_k 1^T  is one more MFMA per tile whose first operand holds the bias
+    //    split into two halves (c = hi + lo, both fp16: exact to 2^-22) in its K columns 0 and 1 and whose second operand is ones there
+    //    — 16 MFMAs instead of 128 v_add_f32 per direction;
+    //  * ReLU on the packed-half VALU after the fp16 rounding (store_relu4_pk);
+    //  * the sigmoid on DENSE lanes: the output tile has its 3 colour channels in 3 of every 16 lanes, so the 64 x 3 pre-activations
+    //    go through a 1 KB LDS patch and every lane finishes the three channels of ONE point (27 instead of 144 VALU per direction).
+    f16x8_t ones = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    if (kg == 0) { ones[0] = (_Float16)1.f; ones[1] = (_Float16)1.f; }
+    __shared__ __attribute__((aligned(16))) float sO[64 * 4];
+    float sum3[3] = {0.f, 0.f, 0.f};
 
 #pragma unroll 1
     for (int k = 0; k < ndir; ++k) {
-        float4 cb_[4];       // the direction's bias for this lane's four hidden units of every 16-column block
+        f16x8_t bfr[4];      // first operand of the bias product for this lane's row (hidden unit cb * 16 + fr): (hi, lo, 0, ...) in the kg == 0 lanes
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) cb_[cb] = dirs ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(dirbias + k * 64 + cb * 16 + kg * 4);
+        for (int cb = 0; cb < 4; ++cb) {
+            const float c = (dirs || kg != 0) ? 0.f : dirbias[k * 64 + cb * 16 + fr];
+            const _Float16 hi = (_Float16)c, lo = (_Float16)(c - (float)hi);
+            bfr[cb] = (f16x8_t){hi, lo, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        }
         wave_sync();
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) store_relu4(sH1, HRS, rb * 16 + fr, cb * 16 + kg * 4, base[rb][cb], cb_[cb].x, cb_[cb].y, cb_[cb].z, cb_[cb].w);
+            for (int cb = 0; cb < 4; ++cb)
+                store_relu4_pk(sH1, HRS, rb * 16 + fr, cb * 16 + kg * 4, __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[cb], ones, base[rb][cb], 0, 0, 0));
         wave_sync();
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
@@ -241,7 +267,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
                     h = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8_t*>(w2 + (cb * 16 + fr) * 64 + kb * 32 + kg * 8), af[kb], h, 0, 0, 0);
-                store_relu4(sH2, HRS, rb * 16 + fr, cb * 16 + kg * 4, h);
+                store_relu4_pk(sH2, HRS, rb * 16 + fr, cb * 16 + kg * 4, h);
             }
         }
         wave_sync();
@@ -250,23 +276,125 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ldsfrag(sH2, HRS, rb * 16 + fr, kb * 32 + kg * 8), w3f[kb], o, 0, 0, 0);
+            if (fr < 4) {        // channel fr of points rb * 16 + kg * 4 + r (channel 3 is padding: written, never read)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float hv = (float)(_Float16)o[r];
-                // v_rcp_f32 (1 ulp) instead of the 12-instruction IEEE division: the result is rounded to fp16 right after
-                sum[rb][r] += (float)(_Float16)__builtin_amdgcn_rcpf(1.f + __expf(-hv));
+                for (int r = 0; r < 4; ++r) sO[(rb * 16 + kg * 4 + r) * 4 + fr] = o[r];
             }
         }
+        wave_sync();
+        const float4 pre = *reinterpret_cast<const float4*>(sO + lane * 4);      // this lane's point: pre-activations of its three channels
+        const float pv[3] = {pre.x, pre.y, pre.z};
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float hv = (float)(_Float16)pv[ch];
+            // v_rcp_f32 (1 ulp) instead of the 12-instruction IEEE division: the result is rounded to fp16 right after
+            sum3[ch] += (float)(_Float16)__builtin_amdgcn_rcpf(1.f + __expf(-hv));
+        }
     }
-    if (fr < 3) {
+    if (p < Np) {
         const float inv = 1.f / (float)ndir;
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
+        for (int ch = 0; ch < 3; ++ch) rgb[(size_t)p * 3 + ch] = sum3[ch] * inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ colour, K shared directions, round 3
+// The same network as ngp_rgb_kernel for the shared-direction case (dirs == nullptr), restructured around what bounded it:
+//  * 64-point waves left a 38 % tail (5,078 waves of ~55 us on 4,096 wave slots) and spilled 16 of their 64 fp32 first-layer tiles;
+//    here a wave owns 16-point chunks (ONE 16 x 64 tile: 16 accumulator registers) and walks  chunk = block, block + grid, ...  with
+//    grid = the chip's wave slots: 20,313 chunks of a 325 k-point block are 4.96 per wave — no tail, no spills;
+//  * every weight fragment (w1: 4, w2: 8, w3: 2 MFMA operands) stays in registers for the whole kernel (the 64-point form re-read
+//    w2 from L1 for every tile and direction: 32 loads per direction);
+//  * the direction's bias joins on the matrix pipe (hi + lo halves against a ones operand: packed by ngp_dir_bias_kernel), ReLU on the
+//    packed-half VALU, the sigmoid on dense lanes (lane = (point, channel) of the chunk): ~50 VALU per chunk and direction.
+// biaspk: uint32 [ndir][64] = fp16 (hi | lo << 16) of c_k[j];  same sums in the same order as ngp_rgb_kernel up to the bias split (2^-22).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void ngp_rgb_chunks_kernel(
+    const _Float16* __restrict__ raw, const _Float16* __restrict__ w1, const _Float16* __restrict__ w2, const _Float16* __restrict__ w3,
+    const uint32_t* __restrict__ biaspk, float* __restrict__ rgb, int ndir, int Np)
+{
+    constexpr int XRS = 32 * 2 + 16, HRS = 64 * 2 + 16;
+    __shared__ __attribute__((aligned(16))) char sH[16 * HRS];      // one 16 x 64 fp16 tile (X aliases its first rows)
+    __shared__ __attribute__((aligned(16))) float sO[16 * 4];
+    const int lane = threadIdx.x & 63;
+    const int fr = lane & 15, kg = lane >> 4;
+    f16x8_t w1f[4], w2f[4][2], w3f[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = p0 + rb * 16 + kg * 4 + r;
-                if (row < Np) rgb[(size_t)row * 3 + fr] = sum[rb][r] * inv;
+    for (int cb = 0; cb < 4; ++cb) {
+        w1f[cb] = *reinterpret_cast<const f16x8_t*>(w1 + (cb * 16 + fr) * 32 + kg * 8);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) w2f[cb][kb] = *reinterpret_cast<const f16x8_t*>(w2 + (cb * 16 + fr) * 64 + kb * 32 + kg * 8);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) w3f[kb] = *reinterpret_cast<const f16x8_t*>(w3 + fr * 64 + kb * 32 + kg * 8);
+    f16x8_t ones = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    if (kg == 0) { ones[0] = (_Float16)1.f; ones[1] = (_Float16)1.f; }
+    const int nchunks = (Np + 15) / 16;
+    const float inv = 1.f / (float)ndir;
+    const int opt = lane / 3, och = lane - opt * 3;                  // dense output role: lanes 0..47 = (point, channel) of the chunk
+#pragma unroll 1
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int p0 = chunk * 16;
+        wave_sync();
+        {   // X = (0 x16 | feat[1..15] | 1): lane (point fr, quarter kg) writes columns kg*4 .. +3 of both halves
+            typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+            const int p = p0 + fr;
+            f16x4_t f = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            if (p < Np) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (kg * 4 + e < 15) f[e] = raw[(size_t)p * 16 + 1 + kg * 4 + e];
             }
+            if (kg == 3) f[3] = (_Float16)1.f;
+            *reinterpret_cast<f16x4_t*>(sH + fr * XRS + kg * 8) = (f16x4_t){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            *reinterpret_cast<f16x4_t*>(sH + fr * XRS + 32 + kg * 8) = f;
+        }
+        wave_sync();
+        f32x4_t base[4];
+        {
+            const f16x8_t af = ldsfrag(sH, XRS, fr, kg * 8);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) base[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[cb], af, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+        float sum = 0.f;
+#pragma unroll 1
+        for (int k = 0; k < ndir; ++k) {
+            f16x8_t bfr[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const uint32_t pk = kg == 0 ? biaspk[k * 64 + cb * 16 + fr] : 0u;
+                typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+                bfr[cb] = __builtin_bit_cast(f16x8_t, (u32x4_t){pk, 0u, 0u, 0u});
+            }
+            wave_sync();
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+                store_relu4_pk(sH, HRS, fr, cb * 16 + kg * 4, __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[cb], ones, base[cb], 0, 0, 0));
+            wave_sync();
+            f16x8_t af[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) af[kb] = ldsfrag(sH, HRS, fr, kb * 32 + kg * 8);
+            f32x4_t h[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                h[cb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) h[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[cb][kb], af[kb], h[cb], 0, 0, 0);
+            }
+            wave_sync();                                  // every lane has read its layer-1 fragments: the tile may be overwritten
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) store_relu4_pk(sH, HRS, fr, cb * 16 + kg * 4, h[cb]);
+            wave_sync();
+            f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ldsfrag(sH, HRS, fr, kb * 32 + kg * 8), w3f[kb], o, 0, 0, 0);
+            if (fr < 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sO[(kg * 4 + r) * 4 + fr] = o[r];
+            }
+            wave_sync();
+            const float hv = (float)(_Float16)sO[(lane < 48 ? opt : 0) * 4 + och];
+            sum += (float)(_Float16)__builtin_amdgcn_rcpf(1.f + __expf(-hv));
+        }
+        if (lane < 48 && p0 + opt < Np) rgb[(size_t)p0 * 3 + lane] = sum * inv;
     }
 }
 
@@ -300,6 +428,8 @@ __global__ void grid_sample_points_kernel(const int64_t* __restrict__ idx, const
 template <typename T> __global__ void f32_to_f16_kernel(const float* __restrict__ in, _Float16* __restrict__ out, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (_Float16)in[i];
 }
+
+static int g_ngp_rgb_chunks = 1;     // tuning (include/dreg_nerf_tuning.h): shared-direction colour queries run the 16-point-chunk kernel (0: the 64-point kernel)
 
 extern "C" {
 
@@ -393,6 +523,9 @@ __global__ void ngp_dir_bias_kernel(const float* __restrict__ dirs, const _Float
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc += (float)w1[j * 32 + i] * (float)(_Float16)sh[i];
     out[k * 64 + j] = acc;
+    // the same value split into two fp16 halves (hi = rn(c), lo = rn(c - hi)), packed: the operand ngp_rgb_chunks_kernel feeds to the MFMA
+    const _Float16 hi = (_Float16)acc, lo = (_Float16)(acc - (float)hi);
+    reinterpret_cast<uint32_t*>(out + (size_t)K * 64)[k * 64 + j] = (uint32_t)__builtin_bit_cast(unsigned short, hi) | ((uint32_t)__builtin_bit_cast(unsigned short, lo) << 16);
 }
 int dreg_ngp_dir_bias(const float* dirs, const void* w1, float* out, int K, void* stream)
 {
@@ -421,11 +554,19 @@ int dreg_ngp_rgb_mean_fwd(const void* raw, const void* w1, const void* w2, const
                           int ndir, int Np, void* stream)
 {
     if (Np == 0) return DREG_OK;
+    // dirbias: fp32 [ndir][64] followed by the packed fp16 halves uint32 [ndir][64] (dreg_ngp_dir_bias writes both: 2 * ndir * 64 words)
+    if (g_ngp_rgb_chunks) {
+        const int nchunks = (Np + 15) / 16;
+        const int slots = 256 * 16;                      // wave slots of the chip at four waves per SIMD
+        hipLaunchKernelGGL(ngp_rgb_chunks_kernel, dim3(nchunks < slots ? nchunks : slots), dim3(64), 0, (hipStream_t)stream, (const _Float16*)raw,
+                           (const _Float16*)w1, (const _Float16*)w2, (const _Float16*)w3, reinterpret_cast<const uint32_t*>(dirbias + (size_t)ndir * 64), rgb, ndir, Np);
+    } else
     hipLaunchKernelGGL(ngp_rgb_kernel, dim3((Np + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const _Float16*)raw,
                        (const _Float16*)w1, (const _Float16*)w2, (const _Float16*)w3, dirbias, rgb, ndir, Np);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
+void dreg_ngp_set_rgb_chunks(int on) { g_ngp_rgb_chunks = on ? 1 : 0; }
 
 int dreg_grid_scatter7(const float* xyz, const float* rgb, const float* alpha, const int64_t* idx, const uint8_t* keep,
                        float* grid, int Np, void* stream)

@@ -175,6 +175,7 @@ SIGNATURES = {
     "dreg_ngp_density_fwd": (I, [P] * 6 + [P] * 5 + [P, I, P]),
     "dreg_ngp_rgb_mean_fwd": (I, [P] * 6 + [I, I, P]),
     "dreg_ngp_dir_bias": (I, [P, P, P, I, P]),
+    "dreg_ngp_set_rgb_chunks": (None, [I]),
     "dreg_ngp_alpha_keep": (I, [P, P, P, I, F, F, P]),
     "dreg_ngp_density_fwd_contract": (I, [P] * 6 + [P] * 5 + [P, I, I, P]),
     "dreg_ngp_rgb_dir_fwd": (I, [P] * 6 + [I, P]),

@@ -150,9 +150,11 @@ class NGPradianceField(nn.Module):
         _, col16 = self._prepared()
         if col16.is_cuda:      # one launch (csrc/ngp.hip) instead of ~30 elementwise ones: the dense query is host-bound on its glue
             d = dirs.to(col16.device).float().contiguous()
-            out = torch.empty(d.shape[0], 64, dtype=torch.float32, device=col16.device)
+            # the library writes [K, 64] fp32 biases followed by [K, 64] packed fp16 (hi | lo) halves of the same values (the MFMA operand of
+            # the chunked colour kernel); the returned view is the fp32 part, dreg_ngp_rgb_mean_fwd reads both from the same buffer
+            out = torch.empty(2 * d.shape[0], 64, dtype=torch.float32, device=col16.device)
             L.check(L.load().dreg_ngp_dir_bias(L.ptr(d), col16.data_ptr(), L.ptr(out), d.shape[0], L.stream()), "dreg_ngp_dir_bias")
-            return out
+            return out[:d.shape[0]]
         w1 = col16[:2048].view(64, 32)[:, :16].float()
         sh = sh4(dirs.to(w1.device)).half().float()
         return (sh @ w1.T).contiguous()

@@ -394,7 +394,8 @@ int dreg_ngp_density_fwd(const float* x, const void* table, const void* w1, cons
                          const uint32_t* offset, const uint32_t* size, const uint32_t* res, const float* scale,
                          const uint32_t* hashed, const float* aabb, int Np, void* stream);
 /* The per-block glue of the dense query as kernels: the direction half of the colour net's first layer for K shared directions
- * (out fp32 [K][64]; what ngp.NGPradianceField.dir_bias computed with ~30 torch launches), and alpha / density mask
+ * (out: 2 * K * 64 words — fp32 [K][64] biases, then uint32 [K][64] = the same values as two packed fp16 halves hi | lo << 16, the MFMA
+ * operand of the colour kernel; dreg_ngp_rgb_mean_fwd takes the pointer to this buffer as `dirbias`), and alpha / density mask
  * (sample_grid.py:338-341: alpha = clip(1 - exp(-delta * density), 0, 1), keep = density > threshold). */
 int dreg_ngp_dir_bias(const float* dirs, const void* w1_f16, float* out, int K, void* stream);
 int dreg_ngp_alpha_keep(const float* density, float* alpha, uint8_t* keep, int N, float delta, float threshold, void* stream);

@@ -43,6 +43,7 @@ void dreg_bn_set_debug_skip(int mask);                /* MEASUREMENT ONLY (wrong
 int dreg_conv3d_igemm_variant(int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksz, int stride, int pad,
                               int transposed, int nrows, int has_ws, int has_addend, int dtype);
 int dreg_conv3d_wgrad_variant(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int rows, int nrows, int occ);
+void dreg_ngp_set_rgb_chunks(int on);                 /* 1 (default): shared-direction colour queries run the persistent 16-point-chunk kernel; 0: the 64-point-per-wave kernel */
 void dreg_conv_set_narrow_small(int on);              /* 1 (default): launches of < 224 128 x 128 tiles use 128 x 64 tiles (twice the workgroups) */
 
 #ifdef __cplusplus
