@@ -1420,9 +1420,10 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
                 mm();
                 if constexpr (FAST) {
 #pragma unroll
-                    for (int q = 0; q < 12; ++q) {            // two non-MFMA instructions per gap between MFMAs (a gap has ~3 idle issue slots)
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    for (int q = 0; q < 14; ++q) {            // ONE non-MFMA instruction per gap between MFMAs (two per gap stretched the
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA cadence from 16 to ~20 cycles: tools/wgrad_phase_probe.py)
                         __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
                     }
                 }

@@ -165,3 +165,22 @@ def test_bench_refuses_more_ranks_than_gpus():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, cwd=root,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "must agree" in (out.stderr + out.stdout)
+
+
+def test_profiler_labels_come_from_the_librarys_dispatch_rules():
+    """bench.py's roofline labels must name the LAUNCHED template instantiation (one rocprofv3 row): they are produced by
+    dreg_conv3d_igemm_variant / dreg_conv3d_wgrad_variant, the library's own dispatch rules (host-only calls: no GPU needed)."""
+    from dreg_nerf_amd import lib as L, ops
+    lib = L.load()
+    name = lambda *a: ops.igemm_kernel_name(lib, *a)
+    # (B, Di, Hi, Wi, cin, Do, Ho, Wo, cout, k, stride, pad, transposed, nrows, has_ws, has_addend, dtype, out_f32)
+    assert name(8, 64, 64, 64, 256, 64, 64, 64, 256, 3, 1, 1, 0, 0, 1, False, L.DT_BF16, False) == "conv_igemm_glds_kernel<bf16,256,256,0,1>"
+    assert name(8, 32, 32, 32, 64, 32, 32, 32, 64, 3, 1, 1, 0, 0, 1, False, L.DT_BF16, False) == "conv_igemm_glds_kernel<bf16,128,64,0,0>"       # 2,048 tiles: four-wave tile
+    assert name(8, 16, 16, 16, 128, 16, 16, 16, 128, 3, 1, 1, 0, 0, 1, False, L.DT_BF16, False) == "conv_igemm_glds_kernel<bf16,128,128,0,1>"  # 256 tiles: anti-phase form
+    sk = name(8, 8, 8, 8, 256, 8, 8, 8, 256, 3, 1, 1, 0, 0, 1, False, L.DT_BF16, False)                                                       # layer3: split-K, two launches
+    assert sk.startswith("conv_igemm_glds_kernel<f32,128,128,0,") and sk.endswith("+splitk_reduce")
+    assert name(8, 64, 64, 64, 256, 64, 64, 64, 256, 3, 1, 1, 0, 90000, 0, False, L.DT_BF16, False) == "conv_igemm_glds_kernel<bf16,256,256,0,1>"   # row list
+    assert name(8, 128, 128, 128, 8, 64, 64, 64, 64, 5, 2, 2, 0, 0, 1, False, L.DT_BF16, False) == "conv_igemm_kernel<bf16,bf16,64>"            # the stem: register-staged
+    assert lib.dreg_conv3d_wgrad_variant(8, 64, 64, 64, 256, 256, 3, 0, 0, 0) == 256256
+    assert lib.dreg_conv3d_wgrad_variant(8, 64, 64, 64, 64, 256, 3, 0, 0, 0) == 256256      # 27 x 64 columns: ragged last tile of the 256-wide form
+    assert lib.dreg_conv3d_wgrad_variant(8, 16, 16, 16, 128, 128, 3, 0, 0, 0) == 128128
