@@ -1388,14 +1388,13 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
                 }
             };
             stamp(-1);
-            auto unit = [&](int u, int slot, bool steady) {
+            auto unit = [&](int u, int slot) {
                 // ---- load half: fragment reads of unit u, then unit u + 3 into the ring slot of unit u - 1 (both groups have read it)
                 rd(slot);
                 if constexpr (FAST && ROWS) list_read();    // rows of unit u + 4: back with the fragments, consumed in the MFMA half
                 stamp(0);
                 // this wave's pieces of unit u + 1 must have landed before the barrier that closes this phase: all but the two youngest
                 // units in flight (steady state: one compare), fewer at the end of the split
-                (void)steady;
                 if (u + 3 < nk) {
                     request(u + 3);
                     stamp(1);
@@ -1411,7 +1410,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
                 __builtin_amdgcn_s_barrier();
                 stamp(3);
                 // ---- MFMA half
-                if (!(rows_fast & 2)) __builtin_amdgcn_s_setprio(1);   // (rows_fast bit 1: experiment, no priority raise)
+                __builtin_amdgcn_s_setprio(1);               // measured against no raise: 1.40 vs 1.35 PFLOP/s (and 1.30 vs 0.86 on the 64 -> 256 layer)
                 // offsets of unit u + 4 (scalar cursor + ~12 VALU), scheduled among the MFMAs: the MFMA half is paced by the matrix pipe and
                 // has idle issue slots, the load half is bound by its instruction count (the same scalar work at the end of the load
                 // half measured 1.11 instead of 1.20 PFLOP/s)
@@ -1435,17 +1434,17 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
             };
             if constexpr (FAST) {
                 for (int u = 0; u < nk; u += 4) {
-                    unit(u, 0, false);
-                    if (u + 1 < nk) unit(u + 1, 1, false);
+                    unit(u, 0);
+                    if (u + 1 < nk) unit(u + 1, 1);
 #pragma unroll
                     for (int k = 0; k < TM + TN; ++k) fa[k] += 2u * STAGE;
-                    if (u + 2 < nk) unit(u + 2, 2, false);
-                    if (u + 3 < nk) unit(u + 3, 3, false);
+                    if (u + 2 < nk) unit(u + 2, 2);
+                    if (u + 3 < nk) unit(u + 3, 3);
 #pragma unroll
                     for (int k = 0; k < TM + TN; ++k) fa[k] -= 2u * STAGE;
                 }
             } else {
-                for (int u = 0; u < nk; ++u) unit(u, u & 3, false);
+                for (int u = 0; u < nk; ++u) unit(u, u & 3);
             }
             if (!grp) __builtin_amdgcn_s_barrier();
             if constexpr (STAMP) {
@@ -2401,7 +2400,7 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
                                      (g.M % 32u) == 0 && (vps % 32u) == 0;
 #define WG_AP(A, APv) do { (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, false, 8, A, 32, 4, 0, APv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
                 hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, false, 8, A, 32, 4, 0, APv>), dim3(tiles256 * nsplit), dim3(512), (size_t)4 * 32 * 512 * 2, st, (const bf16_t*)gout, \
-                                   (const bf16_t*)in, part, g, (g.Kpad + 255) / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr, g_wgrad_pipe ? 2 : 0); } while (0)
+                                   (const bf16_t*)in, part, g, (g.Kpad + 255) / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr, 0); } while (0)
                 if (g_wgrad_ring == 8 || !fast_ok) WG_AP(0, 1);
                 else if (g_wgrad_ring == 3) WG_AP(0, 3);
                 else if (g_wgrad_ring == 4) WG_AP(0, 4);
