@@ -180,7 +180,15 @@ class GradSync:
             for s in self.extra_streams:
                 self._side.wait_stream(s)
             with torch.cuda.stream(self._side):
-                h = dist.all_reduce(g, op=dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM, async_op=True)
+                try:
+                    h = dist.all_reduce(g, op=dist.ReduceOp.AVG if self._use_avg else dist.ReduceOp.SUM, async_op=True)
+                except RuntimeError:
+                    # a collective library without ReduceOp.AVG: only acceptable on the step's FIRST bucket (then every bucket of
+                    # the step is summed and finish() divides once); later it would mix averaged and summed buckets
+                    if not self._use_avg or len(self.launched) != 1:
+                        raise
+                    self._use_avg = False
+                    h = dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True)
             g.record_stream(self._side)
         else:
             h = dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True)
