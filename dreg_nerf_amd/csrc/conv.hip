@@ -2347,13 +2347,18 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
 
             (void)ldsr;
         }
-        if (rows256 && g_wgrad_ring == 3 && ksz <= 3 && (size_t)4 * 32 * 512 * 2 + ((size_t)vps + 5 * 32) * 8 <= (size_t)160 * 1024) {
-            // anti-phase wave groups on the row list ((row, border flags) pairs in LDS; lean load half as in the dense form)
-            const int tiles256 = (Cout / 256) * (g.Kpad / 256);
+        // anti-phase wave groups on the row list ((row, border flags) pairs in LDS; lean load half as in the dense form).  Also for
+        // lists of >= 16,384 rows (the 32^3 level of the active-set head: 28 k rows ran at 0.26 PFLOP/s on the four-wave tile) and for a K
+        // extent that is not a multiple of 256 (27 taps x 64 channels: ragged last column tile, as in the dense form)
+        const bool rows256_ap = rowlist && same_vol && g_rows_fast && g_wgrad_big == 3 && g_wgrad_ring == 3 && ksz <= 3 && Cout % 256 == 0 &&
+                                (g.Kpad % 256 == 0 || g.Kpad >= 1024) && nrows >= 16384 &&
+                                (size_t)4 * 32 * 512 * 2 + ((size_t)vps + 5 * 32) * 8 <= (size_t)160 * 1024;
+        if (rows256_ap) {
+            const int tiles256 = (Cout / 256) * ((g.Kpad + 255) / 256);
             const size_t l_ = (size_t)4 * 32 * 512 * 2 + ((size_t)vps + 5 * 32) * 8;
             (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<256, 256, true, 8, 0, 32, 4, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 256, true, 8, 0, 32, 4, 0, 3>), dim3(tiles256 * nsplit), dim3(512), l_, st, (const bf16_t*)gout,
-                               (const bf16_t*)in, part, g, g.Kpad / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr, 1);
+                               (const bf16_t*)in, part, g, (g.Kpad + 255) / 256, tiles256, nsplit, vps, (uint32_t)gbytes, (uint32_t)ibytes, rowlist, nrows, nullptr, 1);
         } else
         if (rows256) {
             const int tiles256 = (Cout / 256) * (g.Kpad / 256);
@@ -2498,6 +2503,11 @@ int dreg_conv3d_wgrad_variant(int B, int Do, int Ho, int Wo, int Cin, int Cout, 
     const int nsplit = dreg_conv3d_wgrad_splits(B, Do, Ho, Wo, Cin, Cout, ksz, 0);
     const long M = (long)B * Do * Ho * Wo;
     if (!rows && !occ && g_wgrad_big && Cout % 256 == 0 && (Kpad % 256 == 0 || (Kpad >= 1024 && g_wgrad_big == 3 && g_wgrad_ring >= 3 && !g_wgrad_pipe)) && (rows ? nrows : M) >= 65536) return g_wgrad_big == 1 ? 256128 : 256256;
+    if (rows && g_rows_fast && g_wgrad_big == 3 && g_wgrad_ring == 3 && ksz <= 3 && Cout % 256 == 0 && (Kpad % 256 == 0 || Kpad >= 1024) && nrows >= 16384) {   // anti-phase row-list form
+        uint32_t vps = (uint32_t)((nrows + nsplit - 1) / nsplit);
+        vps = ((vps + 63) / 64) * 64;
+        if ((size_t)4 * 32 * 512 * 2 + ((size_t)vps + 5 * 32) * 8 <= (size_t)160 * 1024) return 256256;
+    }
     if (rows && g_rows_fast && g_wgrad_big == 3 && ksz == 3 && Cout % 256 == 0 && Kpad % 256 == 0 && nrows >= 65536) {   // stride 1, same-size volume assumed
         uint32_t vps = (uint32_t)((nrows + nsplit - 1) / nsplit);
         vps = ((vps + 63) / 64) * 64;

@@ -180,8 +180,8 @@ class TrunkExecutor:
             lo, li = (o[14], o[15]) if rows else (-1, -1)
             out[(i, 0)] = (fname, f"fwd{rows} B{B} {x[1]}x{x[2]}x{x[3]}x{x[4]}->{y[1]}x{y[2]}x{y[3]}x{cout} k{k}s{s}", fl, lo, per_row)
             out[(i, 1)] = (dname, f"dgrad{rows} B{B} {y[1]}x{y[2]}x{y[3]}x{cout}->{x[1]}x{x[2]}x{x[3]}x{cin} k{k}s{s}", fl, li, per_row)
-            var = self.lib.dreg_conv3d_wgrad_variant(B, y[1], y[2], y[3], x[4], cout, k, int(bool(rows)), 0, int(o[1] == 0))
-            wname = "conv_wgrad_glds_kernel<256,256,false,8>" if var == 256256 else "conv_wgrad_glds_kernel<256,128,false,4>" if var == 256128 else \
+            var = self.lib.dreg_conv3d_wgrad_variant(B, y[1], y[2], y[3], x[4], cout, k, int(bool(rows)), (1 << 17) if rows else 0, int(o[1] == 0))
+            wname = f"conv_wgrad_glds_kernel<256,256,{'true' if rows else 'false'},8>" if var == 256256 else "conv_wgrad_glds_kernel<256,128,false,4>" if var == 256128 else \
                 f"conv_wgrad_glds_kernel<{var // 1000},{var % 1000},{'true' if rows else 'false'},4>"     # the template arguments rocprofv3 prints
             out[(i, 2)] = (wname, f"wgrad{rows} B{B} {x[1]}x{x[2]}x{x[3]}x{x[4]} g{y[1]}x{y[2]}x{y[3]}x{cout} k{k}s{s}", fl, lo, per_row)
         out[(-1, 3)] = ("wgrad_reduce_batched_kernel", "split sums of a backward range -> torch-layout gradients", 0.0, -1, 0.0)
