@@ -1544,6 +1544,14 @@ __device__ __forceinline__ void wgrad_reduce_block(const WgradReduceDesc& d, int
 {
     const int t = threadIdx.x;
     const size_t slab = (size_t)d.Cout * d.Kpad;
+    // accumulate bit 1: the slices actually written are counted behind them (row-list launches: wgrad_row_splits); the partition of the
+    // work below follows the table's nsplit, the sums the written count
+    int nwritten = d.nsplit;
+    if (d.accumulate & 2) {
+        const int e = *reinterpret_cast<const int*>(d.part + (size_t)d.nsplit * slab);
+        nwritten = e < 1 ? 1 : (e < d.nsplit ? e : d.nsplit);
+    }
+    const bool accum = (d.accumulate & 1) != 0;
     if (d.ntaps == 1) {
         const int epb = wr_epb(d.nsplit), KG = 2048 / epb, EL = 256 / KG, g = t / EL, l = t - g * EL;
         const size_t total = (size_t)d.Cout * d.Cin_real;
@@ -1557,11 +1565,11 @@ __device__ __forceinline__ void wgrad_reduce_block(const WgradReduceDesc& d, int
                 const float* src = d.part + (size_t)co * d.Kpad + ci;
                 if (vec) {
 #pragma unroll 4
-                    for (int k = g; k < d.nsplit; k += KG) {
+                    for (int k = g; k < nwritten; k += KG) {
                         const float4 v = *reinterpret_cast<const float4*>(src + (size_t)k * slab);
                         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
                     }
-                } else a.x = wr_sum(src, slab, g, KG, d.nsplit);
+                } else a.x = wr_sum(src, slab, g, KG, nwritten);
             }
             if (KG > 1) {
                 __syncthreads();
@@ -1575,9 +1583,9 @@ __device__ __forceinline__ void wgrad_reduce_block(const WgradReduceDesc& d, int
             if (g == 0 && i < total) {
                 if (vec) {
                     float4* o = reinterpret_cast<float4*>(d.dw + i);
-                    if (d.accumulate) { const float4 q = *o; a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; }
+                    if (accum) { const float4 q = *o; a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w; }
                     *o = a;
-                } else d.dw[i] = d.accumulate ? d.dw[i] + a.x : a.x;
+                } else d.dw[i] = accum ? d.dw[i] + a.x : a.x;
             }
         }
         return;
@@ -1594,14 +1602,14 @@ __device__ __forceinline__ void wgrad_reduce_block(const WgradReduceDesc& d, int
     const float* src = d.part + (size_t)co * d.Kpad + ci0;
     for (int e = l; e < ne; e += EL) {
         const int tap = e >> sh, cl = e & (chp - 1);
-        if (cl < nci) stage[g * no + cl * d.ntaps + tap] = wr_sum(src + (size_t)tap * d.Cin + cl, slab, g, KG, d.nsplit);   // lanes walk cl: stride ntaps (odd)
+        if (cl < nci) stage[g * no + cl * d.ntaps + tap] = wr_sum(src + (size_t)tap * d.Cin + cl, slab, g, KG, nwritten);   // lanes walk cl: stride ntaps (odd)
     }
     __syncthreads();
     float* o = d.dw + ((size_t)co * d.Cin_real + ci0) * d.ntaps;
     for (int j = t; j < no; j += 256) {
         float a = stage[j];
         for (int q = 1; q < KG; ++q) a += stage[q * no + j];
-        o[j] = d.accumulate ? o[j] + a : a;
+        o[j] = accum ? o[j] + a : a;
     }
 }
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceDesc d)
@@ -2280,8 +2288,43 @@ size_t dreg_conv3d_wgrad_workspace_bytes(int B, int Do, int Ho, int Wo, int Cin,
     const int es = dtype == 0 ? 2 : 4;
     const int bke = 128 / es;
     const int Kpad = ((ksz * ksz * ksz * Cin + bke - 1) / bke) * bke;
-    return (size_t)dreg_conv3d_wgrad_splits(B, Do, Ho, Wo, Cin, Cout, ksz, dtype) * Cout * Kpad * sizeof(float);
+    // + 256: one int behind the slices, the number of slices a row-list launch actually wrote (see wgrad_row_splits)
+    return (size_t)dreg_conv3d_wgrad_splits(B, Do, Ho, Wo, Cin, Cout, ksz, dtype) * Cout * Kpad * sizeof(float) + 256;
 }
+// Voxel splits of a ROW-LIST weight gradient: dreg_conv3d_wgrad_splits sizes the split count (and the workspace) for the dense volume,
+// but an active set holds 4 - 15 % of it — 56 splits of a 28 k-row list are 500 rows each, 1,512 workgroups that spend their life in
+// the prologue and the 256 KB partial tile they write (0.3 PFLOP/s).  The launch uses the first s <= smax slices; the deferred sum reads
+// s from the int behind the slices (descriptor flag, WgradReduceDesc::accumulate bit 1).
+//  * 8-wave 256 x 256 tile (one workgroup per CU; its slice of the (row, flags) list sits in LDS: <= 3,904 rows per split): among the
+//    counts with >= 2,048 rows per split the one whose last round of 256 workgroups is fullest (ties: fewer splits = fewer partials);
+//  * the four-wave tiles: at least 1,024 (3^3) / 512 (1^3) rows per split, as in the dense rule.
+static bool g_row_splits = true;      // tuning (include/dreg_nerf_tuning.h): 0 = row lists use the dense volume's split count
+static int wgrad_row_splits(int Cout, int Kpad, int ksz, uint32_t nrows, int smax, bool tile256)
+{
+    if (smax <= 1 || !g_row_splits) return smax;
+    if (tile256) {
+        const long t256 = (long)(Cout / 256) * ((Kpad + 255) / 256);
+        const long vmax = (((long)160 * 1024 - (long)4 * 32 * 512 * 2 - 5 * 32 * 8) / 8) / 64 * 64;
+        long cmin = ((long)nrows + vmax - 1) / vmax;
+        if (cmin < 1) cmin = 1;
+        if (cmin >= smax) return smax;
+        long cmax = (long)nrows / 2048;
+        if (cmax > smax) cmax = smax;
+        if (cmax < cmin) cmax = cmin;
+        long best = cmin;
+        double best_eff = -1.0;
+        for (long c = cmin; c <= cmax; ++c) {
+            const double eff = (double)(t256 * c) / 256.0 / (double)((t256 * c + 255) / 256);
+            if (eff > best_eff + 1e-9) { best_eff = eff; best = c; }
+        }
+        return (int)best;
+    }
+    const long vmin = ksz == 1 ? 512 : 1024;
+    long s = ((long)nrows + vmin - 1) / vmin;
+    if (s < 1) s = 1;
+    return (int)(s < smax ? s : smax);
+}
+void dreg_conv_set_row_splits(int on) { g_row_splits = on != 0; }
 
 // dW[Cout][Cin_real][ntaps] (torch layout, fp32) (+)= sum_m gout[m][:]^T x gathered in[m][tap][:]
 // gout: [B,Do,Ho,Wo,Cout], in: [B,Di,Hi,Wi,Cin] (same dtype).  use_tr: 1 = LDS transpose reads (bf16 only).
@@ -2299,7 +2342,10 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
     hipStream_t st = (hipStream_t)stream;
     const uint32_t nrows = rowlist ? nrows_list : g.M;
     if (rowlist && !(dtype == 0 && use_tr && g_use_glds)) return DREG_EINVAL;
-    const int nsplit = dreg_conv3d_wgrad_splits(B, Do, Ho, Wo, Cin, Cout, ksz, dtype);
+    const int smax = dreg_conv3d_wgrad_splits(B, Do, Ho, Wo, Cin, Cout, ksz, dtype);
+    const bool row_tile256 = rowlist && g.sn == 1 && g.sd == 1 && g.dsign == 1 && Di == Do && Hi == Ho && Wi == Wo && Do < 1024 && Ho < 1024 && Wo < 1024 &&
+                             g_rows_fast && g_wgrad_big == 3 && g_wgrad_ring == 3 && ksz <= 3 && Cout % 256 == 0 && (g.Kpad % 256 == 0 || g.Kpad >= 1024) && nrows >= 16384;
+    const int nsplit = rowlist ? wgrad_row_splits(Cout, g.Kpad, ksz, nrows, smax, row_tile256) : smax;
     uint32_t vps = (uint32_t)((nrows + nsplit - 1) / nsplit);
     vps = ((vps + 63) / 64) * 64;
     if (vps == 0) vps = 64;
@@ -2430,7 +2476,11 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
 #undef WG_DISPATCH
 #undef WG_LAUNCH
     DREG_LAUNCH_CHECK();
-    if (defer_reduce) return DREG_OK;    // the caller sums the splits later (dreg_wgrad_reduce_batched)
+    if (defer_reduce) {                  // the caller sums the splits later (dreg_wgrad_reduce_batched)
+        // row lists: how many slices were written, behind the slices (a 4-byte fill on the same stream)
+        if (rowlist && hipMemsetD32Async((hipDeviceptr_t)(part + (size_t)smax * Cout * g.Kpad), nsplit, 1, st) != hipSuccess) return DREG_ELAUNCH;
+        return DREG_OK;
+    }
     if (g.ntaps > 1 && (size_t)g.ntaps * (Cin < 64 ? Cin : 64) > (size_t)WR_STAGE) return DREG_EINVAL;
     WgradReduceDesc rd{part, dw, nsplit, Cout, g.Kpad, g.ntaps, Cin, Cin_real, accumulate, 0};
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_blocks(Cout, Cin_real, g.ntaps, nsplit)), dim3(256), 0, st, rd);
@@ -2485,6 +2535,8 @@ int dreg_conv3d_wgrad_partials(const void* gout, const void* in, void* workspace
 }
 // Workgroups the batched reduce spends on one layer: descriptor i starts at block0 = sum of the counts of the descriptors before it.
 int dreg_wgrad_reduce_blocks(int Cout, int Cin_real, int ksz, int nsplit) { return wgrad_reduce_blocks(Cout, Cin_real, ksz * ksz * ksz, nsplit); }
+// `accumulate`: bit 0 = add to dw (else overwrite); bit 1 = the workspace was written by a ROW-LIST launch of dreg_conv3d_wgrad_partials, which
+// uses nwritten <= nsplit slices and stores nwritten as an int behind the nsplit-th slice: the sum covers those only.
 // descs_dev: n descriptors {part, dw, nsplit, Cout, Kpad, ntaps, Cin, Cin_real, accumulate, block0} (48 bytes each, device memory,
 // ascending block0); blocks [block_base, block_base + nblocks) are launched, so a sub-range of a long table can be reduced on its own.
 int dreg_wgrad_reduce_batched(const void* descs_dev, int n, int block_base, int nblocks, void* stream)
@@ -2500,7 +2552,9 @@ int dreg_wgrad_reduce_batched(const void* descs_dev, int n, int block_base, int 
 int dreg_conv3d_wgrad_variant(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int rows, int nrows, int occ)
 {
     const int Kpad = dreg_conv3d_kpad(ksz, Cin, 0);
-    const int nsplit = dreg_conv3d_wgrad_splits(B, Do, Ho, Wo, Cin, Cout, ksz, 0);
+    const int smax = dreg_conv3d_wgrad_splits(B, Do, Ho, Wo, Cin, Cout, ksz, 0);
+    const int nsplit = rows ? wgrad_row_splits(Cout, Kpad, ksz, (uint32_t)nrows, smax, g_rows_fast && g_wgrad_big == 3 && g_wgrad_ring == 3 && ksz <= 3 && Cout % 256 == 0 &&
+                                               (Kpad % 256 == 0 || Kpad >= 1024) && nrows >= 16384 && Do < 1024 && Ho < 1024 && Wo < 1024) : smax;
     const long M = (long)B * Do * Ho * Wo;
     if (!rows && !occ && g_wgrad_big && Cout % 256 == 0 && (Kpad % 256 == 0 || (Kpad >= 1024 && g_wgrad_big == 3 && g_wgrad_ring >= 3 && !g_wgrad_pipe)) && (rows ? nrows : M) >= 65536) return g_wgrad_big == 1 ? 256128 : 256256;
     if (rows && g_rows_fast && g_wgrad_big == 3 && g_wgrad_ring == 3 && ksz <= 3 && Cout % 256 == 0 && (Kpad % 256 == 0 || Kpad >= 1024) && nrows >= 16384) {   // anti-phase row-list form

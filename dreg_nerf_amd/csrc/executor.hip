@@ -229,7 +229,8 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
                     ReduceRec r{};
                     r.dw = w.grad; r.nsplit = dreg_conv3d_wgrad_splits(x.B, y.D, y.H, y.W, x.C, w.d0, o.ksz, 0);
                     r.Cout = w.d0; r.Kpad = dreg_conv3d_kpad(o.ksz, x.C, 0); r.ntaps = o.ksz * o.ksz * o.ksz; r.Cin = x.C; r.Cin_real = w.d1;
-                    r.accumulate = 1; r.block0 = e->reduce_blocks;
+                    r.accumulate = o.kind == OP_CONV_ROWS ? 3 : 1;     // row-list launches write fewer slices than the dense rule sizes (bit 1: count behind the slices)
+                    r.block0 = e->reduce_blocks;
                     e->reduce_blocks += dreg_wgrad_reduce_blocks(w.d0, w.d1, o.ksz, r.nsplit);
                     o.rd = (int)e->reduce.size();
                     e->reduce.push_back(r);

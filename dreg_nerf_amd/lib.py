@@ -51,6 +51,7 @@ SIGNATURES = {
     "dreg_conv_wgrad_probe_read": (I, [P]),
     "dreg_conv_set_wgrad_ring": (None, [I]),
     "dreg_conv_set_wgrad_rows_fast": (None, [I]),
+    "dreg_conv_set_row_splits": (None, [I]),
     "dreg_conv_set_glds_stages": (None, [I]),
     "dreg_conv_set_wgrad_target_blocks": (None, [I]),
     "dreg_conv3d_wgrad_splits": (I, [I] * 8),

@@ -123,7 +123,10 @@ int dreg_conv3d_wgrad_rows(const void* gout, const void* in, float* dw, void* wo
  * _rows / _occ forms, both may be null), and dreg_wgrad_reduce_batched sums the partials of many layers into their torch-layout
  * gradients [Cout][Cin_real][k^3] with ONE launch.  descs_dev: n records of 48 bytes in device memory
  *   { const float* part; float* dw; int nsplit, Cout, Kpad, ntaps, Cin, Cin_real, accumulate, block0; }
- * with block0 = sum of dreg_wgrad_reduce_blocks(...) of the records before it; workgroups [block_base, block_base + nblocks) run. */
+ * with block0 = sum of dreg_wgrad_reduce_blocks(...) of the records before it; workgroups [block_base, block_base + nblocks) run.
+ * nsplit is always dreg_conv3d_wgrad_splits(...) (the dense volume's count, which also sizes the workspace).  accumulate: bit 0 = add
+ * to dw; bit 1 MUST be set for a workspace written with a row list: such a launch fills only as many slices as its row count is
+ * worth and stores that number (int) behind the nsplit-th slice, where the sum reads it. */
 int dreg_conv3d_wgrad_partials(const void* gout, const void* in, void* workspace, size_t workspace_bytes, const int* rows, int nrows,
                                int B, int Di, int Hi, int Wi, int Cin, int Cin_real, int Do, int Ho, int Wo, int Cout,
                                int ksz, int stride, int pad, const uint8_t* rowocc, void* stream);

@@ -19,6 +19,7 @@ int dreg_conv_get_glds(void);
 /* tuning / test knob: force the number of voxel splits of the weight-gradient kernels (0 = automatic) */
 void dreg_conv_set_wgrad_splits(int splits);
 void dreg_conv_set_wgrad_rows_fast(int enable);      /* 1 (default): row-list weight gradients keep packed voxel coordinates in LDS (no decode per load) and take the 8-wave 256 x 256 tile for 256 -> 256 layers */
+void dreg_conv_set_row_splits(int on);               /* 1 (default): a row-list weight gradient splits its rows by the LIST's length (256 x 256 tile: fullest last round of 256 workgroups at >= 2,048 rows per split); 0: by the dense volume's rule */
 void dreg_conv_set_wgrad_ring(int mode);             /* dense 8-wave weight-gradient tile: 3 (default) anti-phase wave groups over a ring of four 32-voxel units (lean load half for stride-1 same-volume layers, general loop otherwise), 8 the general anti-phase loop, 0 lockstep over two 64-voxel stages, 1 / 2 lockstep over four / five 32-voxel stages (measured no gain), 4 = 3 with s_memtime stamps, 5..7 stamped ablations (wrong results) */
 int dreg_conv_wgrad_probe_read(unsigned long long* out8); /* ring mode 4 (measurement only): { issue, fragment reads, wait for loads, barrier, MFMAs, barrier cycles; units x waves; waves } since the last read */
 void dreg_conv_set_wgrad_pipe(int enable);           /* 1: the dense 8-wave weight-gradient tile reads the fragments of the next MFMA group while the current group runs (default 0: measured no gain) */

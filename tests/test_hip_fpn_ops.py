@@ -127,6 +127,49 @@ def test_deferred_wgrad_batched_reduce_is_bit_identical(shape):
     assert torch.equal(b2, ops.conv_wgrad(xo, xo, (64, 64, 1, 1, 1), 64, 1, 1, 0))
 
 
+@pytest.mark.parametrize("cin,cout,D,fill", [(256, 256, 32, 0.12), (64, 256, 32, 0.3), (128, 128, 16, 0.3)])
+def test_deferred_row_list_weight_gradient_sums_only_the_written_slices(cin, cout, D, fill):
+    """A row-list launch of dreg_conv3d_wgrad_partials writes as many slices as its ROW COUNT is worth (fewer than the dense rule's
+    dreg_conv3d_wgrad_splits, which sizes the workspace and the descriptor) and stores that count behind the slices; a descriptor
+    with accumulate bit 1 makes dreg_wgrad_reduce_batched sum those only.  The workspace is filled with NaN first: a sum that
+    touched an unwritten slice would show.  Against the immediate form (dreg_conv3d_wgrad_rows: same splits, its own reduce)."""
+    import numpy as np
+    from dreg_nerf_amd import lib as L
+    lib = L.load()
+    DEV = _dev()
+    B = 8
+    g = torch.Generator().manual_seed(cin + D + 5)
+    keep = torch.rand(B * D ** 3, generator=g) < fill
+    keep[:3] = True; keep[-2:] = True
+    rows = keep.nonzero().flatten().int().to(DEV)
+    n = rows.shape[0]
+    x = torch.randn(B, D, D, D, cin, generator=g).to(DEV).bfloat16()
+    gy = torch.randn(B, D, D, D, cout, generator=g).to(DEV).bfloat16()
+    nbytes = lib.dreg_conv3d_wgrad_workspace_bytes(B, D, D, D, cin, cout, 3, 0)
+    smax = lib.dreg_conv3d_wgrad_splits(B, D, D, D, cin, cout, 3, 0)
+    kpad = lib.dreg_conv3d_kpad(3, cin, 0)
+    assert nbytes >= smax * cout * kpad * 4 + 4
+    ws = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device=DEV)
+    base = torch.randn(cout, cin, 3, 3, 3, generator=g).to(DEV)
+    want = base.clone()
+    ws2 = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    L.check(lib.dreg_conv3d_wgrad_rows(L.ptr(gy), L.ptr(x), L.ptr(want), L.ptr(ws2), nbytes, L.ptr(rows), n, B, D, D, D, cin, cin, D, D, D, cout, 3, 1, 1, 1,
+                                       L.stream()), "dreg_conv3d_wgrad_rows")
+    L.check(lib.dreg_conv3d_wgrad_partials(L.ptr(gy), L.ptr(x), L.ptr(ws), nbytes, L.ptr(rows), n, B, D, D, D, cin, cin, D, D, D, cout, 3, 1, 1, None,
+                                           L.stream()), "dreg_conv3d_wgrad_partials")
+    written = int(ws.view(torch.int32)[smax * cout * kpad].item())
+    assert 1 <= written < smax                              # the list is a fraction of the volume: fewer slices than the dense rule
+    assert torch.isnan(ws[written * cout * kpad:smax * cout * kpad]).all()    # the others were not touched
+    got = base.clone()
+    rec = np.zeros(1, dtype=ops._REDUCE_DT)
+    rec[0] = (ws.data_ptr(), got.data_ptr(), smax, cout, kpad, 27, cin, cin, 3, 0)
+    table = torch.from_numpy(rec.view(np.uint8)).to(DEV)
+    L.check(lib.dreg_wgrad_reduce_batched(L.ptr(table), 1, 0, lib.dreg_wgrad_reduce_blocks(cout, cin, 3, smax), L.stream()), "dreg_wgrad_reduce_batched")
+    assert torch.isfinite(got).all()
+    # the same slices summed in a differently grouped order (the batched sum partitions its work by the table's split count)
+    assert float((got - want).abs().max()) <= 1e-5 * float((want - base).abs().max())
+
+
 @pytest.mark.parametrize("out_f32", [False, True])
 def test_narrow_tiles_for_small_launches_are_bit_identical(out_f32):
     """Launches with fewer 128 x 128 tiles than CUs run 128 x 64 tiles (include/dreg_nerf_tuning.h: dreg_conv_set_narrow_small): every
@@ -279,19 +322,27 @@ def test_row_list_weight_gradient_fast_path_is_bit_identical(cin, cout, D):
     nbytes = lib.dreg_conv3d_wgrad_workspace_bytes(B, D, D, D, cin, cout, 3, 0)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     out = []
+
+    def run():
+        dw = torch.empty(cout, cin, 3, 3, 3, dtype=torch.float32, device=DEV)
+        L.check(lib.dreg_conv3d_wgrad_rows(L.ptr(gy), L.ptr(x), L.ptr(dw), L.ptr(ws), nbytes, L.ptr(rows), n, B, D, D, D, cin, cin, D, D, D, cout, 3, 1, 1, 0,
+                                           L.stream()), "dreg_conv3d_wgrad_rows")
+        return dw
+
     try:
+        lib.dreg_conv_set_row_splits(0)        # the same split count for both loops (the list-length rule depends on the tile)
         for fast in (0, 1):
             lib.dreg_conv_set_wgrad_rows_fast(fast)
-            dw = torch.empty(cout, cin, 3, 3, 3, dtype=torch.float32, device=DEV)
-            L.check(lib.dreg_conv3d_wgrad_rows(L.ptr(gy), L.ptr(x), L.ptr(dw), L.ptr(ws), nbytes, L.ptr(rows), n, B, D, D, D, cin, cin, D, D, D, cout, 3, 1, 1, 0,
-                                               L.stream()), "dreg_conv3d_wgrad_rows")
-            out.append(dw)
+            out.append(run())
     finally:
         lib.dreg_conv_set_wgrad_rows_fast(1)
+        lib.dreg_conv_set_row_splits(1)
     if D == 48:
         assert lib.dreg_conv3d_wgrad_variant(B, D, D, D, cin, cout, 3, 1, n, 0) == 256256
     assert torch.isfinite(out[1]).all() and out[1].abs().max() > 0
     assert torch.equal(out[0], out[1])
+    out[1] = run()                             # default: splits sized by the list's length (fewer, longer splits)
+    assert torch.equal(out[1], run())
     # and against the dense kernel on a gradient that is zero off the rows
     gz = torch.zeros_like(gy).view(-1, cout)
     gz[rows.long()] = gy.view(-1, cout)[rows.long()]
