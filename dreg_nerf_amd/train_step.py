@@ -66,6 +66,9 @@ class TrainStep:
         self.persistent_grad_buffers = True     # dense gradient buffers of the active-set head kept zero by clearing rows (ops.TrilinearGatherFn)
         self.overlap_param_grads = bool(int(os.environ.get("DREG_PG_STREAM", "1"))) and not bool(int(os.environ.get("DREG_SERIAL_STREAMS", "0")))
         self._pg_stream = None
+        # test hook: run the bucketed gradient exchange on a process group of ONE rank too (the only way RCCL itself — ReduceOp.AVG on
+        # views of the flat buffer, its streams and events — can be exercised on a one-GPU box: tests/test_hip_ddp_gpu.py)
+        self.force_grad_sync = bool(int(os.environ.get("DREG_FORCE_GRAD_SYNC", "0")))
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self._sync = None
         self.last_losses = None
@@ -114,7 +117,7 @@ class TrainStep:
             total = total / len(batch)
         dev = next(self.model.parameters()).device
         sync = None
-        if self.world > 1:
+        if self.world > 1 or self.force_grad_sync:
             # gradient averaging overlapped with backward: buckets of the flat gradient buffer are all-reduced as soon as backward
             # has produced them (optim.GradSync; the trunk executor reports progress between its segments)
             if self._sync is None:

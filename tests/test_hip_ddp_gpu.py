@@ -87,6 +87,42 @@ def test_two_ranks_average_equals_one_rank_with_both_pairs():
     assert float((single.double() - g0.double()).norm()) < 2e-6 * float(single.double().norm())
 
 
+def _rccl_worker(port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DREG_FORCE_GRAD_SYNC="1")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    g, ts = _grads_of_one_step([21], dev)
+    sync = ts._sync
+    assert sync is not None and sync._use_avg and len(sync.launched) == len(sync.buckets) > 1
+    ts.step(_batch([23], dev))                       # a second step through the same communicator / streams
+    torch.cuda.synchronize()
+    torch.save({"g": g, "p": ts.optimizer.flat_p[:ts.optimizer.n_active].cpu()}, os.path.join(outdir, "rccl.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_group_of_one_rank_carries_the_gradient_exchange():
+    """RCCL itself (backend 'nccl') on this one-GPU box: a process group of ONE rank, the bucketed exchange forced on
+    (DREG_FORCE_GRAD_SYNC): ReduceOp.AVG on views of the flat gradient buffer, the collective's stream behind events of the main and
+    parameter-gradient streams, record_stream on the slices, barrier, teardown.  The average over one rank is the identity: gradients
+    and the parameters after two steps equal the run without any exchange, bit for bit."""
+    dev = torch.device("cuda", 0)
+    with tempfile.TemporaryDirectory() as td:
+        ctx = mp.get_context("spawn")
+        p = ctx.Process(target=_rccl_worker, args=(29100 + (os.getpid() % 400), td))
+        p.start()
+        p.join(timeout=600)
+        assert p.exitcode == 0
+        got = torch.load(os.path.join(td, "rccl.pt"))
+    single, ts = _grads_of_one_step([21], dev)
+    assert ts._sync is None
+    ts.step(_batch([23], dev))
+    torch.cuda.synchronize()
+    assert torch.equal(single, got["g"])
+    assert torch.equal(ts.optimizer.flat_p[:ts.optimizer.n_active].cpu(), got["p"])
+
+
 def test_bench_script_runs_with_two_ranks():
     """bench.py's multi-rank path (rank-0 broadcast of the weights, barrier + max-over-ranks timing, one JSON line from rank 0 with the
     whole-job rate) with two ranks on this box's one GPU over gloo (DREG_BENCH_BACKEND / DREG_BENCH_ONE_GPU test hooks)."""
