@@ -252,7 +252,7 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
     const bf16_t* __restrict__ in, const bf16_t* __restrict__ wt, TO* __restrict__ out,
     const float* __restrict__ bias, const TO* __restrict__ addend, ConvGeom g,
     int relu, int Da, int Ha, int Wa, int add_shift, int tilesN, uint32_t in_bytes, uint32_t wt_bytes,
-    const int* __restrict__ rowlist, uint32_t nrows, int ksplit, int nstage)
+    const int* __restrict__ rowlist, uint32_t nrows, int ksplit, int nstage, float* __restrict__ bn_part)
 {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     constexpr int NW = (BN == 256 || AP) ? 8 : 4, WAVES_N = NW / 2;      // waves: 2 (M) x WAVES_N (N), (BM/2) x (BN/WAVES_N) each
@@ -559,6 +559,21 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
     float* sC = reinterpret_cast<float*>(smem);
     constexpr int CPR = BN / 8;                    // 8-column chunks per row
     constexpr int NTHR = NW * 64;
+    // bn_part (bf16 output, dense rows; the BatchNorm behind this convolution): sums of the STORED (rounded) values and of their squares
+    // per 128-row chunk and channel, [chunk][Cout][2] — the layout of bn_partial_kernel's chunk sums with 128 rows per chunk, so the
+    // BatchNorm's statistics pass (one more read of this tensor) is not launched.  Which tile shape / wave count a launch gets depends
+    // on how many grids share it, and a grid's statistics must not: EVERY form adds a chunk's rows in the same order —
+    //     sum_{j = 0..15} ( (c[j] + c[j + 32]) + (c[j + 16] + c[j + 48]) ),   c[q] = x[q] + x[q + 64]
+    // A thread always works on the same 8 columns (NTHR % CPR == 0) and on rows NG apart (NG = 16, 32 or 64): it owns the 64 / NG
+    // classes q = its row group + i * NG, keeps one accumulator per class (static register indices: the row loop below is fully
+    // unrolled), combines its own classes as the bracketing above says, and the rest of the bracket is formed across threads in LDS.
+    constexpr int NG = NTHR / CPR, NCLS = 64 / NG, ITER = WMt / NG;
+    static_assert(NTHR % CPR == 0 && (NG == 16 || NG == 32 || NG == 64) && WMt % 64 == 0, "BatchNorm sums: row classes modulo 64");
+    float bs1[NCLS][8], bs2[NCLS][8];
+#pragma unroll
+    for (int i = 0; i < NCLS; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bs1[i][e] = 0.f; bs2[i][e] = 0.f; }
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();
@@ -575,7 +590,9 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
             }
         }
         __syncthreads();
-        for (int c = t; c < WMt * CPR; c += NTHR) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int c = t + it * NTHR;
             const int lrow = c / CPR, cc = (c - lrow * CPR) * 8;
             const int row = pass * WMt + lrow;
             if (m0 + row >= nrows) continue;
@@ -619,6 +636,48 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
 #pragma unroll
                 for (int e = 0; e < 4; ++e) w[e] = f2bf2(v[2 * e], v[2 * e + 1]);
                 *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+                if (bn_part) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo_ = __uint_as_float(w[e] << 16), hi_ = __uint_as_float(w[e] & 0xffff0000u);
+                        bs1[it % NCLS][2 * e] += lo_; bs2[it % NCLS][2 * e] += lo_ * lo_;
+                        bs1[it % NCLS][2 * e + 1] += hi_; bs2[it % NCLS][2 * e + 1] += hi_ * hi_;
+                    }
+                }
+            }
+        }
+        if constexpr (sizeof(TO) == 2) {
+            // a 128-row chunk is complete after both passes of a 128-row tile, after EACH pass (128 rows) of a 256-row tile
+            if (bn_part && (WMt == 128 || pass == 1)) {
+                float* red = reinterpret_cast<float*>(smem);            // [NG row groups][BN][2]
+                __syncthreads();
+                const int chunkc = t % CPR, grp = t / CPR;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float p1, p2;                                        // this thread's classes, combined as the fixed order says
+                    if constexpr (NCLS == 4) { p1 = (bs1[0][e] + bs1[2][e]) + (bs1[1][e] + bs1[3][e]); p2 = (bs2[0][e] + bs2[2][e]) + (bs2[1][e] + bs2[3][e]); }
+                    else if constexpr (NCLS == 2) { p1 = bs1[0][e] + bs1[1][e]; p2 = bs2[0][e] + bs2[1][e]; }
+                    else { p1 = bs1[0][e]; p2 = bs2[0][e]; }
+                    red[((grp * BN) + chunkc * 8 + e) * 2] = p1;
+                    red[((grp * BN) + chunkc * 8 + e) * 2 + 1] = p2;
+                }
+#pragma unroll
+                for (int i = 0; i < NCLS; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { bs1[i][e] = 0.f; bs2[i][e] = 0.f; }
+                __syncthreads();
+                const size_t chunk = WMt == 128 ? (size_t)2 * tile_m + pass : (size_t)tile_m;
+                for (int col = t; col < BN; col += NTHR) {
+                    float a = 0.f, b = 0.f;
+                    auto rd = [&](int q, int w) -> float { return red[(q * BN + col) * 2 + w]; };
+                    for (int jq = 0; jq < 16; ++jq) {
+                        if constexpr (NG == 16) { a += rd(jq, 0); b += rd(jq, 1); }
+                        else if constexpr (NG == 32) { a += rd(jq, 0) + rd(jq + 16, 0); b += rd(jq, 1) + rd(jq + 16, 1); }
+                        else { a += (rd(jq, 0) + rd(jq + 32, 0)) + (rd(jq + 16, 0) + rd(jq + 48, 0)); b += (rd(jq, 1) + rd(jq + 32, 1)) + (rd(jq + 16, 1) + rd(jq + 48, 1)); }
+                    }
+                    float* o = bn_part + (chunk * g.Cout + n0 + col) * 2;
+                    o[0] = a; o[1] = b;
+                }
             }
         }
     }
@@ -1944,7 +2003,7 @@ template <typename T, typename TO>
 static int launch_conv(const void* in, const void* wt, void* out, const float* bias, const void* addend,
                        const ConvGeom& g, int relu, int Da, int Ha, int Wa, int add_shift, hipStream_t st,
                        const int* rowlist = nullptr, uint32_t nrows_in = 0, float* ks_ws = nullptr, size_t ks_ws_bytes = 0,
-                       const uint8_t* rowocc = nullptr)
+                       const uint8_t* rowocc = nullptr, float* bn_part = nullptr)
 {
     // output-row occupancy is honoured by the register-staged kernel for plain forward gathers whose tiles are whole W-rows
     if (rowocc && (rowlist || bias || addend || relu || g.dsign != 1 || g.sd != 1 || g.Wo <= 0 || 128 % g.Wo != 0 || g.M % (uint32_t)g.Wo != 0)) rowocc = nullptr;
@@ -1962,25 +2021,25 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
                 (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<float, 128, 128, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128);
                 hipLaunchKernelGGL((conv_igemm_glds_kernel<float, 128, 128, 0, 1>), dim3(tm_ * (g.Cout / 128), ksplit), dim3(512), (size_t)4 * 256 * 128, st,
                                    (const bf16_t*)in, (const bf16_t*)wt, ks_ws, nullptr, nullptr, g, 0, 0, 0, 0, 0, g.Cout / 128,
-                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, nullptr, g.M, ksplit, 4);
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, nullptr, g.M, ksplit, 4, nullptr);
             } else if (g.Cout % 128 != 0 && g_igemm_ap && tm_ * (g.Cout / 64) * ksplit <= g_igemm_ap) {
                 (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<float, 128, 64, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 192 * 128);
                 hipLaunchKernelGGL((conv_igemm_glds_kernel<float, 128, 64, 0, 1>), dim3(tm_ * (g.Cout / 64), ksplit), dim3(512), (size_t)4 * 192 * 128, st,
                                    (const bf16_t*)in, (const bf16_t*)wt, ks_ws, nullptr, nullptr, g, 0, 0, 0, 0, 0, g.Cout / 64,
-                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, nullptr, g.M, ksplit, 4);
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, nullptr, g.M, ksplit, 4, nullptr);
             } else
             if (g.Cout % 128 == 0) {
                 const int ns = glds_stages(tm_ * (g.Cout / 128) * ksplit);
                 if (ns > 2) (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<float, 128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, ns * 256 * 128);
                 hipLaunchKernelGGL((conv_igemm_glds_kernel<float, 128, 128>), dim3(tm_ * (g.Cout / 128), ksplit), dim3(256), (size_t)ns * 256 * 128, st,
                                    (const bf16_t*)in, (const bf16_t*)wt, ks_ws, nullptr, nullptr, g, 0, 0, 0, 0, 0, g.Cout / 128,
-                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, nullptr, g.M, ksplit, ns);
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, nullptr, g.M, ksplit, ns, nullptr);
             } else {
                 const int ns = glds_stages(tm_ * (g.Cout / 64) * ksplit);
                 if (ns > 2) (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<float, 128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, ns * 192 * 128);
                 hipLaunchKernelGGL((conv_igemm_glds_kernel<float, 128, 64>), dim3(tm_ * (g.Cout / 64), ksplit), dim3(256), (size_t)ns * 192 * 128, st,
                                    (const bf16_t*)in, (const bf16_t*)wt, ks_ws, nullptr, nullptr, g, 0, 0, 0, 0, 0, g.Cout / 64,
-                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, nullptr, g.M, ksplit, ns);
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, nullptr, g.M, ksplit, ns, nullptr);
             }
             DREG_LAUNCH_CHECK();
             const size_t total8 = slice / 8;
@@ -1997,7 +2056,7 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
                 if (lds_ > 65536) (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<TO, BMv, BNv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
                 hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, BMv, BNv>), dim3(tm_ * tn_), dim3(NT), lds_, st, \
                                    (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tn_, \
-                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows, 1, ns_); } while (0)
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows, 1, ns_, bn_part); } while (0)
             const IgemmChoice ch = igemm_choose(g, nrows, rowlist != nullptr, false, addend != nullptr, 2);
             if (ch.bm == 256 && ch.ap) {
                 const int tm_ = (nrows + 255) / 256, tn_ = g.Cout / 256;
@@ -2005,7 +2064,7 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
                 (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<TO, 256, 256, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);
                 hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, 256, 256, 0, 1>), dim3(tm_ * tn_), dim3(512), lds_, st,
                                    (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tn_,
-                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows, 1, 4);
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows, 1, 4, bn_part);
             }
             else if (ch.bm == 256) GL_LAUNCH(256, 256, 512);
             else if (ch.bn == 256) GL_LAUNCH(128, 256, 512);
@@ -2015,7 +2074,7 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
                 const int tm_ = (nrows + 127) / 128, tn_ = g.Cout / 128;
                 hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, 128, 128, 1>), dim3(tm_ * tn_), dim3(256), (size_t)2 * 256 * 128, st,
                                    (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tn_,
-                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows, 1, 2);
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows, 1, 2, bn_part);
             }
 #define GL_LAUNCH_AP(BNv) do { \
                 const int tm_ = (nrows + 127) / 128, tn_ = g.Cout / BNv; \
@@ -2023,7 +2082,7 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
                 (void)hipFuncSetAttribute((const void*)conv_igemm_glds_kernel<TO, 128, BNv, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); \
                 hipLaunchKernelGGL((conv_igemm_glds_kernel<TO, 128, BNv, 0, 1>), dim3(tm_ * tn_), dim3(512), lds_, st, \
                                    (const bf16_t*)in, (const bf16_t*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tn_, \
-                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows, 1, 4); } while (0)
+                                   (uint32_t)in_bytes, (uint32_t)wt_bytes, rowlist, nrows, 1, 4, bn_part); } while (0)
             // launches that put at most one or two workgroups on a CU: the eight-wave anti-phase form of the same tile (bit-identical)
             else if (ch.kind == 0 && ch.ap && ch.bn == 128) GL_LAUNCH_AP(128);
             else if (ch.kind == 0 && ch.ap && ch.bn == 64) GL_LAUNCH_AP(64);
@@ -2102,6 +2161,33 @@ int dreg_conv3d_igemm_occ(const void* in, const void* wt_packed, void* out, cons
         return launch_conv<bf16_t, bf16_t>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st, nullptr, 0, (float*)workspace, workspace_bytes, rowocc);
     }
     return launch_conv<float, float>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_shift, st, nullptr, 0, nullptr, 0, rowocc);
+}
+// Forward bf16 convolution that also leaves the BatchNorm statistics of its OUTPUT behind: bn_partial [B][V / *rows_per_chunk][Cout][2]
+// fp32 = per-chunk (sum, sum of squares) of the stored bf16 values per grid and channel (V = Do*Ho*Wo), the input of
+// dreg_bn3d_fwd_from_sums.  Which launches can do it follows the dispatch rules (the direct-to-LDS kernel without split-K, V a
+// multiple of its row tile): *rows_per_chunk = 128 when the sums were written, 0 when not (the caller then runs the ordinary
+// BatchNorm, whose first pass re-reads the tensor).  Same output as dreg_conv3d_igemm_ws, bit for bit; the sums of a grid do not
+// depend on the tile shape the launch's size selects (every form adds a chunk's rows in one fixed order).
+static int g_bn_stats_epilogue = 1;   // tuning (include/dreg_nerf_tuning.h)
+void dreg_conv_set_bn_stats_epilogue(int on) { g_bn_stats_epilogue = on ? 1 : 0; }
+int dreg_conv3d_igemm_bnstats(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
+                              int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                              int ksz, int stride, int pad, int relu, int Da, int Ha, int Wa, int add_same,
+                              void* workspace, size_t workspace_bytes, float* bn_partial, int* rows_per_chunk, void* stream)
+{
+    if (!rows_per_chunk) return DREG_EINVAL;
+    *rows_per_chunk = 0;
+    ConvGeom g;
+    int rc = fill_geom(g, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, ksz, stride, pad, 0, 2);
+    if (rc) return rc;
+    if (g.M == 0) return DREG_OK;
+    const IgemmChoice c = igemm_choose(g, g.M, false, workspace != nullptr, addend != nullptr, 2);
+    const int V = Do * Ho * Wo;
+    const bool emit = g_bn_stats_epilogue && bn_partial && c.kind == 0 && c.ksplit == 1 && V % c.bm == 0 && V % 128 == 0 && ((c.bm == 128 && c.bn <= 128) || (c.bm == 256 && c.bn == 256));   // (LDS behind the 128 x 256 tile is too small for the class sums)
+    rc = launch_conv<bf16_t, bf16_t>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_same ? 0 : 1, (hipStream_t)stream, nullptr, 0,
+                                     (float*)workspace, workspace_bytes, nullptr, emit ? bn_partial : nullptr);
+    if (rc == DREG_OK && emit) *rows_per_chunk = 128;     // every tile shape writes 128-row chunk sums in one canonical order
+    return rc;
 }
 int dreg_conv3d_igemm(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
                       int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,

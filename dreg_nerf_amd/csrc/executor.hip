@@ -47,6 +47,9 @@ struct Op {
     int cl_count = 0;
     int pool = -1;               // OP_BN: index of the max-pool op fused behind it; OP_MAXPOOL: index of the BatchNorm it is fused into
     int halo = 0;                // OP_CONV: bit 0 = forward, bit 1 = data gradient run on the halo kernel
+    int stats_bn = -1;           // OP_CONV whose bf16 output feeds a large-path BatchNorm: that op's index (its chunk sums come from this convolution's epilogue)
+    size_t stats_off = 0;        // OP_BN with such a producer: its own chunk-sum buffer [B][V / 128][C][2] (the shared workspace may be used in between)
+    int stats_conv = -1;
     int bt = -1;                 // OP_BN on the one-launch small path: index of its record in the two BatchNorm tail tables
     size_t keep_var = 0, keep_sums = 0;   //   per-grid variances [B][C] / gradient sums [B][C][2] kept until the batched tail launch
 };
@@ -121,6 +124,7 @@ struct Scope {   // optional HIP-event bracket of one launch group
 int g_sparse_grads = 1;   // tuning (include/dreg_nerf_tuning.h): row-cleared instead of memset gradient buffers in front of the active-set convolutions
 int g_bn_batch_tails = 1; // tuning (include/dreg_nerf_tuning.h): the small BatchNorms' running-statistics / parameter-gradient launches batched per pass
 int g_fuse_stem = 1;      // tuning (include/dreg_nerf_tuning.h): BatchNorm + ReLU + max-pool of the stem in one pass
+int g_fuse_bn_stats = 1;  // tuning (include/dreg_nerf_tuning.h): statistics of the large BatchNorm layers from the producing convolution's epilogue
 
 bool s2_class_ok(const Param& p, int ksz, int stride, int pad)
 {
@@ -238,6 +242,23 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
             }
             const size_t c = dreg_colsum_workspace_bytes((size_t)y.B * y.D * y.H * y.W, w.d0);
             if (c > cs) cs = c;
+        }
+    }
+    // BatchNorm statistics from the producing convolution's epilogue (training forward): large-path layers whose input is written by
+    // exactly one plain convolution of this program
+    if (g_fuse_bn_stats) {
+        for (size_t j = 0; j < e->ops.size(); ++j) {
+            Op& bn = e->ops[j];
+            if (bn.kind != OP_BN || bn.pool >= 0) continue;
+            const Tensor& x = e->t[bn.in];
+            const int V = x.D * x.H * x.W;
+            if (V % 128 != 0 || dreg_bn_small(x.B, V, x.C, 0)) continue;
+            int prod = -1, writers = 0;
+            for (size_t i = 0; i < j; ++i) if (e->ops[i].out == bn.in) { prod = (int)i; ++writers; }
+            if (writers != 1 || e->ops[prod].kind != OP_CONV || (e->ops[prod].halo & 1) || e->ops[prod].stats_bn >= 0) continue;
+            e->ops[prod].stats_bn = (int)j;
+            bn.stats_conv = prod;
+            bn.stats_off = off; off += align256((size_t)x.B * (V / 128) * x.C * 2 * sizeof(float));
         }
     }
     e->act_bytes = off;
@@ -388,6 +409,7 @@ void dreg_exec_set_input_row_occupancy(void* h, const uint8_t* rowocc) { ((Exec*
 void dreg_exec_set_sparse_grads(int on) { g_sparse_grads = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_bn_batch_tails(int on) { g_bn_batch_tails = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_fuse_stem(int on) { g_fuse_stem = on ? 1 : 0; }   // read when an executor is created
+void dreg_exec_set_fuse_bn_stats(int on) { g_fuse_bn_stats = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_timing(void* h, int enable) { ((Exec*)h)->timing = enable != 0; }   // records are kept until read
 // After a stream synchronisation: elapsed ms of the bracketed launches since the last set_timing; records are (op, kind, ms)
 // with kind 0 forward, 1 data gradient, 2 weight gradient (+reduce).  Returns the number written (<= max) and restarts.
@@ -449,6 +471,7 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
     hipStream_t st = (hipStream_t)stream;
     CK(upload_tables(e, (char*)arena, st));
     std::vector<char> bn_done(e->bn_fwd.size(), 0);
+    std::vector<int> sums_rpc(e->ops.size(), 0);    // per BatchNorm op: rows per chunk of the sums its producer left (0 = none)
     auto act = [&](int s) -> void* { return s == 0 ? (void*)x_in : (void*)(A + e->t[s].off); };
     for (size_t i = 0; i < e->ops.size(); ++i) {
         const Op& o = e->ops[i];
@@ -463,6 +486,12 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
             if (o.halo & 1) {
                 CK(dreg_conv3_halo(act(o.in), PK + w.pk_halo_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0,
                                    o.add_same, 0, stream));
+                continue;
+            }
+            if (train && o.stats_bn >= 0 && !(o.in == 0 && e->in_rowocc)) {
+                CK(dreg_conv3d_igemm_bnstats(act(o.in), PK + w.pk_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0,
+                                             o.ksz, o.stride, o.pad, o.relu, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0, o.add_same,
+                                             A + e->off_ks, e->sz_ks, (float*)(A + e->ops[o.stats_bn].stats_off), &sums_rpc[o.stats_bn], stream));
                 continue;
             }
             CK(dreg_conv3d_igemm_occ(act(o.in), PK + w.pk_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0,
@@ -488,6 +517,11 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
             // done by the BatchNorm in front of it
         } else if (o.kind == OP_BN) {
             const int V = x.D * x.H * x.W;
+            if (train && sums_rpc[i] > 0) {
+                CK(dreg_bn3d_fwd_from_sums(act(o.in), o.in2 >= 0 ? act(o.in2) : nullptr, act(o.out), e->prm[o.w].val, e->prm[o.b].val, e->prm[o.p2].val, e->prm[o.p3].val,
+                                           (float*)(A + o.aux0), (float*)(A + o.aux1), (float*)(A + o.stats_off), sums_rpc[i], x.B, V, x.C, 1e-5f, 0.1f, o.relu, 0, stream));
+                continue;
+            }
             int deferred = 0;
             CK(dreg_bn3d_fwd_defer_update(act(o.in), o.in2 >= 0 ? act(o.in2) : nullptr, act(o.out), e->prm[o.w].val, e->prm[o.b].val, e->prm[o.p2].val, e->prm[o.p3].val,
                                           (float*)(A + o.aux0), (float*)(A + o.aux1), (float*)(A + e->off_bn_ws), x.B, V, x.C, 1e-5f, 0.1f, train, o.relu, 0,

@@ -1370,7 +1370,8 @@ int dreg_bn_num_chunks(int V) { const int r = bn_rows_per_chunk(V); return (V + 
 // workspace: fp32 [B * chunks * C * 2].  scale_shift, mean_rstd: fp32 [B,C,2] outputs (saved for backward).
 static int bn3d_fwd_impl(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                          float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
-                         int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, void* stream, float* var_keep, int* deferred);
+                         int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, void* stream, float* var_keep, int* deferred,
+                         int sums_rows_per_chunk = 0);
 int dreg_bn3d_fwd(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                   float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
                   int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, void* stream)
@@ -1385,6 +1386,16 @@ int dreg_bn3d_fwd_defer_update(const void* x, const void* res, void* y, const fl
                                int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, float* var_keep, int* deferred, void* stream)
 {
     return bn3d_fwd_impl(x, res, y, gamma, beta, running_mean, running_var, scale_shift, mean_rstd, workspace, B, V, C, eps, momentum, train, relu, dtype, stream, var_keep, deferred);
+}
+// Training-mode forward whose statistics pass already happened: workspace = the chunk sums [B][V / rows_per_chunk][C][2] left by
+// dreg_conv3d_igemm_bnstats (rows_per_chunk as returned there, > 0, dividing V).  Finalize (+ running statistics) and apply only.
+int dreg_bn3d_fwd_from_sums(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* sums,
+                            int rows_per_chunk, int B, int V, int C, float eps, float momentum, int relu, int dtype, void* stream)
+{
+    if (rows_per_chunk <= 0) return DREG_EINVAL;
+    return bn3d_fwd_impl(x, res, y, gamma, beta, running_mean, running_var, scale_shift, mean_rstd, sums, B, V, C, eps, momentum, 1, relu, dtype, stream, nullptr, nullptr,
+                         rows_per_chunk);
 }
 int dreg_bn_small(int B, int V, int C, int dtype) { return bn_small_ok(B, V, C, dtype == 0 ? 8 : 4) ? 1 : 0; }
 // descs_dev: n records of 48 bytes { const float* mean_rstd; const float* var; float* running_mean; float* running_var; int B, V, C, block0; }
@@ -1406,7 +1417,8 @@ int dreg_bn_param_grad_batched(const void* descs_dev, int n, int block_base, int
 }
 static int bn3d_fwd_impl(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                          float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
-                         int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, void* stream, float* var_keep, int* deferred)
+                         int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, void* stream, float* var_keep, int* deferred,
+                         int sums_rows_per_chunk)
 {
     hipStream_t st = (hipStream_t)stream;
     if (deferred) *deferred = 0;
@@ -1414,7 +1426,11 @@ static int bn3d_fwd_impl(const void* x, const void* res, void* y, const float* g
     if (C % G) return DREG_EINVAL;
     const int rpc = bn_rows_per_chunk(V), nch = (V + rpc - 1) / rpc;
     const int CG = C / G, slabs = (CG + 255) / 256;
-    if (train && bn_small_ok(B, V, C, G)) {      // 16^3 / 8^3 / 4^3 levels: statistics + apply in one launch, running statistics in a tiny second one
+    // sums_rows_per_chunk > 0 (training mode): the workspace already holds the chunk sums [B][V / that][C][2] (written by the producing
+    // convolution's epilogue: dreg_conv3d_igemm_bnstats) — no statistics pass over x
+    const bool presummed = train && sums_rows_per_chunk > 0;
+    if (presummed && V % sums_rows_per_chunk != 0) return DREG_EINVAL;
+    if (train && !presummed && bn_small_ok(B, V, C, G)) {      // 16^3 / 8^3 / 4^3 levels: statistics + apply in one launch, running statistics in a tiny second one
         const dim3 g1(CG / BNS_COLS, B);
         float* var = var_keep ? var_keep : workspace;   // [B][C] biased variances (the workspace holds >= B * chunks * C * 2 floats)
 #define BNS_FWD(Tt, NRv) hipLaunchKernelGGL((bn_small_fwd_kernel<Tt, NRv>), g1, dim3(256), 0, st, (const Tt*)x, (const Tt*)res, (Tt*)y, gamma, beta, \
@@ -1429,8 +1445,8 @@ static int bn3d_fwd_impl(const void* x, const void* res, void* y, const float* g
         DREG_LAUNCH_CHECK();
         return DREG_OK;
     }
-    if (train && !(g_bn_debug_skip & 1)) {
-        if (train && V < 2) return DREG_EINVAL;  // torch raises for one value per channel
+    if (train && V < 2) return DREG_EINVAL;      // torch raises for one value per channel
+    if (train && !presummed && !(g_bn_debug_skip & 1)) {
         dim3 grid(nch, B, slabs);
         if (dtype == 0) hipLaunchKernelGGL((bn_partial_kernel<bf16_t, 0>), grid, dim3(256), 0, st, (const bf16_t*)x, nullptr, nullptr, nullptr, workspace, V, C, rpc, 0);
         else hipLaunchKernelGGL((bn_partial_kernel<float, 0>), grid, dim3(256), 0, st, (const float*)x, nullptr, nullptr, nullptr, workspace, V, C, rpc, 0);
@@ -1438,7 +1454,7 @@ static int bn3d_fwd_impl(const void* x, const void* res, void* y, const float* g
     }
     if (B > BN_MAX_GRIDS) return DREG_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64 * (B < 8 ? B : 8)), 0, st, workspace, gamma, beta, running_mean, running_var,
-                       scale_shift, mean_rstd, B, nch, C, V, eps, momentum, train);
+                       scale_shift, mean_rstd, B, presummed ? V / sums_rows_per_chunk : nch, C, V, eps, momentum, train);
     DREG_LAUNCH_CHECK();
     const size_t tg = (size_t)B * V * CG;
     (void)tg;

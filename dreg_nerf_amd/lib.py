@@ -34,6 +34,7 @@ SIGNATURES = {
     "dreg_conv3d_igemm_workspace_bytes": (Z, [I] * 15),
     "dreg_conv3d_igemm_ws": (I, [P, P, P, P, P] + [I] * 18 + [I, I, P, Z, P]),
     "dreg_conv3d_igemm_occ": (I, [P, P, P, P, P] + [I] * 18 + [I, I, P, Z, P, P]),
+    "dreg_conv3d_igemm_bnstats": (I, [P, P, P, P, P] + [I] * 17 + [P, Z, P, P, P]),
     "dreg_conv3d_kpad": (I, [I, I, I]),
     "dreg_conv_set_glds": (None, [I]),
     "dreg_conv_get_glds": (I, []),
@@ -76,6 +77,8 @@ SIGNATURES = {
     "dreg_bn_set_store_g": (None, [I]),
     "dreg_bn_set_small_regs": (None, [I]),
     "dreg_exec_set_fuse_stem": (None, [I]),
+    "dreg_exec_set_fuse_bn_stats": (None, [I]),
+    "dreg_conv_set_bn_stats_epilogue": (None, [I]),
     "dreg_exec_set_bn_batch_tails": (None, [I]),
     "dreg_exec_set_sparse_grads": (None, [I]),
     "dreg_conv3_halo_set_variant": (None, [I]),
@@ -89,6 +92,7 @@ SIGNATURES = {
     "dreg_bn3d_bwd": (I, [P] * 11 + [I, I, I, I, I, I, P]),
     "dreg_bn_small": (I, [I, I, I, I]),
     "dreg_bn3d_fwd_defer_update": (I, [P] * 10 + [I, I, I, F, F, I, I, I, P, P, P]),
+    "dreg_bn3d_fwd_from_sums": (I, [P] * 10 + [I, I, I, I, F, F, I, I, P]),
     "dreg_bn3d_bwd_defer_params": (I, [P] * 11 + [I, I, I, I, I, I, P, P, P]),
     "dreg_bn_running_update_batched": (I, [P, I, I, I, F, P]),
     "dreg_bn_param_grad_batched": (I, [P, I, I, I, I, P]),

@@ -70,6 +70,20 @@ int dreg_conv3d_igemm_occ(const void* in, const void* wt_packed, void* out, cons
                           int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
                           int dtype, int out_f32, void* workspace, size_t workspace_bytes, const uint8_t* rowocc, void* stream);
 
+/* Every ResNet3D convolution is followed by a training-mode BatchNorm3d over its own output (resnet3d.py:95-113): the forward bf16
+ * convolution can leave that layer's statistics behind — per (grid, chunk of *rows_per_chunk output voxels, channel) the sum and the
+ * sum of squares of the STORED values, bn_partial fp32 [B][V / *rows_per_chunk][Cout][2] with V = Do*Ho*Wo — so that
+ * dreg_bn3d_fwd_from_sums needs no statistics pass (one full read of the tensor less per layer).  *rows_per_chunk = 0 when this
+ * launch could not do it (split-K, a tile that does not divide V, the register-staged kernel): run the ordinary dreg_bn3d_fwd then.
+ * bn_partial must hold B * (V / 128) * Cout * 2 floats.  The output is the one of dreg_conv3d_igemm_ws, bit for bit. */
+int dreg_conv3d_igemm_bnstats(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
+                              int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                              int ksz, int stride, int pad, int relu, int Da, int Ha, int Wa, int add_same,
+                              void* workspace, size_t workspace_bytes, float* bn_partial, int* rows_per_chunk, void* stream);
+int dreg_bn3d_fwd_from_sums(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* sums,
+                            int rows_per_chunk, int B, int V, int C, float eps, float momentum, int relu, int dtype, void* stream);
+
 /* ---- dense 3^3 / stride 1 / pad 1 convolution with 256 output channels on an LDS-resident input halo (csrc/conv_halo.hip):
  * the FeaturePyramid_v1 head's upsample_transform_* / pyramid_transformation_1 layers (conerf/model/feature_pyramid_net.py:47-56,
  * 97-103; cuDNN conv3d in the reference) and their data gradients.  A workgroup owns a 4 x 8 x 8 box of output voxels, stages its

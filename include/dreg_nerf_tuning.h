@@ -36,6 +36,8 @@ void dreg_exec_set_aux_streams(int n);                /* experiment: weight-grad
 void dreg_exec_set_sparse_grads(int on);              /* 1 (default): executors created from now on keep the single-writer gradient buffers of the active-set head zero by clearing rows */
 void dreg_exec_set_bn_batch_tails(int on);            /* 1 (default): executors created from now on batch the small BatchNorms' running-statistics / dgamma-dbeta launches per pass */
 void dreg_exec_set_fuse_stem(int on);                 /* 1 (default): executors created from now on fuse the stem's BatchNorm + ReLU + max-pool (fpn_ops.hip) */
+void dreg_exec_set_fuse_bn_stats(int on);            /* 1 (default): executors created from now on take the statistics of the large BatchNorm layers from the producing convolution's epilogue (dreg_conv3d_igemm_bnstats) */
+void dreg_conv_set_bn_stats_epilogue(int on);        /* 0: dreg_conv3d_igemm_bnstats never emits sums (callers fall back to the BatchNorm's own statistics pass) */
 void dreg_bn_set_store_g(int enable);                /* 1 (default): the backward of a residual + ReLU BatchNorm stores the masked gradient (= the residual gradient) in its statistics pass; the apply pass reads it instead of dy and y */
 void dreg_bn_set_small_regs(int enable);             /* 1 (default): the one-launch BatchNorms of the 8^3 / 4^3 volumes load their rows once and keep them in registers between statistics and apply */
 void dreg_bn_set_debug_skip(int mask);                /* MEASUREMENT ONLY (wrong results): bit 0 / 1 leave out the forward / backward statistics pass of the large BatchNorms */

@@ -2,6 +2,8 @@
 (through the C ABI via dreg_nerf_amd.ops).  fp32 mode = exact-f32 MFMA (tolerance: fp32 round-off);
 bf16 mode is compared against the fp32 result on bf16-rounded operands."""
 import numpy as np
+import ctypes
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -168,6 +170,90 @@ def test_deferred_row_list_weight_gradient_sums_only_the_written_slices(cin, cou
     assert torch.isfinite(got).all()
     # the same slices summed in a differently grouped order (the batched sum partitions its work by the table's split count)
     assert float((got - want).abs().max()) <= 1e-5 * float((want - base).abs().max())
+
+
+@pytest.mark.parametrize("B,D,cin,cout,k,stride,emits", [
+    (2, 16, 64, 128, 1, 1, True),          # 64 row tiles x 1: the eight-wave anti-phase form of the 128 x 128 tile
+    (2, 16, 128, 128, 3, 1, True),
+    (8, 32, 64, 256, 1, 1, True),          # 262,144 rows, 256 channels: the 256 x 256 tile (chunks of 256 voxels)
+    (8, 32, 256, 64, 1, 1, True),          # 64 output channels: the 128 x 64 tile
+    (2, 32, 128, 128, 3, 2, True),         # stride 2 (the first 3^3 convolution of layer2)
+    (8, 8, 256, 256, 3, 1, False),         # split-K launch: no sums, the caller runs the ordinary BatchNorm
+])
+def test_convolution_epilogue_leaves_the_batchnorm_sums(B, D, cin, cout, k, stride, emits):
+    """dreg_conv3d_igemm_bnstats: the convolution's output is the plain launch's, bit for bit, and the chunk sums it leaves are the
+    sums / sums of squares of the STORED bf16 values per (grid, chunk, channel); dreg_bn3d_fwd_from_sums on them equals the
+    three-pass BatchNorm up to the summation order of the statistics."""
+    from dreg_nerf_amd import lib as L
+    lib = L.load()
+    dev = _dev()
+    g = torch.Generator().manual_seed(B + D + cin + cout)
+    x = torch.randn(B, D, D, D, cin, generator=g).to(dev, torch.bfloat16)
+    w = (torch.randn(cout, cin, k, k, k, generator=g) / (cin * k ** 3) ** 0.5).to(dev)
+    wpk = ops.packed_weight(w, cin, False, 0)
+    pad = k // 2
+    Do = (D + 2 * pad - k) // stride + 1
+    V = Do ** 3
+    want = ops.conv_igemm(x, wpk, None, None, (Do, Do, Do), cin, cout, k, stride, pad, False)
+    out = torch.empty_like(want)
+    sums = torch.full((B * (V // 128) * cout * 2,), float("nan"), dtype=torch.float32, device=dev)
+    nws = lib.dreg_conv3d_igemm_workspace_bytes(B, D, D, D, cin, Do, Do, Do, cout, k, stride, pad, 0, 0, 0)
+    ws = torch.empty(max(int(nws), 16), dtype=torch.uint8, device=dev)
+    rpc = ctypes.c_int(-1)
+    L.check(lib.dreg_conv3d_igemm_bnstats(L.ptr(x), L.ptr(wpk), L.ptr(out), None, None, B, D, D, D, cin, Do, Do, Do, cout, k, stride, pad, 0, 0, 0, 0, 0,
+                                          L.ptr(ws), int(nws), L.ptr(sums), ctypes.addressof(rpc), L.stream()), "dreg_conv3d_igemm_bnstats")
+    assert torch.equal(out, want)
+    if not emits:
+        assert rpc.value == 0
+        return
+    assert rpc.value == 128
+    nch = V // rpc.value
+    # a grid's sums do not depend on the form the launch's size selects: four waves instead of the eight-wave anti-phase form, and
+    # (one grid alone: 32,768 rows) the 128-row tile instead of the 256 x 256 one — bit for bit
+    others = []
+    try:
+        lib.dreg_conv_set_igemm_ap(0)
+        lib.dreg_conv_set_igemm_ap256(0)
+        for nb in (B, 1):
+            o2 = torch.empty(nb, Do, Do, Do, cout, dtype=torch.bfloat16, device=dev)
+            s2 = torch.full_like(sums, float("nan"))
+            r2 = ctypes.c_int(-1)
+            L.check(lib.dreg_conv3d_igemm_bnstats(L.ptr(x), L.ptr(wpk), L.ptr(o2), None, None, nb, D, D, D, cin, Do, Do, Do, cout, k, stride, pad, 0, 0, 0, 0, 0,
+                                                  L.ptr(ws), int(nws), L.ptr(s2), ctypes.addressof(r2), L.stream()), "dreg_conv3d_igemm_bnstats")
+            others.append((nb, o2, s2, r2.value))
+    finally:
+        lib.dreg_conv_set_igemm_ap(256)
+        lib.dreg_conv_set_igemm_ap256(1)
+    for nb, o2, s2, r2 in others:
+        if r2 == 0:
+            continue                                  # (one grid of a small level may run split-K: no sums, nothing to compare)
+        assert torch.equal(o2, out[:nb])
+        assert torch.equal(s2[:nb * nch * cout * 2], sums[:nb * nch * cout * 2]), nb
+    got = sums[:B * nch * cout * 2].view(B, nch, cout, 2).double()
+    ref = out.double().view(B, nch, rpc.value, cout)
+    assert float((got[..., 0] - ref.sum(2)).abs().max()) <= 1e-5 * float(ref.abs().sum(2).max())
+    assert float((got[..., 1] - (ref * ref).sum(2)).abs().max()) <= 1e-5 * float((ref * ref).sum(2).max())
+    # BatchNorm from the sums vs the BatchNorm with its own statistics pass
+    gamma, beta = torch.rand(cout, generator=g).to(dev) + 0.5, torch.randn(cout, generator=g).to(dev)
+    res = torch.randn(B, Do, Do, Do, cout, generator=g).to(dev, torch.bfloat16)
+    outs = []
+    for fused in (False, True):
+        rm, rv = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+        ss, mr = torch.empty(B, cout, 2, device=dev), torch.empty(B, cout, 2, device=dev)
+        y = torch.empty_like(out)
+        if fused:
+            L.check(lib.dreg_bn3d_fwd_from_sums(L.ptr(out), L.ptr(res), L.ptr(y), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(ss), L.ptr(mr), L.ptr(sums),
+                                                rpc.value, B, V, cout, 1e-5, 0.1, 1, 0, L.stream()), "dreg_bn3d_fwd_from_sums")
+        else:
+            bws = torch.empty(B * lib.dreg_bn_num_chunks(V) * cout * 2, dtype=torch.float32, device=dev)
+            L.check(lib.dreg_bn3d_fwd(L.ptr(out), L.ptr(res), L.ptr(y), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.ptr(ss), L.ptr(mr), L.ptr(bws),
+                                      B, V, cout, 1e-5, 0.1, 1, 1, 0, L.stream()), "dreg_bn3d_fwd")
+        outs.append((y, mr, rm, rv))
+    (ya, mra, rma, rva), (yb, mrb, rmb, rvb) = outs
+    assert float((mra - mrb).abs().max()) <= 1e-5 * float(mra.abs().max())
+    assert float((rma - rmb).abs().max()) <= 1e-6 and float((rva - rvb).abs().max()) <= 1e-5
+    assert float((ya.float() - yb.float()).abs().max()) <= 2 ** -7 * float(ya.float().abs().max())     # at most one bf16 step where a value sits on a rounding boundary
+    assert (ya != yb).float().mean().item() < 1e-3
 
 
 @pytest.mark.parametrize("out_f32", [False, True])

@@ -30,9 +30,24 @@ def _grids(res, n, r0=0.55, r1=0.8):
     return gs, idx
 
 
-@pytest.mark.parametrize("sparse", [False, True])
-def test_executor_matches_per_op_path(sparse):
+@pytest.mark.parametrize("sparse,fused_stats", [(False, 0), (True, 0), (False, 1), (True, 1)])
+def test_executor_matches_per_op_path(sparse, fused_stats):
+    """fused_stats = 0: the executor takes every BatchNorm's statistics from the layer's own statistics pass, like the per-op path:
+    bit-identical forward.  1 (default): from the producing convolution's epilogue (per-tile instead of per-chunk partial sums: the
+    means differ in their last bits, and 53 BatchNorm layers at a random initialisation amplify that)."""
+    from dreg_nerf_amd import lib as L
+    L.load().dreg_exec_set_fuse_bn_stats(fused_stats)
+    try:
+        _executor_vs_per_op(sparse, bool(fused_stats))
+    finally:
+        L.load().dreg_exec_set_fuse_bn_stats(1)
+
+
+def _executor_vs_per_op(sparse, fused_stats):
     m, opt = _model()
+    if fused_stats:      # the well-conditioned weight profile (params.PROFILES["wc"]): last-bit differences of a mean stay small through 53 layers
+        from dreg_nerf_amd import params
+        m.load_state_dict(params.synth_state_dict(0, profile="wc"), strict=True)
     res = 64
     grids, idx = _grids(res, 2, *((0.3, 0.34) if sparse else (0.55, 0.8)))   # a thin shell keeps S3 under the 20 % density cap
     x = NeRFRegTr.pack_grids(grids, torch.bfloat16)
@@ -59,13 +74,20 @@ def test_executor_matches_per_op_path(sparse):
         p1.backward(go)
         grads.append(opt.flat_g.clone())
         stats.append({k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k})
-    assert torch.equal(outs[0], outs[1]), "forward must be bit-identical"
-    for k in stats[0]:
-        assert torch.equal(stats[0][k], stats[1][k]), k
+    if not fused_stats:
+        assert torch.equal(outs[0], outs[1]), "forward must be bit-identical"
+        for k in stats[0]:
+            assert torch.equal(stats[0][k], stats[1][k]), k
+    else:
+        d = (outs[0].float() - outs[1].float()).norm().item() / outs[0].float().norm().item()
+        worst = max(float((stats[0][k].float() - stats[1][k].float()).abs().max()) / max(float(stats[0][k].float().abs().max()), 1e-12) for k in stats[0])
+        print(f"fused BatchNorm statistics vs per-op path: output rel. distance {d:.3e}, running statistics worst rel. {worst:.3e}")
+        assert d <= 2e-2 and worst <= 3e-2
     ga, gb = grads
     assert torch.isfinite(gb).all()
     denom = ga.norm().item()
-    assert (ga - gb).norm().item() <= 2e-2 * denom, ((ga - gb).norm().item(), denom)
+    print(f"gradient buffer rel. distance {(ga - gb).norm().item() / denom:.3e}")
+    assert (ga - gb).norm().item() <= (6e-2 if fused_stats else 2e-2) * denom, ((ga - gb).norm().item(), denom)
     # per-parameter: the head / FPN parameters see identical inputs -> (nearly) identical gradients
     off = dict(zip([id(p) for p in opt.params], opt.offsets))
     for name, p in m.named_parameters():
@@ -73,7 +95,7 @@ def test_executor_matches_per_op_path(sparse):
             continue
         a = ga[off[id(p)]:off[id(p)] + p.numel()]
         b = gb[off[id(p)]:off[id(p)] + p.numel()]
-        assert (a - b).norm().item() <= 5e-3 * max(a.norm().item(), 1e-12), name
+        assert (a - b).norm().item() <= (5e-2 if fused_stats else 5e-3) * max(a.norm().item(), 1e-12), (name, (a - b).norm().item() / max(a.norm().item(), 1e-12))
 
 
 def test_executor_eval_mode_and_no_grad():
