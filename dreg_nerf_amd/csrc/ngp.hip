@@ -65,23 +65,11 @@ __device__ __forceinline__ void store_relu4_pk(char* sH, int row_stride, int poi
 // x world [Np,3] fp32 -> density fp32 [Np] (= exp(h0 - 1) * inside), raw fp16 [Np,16] (h0 | 15 geometry features)
 // one wave per workgroup: the waves are independent (no workgroup barrier), and 5,081 small workgroups for a 325 k-point block fill
 // the chip evenly where 1,270 four-wave ones left a quarter-full second round
-__global__ __launch_bounds__(64) void ngp_density_kernel(const float* __restrict__ x, const _Float16* __restrict__ table,
-                                                          const _Float16* __restrict__ w1, const _Float16* __restrict__ w2,
-                                                          float* __restrict__ density, _Float16* __restrict__ raw,
-                                                          NgpLevels lv, float lo0, float lo1, float lo2, float hi0, float hi1, float hi2, int Np,
-                                                          int contract)
+// unit-cube coordinates of point p (clamped) and whether it lies strictly inside (ngp.py:157-167)
+__device__ __forceinline__ bool ngp_unit_coords(const float* __restrict__ x, int p, int Np, float lo0, float lo1, float lo2, float hi0, float hi1, float hi2,
+                                                int contract, float (&u)[3])
 {
-    constexpr int XRS = 32 * 2 + 16, HRS = 64 * 2 + 16;
-    // per wave: ONE 64 x 64 fp16 tile (the encoded input X lives in its first 5 KB until the first layer has read it) + 64 flags:
-    // 9.5 KB per wave, 38 KB per workgroup -> four workgroups per CU (the gathers of the 16 levels are latency: occupancy hides them)
-    __shared__ __attribute__((aligned(16))) char smem[64 * HRS + 64 * 4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    char* sH = smem;
-    char* sX = sH;
-    float* sSel = reinterpret_cast<float*>(sH + 64 * HRS);
-    const int p0 = (int)blockIdx.x * 64;
-    const int p = p0 + lane;
-    float u[3] = {0.f, 0.f, 0.f};
+    u[0] = u[1] = u[2] = 0.f;
     bool inside = false;
     if (p < Np) {
         const float lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
@@ -109,28 +97,102 @@ __global__ __launch_bounds__(64) void ngp_density_kernel(const float* __restrict
             u[c] = fminf(fmaxf(u[c], 0.f), 1.f);
         }
     }
-    sSel[lane] = inside ? 1.f : 0.f;
-#pragma unroll 1
-    for (int l = 0; l < 16; ++l) {
-        const float sc = lv.scale[l];
-        const uint32_t res = lv.res[l], size = lv.size[l], hashed = lv.hashed[l];
-        const _Float16* tl = table + (size_t)lv.offset[l] * 2;
-        float pos[3], w[3];
-        uint32_t g[3];
+    return inside;
+}
+// trilinear interpolation of level l's two features at unit coordinates u (8 corner gathers of 4 bytes)
+__device__ __forceinline__ void ngp_level_features(const _Float16* __restrict__ table, const NgpLevels& lv, int l, const float (&u)[3], float& f0, float& f1)
+{
+    const float sc = lv.scale[l];
+    const uint32_t res = lv.res[l], size = lv.size[l], hashed = lv.hashed[l];
+    const _Float16* tl = table + (size_t)lv.offset[l] * 2;
+    float pos[3], w[3];
+    uint32_t g[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { pos[c] = u[c] * sc + 0.5f; const float fl = floorf(pos[c]); g[c] = (uint32_t)fl; w[c] = pos[c] - fl; }
-        float f0 = 0.f, f1 = 0.f;
+    for (int c = 0; c < 3; ++c) { pos[c] = u[c] * sc + 0.5f; const float fl = floorf(pos[c]); g[c] = (uint32_t)fl; w[c] = pos[c] - fl; }
+    f0 = 0.f; f1 = 0.f;
 #pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {
-            const uint32_t cx = g[0] + (corner & 1), cy = g[1] + ((corner >> 1) & 1), cz = g[2] + ((corner >> 2) & 1);
-            const float wt = ((corner & 1) ? w[0] : 1.f - w[0]) * ((corner & 2) ? w[1] : 1.f - w[1]) * ((corner & 4) ? w[2] : 1.f - w[2]);
-            const uint32_t idx = grid_index(cx, cy, cz, res, size, hashed);
-            const uint32_t pr = *reinterpret_cast<const uint32_t*>(tl + (size_t)idx * 2);
-            union { uint32_t u32; _Float16 h[2]; } cv; cv.u32 = pr;
-            f0 += wt * (float)cv.h[0]; f1 += wt * (float)cv.h[1];
+    for (int corner = 0; corner < 8; ++corner) {
+        const uint32_t cx = g[0] + (corner & 1), cy = g[1] + ((corner >> 1) & 1), cz = g[2] + ((corner >> 2) & 1);
+        const float wt = ((corner & 1) ? w[0] : 1.f - w[0]) * ((corner & 2) ? w[1] : 1.f - w[1]) * ((corner & 4) ? w[2] : 1.f - w[2]);
+        const uint32_t idx = grid_index(cx, cy, cz, res, size, hashed);
+        const uint32_t pr = *reinterpret_cast<const uint32_t*>(tl + (size_t)idx * 2);
+        union { uint32_t u32; _Float16 h[2]; } cv; cv.u32 = pr;
+        f0 += wt * (float)cv.h[0]; f1 += wt * (float)cv.h[1];
+    }
+}
+
+// Hash-grid encoding with the table held in L2: the 16 levels are 25 MB (fits the Infinity Cache, not one XCD's 4 MB L2), and a wave
+// that walks all levels pulls a 128-byte line through the fabric for almost every 4-byte corner (807 MB per 325 k-point block, 5 TB/s:
+// what bounded the fused kernel).  Workgroups are dealt round-robin to the 8 XCDs, so workgroup b works for XCD b & 7 — and takes ONLY
+// the two levels (b & 7) and 15 - (b & 7) (a small dense level with a hashed one: <= 3.5 MB; three XCDs hold two hashed levels, 4 MB)
+// for its share of the points: every XCD's L2 keeps its own levels, the corner gathers become L2 hits.  feat: fp16 [16][Np][2].
+__global__ __launch_bounds__(64) void ngp_encode_xcd_kernel(const float* __restrict__ x, const _Float16* __restrict__ table, _Float16* __restrict__ feat,
+                                                             NgpLevels lv, float lo0, float lo1, float lo2, float hi0, float hi1, float hi2, int Np,
+                                                             int contract, int waves_per_xcd, const int* __restrict__ order, int x_in_slot_order)
+{
+    const int lane = threadIdx.x & 63;
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int la = xcd, lb = 15 - xcd;
+    const int nchunk = (Np + 63) / 64;
+    for (int chunk = slot; chunk < nchunk; chunk += waves_per_xcd) {
+        const int j = chunk * 64 + lane;                               // slot of this lane (feat is kept in slot order)
+        const int p = (order && !x_in_slot_order && j < Np) ? order[j] : j;   // where this slot's coordinates are
+        float u[3];
+        (void)ngp_unit_coords(x, p, Np, lo0, lo1, lo2, hi0, hi1, hi2, contract, u);
+        float a0, a1, b0, b1;
+        ngp_level_features(table, lv, la, u, a0, a1);
+        ngp_level_features(table, lv, lb, u, b0, b1);
+        if (j < Np) {
+            union { uint32_t u32; _Float16 h[2]; } va, vb;
+            va.h[0] = (_Float16)a0; va.h[1] = (_Float16)a1; vb.h[0] = (_Float16)b0; vb.h[1] = (_Float16)b1;
+            reinterpret_cast<uint32_t*>(feat)[(size_t)la * Np + j] = va.u32;
+            reinterpret_cast<uint32_t*>(feat)[(size_t)lb * Np + j] = vb.u32;
         }
-        _Float16* xr = reinterpret_cast<_Float16*>(sX + lane * XRS);
-        xr[2 * l] = (_Float16)f0; xr[2 * l + 1] = (_Float16)f1;
+    }
+}
+
+// PRE: the level features come from ngp_encode_xcd_kernel's buffer (feat) instead of being gathered here
+template <int UNR, bool PRE = false>
+__global__ __launch_bounds__(64) void ngp_density_kernel(const float* __restrict__ x, const _Float16* __restrict__ table,
+                                                          const _Float16* __restrict__ w1, const _Float16* __restrict__ w2,
+                                                          float* __restrict__ density, _Float16* __restrict__ raw,
+                                                          NgpLevels lv, float lo0, float lo1, float lo2, float hi0, float hi1, float hi2, int Np,
+                                                          int contract, const _Float16* __restrict__ feat = nullptr, const int* __restrict__ order = nullptr,
+                                                          int x_in_slot_order = 0)
+{
+    constexpr int XRS = 32 * 2 + 16, HRS = 64 * 2 + 16;
+    // per wave: ONE 64 x 64 fp16 tile (the encoded input X lives in its first 5 KB until the first layer has read it) + 64 flags:
+    // 9.5 KB per wave, 38 KB per workgroup -> four workgroups per CU (the gathers of the 16 levels are latency: occupancy hides them)
+    __shared__ __attribute__((aligned(16))) char smem[64 * HRS + 64 * 4 + 64 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* sH = smem;
+    char* sX = sH;
+    float* sSel = reinterpret_cast<float*>(sH + 64 * HRS);
+    int* sPt = reinterpret_cast<int*>(sH + 64 * HRS + 64 * 4);            // the point each slot of this wave works on
+    const int p0 = (int)blockIdx.x * 64;
+    const int jslot = p0 + lane;                                         // slot; the point is order[slot] (identity without an order)
+    const int p = (order && jslot < Np) ? order[jslot] : jslot;
+    float u[3];
+    const bool inside = ngp_unit_coords(x, x_in_slot_order ? jslot : p, Np, lo0, lo1, lo2, hi0, hi1, hi2, contract, u);
+    sSel[lane] = inside ? 1.f : 0.f;
+    sPt[lane] = p;
+    if constexpr (PRE) {
+        uint32_t fv[16];
+#pragma unroll
+        for (int l = 0; l < 16; ++l) fv[l] = jslot < Np ? reinterpret_cast<const uint32_t*>(feat)[(size_t)l * Np + jslot] : 0u;
+        uint32_t* xr = reinterpret_cast<uint32_t*>(sX + lane * XRS);
+#pragma unroll
+        for (int l = 0; l < 16; ++l) xr[l] = fv[l];
+    } else {
+        // UNR levels at a time: 8 * UNR corner gathers of a lane in flight (measured: no difference between 1 and 8 — the kernel is bound by
+        // the lines it pulls through the fabric, not by the latency of a level)
+#pragma unroll UNR
+        for (int l = 0; l < 16; ++l) {
+            float f0, f1;
+            ngp_level_features(table, lv, l, u, f0, f1);
+            _Float16* xr = reinterpret_cast<_Float16*>(sX + lane * XRS);
+            xr[2 * l] = (_Float16)f0; xr[2 * l + 1] = (_Float16)f1;
+        }
     }
     wave_sync();
     const int fr = lane & 15, kg = lane >> 4;
@@ -164,8 +226,9 @@ __global__ __launch_bounds__(64) void ngp_density_kernel(const float* __restrict
             const int row = rb * 16 + kg * 4 + r;
             if (p0 + row < Np) {
                 const _Float16 hv = (_Float16)o[r];
-                raw[(size_t)(p0 + row) * 16 + fr] = hv;
-                if (fr == 0) density[p0 + row] = __expf((float)hv - 1.f) * sSel[row];
+                const int pt = sPt[row];
+                raw[(size_t)pt * 16 + fr] = hv;
+                if (fr == 0) density[pt] = __expf((float)hv - 1.f) * sSel[row];
             }
         }
     }
@@ -411,24 +474,128 @@ __global__ void grid_scatter7_kernel(const float* __restrict__ xyz, const float*
 }
 
 // occupied-cell sample positions: world = lo + (cell + jitter) / res * (hi - lo)  (sample_grid.py:226-242, AABB contraction)
+// order / world_slot (optional, together): thread j takes point order[j] and ALSO writes its position to world_slot[j] — the coordinates
+// in the order the density query's lanes take them (contiguous reads there instead of eight scattered passes)
 __global__ void grid_sample_points_kernel(const int64_t* __restrict__ idx, const float* __restrict__ jitter, float* __restrict__ world,
-                                          int rx, int ry, int rz, float lo0, float lo1, float lo2, float hi0, float hi1, float hi2, int Np)
+                                          int rx, int ry, int rz, float lo0, float lo1, float lo2, float hi0, float hi1, float hi2, int Np,
+                                          const int* __restrict__ order, float* __restrict__ world_slot)
 {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= Np) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Np) return;
+    const int n = order ? order[j] : j;
     const int64_t f = idx[n];
     const int z = (int)(f % rz), y = (int)((f / rz) % ry), xx = (int)(f / ((int64_t)rz * ry));
     const float u0 = ((float)xx + jitter[(size_t)n * 3]) / (float)rx, u1 = ((float)y + jitter[(size_t)n * 3 + 1]) / (float)ry,
                 u2 = ((float)z + jitter[(size_t)n * 3 + 2]) / (float)rz;
-    world[(size_t)n * 3] = u0 * (hi0 - lo0) + lo0;
-    world[(size_t)n * 3 + 1] = u1 * (hi1 - lo1) + lo1;
-    world[(size_t)n * 3 + 2] = u2 * (hi2 - lo2) + lo2;
+    const float w0 = u0 * (hi0 - lo0) + lo0, w1 = u1 * (hi1 - lo1) + lo1, w2 = u2 * (hi2 - lo2) + lo2;
+    world[(size_t)n * 3] = w0; world[(size_t)n * 3 + 1] = w1; world[(size_t)n * 3 + 2] = w2;
+    if (world_slot) { world_slot[(size_t)j * 3] = w0; world_slot[(size_t)j * 3 + 1] = w1; world_slot[(size_t)j * 3 + 2] = w2; }
+}
+
+// ---- lane order of a block's dense query.  The occupied cells arrive as ascending flat indices (x * ry + y) * rz + z: consecutive points
+// differ in z — the SLOWEST axis of the hash grid's tables (dense levels: x + y * res + z * res^2; hashed: x ^ y * P1 ^ z * P2), so the
+// 64 corner addresses of a gather instruction fall into 64 different cache lines and the kernel is bound by the texture unit's line
+// rate.  With the lanes of a wave running along x the same gathers touch a few lines (155 -> 112 us for 325 k points; with the XCD-
+// resident level pairs 86).  order[j] = index (in the ascending list) of the j-th occupied cell in (z, y, x)-major enumeration.
+// Three small launches per block: column prefix counts along x, an exclusive scan over the ry * rz columns, one pass over the points.
+// pre[f] = occupied cells with smaller x in f's (y, z) column, cnt[z][y] = the column's total.  A workgroup = NS x-segments of 16 cells
+// x COLS consecutive columns: every thread has its 16 loads in flight at once (a thread walking a whole column is a chain of rx
+// dependent steps: 3x the time of the density kernel's gain), the segments are joined through LDS.
+__global__ __launch_bounds__(256) void grid_xprefix_kernel(const uint8_t* __restrict__ binary, uint16_t* __restrict__ pre, int* __restrict__ cnt, int rx, int ry, int rz,
+                                                            int NS, int COLS)
+{
+    __shared__ int seg[256];
+    const int t = threadIdx.x, s_ = t / COLS, c = t - s_ * COLS;          // segment, column within the workgroup (columns fastest: coalesced)
+    const int col = blockIdx.x * COLS + c;                                 // column (y, z), z fastest
+    const bool live = s_ < NS && col < ry * rz;
+    const size_t plane = (size_t)ry * rz;
+    uint8_t b[16];
+    int tot = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int x = s_ * 16 + i; b[i] = (live && x < rx) ? binary[(size_t)col + (size_t)x * plane] : 0; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tot += b[i] ? 1 : 0;
+    seg[t] = live ? tot : 0;
+    __syncthreads();
+    int run = 0;
+    for (int q = 0; q < s_; ++q) run += seg[q * COLS + c];
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int x = s_ * 16 + i;
+            if (x < rx) { pre[(size_t)col + (size_t)x * plane] = (uint16_t)run; run += b[i] ? 1 : 0; }
+        }
+        if (s_ == NS - 1) { const int y = col / rz, z = col - y * rz; cnt[z * ry + y] = run; }   // columns in (z, y) order: the order of the enumeration
+    }
+}
+// exclusive scan in place, one workgroup: rounds of 1024 x 16 entries — a thread's 16 values are loaded at once, scanned in registers,
+// the threads' totals by wave shuffles + one LDS exchange (a loop of dependent loads / block-wide sync steps took 25 us for 16 k entries)
+__global__ __launch_bounds__(1024) void grid_colscan_kernel(int* __restrict__ cnt, int n)
+{
+    __shared__ int wtot[16];
+    __shared__ int carry_s;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int carry = 0;
+    for (int r0 = 0; r0 < n; r0 += 1024 * 16) {
+        const int lo = r0 + t * 16;
+        int v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = lo + i < n ? cnt[lo + i] : 0;
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int c = v[i]; v[i] = s; s += c; }        // exclusive within the thread
+        int inc = s;                                                                     // inclusive scan of the threads' totals within the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        int wbase = 0;
+        for (int q = 0; q < wave; ++q) wbase += wtot[q];
+        const int base = carry + wbase + inc - s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) if (lo + i < n) cnt[lo + i] = base + v[i];
+        if (t == 1023) carry_s = base + s;
+        __syncthreads();
+        carry = carry_s;
+    }
+}
+__global__ void grid_xorder_kernel(const int64_t* __restrict__ idx, const uint16_t* __restrict__ pre, const int* __restrict__ base, int* __restrict__ order,
+                                   int ry, int rz, int Np)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Np) return;
+    const int64_t f = idx[n];
+    const int z = (int)(f % rz), y = (int)((f / rz) % ry);
+    order[base[z * ry + y] + pre[f]] = n;
 }
 
 template <typename T> __global__ void f32_to_f16_kernel(const float* __restrict__ in, _Float16* __restrict__ out, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (_Float16)in[i];
 }
 
+static int g_ngp_density_unroll = 1;   // tuning (include/dreg_nerf_tuning.h): hash-grid levels whose corner gathers are in flight together (1, 2, 4, 8)
+static void ngp_density_launch(const float* x, const void* table, const void* w1, const void* w2, float* density, void* raw, const NgpLevels& lv,
+                               const float* aabb, int Np, int contract, void* stream, const int* order = nullptr, int xslot = 0)
+{
+#define NGP_D(U) hipLaunchKernelGGL(ngp_density_kernel<U>, dim3((Np + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, (const _Float16*)table, \
+                                    (const _Float16*)w1, (const _Float16*)w2, density, (_Float16*)raw, lv, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np, contract, nullptr, order, xslot)
+    if (g_ngp_density_unroll == 8) NGP_D(8); else if (g_ngp_density_unroll == 4) NGP_D(4); else if (g_ngp_density_unroll == 2) NGP_D(2); else NGP_D(1);
+#undef NGP_D
+}
+static int g_ngp_xcd_levels = 1;       // tuning (include/dreg_nerf_tuning.h): with a workspace, encode per XCD-resident level pair first (ngp_encode_xcd_kernel)
+// two launches: the level features of all points into `feat` (fp16 [16][Np][2], XCD-partitioned levels), then the density MLP over them
+static void ngp_density_launch_xcd(const float* x, const void* table, const void* w1, const void* w2, float* density, void* raw, const NgpLevels& lv,
+                                   const float* aabb, int Np, int contract, void* feat, void* stream, const int* order, int xslot)
+{
+    const int nchunk = (Np + 63) / 64;
+    int wpx = 512;                      // waves per XCD: 32 CUs x 16 resident one-wave workgroups
+    if (wpx > nchunk) wpx = nchunk;
+    hipLaunchKernelGGL(ngp_encode_xcd_kernel, dim3(8 * wpx), dim3(64), 0, (hipStream_t)stream, x, (const _Float16*)table, (_Float16*)feat, lv,
+                       aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np, contract, wpx, order, xslot);
+    hipLaunchKernelGGL((ngp_density_kernel<1, true>), dim3(nchunk), dim3(64), 0, (hipStream_t)stream, x, (const _Float16*)table,
+                       (const _Float16*)w1, (const _Float16*)w2, density, (_Float16*)raw, lv, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np, contract,
+                       (const _Float16*)feat, order, xslot);
+}
 static int g_ngp_rgb_chunks = 1;     // tuning (include/dreg_nerf_tuning.h): shared-direction colour queries run the 16-point-chunk kernel (0: the 64-point kernel)
 
 extern "C" {
@@ -471,9 +638,7 @@ int dreg_ngp_density_fwd(const float* x, const void* table, const void* w1, cons
     if (Np == 0) return DREG_OK;
     NgpLevels lv;
     for (int l = 0; l < 16; ++l) { lv.offset[l] = offset[l]; lv.size[l] = size[l]; lv.res[l] = res[l]; lv.scale[l] = scale[l]; lv.hashed[l] = hashed[l]; }
-    hipLaunchKernelGGL(ngp_density_kernel, dim3((Np + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, (const _Float16*)table,
-                       (const _Float16*)w1, (const _Float16*)w2, density, (_Float16*)raw, lv,
-                       aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np, 0);
+    ngp_density_launch(x, table, w1, w2, density, raw, lv, aabb, Np, 0, stream);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
@@ -486,12 +651,29 @@ int dreg_ngp_density_fwd_contract(const float* x, const void* table, const void*
     if (Np == 0) return DREG_OK;
     NgpLevels lv;
     for (int l = 0; l < 16; ++l) { lv.offset[l] = offset[l]; lv.size[l] = size[l]; lv.res[l] = res[l]; lv.scale[l] = scale[l]; lv.hashed[l] = hashed[l]; }
-    hipLaunchKernelGGL(ngp_density_kernel, dim3((Np + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, (const _Float16*)table,
-                       (const _Float16*)w1, (const _Float16*)w2, density, (_Float16*)raw, lv,
-                       aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np, contract);
+    ngp_density_launch(x, table, w1, w2, density, raw, lv, aabb, Np, contract, stream);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
+// order (optional, device int32 [Np], a permutation of 0..Np-1): slot j of the launch works on point order[j] — outputs stay where the
+// point is; what changes is which points share a wave (dreg_grid_x_order: lanes along the tables' fastest axis).
+// The same with a caller-owned scratch buffer of dreg_ngp_density_workspace_bytes(Np) bytes: the hash-grid encoding then runs as its own
+// launch with every XCD working on two levels that stay in its L2 (ngp_encode_xcd_kernel), the MLP as a second one.  Same outputs, bit
+// for bit.  workspace = null (or too small): the fused kernel.
+size_t dreg_ngp_density_workspace_bytes(int Np) { return Np > 0 ? (size_t)16 * Np * 2 * sizeof(_Float16) : 0; }
+int dreg_ngp_density_fwd_ws(const float* x, const void* table, const void* w1, const void* w2, float* density, void* raw,
+                            const uint32_t* offset, const uint32_t* size, const uint32_t* res, const float* scale, const uint32_t* hashed,
+                            const float* aabb, int Np, int contract, void* workspace, size_t workspace_bytes, const int* order, int x_in_slot_order, void* stream)
+{
+    if (Np == 0) return DREG_OK;
+    NgpLevels lv;
+    for (int l = 0; l < 16; ++l) { lv.offset[l] = offset[l]; lv.size[l] = size[l]; lv.res[l] = res[l]; lv.scale[l] = scale[l]; lv.hashed[l] = hashed[l]; }
+    if (g_ngp_xcd_levels && workspace && workspace_bytes >= dreg_ngp_density_workspace_bytes(Np)) ngp_density_launch_xcd(x, table, w1, w2, density, raw, lv, aabb, Np, contract, workspace, stream, order, order ? x_in_slot_order : 0);
+    else ngp_density_launch(x, table, w1, w2, density, raw, lv, aabb, Np, contract, stream, order, order ? x_in_slot_order : 0);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+void dreg_ngp_set_xcd_levels(int on) { g_ngp_xcd_levels = on ? 1 : 0; }
 // colour for ONE viewing direction per point (NGPradianceField.query_rgb(dir, embedding) / forward(positions, directions),
 // conerf/radiance_fields/ngp.py:178-208): dirs fp32 [Np,3] as passed to query_rgb, raw fp16 [Np,16] -> rgb fp32 [Np,3].
 int dreg_ngp_rgb_dir_fwd(const void* raw, const void* w1, const void* w2, const void* w3, const float* dirs, float* rgb, int Np, void* stream)
@@ -567,6 +749,7 @@ int dreg_ngp_rgb_mean_fwd(const void* raw, const void* w1, const void* w2, const
     return DREG_OK;
 }
 void dreg_ngp_set_rgb_chunks(int on) { g_ngp_rgb_chunks = on ? 1 : 0; }
+void dreg_ngp_set_density_unroll(int n) { g_ngp_density_unroll = (n == 2 || n == 4 || n == 8) ? n : 1; }
 
 int dreg_grid_scatter7(const float* xyz, const float* rgb, const float* alpha, const int64_t* idx, const uint8_t* keep,
                        float* grid, int Np, void* stream)
@@ -577,12 +760,43 @@ int dreg_grid_scatter7(const float* xyz, const float* rgb, const float* alpha, c
     return DREG_OK;
 }
 
+// order[j] = position in idx (ascending flat indices (x * ry + y) * rz + z of the occupied cells of `binary`, byte [rx][ry][rz]) of the
+// j-th occupied cell in (z, y, x)-major enumeration, i.e. with x running fastest.  workspace: dreg_grid_x_order_workspace_bytes bytes.
+size_t dreg_grid_x_order_workspace_bytes(int rx, int ry, int rz) { return (size_t)rx * ry * rz * sizeof(uint16_t) + (size_t)ry * rz * sizeof(int) + 256; }
+int dreg_grid_x_order(const uint8_t* binary, const int64_t* idx, int* order, void* workspace, size_t workspace_bytes, int rx, int ry, int rz, int Np, void* stream)
+{
+    if (Np == 0) return DREG_OK;
+    if (!binary || !idx || !order || !workspace || workspace_bytes < dreg_grid_x_order_workspace_bytes(rx, ry, rz) || rx > 65535) return DREG_EINVAL;
+    uint16_t* pre = (uint16_t*)workspace;
+    int* cnt = (int*)((char*)workspace + (((size_t)rx * ry * rz * sizeof(uint16_t) + 255) / 256) * 256);
+    hipStream_t st = (hipStream_t)stream;
+    const int NS = (rx + 15) / 16;                  // x-segments per column
+    if (NS > 256) return DREG_EINVAL;
+    int COLS = 1;
+    while (COLS * 2 * NS <= 256) COLS *= 2;
+    hipLaunchKernelGGL(grid_xprefix_kernel, dim3((ry * rz + COLS - 1) / COLS), dim3(256), 0, st, binary, pre, cnt, rx, ry, rz, NS, COLS);
+    hipLaunchKernelGGL(grid_colscan_kernel, dim3(1), dim3(1024), 0, st, cnt, ry * rz);
+    hipLaunchKernelGGL(grid_xorder_kernel, dim3((Np + 255) / 256), dim3(256), 0, st, idx, pre, cnt, order, ry, rz, Np);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
 int dreg_grid_sample_points(const int64_t* idx, const float* jitter, float* world, int rx, int ry, int rz, const float* aabb,
                             int Np, void* stream)
 {
     if (Np == 0) return DREG_OK;
     hipLaunchKernelGGL(grid_sample_points_kernel, dim3((Np + 255) / 256), dim3(256), 0, (hipStream_t)stream, idx, jitter, world,
-                       rx, ry, rz, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np);
+                       rx, ry, rz, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np, (const int*)nullptr, (float*)nullptr);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// the same, and world_slot[j] = world[order[j]] (the positions in the lane order of dreg_grid_x_order) from the same launch
+int dreg_grid_sample_points_ordered(const int64_t* idx, const float* jitter, const int* order, float* world, float* world_slot,
+                                    int rx, int ry, int rz, const float* aabb, int Np, void* stream)
+{
+    if (Np == 0) return DREG_OK;
+    if (!order || !world_slot) return DREG_EINVAL;
+    hipLaunchKernelGGL(grid_sample_points_kernel, dim3((Np + 255) / 256), dim3(256), 0, (hipStream_t)stream, idx, jitter, world,
+                       rx, ry, rz, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np, order, world_slot);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

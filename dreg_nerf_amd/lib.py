@@ -181,8 +181,15 @@ SIGNATURES = {
     "dreg_ngp_rgb_mean_fwd": (I, [P] * 6 + [I, I, P]),
     "dreg_ngp_dir_bias": (I, [P, P, P, I, P]),
     "dreg_ngp_set_rgb_chunks": (None, [I]),
+    "dreg_ngp_set_density_unroll": (None, [I]),
     "dreg_ngp_alpha_keep": (I, [P, P, P, I, F, F, P]),
     "dreg_ngp_density_fwd_contract": (I, [P] * 6 + [P] * 5 + [P, I, I, P]),
+    "dreg_ngp_density_fwd_ws": (I, [P] * 6 + [P] * 5 + [P, I, I, P, Z, P, I, P]),
+    "dreg_grid_sample_points_ordered": (I, [P, P, P, P, P, I, I, I, P, I, P]),
+    "dreg_grid_x_order_workspace_bytes": (Z, [I, I, I]),
+    "dreg_grid_x_order": (I, [P, P, P, P, Z, I, I, I, I, P]),
+    "dreg_ngp_density_workspace_bytes": (Z, [I]),
+    "dreg_ngp_set_xcd_levels": (None, [I]),
     "dreg_ngp_rgb_dir_fwd": (I, [P] * 6 + [I, P]),
     "dreg_grid_scatter7": (I, [P] * 6 + [I, P]),
     "dreg_grid_sample_points": (I, [P, P, P, I, I, I, P, I, P]),

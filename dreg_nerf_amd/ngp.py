@@ -120,8 +120,10 @@ class NGPradianceField(nn.Module):
         return c[1]
 
     @torch.no_grad()
-    def query_raw(self, x: torch.Tensor):
-        """x [N,3] world -> (density fp32 [N], raw fp16 [N,16])."""
+    def query_raw(self, x: torch.Tensor, order: Optional[torch.Tensor] = None, x_in_slot_order: bool = False):
+        """x [N,3] world -> (density fp32 [N], raw fp16 [N,16]).  order (optional int32 [N] permutation): which points share a wave
+        (SampleGrid.query_dense passes the x-fastest order of its cells); results do not depend on it and stay indexed by point.
+        x_in_slot_order: x[j] is the position of point order[j] (then read contiguously)."""
         lib = L.load()
         import ctypes
         base16, _ = self._prepared()
@@ -130,10 +132,14 @@ class NGPradianceField(nn.Module):
         density = torch.empty(n, dtype=torch.float32, device=x.device)
         raw = torch.empty(n, 16, dtype=torch.float16, device=x.device)
         aabb = (ctypes.c_float * 6)(*self._aabb_host())
-        # unbounded: contract_to_unisphere(x, aabb) before the hash grid (ngp.py:41-63,163-164)
-        L.check(lib.dreg_ngp_density_fwd_contract(L.ptr(x), base16.data_ptr() + 3072 * 2, base16.data_ptr(), base16.data_ptr() + 2048 * 2,
-                                                  L.ptr(density), L.ptr(raw), *self._levels, aabb, n, int(bool(self.unbounded)), L.stream()),
-                "dreg_ngp_density_fwd_contract")
+        # unbounded: contract_to_unisphere(x, aabb) before the hash grid (ngp.py:41-63,163-164).  Queries of a block's size go through the
+        # two-launch form (hash-grid levels pinned to the XCDs' L2s: csrc/ngp.hip); a handful of points through the fused kernel
+        nws = int(lib.dreg_ngp_density_workspace_bytes(n)) if n >= 16384 else 0
+        ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
+        L.check(lib.dreg_ngp_density_fwd_ws(L.ptr(x), base16.data_ptr() + 3072 * 2, base16.data_ptr(), base16.data_ptr() + 2048 * 2,
+                                            L.ptr(density), L.ptr(raw), *self._levels, aabb, n, int(bool(self.unbounded)), L.ptr(ws), nws,
+                                            L.ptr(order) if order is not None else None, int(bool(x_in_slot_order and order is not None)), L.stream()),
+                "dreg_ngp_density_fwd_ws")
         return density, raw
 
     @torch.no_grad()
@@ -318,8 +324,22 @@ class SampleGrid(nn.Module):
             hc = self.__dict__["_host_consts"] = (key, [int(v) for v in self.resolution.tolist()], [float(v) for v in self._roi_aabb.tolist()])
         rx, ry, rz = hc[1]
         aabb = (ctypes.c_float * 6)(*hc[2])
-        L.check(lib.dreg_grid_sample_points(L.ptr(indices), L.ptr(jitter), L.ptr(world), rx, ry, rz, aabb, n, L.stream()), "dreg_grid_sample_points")
-        density, raw = radiance_field.query_raw(world)
+        # the cells come z-fastest, the hash grid's tables are x-fastest: an order in which a wave's 64 lanes run along x (csrc/ngp.hip)
+        order = None
+        if n >= 16384 and rx <= 65535:
+            binary = self._binary.to(device)
+            binary = binary.contiguous().view(torch.uint8) if binary.dtype == torch.bool else binary.to(torch.uint8).contiguous()
+            nb = int(lib.dreg_grid_x_order_workspace_bytes(rx, ry, rz))
+            ows = torch.empty(nb, dtype=torch.uint8, device=device)
+            order = torch.empty(n, dtype=torch.int32, device=device)
+            L.check(lib.dreg_grid_x_order(L.ptr(binary), L.ptr(indices), L.ptr(order), L.ptr(ows), nb, rx, ry, rz, n, L.stream()), "dreg_grid_x_order")
+            world_slot = torch.empty(n, 3, dtype=torch.float32, device=device)
+            L.check(lib.dreg_grid_sample_points_ordered(L.ptr(indices), L.ptr(jitter), L.ptr(order), L.ptr(world), L.ptr(world_slot), rx, ry, rz, aabb, n,
+                                                        L.stream()), "dreg_grid_sample_points_ordered")
+            density, raw = radiance_field.query_raw(world_slot, order=order, x_in_slot_order=True)
+        else:
+            L.check(lib.dreg_grid_sample_points(L.ptr(indices), L.ptr(jitter), L.ptr(world), rx, ry, rz, aabb, n, L.stream()), "dreg_grid_sample_points")
+            density, raw = radiance_field.query_raw(world)
         rgb = radiance_field.query_rgb_mean(raw, self._viewdirs.to(device))
         alpha = torch.empty(n, dtype=torch.float32, device=device)
         keep = torch.empty(n, dtype=torch.uint8, device=device)

@@ -423,6 +423,24 @@ int dreg_ngp_rgb_mean_fwd(const void* raw, const void* w1, const void* w2, const
 int dreg_ngp_density_fwd_contract(const float* x, const void* table, const void* w1, const void* w2, float* density, void* raw,
                                   const uint32_t* offset, const uint32_t* size, const uint32_t* res, const float* scale, const uint32_t* hashed,
                                   const float* aabb, int Np, int contract, void* stream);
+/* the same with a caller-owned scratch buffer (dreg_ngp_density_workspace_bytes(Np) bytes, fp16 [16][Np][2] level features): the hash-grid
+ * encoding (tcnn HashGrid of ngp.py:92-110) runs as its own launch in which every XCD looks up only two of the 16 levels — their tables
+ * stay in that XCD's 4 MB L2 instead of streaming 128-byte lines from the Infinity Cache for 4-byte corners — and the density MLP reads
+ * the features.  Same outputs, bit for bit.  workspace null / too small: the fused kernel of dreg_ngp_density_fwd_contract. */
+size_t dreg_ngp_density_workspace_bytes(int Np);
+int dreg_ngp_density_fwd_ws(const float* x, const void* table, const void* w1, const void* w2, float* density, void* raw,
+                            const uint32_t* offset, const uint32_t* size, const uint32_t* res, const float* scale, const uint32_t* hashed,
+                            const float* aabb, int Np, int contract, void* workspace, size_t workspace_bytes, const int* order, int x_in_slot_order, void* stream);
+/* order (optional; null = the points as given): a permutation (device int32 [Np]); slot j of the launch works on point order[j], outputs
+ * stay at the point's own index.  Consecutive points of a block's query (sample_grid.py:223-231: ascending flat indices, z fastest) differ
+ * along the SLOWEST axis of the hash grid's tables, so a wave's 64 corner reads hit 64 cache lines; dreg_grid_x_order builds the order in
+ * which x runs fastest from the occupancy volume (byte [rx][ry][rz]) and the ascending index list. */
+/* x_in_slot_order = 1 (with an order): x[j] already IS the position of point order[j] (dreg_grid_sample_points_ordered writes that array
+ * next to the ordinary one), so the coordinates are read contiguously; outputs still go to the point's own index. */
+int dreg_grid_sample_points_ordered(const int64_t* idx, const float* jitter, const int* order, float* world, float* world_slot,
+                                    int rx, int ry, int rz, const float* aabb, int Np, void* stream);
+size_t dreg_grid_x_order_workspace_bytes(int rx, int ry, int rz);
+int dreg_grid_x_order(const uint8_t* binary, const int64_t* idx, int* order, void* workspace, size_t workspace_bytes, int rx, int ry, int rz, int Np, void* stream);
 /* one viewing direction per point: NGPradianceField.query_rgb(dir, embedding) / forward (conerf/radiance_fields/ngp.py:178-208) */
 int dreg_ngp_rgb_dir_fwd(const void* raw, const void* w1, const void* w2, const void* w3, const float* dirs, float* rgb, int Np, void* stream);
 /* jittered sample of every occupied cell mapped to world space (sample_grid.py:226-242, AABB contraction) */

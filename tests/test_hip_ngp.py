@@ -179,3 +179,51 @@ def test_dense_query_at_the_baseline_size_128():
     flat = grid.view(-1, 7)
     assert torch.equal(flat[mask, :3], world[dmask]) and torch.equal(flat[mask, 6], alpha[dmask].reshape(-1))
     assert int((flat.abs().sum(dim=1) > 0).sum()) <= int(dmask.sum())
+
+
+@pytest.mark.parametrize("unbounded", [False, True])
+def test_density_query_forms_agree_bit_for_bit(unbounded):
+    """The density query of a block's size has three forms (csrc/ngp.hip): the fused kernel, hash-grid levels pinned to the XCDs' L2s
+    (two launches through a workspace), and either with an ORDER that lets a wave's lanes run along the tables' fastest axis.  Same
+    arithmetic per point in each: identical density / raw; the order is what dreg_grid_x_order builds from the occupancy volume."""
+    from dreg_nerf_amd import lib as L
+    lib = L.load()
+    f = ngp.NGPradianceField(AABB, unbounded=unbounded)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        p = f.mlp_base.params
+        p[:3072] = torch.randn(3072, generator=g) * 0.25
+        p[3072:] = torch.randn(p.numel() - 3072, generator=g) * 0.5
+    f = f.to(DEV)
+    res = (40, 36, 44)                                                     # three different extents: the axis roles must not mix
+    binary = (torch.rand(res, generator=g) < 0.45)
+    binary[0, 0, 0] = True; binary[-1, -1, -1] = True
+    idx = torch.nonzero(binary.flatten())[:, 0].to(DEV)
+    n = idx.shape[0]
+    assert n >= 16384                                                      # the size from which query_raw takes the two-launch form
+    # the order against plain torch: sort the ascending list by (z, y, x)
+    rx, ry, rz = res
+    z, y, x = idx % rz, (idx // rz) % ry, idx // (rz * ry)
+    want = torch.argsort((z * ry + y) * rx + x, stable=True).int()
+    nb = int(lib.dreg_grid_x_order_workspace_bytes(rx, ry, rz))
+    ows = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    order = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+    L.check(lib.dreg_grid_x_order(L.ptr(binary.to(DEV).contiguous().view(torch.uint8)), L.ptr(idx), L.ptr(order), L.ptr(ows), nb, rx, ry, rz, n, L.stream()), "dreg_grid_x_order")
+    assert torch.equal(order, want)
+    cells = torch.stack([x, y, z], 1).float()
+    pts = ((cells + torch.rand(n, 3, generator=g).to(DEV)) / torch.tensor(res, device=DEV) * 3.4 - 1.7).contiguous()   # some points outside the aabb
+    out = {}
+    try:
+        for xcd in (0, 1):
+            lib.dreg_ngp_set_xcd_levels(xcd)
+            for name, o in (("plain", None), ("ordered", order)):
+                d, raw = f.query_raw(pts, order=o)
+                out[(xcd, name)] = (d.clone(), raw.clone())
+            d, raw = f.query_raw(pts[order.long()].contiguous(), order=order, x_in_slot_order=True)      # coordinates handed over in lane order
+            out[(xcd, "ordered, coordinates in slot order")] = (d.clone(), raw.clone())
+    finally:
+        lib.dreg_ngp_set_xcd_levels(1)
+    ref = out[(0, "plain")]
+    assert torch.isfinite(ref[0]).all() and (ref[0] > 0).any() and (unbounded or (ref[0] == 0).any())      # (bounded: the points outside the aabb)
+    for k, v in out.items():
+        assert torch.equal(v[0], ref[0]) and torch.equal(v[1], ref[1]), k
