@@ -317,6 +317,20 @@ class SampleGrid(nn.Module):
         if jitter is None:
             jitter = torch.rand(n, 3, dtype=torch.float32, device=device)
         jitter = jitter.to(device).contiguous()
+        world, density, raw = self.positions_and_density(radiance_field, indices, jitter, device)
+        rgb = radiance_field.query_rgb_mean(raw, self._viewdirs.to(device))
+        alpha = torch.empty(n, dtype=torch.float32, device=device)
+        keep = torch.empty(n, dtype=torch.uint8, device=device)
+        L.check(lib.dreg_ngp_alpha_keep(L.ptr(density), L.ptr(alpha), L.ptr(keep), n, float(self._delta), float(density_thre), L.stream()), "dreg_ngp_alpha_keep")
+        return world, rgb, alpha[:, None], indices, keep.view(torch.bool)
+
+    @torch.no_grad()
+    def positions_and_density(self, radiance_field: NGPradianceField, indices: torch.Tensor, jitter: torch.Tensor, device):
+        """World positions of the jittered samples of the cells `indices` (ascending flat indices) and the field's density / raw features
+        there: (world [n,3], density [n], raw fp16 [n,16]), all indexed like `indices`."""
+        lib = L.load()
+        import ctypes
+        n = indices.shape[0]
         world = torch.empty(n, 3, dtype=torch.float32, device=device)
         hc = self.__dict__.get("_host_consts")      # resolution / aabb on the host, cached: .tolist() of device buffers is a sync each
         key = (self.resolution.data_ptr(), self.resolution._version, self._roi_aabb.data_ptr(), self._roi_aabb._version)
@@ -340,11 +354,7 @@ class SampleGrid(nn.Module):
         else:
             L.check(lib.dreg_grid_sample_points(L.ptr(indices), L.ptr(jitter), L.ptr(world), rx, ry, rz, aabb, n, L.stream()), "dreg_grid_sample_points")
             density, raw = radiance_field.query_raw(world)
-        rgb = radiance_field.query_rgb_mean(raw, self._viewdirs.to(device))
-        alpha = torch.empty(n, dtype=torch.float32, device=device)
-        keep = torch.empty(n, dtype=torch.uint8, device=device)
-        L.check(lib.dreg_ngp_alpha_keep(L.ptr(density), L.ptr(alpha), L.ptr(keep), n, float(self._delta), float(density_thre), L.stream()), "dreg_ngp_alpha_keep")
-        return world, rgb, alpha[:, None], indices, keep.view(torch.bool)
+        return world, density, raw
 
     @torch.no_grad()
     def query_radiance_and_density_from_camera(self, radiance_field, occupancy_grid, meta_data, device,
