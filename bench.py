@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--cpu-samples", type=int, default=3, help="timed samples of the CPU baseline (after one warm-up)")
     ap.add_argument("--occupancy-sweep", action="store_true", help="also time the step on shells of 1e4 .. 1e5 occupied voxels per side (active-set head)")
     ap.add_argument("--ngp", action="store_true", help="BASELINE.json configs[3] instead: NGP grid extraction of 128^3 NeRF blocks (dense hash-MLP query)")
+    ap.add_argument("--eval", action="store_true", help="BASELINE.json configs[4]-style instead: forward-only registration (eval mode, no gradients) of synthetic pairs with a known pose")
     ap.add_argument("--ngp-radius", type=float, default=1.0, help="--ngp: occupied cells = ball of this radius in the [-1.5,1.5]^3 block")
     return ap.parse_args()
 
@@ -153,6 +154,53 @@ def ngp_cpu_baseline(radius: float, cores: int):
             "sample": f"oracle/ngp_oracle.dense_query (hash grid + density MLP + 18-direction colour MLP, fp16-emulating torch CPU) on the bench's block: {n} occupied cells "
                       f"of a 128^3 grid, warm-up {warm:.2f}s, {len(ts)} timed blocks, median {dt:.2f}s",
             "measured_seconds": ts}
+
+
+def eval_bench(args, rank, world, dev):
+    """The eval_nerf_regtr.py path as a throughput line: model.eval() (BatchNorm on running statistics), no gradients, `--pairs` pairs per
+    call and rank (scenes are independent: replicas, no collective); RRE / RTE of the last call's poses against the pair's known relative
+    pose (random-init weights: the errors say nothing about registration quality, only that the metric path runs).  A "step" = one call."""
+    from dreg_nerf_amd import synth
+    from dreg_nerf_amd.losses import rre_rte
+    from dreg_nerf_amd.regtr import NeRFRegTr
+    torch.manual_seed(3407)
+    model = NeRFRegTr(precision=args.precision).to(dev).eval()
+    pose = synth.fixed_pose()
+    batch = []
+    for i in range(args.pairs):
+        s = 1 + 2 * (rank * args.pairs + i)
+        d = synth.shell_pair(args.res, s, s + 1, pose=pose)
+        batch.append({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()})
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            preds = model.forward_batch(batch)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            preds = model.forward_batch(batch)
+        sync()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    if rank != 0:
+        return
+    errs = [rre_rte(p["pose"][-1].float().cpu(), b["pose"].reshape(1, 4, 4).float().cpu()) for p, b in zip(preds, batch)]
+    print(json.dumps({
+        "metric": "nerf_pairs_per_sec_regtr_eval_forward_128", "value": args.pairs * world * args.steps / el, "unit": "pairs/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"RegTR forward only (eval mode, no gradients), shell-R synthetic pairs, {args.res}^3 grids, {args.pairs} pairs per call and GPU, random-init weights",
+                   "resolution": args.res, "pairs_per_call": args.pairs, "parallelism": f"replicas x{world}"},
+        "rre_deg_mean": float(sum(float(e[0]) for e in errs) / len(errs)), "rte_mean": float(sum(float(e[1]) for e in errs) / len(errs)),
+        "note": "RRE / RTE at random initialisation: the metric path (eval_nerf_regtr.py:275-301) runs; no trained checkpoint without network access"}), flush=True)
 
 
 def ngp_bench(args, rank, world, dev):
@@ -302,8 +350,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    if args.ngp:
-        ngp_bench(args, rank, world, dev)
+    if args.ngp or args.eval:
+        (ngp_bench if args.ngp else eval_bench)(args, rank, world, dev)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()

@@ -80,3 +80,21 @@ def test_grid_extraction_from_block_checkpoint(tmp_path):
         assert xyz.shape == (m.numel(), 3) and rgb.shape == (m.numel(), 3)
         assert torch.allclose(torch.from_numpy(xyz).float(), rows[:, :3], atol=1e-6)
         assert torch.equal(torch.from_numpy(rgb).long(), torch.clamp(torch.round(rows[:, 3:6].double() * 255.0), 0, 255).long())
+
+
+def test_bench_eval_and_ngp_lines():
+    """`bench.py --eval` (forward-only registration, RRE / RTE against the known pose) and `bench.py --ngp` (grid extraction) print one
+    JSON line each with the contract's keys."""
+    import json
+    for flags, metric in ((["--eval", "--res", "64", "--pairs", "1", "--steps", "2", "--warmup", "1"], "nerf_pairs_per_sec_regtr_eval_forward_128"),
+                          (["--ngp", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], "ngp_grid_extraction_blocks_per_sec_128")):
+        out = _run(["bench.py"] + flags, timeout=900)
+        lines = [l for l in out.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out[-2000:]
+        d = json.loads(lines[0])
+        assert d["metric"] == metric and d["value"] > 0 and d["n_gpus"] == 1 and d["steps"] == 2 and d["higher_is_better"] is True
+        assert "workload" in d["config"] and d["data"] == "synthetic"
+        if "--eval" in flags:
+            assert 0.0 <= d["rre_deg_mean"] <= 180.0 and d["rte_mean"] >= 0.0
+        else:
+            assert d["roofline"]["density_kernel"]["avg_launch_ms"] > 0
