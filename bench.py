@@ -438,6 +438,16 @@ def main():
             rf["traffic_source"] = src
         if rf["traffic"]:
             rf["traffic_over_compulsory"] = rf["traffic"] / max(rf["compulsory_bytes_per_launch"], 1.0)
+        # the label is ONE template instantiation serving several layer shapes, MFMA-bound 3^3 layers and HBM-bound 1^3 ones alike:
+        # its launches by shape (largest first), each against the roof it is closer to
+        shapes = []
+        for (n, l), (c, ms_l, fl_l) in sorted(((k, v) for k, v in by_label.items() if k[0] == name), key=lambda kv: -kv[1][1]):
+            if ms_l <= 0:
+                continue
+            tf, gb = fl_l / (ms_l * 1e-3) / 1e12, label_bytes(l) * c / (ms_l * 1e-3) / 1e9
+            shapes.append({"shape": l, "launches": c, "avg_launch_ms": ms_l / max(c, 1), "TFLOPs": tf, "mfma_frac": tf / peak,
+                           "compulsory_GBps": gb, "hbm_frac": gb / HBM_PEAK_GBPS, "bound": "mfma" if tf / peak >= gb / HBM_PEAK_GBPS else "hbm"})
+        rf["by_shape"] = shapes[:8]
         if rf["hbm_frac"] > rf["frac"]:   # a family of small / 1x1x1 convolutions sits closer to the HBM roof than to the MFMA roof
             rf.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBPS,
                        "mfma_TFLOPs": ach, "mfma_frac": ach / peak})
