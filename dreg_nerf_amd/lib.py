@@ -195,6 +195,9 @@ SIGNATURES = {
     "dreg_grid_sample_points": (I, [P, P, P, I, I, I, P, I, P]),
     # visibility.hip
     "dreg_surface_visibility": (I, [P] * 7 + [P] * 5 + [P, P, P] + [I] * 5 + [F, F, F, F, P]),
+    "dreg_surface_visibility_queue": (I, [P] * 7 + [P] * 5 + [P, P, P] + [I] * 5 + [F, F, F, F, P, P, P]),
+    "dreg_occupancy_coarse_bits": (I, [P, P, I, I, I, P]),
+    "dreg_visibility_set_waves": (None, [I]),
 }
 
 

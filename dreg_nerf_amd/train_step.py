@@ -26,10 +26,14 @@ def nerf_labels(pred, data):
     from .visibility import compute_visibility_score
     nl = pred["src_kp_warped"][0].shape[0]
     with torch.no_grad():
-        s_gt = compute_visibility_score([pred["src_kp"][0].expand(nl, -1, -1)], data["src_nerf_path"])[0]
-        t_gt = compute_visibility_score([pred["tgt_kp"][0].expand(nl, -1, -1)], data["tgt_nerf_path"])[0]
-        s_tl = compute_visibility_score([pred["src_kp_warped"][0].detach()], data["src_nerf_path"])[0]
-        t_tl = compute_visibility_score([pred["tgt_kp_warped"][0].detach()], data["tgt_nerf_path"])[0]
+        # the reference marches the key points once per decoder layer (the same [N,3] expanded nl times: six identical label sets) and
+        # makes four calls per pair; here every point set is marched once and both sets of a block share one launch: [1 + nl, N, 3]
+        out = []
+        for side in ("src", "tgt"):
+            kp, warped = pred[side + "_kp"][0], pred[side + "_kp_warped"][0].detach()
+            both = compute_visibility_score([torch.cat([kp.reshape(1, -1, 3), warped], 0)], data[side + "_nerf_path"])[0]
+            out.append((both[:1].expand(nl, -1, -1), both[1:]))
+    (s_gt, s_tl), (t_gt, t_tl) = out
     return s_gt, t_gt, s_tl, t_tl
 
 

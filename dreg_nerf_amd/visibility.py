@@ -20,6 +20,8 @@ from . import ngp
 _block_cache: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
 _block_cache_bytes = 0
 BLOCK_CACHE_MAX_BYTES = int(os.environ.get("DREG_BLOCK_CACHE_MB", "2048")) << 20
+COARSE = True             # the persistent kernel walks empty space through a coarse occupancy grid (one bit per 4^3 cells) held in LDS
+PERSISTENT = True         # surface_visibility through the persistent ray-queue kernel (False: one lock-step launch of 64 rays per wave)
 
 
 def _block_bytes(field, binary) -> int:
@@ -60,29 +62,56 @@ def load_block(path: str, device):
     while _block_cache and _block_cache_bytes + nbytes > BLOCK_CACHE_MAX_BYTES:
         _, old = _block_cache.popitem(last=False)
         _block_cache_bytes -= old[3]
-    _block_cache[key] = (field, binary, {k: meta[k] for k in ("aabb", "render_step_size", "cone_angle", "alpha_thre", "camera_poses")}, nbytes)
+    kept = {k: meta[k] for k in ("aabb", "render_step_size", "cone_angle", "alpha_thre", "camera_poses")}
+    # what every call needs, converted ONCE: camera centres on the device, the aabb as host floats (a .tolist() of a device tensor or an
+    # H2D copy per call is a host sync per call: eight per training step, each draining the queue the host had run ahead on)
+    kept["cam_centres_dev"] = torch.as_tensor(meta["camera_poses"])[..., :3, 3].float().contiguous().to(device)
+    kept["aabb_host"] = [float(v) for v in (meta["aabb"].tolist() if torch.is_tensor(meta["aabb"]) else meta["aabb"])]
+    kept["binary_u8"] = binary.contiguous().view(torch.uint8) if binary.dtype == torch.bool else binary.to(torch.uint8).contiguous()
+    kept["coarse_bits"] = coarse_occupancy_bits(kept["binary_u8"])
+    _block_cache[key] = (field, binary, kept, nbytes)
     _block_cache_bytes += nbytes
     return _block_cache[key][:3]
 
 
 @torch.no_grad()
+def coarse_occupancy_bits(binary_u8: torch.Tensor) -> torch.Tensor:
+    """uint8 [rx,ry,rz] occupancy -> int32 words, one bit per 4^3 block (set: some cell of the block is occupied)."""
+    lib = L.load()
+    rx, ry, rz = binary_u8.shape
+    nbits = ((rx + 3) // 4) * ((ry + 3) // 4) * ((rz + 3) // 4)
+    bits = torch.zeros((nbits + 31) // 32, dtype=torch.int32, device=binary_u8.device)
+    L.check(lib.dreg_occupancy_coarse_bits(L.ptr(binary_u8), L.ptr(bits), rx, ry, rz, L.stream()), "dreg_occupancy_coarse_bits")
+    return bits
+
+
+@torch.no_grad()
 def surface_visibility(points: torch.Tensor, cam_centres: torch.Tensor, field: ngp.NGPradianceField, binary: torch.Tensor,
                        roi_aabb, scene_aabb, render_step_size: float, cut_off: float = 0.5, early_stop_eps: float = 1e-4,
-                       alpha_thre: float = 0.0) -> torch.Tensor:
+                       alpha_thre: float = 0.0, coarse_bits: torch.Tensor = None) -> torch.Tensor:
     """points [Np,3], cam_centres [Nc,3] (device) -> bool [Np]: visible from at least one camera with surface field >= cut_off."""
     lib = L.load()
     base16, _ = field._prepared()
     pts = points.reshape(-1, 3).contiguous().float()
     cams = cam_centres.reshape(-1, 3).contiguous().float().to(pts.device)
-    label = torch.zeros(pts.shape[0], dtype=torch.int32, device=pts.device)
-    b8 = binary.to(torch.uint8).contiguous()
+    # labels [Np] int32 followed by the ray queue's counter (8 bytes) in one zeroed buffer
+    buf = torch.zeros(pts.shape[0] + 2 + (pts.shape[0] & 1), dtype=torch.int32, device=pts.device)
+    label = buf[:pts.shape[0]]
+    b8 = binary if binary.dtype == torch.uint8 and binary.is_contiguous() else (binary.contiguous().view(torch.uint8) if binary.dtype == torch.bool else binary.to(torch.uint8).contiguous())
     f6 = lambda v: (ctypes.c_float * 6)(*[float(t) for t in (v.tolist() if torch.is_tensor(v) else v)])
-    L.check(lib.dreg_surface_visibility(L.ptr(cams), L.ptr(pts), L.ptr(b8), L.ptr(label),
-                                        base16.data_ptr() + 3072 * 2, base16.data_ptr(), base16.data_ptr() + 2048 * 2,
-                                        *field._levels, f6(roi_aabb), f6(scene_aabb), f6(field.aabb),
-                                        b8.shape[0], b8.shape[1], b8.shape[2], cams.shape[0], pts.shape[0],
-                                        float(render_step_size), float(cut_off), float(early_stop_eps), float(alpha_thre), L.stream()),
-            "dreg_surface_visibility")
+    common = (L.ptr(cams), L.ptr(pts), L.ptr(b8), L.ptr(label),
+              base16.data_ptr() + 3072 * 2, base16.data_ptr(), base16.data_ptr() + 2048 * 2,
+              *field._levels, f6(roi_aabb), f6(scene_aabb), f6(field._aabb_host()),
+              b8.shape[0], b8.shape[1], b8.shape[2], cams.shape[0], pts.shape[0],
+              float(render_step_size), float(cut_off), float(early_stop_eps), float(alpha_thre))
+    if PERSISTENT:     # lanes refilled from a ray queue, labelled points not marched again (csrc/visibility.hip)
+        qoff = (pts.shape[0] + (pts.shape[0] & 1)) * 4
+        if coarse_bits is None and COARSE:
+            coarse_bits = coarse_occupancy_bits(b8)
+        L.check(lib.dreg_surface_visibility_queue(*common, buf.data_ptr() + qoff, L.ptr(coarse_bits) if (coarse_bits is not None and COARSE) else None, L.stream()),
+                "dreg_surface_visibility_queue")
+    else:
+        L.check(lib.dreg_surface_visibility(*common, L.stream()), "dreg_surface_visibility")
     return label > 0
 
 
@@ -99,8 +128,7 @@ def compute_visibility_score(xyz_list: List[torch.Tensor], nerf_model_path: str,
             density, _ = field.query_raw(xyz.reshape(-1, 3))
             out.append(torch.clip(1 - torch.exp(-delta * density), 0, 1).view(nl, npnt, 1))
             continue
-        cams = meta["camera_poses"][..., :3, 3].to(device)
-        lab = surface_visibility(xyz.reshape(-1, 3), cams, field, binary, meta["aabb"], meta["aabb"], meta["render_step_size"],
-                                 cut_off, 1e-4, float(meta.get("alpha_thre", 0.0)))
+        lab = surface_visibility(xyz.reshape(-1, 3), meta["cam_centres_dev"], field, meta["binary_u8"], meta["aabb_host"], meta["aabb_host"],
+                                 meta["render_step_size"], cut_off, 1e-4, float(meta.get("alpha_thre", 0.0) or 0.0), coarse_bits=meta["coarse_bits"])
         out.append(lab.float().view(nl, npnt, 1))
     return out

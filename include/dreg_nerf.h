@@ -462,6 +462,17 @@ int dreg_surface_visibility(const float* cams, const float* pts, const uint8_t* 
                             const uint32_t* hashed, const float* roi_aabb, const float* scene_aabb, const float* model_aabb,
                             int rx, int ry, int rz, int Nc, int Np, float render_step_size, float cut_off, float early_stop_eps,
                             float alpha_thre, void* stream);
+/* the same labels from a persistent launch: a lane whose ray is decided takes the next ray from a queue, and rays of points that already
+ * carry the label are skipped (the label is an OR over the cameras).  queue: 8 bytes of device memory, zeroed by the caller on `stream`. */
+int dreg_surface_visibility_queue(const float* cams, const float* pts, const uint8_t* binary, int* label,
+                                  const void* table, const void* w1, const void* w2,
+                                  const uint32_t* offset, const uint32_t* size, const uint32_t* res, const float* scale, const uint32_t* hashed,
+                                  const float* roi_aabb, const float* scene_aabb, const float* model_aabb,
+                                  int rx, int ry, int rz, int Nc, int Np, float render_step_size, float cut_off, float early_stop_eps,
+                                  float alpha_thre, void* queue, const uint32_t* coarse_bits, void* stream);
+/* coarse_bits (optional): one bit per 4^3 block of `binary` (dreg_occupancy_coarse_bits; the buffer zeroed first): empty space is then
+ * walked in coarse cells looked up in LDS instead of fine cells looked up in global memory.  Same labels. */
+int dreg_occupancy_coarse_bits(const uint8_t* binary, uint32_t* bits, int rx, int ry, int rz, void* stream);
 
 #ifdef __cplusplus
 }

@@ -85,3 +85,36 @@ def test_surface_visibility_at_block_scale():
     assert decided.float().mean() > 0.8
     assert torch.equal(lab.cpu().int()[pick][decided], lab_ref[decided])
     assert 0 < int(lab.sum()) < 320000
+
+
+@pytest.mark.parametrize("wscale", [0.4, 3.0])
+def test_persistent_ray_queue_gives_the_lock_step_labels(wscale):
+    """The persistent kernel (lanes refilled from a ray queue, rays of already-labelled points skipped or abandoned, empty space walked
+    through a coarse occupancy grid in LDS) against the lock-step launch: a label is an OR over the cameras of per-ray decisions that
+    are computed identically, so the labels are EQUAL — for a transparent field (rays march through the whole block) and an opaque one."""
+    res = 128
+    g = torch.Generator().manual_seed(11)
+    f = ngp.NGPradianceField(AABB)
+    with torch.no_grad():
+        f.mlp_base.params[:3072] = torch.randn(3072, generator=g) * wscale
+        f.mlp_base.params[3072:] = torch.randn(f.mlp_base.params.numel() - 3072, generator=g)
+    f = f.to(DEV)
+    c = (torch.arange(res, dtype=torch.float32) + 0.5) / res * 3 - 1.5
+    X, Y, Z = torch.meshgrid(c, c, c, indexing="ij")
+    rad = torch.stack([X, Y, Z], -1).norm(dim=-1)
+    binary = ((rad > 0.6) & (rad < 0.9) & (X + 0.3 * Y > -0.7)).to(DEV)        # a shell with a piece cut away: some points see no surface
+    pts = ((torch.rand(6000, 3, generator=g) - 0.5) * 2.4).to(DEV)
+    cams = (torch.nn.functional.normalize(torch.randn(12, 3, generator=g), dim=-1) * 2.8).to(DEV)
+    cams[0] = torch.tensor([0.1, 0.0, 0.05])                                    # one camera inside the block
+    dt = 3 * 3 ** 0.5 / 512
+    labs = {}
+    try:
+        for persistent, coarse in ((False, False), (True, False), (True, True)):
+            visibility.PERSISTENT, visibility.COARSE = persistent, coarse
+            labs[(persistent, coarse)] = visibility.surface_visibility(pts, cams, f, binary, AABB, AABB, dt).clone()
+    finally:
+        visibility.PERSISTENT = visibility.COARSE = True
+    ref = labs[(False, False)]
+    assert 0 < int(ref.sum()) and (wscale > 1.0 or int(ref.sum()) < pts.shape[0])      # (the opaque field shows every point to some camera)
+    for k, v in labs.items():
+        assert torch.equal(v, ref), k
