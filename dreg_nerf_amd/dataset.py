@@ -278,10 +278,13 @@ class PrefetchLoader:
     Every yielded sample carries 'ready_event' (recorded on the loader stream after its last device op); NeRFRegTr.forward_batch waits for
     it on the GPU, never on the host."""
 
-    def __init__(self, dataset, indices, device=None, depth: int = 2):
+    def __init__(self, dataset, indices, device=None, depth: int = 2, prefetch_nerf_blocks: bool = True):
         import queue
         import threading
         self.ds, self.indices, self.device = dataset, list(indices), device
+        # NeRF blocks behind the step's overlap labels (train_nerf_regtr.py:186-199): loaded into visibility's block cache HERE, on the
+        # loader thread and stream, so that the training thread finds them resident (a block checkpoint is 60-160 MB on disk)
+        self.prefetch_nerf_blocks = prefetch_nerf_blocks and device is not None and torch.device(device).type == "cuda"
         self.q = queue.Queue(maxsize=max(depth, 1))
         self.stream = torch.cuda.Stream(device=device, priority=-1) if (device is not None and torch.device(device).type == "cuda") else None   # high priority: its few small kernels must not queue behind a saturated training stream
         self._err = None
@@ -302,6 +305,12 @@ class PrefetchLoader:
                 if self.stream is not None:
                     with torch.cuda.stream(self.stream):
                         sample = fetch(i)
+                        if self.prefetch_nerf_blocks:
+                            from . import visibility
+                            for k in ("src_nerf_path", "tgt_nerf_path"):
+                                path = sample.get(k)
+                                if path and os.path.exists(path):
+                                    visibility.load_block(path, torch.device(self.device))
                         ev = torch.cuda.Event()
                         ev.record(self.stream)
                     sample["ready_event"] = ev

@@ -6,6 +6,7 @@ The reference re-loads the block checkpoint from disk twice per call (confidence
 cached per path."""
 import collections
 import ctypes
+import threading
 from typing import Dict, List
 
 import os
@@ -19,21 +20,37 @@ from . import ngp
 # inference copy + the occupancy grid, ~80 MB: an Objaverse epoch touches 3,284 of them, the reference reloads from disk every call).
 _block_cache: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
 _block_cache_bytes = 0
-BLOCK_CACHE_MAX_BYTES = int(os.environ.get("DREG_BLOCK_CACHE_MB", "2048")) << 20
+_block_cache_lock = threading.Lock()     # the prefetching loader's thread fills the cache while the training thread reads it
+# Budget: DREG_BLOCK_CACHE_MB, default 40 % of the device's memory.  A cached block is its fp16 inference copy + occupancy grid (27 MB):
+# the 3,284 blocks of an Objaverse epoch are 90 GB — they stay resident on a 288 GB MI355X next to the training step's ~20-30 GB, so from
+# the second epoch on no block is read from disk again (the reference re-reads each block's checkpoint twice per call).
+_BLOCK_CACHE_ENV = os.environ.get("DREG_BLOCK_CACHE_MB")
+BLOCK_CACHE_MAX_BYTES = int(_BLOCK_CACHE_ENV) << 20 if _BLOCK_CACHE_ENV else None
+
+
+def _cache_budget(device) -> int:
+    if BLOCK_CACHE_MAX_BYTES is not None:
+        return BLOCK_CACHE_MAX_BYTES
+    if torch.device(device).type == "cuda":
+        return int(0.4 * torch.cuda.get_device_properties(device).total_memory)
+    return 2048 << 20
 COARSE = True             # the persistent kernel walks empty space through a coarse occupancy grid (one bit per 4^3 cells) held in LDS
 PERSISTENT = True         # surface_visibility through the persistent ray-queue kernel (False: one lock-step launch of 64 rays per wave)
 
 
 def _block_bytes(field, binary) -> int:
-    """fp32 parameters + the fp16 inference copy NGPradianceField._prepared() makes on first use + the occupancy grid."""
-    n_par = sum(p.numel() for p in field.parameters())
-    return n_par * 4 + n_par * 2 + sum(b.numel() * b.element_size() for b in field.buffers()) + binary.numel() * binary.element_size()
+    """What a cached block holds on the device: the fp16 inference copies (the fp32 parameters are released: freeze_for_inference),
+    the field's buffers and the occupancy grid."""
+    b16, c16 = field._prepared()
+    return (b16.numel() + c16.numel()) * 2 + sum(p.numel() * p.element_size() for p in field.parameters()) + \
+        sum(b.numel() * b.element_size() for b in field.buffers()) + binary.numel() * binary.element_size()
 
 
 def clear_block_cache():
     global _block_cache_bytes
-    _block_cache.clear()
-    _block_cache_bytes = 0
+    with _block_cache_lock:
+        _block_cache.clear()
+        _block_cache_bytes = 0
 
 
 def load_block(path: str, device):
@@ -41,10 +58,11 @@ def load_block(path: str, device):
     (keys: train_ngp_nerf.py:187-209), through a byte-bounded LRU cache."""
     global _block_cache_bytes
     key = (path, str(device))
-    hit = _block_cache.get(key)
-    if hit is not None:
-        _block_cache.move_to_end(key)
-        return hit[:3]
+    with _block_cache_lock:
+        hit = _block_cache.get(key)
+        if hit is not None:
+            _block_cache.move_to_end(key)
+            return hit[:3]
     from .checkpoint import CheckPointManager
     # the reference's two-pass load (conerf/loss/confidence_loss.py:25-50): meta data first, then the modules built from it
     meta = {k: None for k in ("aabb", "unbounded", "grid_resolution", "contraction_type", "render_step_size", "alpha_thre",
@@ -56,12 +74,9 @@ def load_block(path: str, device):
     field = ngp.NGPradianceField(meta["aabb"], unbounded=bool(meta["unbounded"]))
     occ = ngp.OccupancyGrid(meta["aabb"], meta["grid_resolution"], meta["contraction_type"])
     mgr.load_no_config(ckpt_path=path, models={"model": field, "occupancy_grid": occ}, map_location="cpu")
-    field = field.to(device).eval()
+    field = field.to(device).eval().freeze_for_inference()     # fp16 inference copies only: the block is never trained here
     binary = occ.binary.to(device)
     nbytes = _block_bytes(field, binary)
-    while _block_cache and _block_cache_bytes + nbytes > BLOCK_CACHE_MAX_BYTES:
-        _, old = _block_cache.popitem(last=False)
-        _block_cache_bytes -= old[3]
     kept = {k: meta[k] for k in ("aabb", "render_step_size", "cone_angle", "alpha_thre", "camera_poses")}
     # what every call needs, converted ONCE: camera centres on the device, the aabb as host floats (a .tolist() of a device tensor or an
     # H2D copy per call is a host sync per call: eight per training step, each draining the queue the host had run ahead on)
@@ -69,9 +84,17 @@ def load_block(path: str, device):
     kept["aabb_host"] = [float(v) for v in (meta["aabb"].tolist() if torch.is_tensor(meta["aabb"]) else meta["aabb"])]
     kept["binary_u8"] = binary.contiguous().view(torch.uint8) if binary.dtype == torch.bool else binary.to(torch.uint8).contiguous()
     kept["coarse_bits"] = coarse_occupancy_bits(kept["binary_u8"])
-    _block_cache[key] = (field, binary, kept, nbytes)
-    _block_cache_bytes += nbytes
-    return _block_cache[key][:3]
+    with _block_cache_lock:
+        if key in _block_cache:                                  # the other thread loaded it meanwhile
+            _block_cache.move_to_end(key)
+            return _block_cache[key][:3]
+        budget = _cache_budget(device)
+        while _block_cache and _block_cache_bytes + nbytes > budget:
+            _, old = _block_cache.popitem(last=False)
+            _block_cache_bytes -= old[3]
+        _block_cache[key] = (field, binary, kept, nbytes)
+        _block_cache_bytes += nbytes
+    return field, binary, kept
 
 
 @torch.no_grad()
@@ -130,5 +153,11 @@ def compute_visibility_score(xyz_list: List[torch.Tensor], nerf_model_path: str,
             continue
         lab = surface_visibility(xyz.reshape(-1, 3), meta["cam_centres_dev"], field, meta["binary_u8"], meta["aabb_host"], meta["aabb_host"],
                                  meta["render_step_size"], cut_off, 1e-4, float(meta.get("alpha_thre", 0.0) or 0.0), coarse_bits=meta["coarse_bits"])
+        if device.type == "cuda":
+            # the block's tensors may have been allocated on the loader's stream: tell the allocator that THIS stream reads them, so
+            # that an evicted block's memory is not handed out again while the march above is still running
+            cur = torch.cuda.current_stream(device)
+            for t in (field._prepared()[0], meta["binary_u8"], meta["coarse_bits"], meta["cam_centres_dev"]):
+                t.record_stream(cur)
         out.append(lab.float().view(nl, npnt, 1))
     return out

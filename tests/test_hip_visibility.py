@@ -118,3 +118,48 @@ def test_persistent_ray_queue_gives_the_lock_step_labels(wscale):
     assert 0 < int(ref.sum()) and (wscale > 1.0 or int(ref.sum()) < pts.shape[0])      # (the opaque field shows every point to some camera)
     for k, v in labs.items():
         assert torch.equal(v, ref), k
+
+
+def test_block_cache_keeps_inference_copies_and_is_filled_by_the_loader_thread(tmp_path):
+    """visibility.load_block keeps a block as its fp16 inference copy + occupancy grid (the fp32 parameters are released): ~27 MB instead
+    of ~80, so that an epoch's blocks stay resident; labels from a frozen block equal those from the block as loaded; the prefetching
+    loader loads the blocks of the samples it prepares on ITS thread, the training thread then only finds cache hits."""
+    from dreg_nerf_amd.dataset import PrefetchLoader
+    res = 32
+    g = torch.Generator().manual_seed(4)
+    f = ngp.NGPradianceField(AABB)
+    with torch.no_grad():
+        f.mlp_base.params[:3072] = torch.randn(3072, generator=g) * 1.5
+        f.mlp_base.params[3072:] = torch.randn(f.mlp_base.params.numel() - 3072, generator=g) * 2.0
+    binary = torch.rand(res, res, res, generator=g) < 0.3
+    poses = torch.eye(4)[None].repeat(4, 1, 1)
+    poses[:, :3, 3] = torch.tensor([[2.0, 0, 0], [0, 2.0, 0], [0, 0, 2.0], [-2.0, 0.5, 0]])
+    occ = ngp.OccupancyGrid(AABB, res)
+    occ._binary.copy_(binary)
+    paths = []
+    for k in range(2):
+        p = str(tmp_path / f"block_{k}.pth")
+        torch.save({"step": 1, "model": f.state_dict(), "occupancy_grid": occ.state_dict(), "aabb": AABB, "unbounded": False, "near_plane": None, "far_plane": None,
+                    "grid_resolution": res, "contraction_type": ngp.ContractionType.AABB, "render_step_size": 0.02,
+                    "alpha_thre": 0.0, "cone_angle": 0.0, "camera_poses": poses, "block_id": k}, p)
+        paths.append(p)
+    xyz = (torch.rand(3, 200, 3, generator=g) - 0.5).to(DEV) * 2
+    # reference labels: the field as loaded (fp32 parameters present)
+    want = visibility.surface_visibility(xyz.reshape(-1, 3), poses[:, :3, 3].to(DEV), f.to(DEV), binary.to(DEV), AABB, AABB, 0.02)
+    visibility.clear_block_cache()
+
+    class _DS:                                   # two samples naming the two blocks
+        def __len__(self): return 2
+        def __getitem__(self, i): return {"src_nerf_path": paths[i], "tgt_nerf_path": paths[1 - i], "x": torch.zeros(1, device=DEV)}
+    items = list(PrefetchLoader(_DS(), [0, 1], device=torch.device(DEV), depth=2))
+    assert len(items) == 2
+    assert len(visibility._block_cache) == 2     # filled by the loader thread
+    before = dict(visibility._block_cache)
+    got = visibility.compute_visibility_score([xyz], paths[0])[0]
+    assert {k: id(v[0]) for k, v in visibility._block_cache.items()} == {k: id(v[0]) for k, v in before.items()}    # a hit: nothing reloaded
+    assert torch.equal(got.view(-1) > 0, want)
+    field = next(iter(visibility._block_cache.values()))[0]
+    assert field.mlp_base.params.numel() == 0 and field._prepared()[0].numel() == 12602992                          # frozen: fp16 only
+    per_block = next(iter(visibility._block_cache.values()))[3]
+    assert per_block < 30 << 20, per_block
+    visibility.clear_block_cache()
