@@ -55,9 +55,9 @@ def _level_table(log2_hashmap_size: int = 19):
 
 
 class _Params(nn.Module):
-    def __init__(self, n):
+    def __init__(self, n, init: bool = True):
         super().__init__()
-        self.params = nn.Parameter(torch.zeros(n, dtype=torch.float32))
+        self.params = nn.Parameter(torch.zeros(n, dtype=torch.float32) if init else torch.empty(n, dtype=torch.float32))
 
 
 class NGPradianceField(nn.Module):
@@ -66,7 +66,8 @@ class NGPradianceField(nn.Module):
     query_density(..., return_feat=True) returns (density [N,1], feat [N,15] fp32) like the reference and caches nothing."""
 
     def __init__(self, aabb: Union[torch.Tensor, List[float]], num_dim: int = 3, use_viewdirs: bool = True,
-                 unbounded: bool = False, geo_feat_dim: int = 15, n_levels: int = 16, log2_hashmap_size: int = 19):
+                 unbounded: bool = False, geo_feat_dim: int = 15, n_levels: int = 16, log2_hashmap_size: int = 19, init: bool = True):
+        """init = False: the 12.6 M parameters are left uninitialised (a state_dict is loaded right away: visibility.load_block)."""
         super().__init__()
         if not isinstance(aabb, torch.Tensor):
             aabb = torch.tensor(aabb, dtype=torch.float32)
@@ -75,10 +76,11 @@ class NGPradianceField(nn.Module):
         self.unbounded = unbounded
         self.geo_feat_dim = geo_feat_dim
         self._levels, total = _level_table(log2_hashmap_size)
-        self.mlp_base = _Params(3072 + 2 * total)
-        self.color_mlp = _Params(7168)
+        self.mlp_base = _Params(3072 + 2 * total, init)
+        self.color_mlp = _Params(7168, init)
         self._prep = None
-        self.reset_parameters()
+        if init:
+            self.reset_parameters()
 
     def reset_parameters(self):
         with torch.no_grad():  # tcnn defaults: hash table U(-1e-4, 1e-4), MLP weights Xavier-uniform

@@ -63,17 +63,24 @@ def load_block(path: str, device):
         if hit is not None:
             _block_cache.move_to_end(key)
             return hit[:3]
-    from .checkpoint import CheckPointManager
-    # the reference's two-pass load (conerf/loss/confidence_loss.py:25-50): meta data first, then the modules built from it
-    meta = {k: None for k in ("aabb", "unbounded", "grid_resolution", "contraction_type", "render_step_size", "alpha_thre",
-                              "cone_angle", "camera_poses")}
-    mgr = CheckPointManager(verbose=False)
+    # The reference reads the file twice (conerf/loss/confidence_loss.py:25-50: meta data first, then the modules built from it).  Here it
+    # is opened ONCE and memory-mapped: only the tensors that are used — the field's parameters and the occupancy grid — are paged in,
+    # not the optimizer / scheduler state a training checkpoint also carries (train_ngp_nerf.py:187-209: 60 of its ~160 MB are needed).
     if not os.path.exists(path):
         raise FileNotFoundError(path)
-    mgr.load_no_config(ckpt_path=path, meta_data=meta, map_location="cpu")
-    field = ngp.NGPradianceField(meta["aabb"], unbounded=bool(meta["unbounded"]))
+    ngp.install_pickle_shims()
+    try:
+        snap = torch.load(path, map_location="cpu", weights_only=False, mmap=True)
+    except (RuntimeError, ValueError):                           # a checkpoint in the legacy (non-zip) format cannot be mapped
+        snap = torch.load(path, map_location="cpu", weights_only=False)
+    meta = {k: snap[k] for k in ("aabb", "unbounded", "grid_resolution", "contraction_type", "render_step_size", "alpha_thre",
+                                 "cone_angle", "camera_poses")}
+    with torch.device(device):                                   # parameters allocated on the device, uninitialised: the state_dict's tensors are copied straight in
+        field = ngp.NGPradianceField(meta["aabb"], unbounded=bool(meta["unbounded"]), init=False)
     occ = ngp.OccupancyGrid(meta["aabb"], meta["grid_resolution"], meta["contraction_type"])
-    mgr.load_no_config(ckpt_path=path, models={"model": field, "occupancy_grid": occ}, map_location="cpu")
+    field.load_state_dict(snap["model"])
+    occ.load_state_dict(snap["occupancy_grid"])
+    del snap
     field = field.to(device).eval().freeze_for_inference()     # fp16 inference copies only: the block is never trained here
     binary = occ.binary.to(device)
     nbytes = _block_bytes(field, binary)
