@@ -12,6 +12,7 @@
 // (alpha*T <= T can no longer reach cut_off) — no sample list, no later samples evaluated.  Labels of a point are OR-ed
 // over cameras with one atomic per hit.  nerfacc 0.3.5 / tcnn are absent from the reference tree: parity unpinned.
 #include "common.h"
+#include <cstring>
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
@@ -33,6 +34,7 @@ struct VisArgs {
     int max_steps;
     const uint32_t* coarse;   // optional: one bit per 4^3 block of `binary` (dreg_occupancy_coarse_bits), <= 32,768 bits; null = none
     int cx, cy, cz;           // its extents: ceil(r / 4)
+    unsigned long long* queue;   // persistent forms: this block's ray counter (zeroed by the caller)
 };
 
 __device__ __forceinline__ uint32_t vgrid_index(uint32_t x, uint32_t y, uint32_t z, uint32_t res, uint32_t size, uint32_t hashed) {
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(64) void surface_visibility_kernel(VisArgs a)
 // The MLP stores its hidden layer as in ngp_density_kernel: products formed transposed (weights as the MFMA's first operand), so a lane
 // holds four consecutive hidden units of one sample and writes them with one 8-byte LDS store instead of 64 two-byte ones.
 __device__ __forceinline__ void vwave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-__global__ __launch_bounds__(64) void surface_visibility_persistent_kernel(VisArgs a, unsigned long long* __restrict__ queue)
+__device__ __forceinline__ void vis_march_queue(const VisArgs& a, unsigned long long* __restrict__ queue)
 {
     constexpr int XRS = 32 * 2 + 16, HRS = 64 * 2 + 16;
     typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
@@ -395,6 +397,22 @@ __global__ __launch_bounds__(64) void surface_visibility_persistent_kernel(VisAr
     }
 }
 
+__global__ __launch_bounds__(64) void surface_visibility_persistent_kernel(VisArgs a, unsigned long long* __restrict__ queue)
+{
+    vis_march_queue(a, queue);
+}
+// Several blocks in ONE launch (a training step asks for the labels of 8 blocks: one pair of point sets each).  A call's duration is
+// its longest ray, not its average one, so eight launches cost eight tails; here every wave works through ALL blocks' queues, starting at
+// block (workgroup index mod n): the blocks' tails overlap.  A wave serves one block at a time (its MLP weights live in registers).
+__global__ __launch_bounds__(64) void surface_visibility_multi_kernel(const VisArgs* __restrict__ descs, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        const int b = ((int)blockIdx.x + i) % n;
+        vis_march_queue(descs[b], descs[b].queue);
+        __syncthreads();
+    }
+}
+
 // one bit per 4^3 block of the occupancy volume: set when any of its cells is occupied (bits must be zeroed by the caller)
 __global__ void occupancy_coarse_bits_kernel(const uint8_t* __restrict__ binary, uint32_t* __restrict__ bits, int rx, int ry, int rz, int cx, int cy, int cz)
 {
@@ -438,15 +456,59 @@ int dreg_surface_visibility(const float* cams, const float* pts, const uint8_t* 
     a.rx = rx; a.ry = ry; a.rz = rz; a.Nc = Nc; a.Np = Np;
     a.dt = render_step_size; a.cut_off = cut_off; a.early_eps = early_stop_eps; a.alpha_thre = alpha_thre;
     a.max_steps = 1 << 16;
-    a.coarse = nullptr; a.cx = a.cy = a.cz = 0;
+    a.coarse = nullptr; a.cx = a.cy = a.cz = 0; a.queue = nullptr;
     const long nrays = (long)Nc * Np;
     hipLaunchKernelGGL(surface_visibility_kernel, dim3((unsigned)((nrays + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
+static void vis_fill(VisArgs& a, const float* cams, const float* pts, const uint8_t* binary, int* label, const void* table, const void* w1, const void* w2,
+                     const uint32_t* offset, const uint32_t* size, const uint32_t* res, const float* scale, const uint32_t* hashed,
+                     const float* roi_aabb, const float* scene_aabb, const float* model_aabb, int rx, int ry, int rz, int Nc, int Np,
+                     float render_step_size, float cut_off, float early_stop_eps, float alpha_thre, void* queue, const uint32_t* coarse_bits)
+{
+    a.cams = cams; a.pts = pts; a.binary = binary; a.label = label;
+    a.table = (const _Float16*)table; a.w1 = (const _Float16*)w1; a.w2 = (const _Float16*)w2;
+    for (int l = 0; l < 16; ++l) { a.lv.offset[l] = offset[l]; a.lv.size[l] = size[l]; a.lv.res[l] = res[l]; a.lv.scale[l] = scale[l]; a.lv.hashed[l] = hashed[l]; }
+    for (int k = 0; k < 6; ++k) { a.roi[k] = roi_aabb[k]; a.scene[k] = scene_aabb[k]; a.model[k] = model_aabb[k]; }
+    a.rx = rx; a.ry = ry; a.rz = rz; a.Nc = Nc; a.Np = Np;
+    a.dt = render_step_size; a.cut_off = cut_off; a.early_eps = early_stop_eps; a.alpha_thre = alpha_thre;
+    a.max_steps = 1 << 16;
+    a.cx = (rx + 3) / 4; a.cy = (ry + 3) / 4; a.cz = (rz + 3) / 4;
+    a.coarse = ((long)a.cx * a.cy * a.cz <= 32768) ? coarse_bits : nullptr;      // (the kernel keeps the bits in 4 KB of LDS)
+    a.queue = (unsigned long long*)queue;
+}
+// Descriptor-table form for several blocks per launch.  The caller owns the table: n records of dreg_surface_visibility_desc_bytes() bytes,
+// filled ON THE HOST by dreg_surface_visibility_fill_desc (same arguments as dreg_surface_visibility_queue, one block each), copied to
+// the device by the caller, then passed to dreg_surface_visibility_multi.  Labels / queues of every block zeroed by the caller.
+size_t dreg_surface_visibility_desc_bytes() { return sizeof(VisArgs); }
+int dreg_surface_visibility_fill_desc(void* host_desc, const float* cams, const float* pts, const uint8_t* binary, int* label,
+                                      const void* table, const void* w1, const void* w2,
+                                      const uint32_t* offset, const uint32_t* size, const uint32_t* res, const float* scale, const uint32_t* hashed,
+                                      const float* roi_aabb, const float* scene_aabb, const float* model_aabb,
+                                      int rx, int ry, int rz, int Nc, int Np, float render_step_size, float cut_off, float early_stop_eps,
+                                      float alpha_thre, void* queue, const uint32_t* coarse_bits)
+{
+    if (!host_desc || !queue) return DREG_EINVAL;
+    VisArgs a;
+    vis_fill(a, cams, pts, binary, label, table, w1, w2, offset, size, res, scale, hashed, roi_aabb, scene_aabb, model_aabb, rx, ry, rz, Nc, Np,
+             render_step_size, cut_off, early_stop_eps, alpha_thre, queue, coarse_bits);
+    memcpy(host_desc, &a, sizeof(a));
+    return DREG_OK;
+}
+static int g_vis_waves = 4096;        // tuning (include/dreg_nerf_tuning.h): one-wave workgroups of the persistent launches (256 CUs x 16)
+int dreg_surface_visibility_multi(const void* descs_dev, int n, long total_rays, void* stream)
+{
+    if (n <= 0 || total_rays <= 0) return DREG_OK;
+    if (!descs_dev) return DREG_EINVAL;
+    long waves = (total_rays + 63) / 64;
+    if (waves > g_vis_waves) waves = g_vis_waves;
+    hipLaunchKernelGGL(surface_visibility_multi_kernel, dim3((unsigned)waves), dim3(64), 0, (hipStream_t)stream, (const VisArgs*)descs_dev, n);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
 // The same labels from the persistent kernel (lanes refilled from a ray queue; rays of points that already carry the label are not
 // marched).  queue: 8 bytes of device memory the CALLER has zeroed on this stream (the ray counter).
-static int g_vis_waves = 4096;        // tuning (include/dreg_nerf_tuning.h): one-wave workgroups of the persistent launch (256 CUs x 16)
 void dreg_visibility_set_waves(int n) { g_vis_waves = n > 0 ? n : 4096; }
 int dreg_surface_visibility_queue(const float* cams, const float* pts, const uint8_t* binary, int* label,
                                   const void* table, const void* w1, const void* w2,
@@ -458,15 +520,8 @@ int dreg_surface_visibility_queue(const float* cams, const float* pts, const uin
     if ((long)Nc * Np == 0) return DREG_OK;
     if (!queue) return DREG_EINVAL;
     VisArgs a;
-    a.cams = cams; a.pts = pts; a.binary = binary; a.label = label;
-    a.table = (const _Float16*)table; a.w1 = (const _Float16*)w1; a.w2 = (const _Float16*)w2;
-    for (int l = 0; l < 16; ++l) { a.lv.offset[l] = offset[l]; a.lv.size[l] = size[l]; a.lv.res[l] = res[l]; a.lv.scale[l] = scale[l]; a.lv.hashed[l] = hashed[l]; }
-    for (int k = 0; k < 6; ++k) { a.roi[k] = roi_aabb[k]; a.scene[k] = scene_aabb[k]; a.model[k] = model_aabb[k]; }
-    a.rx = rx; a.ry = ry; a.rz = rz; a.Nc = Nc; a.Np = Np;
-    a.dt = render_step_size; a.cut_off = cut_off; a.early_eps = early_stop_eps; a.alpha_thre = alpha_thre;
-    a.max_steps = 1 << 16;
-    a.cx = (rx + 3) / 4; a.cy = (ry + 3) / 4; a.cz = (rz + 3) / 4;
-    a.coarse = ((long)a.cx * a.cy * a.cz <= 32768) ? coarse_bits : nullptr;      // (the kernel keeps the bits in 4 KB of LDS)
+    vis_fill(a, cams, pts, binary, label, table, w1, w2, offset, size, res, scale, hashed, roi_aabb, scene_aabb, model_aabb, rx, ry, rz, Nc, Np,
+             render_step_size, cut_off, early_stop_eps, alpha_thre, queue, coarse_bits);
     const long nrays = (long)Nc * Np;
     long waves = (nrays + 63) / 64;
     if (waves > g_vis_waves) waves = g_vis_waves;

@@ -197,6 +197,9 @@ SIGNATURES = {
     "dreg_surface_visibility": (I, [P] * 7 + [P] * 5 + [P, P, P] + [I] * 5 + [F, F, F, F, P]),
     "dreg_surface_visibility_queue": (I, [P] * 7 + [P] * 5 + [P, P, P] + [I] * 5 + [F, F, F, F, P, P, P]),
     "dreg_occupancy_coarse_bits": (I, [P, P, I, I, I, P]),
+    "dreg_surface_visibility_desc_bytes": (Z, []),
+    "dreg_surface_visibility_fill_desc": (I, [P] + [P] * 7 + [P] * 5 + [P, P, P] + [I] * 5 + [F, F, F, F, P, P]),
+    "dreg_surface_visibility_multi": (I, [P, I, ctypes.c_long, P]),
     "dreg_visibility_set_waves": (None, [I]),
 }
 

@@ -37,6 +37,24 @@ def nerf_labels(pred, data):
     return s_gt, t_gt, s_tl, t_tl
 
 
+def nerf_labels_batched(preds, batch):
+    """nerf_labels for every pair of a step from ONE ray-march launch over all their blocks (visibility.compute_visibility_scores_batched)."""
+    from .visibility import compute_visibility_scores_batched
+    reqs = []
+    with torch.no_grad():
+        for pred, data in zip(preds, batch):
+            for side in ("src", "tgt"):
+                kp, warped = pred[side + "_kp"][0], pred[side + "_kp_warped"][0].detach()
+                reqs.append((torch.cat([kp.reshape(1, -1, 3), warped], 0), data[side + "_nerf_path"]))
+        outs = compute_visibility_scores_batched(reqs)
+    res = []
+    for i, pred in enumerate(preds):
+        nl = pred["src_kp_warped"][0].shape[0]
+        s, t = outs[2 * i], outs[2 * i + 1]
+        res.append((s[:1].expand(nl, -1, -1), t[:1].expand(nl, -1, -1), s[1:], t[1:]))
+    return res
+
+
 def _default_labels(pred):
     """Synthetic {0,1} visibility labels for data without NeRF blocks on disk (bench, synthetic scenes)."""
     s_kp, t_kp = pred["src_kp"][0], pred["tgt_kp"][0]
@@ -96,8 +114,9 @@ class TrainStep:
                     tilde = (bt["corr"][..., 0] + 0.31 * bt["corr"][..., 1] - 0.17 * bt["corr"][..., 2] > 0.0123).float()
             else:
                 gts, tls = [], []
+                from_blocks = iter(nerf_labels_batched([p for p, hn in zip(preds, have_nerf) if hn], [d for d, hn in zip(batch, have_nerf) if hn]))
                 for d, pred, hn in zip(batch, preds, have_nerf):
-                    s_gt, t_gt, s_tl, t_tl = nerf_labels(pred, d) if hn else self.label_fn(pred)
+                    s_gt, t_gt, s_tl, t_tl = next(from_blocks) if hn else self.label_fn(pred)
                     gts += [s_gt[..., 0], t_gt[..., 0]]
                     tls += [s_tl[..., 0], t_tl[..., 0]]
                 gt, tilde = torch.cat(gts, dim=1), torch.cat(tls, dim=1)

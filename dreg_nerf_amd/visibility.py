@@ -168,3 +168,48 @@ def compute_visibility_score(xyz_list: List[torch.Tensor], nerf_model_path: str,
                 t.record_stream(cur)
         out.append(lab.float().view(nl, npnt, 1))
     return out
+
+
+@torch.no_grad()
+def compute_visibility_scores_batched(requests, cut_off: float = 0.5) -> List[torch.Tensor]:
+    """requests: list of (xyz [L,N,3], nerf_model_path) -> list of [L,N,1] float {0,1}, the labels of compute_visibility_score for each —
+    from ONE launch over all blocks (a training step asks for 8: two per pair).  A call's duration is its longest ray, so eight
+    launches cost eight tails; here every wave of one persistent launch works through all the blocks' ray queues."""
+    if not requests:
+        return []
+    lib = L.load()
+    device = requests[0][0].device
+    blocks = [load_block(path, device) for _, path in requests]
+    npts = [int(x.shape[0] * x.shape[1]) for x, _ in requests]
+    # one zeroed buffer: every block's labels, then one 8-byte ray counter per block
+    lab_off, off = [], 0
+    for n in npts:
+        lab_off.append(off)
+        off += n + (n & 1)
+    q_off = off
+    buf = torch.zeros(off + 2 * len(requests), dtype=torch.int32, device=device)
+    nb = int(lib.dreg_surface_visibility_desc_bytes())
+    host = torch.empty(len(requests), nb, dtype=torch.uint8).pin_memory()
+    f6 = lambda v: (ctypes.c_float * 6)(*[float(t) for t in v])
+    keep, total = [], 0
+    for i, ((xyz, _), (field, _, meta)) in enumerate(zip(requests, blocks)):
+        pts = xyz.reshape(-1, 3).contiguous().float()
+        keep.append(pts)
+        base16, _ = field._prepared()
+        b8, cams = meta["binary_u8"], meta["cam_centres_dev"]
+        total += cams.shape[0] * pts.shape[0]
+        L.check(lib.dreg_surface_visibility_fill_desc(host[i].data_ptr(), L.ptr(cams), L.ptr(pts), L.ptr(b8), buf.data_ptr() + 4 * lab_off[i],
+                                                      base16.data_ptr() + 3072 * 2, base16.data_ptr(), base16.data_ptr() + 2048 * 2,
+                                                      *field._levels, f6(meta["aabb_host"]), f6(meta["aabb_host"]), f6(field._aabb_host()),
+                                                      b8.shape[0], b8.shape[1], b8.shape[2], cams.shape[0], pts.shape[0],
+                                                      float(meta["render_step_size"]), float(cut_off), 1e-4, float(meta.get("alpha_thre", 0.0) or 0.0),
+                                                      buf.data_ptr() + 4 * (q_off + 2 * i), L.ptr(meta["coarse_bits"]) if COARSE else None),
+                "dreg_surface_visibility_fill_desc")
+    descs = host.to(device, non_blocking=True)
+    L.check(lib.dreg_surface_visibility_multi(L.ptr(descs), len(requests), total, L.stream()), "dreg_surface_visibility_multi")
+    if device.type == "cuda":
+        cur = torch.cuda.current_stream(device)
+        for field, _, meta in blocks:
+            for t in (field._prepared()[0], meta["binary_u8"], meta["coarse_bits"], meta["cam_centres_dev"]):
+                t.record_stream(cur)
+    return [(buf[lab_off[i]:lab_off[i] + npts[i]] > 0).float().view(x.shape[0], x.shape[1], 1) for i, (x, _) in enumerate(requests)]

@@ -473,6 +473,18 @@ int dreg_surface_visibility_queue(const float* cams, const float* pts, const uin
 /* coarse_bits (optional): one bit per 4^3 block of `binary` (dreg_occupancy_coarse_bits; the buffer zeroed first): empty space is then
  * walked in coarse cells looked up in LDS instead of fine cells looked up in global memory.  Same labels. */
 int dreg_occupancy_coarse_bits(const uint8_t* binary, uint32_t* bits, int rx, int ry, int rz, void* stream);
+/* Several blocks in one launch (a training step's labels: 8 blocks).  The caller owns a table of n records of
+ * dreg_surface_visibility_desc_bytes() bytes: each filled on the HOST by dreg_surface_visibility_fill_desc (the arguments of
+ * dreg_surface_visibility_queue for one block), the table copied to the device by the caller; every wave of the one persistent launch then
+ * works through all blocks' ray queues (total_rays = sum of Nc * Np), so the blocks' tails overlap.  Same labels. */
+size_t dreg_surface_visibility_desc_bytes(void);
+int dreg_surface_visibility_fill_desc(void* host_desc, const float* cams, const float* pts, const uint8_t* binary, int* label,
+                                      const void* table, const void* w1, const void* w2,
+                                      const uint32_t* offset, const uint32_t* size, const uint32_t* res, const float* scale, const uint32_t* hashed,
+                                      const float* roi_aabb, const float* scene_aabb, const float* model_aabb,
+                                      int rx, int ry, int rz, int Nc, int Np, float render_step_size, float cut_off, float early_stop_eps,
+                                      float alpha_thre, void* queue, const uint32_t* coarse_bits);
+int dreg_surface_visibility_multi(const void* descs_dev, int n, long total_rays, void* stream);
 
 #ifdef __cplusplus
 }

@@ -163,3 +163,32 @@ def test_block_cache_keeps_inference_copies_and_is_filled_by_the_loader_thread(t
     per_block = next(iter(visibility._block_cache.values()))[3]
     assert per_block < 30 << 20, per_block
     visibility.clear_block_cache()
+
+
+def test_batched_labels_of_several_blocks_equal_the_per_block_calls(tmp_path):
+    """compute_visibility_scores_batched (one persistent launch over all blocks of a training step) against compute_visibility_score per block."""
+    res = 32
+    g = torch.Generator().manual_seed(9)
+    reqs = []
+    for k in range(3):
+        f = ngp.NGPradianceField(AABB)
+        with torch.no_grad():
+            f.mlp_base.params[:3072] = torch.randn(3072, generator=g) * (0.1, 0.6, 2.5)[k]      # a transparent, a foggy and an opaque block
+            f.mlp_base.params[3072:] = torch.randn(f.mlp_base.params.numel() - 3072, generator=g) * 2.0
+        occ = ngp.OccupancyGrid(AABB, res)
+        occ._binary.copy_(torch.rand(res, res, res, generator=g) < 0.3)
+        poses = torch.eye(4)[None].repeat(3 + k, 1, 1)
+        poses[:, :3, 3] = torch.nn.functional.normalize(torch.randn(3 + k, 3, generator=g), dim=-1) * 2.2
+        p = str(tmp_path / f"block_{k}.pth")
+        torch.save({"step": 1, "model": f.state_dict(), "occupancy_grid": occ.state_dict(), "aabb": AABB, "unbounded": False, "near_plane": None, "far_plane": None,
+                    "grid_resolution": res, "contraction_type": ngp.ContractionType.AABB, "render_step_size": 0.02,
+                    "alpha_thre": 0.0, "cone_angle": 0.0, "camera_poses": poses, "block_id": k}, p)
+        reqs.append(((torch.rand(2 + k, 150 + 37 * k, 3, generator=g) - 0.5).to(DEV) * 2, p))
+    visibility.clear_block_cache()
+    want = [visibility.compute_visibility_score([x], p)[0] for x, p in reqs]
+    got = visibility.compute_visibility_scores_batched(reqs)
+    assert len(got) == 3
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert 0 < sum(float(b.sum()) for b in want) < sum(b.numel() for b in want)
+    visibility.clear_block_cache()
