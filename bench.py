@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--occupancy-sweep", action="store_true", help="also time the step on shells of 1e4 .. 1e5 occupied voxels per side (active-set head)")
     ap.add_argument("--ngp", action="store_true", help="BASELINE.json configs[3] instead: NGP grid extraction of 128^3 NeRF blocks (dense hash-MLP query)")
     ap.add_argument("--eval", action="store_true", help="BASELINE.json configs[4]-style instead: forward-only registration (eval mode, no gradients) of synthetic pairs with a known pose")
+    ap.add_argument("--nerf-labels", action="store_true", help="the training step with its overlap labels ray-marched from the pairs' NeRF blocks (train_nerf_regtr.py:186-199) instead of synthetic labels: generated blocks, 50 cameras each")
     ap.add_argument("--ngp-radius", type=float, default=1.0, help="--ngp: occupied cells = ball of this radius in the [-1.5,1.5]^3 block")
     return ap.parse_args()
 
@@ -203,6 +204,84 @@ def eval_bench(args, rank, world, dev):
         "note": "RRE / RTE at random initialisation: the metric path (eval_nerf_regtr.py:275-301) runs; no trained checkpoint without network access"}), flush=True)
 
 
+def nerf_labels_bench(args, rank, world, dev):
+    """The training step as the reference runs it on real data: the overlap ground truth and the 'tilde' scores of every pair are the
+    surface-field visibility of its key points / predicted correspondences in the pair's two NeRF blocks (train_nerf_regtr.py:186-199,
+    confidence_loss.py:56-160) — here through ONE persistent ray-march launch per step over all blocks (csrc/visibility.hip).  Blocks are
+    generated (no checkpoints without network access): a shell-shaped 128^3 occupancy grid around the pairs' key points, NGP weights
+    scaled so that surfaces are opaque (rays end within a few samples, as in a trained block), 50 training cameras on a sphere."""
+    import tempfile
+    from dreg_nerf_amd import ngp, synth
+    from dreg_nerf_amd.regtr import NeRFRegTr
+    from dreg_nerf_amd.train_step import TrainStep
+    ncam, aabb, res = 50, [-1.5] * 3 + [1.5] * 3, 128
+    g = torch.Generator().manual_seed(rank)
+    td = tempfile.mkdtemp(prefix="dreg_nl_")
+    c = (torch.arange(res, dtype=torch.float32) + 0.5) / res * 3 - 1.5
+    X, Y, Z = torch.meshgrid(c, c, c, indexing="ij")
+    rad = torch.stack([X, Y, Z], -1).norm(dim=-1)
+    paths = []
+    for b in range(2 * args.pairs):
+        f = ngp.NGPradianceField(aabb)
+        with torch.no_grad():
+            f.mlp_base.params[:3072] = torch.randn(3072, generator=g) * 3.0
+            f.mlp_base.params[3072:] = torch.randn(f.mlp_base.params.numel() - 3072, generator=g)
+        occ = ngp.OccupancyGrid(aabb, res)
+        occ._binary.copy_((rad > 0.75) & (rad < 0.88))
+        poses = torch.eye(4)[None].repeat(ncam, 1, 1)
+        poses[:, :3, 3] = torch.nn.functional.normalize(torch.randn(ncam, 3, generator=g), dim=-1) * 3.0
+        p = os.path.join(td, f"block_{b}.pth")
+        torch.save({"step": 1, "model": f.state_dict(), "occupancy_grid": occ.state_dict(), "aabb": aabb, "unbounded": False, "near_plane": None, "far_plane": None,
+                    "grid_resolution": res, "contraction_type": ngp.ContractionType.AABB, "render_step_size": 3 * 3 ** 0.5 / 1024,
+                    "alpha_thre": 0.0, "cone_angle": 0.0, "camera_poses": poses, "block_id": b}, p)
+        paths.append(p)
+    torch.manual_seed(3407)
+    model = NeRFRegTr(precision=args.precision).to(dev).train()
+    if world > 1:
+        for p_ in model.parameters():
+            dist.broadcast(p_.data, 0)
+    ts = TrainStep(model)
+    pose = synth.fixed_pose()
+    batch = []
+    for i in range(args.pairs):
+        s = 1 + 2 * (rank * args.pairs + i)
+        d = synth.shell_pair(args.res, s, s + 1, pose=pose)
+        d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
+        d["src_nerf_path"], d["tgt_nerf_path"] = paths[2 * i], paths[2 * i + 1]
+        batch.append(d)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        ts.step(batch)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts.step(batch)
+    sync()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    import shutil
+    shutil.rmtree(td, ignore_errors=True)
+    if rank != 0:
+        return
+    kp = int(ts.last_preds[0]["src_kp"][0].shape[0])
+    rays = 2 * args.pairs * 7 * kp * ncam
+    print(json.dumps({
+        "metric": "nerf_pairs_per_sec_regtr_fwd_bwd_128_labels_from_nerf_blocks", "value": args.pairs * world * args.steps / el, "unit": "pairs/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"RegTR fwd+bwd+AdamW with overlap labels ray-marched from the pairs' NeRF blocks: {args.pairs} pairs ({2 * args.pairs} generated 128^3 blocks, "
+                               f"{ncam} cameras each) per GPU per step, ~{kp} key points per cloud, 7 point sets per block = {rays / 1e6:.1f} M rays per step in one launch",
+                   "global_batch_pairs": args.pairs * world, "resolution": args.res, "parallelism": f"dp{world}"}}), flush=True)
+
+
 def ngp_bench(args, rank, world, dev):
     """BASELINE.json configs[3]: one 128^3 NeRF block = Np occupied cells -> world samples -> density (hash grid + MLP) -> colour x 18
     directions -> alpha / masks -> voxel_grid + voxel_mask (eval_ngp_nerf.py:336-412 without the surface ray march, which needs the
@@ -350,8 +429,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    if args.ngp or args.eval:
-        (ngp_bench if args.ngp else eval_bench)(args, rank, world, dev)
+    if args.ngp or args.eval or args.nerf_labels:
+        (ngp_bench if args.ngp else eval_bench if args.eval else nerf_labels_bench)(args, rank, world, dev)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()

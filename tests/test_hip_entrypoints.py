@@ -87,6 +87,7 @@ def test_bench_eval_and_ngp_lines():
     JSON line each with the contract's keys."""
     import json
     for flags, metric in ((["--eval", "--res", "64", "--pairs", "1", "--steps", "2", "--warmup", "1"], "nerf_pairs_per_sec_regtr_eval_forward_128"),
+                          (["--nerf-labels", "--res", "64", "--pairs", "1", "--steps", "2", "--warmup", "1"], "nerf_pairs_per_sec_regtr_fwd_bwd_128_labels_from_nerf_blocks"),
                           (["--ngp", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], "ngp_grid_extraction_blocks_per_sec_128")):
         out = _run(["bench.py"] + flags, timeout=900)
         lines = [l for l in out.splitlines() if l.startswith("{")]
@@ -96,5 +97,5 @@ def test_bench_eval_and_ngp_lines():
         assert "workload" in d["config"] and d["data"] == "synthetic"
         if "--eval" in flags:
             assert 0.0 <= d["rre_deg_mean"] <= 180.0 and d["rte_mean"] >= 0.0
-        else:
+        elif "--ngp" in flags:
             assert d["roofline"]["density_kernel"]["avg_launch_ms"] > 0
