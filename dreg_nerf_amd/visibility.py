@@ -170,6 +170,27 @@ def compute_visibility_score(xyz_list: List[torch.Tensor], nerf_model_path: str,
     return out
 
 
+# Pinned staging for the descriptor tables: a ring of four buffers per device, each guarded by an event recorded behind its last copy
+# (allocating / freeing pinned memory every step costs a host-side hipHostMalloc / hipHostFree pair, the latter a possible device sync).
+_staging: Dict[str, list] = {}
+
+
+def _desc_staging(nbytes: int, device):
+    if torch.device(device).type != "cuda":
+        return torch.empty(nbytes, dtype=torch.uint8), None
+    ring = _staging.setdefault(str(device), [0, []])
+    if len(ring[1]) < 4:
+        ring[1].append([torch.empty(max(nbytes, 16384), dtype=torch.uint8).pin_memory(), torch.cuda.Event()])
+        slot = ring[1][-1]
+    else:
+        slot = ring[1][ring[0] % 4]
+        ring[0] += 1
+        slot[1].synchronize()                                   # only waits when the GPU is four label launches behind the host
+        if slot[0].numel() < nbytes:
+            slot[0] = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    return slot[0], slot[1]
+
+
 @torch.no_grad()
 def compute_visibility_scores_batched(requests, cut_off: float = 0.5) -> List[torch.Tensor]:
     """requests: list of (xyz [L,N,3], nerf_model_path) -> list of [L,N,1] float {0,1}, the labels of compute_visibility_score for each —
@@ -189,7 +210,8 @@ def compute_visibility_scores_batched(requests, cut_off: float = 0.5) -> List[to
     q_off = off
     buf = torch.zeros(off + 2 * len(requests), dtype=torch.int32, device=device)
     nb = int(lib.dreg_surface_visibility_desc_bytes())
-    host = torch.empty(len(requests), nb, dtype=torch.uint8).pin_memory()
+    host, host_ev = _desc_staging(len(requests) * nb, device)
+    host = host[:len(requests) * nb].view(len(requests), nb)
     f6 = lambda v: (ctypes.c_float * 6)(*[float(t) for t in v])
     keep, total = [], 0
     for i, ((xyz, _), (field, _, meta)) in enumerate(zip(requests, blocks)):
@@ -206,6 +228,8 @@ def compute_visibility_scores_batched(requests, cut_off: float = 0.5) -> List[to
                                                       buf.data_ptr() + 4 * (q_off + 2 * i), L.ptr(meta["coarse_bits"]) if COARSE else None),
                 "dreg_surface_visibility_fill_desc")
     descs = host.to(device, non_blocking=True)
+    if host_ev is not None:
+        host_ev.record(torch.cuda.current_stream(device))       # the staging buffer may be refilled once this copy has run
     L.check(lib.dreg_surface_visibility_multi(L.ptr(descs), len(requests), total, L.stream()), "dreg_surface_visibility_multi")
     if device.type == "cuda":
         cur = torch.cuda.current_stream(device)
