@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--event-steps", type=int, default=1, help="timed steps whose conv launches are bracketed by HIP events (roofline line)")
     ap.add_argument("--kernel-report", default="", help="write the per-kernel/per-shape event timing table here")
     ap.add_argument("--no-dense-reference", action="store_true", help="skip the additional dense-head measurement")
+    ap.add_argument("--no-nerf-labels-reference", action="store_true", help="skip the additional measurement of the step with overlap labels from generated NeRF blocks")
     ap.add_argument("--dense-head", action="store_true", help="evaluate the FPN head densely (BASELINE.md FLOP accounting) instead of on the active set")
     ap.add_argument("--cpu-samples", type=int, default=3, help="timed samples of the CPU baseline (after one warm-up)")
     ap.add_argument("--occupancy-sweep", action="store_true", help="also time the step on shells of 1e4 .. 1e5 occupied voxels per side (active-set head)")
@@ -204,24 +205,19 @@ def eval_bench(args, rank, world, dev):
         "note": "RRE / RTE at random initialisation: the metric path (eval_nerf_regtr.py:275-301) runs; no trained checkpoint without network access"}), flush=True)
 
 
-def nerf_labels_bench(args, rank, world, dev):
-    """The training step as the reference runs it on real data: the overlap ground truth and the 'tilde' scores of every pair are the
-    surface-field visibility of its key points / predicted correspondences in the pair's two NeRF blocks (train_nerf_regtr.py:186-199,
-    confidence_loss.py:56-160) — here through ONE persistent ray-march launch per step over all blocks (csrc/visibility.hip).  Blocks are
-    generated (no checkpoints without network access): a shell-shaped 128^3 occupancy grid around the pairs' key points, NGP weights
-    scaled so that surfaces are opaque (rays end within a few samples, as in a trained block), 50 training cameras on a sphere."""
+def write_generated_blocks(n, ncam, seed):
+    """n NeRF block checkpoints in the reference's format (train_ngp_nerf.py:187-209) under a fresh temporary directory: a shell-shaped
+    128^3 occupancy grid around the synthetic pairs' key points, NGP weights scaled so that surfaces are opaque, ncam cameras on a sphere."""
     import tempfile
-    from dreg_nerf_amd import ngp, synth
-    from dreg_nerf_amd.regtr import NeRFRegTr
-    from dreg_nerf_amd.train_step import TrainStep
-    ncam, aabb, res = 50, [-1.5] * 3 + [1.5] * 3, 128
-    g = torch.Generator().manual_seed(rank)
+    from dreg_nerf_amd import ngp
+    aabb, res = [-1.5] * 3 + [1.5] * 3, 128
+    g = torch.Generator().manual_seed(seed)
     td = tempfile.mkdtemp(prefix="dreg_nl_")
     c = (torch.arange(res, dtype=torch.float32) + 0.5) / res * 3 - 1.5
     X, Y, Z = torch.meshgrid(c, c, c, indexing="ij")
     rad = torch.stack([X, Y, Z], -1).norm(dim=-1)
     paths = []
-    for b in range(2 * args.pairs):
+    for b in range(n):
         f = ngp.NGPradianceField(aabb)
         with torch.no_grad():
             f.mlp_base.params[:3072] = torch.randn(3072, generator=g) * 3.0
@@ -235,6 +231,20 @@ def nerf_labels_bench(args, rank, world, dev):
                     "grid_resolution": res, "contraction_type": ngp.ContractionType.AABB, "render_step_size": 3 * 3 ** 0.5 / 1024,
                     "alpha_thre": 0.0, "cone_angle": 0.0, "camera_poses": poses, "block_id": b}, p)
         paths.append(p)
+    return td, paths
+
+
+def nerf_labels_bench(args, rank, world, dev):
+    """The training step as the reference runs it on real data: the overlap ground truth and the 'tilde' scores of every pair are the
+    surface-field visibility of its key points / predicted correspondences in the pair's two NeRF blocks (train_nerf_regtr.py:186-199,
+    confidence_loss.py:56-160) — here through ONE persistent ray-march launch per step over all blocks (csrc/visibility.hip).  Blocks are
+    generated (no checkpoints without network access): a shell-shaped 128^3 occupancy grid around the pairs' key points, NGP weights
+    scaled so that surfaces are opaque (rays end within a few samples, as in a trained block), 50 training cameras on a sphere."""
+    from dreg_nerf_amd import synth
+    from dreg_nerf_amd.regtr import NeRFRegTr
+    from dreg_nerf_amd.train_step import TrainStep
+    ncam = 50
+    td, paths = write_generated_blocks(2 * args.pairs, ncam, rank)
     torch.manual_seed(3407)
     model = NeRFRegTr(precision=args.precision).to(dev).train()
     if world > 1:
@@ -570,6 +580,32 @@ def main():
                 rc = list(ex.last_row_counts)
             sweep.append({"shell_r1": r1, "n_mask_per_side": int(b2[0]["src_mask"].shape[0]), "pairs_per_s": args.pairs / el_, "ms_per_step": 1e3 * el_,
                           "active_rows": rc, "head": "active-set" if rc else "dense fallback"})
+    # the same step with its overlap labels ray-marched from the pairs' NeRF blocks, as on real data (train_nerf_regtr.py:186-199): an extra,
+    # clearly separate figure next to the headline (whose labels are synthetic, like every other input)
+    with_labels = None
+    if world == 1 and args.precision == "bf16" and args.res == 128 and not args.dense_head and not args.no_nerf_labels_reference:
+        try:
+            import shutil
+            td, paths = write_generated_blocks(2 * args.pairs, 50, 0)
+            b3 = [dict(d, src_nerf_path=paths[2 * i], tgt_nerf_path=paths[2 * i + 1]) for i, d in enumerate(batch)]
+            model.active_set = True
+            for _ in range(3):
+                ts.step(b3)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                ts.step(b3)
+            torch.cuda.synchronize()
+            el_l = (time.perf_counter() - t0) / 10
+            kp = int(ts.last_preds[0]["src_kp"][0].shape[0])
+            with_labels = {"value": args.pairs / el_l, "unit": "pairs/s", "ms_per_step": 1e3 * el_l, "steps": 10,
+                           "rays_per_step": 2 * args.pairs * 7 * kp * 50,
+                           "note": f"overlap ground truth and 'tilde' scores of every pair = surface-field visibility of its key points / predicted correspondences in the "
+                                   f"pair's two NeRF blocks ({2 * args.pairs} generated 128^3 blocks with opaque surfaces, 50 cameras each), one persistent ray-march launch per step "
+                                   f"(csrc/visibility.hip); `python bench.py --nerf-labels` is the same measurement as a line of its own"}
+            shutil.rmtree(td, ignore_errors=True)
+        except Exception as e:      # never lose the headline line to the extra figure
+            with_labels = {"error": repr(e)[:300]}
     if rank == 0:
         roofline, by_label = roofline_of(prof, "dense_head" if args.dense_head else "active_set")
         if args.kernel_report:
@@ -595,6 +631,8 @@ def main():
             out["dense_head"] = dense
         if sweep is not None:
             out["occupancy_sweep"] = sweep
+        if with_labels is not None:
+            out["labels_from_nerf_blocks"] = with_labels
         if world == 1 and not args.no_cpu_baseline:
             cres = args.cpu_res or (128 if (os.cpu_count() or 1) >= 32 else 64)
             out["cpu_baseline"] = cpu_baseline(min(cres, args.res), args.res, args.cpu_samples)
