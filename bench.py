@@ -353,7 +353,7 @@ def ngp_bench(args, rank, world, dev):
         return s.elapsed_time(e) / n
 
     idx_pts = sg.uniform_sample_occupied_voxels().to(dev)
-    ms_d = ev_time(lambda: sg.positions_and_density(f, idx_pts, jitter, dev))     # the product path: lane order + positions + encode + MLP
+    ms_d = ev_time(lambda: sg.positions_and_density(f, idx_pts, jitter, dev, all_occupied=True))     # the product path: lane order + positions + encode + MLP
     raw = f.query_raw(world_pts)[1]
     ms_c = ev_time(lambda: f.query_rgb_mean(raw, dirs))
     fl_c = npts * (18 * (64 * 64 + 16 * 64) + 64 * 32) * 2.0        # colour net x 18 directions (geometry half of layer 1 once)

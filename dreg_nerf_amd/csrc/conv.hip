@@ -220,8 +220,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
                 const int n = n0 + wn * WN + j * 16 + col_l;
                 float v = acc[i][j][r];
                 if (bias) v += bias[n];
-                if (addend) v += Elem<TO>::ld(addend + arow + n);
-                if (relu) v = fmaxf(v, 0.f);
+                if (addend) { if (relu == 2) v = Elem<TO>::ld(addend + arow + n) > 0.f ? v : 0.f; else v += Elem<TO>::ld(addend + arow + n); }
+                if (relu == 1) v = fmaxf(v, 0.f);
                 Elem<TO>::st(out + (size_t)m * g.Cout + n, v);
             }
         }
@@ -610,10 +610,17 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
                 int b, z, y, x;
                 vox_decode(m, g, b, z, y, x);
                 const TO* ap = addend + ((size_t)((b * Da + (z >> add_shift)) * Ha + (y >> add_shift)) * Wa + (x >> add_shift)) * g.Cout + n;
+                if (relu == 2) {
+                    // ReLU-backward mask (the data gradient of a layer whose forward epilogue applied ReLU): the "addend" is that
+                    // layer's stored activation, and the gradient passes where it is positive (transformer.py:291 linear1 -> relu)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += Elem<TO>::ld(ap + e);
+                    for (int e = 0; e < 8; ++e) v[e] = Elem<TO>::ld(ap + e) > 0.f ? v[e] : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += Elem<TO>::ld(ap + e);
+                }
             }
-            if (relu) {
+            if (relu == 1) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }

@@ -1020,6 +1020,71 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     if (lane == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
+// The bias gradients of ALL linear layers of a backward pass in two launches (the point-set executor keeps every layer's output
+// gradient until its pass ends; per layer they were a partial + a final launch, ~90 launches per step).  bf16 gradients with C <= 2048
+// (one slab); a record's chunks are dreg_colsum's (colsum_rows_per_chunk), every partial and final sum is formed in the same order.
+struct ColsumDesc { const bf16_t* g; float* out; float* partial; int M, C, rpc, nch, pblock0, fblock0, accumulate, pad; };
+static_assert(sizeof(ColsumDesc) == 56, "column-sum record: 56 bytes");
+__device__ __forceinline__ int colsum_find(const ColsumDesc* __restrict__ descs, int n, int blk, bool final_pass)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((final_pass ? descs[mid].fblock0 : descs[mid].pblock0) <= blk) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void colsum_partial_batched_kernel(const ColsumDesc* __restrict__ descs, int n)
+{
+    constexpr int G = 8;
+    const ColsumDesc d = descs[colsum_find(descs, n, blockIdx.x, false)];
+    const int chunk = blockIdx.x - d.pblock0;
+    const int C = d.C, CG = C / G;
+    const int cgs = CG < 256 ? CG : 256, rpi = 256 / cgs;
+    const int t = threadIdx.x, cg = t % cgs, r0 = t / cgs;
+    const size_t M = (size_t)d.M;
+    const size_t v0 = (size_t)chunk * d.rpc, v1 = min(v0 + (size_t)d.rpc, M);
+    float s[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) s[i] = 0.f;
+    if (r0 < rpi) {
+        constexpr int UN = 4;
+        for (size_t v = v0 + r0; v < v1; v += (size_t)rpi * UN) {
+            uint4 q[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (v + (size_t)u * rpi < v1) q[u] = *reinterpret_cast<const uint4*>(d.g + (v + (size_t)u * rpi) * C + (size_t)cg * G);
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (v + (size_t)u * rpi < v1) {
+                    float x[G];
+                    Gran<bf16_t>::unpack(q[u], x);
+#pragma unroll
+                    for (int i = 0; i < G; ++i) s[i] += x[i];
+                }
+        }
+    }
+    __shared__ float red[256][9];
+#pragma unroll
+    for (int i = 0; i < G; ++i) red[t][i] = s[i];
+    __syncthreads();
+    if (t < cgs) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) { float a = 0.f; for (int r = 0; r < rpi; ++r) a += red[r * cgs + t][i]; d.partial[(size_t)chunk * C + (size_t)cg * G + i] = a; }
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_batched_kernel(const ColsumDesc* __restrict__ descs, int n)
+{
+    const ColsumDesc d = descs[colsum_find(descs, n, blockIdx.x, true)];
+    const int c = (blockIdx.x - d.fblock0) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= d.C) return;
+    double s = 0.0;
+#pragma unroll 4
+    for (int k = lane; k < d.nch; k += 64) s += d.partial[(size_t)k * d.C + c];
+    s = wave_sum_d(s);
+    if (lane == 0) d.out[c] = d.accumulate ? d.out[c] + (float)s : (float)s;
+}
+
 // ------------------------------------------------------------------------------------------------ trilinear gather
 // feats[n][:] = trilinear sample (align_corners=True) of p1[b] at fine voxel index idx[n] of a (Zr,Xr,Yr) grid whose
 // flat index is (x*Yr + y)*Zr + z  (nerf_regtr.py:144-147).  p1 dims (d,h,w) correspond to (z,x,y).
@@ -1642,6 +1707,21 @@ int dreg_colsum(const void* g, float* out, float* workspace, size_t M, int C, in
     else hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(nch, slabs), dim3(256), 0, st, (const float*)g, workspace, M, C, rpc);
     DREG_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, out, nch, C, accumulate);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// Batched form.  descs_dev: n records of 56 bytes { const bf16* g [M][C]; float* out [C]; float* partial (dreg_colsum_workspace_bytes(M, C),
+// one per record); int M, C, rpc (dreg_colsum_rows_per_chunk(M)), nch = ceil(M / rpc), pblock0 (sum of nch of the records before),
+// fblock0 (sum of ceil(C / 4) before), accumulate, pad }; total_pblocks / total_fblocks = the sums over all records.  bf16, C % 8 == 0, C <= 2048.
+int dreg_colsum_rows_per_chunk(size_t M) { return colsum_rows_per_chunk(M); }
+int dreg_colsum_batched(const void* descs_dev, int n, int total_pblocks, int total_fblocks, void* stream)
+{
+    if (n <= 0 || total_pblocks <= 0) return DREG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial_batched_kernel, dim3(total_pblocks), dim3(256), 0, st, (const ColsumDesc*)descs_dev, n);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_batched_kernel, dim3(total_fblocks), dim3(256), 0, st, (const ColsumDesc*)descs_dev, n);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

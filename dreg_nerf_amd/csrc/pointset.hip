@@ -38,12 +38,39 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     st4(y + (size_t)row * 256 + lane * 4, o);
     if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
+// The final norm of the encoder is applied to the six layer outputs twice (nerf_regtr.py:170-206: `cond` = LN(x) in fp32 for the heads
+// and the losses, LN(x) + pe in the compute dtype for the decoder's projections): both from ONE read of x.  pe has pe_rows rows and is
+// indexed by row % pe_rows (the six layers share the key points' embedding).  Each output is bit-identical to layernorm_fwd_kernel's.
+__global__ __launch_bounds__(256) void layernorm_fwd2_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                             const float* __restrict__ pe, int pe_rows, float* __restrict__ y32, bf16_t* __restrict__ y16,
+                                                             float* __restrict__ stats, int N, float eps)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * 256 + lane * 4);
+    const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
+    const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+    const float var = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.f / 256.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4), bb = *reinterpret_cast<const float4*>(b + lane * 4);
+    float o[4] = {d0 * rstd * gg.x + bb.x, d1 * rstd * gg.y + bb.y, d2 * rstd * gg.z + bb.z, d3 * rstd * gg.w + bb.w};
+    if (y32) st4(y32 + (size_t)row * 256 + lane * 4, o);
+    if (y16) {
+        if (pe) { const float4 p = *reinterpret_cast<const float4*>(pe + (size_t)(row % pe_rows) * 256 + lane * 4); o[0] += p.x; o[1] += p.y; o[2] += p.z; o[3] += p.w; }
+        st4(y16 + (size_t)row * 256 + lane * 4, o);
+    }
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
 // dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  partial dgamma/dbeta per block of rows
 template <typename TG>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const TG* __restrict__ dy, const float* __restrict__ g,
                                                             const float* __restrict__ stats, float* __restrict__ dx, float* __restrict__ part,
-                                                            int N, int rows_per_block, const float* dx_add)
+                                                            int N, int rows_per_block, const float* dx_add, const float* dx_add2 = nullptr,
+                                                            bf16_t* __restrict__ dx_bf = nullptr, const bf16_t* __restrict__ dy2 = nullptr)
 {
+    // dx = (LayerNorm-backward(dy [+ dy2]) + dx_add) + dx_add2 (both optional, either may alias dx); dx_bf (optional): the same values
+    // rounded to bf16 — the operand of the GEMMs that consume this gradient (no separate cast launch); dy2 (optional, bf16): a second
+    // upstream gradient of the SAME LayerNorm application (the backward is linear in dy), added to dy in fp32 before anything else
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4);
     float dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
@@ -54,7 +81,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
     for (int rb = r0 + wave; rb < rend; rb += 16) {
         constexpr int U = 4;
-        float4 v[U], old[U];
+        float4 v[U], old[U], old2[U];
         float d[U][4], mean[U], rstd[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -62,8 +89,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             if (row < rend) {
                 v[u] = *reinterpret_cast<const float4*>(x + (size_t)row * 256 + lane * 4);
                 ld4(dy + (size_t)row * 256 + lane * 4, d[u]);
+                if (dy2) { float e2[4]; ld4(dy2 + (size_t)row * 256 + lane * 4, e2); d[u][0] += e2[0]; d[u][1] += e2[1]; d[u][2] += e2[2]; d[u][3] += e2[3]; }
                 mean[u] = stats[2 * row]; rstd[u] = stats[2 * row + 1];
                 if (dx_add) old[u] = *reinterpret_cast<const float4*>(dx_add + (size_t)row * 256 + lane * 4);
+                if (dx_add2) old2[u] = *reinterpret_cast<const float4*>(dx_add2 + (size_t)row * 256 + lane * 4);
             }
         }
 #pragma unroll
@@ -79,7 +108,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = rstd[u] * (d[u][i] * gv[i] - s1 - xh[i] * s2);
                 if (dx_add) { o[0] += old[u].x; o[1] += old[u].y; o[2] += old[u].z; o[3] += old[u].w; }
+                if (dx_add2) { o[0] += old2[u].x; o[1] += old2[u].y; o[2] += old2[u].z; o[3] += old2[u].w; }
                 *reinterpret_cast<float4*>(dx + (size_t)row * 256 + lane * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                if (dx_bf) st4(dx_bf + (size_t)row * 256 + lane * 4, o);
             }
         }
     }
@@ -102,6 +133,26 @@ __global__ void layernorm_bwd_final_kernel(const float* __restrict__ part, float
     if (lane == 0) {
         float* dst = c < 256 ? dg + c : db + (c - 256);
         *dst = accumulate ? *dst + (float)s : (float)s;
+    }
+}
+
+// The dgamma / dbeta sums of ALL LayerNorm applications of a backward pass in one launch (the point-set executor keeps every
+// application's block partials until its pass ends): 128 workgroups per record, the same column sums in the same order.
+struct LnFinalDesc { const float* part; float* dg; float* db; int nblk, accumulate; };
+static_assert(sizeof(LnFinalDesc) == 32, "LayerNorm final record: 32 bytes");
+__global__ void layernorm_bwd_final_batched_kernel(const LnFinalDesc* __restrict__ descs)
+{
+    const LnFinalDesc d = descs[blockIdx.x >> 7];
+    const int c = (blockIdx.x & 127) * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= 512) return;
+    double s = 0.0;
+#pragma unroll 8
+    for (int k = lane; k < d.nblk; k += 64) s += d.part[(size_t)k * 512 + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) {
+        float* dst = c < 256 ? d.dg + c : d.db + (c - 256);
+        *dst = d.accumulate ? *dst + (float)s : (float)s;
     }
 }
 
@@ -137,7 +188,7 @@ __global__ __launch_bounds__(256) void overlap_fwd_kernel(const float* __restric
 }
 __global__ __launch_bounds__(256) void overlap_bwd_kernel(const float* __restrict__ f, const float* __restrict__ w, const float* __restrict__ s,
                                                           const float* __restrict__ gy, float* __restrict__ df, float* __restrict__ part,
-                                                          int N, int rows_per_block)
+                                                          int N, int rows_per_block, const float* df_add = nullptr)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float4 ww = *reinterpret_cast<const float4*>(w + lane * 4);
@@ -146,7 +197,12 @@ __global__ __launch_bounds__(256) void overlap_bwd_kernel(const float* __restric
     for (int row = r0 + wave; row < min(r0 + rows_per_block, N); row += 4) {
         const float sv = s[row], dl = gy[row] * sv * (1.f - sv);
         const float4 v = *reinterpret_cast<const float4*>(f + (size_t)row * 256 + lane * 4);
-        *reinterpret_cast<float4*>(df + (size_t)row * 256 + lane * 4) = make_float4(dl * ww.x, dl * ww.y, dl * ww.z, dl * ww.w);
+        float4 o = make_float4(dl * ww.x, dl * ww.y, dl * ww.z, dl * ww.w);
+        if (df_add) {           // the other gradient of f (f feeds the losses directly as well; may be df itself): df = df_add + dlogit * w
+            const float4 p = *reinterpret_cast<const float4*>(df_add + (size_t)row * 256 + lane * 4);
+            o.x = p.x + o.x; o.y = p.y + o.y; o.z = p.z + o.z; o.w = p.w + o.w;
+        }
+        *reinterpret_cast<float4*>(df + (size_t)row * 256 + lane * 4) = o;
         dw[0] += dl * v.x; dw[1] += dl * v.y; dw[2] += dl * v.z; dw[3] += dl * v.w;
         dbias += dl;
     }
@@ -157,7 +213,7 @@ __global__ __launch_bounds__(256) void overlap_bwd_kernel(const float* __restric
     __syncthreads();
     for (int c = threadIdx.x; c < 257; c += 256) part[(size_t)blockIdx.x * 257 + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
-__global__ void overlap_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblk)
+__global__ void overlap_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblk, int accumulate = 0)
 {
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= 257) return;
@@ -165,7 +221,7 @@ __global__ void overlap_bwd_final_kernel(const float* __restrict__ part, float* 
     for (int k = lane; k < nblk; k += 64) s += part[(size_t)k * 257 + c];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (lane == 0) { if (c < 256) dw[c] = (float)s; else db[0] = (float)s; }
+    if (lane == 0) { float* dst = c < 256 ? dw + c : db; *dst = accumulate ? *dst + (float)s : (float)s; }
 }
 
 // ------------------------------------------------------------------------------------------------ elementwise helpers
@@ -472,6 +528,53 @@ int dreg_layernorm_bwd_add(const float* x, const void* dy, const float* gamma, c
     else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nblk), dim3(256), 0, st, x, (const float*)dy, gamma, stats, dx, workspace, N, LN_BWD_ROWS, dx_add);
     DREG_LAUNCH_CHECK();
     hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3(128), dim3(256), 0, st, workspace, dgamma, dbeta, nblk, accumulate_w);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// y32 (fp32, no pe) and / or y16 (bf16, + pe[row % pe_rows]) of the same LayerNorm from one read of x (either output may be null)
+int dreg_layernorm_fwd2(const float* x, const float* gamma, const float* beta, const float* pe, int pe_rows, float* y32, void* y16, float* stats,
+                        int N, int C, float eps, void* stream)
+{
+    if (C != 256 || (pe && pe_rows <= 0)) return DREG_EINVAL;
+    if (N == 0) return DREG_OK;
+    hipLaunchKernelGGL(layernorm_fwd2_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, pe, pe_rows, y32, (bf16_t*)y16, stats, N, eps);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// The row pass of the LayerNorm backward alone: dx = (LN-backward(dy [+ dy2]) + dx_add) + dx_add2, optional bf16 copy dx_bf16, block
+// partials of dgamma / dbeta into `part` (dreg_layernorm_bwd_workspace_bytes(N), kept by the caller until dreg_layernorm_bwd_final_batched).
+int dreg_layernorm_bwd_parts(const float* x, const void* dy, const void* dy2_bf16, const float* gamma, const float* stats, float* dx, const float* dx_add,
+                             const float* dx_add2, void* dx_bf16, float* part, int N, int C, int g_dtype, void* stream)
+{
+    if (C != 256) return DREG_EINVAL;
+    if (N == 0) return DREG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = (N + LN_BWD_ROWS - 1) / LN_BWD_ROWS;
+    if (g_dtype == 0) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, x, (const bf16_t*)dy, gamma, stats, dx, part, N, LN_BWD_ROWS, dx_add, dx_add2, (bf16_t*)dx_bf16, (const bf16_t*)dy2_bf16);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(nblk), dim3(256), 0, st, x, (const float*)dy, gamma, stats, dx, part, N, LN_BWD_ROWS, dx_add, dx_add2, (bf16_t*)dx_bf16, (const bf16_t*)dy2_bf16);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+int dreg_layernorm_bwd_blocks(int N) { return (N + LN_BWD_ROWS - 1) / LN_BWD_ROWS; }
+// descs_dev: n records of 32 bytes { const float* part; float* dgamma; float* dbeta; int nblk (dreg_layernorm_bwd_blocks); int accumulate; }
+int dreg_layernorm_bwd_final_batched(const void* descs_dev, int n, void* stream)
+{
+    if (n <= 0) return DREG_OK;
+    hipLaunchKernelGGL(layernorm_bwd_final_batched_kernel, dim3(128 * n), dim3(256), 0, (hipStream_t)stream, (const LnFinalDesc*)descs_dev);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// dreg_overlap_bwd with accumulation: df = df_add + dlogit * w (df_add fp32 [N,256] or null; may be df), dw / db += when accumulate_w
+int dreg_overlap_bwd_acc(const float* f, const float* w, const float* s, const float* gy, float* df, const float* df_add, float* dw, float* db,
+                         int accumulate_w, float* workspace, int N, void* stream)
+{
+    if (N == 0) return DREG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = (N + 63) / 64;
+    hipLaunchKernelGGL(overlap_bwd_kernel, dim3(nblk), dim3(256), 0, st, f, w, s, gy, df, workspace, N, 64, df_add);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(overlap_bwd_final_kernel, dim3(65), dim3(256), 0, st, workspace, dw, db, nblk, accumulate_w);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

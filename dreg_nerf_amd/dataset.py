@@ -293,7 +293,10 @@ class PrefetchLoader:
         seed = random.getrandbits(62)
         self._rng = random.Random(seed)
         self._cpu_gen = torch.Generator().manual_seed(seed)
-        self._gen = torch.Generator(device=device).manual_seed(seed) if self.stream is not None else self._cpu_gen
+        # the jitter is drawn on the device the DATASET puts its tensors on (a CPU dataset behind a CUDA loader draws on the CPU generator)
+        ds_dev = getattr(dataset, "device", None)
+        on_gpu = ds_dev is not None and torch.device(ds_dev).type == "cuda"
+        self._gen = torch.Generator(device=ds_dev).manual_seed(seed) if on_gpu else self._cpu_gen
         self._own_rng = hasattr(dataset, "get")
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.thread.start()

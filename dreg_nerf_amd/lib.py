@@ -155,6 +155,22 @@ SIGNATURES = {
     "dreg_layernorm_bwd_workspace_bytes": (Z, [I]),
     "dreg_layernorm_bwd": (I, [P] * 8 + [I] * 5 + [P]),
     "dreg_layernorm_bwd_add": (I, [P] * 9 + [I] * 4 + [P]),
+    "dreg_layernorm_fwd2": (I, [P, P, P, P, I, P, P, P, I, I, F, P]),
+    "dreg_layernorm_bwd_parts": (I, [P] * 10 + [I, I, I, P]),
+    "dreg_layernorm_bwd_blocks": (I, [I]),
+    "dreg_layernorm_bwd_final_batched": (I, [P, I, P]),
+    "dreg_overlap_bwd_acc": (I, [P, P, P, P, P, P, P, P, I, P, I, P]),
+    "dreg_colsum_rows_per_chunk": (I, [Z]),
+    "dreg_colsum_batched": (I, [P, I, I, I, P]),
+    # pointset_exec.hip
+    "dreg_ps_num_params": (I, []),
+    "dreg_ps_num_linears": (I, []),
+    "dreg_ps_create": (P, [P]),
+    "dreg_ps_destroy": (None, [P]),
+    "dreg_ps_set_fuse": (None, [P, I]),
+    "dreg_ps_arena_bytes": (Z, [P, I]),
+    "dreg_ps_forward": (I, [P, P, Z, P, P, P, P, P, P, I, I, I, P, P, P, P]),
+    "dreg_ps_backward": (I, [P, P, Z, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P]),
     "dreg_posenc_sine": (I, [P, P, I, F, F, P]),
     "dreg_overlap_fwd": (I, [P, P, P, P, I, P]),
     "dreg_overlap_bwd_workspace_bytes": (Z, [I]),

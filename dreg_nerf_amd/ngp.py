@@ -334,7 +334,7 @@ class SampleGrid(nn.Module):
         if jitter is None:
             jitter = torch.rand(n, 3, dtype=torch.float32, device=device)
         jitter = jitter.to(device).contiguous()
-        world, density, raw = self.positions_and_density(radiance_field, indices, jitter, device)
+        world, density, raw = self.positions_and_density(radiance_field, indices, jitter, device, all_occupied=True)
         rgb = radiance_field.query_rgb_mean(raw, self._viewdirs.to(device))
         alpha = torch.empty(n, dtype=torch.float32, device=device)
         keep = torch.empty(n, dtype=torch.uint8, device=device)
@@ -342,9 +342,14 @@ class SampleGrid(nn.Module):
         return world, rgb, alpha[:, None], indices, keep.view(torch.bool)
 
     @torch.no_grad()
-    def positions_and_density(self, radiance_field: NGPradianceField, indices: torch.Tensor, jitter: torch.Tensor, device):
+    def positions_and_density(self, radiance_field: NGPradianceField, indices: torch.Tensor, jitter: torch.Tensor, device,
+                              all_occupied: bool = False):
         """World positions of the jittered samples of the cells `indices` (ascending flat indices) and the field's density / raw features
-        there: (world [n,3], density [n], raw fp16 [n,16]), all indexed like `indices`."""
+        there: (world [n,3], density [n], raw fp16 [n,16]), all indexed like `indices`.
+        all_occupied=True asserts that `indices` is EXACTLY uniform_sample_occupied_voxels() of the current binary field (every occupied
+        cell, ascending): only then may the x-ordered query be used — dreg_grid_x_order derives each cell's slot from the occupancy
+        volume and would write outside `order` (or leave holes in it) for any other index set.  Subsets, chunks or indices taken
+        before set_binary_fields() changed the field take the unordered query (same results, slower)."""
         lib = L.load()
         import ctypes
         n = indices.shape[0]
@@ -357,7 +362,7 @@ class SampleGrid(nn.Module):
         aabb = (ctypes.c_float * 6)(*hc[2])
         # the cells come z-fastest, the hash grid's tables are x-fastest: an order in which a wave's 64 lanes run along x (csrc/ngp.hip)
         order = None
-        if n >= 16384 and rx <= 65535:
+        if all_occupied and n >= 16384 and rx <= 65535:
             binary = self._binary.to(device)
             binary = binary.contiguous().view(torch.uint8) if binary.dtype == torch.bool else binary.to(torch.uint8).contiguous()
             nb = int(lib.dreg_grid_x_order_workspace_bytes(rx, ry, rz))

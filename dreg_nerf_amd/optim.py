@@ -208,3 +208,31 @@ class GradSync:
             self.opt.flat_g[:self.opt.n_active].div_(self.world)
         if self._side is not None:
             torch.cuda.current_stream(self.opt.flat_g.device).wait_stream(self._side)
+
+
+def broadcast_buffers(module: torch.nn.Module, src: int = 0):
+    """Every rank takes rank `src`'s module BUFFERS (the BatchNorm running statistics and num_batches_tracked): plain DDP averages
+    gradients only, so each rank's running statistics follow its own pairs (the reference has no opinion; the build
+    broadcasts rank 0's at validation / checkpoint time).  One collective per dtype: the buffers are flattened into a single message
+    (159 BatchNorm buffers of the registration network = 0.2 MB) and copied back in place.  No-op outside a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    by_dtype = {}
+    seen = set()
+    for b in module.buffers():
+        if b.data_ptr() in seen:              # the ResNet is registered under two names (feature_pyramid_net.py:43,194-200): one storage
+            continue
+        seen.add(b.data_ptr())
+        by_dtype.setdefault(b.dtype, []).append(b)
+    n = 0
+    with torch.no_grad():
+        for dt in sorted(by_dtype, key=str):   # same order on every rank
+            bufs = by_dtype[dt]
+            flat = torch.cat([b.reshape(-1) for b in bufs])
+            dist.broadcast(flat, src)
+            off = 0
+            for b in bufs:
+                b.copy_(flat[off:off + b.numel()].view_as(b))
+                off += b.numel()
+            n += len(bufs)
+    return n

@@ -1,0 +1,190 @@
+"""Native (C++) execution of the point-set half of the registration network — the 6-layer self / cross attention encoder, the shared
+final norm, the correspondence decoder and the overlap head — through ``csrc/pointset_exec.hip``: ONE C call for the forward pass,
+ONE for the backward pass (parameter gradients accumulated straight into FlatAdamW's buffers, weight / bias gradients on the
+process-wide second stream).
+
+Reference network: conerf/register/transformer.py:50-86,225-299, conerf/register/nerf_regtr.py:170-206,273-308,350-394.
+``transformer_ops.encode_decode_batched`` stays the description of record (and the fp32 parity path); this module only changes who
+issues the launches (and, with ``fuse``, folds a few element-wise passes into their producers): with ``fuse = 0`` the two are equal
+bit for bit, outputs and every gradient (tests/test_hip_pointset_exec.py).
+"""
+import ctypes
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import ops
+
+N_LAYERS = 6
+_PER_LAYER = ("norm1.weight", "norm1.bias", "self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
+              "self_attn.out_proj.bias", "norm2.weight", "norm2.bias", "cross_attn.in_proj_weight", "cross_attn.in_proj_bias",
+              "cross_attn.out_proj.weight", "cross_attn.out_proj.bias", "norm3.weight", "norm3.bias", "linear1.weight", "linear1.bias",
+              "linear2.weight", "linear2.bias")
+_TAIL = ("transformer_encoder.norm.weight", "transformer_encoder.norm.bias", "correspondence_decoder.q_proj.weight",
+         "correspondence_decoder.q_proj.bias", "correspondence_decoder.k_proj.weight", "correspondence_decoder.k_proj.bias",
+         "correspondence_decoder.conf_logits_decoder.weight", "correspondence_decoder.conf_logits_decoder.bias")
+_LINEARS = ("self_attn.in_proj_weight", "self_attn.out_proj.weight", "cross_attn.in_proj_weight", "cross_attn.out_proj.weight",
+            "linear1.weight", "linear2.weight")
+
+FUSE = True      # False: the per-op path's arithmetic, bit for bit (tests; dreg_ps_set_fuse)
+
+
+def param_names():
+    names = [f"transformer_encoder.layers.{l}.{n}" for l in range(N_LAYERS) for n in _PER_LAYER]
+    return names + list(_TAIL)
+
+
+def linear_names():
+    names = [f"transformer_encoder.layers.{l}.{n}" for l in range(N_LAYERS) for n in _LINEARS]
+    return names + ["correspondence_decoder.q_proj.weight", "correspondence_decoder.k_proj.weight"]
+
+
+class PointSetExecutor:
+    """The recorded parameter table + the arena of one model (grown on demand: the row count changes every step)."""
+
+    def __init__(self, P: Dict[str, torch.Tensor], with_grad: bool):
+        self.lib = L.load()
+        names = param_names()
+        assert len(names) == self.lib.dreg_ps_num_params()
+        self.params = [P[n] for n in names]
+        self.linears = [P[n] for n in linear_names()]
+        assert len(self.linears) == self.lib.dreg_ps_num_linears()
+        self.with_grad = with_grad
+        tab = np.zeros((len(names), 2), dtype=np.int64)
+        self._sig = []
+        for i, t in enumerate(self.params):
+            assert t.is_contiguous() and t.dtype == torch.float32, "the executor reads fp32 master parameters in place"
+            g = t.grad if with_grad else None
+            if with_grad and (g is None or not g.is_contiguous() or g.dtype != torch.float32):
+                raise L.DregError("PointSetExecutor needs preallocated contiguous fp32 .grad buffers (FlatAdamW) on every parameter")
+            tab[i, 0] = t.data_ptr()
+            tab[i, 1] = g.data_ptr() if g is not None else 0
+            self._sig.append((t.data_ptr(), int(tab[i, 1])))
+        self.h = self.lib.dreg_ps_create(tab.ctypes.data)
+        if not self.h:
+            raise L.DregError("dreg_ps_create failed")
+        self.lib.dreg_ps_set_fuse(self.h, int(FUSE))
+        self._fuse = FUSE
+        self.device = self.params[0].device
+        self.arena = None
+        self.arena_bytes = 0
+        self._packs = (ctypes.c_int64 * (2 * len(self.linears)))()
+        self._pack_stamp = None
+        self._pack_keep = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.dreg_ps_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def still_valid(self) -> bool:
+        for t, (vp, gp) in zip(self.params, self._sig):
+            g = t.grad if self.with_grad else None
+            if t.data_ptr() != vp or (g.data_ptr() if g is not None else 0) != gp:
+                return False
+        return True
+
+    def _pack_table(self):
+        """Device pointers of the (forward, data-gradient) bf16 packs of every linear layer: the packs of ops.packed_weight's cache
+        (refreshed by ONE batched launch after every optimizer update: ops.repack_all), looked up again only when a weight changed."""
+        stamp = (ops._weight_generation, sum(t._version for t in self.linears))
+        if stamp != self._pack_stamp:
+            keep = []
+            for i, w in enumerate(self.linears):
+                f = ops.packed_weight(w, w.shape[1], False, L.DT_BF16)
+                d = ops.packed_weight(w, w.shape[1], True, L.DT_BF16)
+                self._packs[2 * i], self._packs[2 * i + 1] = f.data_ptr(), d.data_ptr()
+                keep += [f, d]
+            self._pack_keep, self._pack_stamp = keep, stamp
+        return ctypes.addressof(self._packs)
+
+    def _arena_for(self, R: int):
+        need = self.lib.dreg_ps_arena_bytes(self.h, R)
+        if need > self.arena_bytes:
+            self.arena = None                                             # release before growing (15 KB per row: ~150 MB at 10^4 rows)
+            self.arena_bytes = int(need * 1.25)
+            self.arena = torch.empty(self.arena_bytes, dtype=torch.uint8, device=self.device)
+        return self.arena
+
+    def forward(self, feats, xyz, pe, tab):
+        if self._fuse != FUSE:
+            self.lib.dreg_ps_set_fuse(self.h, int(FUSE))
+            self._fuse = FUSE
+        ops.wait_packs()
+        R = feats.shape[0]
+        arena = self._arena_for(R)
+        dev = feats.device
+        cond = torch.empty(N_LAYERS, R, 256, dtype=torch.float32, device=dev)
+        corr = torch.empty(N_LAYERS, R, 3, dtype=torch.float32, device=dev)
+        ov = torch.empty(N_LAYERS, R, 1, dtype=torch.float32, device=dev)
+        L.check(self.lib.dreg_ps_forward(self.h, L.ptr(arena), self.arena_bytes, self._pack_table(), L.ptr(feats), L.ptr(xyz), L.ptr(pe),
+                                         L.ptr(tab.self_probs), L.ptr(tab.cross_probs), tab.nprob, tab.max_len, R,
+                                         L.ptr(cond), L.ptr(corr), L.ptr(ov), L.stream()), "dreg_ps_forward")
+        return cond, corr, ov
+
+    def backward(self, feats, xyz, pe, tab, cond, corr, ov, g_cond, g_corr, g_ov):
+        R = feats.shape[0]
+        d_feats = torch.empty_like(feats)
+        aux = ops.PARAM_GRAD_STREAM
+        if aux is not None:
+            self.arena.record_stream(aux)
+        L.check(self.lib.dreg_ps_backward(self.h, L.ptr(self.arena), self.arena_bytes, self._pack_table(), L.ptr(feats), L.ptr(xyz), L.ptr(pe),
+                                          L.ptr(tab.self_probs), L.ptr(tab.cross_probs), tab.nprob, tab.max_len, R,
+                                          L.ptr(cond), L.ptr(corr), L.ptr(ov), L.ptr(g_cond), L.ptr(g_corr), L.ptr(g_ov), L.ptr(d_feats),
+                                          L.stream(), aux.cuda_stream if aux is not None else None), "dreg_ps_backward")
+        return d_feats
+
+
+class _PointSetFn(torch.autograd.Function):
+    """(cond, corr, ov) = point-set half(feats).  `anchor` (any trainable parameter) keeps the node in the graph when feats itself
+    carries no gradient; the executor accumulates every parameter gradient itself."""
+
+    @staticmethod
+    def forward(ctx, feats, anchor, ex: PointSetExecutor, xyz, pe, tab):
+        cond, corr, ov = ex.forward(feats, xyz, pe, tab)
+        ctx.ex, ctx.tab = ex, tab
+        ctx.save_for_backward(feats, xyz, pe, cond, corr, ov)
+        ctx.set_materialize_grads(False)
+        return cond, corr, ov
+
+    @staticmethod
+    def backward(ctx, g_cond, g_corr, g_ov):
+        feats, xyz, pe, cond, corr, ov = ctx.saved_tensors
+        gc = g_cond.contiguous().float() if g_cond is not None else None
+        gr = g_corr.contiguous().float() if g_corr is not None else None
+        go = g_ov.contiguous().float() if g_ov is not None else None
+        d_feats = ctx.ex.backward(feats, xyz, pe, ctx.tab, cond, corr, ov, gc, gr, go)
+        return d_feats, None, None, None, None, None
+
+
+def executor_for(model, P) -> Optional[PointSetExecutor]:
+    """The model's native point-set executor for the current grad mode, or None when it does not apply (fp32 parity mode, learned
+    position embedding — its gradient flows through the per-op LayerNorm nodes —, training without preallocated gradient buffers, or
+    bench.py's bracketed profiling step, which wants one timed launch per linear layer)."""
+    if model.precision != "bf16" or model.pos_emb_type != "sine" or not getattr(model, "native_pointset", True):
+        return None
+    if ops.PROFILER is not None and ops.PROFILER.enabled:
+        return None
+    names = param_names()
+    train = torch.is_grad_enabled() and any(P[n].requires_grad for n in names)
+    if train and not all(P[n].requires_grad for n in names):
+        return None
+    if train and any(P[n].grad is None or not P[n].grad.is_contiguous() for n in names):
+        return None
+    cache = model.__dict__.setdefault("_ps_cache", {})
+    ex = cache.get(train)
+    if ex is not None and not ex.still_valid():
+        ex = None
+    if ex is None:
+        ex = cache[train] = PointSetExecutor(P, train)
+    return ex
+
+
+def encode_decode(ex: PointSetExecutor, feats, xyz, pe, tab, anchor):
+    feats = feats.float().contiguous()
+    return _PointSetFn.apply(feats, anchor, ex, xyz.contiguous(), pe.contiguous(), tab)

@@ -106,6 +106,8 @@ class NeRFRegTr(nn.Module):
         # Run the data-dependent geometry phase of forward_batch on its own high-priority stream (see forward_batch)
         self.async_geometry = True
         self.skip_empty_stem_rows = True   # stem output rows whose receptive field is all zero are written as zeros, not computed
+        # Issue the point-set half (encoder, decoder, heads) of forward_batch from the C++ executor (csrc/pointset_exec.hip)
+        self.native_pointset = True
         self._spec = params.regtr_spec(self.pos_emb_type)
         _build_tree(self, self._spec)
         _reset_parameters(self, self._spec)
@@ -405,7 +407,14 @@ class NeRFRegTr(nn.Module):
         sizes = [idxs[2 * i].shape[0] + idxs[2 * i + 1].shape[0] for i in range(len(batch))]
         feat_l = [T.apply_subsample_plan(plans[i], f) for i, f in enumerate(feats.split(sizes))]
         xyz_all = torch.cat(pts_l) if len(pts_l) > 1 else pts_l[0]
-        cond, corr, ov = T.encode_decode_batched(P, torch.cat(feat_l) if len(feat_l) > 1 else feat_l[0], xyz_all, tab, self.position_embedding)
+        feats_all = torch.cat(feat_l) if len(feat_l) > 1 else feat_l[0]
+        from . import pointset_exec
+        ps = pointset_exec.executor_for(self, P)
+        if ps is not None:     # the whole point-set half from C++: one call forward, one backward (csrc/pointset_exec.hip)
+            cond, corr, ov = pointset_exec.encode_decode(ps, feats_all, xyz_all, self.position_embedding(xyz_all), tab,
+                                                         P["transformer_encoder.norm.weight"])
+        else:
+            cond, corr, ov = T.encode_decode_batched(P, feats_all, xyz_all, tab, self.position_embedding)
         outs = []
         poses = A.weighted_kabsch_pairs(xyz_all, corr, ov, tab)   # [P,6,3,4]: every (pair, layer) solve in one launch
         # the batched view of the same results (row space of all pairs) for the fused training losses

@@ -32,7 +32,10 @@ def _cache_budget(device) -> int:
     if BLOCK_CACHE_MAX_BYTES is not None:
         return BLOCK_CACHE_MAX_BYTES
     if torch.device(device).type == "cuda":
-        return int(0.4 * torch.cuda.get_device_properties(device).total_memory)
+        # what is free NOW plus what the cache already holds, never more than 40 % of the device: several processes on one GPU, or a
+        # smaller-HBM part, shrink the cache (evicting) instead of running the training step out of memory
+        free, total = torch.cuda.mem_get_info(device)
+        return int(min(0.4 * total, 0.5 * (free + _block_cache_bytes)))
     return 2048 << 20
 COARSE = True             # the persistent kernel walks empty space through a coarse occupancy grid (one bit per 4^3 cells) held in LDS
 PERSISTENT = True         # surface_visibility through the persistent ray-queue kernel (False: one lock-step launch of 64 rays per wave)
@@ -84,7 +87,8 @@ def load_block(path: str, device):
     field = field.to(device).eval().freeze_for_inference()     # fp16 inference copies only: the block is never trained here
     binary = occ.binary.to(device)
     nbytes = _block_bytes(field, binary)
-    kept = {k: meta[k] for k in ("aabb", "render_step_size", "cone_angle", "alpha_thre", "camera_poses")}
+    # small meta tensors are cloned: a view into the memory-mapped checkpoint would keep one file mapping alive per cached block
+    kept = {k: (meta[k].clone() if torch.is_tensor(meta[k]) else meta[k]) for k in ("aabb", "render_step_size", "cone_angle", "alpha_thre", "camera_poses")}
     # what every call needs, converted ONCE: camera centres on the device, the aabb as host floats (a .tolist() of a device tensor or an
     # H2D copy per call is a host sync per call: eight per training step, each draining the queue the host had run ahead on)
     kept["cam_centres_dev"] = torch.as_tensor(meta["camera_poses"])[..., :3, 3].float().contiguous().to(device)

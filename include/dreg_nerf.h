@@ -52,7 +52,10 @@ int dreg_pack_conv_weights_batched(const void* descs, int n, int total_rows, int
  * in [B,Di,Hi,Wi,Cin], out [B,Do,Ho,Wo,Cout]; Cout % 64 == 0; ksz in {1,3,5}; stride in {1,2}; Cin a power of two
  * unless ksz == 1.  addend (optional, dtype of out) is [B,Da,Ha,Wa,Cout], added with nearest x2 upsampling + crop
  * (FeaturePyramid_v1._upsample, feature_pyramid_net.py:58-61), or element-wise when add_same = 1 (the transformer's
- * residual connections, transformer.py:250,262,283-284,289,293).  out_f32 = 1: bf16 operands, fp32 output. */
+ * residual connections, transformer.py:250,262,283-284,289,293).  out_f32 = 1: bf16 operands, fp32 output.
+ * relu = 2 (with add_same = 1): the "addend" is NOT added but used as a mask — out = addend > 0 ? value : 0 — the ReLU backward of a
+ * layer whose forward epilogue applied ReLU (addend = that layer's stored activation), fused into the data gradient that produces its
+ * output gradient (transformer.py:291 linear1 -> relu -> linear2). */
 int dreg_conv3d_igemm(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
                       int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
                       int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
@@ -212,6 +215,12 @@ int dreg_trilinear_gather_fwd(const void* p1, const int64_t* idx, const int* pt_
 int dreg_trilinear_gather_bwd(const float* dfeat, const int64_t* idx, const int* pt_batch, float* dp1_f32, int N, int d,
                               int h, int w, int C, int Zr, int Xr, int Yr, void* stream);
 int dreg_cast_from_f32(const float* in, void* out, size_t n, int dtype, void* stream);
+/* Bias gradients of many linear layers in two launches.  descs_dev: n records of 56 bytes { const bf16* g [M][C]; float* out [C];
+ * float* partial (dreg_colsum_workspace_bytes(M, C), one per record); int M, C, rpc (dreg_colsum_rows_per_chunk(M)), nch = ceil(M / rpc),
+ * pblock0 (sum of nch of the records before), fblock0 (sum of ceil(C / 4) before), accumulate, pad }; total_pblocks / total_fblocks = the
+ * sums over all records.  bf16, C % 8 == 0, C <= 2048.  Every sum is formed in dreg_colsum's order (bit-identical results). */
+int dreg_colsum_rows_per_chunk(size_t M);
+int dreg_colsum_batched(const void* descs_dev, int n, int total_pblocks, int total_fblocks, void* stream);
 int dreg_add_inplace(void* dst, const void* src, size_t n, int dtype, void* stream);   /* dst += src */
 /* Input staging (nerf_regtr.py:131-147): grids = DEVICE array of B pointers to fp32 [7,Z,X,Y] voxel grids (xyz | rgb | alpha).
  * pack: -> [B,Z,X,Y,8] (dtype) = rgba + 4 zero channels, the NDHWC stem input.  gather: xyz fp32 [N,3] of the occupied voxels
@@ -338,6 +347,20 @@ int dreg_layernorm_bwd(const float* x, const void* dy, const float* gamma, const
 int dreg_layernorm_bwd_add(const float* x, const void* dy, const float* gamma, const float* stats, float* dx, const float* dx_add, float* dgamma,
                            float* dbeta, float* workspace, int N, int C, int g_dtype, int accumulate_w, void* stream);
 
+/* The same LayerNorm with two outputs from one read of x: y32 fp32 (no pe) and / or y16 bf16 (+ pe[row % pe_rows]); either may be null.
+ * The encoder's shared final norm feeds the heads / losses in fp32 and the decoder's projections as LN(x) + pe (nerf_regtr.py:170-206). */
+int dreg_layernorm_fwd2(const float* x, const float* gamma, const float* beta, const float* pe, int pe_rows, float* y32, void* y16, float* stats,
+                        int N, int C, float eps, void* stream);
+/* Row pass of the LayerNorm backward alone: dx = (LN-backward(dy [+ dy2_bf16]) + dx_add) + dx_add2 (addends optional, may alias dx),
+ * optional bf16 copy of dx (the operand of the GEMMs that consume it), block partials of dgamma / dbeta into `part`
+ * (dreg_layernorm_bwd_workspace_bytes(N), kept by the caller).  dreg_layernorm_bwd_final_batched sums the partials of many LayerNorm
+ * applications with one launch: descs_dev = n records of 32 bytes { const float* part; float* dgamma; float* dbeta; int nblk
+ * (dreg_layernorm_bwd_blocks(N)); int accumulate; }. */
+int dreg_layernorm_bwd_parts(const float* x, const void* dy, const void* dy2_bf16, const float* gamma, const float* stats, float* dx, const float* dx_add,
+                             const float* dx_add2, void* dx_bf16, float* part, int N, int C, int g_dtype, void* stream);
+int dreg_layernorm_bwd_blocks(int N);
+int dreg_layernorm_bwd_final_batched(const void* descs_dev, int n, void* stream);
+
 /* PositionEmbeddingCoordsSine.forward (position_embedding.py:30-53): xyz fp32 [N,3] -> pe fp32 [N,256]. */
 int dreg_posenc_sine(const float* xyz, float* pe, int N, float scale, float temperature, void* stream);
 
@@ -346,6 +369,11 @@ int dreg_overlap_fwd(const float* f, const float* w, const float* b, float* s, i
 size_t dreg_overlap_bwd_workspace_bytes(int N);
 int dreg_overlap_bwd(const float* f, const float* w, const float* s, const float* gy, float* df, float* dw, float* db,
                      float* workspace, int N, void* stream);
+
+/* the same with accumulation: df = df_add + dlogit * w (df_add: the gradient f receives from elsewhere — f also feeds the losses directly —
+ * or null; may be df itself), dw / db += when accumulate_w */
+int dreg_overlap_bwd_acc(const float* f, const float* w, const float* s, const float* gy, float* df, const float* df_add, float* dw, float* db,
+                         int accumulate_w, float* workspace, int N, void* stream);
 
 /* out = (y > 0 ? g : 0) cast to out_dtype (backward of the fused ReLU epilogue; also the fp32 -> bf16 gradient cast). */
 int dreg_relu_bwd(const void* y, const void* g, void* out, size_t n, int y_dtype, int g_dtype, int out_dtype, void* stream);
@@ -416,7 +444,9 @@ int dreg_ngp_density_fwd(const float* x, const void* table, const void* w1, cons
  * (sample_grid.py:338-341: alpha = clip(1 - exp(-delta * density), 0, 1), keep = density > threshold). */
 int dreg_ngp_dir_bias(const float* dirs, const void* w1_f16, float* out, int K, void* stream);
 int dreg_ngp_alpha_keep(const float* density, float* alpha, uint8_t* keep, int N, float delta, float threshold, void* stream);
-/* mean over ndir fixed viewing directions of the colour net: dirbias fp32 [ndir,64] = W1[:, :16] . sh4(dir_k) */
+/* mean over ndir fixed viewing directions of the colour net.  dirbias = the buffer dreg_ngp_dir_bias wrote: 2 * ndir * 64 words —
+ * fp32 [ndir][64] = W1[:, :16] . sh4(dir_k), FOLLOWED BY uint32 [ndir][64] (the same values as packed fp16 halves hi | lo << 16).
+ * The kernel reads the second half at dirbias + ndir * 64: a caller that builds its own bias table must supply both halves. */
 int dreg_ngp_rgb_mean_fwd(const void* raw, const void* w1, const void* w2, const void* w3, const float* dirbias, float* rgb,
                           int ndir, int Np, void* stream);
 /* unbounded scenes: positions pass through contract_to_unisphere (conerf/radiance_fields/ngp.py:41-63) before the hash grid */
@@ -485,6 +515,33 @@ int dreg_surface_visibility_fill_desc(void* host_desc, const float* cams, const 
                                       int rx, int ry, int rz, int Nc, int Np, float render_step_size, float cut_off, float early_stop_eps,
                                       float alpha_thre, void* queue, const uint32_t* coarse_bits);
 int dreg_surface_visibility_multi(const void* descs_dev, int n, long total_rays, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- native point-set executor
+ * (csrc/pointset_exec.hip) The six encoder layers (conerf/register/transformer.py:50-86,225-299), the shared final norm
+ * (nerf_regtr.py:170-206), the correspondence decoder and the overlap head (nerf_regtr.py:273-308,350-394,384-387): forward in one
+ * call, backward in one call, for the key points of every pair of a step (R rows; `probs` = attention problem tables as in the
+ * varlen attention calls).  params: int64 [dreg_ps_num_params()][2] = (fp32 value ptr, fp32 grad ptr or 0) in the order: per layer
+ * norm1.{weight,bias}, self_attn.{in_proj_weight,in_proj_bias,out_proj.weight,out_proj.bias}, norm2.*, cross_attn.{same four},
+ * norm3.*, linear1.*, linear2.*; then transformer_encoder.norm.*, correspondence_decoder.{q_proj,k_proj,conf_logits_decoder}.*.
+ * packs: int64 [dreg_ps_num_linears()][2] = (forward pack, data-gradient pack) device pointers of every linear layer (per layer
+ * in_proj_s, out_proj_s, in_proj_c, out_proj_c, linear1, linear2; then q_proj, k_proj), bf16 from dreg_pack_conv_weight.
+ * The arena (dreg_ps_arena_bytes(R), caller-owned) keeps the forward pass's activations for the backward call of the SAME R.
+ * dreg_ps_backward: g_cond (fp32 [6,R,256]), g_corr, g_ov may each be null; parameter
+ * gradients are accumulated into the grad pointers; weight / bias gradients run on aux_stream (optional) and the caller joins it with
+ * `stream` before reading any gradient.  dreg_ps_set_fuse(0): the arithmetic of the per-op path, bit for bit (tests). */
+int dreg_ps_num_params(void);
+int dreg_ps_num_linears(void);
+void* dreg_ps_create(const int64_t* params);
+void dreg_ps_destroy(void* h);
+void dreg_ps_set_fuse(void* h, int fuse);
+size_t dreg_ps_arena_bytes(void* h, int R);
+int dreg_ps_forward(void* h, void* arena, size_t arena_bytes, const int64_t* packs, const float* feats, const float* xyz, const float* pe,
+                    const int* probs_self, const int* probs_cross, int nprob, int max_len, int R,
+                    float* cond, float* corr, float* ov, void* stream);
+int dreg_ps_backward(void* h, void* arena, size_t arena_bytes, const int64_t* packs, const float* feats, const float* xyz, const float* pe,
+                     const int* probs_self, const int* probs_cross, int nprob, int max_len, int R,
+                     const float* cond, const float* corr, const float* ov, const float* g_cond, const float* g_corr, const float* g_ov,
+                     float* d_feats, void* stream, void* aux_stream);
 
 #ifdef __cplusplus
 }

@@ -148,6 +148,98 @@ def test_grad_sync_two_ranks_equal_one_rank_on_concatenated_batch():
     assert res[0][1] == res[1][1]
 
 
+def _uneven_worker(rank, world, port, q):
+    """Four ranks whose backward passes report progress on DIFFERENT schedules (each rank reaches the bucket boundaries after a different
+    number of ready() calls, some ranks skip straight to finish()): buckets must still be launched in ONE order on every rank — the
+    collectives of a process group match by issue order — and the exchange must complete (a rank launching bucket k+1 before bucket k
+    while a peer does the opposite is the deadlock / mismatched-reduction case)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dreg_nerf_amd.optim import FlatAdamW, GradSync
+    import time
+    sizes = (513, 7, 1000, 64, 129, 300, 2048, 11)
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in sizes]
+    opt = FlatAdamW(ps)
+    sync = GradSync(opt, world, bucket_bytes=200 * 4)
+    schedules = {0: (4000, 3900, 3000, 2999, 2000, 1000, 500, 1),      # fine-grained
+                 1: (2000,),                                         # one report in the middle
+                 2: (),                                              # nothing before finish()
+                 3: (4071, 10, 9, 8)}                                # a late jump over many buckets
+    out = []
+    for step in range(3):                                            # several steps: begin() must reset the bucket cursor
+        opt.zero_grad()
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        mine = torch.randn(opt.n_active, generator=g)
+        opt.flat_g[:opt.n_active].copy_(mine)
+        sync.begin()
+        for lo in schedules[rank]:
+            time.sleep(0.002 * ((rank * 7 + step) % 3))              # ranks drift apart in time as well
+            sync.ready(lo)
+        sync.finish()
+        out.append((mine.tolist(), opt.flat_g[:opt.n_active].tolist(), list(sync.launched)))
+    q.put((rank, out, sync.buckets))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_sync_world4_uneven_ready_schedules():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30111 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=180) for _ in range(4))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for step in range(3):
+        want = sum(torch.tensor(res[r][0][step][0]) for r in range(4)) / 4
+        for r in range(4):
+            mine, flat, launched = res[r][0][step]
+            assert torch.allclose(torch.tensor(flat), want, rtol=0, atol=1e-6)
+            assert launched == res[r][1], "every bucket exactly once, from the end of the buffer, on every schedule"
+        assert all(res[r][0][step][1] == res[0][0][step][1] for r in range(4)), "all ranks hold the same averaged gradient, bit for bit"
+
+
+def _bn_buffer_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dreg_nerf_amd.optim import broadcast_buffers
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Conv3d(2, 4, 1), torch.nn.BatchNorm3d(4), torch.nn.BatchNorm3d(4))
+    m.alias = m[1]                                                   # the same module under a second name (the reference's ResNet alias)
+    with torch.no_grad():
+        for i, b in enumerate(m.buffers()):
+            b.copy_(torch.full_like(b, 10 * rank + i))                 # every rank has drifted to its own statistics
+        w0 = m[0].weight.clone()
+    n = broadcast_buffers(m, 0)
+    q.put((rank, n, [b.tolist() if b.dim() else int(b) for b in m.buffers()], bool(torch.equal(m[0].weight, w0))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bn_buffers_follow_rank0_at_checkpoint_time():
+    """BatchNorm running statistics are rank-local under plain DDP; broadcast_buffers (called by train_nerf_regtr.py
+    before validation and at the checkpoint cadence) gives every rank rank 0's — floats and the int64 counters, parameters untouched."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30411 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_bn_buffer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=120) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][0] == res[1][0] == 6                               # 2 x (mean, var, counter); the alias is not sent twice
+    assert res[0][1] == res[1][1]
+    assert res[1][1][0] == [0.0] * 4 and res[1][1][2] == 2            # rank 1 now holds rank 0's values (10 * 0 + i)
+    assert res[0][2] and res[1][2]
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     """`python bench.py --gpus 2` on a box with fewer GPUs must fail loudly, never run fewer ranks (here: no GPU at all)."""
     import subprocess

@@ -19,6 +19,7 @@ from dreg_nerf_amd.config import config_parser
 from dreg_nerf_amd.dataset import NeRFRegDataset, PrefetchLoader, SyntheticRegDataset
 from dreg_nerf_amd.regtr import NeRFRegTr
 from dreg_nerf_amd.train_step import TrainStep
+from dreg_nerf_amd.optim import broadcast_buffers
 
 
 def to_device(d, dev):
@@ -30,6 +31,9 @@ def validate(model, dataset, dev, frac=0.2, rank=0, world=1):
     """train_nerf_regtr.py:258-291: RRE/RTE on the first 20 % of the validation scenes; score = n / sum(R_mean).
     With several ranks EVERY rank calls this at the same iteration and evaluates scenes rank, rank + world, ...; the two error sums
     are added over the ranks (one small all-reduce), so no rank waits in the next step's gradient exchange while rank 0 validates."""
+    if world > 1:
+        # plain DDP averages gradients, not BatchNorm running statistics: every rank evaluates (and rank 0 later saves) rank 0's buffers
+        broadcast_buffers(model, 0)
     model.eval()
     n = max(1, int(len(dataset) * frac))
     sums = torch.zeros(2, dtype=torch.float64, device=dev)
@@ -116,6 +120,8 @@ def main():
                 score, r, t = validate(model, val_ds, dev, rank=rank, world=world)
                 if rank == 0:
                     print(f"val it {iteration}: R_mean={r:.3f} t_mean={t:.4f}", flush=True)
+            if iteration % cfg.n_checkpoint == 0 and world > 1:
+                broadcast_buffers(model, 0)     # checkpoint time: all ranks continue from the statistics that are saved
             if iteration % cfg.n_checkpoint == 0 and rank == 0:
                 ckpt.save(models, {"optimizer": ts.optimizer}, iteration, schedulers={"scheduler": ts.scheduler}, score=score)
         torch.cuda.synchronize()
