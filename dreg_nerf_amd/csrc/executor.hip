@@ -27,6 +27,7 @@ namespace {
 enum { OP_CONV = 0, OP_BN = 1, OP_MAXPOOL = 2, OP_CONV_ROWS = 3 };
 constexpr int OP_INTS = 16;      // ints per op record
 constexpr int TENSOR_INTS = 5;   // B, D, H, W, C
+constexpr int RL = 8;           // int64 fields per row list: rows, count, brick tiles, ntiles, halo_vox, nbr, rows_sorted, reserved
 constexpr int PARAM_I64 = 5;     // value ptr, grad ptr, d0, d1, ksz  (conv weight: [d0=Cout][d1=Cin][ksz^3]; vectors: d0 = length)
 
 struct Tensor { int B, D, H, W, C; size_t bytes, off, goff; };
@@ -34,6 +35,7 @@ struct Param {
     float* val; float* grad; int d0, d1, ksz;
     size_t pk_fwd = SIZE_MAX, pk_dgrad = SIZE_MAX, pk_cls = SIZE_MAX;   // offsets in the pack buffer
     size_t pk_halo_fwd = SIZE_MAX, pk_halo_dgrad = SIZE_MAX;            // halo-kernel packs (conv_halo.hip)
+    size_t pk_brick_fwd = SIZE_MAX, pk_brick_dgrad = SIZE_MAX;          // staged-neighbourhood packs of the active-set 3^3 layers (conv_brick.hip)
     int cin_pad = 0;
 };
 struct Op {
@@ -53,7 +55,7 @@ struct Op {
     int bt = -1;                 // OP_BN on the one-launch small path: index of its record in the two BatchNorm tail tables
     size_t keep_var = 0, keep_sums = 0;   //   per-grid variances [B][C] / gradient sums [B][C][2] kept until the batched tail launch
 };
-struct HaloPack { const float* w; size_t off; int Cout, Cin, transposed; };
+struct HaloPack { const float* w; size_t off; int Cout, Cin, transposed, brick; };
 struct PackRec { const float* w; void* out; int Cout, Cin_real, inner, ntaps, for_dgrad, Kpad, dtype, row0; };
 static_assert(sizeof(PackRec) == 48, "matches PackDesc of conv.hip");
 
@@ -124,6 +126,7 @@ struct Scope {   // optional HIP-event bracket of one launch group
 int g_sparse_grads = 1;   // tuning (include/dreg_nerf_tuning.h): row-cleared instead of memset gradient buffers in front of the active-set convolutions
 int g_bn_batch_tails = 1; // tuning (include/dreg_nerf_tuning.h): the small BatchNorms' running-statistics / parameter-gradient launches batched per pass
 int g_fuse_stem = 1;      // tuning (include/dreg_nerf_tuning.h): BatchNorm + ReLU + max-pool of the stem in one pass
+int g_brick = 1;          // tuning (include/dreg_nerf_tuning.h): bit 0: active-set 3^3 launches with 64 output channels on csrc/conv_brick.hip when the caller hands over tile tables, bit 1: those with 256 as well
 int g_fuse_bn_stats = 1;  // tuning (include/dreg_nerf_tuning.h): statistics of the large BatchNorm layers from the producing convolution's epilogue
 
 bool s2_class_ok(const Param& p, int ksz, int stride, int pad)
@@ -315,8 +318,14 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
         return o;
     };
     auto add_halo_pack = [&](Param& p, int transposed) {
-        HaloPack hp{p.val, poff, p.d0, p.d1, transposed};
+        HaloPack hp{p.val, poff, p.d0, p.d1, transposed, 0};
         poff += align256(dreg_conv3_halo_pack_bytes(transposed ? p.d0 : p.d1));
+        e->halo_packs.push_back(hp);
+        return hp.off;
+    };
+    auto add_brick_pack = [&](Param& p, int transposed) {
+        HaloPack hp{p.val, poff, p.d0, p.d1, transposed, 1};
+        poff += align256(dreg_conv3_brick_pack_bytes(transposed ? p.d1 : p.d0, transposed ? p.d0 : p.d1));
         e->halo_packs.push_back(hp);
         return hp.off;
     };
@@ -329,6 +338,11 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
             // dense 3^3 convolutions with 256 output channels on large volumes: forward x -> y, data gradient gy -> gx (needs 256 INPUT channels)
             if (dreg_conv3_halo_use(x.B, x.D, x.H, x.W, x.C, p.d0, o.ksz, o.stride, o.pad) && p.d1 == x.C) o.halo |= 1;
             if (e->needs_grad[o.in] && dreg_conv3_halo_use(y.B, y.D, y.H, y.W, p.d0, p.d1, o.ksz, o.stride, o.pad) && p.d0 % 32 == 0) o.halo |= 2;
+        }
+        if (o.kind == OP_CONV_ROWS && o.ksz == 3 && o.pad == 1 && p.d1 == x.C && dreg_brick_supported(x.B, x.D, x.H, x.W, 16, 256)) {
+            // the same layer in the staged-neighbourhood form (used when the step's row sets come with tile tables)
+            if ((p.d0 == 256 || p.d0 == 64) && p.d1 % 16 == 0 && p.pk_brick_fwd == SIZE_MAX) p.pk_brick_fwd = add_brick_pack(p, 0);
+            if (e->needs_grad[o.in] && (p.d1 == 256 || p.d1 == 64) && p.d0 % 16 == 0 && p.pk_brick_dgrad == SIZE_MAX) p.pk_brick_dgrad = add_brick_pack(p, 1);
         }
         if (o.halo & 1) { if (p.pk_halo_fwd == SIZE_MAX) p.pk_halo_fwd = add_halo_pack(p, 0); }
         else if (p.pk_fwd == SIZE_MAX) { p.cin_pad = x.C; p.pk_fwd = add_pack(p, 0, x.C); }
@@ -379,8 +393,10 @@ int dreg_exec_repack(void* h, const void* descs_dev, const int* row_desc_dev, vo
 {
     Exec* e = (Exec*)h;
     CK(dreg_pack_conv_weights_batched(descs_dev, (int)e->packs.size(), e->pack_rows, e->pack_max_floats, row_desc_dev, stream));
-    for (const HaloPack& hp : e->halo_packs)
-        CK(dreg_pack_conv_weight_halo(hp.w, e->pack_base + hp.off, hp.Cout, hp.Cin, hp.transposed, stream));
+    for (const HaloPack& hp : e->halo_packs) {
+        if (hp.brick) CK(dreg_pack_conv_weight_brick(hp.w, e->pack_base + hp.off, hp.Cout, hp.Cin, hp.transposed, stream));
+        else CK(dreg_pack_conv_weight_halo(hp.w, e->pack_base + hp.off, hp.Cout, hp.Cin, hp.transposed, stream));
+    }
     return DREG_OK;
 }
 // bit 0 / bit 1: the forward / data gradient of op `op` runs on the halo kernel (labels of the HIP-event timing records)
@@ -410,6 +426,7 @@ void dreg_exec_set_sparse_grads(int on) { g_sparse_grads = on ? 1 : 0; }   // re
 void dreg_exec_set_bn_batch_tails(int on) { g_bn_batch_tails = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_fuse_stem(int on) { g_fuse_stem = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_fuse_bn_stats(int on) { g_fuse_bn_stats = on ? 1 : 0; }   // read when an executor is created
+void dreg_exec_set_brick(int mask) { g_brick = mask & 3; }   // read at every forward / backward call
 void dreg_exec_set_timing(void* h, int enable) { ((Exec*)h)->timing = enable != 0; }   // records are kept until read
 // After a stream synchronisation: elapsed ms of the bracketed launches since the last set_timing; records are (op, kind, ms)
 // with kind 0 forward, 1 data gradient, 2 weight gradient (+reduce).  Returns the number written (<= max) and restarts.
@@ -460,7 +477,7 @@ static int flush_bn_tails(Exec* e, char* A, std::vector<char>& done, int what, h
     return DREG_OK;
 }
 
-// rowlists: int64 [nlists][2] = (device int32* rows, count).  x: tensor 0.  The result lands at dreg_exec_tensor_offset(output slot).
+// rowlists: int64 [nlists][RL] = (device int32* rows, count, brick tile tables or zeros: include/dreg_nerf.h).  x: tensor 0.  The result lands at dreg_exec_tensor_offset(output slot).
 int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack_base, const void* x_in,
                       const int64_t* rowlists, int nlists, int train, void* stream)
 {
@@ -504,7 +521,13 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
             const void* add = o.in2 >= 0 ? act(o.in2) : nullptr;
             const Tensor* ta = o.in2 >= 0 ? &e->t[o.in2] : nullptr;
             Scope sc(e, st, (int)i, 0);
-            CK(dreg_conv3d_igemm_rows(act(o.in), PK + w.pk_fwd, act(o.out), bias, add, (const int*)rowlists[2 * o.rows_out], (int)rowlists[2 * o.rows_out + 1],
+            const int64_t* rl = rowlists + RL * o.rows_out;
+            if ((g_brick & (w.d0 == 64 ? 1 : 2)) && w.pk_brick_fwd != SIZE_MAX && rl[2] && rl[3] > 0) {
+                CK(dreg_conv3_brick(act(o.in), PK + w.pk_brick_fwd, act(o.out), bias, add, (const void*)rl[2], (int)rl[3], (const int*)rl[4], (const void*)rl[5],
+                                    (const int*)rl[6], x.B, x.D, x.H, x.W, x.C, w.d0, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0, 0, 0, stream));
+                continue;
+            }
+            CK(dreg_conv3d_igemm_rows(act(o.in), PK + w.pk_fwd, act(o.out), bias, add, (const int*)rl[0], (int)rl[1],
                                       x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0, o.ksz, 1, o.pad, 0, 0, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0,
                                       0, 0, stream));
         } else if (o.kind == OP_BN && o.pool >= 0) {
@@ -651,8 +674,8 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
         if (o.kind == OP_CONV || o.kind == OP_CONV_ROWS) {
             const Param& w = e->prm[o.w];
             const bool rows = o.kind == OP_CONV_ROWS;
-            const int* r_out = rows ? (const int*)rowlists[2 * o.rows_out] : nullptr;
-            const int n_out = rows ? (int)rowlists[2 * o.rows_out + 1] : 0;
+            const int* r_out = rows ? (const int*)rowlists[RL * o.rows_out] : nullptr;
+            const int n_out = rows ? (int)rowlists[RL * o.rows_out + 1] : 0;
             // parameter gradients first, on the second stream: gy is complete here (every consumer of this op's output has been
             // processed), and nothing below modifies gy or the op's input activation
             const bool pg = w.grad || (o.b >= 0 && e->prm[o.b].grad);
@@ -703,7 +726,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                 else if (rows && o.ds_rows >= 0 && o.ds_rows < nlists) {
                     void* dst = dst_for(o.in2);
                     if (hipMemsetAsync(dst, 0, (size_t)ta.B * ta.D * ta.H * ta.W * ta.C * 2, st) != hipSuccess) return DREG_ELAUNCH;
-                    CK(dreg_downsample_sum_rows(gy, dst, (const int*)rowlists[2 * o.ds_rows], (int)rowlists[2 * o.ds_rows + 1],
+                    CK(dreg_downsample_sum_rows(gy, dst, (const int*)rowlists[RL * o.ds_rows], (int)rowlists[RL * o.ds_rows + 1],
                                                 y.D, y.H, y.W, ta.D, ta.H, ta.W, y.C, 0, stream));
                 }
                 else CK(dreg_downsample_sum(gy, dst_for(o.in2), y.B, y.D, y.H, y.W, ta.D, ta.H, ta.W, y.C, 0, stream));
@@ -726,15 +749,20 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                                             o.ksz, o.stride, o.pad, 1, 0, x.D, x.H, x.W, 1, 0, 0, A + e->off_ks, e->sz_ks, stream));
                 } else if (rows) {
                     if (o.rows_in < 0 || o.rows_in >= nlists) return DREG_EINVAL;
-                    const int* r_in = (const int*)rowlists[2 * o.rows_in];
-                    const int n_in = (int)rowlists[2 * o.rows_in + 1];
+                    const int64_t* rl = rowlists + RL * o.rows_in;
+                    const int* r_in = (const int*)rl[0];
+                    const int n_in = (int)rl[1];
                     if (o.sparse_gx && gx == grad(o.in)) {
                         // the buffer is zero everywhere (see the start of this call); remember which rows this step writes
                         if (n_in > 0 && hipMemcpyAsync(A + o.cl_off, r_in, (size_t)n_in * sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess) return DREG_ELAUNCH;
                         const_cast<Op&>(o).cl_count = n_in;
                     } else if (hipMemsetAsync(gx, 0, (size_t)x.B * x.D * x.H * x.W * x.C * 2, st) != hipSuccess) return DREG_ELAUNCH;
-                    CK(dreg_conv3d_igemm_rows(gy, PK + w.pk_dgrad, gx, nullptr, nullptr, (const int*)rowlists[2 * o.rows_in], (int)rowlists[2 * o.rows_in + 1],
-                                              x.B, y.D, y.H, y.W, w.d0, x.D, x.H, x.W, x.C, o.ksz, 1, o.pad, 1, 0, 0, 0, 0, 0, 0, stream));
+                    if ((g_brick & (w.d1 == 64 ? 1 : 2)) && w.pk_brick_dgrad != SIZE_MAX && rl[2] && rl[3] > 0)
+                        CK(dreg_conv3_brick(gy, PK + w.pk_brick_dgrad, gx, nullptr, nullptr, (const void*)rl[2], (int)rl[3], (const int*)rl[4], (const void*)rl[5],
+                                            (const int*)rl[6], x.B, x.D, x.H, x.W, w.d0, w.d1, 0, 0, 0, 0, 0, stream));
+                    else
+                        CK(dreg_conv3d_igemm_rows(gy, PK + w.pk_dgrad, gx, nullptr, nullptr, r_in, n_in,
+                                                  x.B, y.D, y.H, y.W, w.d0, x.D, x.H, x.W, x.C, o.ksz, 1, o.pad, 1, 0, 0, 0, 0, 0, 0, stream));
                 } else if (w.pk_cls != SIZE_MAX && s2_class_ok(w, o.ksz, o.stride, o.pad)) {
                     CK(dreg_conv3d_dgrad_s2(gy, PK + w.pk_cls, gx, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0, o.ksz, o.pad, stream));
                 } else {

@@ -78,6 +78,7 @@ SIGNATURES = {
     "dreg_bn_set_small_regs": (None, [I]),
     "dreg_exec_set_fuse_stem": (None, [I]),
     "dreg_exec_set_fuse_bn_stats": (None, [I]),
+    "dreg_exec_set_brick": (None, [I]),
     "dreg_conv_set_bn_stats_epilogue": (None, [I]),
     "dreg_exec_set_bn_batch_tails": (None, [I]),
     "dreg_exec_set_sparse_grads": (None, [I]),
@@ -162,6 +163,13 @@ SIGNATURES = {
     "dreg_overlap_bwd_acc": (I, [P, P, P, P, P, P, P, P, I, P, I, P]),
     "dreg_colsum_rows_per_chunk": (I, [Z]),
     "dreg_colsum_batched": (I, [P, I, I, I, P]),
+    # conv_brick.hip
+    "dreg_brick_supported": (I, [I] * 6),
+    "dreg_conv3_brick_pack_bytes": (Z, [I, I]),
+    "dreg_pack_conv_weight_brick": (I, [P, P, I, I, I, P]),
+    "dreg_brick_tiles_workspace_bytes": (Z, [I] * 4),
+    "dreg_brick_tiles_build": (I, [P, I, I, I, I, I, I, P, Z, P, P, P, P, P, P]),
+    "dreg_conv3_brick": (I, [P, P, P, P, P, P, I, P, P, P] + [I] * 11 + [P]),
     # pointset_exec.hip
     "dreg_ps_num_params": (I, []),
     "dreg_ps_num_linears": (I, []),

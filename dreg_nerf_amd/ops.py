@@ -654,8 +654,14 @@ def conv3d_rows(x, w, bias, addend, pad, out_rows, in_rows):
     return SparseConv3dFn.apply(x, w, bias, addend, pad, out_rows, in_rows)
 
 
+class RowSets(tuple):
+    """The tuple active_sets returns, plus `tiles`: {row-list position -> brick.BrickTiles} when tile tables were requested (the
+    active-set 3^3 convolutions then run on csrc/conv_brick.hip: staged-neighbourhood reuse instead of a 27-tap gather per row)."""
+    tiles = None
+
+
 def active_sets(idx_list, fine_res, coarse_dims, device, pt_batch=None, idx_cat=None, density_cap: float = 0.3,
-                level2: bool = True, level2_cap: float = 0.5):
+                level2: bool = True, level2_cap: float = 0.5, brick_tiles=False):
     """Row lists for the FPN head: S1 = trilinear-gather corner voxels of the occupied fine voxels (where P1 is consumed),
     S2 = S1 dilated by 3^3 (where the lateral sum is consumed), S3 = S2 dilated (where dc1 of the head is non-zero).
     idx_list: per grid int64 flat fine indices ((x*Yr + y)*Zr + z).  Returns three ascending int32 tensors of flat indices
@@ -694,8 +700,21 @@ def active_sets(idx_list, fine_res, coarse_dims, device, pt_batch=None, idx_cat=
     if n3 > density_cap * V:   # dense scenes: the row lists stop paying (and the wgrad slice cap applies)
         return None
     out = (rows[0, :n1], rows[1, :n2], rows[2, :n3], map1)
-    if level2 and m2 <= level2_cap * V2:
+    use2 = level2 and m2 <= level2_cap * V2
+    if use2:
         out = out + (rows2[0, :m1], rows2[1, :m2])
+    out = RowSets(out)
+    if brick_tiles and lib.dreg_brick_supported(B, d, h, w, 16, 256):
+        # tile tables of every row set from its flag volume (still in the builders' workspaces), one more host read for the tile counts
+        from . import brick
+        sets = [(0, ws[0:V], n1, (B, d, h, w)), (1, ws[V:2 * V], n2, (B, d, h, w)), (2, ws[2 * V:3 * V], n3, (B, d, h, w))]
+        if use2:
+            sets += [(4, ws2[0:V2], m1, (B, d2, h2, w2)), (5, ws2[V2:2 * V2], m2, (B, d2, h2, w2))]
+        want = None if brick_tiles is True else set(brick_tiles)      # True: every set; else the row-list positions asked for
+        bts = {k: brick.build_async(f.view(*dims), n) for k, f, n, dims in sets if n > 0 and (want is None or k in want)}
+        if bts:
+            metas = torch.stack([bt.meta for bt in bts.values()]).tolist()
+            out.tiles = {k: bt for (k, bt), mh in zip(bts.items(), metas) if not brick.finish(bt, mh).overflow}
     return out
 
 

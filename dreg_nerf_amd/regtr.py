@@ -106,6 +106,13 @@ class NeRFRegTr(nn.Module):
         # Run the data-dependent geometry phase of forward_batch on its own high-priority stream (see forward_batch)
         self.async_geometry = True
         self.skip_empty_stem_rows = True   # stem output rows whose receptive field is all zero are written as zeros, not computed
+        # The active-set 3^3 head convolutions (forward and data gradient) on csrc/conv_brick.hip: the union of a 256-row tile's
+        # neighbourhoods staged once instead of a 27-tap gather per row (same results up to the order of the fp32 sums)
+        self.brick_head = True
+        # row sets that get tile tables (positions in ops.active_sets' tuple): S3 = the rows of the 256 -> 64 data gradient of
+        # pyramid_transformation_1, the one launch the staged form wins clearly (309 vs 455 us); the executor's dreg_exec_set_brick
+        # mask decides which launches use tables that exist (tools/bench_conv_brick.py measures all six)
+        self.brick_sets = (2,)
         # Issue the point-set half (encoder, decoder, heads) of forward_batch from the C++ executor (csrc/pointset_exec.hip)
         self.native_pointset = True
         self._spec = params.regtr_spec(self.pos_emb_type)
@@ -342,7 +349,8 @@ class NeRFRegTr(nn.Module):
             offs.append(offs[-1] + c)
         rows = None
         if self.active_set and self.precision == "bf16":
-            rows = ops.active_sets(idxs, res, tuple((r + 1) // 2 for r in res), dev, pt_batch=pb_cat, idx_cat=idx_cat)
+            rows = ops.active_sets(idxs, res, tuple((r + 1) // 2 for r in res), dev, pt_batch=pb_cat, idx_cat=idx_cat,
+                                   brick_tiles=self.brick_sets if (self.brick_head and self.native_trunk) else False)
         # the gather backward is evaluated per consumed coarse voxel (S1) in every mode: atomic-free, deterministic
         s1_rows = rows[0] if rows is not None else \
             ops.active_sets(idxs, res, tuple((r + 1) // 2 for r in res), dev, pt_batch=pb_cat, idx_cat=idx_cat, density_cap=1.0, level2=False)[0]
@@ -387,6 +395,9 @@ class NeRFRegTr(nn.Module):
                 keep.append(grids[0])
             if rows is not None and len(rows) >= 6:
                 keep.append(rows[4])
+            if rows is not None and getattr(rows, "tiles", None):
+                for bt in rows.tiles.values():
+                    bt.record_stream(main)
             for rounds in plans:
                 for rnd in rounds:
                     keep += [rnd.order, rnd.starts, rnd.n_out_dev, rnd.inv_seg, rnd.inv_cnt]

@@ -16,6 +16,7 @@ from . import lib as L
 from . import ops
 
 OP_CONV, OP_BN, OP_MAXPOOL, OP_CONV_ROWS = 0, 1, 2, 3
+RL_FIELDS = 8      # int64 fields per row list handed to the executor: rows, count, then the brick tile tables (tiles, ntiles, halo, nbr, rows_sorted, 0)
 # DREG_SERIAL_STREAMS=1: no second stream for parameter gradients (every kernel alone on the GPU: what a per-kernel profile wants)
 SERIAL_STREAMS = bool(int(__import__("os").environ.get("DREG_SERIAL_STREAMS", "0")))
 KIND_NAMES = {0: "fwd", 1: "dgrad", 2: "wgrad"}
@@ -209,12 +210,17 @@ class TrunkExecutor:
         if rows is None:
             return None, 0
         n = len(rows)
-        a = (ctypes.c_int64 * (2 * n))()
+        a = (ctypes.c_int64 * (RL_FIELDS * n))()
+        tiles = getattr(rows, "tiles", None) or {}
         for i in range(n):
             if i == 3 or rows[i] is None:   # slot 3 is map1 (not a row list)
                 continue
-            a[2 * i] = rows[i].data_ptr()
-            a[2 * i + 1] = rows[i].shape[0]
+            a[RL_FIELDS * i] = rows[i].data_ptr()
+            a[RL_FIELDS * i + 1] = rows[i].shape[0]
+            bt = tiles.get(i)
+            if bt is not None and bt.ntiles > 0:   # tile tables of csrc/conv_brick.hip for this row set
+                a[RL_FIELDS * i + 2], a[RL_FIELDS * i + 3] = bt.tiles.data_ptr(), bt.ntiles
+                a[RL_FIELDS * i + 4], a[RL_FIELDS * i + 5], a[RL_FIELDS * i + 6] = bt.halo.data_ptr(), bt.nbr.data_ptr(), bt.rows_sorted.data_ptr()
         return a, n
 
     def forward(self, x: torch.Tensor, rows, train: bool) -> torch.Tensor:

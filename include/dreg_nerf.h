@@ -297,6 +297,9 @@ void dreg_exec_set_overlap(void* h, int enable);
 void dreg_exec_set_input_row_occupancy(void* h, const uint8_t* rowocc);   /* flags for the convolution that reads x_in (the stem); null = none */                             /* 1 (default): weight gradients on aux_stream */
 void dreg_exec_set_timing(void* h, int enable);                              /* HIP events around every convolution launch */
 int dreg_exec_read_timings(void* h, int* op_kind, float* ms, int max);       /* (op, kind 0 fwd / 1 dgrad / 2 wgrad), ms */
+/* rowlists: int64 [nlists][8] per active-set row list = { device int32* rows, count, then (or zeros) the tile tables of
+ * dreg_brick_tiles_build for the same set: tiles, ntiles, halo_vox, nbr, rows_sorted, 0 }.  A 3^3 active-set convolution whose row
+ * list (forward: output rows; data gradient: input rows) comes with tables runs on dreg_conv3_brick, otherwise on dreg_conv3d_igemm_rows. */
 int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack_base, const void* x_in,
                       const int64_t* rowlists, int nlists, int train, void* stream);
 int dreg_exec_backward(void* h, void* arena, size_t arena_bytes, const void* pack_base, const void* x_in,
@@ -515,6 +518,26 @@ int dreg_surface_visibility_fill_desc(void* host_desc, const float* cams, const 
                                       int rx, int ry, int rz, int Nc, int Np, float render_step_size, float cut_off, float early_stop_eps,
                                       float alpha_thre, void* queue, const uint32_t* coarse_bits);
 int dreg_surface_visibility_multi(const void* descs_dev, int n, long total_rays, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- active-set 3^3 convolution with
+ * staged-neighbourhood reuse (csrc/conv_brick.hip): the FPN head layers upsample_transform_{1,2} / pyramid_transformation_1 and their
+ * data gradients on the voxels around the occupied surface (conerf/model/feature_pyramid_net.py:47-56,97-103; the reference runs
+ * cuDNN conv3d over the whole volume).  Same results as dreg_conv3d_igemm_rows up to the order of the fp32 sums.
+ * dreg_brick_tiles_build: flags uint8 [B,D,H,W] (1 = row is computed) -> rows in brick-major order + tile tables:
+ *   meta int32 [4] = (rows, candidate tiles, tiles emitted, overflow flag); rows_sorted int32 [max_rows]; tiles [max_tiles] x 16 B
+ *   { row0, nrows, nhalo, pad }; halo_vox int32 [max_tiles][1280] (voxel staged in each LDS slot); nbr uint16 [max_tiles][256][28]
+ *   (LDS byte offset of every (row, tap) neighbour).  The caller reads meta[2] (= ntiles) / meta[3] on the host before it launches.
+ * dreg_conv3_brick: out[rows] = bias + addend + conv3(in) at the tiled rows; Cout in {256, 64}; Cin % 16 == 0; wpk from
+ * dreg_pack_conv_weight_brick (transposed = 1: the data-gradient pack, rows = Cin of the layer). */
+int dreg_brick_supported(int B, int D, int H, int W, int Cin, int Cout);
+size_t dreg_conv3_brick_pack_bytes(int rows, int red);
+int dreg_pack_conv_weight_brick(const float* w, void* out, int Cout, int Cin, int transposed, void* stream);
+size_t dreg_brick_tiles_workspace_bytes(int B, int D, int H, int W);
+int dreg_brick_tiles_build(const uint8_t* flags, int B, int D, int H, int W, int max_rows, int max_tiles, void* workspace, size_t workspace_bytes,
+                           int* meta, int* rows_sorted, void* tiles, int* halo_vox, void* nbr, void* stream);
+int dreg_conv3_brick(const void* in, const void* wpk, void* out, const float* bias, const void* addend, const void* tiles, int ntiles,
+                     const int* halo_vox, const void* nbr, const int* rows_sorted,
+                     int B, int D, int H, int W, int Cin, int Cout, int Da, int Ha, int Wa, int add_same, int out_f32, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- native point-set executor
  * (csrc/pointset_exec.hip) The six encoder layers (conerf/register/transformer.py:50-86,225-299), the shared final norm
