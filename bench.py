@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--event-steps", type=int, default=1, help="timed steps whose conv launches are bracketed by HIP events (roofline line)")
     ap.add_argument("--kernel-report", default="", help="write the per-kernel/per-shape event timing table here")
     ap.add_argument("--no-dense-reference", action="store_true", help="skip the additional dense-head measurement")
+    ap.add_argument("--no-ngp-reference", action="store_true", help="skip the additional NGP grid-extraction measurement (BASELINE.json configs[3]) of the default line")
     ap.add_argument("--no-nerf-labels-reference", action="store_true", help="skip the additional measurement of the step with overlap labels from generated NeRF blocks")
     ap.add_argument("--dense-head", action="store_true", help="evaluate the FPN head densely (BASELINE.md FLOP accounting) instead of on the active set")
     ap.add_argument("--cpu-samples", type=int, default=3, help="timed samples of the CPU baseline (after one warm-up)")
@@ -292,7 +293,7 @@ def nerf_labels_bench(args, rank, world, dev):
                    "global_batch_pairs": args.pairs * world, "resolution": args.res, "parallelism": f"dp{world}"}}), flush=True)
 
 
-def ngp_bench(args, rank, world, dev):
+def ngp_measure(args, rank, world, dev):
     """BASELINE.json configs[3]: one 128^3 NeRF block = Np occupied cells -> world samples -> density (hash grid + MLP) -> colour x 18
     directions -> alpha / masks -> voxel_grid + voxel_mask (eval_ngp_nerf.py:336-412 without the surface ray march, which needs the
     block's training cameras).  Every rank extracts its own blocks (replicas only, no collective).  A "step" = one block."""
@@ -337,7 +338,7 @@ def ngp_bench(args, rank, world, dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     if rank != 0:
-        return
+        return None
     # per-kernel times (events on the launch stream = torch's current stream), same inputs
     world_pts = sg.query_dense(f, dev, jitter=jitter)[0]
 
@@ -382,14 +383,20 @@ def ngp_bench(args, rank, world, dev):
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = ngp_cpu_baseline(args.ngp_radius, min(os.cpu_count() or 1, 16))
-    print(json.dumps({
+    return {
         "metric": "ngp_grid_extraction_blocks_per_sec_128", "value": args.steps * world / el, "unit": "blocks/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"NGP occupancy-grid extraction, one 128^3 block per step: {npts} occupied cells (ball r={args.ngp_radius}) -> density + "
                                f"18-direction colour + voxel_grid writer; generated hash-grid / MLP weights", "points_per_block": npts,
                    "parallelism": f"replicas x{world}"},
-        "points_per_sec": npts * args.steps * world / el, "roofline": rf, **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
+        "points_per_sec": npts * args.steps * world / el, "roofline": rf, **({"cpu_baseline": cpu} if cpu else {})}
+
+
+def ngp_bench(args, rank, world, dev):
+    out = ngp_measure(args, rank, world, dev)
+    if out is not None:
+        print(json.dumps(out), flush=True)
 
 
 def spawn_ranks(args):
@@ -476,6 +483,9 @@ def main():
             ts.step(batch)
         sync()
         ops.PROFILER = ops.KernelTimer()
+        # --kernel-report wants every linear layer of the point-set half as a bracketed launch of its own (per-op path for the bracketed
+        # step); the default line keeps the native point-set executor in that step too (the roofline kernel belongs to the trunk)
+        ops.PROFILER.include_pointset = bool(args.kernel_report)
         t0 = time.perf_counter()
         for i in range(args.steps):
             if i == args.event_steps:      # HIP-event brackets on the first steps of the timed region only (they cost host time)
@@ -627,12 +637,39 @@ def main():
                        "parallelism": f"dp{world}"},
             "roofline": roofline,
         }
+        # the step as a whole against the same roof: every bracketed convolution / linear launch of the bracketed step (algorithmic
+        # FLOPs; stride-2 data gradients at 1/8 of the dense taps) + the point-set half's linear layers when they ran unbracketed
+        # (1,048,576 MAC per key point and encoder layer, 131,072 per decoder layer-row: SURVEY.md 8(d)), over the step's wall time
+        bracketed = sum(fl for (c, m, fl) in prof.summary(subtract_overhead=False)[0].values()) / max(min(args.event_steps, args.steps), 1)
+        lin = 0.0
+        if not args.kernel_report and getattr(model, "last_batched", None) is not None and args.precision == "bf16":
+            R = int(model.last_batched["xyz"].shape[0])
+            lin = 3.0 * 2.0 * R * 6 * (1048576 + 131072)
+        out["whole_step"] = {"algorithmic_TFLOP_per_step": (bracketed + lin) / 1e12, "achieved_TFLOPs": (bracketed + lin) / (elapsed / args.steps) / 1e12,
+                             "frac_of_mfma_roof": (bracketed + lin) / (elapsed / args.steps) / 1e12 / peak,
+                             "note": "convolutions + linear layers only (attention, BatchNorm, LayerNorm, optimizer excluded from the FLOPs, included in the time)"}
         if dense is not None:
             out["dense_head"] = dense
         if sweep is not None:
             out["occupancy_sweep"] = sweep
         if with_labels is not None:
             out["labels_from_nerf_blocks"] = with_labels
+        if world == 1 and not args.no_ngp_reference and args.precision == "bf16":
+            # BASELINE.json configs[3] beside the headline (the driver only runs the default line): NGP grid extraction of one 128^3 block,
+            # the same measurement as `python bench.py --ngp`, compact
+            try:
+                import copy
+                a2 = copy.copy(args)
+                a2.steps, a2.warmup = 20, 3
+                ng = ngp_measure(a2, rank, world, dev)
+                rf_n = ng["roofline"]
+                out["ngp_config4"] = {"metric": ng["metric"], "value": ng["value"], "unit": ng["unit"], "ms_per_block": ng["ms_per_step"],
+                                      "points_per_block": ng["config"]["points_per_block"],
+                                      "roofline": {k: rf_n.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms")},
+                                      "density_query": {k: rf_n["density_kernel"].get(k) for k in ("kernel", "avg_launch_ms", "Gpts_per_s", "traffic", "gathered_over_hbm_bytes")},
+                                      **({"cpu_baseline": ng["cpu_baseline"]} if "cpu_baseline" in ng else {})}
+            except Exception as e:      # never lose the headline line to the extra figure
+                out["ngp_config4"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             cres = args.cpu_res or (128 if (os.cpu_count() or 1) >= 32 else 64)
             out["cpu_baseline"] = cpu_baseline(min(cres, args.res), args.res, args.cpu_samples)

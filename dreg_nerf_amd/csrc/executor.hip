@@ -65,7 +65,7 @@ static_assert(sizeof(ReduceRec) == 48, "matches WgradReduceDesc of conv.hip");
 struct BnTailRec { const float* a; const float* b; float* o0; float* o1; int B, V, C, block0; };
 static_assert(sizeof(BnTailRec) == 48, "matches BnTailDesc of fpn_ops.hip");
 
-struct TimedLaunch { hipEvent_t e0, e1; int op, kind; };
+struct TimedLaunch { hipEvent_t e0, e1; int op, kind, variant; };   // variant: 0 = implicit-GEMM dispatch, 2 = conv_brick.hip (the halo kernel is dreg_exec_op_halo)
 
 struct Exec {
     std::vector<Tensor> t;
@@ -115,10 +115,11 @@ struct Scope {   // optional HIP-event bracket of one launch group
             e->timed.push_back(n);
         }
         tl = &e->timed[e->timed_used++];
-        tl->op = op; tl->kind = kind;
+        tl->op = op; tl->kind = kind; tl->variant = 0;
         (void)hipEventRecord(tl->e0, st);
     }
     ~Scope() { if (tl) (void)hipEventRecord(tl->e1, st); }
+    void variant(int v) { if (tl) tl->variant = v; }
 };
 
 #define CK(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
@@ -428,8 +429,8 @@ void dreg_exec_set_fuse_stem(int on) { g_fuse_stem = on ? 1 : 0; }   // read whe
 void dreg_exec_set_fuse_bn_stats(int on) { g_fuse_bn_stats = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_brick(int mask) { g_brick = mask & 3; }   // read at every forward / backward call
 void dreg_exec_set_timing(void* h, int enable) { ((Exec*)h)->timing = enable != 0; }   // records are kept until read
-// After a stream synchronisation: elapsed ms of the bracketed launches since the last set_timing; records are (op, kind, ms)
-// with kind 0 forward, 1 data gradient, 2 weight gradient (+reduce).  Returns the number written (<= max) and restarts.
+// After a stream synchronisation: elapsed ms of the bracketed launches since the last set_timing; records are (op, kind, variant, ms)
+// with kind 0 forward, 1 data gradient, 2 weight gradient (+reduce); variant 2 = the launch ran on csrc/conv_brick.hip; op_kind holds 3 ints per record.  Returns the number written (<= max) and restarts.
 int dreg_exec_read_timings(void* h, int* op_kind, float* ms, int max)
 {
     Exec* e = (Exec*)h;
@@ -437,7 +438,7 @@ int dreg_exec_read_timings(void* h, int* op_kind, float* ms, int max)
     for (size_t i = 0; i < e->timed_used && n < max; ++i) {
         float v = 0.f;
         if (hipEventElapsedTime(&v, e->timed[i].e0, e->timed[i].e1) != hipSuccess) continue;
-        op_kind[2 * n] = e->timed[i].op; op_kind[2 * n + 1] = e->timed[i].kind; ms[n] = v; ++n;
+        op_kind[3 * n] = e->timed[i].op; op_kind[3 * n + 1] = e->timed[i].kind; op_kind[3 * n + 2] = e->timed[i].variant; ms[n] = v; ++n;
     }
     e->timed_used = 0;
     return n;
@@ -523,6 +524,7 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
             Scope sc(e, st, (int)i, 0);
             const int64_t* rl = rowlists + RL * o.rows_out;
             if ((g_brick & (w.d0 == 64 ? 1 : 2)) && w.pk_brick_fwd != SIZE_MAX && rl[2] && rl[3] > 0) {
+                sc.variant(2);
                 CK(dreg_conv3_brick(act(o.in), PK + w.pk_brick_fwd, act(o.out), bias, add, (const void*)rl[2], (int)rl[3], (const int*)rl[4], (const void*)rl[5],
                                     (const int*)rl[6], x.B, x.D, x.H, x.W, x.C, w.d0, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0, 0, 0, stream));
                 continue;
@@ -757,10 +759,11 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                         if (n_in > 0 && hipMemcpyAsync(A + o.cl_off, r_in, (size_t)n_in * sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess) return DREG_ELAUNCH;
                         const_cast<Op&>(o).cl_count = n_in;
                     } else if (hipMemsetAsync(gx, 0, (size_t)x.B * x.D * x.H * x.W * x.C * 2, st) != hipSuccess) return DREG_ELAUNCH;
-                    if ((g_brick & (w.d1 == 64 ? 1 : 2)) && w.pk_brick_dgrad != SIZE_MAX && rl[2] && rl[3] > 0)
+                    if ((g_brick & (w.d1 == 64 ? 1 : 2)) && w.pk_brick_dgrad != SIZE_MAX && rl[2] && rl[3] > 0) {
+                        sc.variant(2);
                         CK(dreg_conv3_brick(gy, PK + w.pk_brick_dgrad, gx, nullptr, nullptr, (const void*)rl[2], (int)rl[3], (const int*)rl[4], (const void*)rl[5],
                                             (const int*)rl[6], x.B, x.D, x.H, x.W, w.d0, w.d1, 0, 0, 0, 0, 0, stream));
-                    else
+                    } else
                         CK(dreg_conv3d_igemm_rows(gy, PK + w.pk_dgrad, gx, nullptr, nullptr, r_in, n_in,
                                                   x.B, y.D, y.H, y.W, w.d0, x.D, x.H, x.W, x.C, o.ksz, 1, o.pad, 1, 0, 0, 0, 0, 0, 0, stream));
                 } else if (w.pk_cls != SIZE_MAX && s2_class_ok(w, o.ksz, o.stride, o.pad)) {

@@ -251,7 +251,7 @@ int dreg_ps_forward(void* h, void* arena, size_t arena_bytes, const int64_t* pac
 int dreg_ps_backward(void* h, void* arena, size_t arena_bytes, const int64_t* packs, const float* feats, const float* xyz, const float* pe,
                      const int* probs_self, const int* probs_cross, int nprob, int max_len, int R,
                      const float* cond, const float* corr, const float* ov, const float* g_cond, const float* g_corr, const float* g_ov,
-                     float* d_feats, void* stream, void* aux_stream)
+                     float* d_feats, void* stream, void* aux_stream, int last_only)
 {
     Ps* p = (Ps*)h;
     if (R <= 0 || R != p->lay.R) return DREG_EINVAL;     // the arena holds the forward pass of exactly this row space
@@ -263,9 +263,15 @@ int dreg_ps_backward(void* h, void* arena, size_t arena_bytes, const int64_t* pa
     hipStream_t ax = aux_stream && aux_stream != stream ? (hipStream_t)aux_stream : st;
     const bool two = ax != st;
     const float sc = 0.17677669529663687f;
-    const int R6 = NL * R;
+    // last_only: the three gradients belong to the LAST layer's outputs only ([R,256] / [R,3] / [R]) — the training losses read nothing else
+    // (train_nerf_regtr.py:178,195,205-206,214,220) — so the heads, the decoder and the final norm are differentiated for that layer's R
+    // rows instead of 6R rows of which five sixths carry a zero gradient (the reference's per-layer autograd nodes are never reached either)
+    const int LB = last_only ? NL - 1 : 0, nlb = last_only ? 1 : NL;
+    const int R6 = nlb * R;
+    const size_t rb = (size_t)LB * R;                    // first row of the differentiated block in the [6R, ...] tensors
     const int fuse = p->fuse;
     auto pk = [&](int li, int t) { return (const void*)packs[2 * li + t]; };
+    cond += rb * E; corr += rb * 3; ov += rb;
     if (p->ev.size() < (size_t)NLIN + 2) {
         p->ev.resize(NLIN + 2, nullptr);
         for (auto& e : p->ev) if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DREG_ELAUNCH;
@@ -304,45 +310,53 @@ int dreg_ps_backward(void* h, void* arena, size_t arena_bytes, const int64_t* pa
     const float* Gcond = g_cond;
     if (g_ov) {
         // cond's gradient = what the losses sent (g_cond) + the head's, formed in dallx (free until the final norm's backward writes it)
-        CK(dreg_overlap_bwd_acc(cond, p->val[CW], ov, g_ov, (float*)(A + y.dallx), g_cond, p->grad[CW], p->grad[CB], 1, (float*)(A + y.ov_ws), R6, stream));
-        Gcond = (const float*)(A + y.dallx);
+        CK(dreg_overlap_bwd_acc(cond, p->val[CW], ov, g_ov, (float*)(A + y.dallx) + rb * E, g_cond, p->grad[CW], p->grad[CB], 1, (float*)(A + y.ov_ws), R6, stream));
+        Gcond = (const float*)(A + y.dallx) + rb * E;
     }
     // ---- correspondence decoder (nerf_regtr.py:273-308,350-394)
     bool have_dec = false;
     if (g_corr) {
-        CK(dreg_corr_attention_varlen_bwd(A + y.q, A + y.k, xyz, corr, g_corr, (const float*)(A + y.corr_lse), (float*)(A + y.dvec), A + y.dq, A + y.dk,
-                                          probs_cross, nprob, max_len, max_len, NL, R, 0.0625f, 0, stream));
-        CK(param_grads(NLIN - 1, A + y.dk, A + y.dec_in, R6, y.wgk, y.csk));
-        CK(param_grads(NLIN - 2, A + y.dq, A + y.dec_in, R6, y.wgq, y.csq));
-        CK(linear_dgrad(p, y, A, A + y.dk, pk(NLIN - 1, 1), A + y.ddec, nullptr, nullptr, R6, E, E, stream));
-        if (fuse) CK(linear_dgrad(p, y, A, A + y.dq, pk(NLIN - 2, 1), A + y.ddec, nullptr, A + y.ddec, R6, E, E, stream));
+        const size_t ob = rb * E * 2;                     // byte offset of the block in the bf16 [6R,256] tensors
+        CK(dreg_corr_attention_varlen_bwd(A + y.q + ob, A + y.k + ob, xyz, corr, g_corr, (const float*)(A + y.corr_lse) + rb, (float*)(A + y.dvec), A + y.dq + ob, A + y.dk + ob,
+                                          probs_cross, nprob, max_len, max_len, nlb, R, 0.0625f, 0, stream));
+        CK(param_grads(NLIN - 1, A + y.dk + ob, A + y.dec_in + ob, R6, y.wgk, y.csk));
+        CK(param_grads(NLIN - 2, A + y.dq + ob, A + y.dec_in + ob, R6, y.wgq, y.csq));
+        CK(linear_dgrad(p, y, A, A + y.dk + ob, pk(NLIN - 1, 1), A + y.ddec + ob, nullptr, nullptr, R6, E, E, stream));
+        if (fuse) CK(linear_dgrad(p, y, A, A + y.dq + ob, pk(NLIN - 2, 1), A + y.ddec + ob, nullptr, A + y.ddec + ob, R6, E, E, stream));
         else {
-            CK(linear_dgrad(p, y, A, A + y.dq, pk(NLIN - 2, 1), A + y.ddec2, nullptr, nullptr, R6, E, E, stream));
-            CK(dreg_add_inplace(A + y.ddec, A + y.ddec2, (size_t)R6 * E, 0, stream));
+            CK(linear_dgrad(p, y, A, A + y.dq + ob, pk(NLIN - 2, 1), A + y.ddec2 + ob, nullptr, nullptr, R6, E, E, stream));
+            CK(dreg_add_inplace(A + y.ddec + ob, A + y.ddec2 + ob, (size_t)R6 * E, 0, stream));
         }
         have_dec = true;
     }
     // ---- the final norm's two applications: dallx = LN'(Gcond) + LN'(ddec), with a bf16 copy for the first GEMMs below
     float* dallx = (float*)(A + y.dallx);
     const float* allx = (const float*)(A + y.allx);
-    const float* stf = (const float*)(A + y.stf);
+    {
+        // the differentiated block of the final norm: rows [rb, rb + R6) of allx / its statistics / dallx / the bf16 copy
+        const float* ax = allx + rb * E;
+        const float* stf = (const float*)(A + y.stf) + rb * 2;
+        float* dg = dallx + rb * E;
+        char* dgb = A + y.dallx_bf + rb * E * 2;
+        const char* dd = A + y.ddec + rb * E * 2;
     if (Gcond && have_dec && fuse) {
-        CK(dreg_layernorm_bwd_parts(allx, Gcond, A + y.ddec, p->val[FNW], stf, dallx, nullptr, nullptr, A + y.dallx_bf, (float*)(A + y.lnpf[0]), R6, E, 1, stream));
+        CK(dreg_layernorm_bwd_parts(ax, Gcond, dd, p->val[FNW], stf, dg, nullptr, nullptr, dgb, (float*)(A + y.lnpf[0]), R6, E, 1, stream));
         ln_rec(y.lnpf[0], FNW, FNB, R6);
     } else if (Gcond || have_dec) {
         bool first = true;
         if (Gcond) {
             // Gcond may BE dallx (head-only gradient): the row pass reads a row's dy before it writes the row's dx, each row by one wave
-            CK(dreg_layernorm_bwd_parts(allx, Gcond, nullptr, p->val[FNW], stf, dallx, nullptr, nullptr, have_dec ? nullptr : A + y.dallx_bf, (float*)(A + y.lnpf[0]), R6, E, 1, stream));
+            CK(dreg_layernorm_bwd_parts(ax, Gcond, nullptr, p->val[FNW], stf, dg, nullptr, nullptr, have_dec ? nullptr : dgb, (float*)(A + y.lnpf[0]), R6, E, 1, stream));
             ln_rec(y.lnpf[0], FNW, FNB, R6);
             first = false;
         }
         if (have_dec) {
-            CK(dreg_layernorm_bwd_parts(allx, A + y.ddec, nullptr, p->val[FNW], stf, dallx, first ? nullptr : dallx, nullptr, A + y.dallx_bf, (float*)(A + y.lnpf[1]), R6, E, 0, stream));
+            CK(dreg_layernorm_bwd_parts(ax, dd, nullptr, p->val[FNW], stf, dg, first ? nullptr : dg, nullptr, dgb, (float*)(A + y.lnpf[1]), R6, E, 0, stream));
             ln_rec(y.lnpf[1], FNW, FNB, R6);
         }
     } else {
         return DREG_EINVAL;     // no gradient reaches the network
+    }
     }
 
     // ---- encoder layers, last to first.  G: fp32 gradient of the layer's output; its bf16 copy is the operand of the GEMMs
@@ -392,7 +406,8 @@ int dreg_ps_backward(void* h, void* arena, size_t arena_bytes, const int64_t* pa
         } else {
             float* Gprev = dallx + (size_t)(l - 1) * R * E;             // in place: dallx[l-1] becomes the previous layer's output gradient
             void* Gprev_bf = A + y.dallx_bf + (size_t)(l - 1) * R * E * 2;
-            CK(dreg_layernorm_bwd_parts(xin, A + y.dH, nullptr, p->val[o + N1W], (const float*)(A + b.st1), Gprev, Ga, Gprev, Gprev_bf,
+            // (last_only: dallx[l-1] was never produced — the final norm sent nothing to the earlier layers' outputs)
+            CK(dreg_layernorm_bwd_parts(xin, A + y.dH, nullptr, p->val[o + N1W], (const float*)(A + b.st1), Gprev, Ga, last_only ? nullptr : Gprev, Gprev_bf,
                                         (float*)(A + b.lnp[0]), R, E, 0, stream));
             G = Gprev; Gbf = Gprev_bf;
         }

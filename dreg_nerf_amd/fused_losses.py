@@ -67,7 +67,10 @@ def regtr_losses(batched: dict, poses, feature_loss, gt, tilde, robust: bool = F
     """batched: NeRFRegTr.last_batched (cond [6,R,256], corr [6,R,3], ov [6,R,1], xyz [R,3], tab); poses [P,4,4];
     gt / tilde: {0,1} labels [6,R] of the key points / of the predicted correspondences.
     Returns {"overlap","nerf_cont","feature","corr","total"}: means over the pairs, 'total' differentiable."""
-    total, stats = _RegLossFn.apply(batched["cond"][-1], batched["corr"][-1], batched["ov"][-1, :, 0], batched["xyz"], gt, tilde, poses,
+    cond_l = batched["cond_last"] if "cond_last" in batched else batched["cond"][-1]
+    corr_l = batched["corr_last"] if "corr_last" in batched else batched["corr"][-1]
+    ov_l = batched["ov_last"][:, 0] if "ov_last" in batched else batched["ov"][-1, :, 0]
+    total, stats = _RegLossFn.apply(cond_l, corr_l, ov_l, batched["xyz"], gt, tilde, poses,
                                     feature_loss.W, batched["tab"], bool(robust), float(feature_loss.r_p), float(feature_loss.r_n))
     out = {k: stats[i] for i, k in enumerate(NAMES[:4])}
     out["total"] = total

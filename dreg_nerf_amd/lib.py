@@ -178,7 +178,7 @@ SIGNATURES = {
     "dreg_ps_set_fuse": (None, [P, I]),
     "dreg_ps_arena_bytes": (Z, [P, I]),
     "dreg_ps_forward": (I, [P, P, Z, P, P, P, P, P, P, I, I, I, P, P, P, P]),
-    "dreg_ps_backward": (I, [P, P, Z, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P]),
+    "dreg_ps_backward": (I, [P, P, Z, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P, I]),
     "dreg_posenc_sine": (I, [P, P, I, F, F, P]),
     "dreg_overlap_fwd": (I, [P, P, P, P, I, P]),
     "dreg_overlap_bwd_workspace_bytes": (Z, [I]),

@@ -421,15 +421,18 @@ class NeRFRegTr(nn.Module):
         feats_all = torch.cat(feat_l) if len(feat_l) > 1 else feat_l[0]
         from . import pointset_exec
         ps = pointset_exec.executor_for(self, P)
+        last = None
         if ps is not None:     # the whole point-set half from C++: one call forward, one backward (csrc/pointset_exec.hip)
-            cond, corr, ov = pointset_exec.encode_decode(ps, feats_all, xyz_all, self.position_embedding(xyz_all), tab,
-                                                         P["transformer_encoder.norm.weight"])
+            cond, corr, ov, *last = pointset_exec.encode_decode(ps, feats_all, xyz_all, self.position_embedding(xyz_all), tab,
+                                                                P["transformer_encoder.norm.weight"], with_last=True)
         else:
             cond, corr, ov = T.encode_decode_batched(P, feats_all, xyz_all, tab, self.position_embedding)
         outs = []
         poses = A.weighted_kabsch_pairs(xyz_all, corr, ov, tab)   # [P,6,3,4]: every (pair, layer) solve in one launch
         # the batched view of the same results (row space of all pairs) for the fused training losses
         self.last_batched = {"cond": cond, "corr": corr, "ov": ov, "xyz": xyz_all, "tab": tab}
+        if last:   # the last layer's outputs as tensors of their own: losses that read only these let the backward pass skip five sixths of the decoder
+            self.last_batched.update(cond_last=last[0], corr_last=last[1], ov_last=last[2])
         for pi, (s0, ns, t0, nt) in enumerate(tab.segs):
             s_xyz, t_xyz = xyz_all[s0:s0 + ns], xyz_all[t0:t0 + nt]
             s_c, t_c = cond[:, s0:s0 + ns], cond[:, t0:t0 + nt]

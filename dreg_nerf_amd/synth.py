@@ -37,16 +37,17 @@ def shell_radii(res: int) -> Tuple[float, float]:
     return (0.8, 0.9) if res <= 32 else (0.8, 0.83)
 
 
-def fixed_pose() -> torch.Tensor:
-    """A fixed SE(3) (rotation ~17 deg about a skew axis, small translation) for RRE/RTE checks."""
-    ax = torch.tensor([0.3, -0.5, 0.8])
+def fixed_pose(variant: int = 0) -> torch.Tensor:
+    """A fixed SE(3) (rotation ~17 deg about a skew axis, small translation) for RRE/RTE checks.  variant 1: another axis, ~26 deg,
+    another translation (the second pinned training step: tests/golden/train64_wc_b.npz)."""
+    ax = torch.tensor([0.3, -0.5, 0.8] if variant == 0 else [-0.6, 0.2, 0.35])
     ax = ax / ax.norm()
-    ang = 0.3
+    ang = 0.3 if variant == 0 else -0.45
     K = torch.tensor([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
     R = torch.eye(3) + torch.sin(torch.tensor(ang)) * K + (1 - torch.cos(torch.tensor(ang))) * (K @ K)
     T = torch.eye(4)
     T[:3, :3] = R
-    T[:3, 3] = torch.tensor([0.05, -0.03, 0.02])
+    T[:3, 3] = torch.tensor([0.05, -0.03, 0.02] if variant == 0 else [-0.04, 0.06, 0.03])
     return T
 
 

@@ -296,7 +296,7 @@ int dreg_exec_op_halo(void* h, int op);   /* bit 0 / 1: forward / data gradient 
 void dreg_exec_set_overlap(void* h, int enable);
 void dreg_exec_set_input_row_occupancy(void* h, const uint8_t* rowocc);   /* flags for the convolution that reads x_in (the stem); null = none */                             /* 1 (default): weight gradients on aux_stream */
 void dreg_exec_set_timing(void* h, int enable);                              /* HIP events around every convolution launch */
-int dreg_exec_read_timings(void* h, int* op_kind, float* ms, int max);       /* (op, kind 0 fwd / 1 dgrad / 2 wgrad), ms */
+int dreg_exec_read_timings(void* h, int* op_kind, float* ms, int max);       /* op_kind: 3 ints per record (op, kind 0 fwd / 1 dgrad / 2 wgrad, variant: 2 = ran on conv_brick.hip), ms */
 /* rowlists: int64 [nlists][8] per active-set row list = { device int32* rows, count, then (or zeros) the tile tables of
  * dreg_brick_tiles_build for the same set: tiles, ntiles, halo_vox, nbr, rows_sorted, 0 }.  A 3^3 active-set convolution whose row
  * list (forward: output rows; data gradient: input rows) comes with tables runs on dreg_conv3_brick, otherwise on dreg_conv3d_igemm_rows. */
@@ -551,7 +551,9 @@ int dreg_conv3_brick(const void* in, const void* wpk, void* out, const float* bi
  * The arena (dreg_ps_arena_bytes(R), caller-owned) keeps the forward pass's activations for the backward call of the SAME R.
  * dreg_ps_backward: g_cond (fp32 [6,R,256]), g_corr, g_ov may each be null; parameter
  * gradients are accumulated into the grad pointers; weight / bias gradients run on aux_stream (optional) and the caller joins it with
- * `stream` before reading any gradient.  dreg_ps_set_fuse(0): the arithmetic of the per-op path, bit for bit (tests). */
+ * `stream` before reading any gradient.  last_only = 1: g_cond [R,256] / g_corr [R,3] / g_ov [R] are the gradients of the LAST layer's
+ * outputs only (what the training losses read: train_nerf_regtr.py:178,195,205-206,214,220); heads, decoder and final norm are then
+ * differentiated for that layer's R rows instead of 6R.  dreg_ps_set_fuse(0): the arithmetic of the per-op path, bit for bit (tests). */
 int dreg_ps_num_params(void);
 int dreg_ps_num_linears(void);
 void* dreg_ps_create(const int64_t* params);
@@ -564,7 +566,7 @@ int dreg_ps_forward(void* h, void* arena, size_t arena_bytes, const int64_t* pac
 int dreg_ps_backward(void* h, void* arena, size_t arena_bytes, const int64_t* packs, const float* feats, const float* xyz, const float* pe,
                      const int* probs_self, const int* probs_cross, int nprob, int max_len, int R,
                      const float* cond, const float* corr, const float* ov, const float* g_cond, const float* g_corr, const float* g_ov,
-                     float* d_feats, void* stream, void* aux_stream);
+                     float* d_feats, void* stream, void* aux_stream, int last_only);
 
 #ifdef __cplusplus
 }

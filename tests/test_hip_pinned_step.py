@@ -44,8 +44,10 @@ def _unclipped_grads(named, out, max_norm=0.1):
 
 def _product_step(g, res, active_set=True, native_trunk=True, profile="default"):
     """One TrainStep.step on shell_pair(res, 1, 2) with the golden's weights / InfoNCE W; returns everything the fixture pins."""
+    # which sample the fixture pins: (source grid seed, target grid seed, pose variant, weight seed, W seed); older fixtures: the first
+    sample = tuple(int(v) for v in g["sample"]) if "sample" in g.files else (1, 2, 0, 0, int(g["W_seed"]))
     m = NeRFRegTr(precision="bf16")
-    m.load_state_dict(params.synth_state_dict(0, profile=profile), strict=True)
+    m.load_state_dict(params.synth_state_dict(sample[3], profile=profile), strict=True)
     m = m.cuda().train()
     m.active_set, m.native_trunk = active_set, native_trunk
     ts = TrainStep(m)     # reference hyper-parameters: AdamW(lr 1e-4, wd 1e-4), clip 0.1 (train_nerf_regtr.py:96-102,232-237)
@@ -54,7 +56,7 @@ def _product_step(g, res, active_set=True, native_trunk=True, profile="default")
         ts.feature_loss.W.copy_((0.1 * torch.randn(256, 256, generator=torch.Generator().manual_seed(int(g["W_seed"])))).cuda())
     named = dict(m.named_parameters())
     before = {k: p.detach().clone() for k, p in named.items()}
-    data = _to(synth.shell_pair(res, 1, 2, pose=synth.fixed_pose()))
+    data = _to(synth.shell_pair(res, sample[0], sample[1], pose=synth.fixed_pose(sample[2])))
     out = ts.step([data])
     torch.cuda.synchronize()
     pred = ts.last_preds[0]
@@ -289,6 +291,15 @@ def test_bf16_product_step_absolute_bounds_wc_64(golden_dir, active_set):
     m, ts, out, pred, grads, delta = _product_step(g, 64, active_set=active_set, profile="wc")
     assert m.__dict__.get("_trunk_cache"), "the native trunk executor did not run"
     _check_absolute(g, "wc_bf16_64_" + ("active" if active_set else "dense"), out, pred, grads, delta, m, emu, cos_deep=0.8)
+
+
+def test_bf16_product_step_absolute_bounds_wc_64_second_sample(golden_dir):
+    """The same absolute bounds on a SECOND reference-generated step (other grids, another relative pose, other weight / W seeds:
+    tools/make_golden.py train64_wc_b): the tolerances are not tuned to one sample."""
+    g, emu = _wc(golden_dir, "train64_wc_b")
+    assert tuple(int(v) for v in g["sample"]) == (7, 8, 1, 1, 9)
+    m, ts, out, pred, grads, delta = _product_step(g, 64, profile="wc")
+    _check_absolute(g, "wc_bf16_64_b_active", out, pred, grads, delta, m, emu, cos_deep=0.8)
 
 
 def test_bf16_product_step_absolute_bounds_wc_128(golden_dir):

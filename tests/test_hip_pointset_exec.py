@@ -153,3 +153,36 @@ def test_training_step_through_the_native_point_set_half():
     for k in ld:
         assert abs(lc[k] - ld[k]) <= 1e-6 * max(1.0, abs(ld[k])), k      # the forward pass is bit-identical
 
+
+
+def test_last_layer_only_backward_equals_the_full_backward():
+    """The training losses read the last layer's outputs only (train_nerf_regtr.py:178,195,205-206,214,220): through the *_last outputs the
+    backward pass differentiates heads / decoder / final norm for that layer's R rows; through slices of the full outputs it runs over
+    all 6R rows, five sixths of them with a zero gradient.  Same gradients (the split sums of two weight gradients are formed in another
+    order, nothing else differs)."""
+    segs = [(200, 180), (150, 170)]
+    m, opt = _model()
+    tab = A.ProblemTable(segs, torch.device("cuda"))
+    feats, xyz, w = _inputs(segs, seed=7)
+    P = m._P()
+    A.set_precision("bf16")
+    res = []
+    for last in (False, True):
+        opt.zero_grad()
+        feats.grad = None
+        ex = PX.executor_for(m, P)
+        cond, corr, ov, cl, rl, ol = PX.encode_decode(ex, feats, xyz, m.position_embedding(xyz), tab, P["transformer_encoder.norm.weight"], with_last=True)
+        assert torch.equal(cl, cond[-1]) and torch.equal(rl, corr[-1]) and torch.equal(ol, ov[-1])
+        c, r, o = (cl, rl, ol) if last else (cond[-1], corr[-1], ov[-1])
+        loss = (c * w[0][-1]).sum() * 1e-2 + (r * w[1][-1]).sum() + (o * w[2][-1]).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((feats.grad.clone(), {n: P[n].grad.clone() for n in PX.param_names()}))
+    (df_a, g_a), (df_b, g_b) = res
+    assert torch.equal(df_a, df_b), "the encoder sees the identical gradient"
+    for n in g_a:
+        d = float((g_a[n] - g_b[n]).norm() / g_a[n].norm().clamp_min(1e-20))
+        if "q_proj" in n or "k_proj" in n or "transformer_encoder.norm" in n or "conf_logits" in n:
+            assert d < 1e-5, (n, d)          # sums over R instead of 6R rows (zeros left out): another split / block order
+        else:
+            assert d == 0.0, (n, d)

@@ -4,8 +4,8 @@ mkdir -p gpurun_out/art
 timeout 900 python bench.py --kernel-report gpurun_out/art/bench_event_timing_by_shape.tsv > gpurun_out/art/bench.log 2>&1; tail -1 gpurun_out/art/bench.log > gpurun_out/art/bench.json
 for mode in active_set dense_head; do
   flag=""; [ $mode = dense_head ] && flag="--dense-head"
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/art/two_$mode -o k -- python bench.py --no-cpu-baseline --no-dense-reference --no-nerf-labels-reference $flag > gpurun_out/art/two_$mode.log 2>&1
-  DREG_SERIAL_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/art/ser_$mode -o k -- python bench.py --no-cpu-baseline --no-dense-reference --no-nerf-labels-reference $flag > gpurun_out/art/ser_$mode.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/art/two_$mode -o k -- python bench.py --no-cpu-baseline --no-dense-reference --no-nerf-labels-reference --no-ngp-reference $flag > gpurun_out/art/two_$mode.log 2>&1
+  DREG_SERIAL_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/art/ser_$mode -o k -- python bench.py --no-cpu-baseline --no-dense-reference --no-nerf-labels-reference --no-ngp-reference $flag > gpurun_out/art/ser_$mode.log 2>&1
 done
 find gpurun_out/art -name "*kernel_stats.csv" | head; du -sh gpurun_out/art
 # keep only the stats csv (traces are large)

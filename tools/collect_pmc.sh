@@ -7,7 +7,7 @@ mkdir -p gpurun_out/pmc
 for mode in active_set dense_head; do
   flag=""; [ $mode = dense_head ] && flag="--dense-head"
   for c in FETCH_SIZE WRITE_SIZE; do
-    DREG_SERIAL_STREAMS=1 timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc/${mode}_$c -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-dense-reference --no-nerf-labels-reference $flag > gpurun_out/pmc/${mode}_$c.log 2>&1
+    DREG_SERIAL_STREAMS=1 timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc/${mode}_$c -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-dense-reference --no-nerf-labels-reference --no-ngp-reference $flag > gpurun_out/pmc/${mode}_$c.log 2>&1
   done
 done
 # BASELINE config 4 (bench.py --ngp): the two NGP kernels

@@ -7,7 +7,7 @@ bash tools/collect_pmc.sh > gpurun_out/round/collect_pmc.log 2>&1
 cp gpurun_out/pmc/hbm_per_launch.json profiles/pmc_hbm_per_launch.json      # bench.py reads roofline.traffic from here (keyed by the kernel-source sha)
 bash tools/collect_artifacts.sh > gpurun_out/round/collect_artifacts.log 2>&1
 timeout 600 python bench.py --ngp > gpurun_out/round/bench_ngp.log 2>&1; tail -1 gpurun_out/round/bench_ngp.log > gpurun_out/round/bench_ngp.json
-timeout 900 python bench.py --occupancy-sweep --no-cpu-baseline --no-dense-reference --no-nerf-labels-reference > gpurun_out/round/occ.log 2>&1; tail -1 gpurun_out/round/occ.log > gpurun_out/round/bench_occupancy_sweep.json
+timeout 900 python bench.py --occupancy-sweep --no-cpu-baseline --no-dense-reference --no-nerf-labels-reference --no-ngp-reference > gpurun_out/round/occ.log 2>&1; tail -1 gpurun_out/round/occ.log > gpurun_out/round/bench_occupancy_sweep.json
 timeout 900 bash tools/pmc_kernel_clock.sh "python tools/bench_wgrad.py" conv_ > gpurun_out/round/pmc_kernel_clock_wgrad.txt 2>&1
 timeout 900 bash tools/pmc_kernel_clock.sh "python tools/bench_igemm_ap.py" conv_igemm > gpurun_out/round/pmc_kernel_clock_igemm.txt 2>&1
 timeout 600 python tools/wgrad_phase_probe.py > gpurun_out/round/wgrad_phase_probe.txt 2>&1

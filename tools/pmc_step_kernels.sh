@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/pmc_step
 mkdir -p $OUT
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD"; do
   tag=$(echo $grp | tr ' ' '_' | cut -c1-60)
-  DREG_SERIAL_STREAMS=1 timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/$tag -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-dense-reference --no-nerf-labels-reference > $OUT/$tag.log 2>&1
+  DREG_SERIAL_STREAMS=1 timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/$tag -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-dense-reference --no-nerf-labels-reference --no-ngp-reference > $OUT/$tag.log 2>&1
 done
 python - <<PY
 import csv, glob, os, collections

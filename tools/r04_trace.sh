@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/${1:-trace}; mkdir -p $out
 for mode in ser two; do
   env_=""; [ $mode = ser ] && env_="DREG_SERIAL_STREAMS=1"
-  env $env_ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$mode -o k -- python bench.py --no-cpu-baseline --no-dense-reference --no-nerf-labels-reference --steps 8 --warmup 3 > $out/$mode.log 2>&1
+  env $env_ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$mode -o k -- python bench.py --no-cpu-baseline --no-dense-reference --no-nerf-labels-reference --no-ngp-reference --steps 8 --warmup 3 > $out/$mode.log 2>&1
   f=$(find $out/$mode -name "*kernel_trace.csv" | head -1); python tools/timeline.py $f > $out/timeline_$mode.txt 2>&1
   python - <<PY
 import csv,re
