@@ -128,6 +128,7 @@ int g_sparse_grads = 1;   // tuning (include/dreg_nerf_tuning.h): row-cleared in
 int g_bn_batch_tails = 1; // tuning (include/dreg_nerf_tuning.h): the small BatchNorms' running-statistics / parameter-gradient launches batched per pass
 int g_fuse_stem = 1;      // tuning (include/dreg_nerf_tuning.h): BatchNorm + ReLU + max-pool of the stem in one pass
 int g_brick = 1;          // tuning (include/dreg_nerf_tuning.h): bit 0: active-set 3^3 launches with 64 output channels on csrc/conv_brick.hip when the caller hands over tile tables, bit 1: those with 256 as well
+int g_defer_head_pg = 0;  // tuning (include/dreg_nerf_tuning.h): the head's weight / bias gradient launches are held back until the backward pass reaches the 8^3 / 4^3 levels
 int g_fuse_bn_stats = 1;  // tuning (include/dreg_nerf_tuning.h): statistics of the large BatchNorm layers from the producing convolution's epilogue
 
 bool s2_class_ok(const Param& p, int ksz, int stride, int pad)
@@ -428,6 +429,7 @@ void dreg_exec_set_bn_batch_tails(int on) { g_bn_batch_tails = on ? 1 : 0; }   /
 void dreg_exec_set_fuse_stem(int on) { g_fuse_stem = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_fuse_bn_stats(int on) { g_fuse_bn_stats = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_brick(int mask) { g_brick = mask & 3; }   // read at every forward / backward call
+void dreg_exec_set_defer_head_pg(int on) { g_defer_head_pg = on ? 1 : 0; }   // read at every backward call
 void dreg_exec_set_timing(void* h, int enable) { ((Exec*)h)->timing = enable != 0; }   // records are kept until read
 // After a stream synchronisation: elapsed ms of the bracketed launches since the last set_timing; records are (op, kind, variant, ms)
 // with kind 0 forward, 1 data gradient, 2 weight gradient (+reduce); variant 2 = the launch ran on csrc/conv_brick.hip; op_kind holds 3 ints per record.  Returns the number written (<= max) and restarts.
@@ -655,6 +657,65 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
         }
         return DREG_OK;
     };
+    // weight / bias gradient launches of convolution op i (second stream behind the event "its output gradient is complete")
+    auto param_grads = [&](int i, bool event_recorded) -> int {
+        const Op& o = e->ops[i];
+        const Tensor& x = e->t[o.in];
+        const Tensor& y = e->t[o.out];
+        const Param& w = e->prm[o.w];
+        const void* gy = grad(o.out);
+        const bool rows = o.kind == OP_CONV_ROWS;
+        const int* r_out = rows ? (const int*)rowlists[RL * o.rows_out] : nullptr;
+        const int n_out = rows ? (int)rowlists[RL * o.rows_out + 1] : 0;
+        hipStream_t ws = st;
+        if (aux_on) {
+            if (!e->ev[i] && hipEventCreateWithFlags(&e->ev[i], hipEventDisableTiming) != hipSuccess) return DREG_ELAUNCH;
+            if (!event_recorded && hipEventRecord(e->ev[i], st) != hipSuccess) return DREG_ELAUNCH;
+            if (hipStreamWaitEvent(e->aux, e->ev[i], 0) != hipSuccess) return DREG_ELAUNCH;
+            ws = e->aux;
+            aux_used = true;
+        }
+        hipStream_t bs = ws;                  // bias sums stay on the second stream (they share one scratch buffer)
+        if (w.grad && n_ws > 1 && o.rd >= 0) {  // deferred-sum weight gradients rotate over the streams
+            const int k = ws_rr++ % n_ws;
+            if (k > 0) {
+                if (hipStreamWaitEvent(g_extra_stream[k - 1], e->ev[i], 0) != hipSuccess) return DREG_ELAUNCH;
+                ws = g_extra_stream[k - 1];
+                extra_busy[k - 1] = true;
+            }
+        }
+        bool flush_now = false;
+        if (w.grad) {
+            Scope sc(e, ws, i, 2);
+            if (o.rd >= 0) {
+                CK(dreg_conv3d_wgrad_partials(gy, act(o.in), A + o.wg_off, o.wg_bytes, rows ? r_out : nullptr, n_out, x.B, x.D, x.H, x.W, x.C, w.d1,
+                                              y.D, y.H, y.W, w.d0, o.ksz, rows ? 1 : o.stride, o.pad, (!rows && o.in == 0) ? e->in_rowocc : nullptr, (void*)ws));
+                rd_done[o.rd] = 1;
+                rd_stream = n_ws > 1 ? e->aux : ws;
+                rd_pending += o.wg_bytes;
+                flush_now = rd_pending >= ((size_t)192 << 20);
+            } else if (rows) {
+                CK(dreg_conv3d_wgrad_rows(gy, act(o.in), w.grad, A + o.wg_off, o.wg_bytes, r_out, n_out, x.B, x.D, x.H, x.W, x.C, w.d1,
+                                          y.D, y.H, y.W, w.d0, o.ksz, 1, o.pad, 1, (void*)ws));
+            } else {
+                CK(dreg_conv3d_wgrad_occ(gy, act(o.in), w.grad, A + o.wg_off, o.wg_bytes, x.B, x.D, x.H, x.W, x.C, w.d1, y.D, y.H, y.W, w.d0,
+                                         o.ksz, o.stride, o.pad, 1, 0, 1, o.in == 0 ? e->in_rowocc : nullptr, (void*)ws));
+            }
+        }
+        if (flush_now) { CK(flush_reduce()); rd_pending = 0; }   // outside the launch's timing bracket
+        if (o.b >= 0 && e->prm[o.b].grad) {
+            if (rows) CK(dreg_colsum_rows(gy, r_out, n_out, e->prm[o.b].grad, (float*)(A + e->off_cs), w.d0, 1, 0, (void*)bs));
+            else CK(dreg_colsum(gy, e->prm[o.b].grad, (float*)(A + e->off_cs), (size_t)y.B * y.D * y.H * y.W, w.d0, 1, 0, (void*)bs));
+        }
+        return DREG_OK;
+    };
+    std::vector<int> deferred_pg;            // ops whose parameter-gradient launches are held back (their events are recorded)
+    bool deep_reached = false;
+    auto run_deferred = [&]() -> int {
+        for (int j : deferred_pg) CK(param_grads(j, true));
+        deferred_pg.clear();
+        return DREG_OK;
+    };
     for (int i = op_end - 1; i >= op_begin; --i) {
         const Op& o = e->ops[i];
         const Tensor& x = e->t[o.in];
@@ -681,46 +742,17 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
             // parameter gradients first, on the second stream: gy is complete here (every consumer of this op's output has been
             // processed), and nothing below modifies gy or the op's input activation
             const bool pg = w.grad || (o.b >= 0 && e->prm[o.b].grad);
-            if (pg) {
-                hipStream_t ws = st;
-                if (aux_on) {
-                    if (!e->ev[i] && hipEventCreateWithFlags(&e->ev[i], hipEventDisableTiming) != hipSuccess) return DREG_ELAUNCH;
-                    if (hipEventRecord(e->ev[i], st) != hipSuccess || hipStreamWaitEvent(e->aux, e->ev[i], 0) != hipSuccess) return DREG_ELAUNCH;
-                    ws = e->aux;
-                    aux_used = true;
-                }
-                hipStream_t bs = ws;                  // bias sums stay on the second stream (they share one scratch buffer)
-                if (w.grad && n_ws > 1 && o.rd >= 0) {  // deferred-sum weight gradients rotate over the streams
-                    const int k = ws_rr++ % n_ws;
-                    if (k > 0) {
-                        if (hipStreamWaitEvent(g_extra_stream[k - 1], e->ev[i], 0) != hipSuccess) return DREG_ELAUNCH;
-                        ws = g_extra_stream[k - 1];
-                        extra_busy[k - 1] = true;
-                    }
-                }
-                bool flush_now = false;
-                if (w.grad) {
-                    Scope sc(e, ws, i, 2);
-                    if (o.rd >= 0) {
-                        CK(dreg_conv3d_wgrad_partials(gy, act(o.in), A + o.wg_off, o.wg_bytes, rows ? r_out : nullptr, n_out, x.B, x.D, x.H, x.W, x.C, w.d1,
-                                                      y.D, y.H, y.W, w.d0, o.ksz, rows ? 1 : o.stride, o.pad, (!rows && o.in == 0) ? e->in_rowocc : nullptr, (void*)ws));
-                        rd_done[o.rd] = 1;
-                        rd_stream = n_ws > 1 ? e->aux : ws;
-                        rd_pending += o.wg_bytes;
-                        flush_now = rd_pending >= ((size_t)192 << 20);
-                    } else if (rows) {
-                        CK(dreg_conv3d_wgrad_rows(gy, act(o.in), w.grad, A + o.wg_off, o.wg_bytes, r_out, n_out, x.B, x.D, x.H, x.W, x.C, w.d1,
-                                                  y.D, y.H, y.W, w.d0, o.ksz, 1, o.pad, 1, (void*)ws));
-                    } else {
-                        CK(dreg_conv3d_wgrad_occ(gy, act(o.in), w.grad, A + o.wg_off, o.wg_bytes, x.B, x.D, x.H, x.W, x.C, w.d1, y.D, y.H, y.W, w.d0,
-                                                 o.ksz, o.stride, o.pad, 1, 0, 1, o.in == 0 ? e->in_rowocc : nullptr, (void*)ws));
-                    }
-                }
-                if (flush_now) { CK(flush_reduce()); rd_pending = 0; }   // outside the launch's timing bracket
-                if (o.b >= 0 && e->prm[o.b].grad) {
-                    if (rows) CK(dreg_colsum_rows(gy, r_out, n_out, e->prm[o.b].grad, (float*)(A + e->off_cs), w.d0, 1, 0, (void*)bs));
-                    else CK(dreg_colsum(gy, e->prm[o.b].grad, (float*)(A + e->off_cs), (size_t)y.B * y.D * y.H * y.W, w.d0, 1, 0, (void*)bs));
-                }
+            // The FPN head's weight gradients (64^3 / 32^3 volumes: throughput-bound launches) are complete first, exactly while the main
+            // stream runs the head's throughput-bound data gradients: side by side the two only slow each other down (~25 % per kernel).
+            // They are held back until the pass reaches the 8^3 / 4^3 levels, whose launch-latency-bound chain leaves most CUs idle.
+            const long vox_out = (long)y.D * y.H * y.W;
+            if (pg && aux_on && g_defer_head_pg && !deep_reached && vox_out >= 32768 && n_ws == 1) {
+                if (!e->ev[i] && hipEventCreateWithFlags(&e->ev[i], hipEventDisableTiming) != hipSuccess) return DREG_ELAUNCH;
+                if (hipEventRecord(e->ev[i], st) != hipSuccess) return DREG_ELAUNCH;
+                deferred_pg.push_back(i);
+            } else if (pg) {
+                if (vox_out <= 512 && !deep_reached) { deep_reached = true; CK(run_deferred()); }
+                CK(param_grads(i, false));
             }
             if (o.in2 >= 0 && e->needs_grad[o.in2]) {
                 const Tensor& ta = e->t[o.in2];
@@ -816,6 +848,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
             written[o.in] = 1;
         }
     }
+    CK(run_deferred());                      // (a segment that never reached the deep levels)
     CK(flush_reduce());
     CK(flush_bn_tails(e, A, bn_done, 1, st));
     if (aux_on) CK(join_extra());

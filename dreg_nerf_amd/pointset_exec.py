@@ -199,3 +199,4 @@ def encode_decode(ex: PointSetExecutor, feats, xyz, pe, tab, anchor, with_last: 
     feats = feats.float().contiguous()
     out = _PointSetFn.apply(feats, anchor, ex, xyz.contiguous(), pe.contiguous(), tab)
     return out if with_last else out[:3]
+
