@@ -343,8 +343,10 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
         }
         if (o.kind == OP_CONV_ROWS && o.ksz == 3 && o.pad == 1 && p.d1 == x.C && dreg_brick_supported(x.B, x.D, x.H, x.W, 16, 256)) {
             // the same layer in the staged-neighbourhood form (used when the step's row sets come with tile tables)
-            if ((p.d0 == 256 || p.d0 == 64) && p.d1 % 16 == 0 && p.pk_brick_fwd == SIZE_MAX) p.pk_brick_fwd = add_brick_pack(p, 0);
-            if (e->needs_grad[o.in] && (p.d1 == 256 || p.d1 == 64) && p.d0 % 16 == 0 && p.pk_brick_dgrad == SIZE_MAX) p.pk_brick_dgrad = add_brick_pack(p, 1);
+            // (packs only for the launches the mask in force at creation enables: dreg_exec_set_brick before the executor is created)
+            auto on = [&](int nout) { return (nout == 64 && (g_brick & 1)) || (nout == 256 && (g_brick & 2)); };
+            if (on(p.d0) && p.d1 % 16 == 0 && p.pk_brick_fwd == SIZE_MAX) p.pk_brick_fwd = add_brick_pack(p, 0);
+            if (e->needs_grad[o.in] && on(p.d1) && p.d0 % 16 == 0 && p.pk_brick_dgrad == SIZE_MAX) p.pk_brick_dgrad = add_brick_pack(p, 1);
         }
         if (o.halo & 1) { if (p.pk_halo_fwd == SIZE_MAX) p.pk_halo_fwd = add_halo_pack(p, 0); }
         else if (p.pk_fwd == SIZE_MAX) { p.cin_pad = x.C; p.pk_fwd = add_pack(p, 0, x.C); }
@@ -428,7 +430,7 @@ void dreg_exec_set_sparse_grads(int on) { g_sparse_grads = on ? 1 : 0; }   // re
 void dreg_exec_set_bn_batch_tails(int on) { g_bn_batch_tails = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_fuse_stem(int on) { g_fuse_stem = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_fuse_bn_stats(int on) { g_fuse_bn_stats = on ? 1 : 0; }   // read when an executor is created
-void dreg_exec_set_brick(int mask) { g_brick = mask & 3; }   // read at every forward / backward call
+void dreg_exec_set_brick(int mask) { g_brick = mask & 3; }   // packs: read when an executor is created; dispatch: at every forward / backward call
 void dreg_exec_set_defer_head_pg(int on) { g_defer_head_pg = on ? 1 : 0; }   // read at every backward call
 void dreg_exec_set_timing(void* h, int enable) { ((Exec*)h)->timing = enable != 0; }   // records are kept until read
 // After a stream synchronisation: elapsed ms of the bracketed launches since the last set_timing; records are (op, kind, variant, ms)
