@@ -761,7 +761,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                 if (o.add_same) { CK(hipMemcpyAsync(dst_for(o.in2), gy, (size_t)y.B * y.D * y.H * y.W * y.C * 2, hipMemcpyDeviceToDevice, st) == hipSuccess ? 0 : DREG_ELAUNCH); }
                 else if (rows && o.ds_rows >= 0 && o.ds_rows < nlists) {
                     void* dst = dst_for(o.in2);
-                    if (hipMemsetAsync(dst, 0, (size_t)ta.B * ta.D * ta.H * ta.W * ta.C * 2, st) != hipSuccess) return DREG_ELAUNCH;
+                    CK(dreg_fill_zero(dst, (size_t)ta.B * ta.D * ta.H * ta.W * ta.C * 2, stream));
                     CK(dreg_downsample_sum_rows(gy, dst, (const int*)rowlists[RL * o.ds_rows], (int)rowlists[RL * o.ds_rows + 1],
                                                 y.D, y.H, y.W, ta.D, ta.H, ta.W, y.C, 0, stream));
                 }
@@ -792,7 +792,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                         // the buffer is zero everywhere (see the start of this call); remember which rows this step writes
                         if (n_in > 0 && hipMemcpyAsync(A + o.cl_off, r_in, (size_t)n_in * sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess) return DREG_ELAUNCH;
                         const_cast<Op&>(o).cl_count = n_in;
-                    } else if (hipMemsetAsync(gx, 0, (size_t)x.B * x.D * x.H * x.W * x.C * 2, st) != hipSuccess) return DREG_ELAUNCH;
+                    } else CK(dreg_fill_zero(gx, (size_t)x.B * x.D * x.H * x.W * x.C * 2, stream));
                     if ((g_brick & (w.d1 == 64 ? 1 : 2)) && w.pk_brick_dgrad != SIZE_MAX && rl[2] && rl[3] > 0) {
                         sc.variant(2);
                         CK(dreg_conv3_brick(gy, PK + w.pk_brick_dgrad, gx, nullptr, nullptr, (const void*)rl[2], (int)rl[3], (const int*)rl[4], (const void*)rl[5],

@@ -108,6 +108,7 @@ SIGNATURES = {
     "dreg_trilinear_gather_fwd": (I, [P, P, P, P] + [I] * 10 + [P]),
     "dreg_trilinear_gather_bwd": (I, [P, P, P, P] + [I] * 8 + [P]),
     "dreg_cast_from_f32": (I, [P, P, Z, I, P]),
+    "dreg_fill_zero": (I, [P, Z, P]),
     "dreg_active_sets_workspace_bytes": (Z, [I] * 4),
     "dreg_active_sets": (I, [P, P] + [I] * 8 + [P, P, P, P, Z, P]),
     "dreg_active_sets_level2_workspace_bytes": (Z, [I] * 4),

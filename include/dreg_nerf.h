@@ -215,6 +215,8 @@ int dreg_trilinear_gather_fwd(const void* p1, const int64_t* idx, const int* pt_
 int dreg_trilinear_gather_bwd(const float* dfeat, const int64_t* idx, const int* pt_batch, float* dp1_f32, int N, int d,
                               int h, int w, int C, int Zr, int Xr, int Yr, void* stream);
 int dreg_cast_from_f32(const float* in, void* out, size_t n, int dtype, void* stream);
+/* zero fill at HBM rate (bytes % 16 == 0 and a 16-byte aligned pointer; otherwise hipMemsetAsync) */
+int dreg_fill_zero(void* p, size_t bytes, void* stream);
 /* Bias gradients of many linear layers in two launches.  descs_dev: n records of 56 bytes { const bf16* g [M][C]; float* out [C];
  * float* partial (dreg_colsum_workspace_bytes(M, C), one per record); int M, C, rpc (dreg_colsum_rows_per_chunk(M)), nch = ceil(M / rpc),
  * pblock0 (sum of nch of the records before), fblock0 (sum of ceil(C / 4) before), accumulate, pad }; total_pblocks / total_fblocks = the
