@@ -143,3 +143,29 @@ def test_overflowing_candidates_are_split():
     ref = _reference(x, w, rows_flat, None, None)
     got = out.reshape(-1, 256)[rows_flat].float()
     assert float((got - ref).abs().max()) <= 1.2e-2 * float(ref.abs().max())
+
+
+def test_grid_sizes_that_are_no_multiple_of_the_brick_and_an_empty_grid():
+    """20^3 grids (partial bricks at every face), one of three grids without a single flagged voxel, a voxel in every corner."""
+    B, D = 3, 20
+    flags = _shell_flags(B, D, thick=1.2, seed=9)
+    flags[1] = 0
+    for c in (0, D - 1):
+        flags[0, c, c, c] = 1
+        flags[2, c, D - 1 - c, c] = 1
+    n = int(flags.sum())
+    bt = brick.build(flags, n)
+    assert bt.nrows == n and not bt.overflow
+    rows = bt.rows_sorted[:n].cpu().numpy()
+    assert np.array_equal(np.sort(rows), np.nonzero(flags.flatten().cpu().numpy())[0])
+    x = torch.randn(B, D, D, D, 256, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(256, 64, 3, 3, 3) * 0.02).cuda()       # layer 64 -> 256: its data gradient has 64 output channels
+    out = torch.zeros(B, D, D, D, 64, device="cuda", dtype=torch.bfloat16)
+    brick.conv(x, brick.pack_weight(w, True), out, None, None, bt, 256, 64)
+    rows_flat = torch.nonzero(flags.flatten())[:, 0]
+    ref = _reference(x, w.flip(2, 3, 4).transpose(0, 1).contiguous(), rows_flat, None, None)
+    got = out.reshape(-1, 64)[rows_flat].float()
+    assert float((got - ref).abs().max()) <= 1.2e-2 * float(ref.abs().max())
+    untouched = torch.ones(B * D ** 3, dtype=torch.bool, device="cuda")
+    untouched[rows_flat] = False
+    assert torch.all(out.reshape(-1, 64)[untouched] == 0)

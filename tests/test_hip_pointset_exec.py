@@ -186,3 +186,22 @@ def test_last_layer_only_backward_equals_the_full_backward():
             assert d < 1e-5, (n, d)          # sums over R instead of 6R rows (zeros left out): another split / block order
         else:
             assert d == 0.0, (n, d)
+
+
+@pytest.mark.parametrize("segs", [[(3, 5)], [(64, 1), (1, 64), (130, 127)]])
+def test_tiny_and_lopsided_point_sets(segs):
+    """A pair with a handful of key points (fewer rows than one GEMM tile, one attention tile), one-point sets next to larger ones."""
+    m, opt = _model()
+    tab = A.ProblemTable(segs, torch.device("cuda"))
+    feats, xyz, w = _inputs(segs, seed=11)
+    ref_out, ref_df, ref_g = _run(m, opt, feats, xyz, tab, w, native=False)
+    PX.FUSE = False
+    try:
+        out, df, g = _run(m, opt, feats, xyz, tab, w, native=True)
+    finally:
+        PX.FUSE = True
+    assert all(torch.equal(a, b) for a, b in zip(out, ref_out)) and torch.equal(df, ref_df)
+    assert all(torch.equal(g[n], ref_g[n]) for n in ref_g)
+    out2, df2, g2 = _run(m, opt, feats, xyz, tab, w, native=True)          # the product setting
+    assert all(torch.equal(a, b) for a, b in zip(out2, ref_out))
+    assert float((df2 - ref_df).norm() / ref_df.norm()) < 2e-2
