@@ -153,6 +153,8 @@ class TrunkExecutor:
     def _labels(self):
         """(name, label, flops) per (op index, kind) for the HIP-event timing records."""
         out = {}
+        lib = self.lib       # the name functions below must not capture `self`: a reference cycle would keep a dropped executor (and its
+                             # 10 GB arena) alive until the cyclic collector runs (tools/stability.py SOAK_EDGE: out of memory after ~20 shapes)
         for i, o in enumerate(self.rec.ops):
             if o[0] not in (OP_CONV, OP_CONV_ROWS):
                 continue
@@ -168,14 +170,14 @@ class TrunkExecutor:
             is_rows = o[0] == OP_CONV_ROWS
 
             def fwd_name(nr, B=B, x=x, y=y, cout=cout, k=k, s=s, pd=pd):
-                return ops.igemm_kernel_name(self.lib, B, x[1], x[2], x[3], x[4], y[1], y[2], y[3], cout, k, s, pd, 0, nr, 0 if nr else 1, False, L.DT_BF16, False)
+                return ops.igemm_kernel_name(lib, B, x[1], x[2], x[3], x[4], y[1], y[2], y[3], cout, k, s, pd, 0, nr, 0 if nr else 1, False, L.DT_BF16, False)
 
             def dgrad_name(nr, B=B, x=x, y=y, cout=cout, k=k, s=s, pd=pd):
                 if s == 2:   # the parity-class form (dreg_conv3d_dgrad_s2): a 2^3-tap (or 1-tap) stride-1 convolution over dOut with 8 x Cin (or Cin) output channels
                     dc = tuple((d + 1) // 2 for d in x[1:4])
-                    return ops.igemm_kernel_name(self.lib, B, y[1], y[2], y[3], cout, dc[0], dc[1], dc[2], (1 if k == 1 else 8) * x[4], 1 if k == 1 else 2, 1, 0, 0, 0, 0, False,
+                    return ops.igemm_kernel_name(lib, B, y[1], y[2], y[3], cout, dc[0], dc[1], dc[2], (1 if k == 1 else 8) * x[4], 1 if k == 1 else 2, 1, 0, 0, 0, 0, False,
                                                  L.DT_BF16, False)
-                return ops.igemm_kernel_name(self.lib, B, y[1], y[2], y[3], cout, x[1], x[2], x[3], x[4], k, 1, pd, 1, nr, 0 if nr else 1, False, L.DT_BF16, False)
+                return ops.igemm_kernel_name(lib, B, y[1], y[2], y[3], cout, x[1], x[2], x[3], x[4], k, 1, pd, 1, nr, 0 if nr else 1, False, L.DT_BF16, False)
             fname, dname = (fwd_name, dgrad_name) if is_rows else (fwd_name(0), dgrad_name(0))
             halo = self.lib.dreg_exec_op_halo(self.h, i)
             if halo & 1:
@@ -190,7 +192,7 @@ class TrunkExecutor:
             out[(i, 0)] = (fname, f"fwd{rows} B{B} {x[1]}x{x[2]}x{x[3]}x{x[4]}->{y[1]}x{y[2]}x{y[3]}x{cout} k{k}s{s}", fl, lo, per_row, f"conv3_brick_kernel<{cout},bf16>")
             out[(i, 1)] = (dname, f"dgrad{rows} B{B} {y[1]}x{y[2]}x{y[3]}x{cout}->{x[1]}x{x[2]}x{x[3]}x{cin} k{k}s{s}", fl, li, per_row, f"conv3_brick_kernel<{cin},bf16>")
             def wgrad_name(nr, B=B, x=x, y=y, cout=cout, k=k, is_rows=is_rows, first=int(o[1] == 0)):
-                var = self.lib.dreg_conv3d_wgrad_variant(B, y[1], y[2], y[3], x[4], cout, k, int(is_rows), nr, first)
+                var = lib.dreg_conv3d_wgrad_variant(B, y[1], y[2], y[3], x[4], cout, k, int(is_rows), nr, first)
                 if var == 256256:
                     return f"conv_wgrad_glds_kernel<256,256,{'true' if is_rows else 'false'},8>"
                 if var == 256128:
