@@ -401,6 +401,195 @@ __global__ void segment_starts_kernel(const uint64_t* __restrict__ keys, const u
         todo &= ~same;
     }
 }
+// ------------------------------------------------------------------------------------------------ own sort + segments (one workgroup)
+// The voxel keys of one downsample round are a few 10^4 64-bit values (both point sets of a pair): keys, a stable LSD radix sort,
+// segment heads, their scan, the segment starts and the per-batch counts in ONE launch of one 1,024-thread workgroup — it replaces
+// voxel_keys + rocPRIM radix_sort_pairs (7-9 launches) + segment_heads + rocPRIM inclusive_scan (2) + segment_starts, ~15 launches per
+// round and 73 library launches per training step (grid_downsample.py:24-36 is one MinkowskiEngine call in the reference).
+// 4-bit digits; digits in which all keys agree are skipped (coordinates of a NeRF block span a few dozen cells: typically 6-7 of the 16
+// passes run).  Stable: equal keys keep ascending original indices, exactly the order rocPRIM's stable sort gives (bit-identical
+// downstream results).
+constexpr int VS_THREADS = 1024, VS_WAVES = VS_THREADS / 64, VS_MAX_N = 131072;
+// barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global store (s_waitcnt vmcnt(0)), which put the
+// latency of a round's scattered stores in front of every one of its three barriers (940 us per sort on one CU)
+#define VS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+__global__ __launch_bounds__(1024) void voxel_sort_segments_kernel(const float* __restrict__ pts, const int* __restrict__ pt_batch, float dl,
+                                                                   uint64_t* keysA, uint64_t* keysB, uint32_t* valsA, uint32_t* valsB,
+                                                                   uint32_t* __restrict__ starts, int* __restrict__ batch_counts, int* __restrict__ nseg,
+                                                                   int* __restrict__ err, int N, int nbatch)
+{
+    // Elements are visited 1,024 at a time (index = 1024 j + thread: coalesced loads).  Stable rank of an element inside a round = elements
+    // of the same digit in lower lanes of its wave (ballot) + in lower waves (16 x 16 table in LDS); a digit's running base is carried
+    // from round to round.
+    constexpr int E = 4;                            // elements per thread and round: index = 4096 j + 1024 e + thread
+    __shared__ uint32_t wcnt[E][VS_WAVES][16];      // per (sub-block, wave, digit) count of the current round
+    __shared__ uint32_t wpre[E][VS_WAVES][16];      // exclusive prefix over the waves of a sub-block
+    __shared__ uint32_t etot[E][16];                // per (sub-block, digit) count of the round
+    __shared__ uint32_t hsum[2][16];                // per-digit count of the whole array: this pass / the next one (built while this one scatters)
+    __shared__ unsigned long long s_or;
+    __shared__ uint64_t s_k0;
+    __shared__ int s_err;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (t == 0) { s_or = 0ull; s_err = 0; }
+    if (t < 32) hsum[t >> 4][t & 15] = 0;
+    for (int b = t; b < nbatch; b += VS_THREADS) batch_counts[b] = 0;
+    __syncthreads();
+    // ---- keys (voxel_keys_kernel's arithmetic), original indices, and the bits in which the keys differ
+    unsigned long long diff = 0ull;
+    uint64_t key0 = 0;
+    for (int i = t; i < N; i += VS_THREADS) {
+        uint64_t key = (uint64_t)(uint32_t)(pt_batch[i] & 0xffff) << 48;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float q = floorf(pts[(size_t)i * 3 + c] / dl);
+            const int ci = (int)q + 32768;
+            if (ci < 0 || ci > 65535) s_err = 1;
+            key |= (uint64_t)(uint32_t)(ci & 0xffff) << (32 - 16 * c);
+        }
+        if (i == t) key0 = key;
+        diff |= key ^ key0;
+        keysA[i] = key; valsA[i] = (uint32_t)i;
+    }
+    if (t == 0) s_k0 = key0;
+    __syncthreads();
+    if (t < N) diff |= key0 ^ s_k0;               // a thread's diff is relative to its own first key
+    if (diff) atomicOr(&s_or, diff);
+    __syncthreads();
+    const unsigned long long mask = s_or;
+    if (t == 0) *err = s_err;
+    const int rounds = (N + E * VS_THREADS - 1) / (E * VS_THREADS);
+    uint64_t* ksrc = keysA; uint64_t* kdst = keysB;
+    uint32_t* vsrc = valsA; uint32_t* vdst = valsB;
+    // digits that take part, in order; the histogram of the first one needs a walk of its own
+    int digs[16], nd = 0;
+    for (int d = 0; d < 16; ++d) if ((mask >> (4 * d)) & 15ull) digs[nd++] = d;
+    auto add_hist = [&](uint32_t (&cnt)[16], int which) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            uint32_t v = cnt[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0 && v) atomicAdd(&hsum[which][k], v);
+        }
+    };
+    if (nd > 0) {
+        const int sh = 4 * digs[0];
+        uint32_t cnt[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cnt[k] = 0;
+        for (int i = t; i < N; i += VS_THREADS) {
+            const int dg = (int)((ksrc[i] >> sh) & 15ull);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cnt[k] += (dg == k) ? 1u : 0u;
+        }
+        add_hist(cnt, 0);
+    }
+    __syncthreads();
+    for (int pi = 0; pi < nd; ++pi) {
+        const int sh = 4 * digs[pi];
+        const int cur = pi & 1, nxt = cur ^ 1;
+        const bool has_next = pi + 1 < nd;
+        const int sh_n = has_next ? 4 * digs[pi + 1] : 0;
+        uint32_t base[16], ncnt[16];
+        {
+            uint32_t run = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { base[k] = run; run += hsum[cur][k]; ncnt[k] = 0; }
+        }
+        for (int j = 0; j < rounds; ++j) {
+            uint64_t key[E]; uint32_t v[E]; int dg[E]; uint32_t myrank[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = (j * E + e) * VS_THREADS + t;
+                const bool live = i < N;
+                key[e] = 0; v[e] = 0;
+                if (live) { key[e] = ksrc[i]; v[e] = vsrc[i]; }
+                dg[e] = live ? (int)((key[e] >> sh) & 15ull) : -1;
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                myrank[e] = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const unsigned long long m = __ballot(dg[e] == k);
+                    if (dg[e] == k) myrank[e] = (uint32_t)__popcll(m & lt);
+                    if (lane == k) wcnt[e][wave][k] = (uint32_t)__popcll(m);
+                }
+                if (has_next && dg[e] >= 0) {
+                    const int dn = (int)((key[e] >> sh_n) & 15ull);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) ncnt[k] += (dn == k) ? 1u : 0u;
+                }
+            }
+            VS_LDS_BARRIER();
+            {                                         // thread (e, w, k): elements of digit k in the waves below w of sub-block e
+                const int e = t >> 8, w = (t >> 4) & 15, k = t & 15;
+                uint32_t p = 0;
+                for (int w2 = 0; w2 < w; ++w2) p += wcnt[e][w2][k];
+                wpre[e][w][k] = p;
+                if (w == VS_WAVES - 1) etot[e][k] = p + wcnt[e][w][k];
+            }
+            VS_LDS_BARRIER();
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (dg[e] >= 0) {
+                    uint32_t b0 = 0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) if (dg[e] == k) b0 = base[k];
+                    for (int e2 = 0; e2 < e; ++e2) b0 += etot[e2][dg[e]];
+                    const uint32_t pos = b0 + wpre[e][wave][dg[e]] + myrank[e];
+                    kdst[pos] = key[e]; vdst[pos] = v[e];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) base[k] += etot[0][k] + etot[1][k] + etot[2][k] + etot[3][k];
+            VS_LDS_BARRIER();                         // wcnt / wpre / etot are rewritten by the next round (the scattered stores stay in flight)
+        }
+        if (t < 16) hsum[cur][t] = 0;                 // this pass's histogram becomes the buffer of the pass after next
+        if (has_next) add_hist(ncnt, nxt);
+        __syncthreads();
+        { uint64_t* a = ksrc; ksrc = kdst; kdst = a; uint32_t* b = vsrc; vsrc = vdst; vdst = b; }
+    }
+    // the result must end in (keysB, valsB): an even number of passes left it in A
+    if (ksrc == keysA) {
+        for (int i = t; i < N; i += VS_THREADS) { keysB[i] = keysA[i]; valsB[i] = valsA[i]; }
+        __syncthreads();
+    }
+    // ---- segments of equal keys: heads, their ranks (same round / ballot scheme with one class), starts, per-batch segment counts
+    uint32_t hbase = 0;
+    for (int j = 0; j < (N + VS_THREADS - 1) / VS_THREADS; ++j) {
+        const int i = j * VS_THREADS + t;
+        const bool live = i < N;
+        const uint64_t key = live ? keysB[i] : 0;
+        const bool is_head = live && (i == 0 || key != keysB[i - 1]);
+        const unsigned long long m = __ballot(is_head);
+        if (lane == 0) wcnt[0][wave][0] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (t < VS_WAVES) {
+            uint32_t p = 0;
+            for (int w2 = 0; w2 < t; ++w2) p += wcnt[0][w2][0];
+            wpre[0][t][0] = p;
+            if (t == VS_WAVES - 1) etot[0][0] = p + wcnt[0][t][0];
+        }
+        __syncthreads();
+        if (is_head) starts[hbase + wpre[0][wave][0] + (uint32_t)__popcll(m & lt)] = (uint32_t)i;
+        // one atomic per (wave, batch id): keys are sorted, a wave sees very few distinct ids
+        const int b = is_head ? (int)(key >> 48) : -1;
+        unsigned long long todo = m;
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int b0 = __shfl(b, leader, 64);
+            const unsigned long long same = __ballot(is_head && b == b0);
+            if (lane == leader) atomicAdd(batch_counts + b0, (int)__popcll(same));
+            todo &= ~same;
+        }
+        hbase += etot[0][0];
+        __syncthreads();
+    }
+    if (t == 0) { starts[hbase] = (uint32_t)N; *nseg = (int)hbase; }
+}
+
 // one wave per output row: mean over the segment's members (ascending original index = stable sort order)
 __global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restrict__ pts, const float* __restrict__ feats, const uint32_t* __restrict__ order,
                                                            const uint32_t* __restrict__ starts, const int* __restrict__ nseg,
@@ -661,6 +850,10 @@ size_t dreg_voxel_downsample_workspace_bytes(int N)
     const size_t a = ((size_t)N * 8 + 255) / 256 * 256, b4 = ((size_t)(N + 1) * 4 + 255) / 256 * 256;
     return 2 * a + 5 * b4 + tmp + 256;
 }
+static int g_own_sort = 0;     // tuning (include/dreg_nerf_tuning.h): 1 = the one-workgroup kernel above for <= 131,072 keys.  OFF by default: measured 0.45 ms (9 k keys) to
+                               // 1.45 ms (38 k keys) per round on its single CU against ~0.07 ms for rocPRIM's chip-wide sort + scan (round 4, rocprofv3); the rounds' host
+                               // syncs then put the geometry phase on the critical path (19.2 vs 18.2 ms per step).  Results are identical (tested both ways).
+void dreg_voxel_set_own_sort(int on) { g_own_sort = on ? 1 : 0; }
 static int voxel_downsample_impl(const float* pts, const float* feats, const int* pt_batch, float* out_pts, float* out_feats,
                                  int* n_out, int* batch_counts, uint32_t* inv_seg, float* inv_cnt, int* err,
                                  uint32_t* order_out, uint32_t* starts_out,
@@ -682,6 +875,14 @@ static int voxel_downsample_impl(const float* pts, const float* feats, const int
     if (starts_out) starts = starts_out;
     void* tmp = w;
     size_t tmp_bytes = workspace_bytes - (size_t)(w - (char*)workspace);
+    if (g_own_sort && N <= VS_MAX_N) {
+        // keys, sort, segments in one launch (voxel_sort_segments_kernel); `scan` / `head` stay unused
+        hipLaunchKernelGGL(voxel_sort_segments_kernel, dim3(1), dim3(VS_THREADS), 0, st, pts, pt_batch, dl, keys, keys_s, vals, order, starts, batch_counts, n_out, err, N, nbatch);
+        DREG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(segment_mean_kernel, dim3((N + 3) / 4), dim3(256), 0, st, pts, feats, order, starts, n_out, out_pts, out_feats, inv_seg, inv_cnt, C);
+        DREG_LAUNCH_CHECK();
+        return DREG_OK;
+    }
     if (hipMemsetAsync(batch_counts, 0, sizeof(int) * nbatch, st) != hipSuccess) return DREG_ELAUNCH;
     if (hipMemsetAsync(err, 0, sizeof(int), st) != hipSuccess) return DREG_ELAUNCH;
     const int nb = (N + 255) / 256;

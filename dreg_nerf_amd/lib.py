@@ -79,6 +79,7 @@ SIGNATURES = {
     "dreg_exec_set_fuse_stem": (None, [I]),
     "dreg_exec_set_fuse_bn_stats": (None, [I]),
     "dreg_exec_set_brick": (None, [I]),
+    "dreg_voxel_set_own_sort": (None, [I]),
     "dreg_exec_set_defer_head_pg": (None, [I]),
     "dreg_conv_set_bn_stats_epilogue": (None, [I]),
     "dreg_exec_set_bn_batch_tails": (None, [I]),

@@ -251,3 +251,41 @@ def test_adamw_and_grad_norm_match_torch():
         np.testing.assert_allclose(float(norm), float(tn), rtol=1e-5)
         L.check(lib.dreg_adamw_step(L.ptr(p), L.ptr(gd), L.ptr(m), L.ptr(v), L.ptr(norm), n, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step, 0.1, L.stream()), "dreg_adamw_step")
         np.testing.assert_allclose(p.cpu().numpy(), ref_p.detach().numpy(), atol=2e-6)
+
+
+@pytest.mark.parametrize("n,nbatch", [(7, 1), (1023, 2), (1025, 2), (38352, 2), (70001, 3), (131072, 2)])
+def test_own_sort_and_segments_equal_the_rocprim_form_bit_for_bit(n, nbatch):
+    """One launch (keys + stable 4-bit LSD radix sort + heads + scan + starts + batch counts in one workgroup: voxel_sort_segments_kernel)
+    against rocPRIM's radix_sort_pairs + inclusive_scan with the small kernels around them: every output of the plan identical — the
+    averaged points, their order, the segment table, the per-batch counts, the inverse maps."""
+    from dreg_nerf_amd import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(n)
+    lens = [n // nbatch] * (nbatch - 1) + [n - (n // nbatch) * (nbatch - 1)]
+    pts = (torch.rand(n, 3, generator=g) - 0.5) * 3.0
+    pts[: min(n, 40)] = pts[0]                                   # many duplicates of one cell
+    if n > 100:
+        pts[50:60] = torch.tensor([-1.4999, 0.05, -0.0500001])     # on cell borders, negative coordinates
+    pts = pts.to(DEV)
+    res = []
+    for own in (0, 1):
+        lib.dreg_voxel_set_own_sort(own)
+        try:
+            rnd, p, counts = A.plan_voxel_downsample(pts, lens, 0.05)
+        finally:
+            lib.dreg_voxel_set_own_sort(0)
+        torch.cuda.synchronize()
+        res.append((rnd.n_out, [int(c) for c in counts], p.clone(), rnd.order.clone(), rnd.starts[:rnd.n_out + 1].clone(), rnd.inv_seg.clone(), rnd.inv_cnt.clone()))
+    a, b = res
+    assert a[0] == b[0] and a[1] == b[1] and sum(a[1]) == a[0]
+    for x, y in zip(a[2:], b[2:]):
+        assert torch.equal(x, y)
+    # and the order is a stable sort by (batch, ix, iy, iz): ascending original index inside a cell
+    order = a[3].long().cpu()
+    cell = torch.floor(pts.cpu() / 0.05).long()
+    pb = torch.repeat_interleave(torch.arange(nbatch), torch.tensor(lens))
+    key = ((pb * 65536 + cell[:, 0] + 32768) * 65536 + cell[:, 1] + 32768) * 65536 + cell[:, 2] + 32768
+    ks = key[order]
+    assert torch.all(ks[1:] >= ks[:-1])
+    same = ks[1:] == ks[:-1]
+    assert torch.all(order[1:][same] > order[:-1][same])
