@@ -126,7 +126,7 @@ class pack_region:
 
 
 def wait_packs():
-    """Called in front of every consumer of a weight pack (and by TrainStep.step before any work): the CURRENT stream waits for the
+    """Called in front of every consumer of a weight pack: the CURRENT stream waits for the
     side-stream repacks.  The events stay until the next update's repack replaces them, so a consumer on any other stream (the
     parameter-gradient stream, the geometry stream, a loader thread) waits too — once per stream and repack."""
     if _PACK_EVENTS:
