@@ -16,6 +16,7 @@
 // 128 bytes of K per step, register-staged double-buffered LDS with a 16-byte-slot XOR swizzle
 // (slot ^= (row>>1)&7) so the ds_read_b128 fragment reads of 16 consecutive rows are conflict free.
 #include "common.h"
+extern "C" int dreg_fill_zero(void* p, size_t bytes, void* stream);   // fpn_ops.hip (include/dreg_nerf.h)
 
 struct ConvGeom {
     int B, Di, Hi, Wi, Cin, log2Cin;  // gathered operand [B,Di,Hi,Wi,Cin]; ksz==1: log2Cin=30 (tap always 0)
@@ -2223,7 +2224,7 @@ int dreg_conv3d_dgrad_s2(const void* gout, const void* wt_class_packed, void* di
     int rc = fill_geom(g, B, Do, Ho, Wo, Cout, Dc, Hc, Wc, ncls * Cin, ksz == 1 ? 1 : 2, 1, 0, 0, 2);
     if (rc) return rc;
     if (g.M == 0) return DREG_OK;
-    if (ksz == 1 && hipMemsetAsync(din, 0, (size_t)B * Di * Hi * Wi * Cin * 2, st) != hipSuccess) return DREG_ELAUNCH;
+    if (ksz == 1 && dreg_fill_zero(din, (size_t)B * Di * Hi * Wi * Cin * 2, st) != DREG_OK) return DREG_ELAUNCH;   // (own fill kernel: HBM rate; hipMemsetAsync's runs 256 workgroups)
     return launch_conv<bf16_t, bf16_t>(gout, wt_class_packed, din, nullptr, nullptr, g, 0, Di, Hi, Wi, -Cin, st);
 }
 

@@ -7,6 +7,7 @@
 // conerf/model/feature_pyramid_net.py:58-61 (_upsample), conerf/register/nerf_regtr.py:138-147 (gather).
 // All tensors are NDHWC, 16-byte channel granules per thread, fp32 math.
 #include "common.h"
+extern "C" int dreg_fill_zero(void* p, size_t bytes, void* stream);   // fpn_ops.hip (include/dreg_nerf.h)
 
 template <typename T> struct Gran;
 template <> struct Gran<float> {
@@ -1812,7 +1813,7 @@ int dreg_pack_rgba_sparse_occ(const float* vals, const int64_t* idx, const int* 
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = (size_t)B * Z * X * Y * 8 * (dtype == 0 ? 2 : 4);
     if (bytes == 0) return DREG_OK;
-    if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) return DREG_ELAUNCH;
+    if (dreg_fill_zero(out, bytes, st) != DREG_OK) return DREG_ELAUNCH;
     if (inocc && hipMemsetAsync(inocc, 0, (size_t)B * Z * X, st) != hipSuccess) return DREG_ELAUNCH;
     if (N <= 0) return DREG_OK;
     if (dtype == 0) hipLaunchKernelGGL(scatter_rgba_kernel<bf16_t>, dim3((N + 255) / 256), dim3(256), 0, st, vals, idx, pt_batch, (bf16_t*)out, N, Z, X, Y, inocc);
@@ -1868,7 +1869,7 @@ int dreg_trilinear_gather_bwd_rows(const float* dfeat, const int64_t* idx, const
     const int G = dtype == 0 ? 8 : 4;
     if (C % G) return DREG_EINVAL;
     const size_t dense_bytes = (size_t)B * d * h * w * C * (dtype == 0 ? 2 : 4);
-    if (hipMemsetAsync(dp1, 0, dense_bytes, st) != hipSuccess) return DREG_ELAUNCH;
+    if (dreg_fill_zero(dp1, dense_bytes, st) != DREG_OK) return DREG_ELAUNCH;
     if (N == 0 || n1 == 0) return DREG_OK;
     if (hipMemsetAsync(comp, 0, (size_t)n1 * C * sizeof(float), st) != hipSuccess) return DREG_ELAUNCH;
     hipLaunchKernelGGL(trilinear_gather_bwd_rows_kernel, dim3(nblocks((size_t)N * C)), dim3(256), 0, st, dfeat, idx, pt_batch, map1, comp, N, d, h, w, C, Zr, Xr, Yr);
@@ -1912,7 +1913,7 @@ static int tri_bwd_gather(const float* dfeat, const int64_t* idx, const int* pt_
     hipStream_t st = (hipStream_t)stream;
     if (C % 64 || C > 256) return DREG_EINVAL;
     const size_t dense_bytes = (size_t)B * d * h * w * C * (dtype == 0 ? 2 : 4);
-    if (zero_dense && hipMemsetAsync(dp1, 0, dense_bytes, st) != hipSuccess) return DREG_ELAUNCH;
+    if (zero_dense && dreg_fill_zero(dp1, dense_bytes, st) != DREG_OK) return DREG_ELAUNCH;
     if (N == 0 || n1 == 0) return DREG_OK;
     const size_t Vf = (size_t)Zr * Xr * Yr;
     if (hipMemsetAsync(fine_map, 0xff, (size_t)B * Vf * sizeof(int), st) != hipSuccess) return DREG_ELAUNCH;

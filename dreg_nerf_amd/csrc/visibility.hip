@@ -200,6 +200,7 @@ __global__ __launch_bounds__(64) void surface_visibility_kernel(VisArgs a)
 // camera, so the later cameras mostly find the label set).  Per-ray arithmetic is unchanged: the labels are the same.
 // The MLP stores its hidden layer as in ngp_density_kernel: products formed transposed (weights as the MFMA's first operand), so a lane
 // holds four consecutive hidden units of one sample and writes them with one 8-byte LDS store instead of 64 two-byte ones.
+__device__ long g_pass_bound = 1L << 22;   // passes of the march loop per wave (test hook: dreg_visibility_set_pass_bound)
 __device__ __forceinline__ void vwave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ void vis_march_queue(const VisArgs& a, unsigned long long* __restrict__ queue)
 {
@@ -236,7 +237,9 @@ __device__ __forceinline__ void vis_march_queue(const VisArgs& a, unsigned long 
     int p = 0, n = 0;
     float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f}, tmax = 0.f, tmin = 0.f, T = 1.f, best = 0.f;
 
-    for (long it = 0; it < (1L << 22); ++it) {                      // (bound: a safety net, never reached — every pass advances every live ray)
+    bool finished = false;
+    const long pass_bound = g_pass_bound;
+    for (long it = 0; it < pass_bound; ++it) {                    // (bound: a safety net, never reached — every pass advances every live ray)
         // ---- refill: lanes without a ray take the next ones from the queue, skipping rays whose point is already labelled
         for (int tries = 0; tries < 1024; ++tries) {
             const bool need = !active && !exhausted;
@@ -274,7 +277,7 @@ __device__ __forceinline__ void vis_march_queue(const VisArgs& a, unsigned long 
             }
         }
         if (!__any(active)) {
-            if (__all(exhausted)) break;                             // the queue is empty and nothing is in flight
+            if (__all(exhausted)) { finished = true; break; }        // the queue is empty and nothing is in flight
             continue;                                                // (a long run of skipped rays used up this pass's refill rounds)
         }
         // ---- advance every live ray to its next lattice sample inside an occupied cell
@@ -395,6 +398,9 @@ __device__ __forceinline__ void vis_march_queue(const VisArgs& a, unsigned long 
         }
         vwave_sync();
     }
+    // the bound was reached with rays still queued or in flight: their points stay unlabelled — say so in bit 63 of the ray counter
+    // (the caller reads it back: dreg_nerf_amd/visibility.py raises on the next call)
+    if (!finished && lane == 0) atomicOr(queue, 1ull << 63);
 }
 
 __global__ __launch_bounds__(64) void surface_visibility_persistent_kernel(VisArgs a, unsigned long long* __restrict__ queue)
@@ -510,6 +516,13 @@ int dreg_surface_visibility_multi(const void* descs_dev, int n, long total_rays,
 // The same labels from the persistent kernel (lanes refilled from a ray queue; rays of points that already carry the label are not
 // marched).  queue: 8 bytes of device memory the CALLER has zeroed on this stream (the ray counter).
 void dreg_visibility_set_waves(int n) { g_vis_waves = n > 0 ? n : 4096; }
+// Test hook: passes of the persistent kernels' march loop per wave (0 = the default 2^22, never reached by a real extraction).  A launch
+// that hits the bound sets bit 63 of its ray counter(s) — the caller's `queue` words — instead of silently leaving points unlabelled.
+int dreg_visibility_set_pass_bound(long passes)
+{
+    const long v = passes > 0 ? passes : (1L << 22);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pass_bound), &v, sizeof(v));
+}
 int dreg_surface_visibility_queue(const float* cams, const float* pts, const uint8_t* binary, int* label,
                                   const void* table, const void* w1, const void* w2,
                                   const uint32_t* offset, const uint32_t* size, const uint32_t* res, const float* scale, const uint32_t* hashed,

@@ -228,6 +228,7 @@ SIGNATURES = {
     "dreg_surface_visibility_fill_desc": (I, [P] + [P] * 7 + [P] * 5 + [P, P, P] + [I] * 5 + [F, F, F, F, P, P]),
     "dreg_surface_visibility_multi": (I, [P, I, ctypes.c_long, P]),
     "dreg_visibility_set_waves": (None, [I]),
+    "dreg_visibility_set_pass_bound": (I, [ctypes.c_long]),
 }
 
 

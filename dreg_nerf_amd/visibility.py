@@ -142,8 +142,10 @@ def surface_visibility(points: torch.Tensor, cam_centres: torch.Tensor, field: n
         qoff = (pts.shape[0] + (pts.shape[0] & 1)) * 4
         if coarse_bits is None and COARSE:
             coarse_bits = coarse_occupancy_bits(b8)
+        OVERRUN.check()
         L.check(lib.dreg_surface_visibility_queue(*common, buf.data_ptr() + qoff, L.ptr(coarse_bits) if (coarse_bits is not None and COARSE) else None, L.stream()),
                 "dreg_surface_visibility_queue")
+        OVERRUN.watch(buf[qoff // 4:qoff // 4 + 2])
     else:
         L.check(lib.dreg_surface_visibility(*common, L.stream()), "dreg_surface_visibility")
     return label > 0
@@ -177,6 +179,54 @@ def compute_visibility_score(xyz_list: List[torch.Tensor], nerf_model_path: str,
 # Pinned staging for the descriptor tables: a ring of four buffers per device, each guarded by an event recorded behind its last copy
 # (allocating / freeing pinned memory every step costs a host-side hipHostMalloc / hipHostFree pair, the latter a possible device sync).
 _staging: Dict[str, list] = {}
+
+
+class _OverrunWatch:
+    """The persistent kernels set bit 63 of a launch's ray counter(s) when a wave leaves the march loop through its safety bound with rays
+    still queued or in flight (their points would stay unlabelled).  Reading the counters back right away would be a host sync per label
+    launch; instead they are copied to a pinned slot behind the launch and looked at when a later call finds the copy done (or by
+    check(wait=True): tests, the end of an extraction)."""
+
+    SLOTS, WORDS = 8, 64           # pinned slots (allocated once), ray counters per slot
+
+    def __init__(self):
+        self.pending = []          # (event, pinned int64 view)
+        self.free = None
+
+    def watch(self, counters: torch.Tensor):
+        n = counters.numel() // 2
+        if counters.device.type != "cuda" or n > self.WORDS:
+            return
+        if self.free is None:
+            self.free = [(torch.cuda.Event(), torch.empty(self.WORDS, dtype=torch.int64).pin_memory()) for _ in range(self.SLOTS)]
+        if not self.free:
+            self.check()
+            if not self.free:      # the GPU is eight label launches behind the host
+                self.pending[0][0].synchronize()
+                self.check()
+        ev, slot = self.free.pop()
+        host = slot[:n]
+        host.copy_(counters.view(torch.int64), non_blocking=True)
+        ev.record(torch.cuda.current_stream(counters.device))
+        self.pending.append((ev, host, slot))
+
+    def check(self, wait: bool = False):
+        keep, bad = [], False
+        for ev, host, slot in self.pending:
+            if wait:
+                ev.synchronize()
+            if not ev.query():
+                keep.append((ev, host, slot))
+                continue
+            bad = bad or bool((host < 0).any())
+            self.free.append((ev, slot))
+        self.pending = keep
+        if bad:
+            raise L.DregError("surface visibility: a persistent launch reached its pass bound with rays left — points of that call are "
+                              "unlabelled (dreg_visibility_set_pass_bound / dreg_visibility_set_waves too small for this extraction)")
+
+
+OVERRUN = _OverrunWatch()
 
 
 def _desc_staging(nbytes: int, device):
@@ -234,7 +284,9 @@ def compute_visibility_scores_batched(requests, cut_off: float = 0.5) -> List[to
     descs = host.to(device, non_blocking=True)
     if host_ev is not None:
         host_ev.record(torch.cuda.current_stream(device))       # the staging buffer may be refilled once this copy has run
+    OVERRUN.check()
     L.check(lib.dreg_surface_visibility_multi(L.ptr(descs), len(requests), total, L.stream()), "dreg_surface_visibility_multi")
+    OVERRUN.watch(buf[q_off:q_off + 2 * len(requests)])
     if device.type == "cuda":
         cur = torch.cuda.current_stream(device)
         for field, _, meta in blocks:

@@ -52,6 +52,7 @@ int dreg_conv3d_wgrad_variant(int B, int Do, int Ho, int Wo, int Cin, int Cout, 
 void dreg_ngp_set_rgb_chunks(int on);                 /* 1 (default): shared-direction colour queries run the persistent 16-point-chunk kernel; 0: the 64-point-per-wave kernel */
 void dreg_ngp_set_density_unroll(int n);             /* hash-grid levels of the density kernel whose 8 corner gathers are issued together: 1, 2, 4 or 8 */
 void dreg_ngp_set_xcd_levels(int on);                /* 1 (default): dreg_ngp_density_fwd_ws encodes with XCD-resident level pairs (two launches); 0: the fused kernel */
+int dreg_visibility_set_pass_bound(long passes);   /* test hook: passes of the persistent visibility kernels' march loop per wave (0 = default 2^22); a launch that reaches it sets bit 63 of its ray counter words */
 void dreg_visibility_set_waves(int n);               /* one-wave workgroups of dreg_surface_visibility_queue's persistent launch (default 4096 = 256 CUs x 16) */
 void dreg_conv_set_narrow_small(int on);              /* 1 (default): launches of < 224 128 x 128 tiles use 128 x 64 tiles (twice the workgroups) */
 

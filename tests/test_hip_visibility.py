@@ -120,6 +120,40 @@ def test_persistent_ray_queue_gives_the_lock_step_labels(wscale):
         assert torch.equal(v, ref), k
 
 
+def test_pass_bound_of_the_persistent_kernel_is_reported():
+    """A persistent launch that leaves its march loop through the safety bound (never on a real extraction; forced here with a bound of
+    two passes) must not leave points silently unlabelled: bit 63 of its ray counter is set and the next look at it raises."""
+    from dreg_nerf_amd import lib as L
+    lib = L.load()
+    res = 64
+    g = torch.Generator().manual_seed(5)
+    f = ngp.NGPradianceField(AABB)
+    with torch.no_grad():
+        f.mlp_base.params[:3072] = torch.randn(3072, generator=g) * 3.0           # an opaque field: every ray finds a surface
+        f.mlp_base.params[3072:] = torch.randn(f.mlp_base.params.numel() - 3072, generator=g)
+    f = f.to(DEV)
+    c = (torch.arange(res, dtype=torch.float32) + 0.5) / res * 3 - 1.5
+    X, Y, Z = torch.meshgrid(c, c, c, indexing="ij")
+    rad = torch.stack([X, Y, Z], -1).norm(dim=-1)
+    binary = ((rad > 0.6) & (rad < 0.9)).to(DEV)
+    pts = ((torch.rand(20000, 3, generator=g) - 0.5) * 2.4).to(DEV)
+    cams = (torch.nn.functional.normalize(torch.randn(6, 3, generator=g), dim=-1) * 2.8).to(DEV)
+    dt = 3 * 3 ** 0.5 / 256
+    visibility.OVERRUN.check(wait=True)
+    assert lib.dreg_visibility_set_pass_bound(2) == 0
+    lib.dreg_visibility_set_waves(64)
+    try:
+        visibility.surface_visibility(pts, cams, f, binary, AABB, AABB, dt)
+        with pytest.raises(L.DregError, match="pass bound"):
+            visibility.OVERRUN.check(wait=True)
+    finally:
+        assert lib.dreg_visibility_set_pass_bound(0) == 0
+        lib.dreg_visibility_set_waves(0)
+    lab = visibility.surface_visibility(pts, cams, f, binary, AABB, AABB, dt)
+    visibility.OVERRUN.check(wait=True)                  # the default bound is never reached
+    assert 0 < int(lab.sum())
+
+
 def test_block_cache_keeps_inference_copies_and_is_filled_by_the_loader_thread(tmp_path):
     """visibility.load_block keeps a block as its fp16 inference copy + occupancy grid (the fp32 parameters are released): ~27 MB instead
     of ~80, so that an epoch's blocks stay resident; labels from a frozen block equal those from the block as loaded; the prefetching

@@ -8,6 +8,9 @@ for mode in active_set dense_head; do
   DREG_SERIAL_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/art/ser_$mode -o k -- python bench.py --no-cpu-baseline --no-dense-reference --no-nerf-labels-reference --no-ngp-reference $flag > gpurun_out/art/ser_$mode.log 2>&1
 done
 find gpurun_out/art -name "*kernel_stats.csv" | head; du -sh gpurun_out/art
-# keep only the stats csv (traces are large)
+# per-queue timeline of one steady-state step (launch counts per queue, gaps) from the traces, then keep only the stats csv (traces are large)
+for m in two_active_set ser_active_set; do
+  f=$(find gpurun_out/art/$m -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/timeline.py $f > gpurun_out/art/timeline_$m.txt 2>&1
+done
 find gpurun_out/art -name "*kernel_trace.csv" -delete; find gpurun_out/art -name "*.db" -delete
 du -sh gpurun_out/art

@@ -13,6 +13,7 @@ timeout 900 bash tools/pmc_kernel_clock.sh "python tools/bench_igemm_ap.py" conv
 timeout 600 python tools/wgrad_phase_probe.py > gpurun_out/round/wgrad_phase_probe.txt 2>&1
 timeout 600 python tools/bench_wgrad.py 8 > gpurun_out/round/bench_wgrad.txt 2>&1
 timeout 600 python tools/bench_igemm_ap.py > gpurun_out/round/bench_igemm_ap.txt 2>&1
+timeout 600 python tools/bench_conv_brick.py > gpurun_out/round/bench_conv_brick.txt 2>&1
 timeout 300 python tools/repack_bubble.py > gpurun_out/round/repack_bubble.txt 2>&1
 tail -2 gpurun_out/art/bench.log | cut -c1-600
 ls -la gpurun_out/round gpurun_out/art

@@ -1,4 +1,4 @@
-# usage: bash tools/r04_run.sh "<pytest args>" [bench args...]   (one gpurun call: tests, then a short bench)
+# usage: bash tools/gpu_run.sh "<pytest args>" [bench args...]   (one gpurun call: tests, then a short bench)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/run
 timeout 1500 python -m pytest $1 -x -q 2>&1 | tail -25 > gpurun_out/run/pytest.txt

@@ -11,6 +11,8 @@ cp gpurun_out/round/bench_ngp.json profiles/${R}_bench_ngp_config4.json; cp gpur
 (echo '# tools/pmc_kernel_clock.sh "python tools/bench_wgrad.py" conv_'; cat gpurun_out/round/pmc_kernel_clock_wgrad.txt; echo '# tools/pmc_kernel_clock.sh "python tools/bench_igemm_ap.py" conv_igemm'; cat gpurun_out/round/pmc_kernel_clock_igemm.txt) > profiles/${R}_pmc_kernel_clock_wgrad_igemm.txt
 cp gpurun_out/round/wgrad_phase_probe.txt profiles/${R}_wgrad_phase_probe.txt; cp gpurun_out/round/bench_wgrad.txt profiles/${R}_bench_wgrad.txt
 cp gpurun_out/round/bench_igemm_ap.txt profiles/${R}_bench_igemm_ap.txt; cp gpurun_out/round/repack_bubble.txt profiles/${R}_repack_bubble.txt
+cp gpurun_out/round/bench_conv_brick.txt profiles/${R}_bench_conv_brick.txt
+for m in two ser; do cp gpurun_out/art/timeline_${m}_active_set.txt profiles/${R}_timeline_per_queue_${m}_streams_under_profiler.txt; done
 [ -f gpurun_out/pinned_step_report.json ] && cp gpurun_out/pinned_step_report.json profiles/${R}_pinned_step_report.json
 python - <<'PY'
 import json, sys
