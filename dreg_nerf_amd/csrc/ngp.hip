@@ -151,6 +151,9 @@ __global__ __launch_bounds__(64) void ngp_encode_xcd_kernel(const float* __restr
     }
 }
 
+// optional epilogue of the density kernel (SampleGrid.query_dense): alpha[n] = clip(1 - exp(-delta * density)), keep[n] = density > thre
+// (counting the kept cells per row here with atomics doubled the launch's 17 us; dreg_grid_write_kept counts them with a wave per row)
+struct NgpKeepEpi { float* alpha; uint8_t* keep; float delta, thre; };
 // PRE: the level features come from ngp_encode_xcd_kernel's buffer (feat) instead of being gathered here
 template <int UNR, bool PRE = false>
 __global__ __launch_bounds__(64) void ngp_density_kernel(const float* __restrict__ x, const _Float16* __restrict__ table,
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(64) void ngp_density_kernel(const float* __restrict
                                                           float* __restrict__ density, _Float16* __restrict__ raw,
                                                           NgpLevels lv, float lo0, float lo1, float lo2, float hi0, float hi1, float hi2, int Np,
                                                           int contract, const _Float16* __restrict__ feat = nullptr, const int* __restrict__ order = nullptr,
-                                                          int x_in_slot_order = 0)
+                                                          int x_in_slot_order = 0, NgpKeepEpi ke = NgpKeepEpi{})
 {
     constexpr int XRS = 32 * 2 + 16, HRS = 64 * 2 + 16;
     // per wave: ONE 64 x 64 fp16 tile (the encoded input X lives in its first 5 KB until the first layer has read it) + 64 flags:
@@ -228,7 +231,15 @@ __global__ __launch_bounds__(64) void ngp_density_kernel(const float* __restrict
                 const _Float16 hv = (_Float16)o[r];
                 const int pt = sPt[row];
                 raw[(size_t)pt * 16 + fr] = hv;
-                if (fr == 0) density[pt] = __expf((float)hv - 1.f) * sSel[row];
+                if (fr == 0) {
+                    const float d = __expf((float)hv - 1.f) * sSel[row];
+                    density[pt] = d;
+                    if (ke.alpha) {                     // the dense query's alpha / density mask from the same launch (ngp_alpha_keep_kernel's arithmetic)
+                        ke.alpha[pt] = fminf(fmaxf(1.f - __expf(-ke.delta * d), 0.f), 1.f);
+                        const bool kp = d > ke.thre;
+                        ke.keep[pt] = kp ? 1 : 0;
+                    }
+                }
             }
         }
     }
@@ -501,12 +512,12 @@ __global__ void grid_sample_points_kernel(const int64_t* __restrict__ idx, const
 // pre[f] = occupied cells with smaller x in f's (y, z) column, cnt[z][y] = the column's total.  A workgroup = NS x-segments of 16 cells
 // x COLS consecutive columns: every thread has its 16 loads in flight at once (a thread walking a whole column is a chain of rx
 // dependent steps: 3x the time of the density kernel's gain), the segments are joined through LDS.
-__global__ __launch_bounds__(256) void grid_xprefix_kernel(const uint8_t* __restrict__ binary, uint16_t* __restrict__ pre, int* __restrict__ cnt, int rx, int ry, int rz,
-                                                            int NS, int COLS)
+__device__ __forceinline__ void grid_xprefix(const uint8_t* __restrict__ binary, uint16_t* __restrict__ pre, int* __restrict__ cnt, int rx, int ry, int rz,
+                                             int NS, int COLS, int block)
 {
     __shared__ int seg[256];
     const int t = threadIdx.x, s_ = t / COLS, c = t - s_ * COLS;          // segment, column within the workgroup (columns fastest: coalesced)
-    const int col = blockIdx.x * COLS + c;                                 // column (y, z), z fastest
+    const int col = block * COLS + c;                                      // column (y, z), z fastest
     const bool live = s_ < NS && col < ry * rz;
     const size_t plane = (size_t)ry * rz;
     uint8_t b[16];
@@ -527,6 +538,11 @@ __global__ __launch_bounds__(256) void grid_xprefix_kernel(const uint8_t* __rest
         }
         if (s_ == NS - 1) { const int y = col / rz, z = col - y * rz; cnt[z * ry + y] = run; }   // columns in (z, y) order: the order of the enumeration
     }
+}
+__global__ __launch_bounds__(256) void grid_xprefix_kernel(const uint8_t* __restrict__ binary, uint16_t* __restrict__ pre, int* __restrict__ cnt, int rx, int ry, int rz,
+                                                            int NS, int COLS)
+{
+    grid_xprefix(binary, pre, cnt, rx, ry, rz, NS, COLS, (int)blockIdx.x);
 }
 // exclusive scan in place, one workgroup: rounds of 1024 x 16 entries — a thread's 16 values are loaded at once, scanned in registers,
 // the threads' totals by wave shuffles + one LDS exchange (a loop of dependent loads / block-wide sync steps took 25 us for 16 k entries)
@@ -575,17 +591,17 @@ template <typename T> __global__ void f32_to_f16_kernel(const float* __restrict_
 
 static int g_ngp_density_unroll = 1;   // tuning (include/dreg_nerf_tuning.h): hash-grid levels whose corner gathers are in flight together (1, 2, 4, 8)
 static void ngp_density_launch(const float* x, const void* table, const void* w1, const void* w2, float* density, void* raw, const NgpLevels& lv,
-                               const float* aabb, int Np, int contract, void* stream, const int* order = nullptr, int xslot = 0)
+                               const float* aabb, int Np, int contract, void* stream, const int* order = nullptr, int xslot = 0, NgpKeepEpi ke = NgpKeepEpi{})
 {
 #define NGP_D(U) hipLaunchKernelGGL(ngp_density_kernel<U>, dim3((Np + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, (const _Float16*)table, \
-                                    (const _Float16*)w1, (const _Float16*)w2, density, (_Float16*)raw, lv, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np, contract, nullptr, order, xslot)
+                                    (const _Float16*)w1, (const _Float16*)w2, density, (_Float16*)raw, lv, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np, contract, nullptr, order, xslot, ke)
     if (g_ngp_density_unroll == 8) NGP_D(8); else if (g_ngp_density_unroll == 4) NGP_D(4); else if (g_ngp_density_unroll == 2) NGP_D(2); else NGP_D(1);
 #undef NGP_D
 }
 static int g_ngp_xcd_levels = 1;       // tuning (include/dreg_nerf_tuning.h): with a workspace, encode per XCD-resident level pair first (ngp_encode_xcd_kernel)
 // two launches: the level features of all points into `feat` (fp16 [16][Np][2], XCD-partitioned levels), then the density MLP over them
 static void ngp_density_launch_xcd(const float* x, const void* table, const void* w1, const void* w2, float* density, void* raw, const NgpLevels& lv,
-                                   const float* aabb, int Np, int contract, void* feat, void* stream, const int* order, int xslot)
+                                   const float* aabb, int Np, int contract, void* feat, void* stream, const int* order, int xslot, NgpKeepEpi ke = NgpKeepEpi{})
 {
     const int nchunk = (Np + 63) / 64;
     int wpx = 512;                      // waves per XCD: 32 CUs x 16 resident one-wave workgroups
@@ -594,7 +610,7 @@ static void ngp_density_launch_xcd(const float* x, const void* table, const void
                        aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np, contract, wpx, order, xslot);
     hipLaunchKernelGGL((ngp_density_kernel<1, true>), dim3(nchunk), dim3(64), 0, (hipStream_t)stream, x, (const _Float16*)table,
                        (const _Float16*)w1, (const _Float16*)w2, density, (_Float16*)raw, lv, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np, contract,
-                       (const _Float16*)feat, order, xslot);
+                       (const _Float16*)feat, order, xslot, ke);
 }
 static int g_ngp_rgb_chunks = 1;     // tuning (include/dreg_nerf_tuning.h): shared-direction colour queries run the 16-point-chunk kernel (0: the 64-point kernel)
 
@@ -797,6 +813,249 @@ int dreg_grid_sample_points_ordered(const int64_t* idx, const float* jitter, con
     if (!order || !world_slot) return DREG_EINVAL;
     hipLaunchKernelGGL(grid_sample_points_kernel, dim3((Np + 255) / 256), dim3(256), 0, (hipStream_t)stream, idx, jitter, world,
                        rx, ry, rz, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np, order, world_slot);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ the dense query's cell lists in three launches
+// SampleGrid.query_dense needs, from the block's occupancy volume `binary` [rx][ry][rz]: the ascending list of occupied flat indices
+// (sample_grid.py:223-228: torch.nonzero), the jittered world position of each (:229-242), and — for the hash grid's sake — the x-fastest
+// lane order (dreg_grid_x_order).  torch.nonzero alone is five launches and a host sync; here
+//   1. grid_occupied_count_kernel: the x-prefix counts of dreg_grid_x_order PLUS, in extra workgroups, the occupied cells of every (x, y)
+//      row (a row = rz consecutive bytes) and a cleared kept-cells-per-row table;
+//   2. grid_scan2_kernel: workgroup 0 scans the (z, y) column counts, workgroup 1 the (x, y) row counts and leaves the total N;
+//      (the host reads N: the one sync, needed to size the outputs)
+//   3. grid_occupied_build_kernel: a wave per row ranks its occupied cells by ballot: n = row base + rank (ascending order), slot j =
+//      column base + x-prefix; writes indices[n], order[j], world[n], world_slot[j] with grid_sample_points_kernel's arithmetic.
+// After the query, dreg_grid_write_kept turns keep[] into voxel_mask (ascending kept indices) and voxel_grid the same way: the density
+// kernel's epilogue counted the kept cells per row, one scan gives the rows' offsets, a wave per row ranks its kept points.
+__device__ __forceinline__ void grid_rowcount(const uint8_t* __restrict__ binary, int* __restrict__ rowcnt, int nrows, int rz, int block)
+{
+    const int r = block * 256 + threadIdx.x;
+    if (r >= nrows) return;
+    const uint8_t* b = binary + (size_t)r * rz;
+    int c = 0;
+    int z = 0;
+    if ((rz & 15) == 0 && (((uintptr_t)b) & 15) == 0) {
+        for (; z < rz; z += 16) {
+            const uint4 v = *reinterpret_cast<const uint4*>(b + z);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)         // non-zero bytes of the word: bit 7 of (low seven bits + 0x7f) | byte
+                c += __popc((((w[k] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w[k]) & 0x80808080u);
+        }
+    } else {
+        for (; z < rz; ++z) c += b[z] ? 1 : 0;
+    }
+    rowcnt[r] = c;
+}
+// one launch: workgroups [0, nprefix) are grid_xprefix_kernel's, the rest count the rows
+__global__ __launch_bounds__(256) void grid_occupied_count_kernel(const uint8_t* __restrict__ binary, uint16_t* __restrict__ pre, int* __restrict__ colcnt,
+                                                                   int* __restrict__ rowcnt, int rx, int ry, int rz, int NS, int COLS, int nprefix)
+{
+    if ((int)blockIdx.x < nprefix) grid_xprefix(binary, pre, colcnt, rx, ry, rz, NS, COLS, (int)blockIdx.x);
+    else grid_rowcount(binary, rowcnt, rx * ry, rz, (int)blockIdx.x - nprefix);
+}
+// kept points per (x, y) row: a wave per row over keep[rowbase[r] .. rowbase[r + 1])
+__global__ __launch_bounds__(256) void grid_keeprow_kernel(const int* __restrict__ rowbase, const uint8_t* __restrict__ keep, int* __restrict__ keeprow, int nrows, int Np)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const int nb = rowbase[r], ne = r + 1 < nrows ? rowbase[r + 1] : Np;
+    int c = 0;
+    for (int q = nb; q < ne; q += 64) c += __popcll(__ballot(q + lane < ne && keep[q + lane] != 0));
+    if (lane == 0) keeprow[r] = c;
+}
+// exclusive scans in place, one workgroup each: blockIdx 0 -> (a0, n0), blockIdx 1 -> (a1, n1); totals[blockIdx] = the array's sum
+__global__ __launch_bounds__(1024) void grid_scan2_kernel(int* __restrict__ a0, int n0, int* __restrict__ a1, int n1, int* __restrict__ totals)
+{
+    __shared__ int wtot[16];
+    __shared__ int carry_s;
+    int* cnt = blockIdx.x == 0 ? a0 : a1;
+    const int n = blockIdx.x == 0 ? n0 : n1;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int carry = 0;
+    for (int r0 = 0; r0 < n; r0 += 1024 * 16) {
+        const int lo = r0 + t * 16;
+        int v[16];
+        const bool whole = lo + 16 <= n && ((uintptr_t)(cnt + lo) & 15) == 0;      // a thread's 16 entries as four 16-byte loads (scalar loads at a
+        if (whole) {                                                                 // 64-byte lane stride are 16 x 64 cache-line requests per wave)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int4 q = *reinterpret_cast<const int4*>(cnt + lo + 4 * k);
+                v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = lo + i < n ? cnt[lo + i] : 0;
+        }
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int c = v[i]; v[i] = s; s += c; }
+        int inc = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        int wbase = 0;
+        for (int q = 0; q < wave; ++q) wbase += wtot[q];
+        const int base = carry + wbase + inc - s;
+        if (whole) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                *reinterpret_cast<int4*>(cnt + lo + 4 * k) = make_int4(base + v[4 * k], base + v[4 * k + 1], base + v[4 * k + 2], base + v[4 * k + 3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) if (lo + i < n) cnt[lo + i] = base + v[i];
+        }
+        if (t == 1023) carry_s = base + s;
+        __syncthreads();
+        carry = carry_s;
+        __syncthreads();
+    }
+    if (t == 0 && totals) totals[blockIdx.x] = carry;
+}
+__global__ __launch_bounds__(256) void grid_occupied_build_kernel(const uint8_t* __restrict__ binary, const uint16_t* __restrict__ pre, const int* __restrict__ colbase,
+                                                                   const int* __restrict__ rowbase, const float* __restrict__ jitter,
+                                                                   int64_t* __restrict__ indices, int* __restrict__ order, float* __restrict__ world,
+                                                                   float* __restrict__ world_slot, int rx, int ry, int rz,
+                                                                   float lo0, float lo1, float lo2, float hi0, float hi1, float hi2)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);            // row (x, y)
+    if (r >= rx * ry) return;
+    const int xx = r / ry, y = r - xx * ry;
+    int n0 = rowbase[r];
+    for (int z0 = 0; z0 < rz; z0 += 64) {
+        const int z = z0 + lane;
+        const int64_t f = (int64_t)r * rz + z;
+        const bool occ = z < rz && binary[f] != 0;
+        const unsigned long long m = __ballot(occ);
+        if (occ) {
+            const int n = n0 + __popcll(m & ((1ull << lane) - 1ull));
+            const int j = colbase[z * ry + y] + (int)pre[f];
+            const float u0 = ((float)xx + jitter[(size_t)n * 3]) / (float)rx, u1 = ((float)y + jitter[(size_t)n * 3 + 1]) / (float)ry,
+                        u2 = ((float)z + jitter[(size_t)n * 3 + 2]) / (float)rz;
+            const float w0 = u0 * (hi0 - lo0) + lo0, w1 = u1 * (hi1 - lo1) + lo1, w2 = u2 * (hi2 - lo2) + lo2;
+            indices[n] = f;
+            order[j] = n;
+            world[(size_t)n * 3] = w0; world[(size_t)n * 3 + 1] = w1; world[(size_t)n * 3 + 2] = w2;
+            world_slot[(size_t)j * 3] = w0; world_slot[(size_t)j * 3 + 1] = w1; world_slot[(size_t)j * 3 + 2] = w2;
+        }
+        n0 += __popcll(m);
+    }
+}
+// a wave per (x, y) row: the row's points are n in [rowbase[r], rowbase[r + 1]) (ascending cells); the kept ones go to
+// mask[keepbase[r] + rank] and to the voxel grid (grid_scatter7_kernel's writes)
+__global__ __launch_bounds__(256) void grid_write_kept_kernel(const int* __restrict__ rowbase, const int* __restrict__ keepbase, const uint8_t* __restrict__ keep,
+                                                               const int64_t* __restrict__ indices, const float* __restrict__ xyz, const float* __restrict__ rgb,
+                                                               const float* __restrict__ alpha, int64_t* __restrict__ mask, float* __restrict__ grid,
+                                                               int nrows, int Np)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const int nb = rowbase[r], ne = r + 1 < nrows ? rowbase[r + 1] : Np;
+    int m0 = keepbase[r];
+    for (int q = nb; q < ne; q += 64) {
+        const int n = q + lane;
+        const bool kp = n < ne && keep[n] != 0;
+        const unsigned long long m = __ballot(kp);
+        if (kp) {
+            const int64_t f = indices[n];
+            mask[m0 + __popcll(m & ((1ull << lane) - 1ull))] = f;
+            float* g = grid + (size_t)f * 7;
+            g[0] = xyz[(size_t)n * 3]; g[1] = xyz[(size_t)n * 3 + 1]; g[2] = xyz[(size_t)n * 3 + 2];
+            g[3] = rgb[(size_t)n * 3]; g[4] = rgb[(size_t)n * 3 + 1]; g[5] = rgb[(size_t)n * 3 + 2];
+            g[6] = alpha[n];
+        }
+        m0 += __popcll(m);
+    }
+}
+
+extern "C" {
+
+// workspace layout (bytes, 256-aligned parts): pre uint16 [rx*ry*rz] | colcnt int [ry*rz] | rowcnt int [rx*ry] | keeprow int [rx*ry] | totals int [4]
+static size_t occ_align(size_t v) { return (v + 255) / 256 * 256; }
+size_t dreg_grid_occupied_workspace_bytes(int rx, int ry, int rz)
+{
+    return occ_align((size_t)rx * ry * rz * sizeof(uint16_t)) + occ_align((size_t)ry * rz * sizeof(int)) + 2 * occ_align((size_t)rx * ry * sizeof(int)) + 256;
+}
+struct OccWs { uint16_t* pre; int* colcnt; int* rowcnt; int* keeprow; int* totals; };
+static OccWs occ_ws(void* workspace, int rx, int ry, int rz)
+{
+    char* p = (char*)workspace;
+    OccWs w;
+    w.pre = (uint16_t*)p; p += occ_align((size_t)rx * ry * rz * sizeof(uint16_t));
+    w.colcnt = (int*)p; p += occ_align((size_t)ry * rz * sizeof(int));
+    w.rowcnt = (int*)p; p += occ_align((size_t)rx * ry * sizeof(int));
+    w.keeprow = (int*)p; p += occ_align((size_t)rx * ry * sizeof(int));
+    w.totals = (int*)p;
+    return w;
+}
+// device address of the int32 pair (N = occupied cells, n_keep = kept cells once dreg_grid_write_kept has run) inside the workspace
+void* dreg_grid_occupied_totals(void* workspace, int rx, int ry, int rz) { return occ_ws(workspace, rx, ry, rz).totals; }
+// steps 1 + 2 (see above): after it the int at dreg_grid_occupied_totals()[0] is N
+int dreg_grid_occupied_count(const uint8_t* binary, void* workspace, size_t workspace_bytes, int rx, int ry, int rz, void* stream)
+{
+    if (!binary || !workspace || workspace_bytes < dreg_grid_occupied_workspace_bytes(rx, ry, rz) || rx > 65535 || rx <= 0 || ry <= 0 || rz <= 0) return DREG_EINVAL;
+    const OccWs w = occ_ws(workspace, rx, ry, rz);
+    hipStream_t st = (hipStream_t)stream;
+    const int NS = (rx + 15) / 16;
+    if (NS > 256) return DREG_EINVAL;
+    int COLS = 1;
+    while (COLS * 2 * NS <= 256) COLS *= 2;
+    const int nprefix = (ry * rz + COLS - 1) / COLS;
+    hipLaunchKernelGGL(grid_occupied_count_kernel, dim3(nprefix + (rx * ry + 255) / 256), dim3(256), 0, st, binary, w.pre, w.colcnt, w.rowcnt, rx, ry, rz, NS, COLS, nprefix);
+    hipLaunchKernelGGL(grid_scan2_kernel, dim3(2), dim3(1024), 0, st, w.colcnt, ry * rz, w.rowcnt, rx * ry, w.totals);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// step 3: indices int64 [N], order int32 [N], world / world_slot fp32 [N,3]; jitter fp32 [N,3] indexed like indices; aabb = (lo xyz, hi xyz)
+int dreg_grid_occupied_build(const uint8_t* binary, void* workspace, const float* jitter, const float* aabb, int64_t* indices, int* order,
+                             float* world, float* world_slot, int rx, int ry, int rz, int N, void* stream)
+{
+    if (N == 0) return DREG_OK;
+    if (!binary || !workspace || !jitter || !indices || !order || !world || !world_slot) return DREG_EINVAL;
+    const OccWs w = occ_ws(workspace, rx, ry, rz);
+    hipLaunchKernelGGL(grid_occupied_build_kernel, dim3((rx * ry + 3) / 4), dim3(256), 0, (hipStream_t)stream, binary, w.pre, w.colcnt, w.rowcnt, jitter,
+                       indices, order, world, world_slot, rx, ry, rz, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5]);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// dreg_ngp_density_fwd_ws with the dense query's alpha / keep (dreg_ngp_alpha_keep's arithmetic) written by the same launch and the kept
+// cells counted per (x, y) row into the workspace of dreg_grid_occupied_count (idx = the points' flat cell indices)
+int dreg_ngp_density_keep_fwd_ws(const float* x, const void* table, const void* w1, const void* w2, float* density, void* raw,
+                                 const uint32_t* offset, const uint32_t* size, const uint32_t* res, const float* scale, const uint32_t* hashed,
+                                 const float* aabb, int Np, int contract, void* workspace, size_t workspace_bytes, const int* order, int x_in_slot_order,
+                                 float* alpha, uint8_t* keep, float delta, float threshold, void* stream)
+{
+    if (Np == 0) return DREG_OK;
+    if (!alpha || !keep) return DREG_EINVAL;
+    NgpLevels lv;
+    for (int l = 0; l < 16; ++l) { lv.offset[l] = offset[l]; lv.size[l] = size[l]; lv.res[l] = res[l]; lv.scale[l] = scale[l]; lv.hashed[l] = hashed[l]; }
+    NgpKeepEpi ke{alpha, keep, delta, threshold};
+    if (g_ngp_xcd_levels && workspace && workspace_bytes >= dreg_ngp_density_workspace_bytes(Np))
+        ngp_density_launch_xcd(x, table, w1, w2, density, raw, lv, aabb, Np, contract, workspace, stream, order, order ? x_in_slot_order : 0, ke);
+    else ngp_density_launch(x, table, w1, w2, density, raw, lv, aabb, Np, contract, stream, order, order ? x_in_slot_order : 0, ke);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// voxel_mask (ascending kept flat indices, int64, capacity Np) and voxel_grid[idx] = (xyz, rgb, alpha) of the kept points from the per-row
+// kept counts the density launch left in the workspace; afterwards dreg_grid_occupied_totals()[1] = number of kept cells.  grid must be zeroed.
+int dreg_grid_write_kept(void* occ_workspace, const float* xyz, const float* rgb, const float* alpha, const int64_t* indices, const uint8_t* keep,
+                         int64_t* mask, float* grid, int rx, int ry, int rz, int Np, void* stream)
+{
+    if (!occ_workspace || (Np > 0 && (!mask || !grid || !keep || !indices))) return DREG_EINVAL;
+    const OccWs w = occ_ws(occ_workspace, rx, ry, rz);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(grid_keeprow_kernel, dim3((rx * ry + 3) / 4), dim3(256), 0, st, w.rowcnt, keep, w.keeprow, rx * ry, Np);
+    hipLaunchKernelGGL(grid_scan2_kernel, dim3(1), dim3(1024), 0, st, w.keeprow, rx * ry, (int*)nullptr, 0, w.totals + 1);
+    if (Np > 0)
+        hipLaunchKernelGGL(grid_write_kept_kernel, dim3((rx * ry + 3) / 4), dim3(256), 0, st, w.rowcnt, w.keeprow, keep, indices, xyz, rgb, alpha, mask, grid, rx * ry, Np);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

@@ -215,6 +215,12 @@ SIGNATURES = {
     "dreg_grid_sample_points_ordered": (I, [P, P, P, P, P, I, I, I, P, I, P]),
     "dreg_grid_x_order_workspace_bytes": (Z, [I, I, I]),
     "dreg_grid_x_order": (I, [P, P, P, P, Z, I, I, I, I, P]),
+    "dreg_grid_occupied_workspace_bytes": (Z, [I, I, I]),
+    "dreg_grid_occupied_totals": (P, [P, I, I, I]),
+    "dreg_grid_occupied_count": (I, [P, P, Z, I, I, I, P]),
+    "dreg_grid_occupied_build": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "dreg_ngp_density_keep_fwd_ws": (I, [P] * 6 + [P] * 5 + [P, I, I, P, Z, P, I] + [P, P, F, F, P]),
+    "dreg_grid_write_kept": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "dreg_ngp_density_workspace_bytes": (Z, [I]),
     "dreg_ngp_set_xcd_levels": (None, [I]),
     "dreg_ngp_rgb_dir_fwd": (I, [P] * 6 + [I, P]),

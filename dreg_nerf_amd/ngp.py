@@ -283,6 +283,9 @@ class OccupancyGrid(nn.Module):
         return self._binary.reshape(-1)[flat] & inside
 
 
+FUSED_DENSE = True    # SampleGrid.query_dense on a GPU: cell lists / alpha / mask from the library's fused launches (False: torch.nonzero + separate launches)
+
+
 class SampleGrid(nn.Module):
     NUM_DIM = 3
 
@@ -323,23 +326,92 @@ class SampleGrid(nn.Module):
     def uniform_sample_occupied_voxels(self) -> torch.Tensor:
         return torch.nonzero(self._binary.flatten())[:, 0]
 
+    def _viewdirs_on(self, device) -> torch.Tensor:
+        """The 18 fixed viewing directions on `device` (copied once per device: a pageable host -> device copy per block is a host sync)."""
+        c = self.__dict__.setdefault("_viewdirs_dev", {})
+        key = str(torch.device(device))
+        if key not in c:
+            c[key] = self._viewdirs.to(device).float().contiguous()
+        return c[key]
+
     @torch.no_grad()
     def query_dense(self, radiance_field: NGPradianceField, device, density_thre: float = 0.7, jitter: Optional[torch.Tensor] = None):
         """Dense-query part of query_radiance_and_density_from_camera (sample_grid.py:223-242, 321-341).
-        jitter [Np,3] in [0,1): drawn with torch.rand on `device` when not given (reference: rand_like, quirk Q11)."""
+        jitter [Np,3] in [0,1): drawn with torch.rand on `device` when not given (reference: rand_like, quirk Q11).
+        On a GPU the cell lists come from the library (FUSED_DENSE: csrc/ngp.hip dreg_grid_occupied_*: no torch.nonzero, one host
+        readback), alpha / the density mask from the density launch; the returned mask then carries what build_voxel_grid needs to write
+        voxel_grid / voxel_mask without another compaction (`_dreg_rows`)."""
         lib = L.load()
         import ctypes
+        dev = torch.device(device)
+        if FUSED_DENSE and dev.type == "cuda" and self._binary.dim() == 3 and max(self._binary.shape) <= 65535:
+            return self._query_dense_fused(radiance_field, dev, density_thre, jitter)
         indices = self.uniform_sample_occupied_voxels().to(device)
         n = indices.shape[0]
         if jitter is None:
             jitter = torch.rand(n, 3, dtype=torch.float32, device=device)
         jitter = jitter.to(device).contiguous()
         world, density, raw = self.positions_and_density(radiance_field, indices, jitter, device, all_occupied=True)
-        rgb = radiance_field.query_rgb_mean(raw, self._viewdirs.to(device))
+        rgb = radiance_field.query_rgb_mean(raw, self._viewdirs_on(device))
         alpha = torch.empty(n, dtype=torch.float32, device=device)
         keep = torch.empty(n, dtype=torch.uint8, device=device)
         L.check(lib.dreg_ngp_alpha_keep(L.ptr(density), L.ptr(alpha), L.ptr(keep), n, float(self._delta), float(density_thre), L.stream()), "dreg_ngp_alpha_keep")
         return world, rgb, alpha[:, None], indices, keep.view(torch.bool)
+
+    @torch.no_grad()
+    def _query_dense_fused(self, radiance_field: NGPradianceField, dev, density_thre: float, jitter: Optional[torch.Tensor]):
+        world, indices, raw, alpha, keep, rows = self._cells_and_density_fused(radiance_field, dev, density_thre, jitter)
+        rgb = radiance_field.query_rgb_mean(raw, self._viewdirs_on(dev))
+        mask = keep.view(torch.bool)
+        mask._dreg_rows = rows + (indices, keep)      # for build_voxel_grid (same world / rgb / alpha / indices / mask only)
+        return world, rgb, alpha[:, None], indices, mask
+
+    @torch.no_grad()
+    def _cells_and_density_fused(self, radiance_field: NGPradianceField, dev, density_thre: float, jitter: Optional[torch.Tensor]):
+        """The first half of the fused dense query: occupied cells (ascending), their jittered positions, density / raw features / alpha /
+        density mask — five launches and the one host readback (the number of occupied cells)."""
+        lib = L.load()
+        import ctypes
+        binary = self._binary.to(dev)
+        b8 = binary.contiguous().view(torch.uint8) if binary.dtype == torch.bool else (binary != 0).to(torch.uint8).contiguous()
+        rx, ry, rz = (int(v) for v in b8.shape)
+        hc = self.__dict__.get("_host_consts")
+        key = (self.resolution.data_ptr(), self.resolution._version, self._roi_aabb.data_ptr(), self._roi_aabb._version)
+        if hc is None or hc[0] != key:
+            hc = self.__dict__["_host_consts"] = (key, [int(v) for v in self.resolution.tolist()], [float(v) for v in self._roi_aabb.tolist()])
+        aabb = (ctypes.c_float * 6)(*hc[2])
+        nb = int(lib.dreg_grid_occupied_workspace_bytes(rx, ry, rz))
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        L.check(lib.dreg_grid_occupied_count(L.ptr(b8), L.ptr(ws), nb, rx, ry, rz, L.stream()), "dreg_grid_occupied_count")
+        toff = int(lib.dreg_grid_occupied_totals(L.ptr(ws), rx, ry, rz)) - ws.data_ptr()
+        totals = ws[toff:toff + 8].view(torch.int32)
+        # the zeroed voxel grid build_voxel_grid will fill (cubes): issued here so that its fill runs while the host waits for N
+        grid = torch.zeros(rx * ry * rz, 7, dtype=torch.float32, device=dev) if rx == ry == rz else None
+        n = int(totals[0].item())                                   # the query's one host readback: the outputs' size
+        if jitter is None:
+            jitter = torch.rand(n, 3, dtype=torch.float32, device=dev)
+        jitter = jitter.to(dev).float().contiguous()
+        if jitter.shape[0] != n:
+            raise ValueError(f"jitter has {jitter.shape[0]} rows, the field {n} occupied cells")
+        indices = torch.empty(n, dtype=torch.int64, device=dev)
+        order = torch.empty(n, dtype=torch.int32, device=dev)
+        world = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        world_slot = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        L.check(lib.dreg_grid_occupied_build(L.ptr(b8), L.ptr(ws), L.ptr(jitter), aabb, L.ptr(indices), L.ptr(order), L.ptr(world), L.ptr(world_slot),
+                                             rx, ry, rz, n, L.stream()), "dreg_grid_occupied_build")
+        base16, _ = radiance_field._prepared()
+        density = torch.empty(n, dtype=torch.float32, device=dev)
+        raw = torch.empty(n, 16, dtype=torch.float16, device=dev)
+        alpha = torch.empty(n, dtype=torch.float32, device=dev)
+        keep = torch.empty(n, dtype=torch.uint8, device=dev)
+        faabb = (ctypes.c_float * 6)(*radiance_field._aabb_host())
+        nws = int(lib.dreg_ngp_density_workspace_bytes(n)) if n >= 16384 else 0
+        dws = torch.empty(nws, dtype=torch.uint8, device=dev) if nws else None
+        L.check(lib.dreg_ngp_density_keep_fwd_ws(L.ptr(world_slot), base16.data_ptr() + 3072 * 2, base16.data_ptr(), base16.data_ptr() + 2048 * 2,
+                                                 L.ptr(density), L.ptr(raw), *radiance_field._levels, faabb, n, int(bool(radiance_field.unbounded)),
+                                                 L.ptr(dws), nws, L.ptr(order), 1, L.ptr(alpha), L.ptr(keep), float(self._delta), float(density_thre),
+                                                 L.stream()), "dreg_ngp_density_keep_fwd_ws")
+        return world, indices, raw, alpha, keep, (ws, totals, (rx, ry, rz), grid)
 
     @torch.no_grad()
     def positions_and_density(self, radiance_field: NGPradianceField, indices: torch.Tensor, jitter: torch.Tensor, device,
@@ -402,6 +474,19 @@ def build_voxel_grid(world, rgb, alpha, indices, keep, resolution: int):
     (voxel_grid fp32 [res,res,res,7], voxel_mask int64 ascending)."""
     lib = L.load()
     dev = world.device
+    rows = getattr(keep, "_dreg_rows", None)
+    if rows is not None and rows[4] is indices and rows[2] == (resolution,) * 3 and world.is_contiguous() and rgb.is_contiguous():
+        # straight from SampleGrid.query_dense: kept points per (x, y) row, one scan, one launch that writes voxel_mask (ascending) and
+        # voxel_grid; one readback gives the mask's length.  (The zeroed grid was issued by the query, once: a second call allocates its own.)
+        ws, totals, (rx, ry, rz), grid, _, keep_u8 = rows
+        keep._dreg_rows = (ws, totals, (rx, ry, rz), None, indices, keep_u8)
+        if grid is None:
+            grid = torch.zeros(resolution ** 3, 7, dtype=torch.float32, device=dev)
+        n = world.shape[0]
+        mask = torch.empty(n, dtype=torch.int64, device=dev)
+        L.check(lib.dreg_grid_write_kept(L.ptr(ws), L.ptr(world), L.ptr(rgb), L.ptr(alpha.reshape(-1).contiguous()), L.ptr(indices), L.ptr(keep_u8),
+                                         L.ptr(mask), L.ptr(grid), rx, ry, rz, n, L.stream()), "dreg_grid_write_kept")
+        return grid.view(resolution, resolution, resolution, 7), mask[:int(totals[1].item())]
     grid = torch.zeros(resolution ** 3, 7, dtype=torch.float32, device=dev)
     keep_u8 = keep.to(torch.uint8).contiguous()
     L.check(lib.dreg_grid_scatter7(L.ptr(world.contiguous()), L.ptr(rgb.contiguous()), L.ptr(alpha.reshape(-1).contiguous()),

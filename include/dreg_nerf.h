@@ -476,6 +476,28 @@ int dreg_grid_sample_points_ordered(const int64_t* idx, const float* jitter, con
                                     int rx, int ry, int rz, const float* aabb, int Np, void* stream);
 size_t dreg_grid_x_order_workspace_bytes(int rx, int ry, int rz);
 int dreg_grid_x_order(const uint8_t* binary, const int64_t* idx, int* order, void* workspace, size_t workspace_bytes, int rx, int ry, int rz, int Np, void* stream);
+/* The dense query's cell lists without torch.nonzero (conerf/register/sample_grid.py:223-242: nonzero + jittered positions), plus the
+ * x-fastest lane order, in four launches and ONE host readback:
+ *   dreg_grid_occupied_count   x-prefix counts per (y, z) column, occupied cells per (x, y) row, both scanned; the int32 at
+ *                              dreg_grid_occupied_totals(workspace)[0] then holds N = number of occupied cells (the caller reads it);
+ *   dreg_grid_occupied_build   indices int64 [N] ascending, order int32 [N] (dreg_grid_x_order's), world / world_slot fp32 [N,3]
+ *                              (dreg_grid_sample_points_ordered's arithmetic; jitter fp32 [N,3] indexed like indices);
+ *   dreg_ngp_density_keep_fwd_ws = dreg_ngp_density_fwd_ws + alpha / keep (dreg_ngp_alpha_keep's arithmetic) from the same launch;
+ *   dreg_grid_write_kept       voxel_mask int64 (capacity N, ascending kept indices) and voxel_grid[idx] = (xyz, rgb, alpha) of the kept
+ *                              points (grid zeroed by the caller) in three launches (kept points per row, scan, write); totals[1] = number
+ *                              of kept cells.
+ * workspace: dreg_grid_occupied_workspace_bytes(rx, ry, rz) bytes, owned by the caller from _count to _write_kept. */
+size_t dreg_grid_occupied_workspace_bytes(int rx, int ry, int rz);
+void* dreg_grid_occupied_totals(void* workspace, int rx, int ry, int rz);
+int dreg_grid_occupied_count(const uint8_t* binary, void* workspace, size_t workspace_bytes, int rx, int ry, int rz, void* stream);
+int dreg_grid_occupied_build(const uint8_t* binary, void* workspace, const float* jitter, const float* aabb, int64_t* indices, int* order,
+                             float* world, float* world_slot, int rx, int ry, int rz, int N, void* stream);
+int dreg_ngp_density_keep_fwd_ws(const float* x, const void* table, const void* w1, const void* w2, float* density, void* raw,
+                                 const uint32_t* offset, const uint32_t* size, const uint32_t* res, const float* scale, const uint32_t* hashed,
+                                 const float* aabb, int Np, int contract, void* workspace, size_t workspace_bytes, const int* order, int x_in_slot_order,
+                                 float* alpha, uint8_t* keep, float delta, float threshold, void* stream);
+int dreg_grid_write_kept(void* occ_workspace, const float* xyz, const float* rgb, const float* alpha, const int64_t* indices, const uint8_t* keep,
+                         int64_t* mask, float* grid, int rx, int ry, int rz, int Np, void* stream);
 /* one viewing direction per point: NGPradianceField.query_rgb(dir, embedding) / forward (conerf/radiance_fields/ngp.py:178-208) */
 int dreg_ngp_rgb_dir_fwd(const void* raw, const void* w1, const void* w2, const void* w3, const float* dirs, float* rgb, int Np, void* stream);
 /* jittered sample of every occupied cell mapped to world space (sample_grid.py:226-242, AABB contraction) */

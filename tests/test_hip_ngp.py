@@ -181,6 +181,48 @@ def test_dense_query_at_the_baseline_size_128():
     assert int((flat.abs().sum(dim=1) > 0).sum()) <= int(dmask.sum())
 
 
+@pytest.mark.parametrize("shape,fill", [((128, 128, 128), "ball"), ((40, 24, 72), "random"), ((16, 16, 16), "all"), ((24, 24, 24), "none"),
+                                        ((33, 20, 50), "random")])
+def test_fused_dense_query_equals_the_nonzero_form_bit_for_bit(shape, fill):
+    """SampleGrid.query_dense through the library's cell-list launches (dreg_grid_occupied_count / _build, alpha / mask in the density
+    launch, dreg_grid_write_kept) against the form that uses torch.nonzero, separate position / alpha launches and a boolean-index
+    compaction: every output identical — cubes, boxes whose z extent is no multiple of 16 or 64, fewer cells than the x-ordered query's
+    threshold, all cells, no cell."""
+    rx, ry, rz = shape
+    g = torch.Generator().manual_seed(21)
+    if fill == "ball":
+        c = [(torch.arange(r, dtype=torch.float32) + 0.5) / r * 3 - 1.5 for r in shape]
+        X, Y, Z = torch.meshgrid(*c, indexing="ij")
+        binary = torch.stack([X, Y, Z], -1).norm(dim=-1) < 1.0
+    elif fill == "random":
+        binary = torch.rand(shape, generator=g) < 0.3
+    else:
+        binary = torch.full(shape, fill == "all", dtype=torch.bool)
+    n = int(binary.sum())
+    f = _field(4, table_scale=1.0).to(DEV)
+    jitter = torch.rand(n, 3, generator=g).to(DEV)
+    sg = ngp.SampleGrid(AABB, list(shape)).to(DEV)
+    sg.set_binary_fields(binary.to(DEV))
+    outs = {}
+    try:
+        for fused in (False, True):
+            ngp.FUSED_DENSE = fused
+            world, rgb, alpha, indices, dmask = sg.query_dense(f, DEV, jitter=jitter)
+            assert (getattr(dmask, "_dreg_rows", None) is not None) == fused
+            o = [world, rgb, alpha, indices, dmask]
+            if rx == ry == rz:
+                grid, mask = ngp.build_voxel_grid(world, rgb, alpha, indices, dmask, rx)
+                o += [grid, mask]
+            outs[fused] = [t.clone() for t in o]
+    finally:
+        ngp.FUSED_DENSE = True
+    assert outs[True][3].shape[0] == n
+    for a, b, name in zip(outs[True], outs[False], ("world", "rgb", "alpha", "indices", "mask", "voxel_grid", "voxel_mask")):
+        assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b), name
+    if n and rx == ry == rz:
+        assert 0 < outs[True][6].shape[0] <= n or fill == "all"
+
+
 @pytest.mark.parametrize("unbounded", [False, True])
 def test_density_query_forms_agree_bit_for_bit(unbounded):
     """The density query of a block's size has three forms (csrc/ngp.hip): the fused kernel, hash-grid levels pinned to the XCDs' L2s
