@@ -172,8 +172,8 @@ def main():
     if "train128_wc" in want:
         train_golden(nr, sd_wc, 128, "train128_wc", with_fp64=bool(int(os.environ.get("DREG_GOLDEN_FP64_128", "1"))), profile="wc")
     if "train128_wc_b" in want:
-        # ... and at the BASELINE size (same second sample; the fp64 pass is skipped by default here: 40 GB, 20 min)
-        train_golden(nr, params.synth_state_dict(seed=1, profile="wc"), 128, "train128_wc_b", with_fp64=bool(int(os.environ.get("DREG_GOLDEN_FP64_128B", "0"))),
+        # ... and at the BASELINE size (same second sample; with the fp64 oracle pass: ~40 GB, ~20 min)
+        train_golden(nr, params.synth_state_dict(seed=1, profile="wc"), 128, "train128_wc_b", with_fp64=bool(int(os.environ.get("DREG_GOLDEN_FP64_128B", "1"))),
                      profile="wc", sample=(7, 8, 1, 1, 9))
     if "bf16emu64_wc" in want:
         bf16_yardstick(64, "train64_wc", "wc")
