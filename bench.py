@@ -483,9 +483,7 @@ def main():
             ts.step(batch)
         sync()
         ops.PROFILER = ops.KernelTimer()
-        # --kernel-report wants every linear layer of the point-set half as a bracketed launch of its own (per-op path for the bracketed
-        # step); the default line keeps the native point-set executor in that step too (the roofline kernel belongs to the trunk)
-        ops.PROFILER.include_pointset = bool(args.kernel_report)
+        # (both native executors bracket their own convolution / linear launches with HIP events while the profiler is enabled)
         t0 = time.perf_counter()
         for i in range(args.steps):
             if i == args.event_steps:      # HIP-event brackets on the first steps of the timed region only (they cost host time)

@@ -575,6 +575,9 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
     for (int i = 0; i < NCLS; ++i)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { bs1[i][e] = 0.f; bs2[i][e] = 0.f; }
+    float bias8[8];                                  // a thread's 8 columns never change: its bias values are loaded once
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = bias ? bias[n0 + (t % CPR) * 8 + e] : 0.f;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();
@@ -591,13 +594,41 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
             }
         }
         __syncthreads();
+        // The addend (and the row list) are fetched for EPF rows at a time before any of them is used: one row per round trip made the
+        // accumulate-epilogues of the 1^3 data gradients a chain of 32 dependent global loads per tile (2.5 TB/s on an HBM-bound layer).
+        // (128-row tiles only: the 256 x 256 tile has no registers left — its BatchNorm sums went to scratch and the forward launches slowed down)
+        constexpr int EPF = (sizeof(TO) == 2 && ITER % 4 == 0 && BM == 128) ? 4 : 1;
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) {
+        for (int it0 = 0; it0 < ITER; it0 += EPF) {
+        uint32_t pm[EPF];
+        uint4 pq[EPF];
+#pragma unroll
+        for (int u = 0; u < EPF; ++u) {
+            const int lrow = (t + (it0 + u) * NTHR) / CPR;
+            const int row = pass * WMt + lrow;
+            pm[u] = (m0 + row < nrows) ? (rowlist ? (uint32_t)rowlist[m0 + row] : m0 + row) : 0xffffffffu;
+        }
+        if constexpr (EPF > 1) {
+            if (addend) {
+#pragma unroll
+                for (int u = 0; u < EPF; ++u) {
+                    pq[u] = make_uint4(0u, 0u, 0u, 0u);
+                    if (pm[u] != 0xffffffffu) {
+                        int b, z, y, x;
+                        vox_decode(pm[u], g, b, z, y, x);
+                        pq[u] = *reinterpret_cast<const uint4*>(addend + ((size_t)((b * Da + (z >> add_shift)) * Ha + (y >> add_shift)) * Wa + (x >> add_shift)) * g.Cout + n0 + (t % CPR) * 8);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < EPF; ++u) {
+            const int it = it0 + u;
             const int c = t + it * NTHR;
             const int lrow = c / CPR, cc = (c - lrow * CPR) * 8;
             const int row = pass * WMt + lrow;
-            if (m0 + row >= nrows) continue;
-            const uint32_t m = rowlist ? (uint32_t)rowlist[m0 + row] : m0 + row;
+            if (pm[u] == 0xffffffffu) continue;
+            const uint32_t m = pm[u];
             const int g0 = cc >> 2, sw = lrow & 15;
             const float4 lo = *reinterpret_cast<const float4*>(sC + lrow * BN + ((g0 ^ sw) << 2));
             const float4 hi = *reinterpret_cast<const float4*>(sC + lrow * BN + (((g0 + 1) ^ sw) << 2));
@@ -605,20 +636,32 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
             const int n = n0 + cc;
             if (bias) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += bias[n + e];
+                for (int e = 0; e < 8; ++e) v[e] += bias8[e];
             }
             if (addend) {
                 int b, z, y, x;
                 vox_decode(m, g, b, z, y, x);
                 const TO* ap = addend + ((size_t)((b * Da + (z >> add_shift)) * Ha + (y >> add_shift)) * Wa + (x >> add_shift)) * g.Cout + n;
+                // the row's 8 addend values in ONE 16-byte load (n and Cout are multiples of 8: 16-byte aligned on a 16-byte aligned tensor);
+                // eight 2-byte loads per thread and row made the accumulate-epilogue of the 1^3 data gradients latency-bound
+                float a8[8];
+                if constexpr (sizeof(TO) == 2) {
+                    const uint4 q = EPF > 1 ? pq[u] : *reinterpret_cast<const uint4*>(ap);
+                    const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a8[2 * e] = __uint_as_float(w4[e] << 16); a8[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u); }
+                } else {
+                    const float4 q0 = *reinterpret_cast<const float4*>(ap), q1 = *reinterpret_cast<const float4*>(ap + 4);
+                    a8[0] = q0.x; a8[1] = q0.y; a8[2] = q0.z; a8[3] = q0.w; a8[4] = q1.x; a8[5] = q1.y; a8[6] = q1.z; a8[7] = q1.w;
+                }
                 if (relu == 2) {
                     // ReLU-backward mask (the data gradient of a layer whose forward epilogue applied ReLU): the "addend" is that
                     // layer's stored activation, and the gradient passes where it is positive (transformer.py:291 linear1 -> relu)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = Elem<TO>::ld(ap + e) > 0.f ? v[e] : 0.f;
+                    for (int e = 0; e < 8; ++e) v[e] = a8[e] > 0.f ? v[e] : 0.f;
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += Elem<TO>::ld(ap + e);
+                    for (int e = 0; e < 8; ++e) v[e] += a8[e];
                 }
             }
             if (relu == 1) {
@@ -653,6 +696,7 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
                     }
                 }
             }
+        }
         }
         if constexpr (sizeof(TO) == 2) {
             // a 128-row chunk is complete after both passes of a 128-row tile, after EACH pass (128 rows) of a 256-row tile
@@ -1971,6 +2015,7 @@ static inline int glds_stages(long blocks) { (void)blocks; return g_glds_stages 
 
 static int g_igemm_probe = 0;         // measurement only (tools/igemm_phase_probe.py): the 128 x 128 kernel with s_memtime stamps
 static int g_narrow_thr = 224;        // tile count below which a launch takes the narrower tiles
+static int g_pointwise_rmw_cin = 128;  // tuning (include/dreg_nerf_tuning.h): see igemm_choose
 static int g_igemm_ap256 = 1;         // tuning (include/dreg_nerf_tuning.h): the 256 x 256 tile of large launches runs in its anti-phase form (32-channel stages)
 static int g_igemm_ap = 256;          // tuning (include/dreg_nerf_tuning.h): launches of at most this many 128-row tiles take the eight-wave anti-phase form (0: never)
 static int g_narrow_small = 2;        // tuning (include/dreg_nerf_tuning.h): 128 x 64 tiles for launches of < 224 128 x 128 tiles
@@ -1993,7 +2038,10 @@ static IgemmChoice igemm_choose(const ConvGeom& g, uint32_t nrows, bool rowlist,
         if (g_use_glds && g.sd == 1 && g.Cin % 64 == 0 && g.ntaps <= 32 && fits) {
             c.kind = 0;
             const uint32_t tm_ = (nrows + 127) / 128;
-            if (g.Cout % 256 == 0 && (g_use_glds == 1 || g_use_glds == 4 || g_use_glds == 5) && nrows >= 65536) { c.bm = 256; c.bn = 256; c.ap = g_igemm_ap256 ? 1 : 0; }
+            // (1^3 layers with few input channels and an addend — the accumulating data gradients of layer 1 / 2's first convolutions — are
+            //  HBM-bound read-modify-write passes: the 128-row tile, two workgroups per CU and the addend fetched four rows ahead)
+            const bool rmw_pointwise = g.ntaps == 1 && has_addend && g.Cin <= g_pointwise_rmw_cin;
+            if (g.Cout % 256 == 0 && (g_use_glds == 1 || g_use_glds == 4 || g_use_glds == 5) && nrows >= 65536 && !rmw_pointwise) { c.bm = 256; c.bn = 256; c.ap = g_igemm_ap256 ? 1 : 0; }
             else if (g.Cout % 256 == 0 && g_use_glds == 3 && nrows >= 65536) { c.bm = 128; c.bn = 256; }
             else if (g_igemm_ap && g.Cout % 128 == 0 && tm_ * (g.Cout / 128) <= (uint32_t)g_igemm_ap) { c.bn = 128; c.ap = 1; }
             else if (g_igemm_ap && g.Cout % 128 != 0 && g.Cout % 64 == 0 && tm_ * (g.Cout / 64) <= (uint32_t)g_igemm_ap) { c.bn = 64; c.ap = 1; }
@@ -2251,6 +2299,7 @@ int dreg_conv3d_igemm_variant(int B, int Di, int Hi, int Wi, int Cin, int Do, in
 void dreg_conv_igemm_probe(int enable) { g_igemm_probe = enable; }
 void dreg_conv_set_igemm_ap(int max_tiles) { g_igemm_ap = max_tiles > 0 ? max_tiles : 0; }
 void dreg_conv_set_igemm_ap256(int on) { g_igemm_ap256 = on ? 1 : 0; }
+void dreg_conv_set_pointwise_rmw_cin(int max_cin) { g_pointwise_rmw_cin = max_cin > 0 ? max_cin : 0; }
 int dreg_conv_igemm_probe_read(unsigned long long* out6)
 {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};

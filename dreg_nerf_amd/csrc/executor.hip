@@ -65,7 +65,7 @@ static_assert(sizeof(ReduceRec) == 48, "matches WgradReduceDesc of conv.hip");
 struct BnTailRec { const float* a; const float* b; float* o0; float* o1; int B, V, C, block0; };
 static_assert(sizeof(BnTailRec) == 48, "matches BnTailDesc of fpn_ops.hip");
 
-struct TimedLaunch { hipEvent_t e0, e1; int op, kind, variant; };   // variant: 0 = implicit-GEMM dispatch, 2 = conv_brick.hip (the halo kernel is dreg_exec_op_halo)
+struct TimedLaunch { hipEvent_t e0, e1; int op, kind, variant; };   // variant: 0 = implicit-GEMM dispatch, 1 = the same with an in-place addend (accumulating data gradient), 2 = conv_brick.hip (the halo kernel is dreg_exec_op_halo)
 
 struct Exec {
     std::vector<Tensor> t;
@@ -781,6 +781,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                     CK(dreg_conv3_halo(gy, PK + w.pk_halo_dgrad, gx, nullptr, fused_add ? gx : nullptr, y.B, y.D, y.H, y.W, w.d0,
                                        fused_add ? x.D : 0, fused_add ? x.H : 0, fused_add ? x.W : 0, 1, 0, stream));
                 } else if (fused_add) {
+                    sc.variant(1);        // dispatched WITH an addend (igemm_choose may pick another tile for it)
                     CK(dreg_conv3d_igemm_ws(gy, PK + w.pk_dgrad, gx, nullptr, gx, x.B, y.D, y.H, y.W, w.d0, x.D, x.H, x.W, w.d1,
                                             o.ksz, o.stride, o.pad, 1, 0, x.D, x.H, x.W, 1, 0, 0, A + e->off_ks, e->sz_ks, stream));
                 } else if (rows) {

@@ -70,6 +70,27 @@ struct Ps {
     char* pinned = nullptr;
     hipEvent_t ring_ev[RING] = {};
     unsigned ring_next = 0;
+    // optional HIP-event brackets around every linear-layer launch (forward / data gradient / weight gradient): dreg_ps_set_timing
+    struct Timed { hipEvent_t e0, e1; int kind, rows, cin, cout, flags; };     // kind 0 fwd, 1 dgrad, 2 wgrad; flags: 1 addend, 2 fp32 output, 4 split-K workspace offered
+    bool timing = false;
+    std::vector<Timed> timed;
+    size_t timed_used = 0;
+};
+
+struct PsScope {   // bracket of one launch (no-op unless timing is on)
+    Ps::Timed* t = nullptr; hipStream_t st;
+    PsScope(Ps* p, void* stream, int kind, int rows, int cin, int cout, int flags) : st((hipStream_t)stream) {
+        if (!p->timing) return;
+        if (p->timed_used == p->timed.size()) {
+            Ps::Timed n{};
+            if (hipEventCreate(&n.e0) != hipSuccess || hipEventCreate(&n.e1) != hipSuccess) return;
+            p->timed.push_back(n);
+        }
+        t = &p->timed[p->timed_used++];
+        t->kind = kind; t->rows = rows; t->cin = cin; t->cout = cout; t->flags = flags;
+        (void)hipEventRecord(t->e0, st);
+    }
+    ~PsScope() { if (t) (void)hipEventRecord(t->e1, st); }
 };
 
 inline int lin_index(int layer, int which) { return layer * LIN_PER_LAYER + which; }
@@ -138,6 +159,7 @@ void build_layout(Ps* p, int R)
 int linear_fwd(Ps* p, const Layout& y, char* A, const void* x, const void* wpk, const float* bias, const void* residual, void* out,
                int rows, int cin, int cout, int relu, int out_f32, void* st)
 {
+    PsScope sc(p, st, 0, rows, cin, cout, (residual ? 1 : 0) | (out_f32 ? 2 : 0) | (y.ks_bytes ? 4 : 0));
     return dreg_conv3d_igemm_ws(x, wpk, out, bias, residual, rows, 1, 1, 1, cin, 1, 1, 1, cout, 1, 1, 0, 0, relu, residual ? 1 : 0, residual ? 1 : 0,
                                 residual ? 1 : 0, residual ? 1 : 0, 0, out_f32, y.ks_bytes ? A + y.ks_ws : nullptr, y.ks_bytes, st);
 }
@@ -147,6 +169,7 @@ int linear_dgrad(Ps* p, const Layout& y, char* A, const void* g, const void* wpk
                  int rows, int cin, int cout, void* st)
 {
     const void* addend = mask ? mask : add;
+    PsScope sc(p, st, 1, rows, cin, cout, (addend ? 1 : 0) | (y.ks_bytes ? 4 : 0));
     return dreg_conv3d_igemm_ws(g, wpk_t, gx, nullptr, addend, rows, 1, 1, 1, cout, 1, 1, 1, cin, 1, 1, 0, 1, mask ? 2 : 0, addend ? 1 : 0, addend ? 1 : 0,
                                 addend ? 1 : 0, addend ? 1 : 0, 0, 0, y.ks_bytes ? A + y.ks_ws : nullptr, y.ks_bytes, st);
 }
@@ -186,6 +209,7 @@ void dreg_ps_destroy(void* h)
     for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
     if (p->ev_done) (void)hipEventDestroy(p->ev_done);
     for (auto& e : p->ring_ev) if (e) (void)hipEventDestroy(e);
+    for (auto& t : p->timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
     if (p->pinned) (void)hipHostFree(p->pinned);
     delete p;
 }
@@ -193,6 +217,24 @@ void dreg_ps_destroy(void* h)
 // 1 (default): ReLU mask and the decoder's gradient sum in the data-gradient epilogues, one LayerNorm backward for the final norm's two
 // applications, all bias column sums in one batched launch pair
 void dreg_ps_set_fuse(void* h, int fuse) { ((Ps*)h)->fuse = fuse ? 1 : 0; }
+// HIP events around every linear-layer launch of the following passes (bench.py's bracketed step); read them back AFTER a device
+// synchronisation: info[5 * i] = (kind 0 fwd / 1 dgrad / 2 wgrad, rows, cin, cout, flags: 1 addend, 2 fp32 output, 4 split-K workspace
+// offered), ms[i] = the launch's duration.  Returns the number of records (and clears them).
+void dreg_ps_set_timing(void* h, int enable) { ((Ps*)h)->timing = enable != 0; }     // (records stay until they are read)
+int dreg_ps_read_timings(void* h, int* info, float* ms, int cap)
+{
+    Ps* p = (Ps*)h;
+    int n = 0;
+    for (size_t i = 0; i < p->timed_used && n < cap; ++i) {
+        const Ps::Timed& t = p->timed[i];
+        float v = 0.f;
+        if (hipEventElapsedTime(&v, t.e0, t.e1) != hipSuccess) continue;
+        info[5 * n] = t.kind; info[5 * n + 1] = t.rows; info[5 * n + 2] = t.cin; info[5 * n + 3] = t.cout; info[5 * n + 4] = t.flags;
+        ms[n++] = v;
+    }
+    p->timed_used = 0;
+    return n;
+}
 size_t dreg_ps_arena_bytes(void* h, int R) { Ps* p = (Ps*)h; build_layout(p, R); return p->lay.total; }
 
 // packs: pointers [dreg_ps_num_linears()][2] = (forward pack [Cout][kpad(Cin)], data-gradient pack [Cin][kpad(Cout)]) of every linear
@@ -286,7 +328,10 @@ int dreg_ps_backward(void* h, void* arena, size_t arena_bytes, const int64_t* pa
     auto param_grads = [&](int li, const void* g, const void* x, int rows, size_t wg_off, size_t cs_off) -> int {
         const Lin& l = p->lin[li];
         if (two) { if (hipEventRecord(p->ev[li], st) != hipSuccess || hipStreamWaitEvent(ax, p->ev[li], 0) != hipSuccess) return DREG_ELAUNCH; }
-        CK(dreg_conv3d_wgrad_partials(g, x, A + wg_off, y.wg_bytes[li], nullptr, 0, rows, 1, 1, 1, l.cin, l.cin, 1, 1, 1, l.cout, 1, 1, 0, nullptr, ax));
+        {
+            PsScope sc(p, ax, 2, rows, l.cin, l.cout, 0);
+            CK(dreg_conv3d_wgrad_partials(g, x, A + wg_off, y.wg_bytes[li], nullptr, 0, rows, 1, 1, 1, l.cin, l.cin, 1, 1, 1, l.cout, 1, 1, 0, nullptr, ax));
+        }
         ReduceRec r{};
         r.part = (const float*)(A + wg_off); r.dw = p->grad[l.w];
         r.nsplit = dreg_conv3d_wgrad_splits(rows, 1, 1, 1, l.cin, l.cout, 1, 0);

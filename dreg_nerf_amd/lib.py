@@ -46,6 +46,7 @@ SIGNATURES = {
     "dreg_conv_igemm_probe": (None, [I]),
     "dreg_conv_set_igemm_ap": (None, [I]),
     "dreg_conv_set_igemm_ap256": (None, [I]),
+    "dreg_conv_set_pointwise_rmw_cin": (None, [I]),
     "dreg_exec_set_aux_streams": (None, [I]),
     "dreg_conv_igemm_probe_read": (I, [P]),
     "dreg_conv_set_wgrad_pipe": (None, [I]),
@@ -179,6 +180,8 @@ SIGNATURES = {
     "dreg_ps_create": (P, [P]),
     "dreg_ps_destroy": (None, [P]),
     "dreg_ps_set_fuse": (None, [P, I]),
+    "dreg_ps_set_timing": (None, [P, I]),
+    "dreg_ps_read_timings": (I, [P, P, P, I]),
     "dreg_ps_arena_bytes": (Z, [P, I]),
     "dreg_ps_forward": (I, [P, P, Z, P, P, P, P, P, P, I, I, I, P, P, P, P]),
     "dreg_ps_backward": (I, [P, P, Z, P, P, P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P, I]),

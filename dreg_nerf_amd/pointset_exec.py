@@ -70,6 +70,7 @@ class PointSetExecutor:
         self.device = self.params[0].device
         self.arena = None
         self.arena_bytes = 0
+        self._timing = False
         self._packs = (ctypes.c_int64 * (2 * len(self.linears)))()
         self._pack_stamp = None
         self._pack_keep = None
@@ -111,10 +112,41 @@ class PointSetExecutor:
             self.arena = torch.empty(self.arena_bytes, dtype=torch.uint8, device=self.device)
         return self.arena
 
+    def set_timing(self, on: bool):
+        """HIP-event brackets around every linear-layer launch (bench.py's bracketed step).  While they are on, the weight-gradient
+        launches stay on the caller's stream, so a bracket measures its kernel alone (as the trunk executor does)."""
+        self._timing = bool(on)
+        self.lib.dreg_ps_set_timing(self.h, int(on))
+
+    def drain_timings(self, profiler: "ops.KernelTimer"):
+        """After a device synchronisation: the executor's records as (instantiation name, shape label, FLOPs, ms) — names from the
+        library's own dispatch rules (dreg_conv3d_igemm_variant / dreg_conv3d_wgrad_variant), i.e. the rows rocprofv3 prints."""
+        cap = 4096
+        info = (ctypes.c_int * (5 * cap))()
+        ms = (ctypes.c_float * cap)()
+        n = self.lib.dreg_ps_read_timings(self.h, info, ms, cap)
+        for i in range(n):
+            kind, rows, cin, cout, flags = (info[5 * i + k] for k in range(5))
+            fl = 2.0 * rows * cin * cout
+            if kind == 2:
+                var = self.lib.dreg_conv3d_wgrad_variant(rows, 1, 1, 1, cin, cout, 1, 0, 0, 0)
+                name = "conv_wgrad_glds_kernel<256,256,false,8>" if var == 256256 else f"conv_wgrad_glds_kernel<{var // 1000},{var % 1000},false,4>"
+                label = f"wgrad B{rows} 1x1x1x{cin} g1x1x1x{cout} k1s1"
+            elif kind == 1:     # data gradient: the transposed problem (cout -> cin)
+                name = ops.igemm_kernel_name(self.lib, rows, 1, 1, 1, cout, 1, 1, 1, cin, 1, 1, 0, 1, 0, bool(flags & 4), bool(flags & 1), L.DT_BF16, False)
+                label = f"dgrad B{rows} 1x1x1x{cout}->1x1x1x{cin} k1s1"
+            else:
+                name = ops.igemm_kernel_name(self.lib, rows, 1, 1, 1, cin, 1, 1, 1, cout, 1, 1, 0, 0, 0, bool(flags & 4), bool(flags & 1), L.DT_BF16, bool(flags & 2))
+                label = f"fwd B{rows} 1x1x1x{cin}->1x1x1x{cout} k1s1"
+            profiler.add_measured(name, label, fl, ms[i])
+
     def forward(self, feats, xyz, pe, tab):
         if self._fuse != FUSE:
             self.lib.dreg_ps_set_fuse(self.h, int(FUSE))
             self._fuse = FUSE
+        want = ops.PROFILER is not None and ops.PROFILER.enabled
+        if want != self._timing:
+            self.set_timing(want)
         ops.wait_packs()
         R = feats.shape[0]
         arena = self._arena_for(R)
@@ -130,7 +162,7 @@ class PointSetExecutor:
     def backward(self, feats, xyz, pe, tab, cond, corr, ov, g_cond, g_corr, g_ov, last_only=False):
         R = feats.shape[0]
         d_feats = torch.empty_like(feats)
-        aux = ops.PARAM_GRAD_STREAM
+        aux = None if self._timing else ops.PARAM_GRAD_STREAM
         if aux is not None:
             self.arena.record_stream(aux)
         L.check(self.lib.dreg_ps_backward(self.h, L.ptr(self.arena), self.arena_bytes, self._pack_table(), L.ptr(feats), L.ptr(xyz), L.ptr(pe),
@@ -173,12 +205,9 @@ class _PointSetFn(torch.autograd.Function):
 
 def executor_for(model, P) -> Optional[PointSetExecutor]:
     """The model's native point-set executor for the current grad mode, or None when it does not apply (fp32 parity mode, learned
-    position embedding — its gradient flows through the per-op LayerNorm nodes —, training without preallocated gradient buffers, or
-    bench.py's bracketed profiling step when the per-kernel report asks for one timed launch per linear layer)."""
+    position embedding — its gradient flows through the per-op LayerNorm nodes —, or training without preallocated gradient buffers)."""
     if model.precision != "bf16" or model.pos_emb_type != "sine" or not getattr(model, "native_pointset", True):
         return None
-    if ops.PROFILER is not None and ops.PROFILER.enabled and getattr(ops.PROFILER, "include_pointset", False):
-        return None      # bench.py --kernel-report: one bracketed launch per linear layer through the per-op path
     names = param_names()
     train = torch.is_grad_enabled() and any(P[n].requires_grad for n in names)
     if train and not all(P[n].requires_grad for n in names):

@@ -255,8 +255,8 @@ class NeRFRegTr(nn.Module):
 
     def drain_trunk_timings(self, profiler):
         """Move the native executor's HIP-event records (one per convolution launch) into `profiler` and stop timing."""
-        for ex in self.__dict__.get("_trunk_cache", {}).values():
-            torch.cuda.synchronize()
+        for ex in list(self.__dict__.get("_trunk_cache", {}).values()) + list(self.__dict__.get("_ps_cache", {}).values()):
+            torch.cuda.synchronize()      # (trunk executors and the point-set executor: csrc/executor.hip, csrc/pointset_exec.hip)
             ex.drain_timings(profiler)
             ex.set_timing(False)
 

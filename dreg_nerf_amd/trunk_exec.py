@@ -172,13 +172,14 @@ class TrunkExecutor:
             def fwd_name(nr, B=B, x=x, y=y, cout=cout, k=k, s=s, pd=pd):
                 return ops.igemm_kernel_name(lib, B, x[1], x[2], x[3], x[4], y[1], y[2], y[3], cout, k, s, pd, 0, nr, 0 if nr else 1, False, L.DT_BF16, False)
 
-            def dgrad_name(nr, B=B, x=x, y=y, cout=cout, k=k, s=s, pd=pd):
+            def dgrad_name(nr, B=B, x=x, y=y, cout=cout, k=k, s=s, pd=pd, add=False):
                 if s == 2:   # the parity-class form (dreg_conv3d_dgrad_s2): a 2^3-tap (or 1-tap) stride-1 convolution over dOut with 8 x Cin (or Cin) output channels
                     dc = tuple((d + 1) // 2 for d in x[1:4])
                     return ops.igemm_kernel_name(lib, B, y[1], y[2], y[3], cout, dc[0], dc[1], dc[2], (1 if k == 1 else 8) * x[4], 1 if k == 1 else 2, 1, 0, 0, 0, 0, False,
                                                  L.DT_BF16, False)
-                return ops.igemm_kernel_name(lib, B, y[1], y[2], y[3], cout, x[1], x[2], x[3], x[4], k, 1, pd, 1, nr, 0 if nr else 1, False, L.DT_BF16, False)
+                return ops.igemm_kernel_name(lib, B, y[1], y[2], y[3], cout, x[1], x[2], x[3], x[4], k, 1, pd, 1, nr, 0 if nr else 1, add, L.DT_BF16, False)
             fname, dname = (fwd_name, dgrad_name) if is_rows else (fwd_name(0), dgrad_name(0))
+            dname_add = None if is_rows else dgrad_name(0, add=True)      # the accumulating form (the executor reports which one ran)
             halo = self.lib.dreg_exec_op_halo(self.h, i)
             if halo & 1:
                 fname = "conv3_halo_kernel<bf16>"
@@ -189,8 +190,8 @@ class TrunkExecutor:
             # active-set launches: flops per row, scaled by the step's row count (list id) when the records are drained
             per_row = 2.0 * cout * k ** 3 * cin
             lo, li = (o[14], o[15]) if rows else (-1, -1)
-            out[(i, 0)] = (fname, f"fwd{rows} B{B} {x[1]}x{x[2]}x{x[3]}x{x[4]}->{y[1]}x{y[2]}x{y[3]}x{cout} k{k}s{s}", fl, lo, per_row, f"conv3_brick_kernel<{cout},bf16>")
-            out[(i, 1)] = (dname, f"dgrad{rows} B{B} {y[1]}x{y[2]}x{y[3]}x{cout}->{x[1]}x{x[2]}x{x[3]}x{cin} k{k}s{s}", fl, li, per_row, f"conv3_brick_kernel<{cin},bf16>")
+            out[(i, 0)] = (fname, f"fwd{rows} B{B} {x[1]}x{x[2]}x{x[3]}x{x[4]}->{y[1]}x{y[2]}x{y[3]}x{cout} k{k}s{s}", fl, lo, per_row, f"conv3_brick_kernel<{cout},bf16>", None)
+            out[(i, 1)] = (dname, f"dgrad{rows} B{B} {y[1]}x{y[2]}x{y[3]}x{cout}->{x[1]}x{x[2]}x{x[3]}x{cin} k{k}s{s}", fl, li, per_row, f"conv3_brick_kernel<{cin},bf16>", dname_add)
             def wgrad_name(nr, B=B, x=x, y=y, cout=cout, k=k, is_rows=is_rows, first=int(o[1] == 0)):
                 var = lib.dreg_conv3d_wgrad_variant(B, y[1], y[2], y[3], x[4], cout, k, int(is_rows), nr, first)
                 if var == 256256:
@@ -199,10 +200,10 @@ class TrunkExecutor:
                     return "conv_wgrad_glds_kernel<256,128,false,4>"
                 return f"conv_wgrad_glds_kernel<{var // 1000},{var % 1000},{'true' if is_rows else 'false'},4>"     # the template arguments rocprofv3 prints
             wname = wgrad_name if is_rows else wgrad_name(0)
-            out[(i, 2)] = (wname, f"wgrad{rows} B{B} {x[1]}x{x[2]}x{x[3]}x{x[4]} g{y[1]}x{y[2]}x{y[3]}x{cout} k{k}s{s}", fl, lo, per_row, None)
-        out[(-1, 3)] = ("wgrad_reduce_batched_kernel", "split sums of a backward range -> torch-layout gradients", 0.0, -1, 0.0, None)
-        out[(-1, 4)] = ("bn_tail_batched_kernel<0>", "running statistics of the small BatchNorms of a forward pass", 0.0, -1, 0.0, None)
-        out[(-1, 5)] = ("bn_tail_batched_kernel<1>", "dgamma / dbeta of the small BatchNorms of a backward range", 0.0, -1, 0.0, None)
+            out[(i, 2)] = (wname, f"wgrad{rows} B{B} {x[1]}x{x[2]}x{x[3]}x{x[4]} g{y[1]}x{y[2]}x{y[3]}x{cout} k{k}s{s}", fl, lo, per_row, None, None)
+        out[(-1, 3)] = ("wgrad_reduce_batched_kernel", "split sums of a backward range -> torch-layout gradients", 0.0, -1, 0.0, None, None)
+        out[(-1, 4)] = ("bn_tail_batched_kernel<0>", "running statistics of the small BatchNorms of a forward pass", 0.0, -1, 0.0, None, None)
+        out[(-1, 5)] = ("bn_tail_batched_kernel<1>", "dgamma / dbeta of the small BatchNorms of a backward range", 0.0, -1, 0.0, None, None)
         return out
 
     # ------------------------------------------------------------------ per-step calls
@@ -328,7 +329,7 @@ class TrunkExecutor:
         ms = (ctypes.c_float * cap)()
         n = self.lib.dreg_exec_read_timings(self.h, ok, ms, cap)
         for i in range(n):
-            name, label, fl, lid, per_row, brick_name = self.labels[(ok[3 * i], ok[3 * i + 1])]
+            name, label, fl, lid, per_row, brick_name, add_name = self.labels[(ok[3 * i], ok[3 * i + 1])]
             if lid >= 0:   # active-set launch: algorithmic flops and the tile shape follow the (last) step's row count
                 nr = self.last_row_counts[lid]
                 fl, label = per_row * nr, f"{label} rows{nr}"
@@ -336,6 +337,8 @@ class TrunkExecutor:
                     name = name(nr)
             if ok[3 * i + 2] == 2 and brick_name:      # the launch ran on csrc/conv_brick.hip (the executor says so)
                 name = brick_name
+            elif ok[3 * i + 2] == 1 and add_name:      # an accumulating data gradient: dispatched with an addend
+                name = add_name
             profiler.add_measured(name, label, fl, ms[i])
 
 

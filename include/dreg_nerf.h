@@ -583,6 +583,8 @@ int dreg_ps_num_linears(void);
 void* dreg_ps_create(const int64_t* params);
 void dreg_ps_destroy(void* h);
 void dreg_ps_set_fuse(void* h, int fuse);
+void dreg_ps_set_timing(void* h, int enable);            /* HIP events around every linear-layer launch (forward, data gradient, weight gradient) */
+int dreg_ps_read_timings(void* h, int* info, float* ms, int cap);   /* after a device sync: 5 ints per record (kind, rows, cin, cout, flags) + ms; returns the count */
 size_t dreg_ps_arena_bytes(void* h, int R);
 int dreg_ps_forward(void* h, void* arena, size_t arena_bytes, const int64_t* packs, const float* feats, const float* xyz, const float* pe,
                     const int* probs_self, const int* probs_cross, int nprob, int max_len, int R,

@@ -24,6 +24,7 @@ void dreg_conv_set_wgrad_ring(int mode);             /* dense 8-wave weight-grad
 int dreg_conv_wgrad_probe_read(unsigned long long* out8); /* ring mode 4 (measurement only): { issue, fragment reads, wait for loads, barrier, MFMAs, barrier cycles; units x waves; waves } since the last read */
 void dreg_conv_set_wgrad_pipe(int enable);           /* 1: the dense 8-wave weight-gradient tile reads the fragments of the next MFMA group while the current group runs (default 0: measured no gain) */
 void dreg_conv_set_igemm_ap(int max_tiles);          /* bf16 implicit-GEMM launches of at most this many 128-row tiles run the eight-wave anti-phase form of the tile (default 256 = one workgroup per CU; 0: never); bit-identical results */
+void dreg_conv_set_pointwise_rmw_cin(int max_cin);  /* 1^3 convolutions with an addend and <= max_cin input channels (default 128) take the 128-row tile on large launches too (read-modify-write passes: HBM-bound, the addend prefetched four rows ahead); 0: the 256 x 256 tile */
 void dreg_conv_set_igemm_ap256(int on);              /* 1 (default): the 256 x 256 implicit-GEMM tile of large launches runs as two anti-phase wave groups over a ring of four 32-channel stages; 0: lockstep over two 64-channel stages; bit-identical results */
 void dreg_conv_igemm_probe(int enable);               /* MEASUREMENT ONLY: bf16 launches with Cout % 128 == 0 run the 128 x 128 implicit-GEMM kernel with s_memtime stamps around the phases of a K step */
 int dreg_conv_igemm_probe_read(unsigned long long* out6); /* { wait-for-loads, barrier, issue, compute cycles; K steps x waves; waves }, summed over the waves since the last read */
