@@ -56,7 +56,8 @@ template <typename T, typename TO, int BN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const T* __restrict__ in, const T* __restrict__ wt, TO* __restrict__ out,
     const float* __restrict__ bias, const TO* __restrict__ addend, ConvGeom g,
-    int relu, int Da, int Ha, int Wa, int add_shift, int tilesN, const uint8_t* __restrict__ rowocc = nullptr)
+    int relu, int Da, int Ha, int Wa, int add_shift, int tilesN, const uint8_t* __restrict__ rowocc = nullptr,
+    const int* __restrict__ rowlist = nullptr, uint32_t nrows = 0)     // rowlist (optional): only output voxels rowlist[0 .. nrows) are computed
 {
     constexpr int BM = 128;
     constexpr int G = 16 / sizeof(T);
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         uint32_t m = m0 + rbase + 32 * i;
-        mv[i] = m < g.M;
+        mv[i] = m < (rowlist ? nrows : g.M);
+        if (rowlist) m = mv[i] ? (uint32_t)rowlist[m] : 0u;
         int b, z, y, x;
         vox_decode(mv[i] ? m : 0, g, b, z, y, x);
         zb[i] = z * g.sn + g.off; yb[i] = y * g.sn + g.off; xb[i] = x * g.sn + g.off;
@@ -208,8 +210,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint32_t m = m0 + wm * 64 + i * 16 + rowq + r;
-            if (m >= g.M) continue;
+            uint32_t m = m0 + wm * 64 + i * 16 + rowq + r;
+            if (m >= (rowlist ? nrows : g.M)) continue;
+            if (rowlist) m = (uint32_t)rowlist[m];
             size_t arow = 0;
             if (addend) {
                 int b, z, y, x;
@@ -2051,7 +2054,7 @@ static IgemmChoice igemm_choose(const ConvGeom& g, uint32_t nrows, bool rowlist,
             return c;
         }
     }
-    if (rowlist || (g.Cout % 128 != 0 && g.Cout % 64 != 0)) c.kind = -1;
+    if (g.Cout % 128 != 0 && g.Cout % 64 != 0) c.kind = -1;      // (row lists outside the direct-to-LDS shapes: the register-staged kernel takes them too)
     return c;
 }
 
@@ -2151,17 +2154,18 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
             return DREG_OK;
         }
     }
-    if (rowlist) return DREG_EINVAL;  // row lists are served by the direct-to-LDS kernel only
+    // (row lists: the direct-to-LDS kernels above; shapes they do not take — the stem: 5^3 taps, stride 2, 8 input channels — run the
+    //  register-staged kernel on the list)
     if (g.Cout % 128 == 0) {
         const int tilesN = g.Cout / 128;
         const size_t lds = 2 * (128 + 128) * 128;
         hipLaunchKernelGGL((conv_igemm_kernel<T, TO, 128>), dim3(tilesM * tilesN), dim3(256), lds, st,
-                           (const T*)in, (const T*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN, rowocc);
+                           (const T*)in, (const T*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN, rowocc, rowlist, nrows);
     } else if (g.Cout % 64 == 0) {
         const int tilesN = g.Cout / 64;
         const size_t lds = 2 * (128 + 64) * 128;
         hipLaunchKernelGGL((conv_igemm_kernel<T, TO, 64>), dim3(tilesM * tilesN), dim3(256), lds, st,
-                           (const T*)in, (const T*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN, rowocc);
+                           (const T*)in, (const T*)wt, (TO*)out, bias, (const TO*)addend, g, relu, Da, Ha, Wa, add_shift, tilesN, rowocc, rowlist, nrows);
     } else return DREG_EINVAL;
     DREG_LAUNCH_CHECK();
     return DREG_OK;

@@ -100,6 +100,7 @@ struct Exec {
     char* pack_base = nullptr;            // device address of the pack buffer (dreg_exec_export_pack_table)
     std::vector<char> written;            // backward pass state, kept across the segments of dreg_exec_backward_range
     bool aux_used = false;
+    const void* fwd_rows_arena = nullptr;  // the arena whose row-list convolution outputs (rows_out >= 0) are known to be zero outside their last lists
 };
 
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -238,7 +239,7 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
                     ReduceRec r{};
                     r.dw = w.grad; r.nsplit = dreg_conv3d_wgrad_splits(x.B, y.D, y.H, y.W, x.C, w.d0, o.ksz, 0);
                     r.Cout = w.d0; r.Kpad = dreg_conv3d_kpad(o.ksz, x.C, 0); r.ntaps = o.ksz * o.ksz * o.ksz; r.Cin = x.C; r.Cin_real = w.d1;
-                    r.accumulate = o.kind == OP_CONV_ROWS ? 3 : 1;     // row-list launches write fewer slices than the dense rule sizes (bit 1: count behind the slices)
+                    r.accumulate = (o.kind == OP_CONV_ROWS || o.rows_out >= 0) ? 3 : 1;     // row-list launches write fewer slices than the dense rule sizes (bit 1: count behind the slices)
                     r.block0 = e->reduce_blocks;
                     e->reduce_blocks += dreg_wgrad_reduce_blocks(w.d0, w.d1, o.ksz, r.nsplit);
                     o.rd = (int)e->reduce.size();
@@ -287,6 +288,13 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
         if (writers != 1 || !g_sparse_grads) continue;
         const Tensor& x = e->t[o.in];
         o.sparse_gx = 1; o.cl_off = off; off += align256((size_t)x.B * x.D * x.H * x.W * sizeof(int));
+    }
+    // a dense-layout convolution computed on an output row list (the stem over a sparse volume: rows_out >= 0): its output is kept zero
+    // outside the list the same way — the rows of the step before are cleared, a copy of the list lives in the arena
+    for (Op& o : e->ops) {
+        if (o.kind != OP_CONV || o.rows_out < 0) continue;
+        const Tensor& y = e->t[o.out];
+        o.cl_off = off; off += align256((size_t)y.B * y.D * y.H * y.W * sizeof(int));
     }
     e->off_bn_ws = off; off += align256(bn_ws);
     e->off_coef = off; off += align256(coef);
@@ -494,6 +502,7 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
     CK(upload_tables(e, (char*)arena, st));
     std::vector<char> bn_done(e->bn_fwd.size(), 0);
     std::vector<int> sums_rpc(e->ops.size(), 0);    // per BatchNorm op: rows per chunk of the sums its producer left (0 = none)
+    struct ArenaMark { Exec* e; const void* a; ~ArenaMark() { e->fwd_rows_arena = a; } } arena_mark{e, arena};   // (after this pass the row-list outputs of `arena` are in the known state)
     auto act = [&](int s) -> void* { return s == 0 ? (void*)x_in : (void*)(A + e->t[s].off); };
     for (size_t i = 0; i < e->ops.size(); ++i) {
         const Op& o = e->ops[i];
@@ -504,6 +513,24 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
             const float* bias = o.b >= 0 ? e->prm[o.b].val : nullptr;
             const void* add = o.in2 >= 0 ? act(o.in2) : nullptr;
             const Tensor* ta = o.in2 >= 0 ? &e->t[o.in2] : nullptr;
+            if (o.rows_out >= 0) {
+                // only the listed output voxels can be non-zero (bias-free layer over a sparse volume): compute those, keep the rest zero
+                if (o.rows_out >= nlists || bias || add) return DREG_EINVAL;
+                const int64_t* rl = rowlists + RL * o.rows_out;
+                const int* r = (const int*)rl[0];
+                const int n = (int)rl[1];
+                Op& om = const_cast<Op&>(o);
+                if (e->fwd_rows_arena != arena) CK(dreg_fill_zero(act(o.out), y.bytes, stream));
+                else if (om.cl_count > 0) CK(dreg_zero_rows(act(o.out), (const int*)(A + o.cl_off), om.cl_count, y.C, 0, stream));
+                if (n > 0 && hipMemcpyAsync(A + o.cl_off, r, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess) return DREG_ELAUNCH;
+                om.cl_count = n;
+                if (n > 0) {
+                    Scope sc(e, st, (int)i, 0);
+                    CK(dreg_conv3d_igemm_rows(act(o.in), PK + w.pk_fwd, act(o.out), nullptr, nullptr, r, n, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0,
+                                              o.ksz, o.stride, o.pad, 0, o.relu, 0, 0, 0, 0, 0, stream));
+                }
+                continue;
+            }
             Scope sc(e, st, (int)i, 0);
             if (o.halo & 1) {
                 CK(dreg_conv3_halo(act(o.in), PK + w.pk_halo_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0,
@@ -667,8 +694,9 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
         const Param& w = e->prm[o.w];
         const void* gy = grad(o.out);
         const bool rows = o.kind == OP_CONV_ROWS;
-        const int* r_out = rows ? (const int*)rowlists[RL * o.rows_out] : nullptr;
-        const int n_out = rows ? (int)rowlists[RL * o.rows_out + 1] : 0;
+        const bool lrows = rows || (o.kind == OP_CONV && o.rows_out >= 0 && o.rows_out < nlists);    // reduced over an output row list
+        const int* r_out = lrows ? (const int*)rowlists[RL * o.rows_out] : nullptr;
+        const int n_out = lrows ? (int)rowlists[RL * o.rows_out + 1] : 0;
         hipStream_t ws = st;
         if (aux_on) {
             if (!e->ev[i] && hipEventCreateWithFlags(&e->ev[i], hipEventDisableTiming) != hipSuccess) return DREG_ELAUNCH;
@@ -690,15 +718,15 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
         if (w.grad) {
             Scope sc(e, ws, i, 2);
             if (o.rd >= 0) {
-                CK(dreg_conv3d_wgrad_partials(gy, act(o.in), A + o.wg_off, o.wg_bytes, rows ? r_out : nullptr, n_out, x.B, x.D, x.H, x.W, x.C, w.d1,
-                                              y.D, y.H, y.W, w.d0, o.ksz, rows ? 1 : o.stride, o.pad, (!rows && o.in == 0) ? e->in_rowocc : nullptr, (void*)ws));
+                CK(dreg_conv3d_wgrad_partials(gy, act(o.in), A + o.wg_off, o.wg_bytes, lrows ? r_out : nullptr, n_out, x.B, x.D, x.H, x.W, x.C, w.d1,
+                                              y.D, y.H, y.W, w.d0, o.ksz, rows ? 1 : o.stride, o.pad, (!lrows && o.in == 0) ? e->in_rowocc : nullptr, (void*)ws));
                 rd_done[o.rd] = 1;
                 rd_stream = n_ws > 1 ? e->aux : ws;
                 rd_pending += o.wg_bytes;
                 flush_now = rd_pending >= ((size_t)192 << 20);
-            } else if (rows) {
+            } else if (lrows) {
                 CK(dreg_conv3d_wgrad_rows(gy, act(o.in), w.grad, A + o.wg_off, o.wg_bytes, r_out, n_out, x.B, x.D, x.H, x.W, x.C, w.d1,
-                                          y.D, y.H, y.W, w.d0, o.ksz, 1, o.pad, 1, (void*)ws));
+                                          y.D, y.H, y.W, w.d0, o.ksz, rows ? 1 : o.stride, o.pad, 1, (void*)ws));
             } else {
                 CK(dreg_conv3d_wgrad_occ(gy, act(o.in), w.grad, A + o.wg_off, o.wg_bytes, x.B, x.D, x.H, x.W, x.C, w.d1, y.D, y.H, y.W, w.d0,
                                          o.ksz, o.stride, o.pad, 1, 0, 1, o.in == 0 ? e->in_rowocc : nullptr, (void*)ws));

@@ -2092,6 +2092,52 @@ int dreg_active_sets(const int64_t* idx, const int* pt_batch, int N, int B, int 
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
+// Output voxels of a strided convolution over a sparse volume whose receptive field holds an occupied input voxel (everywhere else the
+// result of a bias-free convolution is exactly zero): the stem of the feature network (5^3 taps, stride 2, pad 2: 128^3 -> 64^3) computes
+// ~5 % of its rows.  idx / pt_batch as in dreg_active_sets (flat fine indices (x * Yr + y) * Zr + z); rows: ascending int32 flat indices
+// into [B, d, h, w] (capacity V), count: device int32.  workspace: dreg_conv_rows_workspace_bytes.
+size_t dreg_conv_rows_workspace_bytes(int B, int d, int h, int w)
+{
+    const size_t V = (size_t)B * d * h * w;
+    const size_t nblk = (V + ASET_PER_BLOCK - 1) / ASET_PER_BLOCK;
+    return (V + 255) / 256 * 256 + nblk * sizeof(int) + 256;
+}
+}  // extern "C"
+__global__ void conv_rows_mark_kernel(const int64_t* __restrict__ idx, const int* __restrict__ pt_batch, uint8_t* __restrict__ f,
+                                      int N, int d, int h, int w, int Zr, int Xr, int Yr, int ksz, int stride, int pad)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int64_t fl = idx[n];
+    const int z = (int)(fl % Zr), y = (int)((fl / Zr) % Yr), x = (int)(fl / ((int64_t)Zr * Yr));
+    const int b = pt_batch[n];
+    // outputs o with o * stride - pad <= i <= o * stride - pad + ksz - 1
+    auto lo = [&](int i) { const int t = i + pad - ksz + 1; return t <= 0 ? 0 : (t + stride - 1) / stride; };
+    auto hi = [&](int i, int ext) { const int t = (i + pad) / stride; return t < ext ? t : ext - 1; };
+    const int z0 = lo(z), z1 = hi(z, d), x0 = lo(x), x1 = hi(x, h), y0 = lo(y), y1 = hi(y, w);
+    for (int zo = z0; zo <= z1; ++zo)
+        for (int xo = x0; xo <= x1; ++xo)
+            for (int yo = y0; yo <= y1; ++yo) f[(((size_t)b * d + zo) * h + xo) * w + yo] = 1;
+}
+extern "C" {
+int dreg_conv_rows(const int64_t* idx, const int* pt_batch, int N, int B, int Zr, int Xr, int Yr, int d, int h, int w, int ksz, int stride, int pad,
+                   int* rows, int* count, void* workspace, size_t workspace_bytes, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const size_t V = (size_t)B * d * h * w;
+    if (V == 0 || V > 0x7fffffffull || N < 0 || ksz < 1 || stride < 1 || pad < 0) return DREG_EINVAL;
+    if (workspace_bytes < dreg_conv_rows_workspace_bytes(B, d, h, w)) return DREG_EINVAL;
+    const int nblk = (int)((V + ASET_PER_BLOCK - 1) / ASET_PER_BLOCK);
+    uint8_t* flags = (uint8_t*)workspace;
+    int* blk = (int*)((char*)workspace + (V + 255) / 256 * 256);
+    if (hipMemsetAsync(flags, 0, V, st) != hipSuccess) return DREG_ELAUNCH;
+    if (N > 0) hipLaunchKernelGGL(conv_rows_mark_kernel, dim3((N + 255) / 256), dim3(256), 0, st, idx, pt_batch, flags, N, d, h, w, Zr, Xr, Yr, ksz, stride, pad);
+    hipLaunchKernelGGL(aset_count_kernel, dim3(nblk, 1), dim3(256), 0, st, flags, blk, V, nblk);
+    hipLaunchKernelGGL(aset_scan_kernel, dim3(1), dim3(1024), 0, st, blk, count, nblk);
+    hipLaunchKernelGGL(aset_write_kernel, dim3(nblk, 1), dim3(256), 0, st, flags, blk, rows, (int*)nullptr, V, nblk);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
 // Second pyramid level of the active sets: child_flags = the S2 flags of dreg_active_sets (bytes [V, 2V) of ITS workspace, on
 // [B,d,h,w]); A = parents of S2 on [B,d2,h2,w2] (where the next-coarser FPN map P2 is consumed by the nearest-x2 upsample-add),
 // A2 = A dilated by 3^3 (where its lateral sum is consumed).  rows2 int32 [2][V2], counts2 device int32 [2].

@@ -115,6 +115,8 @@ SIGNATURES = {
     "dreg_active_sets": (I, [P, P] + [I] * 8 + [P, P, P, P, Z, P]),
     "dreg_active_sets_level2_workspace_bytes": (Z, [I] * 4),
     "dreg_active_sets_level2": (I, [P] + [I] * 7 + [P, P, P, Z, P]),
+    "dreg_conv_rows_workspace_bytes": (Z, [I, I, I, I]),
+    "dreg_conv_rows": (I, [P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, P, Z, P]),
     "dreg_trilinear_gather_bwd_rows": (I, [P, P, P, P, I, P, P, P] + [I] * 10 + [P]),
     "dreg_colsum_rows": (I, [P, P, I, P, P, I, I, I, P]),
     "dreg_trilinear_gather_bwd_gather": (I, [P, P, P, P, I, P, P] + [I] * 10 + [P]),

@@ -546,8 +546,63 @@ class Conv3dFn(torch.autograd.Function):
         return gx, gw, gb, ga, None, None, None, None, None
 
 
-def conv3d(x, w, bias=None, addend=None, stride=1, pad=0):
+def conv3d(x, w, bias=None, addend=None, stride=1, pad=0, out_rows=None):
+    """out_rows (optional, int32 ascending flat output-voxel indices: dreg_conv_rows): the output rows of a bias-free convolution over a
+    sparse volume whose receptive field holds an occupied voxel — only those are computed (the others are exactly zero) and only those
+    enter the weight gradient (the network's stem, conerf/model/resnet3d.py conv1)."""
+    if out_rows is not None and bias is None and addend is None and L.dt_of(x) == L.DT_BF16 and not x.requires_grad:
+        return StridedRowsConv3dFn.apply(x, w, stride, pad, out_rows)
     return Conv3dFn.apply(x, w, bias, addend, stride, pad)
+
+
+class StridedRowsConv3dFn(torch.autograd.Function):
+    """y = conv3d(x, w, stride, pad) for a bias-free layer whose input is zero outside a known voxel set: computed on `rows` (the output
+    voxels that can be non-zero), zero elsewhere — the dense result bit for bit; the weight gradient is reduced over `rows` only (the
+    other rows multiply all-zero patches).  No input gradient (the layer reads the network input)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride: int, pad: int, rows):
+        lib = L.load()
+        B, Di, Hi, Wi, cin = x.shape
+        cout, ksz = w.shape[0], w.shape[2]
+        Do, Ho, Wo = ((d + 2 * pad - ksz) // stride + 1 for d in (Di, Hi, Wi))
+        wpk = packed_weight(w, cin, False, L.DT_BF16)
+        y = torch.zeros(B, Do, Ho, Wo, cout, dtype=x.dtype, device=x.device)
+        ev = None
+        if PROFILER is not None:
+            ev = PROFILER.record(igemm_kernel_name(lib, B, Di, Hi, Wi, cin, Do, Ho, Wo, cout, ksz, stride, pad, False, rows.shape[0], 0, False, L.DT_BF16, False),
+                                 f"fwd-rows B{B} {Di}x{Hi}x{Wi}x{cin}->{Do}x{Ho}x{Wo}x{cout} k{ksz}s{stride} rows{rows.shape[0]}",
+                                 2.0 * rows.shape[0] * cout * (ksz ** 3) * w.shape[1])
+            if ev is not None:
+                ev[0].record()
+        L.check(lib.dreg_conv3d_igemm_rows(L.ptr(x), L.ptr(wpk), L.ptr(y), None, None, L.ptr(rows), rows.shape[0], B, Di, Hi, Wi, cin, Do, Ho, Wo, cout,
+                                           ksz, stride, pad, 0, 0, 0, 0, 0, 0, 0, L.stream()), "dreg_conv3d_igemm_rows")
+        if ev is not None:
+            ev[1].record()
+        ctx.save_for_backward(x, w, rows)
+        ctx.cfg = (stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, rows = ctx.saved_tensors
+        stride, pad = ctx.cfg
+        lib = L.load()
+        gy = gy.contiguous()
+        gw = None
+        if ctx.needs_input_grad[1]:
+            B, Di, Hi, Wi, cin = x.shape
+            Do, Ho, Wo, cout = gy.shape[1:]
+            ksz = w.shape[2]
+            nbytes = lib.dreg_conv3d_wgrad_workspace_bytes(B, Do, Ho, Wo, cin, cout, ksz, 0)
+            ws = _ws(nbytes, x.device)
+            sink = _grad_sink(w)
+            gw_t = sink if sink is not None else torch.empty(tuple(w.shape), dtype=torch.float32, device=x.device)
+            L.check(lib.dreg_conv3d_wgrad_rows(L.ptr(gy), L.ptr(x), L.ptr(gw_t), L.ptr(ws), nbytes, L.ptr(rows), rows.shape[0],
+                                               B, Di, Hi, Wi, cin, w.shape[1], Do, Ho, Wo, cout, ksz, stride, pad, int(sink is not None),
+                                               L.stream()), "dreg_conv3d_wgrad_rows")
+            gw = None if sink is not None else gw_t
+        return None, gw, None, None, None
 
 
 def igemm_kernel_name(lib, B, Di, Hi, Wi, cin, Do, Ho, Wo, cout, ksz, stride, pad, transposed, nrows, has_ws, has_addend, dt, out_f32):
@@ -656,12 +711,14 @@ def conv3d_rows(x, w, bias, addend, pad, out_rows, in_rows):
 
 class RowSets(tuple):
     """The tuple active_sets returns, plus `tiles`: {row-list position -> brick.BrickTiles} when tile tables were requested (the
-    active-set 3^3 convolutions then run on csrc/conv_brick.hip: staged-neighbourhood reuse instead of a 27-tap gather per row)."""
+    active-set 3^3 convolutions then run on csrc/conv_brick.hip: staged-neighbourhood reuse instead of a 27-tap gather per row), and
+    `stem`: the output rows of the stem convolution whose receptive field holds an occupied voxel (dreg_conv_rows), or None."""
     tiles = None
+    stem = None
 
 
 def active_sets(idx_list, fine_res, coarse_dims, device, pt_batch=None, idx_cat=None, density_cap: float = 0.3,
-                level2: bool = True, level2_cap: float = 0.5, brick_tiles=False):
+                level2: bool = True, level2_cap: float = 0.5, brick_tiles=False, stem=None):
     """Row lists for the FPN head: S1 = trilinear-gather corner voxels of the occupied fine voxels (where P1 is consumed),
     S2 = S1 dilated by 3^3 (where the lateral sum is consumed), S3 = S2 dilated (where dc1 of the head is non-zero).
     idx_list: per grid int64 flat fine indices ((x*Yr + y)*Zr + z).  Returns three ascending int32 tensors of flat indices
@@ -678,7 +735,14 @@ def active_sets(idx_list, fine_res, coarse_dims, device, pt_batch=None, idx_cat=
     if pt_batch is None:
         pt_batch = torch.cat([torch.full((f.shape[0],), b, dtype=torch.int32, device=device) for b, f in enumerate(idx_list)])
     rows = torch.empty(3, V, dtype=torch.int32, device=device)
-    counts = torch.empty(3, dtype=torch.int32, device=device)
+    counts = torch.zeros(4, dtype=torch.int32, device=device)         # S1, S2, S3, stem rows
+    srows = None
+    if stem is not None:     # (ksz, stride, pad) of the convolution that reads the fine volume and writes [B, d, h, w]: its non-zero output rows
+        nbs = lib.dreg_conv_rows_workspace_bytes(B, d, h, w)
+        wss = torch.empty(nbs, dtype=torch.uint8, device=device)
+        srows = torch.empty(V, dtype=torch.int32, device=device)
+        L.check(lib.dreg_conv_rows(L.ptr(idx_cat), L.ptr(pt_batch), idx_cat.shape[0], B, Zr, Xr, Yr, d, h, w, int(stem[0]), int(stem[1]), int(stem[2]),
+                                   L.ptr(srows), counts.data_ptr() + 12, L.ptr(wss), nbs, L.stream()), "dreg_conv_rows")
     nbytes = lib.dreg_active_sets_workspace_bytes(B, d, h, w)
     ws = _ws(nbytes, device)
     map1 = torch.empty(V, dtype=torch.int32, device=device)
@@ -694,9 +758,9 @@ def active_sets(idx_list, fine_res, coarse_dims, device, pt_batch=None, idx_cat=
         ws2 = _ws(nb2, device)
         L.check(lib.dreg_active_sets_level2(ws.data_ptr() + V, B, d, h, w, d2, h2, w2, L.ptr(rows2), L.ptr(counts2), L.ptr(ws2), nb2, L.stream()),
                 "dreg_active_sets_level2")
-        n1, n2, n3, m1, m2 = torch.cat([counts, counts2]).tolist()
+        n1, n2, n3, ns, m1, m2 = torch.cat([counts, counts2]).tolist()
     else:
-        (n1, n2, n3), m1, m2 = counts.tolist(), 0, V2
+        (n1, n2, n3, ns), m1, m2 = counts.tolist(), 0, V2
     if n3 > density_cap * V:   # dense scenes: the row lists stop paying (and the wgrad slice cap applies)
         return None
     out = (rows[0, :n1], rows[1, :n2], rows[2, :n3], map1)
@@ -704,6 +768,8 @@ def active_sets(idx_list, fine_res, coarse_dims, device, pt_batch=None, idx_cat=
     if use2:
         out = out + (rows2[0, :m1], rows2[1, :m2])
     out = RowSets(out)
+    if srows is not None:
+        out.stem = srows[:ns]
     if brick_tiles and lib.dreg_brick_supported(B, d, h, w, 16, 256):
         # tile tables of every row set from its flag volume (still in the builders' workspaces), one more host read for the tile counts
         from . import brick

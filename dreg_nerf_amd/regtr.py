@@ -115,6 +115,11 @@ class NeRFRegTr(nn.Module):
         self.brick_sets = (2,)
         # Issue the point-set half (encoder, decoder, heads) of forward_batch from the C++ executor (csrc/pointset_exec.hip)
         self.native_pointset = True
+        # The stem (5^3 / stride 2 over the 8 x 128^3 input) only on the output voxels whose receptive field holds an occupied voxel (~5 %
+        # of them for the benchmark's shells; everything else is exactly zero).  Contract: a grid is zero outside its voxel_mask — what
+        # eval_ngp_nerf.py:397-405 writes and dataset.py:277-331 keeps (augmentations touch mask voxels only).  False: the dense stem
+        # with per-row occupancy flags taken from the VALUES.
+        self.stem_rows = True
         self._spec = params.regtr_spec(self.pos_emb_type)
         _build_tree(self, self._spec)
         _reset_parameters(self, self._spec)
@@ -170,7 +175,10 @@ class NeRFRegTr(nn.Module):
             return O.batchnorm(t, P[name + ".weight"], P[name + ".bias"], P[name + ".running_mean"],
                                P[name + ".running_var"], res=res, relu=relu, train=train)
 
-        c1 = bn(O.conv3d(x, P[r + "conv1.weight"], stride=2, pad=2), r + "bn1")
+        # the stem on the output rows whose receptive field holds an occupied voxel (ops.RowSets.stem: a tensor for the eager ops, a row-list
+        # id for the recorder), dense otherwise
+        stem = getattr(rows, "stem", None) if rows is not None else None
+        c1 = bn(O.conv3d(x, P[r + "conv1.weight"], stride=2, pad=2, **({"out_rows": stem} if stem is not None else {})), r + "bn1")
         h = O.maxpool3d(c1)
         feats = [c1]
         for li, nblk in enumerate(params.RESNET50_BLOCKS):
@@ -221,14 +229,15 @@ class NeRFRegTr(nn.Module):
         if with_grad and any(p.requires_grad and (p.grad is None or not p.grad.is_contiguous()) for p in self.fpn3d.parameters()):
             return None
         sparse_level = 0 if rows is None else (2 if len(rows) >= 6 else 1)
-        key = (tuple(x.shape), sparse_level, with_grad)
+        stem = rows is not None and getattr(rows, "stem", None) is not None
+        key = (tuple(x.shape), sparse_level, with_grad, stem)
         cache = self.__dict__.setdefault("_trunk_cache", {})
         ex = cache.get(key)
         if ex is not None and not ex.still_valid():
             ex = None
         if ex is None:
             cache.clear()   # one live program: its arena holds every activation of the network
-            ex = trunk_exec.TrunkExecutor(self, tuple(x.shape), sparse_level, with_grad)
+            ex = trunk_exec.TrunkExecutor(self, tuple(x.shape), sparse_level, with_grad, stem_rows=stem)
             cache[key] = ex
         return ex
 
@@ -350,7 +359,8 @@ class NeRFRegTr(nn.Module):
         rows = None
         if self.active_set and self.precision == "bf16":
             rows = ops.active_sets(idxs, res, tuple((r + 1) // 2 for r in res), dev, pt_batch=pb_cat, idx_cat=idx_cat,
-                                   brick_tiles=self.brick_sets if (self.brick_head and self.native_trunk) else False)
+                                   brick_tiles=self.brick_sets if (self.brick_head and self.native_trunk) else False,
+                                   stem=(5, 2, 2) if self.stem_rows else None)
         # the gather backward is evaluated per consumed coarse voxel (S1) in every mode: atomic-free, deterministic
         s1_rows = rows[0] if rows is not None else \
             ops.active_sets(idxs, res, tuple((r + 1) // 2 for r in res), dev, pt_batch=pb_cat, idx_cat=idx_cat, density_cap=1.0, level2=False)[0]
@@ -398,6 +408,8 @@ class NeRFRegTr(nn.Module):
             if rows is not None and getattr(rows, "tiles", None):
                 for bt in rows.tiles.values():
                     bt.record_stream(main)
+            if rows is not None and getattr(rows, "stem", None) is not None:
+                keep.append(rows.stem)
             for rounds in plans:
                 for rnd in rounds:
                     keep += [rnd.order, rnd.starts, rnd.n_out_dev, rnd.inv_seg, rnd.inv_cnt]
@@ -410,6 +422,7 @@ class NeRFRegTr(nn.Module):
             x_in, row_occ = self.pack_sparse(grids[0], idx_cat, pb_cat, grids[1], res, self.act_dtype, occupancy=True)
         else:
             x_in, row_occ = self.pack_grids(grids, self.act_dtype, table, occupancy=True)
+        self._check_stem_contract(rows, row_occ)
         p1 = self.fpn(x_in, rows, row_occ if self.skip_empty_stem_rows else None)
         feats = ops.trilinear_gather(p1, idx_cat, pb_cat, res, s1_rows, rows[3] if rows is not None else None)
         P = self._P()
@@ -447,6 +460,30 @@ class NeRFRegTr(nn.Module):
                 "pose": pose,
             })
         return outs
+
+    def _check_stem_contract(self, rows, row_occ):
+        """stem_rows rests on "a grid is zero outside its voxel_mask".  The packers' row flags come from the VALUES: an output row of the
+        stem that the values mark occupied but no listed voxel lies in means the contract is broken (the stem would silently drop
+        input).  Checked on the first calls and every 64th, one step late (no host sync on fresh work); raises ValueError."""
+        prev = self.__dict__.pop("_stem_violation", None)
+        if prev is not None and bool(prev):
+            raise ValueError("stem_rows: an input grid holds non-zero values outside its voxel_mask (set model.stem_rows = False for such data)")
+        stem = getattr(rows, "stem", None) if rows is not None else None
+        if stem is None or row_occ is None:
+            return
+        n = self.__dict__["_stem_calls"] = self.__dict__.get("_stem_calls", 0) + 1
+        if n > 4 and n % 64:
+            return
+        with torch.no_grad():
+            # (flat rows are (b, z, x, y): a W-row is the index without its last coordinate)
+            Wo = int(self._stem_out_w(row_occ, rows))
+            flags = torch.zeros(row_occ.numel(), dtype=torch.bool, device=row_occ.device)
+            flags[torch.div(stem, Wo, rounding_mode="floor").long()] = True
+            self.__dict__["_stem_violation"] = (row_occ.reshape(-1) != 0).logical_and_(~flags).any()
+
+    @staticmethod
+    def _stem_out_w(row_occ, rows):
+        return rows[3].numel() // row_occ.numel()       # map1 has one entry per output voxel [B, d, h, w]; row_occ one per (b, z, x)
 
     def forward(self, data: dict) -> dict:
         """Reference contract (nerf_regtr.py:112-248): one pair in, the 9-key dict out."""

@@ -49,13 +49,14 @@ class _Recorder:
             self.params.append(t)
         return self.pindex[k]
 
-    def conv3d(self, x, w, bias=None, addend=None, stride=1, pad=0):
+    def conv3d(self, x, w, bias=None, addend=None, stride=1, pad=0, out_rows: int = -1):
         B, D, H, W, _ = x.shape
         k = w.shape[2]
         od = tuple((d + 2 * pad - k) // stride + 1 for d in (D, H, W))
         y = self._new((B,) + od + (w.shape[0],))
+        # out_rows (row-list id): a dense-layout convolution whose output is zero outside that list (the stem over a sparse volume)
         self.ops.append([OP_CONV, x.slot, y.slot, addend.slot if addend is not None else -1, self._p(w), self._p(bias), -1, -1, -1,
-                         k, stride, pad, 0, 0, -1, -1])
+                         k, stride, pad, 0, 0, out_rows if (bias is None and addend is None) else -1, -1])
         return y
 
     def conv3d_rows(self, x, w, bias, addend, pad, out_rows: int, in_rows: int):
@@ -80,14 +81,17 @@ class _Recorder:
 class TrunkExecutor:
     """One recorded program + its arena and packed-weight buffer."""
 
-    def __init__(self, model, x_shape, sparse_head: int, with_grad: bool = True):
+    def __init__(self, model, x_shape, sparse_head: int, with_grad: bool = True, stem_rows: bool = False):
         self.lib = L.load()
         P = model._P()
         rec = _Recorder(P, x_shape)
         x0 = _Recorder.T(0, x_shape)
         self.nbt = []
         # row-list ids: 0..2 = S1, S2, S3 (head), 4, 5 = A, A2 (second pyramid level) — positions in ops.active_sets' tuple
-        rl = None if not sparse_head else ((0, 1, 2, None) if sparse_head == 1 else (0, 1, 2, None, 4, 5))
+        rl = None if not sparse_head else ops.RowSets((0, 1, 2, None) if sparse_head == 1 else (0, 1, 2, None, 4, 5))
+        if rl is not None and stem_rows:
+            rl.stem = len(rl)          # the stem's row list travels behind the head's (see _rowlist_array)
+        self.stem_slot = rl.stem if (rl is not None and stem_rows) else -1
         out = model._fpn_program(rec, x0, rl, self.nbt, True)
         self.out_shape = out.shape
         self.rec = rec
@@ -167,7 +171,7 @@ class TrunkExecutor:
             # names of the LAUNCHED instantiations (dreg_conv3d_igemm_variant: the library's own dispatch rules).  Active-set launches:
             # the tile shape depends on the step's row count, so their names are functions of it, evaluated when the records are drained
             pd = o[11] if len(o) > 11 else k // 2
-            is_rows = o[0] == OP_CONV_ROWS
+            is_rows = o[0] == OP_CONV_ROWS or o[14] >= 0       # (a dense-layout convolution on an output row list: the stem)
 
             def fwd_name(nr, B=B, x=x, y=y, cout=cout, k=k, s=s, pd=pd):
                 return ops.igemm_kernel_name(lib, B, x[1], x[2], x[3], x[4], y[1], y[2], y[3], cout, k, s, pd, 0, nr, 0 if nr else 1, False, L.DT_BF16, False)
@@ -226,7 +230,10 @@ class TrunkExecutor:
         if rows is None:
             return None, 0
         n = len(rows)
-        a = (ctypes.c_int64 * (RL_FIELDS * n))()
+        stem = getattr(rows, "stem", None)
+        a = (ctypes.c_int64 * (RL_FIELDS * (n + (1 if stem is not None else 0))))()
+        if stem is not None:            # list id n: the stem's output rows
+            a[RL_FIELDS * n], a[RL_FIELDS * n + 1] = stem.data_ptr(), stem.shape[0]
         tiles = getattr(rows, "tiles", None) or {}
         for i in range(n):
             if i == 3 or rows[i] is None:   # slot 3 is map1 (not a row list)
@@ -237,7 +244,7 @@ class TrunkExecutor:
             if bt is not None and bt.ntiles > 0:   # tile tables of csrc/conv_brick.hip for this row set
                 a[RL_FIELDS * i + 2], a[RL_FIELDS * i + 3] = bt.tiles.data_ptr(), bt.ntiles
                 a[RL_FIELDS * i + 4], a[RL_FIELDS * i + 5], a[RL_FIELDS * i + 6] = bt.halo.data_ptr(), bt.nbr.data_ptr(), bt.rows_sorted.data_ptr()
-        return a, n
+        return a, n + (1 if stem is not None else 0)
 
     def forward(self, x: torch.Tensor, rows, train: bool) -> torch.Tensor:
         ops.wait_packs()
@@ -246,6 +253,8 @@ class TrunkExecutor:
         if want != self._timing:
             self.set_timing(want)
         self.last_row_counts = [int(r.shape[0]) if (r is not None and i != 3) else 0 for i, r in enumerate(rows)] if rows is not None else []
+        if rows is not None and getattr(rows, "stem", None) is not None:
+            self.last_row_counts.append(int(rows.stem.shape[0]))
         ra, n = self._rowlist_array(rows)
         L.check(self.lib.dreg_exec_forward(self.h, L.ptr(self.arena), self.arena_bytes, L.ptr(self.pack), L.ptr(x),
                                            ctypes.addressof(ra) if ra is not None else None, n, int(train), L.stream()), "dreg_exec_forward")

@@ -256,6 +256,13 @@ int dreg_active_sets(const int64_t* idx, const int* pt_batch, int N, int B, int 
 size_t dreg_active_sets_level2_workspace_bytes(int B, int d2, int h2, int w2);
 int dreg_active_sets_level2(const uint8_t* child_flags, int B, int d, int h, int w, int d2, int h2, int w2, int* rows2,
                             int* counts2, void* workspace, size_t workspace_bytes, void* stream);
+/* Output voxels of a strided convolution over a sparse volume whose receptive field holds an occupied input voxel (a bias-free
+ * convolution is exactly zero everywhere else): the stem (conerf/model/resnet3d.py conv1: 5^3 taps, stride 2, pad 2) then runs on ~5 %
+ * of its rows (dreg_conv3d_igemm_rows / dreg_conv3d_wgrad_partials take the list).  idx / pt_batch as in dreg_active_sets; rows: ascending
+ * int32 flat indices into [B, d, h, w] (capacity B*d*h*w); count: device int32. */
+size_t dreg_conv_rows_workspace_bytes(int B, int d, int h, int w);
+int dreg_conv_rows(const int64_t* idx, const int* pt_batch, int N, int B, int Zr, int Xr, int Yr, int d, int h, int w, int ksz, int stride, int pad,
+                   int* rows, int* count, void* workspace, size_t workspace_bytes, void* stream);
 /* active-set forms of the gather backward (dp1 zero-filled here, gradient on the S1 rows only; comp: fp32 [n1,C] scratch) and
  * of the bias-gradient column sum (rows of g outside the list are known to be zero). */
 int dreg_trilinear_gather_bwd_rows(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
