@@ -48,6 +48,9 @@ struct Op {
     size_t cl_off = 0;           //   arena copy of the row list that was written (cleared at the start of the next backward)
     int cl_count = 0;
     int pool = -1;               // OP_BN: index of the max-pool op fused behind it; OP_MAXPOOL: index of the BatchNorm it is fused into
+    int sstem = 0;               // OP_BN fused with its max-pool behind a row-list convolution over a sparse volume (fpn_ops.hip "stem over a sparse volume")
+    int sstem_conv = -1, sstem_lat = -1;   //   that convolution; the active-set convolution that also reads the activation (-1: none)
+    size_t xam_off = 0, pmask_off = 0;     //   raw x of the arg-max voxels [B,Do,Ho,Wo,C] bf16; pooled-window flags
     int halo = 0;                // OP_CONV: bit 0 = forward, bit 1 = data gradient run on the halo kernel
     int stats_bn = -1;           // OP_CONV whose bf16 output feeds a large-path BatchNorm: that op's index (its chunk sums come from this convolution's epilogue)
     size_t stats_off = 0;        // OP_BN with such a producer: its own chunk-sum buffer [B][V / 128][C][2] (the shared workspace may be used in between)
@@ -127,6 +130,7 @@ struct Scope {   // optional HIP-event bracket of one launch group
 
 int g_sparse_grads = 1;   // tuning (include/dreg_nerf_tuning.h): row-cleared instead of memset gradient buffers in front of the active-set convolutions
 int g_bn_batch_tails = 1; // tuning (include/dreg_nerf_tuning.h): the small BatchNorms' running-statistics / parameter-gradient launches batched per pass
+int g_sparse_stem = 1;    // tuning (include/dreg_nerf_tuning.h): BatchNorm + ReLU + max-pool behind a row-list stem run from the row lists (statistics over the listed rows, activation on the lateral's rows only)
 int g_fuse_stem = 1;      // tuning (include/dreg_nerf_tuning.h): BatchNorm + ReLU + max-pool of the stem in one pass
 int g_brick = 1;          // tuning (include/dreg_nerf_tuning.h): bit 0: active-set 3^3 launches with 64 output channels on csrc/conv_brick.hip when the caller hands over tile tables, bit 1: those with 256 as well
 int g_defer_head_pg = 0;  // tuning (include/dreg_nerf_tuning.h): the head's weight / bias gradient launches are held back until the backward pass reaches the 8^3 / 4^3 levels
@@ -191,6 +195,21 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
             if (q.in == o.out || q.in2 == o.out) { ++users; if (q.kind == OP_MAXPOOL && q.in == o.out && j > i) pool = (int)j; }
         }
         if (users == 1 && pool >= 0 && e->t[o.out].C % 8 == 0 && g_fuse_stem) { o.pool = pool; e->ops[pool].pool = (int)i; }
+        // ... or, behind a convolution computed on a row list (its output is zero elsewhere), with at most one more reader that is an
+        // active-set convolution (the FPN's finest lateral): everything runs from the two row lists
+        if (o.pool < 0 && pool >= 0 && o.relu && e->t[o.out].C % 8 == 0 && g_sparse_stem && g_fuse_stem) {
+            int prod = -1, writers = 0, lat = -1, others = 0;
+            for (size_t j = 0; j < e->ops.size(); ++j) {
+                const Op& q = e->ops[j];
+                if (q.out == o.in) { prod = (int)j; ++writers; }
+                if ((int)j == pool) continue;
+                if (q.in2 == o.out) ++others;
+                else if (q.in == o.out) { if (q.kind == OP_CONV_ROWS && q.rows_in >= 0 && lat < 0) lat = (int)j; else ++others; }
+            }
+            if (writers == 1 && others == 0 && e->ops[prod].kind == OP_CONV && e->ops[prod].rows_out >= 0 && o.b >= 0) {
+                o.pool = pool; e->ops[pool].pool = (int)i; o.sstem = 1; o.sstem_conv = prod; o.sstem_lat = lat;
+            }
+        }
     }
 
     // arena: activations | BN statistics / argmax | gradients | scratch
@@ -203,7 +222,14 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
             const size_t sb = align256((size_t)x.B * x.C * 2 * sizeof(float));
             o.aux0 = off; off += sb; o.aux1 = off; off += sb;
             const size_t V = (size_t)x.D * x.H * x.W;
-            const size_t w = (size_t)x.B * dreg_bn_num_chunks((int)V) * x.C * 2 * sizeof(float);
+            size_t w = (size_t)x.B * dreg_bn_num_chunks((int)V) * x.C * 2 * sizeof(float);
+            if (o.sstem) {
+                const Tensor& p = e->t[e->ops[o.pool].out];
+                const size_t w2 = dreg_sparse_stem_workspace_floats(p.B, p.D, p.H, p.W, p.C) * sizeof(float);
+                if (w2 > w) w = w2;
+                o.xam_off = off; off += align256((size_t)p.B * p.D * p.H * p.W * p.C * 2);
+                o.pmask_off = off; off += align256((size_t)p.B * p.D * p.H * p.W);
+            }
             if (w > bn_ws) bn_ws = w;
             if (sb > coef) coef = sb;
             bool shared = false;          // parameters used by two layers: both keep their own tail launches
@@ -284,7 +310,10 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
     for (Op& o : e->ops) {
         if (o.kind != OP_CONV_ROWS || !e->needs_grad[o.in] || o.in == 0 || e->t[o.in].goff == SIZE_MAX) continue;
         int writers = 0;
-        for (const Op& q : e->ops) if ((q.in == o.in || q.in2 == o.in) && e->needs_grad[q.out]) ++writers;
+        for (const Op& q : e->ops) {
+            if (q.kind == OP_MAXPOOL && q.pool >= 0 && e->ops[q.pool].sstem) continue;    // its gradient never passes through the dense buffer
+            if ((q.in == o.in || q.in2 == o.in) && e->needs_grad[q.out]) ++writers;
+        }
         if (writers != 1 || !g_sparse_grads) continue;
         const Tensor& x = e->t[o.in];
         o.sparse_gx = 1; o.cl_off = off; off += align256((size_t)x.B * x.D * x.H * x.W * sizeof(int));
@@ -437,6 +466,7 @@ void dreg_exec_set_input_row_occupancy(void* h, const uint8_t* rowocc) { ((Exec*
 void dreg_exec_set_sparse_grads(int on) { g_sparse_grads = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_bn_batch_tails(int on) { g_bn_batch_tails = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_fuse_stem(int on) { g_fuse_stem = on ? 1 : 0; }   // read when an executor is created
+void dreg_exec_set_sparse_stem(int on) { g_sparse_stem = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_fuse_bn_stats(int on) { g_fuse_bn_stats = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_brick(int mask) { g_brick = mask & 3; }   // packs: read when an executor is created; dispatch: at every forward / backward call
 void dreg_exec_set_defer_head_pg(int on) { g_defer_head_pg = on ? 1 : 0; }   // read at every backward call
@@ -563,6 +593,21 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
             CK(dreg_conv3d_igemm_rows(act(o.in), PK + w.pk_fwd, act(o.out), bias, add, (const int*)rl[0], (int)rl[1],
                                       x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0, o.ksz, 1, o.pad, 0, 0, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0,
                                       0, 0, stream));
+        } else if (o.kind == OP_BN && o.pool >= 0 && o.sstem) {
+            const Op& q = e->ops[o.pool];
+            const Tensor& p = e->t[q.out];
+            const Op& cv = e->ops[o.sstem_conv];
+            if (cv.rows_out >= nlists) return DREG_EINVAL;
+            const int64_t* rl = rowlists + RL * cv.rows_out;
+            const int* ra = nullptr; int na = 0;
+            if (o.sstem_lat >= 0) {
+                const int li = e->ops[o.sstem_lat].rows_in;
+                if (li < 0 || li >= nlists) return DREG_EINVAL;
+                ra = (const int*)rowlists[RL * li]; na = (int)rowlists[RL * li + 1];
+            }
+            CK(dreg_sparse_stem_fwd(act(o.in), (const int*)rl[0], (int)rl[1], ra, na, act(o.out), act(q.out), (uint8_t*)(A + q.aux0), A + o.xam_off, (uint8_t*)(A + o.pmask_off),
+                                    e->prm[o.w].val, e->prm[o.b].val, e->prm[o.p2].val, e->prm[o.p3].val, (float*)(A + o.aux0), (float*)(A + o.aux1),
+                                    (float*)(A + e->off_bn_ws), x.B, x.D, x.H, x.W, p.D, p.H, p.W, x.C, 1e-5f, 0.1f, train, o.relu, stream));
         } else if (o.kind == OP_BN && o.pool >= 0) {
             const Op& q = e->ops[o.pool];
             const Tensor& p = e->t[q.out];
@@ -756,6 +801,19 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
             const Tensor& p = e->t[q.out];
             if (!e->needs_grad[q.out] || !written[q.out]) continue;
             if (!e->prm[o.w].grad || !e->prm[o.b].grad) return DREG_EINVAL;
+            if (o.sstem) {
+                const Op& cv = e->ops[o.sstem_conv];
+                if (cv.rows_out >= nlists) return DREG_EINVAL;
+                const int64_t* rl = rowlists + RL * cv.rows_out;
+                const int* ra = nullptr; int na = 0;
+                const bool lat = o.sstem_lat >= 0 && written[o.out];       // the lateral's data gradient reached the activation
+                if (lat) { const int li = e->ops[o.sstem_lat].rows_in; ra = (const int*)rowlists[RL * li]; na = (int)rowlists[RL * li + 1]; }
+                CK(dreg_sparse_stem_bwd(act(o.in), grad(q.out), (const uint8_t*)(A + q.aux0), A + o.xam_off, lat ? grad(o.out) : nullptr, ra, na,
+                                        (const int*)rl[0], (int)rl[1], (float*)(A + o.aux0), (float*)(A + o.aux1), dst_for(o.in), e->prm[o.w].grad, e->prm[o.b].grad,
+                                        (float*)(A + e->off_coef), (float*)(A + e->off_bn_ws), x.B, x.D, x.H, x.W, p.D, p.H, p.W, x.C, o.relu, 1, stream));
+                CK(commit(o.in));
+                continue;
+            }
             CK(dreg_bn_relu_maxpool_bwd(act(o.in), grad(q.out), (const uint8_t*)(A + q.aux0), (float*)(A + o.aux0), (float*)(A + o.aux1), dst_for(o.in),
                                         e->prm[o.w].grad, e->prm[o.b].grad, (float*)(A + e->off_coef), (float*)(A + e->off_bn_ws),
                                         x.B, x.D, x.H, x.W, p.D, p.H, p.W, x.C, o.relu, 1, stream));

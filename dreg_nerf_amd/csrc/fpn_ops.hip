@@ -1417,6 +1417,270 @@ __global__ void cast_from_f32_kernel(const float* __restrict__ in, T* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
+// ------------------------------------------------------------------------------------------------ stem over a sparse volume
+// The stem's convolution (5^3, stride 2, no bias) over a sparse input volume is non-zero on a short list R of output rows (~5 % at
+// the benchmark's shells: dreg_conv_rows); behind it resnet3d.py:118-123 runs bn1 -> relu -> maxpool, and the FPN's finest lateral
+// (feature_pyramid_net.py:97-103) reads the activation on its own row list S3.  Everything the dense passes did with the 8 x 64^3 x 64
+// tensors follows from the lists:
+//  * statistics: the zero rows add nothing to (sum x, sum x^2): sums over R, mean / variance over all V rows;
+//  * pooling: a window without a listed row holds the constant relu(shift) (its first in-bounds tap wins the strict comparison);
+//    the others run the 27 taps.  The raw x of the arg-max voxel is kept per pooled element (xam);
+//  * the activation itself is written on S3 only (nobody else reads it);
+//  * backward: every pooled gradient lands on exactly one input voxel, so (sum g, sum g xhat) over all input voxels is a sum over
+//    the POOLED elements (mask and xhat from xam) plus the lateral's gradient on S3; dx is needed on R only (the stem's weight
+//    gradient reads nothing else, and there is no gradient for the network input).
+// Row lists: ascending int32 flat indices into [B, V]; a grid's segment is found by binary search.
+__device__ __forceinline__ int rows_lower_bound(const int* __restrict__ rows, int n, long long key)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((long long)rows[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+constexpr int SSTEM_NCH = 64;       // chunks a grid's list segment is split into (statistics passes)
+// partial[b][chunk0 + chunk][c][2] over the chunk's piece of grid b's list segment.  MODE 0: (sum x, sum x^2) of x at the rows;
+// MODE 1: (sum g, sum g*xhat), g = dl at the row masked by the ReLU (x*scale + shift > 0).  grid (SSTEM_NCH, B, slabs).
+template <int MODE>
+__device__ __forceinline__ void sstem_rows_sums(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dl, const int* __restrict__ rows, int n,
+                                                const float* __restrict__ mean_rstd, const float* __restrict__ scale_shift, float* __restrict__ partial,
+                                                int V, int C, int chunk, int nch, int chunk0, int nch_total, int relu, float (*red)[17])
+{
+    constexpr int G = 8;
+    const int CG = C / G, cgs = CG < 256 ? CG : 256, rpi = 256 / cgs;
+    const int t = threadIdx.x, cg = blockIdx.z * cgs + (t % cgs), r0 = t / cgs, b = blockIdx.y;
+    const int s = rows_lower_bound(rows, n, (long long)b * V), e = rows_lower_bound(rows, n, (long long)(b + 1) * V);
+    const int len = e - s;
+    const int i0 = s + (int)((long long)len * chunk / nch), i1 = s + (int)((long long)len * (chunk + 1) / nch);
+    float s1[G], s2[G], mu[G], rs[G], sc[G], sh[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        s1[i] = s2[i] = 0.f;
+        if (MODE == 1) {
+            const size_t pc = ((size_t)b * C + cg * G + i) * 2;
+            mu[i] = mean_rstd[pc]; rs[i] = mean_rstd[pc + 1]; sc[i] = scale_shift[pc]; sh[i] = scale_shift[pc + 1];
+        }
+    }
+    if (r0 < rpi && cg < CG)
+        for (int v = i0 + r0; v < i1; v += rpi) {
+            const size_t off = (size_t)rows[v] * C + (size_t)cg * G;
+            float xv[G], gv[G];
+            Gran<bf16_t>::ld(x + off, xv);
+            if (MODE == 1) Gran<bf16_t>::ld(dl + off, gv);
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                if (MODE == 0) { s1[k] += xv[k]; s2[k] += xv[k] * xv[k]; }
+                else {
+                    const float g = (relu && !((xv[k] * sc[k] + sh[k]) > 0.f)) ? 0.f : gv[k];
+                    s1[k] += g; s2[k] += g * (xv[k] - mu[k]) * rs[k];
+                }
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < G; ++i) { red[t][i] = s1[i]; red[t][G + i] = s2[i]; }
+    __syncthreads();
+    if (t < cgs && cg < CG) {
+        float a1[G], a2[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) { a1[i] = 0.f; a2[i] = 0.f; }
+        for (int r = 0; r < rpi; ++r)
+#pragma unroll
+            for (int i = 0; i < G; ++i) { a1[i] += red[r * cgs + t][i]; a2[i] += red[r * cgs + t][G + i]; }
+        float* dst = partial + (((size_t)b * nch_total + chunk0 + chunk) * C + (size_t)cg * G) * 2;
+#pragma unroll
+        for (int i = 0; i < G; ++i) { dst[2 * i] = a1[i]; dst[2 * i + 1] = a2[i]; }
+    }
+}
+__global__ __launch_bounds__(256) void sstem_stats_kernel(const bf16_t* __restrict__ x, const int* __restrict__ rows, int n, float* __restrict__ partial, int V, int C)
+{
+    __shared__ float red[256][17];
+    sstem_rows_sums<0>(x, nullptr, rows, n, nullptr, nullptr, partial, V, C, blockIdx.x, gridDim.x, 0, gridDim.x, 0, red);
+}
+// pooled windows (3^3, stride 2, pad 1) that contain a listed row
+__global__ void sstem_pool_mark_kernel(const int* __restrict__ rows, int n, uint8_t* __restrict__ pmask, int Di, int Hi, int Wi, int Do, int Ho, int Wo)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int r = rows[i];
+    const int ix = r % Wi; r /= Wi;
+    const int iy = r % Hi; r /= Hi;
+    const int iz = r % Di; const int b = r / Di;
+    for (int oz = iz >> 1; oz <= ((iz + 1) >> 1) && oz < Do; ++oz)
+        for (int oy = iy >> 1; oy <= ((iy + 1) >> 1) && oy < Ho; ++oy)
+            for (int ox = ix >> 1; ox <= ((ix + 1) >> 1) && ox < Wo; ++ox) pmask[(((size_t)b * Do + oz) * Ho + oy) * Wo + ox] = 1;
+}
+// pooled = maxpool3(relu(bn(x))) as bn_relu_maxpool_fwd_kernel (same rounding, tap order, strict comparison), xam = raw x of the arg-max voxel
+__global__ void sstem_pool_fwd_kernel(const bf16_t* __restrict__ x, const uint8_t* __restrict__ pmask, const float* __restrict__ scale_shift,
+                                      bf16_t* __restrict__ y, uint8_t* __restrict__ arg, bf16_t* __restrict__ xam,
+                                      int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int relu)
+{
+    constexpr int G = 8;
+    const int CG = C / G;
+    const size_t total = (size_t)B * Do * Ho * Wo * CG;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int cg, ox, oy, oz, b;
+        decode_gxyzb(i, CG, Wo, Ho, Do, cg, ox, oy, oz, b);
+        float sc[G], sh[G], best[G], xb[G];
+        int bi[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            sc[k] = scale_shift[((size_t)b * C + cg * G + k) * 2]; sh[k] = scale_shift[((size_t)b * C + cg * G + k) * 2 + 1];
+            best[k] = -INFINITY; bi[k] = 0; xb[k] = 0.f;
+        }
+        if (!pmask[i / CG]) {
+            // every row of the window is zero: relu(0 * scale + shift) everywhere, the first in-bounds tap wins
+            const int tap = ((oz == 0 ? 1 : 0) * 3 + (oy == 0 ? 1 : 0)) * 3 + (ox == 0 ? 1 : 0);
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                float o = 0.f * sc[k] + sh[k];
+                o = relu ? fmaxf(o, 0.f) : o;
+                best[k] = bf2f(f2bf(o)); bi[k] = tap;
+            }
+        } else {
+            for (int dz = 0; dz < 3; ++dz) {
+                const int z = oz * 2 - 1 + dz; if ((unsigned)z >= (unsigned)Di) continue;
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int yy = oy * 2 - 1 + dy; if ((unsigned)yy >= (unsigned)Hi) continue;
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int xx = ox * 2 - 1 + dx; if ((unsigned)xx >= (unsigned)Wi) continue;
+                        float v[G];
+                        Gran<bf16_t>::ld(x + ((((size_t)b * Di + z) * Hi + yy) * Wi + xx) * C + (size_t)cg * G, v);
+                        const int tap = (dz * 3 + dy) * 3 + dx;
+#pragma unroll
+                        for (int k = 0; k < G; ++k) {
+                            float o = v[k] * sc[k] + sh[k];
+                            o = relu ? fmaxf(o, 0.f) : o;
+                            o = bf2f(f2bf(o));
+                            if (o > best[k]) { best[k] = o; bi[k] = tap; xb[k] = v[k]; }
+                        }
+                    }
+                }
+            }
+        }
+        Gran<bf16_t>::st(y + i * G, best);
+        Gran<bf16_t>::st(xam + i * G, xb);
+#pragma unroll
+        for (int k = 0; k < G; ++k) arg[i * G + k] = (uint8_t)bi[k];
+    }
+}
+// a = relu(x * scale + shift) on a row list
+__global__ void sstem_apply_rows_kernel(const bf16_t* __restrict__ x, const int* __restrict__ rows, int n, const float* __restrict__ scale_shift,
+                                        bf16_t* __restrict__ a, int V, int C, int relu)
+{
+    constexpr int G = 8;
+    const int CG = C / G;
+    const size_t total = (size_t)n * CG;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        const size_t row = (size_t)rows[i / CG];
+        const int b = (int)(row / V);
+        float v[G];
+        Gran<bf16_t>::ld(x + row * C + (size_t)cg * G, v);
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const size_t pc = ((size_t)b * C + cg * G + k) * 2;
+            const float o = v[k] * scale_shift[pc] + scale_shift[pc + 1];
+            v[k] = relu ? fmaxf(o, 0.f) : o;
+        }
+        Gran<bf16_t>::st(a + row * C + (size_t)cg * G, v);
+    }
+}
+// backward sums: chunks [0, nchp) walk the pooled elements of grid b (g = dp masked through xam, xhat from xam), chunks [nchp, nchp + SSTEM_NCH)
+// the lateral's gradient on its row list (when there is one).  grid (nchp + SSTEM_NCH or nchp, B, slabs).
+__global__ __launch_bounds__(256) void sstem_bwd_sums_kernel(const bf16_t* __restrict__ xam, const bf16_t* __restrict__ dp, const bf16_t* __restrict__ x,
+                                                             const bf16_t* __restrict__ dl, const int* __restrict__ rows_a, int n_a,
+                                                             const float* __restrict__ mean_rstd, const float* __restrict__ scale_shift, float* __restrict__ partial,
+                                                             int V, int Vo, int C, int rpc, int nchp, int relu)
+{
+    constexpr int G = 8;
+    __shared__ float red[256][17];
+    const int chunk = blockIdx.x, nch_total = gridDim.x;
+    if (chunk >= nchp) {
+        sstem_rows_sums<1>(x, dl, rows_a, n_a, mean_rstd, scale_shift, partial, V, C, chunk - nchp, SSTEM_NCH, nchp, nch_total, relu, red);
+        return;
+    }
+    const int CG = C / G, cgs = CG < 256 ? CG : 256, rpi = 256 / cgs;
+    const int t = threadIdx.x, cg = blockIdx.z * cgs + (t % cgs), r0 = t / cgs, b = blockIdx.y;
+    const int v0 = chunk * rpc, v1 = min(v0 + rpc, Vo);
+    float s1[G], s2[G], mu[G], rs[G], sc[G], sh[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const size_t pc = ((size_t)b * C + cg * G + i) * 2;
+        mu[i] = mean_rstd[pc]; rs[i] = mean_rstd[pc + 1]; sc[i] = scale_shift[pc]; sh[i] = scale_shift[pc + 1];
+        s1[i] = s2[i] = 0.f;
+    }
+    if (r0 < rpi && cg < CG) {
+        constexpr int UN = 4;
+        for (int v = v0 + r0; v < v1; v += rpi * UN) {
+            float xv[UN][G], gv[UN][G];
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (v + u * rpi < v1) {
+                    const size_t off = ((size_t)b * Vo + v + u * rpi) * C + (size_t)cg * G;
+                    Gran<bf16_t>::ld(xam + off, xv[u]);
+                    Gran<bf16_t>::ld(dp + off, gv[u]);
+                }
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (v + u * rpi < v1) {
+#pragma unroll
+                    for (int k = 0; k < G; ++k) {
+                        const float g = (relu && !((xv[u][k] * sc[k] + sh[k]) > 0.f)) ? 0.f : gv[u][k];
+                        s1[k] += g; s2[k] += g * (xv[u][k] - mu[k]) * rs[k];
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i) { red[t][i] = s1[i]; red[t][G + i] = s2[i]; }
+    __syncthreads();
+    if (t < cgs && cg < CG) {
+        float a1[G], a2[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) { a1[i] = 0.f; a2[i] = 0.f; }
+        for (int r = 0; r < rpi; ++r)
+#pragma unroll
+            for (int i = 0; i < G; ++i) { a1[i] += red[r * cgs + t][i]; a2[i] += red[r * cgs + t][G + i]; }
+        float* dst = partial + (((size_t)b * nch_total + chunk) * C + (size_t)cg * G) * 2;
+#pragma unroll
+        for (int i = 0; i < G; ++i) { dst[2 * i] = a1[i]; dst[2 * i + 1] = a2[i]; }
+    }
+}
+// dx = scale * (g - c1 - xhat * c2) on the convolution's row list; g = relu mask * (un-pooled dp [+ dl])
+__global__ void sstem_bwd_rows_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dp, const uint8_t* __restrict__ arg, const bf16_t* __restrict__ dl,
+                                      const int* __restrict__ rows, int n, const float* __restrict__ mean_rstd, const float* __restrict__ scale_shift,
+                                      const float* __restrict__ coef, bf16_t* __restrict__ dx, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int relu)
+{
+    constexpr int G = 8;
+    const int CG = C / G;
+    const size_t total = (size_t)n * CG;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CG);
+        const size_t row = (size_t)rows[i / CG];
+        int r = (int)row;
+        const int ix = r % Wi; r /= Wi;
+        const int iy = r % Hi; r /= Hi;
+        const int iz = r % Di; const int b = r / Di;
+        const size_t off = row * C + (size_t)cg * G;
+        float xv[G], g[G], lv[G];
+        Gran<bf16_t>::ld(x + off, xv);
+        unpool_gather<bf16_t>(dp, arg, b, iz, iy, ix, Do, Ho, Wo, C, cg * G, g);
+        if (dl) {
+            Gran<bf16_t>::ld(dl + off, lv);
+#pragma unroll
+            for (int k = 0; k < G; ++k) g[k] += lv[k];
+        }
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const size_t pc = ((size_t)b * C + cg * G + k) * 2;
+            const float sc = scale_shift[pc], sh = scale_shift[pc + 1];
+            if (relu && !((xv[k] * sc + sh) > 0.f)) g[k] = 0.f;
+            const float xh = (xv[k] - mean_rstd[pc]) * mean_rstd[pc + 1];
+            xv[k] = sc * (g[k] - coef[pc] - xh * coef[pc + 1]);
+        }
+        Gran<bf16_t>::st(dx + off, xv);
+    }
+}
+
+
 static inline int nblocks(size_t total, int per = 256, int cap = 8192) {
     size_t b = (total + per - 1) / per;
     return (int)(b > (size_t)cap ? cap : (b ? b : 1));
@@ -1638,6 +1902,62 @@ int dreg_bn_relu_maxpool_bwd(const void* x, const void* dp, const uint8_t* argma
     DREG_LAUNCH_CHECK();
     hipLaunchKernelGGL((bn_pool_bwd_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dp, argmax, mean_rstd, scale_shift, coef, nullptr,
                        (bf16_t*)dx, Di, Hi, Wi, Do, Ho, Wo, C, rpc, relu);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// Stem over a sparse volume (see the kernels above).  x: [B,Di,Hi,Wi,C] bf16, zero outside `rows` (ascending flat row indices, n of them);
+// pooled / argmax as dreg_bn_relu_maxpool_fwd; xam: bf16 [B,Do,Ho,Wo,C] (raw x of the arg-max voxels, for the backward sums); pmask: B*Do*Ho*Wo
+// bytes of scratch; act (optional): the dense-layout activation, written on rows_a only.  workspace: fp32 [B][64][C][2].
+size_t dreg_sparse_stem_workspace_floats(int B, int Do, int Ho, int Wo, int C)
+{
+    const int Vo = Do * Ho * Wo;
+    return (size_t)B * (dreg_bn_num_chunks(Vo) + SSTEM_NCH) * C * 2;
+}
+int dreg_sparse_stem_fwd(const void* x, const int* rows, int n, const int* rows_a, int n_a, void* act, void* pooled, uint8_t* argmax, void* xam, uint8_t* pmask,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
+                         int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, float eps, float momentum, int train, int relu, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int V = Di * Hi * Wi;
+    if (C % 8 || B > BN_MAX_GRIDS || (train && V < 2) || n < 0 || n_a < 0 || (size_t)B * V > 0x7fffffffull) return DREG_EINVAL;
+    const int CG = C / 8, slabs = (CG + 255) / 256;
+    if (train) {
+        hipLaunchKernelGGL(sstem_stats_kernel, dim3(SSTEM_NCH, B, slabs), dim3(256), 0, st, (const bf16_t*)x, rows, n, workspace, V, C);
+        DREG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64 * (B < 8 ? B : 8)), 0, st, workspace, gamma, beta, running_mean, running_var,
+                       scale_shift, mean_rstd, B, SSTEM_NCH, C, V, eps, momentum, train);
+    DREG_LAUNCH_CHECK();
+    const size_t Po = (size_t)B * Do * Ho * Wo;
+    if (hipMemsetAsync(pmask, 0, Po, st) != hipSuccess) return DREG_ELAUNCH;
+    if (n > 0) hipLaunchKernelGGL(sstem_pool_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rows, n, pmask, Di, Hi, Wi, Do, Ho, Wo);
+    hipLaunchKernelGGL(sstem_pool_fwd_kernel, dim3(nblocks(Po * CG)), dim3(256), 0, st, (const bf16_t*)x, pmask, scale_shift, (bf16_t*)pooled, argmax, (bf16_t*)xam,
+                       B, Di, Hi, Wi, Do, Ho, Wo, C, relu);
+    if (act && n_a > 0) hipLaunchKernelGGL(sstem_apply_rows_kernel, dim3(nblocks((size_t)n_a * CG)), dim3(256), 0, st, (const bf16_t*)x, rows_a, n_a, scale_shift, (bf16_t*)act, V, C, relu);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// Its backward.  dp: gradient of `pooled`; dl (optional): gradient of the activation, non-zero on rows_a only (zero elsewhere); dx is
+// written on `rows` only.  dgamma / dbeta as dreg_bn3d_bwd; coef: fp32 [B,C,2] scratch; workspace: dreg_sparse_stem_workspace_floats.
+int dreg_sparse_stem_bwd(const void* x, const void* dp, const uint8_t* argmax, const void* xam, const void* dl, const int* rows_a, int n_a,
+                         const int* rows, int n, const float* scale_shift, const float* mean_rstd, void* dx, float* dgamma, float* dbeta, float* coef, float* workspace,
+                         int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int relu, int accumulate, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int V = Di * Hi * Wi, Vo = Do * Ho * Wo;
+    if (C % 8 || B > BN_MAX_GRIDS || n < 0 || n_a < 0 || (size_t)B * V > 0x7fffffffull) return DREG_EINVAL;
+    const int CG = C / 8, slabs = (CG + 255) / 256;
+    const int rpc = bn_rows_per_chunk(Vo), nchp = (Vo + rpc - 1) / rpc;
+    const bool lat = dl && n_a > 0;
+    const int nch = nchp + (lat ? SSTEM_NCH : 0);
+    hipLaunchKernelGGL(sstem_bwd_sums_kernel, dim3(nch, B, slabs), dim3(256), 0, st, (const bf16_t*)xam, (const bf16_t*)dp, (const bf16_t*)x, (const bf16_t*)dl, rows_a, n_a,
+                       mean_rstd, scale_shift, workspace, V, Vo, C, rpc, nchp, relu);
+    DREG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64 * (B < 8 ? B : 8)), 0, st, workspace, coef, dgamma, dbeta, B, nch, C, V, accumulate);
+    DREG_LAUNCH_CHECK();
+    if (n > 0) hipLaunchKernelGGL(sstem_bwd_rows_kernel, dim3(nblocks((size_t)n * CG)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dp, argmax, lat ? (const bf16_t*)dl : nullptr,
+                                  rows, n, mean_rstd, scale_shift, coef, (bf16_t*)dx, Di, Hi, Wi, Do, Ho, Wo, C, relu);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

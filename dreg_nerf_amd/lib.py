@@ -78,6 +78,7 @@ SIGNATURES = {
     "dreg_bn_set_store_g": (None, [I]),
     "dreg_bn_set_small_regs": (None, [I]),
     "dreg_exec_set_fuse_stem": (None, [I]),
+    "dreg_exec_set_sparse_stem": (None, [I]),
     "dreg_exec_set_fuse_bn_stats": (None, [I]),
     "dreg_exec_set_brick": (None, [I]),
     "dreg_voxel_set_own_sort": (None, [I]),
@@ -92,6 +93,9 @@ SIGNATURES = {
     "dreg_bn_set_small_max_voxels": (None, [I]),
     "dreg_bn_relu_maxpool_fwd": (I, [P] * 10 + [I] * 8 + [F, F, I, I, P]),
     "dreg_bn_relu_maxpool_bwd": (I, [P] * 10 + [I] * 10 + [P]),
+    "dreg_sparse_stem_workspace_floats": (Z, [I] * 5),
+    "dreg_sparse_stem_fwd": (I, [P, P, I, P, I] + [P] * 12 + [I] * 8 + [F, F, I, I, P]),
+    "dreg_sparse_stem_bwd": (I, [P] * 6 + [I, P, I] + [P] * 7 + [I] * 10 + [P]),
     "dreg_bn3d_fwd": (I, [P] * 10 + [I, I, I, F, F, I, I, I, P]),
     "dreg_bn3d_bwd": (I, [P] * 11 + [I, I, I, I, I, I, P]),
     "dreg_bn_small": (I, [I, I, I, I]),

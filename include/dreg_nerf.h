@@ -188,6 +188,20 @@ int dreg_bn_relu_maxpool_fwd(const void* x, void* pooled, uint8_t* argmax, const
 int dreg_bn_relu_maxpool_bwd(const void* x, const void* dp, const uint8_t* argmax, const float* scale_shift, const float* mean_rstd,
                              void* dx, float* dgamma, float* dbeta, float* coef, float* workspace,
                              int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int relu, int accumulate, void* stream);
+/* The same behind a stem computed on a row list over a sparse volume (dreg_conv_rows: x is zero outside `rows`, ascending flat indices into
+ * [B,Di*Hi*Wi]): statistics over the listed rows, pooled windows without a listed row written as the constant relu(shift), the dense-layout
+ * activation `act` (optional) written on rows_a only (the FPN's finest lateral reads nothing else: feature_pyramid_net.py:97-103), xam = raw
+ * x of the arg-max voxels (bf16 [B,Do,Ho,Wo,C]); pmask: B*Do*Ho*Wo bytes of scratch.  Backward: the BatchNorm sums run over the POOLED
+ * elements (+ dl, the activation's gradient from the lateral, non-zero on rows_a only); dx is written on `rows` only (all the stem's weight
+ * gradient reads).  Pooled values / arg-max taps equal dreg_bn_relu_maxpool_fwd's given the same scale / shift; the statistics differ by
+ * fp32 summation order.  workspace: dreg_sparse_stem_workspace_floats floats. */
+size_t dreg_sparse_stem_workspace_floats(int B, int Do, int Ho, int Wo, int C);
+int dreg_sparse_stem_fwd(const void* x, const int* rows, int n, const int* rows_a, int n_a, void* act, void* pooled, uint8_t* argmax, void* xam, uint8_t* pmask,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
+                         int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, float eps, float momentum, int train, int relu, void* stream);
+int dreg_sparse_stem_bwd(const void* x, const void* dp, const uint8_t* argmax, const void* xam, const void* dl, const int* rows_a, int n_a,
+                         const int* rows, int n, const float* scale_shift, const float* mean_rstd, void* dx, float* dgamma, float* dbeta, float* coef, float* workspace,
+                         int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int relu, int accumulate, void* stream);
 /* nn.MaxPool3d(3, 2, 1) (resnet3d.py:123,161); argmax: uint8 [B,Do,Ho,Wo,C] tap index for the backward pass. */
 int dreg_maxpool3d_fwd(const void* x, void* y, uint8_t* argmax, int B, int Di, int Hi, int Wi, int Do, int Ho, int Wo,
                        int C, int dtype, void* stream);

@@ -1,0 +1,228 @@
+"""GPU: BatchNorm + ReLU + max-pool behind a stem computed on a row list over a sparse volume (resnet3d.py:118-123 conv1 -> bn1 -> relu ->
+maxpool, with the FPN's finest lateral, feature_pyramid_net.py:97-103, reading the activation on its own row list): dreg_sparse_stem_fwd /
+_bwd against the dense fused form of the library (bit for bit where the arithmetic is the same) and against a plain torch fp32 reference
+of the same op, and a whole training step with the switch on and off."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from dreg_nerf_amd import lib as L, params, synth  # noqa: E402
+from dreg_nerf_amd.regtr import NeRFRegTr  # noqa: E402
+from dreg_nerf_amd.train_step import TrainStep  # noqa: E402
+
+DEV = torch.device("cuda", 0)
+
+
+def _case(B, D, H, W, C, frac_rows, frac_a, seed):
+    g = torch.Generator().manual_seed(seed)
+    V = D * H * W
+    occ = torch.rand(B * V, generator=g) < frac_rows
+    if B > 1:
+        occ[V:2 * V] = False                                   # a grid without a listed row
+    occ[0] = occ[B * V - 1] = True                             # corners
+    rows = torch.nonzero(occ)[:, 0].int()
+    x = torch.zeros(B * V, C)
+    x[rows.long()] = torch.randn(rows.numel(), C, generator=g) * 2 + 0.3
+    x[rows.long()[::5], ::3] = 0.0                             # exact zeros inside listed rows
+    xa = torch.rand(B * V, generator=g) < frac_a
+    rows_a = torch.nonzero(xa)[:, 0].int()
+    Do, Ho, Wo = ((d + 2 - 3) // 2 + 1 for d in (D, H, W))
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.3                   # both signs: windows of zeros pool to relu(shift) = 0 or > 0
+    dp = torch.randn(B * Do * Ho * Wo, C, generator=g)
+    dl = torch.zeros(B * V, C)
+    dl[rows_a.long()] = torch.randn(rows_a.numel(), C, generator=g)
+    return dict(B=B, D=D, H=H, W=W, C=C, V=V, Do=Do, Ho=Ho, Wo=Wo, rows=rows.to(DEV), rows_a=rows_a.to(DEV),
+                x=x.to(DEV).bfloat16().contiguous(), gamma=gamma.to(DEV), beta=beta.to(DEV), dp=dp.to(DEV).bfloat16().contiguous(),
+                dl=dl.to(DEV).bfloat16().contiguous())
+
+
+def _sparse_fwd(c, train, act=True):
+    lib = L.load()
+    B, C = c["B"], c["C"]
+    Po = B * c["Do"] * c["Ho"] * c["Wo"]
+    o = dict(pooled=torch.empty(Po, C, dtype=torch.bfloat16, device=DEV), arg=torch.empty(Po, C, dtype=torch.uint8, device=DEV),
+             xam=torch.empty(Po, C, dtype=torch.bfloat16, device=DEV), pmask=torch.empty(Po, dtype=torch.uint8, device=DEV),
+             act=torch.full((B * c["V"], C), float("nan"), dtype=torch.bfloat16, device=DEV) if act else None,
+             rm=torch.zeros(C, device=DEV) + 0.1, rv=torch.ones(C, device=DEV) * 1.5, ss=torch.empty(B, C, 2, device=DEV), mr=torch.empty(B, C, 2, device=DEV),
+             ws=torch.empty(int(lib.dreg_sparse_stem_workspace_floats(B, c["Do"], c["Ho"], c["Wo"], C)), device=DEV))
+    L.check(lib.dreg_sparse_stem_fwd(L.ptr(c["x"]), L.ptr(c["rows"]), c["rows"].numel(), L.ptr(c["rows_a"]), c["rows_a"].numel(), L.ptr(o["act"]), L.ptr(o["pooled"]),
+                                     L.ptr(o["arg"]), L.ptr(o["xam"]), L.ptr(o["pmask"]), L.ptr(c["gamma"]), L.ptr(c["beta"]), L.ptr(o["rm"]), L.ptr(o["rv"]),
+                                     L.ptr(o["ss"]), L.ptr(o["mr"]), L.ptr(o["ws"]), B, c["D"], c["H"], c["W"], c["Do"], c["Ho"], c["Wo"], C, 1e-5, 0.1, int(train), 1,
+                                     L.stream()), "dreg_sparse_stem_fwd")
+    return o
+
+
+def _dense_fwd(c, train):
+    lib = L.load()
+    B, C = c["B"], c["C"]
+    Po = B * c["Do"] * c["Ho"] * c["Wo"]
+    o = dict(pooled=torch.empty(Po, C, dtype=torch.bfloat16, device=DEV), arg=torch.empty(Po, C, dtype=torch.uint8, device=DEV),
+             rm=torch.zeros(C, device=DEV) + 0.1, rv=torch.ones(C, device=DEV) * 1.5, ss=torch.empty(B, C, 2, device=DEV), mr=torch.empty(B, C, 2, device=DEV),
+             ws=torch.empty(B * int(lib.dreg_bn_num_chunks(c["V"])) * C * 2, device=DEV))
+    L.check(lib.dreg_bn_relu_maxpool_fwd(L.ptr(c["x"]), L.ptr(o["pooled"]), L.ptr(o["arg"]), L.ptr(c["gamma"]), L.ptr(c["beta"]), L.ptr(o["rm"]), L.ptr(o["rv"]),
+                                         L.ptr(o["ss"]), L.ptr(o["mr"]), L.ptr(o["ws"]), B, c["D"], c["H"], c["W"], c["Do"], c["Ho"], c["Wo"], C, 1e-5, 0.1, int(train), 1,
+                                         L.stream()), "dreg_bn_relu_maxpool_fwd")
+    return o
+
+
+CASES = [(3, 16, 16, 16, 64, 0.06, 0.2, 1), (2, 9, 12, 7, 64, 0.3, 0.5, 2), (1, 8, 8, 8, 128, 0.02, 0.0, 3)]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_eval_mode_forward_is_the_dense_fused_form_bit_for_bit(case):
+    """Running statistics (no statistics pass): identical scale / shift, so pooled values and arg-max taps must be identical, the activation on
+    rows_a the BatchNorm's, and xam the raw value at the arg-max voxel."""
+    c = _case(*case)
+    s, d = _sparse_fwd(c, False), _dense_fwd(c, False)
+    assert torch.equal(s["ss"], d["ss"]) and torch.equal(s["mr"], d["mr"])
+    assert torch.equal(s["pooled"].view(torch.int16), d["pooled"].view(torch.int16))
+    assert torch.equal(s["arg"], d["arg"])
+    _check_act_and_xam(c, s)
+
+
+def _check_act_and_xam(c, s):
+    B, V, C = c["B"], c["V"], c["C"]
+    sc, sh = s["ss"][..., 0], s["ss"][..., 1]
+    x = c["x"].float().view(B, V, C)
+    a = torch.relu(x * sc[:, None] + sh[:, None]).bfloat16().view(B * V, C)
+    ra = c["rows_a"].long()
+    assert torch.equal(s["act"][ra].view(torch.int16), a[ra].view(torch.int16))
+    keep = torch.ones(B * V, dtype=torch.bool, device=DEV)
+    keep[ra] = False
+    assert torch.isnan(s["act"][keep].float()).all()           # nothing else is written
+    # xam: relu(bn(xam)) rounded is the pooled value, and xam is the raw x at the arg-max tap
+    Po = B * c["Do"] * c["Ho"] * c["Wo"]
+    xam = s["xam"].float().view(B, -1, C)
+    v = torch.relu(xam * sc[:, None] + sh[:, None]).bfloat16().view(Po, C)
+    assert torch.equal(v.view(torch.int16), s["pooled"].view(torch.int16))
+    vox = _argmax_voxels(c, s["arg"])
+    xg = torch.gather(x.view(B * V, C), 0, vox)
+    assert torch.equal(xg.bfloat16().view(torch.int16), s["xam"].view(torch.int16))
+
+
+def _argmax_voxels(c, arg):
+    """flat input row index [Po, C] of every pooled element's arg-max tap"""
+    B, D, H, W, Do, Ho, Wo = (c[k] for k in ("B", "D", "H", "W", "Do", "Ho", "Wo"))
+    p = torch.arange(B * Do * Ho * Wo, device=DEV)
+    ox, oy, oz, b = p % Wo, (p // Wo) % Ho, (p // (Wo * Ho)) % Do, p // (Wo * Ho * Do)
+    t = arg.long()
+    dz, dy, dx = t // 9, (t // 3) % 3, t % 3
+    z, y, x = oz[:, None] * 2 - 1 + dz, oy[:, None] * 2 - 1 + dy, ox[:, None] * 2 - 1 + dx
+    assert ((z >= 0) & (z < D) & (y >= 0) & (y < H) & (x >= 0) & (x < W)).all()
+    return ((b[:, None] * D + z) * H + y) * W + x
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_training_forward_against_torch(case):
+    c = _case(*case)
+    B, V, C = c["B"], c["V"], c["C"]
+    s = _sparse_fwd(c, True)
+    x = c["x"].double().view(B, V, C)
+    mean, var = x.mean(1), x.var(1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    torch.testing.assert_close(s["mr"][..., 0].double(), mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(s["mr"][..., 1].double(), rstd, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(s["ss"][..., 0].double(), c["gamma"].double() * rstd, rtol=1e-5, atol=1e-6)
+    # running statistics: sequential over the grids (one grid per BatchNorm call in the reference: nerf_regtr.py:135)
+    rm, rv = torch.zeros(C, dtype=torch.float64, device=DEV) + 0.1, torch.ones(C, dtype=torch.float64, device=DEV) * 1.5
+    for b in range(B):
+        rm = 0.9 * rm + 0.1 * mean[b]
+        rv = 0.9 * rv + 0.1 * var[b] * V / (V - 1)
+    torch.testing.assert_close(s["rm"].double(), rm, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(s["rv"].double(), rv, rtol=1e-5, atol=1e-6)
+    # pooled values against torch's max_pool3d of the activation computed with the kernel's own scale / shift
+    sc, sh = s["ss"][..., 0], s["ss"][..., 1]
+    a = torch.relu(c["x"].float().view(B, V, C) * sc[:, None] + sh[:, None]).bfloat16().float()
+    a5 = a.view(B, c["D"], c["H"], c["W"], C).permute(0, 4, 1, 2, 3)
+    ref = torch.nn.functional.max_pool3d(a5, 3, 2, 1).permute(0, 2, 3, 4, 1).reshape(-1, C)
+    assert torch.equal(ref.bfloat16().view(torch.int16), s["pooled"].view(torch.int16))
+    _check_act_and_xam(c, s)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("lateral", [True, False])
+def test_backward_against_torch(case, lateral):
+    lib = L.load()
+    c = _case(*case)
+    if lateral and c["rows_a"].numel() == 0:
+        pytest.skip("no lateral rows in this case")
+    B, V, C = c["B"], c["V"], c["C"]
+    s = _sparse_fwd(c, True)
+    dx = torch.full((B * V, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dgamma, dbeta = torch.ones(C, device=DEV), torch.ones(C, device=DEV) * 2      # accumulated into
+    coef = torch.empty(B, C, 2, device=DEV)
+    L.check(lib.dreg_sparse_stem_bwd(L.ptr(c["x"]), L.ptr(c["dp"]), L.ptr(s["arg"]), L.ptr(s["xam"]), L.ptr(c["dl"]) if lateral else None,
+                                     L.ptr(c["rows_a"]) if lateral else None, c["rows_a"].numel() if lateral else 0, L.ptr(c["rows"]), c["rows"].numel(),
+                                     L.ptr(s["ss"]), L.ptr(s["mr"]), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef), L.ptr(s["ws"]),
+                                     B, c["D"], c["H"], c["W"], c["Do"], c["Ho"], c["Wo"], C, 1, 1, L.stream()), "dreg_sparse_stem_bwd")
+    # torch reference (fp64) with the kernel's statistics
+    x = c["x"].double().view(B, V, C)
+    sc, sh, mu, rs = (t.double() for t in (s["ss"][..., 0], s["ss"][..., 1], s["mr"][..., 0], s["mr"][..., 1]))
+    g = torch.zeros(B * V, C, dtype=torch.float64, device=DEV)
+    g.scatter_add_(0, _argmax_voxels(c, s["arg"]), c["dp"].double())
+    if lateral:
+        g += c["dl"].double()
+    g = g.view(B, V, C) * ((c["x"].float().view(B, V, C) * s["ss"][..., 0][:, None] + s["ss"][..., 1][:, None]) > 0)
+    xh = (x - mu[:, None]) * rs[:, None]
+    s1, s2 = g.sum(1), (g * xh).sum(1)
+    ref = sc[:, None] * (g - s1[:, None] / V - xh * s2[:, None] / V)
+    r = c["rows"].long()
+    torch.testing.assert_close(dx[r].double(), ref.view(B * V, C)[r], rtol=1e-2, atol=1e-2 * float(ref.abs().max()) / 64)
+    keep = torch.ones(B * V, dtype=torch.bool, device=DEV)
+    keep[r] = False
+    assert torch.isnan(dx[keep].float()).all()                 # only the listed rows are written
+    torch.testing.assert_close(dgamma.double() - 1, s2.sum(0), rtol=1e-4, atol=1e-4 * float(s2.abs().max()))
+    torch.testing.assert_close(dbeta.double() - 2, s1.sum(0), rtol=1e-4, atol=1e-4 * float(s1.abs().max()))
+    if not lateral:
+        # the library's dense fused backward on the same statistics: same gradient on the listed rows to bf16 rounding of the output
+        dxd = torch.empty(B * V, C, dtype=torch.bfloat16, device=DEV)
+        dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        ws = torch.empty(B * int(lib.dreg_bn_num_chunks(V)) * C * 2, device=DEV)
+        L.check(lib.dreg_bn_relu_maxpool_bwd(L.ptr(c["x"]), L.ptr(c["dp"]), L.ptr(s["arg"]), L.ptr(s["ss"]), L.ptr(s["mr"]), L.ptr(dxd), L.ptr(dg2), L.ptr(db2),
+                                             L.ptr(coef), L.ptr(ws), B, c["D"], c["H"], c["W"], c["Do"], c["Ho"], c["Wo"], C, 1, 0, L.stream()), "dreg_bn_relu_maxpool_bwd")
+        torch.testing.assert_close(dx[r].float(), dxd[r].float(), rtol=2e-2, atol=2e-2 * float(ref.abs().max()) / 64)
+        torch.testing.assert_close(dgamma - 1, dg2, rtol=1e-4, atol=1e-4 * float(s2.abs().max()))
+
+
+def _batch(res, n_pairs=2):
+    out = []
+    for i in range(n_pairs):
+        d = synth.shell_pair(res, 1 + 2 * i, 2 + 2 * i, pose=synth.fixed_pose())
+        out.append({k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in d.items()})
+    return out
+
+
+def _step(sparse_stem, res=64):
+    lib = L.load()
+    lib.dreg_exec_set_sparse_stem(int(sparse_stem))
+    try:
+        torch.manual_seed(3407)
+        m = NeRFRegTr(precision="bf16")
+        m.load_state_dict(params.synth_state_dict(0, profile="wc"), strict=True)
+        m = m.to(DEV).train()
+        ts = TrainStep(m)
+        out = ts.step(_batch(res))
+        torch.cuda.synchronize()
+    finally:
+        lib.dreg_exec_set_sparse_stem(1)
+    g = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    bufs = {n: b.detach().clone() for n, b in m.named_buffers() if "bn1.running" in n and "layer" not in n}
+    return {k: float(v) for k, v in out["losses"].items()}, float(out["grad_norm"]), g, bufs
+
+
+def test_training_step_with_and_without_the_sparse_stem():
+    """The same optimizer step with the stem's BatchNorm / pool run from the row lists and in the dense three-pass form: the statistics
+    differ by fp32 summation order only, so losses, the gradient norm, the stem's own gradients and its running statistics agree tightly."""
+    la, na, ga, ba = _step(False)
+    lb, nb, gb, bb = _step(True)
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 2e-3 * max(abs(la[k]), 1e-3), (k, la[k], lb[k])
+    assert abs(na - nb) <= 2e-2 * na
+    for k in ba:
+        torch.testing.assert_close(ba[k], bb[k], rtol=1e-4, atol=1e-6)
+    for w in ("fpn3d.backbone_net.conv1.weight", "fpn3d.backbone_net.bn1.weight", "fpn3d.backbone_net.bn1.bias"):
+        cos = float(torch.nn.functional.cosine_similarity(ga[w].flatten(), gb[w].flatten(), dim=0))
+        assert cos > 0.995, (w, cos)
+        assert abs(float(ga[w].norm()) - float(gb[w].norm())) <= 5e-2 * float(ga[w].norm()), w
