@@ -1714,6 +1714,26 @@ __device__ __forceinline__ void wgrad_reduce_block(const WgradReduceDesc& d, int
     const int no = nci * d.ntaps;                             // output elements, ordered (channel, tap)
     const int KG = (d.nsplit >= 8 && 4 * no <= WR_STAGE) ? 4 : 1, EL = 256 / KG, g = t / EL, l = t - g * EL;
     const float* src = d.part + (size_t)co * d.Kpad + ci0;
+    if ((chp & 3) == 0 && (d.Cin & 3) == 0 && (d.Kpad & 3) == 0) {
+        // four channels of a tap per thread and split (16-byte loads; every element's splits are still added in ascending order: the sums
+        // are those of the scalar form below, bit for bit — the scalar form issued four times the loads and ran at 1.8 TB/s)
+        for (int e = l; e < (ne >> 2); e += EL) {
+            const int tap = (e << 2) >> sh, cl = (e << 2) & (chp - 1);
+            if (cl >= nci) continue;
+            const float* p = src + (size_t)tap * d.Cin + cl;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+            for (int k = g; k < nwritten; k += KG) {
+                const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * slab);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            float* q = stage + g * no + cl * d.ntaps + tap;
+            q[0] = a.x;
+            if (cl + 1 < nci) q[d.ntaps] = a.y;
+            if (cl + 2 < nci) q[2 * d.ntaps] = a.z;
+            if (cl + 3 < nci) q[3 * d.ntaps] = a.w;
+        }
+    } else
     for (int e = l; e < ne; e += EL) {
         const int tap = e >> sh, cl = e & (chp - 1);
         if (cl < nci) stage[g * no + cl * d.ntaps + tap] = wr_sum(src + (size_t)tap * d.Cin + cl, slab, g, KG, nwritten);   // lanes walk cl: stride ntaps (odd)

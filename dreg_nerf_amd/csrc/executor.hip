@@ -47,6 +47,9 @@ struct Op {
     int sparse_gx = 0;           // OP_CONV_ROWS: the input's gradient buffer has no other writer: kept zero outside the rows of the last step
     size_t cl_off = 0;           //   arena copy of the row list that was written (cleared at the start of the next backward)
     int cl_count = 0;
+    int ds_sparse = 0;           // OP_CONV_ROWS with ds_rows >= 0 that is the only writer of its addend's gradient: that buffer is kept zero outside the rows of the last step as well
+    size_t cl2_off = 0;
+    int cl2_count = 0;
     int pool = -1;               // OP_BN: index of the max-pool op fused behind it; OP_MAXPOOL: index of the BatchNorm it is fused into
     int sstem = 0;               // OP_BN fused with its max-pool behind a row-list convolution over a sparse volume (fpn_ops.hip "stem over a sparse volume")
     int sstem_conv = -1, sstem_lat = -1;   //   that convolution; the active-set convolution that also reads the activation (-1: none)
@@ -317,6 +320,14 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
         if (writers != 1 || !g_sparse_grads) continue;
         const Tensor& x = e->t[o.in];
         o.sparse_gx = 1; o.cl_off = off; off += align256((size_t)x.B * x.D * x.H * x.W * sizeof(int));
+    }
+    for (Op& o : e->ops) {
+        if (o.kind != OP_CONV_ROWS || o.ds_rows < 0 || e->t[o.in2].goff == SIZE_MAX || !g_sparse_grads) continue;
+        int writers = 0;
+        for (const Op& q : e->ops) if ((q.in == o.in2 || q.in2 == o.in2) && e->needs_grad[q.out]) ++writers;
+        if (writers != 1) continue;
+        const Tensor& ta = e->t[o.in2];
+        o.ds_sparse = 1; o.cl2_off = off; off += align256((size_t)ta.B * ta.D * ta.H * ta.W * sizeof(int));
     }
     // a dense-layout convolution computed on an output row list (the stem over a sparse volume: rows_out >= 0): its output is kept zero
     // outside the list the same way — the rows of the step before are cleared, a copy of the list lives in the arena
@@ -696,6 +707,13 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
             else if (o.cl_count > 0) CK(dreg_zero_rows(A + x.goff, (const int*)(A + o.cl_off), o.cl_count, x.C, 0, stream));
             o.cl_count = 0;
         }
+        for (Op& o : e->ops) {
+            if (!o.ds_sparse) continue;
+            const Tensor& ta = e->t[o.in2];
+            if (fresh) { if (hipMemsetAsync(A + ta.goff, 0, (size_t)ta.B * ta.D * ta.H * ta.W * ta.C * 2, st) != hipSuccess) return DREG_ELAUNCH; }
+            else if (o.cl2_count > 0) CK(dreg_zero_rows(A + ta.goff, (const int*)(A + o.cl2_off), o.cl2_count, ta.C, 0, stream));
+            o.cl2_count = 0;
+        }
         e->sparse_arena = arena;
     }
     const int n_ws = (aux_on && g_aux_streams > 1 && extra_streams_ready(g_aux_streams)) ? g_aux_streams : 1;
@@ -847,6 +865,12 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                 if (o.add_same) { CK(hipMemcpyAsync(dst_for(o.in2), gy, (size_t)y.B * y.D * y.H * y.W * y.C * 2, hipMemcpyDeviceToDevice, st) == hipSuccess ? 0 : DREG_ELAUNCH); }
                 else if (rows && o.ds_rows >= 0 && o.ds_rows < nlists) {
                     void* dst = dst_for(o.in2);
+                    const int nds = (int)rowlists[RL * o.ds_rows + 1];
+                    if (o.ds_sparse && dst == grad(o.in2)) {
+                        // zero everywhere (see the start of this call); remember which rows this step writes
+                        if (nds > 0 && hipMemcpyAsync(A + o.cl2_off, (const int*)rowlists[RL * o.ds_rows], (size_t)nds * sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess) return DREG_ELAUNCH;
+                        const_cast<Op&>(o).cl2_count = nds;
+                    } else
                     CK(dreg_fill_zero(dst, (size_t)ta.B * ta.D * ta.H * ta.W * ta.C * 2, stream));
                     CK(dreg_downsample_sum_rows(gy, dst, (const int*)rowlists[RL * o.ds_rows], (int)rowlists[RL * o.ds_rows + 1],
                                                 y.D, y.H, y.W, ta.D, ta.H, ta.W, y.C, 0, stream));

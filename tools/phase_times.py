@@ -39,13 +39,18 @@ for _ in range(3): ts.step(batch)
 torch.cuda.synchronize()
 acc = {}
 N = 8
+NOSYNC = "--nosync" in sys.argv      # steady state: the host runs ahead, steps are not separated by a device synchronisation
+allm = []
 for _ in range(N):
     marks.clear()
     mark("step_start"); ts.step(batch); mark("step_end")
-    torch.cuda.synchronize()
-    base = marks[0][1]
-    for (n1, e1) in marks[1:]:
+    if not NOSYNC: torch.cuda.synchronize()
+    allm.append(list(marks))
+torch.cuda.synchronize()
+for ms in allm[2:]:
+    base = ms[0][1]
+    for (n1, e1) in ms[1:]:
         acc[("step_start", n1)] = acc.get(("step_start", n1), 0.0) + base.elapsed_time(e1)
-for k, v in acc.items(): print(f"{k[0]:20s} -> {k[1]:20s} {v/N:7.2f} ms")
+for k, v in acc.items(): print(f"{k[0]:20s} -> {k[1]:20s} {v/(N-2):7.2f} ms")
 # fwd trunk = fpn_fwd_end - fpn_fwd_start; point-set half fwd + losses + its backward = fpn_bwd_start - fpn_fwd_end;
 # trunk backward = fpn_bwd_end - fpn_bwd_start; reduce join + clip + AdamW + repack = step_end - fpn_bwd_end
