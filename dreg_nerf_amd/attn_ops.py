@@ -441,6 +441,64 @@ def segment_mean(feats, rnd: SubsampleRound):
     return _SegmentMeanFn.apply(feats, rnd)
 
 
+class _SubsampleAllFn(torch.autograd.Function):
+    """The voxel-average rounds of EVERY pair of a step as one autograd node (grid_downsample.py:6-94 applied per pair, nerf_regtr.py:150-168):
+    feats fp32 [N_total, C] (the pairs' point sets one after the other, sizes[i] rows each), plans[i] = that pair's rounds.  Same launches
+    as segment_mean per pair and round, but the last round of every pair writes straight into its rows of the joint output and — backward
+    — the first round's gradient straight into its rows of d(feats): no torch.cat of the per-pair results (forward) and no concatenation
+    of the per-pair gradients (backward: 150 MB copied per step at 4 pairs)."""
+
+    @staticmethod
+    def forward(ctx, feats, plans, sizes):
+        lib = L.load()
+        feats = feats.contiguous()
+        assert feats.dtype == torch.float32 and feats.shape[0] == sum(sizes)
+        c = feats.shape[1]
+        n_out = [(rounds[-1].n_out if rounds else sz) for rounds, sz in zip(plans, sizes)]
+        out = torch.empty(sum(n_out), c, dtype=torch.float32, device=feats.device)
+        io, oo = 0, 0
+        for rounds, sz, no in zip(plans, sizes, n_out):
+            x = feats[io:io + sz]
+            if not rounds:
+                out[oo:oo + no].copy_(x)
+            for k, rnd in enumerate(rounds):
+                assert x.shape[0] == rnd.n_in
+                y = out[oo:oo + no] if k == len(rounds) - 1 else torch.empty(rnd.n_out, c, dtype=torch.float32, device=feats.device)
+                L.check(lib.dreg_voxel_segment_mean(L.ptr(x), L.ptr(rnd.order), L.ptr(rnd.starts), L.ptr(rnd.n_out_dev), L.ptr(y),
+                                                    rnd.n_out, c, L.stream()), "dreg_voxel_segment_mean")
+                x = y
+            io += sz
+            oo += no
+        ctx.plans, ctx.sizes, ctx.n_out = plans, sizes, n_out
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.load()
+        g = g.contiguous()
+        c = g.shape[1]
+        gin_all = torch.empty(sum(ctx.sizes), c, dtype=torch.float32, device=g.device)
+        io, oo = 0, 0
+        for rounds, sz, no in zip(ctx.plans, ctx.sizes, ctx.n_out):
+            gy = g[oo:oo + no]
+            if not rounds:
+                gin_all[io:io + sz].copy_(gy)
+            for k in range(len(rounds) - 1, -1, -1):
+                rnd = rounds[k]
+                gx = gin_all[io:io + sz] if k == 0 else torch.empty(rnd.n_in, c, dtype=torch.float32, device=g.device)
+                L.check(lib.dreg_voxel_downsample_bwd(L.ptr(gy), L.ptr(rnd.inv_seg), L.ptr(rnd.inv_cnt), L.ptr(gx), rnd.n_in, c, L.stream()),
+                        "dreg_voxel_downsample_bwd")
+                gy = gx
+            io += sz
+            oo += no
+        return gin_all, None, None
+
+
+def subsample_all(feats, plans, sizes):
+    """[N_total, C] -> [sum of the pairs' key points, C]: every pair's voxel-average rounds, one autograd node."""
+    return _SubsampleAllFn.apply(feats, plans, sizes)
+
+
 def weighted_kabsch(a, b, w, eps: float = 1e-6):
     """a,b [P,N,3], w [P,N] -> [P,3,4] (no gradient: the pose enters no loss, train_nerf_regtr.py:186-228)."""
     lib = L.load()

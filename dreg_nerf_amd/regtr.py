@@ -120,6 +120,7 @@ class NeRFRegTr(nn.Module):
         # eval_ngp_nerf.py:397-405 writes and dataset.py:277-331 keeps (augmentations touch mask voxels only).  False: the dense stem
         # with per-row occupancy flags taken from the VALUES.
         self.stem_rows = True
+        self.batched_subsample = True   # the pairs' voxel-average rounds as one autograd node (attn_ops.subsample_all)
         self._spec = params.regtr_spec(self.pos_emb_type)
         _build_tree(self, self._spec)
         _reset_parameters(self, self._spec)
@@ -429,9 +430,12 @@ class NeRFRegTr(nn.Module):
         # one split (backward: one concatenation) instead of per-pair slices: autograd turns every slice of the [N_mask_total, 256]
         # feature tensor into a zero-filled full-size gradient plus an add (2.3 GB of traffic per step at 4 pairs)
         sizes = [idxs[2 * i].shape[0] + idxs[2 * i + 1].shape[0] for i in range(len(batch))]
-        feat_l = [T.apply_subsample_plan(plans[i], f) for i, f in enumerate(feats.split(sizes))]
         xyz_all = torch.cat(pts_l) if len(pts_l) > 1 else pts_l[0]
-        feats_all = torch.cat(feat_l) if len(feat_l) > 1 else feat_l[0]
+        if feats.is_cuda and feats.dtype == torch.float32 and self.batched_subsample:
+            feats_all = A.subsample_all(feats, plans, sizes)       # the same launches, results / gradients written in place (no cat)
+        else:
+            feat_l = [T.apply_subsample_plan(plans[i], f) for i, f in enumerate(feats.split(sizes))]
+            feats_all = torch.cat(feat_l) if len(feat_l) > 1 else feat_l[0]
         from . import pointset_exec
         ps = pointset_exec.executor_for(self, P)
         last = None
