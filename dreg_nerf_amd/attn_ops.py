@@ -494,6 +494,87 @@ class _SubsampleAllFn(torch.autograd.Function):
         return gin_all, None, None
 
 
+class _GatherSubsampleFn(torch.autograd.Function):
+    """ops.trilinear_gather followed by subsample_all as ONE autograd node (nerf_regtr.py:138-168): forward = the two forwards; backward:
+    the voxel-average rounds are differentiated down to the FIRST round's outputs only, and the gather's backward reads the gradient of
+    the gathered features through that round (d feats[n] = g1[inv_seg[n]] * inv_cnt[n]: dreg_trilinear_gather_bwd_gather_seg) — the
+    [N_total, 256] fp32 gradient (150 MB at 4 pairs) is never written, the gather reads rows of a tensor a sixth of its size.  Same
+    arithmetic in the same order as the two nodes: bit-identical gradients (tests/test_hip_pointset_ops.py)."""
+
+    @staticmethod
+    def forward(ctx, p1, idx, pt_batch, fine_res, rows1, plans, sizes):
+        from . import ops
+        feats = ops.TrilinearGatherFn.forward(ctx, p1, idx, pt_batch, fine_res, rows1, None)      # saves idx / pt_batch / rows1, sets ctx.cfg
+        out = _SubsampleAllFn.forward(ctx, feats, plans, sizes)                                   # sets ctx.plans / sizes / n_out
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        lib = L.load()
+        idx, pt_batch, rows1, _ = ctx.saved_tensors
+        shape, dtype, (Zr, Xr, Yr) = ctx.cfg
+        B, d, h, w, C = shape
+        g = g.contiguous().float()
+        dev = g.device
+        n1 = [rounds[0].n_out for rounds in ctx.plans]
+        g1 = torch.empty(sum(n1), C, dtype=torch.float32, device=dev)
+        oo, ro = 0, 0
+        table = []
+        pstart = 0
+        for i, (rounds, sz, no) in enumerate(zip(ctx.plans, ctx.sizes, ctx.n_out)):
+            gy = g[oo:oo + no]
+            if len(rounds) == 1:
+                g1[ro:ro + n1[i]].copy_(gy)
+            for k in range(len(rounds) - 1, 0, -1):
+                rnd = rounds[k]
+                gx = g1[ro:ro + n1[i]] if k == 1 else torch.empty(rnd.n_in, C, dtype=torch.float32, device=dev)
+                L.check(lib.dreg_voxel_downsample_bwd(L.ptr(gy), L.ptr(rnd.inv_seg), L.ptr(rnd.inv_cnt), L.ptr(gx), rnd.n_in, C, L.stream()),
+                        "dreg_voxel_downsample_bwd")
+                gy = gx
+            row = [rounds[0].inv_seg.data_ptr(), rounds[0].inv_cnt.data_ptr(), pstart, ro]
+            table += [row, row]                  # both grids of the pair (point sets: source then target, one plan)
+            oo += no
+            ro += n1[i]
+            pstart += sz
+        assert len(table) == B, "one plan per pair of grids"
+        descs = L.to_device_async([v for r in table for v in r], torch.int64, dev)
+        fmap = torch.empty(B * Zr * Xr * Yr, dtype=torch.int32, device=dev)
+        if ops.PERSISTENT_GRAD_BUFFERS:          # the dense gradient buffer kept across steps, zero outside the rows of the step that wrote it (ops.TrilinearGatherFn)
+            key = (shape, dtype, dev)
+            ent = ops._DP1_CACHE.get(key)
+            if ent is not None and ent[2]:
+                ent = [torch.zeros(shape, dtype=dtype, device=dev), None, True]
+            elif ent is None:
+                while len(ops._DP1_CACHE) >= 2:
+                    ops._DP1_CACHE.pop(next(iter(ops._DP1_CACHE)))
+                ent = ops._DP1_CACHE[key] = [torch.zeros(shape, dtype=dtype, device=dev), None, False]
+            ent[2] = True
+            gp1, dirty = ent[0], ent[1]
+            if dirty is not None:
+                L.check(lib.dreg_zero_rows(L.ptr(gp1), L.ptr(dirty), dirty.shape[0], C, L.dt_of(gp1), L.stream()), "dreg_zero_rows")
+            ent[1] = rows1
+            zero_dense = 0
+        else:
+            gp1 = torch.empty(shape, dtype=dtype, device=dev)
+            zero_dense = 1
+        L.check(lib.dreg_trilinear_gather_bwd_gather_seg(L.ptr(g1), L.ptr(descs), L.ptr(idx), L.ptr(pt_batch), L.ptr(rows1), rows1.shape[0], L.ptr(fmap),
+                                                         L.ptr(gp1), idx.shape[0], B, d, h, w, C, Zr, Xr, Yr, L.dt_of(gp1), zero_dense, L.stream()),
+                "dreg_trilinear_gather_bwd_gather_seg")
+        return gp1, None, None, None, None, None, None
+
+
+def gather_subsample_applies(p1, rows1, plans) -> bool:
+    """The fused node needs the gather's deterministic per-S1-voxel backward (C a multiple of 64 up to 256, a row list) and at least one
+    voxel-average round in every pair."""
+    return p1.is_cuda and rows1 is not None and p1.shape[-1] % 64 == 0 and p1.shape[-1] <= 256 and all(len(r) >= 1 for r in plans)
+
+
+def gather_subsample(p1, idx, pt_batch, fine_res, rows1, plans, sizes):
+    """[B,d,h,w,C] -> [sum of the pairs' key points, C] fp32: trilinear gather at the occupied fine voxels + every pair's voxel-average rounds."""
+    return _GatherSubsampleFn.apply(p1, idx, pt_batch, fine_res, rows1, plans, sizes)
+
+
 def subsample_all(feats, plans, sizes):
     """[N_total, C] -> [sum of the pairs' key points, C]: every pair's voxel-average rounds, one autograd node."""
     return _SubsampleAllFn.apply(feats, plans, sizes)

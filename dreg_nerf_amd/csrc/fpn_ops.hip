@@ -1177,8 +1177,8 @@ __global__ void trilinear_gather_bwd_rows_kernel(const float* __restrict__ dfeat
     }
 }
 // Deterministic (atomic-free) form: one wave per S1 voxel gathers the contributions of the occupied fine voxels whose
-// trilinear corner set contains it.  fine_map[b][idx] = point index or -1.  Candidates per axis: the <= 6 fine coordinates with
-// i*s in (c-1, c+1), each tested with tri_axis() itself, so the weights are the forward's bit for bit.
+// trilinear corner set contains it.  fine_map[b][idx] = point index or -1.  Candidates per axis: the <= 5 fine coordinates with
+// i*s in (c-1, c+1) (tri_range), each tested with tri_axis() itself, so the weights are the forward's bit for bit.
 __global__ void fine_map_fill_kernel(const int64_t* __restrict__ idx, const int* __restrict__ pt_batch, int* __restrict__ fine_map, int N, size_t Vf)
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1186,18 +1186,28 @@ __global__ void fine_map_fill_kernel(const int64_t* __restrict__ idx, const int*
 }
 __device__ __forceinline__ void tri_range(int c, int n_out, int n_in, int& lo, int& hi) {
     if (n_out <= 1 || n_in <= 1) { lo = 0; hi = n_out - 1; return; }
+    // fine coordinates i whose source coordinate i * s (tri_axis) lies strictly inside (c - 1, c + 1): i in ((c-1)/s, (c+1)/s), widened by
+    // 0.01 against the rounding of the two products (coordinates < 2^16: errors ~1e-3 at most) — at most 5 per axis at a 2:1 ratio, so the
+    // 125 candidates of a coarse voxel take two rounds of the 64 lanes (the former floor - 1 / ceil + 1 bracket: 7 per axis, six rounds)
     const float inv = (float)(n_out - 1) / (float)(n_in - 1);
-    lo = max(0, (int)floorf((float)(c - 1) * inv) - 1);
-    hi = min(n_out - 1, (int)ceilf((float)(c + 1) * inv) + 1);
+    lo = max(0, (int)floorf((float)(c - 1) * inv - 0.01f) + 1);
+    hi = min(n_out - 1, (int)ceilf((float)(c + 1) * inv + 0.01f) - 1);
 }
 __device__ __forceinline__ float tri_weight(int i, int c, int n_out, int n_in) {
     const TriAxis a = tri_axis(i, n_out, n_in);
     return (a.i0 == c ? 1.f - a.t : 0.f) + (a.i1 == c ? a.t : 0.f);
 }
-template <typename T, int CPL>
+// SEG: the gradient of the gathered features is not materialised — the features went straight into the first voxel-average round of
+// their pair (grid_downsample.py:6-94), so d(feats)[n] = g1[inv_seg[n]] * inv_cnt[n] with g1 the gradient of that round's output (one
+// sixth of the rows: L2-resident): dfeat = g1 (the pairs' blocks one after the other), seg[grid] = (inv_seg, inv_cnt, first point, first
+// g1 row) of the grid's pair.  The product is rounded to fp32 before it is weighted, exactly as the stored d(feats) was: bit-identical.
+struct TriSegDesc { const uint32_t* inv_seg; const float* inv_cnt; long long point_start, row_off; };
+static_assert(sizeof(TriSegDesc) == 32, "int64 [B][4] on the Python side");
+template <typename T, int CPL, bool SEG = false>
 __global__ __launch_bounds__(256) void trilinear_gather_bwd_gather_kernel(const float* __restrict__ dfeat, const int* __restrict__ fine_map,
                                                                           const int* __restrict__ rows1, int n1, T* __restrict__ dp1,
-                                                                          int d, int h, int w, int Zr, int Xr, int Yr)
+                                                                          int d, int h, int w, int Zr, int Xr, int Yr,
+                                                                          const TriSegDesc* __restrict__ seg = nullptr)
 {
     constexpr int C = CPL * 64;
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1221,13 +1231,22 @@ __global__ __launch_bounds__(256) void trilinear_gather_bwd_gather_kernel(const 
             wgt = tri_weight(z, zc, Zr, d) * tri_weight(x, xc, Xr, h) * tri_weight(y, yc, Yr, w);
             if (wgt != 0.f) n = fine_map[(size_t)b * Vf + ((size_t)x * Yr + y) * Zr + z];
         }
+        float scl = 1.f;
+        if constexpr (SEG) {
+            if (n >= 0) {
+                const TriSegDesc sd = seg[b];
+                const long long loc = (long long)n - sd.point_start;
+                scl = sd.inv_cnt[loc];
+                n = (int)((long long)sd.inv_seg[loc] + sd.row_off);
+            }
+        }
         unsigned long long m = __ballot(n >= 0);
         // four contributing points per round: their rows are requested together and added in the same (ascending) order — one row in
         // flight per wave made the kernel a chain of ~20 memory round trips per coarse voxel
         while (m) {
             constexpr int U = 4;
             int nn[U];
-            float ww[U], r[U][CPL];
+            float ww[U], ss[U], r[U][CPL];
             bool ok[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -1236,6 +1255,7 @@ __global__ __launch_bounds__(256) void trilinear_gather_bwd_gather_kernel(const 
                 if (ok[u]) m &= m - 1;
                 nn[u] = __shfl(n, l, 64);
                 ww[u] = __shfl(wgt, l, 64);
+                if constexpr (SEG) ss[u] = __shfl(scl, l, 64);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -1243,6 +1263,14 @@ __global__ __launch_bounds__(256) void trilinear_gather_bwd_gather_kernel(const 
 #pragma unroll
                     for (int k = 0; k < CPL; ++k) r[u][k] = dfeat[(size_t)nn[u] * C + lane + 64 * k];
                 }
+            if constexpr (SEG) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (ok[u]) {
+#pragma unroll
+                        for (int k = 0; k < CPL; ++k) r[u][k] = r[u][k] * ss[u];
+                    }
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (ok[u]) {
@@ -2217,7 +2245,15 @@ int dreg_zero_rows(void* buf, const int* rows, int nrows, int C, int dtype, void
 // zero_dense = 0: dp1 is already zero outside rows1 (a persistent buffer the caller cleans with dreg_zero_rows); only rows1 are written.
 static int tri_bwd_gather(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
                           int* fine_map, void* dp1, int N, int B, int d, int h, int w, int C, int Zr, int Xr, int Yr,
-                          int dtype, int zero_dense, void* stream);
+                          int dtype, int zero_dense, void* stream, const void* seg = nullptr);
+// The same with the gradient of the gathered features given through the first voxel-average round that consumed them: g1 fp32 [rows, C] =
+// gradient of that round's outputs (the pairs' blocks one after the other), seg_descs: device int64 [B][4] = per grid (inv_seg pointer,
+// inv_cnt pointer, index of its pair's first point, first g1 row of its pair) — see TriSegDesc.  Bit-identical to running
+// dreg_voxel_downsample_bwd per pair and handing the concatenated result to dreg_trilinear_gather_bwd_gather[_rows_only].
+int dreg_trilinear_gather_bwd_gather_seg(const float* g1, const void* seg_descs, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
+                                         int* fine_map, void* dp1, int N, int B, int d, int h, int w, int C, int Zr, int Xr, int Yr,
+                                         int dtype, int zero_dense, void* stream)
+{ return seg_descs ? tri_bwd_gather(g1, idx, pt_batch, rows1, n1, fine_map, dp1, N, B, d, h, w, C, Zr, Xr, Yr, dtype, zero_dense, stream, seg_descs) : DREG_EINVAL; }
 int dreg_trilinear_gather_bwd_gather(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
                                      int* fine_map, void* dp1, int N, int B, int d, int h, int w, int C, int Zr, int Xr, int Yr,
                                      int dtype, void* stream)
@@ -2228,7 +2264,7 @@ int dreg_trilinear_gather_bwd_gather_rows_only(const float* dfeat, const int64_t
 { return tri_bwd_gather(dfeat, idx, pt_batch, rows1, n1, fine_map, dp1, N, B, d, h, w, C, Zr, Xr, Yr, dtype, 0, stream); }
 static int tri_bwd_gather(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
                           int* fine_map, void* dp1, int N, int B, int d, int h, int w, int C, int Zr, int Xr, int Yr,
-                          int dtype, int zero_dense, void* stream)
+                          int dtype, int zero_dense, void* stream, const void* seg)
 {
     hipStream_t st = (hipStream_t)stream;
     if (C % 64 || C > 256) return DREG_EINVAL;
@@ -2240,7 +2276,8 @@ static int tri_bwd_gather(const float* dfeat, const int64_t* idx, const int* pt_
     hipLaunchKernelGGL(fine_map_fill_kernel, dim3((N + 255) / 256), dim3(256), 0, st, idx, pt_batch, fine_map, N, Vf);
     DREG_LAUNCH_CHECK();
     const dim3 grid((n1 + 3) / 4);
-#define TG_LAUNCH(T, CPL) hipLaunchKernelGGL((trilinear_gather_bwd_gather_kernel<T, CPL>), grid, dim3(256), 0, st, dfeat, fine_map, rows1, n1, (T*)dp1, d, h, w, Zr, Xr, Yr)
+#define TG_LAUNCH(T, CPL) do { if (seg) hipLaunchKernelGGL((trilinear_gather_bwd_gather_kernel<T, CPL, true>), grid, dim3(256), 0, st, dfeat, fine_map, rows1, n1, (T*)dp1, d, h, w, Zr, Xr, Yr, (const TriSegDesc*)seg); \
+        else hipLaunchKernelGGL((trilinear_gather_bwd_gather_kernel<T, CPL, false>), grid, dim3(256), 0, st, dfeat, fine_map, rows1, n1, (T*)dp1, d, h, w, Zr, Xr, Yr, (const TriSegDesc*)nullptr); } while (0)
     const int cpl = C / 64;
     if (dtype == 0) { if (cpl == 1) TG_LAUNCH(bf16_t, 1); else if (cpl == 2) TG_LAUNCH(bf16_t, 2); else if (cpl == 3) TG_LAUNCH(bf16_t, 3); else TG_LAUNCH(bf16_t, 4); }
     else { if (cpl == 1) TG_LAUNCH(float, 1); else if (cpl == 2) TG_LAUNCH(float, 2); else if (cpl == 3) TG_LAUNCH(float, 3); else TG_LAUNCH(float, 4); }

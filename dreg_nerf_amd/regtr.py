@@ -121,6 +121,7 @@ class NeRFRegTr(nn.Module):
         # with per-row occupancy flags taken from the VALUES.
         self.stem_rows = True
         self.batched_subsample = True   # the pairs' voxel-average rounds as one autograd node (attn_ops.subsample_all)
+        self.fused_gather_subsample = True   # ... together with the trilinear gather in front of them (attn_ops.gather_subsample)
         self._spec = params.regtr_spec(self.pos_emb_type)
         _build_tree(self, self._spec)
         _reset_parameters(self, self._spec)
@@ -425,13 +426,20 @@ class NeRFRegTr(nn.Module):
             x_in, row_occ = self.pack_grids(grids, self.act_dtype, table, occupancy=True)
         self._check_stem_contract(rows, row_occ)
         p1 = self.fpn(x_in, rows, row_occ if self.skip_empty_stem_rows else None)
-        feats = ops.trilinear_gather(p1, idx_cat, pb_cat, res, s1_rows, rows[3] if rows is not None else None)
         P = self._P()
         # one split (backward: one concatenation) instead of per-pair slices: autograd turns every slice of the [N_mask_total, 256]
         # feature tensor into a zero-filled full-size gradient plus an add (2.3 GB of traffic per step at 4 pairs)
         sizes = [idxs[2 * i].shape[0] + idxs[2 * i + 1].shape[0] for i in range(len(batch))]
         xyz_all = torch.cat(pts_l) if len(pts_l) > 1 else pts_l[0]
-        if feats.is_cuda and feats.dtype == torch.float32 and self.batched_subsample:
+        if self.batched_subsample and self.fused_gather_subsample and A.gather_subsample_applies(p1, s1_rows, plans):
+            # gather + rounds as one node: its backward never writes the [N_mask_total, 256] gradient of the gathered features
+            feats_all = A.gather_subsample(p1, idx_cat, pb_cat, res, s1_rows, plans, sizes)
+            feats = None
+        else:
+            feats = ops.trilinear_gather(p1, idx_cat, pb_cat, res, s1_rows, rows[3] if rows is not None else None)
+        if feats is None:
+            pass
+        elif feats.is_cuda and feats.dtype == torch.float32 and self.batched_subsample:
             feats_all = A.subsample_all(feats, plans, sizes)       # the same launches, results / gradients written in place (no cat)
         else:
             feat_l = [T.apply_subsample_plan(plans[i], f) for i, f in enumerate(feats.split(sizes))]

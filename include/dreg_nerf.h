@@ -293,6 +293,13 @@ int dreg_trilinear_gather_bwd_gather(const float* dfeat, const int64_t* idx, con
 int dreg_trilinear_gather_bwd_gather_rows_only(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
                                                int* fine_map, void* dp1, int N, int B, int d, int h, int w, int C, int Zr, int Xr, int Yr,
                                                int dtype, void* stream);
+/* The same with d(feats) given through the first voxel-average round that consumed the gathered features (grid_downsample.py:6-94): g1 fp32
+ * [rows, C] = gradient of that round's outputs, the pairs' blocks one after the other; seg_descs: device int64 [B][4] = per grid (inv_seg
+ * pointer, inv_cnt pointer, index of its pair's first point, first g1 row of its pair); zero_dense as the two forms above (1 = memset dp1).
+ * Bit-identical to dreg_voxel_downsample_bwd per pair + dreg_trilinear_gather_bwd_gather, without the [N, C] gradient in between. */
+int dreg_trilinear_gather_bwd_gather_seg(const float* g1, const void* seg_descs, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
+                                         int* fine_map, void* dp1, int N, int B, int d, int h, int w, int C, int Zr, int Xr, int Yr,
+                                         int dtype, int zero_dense, void* stream);
 int dreg_zero_rows(void* buf, const int* rows, int nrows, int C, int dtype, void* stream);
 int dreg_colsum_rows(const void* g, const int* rows, int nrows, float* out, float* workspace, int C, int accumulate,
                      int dtype, void* stream);

@@ -291,29 +291,33 @@ def test_own_sort_and_segments_equal_the_rocprim_form_bit_for_bit(n, nbatch):
     assert torch.all(order[1:][same] > order[:-1][same])
 
 
-def test_batched_subsample_node_changes_nothing():
-    """attn_ops.subsample_all (every pair's voxel-average rounds as ONE autograd node that writes results / gradients in place) against the
-    per-pair nodes + torch.cat / split: the same launches on the same data — losses, gradient norm and every gradient bit for bit."""
+def test_batched_subsample_and_fused_gather_nodes_change_nothing():
+    """attn_ops.subsample_all (every pair's voxel-average rounds as ONE autograd node that writes results / gradients in place) and
+    attn_ops.gather_subsample (the trilinear gather in front of them in the same node: its backward reads the features' gradient through
+    the first round instead of a materialised [N, 256] tensor) against the per-pair nodes + torch.cat / split: the same arithmetic in the
+    same order — losses, gradient norm and every gradient bit for bit."""
     from dreg_nerf_amd import params, synth
     from dreg_nerf_amd.regtr import NeRFRegTr
     from dreg_nerf_amd.train_step import TrainStep
     dev = torch.device("cuda", 0)
     res = []
-    for batched in (False, True):
+    for batched, fused in ((False, False), (True, False), (True, True)):
         torch.manual_seed(3407)
         m = NeRFRegTr(precision="bf16")
         m.load_state_dict(params.synth_state_dict(0, profile="wc"), strict=True)
         m = m.to(dev).train()
-        m.batched_subsample = batched
+        m.batched_subsample, m.fused_gather_subsample = batched, fused
         ts = TrainStep(m)
         batch = []
         for i in range(2):
             d = synth.shell_pair(64, 1 + 2 * i, 2 + 2 * i, pose=synth.fixed_pose())
             batch.append({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()})
-        out = ts.step(batch)
+        for _ in range(2):                       # two steps: the second one runs on the persistent gradient buffer the first one dirtied
+            out = ts.step(batch)
         torch.cuda.synchronize()
         res.append(({k: float(v) for k, v in out["losses"].items()}, float(out["grad_norm"]),
                     {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
-    assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
-    for k in res[0][2]:
-        assert torch.equal(res[0][2][k], res[1][2][k]), k
+    for r in res[1:]:
+        assert res[0][0] == r[0] and res[0][1] == r[1]
+        for k in res[0][2]:
+            assert torch.equal(res[0][2][k], r[2][k]), k
