@@ -495,7 +495,8 @@ class _SubsampleAllFn(torch.autograd.Function):
 
 
 class _GatherSubsampleFn(torch.autograd.Function):
-    """ops.trilinear_gather followed by subsample_all as ONE autograd node (nerf_regtr.py:138-168): forward = the two forwards; backward:
+    """ops.trilinear_gather followed by subsample_all as ONE autograd node (nerf_regtr.py:138-168): forward = the first round of every pair
+    straight from the feature map (dreg_gather_segment_mean), the other rounds as subsample_all; backward:
     the voxel-average rounds are differentiated down to the FIRST round's outputs only, and the gather's backward reads the gradient of
     the gathered features through that round (d feats[n] = g1[inv_seg[n]] * inv_cnt[n]: dreg_trilinear_gather_bwd_gather_seg) — the
     [N_total, 256] fp32 gradient (150 MB at 4 pairs) is never written, the gather reads rows of a tensor a sixth of its size.  Same
@@ -503,9 +504,32 @@ class _GatherSubsampleFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, p1, idx, pt_batch, fine_res, rows1, plans, sizes):
-        from . import ops
-        feats = ops.TrilinearGatherFn.forward(ctx, p1, idx, pt_batch, fine_res, rows1, None)      # saves idx / pt_batch / rows1, sets ctx.cfg
-        out = _SubsampleAllFn.forward(ctx, feats, plans, sizes)                                   # sets ctx.plans / sizes / n_out
+        lib = L.load()
+        p1 = p1.contiguous()
+        B, d, h, w, C = p1.shape
+        Zr, Xr, Yr = fine_res
+        dev = p1.device
+        n_out = [rounds[-1].n_out for rounds in plans]
+        out = torch.empty(sum(n_out), C, dtype=torch.float32, device=dev)
+        io, oo = 0, 0
+        for rounds, sz, no in zip(plans, sizes, n_out):
+            # round 0 straight from p1 (dreg_gather_segment_mean: the [N_total, C] gathered features are never written), the others as subsample_all
+            x = None
+            for k, rnd in enumerate(rounds):
+                y = out[oo:oo + no] if k == len(rounds) - 1 else torch.empty(rnd.n_out, C, dtype=torch.float32, device=dev)
+                if k == 0:
+                    assert rnd.n_in == sz
+                    L.check(lib.dreg_gather_segment_mean(L.ptr(p1), L.ptr(idx), L.ptr(pt_batch), io, L.ptr(rnd.order), L.ptr(rnd.starts), L.ptr(rnd.n_out_dev),
+                                                         L.ptr(y), rnd.n_out, d, h, w, C, Zr, Xr, Yr, L.dt_of(p1), L.stream()), "dreg_gather_segment_mean")
+                else:
+                    L.check(lib.dreg_voxel_segment_mean(L.ptr(x), L.ptr(rnd.order), L.ptr(rnd.starts), L.ptr(rnd.n_out_dev), L.ptr(y),
+                                                        rnd.n_out, C, L.stream()), "dreg_voxel_segment_mean")
+                x = y
+            io += sz
+            oo += no
+        ctx.save_for_backward(idx, pt_batch, rows1, None)
+        ctx.cfg = (tuple(p1.shape), p1.dtype, fine_res)
+        ctx.plans, ctx.sizes, ctx.n_out = plans, sizes, n_out
         return out
 
     @staticmethod

@@ -1132,6 +1132,55 @@ __global__ void trilinear_gather_fwd_kernel(const T* __restrict__ p1, const int6
         }
     }
 }
+// The gather fused with the first voxel-average round that consumes it (grid_downsample.py:6-94 on the gathered features): one wave per
+// output row sums its members' trilinear samples — every sample formed exactly as trilinear_gather_fwd_kernel forms it (corner order,
+// fp32 products and sums), the members added in ascending order and scaled as segment_mean_kernel does: bit-identical to the two
+// launches, without the [N, C] fp32 feature tensor between them (150 MB written and read back per step at 4 pairs).
+// order / starts / nseg: the round's plan (member indices are local to the pair: + point_start).
+template <typename T>
+__global__ __launch_bounds__(256) void gather_segment_mean_kernel(const T* __restrict__ p1, const int64_t* __restrict__ idx, const int* __restrict__ pt_batch,
+                                                                  int point_start, const uint32_t* __restrict__ order, const uint32_t* __restrict__ starts,
+                                                                  const int* __restrict__ nseg, float* __restrict__ out,
+                                                                  int d, int h, int w, int C, int Zr, int Xr, int Yr)
+{
+    const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (seg >= *nseg) return;
+    const uint32_t s0 = starts[seg], s1 = starts[seg + 1];
+    const float inv = 1.f / (float)(s1 - s0);
+    for (int c0 = lane * 4; c0 < C; c0 += 256) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (uint32_t j = s0; j < s1; ++j) {
+            const int n = point_start + (int)order[j];
+            const int64_t f = idx[n];
+            const int z = (int)(f % Zr), y = (int)((f / Zr) % Yr), x = (int)(f / ((int64_t)Zr * Yr));
+            const int b = pt_batch[n];
+            const TriAxis az = tri_axis(z, Zr, d), ax = tri_axis(x, Xr, h), ay = tri_axis(y, Yr, w);
+            float v[8][4], wg[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int zi = (c & 4) ? az.i1 : az.i0, xi = (c & 2) ? ax.i1 : ax.i0, yi = (c & 1) ? ay.i1 : ay.i0;
+                wg[c] = ((c & 4) ? az.t : 1.f - az.t) * ((c & 2) ? ax.t : 1.f - ax.t) * ((c & 1) ? ay.t : 1.f - ay.t);
+                const T* src = p1 + ((((size_t)b * d + zi) * h + xi) * w + yi) * C + c0;
+                if constexpr (sizeof(T) == 2) {
+                    const uint2 q = *reinterpret_cast<const uint2*>(src);
+                    v[c][0] = __uint_as_float(q.x << 16); v[c][1] = __uint_as_float(q.x & 0xffff0000u);
+                    v[c][2] = __uint_as_float(q.y << 16); v[c][3] = __uint_as_float(q.y & 0xffff0000u);
+                } else {
+                    const float4 q = *reinterpret_cast<const float4*>(src);
+                    v[c][0] = q.x; v[c][1] = q.y; v[c][2] = q.z; v[c][3] = q.w;
+                }
+            }
+            float smp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) smp[k] += v[c][k] * wg[c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += smp[k];
+        }
+        *reinterpret_cast<float4*>(out + (size_t)seg * C + c0) = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+    }
+}
 // backward: scatter-add of dfeats into an fp32 grid gradient (atomics; the gradient is sparse around the mask)
 template <typename TG>
 __global__ void trilinear_gather_bwd_kernel(const TG* __restrict__ dfeat, const int64_t* __restrict__ idx, const int* __restrict__ pt_batch,
@@ -2246,6 +2295,20 @@ int dreg_zero_rows(void* buf, const int* rows, int nrows, int C, int dtype, void
 static int tri_bwd_gather(const float* dfeat, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
                           int* fine_map, void* dp1, int N, int B, int d, int h, int w, int C, int Zr, int Xr, int Yr,
                           int dtype, int zero_dense, void* stream, const void* seg = nullptr);
+// Trilinear gather fused with the first voxel-average round of ONE pair (see gather_segment_mean_kernel): p1 [B,d,h,w,C] (dtype 0 bf16 / 1
+// fp32), idx / pt_batch of ALL points, point_start = index of the pair's first point, order / starts / n_out = the round's plan
+// (dreg_voxel_downsample_plan), out fp32 [M, C] (rows beyond *n_out untouched).  C a multiple of 4.
+int dreg_gather_segment_mean(const void* p1, const int64_t* idx, const int* pt_batch, int point_start, const uint32_t* order, const uint32_t* starts,
+                             const int* n_out, float* out, int M, int d, int h, int w, int C, int Zr, int Xr, int Yr, int dtype, void* stream)
+{
+    if (M <= 0) return DREG_OK;
+    if (C % 4 || point_start < 0) return DREG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0) hipLaunchKernelGGL(gather_segment_mean_kernel<bf16_t>, dim3((M + 3) / 4), dim3(256), 0, st, (const bf16_t*)p1, idx, pt_batch, point_start, order, starts, n_out, out, d, h, w, C, Zr, Xr, Yr);
+    else hipLaunchKernelGGL(gather_segment_mean_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, st, (const float*)p1, idx, pt_batch, point_start, order, starts, n_out, out, d, h, w, C, Zr, Xr, Yr);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
 // The same with the gradient of the gathered features given through the first voxel-average round that consumed them: g1 fp32 [rows, C] =
 // gradient of that round's outputs (the pairs' blocks one after the other), seg_descs: device int64 [B][4] = per grid (inv_seg pointer,
 // inv_cnt pointer, index of its pair's first point, first g1 row of its pair) — see TriSegDesc.  Bit-identical to running

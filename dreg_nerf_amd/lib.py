@@ -126,6 +126,7 @@ SIGNATURES = {
     "dreg_trilinear_gather_bwd_gather": (I, [P, P, P, P, I, P, P] + [I] * 10 + [P]),
     "dreg_trilinear_gather_bwd_gather_rows_only": (I, [P, P, P, P, I, P, P] + [I] * 10 + [P]),
     "dreg_trilinear_gather_bwd_gather_seg": (I, [P, P, P, P, P, I, P, P] + [I] * 11 + [P]),
+    "dreg_gather_segment_mean": (I, [P, P, P, I, P, P, P, P] + [I] * 9 + [P]),
     "dreg_zero_rows": (I, [P, P, I, I, I, P]),
     "dreg_add_inplace": (I, [P, P, Z, I, P]),
     "dreg_pack_rgba_grids": (I, [P, P, I, I, I, I, I, P]),

@@ -300,6 +300,11 @@ int dreg_trilinear_gather_bwd_gather_rows_only(const float* dfeat, const int64_t
 int dreg_trilinear_gather_bwd_gather_seg(const float* g1, const void* seg_descs, const int64_t* idx, const int* pt_batch, const int* rows1, int n1,
                                          int* fine_map, void* dp1, int N, int B, int d, int h, int w, int C, int Zr, int Xr, int Yr,
                                          int dtype, int zero_dense, void* stream);
+/* nerf_regtr.py:138-168, forward: the trilinear gather fused with the first voxel-average round of ONE pair — out[seg] = mean over the round's
+ * members of their trilinear samples (bit-identical to dreg_trilinear_gather_fwd + dreg_voxel_segment_mean; the [N, C] features are never
+ * written).  idx / pt_batch: all points; point_start: the pair's first point; order / starts / n_out: the round's plan. */
+int dreg_gather_segment_mean(const void* p1, const int64_t* idx, const int* pt_batch, int point_start, const uint32_t* order, const uint32_t* starts,
+                             const int* n_out, float* out, int M, int d, int h, int w, int C, int Zr, int Xr, int Yr, int dtype, void* stream);
 int dreg_zero_rows(void* buf, const int* rows, int nrows, int C, int dtype, void* stream);
 int dreg_colsum_rows(const void* g, const int* rows, int nrows, float* out, float* workspace, int C, int accumulate,
                      int dtype, void* stream);
