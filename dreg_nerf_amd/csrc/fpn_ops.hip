@@ -1513,7 +1513,36 @@ __device__ __forceinline__ int rows_lower_bound(const int* __restrict__ rows, in
     while (lo < hi) { const int mid = (lo + hi) >> 1; if ((long long)rows[mid] < key) lo = mid + 1; else hi = mid; }
     return lo;
 }
-constexpr int SSTEM_NCH = 64;       // chunks a grid's list segment is split into (statistics passes)
+// [s, e) = grid b's segment of an ascending row list, found by the block's first wave: the two bounds side by side (lanes 0-31 / 32-63), 32
+// probes per round (four rounds of dependent loads for 2^18 rows instead of the 2 x 18 of two scalar binary searches), published through LDS.
+// Every thread of the block must call it (it ends with a barrier).
+__device__ __forceinline__ void rows_segment(const int* __restrict__ rows, int n, long long V, int b, int& s, int& e)
+{
+    __shared__ int seg_bounds[2];
+    if (threadIdx.x < 64) {
+        const int half = threadIdx.x >> 5, l = threadIdx.x & 31;
+        const long long key = (long long)(b + half) * V;
+        int lo = 0, hi = n;                                   // first index with rows[i] >= key lies in [lo, hi]
+        while (hi - lo > 0) {
+            const int span = hi - lo;
+            const int pos = lo + (int)(((long long)span * (l + 1)) / 33);      // 32 probes strictly inside or at lo .. hi - 1
+            const int p = pos < hi ? pos : hi - 1;
+            const bool less = (long long)rows[p] < key;
+            const unsigned long long m = __ballot(less);
+            const unsigned mm = (unsigned)(half ? (m >> 32) : (m & 0xffffffffull));
+            const int cnt = __popc(mm);                       // probes are ascending, the predicate is monotone: the first cnt are true
+            // new bracket: after the last true probe, up to the first false probe
+            const int p_last_true = cnt > 0 ? __shfl(p, (half << 5) + cnt - 1, 64) : lo - 1;
+            const int p_first_false = cnt < 32 ? __shfl(p, (half << 5) + cnt, 64) : hi;
+            lo = p_last_true + 1;
+            hi = p_first_false;
+        }
+        if (l == 0) seg_bounds[half] = lo;
+    }
+    __syncthreads();
+    s = seg_bounds[0]; e = seg_bounds[1];
+}
+constexpr int SSTEM_NCH = 128;      // chunks a grid's list segment is split into (statistics passes)
 // partial[b][chunk0 + chunk][c][2] over the chunk's piece of grid b's list segment.  MODE 0: (sum x, sum x^2) of x at the rows;
 // MODE 1: (sum g, sum g*xhat), g = dl at the row masked by the ReLU (x*scale + shift > 0).  grid (SSTEM_NCH, B, slabs).
 template <int MODE>
@@ -1524,7 +1553,8 @@ __device__ __forceinline__ void sstem_rows_sums(const bf16_t* __restrict__ x, co
     constexpr int G = 8;
     const int CG = C / G, cgs = CG < 256 ? CG : 256, rpi = 256 / cgs;
     const int t = threadIdx.x, cg = blockIdx.z * cgs + (t % cgs), r0 = t / cgs, b = blockIdx.y;
-    const int s = rows_lower_bound(rows, n, (long long)b * V), e = rows_lower_bound(rows, n, (long long)(b + 1) * V);
+    int s, e;
+    rows_segment(rows, n, V, b, s, e);
     const int len = e - s;
     const int i0 = s + (int)((long long)len * chunk / nch), i1 = s + (int)((long long)len * (chunk + 1) / nch);
     float s1[G], s2[G], mu[G], rs[G], sc[G], sh[G];
@@ -1536,21 +1566,34 @@ __device__ __forceinline__ void sstem_rows_sums(const bf16_t* __restrict__ x, co
             mu[i] = mean_rstd[pc]; rs[i] = mean_rstd[pc + 1]; sc[i] = scale_shift[pc]; sh[i] = scale_shift[pc + 1];
         }
     }
-    if (r0 < rpi && cg < CG)
-        for (int v = i0 + r0; v < i1; v += rpi) {
-            const size_t off = (size_t)rows[v] * C + (size_t)cg * G;
-            float xv[G], gv[G];
-            Gran<bf16_t>::ld(x + off, xv);
-            if (MODE == 1) Gran<bf16_t>::ld(dl + off, gv);
+    if (r0 < rpi && cg < CG) {
+        constexpr int UN = 4;                       // rows in flight per thread (added in row order)
+        for (int v = i0 + r0; v < i1; v += rpi * UN) {
+            uint4 xq[UN], gq[UN];
 #pragma unroll
-            for (int k = 0; k < G; ++k) {
-                if (MODE == 0) { s1[k] += xv[k]; s2[k] += xv[k] * xv[k]; }
-                else {
-                    const float g = (relu && !((xv[k] * sc[k] + sh[k]) > 0.f)) ? 0.f : gv[k];
-                    s1[k] += g; s2[k] += g * (xv[k] - mu[k]) * rs[k];
+            for (int u = 0; u < UN; ++u)
+                if (v + u * rpi < i1) {
+                    const size_t off = (size_t)rows[v + u * rpi] * C + (size_t)cg * G;
+                    xq[u] = *reinterpret_cast<const uint4*>(x + off);
+                    if (MODE == 1) gq[u] = *reinterpret_cast<const uint4*>(dl + off);
                 }
-            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (v + u * rpi < i1) {
+                    float xv[G], gv[G];
+                    Gran<bf16_t>::unpack(xq[u], xv);
+                    if (MODE == 1) Gran<bf16_t>::unpack(gq[u], gv);
+#pragma unroll
+                    for (int k = 0; k < G; ++k) {
+                        if (MODE == 0) { s1[k] += xv[k]; s2[k] += xv[k] * xv[k]; }
+                        else {
+                            const float g = (relu && !((xv[k] * sc[k] + sh[k]) > 0.f)) ? 0.f : gv[k];
+                            s1[k] += g; s2[k] += g * (xv[k] - mu[k]) * rs[k];
+                        }
+                    }
+                }
         }
+    }
 #pragma unroll
     for (int i = 0; i < G; ++i) { red[t][i] = s1[i]; red[t][G + i] = s2[i]; }
     __syncthreads();
@@ -1591,18 +1634,24 @@ __global__ void sstem_pool_fwd_kernel(const bf16_t* __restrict__ x, const uint8_
 {
     constexpr int G = 8;
     const int CG = C / G;
-    const size_t total = (size_t)B * Do * Ho * Wo * CG;
+    const size_t total = (size_t)B * Do * Ho * Wo * CG;        // < 2^32 (checked by the host): 32-bit index arithmetic
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        int cg, ox, oy, oz, b;
-        decode_gxyzb(i, CG, Wo, Ho, Do, cg, ox, oy, oz, b);
+        uint32_t r = (uint32_t)i;
+        const int cg = (int)(r % (uint32_t)CG); r /= (uint32_t)CG;
+        const uint32_t pv = r;                                   // pooled voxel
+        const int ox = (int)(r % (uint32_t)Wo); r /= (uint32_t)Wo;
+        const int oy = (int)(r % (uint32_t)Ho); r /= (uint32_t)Ho;
+        const int oz = (int)(r % (uint32_t)Do); const int b = (int)(r / (uint32_t)Do);
         float sc[G], sh[G], best[G], xb[G];
         int bi[G];
+        {
+            const float4* ss = reinterpret_cast<const float4*>(scale_shift + ((size_t)b * C + (size_t)cg * G) * 2);    // (scale, shift) x 8: 64 bytes
 #pragma unroll
-        for (int k = 0; k < G; ++k) {
-            sc[k] = scale_shift[((size_t)b * C + cg * G + k) * 2]; sh[k] = scale_shift[((size_t)b * C + cg * G + k) * 2 + 1];
-            best[k] = -INFINITY; bi[k] = 0; xb[k] = 0.f;
+            for (int q = 0; q < 4; ++q) { const float4 v = ss[q]; sc[2 * q] = v.x; sh[2 * q] = v.y; sc[2 * q + 1] = v.z; sh[2 * q + 1] = v.w; }
         }
-        if (!pmask[i / CG]) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) { best[k] = -INFINITY; bi[k] = 0; xb[k] = 0.f; }
+        if (!pmask[pv]) {
             // every row of the window is zero: relu(0 * scale + shift) everywhere, the first in-bounds tap wins
             const int tap = ((oz == 0 ? 1 : 0) * 3 + (oy == 0 ? 1 : 0)) * 3 + (ox == 0 ? 1 : 0);
 #pragma unroll
@@ -1612,52 +1661,82 @@ __global__ void sstem_pool_fwd_kernel(const bf16_t* __restrict__ x, const uint8_
                 best[k] = bf2f(f2bf(o)); bi[k] = tap;
             }
         } else {
+            // one z-plane of the window at a time: its (up to) nine granules are requested together, then compared in tap order.  Most
+            // granules of a marked window are still all-zero (rows outside the list): their value is the constant relu(0 * scale + shift)
+            float c0[G];
+#pragma unroll
+            for (int k = 0; k < G; ++k) { float o = 0.f * sc[k] + sh[k]; o = relu ? fmaxf(o, 0.f) : o; c0[k] = bf2f(f2bf(o)); }
             for (int dz = 0; dz < 3; ++dz) {
                 const int z = oz * 2 - 1 + dz; if ((unsigned)z >= (unsigned)Di) continue;
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int yy = oy * 2 - 1 + dy; if ((unsigned)yy >= (unsigned)Hi) continue;
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const int xx = ox * 2 - 1 + dx; if ((unsigned)xx >= (unsigned)Wi) continue;
-                        float v[G];
-                        Gran<bf16_t>::ld(x + ((((size_t)b * Di + z) * Hi + yy) * Wi + xx) * C + (size_t)cg * G, v);
-                        const int tap = (dz * 3 + dy) * 3 + dx;
+                uint4 q[9];
+                bool ok[9];
 #pragma unroll
-                        for (int k = 0; k < G; ++k) {
-                            float o = v[k] * sc[k] + sh[k];
-                            o = relu ? fmaxf(o, 0.f) : o;
-                            o = bf2f(f2bf(o));
-                            if (o > best[k]) { best[k] = o; bi[k] = tap; xb[k] = v[k]; }
-                        }
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = oy * 2 - 1 + t / 3, xx = ox * 2 - 1 + t % 3;
+                    ok[t] = (unsigned)yy < (unsigned)Hi && (unsigned)xx < (unsigned)Wi;
+                    if (ok[t]) q[t] = *reinterpret_cast<const uint4*>(x + ((((size_t)b * Di + z) * Hi + yy) * Wi + xx) * C + (size_t)cg * G);
+                }
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    if (!ok[t]) continue;
+                    const int tap = dz * 9 + t;
+                    if ((q[t].x | q[t].y | q[t].z | q[t].w) == 0u) {          // +0.0 in all eight channels
+#pragma unroll
+                        for (int k = 0; k < G; ++k)
+                            if (c0[k] > best[k]) { best[k] = c0[k]; bi[k] = tap; xb[k] = 0.f; }
+                        continue;
+                    }
+                    float v[G];
+                    Gran<bf16_t>::unpack(q[t], v);
+#pragma unroll
+                    for (int k = 0; k < G; ++k) {
+                        float o = v[k] * sc[k] + sh[k];
+                        o = relu ? fmaxf(o, 0.f) : o;
+                        o = bf2f(f2bf(o));
+                        if (o > best[k]) { best[k] = o; bi[k] = tap; xb[k] = v[k]; }
                     }
                 }
             }
         }
         Gran<bf16_t>::st(y + i * G, best);
         Gran<bf16_t>::st(xam + i * G, xb);
-#pragma unroll
-        for (int k = 0; k < G; ++k) arg[i * G + k] = (uint8_t)bi[k];
+        *reinterpret_cast<uint2*>(arg + i * G) = make_uint2((uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24),
+                                                            (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24));
     }
 }
-// a = relu(x * scale + shift) on a row list
-__global__ void sstem_apply_rows_kernel(const bf16_t* __restrict__ x, const int* __restrict__ rows, int n, const float* __restrict__ scale_shift,
-                                        bf16_t* __restrict__ a, int V, int C, int relu)
+// a = relu(x * scale + shift) on a row list: grid (chunks, B, slabs) over the pieces of grid b's list segment, a thread keeps one channel
+// granule's parameters in registers and walks down the piece's rows
+constexpr int SSTEM_NCH_ROWS = 128;
+__global__ __launch_bounds__(256) void sstem_apply_rows_kernel(const bf16_t* __restrict__ x, const int* __restrict__ rows, int n, const float* __restrict__ scale_shift,
+                                                               bf16_t* __restrict__ a, int V, int C, int relu)
 {
     constexpr int G = 8;
-    const int CG = C / G;
-    const size_t total = (size_t)n * CG;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % CG);
-        const size_t row = (size_t)rows[i / CG];
-        const int b = (int)(row / V);
-        float v[G];
-        Gran<bf16_t>::ld(x + row * C + (size_t)cg * G, v);
+    const int CG = C / G, cgs = CG < 256 ? CG : 256, rpi = 256 / cgs;
+    const int t = threadIdx.x, cg = blockIdx.z * cgs + (t % cgs), r0 = t / cgs, b = blockIdx.y;
+    int s, e;
+    rows_segment(rows, n, V, b, s, e);
+    if (r0 >= rpi || cg >= CG) return;
+    const int len = e - s, nch = gridDim.x, chunk = blockIdx.x;
+    const int i0 = s + (int)((long long)len * chunk / nch), i1 = s + (int)((long long)len * (chunk + 1) / nch);
+    float sc[G], sh[G];
 #pragma unroll
-        for (int k = 0; k < G; ++k) {
-            const size_t pc = ((size_t)b * C + cg * G + k) * 2;
-            const float o = v[k] * scale_shift[pc] + scale_shift[pc + 1];
-            v[k] = relu ? fmaxf(o, 0.f) : o;
-        }
-        Gran<bf16_t>::st(a + row * C + (size_t)cg * G, v);
+    for (int i = 0; i < G; ++i) { sc[i] = scale_shift[((size_t)b * C + cg * G + i) * 2]; sh[i] = scale_shift[((size_t)b * C + cg * G + i) * 2 + 1]; }
+    constexpr int UN = 4;
+    for (int v = i0 + r0; v < i1; v += rpi * UN) {
+        uint4 xq[UN];
+        size_t off[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (v + u * rpi < i1) { off[u] = (size_t)rows[v + u * rpi] * C + (size_t)cg * G; xq[u] = *reinterpret_cast<const uint4*>(x + off[u]); }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (v + u * rpi < i1) {
+                float xv[G];
+                Gran<bf16_t>::unpack(xq[u], xv);
+#pragma unroll
+                for (int k = 0; k < G; ++k) { const float o = xv[k] * sc[k] + sh[k]; xv[k] = relu ? fmaxf(o, 0.f) : o; }
+                Gran<bf16_t>::st(a + off[u], xv);
+            }
     }
 }
 // backward sums: chunks [0, nchp) walk the pooled elements of grid b (g = dp masked through xam, xhat from xam), chunks [nchp, nchp + SSTEM_NCH)
@@ -1721,42 +1800,84 @@ __global__ __launch_bounds__(256) void sstem_bwd_sums_kernel(const bf16_t* __res
         for (int i = 0; i < G; ++i) { dst[2 * i] = a1[i]; dst[2 * i + 1] = a2[i]; }
     }
 }
-// dx = scale * (g - c1 - xhat * c2) on the convolution's row list; g = relu mask * (un-pooled dp [+ dl])
-__global__ void sstem_bwd_rows_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dp, const uint8_t* __restrict__ arg, const bf16_t* __restrict__ dl,
-                                      const int* __restrict__ rows, int n, const float* __restrict__ mean_rstd, const float* __restrict__ scale_shift,
-                                      const float* __restrict__ coef, bf16_t* __restrict__ dx, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int relu)
+// dx = scale * (g - c1 - xhat * c2) on the convolution's row list; g = relu mask * (un-pooled dp [+ dl]).  grid (chunks, B, slabs) over the pieces
+// of grid b's list segment, a thread keeps one channel granule's parameters in registers; the (at most eight) pooled windows that contain a
+// voxel are enumerated statically, in the z, y, x order of unpool_gather, with all their loads in flight together
+__global__ __launch_bounds__(256) void sstem_bwd_rows_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dp, const uint8_t* __restrict__ arg, const bf16_t* __restrict__ dl,
+                                                             const int* __restrict__ rows, int n, const float* __restrict__ mean_rstd, const float* __restrict__ scale_shift,
+                                                             const float* __restrict__ coef, bf16_t* __restrict__ dx, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int C, int relu)
 {
     constexpr int G = 8;
-    const int CG = C / G;
-    const size_t total = (size_t)n * CG;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int cg = (int)(i % CG);
-        const size_t row = (size_t)rows[i / CG];
-        int r = (int)row;
+    const int V = Di * Hi * Wi;
+    const int CG = C / G, cgs = CG < 256 ? CG : 256, rpi = 256 / cgs;
+    const int t = threadIdx.x, cg = blockIdx.z * cgs + (t % cgs), r0 = t / cgs, b = blockIdx.y;
+    int s, e;
+    rows_segment(rows, n, V, b, s, e);
+    if (r0 >= rpi || cg >= CG) return;
+    const int len = e - s, nch = gridDim.x, chunk = blockIdx.x;
+    const int i0 = s + (int)((long long)len * chunk / nch), i1 = s + (int)((long long)len * (chunk + 1) / nch);
+    float mu[G], rs[G], sc[G], sh[G], c1[G], c2[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const size_t pc = ((size_t)b * C + cg * G + i) * 2;
+        mu[i] = mean_rstd[pc]; rs[i] = mean_rstd[pc + 1]; sc[i] = scale_shift[pc]; sh[i] = scale_shift[pc + 1]; c1[i] = coef[pc]; c2[i] = coef[pc + 1];
+    }
+    for (int v = i0 + r0; v < i1; v += rpi) {
+        const size_t row = (size_t)rows[v];
+        int r = (int)(row - (size_t)b * V);
         const int ix = r % Wi; r /= Wi;
-        const int iy = r % Hi; r /= Hi;
-        const int iz = r % Di; const int b = r / Di;
+        const int iy = r % Hi; const int iz = r / Hi;
         const size_t off = row * C + (size_t)cg * G;
+        const uint4 xq = *reinterpret_cast<const uint4*>(x + off);
+        uint4 lq = make_uint4(0u, 0u, 0u, 0u);
+        if (dl) lq = *reinterpret_cast<const uint4*>(dl + off);
+        // windows containing voxel i: per axis the one starting at floor(i/2) and, for odd i, the next one (ascending: unpool_gather's order)
+        const int oz0 = iz >> 1, oy0 = iy >> 1, ox0 = ix >> 1;
+        uint4 gq[8];
+        uint2 aq[8];
+        bool ok[8];
+        int tp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int uz = u >> 2, uy = (u >> 1) & 1, ux = u & 1;
+            const int oz = oz0 + uz, oy = oy0 + uy, ox = ox0 + ux;
+            ok[u] = (!uz || (iz & 1)) && (!uy || (iy & 1)) && (!ux || (ix & 1)) && oz < Do && oy < Ho && ox < Wo;
+            tp[u] = ((iz - 2 * oz + 1) * 3 + (iy - 2 * oy + 1)) * 3 + (ix - 2 * ox + 1);
+            if (ok[u]) {
+                const size_t o = ((((size_t)b * Do + oz) * Ho + oy) * Wo + ox) * C + (size_t)cg * G;
+                gq[u] = *reinterpret_cast<const uint4*>(dp + o);
+                aq[u] = *reinterpret_cast<const uint2*>(arg + o);
+            }
+        }
         float xv[G], g[G], lv[G];
-        Gran<bf16_t>::ld(x + off, xv);
-        unpool_gather<bf16_t>(dp, arg, b, iz, iy, ix, Do, Ho, Wo, C, cg * G, g);
+        Gran<bf16_t>::unpack(xq, xv);
+#pragma unroll
+        for (int k = 0; k < G; ++k) g[k] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (ok[u]) {
+                float gg[G];
+                Gran<bf16_t>::unpack(gq[u], gg);
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const uint32_t a = ((k < 4 ? aq[u].x : aq[u].y) >> (8 * (k & 3))) & 0xffu;
+                    if ((int)a == tp[u]) g[k] += gg[k];
+                }
+            }
         if (dl) {
-            Gran<bf16_t>::ld(dl + off, lv);
+            Gran<bf16_t>::unpack(lq, lv);
 #pragma unroll
             for (int k = 0; k < G; ++k) g[k] += lv[k];
         }
 #pragma unroll
         for (int k = 0; k < G; ++k) {
-            const size_t pc = ((size_t)b * C + cg * G + k) * 2;
-            const float sc = scale_shift[pc], sh = scale_shift[pc + 1];
-            if (relu && !((xv[k] * sc + sh) > 0.f)) g[k] = 0.f;
-            const float xh = (xv[k] - mean_rstd[pc]) * mean_rstd[pc + 1];
-            xv[k] = sc * (g[k] - coef[pc] - xh * coef[pc + 1]);
+            if (relu && !((xv[k] * sc[k] + sh[k]) > 0.f)) g[k] = 0.f;
+            const float xh = (xv[k] - mu[k]) * rs[k];
+            xv[k] = sc[k] * (g[k] - c1[k] - xh * c2[k]);
         }
         Gran<bf16_t>::st(dx + off, xv);
     }
 }
-
 
 static inline int nblocks(size_t total, int per = 256, int cap = 8192) {
     size_t b = (total + per - 1) / per;
@@ -1986,6 +2107,8 @@ int dreg_bn_relu_maxpool_bwd(const void* x, const void* dp, const uint8_t* argma
 // Stem over a sparse volume (see the kernels above).  x: [B,Di,Hi,Wi,C] bf16, zero outside `rows` (ascending flat row indices, n of them);
 // pooled / argmax as dreg_bn_relu_maxpool_fwd; xam: bf16 [B,Do,Ho,Wo,C] (raw x of the arg-max voxels, for the backward sums); pmask: B*Do*Ho*Wo
 // bytes of scratch; act (optional): the dense-layout activation, written on rows_a only.  workspace: fp32 [B][64][C][2].
+static int g_sstem_pool_blocks = 8192;
+void dreg_sstem_set_pool_blocks(int n) { g_sstem_pool_blocks = n > 0 ? n : 8192; }    // measurement (tools/bench_sparse_stem.py)
 size_t dreg_sparse_stem_workspace_floats(int B, int Do, int Ho, int Wo, int C)
 {
     const int Vo = Do * Ho * Wo;
@@ -2007,11 +2130,12 @@ int dreg_sparse_stem_fwd(const void* x, const int* rows, int n, const int* rows_
                        scale_shift, mean_rstd, B, SSTEM_NCH, C, V, eps, momentum, train);
     DREG_LAUNCH_CHECK();
     const size_t Po = (size_t)B * Do * Ho * Wo;
+    if (Po * CG > 0xffffffffull) return DREG_EINVAL;
     if (hipMemsetAsync(pmask, 0, Po, st) != hipSuccess) return DREG_ELAUNCH;
     if (n > 0) hipLaunchKernelGGL(sstem_pool_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rows, n, pmask, Di, Hi, Wi, Do, Ho, Wo);
-    hipLaunchKernelGGL(sstem_pool_fwd_kernel, dim3(nblocks(Po * CG)), dim3(256), 0, st, (const bf16_t*)x, pmask, scale_shift, (bf16_t*)pooled, argmax, (bf16_t*)xam,
+    hipLaunchKernelGGL(sstem_pool_fwd_kernel, dim3(nblocks(Po * CG, 256, g_sstem_pool_blocks)), dim3(256), 0, st, (const bf16_t*)x, pmask, scale_shift, (bf16_t*)pooled, argmax, (bf16_t*)xam,
                        B, Di, Hi, Wi, Do, Ho, Wo, C, relu);
-    if (act && n_a > 0) hipLaunchKernelGGL(sstem_apply_rows_kernel, dim3(nblocks((size_t)n_a * CG)), dim3(256), 0, st, (const bf16_t*)x, rows_a, n_a, scale_shift, (bf16_t*)act, V, C, relu);
+    if (act && n_a > 0) hipLaunchKernelGGL(sstem_apply_rows_kernel, dim3(SSTEM_NCH_ROWS, B, slabs), dim3(256), 0, st, (const bf16_t*)x, rows_a, n_a, scale_shift, (bf16_t*)act, V, C, relu);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
@@ -2033,7 +2157,7 @@ int dreg_sparse_stem_bwd(const void* x, const void* dp, const uint8_t* argmax, c
     DREG_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64 * (B < 8 ? B : 8)), 0, st, workspace, coef, dgamma, dbeta, B, nch, C, V, accumulate);
     DREG_LAUNCH_CHECK();
-    if (n > 0) hipLaunchKernelGGL(sstem_bwd_rows_kernel, dim3(nblocks((size_t)n * CG)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dp, argmax, lat ? (const bf16_t*)dl : nullptr,
+    if (n > 0) hipLaunchKernelGGL(sstem_bwd_rows_kernel, dim3(SSTEM_NCH_ROWS, B, slabs), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dp, argmax, lat ? (const bf16_t*)dl : nullptr,
                                   rows, n, mean_rstd, scale_shift, coef, (bf16_t*)dx, Di, Hi, Wi, Do, Ho, Wo, C, relu);
     DREG_LAUNCH_CHECK();
     return DREG_OK;

@@ -79,6 +79,7 @@ SIGNATURES = {
     "dreg_bn_set_small_regs": (None, [I]),
     "dreg_exec_set_fuse_stem": (None, [I]),
     "dreg_exec_set_sparse_stem": (None, [I]),
+    "dreg_sstem_set_pool_blocks": (None, [I]),
     "dreg_exec_set_fuse_bn_stats": (None, [I]),
     "dreg_exec_set_brick": (None, [I]),
     "dreg_voxel_set_own_sort": (None, [I]),
