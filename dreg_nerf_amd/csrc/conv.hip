@@ -612,7 +612,7 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
             pm[u] = (m0 + row < nrows) ? (rowlist ? (uint32_t)rowlist[m0 + row] : m0 + row) : 0xffffffffu;
         }
         if constexpr (EPF > 1) {
-            if (addend) {
+            if (addend && add_shift >= 0) {
 #pragma unroll
                 for (int u = 0; u < EPF; ++u) {
                     pq[u] = make_uint4(0u, 0u, 0u, 0u);
@@ -641,7 +641,7 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += bias8[e];
             }
-            if (addend) {
+            if (addend && add_shift >= 0) {
                 int b, z, y, x;
                 vox_decode(m, g, b, z, y, x);
                 const TO* ap = addend + ((size_t)((b * Da + (z >> add_shift)) * Ha + (y >> add_shift)) * Wa + (x >> add_shift)) * g.Cout + n;
@@ -681,6 +681,15 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
                 const int zf = 2 * z + (p >> 2), yf = 2 * y + ((p >> 1) & 1), xf = 2 * x + (p & 1);
                 if (zf >= Da || yf >= Ha || xf >= Wa) continue;
                 dst = out + ((size_t)((b * Da + zf) * Ha + yf) * Wa + xf) * cin + ci;
+                if constexpr (sizeof(TO) == 2) {
+                    if (addend) {      // accumulating form (addend == out): a second contribution to an existing gradient, added in fp32 at the
+                                       // voxel the class lands on — one rounding, no temporary + add pass (dreg_conv3d_dgrad_s2_acc)
+                        const uint4 q = *reinterpret_cast<const uint4*>(dst);
+                        const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(w4[e] << 16); v[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u); }
+                    }
+                }
             }
             if constexpr (sizeof(TO) == 4) {
                 *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
@@ -2278,6 +2287,7 @@ int dreg_conv3d_igemm(const void* in, const void* wt_packed, void* out, const fl
                                 Da, Ha, Wa, add_same, dtype, out_f32, nullptr, 0, stream);
 }
 
+static thread_local bool g_s2_accumulate_call = false;   // set by dreg_conv3d_dgrad_s2_acc around its call of dreg_conv3d_dgrad_s2
 // Data gradient of a stride-2 convolution (ksz 3 / pad 1 or ksz 1 / pad 0; bf16) without the 7/8 structurally-zero taps of the
 // gather form: one 2^3-tap convolution over dOut [B,Do,Ho,Wo,Cout] whose 8 x Cin output channels are the 8 parity classes
 // of dIn [B,Di,Hi,Wi,Cin] (written in place by the epilogue).  wt_class_packed: dreg_pack_conv_weight(..., for_dgrad = 2).
@@ -2296,8 +2306,18 @@ int dreg_conv3d_dgrad_s2(const void* gout, const void* wt_class_packed, void* di
     int rc = fill_geom(g, B, Do, Ho, Wo, Cout, Dc, Hc, Wc, ncls * Cin, ksz == 1 ? 1 : 2, 1, 0, 0, 2);
     if (rc) return rc;
     if (g.M == 0) return DREG_OK;
-    if (ksz == 1 && dreg_fill_zero(din, (size_t)B * Di * Hi * Wi * Cin * 2, st) != DREG_OK) return DREG_ELAUNCH;   // (own fill kernel: HBM rate; hipMemsetAsync's runs 256 workgroups)
-    return launch_conv<bf16_t, bf16_t>(gout, wt_class_packed, din, nullptr, nullptr, g, 0, Di, Hi, Wi, -Cin, st);
+    if (ksz == 1 && !g_s2_accumulate_call && dreg_fill_zero(din, (size_t)B * Di * Hi * Wi * Cin * 2, st) != DREG_OK) return DREG_ELAUNCH;   // (own fill kernel: HBM rate; hipMemsetAsync's runs 256 workgroups)
+    return launch_conv<bf16_t, bf16_t>(gout, wt_class_packed, din, nullptr, g_s2_accumulate_call ? (const bf16_t*)din : nullptr, g, 0, Di, Hi, Wi, -Cin, st);
+}
+// The same ADDED to an existing dIn (a tensor with a second gradient contribution): in fp32 in the epilogue, one rounding; a 1^3 layer
+// touches the even-coordinate voxels only (the others keep their value: no fill).
+int dreg_conv3d_dgrad_s2_acc(const void* gout, const void* wt_class_packed, void* din, int B, int Di, int Hi, int Wi, int Cin,
+                             int Do, int Ho, int Wo, int Cout, int ksz, int pad, void* stream)
+{
+    g_s2_accumulate_call = true;
+    const int rc = dreg_conv3d_dgrad_s2(gout, wt_class_packed, din, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, ksz, pad, stream);
+    g_s2_accumulate_call = false;
+    return rc;
 }
 
 // 1 (default): bf16 stride-1 convolutions use the direct-to-LDS kernel (8-wave 256x256 tile when Cout % 256 == 0 and the row

@@ -133,6 +133,7 @@ struct Scope {   // optional HIP-event bracket of one launch group
 
 int g_sparse_grads = 1;   // tuning (include/dreg_nerf_tuning.h): row-cleared instead of memset gradient buffers in front of the active-set convolutions
 int g_bn_batch_tails = 1; // tuning (include/dreg_nerf_tuning.h): the small BatchNorms' running-statistics / parameter-gradient launches batched per pass
+int g_s2_accumulate = 1;  // tuning (include/dreg_nerf_tuning.h): a stride-2 data gradient that is a tensor's second contribution adds in its epilogue (dreg_conv3d_dgrad_s2_acc)
 int g_sparse_stem = 1;    // tuning (include/dreg_nerf_tuning.h): BatchNorm + ReLU + max-pool behind a row-list stem run from the row lists (statistics over the listed rows, activation on the lateral's rows only)
 int g_fuse_stem = 1;      // tuning (include/dreg_nerf_tuning.h): BatchNorm + ReLU + max-pool of the stem in one pass
 int g_brick = 1;          // tuning (include/dreg_nerf_tuning.h): bit 0: active-set 3^3 launches with 64 output channels on csrc/conv_brick.hip when the caller hands over tile tables, bit 1: those with 256 as well
@@ -478,6 +479,7 @@ void dreg_exec_set_sparse_grads(int on) { g_sparse_grads = on ? 1 : 0; }   // re
 void dreg_exec_set_bn_batch_tails(int on) { g_bn_batch_tails = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_fuse_stem(int on) { g_fuse_stem = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_sparse_stem(int on) { g_sparse_stem = on ? 1 : 0; }   // read when an executor is created
+void dreg_exec_set_s2_accumulate(int on) { g_s2_accumulate = on ? 1 : 0; }   // read at every backward call
 void dreg_exec_set_fuse_bn_stats(int on) { g_fuse_bn_stats = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_brick(int mask) { g_brick = mask & 3; }   // packs: read when an executor is created; dispatch: at every forward / backward call
 void dreg_exec_set_defer_head_pg(int on) { g_defer_head_pg = on ? 1 : 0; }   // read at every backward call
@@ -883,13 +885,16 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                 // a second contribution to an existing gradient: the plain data-gradient convolution adds it in its epilogue (fp32,
                 // in place, one rounding) instead of going through the temporary and a separate add
                 const bool halo_d = (o.halo & 2) != 0;
-                fused_add = written[o.in] && !rows && (halo_d || (!(w.pk_cls != SIZE_MAX && s2_class_ok(w, o.ksz, o.stride, o.pad)) && w.pk_dgrad != SIZE_MAX));
+                const bool s2_cls = w.pk_cls != SIZE_MAX && s2_class_ok(w, o.ksz, o.stride, o.pad);
+                fused_add = written[o.in] && !rows && (halo_d || (s2_cls && g_s2_accumulate) || (!s2_cls && w.pk_dgrad != SIZE_MAX));
                 void* gx = fused_add ? grad(o.in) : dst_for(o.in);
                 Scope sc(e, st, i, 1);
                 if (halo_d) {
                     // gx = [gx +] conv(gy, flipped-tap pack): the halo kernel's same-size addend is the in-place accumulation
                     CK(dreg_conv3_halo(gy, PK + w.pk_halo_dgrad, gx, nullptr, fused_add ? gx : nullptr, y.B, y.D, y.H, y.W, w.d0,
                                        fused_add ? x.D : 0, fused_add ? x.H : 0, fused_add ? x.W : 0, 1, 0, stream));
+                } else if (fused_add && s2_cls) {
+                    CK(dreg_conv3d_dgrad_s2_acc(gy, PK + w.pk_cls, gx, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0, o.ksz, o.pad, stream));
                 } else if (fused_add) {
                     sc.variant(1);        // dispatched WITH an addend (igemm_choose may pick another tile for it)
                     CK(dreg_conv3d_igemm_ws(gy, PK + w.pk_dgrad, gx, nullptr, gx, x.B, y.D, y.H, y.W, w.d0, x.D, x.H, x.W, w.d1,

@@ -39,6 +39,7 @@ SIGNATURES = {
     "dreg_conv_set_glds": (None, [I]),
     "dreg_conv_get_glds": (I, []),
     "dreg_conv3d_dgrad_s2": (I, [P, P, P] + [I] * 11 + [P]),
+    "dreg_conv3d_dgrad_s2_acc": (I, [P, P, P] + [I] * 11 + [P]),
     "dreg_pack_conv_weight": (I, [P, P, I, I, I, I, I, I, P]),
     "dreg_pack_conv_weights_batched": (I, [P, I, I, I, P, P]),
     "dreg_conv_set_wgrad_splits": (None, [I]),
@@ -79,6 +80,7 @@ SIGNATURES = {
     "dreg_bn_set_small_regs": (None, [I]),
     "dreg_exec_set_fuse_stem": (None, [I]),
     "dreg_exec_set_sparse_stem": (None, [I]),
+    "dreg_exec_set_s2_accumulate": (None, [I]),
     "dreg_sstem_set_pool_blocks": (None, [I]),
     "dreg_exec_set_fuse_bn_stats": (None, [I]),
     "dreg_exec_set_brick": (None, [I]),

@@ -110,6 +110,9 @@ int dreg_conv3_halo(const void* in, const void* wpk, void* out, const float* bia
  * wt_class_packed = dreg_pack_conv_weight(..., for_dgrad = 2): rows (class, ci), K = tap*Cout + co. */
 int dreg_conv3d_dgrad_s2(const void* gout, const void* wt_class_packed, void* din, int B, int Di, int Hi, int Wi, int Cin,
                          int Do, int Ho, int Wo, int Cout, int ksz, int pad, void* stream);
+/* the same ADDED to an existing dIn (fp32 add in the epilogue, one rounding; a 1^3 layer touches the even-coordinate voxels only) */
+int dreg_conv3d_dgrad_s2_acc(const void* gout, const void* wt_class_packed, void* din, int B, int Di, int Hi, int Wi, int Cin,
+                             int Do, int Ho, int Wo, int Cout, int ksz, int pad, void* stream);
 
 /* Weight gradient (split over voxels, deterministic two-stage reduction):
  * dw[Cout][Cin_real][ksz^3] (fp32, torch layout) (+)= sum_m gout[m,:]^T x in[gather(m, tap), :]. */
