@@ -58,6 +58,7 @@ struct Op {
     int stats_bn = -1;           // OP_CONV whose bf16 output feeds a large-path BatchNorm: that op's index (its chunk sums come from this convolution's epilogue)
     size_t stats_off = 0;        // OP_BN with such a producer: its own chunk-sum buffer [B][V / 128][C][2] (the shared workspace may be used in between)
     int stats_conv = -1;
+    int fold_into = -1, res_from = -1;   // OP_BN (ReLU-free, large path) whose output only feeds BatchNorm `fold_into` as its residual: not applied, that layer applies it on the fly (res_from = this op)
     int bt = -1;                 // OP_BN on the one-launch small path: index of its record in the two BatchNorm tail tables
     size_t keep_var = 0, keep_sums = 0;   //   per-grid variances [B][C] / gradient sums [B][C][2] kept until the batched tail launch
 };
@@ -134,6 +135,7 @@ struct Scope {   // optional HIP-event bracket of one launch group
 int g_sparse_grads = 1;   // tuning (include/dreg_nerf_tuning.h): row-cleared instead of memset gradient buffers in front of the active-set convolutions
 int g_bn_batch_tails = 1; // tuning (include/dreg_nerf_tuning.h): the small BatchNorms' running-statistics / parameter-gradient launches batched per pass
 int g_s2_accumulate = 1;  // tuning (include/dreg_nerf_tuning.h): a stride-2 data gradient that is a tensor's second contribution adds in its epilogue (dreg_conv3d_dgrad_s2_acc)
+int g_fold_res_bn = 1;    // tuning (include/dreg_nerf_tuning.h): the downsample branch's BatchNorm applied inside the BatchNorm that adds it (large path)
 int g_sparse_stem = 1;    // tuning (include/dreg_nerf_tuning.h): BatchNorm + ReLU + max-pool behind a row-list stem run from the row lists (statistics over the listed rows, activation on the lateral's rows only)
 int g_fuse_stem = 1;      // tuning (include/dreg_nerf_tuning.h): BatchNorm + ReLU + max-pool of the stem in one pass
 int g_brick = 1;          // tuning (include/dreg_nerf_tuning.h): bit 0: active-set 3^3 launches with 64 output channels on csrc/conv_brick.hip when the caller hands over tile tables, bit 1: those with 256 as well
@@ -215,6 +217,24 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
             }
         }
     }
+
+    // the downsample branch of a stage's first bottleneck (resnet3d.py:104-110: conv -> BatchNorm, no ReLU) is only ever added inside the
+    // block's last BatchNorm: on the large path that BatchNorm applies the branch's scale / shift while it reads the branch's raw
+    // convolution output, and the branch's own apply pass (read + write of a [B,V,C] tensor) is not launched
+    if (g_fold_res_bn)
+        for (size_t j = 0; j < e->ops.size(); ++j) {
+            Op& bj = e->ops[j];
+            const Tensor& xj = e->t[bj.in];
+            if (bj.kind != OP_BN || bj.in2 >= 0 || bj.relu || bj.pool >= 0 || bj.out == e->out_slot || dreg_bn_small(xj.B, xj.D * xj.H * xj.W, xj.C, 0)) continue;
+            int users = 0, k = -1;
+            for (size_t q = 0; q < e->ops.size(); ++q) {
+                const Op& o = e->ops[q];
+                if (o.in == bj.out) ++users;
+                if (o.in2 == bj.out) { ++users; if (o.kind == OP_BN && q > j && o.pool < 0) k = (int)q; }
+            }
+            if (users != 1 || k < 0 || e->ops[k].res_from >= 0) continue;
+            bj.fold_into = k; e->ops[k].res_from = (int)j;
+        }
 
     // arena: activations | BN statistics / argmax | gradients | scratch
     size_t off = 0;
@@ -479,6 +499,7 @@ void dreg_exec_set_sparse_grads(int on) { g_sparse_grads = on ? 1 : 0; }   // re
 void dreg_exec_set_bn_batch_tails(int on) { g_bn_batch_tails = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_fuse_stem(int on) { g_fuse_stem = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_sparse_stem(int on) { g_sparse_stem = on ? 1 : 0; }   // read when an executor is created
+void dreg_exec_set_fold_res_bn(int on) { g_fold_res_bn = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_s2_accumulate(int on) { g_s2_accumulate = on ? 1 : 0; }   // read at every backward call
 void dreg_exec_set_fuse_bn_stats(int on) { g_fuse_bn_stats = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_brick(int mask) { g_brick = mask & 3; }   // packs: read when an executor is created; dispatch: at every forward / backward call
@@ -631,13 +652,16 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
             // done by the BatchNorm in front of it
         } else if (o.kind == OP_BN) {
             const int V = x.D * x.H * x.W;
+            const void* res_p = o.in2 >= 0 ? act(o.in2) : nullptr;
+            void* out_p = o.fold_into >= 0 ? nullptr : act(o.out);       // folded branch: statistics, scale / shift only
+            if (o.res_from >= 0) { res_p = act(e->ops[o.res_from].in); dreg_bn_set_residual_transform((const float*)(A + e->ops[o.res_from].aux0)); }
             if (train && sums_rpc[i] > 0) {
-                CK(dreg_bn3d_fwd_from_sums(act(o.in), o.in2 >= 0 ? act(o.in2) : nullptr, act(o.out), e->prm[o.w].val, e->prm[o.b].val, e->prm[o.p2].val, e->prm[o.p3].val,
+                CK(dreg_bn3d_fwd_from_sums(act(o.in), res_p, out_p, e->prm[o.w].val, e->prm[o.b].val, e->prm[o.p2].val, e->prm[o.p3].val,
                                            (float*)(A + o.aux0), (float*)(A + o.aux1), (float*)(A + o.stats_off), sums_rpc[i], x.B, V, x.C, 1e-5f, 0.1f, o.relu, 0, stream));
                 continue;
             }
             int deferred = 0;
-            CK(dreg_bn3d_fwd_defer_update(act(o.in), o.in2 >= 0 ? act(o.in2) : nullptr, act(o.out), e->prm[o.w].val, e->prm[o.b].val, e->prm[o.p2].val, e->prm[o.p3].val,
+            CK(dreg_bn3d_fwd_defer_update(act(o.in), res_p, out_p, e->prm[o.w].val, e->prm[o.b].val, e->prm[o.p2].val, e->prm[o.p3].val,
                                           (float*)(A + o.aux0), (float*)(A + o.aux1), (float*)(A + e->off_bn_ws), x.B, V, x.C, 1e-5f, 0.1f, train, o.relu, 0,
                                           o.bt >= 0 ? (float*)(A + o.keep_var) : nullptr, &deferred, stream));
             if (deferred) bn_done[o.bt] = 1;

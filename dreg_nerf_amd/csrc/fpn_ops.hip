@@ -297,18 +297,25 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
 // Column-fixed forms of the two apply kernels (grid (chunks, B, slabs) like bn_partial_kernel): a thread keeps ONE channel granule,
 // holds that granule's per-channel parameters in registers and walks down the rows of its chunk, UN rows in flight.  (The flat
 // forms above re-load 2-6 parameter floats per element on every iteration, which made them instruction- rather than HBM-bound.)
+// res_ss (optional): the residual is itself the output of a ReLU-free BatchNorm that was not applied (the downsample branch of a
+// bottleneck's first block, resnet3d.py:104-110): res holds that layer's INPUT and res_ss its (scale, shift); its output is formed here,
+// rounded to the activation dtype exactly as the separate apply pass stored it (bit-identical, one 2 x tensor pass less).
 template <typename T, int UN>
 __global__ __launch_bounds__(256) void bn_apply_cols_kernel(const T* __restrict__ x, const float* __restrict__ scale_shift, const T* __restrict__ res,
-                                                            T* __restrict__ y, int V, int C, int rows_per_chunk, int relu)
+                                                            T* __restrict__ y, int V, int C, int rows_per_chunk, int relu,
+                                                            const float* __restrict__ res_ss = nullptr)
 {
     constexpr int G = Gran<T>::G;
     const int CG = C / G, cgs = CG < 256 ? CG : 256, rpi = 256 / cgs;
     const int t = threadIdx.x, cg = blockIdx.z * cgs + (t % cgs), r0 = t / cgs, b = blockIdx.y;
     if (r0 >= rpi || cg >= CG) return;
     const int v0 = blockIdx.x * rows_per_chunk, v1 = min(v0 + rows_per_chunk, V);
-    float sc[G], sh[G];
+    float sc[G], sh[G], rsc[G], rsh[G];
 #pragma unroll
-    for (int i = 0; i < G; ++i) { sc[i] = scale_shift[((size_t)b * C + cg * G + i) * 2]; sh[i] = scale_shift[((size_t)b * C + cg * G + i) * 2 + 1]; }
+    for (int i = 0; i < G; ++i) {
+        sc[i] = scale_shift[((size_t)b * C + cg * G + i) * 2]; sh[i] = scale_shift[((size_t)b * C + cg * G + i) * 2 + 1];
+        if (res_ss) { rsc[i] = res_ss[((size_t)b * C + cg * G + i) * 2]; rsh[i] = res_ss[((size_t)b * C + cg * G + i) * 2 + 1]; }
+    }
     for (int v = v0 + r0; v < v1; v += rpi * UN) {
         float xv[UN][G], rv[UN][G];
 #pragma unroll
@@ -324,7 +331,11 @@ __global__ __launch_bounds__(256) void bn_apply_cols_kernel(const T* __restrict_
 #pragma unroll
                 for (int k = 0; k < G; ++k) {
                     float o = xv[u][k] * sc[k] + sh[k];
-                    if (res) o += rv[u][k];
+                    if (res) {
+                        float r = rv[u][k];
+                        if (res_ss) { r = r * rsc[k] + rsh[k]; if constexpr (sizeof(T) == 2) r = bf2f(f2bf(r)); }
+                        o += r;
+                    }
                     xv[u][k] = relu ? fmaxf(o, 0.f) : o;
                 }
                 Gran<T>::st(y + ((size_t)b * V + v + u * rpi) * C + (size_t)cg * G, xv[u]);
@@ -1943,12 +1954,18 @@ int dreg_bn_param_grad_batched(const void* descs_dev, int n, int block_base, int
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
+// The next large-path forward call's residual is the INPUT of a ReLU-free BatchNorm whose (scale, shift) are res_scale_shift (that layer was
+// run with y == nullptr: statistics + finalize only); consumed by that one call.  See bn_apply_cols_kernel.
+static thread_local const float* g_bn_res_ss = nullptr;
+void dreg_bn_set_residual_transform(const float* res_scale_shift) { g_bn_res_ss = res_scale_shift; }
 static int bn3d_fwd_impl(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                          float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
                          int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, void* stream, float* var_keep, int* deferred,
                          int sums_rows_per_chunk)
 {
     hipStream_t st = (hipStream_t)stream;
+    const float* res_ss = g_bn_res_ss;
+    g_bn_res_ss = nullptr;
     if (deferred) *deferred = 0;
     const int G = dtype == 0 ? 8 : 4;
     if (C % G) return DREG_EINVAL;
@@ -1959,6 +1976,7 @@ static int bn3d_fwd_impl(const void* x, const void* res, void* y, const float* g
     const bool presummed = train && sums_rows_per_chunk > 0;
     if (presummed && V % sums_rows_per_chunk != 0) return DREG_EINVAL;
     if (train && !presummed && bn_small_ok(B, V, C, G)) {      // 16^3 / 8^3 / 4^3 levels: statistics + apply in one launch, running statistics in a tiny second one
+        if (res_ss || !y) return DREG_EINVAL;                  // (the deferred-output forms are large-path only)
         const dim3 g1(CG / BNS_COLS, B);
         float* var = var_keep ? var_keep : workspace;   // [B][C] biased variances (the workspace holds >= B * chunks * C * 2 floats)
 #define BNS_FWD(Tt, NRv) hipLaunchKernelGGL((bn_small_fwd_kernel<Tt, NRv>), g1, dim3(256), 0, st, (const Tt*)x, (const Tt*)res, (Tt*)y, gamma, beta, \
@@ -1984,11 +2002,10 @@ static int bn3d_fwd_impl(const void* x, const void* res, void* y, const float* g
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64 * (B < 8 ? B : 8)), 0, st, workspace, gamma, beta, running_mean, running_var,
                        scale_shift, mean_rstd, B, presummed ? V / sums_rows_per_chunk : nch, C, V, eps, momentum, train);
     DREG_LAUNCH_CHECK();
-    const size_t tg = (size_t)B * V * CG;
-    (void)tg;
+    if (!y) return DREG_OK;        // statistics / scale / shift only: the consumer applies them (dreg_bn_set_residual_transform)
     const dim3 agrid(nch, B, slabs);
-    if (dtype == 0) hipLaunchKernelGGL((bn_apply_cols_kernel<bf16_t, 4>), agrid, dim3(256), 0, st, (const bf16_t*)x, scale_shift, (const bf16_t*)res, (bf16_t*)y, V, C, rpc, relu);
-    else hipLaunchKernelGGL((bn_apply_cols_kernel<float, 4>), agrid, dim3(256), 0, st, (const float*)x, scale_shift, (const float*)res, (float*)y, V, C, rpc, relu);
+    if (dtype == 0) hipLaunchKernelGGL((bn_apply_cols_kernel<bf16_t, 4>), agrid, dim3(256), 0, st, (const bf16_t*)x, scale_shift, (const bf16_t*)res, (bf16_t*)y, V, C, rpc, relu, res ? res_ss : nullptr);
+    else hipLaunchKernelGGL((bn_apply_cols_kernel<float, 4>), agrid, dim3(256), 0, st, (const float*)x, scale_shift, (const float*)res, (float*)y, V, C, rpc, relu, res ? res_ss : nullptr);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

@@ -80,6 +80,8 @@ SIGNATURES = {
     "dreg_bn_set_small_regs": (None, [I]),
     "dreg_exec_set_fuse_stem": (None, [I]),
     "dreg_exec_set_sparse_stem": (None, [I]),
+    "dreg_exec_set_fold_res_bn": (None, [I]),
+    "dreg_bn_set_residual_transform": (None, [P]),
     "dreg_exec_set_s2_accumulate": (None, [I]),
     "dreg_sstem_set_pool_blocks": (None, [I]),
     "dreg_exec_set_fuse_bn_stats": (None, [I]),

@@ -180,6 +180,10 @@ int dreg_bn3d_fwd_defer_update(const void* x, const void* res, void* y, const fl
 int dreg_bn3d_bwd_defer_params(const void* x, const void* dy, const void* y, const float* scale_shift, const float* mean_rstd,
                                void* dx, void* dres, float* dgamma, float* dbeta, float* coef, float* workspace,
                                int B, int V, int C, int relu, int accumulate, int dtype, float* sums_keep, int* deferred, void* stream);
+/* The NEXT large-path forward call's residual `res` is the INPUT of a ReLU-free BatchNorm that was run with y == NULL (statistics, scale /
+ * shift only — the downsample branch of a bottleneck's first block, resnet3d.py:104-110): res_scale_shift = that layer's scale_shift; the
+ * branch's output is formed on the fly, rounded as the separate apply pass stores it (bit-identical).  Consumed by that one call. */
+void dreg_bn_set_residual_transform(const float* res_scale_shift);
 int dreg_bn_running_update_batched(const void* descs_dev, int n, int block_base, int nblocks, float momentum, void* stream);
 int dreg_bn_param_grad_batched(const void* descs_dev, int n, int block_base, int nblocks, int accumulate, void* stream);
 
