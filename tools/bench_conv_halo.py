@@ -27,7 +27,15 @@ def main():
         lib.dreg_conv3_halo_set_variant(v)
         L.check(lib.dreg_conv3_halo(L.ptr(x), L.ptr(pk), L.ptr(out), L.ptr(bias), None, B, R, R, R, cin, 0, 0, 0, 0, 0, L.stream()), "halo")
 
-    arms = {"igemm256": lambda: ops.conv3d(x, w, bias, pad=1), "halo": lambda: halo(0), "halo_lockstep": lambda: halo(1), "halo_nosplit": lambda: halo(3)}
+    # the implicit GEMM through the C ABI itself (ops.conv3d would route this shape to the halo kernel — with whatever variant an ablation arm left set)
+    pk_ig = ops.packed_weight(w, cin, False, L.DT_BF16)
+    out_ig = torch.empty_like(out)
+
+    def igemm():
+        L.check(lib.dreg_conv3d_igemm(L.ptr(x), L.ptr(pk_ig), L.ptr(out_ig), L.ptr(bias), None, B, R, R, R, cin, R, R, R, 256, 3, 1, 1, 0, 0, 0, 0, 0, 0,
+                                      L.DT_BF16, 0, L.stream()), "igemm")
+
+    arms = {"igemm256": igemm, "halo": lambda: halo(0), "halo_lockstep": lambda: halo(1), "halo_nosplit": lambda: halo(3)}
     if "--only-halo" in sys.argv:
         arms = {"halo": lambda: halo(0), "igemm256": arms["igemm256"]}
     if "--ablate" in sys.argv:
@@ -47,7 +55,8 @@ def main():
     for f in arms.values():
         f()
     torch.cuda.synchronize()
-    ref = ops.conv3d(x, w, bias, pad=1).float()
+    igemm()
+    ref = out_ig.float()
     halo(0)
     d = (out.float() - ref).abs()
     print(f"max |halo - igemm| = {d.max().item():.4g} (|ref| max {ref.abs().max().item():.3g}), differing elements {(d > 0).float().mean().item():.4f}")
