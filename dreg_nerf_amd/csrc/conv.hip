@@ -16,6 +16,7 @@
 // 128 bytes of K per step, register-staged double-buffered LDS with a 16-byte-slot XOR swizzle
 // (slot ^= (row>>1)&7) so the ds_read_b128 fragment reads of 16 consecutive rows are conflict free.
 #include "common.h"
+#include <cstring>
 extern "C" int dreg_fill_zero(void* p, size_t bytes, void* stream);   // fpn_ops.hip (include/dreg_nerf.h)
 
 struct ConvGeom {
@@ -953,12 +954,38 @@ template <int GP> __device__ __forceinline__ int wg_swz(int row) {   // rows of 
 // transposed fragments of its next unit, while the other group runs the 32 MFMAs of the unit it read one phase earlier at raised
 // priority; then they swap.  Same products in the same order as the lockstep loop (bit-identical), but a SIMD's matrix pipe always
 // has one of its two waves in the MFMA half instead of both loading, then both multiplying behind one barrier per stage.
-template <int BM, int BNC, bool ROWS, int NW = 4, int ABL = 0, int KV_ = 64, int NS_ = 2, int PIPE = 0, int AP = 0>
+// GRP (round 4): ONE launch for the weight gradients of many layers (the 36 linear layers of the point-set half: 4 - 12 weight tiles x 16
+// splits each, ~25 us per launch for ~4 GFLOP — launch- and fill-bound one at a time).  The kernel parameters of a workgroup's layer come
+// from a descriptor table (rowocc carries the table, rows_fast its length; binary search over block0 with a wave-uniform index); the
+// body, the tile / split arithmetic and therefore every partial sum are those of the layer's own launch.
+struct WgradGroupDesc {
+    const bf16_t* gout; const bf16_t* in; float* part;
+    ConvGeom g;
+    int tilesCol, tiles, nsplit;
+    uint32_t vps, gbytes, ibytes, nrows;
+    int block0;
+};
+static_assert(sizeof(WgradGroupDesc) == 144, "descriptor layout is part of the ABI (dreg_wgrad_group_desc_bytes)");
+template <int BM, int BNC, bool ROWS, int NW = 4, int ABL = 0, int KV_ = 64, int NS_ = 2, int PIPE = 0, int AP = 0, bool GRP = false>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
     const bf16_t* __restrict__ gout, const bf16_t* __restrict__ in, float* __restrict__ part,
     ConvGeom g, int tilesCol, int tiles, int nsplit, uint32_t vox_per_split, uint32_t gout_bytes, uint32_t in_bytes,
     const int* __restrict__ rowlist, uint32_t nrows, const uint8_t* __restrict__ rowocc = nullptr, int rows_fast = 0)
 {
+    uint32_t bid = blockIdx.x;
+    if constexpr (GRP) {
+        const WgradGroupDesc* D = reinterpret_cast<const WgradGroupDesc*>(rowocc);
+        int lo = 0, hi = rows_fast - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (D[mid].block0 <= (int)bid) lo = mid; else hi = mid - 1;
+        }
+        const WgradGroupDesc d = D[lo];
+        gout = d.gout; in = d.in; part = d.part; g = d.g; tilesCol = d.tilesCol; tiles = d.tiles; nsplit = d.nsplit;
+        vox_per_split = d.vps; gout_bytes = d.gbytes; in_bytes = d.ibytes; nrows = d.nrows;
+        rowocc = nullptr; rows_fast = 0; rowlist = nullptr;
+        bid -= (uint32_t)d.block0;
+    }
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
     constexpr int KV = KV_, NS = NS_;                     // voxels per stage, LDS ring depth (prefetch distance NS-1)
@@ -980,8 +1007,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
     // XCD-aware placement (block b runs on XCD b % 8): every XCD owns the voxel splits s == xcd (mod 8) and runs all
     // (co, n) tiles of a split back to back, so both streamed operands are fetched from HBM by ONE L2 and re-used there.
     uint32_t split, tile;
-    if ((nsplit & 7) == 0) { const uint32_t xcd = blockIdx.x & 7, j = blockIdx.x >> 3; split = (j / tiles) * 8 + xcd; tile = j % tiles; }
-    else { split = blockIdx.x / tiles; tile = blockIdx.x - split * tiles; }
+    if ((nsplit & 7) == 0) { const uint32_t xcd = bid & 7, j = bid >> 3; split = (j / tiles) * 8 + xcd; tile = j % tiles; }
+    else { split = bid / tiles; tile = bid - split * tiles; }
     const uint32_t tile_r = tile / tilesCol, tile_c = tile - tile_r * tilesCol;
     const int co0 = tile_r * BM, n0 = tile_c * BNC;
     const uint32_t v_begin = split * vox_per_split;
@@ -2671,6 +2698,62 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
     if (g.ntaps > 1 && (size_t)g.ntaps * (Cin < 64 ? Cin : 64) > (size_t)WR_STAGE) return DREG_EINVAL;
     WgradReduceDesc rd{part, dw, nsplit, Cout, g.Kpad, g.ntaps, Cin, Cin_real, accumulate, 0};
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(wgrad_reduce_blocks(Cout, Cin_real, g.ntaps, nsplit)), dim3(256), 0, st, rd);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// ---- weight gradients of MANY linear layers in one launch per tile shape (see GRP above).
+// dreg_linear_wgrad_group_fill writes the 144-byte descriptor of y = x W^T (x: bf16 [rows, Cin], gout: bf16 [rows, Cout], split partials
+// [nsplit][Cout][Kpad] fp32 into `workspace` exactly as dreg_conv3d_wgrad_partials(..., B = rows, 1^3) would leave them) into host memory
+// and returns its tile shape (*variant = BM * 1000 + BNC) and workgroup count; block0 is left to the caller (exclusive prefix of the
+// workgroup counts inside one variant's table).  DREG_EINVAL: the layer does not take the four-wave direct-to-LDS kernel (caller falls back).
+int dreg_wgrad_group_desc_bytes() { return (int)sizeof(WgradGroupDesc); }
+int dreg_linear_wgrad_group_fill(void* desc_host, const void* gout, const void* in, void* workspace, size_t workspace_bytes,
+                                 int rows, int Cin, int Cout, int* variant, int* nblocks)
+{
+    ConvGeom g;
+    int rc = fill_geom(g, rows, 1, 1, 1, Cin, 1, 1, 1, Cout, 1, 1, 0, 0, 2);
+    if (rc) return rc;
+    if ((Cout % 128 != 0 && Cout != 64) || !g_use_glds) return DREG_EINVAL;
+    if (workspace_bytes < dreg_conv3d_wgrad_workspace_bytes(rows, 1, 1, 1, Cin, Cout, 1, 0)) return DREG_EINVAL;
+    const uint32_t nrows = g.M;
+    const int nsplit = dreg_conv3d_wgrad_splits(rows, 1, 1, 1, Cin, Cout, 1, 0);
+    uint32_t vps = (uint32_t)((nrows + nsplit - 1) / nsplit);
+    vps = ((vps + 63) / 64) * 64;
+    if (vps == 0) vps = 64;
+    int bm = (Cout % 128 == 0) ? 128 : 64;
+    const uint64_t gbytes = (uint64_t)g.M * Cout * 2, ibytes = (uint64_t)rows * Cin * 2;
+    if (gbytes >= 0x7fffff00ull || ibytes >= 0x7fffff00ull) return DREG_EINVAL;
+    int bnc = (g.Kpad % 128 == 0 || g.Kpad > 128) ? 128 : 64;
+    if (g_narrow_small >= 2 && (Cout / bm) * ((g.Kpad + bnc - 1) / bnc) * nsplit < g_narrow_thr) {      // the rules of wgrad_impl
+        if (bnc == 128) bnc = 64;
+        if (bm == 128 && (Cout / bm) * (g.Kpad / bnc) * nsplit < g_narrow_thr) bm = 64;
+    }
+    if (g_wgrad_big && Cout % 256 == 0 && (g.Kpad % 256 == 0 || g.Kpad >= 1024) && nrows >= 65536) return DREG_EINVAL;   // (takes the 8-wave tile)
+    const int tilesRow = Cout / bm, tilesCol = (g.Kpad + bnc - 1) / bnc;
+    WgradGroupDesc d{};
+    d.gout = (const bf16_t*)gout; d.in = (const bf16_t*)in; d.part = (float*)workspace; d.g = g;
+    d.tilesCol = tilesCol; d.tiles = tilesRow * tilesCol; d.nsplit = nsplit; d.vps = vps; d.gbytes = (uint32_t)gbytes; d.ibytes = (uint32_t)ibytes;
+    d.nrows = nrows; d.block0 = 0;
+    std::memcpy(desc_host, &d, sizeof(d));
+    *variant = bm * 1000 + bnc;
+    *nblocks = tilesRow * tilesCol * nsplit;
+    return DREG_OK;
+}
+// descs_dev: n descriptors of ONE variant in device memory with ascending block0; total_blocks = the sum of their workgroup counts
+int dreg_wgrad_group_launch(const void* descs_dev, int n, int variant, int total_blocks, void* stream)
+{
+    if (n <= 0 || total_blocks <= 0) return DREG_OK;
+    if (!descs_dev) return DREG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int bm = variant / 1000, bnc = variant % 1000;
+    const ConvGeom g0{};
+#define WGRP(BMv, BNv) hipLaunchKernelGGL((conv_wgrad_glds_kernel<BMv, BNv, false, 4, 0, 64, 2, 0, 0, true>), dim3(total_blocks), dim3(256), (size_t)2 * 64 * (BMv + BNv) * 2, st, \
+        (const bf16_t*)nullptr, (const bf16_t*)nullptr, (float*)nullptr, g0, 0, 0, 0, 0u, 0u, 0u, (const int*)nullptr, 0u, (const uint8_t*)descs_dev, n)
+    if (bm == 128 && bnc == 128) WGRP(128, 128); else if (bm == 128 && bnc == 64) WGRP(128, 64);
+    else if (bm == 64 && bnc == 128) WGRP(64, 128); else if (bm == 64 && bnc == 64) WGRP(64, 64);
+    else return DREG_EINVAL;
+#undef WGRP
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 #include "../../include/dreg_nerf.h"
 #ifndef DREG_ELAUNCH
@@ -154,6 +155,7 @@ void build_layout(Ps* p, int R)
 }
 
 #define CK(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+int g_ps_group_wgrad = 1;   // tuning (include/dreg_nerf_tuning.h): the linear layers' weight-gradient partials of a backward pass in one launch per tile shape
 
 // y = x W^T (+bias) (+residual, fp32 output) (relu): the 1x1x1 path of the implicit-GEMM kernels, rows as the batch dimension
 int linear_fwd(Ps* p, const Layout& y, char* A, const void* x, const void* wpk, const float* bias, const void* residual, void* out,
@@ -217,6 +219,7 @@ void dreg_ps_destroy(void* h)
 // 1 (default): ReLU mask and the decoder's gradient sum in the data-gradient epilogues, one LayerNorm backward for the final norm's two
 // applications, all bias column sums in one batched launch pair
 void dreg_ps_set_fuse(void* h, int fuse) { ((Ps*)h)->fuse = fuse ? 1 : 0; }
+void dreg_ps_set_group_wgrad(int on) { g_ps_group_wgrad = on ? 1 : 0; }   // read at every backward call
 // HIP events around every linear-layer launch of the following passes (bench.py's bracketed step); read them back AFTER a device
 // synchronisation: info[5 * i] = (kind 0 fwd / 1 dgrad / 2 wgrad, rows, cin, cout, flags: 1 addend, 2 fp32 output, 4 split-K workspace
 // offered), ms[i] = the launch's duration.  Returns the number of records (and clears them).
@@ -325,10 +328,20 @@ int dreg_ps_backward(void* h, void* arena, size_t arena_bytes, const int64_t* pa
     int rd_blocks = 0, cs_p = 0, cs_f = 0;
     // parameter gradients of linear layer `li` from its output gradient g (bf16 [rows, cout]) and its input x (bf16 [rows, cin]): split
     // partials now (second stream, behind an event: g is complete on the caller's stream here), sums at the end of the pass
+    // grouped form (dreg_ps_set_group_wgrad, default with fuse): the split partials of ALL linear layers of the pass by one launch per tile
+    // shape at the end of the pass (every operand lives in the arena until then) instead of 36 launches of 50 - 200 workgroups each
+    struct GroupRec { char d[160]; int variant, nblocks; };
+    std::vector<GroupRec> grp;
+    const bool group = fuse && g_ps_group_wgrad && !p->timing;
     auto param_grads = [&](int li, const void* g, const void* x, int rows, size_t wg_off, size_t cs_off) -> int {
         const Lin& l = p->lin[li];
-        if (two) { if (hipEventRecord(p->ev[li], st) != hipSuccess || hipStreamWaitEvent(ax, p->ev[li], 0) != hipSuccess) return DREG_ELAUNCH; }
-        {
+        bool grouped = false;
+        if (group) {
+            GroupRec gr{};
+            if (dreg_linear_wgrad_group_fill(gr.d, g, x, A + wg_off, y.wg_bytes[li], rows, l.cin, l.cout, &gr.variant, &gr.nblocks) == DREG_OK) { grp.push_back(gr); grouped = true; }
+        }
+        if (!grouped) {
+            if (two) { if (hipEventRecord(p->ev[li], st) != hipSuccess || hipStreamWaitEvent(ax, p->ev[li], 0) != hipSuccess) return DREG_ELAUNCH; }
             PsScope sc(p, ax, 2, rows, l.cin, l.cout, 0);
             CK(dreg_conv3d_wgrad_partials(g, x, A + wg_off, y.wg_bytes[li], nullptr, 0, rows, 1, 1, 1, l.cin, l.cin, 1, 1, 1, l.cout, 1, 1, 0, nullptr, ax));
         }
@@ -462,6 +475,11 @@ int dreg_ps_backward(void* h, void* arena, size_t arena_bytes, const int64_t* pa
     // ---- the pass's tails: descriptor tables through pinned staging, then one launch per kind
     const size_t nb_rd = rd.size() * sizeof(ReduceRec), nb_cs = cs.size() * sizeof(ColsumRec), nb_ln = ln.size() * sizeof(LnRec);
     const size_t o_cs = al(nb_rd), o_ln = o_cs + al(nb_cs);
+    // grouped weight-gradient descriptors: one table per tile shape, block0 = exclusive prefix of the workgroup counts inside it
+    const int gd = dreg_wgrad_group_desc_bytes();
+    std::stable_sort(grp.begin(), grp.end(), [](const GroupRec& a, const GroupRec& b) { return a.variant < b.variant; });
+    const size_t o_grp = al(o_ln + nb_ln), nb_grp = grp.size() * (size_t)gd;
+    if (gd > 160 || o_grp + nb_grp > Ps::TABLE_BYTES) return DREG_EINVAL;
     if (o_ln + nb_ln > Ps::TABLE_BYTES) return DREG_EINVAL;
     const unsigned slot = p->ring_next++ % Ps::RING;
     if (!p->ring_ev[slot]) { if (hipEventCreateWithFlags(&p->ring_ev[slot], hipEventDisableTiming) != hipSuccess) return DREG_ELAUNCH; }
@@ -470,14 +488,24 @@ int dreg_ps_backward(void* h, void* arena, size_t arena_bytes, const int64_t* pa
     std::memcpy(host, rd.data(), nb_rd);
     std::memcpy(host + o_cs, cs.data(), nb_cs);
     std::memcpy(host + o_ln, ln.data(), nb_ln);
+    struct GroupLaunch { size_t off; int n, variant, blocks; };
+    std::vector<GroupLaunch> gl;
+    for (size_t i = 0; i < grp.size(); ++i) {
+        if (gl.empty() || gl.back().variant != grp[i].variant) gl.push_back(GroupLaunch{o_grp + i * (size_t)gd, 0, grp[i].variant, 0});
+        const int b0 = gl.back().blocks;
+        std::memcpy(grp[i].d + gd - (int)sizeof(int), &b0, sizeof(int));        // block0 is the descriptor's last field
+        std::memcpy(host + o_grp + i * (size_t)gd, grp[i].d, (size_t)gd);
+        gl.back().n += 1; gl.back().blocks += grp[i].nblocks;
+    }
     // the tables are read on both streams: copy on the caller's stream, the second stream waits for it
-    if (hipMemcpyAsync(A + y.tables, host, o_ln + nb_ln, hipMemcpyHostToDevice, st) != hipSuccess) return DREG_ELAUNCH;
+    if (hipMemcpyAsync(A + y.tables, host, grp.empty() ? o_ln + nb_ln : o_grp + nb_grp, hipMemcpyHostToDevice, st) != hipSuccess) return DREG_ELAUNCH;
     if (hipEventRecord(p->ring_ev[slot], st) != hipSuccess) return DREG_ELAUNCH;
     if (two && hipStreamWaitEvent(ax, p->ring_ev[slot], 0) != hipSuccess) return DREG_ELAUNCH;
     // records 0 and (without fuse) 1 are the final norm's two applications: same destination, so the second one is a launch of its own
     const int ln_dup = (ln.size() >= 2 && ln[0].dg == ln[1].dg) ? 1 : 0;
     if (ln_dup) CK(dreg_layernorm_bwd_final_batched(A + y.tables + o_ln, 1, stream));
     CK(dreg_layernorm_bwd_final_batched(A + y.tables + o_ln + ln_dup * sizeof(LnRec), (int)ln.size() - ln_dup, stream));
+    for (const GroupLaunch& q : gl) CK(dreg_wgrad_group_launch(A + y.tables + q.off, q.n, q.variant, q.blocks, ax));   // (every output gradient is complete: the event above follows the whole pass)
     CK(dreg_wgrad_reduce_batched(A + y.tables, (int)rd.size(), 0, rd_blocks, ax));
     if (fuse) CK(dreg_colsum_batched(A + y.tables + o_cs, (int)cs.size(), cs_p, cs_f, ax));
     return DREG_OK;

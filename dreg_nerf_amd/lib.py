@@ -80,6 +80,10 @@ SIGNATURES = {
     "dreg_bn_set_small_regs": (None, [I]),
     "dreg_exec_set_fuse_stem": (None, [I]),
     "dreg_exec_set_sparse_stem": (None, [I]),
+    "dreg_ps_set_group_wgrad": (None, [I]),
+    "dreg_wgrad_group_desc_bytes": (I, []),
+    "dreg_linear_wgrad_group_fill": (I, [P, P, P, P, Z, I, I, I, P, P]),
+    "dreg_wgrad_group_launch": (I, [P, I, I, I, P]),
     "dreg_exec_set_fold_res_bn": (None, [I]),
     "dreg_bn_set_residual_transform": (None, [P]),
     "dreg_exec_set_s2_accumulate": (None, [I]),

@@ -152,6 +152,16 @@ int dreg_conv3d_wgrad_partials(const void* gout, const void* in, void* workspace
                                int ksz, int stride, int pad, const uint8_t* rowocc, void* stream);
 int dreg_wgrad_reduce_blocks(int Cout, int Cin_real, int ksz, int nsplit);
 int dreg_wgrad_reduce_batched(const void* descs_dev, int n, int block_base, int nblocks, void* stream);
+/* The split partials of MANY linear layers by one launch per tile shape (the 36 `nn.Linear` weight gradients of a backward pass through
+ * transformer.py:225-299 / nerf_regtr.py:268-270: ~25 us per launch for ~4 GFLOP one at a time).  dreg_linear_wgrad_group_fill writes the
+ * descriptor (dreg_wgrad_group_desc_bytes bytes, host memory) of one layer — x: bf16 [rows, Cin], gout: bf16 [rows, Cout], partials into
+ * `workspace` exactly as dreg_conv3d_wgrad_partials(B = rows, 1^3) leaves them — and returns its tile shape (*variant) and workgroup count;
+ * the caller sets block0 (the descriptor's last int: exclusive prefix of the workgroup counts inside one variant's table), copies the tables
+ * to the device and calls dreg_wgrad_group_launch once per variant, then dreg_wgrad_reduce_batched as usual.  Bit-identical partials. */
+int dreg_wgrad_group_desc_bytes(void);
+int dreg_linear_wgrad_group_fill(void* desc_host, const void* gout, const void* in, void* workspace, size_t workspace_bytes,
+                                 int rows, int Cin, int Cout, int* variant, int* nblocks);
+int dreg_wgrad_group_launch(const void* descs_dev, int n, int variant, int total_blocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- FPN3D companions
  * BatchNorm3d with the reference's one-grid-per-call statistics (resnet3d.py:121,159; nerf_regtr.py:135), fused
