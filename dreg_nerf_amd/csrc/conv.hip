@@ -2076,6 +2076,10 @@ static int g_igemm_probe = 0;         // measurement only (tools/igemm_phase_pro
 static int g_narrow_thr = 224;        // tile count below which a launch takes the narrower tiles
 static int g_pointwise_rmw_cin = 128;  // tuning (include/dreg_nerf_tuning.h): see igemm_choose
 static int g_igemm_ap256 = 1;         // tuning (include/dreg_nerf_tuning.h): the 256 x 256 tile of large launches runs in its anti-phase form (32-channel stages)
+// A split-K launch may leave its partials un-summed for the consumer to sum (the small-volume BatchNorm kernels read the fp32 slices
+// directly: dreg_bn_set_splitk_input) — armed for the NEXT launch only, taken when that launch is split-K with bf16 output and no bias / ReLU.
+struct SplitkDefer { int armed = 0, happened = 0, nsplit = 0; size_t slice = 0; };
+static thread_local SplitkDefer g_splitk_defer;
 static int g_igemm_ap = 256;          // tuning (include/dreg_nerf_tuning.h): launches of at most this many 128-row tiles take the eight-wave anti-phase form (0: never)
 static int g_narrow_small = 2;        // tuning (include/dreg_nerf_tuning.h): 128 x 64 tiles for launches of < 224 128 x 128 tiles
 // Which kernel instantiation a bf16 / fp32 convolution launch runs (ONE rule set: launch_conv dispatches on it and
@@ -2157,6 +2161,10 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
                                    (uint32_t)in_bytes, (uint32_t)wt_bytes, nullptr, g.M, ksplit, ns, nullptr);
             }
             DREG_LAUNCH_CHECK();
+            if (g_splitk_defer.armed && !bias && !relu && sizeof(TO) == 2) {      // the consumer sums the slices (dreg_conv_splitk_deferred tells it)
+                g_splitk_defer.armed = 0; g_splitk_defer.happened = 1; g_splitk_defer.nsplit = ksplit; g_splitk_defer.slice = slice;
+                return DREG_OK;
+            }
             const size_t total8 = slice / 8;
             const int nb = (int)((total8 + 255) / 256 > 2048 ? 2048 : (total8 + 255) / 256);
             hipLaunchKernelGGL(splitk_reduce_kernel<TO>, dim3(nb), dim3(256), 0, st, ks_ws, (TO*)out, bias, total8, slice, g.Cout, ksplit, relu);
@@ -2351,6 +2359,16 @@ int dreg_conv3d_dgrad_s2_acc(const void* gout, const void* wt_class_packed, void
 // space is large, else 128 x {128|64}); 2: 128-row tiles only; 3: the 8-wave 128x256
 // tile when Cout % 256 == 0 (measured equal to 128x128 in round 1); 4: the 8-wave 256x256 tile (128x64 per wave);
 // 5: as 1 but never split-K; 0: always the register-staged kernel (A/B checks).
+// Arm (1) / disarm (0) the deferral for the next convolution launch of this thread; dreg_conv_splitk_deferred returns 1 (and the slice
+// count / slice length in elements, and clears the state) when that launch left its split-K partials [nsplit][M * Cout] fp32 in its workspace.
+void dreg_conv_defer_splitk_reduce(int arm) { g_splitk_defer.armed = arm ? 1 : 0; g_splitk_defer.happened = 0; }
+int dreg_conv_splitk_deferred(int* nsplit, size_t* slice)
+{
+    const int h = g_splitk_defer.happened;
+    if (h) { *nsplit = g_splitk_defer.nsplit; *slice = g_splitk_defer.slice; }
+    g_splitk_defer.armed = 0; g_splitk_defer.happened = 0;
+    return h;
+}
 void dreg_conv_set_glds(int enable) { g_use_glds = enable; }
 void dreg_conv_set_wgrad_big(int enable) { g_wgrad_big = enable; }
 // measurement only: enable = 1 routes bf16 launches with Cout % 128 == 0 to the instrumented 128 x 128 kernel; read returns

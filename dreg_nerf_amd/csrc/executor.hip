@@ -58,6 +58,7 @@ struct Op {
     int stats_bn = -1;           // OP_CONV whose bf16 output feeds a large-path BatchNorm: that op's index (its chunk sums come from this convolution's epilogue)
     size_t stats_off = 0;        // OP_BN with such a producer: its own chunk-sum buffer [B][V / 128][C][2] (the shared workspace may be used in between)
     int stats_conv = -1;
+    int fold_sk_fwd = 0, fold_sk_bwd = 0;   // OP_CONV: a split-K launch of its forward / data gradient leaves the slices to the one-launch BatchNorm right behind it (forward: op + 1, backward: op - 1)
     int fold_into = -1, res_from = -1;   // OP_BN (ReLU-free, large path) whose output only feeds BatchNorm `fold_into` as its residual: not applied, that layer applies it on the fly (res_from = this op)
     int bt = -1;                 // OP_BN on the one-launch small path: index of its record in the two BatchNorm tail tables
     size_t keep_var = 0, keep_sums = 0;   //   per-grid variances [B][C] / gradient sums [B][C][2] kept until the batched tail launch
@@ -107,6 +108,8 @@ struct Exec {
     char* pack_base = nullptr;            // device address of the pack buffer (dreg_exec_export_pack_table)
     std::vector<char> written;            // backward pass state, kept across the segments of dreg_exec_backward_range
     bool aux_used = false;
+    int pend_sk_bn = -1, pend_sk_n = 0;    // a BatchNorm op whose dy lies in the split-K workspace as pend_sk_n slices (set by the data gradient of the op behind it; survives a segment boundary)
+    size_t pend_sk_slice = 0;
     const void* fwd_rows_arena = nullptr;  // the arena whose row-list convolution outputs (rows_out >= 0) are known to be zero outside their last lists
 };
 
@@ -135,6 +138,7 @@ struct Scope {   // optional HIP-event bracket of one launch group
 int g_sparse_grads = 1;   // tuning (include/dreg_nerf_tuning.h): row-cleared instead of memset gradient buffers in front of the active-set convolutions
 int g_bn_batch_tails = 1; // tuning (include/dreg_nerf_tuning.h): the small BatchNorms' running-statistics / parameter-gradient launches batched per pass
 int g_s2_accumulate = 1;  // tuning (include/dreg_nerf_tuning.h): a stride-2 data gradient that is a tensor's second contribution adds in its epilogue (dreg_conv3d_dgrad_s2_acc)
+int g_fold_splitk = 1;    // tuning (include/dreg_nerf_tuning.h): split-K sums of the 8^3 / 4^3 convolutions folded into the BatchNorm launch behind them
 int g_fold_res_bn = 1;    // tuning (include/dreg_nerf_tuning.h): the downsample branch's BatchNorm applied inside the BatchNorm that adds it (large path)
 int g_sparse_stem = 1;    // tuning (include/dreg_nerf_tuning.h): BatchNorm + ReLU + max-pool behind a row-list stem run from the row lists (statistics over the listed rows, activation on the lateral's rows only)
 int g_fuse_stem = 1;      // tuning (include/dreg_nerf_tuning.h): BatchNorm + ReLU + max-pool of the stem in one pass
@@ -234,6 +238,25 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
             }
             if (users != 1 || k < 0 || e->ops[k].res_from >= 0) continue;
             bj.fold_into = k; e->ops[k].res_from = (int)j;
+        }
+
+    // split-K convolutions of the 8^3 / 4^3 levels (resnet3d.py:95-113 conv2 of layer3 / layer4) directly in front of (forward) / behind (backward)
+    // a register-resident one-launch BatchNorm: the BatchNorm kernel sums the fp32 slices itself, the convolution's reduce launch is dropped
+    if (g_fold_splitk)
+        for (size_t i = 0; i < e->ops.size(); ++i) {
+            Op& o = e->ops[i];
+            if (o.kind != OP_CONV || o.b >= 0 || o.in2 >= 0 || o.relu || o.rows_out >= 0) continue;
+            auto users = [&](int slot) { int u = 0; for (const Op& q : e->ops) u += (q.in == slot) + (q.in2 == slot); return u; };
+            const Tensor& y = e->t[o.out];
+            if (i + 1 < e->ops.size() && o.out != e->out_slot) {
+                const Op& bn = e->ops[i + 1];
+                if (bn.kind == OP_BN && bn.in == o.out && bn.pool < 0 && users(o.out) == 1 && dreg_bn_small_in_regs(y.B, y.D * y.H * y.W, y.C, 0)) o.fold_sk_fwd = 1;
+            }
+            const Tensor& x = e->t[o.in];
+            if (i >= 1 && o.in != 0) {
+                const Op& bn = e->ops[i - 1];
+                if (bn.kind == OP_BN && bn.out == o.in && bn.pool < 0 && users(o.in) == 1 && dreg_bn_small_in_regs(x.B, x.D * x.H * x.W, x.C, 0) && o.stride == 1) o.fold_sk_bwd = 1;
+            }
         }
 
     // arena: activations | BN statistics / argmax | gradients | scratch
@@ -500,6 +523,7 @@ void dreg_exec_set_bn_batch_tails(int on) { g_bn_batch_tails = on ? 1 : 0; }   /
 void dreg_exec_set_fuse_stem(int on) { g_fuse_stem = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_sparse_stem(int on) { g_sparse_stem = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_fold_res_bn(int on) { g_fold_res_bn = on ? 1 : 0; }   // read when an executor is created
+void dreg_exec_set_fold_splitk(int on) { g_fold_splitk = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_s2_accumulate(int on) { g_s2_accumulate = on ? 1 : 0; }   // read at every backward call
 void dreg_exec_set_fuse_bn_stats(int on) { g_fuse_bn_stats = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_brick(int mask) { g_brick = mask & 3; }   // packs: read when an executor is created; dispatch: at every forward / backward call
@@ -566,6 +590,8 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
     CK(upload_tables(e, (char*)arena, st));
     std::vector<char> bn_done(e->bn_fwd.size(), 0);
     std::vector<int> sums_rpc(e->ops.size(), 0);    // per BatchNorm op: rows per chunk of the sums its producer left (0 = none)
+    int fwd_sk_bn = -1, fwd_sk_n = 0;               // the BatchNorm whose input lies in the split-K workspace as fwd_sk_n slices
+    size_t fwd_sk_slice = 0;
     struct ArenaMark { Exec* e; const void* a; ~ArenaMark() { e->fwd_rows_arena = a; } } arena_mark{e, arena};   // (after this pass the row-list outputs of `arena` are in the known state)
     auto act = [&](int s) -> void* { return s == 0 ? (void*)x_in : (void*)(A + e->t[s].off); };
     for (size_t i = 0; i < e->ops.size(); ++i) {
@@ -607,9 +633,16 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
                                              A + e->off_ks, e->sz_ks, (float*)(A + e->ops[o.stats_bn].stats_off), &sums_rpc[o.stats_bn], stream));
                 continue;
             }
-            CK(dreg_conv3d_igemm_occ(act(o.in), PK + w.pk_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0,
+            const bool try_fold = train && o.fold_sk_fwd && !(o.halo & 1);
+            if (try_fold) dreg_conv_defer_splitk_reduce(1);
+            const int rc_conv = dreg_conv3d_igemm_occ(act(o.in), PK + w.pk_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0,
                                      o.ksz, o.stride, o.pad, 0, o.relu, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0, o.add_same, 0, 0,
-                                     A + e->off_ks, e->sz_ks, o.in == 0 ? e->in_rowocc : nullptr, stream));
+                                     A + e->off_ks, e->sz_ks, o.in == 0 ? e->in_rowocc : nullptr, stream);
+            if (try_fold) {
+                int ns = 0; size_t sl = 0;
+                if (dreg_conv_splitk_deferred(&ns, &sl)) { fwd_sk_bn = (int)i + 1; fwd_sk_n = ns; fwd_sk_slice = sl; }
+            }
+            CK(rc_conv);
         } else if (o.kind == OP_CONV_ROWS) {
             const Param& w = e->prm[o.w];
             if (o.rows_out < 0 || o.rows_out >= nlists) return DREG_EINVAL;
@@ -661,6 +694,7 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
                 continue;
             }
             int deferred = 0;
+            if (fwd_sk_bn == (int)i) { dreg_bn_set_splitk_input((const float*)(A + e->off_ks), fwd_sk_n, fwd_sk_slice); fwd_sk_bn = -1; }
             CK(dreg_bn3d_fwd_defer_update(act(o.in), res_p, out_p, e->prm[o.w].val, e->prm[o.b].val, e->prm[o.p2].val, e->prm[o.p3].val,
                                           (float*)(A + o.aux0), (float*)(A + o.aux1), (float*)(A + e->off_bn_ws), x.B, V, x.C, 1e-5f, 0.1f, train, o.relu, 0,
                                           o.bt >= 0 ? (float*)(A + o.keep_var) : nullptr, &deferred, stream));
@@ -697,7 +731,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
     const char* PK = (const char*)pack_base;
     hipStream_t st = (hipStream_t)stream;
     auto act = [&](int s) -> void* { return s == 0 ? (void*)x_in : (void*)(A + e->t[s].off); };
-    if (flags & 1) { e->written.assign(e->t.size(), 0); e->aux_used = false; }
+    if (flags & 1) { e->written.assign(e->t.size(), 0); e->aux_used = false; e->pend_sk_bn = -1; }
     if (e->written.size() != e->t.size()) return DREG_EINVAL;
     std::vector<char>& written = e->written;
     auto grad = [&](int s) -> void* { return s == e->out_slot ? (void*)grad_out : (void*)(A + e->t[s].goff); };
@@ -944,8 +978,15 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                     CK(dreg_conv3d_dgrad_s2(gy, PK + w.pk_cls, gx, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0, o.ksz, o.pad, stream));
                 } else {
                     if (w.pk_dgrad == SIZE_MAX) return DREG_EINVAL;
-                    CK(dreg_conv3d_igemm_ws(gy, PK + w.pk_dgrad, gx, nullptr, nullptr, x.B, y.D, y.H, y.W, w.d0, x.D, x.H, x.W, w.d1,
-                                            o.ksz, o.stride, o.pad, 1, 0, 0, 0, 0, 0, 0, 0, A + e->off_ks, e->sz_ks, stream));
+                    const bool try_fold = o.fold_sk_bwd && gx == grad(o.in) && i - 1 >= 0;
+                    if (try_fold) dreg_conv_defer_splitk_reduce(1);
+                    const int rc_conv = dreg_conv3d_igemm_ws(gy, PK + w.pk_dgrad, gx, nullptr, nullptr, x.B, y.D, y.H, y.W, w.d0, x.D, x.H, x.W, w.d1,
+                                            o.ksz, o.stride, o.pad, 1, 0, 0, 0, 0, 0, 0, 0, A + e->off_ks, e->sz_ks, stream);
+                    if (try_fold) {
+                        int ns = 0; size_t sl = 0;
+                        if (dreg_conv_splitk_deferred(&ns, &sl)) { e->pend_sk_bn = i - 1; e->pend_sk_n = ns; e->pend_sk_slice = sl; }
+                    }
+                    CK(rc_conv);
                 }
             }
             if (e->needs_grad[o.in] && !fused_add) CK(commit(o.in));
@@ -976,6 +1017,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                 CK(commit(o.in2));
             } else {
                 // without a residual the ReLU mask is recomputed from x: y is not read
+                if (e->pend_sk_bn == i) { dreg_bn_set_splitk_input((const float*)(A + e->off_ks), e->pend_sk_n, e->pend_sk_slice); e->pend_sk_bn = -1; }
                 CK(dreg_bn3d_bwd_defer_params(act(o.in), gy, o.in2 >= 0 ? act(o.out) : nullptr, (float*)(A + o.aux0), (float*)(A + o.aux1), dx, dres, e->prm[o.w].grad, e->prm[o.b].grad,
                                               (float*)(A + e->off_coef), (float*)(A + e->off_bn_ws), x.B, V, x.C, o.relu, 1, 0,
                                               o.bt >= 0 ? (float*)(A + o.keep_sums) : nullptr, &deferred, stream));

@@ -420,11 +420,31 @@ template <int G> __device__ __forceinline__ void bns_reduce(float (&s1)[G], floa
 // NR > 0 (V == NR * 64 rows per grid: 8^3 -> 8, 4^3 -> 1): a thread's rows are loaded ONCE, all loads in flight together, and stay in
 // registers between the statistics and the apply phase (the general form, NR = 0, walks the rows twice, four loads in flight): the
 // kernels are short enough that the second walk and the exposed latencies were most of their time.  Same sums in the same order.
+// part (NR > 0 only): x has not been formed yet — it is the sum of `nsplit` fp32 slices part[s * slice + element] left by a split-K convolution
+// (dreg_conv_defer_splitk_reduce); the slices are added in ascending order, rounded to T and stored to x exactly as the convolution's own
+// reduce pass would have (the backward pass reads x), and the statistics use the rounded values: bit-identical, one launch less.
+template <typename T>
+__device__ __forceinline__ uint4 bns_sum_slices(const float* __restrict__ part, int nsplit, size_t slice, size_t off)
+{
+    constexpr int G = Gran<T>::G;
+    float v[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) v[i] = 0.f;
+#pragma unroll 4
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const float* p = part + (size_t)sp * slice + off;
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+        if constexpr (G == 8) { const float4 b = *reinterpret_cast<const float4*>(p + 4); v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w; }
+    }
+    return Gran<T>::pack(v);
+}
 template <typename T, int NR = 0>
 __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ scale_shift, float* __restrict__ mean_rstd, float* __restrict__ var_out,
-                                                           int V, int C, float eps, int relu)
+                                                           int V, int C, float eps, int relu,
+                                                           const float* __restrict__ part = nullptr, int nsplit = 0, size_t slice = 0)
 {
     constexpr int G = Gran<T>::G;
     const int t = threadIdx.x, col = t & (BNS_COLS - 1), rl = t >> 2, b = blockIdx.y;
@@ -440,7 +460,8 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const T* __restrict__
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             const size_t off = ((size_t)b * V + rl + j * BNS_ROWS) * C + c0;
-            xr[j] = *reinterpret_cast<const uint4*>(x + off);
+            if (part) { xr[j] = bns_sum_slices<T>(part, nsplit, slice, off); *reinterpret_cast<uint4*>(const_cast<T*>(x) + off) = xr[j]; }
+            else xr[j] = *reinterpret_cast<const uint4*>(x + off);
             if (res) rr[j] = *reinterpret_cast<const uint4*>(res + off);
         }
 #pragma unroll
@@ -537,7 +558,8 @@ template <typename T, int NR = 0>
 __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ y,
                                                            const float* __restrict__ scale_shift, const float* __restrict__ mean_rstd,
                                                            T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ sums,
-                                                           int V, int C, int relu)
+                                                           int V, int C, int relu,
+                                                           const float* __restrict__ part = nullptr, int nsplit = 0, size_t slice = 0)   // NR > 0: dy = the rounded sum of these split-K slices (never stored: nobody else reads it)
 {
     constexpr int G = Gran<T>::G;
     const int t = threadIdx.x, col = t & (BNS_COLS - 1), rl = t >> 2, b = blockIdx.y;
@@ -562,7 +584,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const T* __restrict__
         for (int j = 0; j < NR; ++j) {
             const size_t off = ((size_t)b * V + rl + j * BNS_ROWS) * C + c0;
             xr[j] = *reinterpret_cast<const uint4*>(x + off);
-            gr[j] = *reinterpret_cast<const uint4*>(dy + off);
+            gr[j] = part ? bns_sum_slices<T>(part, nsplit, slice, off) : *reinterpret_cast<const uint4*>(dy + off);
             if (relu && !remask) yr[j] = *reinterpret_cast<const uint4*>(y + off);
         }
 #pragma unroll
@@ -1956,6 +1978,16 @@ int dreg_bn_param_grad_batched(const void* descs_dev, int n, int block_base, int
 }
 // The next large-path forward call's residual is the INPUT of a ReLU-free BatchNorm whose (scale, shift) are res_scale_shift (that layer was
 // run with y == nullptr: statistics + finalize only); consumed by that one call.  See bn_apply_cols_kernel.
+// The next small-volume (register-resident) forward / backward call takes its x (forward) / dy (backward) as the sum of split-K slices:
+// see bn_small_fwd_kernel.  Consumed by that one call; DREG_EINVAL if the call does not take the register-resident path.
+struct BnSplitkIn { const float* part = nullptr; int nsplit = 0; size_t slice = 0; };
+static thread_local BnSplitkIn g_bn_splitk_in;
+void dreg_bn_set_splitk_input(const float* part, int nsplit, size_t slice) { g_bn_splitk_in.part = part; g_bn_splitk_in.nsplit = nsplit; g_bn_splitk_in.slice = slice; }
+// 1: a [B,V,C] layer of this dtype takes the register-resident one-launch kernels (what dreg_bn_set_splitk_input needs)
+int dreg_bn_small_in_regs(int B, int V, int C, int dtype)
+{
+    return (g_bn_small_regs && bn_small_ok(B, V, C, dtype == 0 ? 8 : 4) && (V == 8 * BNS_ROWS || V == BNS_ROWS)) ? 1 : 0;
+}
 static thread_local const float* g_bn_res_ss = nullptr;
 void dreg_bn_set_residual_transform(const float* res_scale_shift) { g_bn_res_ss = res_scale_shift; }
 static int bn3d_fwd_impl(const void* x, const void* res, void* y, const float* gamma, const float* beta,
@@ -1966,6 +1998,9 @@ static int bn3d_fwd_impl(const void* x, const void* res, void* y, const float* g
     hipStream_t st = (hipStream_t)stream;
     const float* res_ss = g_bn_res_ss;
     g_bn_res_ss = nullptr;
+    const BnSplitkIn ski = g_bn_splitk_in;
+    g_bn_splitk_in = BnSplitkIn{};
+    if (ski.part && !(train && sums_rows_per_chunk == 0 && dreg_bn_small_in_regs(B, V, C, dtype))) return DREG_EINVAL;
     if (deferred) *deferred = 0;
     const int G = dtype == 0 ? 8 : 4;
     if (C % G) return DREG_EINVAL;
@@ -1980,7 +2015,7 @@ static int bn3d_fwd_impl(const void* x, const void* res, void* y, const float* g
         const dim3 g1(CG / BNS_COLS, B);
         float* var = var_keep ? var_keep : workspace;   // [B][C] biased variances (the workspace holds >= B * chunks * C * 2 floats)
 #define BNS_FWD(Tt, NRv) hipLaunchKernelGGL((bn_small_fwd_kernel<Tt, NRv>), g1, dim3(256), 0, st, (const Tt*)x, (const Tt*)res, (Tt*)y, gamma, beta, \
-                                            scale_shift, mean_rstd, var, V, C, eps, relu)
+                                            scale_shift, mean_rstd, var, V, C, eps, relu, ski.part, ski.nsplit, ski.slice)
         const int nr = !g_bn_small_regs ? 0 : (V == 8 * BNS_ROWS ? 8 : (V == BNS_ROWS ? 1 : 0));
         if (dtype == 0) { if (nr == 8) BNS_FWD(bf16_t, 8); else if (nr == 1) BNS_FWD(bf16_t, 1); else BNS_FWD(bf16_t, 0); }
         else { if (nr == 8) BNS_FWD(float, 8); else if (nr == 1) BNS_FWD(float, 1); else BNS_FWD(float, 0); }
@@ -2035,6 +2070,9 @@ static int bn3d_bwd_impl(const void* x, const void* dy, const void* y, const flo
                          int B, int V, int C, int relu, int accumulate, int dtype, void* stream, float* sums_keep, int* deferred)
 {
     hipStream_t st = (hipStream_t)stream;
+    const BnSplitkIn ski = g_bn_splitk_in;
+    g_bn_splitk_in = BnSplitkIn{};
+    if (ski.part && !dreg_bn_small_in_regs(B, V, C, dtype)) return DREG_EINVAL;
     if (deferred) *deferred = 0;
     const int G = dtype == 0 ? 8 : 4;
     if (C % G) return DREG_EINVAL;
@@ -2044,7 +2082,7 @@ static int bn3d_bwd_impl(const void* x, const void* dy, const void* y, const flo
         const dim3 g1(CG / BNS_COLS, B);
         float* sums = sums_keep ? sums_keep : coef;   // [B][C][2]: per-grid (sum g, sum g xhat)
 #define BNS_BWD(Tt, NRv) hipLaunchKernelGGL((bn_small_bwd_kernel<Tt, NRv>), g1, dim3(256), 0, st, (const Tt*)x, (const Tt*)dy, (const Tt*)y, scale_shift, mean_rstd, \
-                                            (Tt*)dx, (Tt*)dres, sums, V, C, relu)
+                                            (Tt*)dx, (Tt*)dres, sums, V, C, relu, ski.part, ski.nsplit, ski.slice)
         const int nr = !g_bn_small_regs ? 0 : (V == 8 * BNS_ROWS ? 8 : (V == BNS_ROWS ? 1 : 0));
         if (dtype == 0) { if (nr == 8) BNS_BWD(bf16_t, 8); else if (nr == 1) BNS_BWD(bf16_t, 1); else BNS_BWD(bf16_t, 0); }
         else { if (nr == 8) BNS_BWD(float, 8); else if (nr == 1) BNS_BWD(float, 1); else BNS_BWD(float, 0); }

@@ -80,6 +80,11 @@ SIGNATURES = {
     "dreg_bn_set_small_regs": (None, [I]),
     "dreg_exec_set_fuse_stem": (None, [I]),
     "dreg_exec_set_sparse_stem": (None, [I]),
+    "dreg_exec_set_fold_splitk": (None, [I]),
+    "dreg_conv_defer_splitk_reduce": (None, [I]),
+    "dreg_conv_splitk_deferred": (I, [P, P]),
+    "dreg_bn_set_splitk_input": (None, [P, I, Z]),
+    "dreg_bn_small_in_regs": (I, [I, I, I, I]),
     "dreg_ps_set_group_wgrad": (None, [I]),
     "dreg_wgrad_group_desc_bytes": (I, []),
     "dreg_linear_wgrad_group_fill": (I, [P, P, P, P, Z, I, I, I, P, P]),

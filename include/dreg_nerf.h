@@ -194,6 +194,15 @@ int dreg_bn3d_bwd_defer_params(const void* x, const void* dy, const void* y, con
  * shift only — the downsample branch of a bottleneck's first block, resnet3d.py:104-110): res_scale_shift = that layer's scale_shift; the
  * branch's output is formed on the fly, rounded as the separate apply pass stores it (bit-identical).  Consumed by that one call. */
 void dreg_bn_set_residual_transform(const float* res_scale_shift);
+/* Split-K sums folded into the consumer (the 8^3 / 4^3 levels of resnet3d.py's layer3 / layer4: conv2 -> bn2 forward, conv2's data gradient -> bn1
+ * backward).  dreg_conv_defer_splitk_reduce(1) arms the NEXT convolution launch of the calling thread: if it runs split-K with bf16 output and no
+ * bias / ReLU, its fp32 slices [nsplit][M * Cout] stay in its workspace un-summed and dreg_conv_splitk_deferred returns 1 with nsplit / the slice
+ * length (it always disarms).  dreg_bn_set_splitk_input hands them to the NEXT BatchNorm call of the thread, which must take the register-resident
+ * one-launch kernels (dreg_bn_small_in_regs): forward — x := the rounded sum (stored to x: the backward pass reads it); backward — dy := the rounded sum. */
+void dreg_conv_defer_splitk_reduce(int arm);
+int dreg_conv_splitk_deferred(int* nsplit, size_t* slice);
+void dreg_bn_set_splitk_input(const float* part, int nsplit, size_t slice);
+int dreg_bn_small_in_regs(int B, int V, int C, int dtype);
 int dreg_bn_running_update_batched(const void* descs_dev, int n, int block_base, int nblocks, float momentum, void* stream);
 int dreg_bn_param_grad_batched(const void* descs_dev, int n, int block_base, int nblocks, int accumulate, void* stream);
 
