@@ -284,3 +284,36 @@ def test_batched_batchnorm_tails_change_nothing():
     assert torch.equal(got[0][0], got[1][0])
     for k in got[0][1]:
         assert torch.equal(got[0][1][k], got[1][1][k]), k
+
+
+@pytest.mark.parametrize("setter", ["dreg_ps_set_group_wgrad", "dreg_exec_set_fold_splitk", "dreg_exec_set_fold_res_bn"])
+def test_bit_identical_round4_switches(setter):
+    """The round-4 restructurings that claim bit-identity — the point-set half's weight gradients as one launch per tile shape, the split-K sums
+    of the 8^3 / 4^3 convolutions inside the BatchNorm launch next to them, the downsample branch's BatchNorm applied inside the BatchNorm that
+    adds it — switched off and on: the same optimizer step, every gradient and the losses bit for bit."""
+    from dreg_nerf_amd import lib as L, params, synth
+    from dreg_nerf_amd.train_step import TrainStep
+    lib = L.load()
+    fn = getattr(lib, setter)
+    res = []
+    try:
+        for v in (0, 1):
+            fn(v)
+            torch.manual_seed(3407)
+            m = NeRFRegTr(precision="bf16")
+            m.load_state_dict(params.synth_state_dict(0, profile="wc"), strict=True)
+            m = m.to(DEV).train()
+            ts = TrainStep(m)
+            batch = []
+            for i in range(2):
+                d = synth.shell_pair(64, 1 + 2 * i, 2 + 2 * i, pose=synth.fixed_pose())
+                batch.append({k: (t.to(DEV) if torch.is_tensor(t) else t) for k, t in d.items()})
+            out = ts.step(batch)
+            torch.cuda.synchronize()
+            res.append(({k: float(t) for k, t in out["losses"].items()}, float(out["grad_norm"]),
+                        {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
+    finally:
+        fn(1)
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
