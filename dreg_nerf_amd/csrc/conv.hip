@@ -2726,21 +2726,32 @@ static int wgrad_impl(const void* gout, const void* in, float* dw, void* workspa
 // and returns its tile shape (*variant = BM * 1000 + BNC) and workgroup count; block0 is left to the caller (exclusive prefix of the
 // workgroup counts inside one variant's table).  DREG_EINVAL: the layer does not take the four-wave direct-to-LDS kernel (caller falls back).
 int dreg_wgrad_group_desc_bytes() { return (int)sizeof(WgradGroupDesc); }
+int dreg_conv3d_wgrad_group_fill(void* desc_host, const void* gout, const void* in, void* workspace, size_t workspace_bytes,
+                                 int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksz, int stride, int pad,
+                                 int* variant, int* nblocks);
 int dreg_linear_wgrad_group_fill(void* desc_host, const void* gout, const void* in, void* workspace, size_t workspace_bytes,
                                  int rows, int Cin, int Cout, int* variant, int* nblocks)
 {
+    return dreg_conv3d_wgrad_group_fill(desc_host, gout, in, workspace, workspace_bytes, rows, 1, 1, 1, Cin, 1, 1, 1, Cout, 1, 1, 0, variant, nblocks);
+}
+// The same for a dense convolution layer (no row list, no occupancy flags): gout bf16 [B,Do,Ho,Wo,Cout], in bf16 [B,Di,Hi,Wi,Cin]; the
+// descriptor makes the grouped launch write exactly the partials dreg_conv3d_wgrad_partials leaves for the layer.
+int dreg_conv3d_wgrad_group_fill(void* desc_host, const void* gout, const void* in, void* workspace, size_t workspace_bytes,
+                                 int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksz, int stride, int pad,
+                                 int* variant, int* nblocks)
+{
     ConvGeom g;
-    int rc = fill_geom(g, rows, 1, 1, 1, Cin, 1, 1, 1, Cout, 1, 1, 0, 0, 2);
+    int rc = fill_geom(g, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, ksz, stride, pad, 0, 2);
     if (rc) return rc;
     if ((Cout % 128 != 0 && Cout != 64) || !g_use_glds) return DREG_EINVAL;
-    if (workspace_bytes < dreg_conv3d_wgrad_workspace_bytes(rows, 1, 1, 1, Cin, Cout, 1, 0)) return DREG_EINVAL;
+    if (workspace_bytes < dreg_conv3d_wgrad_workspace_bytes(B, Do, Ho, Wo, Cin, Cout, ksz, 0)) return DREG_EINVAL;
     const uint32_t nrows = g.M;
-    const int nsplit = dreg_conv3d_wgrad_splits(rows, 1, 1, 1, Cin, Cout, 1, 0);
+    const int nsplit = dreg_conv3d_wgrad_splits(B, Do, Ho, Wo, Cin, Cout, ksz, 0);
     uint32_t vps = (uint32_t)((nrows + nsplit - 1) / nsplit);
     vps = ((vps + 63) / 64) * 64;
     if (vps == 0) vps = 64;
     int bm = (Cout % 128 == 0) ? 128 : 64;
-    const uint64_t gbytes = (uint64_t)g.M * Cout * 2, ibytes = (uint64_t)rows * Cin * 2;
+    const uint64_t gbytes = (uint64_t)g.M * Cout * 2, ibytes = (uint64_t)B * Di * Hi * Wi * Cin * 2;
     if (gbytes >= 0x7fffff00ull || ibytes >= 0x7fffff00ull) return DREG_EINVAL;
     int bnc = (g.Kpad % 128 == 0 || g.Kpad > 128) ? 128 : 64;
     if (g_narrow_small >= 2 && (Cout / bm) * ((g.Kpad + bnc - 1) / bnc) * nsplit < g_narrow_thr) {      // the rules of wgrad_impl

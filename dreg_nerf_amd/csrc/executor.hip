@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 #include "../../include/dreg_nerf.h"
 #include "../../include/dreg_nerf_tuning.h"   // dreg_conv_get_glds (read only)
@@ -58,6 +59,7 @@ struct Op {
     int stats_bn = -1;           // OP_CONV whose bf16 output feeds a large-path BatchNorm: that op's index (its chunk sums come from this convolution's epilogue)
     size_t stats_off = 0;        // OP_BN with such a producer: its own chunk-sum buffer [B][V / 128][C][2] (the shared workspace may be used in between)
     int stats_conv = -1;
+    int grp = 0;                 // OP_CONV of the 16^3 / 8^3 / 4^3 levels whose weight-gradient partials are written by the pass's grouped launch (dreg_wgrad_group_launch)
     int fold_sk_fwd = 0, fold_sk_bwd = 0;   // OP_CONV: a split-K launch of its forward / data gradient leaves the slices to the one-launch BatchNorm right behind it (forward: op + 1, backward: op - 1)
     int fold_into = -1, res_from = -1;   // OP_BN (ReLU-free, large path) whose output only feeds BatchNorm `fold_into` as its residual: not applied, that layer applies it on the fly (res_from = this op)
     int bt = -1;                 // OP_BN on the one-launch small path: index of its record in the two BatchNorm tail tables
@@ -108,6 +110,12 @@ struct Exec {
     char* pack_base = nullptr;            // device address of the pack buffer (dreg_exec_export_pack_table)
     std::vector<char> written;            // backward pass state, kept across the segments of dreg_exec_backward_range
     bool aux_used = false;
+    // grouped weight gradients: the eligible ops (program order), their descriptor tables per tile shape (built per arena), the launch point
+    struct GrpLaunch { size_t off; int n, variant, blocks; };
+    std::vector<int> grp_ops;
+    std::vector<GrpLaunch> grp_launch;
+    size_t off_grp = 0;
+    bool grp_ready = false;
     int pend_sk_bn = -1, pend_sk_n = 0;    // a BatchNorm op whose dy lies in the split-K workspace as pend_sk_n slices (set by the data gradient of the op behind it; survives a segment boundary)
     size_t pend_sk_slice = 0;
     const void* fwd_rows_arena = nullptr;  // the arena whose row-list convolution outputs (rows_out >= 0) are known to be zero outside their last lists
@@ -138,6 +146,7 @@ struct Scope {   // optional HIP-event bracket of one launch group
 int g_sparse_grads = 1;   // tuning (include/dreg_nerf_tuning.h): row-cleared instead of memset gradient buffers in front of the active-set convolutions
 int g_bn_batch_tails = 1; // tuning (include/dreg_nerf_tuning.h): the small BatchNorms' running-statistics / parameter-gradient launches batched per pass
 int g_s2_accumulate = 1;  // tuning (include/dreg_nerf_tuning.h): a stride-2 data gradient that is a tensor's second contribution adds in its epilogue (dreg_conv3d_dgrad_s2_acc)
+int g_group_wgrad = 1;    // tuning (include/dreg_nerf_tuning.h): the 16^3 / 8^3 / 4^3 levels' weight-gradient partials of a whole backward pass in one launch per tile shape
 int g_fold_splitk = 1;    // tuning (include/dreg_nerf_tuning.h): split-K sums of the 8^3 / 4^3 convolutions folded into the BatchNorm launch behind them
 int g_fold_res_bn = 1;    // tuning (include/dreg_nerf_tuning.h): the downsample branch's BatchNorm applied inside the BatchNorm that adds it (large path)
 int g_sparse_stem = 1;    // tuning (include/dreg_nerf_tuning.h): BatchNorm + ReLU + max-pool behind a row-list stem run from the row lists (statistics over the listed rows, activation on the lateral's rows only)
@@ -384,6 +393,18 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
     e->off_coef = off; off += align256(coef);
     e->off_ks = off; off += align256(e->sz_ks);
     for (Op& o : e->ops) if (o.rd != -1) { o.wg_off = off; off += align256(o.wg_bytes); if (o.rd >= 0) e->reduce[o.rd].part = (const float*)o.wg_off; }
+    // weight gradients of the small-volume ResNet levels (layer2-4: 42 bias-free convolutions at 16^3 / 8^3 / 4^3, 12-50 us launches of 50-400
+    // workgroups each): their split partials are written by ONE launch per tile shape once the pass has produced all their output gradients
+    if (g_group_wgrad)
+        for (size_t i = 0; i < e->ops.size(); ++i) {
+            Op& o = e->ops[i];
+            const Tensor& y = e->t[o.out];
+            if (o.kind != OP_CONV || o.rd < 0 || o.rows_out >= 0 || o.in == 0 || o.b >= 0 || o.out == e->out_slot || !e->prm[o.w].grad) continue;
+            if ((long)y.D * y.H * y.W > 4096) continue;
+            o.grp = 1; e->grp_ops.push_back((int)i);
+        }
+    if (e->grp_ops.size() < 4) { for (int i : e->grp_ops) e->ops[i].grp = 0; e->grp_ops.clear(); }
+    e->off_grp = off; off += align256(e->grp_ops.size() * (size_t)dreg_wgrad_group_desc_bytes() + 16);
     e->off_rd = off; off += align256(e->reduce.size() * sizeof(ReduceRec) + 16);
     e->off_bnf = off; off += align256(e->bn_fwd.size() * sizeof(BnTailRec) + 16);
     e->off_bnb = off; off += align256(e->bn_bwd.size() * sizeof(BnTailRec) + 16);
@@ -524,6 +545,7 @@ void dreg_exec_set_fuse_stem(int on) { g_fuse_stem = on ? 1 : 0; }   // read whe
 void dreg_exec_set_sparse_stem(int on) { g_sparse_stem = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_fold_res_bn(int on) { g_fold_res_bn = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_fold_splitk(int on) { g_fold_splitk = on ? 1 : 0; }   // read when an executor is created
+void dreg_exec_set_group_wgrad(int on) { g_group_wgrad = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_s2_accumulate(int on) { g_s2_accumulate = on ? 1 : 0; }   // read at every backward call
 void dreg_exec_set_fuse_bn_stats(int on) { g_fuse_bn_stats = on ? 1 : 0; }   // read when an executor is created
 void dreg_exec_set_brick(int mask) { g_brick = mask & 3; }   // packs: read when an executor is created; dispatch: at every forward / backward call
@@ -556,6 +578,37 @@ static int upload_tables(Exec* e, char* A, hipStream_t st)
     if (!e->reduce_abs.empty() && hipMemcpyAsync(A + e->off_rd, e->reduce_abs.data(), e->reduce_abs.size() * sizeof(ReduceRec), hipMemcpyHostToDevice, st) != hipSuccess) return DREG_ELAUNCH;
     if (!f.empty() && (hipMemcpyAsync(A + e->off_bnf, f.data(), f.size() * sizeof(BnTailRec), hipMemcpyHostToDevice, st) != hipSuccess ||
                        hipMemcpyAsync(A + e->off_bnb, b.data(), b.size() * sizeof(BnTailRec), hipMemcpyHostToDevice, st) != hipSuccess)) return DREG_ELAUNCH;
+    // grouped weight-gradient descriptors (absolute addresses of this arena): one table per tile shape, block0 = exclusive prefix inside it
+    const int gd = dreg_wgrad_group_desc_bytes();
+    struct Rec { std::vector<char> d; int variant, nblocks, op; };
+    std::vector<Rec> recs;
+    e->grp_launch.clear(); e->grp_ready = false;
+    bool all_ok = !e->grp_ops.empty();
+    for (int i : e->grp_ops) {
+        const Op& o = e->ops[i];
+        const Tensor& x = e->t[o.in];
+        const Tensor& y = e->t[o.out];
+        const Param& w = e->prm[o.w];
+        Rec r; r.d.resize(gd); r.op = i;
+        if (e->t[o.out].goff == SIZE_MAX ||
+            dreg_conv3d_wgrad_group_fill(r.d.data(), A + y.goff, A + x.off, A + o.wg_off, o.wg_bytes, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0,
+                                         o.ksz, o.stride, o.pad, &r.variant, &r.nblocks) != DREG_OK || w.d1 != x.C) { all_ok = false; break; }
+        recs.push_back(std::move(r));
+    }
+    std::vector<char> gtab;
+    if (all_ok) {
+        std::stable_sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) { return a.variant < b.variant; });
+        gtab.resize(recs.size() * (size_t)gd);
+        for (size_t k = 0; k < recs.size(); ++k) {
+            if (e->grp_launch.empty() || e->grp_launch.back().variant != recs[k].variant) e->grp_launch.push_back(Exec::GrpLaunch{e->off_grp + k * (size_t)gd, 0, recs[k].variant, 0});
+            const int b0 = e->grp_launch.back().blocks;
+            std::memcpy(recs[k].d.data() + gd - (int)sizeof(int), &b0, sizeof(int));
+            std::memcpy(gtab.data() + k * (size_t)gd, recs[k].d.data(), (size_t)gd);
+            e->grp_launch.back().n += 1; e->grp_launch.back().blocks += recs[k].nblocks;
+        }
+        if (hipMemcpyAsync(A + e->off_grp, gtab.data(), gtab.size(), hipMemcpyHostToDevice, st) != hipSuccess) return DREG_ELAUNCH;
+        e->grp_ready = true;
+    }
     if (hipStreamSynchronize(st) != hipSuccess) return DREG_ELAUNCH;   // the host copies above are locals
     e->reduce_arena = A;
     return DREG_OK;
@@ -810,6 +863,9 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
         return DREG_OK;
     };
     // weight / bias gradient launches of convolution op i (second stream behind the event "its output gradient is complete")
+    // grouped weight gradients: only in a whole-pass call with the second stream and no per-launch timing brackets
+    const bool grp_active = g_group_wgrad && e->grp_ready && aux_on && n_ws == 1 && !e->timing && op_begin == 0 && op_end == (int)e->ops.size() && (flags & 3) == 3;
+    std::vector<int> grp_seen;
     auto param_grads = [&](int i, bool event_recorded) -> int {
         const Op& o = e->ops[i];
         const Tensor& x = e->t[o.in];
@@ -821,7 +877,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
         const int* r_out = lrows ? (const int*)rowlists[RL * o.rows_out] : nullptr;
         const int n_out = lrows ? (int)rowlists[RL * o.rows_out + 1] : 0;
         hipStream_t ws = st;
-        if (aux_on) {
+        if (aux_on && !(grp_active && o.grp && !(o.b >= 0 && e->prm[o.b].grad))) {
             if (!e->ev[i] && hipEventCreateWithFlags(&e->ev[i], hipEventDisableTiming) != hipSuccess) return DREG_ELAUNCH;
             if (!event_recorded && hipEventRecord(e->ev[i], st) != hipSuccess) return DREG_ELAUNCH;
             if (hipStreamWaitEvent(e->aux, e->ev[i], 0) != hipSuccess) return DREG_ELAUNCH;
@@ -838,6 +894,10 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
             }
         }
         bool flush_now = false;
+        if (w.grad && grp_active && o.grp) {
+            // written by the grouped launch at the pass's launch point (below); nothing else to do for this layer (no bias)
+            grp_seen.push_back(i);
+        } else
         if (w.grad) {
             Scope sc(e, ws, i, 2);
             if (o.rd >= 0) {
@@ -860,6 +920,26 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
             if (rows) CK(dreg_colsum_rows(gy, r_out, n_out, e->prm[o.b].grad, (float*)(A + e->off_cs), w.d0, 1, 0, (void*)bs));
             else CK(dreg_colsum(gy, e->prm[o.b].grad, (float*)(A + e->off_cs), (size_t)y.B * y.D * y.H * y.W, w.d0, 1, 0, (void*)bs));
         }
+        return DREG_OK;
+    };
+    // the held-back weight gradients: one launch per tile shape when every eligible layer was met, else (a layer no gradient reached) one by one
+    auto flush_group = [&](int ev_op) -> int {
+        if (grp_seen.empty()) return DREG_OK;
+        if (!e->ev[ev_op] && hipEventCreateWithFlags(&e->ev[ev_op], hipEventDisableTiming) != hipSuccess) return DREG_ELAUNCH;
+        if (hipEventRecord(e->ev[ev_op], st) != hipSuccess || hipStreamWaitEvent(e->aux, e->ev[ev_op], 0) != hipSuccess) return DREG_ELAUNCH;
+        aux_used = true;
+        if (grp_seen.size() == e->grp_ops.size()) {
+            for (const Exec::GrpLaunch& q : e->grp_launch) CK(dreg_wgrad_group_launch(A + q.off, q.n, q.variant, q.blocks, (void*)e->aux));
+        } else {
+            for (int j : grp_seen) {
+                const Op& oj = e->ops[j]; const Tensor& xj = e->t[oj.in]; const Tensor& yj = e->t[oj.out]; const Param& wj = e->prm[oj.w];
+                CK(dreg_conv3d_wgrad_partials(grad(oj.out), act(oj.in), A + oj.wg_off, oj.wg_bytes, nullptr, 0, xj.B, xj.D, xj.H, xj.W, xj.C, wj.d1,
+                                              yj.D, yj.H, yj.W, wj.d0, oj.ksz, oj.stride, oj.pad, nullptr, (void*)e->aux));
+            }
+        }
+        for (int j : grp_seen) { rd_done[e->ops[j].rd] = 1; rd_pending += e->ops[j].wg_bytes; }
+        rd_stream = e->aux;
+        grp_seen.clear();
         return DREG_OK;
     };
     std::vector<int> deferred_pg;            // ops whose parameter-gradient launches are held back (their events are recorded)
@@ -919,6 +999,8 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
             } else if (pg) {
                 if (vox_out <= 512 && !deep_reached) { deep_reached = true; CK(run_deferred()); }
                 CK(param_grads(i, false));
+                // the first eligible op of the program = the last one the backward pass meets: every grouped layer's output gradient is complete
+                if (grp_active && !e->grp_ops.empty() && i == e->grp_ops.front()) CK(flush_group(i));
             }
             if (o.in2 >= 0 && e->needs_grad[o.in2]) {
                 const Tensor& ta = e->t[o.in2];
@@ -1033,6 +1115,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
         }
     }
     CK(run_deferred());                      // (a segment that never reached the deep levels)
+    if (!grp_seen.empty()) CK(flush_group(e->grp_ops.front()));      // (the launch point was never met)
     CK(flush_reduce());
     CK(flush_bn_tails(e, A, bn_done, 1, st));
     if (aux_on) CK(join_extra());

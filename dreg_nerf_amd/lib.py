@@ -80,6 +80,8 @@ SIGNATURES = {
     "dreg_bn_set_small_regs": (None, [I]),
     "dreg_exec_set_fuse_stem": (None, [I]),
     "dreg_exec_set_sparse_stem": (None, [I]),
+    "dreg_exec_set_group_wgrad": (None, [I]),
+    "dreg_conv3d_wgrad_group_fill": (I, [P, P, P, P, Z] + [I] * 12 + [P, P]),
     "dreg_exec_set_fold_splitk": (None, [I]),
     "dreg_conv_defer_splitk_reduce": (None, [I]),
     "dreg_conv_splitk_deferred": (I, [P, P]),

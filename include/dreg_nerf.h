@@ -161,6 +161,10 @@ int dreg_wgrad_reduce_batched(const void* descs_dev, int n, int block_base, int 
 int dreg_wgrad_group_desc_bytes(void);
 int dreg_linear_wgrad_group_fill(void* desc_host, const void* gout, const void* in, void* workspace, size_t workspace_bytes,
                                  int rows, int Cin, int Cout, int* variant, int* nblocks);
+/* the same for a dense convolution layer (no row list, no occupancy flags): gout bf16 [B,Do,Ho,Wo,Cout], in bf16 [B,Di,Hi,Wi,Cin] */
+int dreg_conv3d_wgrad_group_fill(void* desc_host, const void* gout, const void* in, void* workspace, size_t workspace_bytes,
+                                 int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksz, int stride, int pad,
+                                 int* variant, int* nblocks);
 int dreg_wgrad_group_launch(const void* descs_dev, int n, int variant, int total_blocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- FPN3D companions

@@ -43,6 +43,7 @@ void dreg_exec_set_s2_accumulate(int on);             /* 1 (default): a stride-2
 void dreg_exec_set_fold_res_bn(int on);               /* 1 (default): executors created from now on apply a downsample branch's BatchNorm inside the BatchNorm that adds it (large path; bit-identical) */
 void dreg_ps_set_group_wgrad(int on);                 /* 1 (default, with dreg_ps_set_fuse(1)): the point-set executor launches the split partials of all its linear layers' weight gradients once per tile shape at the end of the backward pass (dreg_wgrad_group_launch); 0: one launch per layer as its output gradient completes.  Bit-identical. */
 void dreg_exec_set_fold_splitk(int on);               /* 1 (default): executors created from now on let the one-launch BatchNorm of the 8^3 / 4^3 levels sum the split-K slices of the convolution in front of (forward) / behind (backward) it; bit-identical */
+void dreg_exec_set_group_wgrad(int on);               /* 1 (default): executors created from now on write the weight-gradient partials of the bias-free 16^3 / 8^3 / 4^3 convolutions (layer2-4) by one launch per tile shape per backward pass (whole-pass calls with a second stream; segmented passes and timed passes launch per layer); bit-identical */
 void dreg_exec_set_brick(int mask);                   /* active-set 3^3 convolutions whose row list comes with tile tables run on csrc/conv_brick.hip: bit 0 (default) = launches with 64 output channels (the data gradient of pyramid_transformation_1: 309 vs 455 us), bit 1 = those with 256 as well (measured slower than the row-list implicit GEMM: tools/bench_conv_brick.py); 0: never (bit-identical to the per-op path) */
 void dreg_exec_set_defer_head_pg(int on);             /* experiment, default 0 — measured no gain (18.50 vs 18.51 ms per step, tools/ab_step.py): 1 = the weight / bias gradient launches of the 64^3 / 32^3 layers the backward pass meets first (the FPN head) are held back until it reaches the 8^3 / 4^3 levels: there the launch-latency-bound main chain leaves the CUs to them, while next to the head's own throughput-bound data gradients they only slowed both down */
 void dreg_voxel_set_own_sort(int on);                 /* experiment, default 0: 1 = the voxel keys of a downsample round (<= 131,072) are built, sorted (stable 4-bit LSD radix sort, ballot ranks) and segmented by ONE launch of one workgroup instead of rocPRIM radix_sort_pairs + inclusive_scan + three small kernels; identical results, but 0.45-1.45 ms per round on its single CU against ~0.07 ms (so the product path keeps rocPRIM) */

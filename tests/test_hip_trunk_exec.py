@@ -286,7 +286,7 @@ def test_batched_batchnorm_tails_change_nothing():
         assert torch.equal(got[0][1][k], got[1][1][k]), k
 
 
-@pytest.mark.parametrize("setter", ["dreg_ps_set_group_wgrad", "dreg_exec_set_fold_splitk", "dreg_exec_set_fold_res_bn"])
+@pytest.mark.parametrize("setter", ["dreg_ps_set_group_wgrad", "dreg_exec_set_group_wgrad", "dreg_exec_set_fold_splitk", "dreg_exec_set_fold_res_bn"])
 def test_bit_identical_round4_switches(setter):
     """The round-4 restructurings that claim bit-identity — the point-set half's weight gradients as one launch per tile shape, the split-K sums
     of the 8^3 / 4^3 convolutions inside the BatchNorm launch next to them, the downsample branch's BatchNorm applied inside the BatchNorm that

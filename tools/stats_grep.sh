@@ -1,7 +1,8 @@
-# usage: bash tools/stats_grep.sh <pattern>   — serial-stream rocprofv3 kernel stats of 8 bench steps, rows matching the pattern (avg us, calls)
+# usage: bash tools/stats_grep.sh <pattern,...> [two]   — rocprofv3 kernel stats of 8 bench steps (serial streams; "two": the production two-stream mode), rows matching a pattern
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/sg; rm -rf $out; mkdir -p $out
-DREG_SERIAL_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/p -o k -- python bench.py --no-cpu-baseline --no-dense-reference --no-nerf-labels-reference --no-ngp-reference --steps 8 --warmup 3 > $out/log.txt 2>&1
+ser=1; [ "$2" = two ] && ser=0
+DREG_SERIAL_STREAMS=$ser timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/p -o k -- python bench.py --no-cpu-baseline --no-dense-reference --no-nerf-labels-reference --no-ngp-reference --steps 8 --warmup 3 > $out/log.txt 2>&1
 f=$(find $out/p -name "*kernel_stats.csv" | head -1)
 python - <<PY
 import csv
