@@ -463,6 +463,8 @@ def main():
         for p in model.parameters():
             dist.broadcast(p.data, 0)
     ts = TrainStep(model)
+    if world > 1 and backend == "nccl" and dist.get_world_size() != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: the RCCL group has {dist.get_world_size()} ranks")
 
     # inputs resident in HBM before the timed region; every rank owns different pairs
     pose = synth.fixed_pose()
@@ -482,6 +484,9 @@ def main():
         for _ in range(args.warmup):
             ts.step(batch)
         sync()
+        if ts._sync is not None:
+            ts._sync.measure_exposed = True
+            ts._sync.exposed_ms()
         ops.PROFILER = ops.KernelTimer()
         # (both native executors bracket their own convolution / linear launches with HIP events while the profiler is enabled)
         t0 = time.perf_counter()
@@ -558,6 +563,19 @@ def main():
             rf_d, _ = roofline_of(pr_d, "dense_head")
             dense = {"value": args.pairs * world * args.steps / el_d, "unit": "pairs/s", "ms_per_step": 1e3 * el_d / args.steps, "roofline": rf_d}
     elapsed, prof = timed(not args.dense_head and args.precision == "bf16")
+    # the multi-rank run validates itself: identical parameters and the same clipped gradient norm on every rank after the timed steps, and how long
+    # the step stream stood still for gradient exchange that backward did not hide (trivially in sync / 0 ms at one rank)
+    from dreg_nerf_amd.optim import ranks_in_sync
+    in_sync = ranks_in_sync(ts.optimizer, ts.optimizer.grad_norm())
+    exposed = ts._sync.exposed_ms() if ts._sync is not None else (0.0, 0)
+    if ts._sync is not None:
+        ts._sync.measure_exposed = False
+    if world > 1:
+        t_ = torch.tensor([exposed[0]], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+        exposed = (float(t_.item()), exposed[1])
+    if not in_sync["ranks_in_sync"]:
+        raise SystemExit(f"bench.py: ranks out of sync after the timed region: {in_sync}")
 
     # the active-set head's work follows the occupied surface: the same step on shells of 1e4 .. 1e5 occupied voxels per side
     sweep = None
@@ -628,6 +646,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "ranks_in_sync": in_sync["ranks_in_sync"], "rank_sync": in_sync,
+            "allreduce_exposed_ms_per_step": exposed[0], "allreduce_buckets": (len(ts._sync.buckets) if ts._sync is not None else 0),
             "config": {"workload": f"RegTR fwd+bwd+AdamW, shell-R synthetic pairs, {args.res}^3 grids, "
                                    f"{args.pairs} pairs ({2 * args.pairs} grids) per GPU per step, random-init weights",
                        "global_batch_pairs": args.pairs * world, "resolution": args.res,

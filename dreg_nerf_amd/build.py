@@ -6,6 +6,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdreg_nerf_hip.so")
+# The measurement build: the same sources with -DDREG_PROBE (csrc/common.h DREG_KNOB: the kernel-variant knobs become mutable, their
+# process-global setters of include/dreg_nerf_probe.h are exported).  Loaded explicitly by tools/ and the variant tests only.
+PROBE_LIB = os.path.join(HERE, "libdreg_nerf_hip_probe.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize / -fno-vectorize: keep packed-fp32 VALU instructions (v_pk_{add,mul,fma}_f32) out of the device code.  On this
 # hardware a v_pk_*_f32 in one wave returned a wrong low element in lanes 48..63 while the implicit-GEMM kernels ran on a second
@@ -26,28 +29,41 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def _build_one(lib, suffix, extra, force, verbose):
     srcs = sources()
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", f) for f in ("dreg_nerf.h",)]
     objs = []
     newest_hdr = max(os.path.getmtime(h) for h in hdrs) if hdrs else 0
     procs = []
     for s in srcs:
-        o = s[:-4] + ".o"
+        o = s[:-4] + suffix
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), newest_hdr):
-            cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + extra + FILE_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd)))
-    for s, p in procs:
-        if p.wait() != 0:
-            raise RuntimeError(f"hipcc failed on {s}")
-    if force or procs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    return objs, procs
+
+
+def _link(lib, objs, relink, verbose):
+    if relink or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+
+
+def build(force: bool = False, verbose: bool = True, probe: bool = True) -> str:
+    """Compile every csrc/*.hip for gfx950 and link libdreg_nerf_hip.so (the product) and, with probe=True, libdreg_nerf_hip_probe.so."""
+    objs, procs = _build_one(LIB, ".o", [], force, verbose)
+    pobjs, pprocs = _build_one(PROBE_LIB, ".probe.o", ["-DDREG_PROBE=1"], force, verbose) if probe else ([], [])
+    for s, p in procs + pprocs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {s}")
+    _link(LIB, objs, force or bool(procs), verbose)
+    if probe:
+        _link(PROBE_LIB, pobjs, force or bool(pprocs), verbose)
     return LIB
 
 

@@ -54,6 +54,15 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Kernel-variant knobs.  The product library (libdreg_nerf_hip.so) has NO process-global mutable state: every knob is a compile-time
+// constant there and its setter does not exist.  The same sources built with -DDREG_PROBE (libdreg_nerf_hip_probe.so, loaded explicitly by
+// tools/ and the variant tests: include/dreg_nerf_probe.h) make them mutable and export the setters.
+#ifdef DREG_PROBE
+#define DREG_KNOB(type, name, value) static type name = value
+#else
+#define DREG_KNOB(type, name, value) static constexpr type name = value
+#endif
+
 #define DREG_LAUNCH_CHECK()                                   \
     do {                                                      \
         hipError_t e__ = hipGetLastError();                   \

@@ -242,7 +242,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 // 27-bit mask computed once per block, so the K loop spends 3 VALU ops per row on addressing.
 // ------------------------------------------------------------------------------------------------
 // DBG (tools/igemm_phase_probe.py, measurement only): s_memtime stamps around the four phases of a K step, summed per wave into g_igemm_dbg
+#ifdef DREG_PROBE
 __device__ unsigned long long g_igemm_dbg[8];
+#endif
 __device__ __forceinline__ unsigned long long dbg_now() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
 // AP (round 3): the 128-row tiles on EIGHT waves in two anti-phase groups, for launches that put at most one or two workgroups on a CU
 // (layer2-4 of the ResNet, the point-set half's linear layers: ~150 launches per training step).  With four waves and one workgroup
@@ -548,11 +550,13 @@ __global__ __launch_bounds__((BN == 256 || AP) ? 512 : 256) void conv_igemm_glds
         ibuf = ibuf + 1 == nstage ? 0 : ibuf + 1;
     }
     if constexpr (DBG) {
+#ifdef DREG_PROBE
         if (lane == 0) {
             for (int q = 0; q < 4; ++q) atomicAdd(&g_igemm_dbg[q], dsum[q]);
             atomicAdd(&g_igemm_dbg[4], (unsigned long long)(k_end - k_begin));   // K steps x waves
             atomicAdd(&g_igemm_dbg[5], 1ull);                                    // waves
         }
+#endif
     }
     }   // !AP
 
@@ -935,7 +939,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 // XOR of the 16-byte granule index with f(row), applied on the SOURCE side of the DMA and on the read address:
 // 256-byte rows: f = ((row&3) + 4*((row>>3)&1)) * 2;  128-byte rows: f = (((row>>1)&1) + 2*((row>>3)&1)) * 2.
 // (ds_read_b64_tr_b16 services a 32-lane half-wave per cycle: voxel rows r..r+3 and r+8..r+11 must land on disjoint banks)
-__device__ unsigned long long g_wgrad_dbg[8];   // AP == 2 (tools/wgrad_phase_probe.py, measurement only): cycles per phase, summed over waves
+#ifdef DREG_PROBE
+__device__ unsigned long long g_wgrad_dbg[8];
+#endif
+//   // AP == 2 (tools/wgrad_phase_probe.py, measurement only): cycles per phase, summed over waves
 template <int GP> __device__ __forceinline__ int wg_swz(int row) {   // rows of >= 256 bytes (GP >= 16): the XOR acts on the low four granule bits
     return GP >= 16 ? (((row & 3) + 4 * ((row >> 3) & 1)) << 1) : ((((row >> 1) & 1) + 2 * ((row >> 3) & 1)) << 1);
 }
@@ -1598,11 +1605,13 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_glds_kernel(
             }
             if (!grp) __builtin_amdgcn_s_barrier();
             if constexpr (STAMP) {
+#ifdef DREG_PROBE
                 if (lane == 0) {
                     for (int q = 0; q < 6; ++q) atomicAdd(&g_wgrad_dbg[q], dsum[q]);
                     atomicAdd(&g_wgrad_dbg[6], (unsigned long long)nk);
                     atomicAdd(&g_wgrad_dbg[7], 1ull);
                 }
+#endif
             }
         }
     } else
@@ -2041,11 +2050,11 @@ static int fill_geom(ConvGeom& g, int B, int Di, int Hi, int Wi, int Cin, int Do
     return DREG_OK;
 }
 
-static int g_use_glds = 1;
-static int g_wgrad_pipe = 0;    // tuning (include/dreg_nerf_tuning.h): the dense 8-wave weight-gradient tile reads its fragments one MFMA group ahead (measured: no gain)
-static int g_wgrad_ring = 3;    // tuning (include/dreg_nerf_tuning.h): dense 8-wave weight-gradient tile: 3 (default) anti-phase wave groups over four 32-voxel units, 0 lockstep over two 64-voxel stages, 1 / 2 lockstep over four / five 32-voxel stages, 4..8 probes
-static int g_rows_fast = 1;     // tuning (include/dreg_nerf_tuning.h): row-list weight gradients keep packed coordinates in LDS (no voxel decode per load) and use the 8-wave tile
-static int g_wgrad_big = 3;     // tuning (include/dreg_nerf_tuning.h): 256-row weight-gradient tiles for large dense layers (1: 256 x 128 / 4 waves, 3: 256 x 256 / 8 waves)
+DREG_KNOB(int, g_use_glds, 1);
+DREG_KNOB(int, g_wgrad_pipe, 0);    // tuning (include/dreg_nerf_probe.h): the dense 8-wave weight-gradient tile reads its fragments one MFMA group ahead (measured: no gain)
+DREG_KNOB(int, g_wgrad_ring, 3);    // tuning (include/dreg_nerf_probe.h): dense 8-wave weight-gradient tile: 3 (default) anti-phase wave groups over four 32-voxel units, 0 lockstep over two 64-voxel stages, 1 / 2 lockstep over four / five 32-voxel stages, 4..8 probes
+DREG_KNOB(int, g_rows_fast, 1);     // tuning (include/dreg_nerf_probe.h): row-list weight gradients keep packed coordinates in LDS (no voxel decode per load) and use the 8-wave tile
+DREG_KNOB(int, g_wgrad_big, 3);     // tuning (include/dreg_nerf_probe.h): 256-row weight-gradient tiles for large dense layers (1: 256 x 128 / 4 waves, 3: 256 x 256 / 8 waves)
 
 // K slices of a small bf16 stride-1-gather convolution (0/1 = no split): fill the chip when the 128-row tiling leaves most CUs idle
 static int conv_ksplit(const ConvGeom& g, bool has_addend)
@@ -2069,19 +2078,18 @@ static int conv_ksplit(const ConvGeom& g, bool has_addend)
 // LDS stages of the direct-to-LDS kernel.  Measured (tools/bench_small_conv.py): a deeper ring (3-4 stages) does not help even when a
 // launch leaves one block per CU — the K step (~1,000 cycles for 32 MFMAs per wave) is bound by the issue cost of its 8 direct-to-LDS
 // pieces per wave, not by their latency.  The default stays 2; dreg_conv_set_glds_stages forces 2..4 for experiments.
-static int g_glds_stages = 0;
+DREG_KNOB(int, g_glds_stages, 0);
 static inline int glds_stages(long blocks) { (void)blocks; return g_glds_stages ? g_glds_stages : 2; }
 
-static int g_igemm_probe = 0;         // measurement only (tools/igemm_phase_probe.py): the 128 x 128 kernel with s_memtime stamps
-static int g_narrow_thr = 224;        // tile count below which a launch takes the narrower tiles
-static int g_pointwise_rmw_cin = 128;  // tuning (include/dreg_nerf_tuning.h): see igemm_choose
-static int g_igemm_ap256 = 1;         // tuning (include/dreg_nerf_tuning.h): the 256 x 256 tile of large launches runs in its anti-phase form (32-channel stages)
+DREG_KNOB(int, g_igemm_probe, 0);         // measurement only (tools/igemm_phase_probe.py): the 128 x 128 kernel with s_memtime stamps
+DREG_KNOB(int, g_narrow_thr, 224);        // tile count below which a launch takes the narrower tiles
+DREG_KNOB(int, g_pointwise_rmw_cin, 128);  // tuning (include/dreg_nerf_probe.h): see igemm_choose
+DREG_KNOB(int, g_igemm_ap256, 1);         // tuning (include/dreg_nerf_probe.h): the 256 x 256 tile of large launches runs in its anti-phase form (32-channel stages)
 // A split-K launch may leave its partials un-summed for the consumer to sum (the small-volume BatchNorm kernels read the fp32 slices
 // directly: dreg_bn_set_splitk_input) — armed for the NEXT launch only, taken when that launch is split-K with bf16 output and no bias / ReLU.
-struct SplitkDefer { int armed = 0, happened = 0, nsplit = 0; size_t slice = 0; };
-static thread_local SplitkDefer g_splitk_defer;
-static int g_igemm_ap = 256;          // tuning (include/dreg_nerf_tuning.h): launches of at most this many 128-row tiles take the eight-wave anti-phase form (0: never)
-static int g_narrow_small = 2;        // tuning (include/dreg_nerf_tuning.h): 128 x 64 tiles for launches of < 224 128 x 128 tiles
+struct SplitkDefer { int* nsplit; size_t* slice; };   // out arguments of dreg_conv3d_igemm_defer (null = always reduce)
+DREG_KNOB(int, g_igemm_ap, 256);          // tuning (include/dreg_nerf_probe.h): launches of at most this many 128-row tiles take the eight-wave anti-phase form (0: never)
+DREG_KNOB(int, g_narrow_small, 2);        // tuning (include/dreg_nerf_probe.h): 128 x 64 tiles for launches of < 224 128 x 128 tiles
 // Which kernel instantiation a bf16 / fp32 convolution launch runs (ONE rule set: launch_conv dispatches on it and
 // dreg_conv3d_igemm_variant reports it, so profiler labels name the launched template arguments — the row rocprofv3 prints).
 struct IgemmChoice { int kind, bm, bn, ap, ksplit; };   // kind 0: direct-to-LDS kernel, 1: register-staged kernel, -1: unsupported
@@ -2122,7 +2130,7 @@ template <typename T, typename TO>
 static int launch_conv(const void* in, const void* wt, void* out, const float* bias, const void* addend,
                        const ConvGeom& g, int relu, int Da, int Ha, int Wa, int add_shift, hipStream_t st,
                        const int* rowlist = nullptr, uint32_t nrows_in = 0, float* ks_ws = nullptr, size_t ks_ws_bytes = 0,
-                       const uint8_t* rowocc = nullptr, float* bn_part = nullptr)
+                       const uint8_t* rowocc = nullptr, float* bn_part = nullptr, const SplitkDefer* defer = nullptr)
 {
     // output-row occupancy is honoured by the register-staged kernel for plain forward gathers whose tiles are whole W-rows
     if (rowocc && (rowlist || bias || addend || relu || g.dsign != 1 || g.sd != 1 || g.Wo <= 0 || 128 % g.Wo != 0 || g.M % (uint32_t)g.Wo != 0)) rowocc = nullptr;
@@ -2161,8 +2169,8 @@ static int launch_conv(const void* in, const void* wt, void* out, const float* b
                                    (uint32_t)in_bytes, (uint32_t)wt_bytes, nullptr, g.M, ksplit, ns, nullptr);
             }
             DREG_LAUNCH_CHECK();
-            if (g_splitk_defer.armed && !bias && !relu && sizeof(TO) == 2) {      // the consumer sums the slices (dreg_conv_splitk_deferred tells it)
-                g_splitk_defer.armed = 0; g_splitk_defer.happened = 1; g_splitk_defer.nsplit = ksplit; g_splitk_defer.slice = slice;
+            if (defer && !bias && !relu && sizeof(TO) == 2) {      // the consumer sums the slices (dreg_conv3d_igemm_defer's out arguments tell it)
+                *defer->nsplit = ksplit; *defer->slice = slice;
                 return DREG_OK;
             }
             const size_t total8 = slice / 8;
@@ -2292,8 +2300,10 @@ int dreg_conv3d_igemm_occ(const void* in, const void* wt_packed, void* out, cons
 // multiple of its row tile): *rows_per_chunk = 128 when the sums were written, 0 when not (the caller then runs the ordinary
 // BatchNorm, whose first pass re-reads the tensor).  Same output as dreg_conv3d_igemm_ws, bit for bit; the sums of a grid do not
 // depend on the tile shape the launch's size selects (every form adds a chunk's rows in one fixed order).
-static int g_bn_stats_epilogue = 1;   // tuning (include/dreg_nerf_tuning.h)
+DREG_KNOB(int, g_bn_stats_epilogue, 1);   // probe knob (include/dreg_nerf_probe.h)
+#ifdef DREG_PROBE
 void dreg_conv_set_bn_stats_epilogue(int on) { g_bn_stats_epilogue = on ? 1 : 0; }
+#endif
 int dreg_conv3d_igemm_bnstats(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
                               int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
                               int ksz, int stride, int pad, int relu, int Da, int Ha, int Wa, int add_same,
@@ -2361,16 +2371,28 @@ int dreg_conv3d_dgrad_s2_acc(const void* gout, const void* wt_class_packed, void
 // 5: as 1 but never split-K; 0: always the register-staged kernel (A/B checks).
 // Arm (1) / disarm (0) the deferral for the next convolution launch of this thread; dreg_conv_splitk_deferred returns 1 (and the slice
 // count / slice length in elements, and clears the state) when that launch left its split-K partials [nsplit][M * Cout] fp32 in its workspace.
-void dreg_conv_defer_splitk_reduce(int arm) { g_splitk_defer.armed = arm ? 1 : 0; g_splitk_defer.happened = 0; }
-int dreg_conv_splitk_deferred(int* nsplit, size_t* slice)
+// dreg_conv3d_igemm_occ (bf16 in / out) that may leave a split-K launch's fp32 slices [*sk_nsplit][M * Cout] UN-SUMMED in its workspace for
+// the consumer to sum (the register-resident BatchNorm kernels: dreg_bn3d_fwd_ex / dreg_bn3d_bwd_ex): *sk_nsplit = 0 when the launch
+// finished its output itself (not split-K, or a bias / ReLU epilogue), else the slice count, *sk_slice = the slice length in elements.
+int dreg_conv3d_igemm_defer(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
+                            int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                            int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
+                            void* workspace, size_t workspace_bytes, const uint8_t* rowocc, int* sk_nsplit, size_t* sk_slice, void* stream)
 {
-    const int h = g_splitk_defer.happened;
-    if (h) { *nsplit = g_splitk_defer.nsplit; *slice = g_splitk_defer.slice; }
-    g_splitk_defer.armed = 0; g_splitk_defer.happened = 0;
-    return h;
+    if (!sk_nsplit || !sk_slice) return DREG_EINVAL;
+    *sk_nsplit = 0; *sk_slice = 0;
+    ConvGeom g;
+    int rc = fill_geom(g, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, ksz, stride, pad, transposed, 2);
+    if (rc) return rc;
+    if (g.M == 0) return DREG_OK;
+    const SplitkDefer d{sk_nsplit, sk_slice};
+    return launch_conv<bf16_t, bf16_t>(in, wt_packed, out, bias, addend, g, relu, Da, Ha, Wa, add_same ? 0 : 1, (hipStream_t)stream, nullptr, 0,
+                                       (float*)workspace, workspace_bytes, rowocc, nullptr, &d);
 }
+#ifdef DREG_PROBE
 void dreg_conv_set_glds(int enable) { g_use_glds = enable; }
 void dreg_conv_set_wgrad_big(int enable) { g_wgrad_big = enable; }
+#endif
 // measurement only: enable = 1 routes bf16 launches with Cout % 128 == 0 to the instrumented 128 x 128 kernel; read returns
 // { cycles waiting for the stage's loads, in the barrier, issuing the next stage, in fragment reads + MFMAs; K steps x waves; waves } and clears them
 // Which kernel a convolution launch of this shape runs (the rules launch_conv applies; for profiler labels):
@@ -2385,6 +2407,7 @@ int dreg_conv3d_igemm_variant(int B, int Di, int Hi, int Wi, int Cin, int Do, in
     if (c.kind < 0) return -1;
     return c.kind * 100000000 + c.bm * 100000 + c.bn * 100 + c.ap * 10 + (c.ksplit > 1 ? 1 : 0);
 }
+#ifdef DREG_PROBE
 void dreg_conv_igemm_probe(int enable) { g_igemm_probe = enable; }
 void dreg_conv_set_igemm_ap(int max_tiles) { g_igemm_ap = max_tiles > 0 ? max_tiles : 0; }
 void dreg_conv_set_igemm_ap256(int on) { g_igemm_ap256 = on ? 1 : 0; }
@@ -2408,6 +2431,7 @@ int dreg_conv_wgrad_probe_read(unsigned long long* out8)
 void dreg_conv_set_wgrad_rows_fast(int enable) { g_rows_fast = enable ? 1 : 0; }
 void dreg_conv_set_wgrad_ring(int mode) { g_wgrad_ring = mode; }
 void dreg_conv_set_wgrad_pipe(int enable) { g_wgrad_pipe = enable ? 1 : 0; }
+#endif
 int dreg_conv_get_glds(void) { return g_use_glds; }
 
 // K padding of the packed weight row for (ntaps, Cin) at dtype.
@@ -2466,14 +2490,16 @@ int dreg_pack_conv_weights_batched(const void* descs, int n, int total_rows, int
 }
 
 // number of voxel splits the weight-gradient kernel will use (pure function of the shape)
+DREG_KNOB(int, g_force_wgrad_splits, 0);
+DREG_KNOB(int, g_wgrad_target_blocks, 3072);
+#ifdef DREG_PROBE
 void dreg_conv_set_narrow_small(int on) { if (on >= 10) { g_narrow_small = 2; g_narrow_thr = on; } else { g_narrow_small = on; g_narrow_thr = 224; } }   // 0 off, 1 forward / data gradient only, 2 weight gradients too; >= 10: mode 2 with this tile-count threshold
-static int g_force_wgrad_splits = 0;
-static int g_wgrad_target_blocks = 3072;
 // tuning knob: workgroups the automatic voxel-split choice of the weight-gradient kernels aims for
 void dreg_conv_set_glds_stages(int stages) { g_glds_stages = (stages >= 2 && stages <= 4) ? stages : 0; }
 void dreg_conv_set_wgrad_target_blocks(int blocks) { g_wgrad_target_blocks = blocks > 0 ? blocks : 3072; }
 // tuning / test knob: force the number of voxel splits of the weight-gradient kernels (0 = automatic)
 void dreg_conv_set_wgrad_splits(int splits) { g_force_wgrad_splits = splits; }
+#endif
 int dreg_conv3d_wgrad_splits(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int dtype) {
     if (g_force_wgrad_splits > 0) {
         const long Mf = (long)B * Do * Ho * Wo;
@@ -2530,7 +2556,10 @@ size_t dreg_conv3d_wgrad_workspace_bytes(int B, int Do, int Ho, int Wo, int Cin,
 //  * 8-wave 256 x 256 tile (one workgroup per CU; its slice of the (row, flags) list sits in LDS: <= 3,904 rows per split): among the
 //    counts with >= 2,048 rows per split the one whose last round of 256 workgroups is fullest (ties: fewer splits = fewer partials);
 //  * the four-wave tiles: at least 1,024 (3^3) / 512 (1^3) rows per split, as in the dense rule.
-static bool g_row_splits = true;      // tuning (include/dreg_nerf_tuning.h): 0 = row lists use the dense volume's split count
+DREG_KNOB(bool, g_row_splits, true);      // tuning (include/dreg_nerf_probe.h): 0 = row lists use the dense volume's split count
+#ifdef DREG_PROBE
+extern "C" void dreg_conv_set_row_splits(int on) { g_row_splits = on != 0; }
+#endif
 static int wgrad_row_splits(int Cout, int Kpad, int ksz, uint32_t nrows, int smax, bool tile256)
 {
     if (smax <= 1 || !g_row_splits) return smax;
@@ -2556,7 +2585,6 @@ static int wgrad_row_splits(int Cout, int Kpad, int ksz, uint32_t nrows, int sma
     if (s < 1) s = 1;
     return (int)(s < smax ? s : smax);
 }
-void dreg_conv_set_row_splits(int on) { g_row_splits = on != 0; }
 
 // dW[Cout][Cin_real][ntaps] (torch layout, fp32) (+)= sum_m gout[m][:]^T x gathered in[m][tap][:]
 // gout: [B,Do,Ho,Wo,Cout], in: [B,Di,Hi,Wi,Cin] (same dtype).  use_tr: 1 = LDS transpose reads (bf16 only).

@@ -300,9 +300,9 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(
 //   forward      : row = co,  column = ci within the chunk, tap as stored:            pack[c][t][co][k] = W[co][32c+k][t]
 //   data gradient: row = ci,  column = co within the chunk, tap flipped (26 - t):     pack[c][t][ci][k] = W[32c+k][ci][26-t]
 // (dIn[v][ci] = sum_{t,co} dOut[v + 1 - d(t)][co] W[co][ci][t] = sum_{t'} sum_co dOut[v - 1 + d(t')][co] W[co][ci][26-t'])
-// experiments only (include/dreg_nerf_tuning.h): 0 = anti-phase groups (default); 1 = lockstep; 3 = all 12 fragment reads in the load half;
+// experiments only (include/dreg_nerf_probe.h): 0 = anti-phase groups (default); 1 = lockstep; 3 = all 12 fragment reads in the load half;
 // 5 = profiled; 1x = ablations; -1 = dreg_conv3_halo_use() answers 0 (the implicit-GEMM kernel serves every shape: A/B tests)
-static int g_halo_variant = 0;
+DREG_KNOB(int, g_halo_variant, 0);
 
 __global__ __launch_bounds__(256) void pack_weight_halo_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int transposed)
 {
@@ -327,12 +327,14 @@ __global__ __launch_bounds__(256) void pack_weight_halo_kernel(const float* __re
 }
 
 
-static unsigned long long* g_halo_prof = nullptr;
+DREG_KNOB(unsigned long long*, g_halo_prof, nullptr);
 
 extern "C" {
 
+#ifdef DREG_PROBE
 void dreg_conv3_halo_set_variant(int v) { g_halo_variant = v; }
 void dreg_conv3_halo_set_prof(void* buf) { g_halo_prof = (unsigned long long*)buf; }   // 64 blocks x 8 waves x 5 u64 (variant 5)
+#endif
 
 // 1 when (shape) is served by the halo kernel: 3^3 / stride 1 / pad 1, 256 output channels, Cin % 32 == 0, volume divisible by the
 // 4 x 8 x 8 box, operands below 2 GiB (32-bit buffer offsets)

@@ -17,8 +17,9 @@
 #include <cstring>
 #include <algorithm>
 #include <vector>
+#include <string>
+#include <cstdio>
 #include "../../include/dreg_nerf.h"
-#include "../../include/dreg_nerf_tuning.h"   // dreg_conv_get_glds (read only)
 #ifndef DREG_ELAUNCH
 #define DREG_ELAUNCH (-2)
 #endif
@@ -119,9 +120,26 @@ struct Exec {
     int pend_sk_bn = -1, pend_sk_n = 0;    // a BatchNorm op whose dy lies in the split-K workspace as pend_sk_n slices (set by the data gradient of the op behind it; survives a segment boundary)
     size_t pend_sk_slice = 0;
     const void* fwd_rows_arena = nullptr;  // the arena whose row-list convolution outputs (rows_out >= 0) are known to be zero outside their last lists
+    // guard mode (opt.guard): a poisoned band behind every region of the arena
+    struct Band { size_t off; const char* tag; int idx; };
+    std::vector<Band> bands;
+    size_t off_guard_tab = 0, off_guard_res = 0;
+    const void* guard_arena = nullptr;     // the arena whose bands are filled
+    int guard_op = -1, guard_pass = 0; long long guard_band = -1;
+    dreg_exec_opts opt;                    // creation options (include/dreg_nerf.h): per handle — the library has no process-global switches
 };
 
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+constexpr size_t GUARD_BYTES = 64 * 1024;
+// The arena's bump pointer.  In guard mode every `off += bytes` is followed by a poisoned band (named by the tag / index in force).
+struct Bump {
+    size_t v = 0;
+    std::vector<Exec::Band>* bands = nullptr;
+    const char* tag = "?"; int idx = -1;
+    operator size_t() const { return v; }
+    Bump& operator+=(size_t n) { v += n; if (bands && n) { bands->push_back(Exec::Band{v, tag, idx}); v += GUARD_BYTES; } return *this; }
+    void name(const char* t, int i) { tag = t; idx = i; }
+};
 inline int out_dim(int i, int k, int s, int p) { return (i + 2 * p - k) / s + 1; }
 
 struct Scope {   // optional HIP-event bracket of one launch group
@@ -143,18 +161,6 @@ struct Scope {   // optional HIP-event bracket of one launch group
 
 #define CK(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 
-int g_sparse_grads = 1;   // tuning (include/dreg_nerf_tuning.h): row-cleared instead of memset gradient buffers in front of the active-set convolutions
-int g_bn_batch_tails = 1; // tuning (include/dreg_nerf_tuning.h): the small BatchNorms' running-statistics / parameter-gradient launches batched per pass
-int g_s2_accumulate = 1;  // tuning (include/dreg_nerf_tuning.h): a stride-2 data gradient that is a tensor's second contribution adds in its epilogue (dreg_conv3d_dgrad_s2_acc)
-int g_group_wgrad = 1;    // tuning (include/dreg_nerf_tuning.h): the 16^3 / 8^3 / 4^3 levels' weight-gradient partials of a whole backward pass in one launch per tile shape
-int g_fold_splitk = 1;    // tuning (include/dreg_nerf_tuning.h): split-K sums of the 8^3 / 4^3 convolutions folded into the BatchNorm launch behind them
-int g_fold_res_bn = 1;    // tuning (include/dreg_nerf_tuning.h): the downsample branch's BatchNorm applied inside the BatchNorm that adds it (large path)
-int g_sparse_stem = 1;    // tuning (include/dreg_nerf_tuning.h): BatchNorm + ReLU + max-pool behind a row-list stem run from the row lists (statistics over the listed rows, activation on the lateral's rows only)
-int g_fuse_stem = 1;      // tuning (include/dreg_nerf_tuning.h): BatchNorm + ReLU + max-pool of the stem in one pass
-int g_brick = 1;          // tuning (include/dreg_nerf_tuning.h): bit 0: active-set 3^3 launches with 64 output channels on csrc/conv_brick.hip when the caller hands over tile tables, bit 1: those with 256 as well
-int g_defer_head_pg = 0;  // tuning (include/dreg_nerf_tuning.h): the head's weight / bias gradient launches are held back until the backward pass reaches the 8^3 / 4^3 levels
-int g_fuse_bn_stats = 1;  // tuning (include/dreg_nerf_tuning.h): statistics of the large BatchNorm layers from the producing convolution's epilogue
-
 bool s2_class_ok(const Param& p, int ksz, int stride, int pad)
 {
     return stride == 2 && ((ksz == 3 && pad == 1) || (ksz == 1 && pad == 0)) && p.d0 % 64 == 0 && p.d1 % 64 == 0 && dreg_conv_get_glds();
@@ -168,9 +174,24 @@ extern "C" {
 //   { kind, in, out, in2 (addend / residual, -1), w, b, p2, p3, p4 (BN: gamma=w, beta=b, running_mean, running_var), ksz, stride,
 //     pad, relu, add_same, rows_out, rows_in (row-list ids of OP_CONV_ROWS) },
 // params: int64 [np][5] { fp32 value ptr, fp32 grad ptr (0 = frozen), d0, d1, ksz }.  The last op's output is the result.
+void dreg_exec_default_opts(dreg_exec_opts* o)
+{
+    std::memset(o, 0, sizeof(*o));
+    o->sparse_grads = 1; o->bn_batch_tails = 1; o->fuse_stem = 1; o->sparse_stem = 1; o->fold_res_bn = 1; o->fold_splitk = 1;
+    o->group_wgrad = 1; o->s2_accumulate = 1; o->fuse_bn_stats = 1; o->brick = 1; o->defer_head_pg = 0;
+}
 void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, const int64_t* params, int np)
 {
+    return dreg_exec_create_opts(tensors, nt, ops, nops, params, np, nullptr);
+}
+void* dreg_exec_create_opts(const int* tensors, int nt, const int* ops, int nops, const int64_t* params, int np, const dreg_exec_opts* opts)
+{
     Exec* e = new Exec();
+    if (opts) e->opt = *opts; else dreg_exec_default_opts(&e->opt);
+    e->opt.brick &= 3;
+    const int g_sparse_grads = e->opt.sparse_grads, g_bn_batch_tails = e->opt.bn_batch_tails, g_fuse_stem = e->opt.fuse_stem, g_sparse_stem = e->opt.sparse_stem,
+              g_fold_res_bn = e->opt.fold_res_bn, g_fold_splitk = e->opt.fold_splitk, g_group_wgrad = e->opt.group_wgrad, g_fuse_bn_stats = e->opt.fuse_bn_stats,
+              g_brick = e->opt.brick;
     e->t.resize(nt);
     for (int i = 0; i < nt; ++i) {
         Tensor& t = e->t[i];
@@ -269,11 +290,13 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
         }
 
     // arena: activations | BN statistics / argmax | gradients | scratch
-    size_t off = 0;
-    for (int i = 1; i < nt; ++i) { e->t[i].off = off; off += e->t[i].bytes; }
+    Bump off;
+    if (e->opt.guard) { off.bands = &e->bands; off.name("arena start", 0); off += 256; }
+    for (int i = 1; i < nt; ++i) { off.name("activation", i); e->t[i].off = off; off += e->t[i].bytes; }
     size_t max_tensor = 0, bn_ws = 0, coef = 0, cs = 0;
     for (Op& o : e->ops) {
         const Tensor& x = e->t[o.in];
+        off.name(o.kind == OP_BN ? "BatchNorm statistics / stem scratch of op" : (o.kind == OP_MAXPOOL ? "max-pool argmax of op" : "conv op"), (int)(&o - e->ops.data()));
         if (o.kind == OP_BN) {
             const size_t sb = align256((size_t)x.B * x.C * 2 * sizeof(float));
             o.aux0 = off; off += sb; o.aux1 = off; off += sb;
@@ -346,12 +369,14 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
             if (writers != 1 || e->ops[prod].kind != OP_CONV || (e->ops[prod].halo & 1) || e->ops[prod].stats_bn >= 0) continue;
             e->ops[prod].stats_bn = (int)j;
             bn.stats_conv = prod;
+            off.name("epilogue chunk sums of BatchNorm op", (int)j);
             bn.stats_off = off; off += align256((size_t)x.B * (V / 128) * x.C * 2 * sizeof(float));
         }
     }
     e->act_bytes = off;
     for (int i = 1; i < nt; ++i) {
         if (e->t[i].bytes > max_tensor) max_tensor = e->t[i].bytes;
+        off.name("gradient of activation", i);
         if (e->needs_grad[i] && i != e->out_slot) { e->t[i].goff = off; off += e->t[i].bytes; } else e->t[i].goff = SIZE_MAX;
     }
     // the gradient of an upsample-add inside the active-set head is zero off the parents of the fine active set, which is the output
@@ -372,6 +397,7 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
         }
         if (writers != 1 || !g_sparse_grads) continue;
         const Tensor& x = e->t[o.in];
+        off.name("row-list copy (sparse_gx) of op", (int)(&o - e->ops.data()));
         o.sparse_gx = 1; o.cl_off = off; off += align256((size_t)x.B * x.D * x.H * x.W * sizeof(int));
     }
     for (Op& o : e->ops) {
@@ -380,6 +406,7 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
         for (const Op& q : e->ops) if ((q.in == o.in2 || q.in2 == o.in2) && e->needs_grad[q.out]) ++writers;
         if (writers != 1) continue;
         const Tensor& ta = e->t[o.in2];
+        off.name("row-list copy (ds_sparse) of op", (int)(&o - e->ops.data()));
         o.ds_sparse = 1; o.cl2_off = off; off += align256((size_t)ta.B * ta.D * ta.H * ta.W * sizeof(int));
     }
     // a dense-layout convolution computed on an output row list (the stem over a sparse volume: rows_out >= 0): its output is kept zero
@@ -387,12 +414,16 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
     for (Op& o : e->ops) {
         if (o.kind != OP_CONV || o.rows_out < 0) continue;
         const Tensor& y = e->t[o.out];
+        off.name("row-list copy (stem output) of op", (int)(&o - e->ops.data()));
         o.cl_off = off; off += align256((size_t)y.B * y.D * y.H * y.W * sizeof(int));
     }
+    off.name("BatchNorm workspace", 0);
     e->off_bn_ws = off; off += align256(bn_ws);
+    off.name("BatchNorm coefficients", 0);
     e->off_coef = off; off += align256(coef);
+    off.name("split-K workspace", 0);
     e->off_ks = off; off += align256(e->sz_ks);
-    for (Op& o : e->ops) if (o.rd != -1) { o.wg_off = off; off += align256(o.wg_bytes); if (o.rd >= 0) e->reduce[o.rd].part = (const float*)o.wg_off; }
+    for (Op& o : e->ops) if (o.rd != -1) { off.name("weight-gradient partials of op", (int)(&o - e->ops.data())); o.wg_off = off; off += align256(o.wg_bytes); if (o.rd >= 0) e->reduce[o.rd].part = (const float*)o.wg_off; }
     // weight gradients of the small-volume ResNet levels (layer2-4: 42 bias-free convolutions at 16^3 / 8^3 / 4^3, 12-50 us launches of 50-400
     // workgroups each): their split partials are written by ONE launch per tile shape once the pass has produced all their output gradients
     if (g_group_wgrad)
@@ -404,12 +435,20 @@ void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, con
             o.grp = 1; e->grp_ops.push_back((int)i);
         }
     if (e->grp_ops.size() < 4) { for (int i : e->grp_ops) e->ops[i].grp = 0; e->grp_ops.clear(); }
+    off.name("descriptor tables", 0);
     e->off_grp = off; off += align256(e->grp_ops.size() * (size_t)dreg_wgrad_group_desc_bytes() + 16);
     e->off_rd = off; off += align256(e->reduce.size() * sizeof(ReduceRec) + 16);
     e->off_bnf = off; off += align256(e->bn_fwd.size() * sizeof(BnTailRec) + 16);
     e->off_bnb = off; off += align256(e->bn_bwd.size() * sizeof(BnTailRec) + 16);
+    off.name("column-sum workspace", 0);
     e->off_cs = off; off += align256(cs);
+    off.name("gradient temporary", 0);
     e->off_tmp = off; off += max_tensor;
+    if (e->opt.guard) {       // the band table + the scan's result words live behind the last band (no band of their own)
+        off.bands = nullptr;
+        e->off_guard_tab = off; off += align256((e->bands.size() + 1) * sizeof(unsigned long long));
+        e->off_guard_res = off; off += 256;
+    }
     e->arena_bytes = off + 256;
 
     // weight packs: forward for every convolution; data-gradient (gather or stride-2 class form) where the input carries a gradient
@@ -521,35 +560,9 @@ int dreg_exec_op_halo(void* h, int op) { Exec* e = (Exec*)h; return op >= 0 && o
 
 // 1 (default): weight / bias gradients on the executor's own second stream, overlapping the data-gradient chain; 0: one stream
 void dreg_exec_set_overlap(void* h, int enable) { ((Exec*)h)->use_aux = enable != 0; }
-// Experiment (include/dreg_nerf_tuning.h): the weight-gradient launches of a backward pass rotate over n streams (the caller's second
-// stream + n - 1 process-wide extra ones) instead of queueing on one: most of them are under-filled (64 - 256 workgroups), so several
-// can share the chip.  1 = one second stream (default).
-static int g_aux_streams = 1;
-static hipStream_t g_extra_stream[3] = {nullptr, nullptr, nullptr};
-static hipEvent_t g_extra_event[3] = {nullptr, nullptr, nullptr};
-void dreg_exec_set_aux_streams(int n) { g_aux_streams = n < 1 ? 1 : (n > 4 ? 4 : n); }
-static bool extra_streams_ready(int n)
-{
-    for (int k = 0; k < n - 1; ++k) {
-        if (!g_extra_stream[k] && hipStreamCreateWithFlags(&g_extra_stream[k], hipStreamNonBlocking) != hipSuccess) return false;
-        if (!g_extra_event[k] && hipEventCreateWithFlags(&g_extra_event[k], hipEventDisableTiming) != hipSuccess) return false;
-    }
-    return true;
-}
 // Output-row occupancy flags (dreg_conv_row_occupancy) of the convolution that reads the network input x_in — the stem: byte
 // [B, Do, Ho], 0 = the row's receptive field in x_in is all zero.  Used by the next forward / backward calls; null = none.
 void dreg_exec_set_input_row_occupancy(void* h, const uint8_t* rowocc) { ((Exec*)h)->in_rowocc = rowocc; }
-void dreg_exec_set_sparse_grads(int on) { g_sparse_grads = on ? 1 : 0; }   // read when an executor is created
-void dreg_exec_set_bn_batch_tails(int on) { g_bn_batch_tails = on ? 1 : 0; }   // read when an executor is created
-void dreg_exec_set_fuse_stem(int on) { g_fuse_stem = on ? 1 : 0; }   // read when an executor is created
-void dreg_exec_set_sparse_stem(int on) { g_sparse_stem = on ? 1 : 0; }   // read when an executor is created
-void dreg_exec_set_fold_res_bn(int on) { g_fold_res_bn = on ? 1 : 0; }   // read when an executor is created
-void dreg_exec_set_fold_splitk(int on) { g_fold_splitk = on ? 1 : 0; }   // read when an executor is created
-void dreg_exec_set_group_wgrad(int on) { g_group_wgrad = on ? 1 : 0; }   // read when an executor is created
-void dreg_exec_set_s2_accumulate(int on) { g_s2_accumulate = on ? 1 : 0; }   // read at every backward call
-void dreg_exec_set_fuse_bn_stats(int on) { g_fuse_bn_stats = on ? 1 : 0; }   // read when an executor is created
-void dreg_exec_set_brick(int mask) { g_brick = mask & 3; }   // packs: read when an executor is created; dispatch: at every forward / backward call
-void dreg_exec_set_defer_head_pg(int on) { g_defer_head_pg = on ? 1 : 0; }   // read at every backward call
 void dreg_exec_set_timing(void* h, int enable) { ((Exec*)h)->timing = enable != 0; }   // records are kept until read
 // After a stream synchronisation: elapsed ms of the bracketed launches since the last set_timing; records are (op, kind, variant, ms)
 // with kind 0 forward, 1 data gradient, 2 weight gradient (+reduce); variant 2 = the launch ran on csrc/conv_brick.hip; op_kind holds 3 ints per record.  Returns the number written (<= max) and restarts.
@@ -567,8 +580,40 @@ int dreg_exec_read_timings(void* h, int* op_kind, float* ms, int max)
 }
 
 // The descriptor tables of the batched launches live in the arena (they hold addresses of this arena's buffers): uploaded once per arena.
+static int guard_setup(Exec* e, char* A, hipStream_t st)
+{
+    if (!e->opt.guard || e->guard_arena == (const void*)A) return DREG_OK;
+    std::vector<unsigned long long> offs(e->bands.size());
+    for (size_t i = 0; i < offs.size(); ++i) offs[i] = e->bands[i].off;
+    if (!offs.empty() && hipMemcpyAsync(A + e->off_guard_tab, offs.data(), offs.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, st) != hipSuccess) return DREG_ELAUNCH;
+    if (hipStreamSynchronize(st) != hipSuccess) return DREG_ELAUNCH;
+    int rc = dreg_guard_fill(A, A + e->off_guard_tab, (int)offs.size(), (int)GUARD_BYTES, (void*)st);
+    if (rc) return rc;
+    e->guard_arena = A;
+    return DREG_OK;
+}
+static int guard_scan(Exec* e, char* A, long long* out4, hipStream_t st)
+{
+    int rc = dreg_guard_scan(A, A + e->off_guard_tab, (int)e->bands.size(), (int)GUARD_BYTES, A + e->off_guard_res, (void*)st);
+    if (rc) return rc;
+    if (hipMemcpyAsync(out4, A + e->off_guard_res, 4 * sizeof(long long), hipMemcpyDeviceToHost, st) != hipSuccess) return DREG_ELAUNCH;
+    if (hipStreamSynchronize(st) != hipSuccess) return DREG_ELAUNCH;
+    return DREG_OK;
+}
+// guard = 2: scan behind op `op` of pass `pass`; DREG_EGUARD (and the place remembered) when a band has changed
+static int guard_after_op(Exec* e, char* A, int op, int pass, hipStream_t st, hipStream_t aux)
+{
+    if (e->opt.guard < 2) return DREG_OK;
+    if (aux && hipStreamSynchronize(aux) != hipSuccess) return DREG_ELAUNCH;
+    long long r[4];
+    int rc = guard_scan(e, A, r, st);
+    if (rc) return rc;
+    if (r[0] > 0) { e->guard_op = op; e->guard_pass = pass; e->guard_band = r[1]; return DREG_EGUARD; }
+    return DREG_OK;
+}
 static int upload_tables(Exec* e, char* A, hipStream_t st)
 {
+    { int rc = guard_setup(e, A, st); if (rc) return rc; }
     if (e->reduce_arena == (const void*)A) return DREG_OK;
     e->reduce_abs = e->reduce;
     for (ReduceRec& r : e->reduce_abs) r.part = (const float*)(A + (size_t)r.part);
@@ -645,9 +690,13 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
     std::vector<int> sums_rpc(e->ops.size(), 0);    // per BatchNorm op: rows per chunk of the sums its producer left (0 = none)
     int fwd_sk_bn = -1, fwd_sk_n = 0;               // the BatchNorm whose input lies in the split-K workspace as fwd_sk_n slices
     size_t fwd_sk_slice = 0;
-    struct ArenaMark { Exec* e; const void* a; ~ArenaMark() { e->fwd_rows_arena = a; } } arena_mark{e, arena};   // (after this pass the row-list outputs of `arena` are in the known state)
+    // After a COMPLETE pass the row-list outputs of `arena` are in the known state (zero outside the copied lists).  Any early error return leaves them
+    // unknown: the next forward then clears them densely and forgets the copied lists.
+    struct ArenaMark { Exec* e; const void* a; bool ok = false;
+                       ~ArenaMark() { if (ok) e->fwd_rows_arena = a; else { e->fwd_rows_arena = nullptr; for (Op& o : e->ops) if (o.kind == OP_CONV && o.rows_out >= 0) o.cl_count = 0; } } } arena_mark{e, arena};
     auto act = [&](int s) -> void* { return s == 0 ? (void*)x_in : (void*)(A + e->t[s].off); };
     for (size_t i = 0; i < e->ops.size(); ++i) {
+        if (i > 0) CK(guard_after_op(e, A, (int)i - 1, 0, st, nullptr));
         const Op& o = e->ops[i];
         const Tensor& x = e->t[o.in];
         const Tensor& y = e->t[o.out];
@@ -686,16 +735,17 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
                                              A + e->off_ks, e->sz_ks, (float*)(A + e->ops[o.stats_bn].stats_off), &sums_rpc[o.stats_bn], stream));
                 continue;
             }
-            const bool try_fold = train && o.fold_sk_fwd && !(o.halo & 1);
-            if (try_fold) dreg_conv_defer_splitk_reduce(1);
-            const int rc_conv = dreg_conv3d_igemm_occ(act(o.in), PK + w.pk_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0,
-                                     o.ksz, o.stride, o.pad, 0, o.relu, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0, o.add_same, 0, 0,
-                                     A + e->off_ks, e->sz_ks, o.in == 0 ? e->in_rowocc : nullptr, stream);
-            if (try_fold) {
+            if (train && o.fold_sk_fwd && !(o.halo & 1)) {
                 int ns = 0; size_t sl = 0;
-                if (dreg_conv_splitk_deferred(&ns, &sl)) { fwd_sk_bn = (int)i + 1; fwd_sk_n = ns; fwd_sk_slice = sl; }
+                CK(dreg_conv3d_igemm_defer(act(o.in), PK + w.pk_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0,
+                                           o.ksz, o.stride, o.pad, 0, o.relu, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0, o.add_same,
+                                           A + e->off_ks, e->sz_ks, o.in == 0 ? e->in_rowocc : nullptr, &ns, &sl, stream));
+                if (ns > 0) { fwd_sk_bn = (int)i + 1; fwd_sk_n = ns; fwd_sk_slice = sl; }
+                continue;
             }
-            CK(rc_conv);
+            CK(dreg_conv3d_igemm_occ(act(o.in), PK + w.pk_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0,
+                                     o.ksz, o.stride, o.pad, 0, o.relu, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0, o.add_same, 0, 0,
+                                     A + e->off_ks, e->sz_ks, o.in == 0 ? e->in_rowocc : nullptr, stream));
         } else if (o.kind == OP_CONV_ROWS) {
             const Param& w = e->prm[o.w];
             if (o.rows_out < 0 || o.rows_out >= nlists) return DREG_EINVAL;
@@ -704,7 +754,7 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
             const Tensor* ta = o.in2 >= 0 ? &e->t[o.in2] : nullptr;
             Scope sc(e, st, (int)i, 0);
             const int64_t* rl = rowlists + RL * o.rows_out;
-            if ((g_brick & (w.d0 == 64 ? 1 : 2)) && w.pk_brick_fwd != SIZE_MAX && rl[2] && rl[3] > 0) {
+            if ((e->opt.brick & (w.d0 == 64 ? 1 : 2)) && w.pk_brick_fwd != SIZE_MAX && rl[2] && rl[3] > 0) {
                 sc.variant(2);
                 CK(dreg_conv3_brick(act(o.in), PK + w.pk_brick_fwd, act(o.out), bias, add, (const void*)rl[2], (int)rl[3], (const int*)rl[4], (const void*)rl[5],
                                     (const int*)rl[6], x.B, x.D, x.H, x.W, x.C, w.d0, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0, 0, 0, stream));
@@ -740,23 +790,52 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
             const int V = x.D * x.H * x.W;
             const void* res_p = o.in2 >= 0 ? act(o.in2) : nullptr;
             void* out_p = o.fold_into >= 0 ? nullptr : act(o.out);       // folded branch: statistics, scale / shift only
-            if (o.res_from >= 0) { res_p = act(e->ops[o.res_from].in); dreg_bn_set_residual_transform((const float*)(A + e->ops[o.res_from].aux0)); }
+            dreg_bn_extra ex{};
+            if (o.res_from >= 0) { res_p = act(e->ops[o.res_from].in); ex.res_scale_shift = (const float*)(A + e->ops[o.res_from].aux0); }
             if (train && sums_rpc[i] > 0) {
-                CK(dreg_bn3d_fwd_from_sums(act(o.in), res_p, out_p, e->prm[o.w].val, e->prm[o.b].val, e->prm[o.p2].val, e->prm[o.p3].val,
-                                           (float*)(A + o.aux0), (float*)(A + o.aux1), (float*)(A + o.stats_off), sums_rpc[i], x.B, V, x.C, 1e-5f, 0.1f, o.relu, 0, stream));
+                CK(dreg_bn3d_fwd_ex(act(o.in), res_p, out_p, e->prm[o.w].val, e->prm[o.b].val, e->prm[o.p2].val, e->prm[o.p3].val,
+                                    (float*)(A + o.aux0), (float*)(A + o.aux1), (float*)(A + o.stats_off), x.B, V, x.C, 1e-5f, 0.1f, 1, o.relu, 0,
+                                    nullptr, nullptr, sums_rpc[i], &ex, stream));
                 continue;
             }
             int deferred = 0;
-            if (fwd_sk_bn == (int)i) { dreg_bn_set_splitk_input((const float*)(A + e->off_ks), fwd_sk_n, fwd_sk_slice); fwd_sk_bn = -1; }
-            CK(dreg_bn3d_fwd_defer_update(act(o.in), res_p, out_p, e->prm[o.w].val, e->prm[o.b].val, e->prm[o.p2].val, e->prm[o.p3].val,
-                                          (float*)(A + o.aux0), (float*)(A + o.aux1), (float*)(A + e->off_bn_ws), x.B, V, x.C, 1e-5f, 0.1f, train, o.relu, 0,
-                                          o.bt >= 0 ? (float*)(A + o.keep_var) : nullptr, &deferred, stream));
+            if (fwd_sk_bn == (int)i) { ex.splitk_part = (const float*)(A + e->off_ks); ex.splitk_nsplit = fwd_sk_n; ex.splitk_slice = fwd_sk_slice; fwd_sk_bn = -1; }
+            CK(dreg_bn3d_fwd_ex(act(o.in), res_p, out_p, e->prm[o.w].val, e->prm[o.b].val, e->prm[o.p2].val, e->prm[o.p3].val,
+                                (float*)(A + o.aux0), (float*)(A + o.aux1), (float*)(A + e->off_bn_ws), x.B, V, x.C, 1e-5f, 0.1f, train, o.relu, 0,
+                                o.bt >= 0 ? (float*)(A + o.keep_var) : nullptr, &deferred, 0, &ex, stream));
             if (deferred) bn_done[o.bt] = 1;
         } else if (o.kind == OP_MAXPOOL) {
             CK(dreg_maxpool3d_fwd(act(o.in), act(o.out), (uint8_t*)(A + o.aux0), x.B, x.D, x.H, x.W, y.D, y.H, y.W, x.C, 0, stream));
         } else return DREG_EINVAL;
     }
+    CK(guard_after_op(e, A, (int)e->ops.size() - 1, 0, st, nullptr));
     CK(flush_bn_tails(e, A, bn_done, 0, st));
+    CK(guard_after_op(e, A, (int)e->ops.size(), 0, st, nullptr));
+    arena_mark.ok = true;
+    return DREG_OK;
+}
+int dreg_exec_guard_bands(void* h) { return (int)((Exec*)h)->bands.size(); }
+int dreg_exec_guard_check(void* h, void* arena, long long* out4, void* stream)
+{
+    Exec* e = (Exec*)h;
+    if (!e->opt.guard || !out4) return DREG_EINVAL;
+    if (e->guard_arena != arena) { out4[0] = 0; out4[1] = (long long)e->bands.size(); out4[2] = 0; out4[3] = 0; return DREG_OK; }   // never filled: nothing ran on it
+    return guard_scan(e, (char*)arena, out4, (hipStream_t)stream);
+}
+int dreg_exec_guard_describe(void* h, int band, char* buf, int buf_bytes)
+{
+    Exec* e = (Exec*)h;
+    if (band < 0 || band >= (int)e->bands.size() || !buf || buf_bytes <= 0) return DREG_EINVAL;
+    const Exec::Band& b = e->bands[band];
+    std::snprintf(buf, (size_t)buf_bytes, "band %d at arena offset %zu, behind: %s %d", band, b.off, b.tag, b.idx);
+    return DREG_OK;
+}
+int dreg_exec_guard_last(void* h, int* op, int* pass, long long* band)
+{
+    Exec* e = (Exec*)h;
+    if (op) *op = e->guard_op;
+    if (pass) *pass = e->guard_pass;
+    if (band) *band = e->guard_band;
     return DREG_OK;
 }
 
@@ -829,17 +908,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
         }
         e->sparse_arena = arena;
     }
-    const int n_ws = (aux_on && g_aux_streams > 1 && extra_streams_ready(g_aux_streams)) ? g_aux_streams : 1;
-    int ws_rr = 0;
-    bool extra_busy[3] = {false, false, false};
-    auto join_extra = [&]() -> int {                  // the second stream continues only behind what the extra streams have been given
-        for (int k = 0; k < 3; ++k) {
-            if (!extra_busy[k]) continue;
-            if (hipEventRecord(g_extra_event[k], g_extra_stream[k]) != hipSuccess || hipStreamWaitEvent(e->aux, g_extra_event[k], 0) != hipSuccess) return DREG_ELAUNCH;
-            extra_busy[k] = false;
-        }
-        return DREG_OK;
-    };
+    const int g_s2_accumulate = e->opt.s2_accumulate, g_group_wgrad = e->opt.group_wgrad, g_brick = e->opt.brick, g_defer_head_pg = e->opt.defer_head_pg;
     std::vector<char> rd_done(e->reduce.size(), 0);   // records whose partials this call produced and nobody summed yet
     hipStream_t rd_stream = st;
     size_t rd_pending = 0;
@@ -848,7 +917,6 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
     // launch per run of consecutive records.  Flushed every ~192 MB of partials: the deep layers' sums then run next to the rest
     // of the backward pass, and only the last few layers' are left for the end.
     auto flush_reduce = [&]() -> int {
-        CK(join_extra());
         for (int lo = 0, nrec = (int)rd_done.size(); lo < nrec;) {
             if (!rd_done[lo]) { ++lo; continue; }
             int hi = lo;
@@ -864,7 +932,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
     };
     // weight / bias gradient launches of convolution op i (second stream behind the event "its output gradient is complete")
     // grouped weight gradients: only in a whole-pass call with the second stream and no per-launch timing brackets
-    const bool grp_active = g_group_wgrad && e->grp_ready && aux_on && n_ws == 1 && !e->timing && op_begin == 0 && op_end == (int)e->ops.size() && (flags & 3) == 3;
+    const bool grp_active = g_group_wgrad && e->grp_ready && aux_on && !e->timing && op_begin == 0 && op_end == (int)e->ops.size() && (flags & 3) == 3;
     std::vector<int> grp_seen;
     auto param_grads = [&](int i, bool event_recorded) -> int {
         const Op& o = e->ops[i];
@@ -884,15 +952,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
             ws = e->aux;
             aux_used = true;
         }
-        hipStream_t bs = ws;                  // bias sums stay on the second stream (they share one scratch buffer)
-        if (w.grad && n_ws > 1 && o.rd >= 0) {  // deferred-sum weight gradients rotate over the streams
-            const int k = ws_rr++ % n_ws;
-            if (k > 0) {
-                if (hipStreamWaitEvent(g_extra_stream[k - 1], e->ev[i], 0) != hipSuccess) return DREG_ELAUNCH;
-                ws = g_extra_stream[k - 1];
-                extra_busy[k - 1] = true;
-            }
-        }
+        hipStream_t bs = ws;                  // bias sums share one scratch buffer: same stream as the weight gradients
         bool flush_now = false;
         if (w.grad && grp_active && o.grp) {
             // written by the grouped launch at the pass's launch point (below); nothing else to do for this layer (no bias)
@@ -904,7 +964,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                 CK(dreg_conv3d_wgrad_partials(gy, act(o.in), A + o.wg_off, o.wg_bytes, lrows ? r_out : nullptr, n_out, x.B, x.D, x.H, x.W, x.C, w.d1,
                                               y.D, y.H, y.W, w.d0, o.ksz, rows ? 1 : o.stride, o.pad, (!lrows && o.in == 0) ? e->in_rowocc : nullptr, (void*)ws));
                 rd_done[o.rd] = 1;
-                rd_stream = n_ws > 1 ? e->aux : ws;
+                rd_stream = ws;
                 rd_pending += o.wg_bytes;
                 flush_now = rd_pending >= ((size_t)192 << 20);
             } else if (lrows) {
@@ -950,6 +1010,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
         return DREG_OK;
     };
     for (int i = op_end - 1; i >= op_begin; --i) {
+        if (i < op_end - 1) CK(guard_after_op(e, A, i + 1, 1, st, aux_on ? e->aux : nullptr));
         const Op& o = e->ops[i];
         const Tensor& x = e->t[o.in];
         const Tensor& y = e->t[o.out];
@@ -992,7 +1053,7 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
             // stream runs the head's throughput-bound data gradients: side by side the two only slow each other down (~25 % per kernel).
             // They are held back until the pass reaches the 8^3 / 4^3 levels, whose launch-latency-bound chain leaves most CUs idle.
             const long vox_out = (long)y.D * y.H * y.W;
-            if (pg && aux_on && g_defer_head_pg && !deep_reached && vox_out >= 32768 && n_ws == 1) {
+            if (pg && aux_on && g_defer_head_pg && !deep_reached && vox_out >= 32768) {
                 if (!e->ev[i] && hipEventCreateWithFlags(&e->ev[i], hipEventDisableTiming) != hipSuccess) return DREG_ELAUNCH;
                 if (hipEventRecord(e->ev[i], st) != hipSuccess) return DREG_ELAUNCH;
                 deferred_pg.push_back(i);
@@ -1060,15 +1121,14 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                     CK(dreg_conv3d_dgrad_s2(gy, PK + w.pk_cls, gx, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0, o.ksz, o.pad, stream));
                 } else {
                     if (w.pk_dgrad == SIZE_MAX) return DREG_EINVAL;
-                    const bool try_fold = o.fold_sk_bwd && gx == grad(o.in) && i - 1 >= 0;
-                    if (try_fold) dreg_conv_defer_splitk_reduce(1);
-                    const int rc_conv = dreg_conv3d_igemm_ws(gy, PK + w.pk_dgrad, gx, nullptr, nullptr, x.B, y.D, y.H, y.W, w.d0, x.D, x.H, x.W, w.d1,
-                                            o.ksz, o.stride, o.pad, 1, 0, 0, 0, 0, 0, 0, 0, A + e->off_ks, e->sz_ks, stream);
-                    if (try_fold) {
+                    if (o.fold_sk_bwd && gx == grad(o.in) && i - 1 >= 0) {
                         int ns = 0; size_t sl = 0;
-                        if (dreg_conv_splitk_deferred(&ns, &sl)) { e->pend_sk_bn = i - 1; e->pend_sk_n = ns; e->pend_sk_slice = sl; }
-                    }
-                    CK(rc_conv);
+                        CK(dreg_conv3d_igemm_defer(gy, PK + w.pk_dgrad, gx, nullptr, nullptr, x.B, y.D, y.H, y.W, w.d0, x.D, x.H, x.W, w.d1,
+                                                   o.ksz, o.stride, o.pad, 1, 0, 0, 0, 0, 0, A + e->off_ks, e->sz_ks, nullptr, &ns, &sl, stream));
+                        if (ns > 0) { e->pend_sk_bn = i - 1; e->pend_sk_n = ns; e->pend_sk_slice = sl; }
+                    } else
+                    CK(dreg_conv3d_igemm_ws(gy, PK + w.pk_dgrad, gx, nullptr, nullptr, x.B, y.D, y.H, y.W, w.d0, x.D, x.H, x.W, w.d1,
+                                            o.ksz, o.stride, o.pad, 1, 0, 0, 0, 0, 0, 0, 0, A + e->off_ks, e->sz_ks, stream));
                 }
             }
             if (e->needs_grad[o.in] && !fused_add) CK(commit(o.in));
@@ -1099,10 +1159,11 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                 CK(commit(o.in2));
             } else {
                 // without a residual the ReLU mask is recomputed from x: y is not read
-                if (e->pend_sk_bn == i) { dreg_bn_set_splitk_input((const float*)(A + e->off_ks), e->pend_sk_n, e->pend_sk_slice); e->pend_sk_bn = -1; }
-                CK(dreg_bn3d_bwd_defer_params(act(o.in), gy, o.in2 >= 0 ? act(o.out) : nullptr, (float*)(A + o.aux0), (float*)(A + o.aux1), dx, dres, e->prm[o.w].grad, e->prm[o.b].grad,
-                                              (float*)(A + e->off_coef), (float*)(A + e->off_bn_ws), x.B, V, x.C, o.relu, 1, 0,
-                                              o.bt >= 0 ? (float*)(A + o.keep_sums) : nullptr, &deferred, stream));
+                dreg_bn_extra ex{};
+                if (e->pend_sk_bn == i) { ex.splitk_part = (const float*)(A + e->off_ks); ex.splitk_nsplit = e->pend_sk_n; ex.splitk_slice = e->pend_sk_slice; e->pend_sk_bn = -1; }
+                CK(dreg_bn3d_bwd_ex(act(o.in), gy, o.in2 >= 0 ? act(o.out) : nullptr, (float*)(A + o.aux0), (float*)(A + o.aux1), dx, dres, e->prm[o.w].grad, e->prm[o.b].grad,
+                                    (float*)(A + e->off_coef), (float*)(A + e->off_bn_ws), x.B, V, x.C, o.relu, 1, 0,
+                                    o.bt >= 0 ? (float*)(A + o.keep_sums) : nullptr, &deferred, &ex, stream));
                 if (deferred) bn_done[o.bt] = 1;
                 if (res_g && dres == (void*)(A + e->off_tmp)) { CK(commit(o.in2)); CK(commit(o.in)); }
                 else { CK(commit(o.in)); if (res_g) CK(commit(o.in2)); }
@@ -1114,11 +1175,12 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
             written[o.in] = 1;
         }
     }
+    CK(guard_after_op(e, A, op_begin, 1, st, aux_on ? e->aux : nullptr));
     CK(run_deferred());                      // (a segment that never reached the deep levels)
     if (!grp_seen.empty()) CK(flush_group(e->grp_ops.front()));      // (the launch point was never met)
     CK(flush_reduce());
     CK(flush_bn_tails(e, A, bn_done, 1, st));
-    if (aux_on) CK(join_extra());
+    CK(guard_after_op(e, A, -1, 1, st, aux_on ? e->aux : nullptr));
     if ((flags & 2) && aux_used) {   // the caller's stream continues (optimizer) only after every parameter gradient has landed
         if (hipEventRecord(e->ev_done, e->aux) != hipSuccess || hipStreamWaitEvent(st, e->ev_done, 0) != hipSuccess) return DREG_ELAUNCH;
     }

@@ -7,6 +7,7 @@
 // conerf/model/feature_pyramid_net.py:58-61 (_upsample), conerf/register/nerf_regtr.py:138-147 (gather).
 // All tensors are NDHWC, 16-byte channel granules per thread, fp32 math.
 #include "common.h"
+#include "../../include/dreg_nerf.h"   // dreg_bn_extra (and a signature check of every entry point defined here)
 extern "C" int dreg_fill_zero(void* p, size_t bytes, void* stream);   // fpn_ops.hip (include/dreg_nerf.h)
 
 template <typename T> struct Gran;
@@ -715,10 +716,10 @@ __global__ void bn_tail_batched_kernel(const BnTailDesc* __restrict__ descs, int
         d.o1[c] = accumulate ? d.o1[c] + (float)db : (float)db;
     }
 }
-static int g_bn_small_regs = 1;  // tuning (include/dreg_nerf_tuning.h): the small BatchNorms keep their rows in registers between the two phases (8^3 / 4^3 volumes)
-static int g_bn_store_g = 1;     // tuning (include/dreg_nerf_tuning.h): residual BatchNorm backward stores the masked gradient in the statistics pass
-static int g_bn_debug_skip = 0;      // measurement only (tools/ab_step.py): bit 0 / bit 1 leave out the forward / backward statistics pass (stale statistics)
-static int g_bn_small_maxv = 512;    // tuning (include/dreg_nerf_tuning.h): largest per-grid volume served by the fused kernels, 0 = never
+DREG_KNOB(int, g_bn_small_regs, 1);  // tuning (include/dreg_nerf_probe.h): the small BatchNorms keep their rows in registers between the two phases (8^3 / 4^3 volumes)
+DREG_KNOB(int, g_bn_store_g, 1);     // tuning (include/dreg_nerf_probe.h): residual BatchNorm backward stores the masked gradient in the statistics pass
+DREG_KNOB(int, g_bn_debug_skip, 0);      // measurement only (tools/ab_step.py): bit 0 / bit 1 leave out the forward / backward statistics pass (stale statistics)
+DREG_KNOB(int, g_bn_small_maxv, 512);    // tuning (include/dreg_nerf_probe.h): largest per-grid volume served by the fused kernels, 0 = never
 static inline bool bn_small_ok(int B, int V, int C, int G) { return V >= 2 && V <= g_bn_small_maxv && C % (BNS_COLS * G) == 0 && B >= 1; }
 
 // ------------------------------------------------------------------------------------------------ max-pool 3^3 s2 p1
@@ -1921,10 +1922,12 @@ static inline int bn_rows_per_chunk(int V) { return V >= 262144 ? 512 : V >= 327
 
 extern "C" {
 
+#ifdef DREG_PROBE
 void dreg_bn_set_debug_skip(int mask) { g_bn_debug_skip = mask; }
 void dreg_bn_set_store_g(int enable) { g_bn_store_g = enable ? 1 : 0; }
 void dreg_bn_set_small_regs(int enable) { g_bn_small_regs = enable ? 1 : 0; }
 void dreg_bn_set_small_max_voxels(int v) { g_bn_small_maxv = v; }
+#endif
 int dreg_bn_num_chunks(int V) { const int r = bn_rows_per_chunk(V); return (V + r - 1) / r; }
 
 // Forward BatchNorm3d over B independent grids (per-grid statistics).  x,y,res: [B,V,C] (dtype 0 bf16 / 1 fp32).
@@ -1932,7 +1935,7 @@ int dreg_bn_num_chunks(int V) { const int r = bn_rows_per_chunk(V); return (V + 
 static int bn3d_fwd_impl(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                          float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
                          int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, void* stream, float* var_keep, int* deferred,
-                         int sums_rows_per_chunk = 0);
+                         int sums_rows_per_chunk = 0, const dreg_bn_extra* ex = nullptr);
 int dreg_bn3d_fwd(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                   float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
                   int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, void* stream)
@@ -1958,6 +1961,17 @@ int dreg_bn3d_fwd_from_sums(const void* x, const void* res, void* y, const float
     return bn3d_fwd_impl(x, res, y, gamma, beta, running_mean, running_var, scale_shift, mean_rstd, sums, B, V, C, eps, momentum, 1, relu, dtype, stream, nullptr, nullptr,
                          rows_per_chunk);
 }
+// The general form: dreg_bn3d_fwd_defer_update (sums_rows_per_chunk = 0) or dreg_bn3d_fwd_from_sums (> 0, workspace = the sums, train implied) with
+// the optional extras of include/dreg_nerf.h's dreg_bn_extra handed over as an ARGUMENT (no per-thread "next call" state in this library).
+int dreg_bn3d_fwd_ex(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
+                     int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, float* var_keep, int* deferred,
+                     int sums_rows_per_chunk, const dreg_bn_extra* ex, void* stream)
+{
+    if (sums_rows_per_chunk < 0) return DREG_EINVAL;
+    return bn3d_fwd_impl(x, res, y, gamma, beta, running_mean, running_var, scale_shift, mean_rstd, workspace, B, V, C, eps, momentum,
+                         sums_rows_per_chunk > 0 ? 1 : train, relu, dtype, stream, var_keep, deferred, sums_rows_per_chunk, ex);
+}
 int dreg_bn_small(int B, int V, int C, int dtype) { return bn_small_ok(B, V, C, dtype == 0 ? 8 : 4) ? 1 : 0; }
 // descs_dev: n records of 48 bytes { const float* mean_rstd; const float* var; float* running_mean; float* running_var; int B, V, C, block0; }
 // with block0 = sum of ceil(C / 256) of the records before; workgroups [block_base, block_base + nblocks) run.
@@ -1981,25 +1995,20 @@ int dreg_bn_param_grad_batched(const void* descs_dev, int n, int block_base, int
 // The next small-volume (register-resident) forward / backward call takes its x (forward) / dy (backward) as the sum of split-K slices:
 // see bn_small_fwd_kernel.  Consumed by that one call; DREG_EINVAL if the call does not take the register-resident path.
 struct BnSplitkIn { const float* part = nullptr; int nsplit = 0; size_t slice = 0; };
-static thread_local BnSplitkIn g_bn_splitk_in;
-void dreg_bn_set_splitk_input(const float* part, int nsplit, size_t slice) { g_bn_splitk_in.part = part; g_bn_splitk_in.nsplit = nsplit; g_bn_splitk_in.slice = slice; }
-// 1: a [B,V,C] layer of this dtype takes the register-resident one-launch kernels (what dreg_bn_set_splitk_input needs)
+// 1: a [B,V,C] layer of this dtype takes the register-resident one-launch kernels (what dreg_bn_extra's split-K slices need)
 int dreg_bn_small_in_regs(int B, int V, int C, int dtype)
 {
     return (g_bn_small_regs && bn_small_ok(B, V, C, dtype == 0 ? 8 : 4) && (V == 8 * BNS_ROWS || V == BNS_ROWS)) ? 1 : 0;
 }
-static thread_local const float* g_bn_res_ss = nullptr;
-void dreg_bn_set_residual_transform(const float* res_scale_shift) { g_bn_res_ss = res_scale_shift; }
 static int bn3d_fwd_impl(const void* x, const void* res, void* y, const float* gamma, const float* beta,
                          float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
                          int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, void* stream, float* var_keep, int* deferred,
-                         int sums_rows_per_chunk)
+                         int sums_rows_per_chunk, const dreg_bn_extra* ex)
 {
     hipStream_t st = (hipStream_t)stream;
-    const float* res_ss = g_bn_res_ss;
-    g_bn_res_ss = nullptr;
-    const BnSplitkIn ski = g_bn_splitk_in;
-    g_bn_splitk_in = BnSplitkIn{};
+    const float* res_ss = ex ? ex->res_scale_shift : nullptr;
+    BnSplitkIn ski;
+    if (ex) { ski.part = ex->splitk_part; ski.nsplit = ex->splitk_nsplit; ski.slice = ex->splitk_slice; }
     if (ski.part && !(train && sums_rows_per_chunk == 0 && dreg_bn_small_in_regs(B, V, C, dtype))) return DREG_EINVAL;
     if (deferred) *deferred = 0;
     const int G = dtype == 0 ? 8 : 4;
@@ -2037,7 +2046,7 @@ static int bn3d_fwd_impl(const void* x, const void* res, void* y, const float* g
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64 * (B < 8 ? B : 8)), 0, st, workspace, gamma, beta, running_mean, running_var,
                        scale_shift, mean_rstd, B, presummed ? V / sums_rows_per_chunk : nch, C, V, eps, momentum, train);
     DREG_LAUNCH_CHECK();
-    if (!y) return DREG_OK;        // statistics / scale / shift only: the consumer applies them (dreg_bn_set_residual_transform)
+    if (!y) return DREG_OK;        // statistics / scale / shift only: the consumer applies them (dreg_bn_extra.res_scale_shift)
     const dim3 agrid(nch, B, slabs);
     if (dtype == 0) hipLaunchKernelGGL((bn_apply_cols_kernel<bf16_t, 4>), agrid, dim3(256), 0, st, (const bf16_t*)x, scale_shift, (const bf16_t*)res, (bf16_t*)y, V, C, rpc, relu, res ? res_ss : nullptr);
     else hipLaunchKernelGGL((bn_apply_cols_kernel<float, 4>), agrid, dim3(256), 0, st, (const float*)x, scale_shift, (const float*)res, (float*)y, V, C, rpc, relu, res ? res_ss : nullptr);
@@ -2050,7 +2059,7 @@ static int bn3d_fwd_impl(const void* x, const void* res, void* y, const float* g
 // read less in both passes.
 static int bn3d_bwd_impl(const void* x, const void* dy, const void* y, const float* scale_shift, const float* mean_rstd,
                          void* dx, void* dres, float* dgamma, float* dbeta, float* coef, float* workspace,
-                         int B, int V, int C, int relu, int accumulate, int dtype, void* stream, float* sums_keep, int* deferred);
+                         int B, int V, int C, int relu, int accumulate, int dtype, void* stream, float* sums_keep, int* deferred, const dreg_bn_extra* ex = nullptr);
 int dreg_bn3d_bwd(const void* x, const void* dy, const void* y, const float* scale_shift, const float* mean_rstd,
                   void* dx, void* dres, float* dgamma, float* dbeta, float* coef, float* workspace,
                   int B, int V, int C, int relu, int accumulate, int dtype, void* stream)
@@ -2065,13 +2074,20 @@ int dreg_bn3d_bwd_defer_params(const void* x, const void* dy, const void* y, con
 {
     return bn3d_bwd_impl(x, dy, y, scale_shift, mean_rstd, dx, dres, dgamma, dbeta, coef, workspace, B, V, C, relu, accumulate, dtype, stream, sums_keep, deferred);
 }
+// ... and with dy handed over as un-summed split-K slices (ex->splitk_*: register-resident small path only)
+int dreg_bn3d_bwd_ex(const void* x, const void* dy, const void* y, const float* scale_shift, const float* mean_rstd,
+                     void* dx, void* dres, float* dgamma, float* dbeta, float* coef, float* workspace,
+                     int B, int V, int C, int relu, int accumulate, int dtype, float* sums_keep, int* deferred, const dreg_bn_extra* ex, void* stream)
+{
+    return bn3d_bwd_impl(x, dy, y, scale_shift, mean_rstd, dx, dres, dgamma, dbeta, coef, workspace, B, V, C, relu, accumulate, dtype, stream, sums_keep, deferred, ex);
+}
 static int bn3d_bwd_impl(const void* x, const void* dy, const void* y, const float* scale_shift, const float* mean_rstd,
                          void* dx, void* dres, float* dgamma, float* dbeta, float* coef, float* workspace,
-                         int B, int V, int C, int relu, int accumulate, int dtype, void* stream, float* sums_keep, int* deferred)
+                         int B, int V, int C, int relu, int accumulate, int dtype, void* stream, float* sums_keep, int* deferred, const dreg_bn_extra* ex)
 {
     hipStream_t st = (hipStream_t)stream;
-    const BnSplitkIn ski = g_bn_splitk_in;
-    g_bn_splitk_in = BnSplitkIn{};
+    BnSplitkIn ski;
+    if (ex) { ski.part = ex->splitk_part; ski.nsplit = ex->splitk_nsplit; ski.slice = ex->splitk_slice; }
     if (ski.part && !dreg_bn_small_in_regs(B, V, C, dtype)) return DREG_EINVAL;
     if (deferred) *deferred = 0;
     const int G = dtype == 0 ? 8 : 4;
@@ -2162,8 +2178,10 @@ int dreg_bn_relu_maxpool_bwd(const void* x, const void* dp, const uint8_t* argma
 // Stem over a sparse volume (see the kernels above).  x: [B,Di,Hi,Wi,C] bf16, zero outside `rows` (ascending flat row indices, n of them);
 // pooled / argmax as dreg_bn_relu_maxpool_fwd; xam: bf16 [B,Do,Ho,Wo,C] (raw x of the arg-max voxels, for the backward sums); pmask: B*Do*Ho*Wo
 // bytes of scratch; act (optional): the dense-layout activation, written on rows_a only.  workspace: fp32 [B][64][C][2].
-static int g_sstem_pool_blocks = 8192;
+DREG_KNOB(int, g_sstem_pool_blocks, 8192);
+#ifdef DREG_PROBE
 void dreg_sstem_set_pool_blocks(int n) { g_sstem_pool_blocks = n > 0 ? n : 8192; }    // measurement (tools/bench_sparse_stem.py)
+#endif
 size_t dreg_sparse_stem_workspace_floats(int B, int Do, int Ho, int Wo, int C)
 {
     const int Vo = Do * Ho * Wo;
@@ -2422,6 +2440,61 @@ int dreg_fill_zero(void* p, size_t bytes, void* stream)
     if ((bytes & 15) || ((uintptr_t)p & 15)) return hipMemsetAsync(p, 0, bytes, (hipStream_t)stream) == hipSuccess ? DREG_OK : DREG_ELAUNCH;
     const size_t n16 = bytes >> 4;
     hipLaunchKernelGGL(fill_zero_kernel, dim3(nblocks(n16, 256, 16384)), dim3(256), 0, (hipStream_t)stream, (uint4*)p, n16);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+// Guard bands (debug mode of the executors: dreg_exec_opts.guard).  n bands of band_bytes (a multiple of 16) at base + offsets[i] are filled with the
+// poison word 0xA5C3A5C3; dreg_guard_scan counts the bands that no longer hold it: result (device int64 [4], zeroed by the scan's own first kernel) =
+// { bands with a changed byte, smallest such band index (n if none), byte offset of its first changed 16-byte word, changed words in total }.
+__global__ void guard_fill_kernel(char* base, const unsigned long long* __restrict__ offsets, int band_bytes)
+{
+    uint4* p = reinterpret_cast<uint4*>(base + offsets[blockIdx.x]);
+    for (int i = threadIdx.x; i < band_bytes / 16; i += blockDim.x) p[i] = make_uint4(0xA5C3A5C3u, 0xA5C3A5C3u, 0xA5C3A5C3u, 0xA5C3A5C3u);
+}
+__global__ void guard_reset_kernel(long long* result, int n) { result[0] = 0; result[1] = n; result[2] = 0; result[3] = 0; }
+__global__ void guard_scan_kernel(const char* base, const unsigned long long* __restrict__ offsets, int band_bytes, long long* result)
+{
+    const uint4* p = reinterpret_cast<const uint4*>(base + offsets[blockIdx.x]);
+    __shared__ int first, count;
+    if (threadIdx.x == 0) { first = 0x7fffffff; count = 0; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < band_bytes / 16; i += blockDim.x) {
+        const uint4 v = p[i];
+        if (v.x != 0xA5C3A5C3u || v.y != 0xA5C3A5C3u || v.z != 0xA5C3A5C3u || v.w != 0xA5C3A5C3u) { atomicMin(&first, i * 16); atomicAdd(&count, 1); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && count) {
+        atomicAdd((unsigned long long*)&result[0], 1ull);
+        atomicAdd((unsigned long long*)&result[3], (unsigned long long)count);
+        atomicMin(&result[1], (long long)blockIdx.x);
+    }
+}
+__global__ void guard_first_kernel(const char* base, const unsigned long long* __restrict__ offsets, int band_bytes, long long* result, int n)
+{
+    const long long b = result[1];
+    if (b >= n) return;
+    const uint4* p = reinterpret_cast<const uint4*>(base + offsets[b]);
+    for (int i = 0; i < band_bytes / 16; ++i) {
+        const uint4 v = p[i];
+        if (v.x != 0xA5C3A5C3u || v.y != 0xA5C3A5C3u || v.z != 0xA5C3A5C3u || v.w != 0xA5C3A5C3u) { result[2] = (long long)i * 16; return; }
+    }
+}
+int dreg_guard_fill(void* base, const void* offsets_dev, int n, int band_bytes, void* stream)
+{
+    if (n <= 0) return DREG_OK;
+    if (band_bytes <= 0 || (band_bytes & 15)) return DREG_EINVAL;
+    hipLaunchKernelGGL(guard_fill_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (char*)base, (const unsigned long long*)offsets_dev, band_bytes);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+int dreg_guard_scan(const void* base, const void* offsets_dev, int n, int band_bytes, void* result_dev, void* stream)
+{
+    if (band_bytes <= 0 || (band_bytes & 15) || !result_dev) return DREG_EINVAL;
+    hipLaunchKernelGGL(guard_reset_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)result_dev, n);
+    if (n > 0) {
+        hipLaunchKernelGGL(guard_scan_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const char*)base, (const unsigned long long*)offsets_dev, band_bytes, (long long*)result_dev);
+        hipLaunchKernelGGL(guard_first_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const char*)base, (const unsigned long long*)offsets_dev, band_bytes, (long long*)result_dev, n);
+    }
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

@@ -589,7 +589,7 @@ template <typename T> __global__ void f32_to_f16_kernel(const float* __restrict_
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (_Float16)in[i];
 }
 
-static int g_ngp_density_unroll = 1;   // tuning (include/dreg_nerf_tuning.h): hash-grid levels whose corner gathers are in flight together (1, 2, 4, 8)
+DREG_KNOB(int, g_ngp_density_unroll, 1);   // tuning (include/dreg_nerf_probe.h): hash-grid levels whose corner gathers are in flight together (1, 2, 4, 8)
 static void ngp_density_launch(const float* x, const void* table, const void* w1, const void* w2, float* density, void* raw, const NgpLevels& lv,
                                const float* aabb, int Np, int contract, void* stream, const int* order = nullptr, int xslot = 0, NgpKeepEpi ke = NgpKeepEpi{})
 {
@@ -598,7 +598,7 @@ static void ngp_density_launch(const float* x, const void* table, const void* w1
     if (g_ngp_density_unroll == 8) NGP_D(8); else if (g_ngp_density_unroll == 4) NGP_D(4); else if (g_ngp_density_unroll == 2) NGP_D(2); else NGP_D(1);
 #undef NGP_D
 }
-static int g_ngp_xcd_levels = 1;       // tuning (include/dreg_nerf_tuning.h): with a workspace, encode per XCD-resident level pair first (ngp_encode_xcd_kernel)
+DREG_KNOB(int, g_ngp_xcd_levels, 1);       // tuning (include/dreg_nerf_probe.h): with a workspace, encode per XCD-resident level pair first (ngp_encode_xcd_kernel)
 // two launches: the level features of all points into `feat` (fp16 [16][Np][2], XCD-partitioned levels), then the density MLP over them
 static void ngp_density_launch_xcd(const float* x, const void* table, const void* w1, const void* w2, float* density, void* raw, const NgpLevels& lv,
                                    const float* aabb, int Np, int contract, void* feat, void* stream, const int* order, int xslot, NgpKeepEpi ke = NgpKeepEpi{})
@@ -612,7 +612,7 @@ static void ngp_density_launch_xcd(const float* x, const void* table, const void
                        (const _Float16*)w1, (const _Float16*)w2, density, (_Float16*)raw, lv, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5], Np, contract,
                        (const _Float16*)feat, order, xslot, ke);
 }
-static int g_ngp_rgb_chunks = 1;     // tuning (include/dreg_nerf_tuning.h): shared-direction colour queries run the 16-point-chunk kernel (0: the 64-point kernel)
+DREG_KNOB(int, g_ngp_rgb_chunks, 1);     // tuning (include/dreg_nerf_probe.h): shared-direction colour queries run the 16-point-chunk kernel (0: the 64-point kernel)
 
 extern "C" {
 
@@ -689,7 +689,9 @@ int dreg_ngp_density_fwd_ws(const float* x, const void* table, const void* w1, c
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
+#ifdef DREG_PROBE
 void dreg_ngp_set_xcd_levels(int on) { g_ngp_xcd_levels = on ? 1 : 0; }
+#endif
 // colour for ONE viewing direction per point (NGPradianceField.query_rgb(dir, embedding) / forward(positions, directions),
 // conerf/radiance_fields/ngp.py:178-208): dirs fp32 [Np,3] as passed to query_rgb, raw fp16 [Np,16] -> rgb fp32 [Np,3].
 int dreg_ngp_rgb_dir_fwd(const void* raw, const void* w1, const void* w2, const void* w3, const float* dirs, float* rgb, int Np, void* stream)
@@ -764,8 +766,10 @@ int dreg_ngp_rgb_mean_fwd(const void* raw, const void* w1, const void* w2, const
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
+#ifdef DREG_PROBE
 void dreg_ngp_set_rgb_chunks(int on) { g_ngp_rgb_chunks = on ? 1 : 0; }
 void dreg_ngp_set_density_unroll(int n) { g_ngp_density_unroll = (n == 2 || n == 4 || n == 8) ? n : 1; }
+#endif
 
 int dreg_grid_scatter7(const float* xyz, const float* rgb, const float* alpha, const int64_t* idx, const uint8_t* keep,
                        float* grid, int Np, void* stream)

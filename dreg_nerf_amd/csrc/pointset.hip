@@ -850,10 +850,12 @@ size_t dreg_voxel_downsample_workspace_bytes(int N)
     const size_t a = ((size_t)N * 8 + 255) / 256 * 256, b4 = ((size_t)(N + 1) * 4 + 255) / 256 * 256;
     return 2 * a + 5 * b4 + tmp + 256;
 }
-static int g_own_sort = 0;     // tuning (include/dreg_nerf_tuning.h): 1 = the one-workgroup kernel above for <= 131,072 keys.  OFF by default: measured 0.45 ms (9 k keys) to
+DREG_KNOB(int, g_own_sort, 0);     // tuning (include/dreg_nerf_probe.h): 1 = the one-workgroup kernel above for <= 131,072 keys.  OFF by default: measured 0.45 ms (9 k keys) to
                                // 1.45 ms (38 k keys) per round on its single CU against ~0.07 ms for rocPRIM's chip-wide sort + scan (round 4, rocprofv3); the rounds' host
                                // syncs then put the geometry phase on the critical path (19.2 vs 18.2 ms per step).  Results are identical (tested both ways).
+#ifdef DREG_PROBE
 void dreg_voxel_set_own_sort(int on) { g_own_sort = on ? 1 : 0; }
+#endif
 static int voxel_downsample_impl(const float* pts, const float* feats, const int* pt_batch, float* out_pts, float* out_feats,
                                  int* n_out, int* batch_counts, uint32_t* inv_seg, float* inv_cnt, int* err,
                                  uint32_t* order_out, uint32_t* starts_out,

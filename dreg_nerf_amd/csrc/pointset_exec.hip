@@ -63,6 +63,7 @@ struct Ps {
     Lin lin[NLIN];
     Layout lay;
     int fuse = 1;
+    int group_wgrad = 1;   // with fuse: the linear layers' weight-gradient partials of a backward pass in one launch per tile shape (bit-identical)
     std::vector<hipEvent_t> ev;            // one per linear layer + spares: "its output gradient is complete" (recorded on the caller's stream)
     hipEvent_t ev_done = nullptr;
     // descriptor tables travel through pinned staging (a pageable host-to-device copy drains the stream on ROCm)
@@ -155,7 +156,6 @@ void build_layout(Ps* p, int R)
 }
 
 #define CK(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
-int g_ps_group_wgrad = 1;   // tuning (include/dreg_nerf_tuning.h): the linear layers' weight-gradient partials of a backward pass in one launch per tile shape
 
 // y = x W^T (+bias) (+residual, fp32 output) (relu): the 1x1x1 path of the implicit-GEMM kernels, rows as the batch dimension
 int linear_fwd(Ps* p, const Layout& y, char* A, const void* x, const void* wpk, const float* bias, const void* residual, void* out,
@@ -219,7 +219,7 @@ void dreg_ps_destroy(void* h)
 // 1 (default): ReLU mask and the decoder's gradient sum in the data-gradient epilogues, one LayerNorm backward for the final norm's two
 // applications, all bias column sums in one batched launch pair
 void dreg_ps_set_fuse(void* h, int fuse) { ((Ps*)h)->fuse = fuse ? 1 : 0; }
-void dreg_ps_set_group_wgrad(int on) { g_ps_group_wgrad = on ? 1 : 0; }   // read at every backward call
+void dreg_ps_set_group_wgrad(void* h, int on) { ((Ps*)h)->group_wgrad = on ? 1 : 0; }   // per handle; read at every backward call
 // HIP events around every linear-layer launch of the following passes (bench.py's bracketed step); read them back AFTER a device
 // synchronisation: info[5 * i] = (kind 0 fwd / 1 dgrad / 2 wgrad, rows, cin, cout, flags: 1 addend, 2 fp32 output, 4 split-K workspace
 // offered), ms[i] = the launch's duration.  Returns the number of records (and clears them).
@@ -332,7 +332,7 @@ int dreg_ps_backward(void* h, void* arena, size_t arena_bytes, const int64_t* pa
     // shape at the end of the pass (every operand lives in the arena until then) instead of 36 launches of 50 - 200 workgroups each
     struct GroupRec { char d[160]; int variant, nblocks; };
     std::vector<GroupRec> grp;
-    const bool group = fuse && g_ps_group_wgrad && !p->timing;
+    const bool group = fuse && p->group_wgrad && !p->timing;
     auto param_grads = [&](int li, const void* g, const void* x, int rows, size_t wg_off, size_t cs_off) -> int {
         const Lin& l = p->lin[li];
         bool grouped = false;

@@ -200,7 +200,11 @@ __global__ __launch_bounds__(64) void surface_visibility_kernel(VisArgs a)
 // camera, so the later cameras mostly find the label set).  Per-ray arithmetic is unchanged: the labels are the same.
 // The MLP stores its hidden layer as in ngp_density_kernel: products formed transposed (weights as the MFMA's first operand), so a lane
 // holds four consecutive hidden units of one sample and writes them with one 8-byte LDS store instead of 64 two-byte ones.
-__device__ long g_pass_bound = 1L << 22;   // passes of the march loop per wave (test hook: dreg_visibility_set_pass_bound)
+#ifdef DREG_PROBE
+__device__ long g_pass_bound = 1L << 22;   // passes of the march loop per wave (test hook of the measurement build: dreg_visibility_set_pass_bound)
+#else
+static constexpr long g_pass_bound = 1L << 22;
+#endif
 __device__ __forceinline__ void vwave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ void vis_march_queue(const VisArgs& a, unsigned long long* __restrict__ queue)
 {
@@ -502,7 +506,7 @@ int dreg_surface_visibility_fill_desc(void* host_desc, const float* cams, const 
     memcpy(host_desc, &a, sizeof(a));
     return DREG_OK;
 }
-static int g_vis_waves = 4096;        // tuning (include/dreg_nerf_tuning.h): one-wave workgroups of the persistent launches (256 CUs x 16)
+DREG_KNOB(int, g_vis_waves, 4096);        // tuning (include/dreg_nerf_probe.h): one-wave workgroups of the persistent launches (256 CUs x 16)
 int dreg_surface_visibility_multi(const void* descs_dev, int n, long total_rays, void* stream)
 {
     if (n <= 0 || total_rays <= 0) return DREG_OK;
@@ -515,6 +519,7 @@ int dreg_surface_visibility_multi(const void* descs_dev, int n, long total_rays,
 }
 // The same labels from the persistent kernel (lanes refilled from a ray queue; rays of points that already carry the label are not
 // marched).  queue: 8 bytes of device memory the CALLER has zeroed on this stream (the ray counter).
+#ifdef DREG_PROBE
 void dreg_visibility_set_waves(int n) { g_vis_waves = n > 0 ? n : 4096; }
 // Test hook: passes of the persistent kernels' march loop per wave (0 = the default 2^22, never reached by a real extraction).  A launch
 // that hits the bound sets bit 63 of its ray counter(s) — the caller's `queue` words — instead of silently leaving points unlabelled.
@@ -523,6 +528,7 @@ int dreg_visibility_set_pass_bound(long passes)
     const long v = passes > 0 ? passes : (1L << 22);
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pass_bound), &v, sizeof(v));
 }
+#endif
 int dreg_surface_visibility_queue(const float* cams, const float* pts, const uint8_t* binary, int* label,
                                   const void* table, const void* w1, const void* w2,
                                   const uint32_t* offset, const uint32_t* size, const uint32_t* res, const float* scale, const uint32_t* hashed,

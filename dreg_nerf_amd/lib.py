@@ -36,27 +36,23 @@ SIGNATURES = {
     "dreg_conv3d_igemm_occ": (I, [P, P, P, P, P] + [I] * 18 + [I, I, P, Z, P, P]),
     "dreg_conv3d_igemm_bnstats": (I, [P, P, P, P, P] + [I] * 17 + [P, Z, P, P, P]),
     "dreg_conv3d_kpad": (I, [I, I, I]),
-    "dreg_conv_set_glds": (None, [I]),
+    "dreg_conv3d_igemm_defer": (I, [P, P, P, P, P] + [I] * 18 + [P, Z, P, P, P, P]),
+    "dreg_bn3d_fwd_ex": (I, [P] * 10 + [I, I, I, F, F, I, I, I, P, P, I, P, P]),
+    "dreg_bn3d_bwd_ex": (I, [P] * 11 + [I] * 6 + [P, P, P, P]),
+    "dreg_exec_default_opts": (None, [P]),
+    "dreg_exec_guard_bands": (I, [P]),
+    "dreg_exec_guard_check": (I, [P, P, P, P]),
+    "dreg_exec_guard_describe": (I, [P, I, P, I]),
+    "dreg_exec_guard_last": (I, [P, P, P, P]),
+    "dreg_guard_fill": (I, [P, P, I, I, P]),
+    "dreg_guard_scan": (I, [P, P, I, I, P, P]),
+    "dreg_exec_create_opts": (P, [P, I, P, I, P, I, P]),
+    "dreg_ps_set_group_wgrad": (None, [P, I]),
     "dreg_conv_get_glds": (I, []),
     "dreg_conv3d_dgrad_s2": (I, [P, P, P] + [I] * 11 + [P]),
     "dreg_conv3d_dgrad_s2_acc": (I, [P, P, P] + [I] * 11 + [P]),
     "dreg_pack_conv_weight": (I, [P, P, I, I, I, I, I, I, P]),
     "dreg_pack_conv_weights_batched": (I, [P, I, I, I, P, P]),
-    "dreg_conv_set_wgrad_splits": (None, [I]),
-    "dreg_conv_set_wgrad_big": (None, [I]),
-    "dreg_conv_igemm_probe": (None, [I]),
-    "dreg_conv_set_igemm_ap": (None, [I]),
-    "dreg_conv_set_igemm_ap256": (None, [I]),
-    "dreg_conv_set_pointwise_rmw_cin": (None, [I]),
-    "dreg_exec_set_aux_streams": (None, [I]),
-    "dreg_conv_igemm_probe_read": (I, [P]),
-    "dreg_conv_set_wgrad_pipe": (None, [I]),
-    "dreg_conv_wgrad_probe_read": (I, [P]),
-    "dreg_conv_set_wgrad_ring": (None, [I]),
-    "dreg_conv_set_wgrad_rows_fast": (None, [I]),
-    "dreg_conv_set_row_splits": (None, [I]),
-    "dreg_conv_set_glds_stages": (None, [I]),
-    "dreg_conv_set_wgrad_target_blocks": (None, [I]),
     "dreg_conv3d_wgrad_splits": (I, [I] * 8),
     "dreg_conv3d_wgrad_workspace_bytes": (Z, [I] * 8),
     "dreg_conv3d_wgrad": (I, [P, P, P, P, Z] + [I] * 16 + [P]),
@@ -72,41 +68,15 @@ SIGNATURES = {
     "dreg_conv3_halo_pack_bytes": (Z, [I]),
     "dreg_pack_conv_weight_halo": (I, [P, P, I, I, I, P]),
     "dreg_conv3_halo": (I, [P, P, P, P, P] + [I] * 10 + [P]),
-    "dreg_conv_set_narrow_small": (None, [I]),
     "dreg_conv3d_wgrad_variant": (I, [I] * 10),
     "dreg_conv3d_igemm_variant": (I, [I] * 17),
-    "dreg_bn_set_debug_skip": (None, [I]),
-    "dreg_bn_set_store_g": (None, [I]),
-    "dreg_bn_set_small_regs": (None, [I]),
-    "dreg_exec_set_fuse_stem": (None, [I]),
-    "dreg_exec_set_sparse_stem": (None, [I]),
-    "dreg_exec_set_group_wgrad": (None, [I]),
     "dreg_conv3d_wgrad_group_fill": (I, [P, P, P, P, Z] + [I] * 12 + [P, P]),
-    "dreg_exec_set_fold_splitk": (None, [I]),
-    "dreg_conv_defer_splitk_reduce": (None, [I]),
-    "dreg_conv_splitk_deferred": (I, [P, P]),
-    "dreg_bn_set_splitk_input": (None, [P, I, Z]),
     "dreg_bn_small_in_regs": (I, [I, I, I, I]),
-    "dreg_ps_set_group_wgrad": (None, [I]),
     "dreg_wgrad_group_desc_bytes": (I, []),
     "dreg_linear_wgrad_group_fill": (I, [P, P, P, P, Z, I, I, I, P, P]),
     "dreg_wgrad_group_launch": (I, [P, I, I, I, P]),
-    "dreg_exec_set_fold_res_bn": (None, [I]),
-    "dreg_bn_set_residual_transform": (None, [P]),
-    "dreg_exec_set_s2_accumulate": (None, [I]),
-    "dreg_sstem_set_pool_blocks": (None, [I]),
-    "dreg_exec_set_fuse_bn_stats": (None, [I]),
-    "dreg_exec_set_brick": (None, [I]),
-    "dreg_voxel_set_own_sort": (None, [I]),
-    "dreg_exec_set_defer_head_pg": (None, [I]),
-    "dreg_conv_set_bn_stats_epilogue": (None, [I]),
-    "dreg_exec_set_bn_batch_tails": (None, [I]),
-    "dreg_exec_set_sparse_grads": (None, [I]),
-    "dreg_conv3_halo_set_variant": (None, [I]),
-    "dreg_conv3_halo_set_prof": (None, [P]),
     # fpn_ops.hip
     "dreg_bn_num_chunks": (I, [I]),
-    "dreg_bn_set_small_max_voxels": (None, [I]),
     "dreg_bn_relu_maxpool_fwd": (I, [P] * 10 + [I] * 8 + [F, F, I, I, P]),
     "dreg_bn_relu_maxpool_bwd": (I, [P] * 10 + [I] * 10 + [P]),
     "dreg_sparse_stem_workspace_floats": (Z, [I] * 5),
@@ -234,8 +204,6 @@ SIGNATURES = {
     "dreg_ngp_density_fwd": (I, [P] * 6 + [P] * 5 + [P, I, P]),
     "dreg_ngp_rgb_mean_fwd": (I, [P] * 6 + [I, I, P]),
     "dreg_ngp_dir_bias": (I, [P, P, P, I, P]),
-    "dreg_ngp_set_rgb_chunks": (None, [I]),
-    "dreg_ngp_set_density_unroll": (None, [I]),
     "dreg_ngp_alpha_keep": (I, [P, P, P, I, F, F, P]),
     "dreg_ngp_density_fwd_contract": (I, [P] * 6 + [P] * 5 + [P, I, I, P]),
     "dreg_ngp_density_fwd_ws": (I, [P] * 6 + [P] * 5 + [P, I, I, P, Z, P, I, P]),
@@ -249,7 +217,6 @@ SIGNATURES = {
     "dreg_ngp_density_keep_fwd_ws": (I, [P] * 6 + [P] * 5 + [P, I, I, P, Z, P, I] + [P, P, F, F, P]),
     "dreg_grid_write_kept": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "dreg_ngp_density_workspace_bytes": (Z, [I]),
-    "dreg_ngp_set_xcd_levels": (None, [I]),
     "dreg_ngp_rgb_dir_fwd": (I, [P] * 6 + [I, P]),
     "dreg_grid_scatter7": (I, [P] * 6 + [I, P]),
     "dreg_grid_sample_points": (I, [P, P, P, I, I, I, P, I, P]),
@@ -260,9 +227,100 @@ SIGNATURES = {
     "dreg_surface_visibility_desc_bytes": (Z, []),
     "dreg_surface_visibility_fill_desc": (I, [P] + [P] * 7 + [P] * 5 + [P, P, P] + [I] * 5 + [F, F, F, F, P, P]),
     "dreg_surface_visibility_multi": (I, [P, I, ctypes.c_long, P]),
+}
+
+
+# include/dreg_nerf_probe.h: process-global kernel-variant setters, exported by the MEASUREMENT build only (libdreg_nerf_hip_probe.so)
+PROBE_SIGNATURES = {
+    "dreg_conv_set_glds": (None, [I]),
+    "dreg_conv_set_wgrad_splits": (None, [I]),
+    "dreg_conv_set_wgrad_big": (None, [I]),
+    "dreg_conv_igemm_probe": (None, [I]),
+    "dreg_conv_set_igemm_ap": (None, [I]),
+    "dreg_conv_set_igemm_ap256": (None, [I]),
+    "dreg_conv_set_pointwise_rmw_cin": (None, [I]),
+    "dreg_conv_igemm_probe_read": (I, [P]),
+    "dreg_conv_set_wgrad_pipe": (None, [I]),
+    "dreg_conv_wgrad_probe_read": (I, [P]),
+    "dreg_conv_set_wgrad_ring": (None, [I]),
+    "dreg_conv_set_wgrad_rows_fast": (None, [I]),
+    "dreg_conv_set_row_splits": (None, [I]),
+    "dreg_conv_set_glds_stages": (None, [I]),
+    "dreg_conv_set_wgrad_target_blocks": (None, [I]),
+    "dreg_conv_set_narrow_small": (None, [I]),
+    "dreg_bn_set_debug_skip": (None, [I]),
+    "dreg_bn_set_store_g": (None, [I]),
+    "dreg_bn_set_small_regs": (None, [I]),
+    "dreg_sstem_set_pool_blocks": (None, [I]),
+    "dreg_voxel_set_own_sort": (None, [I]),
+    "dreg_conv_set_bn_stats_epilogue": (None, [I]),
+    "dreg_conv3_halo_set_variant": (None, [I]),
+    "dreg_conv3_halo_set_prof": (None, [P]),
+    "dreg_bn_set_small_max_voxels": (None, [I]),
+    "dreg_ngp_set_rgb_chunks": (None, [I]),
+    "dreg_ngp_set_density_unroll": (None, [I]),
+    "dreg_ngp_set_xcd_levels": (None, [I]),
     "dreg_visibility_set_waves": (None, [I]),
     "dreg_visibility_set_pass_bound": (I, [ctypes.c_long]),
 }
+PROBE_LIB_PATH = os.path.join(_HERE, "libdreg_nerf_hip_probe.so")
+_probe_lib = None
+
+
+class ExecOpts(ctypes.Structure):
+    """dreg_exec_opts of include/dreg_nerf.h (creation options of one trunk executor)."""
+    _fields_ = [(n, c_int) for n in ("sparse_grads", "bn_batch_tails", "fuse_stem", "sparse_stem", "fold_res_bn", "fold_splitk", "group_wgrad",
+                                     "s2_accumulate", "fuse_bn_stats", "brick", "defer_head_pg", "persistent_deep", "guard")] + [("reserved", c_int * 3)]
+
+
+def load_probe():
+    """The measurement build (every entry point of the product + the setters of include/dreg_nerf_probe.h).  Tools and variant tests only."""
+    global _probe_lib
+    if _probe_lib is None:
+        if not os.path.exists(PROBE_LIB_PATH):
+            raise DregError(f"{PROBE_LIB_PATH} not found: build it with `python -m dreg_nerf_amd.build`")
+        lib = ctypes.CDLL(PROBE_LIB_PATH)
+        for name, (rt, at) in list(SIGNATURES.items()) + list(PROBE_SIGNATURES.items()):
+            _sig(lib, name, rt, at)
+        _probe_lib = lib
+    return _probe_lib
+
+
+def use_probe():
+    """Stand-alone tools only: the measurement build for the rest of the process (every L.load() returns it from now on)."""
+    global _lib
+    _lib = load_probe()
+    return _lib
+
+
+class probe:
+    """``with L.probe() as lib:`` — inside the block every ``L.load()`` of the package returns the measurement build, so the wrappers of
+    dreg_nerf_amd run its kernels and ``lib.dreg_*_set_*`` selects their variants.  On exit the knobs that were touched through ``set()`` are put
+    back and ``L.load()`` is the product library again.  Objects that keep a handle (executors) must be created AND dropped inside the block."""
+
+    def __init__(self):
+        self._restore = []
+
+    def __enter__(self):
+        global _lib
+        self._saved = _lib
+        _lib = load_probe()
+        self.lib = _lib
+        return self
+
+    def set(self, name, value, default):
+        getattr(self.lib, name)(value)
+        self._restore.append((name, default))
+
+    def __getattr__(self, name):
+        return getattr(self.__dict__["lib"], name)
+
+    def __exit__(self, *exc):
+        global _lib
+        for name, default in reversed(self._restore):
+            getattr(self.lib, name)(default)
+        _lib = self._saved
+        return False
 
 
 def load():
@@ -282,6 +340,10 @@ def load():
 
 def declared_symbols():
     return list(SIGNATURES.keys())
+
+
+def probe_symbols():
+    return list(PROBE_SIGNATURES.keys())
 
 
 def ptr(t):

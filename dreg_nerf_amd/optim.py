@@ -161,7 +161,18 @@ class GradSync:
         self.reduce_fn = reduce_fn             # tests: called instead of torch.distributed with (lo, hi)
         self._use_avg = reduce_fn is None and dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
         self._side = None
+        # measure_exposed: events around finish()'s wait — how long the step's own stream stood still for gradient exchange that backward did not
+        # hide (bench.py's multi-rank line: `allreduce_exposed_ms`); off in training (two event records per step)
+        self.measure_exposed = False
+        self._exposed = []
         self.begin()
+
+    def exposed_ms(self, reset: bool = True):
+        """After a device synchronisation: (mean exposed ms per step, steps measured)."""
+        v = [a.elapsed_time(b) for a, b in self._exposed]
+        if reset:
+            self._exposed = []
+        return (sum(v) / len(v) if v else 0.0), len(v)
 
     def begin(self):
         self.next, self.handles, self.launched = 0, [], []
@@ -202,12 +213,42 @@ class GradSync:
 
     def finish(self):
         self.ready(0)
+        ev = None
+        if self.measure_exposed and self.opt.flat_g.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for h in self.handles:
             h.wait()                           # the current stream waits for the collective (no host block on 'nccl')
         if self.reduce_fn is None and not self._use_avg and self.world > 1:
             self.opt.flat_g[:self.opt.n_active].div_(self.world)
         if self._side is not None:
             torch.cuda.current_stream(self.opt.flat_g.device).wait_stream(self._side)
+        if ev is not None:
+            ev[1].record()
+            self._exposed.append(ev)
+
+
+def ranks_in_sync(opt: FlatAdamW, grad_norm: torch.Tensor = None):
+    """Data-parallel self-check: after identical initial weights and averaged gradients every rank must hold the SAME parameters
+    and have clipped by the SAME global gradient norm.  all-reduces (MAX - MIN) of an order-sensitive checksum pair of the flat parameter buffer
+    (fp64 sum, fp64 sum of index-weighted values) and of the last step's gradient norm; returns a dict whose `ranks_in_sync` is True when all spreads
+    are exactly 0 (trivially so outside a process group)."""
+    p = opt.flat_p[:opt.n_active].double()
+    idx = torch.arange(p.numel(), dtype=torch.float64, device=p.device).remainder_(8191.0).add_(1.0)
+    vals = [p.sum(), (p * idx).sum()]
+    vals.append(grad_norm.reshape(-1)[0].double() if grad_norm is not None else torch.zeros((), dtype=torch.float64, device=p.device))
+    v = torch.stack(vals)
+    ranks = 1
+    spread = torch.zeros_like(v)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        ranks = dist.get_world_size()
+        hi, lo = v.clone(), v.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        spread = hi - lo
+    s = [float(x) for x in spread.cpu()]
+    return {"ranks_in_sync": all(x == 0.0 for x in s) and all(torch.isfinite(v).tolist()), "ranks": ranks, "param_checksum": float(v[0]),
+            "param_checksum_spread": s[0], "param_weighted_checksum_spread": s[1], "grad_norm": float(v[2]), "grad_norm_spread": s[2]}
 
 
 def broadcast_buffers(module: torch.nn.Module, src: int = 0):

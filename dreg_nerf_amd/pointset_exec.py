@@ -29,6 +29,7 @@ _LINEARS = ("self_attn.in_proj_weight", "self_attn.out_proj.weight", "cross_attn
             "linear1.weight", "linear2.weight")
 
 FUSE = True      # False: the per-op path's arithmetic, bit for bit (tests; dreg_ps_set_fuse)
+GROUP_WGRAD = True   # False: one weight-gradient launch per linear layer instead of one per tile shape (A/B; dreg_ps_set_group_wgrad, per handle, bit-identical)
 
 
 def param_names():
@@ -66,7 +67,9 @@ class PointSetExecutor:
         if not self.h:
             raise L.DregError("dreg_ps_create failed")
         self.lib.dreg_ps_set_fuse(self.h, int(FUSE))
+        self.lib.dreg_ps_set_group_wgrad(self.h, int(GROUP_WGRAD))
         self._fuse = FUSE
+        self._group = GROUP_WGRAD
         self.device = self.params[0].device
         self.arena = None
         self.arena_bytes = 0
@@ -144,6 +147,9 @@ class PointSetExecutor:
         if self._fuse != FUSE:
             self.lib.dreg_ps_set_fuse(self.h, int(FUSE))
             self._fuse = FUSE
+        if self._group != GROUP_WGRAD:
+            self.lib.dreg_ps_set_group_wgrad(self.h, int(GROUP_WGRAD))
+            self._group = GROUP_WGRAD
         want = ops.PROFILER is not None and ops.PROFILER.enabled
         if want != self._timing:
             self.set_timing(want)
@@ -157,9 +163,13 @@ class PointSetExecutor:
         L.check(self.lib.dreg_ps_forward(self.h, L.ptr(arena), self.arena_bytes, self._pack_table(), L.ptr(feats), L.ptr(xyz), L.ptr(pe),
                                          L.ptr(tab.self_probs), L.ptr(tab.cross_probs), tab.nprob, tab.max_len, R,
                                          L.ptr(cond), L.ptr(corr), L.ptr(ov), L.stream()), "dreg_ps_forward")
+        self.generation = getattr(self, "generation", 0) + 1      # the arena now holds THIS pass's activations (see backward)
         return cond, corr, ov
 
-    def backward(self, feats, xyz, pe, tab, cond, corr, ov, g_cond, g_corr, g_ov, last_only=False):
+    def backward(self, feats, xyz, pe, tab, cond, corr, ov, g_cond, g_corr, g_ov, last_only=False, generation=None):
+        if generation is not None and generation != getattr(self, "generation", 0):
+            raise L.DregError("PointSetExecutor.backward: the shared arena was overwritten by a later forward pass (two grad-mode forwards before a "
+                              "backward: gradient accumulation over several forwards / retain_graph need one executor per live graph)")
         R = feats.shape[0]
         d_feats = torch.empty_like(feats)
         aux = None if self._timing else ops.PARAM_GRAD_STREAM
@@ -181,7 +191,7 @@ class _PointSetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, anchor, ex: PointSetExecutor, xyz, pe, tab):
         cond, corr, ov = ex.forward(feats, xyz, pe, tab)
-        ctx.ex, ctx.tab = ex, tab
+        ctx.ex, ctx.tab, ctx.generation = ex, tab, ex.generation
         ctx.save_for_backward(feats, xyz, pe, cond, corr, ov)
         ctx.set_materialize_grads(False)
         return cond, corr, ov, cond[-1].clone(), corr[-1].clone(), ov[-1].clone()
@@ -191,7 +201,7 @@ class _PointSetFn(torch.autograd.Function):
         feats, xyz, pe, cond, corr, ov = ctx.saved_tensors
         f32 = lambda g: g.contiguous().float() if g is not None else None
         if FUSE and g_cond is None and g_corr is None and g_ov is None:      # (fuse = 0 keeps the per-op path's arithmetic: full zero-padded gradients)
-            d_feats = ctx.ex.backward(feats, xyz, pe, ctx.tab, cond, corr, ov, f32(g_cl), f32(g_rl), f32(g_ol), last_only=True)
+            d_feats = ctx.ex.backward(feats, xyz, pe, ctx.tab, cond, corr, ov, f32(g_cl), f32(g_rl), f32(g_ol), last_only=True, generation=ctx.generation)
             return d_feats, None, None, None, None, None
         full = []
         for g, gl, ref in ((g_cond, g_cl, cond), (g_corr, g_rl, corr), (g_ov, g_ol, ov)):
@@ -199,7 +209,7 @@ class _PointSetFn(torch.autograd.Function):
                 g = torch.zeros_like(ref) if g is None else g.contiguous().float().clone()
                 g[-1] += gl.float()
             full.append(f32(g))
-        d_feats = ctx.ex.backward(feats, xyz, pe, ctx.tab, cond, corr, ov, *full)
+        d_feats = ctx.ex.backward(feats, xyz, pe, ctx.tab, cond, corr, ov, *full, generation=ctx.generation)
         return d_feats, None, None, None, None, None
 
 

@@ -110,8 +110,8 @@ class NeRFRegTr(nn.Module):
         # neighbourhoods staged once instead of a 27-tap gather per row (same results up to the order of the fp32 sums)
         self.brick_head = True
         # row sets that get tile tables (positions in ops.active_sets' tuple): S3 = the rows of the 256 -> 64 data gradient of
-        # pyramid_transformation_1, the one launch the staged form wins clearly (309 vs 455 us); the executor's dreg_exec_set_brick
-        # mask decides which launches use tables that exist (tools/bench_conv_brick.py measures all six)
+        # pyramid_transformation_1, the one launch the staged form wins clearly (309 vs 455 us); the executor's `brick` creation option
+        # (dreg_exec_opts) decides which launches use tables that exist (tools/bench_conv_brick.py measures all six)
         self.brick_sets = (2,)
         # Issue the point-set half (encoder, decoder, heads) of forward_batch from the C++ executor (csrc/pointset_exec.hip)
         self.native_pointset = True

@@ -20,6 +20,27 @@ RL_FIELDS = 8      # int64 fields per row list handed to the executor: rows, cou
 # DREG_SERIAL_STREAMS=1: no second stream for parameter gradients (every kernel alone on the GPU: what a per-kernel profile wants)
 SERIAL_STREAMS = bool(int(__import__("os").environ.get("DREG_SERIAL_STREAMS", "0")))
 KIND_NAMES = {0: "fwd", 1: "dgrad", 2: "wgrad"}
+# Creation options (dreg_exec_opts of include/dreg_nerf.h) of the executors created from now on, on top of dreg_exec_default_opts:
+# e.g. OPTS["sparse_stem"] = 0.  Per handle inside the library; this dict is the Python-side default the A/B tools and the "exact mode"
+# tests change (then drop the model's _trunk_cache).  Empty in the product.
+OPTS: Dict[str, int] = {}
+
+
+class exec_opts:
+    """``with exec_opts(sparse_stem=0):`` — executors created inside the block take these creation options (tests, A/B tools)."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.saved = dict(OPTS)
+        OPTS.update(self.kw)
+        return self
+
+    def __exit__(self, *exc):
+        OPTS.clear()
+        OPTS.update(self.saved)
+        return False
 
 
 class _Recorder:
@@ -81,8 +102,14 @@ class _Recorder:
 class TrunkExecutor:
     """One recorded program + its arena and packed-weight buffer."""
 
-    def __init__(self, model, x_shape, sparse_head: int, with_grad: bool = True, stem_rows: bool = False):
+    def __init__(self, model, x_shape, sparse_head: int, with_grad: bool = True, stem_rows: bool = False, opts: Optional[Dict[str, int]] = None):
         self.lib = L.load()
+        self.opts = L.ExecOpts()
+        self.lib.dreg_exec_default_opts(ctypes.byref(self.opts))
+        for k, v in {**OPTS, **(opts or {})}.items():
+            if not hasattr(self.opts, k):
+                raise L.DregError(f"unknown executor option {k!r}")
+            setattr(self.opts, k, int(v))
         P = model._P()
         rec = _Recorder(P, x_shape)
         x0 = _Recorder.T(0, x_shape)
@@ -115,9 +142,10 @@ class TrunkExecutor:
             prm[i, 3] = t.shape[1] if t.dim() > 1 else 1
             prm[i, 4] = t.shape[2] if t.dim() == 5 else 1
             self._sig.append((t.data_ptr(), prm[i, 1]))
-        self.h = self.lib.dreg_exec_create(tens.ctypes.data, len(rec.tensors), opsa.ctypes.data, len(rec.ops), prm.ctypes.data, len(rec.params))
+        self.h = self.lib.dreg_exec_create_opts(tens.ctypes.data, len(rec.tensors), opsa.ctypes.data, len(rec.ops), prm.ctypes.data, len(rec.params),
+                                                ctypes.byref(self.opts))
         if not self.h:
-            raise L.DregError("dreg_exec_create rejected the op program")
+            raise L.DregError("dreg_exec_create_opts rejected the op program")
         self.arena_bytes = self.lib.dreg_exec_arena_bytes(self.h)
         self.arena = torch.empty(self.arena_bytes, dtype=torch.uint8, device=dev)
         self.pack = torch.empty(self.lib.dreg_exec_pack_bytes(self.h), dtype=torch.uint8, device=dev)
@@ -256,19 +284,48 @@ class TrunkExecutor:
         if rows is not None and getattr(rows, "stem", None) is not None:
             self.last_row_counts.append(int(rows.stem.shape[0]))
         ra, n = self._rowlist_array(rows)
-        L.check(self.lib.dreg_exec_forward(self.h, L.ptr(self.arena), self.arena_bytes, L.ptr(self.pack), L.ptr(x),
-                                           ctypes.addressof(ra) if ra is not None else None, n, int(train), L.stream()), "dreg_exec_forward")
+        self._guarded(self.lib.dreg_exec_forward(self.h, L.ptr(self.arena), self.arena_bytes, L.ptr(self.pack), L.ptr(x),
+                                                 ctypes.addressof(ra) if ra is not None else None, n, int(train), L.stream()), "dreg_exec_forward")
+        # one arena holds the activations of ONE forward pass: a backward must belong to the latest one (see backward)
+        self.generation = getattr(self, "generation", 0) + 1
         nbytes = int(np.prod(self.out_shape)) * 2
         return self.arena[self.out_off:self.out_off + nbytes].view(torch.bfloat16).view(self.out_shape)
 
-    def backward(self, x: torch.Tensor, rows, grad_out: torch.Tensor):
+    def _guarded(self, rc: int, name: str):
+        """L.check + the guard mode's reports (creation option guard >= 1: every region of the arena is followed by a poisoned band)."""
+        if rc == -3:                       # DREG_EGUARD: a guard = 2 pass stopped behind the first op after which a band had changed
+            op, ps, band = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
+            self.lib.dreg_exec_guard_last(self.h, ctypes.byref(op), ctypes.byref(ps), ctypes.byref(band))
+            raise L.DregError(f"{name}: guard band overwritten behind op {op.value} ({'backward' if ps.value else 'forward'} pass; "
+                              f"{self.rec.ops[op.value] if 0 <= op.value < len(self.rec.ops) else 'pass tail'}): {self.guard_describe(band.value)}")
+        L.check(rc, name)
+        if self.opts.guard:
+            bad = self.guard_check()
+            if bad[0]:
+                raise L.DregError(f"{name}: {bad[0]} guard band(s) overwritten ({bad[3]} 16-byte words); first: {self.guard_describe(bad[1])} + {bad[2]} bytes")
+
+    def guard_check(self):
+        out = (ctypes.c_longlong * 4)()
+        L.check(self.lib.dreg_exec_guard_check(self.h, L.ptr(self.arena), out, L.stream()), "dreg_exec_guard_check")
+        return list(out)
+
+    def guard_describe(self, band: int) -> str:
+        buf = ctypes.create_string_buffer(256)
+        self.lib.dreg_exec_guard_describe(self.h, int(band), buf, 256)
+        return buf.value.decode()
+
+    def backward(self, x: torch.Tensor, rows, grad_out: torch.Tensor, generation: Optional[int] = None):
+        if generation is not None and generation != getattr(self, "generation", 0):
+            raise L.DregError("TrunkExecutor.backward: the arena holds the activations of a LATER forward pass than the one this gradient belongs to "
+                              "(two grad-mode forwards before a backward — gradient accumulation over several forwards, retain_graph — need one "
+                              "executor each; the product step runs one forward and one backward per step)")
         ra, n = self._rowlist_array(rows)
         sync = ops.GRAD_SYNC
         self._flush_deferred()
         if sync is None:
-            L.check(self.lib.dreg_exec_backward(self.h, L.ptr(self.arena), self.arena_bytes, L.ptr(self.pack), L.ptr(x), L.ptr(grad_out),
-                                                ctypes.addressof(ra) if ra is not None else None, n, L.stream(), aux_stream(self.device).cuda_stream),
-                    "dreg_exec_backward")
+            self._guarded(self.lib.dreg_exec_backward(self.h, L.ptr(self.arena), self.arena_bytes, L.ptr(self.pack), L.ptr(x), L.ptr(grad_out),
+                                                      ctypes.addressof(ra) if ra is not None else None, n, L.stream(), aux_stream(self.device).cuda_stream),
+                          "dreg_exec_backward")
             return
         # data-parallel step: backward in segments; after each, the gradient buckets it completed start their all-reduce
         plan = self._sync_plan(sync)
@@ -276,9 +333,9 @@ class TrunkExecutor:
         hi = len(self.rec.ops)
         for k, (lo_op, done_from) in enumerate(plan["cuts"]):
             flags = (1 if k == 0 else 0) | (2 if k == len(plan["cuts"]) - 1 else 0)
-            L.check(self.lib.dreg_exec_backward_range(self.h, L.ptr(self.arena), self.arena_bytes, L.ptr(self.pack), L.ptr(x), L.ptr(grad_out),
-                                                      ctypes.addressof(ra) if ra is not None else None, n, L.stream(), aux_stream(self.device).cuda_stream,
-                                                      lo_op, hi, flags), "dreg_exec_backward_range")
+            self._guarded(self.lib.dreg_exec_backward_range(self.h, L.ptr(self.arena), self.arena_bytes, L.ptr(self.pack), L.ptr(x), L.ptr(grad_out),
+                                                            ctypes.addressof(ra) if ra is not None else None, n, L.stream(), aux_stream(self.device).cuda_stream,
+                                                            lo_op, hi, flags), "dreg_exec_backward_range")
             hi = lo_op
             sync.ready(done_from)
 
@@ -391,12 +448,14 @@ class _TrunkFn(torch.autograd.Function):
     def forward(ctx, x, anchor, ex: TrunkExecutor, rows, train: bool):
         ctx.ex, ctx.rows = ex, rows
         ctx.save_for_backward(x)
-        return ex.forward(x, rows, train)
+        y = ex.forward(x, rows, train)
+        ctx.generation = ex.generation
+        return y
 
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
-        ctx.ex.backward(x, ctx.rows, g.contiguous())
+        ctx.ex.backward(x, ctx.rows, g.contiguous(), ctx.generation)
         return None, None, None, None, None
 
 

@@ -223,7 +223,7 @@ class _OverrunWatch:
         self.pending = keep
         if bad:
             raise L.DregError("surface visibility: a persistent launch reached its pass bound with rays left — points of that call are "
-                              "unlabelled (dreg_visibility_set_pass_bound / dreg_visibility_set_waves too small for this extraction)")
+                              "unlabelled (the march loop's pass bound of 2^22 per wave was reached: csrc/visibility.hip g_pass_bound)")
 
 
 OVERRUN = _OverrunWatch()

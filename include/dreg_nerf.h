@@ -25,6 +25,9 @@ extern "C" {
 #define DREG_OK 0
 #define DREG_EINVAL (-1)
 
+/* 1: this build stages the operands of bf16 stride-1 convolutions with buffer_load ... lds (always, in the product library) */
+int dreg_conv_get_glds(void);
+
 /* ---------------------------------------------------------------------------------------------- convolution / GEMM
  * Replaces torch.nn.Conv3d -> cuDNN (conerf/model/resnet3d.py:79-84,120,143-147;
  * conerf/model/feature_pyramid_net.py:21-36,47-56) and torch.nn.Linear -> cuBLAS
@@ -116,6 +119,11 @@ int dreg_conv3d_dgrad_s2_acc(const void* gout, const void* wt_class_packed, void
 
 /* Weight gradient (split over voxels, deterministic two-stage reduction):
  * dw[Cout][Cin_real][ksz^3] (fp32, torch layout) (+)= sum_m gout[m,:]^T x in[gather(m, tap), :]. */
+/* which bf16 weight-gradient kernel a launch of this shape runs: BM * 1000 + BNC (256256 = the 8-wave tile, 256128 = 4 waves / 32-voxel stages); for profiler labels */
+/* which kernel a convolution launch of this shape runs: kind * 1e8 + BM * 1e5 + BN * 100 + AP * 10 + splitK (kind 0 conv_igemm_glds_kernel, 1 conv_igemm_kernel; < 0 unsupported); nrows 0 = dense */
+int dreg_conv3d_igemm_variant(int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksz, int stride, int pad,
+                              int transposed, int nrows, int has_ws, int has_addend, int dtype);
+int dreg_conv3d_wgrad_variant(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int rows, int nrows, int occ);
 int dreg_conv3d_wgrad_splits(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int dtype);
 size_t dreg_conv3d_wgrad_workspace_bytes(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int dtype);
 int dreg_conv3d_wgrad(const void* gout, const void* in, float* dw, void* workspace, size_t workspace_bytes,
@@ -194,18 +202,34 @@ int dreg_bn3d_fwd_defer_update(const void* x, const void* res, void* y, const fl
 int dreg_bn3d_bwd_defer_params(const void* x, const void* dy, const void* y, const float* scale_shift, const float* mean_rstd,
                                void* dx, void* dres, float* dgamma, float* dbeta, float* coef, float* workspace,
                                int B, int V, int C, int relu, int accumulate, int dtype, float* sums_keep, int* deferred, void* stream);
-/* The NEXT large-path forward call's residual `res` is the INPUT of a ReLU-free BatchNorm that was run with y == NULL (statistics, scale /
- * shift only — the downsample branch of a bottleneck's first block, resnet3d.py:104-110): res_scale_shift = that layer's scale_shift; the
- * branch's output is formed on the fly, rounded as the separate apply pass stores it (bit-identical).  Consumed by that one call. */
-void dreg_bn_set_residual_transform(const float* res_scale_shift);
-/* Split-K sums folded into the consumer (the 8^3 / 4^3 levels of resnet3d.py's layer3 / layer4: conv2 -> bn2 forward, conv2's data gradient -> bn1
- * backward).  dreg_conv_defer_splitk_reduce(1) arms the NEXT convolution launch of the calling thread: if it runs split-K with bf16 output and no
- * bias / ReLU, its fp32 slices [nsplit][M * Cout] stay in its workspace un-summed and dreg_conv_splitk_deferred returns 1 with nsplit / the slice
- * length (it always disarms).  dreg_bn_set_splitk_input hands them to the NEXT BatchNorm call of the thread, which must take the register-resident
- * one-launch kernels (dreg_bn_small_in_regs): forward — x := the rounded sum (stored to x: the backward pass reads it); backward — dy := the rounded sum. */
-void dreg_conv_defer_splitk_reduce(int arm);
-int dreg_conv_splitk_deferred(int* nsplit, size_t* slice);
-void dreg_bn_set_splitk_input(const float* part, int nsplit, size_t slice);
+/* Optional extras of ONE BatchNorm call, handed over as an argument (the library keeps no per-thread "next call" state):
+ *  - res_scale_shift (forward, large path): `res` is the INPUT of a ReLU-free BatchNorm that was run with y == NULL (statistics, scale / shift
+ *    only — the downsample branch of a bottleneck's first block, resnet3d.py:104-110); res_scale_shift = that layer's scale_shift.  The branch's
+ *    output is formed on the fly, rounded as the separate apply pass stores it (bit-identical).
+ *  - splitk_part / splitk_nsplit / splitk_slice (register-resident one-launch kernels only, dreg_bn_small_in_regs): the call's x (forward) / dy
+ *    (backward) is the sum of the fp32 split-K slices [nsplit][slice] a convolution left un-summed (dreg_conv3d_igemm_defer: conv2 -> bn2 forward,
+ *    conv2's data gradient -> bn1 backward at the 8^3 / 4^3 levels of resnet3d.py's layer3 / layer4): forward — x := the rounded sum (stored to x:
+ *    the backward pass reads it); backward — dy := the rounded sum.  DREG_EINVAL when the call does not take that path. */
+typedef struct dreg_bn_extra {
+    const float* res_scale_shift;
+    const float* splitk_part;
+    int splitk_nsplit;
+    size_t splitk_slice;
+} dreg_bn_extra;
+/* dreg_bn3d_fwd_defer_update (sums_rows_per_chunk = 0) / dreg_bn3d_fwd_from_sums (> 0: workspace = the chunk sums, training mode) with extras (may be NULL) */
+int dreg_bn3d_fwd_ex(const void* x, const void* res, void* y, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float* scale_shift, float* mean_rstd, float* workspace,
+                     int B, int V, int C, float eps, float momentum, int train, int relu, int dtype, float* var_keep, int* deferred,
+                     int sums_rows_per_chunk, const dreg_bn_extra* ex, void* stream);
+int dreg_bn3d_bwd_ex(const void* x, const void* dy, const void* y, const float* scale_shift, const float* mean_rstd,
+                     void* dx, void* dres, float* dgamma, float* dbeta, float* coef, float* workspace,
+                     int B, int V, int C, int relu, int accumulate, int dtype, float* sums_keep, int* deferred, const dreg_bn_extra* ex, void* stream);
+/* dreg_conv3d_igemm_occ (bf16 in / out) that may leave a split-K launch's fp32 slices [*sk_nsplit][*sk_slice] un-summed in `workspace` for the
+ * BatchNorm behind it: *sk_nsplit = 0 when the launch finished its output itself (not split-K, or a bias / ReLU epilogue). */
+int dreg_conv3d_igemm_defer(const void* in, const void* wt_packed, void* out, const float* bias, const void* addend,
+                            int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+                            int ksz, int stride, int pad, int transposed, int relu, int Da, int Ha, int Wa, int add_same,
+                            void* workspace, size_t workspace_bytes, const uint8_t* rowocc, int* sk_nsplit, size_t* sk_slice, void* stream);
 int dreg_bn_small_in_regs(int B, int V, int C, int dtype);
 int dreg_bn_running_update_batched(const void* descs_dev, int n, int block_base, int nblocks, float momentum, void* stream);
 int dreg_bn_param_grad_batched(const void* descs_dev, int n, int block_base, int nblocks, int accumulate, void* stream);
@@ -261,6 +285,11 @@ int dreg_trilinear_gather_bwd(const float* dfeat, const int64_t* idx, const int*
 int dreg_cast_from_f32(const float* in, void* out, size_t n, int dtype, void* stream);
 /* zero fill at HBM rate (bytes % 16 == 0 and a 16-byte aligned pointer; otherwise hipMemsetAsync) */
 int dreg_fill_zero(void* p, size_t bytes, void* stream);
+/* Guard bands (the executors' debug mode, dreg_exec_opts.guard): n bands of band_bytes (a multiple of 16) at base + offsets[i] (device uint64 [n]) are
+ * filled with the poison word 0xA5C3A5C3; dreg_guard_scan writes result (device int64 [4]) = { bands with a changed word, smallest such band index
+ * (n if none), byte offset of its first changed 16-byte word, changed words in total }. */
+int dreg_guard_fill(void* base, const void* offsets_dev, int n, int band_bytes, void* stream);
+int dreg_guard_scan(const void* base, const void* offsets_dev, int n, int band_bytes, void* result_dev, void* stream);
 /* Bias gradients of many linear layers in two launches.  descs_dev: n records of 56 bytes { const bf16* g [M][C]; float* out [C];
  * float* partial (dreg_colsum_workspace_bytes(M, C), one per record); int M, C, rpc (dreg_colsum_rows_per_chunk(M)), nch = ceil(M / rpc),
  * pblock0 (sum of nch of the records before), fblock0 (sum of ceil(C / 4) before), accumulate, pad }; total_pblocks / total_fblocks = the
@@ -348,6 +377,37 @@ int dreg_colsum_rows(const void* g, const int* rows, int nrows, float* out, floa
  * The caller owns the arena (activations kept for backward, statistics, activation gradients, scratch) and the packed-weight
  * buffer; weight / bias / BatchNorm gradients are ACCUMULATED into the grad pointers.  One forward may be outstanding. */
 void* dreg_exec_create(const int* tensors, int nt, const int* ops, int nops, const int64_t* params, int np);
+/* Creation options of ONE executor (the library has no process-global switches: two handles with different options may run side by side).
+ * Every option only selects between forms that compute the same layer; "bit-identical" / "one rounding" as noted.  dreg_exec_default_opts fills the
+ * product defaults; dreg_exec_create == dreg_exec_create_opts(..., NULL). */
+typedef struct dreg_exec_opts {
+    int sparse_grads;     /* 1: the single-writer gradient buffers of the active-set head are kept zero by clearing rows (0: dense memset per step) */
+    int bn_batch_tails;   /* 1: the small BatchNorms' running-statistics / dgamma-dbeta launches batched per pass (bit-identical) */
+    int fuse_stem;        /* 1: the stem's BatchNorm + ReLU + max-pool in one pass */
+    int sparse_stem;      /* 1: ... and, behind a row-list stem, from the row lists (dreg_sparse_stem_fwd / _bwd); 0: the dense three-pass form (the per-op path's arithmetic) */
+    int fold_res_bn;      /* 1: a downsample branch's BatchNorm applied inside the BatchNorm that adds it (large path; bit-identical) */
+    int fold_splitk;      /* 1: split-K sums of the 8^3 / 4^3 convolutions folded into the one-launch BatchNorm next to them (bit-identical) */
+    int group_wgrad;      /* 1: weight-gradient partials of the 16^3 / 8^3 / 4^3 levels by one launch per tile shape per backward pass (bit-identical) */
+    int s2_accumulate;    /* 1: a stride-2 data gradient that is its input's second contribution adds in its own epilogue (one rounding instead of two) */
+    int fuse_bn_stats;    /* 1: statistics of the large BatchNorm layers from the producing convolution's epilogue (dreg_conv3d_igemm_bnstats) */
+    int brick;            /* mask: bit 0 (default) = active-set 3^3 launches with 64 output channels on csrc/conv_brick.hip, bit 1 = those with 256 as well; 0 = the per-op path's kernels */
+    int defer_head_pg;    /* 0 (default; measured no gain): 1 = the head's weight / bias gradient launches held back until the backward pass reaches the 8^3 / 4^3 levels */
+    int persistent_deep;  /* reserved (0) */
+    int guard;            /* debug: 1 = every region of the arena (each activation, statistic, gradient, row-list copy, scratch buffer) is followed by a 64 KiB
+                             poisoned guard band (dreg_exec_guard_check scans them); 2 = forward / backward additionally scan after EVERY op (stream
+                             synchronisation per op) and return DREG_EGUARD at the first op behind which a band has changed (dreg_exec_guard_last) */
+    int reserved[3];
+} dreg_exec_opts;
+void dreg_exec_default_opts(dreg_exec_opts* o);
+void* dreg_exec_create_opts(const int* tensors, int nt, const int* ops, int nops, const int64_t* params, int np, const dreg_exec_opts* opts);
+/* guard mode (opts.guard >= 1).  dreg_exec_guard_check: scan the bands of `arena` now (synchronises `stream`); out4 = { changed bands, first changed band,
+ * byte offset of its first changed word inside the band, changed 16-byte words }.  dreg_exec_guard_describe: the region in FRONT of band `band`
+ * ("act 17", "bn.aux0 op 5", ...) into buf.  dreg_exec_guard_last: the op index (negative: none) and band a guard = 2 pass stopped at, pass = 0 forward / 1 backward. */
+#define DREG_EGUARD (-3)
+int dreg_exec_guard_bands(void* h);
+int dreg_exec_guard_check(void* h, void* arena, long long* out4, void* stream);
+int dreg_exec_guard_describe(void* h, int band, char* buf, int buf_bytes);
+int dreg_exec_guard_last(void* h, int* op, int* pass, long long* band);
 void dreg_exec_destroy(void* h);
 size_t dreg_exec_arena_bytes(void* h);
 size_t dreg_exec_pack_bytes(void* h);
@@ -646,6 +706,7 @@ int dreg_ps_num_linears(void);
 void* dreg_ps_create(const int64_t* params);
 void dreg_ps_destroy(void* h);
 void dreg_ps_set_fuse(void* h, int fuse);
+void dreg_ps_set_group_wgrad(void* h, int on);   /* 1 (default, with fuse): the split partials of all linear layers' weight gradients by one launch per tile shape at the end of the backward pass (dreg_wgrad_group_launch); 0: one launch per layer.  Bit-identical.  Per handle. */
 void dreg_ps_set_timing(void* h, int enable);            /* HIP events around every linear-layer launch (forward, data gradient, weight gradient) */
 int dreg_ps_read_timings(void* h, int* info, float* ms, int cap);   /* after a device sync: 5 ints per record (kind, rows, cin, cout, flags) + ms; returns the count */
 size_t dreg_ps_arena_bytes(void* h, int R);

@@ -1,11 +1,12 @@
-/* Tuning / experiment switches of libdreg_nerf_hip.so — NOT part of the drop-in boundary (include/dreg_nerf.h).
+/* Kernel-variant switches of libdreg_nerf_hip_probe.so — the MEASUREMENT build of the library, NOT the product.
  *
- * These are process-global knobs used by the A/B tools under tools/ and by a few tests to force a kernel variant; the product path
- * (dreg_nerf_amd/, the entry points, bench.py's timed region) never calls a setter (it reads dreg_conv_get_glds), and every entry point of dreg_nerf.h gives the same
- * results whatever they are set to (variants differ in speed only, except the halo kernel's ablation variants >= 11, which are
- * timing experiments with wrong results and are reachable from tools/bench_conv_halo.py only). */
-#ifndef DREG_NERF_TUNING_H
-#define DREG_NERF_TUNING_H
+ * The product library (libdreg_nerf_hip.so, include/dreg_nerf.h) has no process-global mutable state: every knob below is a compile-time
+ * constant there (csrc/common.h DREG_KNOB) and none of these symbols exists in it.  The same sources compiled with -DDREG_PROBE give
+ * libdreg_nerf_hip_probe.so = every entry point of dreg_nerf.h + the process-global setters below.  It is loaded EXPLICITLY
+ * (dreg_nerf_amd.lib.probe()) by the A/B tools under tools/ and by the tests that force a kernel variant on a small shape; with every knob at
+ * its default it runs the product's code.  Variants differ in speed only, except those marked "wrong results" (timing ablations). */
+#ifndef DREG_NERF_PROBE_H
+#define DREG_NERF_PROBE_H
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -15,7 +16,6 @@ void dreg_conv3_halo_set_variant(int variant);
 void dreg_conv3_halo_set_prof(void* u64_buf_64x8x5);   /* variant 5: per-wave shader-clock breakdown of the first 64 workgroups */
 /* 1 (default): bf16 stride-1 convolutions stage operands with buffer_load...lds; 0: register-staged kernel (A/B checks) */
 void dreg_conv_set_glds(int enable);
-int dreg_conv_get_glds(void);
 /* tuning / test knob: force the number of voxel splits of the weight-gradient kernels (0 = automatic) */
 void dreg_conv_set_wgrad_splits(int splits);
 void dreg_conv_set_wgrad_rows_fast(int enable);      /* 1 (default): row-list weight gradients keep packed voxel coordinates in LDS (no decode per load) and take the 8-wave 256 x 256 tile for 256 -> 256 layers */
@@ -33,30 +33,12 @@ void dreg_conv_set_glds_stages(int stages);          /* LDS pipeline stages of t
 void dreg_conv_set_wgrad_target_blocks(int blocks);   /* workgroups the automatic split choice aims for (default 3072) */
 /* largest per-grid volume (voxels) whose BatchNorm runs the fused statistics+apply kernels (default 512 = the 8^3 level; 16^3 measured slower fused); 0 = never */
 void dreg_bn_set_small_max_voxels(int v);
-void dreg_exec_set_aux_streams(int n);                /* experiment: weight-gradient launches of the executor's backward rotate over n streams (default 1 = the one second stream) */
-void dreg_exec_set_sparse_grads(int on);              /* 1 (default): executors created from now on keep the single-writer gradient buffers of the active-set head zero by clearing rows */
-void dreg_exec_set_bn_batch_tails(int on);            /* 1 (default): executors created from now on batch the small BatchNorms' running-statistics / dgamma-dbeta launches per pass */
-void dreg_exec_set_fuse_stem(int on);                 /* 1 (default): executors created from now on fuse the stem's BatchNorm + ReLU + max-pool (fpn_ops.hip) */
-void dreg_exec_set_sparse_stem(int on);               /* 1 (default): executors created from now on run BatchNorm + ReLU + max-pool behind a row-list stem from the row lists (dreg_sparse_stem_fwd / _bwd); 0: the dense three-pass form (the per-op path's arithmetic) */
 void dreg_sstem_set_pool_blocks(int n);              /* measurement: workgroups of the sparse stem's pooling launch (default 8192 = one pooled granule per thread at 8 x 32^3 x 64) */
-void dreg_exec_set_s2_accumulate(int on);             /* 1 (default): a stride-2 data gradient that is its input's second gradient contribution adds in its own epilogue; 0: temporary + add pass (the per-op path's two roundings) */
-void dreg_exec_set_fold_res_bn(int on);               /* 1 (default): executors created from now on apply a downsample branch's BatchNorm inside the BatchNorm that adds it (large path; bit-identical) */
-void dreg_ps_set_group_wgrad(int on);                 /* 1 (default, with dreg_ps_set_fuse(1)): the point-set executor launches the split partials of all its linear layers' weight gradients once per tile shape at the end of the backward pass (dreg_wgrad_group_launch); 0: one launch per layer as its output gradient completes.  Bit-identical. */
-void dreg_exec_set_fold_splitk(int on);               /* 1 (default): executors created from now on let the one-launch BatchNorm of the 8^3 / 4^3 levels sum the split-K slices of the convolution in front of (forward) / behind (backward) it; bit-identical */
-void dreg_exec_set_group_wgrad(int on);               /* 1 (default): executors created from now on write the weight-gradient partials of the bias-free 16^3 / 8^3 / 4^3 convolutions (layer2-4) by one launch per tile shape per backward pass (whole-pass calls with a second stream; segmented passes and timed passes launch per layer); bit-identical */
-void dreg_exec_set_brick(int mask);                   /* active-set 3^3 convolutions whose row list comes with tile tables run on csrc/conv_brick.hip: bit 0 (default) = launches with 64 output channels (the data gradient of pyramid_transformation_1: 309 vs 455 us), bit 1 = those with 256 as well (measured slower than the row-list implicit GEMM: tools/bench_conv_brick.py); 0: never (bit-identical to the per-op path) */
-void dreg_exec_set_defer_head_pg(int on);             /* experiment, default 0 — measured no gain (18.50 vs 18.51 ms per step, tools/ab_step.py): 1 = the weight / bias gradient launches of the 64^3 / 32^3 layers the backward pass meets first (the FPN head) are held back until it reaches the 8^3 / 4^3 levels: there the launch-latency-bound main chain leaves the CUs to them, while next to the head's own throughput-bound data gradients they only slowed both down */
 void dreg_voxel_set_own_sort(int on);                 /* experiment, default 0: 1 = the voxel keys of a downsample round (<= 131,072) are built, sorted (stable 4-bit LSD radix sort, ballot ranks) and segmented by ONE launch of one workgroup instead of rocPRIM radix_sort_pairs + inclusive_scan + three small kernels; identical results, but 0.45-1.45 ms per round on its single CU against ~0.07 ms (so the product path keeps rocPRIM) */
-void dreg_exec_set_fuse_bn_stats(int on);            /* 1 (default): executors created from now on take the statistics of the large BatchNorm layers from the producing convolution's epilogue (dreg_conv3d_igemm_bnstats) */
 void dreg_conv_set_bn_stats_epilogue(int on);        /* 0: dreg_conv3d_igemm_bnstats never emits sums (callers fall back to the BatchNorm's own statistics pass) */
 void dreg_bn_set_store_g(int enable);                /* 1 (default): the backward of a residual + ReLU BatchNorm stores the masked gradient (= the residual gradient) in its statistics pass; the apply pass reads it instead of dy and y */
 void dreg_bn_set_small_regs(int enable);             /* 1 (default): the one-launch BatchNorms of the 8^3 / 4^3 volumes load their rows once and keep them in registers between statistics and apply */
 void dreg_bn_set_debug_skip(int mask);                /* MEASUREMENT ONLY (wrong results): bit 0 / 1 leave out the forward / backward statistics pass of the large BatchNorms */
-/* which bf16 weight-gradient kernel a launch of this shape runs: BM * 1000 + BNC (256256 = the 8-wave tile, 256128 = 4 waves / 32-voxel stages); for profiler labels */
-/* which kernel a convolution launch of this shape runs: kind * 1e8 + BM * 1e5 + BN * 100 + AP * 10 + splitK (kind 0 conv_igemm_glds_kernel, 1 conv_igemm_kernel; < 0 unsupported); nrows 0 = dense */
-int dreg_conv3d_igemm_variant(int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksz, int stride, int pad,
-                              int transposed, int nrows, int has_ws, int has_addend, int dtype);
-int dreg_conv3d_wgrad_variant(int B, int Do, int Ho, int Wo, int Cin, int Cout, int ksz, int rows, int nrows, int occ);
 void dreg_ngp_set_rgb_chunks(int on);                 /* 1 (default): shared-direction colour queries run the persistent 16-point-chunk kernel; 0: the 64-point-per-wave kernel */
 void dreg_ngp_set_density_unroll(int n);             /* hash-grid levels of the density kernel whose 8 corner gathers are issued together: 1, 2, 4 or 8 */
 void dreg_ngp_set_xcd_levels(int on);                /* 1 (default): dreg_ngp_density_fwd_ws encodes with XCD-resident level pairs (two launches); 0: the fused kernel */

@@ -12,28 +12,51 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
-    syms = set()
-    inc = os.path.join(ROOT, "include")
-    for f in os.listdir(inc):
-        if f.endswith(".h"):
-            txt = open(os.path.join(inc, f)).read()
-            txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-            syms |= set(re.findall(r"\b(dreg_\w+)\s*\(", txt))
-    return syms
+def _header_symbols(name):
+    txt = open(os.path.join(ROOT, "include", name)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return set(re.findall(r"\b(dreg_\w+)\s*\(", txt))
+
+
+def _exports(path):
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return {l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("dreg_")}
 
 
 def test_library_exports_every_declared_symbol():
     from dreg_nerf_amd import build, lib
-    if not os.path.exists(lib.LIB_PATH):
+    if not os.path.exists(lib.LIB_PATH) or not os.path.exists(lib.PROBE_LIB_PATH):
         build.build(verbose=False)
-    cdll = ctypes.CDLL(lib.LIB_PATH)
-    syms = _header_symbols()
-    assert len(syms) >= 15
-    for s in syms:
-        assert hasattr(cdll, s), f"{s} declared in include/ but not exported"
-    # the python binding covers the same set
+    syms = _header_symbols("dreg_nerf.h")
+    assert len(syms) >= 150
+    # the product library exports exactly what include/dreg_nerf.h declares, and the python binding covers the same set
+    assert _exports(lib.LIB_PATH) == syms
     assert set(lib.declared_symbols()) == syms
+    # the measurement build: the same + include/dreg_nerf_probe.h
+    psyms = _header_symbols("dreg_nerf_probe.h")
+    assert _exports(lib.PROBE_LIB_PATH) == syms | psyms
+    assert set(lib.probe_symbols()) == psyms
+
+
+def test_product_library_has_no_process_global_switches():
+    """a re-entrant library.  Nothing the product .so exports sets process-wide state: every remaining *_set_* takes the handle it
+    configures as its first argument (dreg_exec_* / dreg_ps_*), and no symbol of include/dreg_nerf_probe.h (the kernel-variant knobs, the
+    "wrong results" timing ablations) exists in it."""
+    from dreg_nerf_amd import lib
+    exp = _exports(lib.LIB_PATH)
+    setters = {s for s in exp if "_set_" in s or "probe" in s}
+    assert setters == {"dreg_exec_set_overlap", "dreg_exec_set_input_row_occupancy", "dreg_exec_set_timing", "dreg_ps_set_fuse", "dreg_ps_set_group_wgrad",
+                       "dreg_ps_set_timing"}, setters
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dreg_nerf.h")).read(), flags=re.S)
+    for s in setters:
+        assert re.search(r"\b%s\s*\(\s*void\s*\*\s*h\b" % s, txt), f"{s} is not handle-scoped"
+    assert not (exp & _header_symbols("dreg_nerf_probe.h"))
+    # no writable data symbol of the library's own either (device-side globals live in the code objects, not in the host image)
+    import subprocess
+    out = subprocess.check_output(["nm", "--defined-only", lib.LIB_PATH], text=True)
+    writable = [l for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] in "dDbB" and re.search(r"\bg_[a-z]", l.split()[2])]
+    assert not writable, writable
 
 
 def test_device_code_has_no_packed_fp32_instructions():
@@ -74,7 +97,12 @@ def _ddp_worker(rank, world, port, q):
         if not (rank == 1 and i == 2):  # one rank contributes no gradient for a parameter: it stays zero there
             p.grad.add_(float(rank + 1) * (i + 1))
     opt.all_reduce_mean(world, bucket_elems=256)
-    q.put((rank, [p.grad.tolist() for p in ps]))
+    # the self-check bench.py's multi-rank line carries (optim.ranks_in_sync): identical parameters + the same gradient norm on every rank ...
+    from dreg_nerf_amd.optim import ranks_in_sync
+    ok = ranks_in_sync(opt, opt.flat_g.norm().reshape(1))
+    opt.flat_p[301 + rank] += 1e-3 * rank                       # ... and a rank that has drifted by one parameter is seen by every rank
+    bad = ranks_in_sync(opt, opt.flat_g.norm().reshape(1))
+    q.put((rank, [p.grad.tolist() for p in ps], ok, bad))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -86,10 +114,14 @@ def test_grad_buckets_gloo_world2():
     procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in range(2))
+    got = [q.get(timeout=120) for _ in range(2)]
+    res = {g[0]: g[1] for g in got}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    for _, _, ok, bad in got:
+        assert ok["ranks_in_sync"] is True and ok["ranks"] == 2 and ok["param_checksum_spread"] == 0.0 and ok["grad_norm_spread"] == 0.0
+        assert bad["ranks_in_sync"] is False and bad["param_checksum_spread"] > 0
     for i in range(4):
         exp = (1.0 * (i + 1) + (0.0 if i == 2 else 2.0 * (i + 1))) / 2
         for r in range(2):

@@ -13,7 +13,11 @@ DEV = "cuda:0"
 
 
 def _halo(x, w, bias=None, addend=None, add_same=False, transposed=False, out_f32=False, variant=0):
-    """x [B,D,H,W,Cin] bf16, w fp32 [Cout,Cin,3,3,3] -> [B,D,H,W,256]"""
+    """x [B,D,H,W,Cin] bf16, w fp32 [Cout,Cin,3,3,3] -> [B,D,H,W,256]; variant != 0: that loop form of the measurement build (include/dreg_nerf_probe.h)"""
+    if variant:
+        with L.probe() as pr:
+            pr.set("dreg_conv3_halo_set_variant", variant, 0)
+            return _halo(x, w, bias, addend, add_same, transposed, out_f32, 0)
     lib = L.load()
     B, D, H, W, Cin = x.shape
     cout, cin = w.shape[0], w.shape[1]
@@ -23,10 +27,8 @@ def _halo(x, w, bias=None, addend=None, add_same=False, transposed=False, out_f3
     L.check(lib.dreg_pack_conv_weight_halo(L.ptr(w.contiguous()), L.ptr(pk), cout, cin, int(transposed), L.stream()), "pack_halo")
     out = torch.empty(B, D, H, W, 256, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     da, ha, wa = (addend.shape[1:4] if addend is not None else (0, 0, 0))
-    lib.dreg_conv3_halo_set_variant(variant)
     L.check(lib.dreg_conv3_halo(L.ptr(x), L.ptr(pk), L.ptr(out), L.ptr(bias), L.ptr(addend), B, D, H, W, red, da, ha, wa, int(add_same),
                                 int(out_f32), L.stream()), "dreg_conv3_halo")
-    lib.dreg_conv3_halo_set_variant(0)
     return out
 
 

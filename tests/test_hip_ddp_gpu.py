@@ -141,6 +141,10 @@ def test_bench_script_runs_with_two_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] - 2 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # whole-job pairs/s = ranks x pairs / step time
+    # the run validates itself: same parameters and same clipped gradient norm on both ranks after the timed steps (bench.py exits non-zero otherwise)
+    rs = d["rank_sync"]
+    assert d["ranks_in_sync"] is True and rs["ranks"] == 2 and rs["param_checksum_spread"] == 0.0 and rs["grad_norm_spread"] == 0.0 and rs["grad_norm"] > 0
+    assert d["allreduce_buckets"] > 1 and d["allreduce_exposed_ms_per_step"] >= 0.0
 
 
 def test_bench_script_spawns_its_own_ranks():
@@ -186,6 +190,7 @@ def test_two_rccl_ranks_on_two_gpus_equal_one_rank_on_the_concatenated_batch():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    assert d["ranks_in_sync"] is True and d["rank_sync"]["ranks"] == 2 and d["rank_sync"]["param_checksum_spread"] == 0.0
     # and the gradients: two RCCL ranks with one pair each == one rank with both pairs (the gloo form of this check is
     # test_two_ranks_average_equals_one_rank_with_both_pairs; here the collective is RCCL's ReduceOp.AVG over xGMI / PCIe)
     import tempfile

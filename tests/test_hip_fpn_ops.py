@@ -180,7 +180,7 @@ def test_deferred_row_list_weight_gradient_sums_only_the_written_slices(cin, cou
     (2, 32, 128, 128, 3, 2, True),         # stride 2 (the first 3^3 convolution of layer2)
     (8, 8, 256, 256, 3, 1, False),         # split-K launch: no sums, the caller runs the ordinary BatchNorm
 ])
-def test_convolution_epilogue_leaves_the_batchnorm_sums(B, D, cin, cout, k, stride, emits):
+def test_convolution_epilogue_leaves_the_batchnorm_sums(B, D, cin, cout, k, stride, emits, probe_lib):
     """dreg_conv3d_igemm_bnstats: the convolution's output is the plain launch's, bit for bit, and the chunk sums it leaves are the
     sums / sums of squares of the STORED bf16 values per (grid, chunk, channel); dreg_bn3d_fwd_from_sums on them equals the
     three-pass BatchNorm up to the summation order of the statistics."""
@@ -257,8 +257,8 @@ def test_convolution_epilogue_leaves_the_batchnorm_sums(B, D, cin, cout, k, stri
 
 
 @pytest.mark.parametrize("out_f32", [False, True])
-def test_narrow_tiles_for_small_launches_are_bit_identical(out_f32):
-    """Launches with fewer 128 x 128 tiles than CUs run 128 x 64 tiles (include/dreg_nerf_tuning.h: dreg_conv_set_narrow_small): every
+def test_narrow_tiles_for_small_launches_are_bit_identical(out_f32, probe_lib):
+    """Launches with fewer 128 x 128 tiles than CUs run 128 x 64 tiles (include/dreg_nerf_probe.h: dreg_conv_set_narrow_small): every
     output element is the same K-ordered MFMA accumulation, so which tile shape a batch size lands on cannot change a result."""
     from dreg_nerf_amd import lib as L
     dev = _dev()
@@ -335,8 +335,8 @@ def test_fused_stem_bn_relu_maxpool_matches_the_unfused_pair(shape):
     assert d <= 2e-2 * a["dx"].float().abs().max().item(), d
 
 
-def test_large_layer_weight_gradient_tiles_are_bit_identical():
-    """The 256-row weight-gradient tiles of large dense layers (include/dreg_nerf_tuning.h: dreg_conv_set_wgrad_big — 1: 4 waves on
+def test_large_layer_weight_gradient_tiles_are_bit_identical(probe_lib):
+    """The 256-row weight-gradient tiles of large dense layers (include/dreg_nerf_probe.h: dreg_conv_set_wgrad_big — 1: 4 waves on
     256 x 128 with 32-voxel stages; 3: 8 waves on 256 x 256, the default) against the 128 x 128 tile: the same per-element accumulation
     order, so the same bits."""
     from dreg_nerf_amd import lib as L
@@ -391,7 +391,7 @@ def test_large_layer_weight_gradient_tiles_are_bit_identical():
 
 
 @pytest.mark.parametrize("cin,cout,D", [(256, 256, 48), (64, 256, 32), (128, 128, 16)])
-def test_row_list_weight_gradient_fast_path_is_bit_identical(cin, cout, D):
+def test_row_list_weight_gradient_fast_path_is_bit_identical(cin, cout, D, probe_lib):
     """Row-list weight gradient with (row, packed z|y|x) pairs in LDS read once per stage — and, for 256 -> 256 layers with >= 65,536
     rows, the 8-wave 256 x 256 tile — against the loop that decodes the voxel per load: same products in the same order."""
     from dreg_nerf_amd import lib as L
@@ -544,7 +544,7 @@ def test_batchnorm_train_fwd_bwd(shape, dtype, with_res):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_batchnorm_backward_with_the_masked_gradient_stored_once_is_bit_identical(dtype):
+def test_batchnorm_backward_with_the_masked_gradient_stored_once_is_bit_identical(dtype, probe_lib):
     """Residual + ReLU BatchNorm, three-kernel form (dreg_bn_set_store_g): the statistics pass stores g = dy * (y > 0) as the residual
     branch's gradient and the apply pass reads it back, against both passes reading dy and y."""
     from dreg_nerf_amd import lib as L
@@ -575,7 +575,7 @@ def test_batchnorm_backward_with_the_masked_gradient_stored_once_is_bit_identica
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("with_res", [True, False])
 @pytest.mark.parametrize("D,C", [(8, 256), (4, 512)])
-def test_small_batchnorm_with_rows_in_registers_is_bit_identical(D, C, with_res, dtype):
+def test_small_batchnorm_with_rows_in_registers_is_bit_identical(D, C, with_res, dtype, probe_lib):
     """8^3 / 4^3 volumes (dreg_bn_set_small_regs): rows loaded once and kept in registers between the statistics and the apply phase
     against the form that walks them twice — forward output, running statistics and every gradient."""
     from dreg_nerf_amd import lib as L
@@ -684,7 +684,7 @@ def test_trilinear_gather_backward_on_active_set_is_exact_and_deterministic(res,
 
 
 @pytest.mark.parametrize("mode", [3, 4])
-def test_conv_glds_large_tiles_match_default(mode):
+def test_conv_glds_large_tiles_match_default(mode, probe_lib):
     """128x256 and 256x256 tile variants of the direct-to-LDS kernel == the 128x128 tile, bit for bit."""
     from dreg_nerf_amd import lib as L
     dev = _dev()

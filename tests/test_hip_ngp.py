@@ -224,7 +224,7 @@ def test_fused_dense_query_equals_the_nonzero_form_bit_for_bit(shape, fill):
 
 
 @pytest.mark.parametrize("unbounded", [False, True])
-def test_density_query_forms_agree_bit_for_bit(unbounded):
+def test_density_query_forms_agree_bit_for_bit(unbounded, probe_lib):
     """The density query of a block's size has three forms (csrc/ngp.hip): the fused kernel, hash-grid levels pinned to the XCDs' L2s
     (two launches through a workspace), and either with an ORDER that lets a wave's lanes run along the tables' fastest axis.  Same
     arithmetic per point in each: identical density / raw; the order is what dreg_grid_x_order builds from the occupancy volume."""

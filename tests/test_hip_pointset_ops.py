@@ -254,7 +254,7 @@ def test_adamw_and_grad_norm_match_torch():
 
 
 @pytest.mark.parametrize("n,nbatch", [(7, 1), (1023, 2), (1025, 2), (38352, 2), (70001, 3), (131072, 2)])
-def test_own_sort_and_segments_equal_the_rocprim_form_bit_for_bit(n, nbatch):
+def test_own_sort_and_segments_equal_the_rocprim_form_bit_for_bit(n, nbatch, probe_lib):
     """One launch (keys + stable 4-bit LSD radix sort + heads + scan + starts + batch counts in one workgroup: voxel_sort_segments_kernel)
     against rocPRIM's radix_sort_pairs + inclusive_scan with the small kernels around them: every output of the plan identical — the
     averaged points, their order, the segment table, the per-batch counts, the inverse maps."""

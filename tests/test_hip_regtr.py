@@ -97,13 +97,14 @@ def test_e2e_eval32_bf16_close_to_fp32(golden_dir):
 
 def _head_modes(dense_kernel):
     """(key-point predictions, pose, gradients) of the dense and the active-set head on one pair; dense_kernel: 'igemm' forces the
-    implicit-GEMM kernel on the dense path (include/dreg_nerf_tuning.h), 'halo' is the product default."""
+    implicit-GEMM kernel on the dense path (the measurement build: include/dreg_nerf_probe.h), 'halo' is the product default."""
     from dreg_nerf_amd import lib as L
     data = synth.shell_pair(64, 1, 2, pose=synth.fixed_pose())
     res = {}
-    lib = L.load()
-    lib.dreg_conv3_halo_set_variant(-1 if dense_kernel == "igemm" else 0)
-    try:
+    import contextlib
+    with (L.probe() if dense_kernel == "igemm" else contextlib.nullcontext()) as pr:
+        if pr is not None:
+            pr.set("dreg_conv3_halo_set_variant", -1, 0)
         for mode in (False, True):
             m = _model("bf16", True)
             m.active_set = mode
@@ -117,8 +118,6 @@ def _head_modes(dense_kernel):
                                                                   "fpn3d.feature_pyramid.pyramid_transformation_1.bias",
                                                                   "fpn3d.backbone_net.conv1.weight",
                                                                   "fpn3d.backbone_net.layer2.0.conv2.weight")})
-    finally:
-        lib.dreg_conv3_halo_set_variant(0)
     return res
 
 

@@ -135,9 +135,11 @@ def test_training_forward_against_torch(case):
     # pooled values against torch's max_pool3d of the activation computed with the kernel's own scale / shift
     sc, sh = s["ss"][..., 0], s["ss"][..., 1]
     a = torch.relu(c["x"].float().view(B, V, C) * sc[:, None] + sh[:, None]).bfloat16().float()
-    a5 = a.view(B, c["D"], c["H"], c["W"], C).permute(0, 4, 1, 2, 3).contiguous().cpu()      # (the reference pooling on the host: a few MB)
+    # (the reference pooling on the GPU again: round 4 moved it to the host after ONE full-suite run aborted at the torch.equal below; round 5 put every
+    #  buffer the sstem_* kernels write between poisoned guard bands — tools/guard_sweep.py, profiles/r05_guard_sweep.txt — and found no stray write)
+    a5 = a.view(B, c["D"], c["H"], c["W"], C).permute(0, 4, 1, 2, 3).contiguous()
     ref = torch.nn.functional.max_pool3d(a5, 3, 2, 1).permute(0, 2, 3, 4, 1).reshape(-1, C)
-    assert torch.equal(ref.bfloat16().view(torch.int16), s["pooled"].cpu().view(torch.int16))
+    assert torch.equal(ref.bfloat16().view(torch.int16), s["pooled"].view(torch.int16))
     _check_act_and_xam(c, s)
 
 
@@ -195,9 +197,8 @@ def _batch(res, n_pairs=2):
 
 
 def _step(sparse_stem, res=64):
-    lib = L.load()
-    lib.dreg_exec_set_sparse_stem(int(sparse_stem))
-    try:
+    from dreg_nerf_amd.trunk_exec import exec_opts
+    with exec_opts(sparse_stem=int(sparse_stem)):
         torch.manual_seed(3407)
         m = NeRFRegTr(precision="bf16")
         m.load_state_dict(params.synth_state_dict(0, profile="wc"), strict=True)
@@ -205,8 +206,6 @@ def _step(sparse_stem, res=64):
         ts = TrainStep(m)
         out = ts.step(_batch(res))
         torch.cuda.synchronize()
-    finally:
-        lib.dreg_exec_set_sparse_stem(1)
     g = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
     bufs = {n: b.detach().clone() for n, b in m.named_buffers() if "bn1.running" in n and "layer" not in n}
     return {k: float(v) for k, v in out["losses"].items()}, float(out["grad_norm"]), g, bufs

@@ -68,14 +68,12 @@ def test_training_step_with_the_stem_on_its_row_list(native):
     """The same step with the dense stem and with the stem on its row list (through the native executor and through the per-op path):
     identical losses (the forward pass is bit-identical), the stem's weight gradient equal to summation order, every other gradient
     within the bf16 noise that difference causes downstream of nothing (they are upstream of the stem: identical).  (The executor's
-    BatchNorm / pool behind the row-list stem in its dense form, dreg_exec_set_sparse_stem(0): the list form sums the statistics in another
+    BatchNorm / pool behind the row-list stem in its dense form, creation option sparse_stem = 0: the list form sums the statistics in another
     order — tests/test_hip_sparse_stem.py.)"""
-    L.load().dreg_exec_set_sparse_stem(0)
-    try:
+    from dreg_nerf_amd.trunk_exec import exec_opts
+    with exec_opts(sparse_stem=0):
         la, na, ga, _ = _step(False, native)
         lb, nb, gb, m = _step(True, native)
-    finally:
-        L.load().dreg_exec_set_sparse_stem(1)
     assert la == lb
     w = "fpn3d.backbone_net.conv1.weight"
     rel = float((ga[w] - gb[w]).norm() / ga[w].norm())
@@ -87,17 +85,12 @@ def test_training_step_with_the_stem_on_its_row_list(native):
 
 
 def test_executor_and_per_op_path_forward_agree_bit_for_bit_with_stem_rows():
-    """With every BatchNorm's statistics from its own statistics pass (dreg_exec_set_fuse_bn_stats(0): the per-op path's arithmetic) the
+    """With every BatchNorm's statistics from its own statistics pass (creation option fuse_bn_stats = 0: the per-op path's arithmetic) the
     native executor's forward pass equals the per-op path's bit for bit — also with the stem on its row list in both."""
-    lib = L.load()
-    lib.dreg_exec_set_fuse_bn_stats(0)
-    lib.dreg_exec_set_sparse_stem(0)
-    try:
+    from dreg_nerf_amd.trunk_exec import exec_opts
+    with exec_opts(fuse_bn_stats=0, sparse_stem=0):
         la, na, ga, _ = _step(True, True)
         lb, nb, gb, _ = _step(True, False)
-    finally:
-        lib.dreg_exec_set_fuse_bn_stats(1)
-        lib.dreg_exec_set_sparse_stem(1)
     assert la == lb
     w = "fpn3d.backbone_net.conv1.weight"
     assert float((ga[w] - gb[w]).norm() / ga[w].norm()) < 2e-2

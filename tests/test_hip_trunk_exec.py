@@ -35,12 +35,9 @@ def test_executor_matches_per_op_path(sparse, fused_stats):
     """fused_stats = 0: the executor takes every BatchNorm's statistics from the layer's own statistics pass, like the per-op path:
     bit-identical forward.  1 (default): from the producing convolution's epilogue (per-tile instead of per-chunk partial sums: the
     means differ in their last bits, and 53 BatchNorm layers at a random initialisation amplify that)."""
-    from dreg_nerf_amd import lib as L
-    L.load().dreg_exec_set_fuse_bn_stats(fused_stats)
-    try:
+    from dreg_nerf_amd.trunk_exec import exec_opts
+    with exec_opts(fuse_bn_stats=fused_stats):
         _executor_vs_per_op(sparse, bool(fused_stats))
-    finally:
-        L.load().dreg_exec_set_fuse_bn_stats(1)
 
 
 def _executor_vs_per_op(sparse, fused_stats):
@@ -186,10 +183,10 @@ def test_segmented_backward_reports_gradient_buckets_in_order_and_changes_nothin
             from dreg_nerf_amd import trunk_exec
             orig = trunk_exec.TrunkExecutor.backward
 
-            def spy(self, x, rows, g):
+            def spy(self, x, rows, g, generation=None):
                 plan = self._sync_plan(ops.GRAD_SYNC)
                 log.append(("plan", len(plan["cuts"]), plan["above"]))
-                return orig(self, x, rows, g)
+                return orig(self, x, rows, g, generation)
             trunk_exec.TrunkExecutor.backward = spy
             try:
                 ts.step([data])
@@ -217,14 +214,13 @@ def test_row_cleared_gradient_buffers_equal_memset_ones_over_changing_active_set
     """The dense gradient buffers in front of the active-set convolutions (dP1 from the trilinear gather, the lateral sums inside the
     executor) are kept zero across steps by clearing the rows the last step wrote instead of a dense memset per step.  Three optimizer
     steps over pairs whose active sets grow and shrink end in bit-identical parameters with the feature on and off."""
-    from dreg_nerf_amd import lib as L, synth
+    from dreg_nerf_amd import synth
     from dreg_nerf_amd.train_step import TrainStep
-    lib = L.load()
+    from dreg_nerf_amd.trunk_exec import exec_opts
     dev = torch.device("cuda")
 
     def run(sparse: bool):
-        lib.dreg_exec_set_sparse_grads(int(sparse))
-        try:
+        with exec_opts(sparse_grads=int(sparse)):
             torch.manual_seed(7)
             m = NeRFRegTr(precision="bf16").to(dev).train()
             ts = TrainStep(m)
@@ -242,8 +238,6 @@ def test_row_cleared_gradient_buffers_equal_memset_ones_over_changing_active_set
                 ts.step(batch)
             torch.cuda.synchronize()
             return {k: v.detach().clone() for k, v in m.state_dict().items()}
-        finally:
-            lib.dreg_exec_set_sparse_grads(1)
 
     a, b = run(True), run(False)
     for k in a:
@@ -253,8 +247,7 @@ def test_row_cleared_gradient_buffers_equal_memset_ones_over_changing_active_set
 def test_batched_batchnorm_tails_change_nothing():
     """The running-statistics / dgamma-dbeta launches of the small BatchNorms batched per pass (one launch each) against one launch
     per layer: same arithmetic per channel, so gradients and running statistics are bit-identical."""
-    from dreg_nerf_amd import lib as L
-    lib = L.load()
+    from dreg_nerf_amd import trunk_exec
     m, opt = _model(2)
     res = 64
     grids, _ = _grids(res, 2)
@@ -264,8 +257,8 @@ def test_batched_batchnorm_tails_change_nothing():
     got = []
     try:
         for batched in (0, 1):
-            lib.dreg_exec_set_bn_batch_tails(batched)
-            m.__dict__.pop("_trunk_cache", None)       # read when an executor is created
+            trunk_exec.OPTS["bn_batch_tails"] = batched
+            m.__dict__.pop("_trunk_cache", None)       # a creation option of the executor
             m.load_state_dict(sd0)
             ops.bump_weight_generation()
             m.native_trunk = True
@@ -278,7 +271,7 @@ def test_batched_batchnorm_tails_change_nothing():
                 p1.backward(go)
             got.append((opt.flat_g.clone(), {k: v.clone() for k, v in m.state_dict().items() if "running" in k}))
     finally:
-        lib.dreg_exec_set_bn_batch_tails(1)
+        trunk_exec.OPTS.pop("bn_batch_tails", None)
         m.__dict__.pop("_trunk_cache", None)
     assert torch.isfinite(got[1][0]).all() and got[1][0].abs().sum() > 0
     assert torch.equal(got[0][0], got[1][0])
@@ -286,15 +279,21 @@ def test_batched_batchnorm_tails_change_nothing():
         assert torch.equal(got[0][1][k], got[1][1][k]), k
 
 
-@pytest.mark.parametrize("setter", ["dreg_ps_set_group_wgrad", "dreg_exec_set_group_wgrad", "dreg_exec_set_fold_splitk", "dreg_exec_set_fold_res_bn"])
-def test_bit_identical_round4_switches(setter):
+@pytest.mark.parametrize("option", ["ps_group_wgrad", "group_wgrad", "fold_splitk", "fold_res_bn"])
+def test_bit_identical_round4_switches(option):
     """The round-4 restructurings that claim bit-identity — the point-set half's weight gradients as one launch per tile shape, the split-K sums
     of the 8^3 / 4^3 convolutions inside the BatchNorm launch next to them, the downsample branch's BatchNorm applied inside the BatchNorm that
     adds it — switched off and on: the same optimizer step, every gradient and the losses bit for bit."""
-    from dreg_nerf_amd import lib as L, params, synth
+    from dreg_nerf_amd import params, pointset_exec, synth, trunk_exec
     from dreg_nerf_amd.train_step import TrainStep
-    lib = L.load()
-    fn = getattr(lib, setter)
+
+    def fn(v):      # per-handle options of the two executors (the library has no process-global switches)
+        if option == "ps_group_wgrad":
+            pointset_exec.GROUP_WGRAD = bool(v)
+        elif v:
+            trunk_exec.OPTS.pop(option, None)
+        else:
+            trunk_exec.OPTS[option] = 0
     res = []
     try:
         for v in (0, 1):

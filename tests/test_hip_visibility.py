@@ -120,7 +120,7 @@ def test_persistent_ray_queue_gives_the_lock_step_labels(wscale):
         assert torch.equal(v, ref), k
 
 
-def test_pass_bound_of_the_persistent_kernel_is_reported():
+def test_pass_bound_of_the_persistent_kernel_is_reported(probe_lib):
     """A persistent launch that leaves its march loop through the safety bound (never on a real extraction; forced here with a bound of
     two passes) must not leave points silently unlabelled: bit 63 of its ray counter is set and the next look at it raises."""
     from dreg_nerf_amd import lib as L

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dreg_nerf_amd import ngp, lib as L
 dev = torch.device("cuda", 0)
-lib = L.load()
+lib = L.use_probe()
 res, aabb = 128, [-1.5] * 3 + [1.5] * 3
 g = torch.Generator().manual_seed(100)
 f = ngp.NGPradianceField(aabb)

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dreg_nerf_amd import lib as L, ops
 
 dev = "cuda:0"
-lib = L.load()
+lib = L.use_probe()
 for (V3, C) in ((16, 128), (16, 512), (8, 256), (8, 1024), (4, 512), (4, 2048), (32, 64), (32, 256)):
     B = 8
     x = torch.randn(B, V3, V3, V3, C, device=dev).to(torch.bfloat16).requires_grad_(True)

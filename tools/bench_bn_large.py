@@ -4,7 +4,7 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dreg_nerf_amd import lib as L
-dev = torch.device("cuda:0"); lib = L.load()
+dev = torch.device("cuda:0"); lib = L.use_probe()
 def timeit(fn, n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()

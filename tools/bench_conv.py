@@ -6,7 +6,7 @@ from dreg_nerf_amd import ops, lib as L
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = "cuda"
-lib = L.load()
+lib = L.use_probe()
 
 def timeit(fn, n=5):
     fn(); torch.cuda.synchronize()

@@ -13,7 +13,7 @@ def main():
     pos = [a for a in sys.argv[1:] if not a.startswith("--")]
     B, R, cin = (int(a) for a in (pos + ["8", "64", "256"][len(pos):]))
     dev = "cuda:0"
-    lib = L.load()
+    lib = L.use_probe()
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, R, R, R, cin, generator=g).to(dev).to(torch.bfloat16)
     w = (torch.randn(256, cin, 3, 3, 3, generator=g) * 0.017).to(dev)

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dreg_nerf_amd import ops, lib as L
 dev = "cuda"
-lib = L.load()
+lib = L.use_probe()
 shapes = [("8^3 x 8  256 -> 256 k3", 8, 8, 256, 256, 3), ("8^3 x 8  1024 -> 256 k1", 8, 8, 1024, 256, 1), ("8^3 x 8  256 -> 1024 k1", 8, 8, 256, 1024, 1),
           ("4^3 x 8  512 -> 512 k3", 8, 4, 512, 512, 3), ("4^3 x 8  2048 -> 512 k1", 8, 4, 2048, 512, 1),
           ("16^3 x 8  128 -> 128 k3", 8, 16, 128, 128, 3), ("16^3 x 8  512 -> 128 k1", 8, 16, 512, 128, 1), ("16^3 x 8  128 -> 512 k1", 8, 16, 128, 512, 1),

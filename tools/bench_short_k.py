@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dreg_nerf_amd import ops, lib as L
 dev = "cuda"
-lib = L.load()
+lib = L.use_probe()
 shapes = [("linear 9752 x 256 -> 768", 9752, 1, 256, 768), ("linear 9752 x 256 -> 256", 9752, 1, 256, 256), ("linear 9752 x 256 -> 1024", 9752, 1, 256, 1024),
           ("linear 9752 x 1024 -> 256", 9752, 1, 1024, 256), ("8^3 x 8 1024 -> 256", 8, 8, 1024, 256), ("8^3 x 8 256 -> 1024", 8, 8, 256, 1024),
           ("16^3 x 8 512 -> 128", 8, 16, 512, 128), ("16^3 x 8 128 -> 512", 8, 16, 128, 512), ("4^3 x 8 2048 -> 512", 8, 4, 2048, 512)]

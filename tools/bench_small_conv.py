@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dreg_nerf_amd import ops, lib as L
 dev = "cuda"
-lib = L.load()
+lib = L.use_probe()
 def timeit(fn, n=20):
     fn(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -4,7 +4,7 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dreg_nerf_amd import lib as L
-lib = L.load()
+lib = L.use_probe()
 dev = torch.device("cuda", 0)
 B, D, C = 8, 64, 64
 V, Do = D ** 3, 32

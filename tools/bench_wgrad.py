@@ -7,7 +7,7 @@ from dreg_nerf_amd import ops, lib as L
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = "cuda"
-lib = L.load()
+lib = L.use_probe()
 for (D, cin, cout) in ((64, 256, 256), (32, 256, 256), (64, 64, 256)):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, D, D, D, cin, generator=g).to(dev).bfloat16()

@@ -3,7 +3,7 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dreg_nerf_amd import ops, lib as L
-lib = L.load(); dev = "cuda"
+lib = L.use_probe(); dev = "cuda"
 B, D, cin, cout = 8, 64, 256, 256
 g = torch.Generator().manual_seed(0)
 x = torch.randn(B, D, D, D, cin, generator=g).to(dev).bfloat16(); gy = torch.randn(B, D, D, D, cout, generator=g).to(dev).bfloat16()

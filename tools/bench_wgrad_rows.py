@@ -10,7 +10,7 @@ from dreg_nerf_amd import lib as L, synth
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = "cuda"
-lib = L.load()
+lib = L.use_probe()
 
 
 def shell_rows(D, r0, r1):

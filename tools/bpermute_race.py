@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dreg_nerf_amd import ops, lib as L
 dev = torch.device("cuda", 0)
-lib = L.load()
+lib = L.use_probe()
 g0 = torch.Generator().manual_seed(1)
 side = torch.cuda.Stream()
 R = 1920

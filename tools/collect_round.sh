@@ -18,6 +18,6 @@ timeout 300 python tools/repack_bubble.py > gpurun_out/round/repack_bubble.txt 2
 timeout 300 python tools/phase_times.py --nosync > gpurun_out/round/phase_times_steady_state.txt 2>&1
 timeout 600 python tools/bench_conv_halo.py --ablate > gpurun_out/round/halo_ablation.txt 2>&1
 timeout 300 python tools/halo_data_power.py > gpurun_out/round/halo_data_power.txt 2>&1
-(bash tools/ab_step.sh dreg_exec_set_sparse_stem 0 1; bash tools/ab_step.sh dreg_exec_set_sparse_grads 0 1; bash tools/ab_step.sh dreg_exec_set_s2_accumulate 0 1; bash tools/ab_step.sh dreg_exec_set_fold_res_bn 0 1; bash tools/ab_step.sh dreg_ps_set_group_wgrad 0 1; bash tools/ab_step.sh dreg_exec_set_group_wgrad 0 1) > gpurun_out/round/ab_round4_switches.txt 2>&1
+(bash tools/ab_step.sh opt:sparse_stem 0 1; bash tools/ab_step.sh opt:sparse_grads 0 1; bash tools/ab_step.sh opt:s2_accumulate 0 1; bash tools/ab_step.sh opt:fold_res_bn 0 1; bash tools/ab_step.sh ps:group_wgrad 0 1; bash tools/ab_step.sh opt:group_wgrad 0 1) > gpurun_out/round/ab_switches.txt 2>&1
 tail -2 gpurun_out/art/bench.log | cut -c1-600
 ls -la gpurun_out/round gpurun_out/art

@@ -10,7 +10,7 @@ if not os.path.exists(so):
 V = ctypes.CDLL(so)
 for f in (V.probe_fill, V.probe_load_check, V.probe_valu_check): f.restype = ctypes.c_int
 vp = ctypes.c_void_p
-dev = torch.device("cuda", 0); lib = L.load()
+dev = torch.device("cuda", 0); lib = L.use_probe()
 R = 1920
 x = torch.empty(R * 256, dtype=torch.int32, device=dev); y = torch.empty(R * 128, dtype=torch.int32, device=dev); s = torch.empty(R * 2, dtype=torch.int32, device=dev)
 for t in (x, y, s): V.probe_fill(vp(t.data_ptr()), ctypes.c_size_t(t.numel()), vp(L.stream()))

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from dreg_nerf_amd import ops, lib as L
 V = ctypes.CDLL(os.path.join(HERE, os.environ.get("VICTIM_SO", "libvictim.so"))); V.probe_ln_debug.restype = ctypes.c_int
 vp = ctypes.c_void_p
-dev = torch.device("cuda", 0); lib = L.load()
+dev = torch.device("cuda", 0); lib = L.use_probe()
 g0 = torch.Generator().manual_seed(1)
 R = 1920
 xl = torch.randn(R, 256, generator=g0).to(dev); dy = torch.randn(R, 256, generator=g0).to(dev).bfloat16()

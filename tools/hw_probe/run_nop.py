@@ -15,7 +15,7 @@ if not os.path.exists(so2):
 V = ctypes.CDLL(so); V.probe_ln_variant.restype = ctypes.c_int
 V2 = ctypes.CDLL(so2); V2.probe_ln_variant.restype = ctypes.c_int
 vp = ctypes.c_void_p
-dev = torch.device("cuda", 0); lib = L.load()
+dev = torch.device("cuda", 0); lib = L.use_probe()
 g0 = torch.Generator().manual_seed(1)
 R = 1920
 xl = torch.randn(R, 256, generator=g0).to(dev); dy = torch.randn(R, 256, generator=g0).to(dev).bfloat16()

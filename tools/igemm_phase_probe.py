@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dreg_nerf_amd import ops, lib as L
 dev = "cuda"
-lib = L.load()
+lib = L.use_probe()
 shapes = [("16^3 x 8  128 -> 128 k3", 8, 16, 128, 128, 3), ("16^3 x 8  512 -> 128 k1", 8, 16, 512, 128, 1), ("32^3 x 8  256 -> 128 k1", 8, 32, 256, 128, 1),
           ("32^3 x 8  128 -> 128 k3", 8, 32, 128, 128, 3), ("linear 9752 x 256 -> 768", 9752, 1, 256, 768, 1), ("linear 9752 x 1024 -> 256", 9752, 1, 1024, 256, 1)]
 buf = (ctypes.c_ulonglong * 8)()

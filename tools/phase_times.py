@@ -24,8 +24,8 @@ def fpn(x, rows=None, *a, **kw):
 model.fpn = fpn
 from dreg_nerf_amd import trunk_exec
 orig_bwd = trunk_exec.TrunkExecutor.backward
-def bwd(self, x, rows, g):
-    mark("fpn_bwd_start"); orig_bwd(self, x, rows, g); mark("fpn_bwd_end")
+def bwd(self, x, rows, g, generation=None):
+    mark("fpn_bwd_start"); orig_bwd(self, x, rows, g, generation); mark("fpn_bwd_end")
 trunk_exec.TrunkExecutor.backward = bwd
 orig_fb = model.forward_batch
 def fb(b):

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dreg_nerf_amd import ops, lib as L
 dev = "cuda"
-lib = L.load()
+lib = L.use_probe()
 buf = (ctypes.c_ulonglong * 8)()
 for (B, D, cin, cout) in ((8, 64, 256, 256),):
     g = torch.Generator().manual_seed(0)
