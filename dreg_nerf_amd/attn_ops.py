@@ -159,7 +159,7 @@ class ProblemTable:
             so.append(a)
             lo.append(b)
             a += ns
-            b += ns * nt
+            b += ns * ((nt + 3) // 4 * 4)          # a pair's logits block is [ns][nt rounded up to 4 floats] (csrc/losses.hip: the GEMMs' vector loads)
         self.total_src, self.total_logits = a, b
         self.logit_off_host = lo
         # ONE upload for the five tables (each was its own small copy in front of the transformer): int64 offsets first (alignment),

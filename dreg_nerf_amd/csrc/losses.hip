@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void infonce_rows_kernel(float* __restrict__ l
     float a[3];
     for (int c = 0; c < 3; ++c) a[c] = s[0] * Pm[c * 4] + s[1] * Pm[c * 4 + 1] + s[2] * Pm[c * 4 + 2] + Pm[c * 4 + 3];
     const float* tb = (staged && p == p0) ? sx : xyz + (size_t)t0 * 3;
-    float* lg = logits + logit_off[p] + (size_t)i * nt;
+    float* lg = logits + logit_off[p] + (size_t)i * ((nt + 3) & ~3);      // rows padded to four floats (the GEMMs' vector loads)
     const int jn = nn[wv];
     // online logsumexp over the included columns
     float mx = -3.4e38f, se = 0.f;
@@ -234,6 +234,117 @@ __global__ __launch_bounds__(256) void reg_losses_final_kernel(const float* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------ InfoNCE GEMMs (round 5)
+// The feature loss's matrix products (feature_loss.py:24-60: logits = f_a (triu(W) + triu(W)^T) f_p^T per pair, and their gradients) as
+// BATCHED fp32 GEMMs on the exact-fp32 MFMA (16 x 16 x 4), one launch per dependency level over a descriptor table instead of one library
+// GEMM per pair and product (14 rocBLAS launches + ~40 small ATen launches per step in round 4).
+//   C[M x N] = op(A)[M x K] . op(B)[K x N],  row-major;  tA = 0: A[m * lda + k], 1: A[k * lda + m];  tB = 0: B[k * ldb + n], 1: B[n * ldb + k].
+// The operands are addressed as (base pointer id, element offset): the table depends on the step's segment lengths only and is built once
+// per row-space table; the base pointers (this step's tensors) are kernel arguments.  64 x 64 tiles, 16-wide K steps through LDS ([k][m] /
+// [k][n] images, rows 80 floats apart: the four k rows of an MFMA operand read land in disjoint bank groups), register prefetch of the next
+// K step.  Every output element adds its K steps in ascending order: deterministic.
+struct GemmDesc { int a_id, b_id, c_id, tA, tB, M, N, K, lda, ldb, ldc, tile0; long long a_off, b_off, c_off; };
+static_assert(sizeof(GemmDesc) == 72, "descriptor layout is part of the ABI (dreg_gemm_f32_desc_bytes)");
+struct GemmBases { const float* p[8]; };
+constexpr int GT = 64, GK = 16, GLD = 80;
+
+__global__ __launch_bounds__(256) void gemm_f32_batched_kernel(const GemmDesc* __restrict__ descs, int n, GemmBases bases)
+{
+    __shared__ float sA[GK][GLD], sB[GK][GLD];
+    int d = 0;
+    while (d + 1 < n && descs[d + 1].tile0 <= (int)blockIdx.x) ++d;
+    const GemmDesc D = descs[d];
+    const int tiles_n = (D.N + GT - 1) / GT;
+    const int tl = (int)blockIdx.x - D.tile0, tm = tl / tiles_n, tn = tl - tm * tiles_n;
+    const int m0 = tm * GT, n0 = tn * GT;
+    const float* A = bases.p[D.a_id] + D.a_off;
+    const float* B = bases.p[D.b_id] + D.b_off;
+    float* C = const_cast<float*>(bases.p[D.c_id]) + D.c_off;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;                   // wave tile 32 x 32
+    const int fr = lane & 15, kg = lane >> 4;
+    // staging roles.  contiguous-along-K operand (tA = 0 / tB = 1): thread = (row r = t / 4, k4 = 4 (t % 4)), four consecutive k;
+    // contiguous-along-M/N operand (tA = 1 / tB = 0): thread = (k = t / 16, c4 = 4 (t % 16)), four consecutive rows / columns
+    float ra[4], rb[4];
+    auto ldg = [&](const float* P, int tr, int rows_total, int row0, int ld, int k0, float (&r)[4]) {
+        // tr = 1: P[k * ld + row] (row-contiguous); tr = 0: P[row * ld + k] (k-contiguous)
+        if (tr) {
+            const int k = k0 + (t >> 4), c = row0 + 4 * (t & 15);
+            const float* q = P + (size_t)k * ld + c;
+            const bool kv = k < D.K;
+            if (kv && c + 3 < rows_total && ((ld | c) & 3) == 0 && (((uintptr_t)P) & 15) == 0) { const float4 v = *reinterpret_cast<const float4*>(q); r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = (kv && c + e < rows_total) ? q[e] : 0.f;
+            }
+        } else {
+            const int row = row0 + (t >> 2), k = k0 + 4 * (t & 3);
+            const float* q = P + (size_t)row * ld + k;
+            const bool rv = row < rows_total;
+            if (rv && k + 3 < D.K && ((ld | k) & 3) == 0 && (((uintptr_t)P) & 15) == 0) { const float4 v = *reinterpret_cast<const float4*>(q); r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = (rv && k + e < D.K) ? q[e] : 0.f;
+            }
+        }
+    };
+    auto sts = [&](float (*S)[GLD], int tr, const float (&r)[4]) {
+        if (tr) *reinterpret_cast<float4*>(&S[t >> 4][4 * (t & 15)]) = make_float4(r[0], r[1], r[2], r[3]);
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S[4 * (t & 3) + e][t >> 2] = r[e];
+        }
+    };
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int nk = (D.K + GK - 1) / GK;
+    ldg(A, D.tA, D.M, m0, D.lda, 0, ra);
+    ldg(B, !D.tB, D.N, n0, D.ldb, 0, rb);
+    for (int ks = 0; ks < nk; ++ks) {
+        __syncthreads();                                       // the previous step's fragment reads are done
+        sts(sA, D.tA, ra);
+        sts(sB, !D.tB, rb);
+        __syncthreads();
+        if (ks + 1 < nk) { ldg(A, D.tA, D.M, m0, D.lda, (ks + 1) * GK, ra); ldg(B, !D.tB, D.N, n0, D.ldb, (ks + 1) * GK, rb); }
+#pragma unroll
+        for (int q = 0; q < GK / 4; ++q) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = sA[q * 4 + kg][wm * 32 + i * 16 + fr];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = sB[q * 4 + kg][wn * 32 + j * 16 + fr];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // C/D layout of the 16 x 16 MFMA: column = lane & 15, rows = (lane >> 4) * 4 + r
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 32 + i * 16 + kg * 4 + r;
+            if (m >= D.M) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nn_ = n0 + wn * 32 + j * 16 + fr;
+                if (nn_ < D.N) C[(size_t)m * D.ldc + nn_] = acc[i][j][r];
+            }
+        }
+}
+// Wsym = triu(W) + triu(W)^T (feature_loss.py:43-44), [E][E]
+__global__ void infonce_wsym_kernel(const float* __restrict__ W, float* __restrict__ out, int E)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= E * E) return;
+    const int r = i / E, c = i - r * E;
+    out[i] = (r <= c ? W[(size_t)r * E + c] : 0.f) + (c <= r ? W[(size_t)c * E + r] : 0.f);
+}
+
 extern "C" {
 
 int dreg_reg_point_losses(const float* gt, const float* tilde, const float* ov, const float* corr, const float* xyz, const float* pose,
@@ -289,6 +400,26 @@ int dreg_reg_losses_final(const float* partial, const float* loss_row, const flo
     if (P <= 0) return DREG_OK;
     hipLaunchKernelGGL(reg_losses_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, loss_row, count, probs, src_off, out, P, L, eps,
                        w_overlap, w_cont, w_feat, w_corr);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// Batched fp32 GEMMs over a descriptor table (see gemm_f32_batched_kernel).  descs_dev: n records of dreg_gemm_f32_desc_bytes() bytes
+//   { int a_id, b_id, c_id, tA, tB, M, N, K, lda, ldb, ldc, tile0; int64 a_off, b_off, c_off }
+// with tile0 = the number of 64 x 64 output tiles of the records before (total_tiles = that of all n); bases: 8 device pointers the ids index.
+int dreg_gemm_f32_desc_bytes(void) { return (int)sizeof(GemmDesc); }
+int dreg_gemm_f32_batched(const void* descs_dev, int n, int total_tiles, const float* const* bases8, void* stream)
+{
+    if (n <= 0 || total_tiles <= 0) return DREG_OK;
+    GemmBases b;
+    for (int i = 0; i < 8; ++i) b.p[i] = bases8[i];
+    hipLaunchKernelGGL(gemm_f32_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const GemmDesc*)descs_dev, n, b);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+int dreg_infonce_wsym(const float* W, float* out, int E, void* stream)
+{
+    hipLaunchKernelGGL(infonce_wsym_kernel, dim3((E * E + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, out, E);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

@@ -1,10 +1,58 @@
 """The four training losses of a step for all pairs at once, through csrc/losses.hip (one autograd node instead of ~120 small
 torch kernels per pair).  Reference: train_nerf_regtr.py:186-229, conerf/loss/correspondence_loss.py:16-51,
 conerf/loss/feature_loss.py:24-73; dreg_nerf_amd/losses.py keeps the per-pair torch formulation (evaluation, tests)."""
+import ctypes
+import struct
+
 import torch
 
 from . import lib as L
 from .losses import LOSS_WEIGHTS
+
+_WSYM = {}
+
+
+def _wsym(W):
+    """triu(W) + triu(W)^T, cached against W's storage, its version counter and the optimizer generation (FlatAdamW writes parameters behind torch's
+    version counters; the reference never optimises W — feature_loss.py quirk Q5 — so in training this is one tiny launch per optimizer step)."""
+    from . import ops
+    key = (W.data_ptr(), W._version, ops._weight_generation, W.device)
+    hit = _WSYM.get("w")
+    if hit is None or hit[0] != key:
+        out = torch.empty(256, 256, dtype=torch.float32, device=W.device)
+        L.check(L.load().dreg_infonce_wsym(L.ptr(W.detach().contiguous()), L.ptr(out), 256, L.stream()), "dreg_infonce_wsym")
+        _WSYM["w"] = hit = (key, out)
+    return hit[1]
+
+
+def _gemm_tables(tab, dev):
+    """The four descriptor tables (one per dependency level) of a step's InfoNCE GEMMs: they depend on the segment lengths only and live with the
+    row-space table.  Base pointer ids: 0 cond_last, 1 Wsym, 2 q, 3 logits / their gradient, 4 dq, 5 d_cond."""
+    gm = getattr(tab, "_infonce_gemms", None)
+    if gm is not None:
+        return gm
+    COND, WS, Q, LG, DQ, DC = range(6)
+    levels = [[], [], [], []]
+    for (s0, ns, t0, nt), lo in zip(tab.segs, tab.logit_off_host):
+        ld = (nt + 3) // 4 * 4
+        #               a_id b_id c_id tA tB  M   N    K    lda  ldb  ldc   a_off      b_off      c_off
+        levels[0].append((COND, WS, Q, 0, 0, ns, 256, 256, 256, 256, 256, s0 * 256, 0, s0 * 256))
+        levels[1].append((Q, COND, LG, 0, 1, ns, nt, 256, 256, 256, ld, s0 * 256, t0 * 256, lo))
+        levels[2].append((LG, COND, DQ, 0, 0, ns, 256, nt, ld, 256, 256, lo, t0 * 256, s0 * 256))
+        levels[2].append((LG, Q, DC, 1, 0, nt, 256, ns, ld, 256, 256, lo, s0 * 256, t0 * 256))
+        levels[3].append((DQ, WS, DC, 0, 0, ns, 256, 256, 256, 256, 256, s0 * 256, 0, s0 * 256))
+    gm = []
+    for recs in levels:
+        blob, tiles = b"", 0
+        for (a, b, c, ta, tb, M, N, K, lda, ldb, ldc, ao, bo, co) in recs:
+            blob += struct.pack("<12i3q", a, b, c, ta, tb, M, N, K, lda, ldb, ldc, tiles, ao, bo, co)
+            tiles += ((M + 63) // 64) * ((N + 63) // 64)
+        assert len(blob) == len(recs) * L.load().dreg_gemm_f32_desc_bytes()
+        t = L.to_device_async(list(blob), torch.uint8, dev)
+        gm.append((t, len(recs), tiles))
+    tab._infonce_gemms = gm
+    return gm
+
 
 NAMES = ("overlap", "nerf_cont", "feature", "corr", "total")
 
@@ -25,13 +73,22 @@ class _RegLossFn(torch.autograd.Function):
         L.check(lib.dreg_reg_point_losses(L.ptr(gt), L.ptr(tilde), L.ptr(ov_last), L.ptr(corr_last), L.ptr(xyz), L.ptr(poses), L.ptr(tab.pair_probs),
                                           L.ptr(partial), L.ptr(d_ov), L.ptr(d_corr), Ln, R, P_, int(robust), 1e-6, wo, wr, L.stream()),
                 "dreg_reg_point_losses")
-        # InfoNCE: logits = (A Wsym) P^T in fp32 (torch.mm = rocBLAS), everything after the GEMMs in two kernels
-        wt = torch.triu(W.detach())
-        wsym = wt + wt.T
-        q_all = cond_last @ wsym
+        # InfoNCE: logits = (A Wsym) P^T in exact fp32 — batched MFMA GEMMs of csrc/losses.hip, one launch per dependency level (round 5; rounds 1-4:
+        # torch.mm = rocBLAS per pair and product), everything after the GEMMs in two kernels
+        gm = _gemm_tables(tab, dev)
+        wsym = _wsym(W)
+        q_all = torch.empty(R, 256, dtype=torch.float32, device=dev)          # rows of the source sets only are written / read
         logits = torch.empty(max(tab.total_logits, 1), dtype=torch.float32, device=dev)
-        for (s0, ns, t0, nt), off in zip(tab.segs, tab.logit_off_host):
-            torch.mm(q_all[s0:s0 + ns], cond_last[t0:t0 + nt].T, out=logits[off:off + ns * nt].view(ns, nt))
+        dq = torch.empty(R, 256, dtype=torch.float32, device=dev) if need_grad else None
+        d_cond = torch.empty(R, 256, dtype=torch.float32, device=dev) if need_grad else None
+        bases = (ctypes.c_void_p * 8)(cond_last.data_ptr(), wsym.data_ptr(), q_all.data_ptr(), logits.data_ptr(),
+                                      dq.data_ptr() if need_grad else 0, d_cond.data_ptr() if need_grad else 0, 0, 0)
+
+        def level(k):
+            t, n, tiles = gm[k]
+            L.check(lib.dreg_gemm_f32_batched(L.ptr(t), n, tiles, bases, L.stream()), "dreg_gemm_f32_batched")
+        level(0)                                   # q = f_src Wsym
+        level(1)                                   # logits_p = q_p f_tgt_p^T
         nn = torch.empty(tab.total_src, dtype=torch.int32, device=dev)
         mask = torch.empty(tab.total_src, dtype=torch.float32, device=dev)
         count = torch.empty(P_, dtype=torch.float32, device=dev)
@@ -45,12 +102,8 @@ class _RegLossFn(torch.autograd.Function):
         L.check(lib.dreg_reg_losses_final(L.ptr(partial), L.ptr(loss_row), L.ptr(count), L.ptr(tab.pair_probs), L.ptr(tab.src_off), L.ptr(out),
                                           P_, Ln, 1e-6, wo, wc, wf, wr, L.stream()), "dreg_reg_losses_final")
         if need_grad:
-            dq = torch.zeros(R, 256, dtype=torch.float32, device=dev)
-            for (s0, ns, t0, nt), off in zip(tab.segs, tab.logit_off_host):
-                torch.mm(logits[off:off + ns * nt].view(ns, nt), cond_last[t0:t0 + nt], out=dq[s0:s0 + ns])
-            d_cond = dq @ wsym                      # rows of the target sets are still zero here (Wsym is symmetric)
-            for (s0, ns, t0, nt), off in zip(tab.segs, tab.logit_off_host):
-                torch.mm(logits[off:off + ns * nt].view(ns, nt).T, q_all[s0:s0 + ns], out=d_cond[t0:t0 + nt])
+            level(2)                               # dq_p = G_p f_tgt_p  and  d f_tgt_p = G_p^T q_p  (G = the in-place logits gradient)
+            level(3)                               # d f_src_p = dq_p Wsym  (Wsym is symmetric)
             ctx.save_for_backward(d_cond, d_corr, d_ov)
         total = out[4]
         stats = out[:4]

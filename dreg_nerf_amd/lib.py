@@ -36,6 +36,9 @@ SIGNATURES = {
     "dreg_conv3d_igemm_occ": (I, [P, P, P, P, P] + [I] * 18 + [I, I, P, Z, P, P]),
     "dreg_conv3d_igemm_bnstats": (I, [P, P, P, P, P] + [I] * 17 + [P, Z, P, P, P]),
     "dreg_conv3d_kpad": (I, [I, I, I]),
+    "dreg_gemm_f32_desc_bytes": (I, []),
+    "dreg_gemm_f32_batched": (I, [P, I, I, P, P]),
+    "dreg_infonce_wsym": (I, [P, P, I, P]),
     "dreg_conv3d_igemm_defer": (I, [P, P, P, P, P] + [I] * 18 + [P, Z, P, P, P, P]),
     "dreg_bn3d_fwd_ex": (I, [P] * 10 + [I, I, I, F, F, I, I, I, P, P, I, P, P]),
     "dreg_bn3d_bwd_ex": (I, [P] * 11 + [I] * 6 + [P, P, P, P]),

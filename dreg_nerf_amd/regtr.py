@@ -471,27 +471,42 @@ class NeRFRegTr(nn.Module):
                 "src_overlap": [s_ov], "tgt_overlap": [t_ov],
                 "pose": pose,
             })
+        if not self.training:
+            self._raise_stem_violation()
         return outs
 
     def _check_stem_contract(self, rows, row_occ):
         """stem_rows rests on "a grid is zero outside its voxel_mask".  The packers' row flags come from the VALUES: an output row of the
         stem that the values mark occupied but no listed voxel lies in means the contract is broken (the stem would silently drop
-        input).  Checked on the first calls and every 64th, one step late (no host sync on fresh work); raises ValueError."""
-        prev = self.__dict__.pop("_stem_violation", None)
-        if prev is not None and bool(prev):
+        input).  Evaluation (model.eval()): checked on EVERY call and raised by that same call (_raise_stem_violation at the end of
+        forward_batch: one host sync behind work that is already enqueued).  Training: checked on the first calls and every 64th into a
+        STICKY device flag that the next call reads (no host sync on fresh work; a violation between two samples is still reported, late).
+        NOTE: on the pack_sparse input path (dataset grids that arrive as (mask, values) lists) values outside the mask never reach the network at
+        all — the packer writes listed voxels only — so there is nothing to check there: the contract holds by construction.  Raises ValueError."""
+        prev = self.__dict__.get("_stem_violation", None)
+        if self.training and prev is not None and bool(prev):
+            self.__dict__.pop("_stem_violation", None)
             raise ValueError("stem_rows: an input grid holds non-zero values outside its voxel_mask (set model.stem_rows = False for such data)")
         stem = getattr(rows, "stem", None) if rows is not None else None
         if stem is None or row_occ is None:
             return
         n = self.__dict__["_stem_calls"] = self.__dict__.get("_stem_calls", 0) + 1
-        if n > 4 and n % 64:
+        if self.training and n > 4 and n % 64:
             return
         with torch.no_grad():
             # (flat rows are (b, z, x, y): a W-row is the index without its last coordinate)
             Wo = int(self._stem_out_w(row_occ, rows))
             flags = torch.zeros(row_occ.numel(), dtype=torch.bool, device=row_occ.device)
             flags[torch.div(stem, Wo, rounding_mode="floor").long()] = True
-            self.__dict__["_stem_violation"] = (row_occ.reshape(-1) != 0).logical_and_(~flags).any()
+            v = (row_occ.reshape(-1) != 0).logical_and_(~flags).any()
+            prev = self.__dict__.get("_stem_violation", None)
+            self.__dict__["_stem_violation"] = v if prev is None else prev.logical_or(v)     # sticky until it has been read
+
+    def _raise_stem_violation(self):
+        """Evaluation: the flag of THIS call, read once all of the call's launches are enqueued."""
+        v = self.__dict__.pop("_stem_violation", None)
+        if v is not None and bool(v):
+            raise ValueError("stem_rows: an input grid holds non-zero values outside its voxel_mask (set model.stem_rows = False for such data)")
 
     @staticmethod
     def _stem_out_w(row_occ, rows):

@@ -174,6 +174,11 @@ class TrainStep:
             self.scheduler.step()
         self.last_losses = means if agg is None else {k: v / len(batch) for k, v in agg.items()}
         self.last_preds = preds
+        from . import visibility
+        if visibility.OVERRUN.pending:
+            # labels marched from NeRF blocks this step: a persistent launch that ran into its pass bound (points left unlabelled) is reported here
+            # as soon as its counters have arrived — without stalling on this step's own launch (check(wait=True) at checkpoints / the end of a run)
+            visibility.OVERRUN.check()
         return {"losses": self.last_losses, "grad_norm": gnorm}
 
     def close(self):

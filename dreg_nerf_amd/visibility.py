@@ -185,32 +185,43 @@ class _OverrunWatch:
     """The persistent kernels set bit 63 of a launch's ray counter(s) when a wave leaves the march loop through its safety bound with rays
     still queued or in flight (their points would stay unlabelled).  Reading the counters back right away would be a host sync per label
     launch; instead they are copied to a pinned slot behind the launch and looked at when a later call finds the copy done (or by
-    check(wait=True): tests, the end of an extraction)."""
+    check(wait=True): tests, the end of an extraction, the end of a training step — train_step.TrainStep.step — so that an overrun is raised
+    before the optimizer has used labels that were never written).  A launch with more counters than a slot holds is watched in several slots.
+    Labels are requested from the loader thread and from the geometry thread: the slot lists are guarded by a lock."""
 
     SLOTS, WORDS = 8, 64           # pinned slots (allocated once), ray counters per slot
 
     def __init__(self):
-        self.pending = []          # (event, pinned int64 view)
+        import threading
+        self.pending = []          # (event, pinned int64 view, slot)
         self.free = None
+        self.lock = threading.Lock()
 
     def watch(self, counters: torch.Tensor):
-        n = counters.numel() // 2
-        if counters.device.type != "cuda" or n > self.WORDS:
+        if counters.device.type != "cuda":
             return
-        if self.free is None:
-            self.free = [(torch.cuda.Event(), torch.empty(self.WORDS, dtype=torch.int64).pin_memory()) for _ in range(self.SLOTS)]
-        if not self.free:
-            self.check()
-            if not self.free:      # the GPU is eight label launches behind the host
-                self.pending[0][0].synchronize()
-                self.check()
-        ev, slot = self.free.pop()
-        host = slot[:n]
-        host.copy_(counters.view(torch.int64), non_blocking=True)
-        ev.record(torch.cuda.current_stream(counters.device))
-        self.pending.append((ev, host, slot))
+        words = counters.view(torch.int64).reshape(-1)
+        with self.lock:
+            if self.free is None:
+                self.free = [(torch.cuda.Event(), torch.empty(self.WORDS, dtype=torch.int64).pin_memory()) for _ in range(self.SLOTS)]
+            for o in range(0, words.numel(), self.WORDS):          # a batched label call with more than WORDS requests: one slot per chunk
+                chunk = words[o:o + self.WORDS]
+                if not self.free:
+                    self._check_locked(False)
+                    if not self.free:      # the GPU is eight label launches behind the host
+                        self.pending[0][0].synchronize()
+                        self._check_locked(False)
+                ev, slot = self.free.pop()
+                host = slot[:chunk.numel()]
+                host.copy_(chunk, non_blocking=True)
+                ev.record(torch.cuda.current_stream(counters.device))
+                self.pending.append((ev, host, slot))
 
     def check(self, wait: bool = False):
+        with self.lock:
+            self._check_locked(wait)
+
+    def _check_locked(self, wait: bool):
         keep, bad = [], False
         for ev, host, slot in self.pending:
             if wait:

@@ -35,6 +35,8 @@ def extract_block(ckpt_path: str, dev, density_thre: float = 0.7):
     keep = dmask & smask
     grid, mask = ngp.build_voxel_grid(world, rgb, alpha, idx, keep, res)
     ngp.save_voxel_grid(out_dir, grid, mask, points=world[keep], colors=rgb[keep])
+    from dreg_nerf_amd import visibility
+    visibility.OVERRUN.check(wait=True)      # a surface-label launch that hit its pass bound is an error of THIS block, raised before the next one
     return int(mask.shape[0])
 
 

@@ -521,6 +521,16 @@ int dreg_weighted_kabsch_pairs(const float* xyz, const float* corr, const float*
 int dreg_reg_point_losses(const float* gt, const float* tilde, const float* ov, const float* corr, const float* xyz,
                           const float* pose, const int* probs, float* partial, float* d_ov, float* d_corr, int L, int R, int P,
                           int robust, float eps, float w_overlap, float w_corr, void* stream);
+/* InfoNCE's matrix products (feature_loss.py:43-47: logits = f_a (triu(W) + triu(W)^T) f_p^T per pair; and their gradients) replace torch.mm ->
+ * rocBLAS: batched exact-fp32 MFMA GEMMs over a descriptor table, C[M x N] = op(A)[M x K] . op(B)[K x N] row-major (tA = 1: A stored [K][M]; tB = 1: B
+ * stored [N][K]).  descs_dev: n records of dreg_gemm_f32_desc_bytes() = 72 bytes
+ *   { int a_id, b_id, c_id, tA, tB, M, N, K, lda, ldb, ldc, tile0; int64 a_off, b_off, c_off }     (offsets in elements)
+ * tile0 = 64 x 64 output tiles of the records before, total_tiles = of all; bases8: 8 device pointers indexed by the ids (host array).
+ * A pair's logits block is [ns][ld] with ld = nt rounded up to a multiple of 4 (dreg_infonce_rows reads / writes it with that stride).
+ * dreg_infonce_wsym: out[E][E] = triu(W) + triu(W)^T. */
+int dreg_gemm_f32_desc_bytes(void);
+int dreg_gemm_f32_batched(const void* descs_dev, int n, int total_tiles, const float* const* bases8, void* stream);
+int dreg_infonce_wsym(const float* W, float* out, int E, void* stream);
 int dreg_infonce_nn(const float* xyz, const float* pose, const int* probs, const int* src_off, int* nn, float* mask,
                     float* count, int P, int total_src, float r_p, void* stream);
 int dreg_infonce_rows(float* logits, const float* xyz, const float* pose, const int* probs, const int* src_off,

@@ -83,3 +83,39 @@ def test_kabsch_pairs_equals_per_pair_kernel():
         w = torch.cat([ov_d[:, s0:s0 + ns, 0], ov_d[:, t0:t0 + nt, 0]], dim=1)
         ref = A.weighted_kabsch(a, b, w)
         assert torch.equal(got[p], ref)
+
+
+@pytest.mark.parametrize("tA,tB,M,N,K", [(0, 0, 310, 256, 256), (0, 1, 310, 277, 256), (0, 0, 131, 256, 2101), (1, 0, 2101, 256, 131),
+                                          (1, 1, 65, 63, 17), (0, 1, 1, 1, 1)])
+def test_batched_fp32_gemm_all_operand_forms(tA, tB, M, N, K):
+    """dreg_gemm_f32_batched (exact-fp32 MFMA, csrc/losses.hip): two records per launch (the same problem at two offsets) against torch in fp64, ragged
+    sizes, leading dimensions that are / are not multiples of four (vector and scalar load paths)."""
+    import ctypes
+    import struct
+    from dreg_nerf_amd import lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    for pad in (0, 3):
+        lda = (M if tA else K) + pad
+        ldb = (K if tB else N) + pad
+        ldc = N + pad
+        a = torch.randn((K if tA else M), lda, generator=g).to(DEV)
+        b = torch.randn((N if tB else K), ldb, generator=g).to(DEV)
+        c = torch.full((2, M, ldc), float("nan"), device=DEV)
+        a2 = torch.cat([a.reshape(-1), a.reshape(-1) * 2.0])             # second record: the same A scaled, at an offset
+        tiles1 = ((M + 63) // 64) * ((N + 63) // 64)
+        blob = struct.pack("<12i3q", 0, 1, 2, tA, tB, M, N, K, lda, ldb, ldc, 0, 0, 0, 0) + \
+            struct.pack("<12i3q", 0, 1, 2, tA, tB, M, N, K, lda, ldb, ldc, tiles1, a.numel(), 0, M * ldc)
+        assert len(blob) == 2 * lib.dreg_gemm_f32_desc_bytes()
+        tab = torch.tensor(list(blob), dtype=torch.uint8).to(DEV)
+        bases = (ctypes.c_void_p * 8)(a2.data_ptr(), b.data_ptr(), c.data_ptr(), 0, 0, 0, 0, 0)
+        L.check(lib.dreg_gemm_f32_batched(L.ptr(tab), 2, 2 * tiles1, bases, L.stream()), "dreg_gemm_f32_batched")
+        A_ = (a[:, :M].T if tA else a[:, :K]).double()
+        B_ = (b[:, :K].T if tB else b[:, :N]).double()
+        ref = A_ @ B_
+        got = c[:, :, :N].double()
+        tol = 2e-6 * float(ref.abs().max()) * max(1.0, K ** 0.5 / 8) + 1e-7
+        assert float((got[0] - ref).abs().max()) <= tol
+        assert float((got[1] - 2.0 * ref).abs().max()) <= 2 * tol
+        if pad:
+            assert torch.isnan(c[:, :, N:]).all()                          # nothing outside the [M x N] block is written

@@ -97,7 +97,7 @@ def test_executor_and_per_op_path_forward_agree_bit_for_bit_with_stem_rows():
 
 
 def test_values_outside_the_mask_are_reported():
-    """stem_rows rests on "a grid is zero outside its voxel_mask"; a grid that breaks it is reported (one call late: no host sync)."""
+    """stem_rows rests on "a grid is zero outside its voxel_mask"; in evaluation a grid that breaks it is reported by the very call that was handed it."""
     torch.manual_seed(0)
     m = NeRFRegTr(precision="bf16").to(DEV).eval()
     batch = _batch(64, 1)
@@ -106,6 +106,12 @@ def test_values_outside_the_mask_are_reported():
     g.view(-1)[::7919] += 0.5                                 # values all over the volume
     with torch.no_grad():
         m.forward_batch(batch)                                # a clean call first
+        with pytest.raises(ValueError, match="voxel_mask"):
+            m.forward_batch([bad])
+        m.forward_batch(batch)                                # ... and the flag does not outlive the report
+    # training: a sticky device flag, read by the next call (no host sync on fresh work)
+    m.train()
+    with torch.no_grad():
         m.forward_batch([bad])
         with pytest.raises(ValueError, match="voxel_mask"):
             m.forward_batch(batch)

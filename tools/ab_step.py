@@ -38,7 +38,8 @@ res = {v: [] for v in vals}
 for r in range(rounds):
     for v in (vals if r % 2 == 0 else vals[::-1]):
         fn(v)
-        model.__dict__.pop('_trunk_cache', None)      # creation options take effect
+        model.__dict__.pop('_trunk_cache', None)      # creation options / shape-dependent choices made at executor creation take effect
+        model.__dict__.pop('_ps_cache', None)
         for _ in range(2): ts.step(batch)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(steps): ts.step(batch)
