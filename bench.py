@@ -625,8 +625,9 @@ def main():
         t_ = torch.tensor([exposed[0]], dtype=torch.float64, device=dev)
         dist.all_reduce(t_, op=dist.ReduceOp.MAX)
         exposed = (float(t_.item()), exposed[1])
-    if not in_sync["ranks_in_sync"]:
-        raise SystemExit(f"bench.py: ranks out of sync after the timed region: {in_sync}")
+    if not in_sync["ranks_in_sync"] and rank == 0:
+        # reported in the line (`ranks_in_sync`: false) and loudly here; the throughput of an out-of-sync run must not be read as a DDP measurement
+        print(f"bench.py: RANKS OUT OF SYNC after the timed region: {in_sync}", file=sys.stderr, flush=True)
 
     # the active-set head's work follows the occupied surface: the same step on shells of 1e4 .. 1e5 occupied voxels per side
     sweep = None

@@ -53,12 +53,16 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
 // ------------------------------------------------------------------------------------------------
 // forward / data-gradient
 // ------------------------------------------------------------------------------------------------
-template <typename T, typename TO, int BN>
+// ATR (measurement build only, tools/bench_bn_conv_fuse.py — round-5 review item 1): the A operand is transformed on its way from global memory to
+// LDS, a = relu(x * scale[b, ci] + shift[b, ci]) rounded to bf16 — a training-mode BatchNorm + ReLU applied INSIDE the 1^3 convolution that consumes
+// it (bn2 -> relu -> conv3 of a bottleneck, resnet3d.py:99-104) instead of as a pass of its own.  a_ss: fp32 [B][Cin][2].
+template <typename T, typename TO, int BN, bool ATR = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const T* __restrict__ in, const T* __restrict__ wt, TO* __restrict__ out,
     const float* __restrict__ bias, const TO* __restrict__ addend, ConvGeom g,
     int relu, int Da, int Ha, int Wa, int add_shift, int tilesN, const uint8_t* __restrict__ rowocc = nullptr,
-    const int* __restrict__ rowlist = nullptr, uint32_t nrows = 0)     // rowlist (optional): only output voxels rowlist[0 .. nrows) are computed
+    const int* __restrict__ rowlist = nullptr, uint32_t nrows = 0,     // rowlist (optional): only output voxels rowlist[0 .. nrows) are computed
+    const float* __restrict__ a_ss = nullptr)
 {
     constexpr int BM = 128;
     constexpr int G = 16 / sizeof(T);
@@ -136,6 +140,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
             uint32_t vox = vb[i] + (uint32_t)((z * g.Hi + y) * g.Wi + x);
             const T* p = in + (size_t)vox * g.Cin + ci;
             ra[i] = v ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+            if constexpr (ATR && sizeof(T) == 2) {
+                if (v) {        // (padding stays zero: the transform applies to voxels that exist)
+                    const float* ss = a_ss + ((size_t)(vb[i] / (uint32_t)(g.Di * g.Hi * g.Wi)) * g.Cin + ci) * 2;
+                    const uint32_t w4[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+                    uint32_t o4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float4 q = *reinterpret_cast<const float4*>(ss + 4 * e);      // (scale, shift) of channels ci + 2e, ci + 2e + 1
+                        const float lo = fmaxf(__uint_as_float(w4[e] << 16) * q.x + q.y, 0.f), hi = fmaxf(__uint_as_float(w4[e] & 0xffff0000u) * q.z + q.w, 0.f);
+                        o4[e] = f2bf2(lo, hi);
+                    }
+                    ra[i] = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -2392,6 +2410,19 @@ int dreg_conv3d_igemm_defer(const void* in, const void* wt_packed, void* out, co
 #ifdef DREG_PROBE
 void dreg_conv_set_glds(int enable) { g_use_glds = enable; }
 void dreg_conv_set_wgrad_big(int enable) { g_wgrad_big = enable; }
+// MEASUREMENT (tools/bench_bn_conv_fuse.py): out = conv1x1(relu(in * scale + shift)) with the BatchNorm + ReLU applied on the A load of the
+// register-staged kernel (bf16, dense rows, Cout % 128 == 0); a_scale_shift fp32 [B][Cin][2]
+int dreg_conv1_bnrelu_a_probe(const void* in, const void* wt_packed, void* out, const float* a_scale_shift, int B, int D, int H, int W, int Cin, int Cout, void* stream)
+{
+    ConvGeom g;
+    int rc = fill_geom(g, B, D, H, W, Cin, D, H, W, Cout, 1, 1, 0, 0, 2);
+    if (rc || Cout % 128 != 0 || Cin % 8 != 0) return DREG_EINVAL;
+    const int tilesM = (g.M + 127) / 128, tilesN = Cout / 128;
+    hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, bf16_t, 128, true>), dim3(tilesM * tilesN), dim3(256), 2 * (128 + 128) * 128, (hipStream_t)stream,
+                       (const bf16_t*)in, (const bf16_t*)wt_packed, (bf16_t*)out, nullptr, nullptr, g, 0, 0, 0, 0, 0, tilesN, nullptr, nullptr, 0u, a_scale_shift);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
 #endif
 // measurement only: enable = 1 routes bf16 launches with Cout % 128 == 0 to the instrumented 128 x 128 kernel; read returns
 // { cycles waiting for the stage's loads, in the barrier, issuing the next stage, in fragment reads + MFMAs; K steps x waves; waves } and clears them

@@ -235,6 +235,7 @@ SIGNATURES = {
 
 # include/dreg_nerf_probe.h: process-global kernel-variant setters, exported by the MEASUREMENT build only (libdreg_nerf_hip_probe.so)
 PROBE_SIGNATURES = {
+    "dreg_conv1_bnrelu_a_probe": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "dreg_conv_set_glds": (None, [I]),
     "dreg_conv_set_wgrad_splits": (None, [I]),
     "dreg_conv_set_wgrad_big": (None, [I]),

@@ -16,6 +16,8 @@ void dreg_conv3_halo_set_variant(int variant);
 void dreg_conv3_halo_set_prof(void* u64_buf_64x8x5);   /* variant 5: per-wave shader-clock breakdown of the first 64 workgroups */
 /* 1 (default): bf16 stride-1 convolutions stage operands with buffer_load...lds; 0: register-staged kernel (A/B checks) */
 void dreg_conv_set_glds(int enable);
+/* MEASUREMENT (tools/bench_bn_conv_fuse.py, round-5 review item 1): 1^3 convolution whose A load applies a BatchNorm + ReLU, a = relu(x * scale[b,ci] + shift[b,ci]) (register-staged kernel) */
+int dreg_conv1_bnrelu_a_probe(const void* in, const void* wt_packed, void* out, const float* a_scale_shift, int B, int D, int H, int W, int Cin, int Cout, void* stream);
 /* tuning / test knob: force the number of voxel splits of the weight-gradient kernels (0 = automatic) */
 void dreg_conv_set_wgrad_splits(int splits);
 void dreg_conv_set_wgrad_rows_fast(int enable);      /* 1 (default): row-list weight gradients keep packed voxel coordinates in LDS (no decode per load) and take the 8-wave 256 x 256 tile for 256 -> 256 layers */
