@@ -12,7 +12,7 @@ cp gpurun_out/round/bench_ngp.json profiles/${R}_bench_ngp_config4.json; cp gpur
 cp gpurun_out/round/wgrad_phase_probe.txt profiles/${R}_wgrad_phase_probe.txt; cp gpurun_out/round/bench_wgrad.txt profiles/${R}_bench_wgrad.txt
 cp gpurun_out/round/bench_igemm_ap.txt profiles/${R}_bench_igemm_ap.txt; cp gpurun_out/round/repack_bubble.txt profiles/${R}_repack_bubble.txt
 cp gpurun_out/round/bench_conv_brick.txt profiles/${R}_bench_conv_brick.txt
-for f in phase_times_steady_state halo_ablation halo_data_power ab_round4_switches; do [ -f gpurun_out/round/$f.txt ] && grep -v "amdgpu.ids" gpurun_out/round/$f.txt > profiles/${R}_$f.txt; done
+for f in phase_times_steady_state halo_ablation halo_data_power ab_switches; do [ -f gpurun_out/round/$f.txt ] && grep -v "amdgpu.ids" gpurun_out/round/$f.txt > profiles/${R}_$f.txt; done
 for m in two ser; do cp gpurun_out/art/timeline_${m}_active_set.txt profiles/${R}_timeline_per_queue_${m}_streams_under_profiler.txt; done
 [ -f gpurun_out/pinned_step_report.json ] && cp gpurun_out/pinned_step_report.json profiles/${R}_pinned_step_report.json
 python - <<'PY'
