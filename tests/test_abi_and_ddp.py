@@ -59,6 +59,21 @@ def test_product_library_has_no_process_global_switches():
     assert not writable, writable
 
 
+def test_headers_are_plain_c(tmp_path):
+    """The boundary is a C ABI: both headers compile as C99 with -pedantic (what a cgo / JNI / ctypes-generator front end would feed them to), and a C
+    program can name a struct of the ABI (dreg_exec_opts, dreg_bn_extra) by value."""
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    src = tmp_path / "hdr.c"
+    src.write_text(f'#include "{ROOT}/include/dreg_nerf.h"\n#include "{ROOT}/include/dreg_nerf_probe.h"\n'
+                   "int main(void) { dreg_exec_opts o; dreg_bn_extra e; e.splitk_nsplit = 0; o.guard = e.splitk_nsplit; return o.guard + DREG_OK + (DREG_EGUARD != -3); }\n")
+    r = subprocess.run([cc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_device_code_has_no_packed_fp32_instructions():
     """v_pk_*_f32 returned wrong lanes next to the implicit-GEMM kernels of a second stream (DESIGN.md "co-execution",
     tools/hw_probe); the build flags keep them out of every code object and this pins it."""
