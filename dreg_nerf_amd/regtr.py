@@ -454,6 +454,10 @@ class NeRFRegTr(nn.Module):
             cond, corr, ov = T.encode_decode_batched(P, feats_all, xyz_all, tab, self.position_embedding)
         outs = []
         poses = A.weighted_kabsch_pairs(xyz_all, corr, ov, tab)   # [P,6,3,4]: every (pair, layer) solve in one launch
+        if not self.training and self.__dict__.get("_stem_violation") is not None:
+            # evaluation: a call that was handed a grid with values outside its voxel_mask must not return a plausible pose — the poses of THIS call become
+            # NaN on the device (no host sync here); check_inputs() / the next call raise with the explanation
+            poses = torch.where(self.__dict__["_stem_violation"], torch.full_like(poses, float("nan")), poses)
         # the batched view of the same results (row space of all pairs) for the fused training losses
         self.last_batched = {"cond": cond, "corr": corr, "ov": ov, "xyz": xyz_all, "tab": tab}
         if last:   # the last layer's outputs as tensors of their own: losses that read only these let the backward pass skip five sixths of the decoder
@@ -471,21 +475,19 @@ class NeRFRegTr(nn.Module):
                 "src_overlap": [s_ov], "tgt_overlap": [t_ov],
                 "pose": pose,
             })
-        if not self.training:
-            self._raise_stem_violation()
         return outs
 
     def _check_stem_contract(self, rows, row_occ):
         """stem_rows rests on "a grid is zero outside its voxel_mask".  The packers' row flags come from the VALUES: an output row of the
         stem that the values mark occupied but no listed voxel lies in means the contract is broken (the stem would silently drop
-        input).  Evaluation (model.eval()): checked on EVERY call and raised by that same call (_raise_stem_violation at the end of
-        forward_batch: one host sync behind work that is already enqueued).  Training: checked on the first calls and every 64th into a
-        STICKY device flag that the next call reads (no host sync on fresh work; a violation between two samples is still reported, late).
+        input).  Evaluation (model.eval()): checked on EVERY call; the poses of a violating call are returned as NaN (on the device: no host sync, so a
+        forward-only loop keeps its pipelining) and `check_inputs()` — eval_nerf_regtr.py calls it where it reads the pose back anyway — or the next call
+        raises.  Training: checked on the first calls and every 64th into a STICKY device flag that the next call reads (no host sync on fresh work;
+        a violation between two samples is still reported, late).
         NOTE: on the pack_sparse input path (dataset grids that arrive as (mask, values) lists) values outside the mask never reach the network at
         all — the packer writes listed voxels only — so there is nothing to check there: the contract holds by construction.  Raises ValueError."""
-        prev = self.__dict__.get("_stem_violation", None)
-        if self.training and prev is not None and bool(prev):
-            self.__dict__.pop("_stem_violation", None)
+        prev = self.__dict__.pop("_stem_violation", None)
+        if prev is not None and bool(prev):             # (the flag of an EARLIER call: its work has long been enqueued)
             raise ValueError("stem_rows: an input grid holds non-zero values outside its voxel_mask (set model.stem_rows = False for such data)")
         stem = getattr(rows, "stem", None) if rows is not None else None
         if stem is None or row_occ is None:
@@ -498,12 +500,10 @@ class NeRFRegTr(nn.Module):
             Wo = int(self._stem_out_w(row_occ, rows))
             flags = torch.zeros(row_occ.numel(), dtype=torch.bool, device=row_occ.device)
             flags[torch.div(stem, Wo, rounding_mode="floor").long()] = True
-            v = (row_occ.reshape(-1) != 0).logical_and_(~flags).any()
-            prev = self.__dict__.get("_stem_violation", None)
-            self.__dict__["_stem_violation"] = v if prev is None else prev.logical_or(v)     # sticky until it has been read
+            self.__dict__["_stem_violation"] = (row_occ.reshape(-1) != 0).logical_and_(~flags).any()      # read (and cleared) by the next call / check_inputs()
 
-    def _raise_stem_violation(self):
-        """Evaluation: the flag of THIS call, read once all of the call's launches are enqueued."""
+    def check_inputs(self):
+        """Raise if a grid handed to an earlier call broke the stem_rows contract (one host sync; evaluation scripts call it where they read results back)."""
         v = self.__dict__.pop("_stem_violation", None)
         if v is not None and bool(v):
             raise ValueError("stem_rows: an input grid holds non-zero values outside its voxel_mask (set model.stem_rows = False for such data)")

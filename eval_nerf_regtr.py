@@ -55,6 +55,7 @@ def main():
             pred = model(data)
             torch.cuda.synchronize()
             dt = time.time() - t0
+            model.check_inputs()      # a grid with values outside its voxel_mask (the row-list stem would have dropped them) is an error of THIS scene
             err = LS.evaluate_camera_alignment(pred["pose"][-1], data["pose"])
             rows[data["scene"]] = {"R_mean": float(err["R_error_mean"]), "t_mean": float(err["t_error_mean"]),
                                    "R_med": float(err["R_error_med"]), "t_med": float(err["t_error_med"]), "time": dt}

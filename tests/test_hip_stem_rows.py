@@ -97,7 +97,8 @@ def test_executor_and_per_op_path_forward_agree_bit_for_bit_with_stem_rows():
 
 
 def test_values_outside_the_mask_are_reported():
-    """stem_rows rests on "a grid is zero outside its voxel_mask"; in evaluation a grid that breaks it is reported by the very call that was handed it."""
+    """stem_rows rests on "a grid is zero outside its voxel_mask"; in evaluation the call that was handed a violating grid returns NaN poses (no host
+    sync inside the call) and check_inputs() / the next call raise; in training a sticky device flag is read by the next call."""
     torch.manual_seed(0)
     m = NeRFRegTr(precision="bf16").to(DEV).eval()
     batch = _batch(64, 1)
@@ -105,12 +106,20 @@ def test_values_outside_the_mask_are_reported():
     g = bad["src_xyz_rgba"]
     g.view(-1)[::7919] += 0.5                                 # values all over the volume
     with torch.no_grad():
-        m.forward_batch(batch)                                # a clean call first
+        ok = m.forward_batch(batch)                           # a clean call first
+        m.check_inputs()
+        assert torch.isfinite(ok[0]["pose"]).all()
+        out = m.forward_batch([bad])
+        assert torch.isnan(out[0]["pose"]).all()              # never a plausible pose from dropped input
         with pytest.raises(ValueError, match="voxel_mask"):
-            m.forward_batch([bad])
-        m.forward_batch(batch)                                # ... and the flag does not outlive the report
-    # training: a sticky device flag, read by the next call (no host sync on fresh work)
+            m.check_inputs()
+        m.forward_batch([bad])
+        with pytest.raises(ValueError, match="voxel_mask"):   # ... or the next call reports it
+            m.forward_batch(batch)
+        assert torch.isfinite(m.forward_batch(batch)[0]["pose"]).all()
+    # training: the flag of a sampled call is read by the next call (no host sync on fresh work)
     m.train()
+    m.__dict__["_stem_calls"] = 0                             # (training samples the check: the first calls and every 64th)
     with torch.no_grad():
         m.forward_batch([bad])
         with pytest.raises(ValueError, match="voxel_mask"):
