@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--ngp", action="store_true", help="BASELINE.json configs[3] instead: NGP grid extraction of 128^3 NeRF blocks (dense hash-MLP query)")
     ap.add_argument("--eval", action="store_true", help="BASELINE.json configs[4]-style instead: forward-only registration (eval mode, no gradients) of synthetic pairs with a known pose")
     ap.add_argument("--nerf-labels", action="store_true", help="the training step with its overlap labels ray-marched from the pairs' NeRF blocks (train_nerf_regtr.py:186-199) instead of synthetic labels: generated blocks, 50 cameras each")
+    ap.add_argument("--chain", action="store_true", help="BASELINE.json configs[4] as a line of its own: extraction + registration of generated scenes, pipelined (and, with --chain-serial, the block-at-a-time chain beside it)")
+    ap.add_argument("--chain-serial", action="store_true", help="--chain: also time the serial chain of rounds 3-5 on the same blocks")
+    ap.add_argument("--chain-scenes", type=int, default=16, help="--chain: scenes (pairs of blocks) per pass")
     ap.add_argument("--ngp-radius", type=float, default=1.0, help="--ngp: occupied cells = ball of this radius in the [-1.5,1.5]^3 block")
     return ap.parse_args()
 
@@ -235,33 +238,53 @@ def write_generated_blocks(n, ncam, seed):
     return td, paths
 
 
-def eval_end_to_end(args, dev, reps: int = 2):
-    """BASELINE.json configs[4] as a throughput figure beside the headline: `--pairs` scenes of two generated 128^3 NeRF blocks each go through the whole
-    evaluation chain — eval_ngp_nerf.py's per-block grid extraction (checkpoint load, dense density + 18-direction colour query, surface labels,
-    voxel_grid.pt / voxel_mask.pt / .ply written) and eval_nerf_regtr.py's registration (grids read back, RegTR forward in eval mode, RRE / RTE) —
-    and the rate is pairs per second of wall time INCLUDING extraction and file I/O.  Generated blocks + random-init RegTR weights (no checkpoints
-    without network access): RRE / RTE only show that the metric path runs."""
+def eval_end_to_end(args, dev, reps: int = 2, scenes_per_pass: int = 16, serial: bool = False, model=None, pose_fn=None):
+    """BASELINE.json configs[4] as a throughput figure beside the headline: `scenes_per_pass` scenes of two generated 128^3 NeRF blocks each go through the
+    whole evaluation chain — eval_ngp_nerf.py's per-block grid extraction (checkpoint load, dense density + 18-direction colour query, surface labels,
+    voxel_grid.pt / voxel_mask.pt / .ply and their density_voxel_* twins written) and eval_nerf_regtr.py's registration (eval-mode forward, RRE / RTE) —
+    and the rate is pairs per second of wall time INCLUDING extraction and every file (the pass ends when the last file is closed).
+    Default: the pipelined chain (dreg_nerf_amd/eval_pipeline.py: loader threads, no host readbacks, writer threads, registration in batches of
+    `--pairs` from the device-resident grids).  serial=True: the block-at-a-time chain of rounds 3-5 (files read back for registration).
+    Generated blocks (eight distinct checkpoints, hard-linked into the scene directories) + random-init RegTR weights unless `model` is given: then
+    RRE / RTE are those of that checkpoint."""
     import shutil
     import eval_ngp_nerf as E
     from dreg_nerf_amd.losses import rre_rte
     from dreg_nerf_amd.regtr import NeRFRegTr
-    td, paths = write_generated_blocks(2 * args.pairs, 6, 11)
+    n_scenes = args.pairs if serial else scenes_per_pass
+    td, paths = write_generated_blocks(8, 6, 11)
+    pipe = None
     try:
-        # one block checkpoint per directory, as the scripts expect (<scene>/block_k/model.pth)
-        blocks = []
-        for i, p_ in enumerate(paths):
-            d = os.path.join(td, f"scene_{i // 2}", f"block_{i % 2}")
-            os.makedirs(d)
-            os.replace(p_, os.path.join(d, "model.pth"))
-            blocks.append(d)
-        torch.manual_seed(3407)
-        model = NeRFRegTr(precision=args.precision).to(dev).eval()
+        # one block checkpoint per directory, as the scripts expect (<scene>/block_k/model.pth); every pass (warm-up + timed) gets directories of its own:
+        # an evaluation run writes its grid files once, into directories that hold none yet (re-writing existing files was measured ~2x slower)
+        passes = []
+        for ps in range(reps + 1):
+            blocks = []
+            for i in range(2 * n_scenes):
+                d = os.path.join(td, f"pass_{ps}", f"scene_{i // 2}", f"block_{i % 2}")
+                os.makedirs(d)
+                try:
+                    os.link(paths[i % len(paths)], os.path.join(d, "model.pth"))
+                except OSError:
+                    shutil.copyfile(paths[i % len(paths)], os.path.join(d, "model.pth"))
+                blocks.append(d)
+            passes.append(blocks)
+        pass_no = [0]
+
+        def next_blocks():
+            b_ = passes[min(pass_no[0], len(passes) - 1)]
+            pass_no[0] += 1
+            return b_
+        if model is None:
+            torch.manual_seed(3407)
+            model = NeRFRegTr(precision=args.precision).to(dev).eval()
         pose = torch.eye(4)[None]
 
-        def once():
+        def once_serial():
+            blocks = next_blocks()
             kept = [E.extract_block(os.path.join(d, "model.pth"), dev) for d in blocks]
             batch = []
-            for i in range(args.pairs):
+            for i in range(n_scenes):
                 g = [torch.load(os.path.join(blocks[2 * i + k], "voxel_grid.pt")) for k in range(2)]
                 m = [torch.load(os.path.join(blocks[2 * i + k], "voxel_mask.pt")) for k in range(2)]
                 batch.append({"src_xyz_rgba": g[0].permute(3, 2, 0, 1).unsqueeze(0).contiguous().to(dev), "tgt_xyz_rgba": g[1].permute(3, 2, 0, 1).unsqueeze(0).contiguous().to(dev),
@@ -269,20 +292,46 @@ def eval_end_to_end(args, dev, reps: int = 2):
             with torch.no_grad():
                 preds = model.forward_batch(batch)
             errs = [rre_rte(p["pose"][-1].float().cpu(), pose) for p in preds]
-            return kept, errs
-        once()                                       # warm-up (first-use allocations, executor recording)
+            return kept, [float(e[0]) for e in errs], [float(e[1]) for e in errs], None
+
+        from dreg_nerf_amd.eval_pipeline import ExtractionPipeline, extract_and_register
+        pipe = None if serial else ExtractionPipeline(dev)
+
+        def once_pipelined():
+            blocks = next_blocks()
+            scenes = [(f"scene_{i}", os.path.join(blocks[2 * i], "model.pth"), os.path.join(blocks[2 * i + 1], "model.pth"), pose[0]) for i in range(n_scenes)]
+            for k in pipe.timings:
+                pipe.timings[k] = {} if isinstance(pipe.timings[k], dict) else 0 if isinstance(pipe.timings[k], int) else 0.0
+            rows, tm = extract_and_register(scenes, model, dev, batch_pairs=args.pairs, pipeline=pipe)
+            return [v for r in rows.values() for v in r["voxels"]], [r["R_mean"] for r in rows.values()], [r["t_mean"] for r in rows.values()], tm
+
+        once = once_serial if serial else once_pipelined
+        once()                                       # warm-up (first-use allocations, pinned staging, executor recording)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
-            kept, errs = once()
+            kept, rre, rte, tm = once()
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / reps
-        return {"metric": "nerf_pairs_per_sec_extract_plus_register_128", "value": args.pairs / el, "unit": "pairs/s", "s_per_pass": el, "pairs": args.pairs,
-                "blocks_extracted": len(blocks), "voxels_kept_per_block": int(sum(kept) / len(kept)),
-                "rre_deg_mean": float(sum(float(e[0]) for e in errs) / len(errs)), "rte_mean": float(sum(float(e[1]) for e in errs) / len(errs)),
-                "note": "wall time of extraction (incl. checkpoint load and the .pt / .ply files) + registration (grids read back, eval-mode forward, RRE / RTE); "
-                        "generated blocks, random-init weights: the errors only show that the metric path runs"}
+        if pipe is not None:
+            pipe.close()
+        out = {"metric": "nerf_pairs_per_sec_extract_plus_register_128", "value": n_scenes / el, "unit": "pairs/s", "s_per_pass": el, "pairs": n_scenes,
+               "blocks_extracted": 2 * n_scenes, "voxels_kept_per_block": int(sum(kept) / len(kept)), "chain": "serial" if serial else "pipelined", **({} if serial else {"writers": f"{len(pipe._procs) or pipe._writers._max_workers} {pipe.writer_mode}es" if pipe.writer_mode == "process" else f"{pipe._writers._max_workers} threads"}),
+               "rre_deg_mean": float(sum(rre) / len(rre)), "rte_mean": float(sum(rte) / len(rte)),
+               "note": "wall time of extraction (checkpoint load, query, surface labels, the six files per block) + registration (eval-mode forward in batches of "
+                       f"{args.pairs} pairs, RRE / RTE), last file closed inside the timed region; generated blocks, random-init weights: the errors only show that the metric path runs"}
+        if tm is not None:      # per-phase breakdown of the LAST pass: thread-seconds of work, what the main thread waited for, GPU time by phase
+            gpu_ms = tm["gpu_query_ms"] + tm["gpu_surface_ms"] + tm["gpu_grids_ms"] + tm["gpu_copy_ms"] + tm["gpu_register_ms"]
+            out["phases"] = {"load_thread_s": tm["load_thread_s"], "write_thread_s": tm["write_thread_s"], "GB_written": tm["bytes_written"] / 1e9,
+                             "main_thread": {"waited_for_loads_s": tm["load_wait_s"], "waited_for_staging_slots_s": tm["slot_wait_s"], "enqueue_extraction_s": tm["enqueue_s"], "enqueue_detail_s": tm["host_detail_s"],
+                                             "register_s": tm["register_s"], "final_flush_of_writers_s": tm["flush_s"]},
+                             "gpu_ms": {"query": tm["gpu_query_ms"], "surface": tm["gpu_surface_ms"], "grid_writers": tm["gpu_grids_ms"], "copies_to_host": tm["gpu_copy_ms"],
+                                        "register": tm["gpu_register_ms"]},
+                             "gpu_busy_frac_of_pass": gpu_ms * 1e-3 / el}
+        return out
     finally:
+        if pipe is not None:
+            pipe.close()
         shutil.rmtree(td, ignore_errors=True)
 
 
@@ -497,6 +546,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    if args.chain:
+        out = eval_end_to_end(args, dev, scenes_per_pass=args.chain_scenes)
+        if args.chain_serial:
+            out["serial_chain"] = eval_end_to_end(args, dev, serial=True)
+        print(json.dumps(out), flush=True)
+        return
     if args.ngp or args.eval or args.nerf_labels:
         (ngp_bench if args.ngp else eval_bench if args.eval else nerf_labels_bench)(args, rank, world, dev)
         if world > 1:

@@ -47,6 +47,9 @@ def config_parser(argv=None):
                    help="eval: per scene, transformation_est.json and the registration's point clouds as PLY files (eval_nerf_regtr.py:313-438)")
     p.add_argument("--fgr_baseline", action="store_true",
                    help="also run the Fast Global Registration baseline on every pair and write fgr_metrics_{split}.json (eval_nerf_regtr.py:303-311 of the reference)")
+    p.add_argument("--eval_batch", type=int, default=4, help="eval: pairs per forward call (reference: 1; results per scene do not depend on it beyond bf16 rounding)")
+    p.add_argument("--extract_grids", action="store_true",
+                   help="eval_nerf_regtr.py: extract the voxel grids of the split's NeRF blocks first (what eval_ngp_nerf.py does, same files) and register from the device-resident grids, pipelined")
     args, _unknown = p.parse_known_args(argv)
     if isinstance(args.aabb, str):
         args.aabb = [float(v) for v in args.aabb.split(",")]

@@ -16,6 +16,7 @@
 // 128 bytes of K per step, register-staged double-buffered LDS with a 16-byte-slot XOR swizzle
 // (slot ^= (row>>1)&7) so the ds_read_b128 fragment reads of 16 consecutive rows are conflict free.
 #include "common.h"
+#include "../../include/dreg_nerf.h"   // signature check of every entry point defined here
 #include <cstring>
 extern "C" int dreg_fill_zero(void* p, size_t bytes, void* stream);   // fpn_ops.hip (include/dreg_nerf.h)
 
@@ -2104,7 +2105,8 @@ DREG_KNOB(int, g_narrow_thr, 224);        // tile count below which a launch tak
 DREG_KNOB(int, g_pointwise_rmw_cin, 128);  // tuning (include/dreg_nerf_probe.h): see igemm_choose
 DREG_KNOB(int, g_igemm_ap256, 1);         // tuning (include/dreg_nerf_probe.h): the 256 x 256 tile of large launches runs in its anti-phase form (32-channel stages)
 // A split-K launch may leave its partials un-summed for the consumer to sum (the small-volume BatchNorm kernels read the fp32 slices
-// directly: dreg_bn_set_splitk_input) — armed for the NEXT launch only, taken when that launch is split-K with bf16 output and no bias / ReLU.
+// directly: dreg_bn_extra.splitk_part of dreg_bn3d_fwd_ex / _bwd_ex) — asked for per call through dreg_conv3d_igemm_defer's out arguments (no
+// per-thread "armed" state), taken when that launch is split-K with bf16 output and no bias / ReLU.
 struct SplitkDefer { int* nsplit; size_t* slice; };   // out arguments of dreg_conv3d_igemm_defer (null = always reduce)
 DREG_KNOB(int, g_igemm_ap, 256);          // tuning (include/dreg_nerf_probe.h): launches of at most this many 128-row tiles take the eight-wave anti-phase form (0: never)
 DREG_KNOB(int, g_narrow_small, 2);        // tuning (include/dreg_nerf_probe.h): 128 x 64 tiles for launches of < 224 128 x 128 tiles
@@ -2387,8 +2389,6 @@ int dreg_conv3d_dgrad_s2_acc(const void* gout, const void* wt_class_packed, void
 // space is large, else 128 x {128|64}); 2: 128-row tiles only; 3: the 8-wave 128x256
 // tile when Cout % 256 == 0 (measured equal to 128x128 in round 1); 4: the 8-wave 256x256 tile (128x64 per wave);
 // 5: as 1 but never split-K; 0: always the register-staged kernel (A/B checks).
-// Arm (1) / disarm (0) the deferral for the next convolution launch of this thread; dreg_conv_splitk_deferred returns 1 (and the slice
-// count / slice length in elements, and clears the state) when that launch left its split-K partials [nsplit][M * Cout] fp32 in its workspace.
 // dreg_conv3d_igemm_occ (bf16 in / out) that may leave a split-K launch's fp32 slices [*sk_nsplit][M * Cout] UN-SUMMED in its workspace for
 // the consumer to sum (the register-resident BatchNorm kernels: dreg_bn3d_fwd_ex / dreg_bn3d_bwd_ex): *sk_nsplit = 0 when the launch
 // finished its output itself (not split-K, or a bias / ReLU epilogue), else the slice count, *sk_slice = the slice length in elements.

@@ -495,7 +495,7 @@ void* dreg_exec_create_opts(const int* tensors, int nt, const int* ops, int nops
         }
         if (o.kind == OP_CONV_ROWS && o.ksz == 3 && o.pad == 1 && p.d1 == x.C && dreg_brick_supported(x.B, x.D, x.H, x.W, 16, 256)) {
             // the same layer in the staged-neighbourhood form (used when the step's row sets come with tile tables)
-            // (packs only for the launches the mask in force at creation enables: dreg_exec_set_brick before the executor is created)
+            // (packs only for the launches the mask in force at creation enables: dreg_exec_opts.brick of dreg_exec_create_opts)
             auto on = [&](int nout) { return (nout == 64 && (g_brick & 1)) || (nout == 256 && (g_brick & 2)); };
             if (on(p.d0) && p.d1 % 16 == 0 && p.pk_brick_fwd == SIZE_MAX) p.pk_brick_fwd = add_brick_pack(p, 0);
             if (e->needs_grad[o.in] && on(p.d1) && p.d0 % 16 == 0 && p.pk_brick_dgrad == SIZE_MAX) p.pk_brick_dgrad = add_brick_pack(p, 1);

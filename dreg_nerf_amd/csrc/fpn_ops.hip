@@ -422,7 +422,7 @@ template <int G> __device__ __forceinline__ void bns_reduce(float (&s1)[G], floa
 // registers between the statistics and the apply phase (the general form, NR = 0, walks the rows twice, four loads in flight): the
 // kernels are short enough that the second walk and the exposed latencies were most of their time.  Same sums in the same order.
 // part (NR > 0 only): x has not been formed yet — it is the sum of `nsplit` fp32 slices part[s * slice + element] left by a split-K convolution
-// (dreg_conv_defer_splitk_reduce); the slices are added in ascending order, rounded to T and stored to x exactly as the convolution's own
+// (dreg_conv3d_igemm_defer's sk_nsplit / sk_slice out arguments, handed on as dreg_bn_extra.splitk_part); the slices are added in ascending order, rounded to T and stored to x exactly as the convolution's own
 // reduce pass would have (the backward pass reads x), and the statistics use the rounded values: bit-identical, one launch less.
 template <typename T>
 __device__ __forceinline__ uint4 bns_sum_slices(const float* __restrict__ part, int nsplit, size_t slice, size_t off)

@@ -52,8 +52,11 @@ __global__ __launch_bounds__(256) void reg_point_losses_kernel(
         bce += (double)(fmaxf(x, 0.f) - x * tt + log1pf(expf(-fabsf(x))));
         d_ov[row] = -x * inv_n * w_overlap / (float)P;
         for (int l = 0; l < L; ++l) {
-            const float g = gt[(size_t)l * R + row], d = g - tilde[(size_t)l * R + row], a = fabsf(d);
-            sl1 += (double)(a < 1.f ? 0.5f * d * d : a - 0.5f);
+            const float g = gt[(size_t)l * R + row];
+            if (tilde) {     // null: the label-consistency term is formed later by dreg_nerf_cont_deferred (it carries no gradient)
+                const float d = g - tilde[(size_t)l * R + row], a = fabsf(d);
+                sl1 += (double)(a < 1.f ? 0.5f * d * d : a - 0.5f);
+            }
             wsum += (double)g;
         }
         float e = 0.f;
@@ -234,6 +237,42 @@ __global__ __launch_bounds__(256) void reg_losses_final_kernel(const float* __re
     }
 }
 
+// The label-consistency term ('nerf_cont', train_nerf_regtr.py:198-201) formed AFTER the other three: its 'tilde' labels — the visibility of the
+// PREDICTED correspondences, six point sets per block — feed nothing that carries a gradient, so the training step marches them on a
+// side stream while backward runs and completes the step's loss values here.  Same arithmetic, in the same order, as reg_point_losses_kernel /
+// reg_losses_final_kernel with tilde given: partial[.][1] and out[1], out[4] come out bit-identical.  grid = 2P blocks, then one single-thread launch.
+__global__ __launch_bounds__(256) void nerf_cont_partial_kernel(const float* __restrict__ gt, const float* __restrict__ tilde, const int* __restrict__ probs,
+                                                                float* __restrict__ partial, int L, int R)
+{
+    __shared__ double red[256];
+    const int p = blockIdx.x >> 1, side = blockIdx.x & 1, t = threadIdx.x;
+    const int r0 = side ? probs[p * 4 + 2] : probs[p * 4], n = side ? probs[p * 4 + 3] : probs[p * 4 + 1];
+    double sl1 = 0.0;
+    for (int i = t; i < n; i += 256) {
+        const int row = r0 + i;
+        for (int l = 0; l < L; ++l) {
+            const float g = gt[(size_t)l * R + row], d = g - tilde[(size_t)l * R + row], a = fabsf(d);
+            sl1 += (double)(a < 1.f ? 0.5f * d * d : a - 0.5f);
+        }
+    }
+    sl1 = block_sum_d(sl1, red);
+    if (t == 0) partial[(size_t)blockIdx.x * 4 + 1] = (float)sl1;
+}
+__global__ void nerf_cont_final_kernel(const float* __restrict__ partial, const int* __restrict__ probs, float* __restrict__ out, int P, int L,
+                                       float w_overlap, float w_cont, float w_feat, float w_corr)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double acc = 0.0;
+    for (int p = 0; p < P; ++p) {
+        const float* a = partial + (size_t)(2 * p) * 4;
+        const float* b = a + 4;
+        const double n = (double)(probs[p * 4 + 1] + probs[p * 4 + 3]);
+        acc += ((double)a[1] + (double)b[1]) / (n * L);
+    }
+    out[1] = (float)(acc / P);
+    out[4] = w_overlap * out[0] + w_cont * out[1] + w_feat * out[2] + w_corr * out[3];
+}
+
 // ------------------------------------------------------------------------------------------------ InfoNCE GEMMs (round 5)
 // The feature loss's matrix products (feature_loss.py:24-60: logits = f_a (triu(W) + triu(W)^T) f_p^T per pair, and their gradients) as
 // BATCHED fp32 GEMMs on the exact-fp32 MFMA (16 x 16 x 4), one launch per dependency level over a descriptor table instead of one library
@@ -400,6 +439,18 @@ int dreg_reg_losses_final(const float* partial, const float* loss_row, const flo
     if (P <= 0) return DREG_OK;
     hipLaunchKernelGGL(reg_losses_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, loss_row, count, probs, src_off, out, P, L, eps,
                        w_overlap, w_cont, w_feat, w_corr);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
+// completes partial[.][1], out[1] (nerf_cont) and out[4] (total) of a step whose dreg_reg_point_losses ran with tilde = null
+int dreg_nerf_cont_deferred(const float* gt, const float* tilde, const int* probs, float* partial, float* out, int P, int L, int R,
+                            float w_overlap, float w_cont, float w_feat, float w_corr, void* stream)
+{
+    if (P <= 0) return DREG_OK;
+    if (!gt || !tilde || !probs || !partial || !out) return DREG_EINVAL;
+    hipLaunchKernelGGL(nerf_cont_partial_kernel, dim3(2 * P), dim3(256), 0, (hipStream_t)stream, gt, tilde, probs, partial, L, R);
+    hipLaunchKernelGGL(nerf_cont_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, probs, out, P, L, w_overlap, w_cont, w_feat, w_corr);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

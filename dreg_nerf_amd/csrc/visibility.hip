@@ -507,15 +507,23 @@ int dreg_surface_visibility_fill_desc(void* host_desc, const float* cams, const 
     return DREG_OK;
 }
 DREG_KNOB(int, g_vis_waves, 4096);        // tuning (include/dreg_nerf_probe.h): one-wave workgroups of the persistent launches (256 CUs x 16)
-int dreg_surface_visibility_multi(const void* descs_dev, int n, long total_rays, void* stream)
+// max_waves (0 = the default 4096 = 16 per CU): one-wave workgroups of the persistent launch.  A workgroup holds 18.7 KB of LDS for as long as the launch
+// runs, so a full-width launch leaves a CU's LDS to nobody else; a BACKGROUND launch — the training step's gradient-free 'tilde' labels, marched on a side
+// stream while backward runs (train_step.TrainStep.split_labels) — asks for one or two waves per CU and takes proportionally longer.  Same labels.
+int dreg_surface_visibility_multi_waves(const void* descs_dev, int n, long total_rays, int max_waves, void* stream)
 {
     if (n <= 0 || total_rays <= 0) return DREG_OK;
-    if (!descs_dev) return DREG_EINVAL;
+    if (!descs_dev || max_waves < 0) return DREG_EINVAL;
     long waves = (total_rays + 63) / 64;
     if (waves > g_vis_waves) waves = g_vis_waves;
+    if (max_waves > 0 && waves > max_waves) waves = max_waves;
     hipLaunchKernelGGL(surface_visibility_multi_kernel, dim3((unsigned)waves), dim3(64), 0, (hipStream_t)stream, (const VisArgs*)descs_dev, n);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
+}
+int dreg_surface_visibility_multi(const void* descs_dev, int n, long total_rays, void* stream)
+{
+    return dreg_surface_visibility_multi_waves(descs_dev, n, total_rays, 0, stream);
 }
 // The same labels from the persistent kernel (lanes refilled from a ray queue; rays of points that already carry the label are not
 // marched).  queue: 8 bytes of device memory the CALLER has zeroed on this stream (the ray counter).

@@ -186,9 +186,10 @@ def load_split(json_dir: str, dataset: str) -> dict:
 
 class NeRFRegDataset:
     def __init__(self, root_fp: str, json_dir: str, dataset: str = "objaverse", split: str = "train", model_dir: str = "nerf_models",
-                 sparse: bool = False, device=None):
+                 sparse: bool = False, device=None, require_grids: bool = True):
         """sparse=True: samples carry 'src_sparse'/'tgt_sparse' (SparseBlock) instead of the dense grids — ~0.6 MB per block over PCIe
-        instead of 58.7 MB — and the training augmentation runs on `device` after the upload."""
+        instead of 58.7 MB — and the training augmentation runs on `device` after the upload.  require_grids=False: blocks count as usable when
+        their NeRF checkpoint exists (eval_nerf_regtr.py --extract_grids writes the grids itself)."""
         self.mode = split
         self.sparse, self.device = sparse, device
         self.meta = []
@@ -203,7 +204,7 @@ class NeRFRegDataset:
             blocks = {}
             for k in sorted(transforms):
                 d = os.path.join(root_fp, dataset, model_dir, scene, f"block_{k}")
-                if os.path.exists(os.path.join(d, "voxel_grid.pt")):
+                if os.path.exists(os.path.join(d, "voxel_grid.pt")) or (not require_grids and os.path.exists(os.path.join(d, "model.pth"))):
                     blocks[k] = {"dir": d, "transform": transforms[k]}
             if len(blocks) >= 2:
                 self.meta.append({"scene": scene, "dataset": dataset, "blocks": blocks})
@@ -223,12 +224,18 @@ class NeRFRegDataset:
     def __getitem__(self, index):
         return self.get(index)
 
-    def get(self, index, rng=None, gen=None, cpu_gen=None):
+    def draw_block_order(self, index, rng=None):
+        """The shuffle `get` applies to a scene's block ids (quirk Q15), as a call of its own: evaluation draws it for every scene in scene order on
+        every rank and passes it back as get(..., block_order=), so a scene's source / target assignment does not depend on how scenes are sharded."""
+        ids = list(self.meta[index]["blocks"].keys())
+        (rng or random).shuffle(ids)
+        return ids
+
+    def get(self, index, rng=None, gen=None, cpu_gen=None, block_order=None):
         """rng / gen / cpu_gen: the caller's own random.Random, device and CPU torch.Generator (PrefetchLoader's thread); default = the
         process-global generators, as the reference's dataset uses them."""
         sm = self.meta[index]
-        ids = list(sm["blocks"].keys())
-        (rng or random).shuffle(ids)  # also in test mode, as the reference (quirk Q15)
+        ids = list(block_order) if block_order is not None else self.draw_block_order(index, rng)  # also in test mode, as the reference (quirk Q15)
         s, t = sm["blocks"][ids[0]], sm["blocks"][ids[1]]
         if self.sparse:
             data = {"src_sparse": load_block_sparse(s["dir"]), "tgt_sparse": load_block_sparse(t["dir"]),

@@ -16,6 +16,10 @@ def _wsym(W):
     """triu(W) + triu(W)^T, cached against W's storage, its version counter and the optimizer generation (FlatAdamW writes parameters behind torch's
     version counters; the reference never optimises W — feature_loss.py quirk Q5 — so in training this is one tiny launch per optimizer step)."""
     from . import ops
+    # the kernel and the GEMM descriptor tables are built for the model width 256 (the reference's InfoNCELoss(256, ...)); anything else would read out of bounds.
+    # Writers that change W behind torch's version counter (W.data[...] = ..., raw kernels) other than FlatAdamW must call ops.bump_weight_generation().
+    if tuple(W.shape) != (256, 256) or W.dtype != torch.float32:
+        raise ValueError(f"InfoNCE W must be fp32 [256, 256] (got {W.dtype} {tuple(W.shape)})")
     key = (W.data_ptr(), W._version, ops._weight_generation, W.device)
     hit = _WSYM.get("w")
     if hit is None or hit[0] != key:
@@ -59,11 +63,14 @@ NAMES = ("overlap", "nerf_cont", "feature", "corr", "total")
 
 class _RegLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cond_last, corr_last, ov_last, xyz, gt, tilde, poses, W, tab, robust: bool, r_p: float, r_n: float):
+    def forward(ctx, cond_last, corr_last, ov_last, xyz, gt, tilde, poses, W, tab, robust: bool, r_p: float, r_n: float, defer=None):
         lib = L.load()
         dev = xyz.device
+        if cond_last.shape[-1] != 256:
+            raise ValueError(f"fused losses: feature width {cond_last.shape[-1]} != 256")
         cond_last, corr_last, ov_last = cond_last.contiguous(), corr_last.contiguous(), ov_last.contiguous()
-        xyz, gt, tilde, poses = xyz.contiguous(), gt.contiguous(), tilde.contiguous(), poses.contiguous().float()
+        xyz, gt, poses = xyz.contiguous(), gt.contiguous(), poses.contiguous().float()
+        tilde = tilde.contiguous() if tilde is not None else None       # None: 'nerf_cont' is completed later by finish_nerf_cont(defer, tilde)
         P_, Ln, R = len(tab.segs), gt.shape[0], xyz.shape[0]
         need_grad = any(ctx.needs_input_grad[:3])
         wo, wc, wf, wr = LOSS_WEIGHTS["overlap"], LOSS_WEIGHTS["nerf_cont"], LOSS_WEIGHTS["feature"], LOSS_WEIGHTS["corr"]
@@ -105,6 +112,8 @@ class _RegLossFn(torch.autograd.Function):
             level(2)                               # dq_p = G_p f_tgt_p  and  d f_tgt_p = G_p^T q_p  (G = the in-place logits gradient)
             level(3)                               # d f_src_p = dq_p Wsym  (Wsym is symmetric)
             ctx.save_for_backward(d_cond, d_corr, d_ov)
+        if defer is not None:
+            defer.update(partial=partial, out=out, gt=gt, probs=tab.pair_probs, P=P_, L=Ln, R=R, weights=(wo, wc, wf, wr))
         total = out[4]
         stats = out[:4]
         ctx.mark_non_differentiable(stats)
@@ -113,18 +122,32 @@ class _RegLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gs):
         d_cond, d_corr, d_ov = ctx.saved_tensors
-        return d_cond * g, d_corr * g, d_ov * g, None, None, None, None, None, None, None, None, None
+        return d_cond * g, d_corr * g, d_ov * g, None, None, None, None, None, None, None, None, None, None
 
 
-def regtr_losses(batched: dict, poses, feature_loss, gt, tilde, robust: bool = False):
+def finish_nerf_cont(defer: dict, tilde: torch.Tensor):
+    """Complete a regtr_losses(..., tilde=None, defer=defer) call on the CURRENT stream: 'nerf_cont' and 'total' of the dict it returned take the values
+    the one-call form gives, bit for bit (train_nerf_regtr.py:198-201; the term has no gradient — SURVEY.md quirk Q4 — so backward never waits for it).
+    The caller orders this stream behind the losses' stream and the readers of the loss values behind this one."""
+    wo, wc, wf, wr = defer["weights"]
+    tilde = tilde.contiguous()
+    assert tuple(tilde.shape) == (defer["L"], defer["R"]) and tilde.dtype == torch.float32
+    L.check(L.load().dreg_nerf_cont_deferred(L.ptr(defer["gt"]), L.ptr(tilde), L.ptr(defer["probs"]), L.ptr(defer["partial"]), L.ptr(defer["out"]),
+                                             defer["P"], defer["L"], defer["R"], wo, wc, wf, wr, L.stream()), "dreg_nerf_cont_deferred")
+
+
+def regtr_losses(batched: dict, poses, feature_loss, gt, tilde, robust: bool = False, defer: dict = None):
     """batched: NeRFRegTr.last_batched (cond [6,R,256], corr [6,R,3], ov [6,R,1], xyz [R,3], tab); poses [P,4,4];
-    gt / tilde: {0,1} labels [6,R] of the key points / of the predicted correspondences.
+    gt / tilde: {0,1} labels [6,R] of the key points / of the predicted correspondences.  tilde = None with a dict `defer`: the
+    label-consistency term is left at 0 until finish_nerf_cont(defer, tilde).
     Returns {"overlap","nerf_cont","feature","corr","total"}: means over the pairs, 'total' differentiable."""
+    if tilde is None and defer is None:
+        raise ValueError("regtr_losses: tilde = None needs a `defer` dict for finish_nerf_cont")
     cond_l = batched["cond_last"] if "cond_last" in batched else batched["cond"][-1]
     corr_l = batched["corr_last"] if "corr_last" in batched else batched["corr"][-1]
     ov_l = batched["ov_last"][:, 0] if "ov_last" in batched else batched["ov"][-1, :, 0]
     total, stats = _RegLossFn.apply(cond_l, corr_l, ov_l, batched["xyz"], gt, tilde, poses,
-                                    feature_loss.W, batched["tab"], bool(robust), float(feature_loss.r_p), float(feature_loss.r_n))
+                                    feature_loss.W, batched["tab"], bool(robust), float(feature_loss.r_p), float(feature_loss.r_n), defer)
     out = {k: stats[i] for i, k in enumerate(NAMES[:4])}
     out["total"] = total
     return out

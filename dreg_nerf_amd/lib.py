@@ -194,6 +194,7 @@ SIGNATURES = {
     "dreg_infonce_nn": (I, [P] * 7 + [I, I, F, P]),
     "dreg_infonce_rows": (I, [P] * 10 + [I, I, F, F, I, P]),
     "dreg_reg_losses_final": (I, [P] * 6 + [I, I, F, F, F, F, F, P]),
+    "dreg_nerf_cont_deferred": (I, [P] * 5 + [I, I, I, F, F, F, F, P]),
     "dreg_voxel_downsample_workspace_bytes": (Z, [I]),
     "dreg_voxel_downsample_fwd": (I, [P] * 11 + [Z, I, I, I, F, P]),
     "dreg_voxel_downsample_bwd": (I, [P, P, P, P, I, I, P]),
@@ -230,6 +231,7 @@ SIGNATURES = {
     "dreg_surface_visibility_desc_bytes": (Z, []),
     "dreg_surface_visibility_fill_desc": (I, [P] + [P] * 7 + [P] * 5 + [P, P, P] + [I] * 5 + [F, F, F, F, P, P]),
     "dreg_surface_visibility_multi": (I, [P, I, ctypes.c_long, P]),
+    "dreg_surface_visibility_multi_waves": (I, [P, I, ctypes.c_long, I, P]),
 }
 
 
@@ -300,7 +302,9 @@ def use_probe():
 class probe:
     """``with L.probe() as lib:`` — inside the block every ``L.load()`` of the package returns the measurement build, so the wrappers of
     dreg_nerf_amd run its kernels and ``lib.dreg_*_set_*`` selects their variants.  On exit the knobs that were touched through ``set()`` are put
-    back and ``L.load()`` is the product library again.  Objects that keep a handle (executors) must be created AND dropped inside the block."""
+    back and ``L.load()`` is the product library again.  Objects that keep a handle (executors) must be created AND dropped inside the block.
+    The swap is of a module global and is NOT thread-safe: do not enter / leave the block while background threads of this package (the prefetching
+    loader, the label / geometry threads, the evaluation pipeline's workers) may call ``L.load()`` — they would launch on whichever build is current."""
 
     def __init__(self):
         self._restore = []

@@ -82,6 +82,26 @@ class NGPradianceField(nn.Module):
         if init:
             self.reset_parameters()
 
+    @classmethod
+    def from_inference_copies(cls, aabb, unbounded: bool, base16: torch.Tensor, col16: torch.Tensor, device):
+        """A field that is only queried, built straight from the fp16 inference copies of its parameters (mlp_base.params / color_mlp.params converted
+        with round-to-nearest-even, tcnn's params_inference): the state freeze_for_inference() leaves, without ever holding the fp32 parameters on
+        the device (visibility.load_block)."""
+        dev = torch.device(device)
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        aabb_host = [float(v) for v in (aabb.tolist() if torch.is_tensor(aabb) else aabb)]
+        self.register_buffer("aabb", L.to_device_async(aabb_host, torch.float32, dev) if dev.type == "cuda" else torch.tensor(aabb_host, dtype=torch.float32))
+        self.unbounded, self.geo_feat_dim = bool(unbounded), 15
+        self._levels, total = _level_table(19)
+        assert base16.numel() == 3072 + 2 * total and col16.numel() == 7168 and base16.dtype == torch.float16 and col16.dtype == torch.float16
+        self.mlp_base, self.color_mlp = _Params(0, False), _Params(0, False)
+        self.mlp_base.params.data = torch.empty(0, device=dev)
+        self.color_mlp.params.data = torch.empty(0, device=dev)
+        self._prep = ("frozen", base16, col16)
+        self.__dict__["_aabb_cache"] = ((self.aabb.data_ptr(), self.aabb._version), aabb_host)
+        return self.eval()
+
     def reset_parameters(self):
         with torch.no_grad():  # tcnn defaults: hash table U(-1e-4, 1e-4), MLP weights Xavier-uniform
             p = self.mlp_base.params
@@ -367,9 +387,11 @@ class SampleGrid(nn.Module):
         return world, rgb, alpha[:, None], indices, mask
 
     @torch.no_grad()
-    def _cells_and_density_fused(self, radiance_field: NGPradianceField, dev, density_thre: float, jitter: Optional[torch.Tensor]):
+    def _cells_and_density_fused(self, radiance_field: NGPradianceField, dev, density_thre: float, jitter: Optional[torch.Tensor],
+                                 n_known: Optional[int] = None):
         """The first half of the fused dense query: occupied cells (ascending), their jittered positions, density / raw features / alpha /
-        density mask — five launches and the one host readback (the number of occupied cells)."""
+        density mask — five launches and the one host readback (the number of occupied cells).  n_known: that number when the caller has it
+        already (eval_pipeline counts the checkpoint's occupancy grid on the loader thread, on the host): no readback at all."""
         lib = L.load()
         import ctypes
         binary = self._binary.to(dev)
@@ -387,7 +409,7 @@ class SampleGrid(nn.Module):
         totals = ws[toff:toff + 8].view(torch.int32)
         # the zeroed voxel grid build_voxel_grid will fill (cubes): issued here so that its fill runs while the host waits for N
         grid = torch.zeros(rx * ry * rz, 7, dtype=torch.float32, device=dev) if rx == ry == rz else None
-        n = int(totals[0].item())                                   # the query's one host readback: the outputs' size
+        n = int(totals[0].item()) if n_known is None else int(n_known)   # the query's one host readback: the outputs' size
         if jitter is None:
             jitter = torch.rand(n, 3, dtype=torch.float32, device=dev)
         jitter = jitter.to(dev).float().contiguous()
@@ -492,6 +514,25 @@ def build_voxel_grid(world, rgb, alpha, indices, keep, resolution: int):
     L.check(lib.dreg_grid_scatter7(L.ptr(world.contiguous()), L.ptr(rgb.contiguous()), L.ptr(alpha.reshape(-1).contiguous()),
                                    L.ptr(indices.contiguous()), L.ptr(keep_u8), L.ptr(grid), world.shape[0], L.stream()), "dreg_grid_scatter7")
     return grid.view(resolution, resolution, resolution, 7), indices[keep]
+
+
+@torch.no_grad()
+def write_kept_async(rows, world, rgb, alpha, indices, keep_u8, resolution: int, grid: Optional[torch.Tensor] = None):
+    """build_voxel_grid without its host readback, for any keep mask over the cells of ONE dense query (rows = the `_dreg_rows` / fourth result of
+    SampleGrid._cells_and_density_fused): returns (voxel_grid fp32 [res,res,res,7], voxel_mask int64 buffer of capacity N whose first `count`
+    entries are the kept indices, ascending, count int32 [1] on the device).  May be called several times on the same query (density mask, then
+    density AND surface mask: eval_ngp_nerf.py:350-412): every call recounts the kept cells per row from `keep_u8`."""
+    lib = L.load()
+    ws, totals, (rx, ry, rz) = rows[0], rows[1], rows[2]
+    assert (rx, ry, rz) == (resolution,) * 3
+    dev = world.device
+    if grid is None:
+        grid = torch.zeros(resolution ** 3, 7, dtype=torch.float32, device=dev)
+    n = world.shape[0]
+    mask = torch.empty(n, dtype=torch.int64, device=dev)
+    L.check(lib.dreg_grid_write_kept(L.ptr(ws), L.ptr(world), L.ptr(rgb), L.ptr(alpha.reshape(-1).contiguous()), L.ptr(indices), L.ptr(keep_u8),
+                                     L.ptr(mask), L.ptr(grid), rx, ry, rz, n, L.stream()), "dreg_grid_write_kept")
+    return grid.view(resolution, resolution, resolution, 7), mask, totals[1:2].clone()
 
 
 def save_voxel_grid(out_dir: str, voxel_grid: torch.Tensor, voxel_mask: torch.Tensor, prefix: str = "voxel", points=None, colors=None):

@@ -399,6 +399,9 @@ class NeRFRegTr(nn.Module):
             with torch.cuda.stream(side):
                 geo = self._geometry(batch, dev)
                 tab = A.ProblemTable(geo[8], dev)      # the attention / Kabsch / loss tables: uploaded next to the geometry, not in front of the transformer
+            hook = self.__dict__.get("_after_geometry")
+            if hook is not None:       # the key points are known here, before the feature network has run: train_step marches their visibility labels now
+                hook(geo[7], geo[8], side)
             main.wait_stream(side)
             grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs, table, s1_rows = geo
             # these were allocated on the side stream and are consumed on the main one
@@ -420,6 +423,9 @@ class NeRFRegTr(nn.Module):
         else:
             grids, idxs, res, idx_cat, pb_cat, rows, plans, pts_l, segs, table, s1_rows = self._geometry(batch, dev)
             tab = A.ProblemTable(segs, dev)
+            hook = self.__dict__.get("_after_geometry")
+            if hook is not None:
+                hook(pts_l, segs, None)
         if isinstance(grids, tuple):   # sparse input form
             x_in, row_occ = self.pack_sparse(grids[0], idx_cat, pb_cat, grids[1], res, self.act_dtype, occupancy=True)
         else:
@@ -482,8 +488,10 @@ class NeRFRegTr(nn.Module):
         stem that the values mark occupied but no listed voxel lies in means the contract is broken (the stem would silently drop
         input).  Evaluation (model.eval()): checked on EVERY call; the poses of a violating call are returned as NaN (on the device: no host sync, so a
         forward-only loop keeps its pipelining) and `check_inputs()` — eval_nerf_regtr.py calls it where it reads the pose back anyway — or the next call
-        raises.  Training: checked on the first calls and every 64th into a STICKY device flag that the next call reads (no host sync on fresh work;
-        a violation between two samples is still reported, late).
+        raises.  Training: SAMPLED — checked on the first four calls and on every 64th only (the check costs six small launches); the flag of a checked call
+        is read by the next call (no host sync on fresh work).  A grid that breaks the contract on an unsampled training call is NOT seen: the row-list
+        stem drops its out-of-mask values silently.  Data of unknown provenance should be validated once with model.eval() (every call checked) or run
+        with model.stem_rows = False.
         NOTE: on the pack_sparse input path (dataset grids that arrive as (mask, values) lists) values outside the mask never reach the network at
         all — the packer writes listed voxels only — so there is nothing to check there: the contract holds by construction.  Raises ValueError."""
         prev = self.__dict__.pop("_stem_violation", None)

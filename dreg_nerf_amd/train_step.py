@@ -66,6 +66,73 @@ def _default_labels(pred):
     return s_gt, t_gt, s_tl, t_tl
 
 
+class _SplitLabels:
+    """One step's NeRF-block labels in two launches on TrainStep's label stream (see TrainStep.split_labels)."""
+
+    def __init__(self, ts, batch, dev):
+        self.ts, self.batch, self.dev = ts, batch, dev
+        if ts._label_stream is None or ts._label_stream.device != dev:
+            ts._label_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("DREG_LABEL_PRIORITY", "0")))
+        self.stream = ts._label_stream
+        self.main = torch.cuda.current_stream(dev)
+        self.gt_row = self.ev_gt = None
+
+    def after_geometry(self, pts_l, segs, producer):
+        """Called by forward_batch when the key points exist (on `producer`, the geometry stream, which runs ahead of the step stream)."""
+        from .visibility import compute_visibility_scores_batched
+        ls = self.stream
+        ls.wait_stream(producer if producer is not None else self.main)
+        with torch.cuda.stream(ls), torch.no_grad():
+            reqs = []
+            for pts, (ns, nt), d in zip(pts_l, segs, self.batch):
+                pts.record_stream(ls)
+                reqs.append((pts[:ns].reshape(1, ns, 3), d["src_nerf_path"]))
+                reqs.append((pts[ns:ns + nt].reshape(1, nt, 3), d["tgt_nerf_path"]))
+            outs = compute_visibility_scores_batched(reqs, max_waves=self.ts.label_waves[0])
+            self.gt_row = torch.cat([o.reshape(-1) for o in outs])                 # [R]: rows in the batch's row space (pair 0 src | tgt, pair 1 ...)
+            self.ev_gt = torch.cuda.Event()
+            self.ev_gt.record(ls)
+
+    def after_forward(self, bt):
+        """gt [6,R] for the losses (the same key-point labels for every decoder layer, as the reference expands them) and the 'tilde' march behind forward."""
+        from .visibility import compute_visibility_scores_batched
+        main, ls = self.main, self.stream
+        main.wait_event(self.ev_gt)
+        self.gt_row.record_stream(main)
+        corr = bt["corr"]
+        nl = corr.shape[0]
+        gt = self.gt_row[None].expand(nl, -1).contiguous()
+        ev_fwd = torch.cuda.Event()
+        ev_fwd.record(main)
+        ls.wait_event(ev_fwd)
+        with torch.cuda.stream(ls), torch.no_grad():
+            corr.record_stream(ls)
+            c = corr.detach()
+            reqs = []
+            for (s0, ns, t0, nt), d in zip(bt["tab"].segs, self.batch):
+                reqs.append((c[:, s0:s0 + ns], d["src_nerf_path"]))
+                reqs.append((c[:, t0:t0 + nt], d["tgt_nerf_path"]))
+            outs = compute_visibility_scores_batched(reqs, max_waves=self.ts.label_waves[1])
+            self.tilde = torch.cat([o[..., 0] for o in outs], dim=1)             # [6,R]
+        return gt
+
+    def after_losses(self, defer):
+        main, ls = self.main, self.stream
+        ev = torch.cuda.Event()
+        ev.record(main)
+        ls.wait_event(ev)                       # the losses' own final kernel has written out[1] = 0 / out[4] before they are completed
+        for t in (defer["partial"], defer["out"], defer["gt"]):
+            t.record_stream(ls)
+        with torch.cuda.stream(ls):
+            FL.finish_nerf_cont(defer, self.tilde)
+        self.ev_done = torch.cuda.Event()
+        self.ev_done.record(ls)
+
+    def join(self):
+        self.main.wait_event(self.ev_done)
+        self.tilde.record_stream(self.main)
+
+
 class TrainStep:
     def __init__(self, model, lr: float = 1e-4, weight_decay: float = 1e-4, grad_clip: float = 0.1,
                  robust_loss: bool = False, step_lr: int = 34000, gamma: float = 0.5, finetune: bool = False,
@@ -82,6 +149,15 @@ class TrainStep:
         self.finetune = finetune
         self.label_fn = label_fn or _default_labels
         self.fused_losses = fused_losses
+        # Labels from NeRF blocks in two parts (review item 2 of round 5): the key points' visibility — the overlap ground truth, the only labels a gradient
+        # depends on — is marched as soon as the geometry phase has produced the key points (on the label stream, under the feature network's forward); the
+        # six predicted-correspondence sets per block ('tilde', 6/7 of the rays) feed only 'nerf_cont', which has no gradient (train_nerf_regtr.py:198-201,
+        # SURVEY.md quirk Q4): they are marched on the label stream while backward runs and complete the step's loss VALUES there.  Same labels, same
+        # losses bit for bit (tests/test_hip_visibility.py, tests/test_hip_bench_labels.py).  DREG_SPLIT_LABELS=0: everything in front of the loss.
+        self.split_labels = bool(int(os.environ.get("DREG_SPLIT_LABELS", "1")))
+        self._label_stream = None
+        # one-wave workgroups of the two background label launches (key points, predicted correspondences): DREG_LABEL_WAVES="kp,tilde", 0 = full width
+        self.label_waves = tuple(int(v) for v in os.environ.get("DREG_LABEL_WAVES", "128,128").split(","))
         # Second stream for the weight / bias gradients of the point-set half's linear layers (Conv3dFn.backward), ~1.3 ms per step.
         # (It exposed the packed-fp32 co-execution fault described in DESIGN.md; the library is built without those instructions
         # and steps are bitwise reproducible with it: tests/test_hip_trunk_exec.py.)  DREG_PG_STREAM=0 turns it off.
@@ -103,13 +179,24 @@ class TrainStep:
         self.optimizer.zero_grad()
         if self.feature_loss.W.grad is not None:
             self.feature_loss.W.grad = None
-        preds = self.model.forward_batch(batch)
+        have_nerf = [bool(d.get("src_nerf_path")) and os.path.exists(d["src_nerf_path"]) and os.path.exists(d.get("tgt_nerf_path", ""))
+                     for d in batch]
+        dev0 = next(self.model.parameters()).device
+        split = self.fused_losses and self.split_labels and dev0.type == "cuda" and all(have_nerf) and len(batch) > 0
+        lab = _SplitLabels(self, batch, dev0) if split else None
+        if lab is not None:
+            self.model.__dict__["_after_geometry"] = lab.after_geometry
+        try:
+            preds = self.model.forward_batch(batch)
+        finally:
+            self.model.__dict__.pop("_after_geometry", None)
         if self.fused_losses:
             # all pairs at once through csrc/losses.hip: labels in the shared row space [6,R], one autograd node
             bt = self.model.last_batched
-            have_nerf = [bool(d.get("src_nerf_path")) and os.path.exists(d["src_nerf_path"]) and os.path.exists(d.get("tgt_nerf_path", ""))
-                         for d in batch]
-            if not any(have_nerf) and self.label_fn is _default_labels:
+            defer = None
+            if lab is not None:
+                gt, tilde, defer = lab.after_forward(bt), None, {}
+            elif not any(have_nerf) and self.label_fn is _default_labels:
                 with torch.no_grad():
                     gt = synth.synthetic_overlap_gt(bt["xyz"])[..., 0]
                     tilde = (bt["corr"][..., 0] + 0.31 * bt["corr"][..., 1] - 0.17 * bt["corr"][..., 2] > 0.0123).float()
@@ -122,7 +209,9 @@ class TrainStep:
                     tls += [s_tl[..., 0], t_tl[..., 0]]
                 gt, tilde = torch.cat(gts, dim=1), torch.cat(tls, dim=1)
             poses = torch.cat([d["pose"].reshape(1, 4, 4) for d in batch]).float()
-            ls = FL.regtr_losses(bt, poses, self.feature_loss, gt, tilde, self.robust)
+            ls = FL.regtr_losses(bt, poses, self.feature_loss, gt, tilde, self.robust, defer=defer)
+            if lab is not None:
+                lab.after_losses(defer)
             total = ls["total"]
             agg = None                       # the fused losses are batch means already (no x len / len round trip: ten tiny launches)
             means = {k: v.detach() for k, v in ls.items()}
@@ -172,13 +261,15 @@ class TrainStep:
         gnorm = self.optimizer.grad_norm()
         if not self.finetune:
             self.scheduler.step()
+        if lab is not None:
+            lab.join()                     # readers of the loss values (this stream) come behind the label stream's completion of 'nerf_cont' / 'total'
         self.last_losses = means if agg is None else {k: v / len(batch) for k, v in agg.items()}
         self.last_preds = preds
         from . import visibility
-        if visibility.OVERRUN.pending:
-            # labels marched from NeRF blocks this step: a persistent launch that ran into its pass bound (points left unlabelled) is reported here
-            # as soon as its counters have arrived — without stalling on this step's own launch (check(wait=True) at checkpoints / the end of a run)
-            visibility.OVERRUN.check()
+        # labels marched from NeRF blocks: a persistent launch that ran into its pass bound (points left unlabelled) is reported here as soon as its
+        # counters have arrived — late (this step's update is applied), without stalling on this step's own launch (check(wait=True) at checkpoints /
+        # the end of a run).  check() takes the watch's lock: `pending` is also filled from the loader / geometry threads.
+        visibility.OVERRUN.check()
         return {"losses": self.last_losses, "grad_norm": gnorm}
 
     def close(self):

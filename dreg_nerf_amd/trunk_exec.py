@@ -305,6 +305,10 @@ class TrunkExecutor:
                 raise L.DregError(f"{name}: {bad[0]} guard band(s) overwritten ({bad[3]} 16-byte words); first: {self.guard_describe(bad[1])} + {bad[2]} bytes")
 
     def guard_check(self):
+        """Scan the guard bands now.  dreg_exec_guard_check synchronises the caller's stream only; the weight / bias gradient launches of a backward
+        pass run on the executor's aux stream, so that stream is drained first — a stray write from one of them is attributed to THIS pass."""
+        if self.device.type == "cuda":
+            aux_stream(self.device).synchronize()
         out = (ctypes.c_longlong * 4)()
         L.check(self.lib.dreg_exec_guard_check(self.h, L.ptr(self.arena), out, L.stream()), "dreg_exec_guard_check")
         return list(out)

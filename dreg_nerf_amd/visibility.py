@@ -56,13 +56,29 @@ def clear_block_cache():
         _block_cache_bytes = 0
 
 
-def load_block(path: str, device):
+_load_tls = threading.local()
+
+
+def _load_staging(n_f32: int, n_u8: int):
+    """This thread's pinned staging buffers for load_block's uploads (allocated once per thread, grown on demand) and the event behind their last upload."""
+    st = getattr(_load_tls, "st", None)
+    if st is None or st["f32"].numel() < n_f32 or st["u8"].numel() < n_u8:
+        if st is not None:
+            st["ev"].synchronize()
+        st = _load_tls.st = {"f32": torch.empty(max(n_f32, 1), dtype=torch.float32).pin_memory(), "u8": torch.empty(max(n_u8, 1), dtype=torch.uint8).pin_memory(),
+                             "ev": torch.cuda.Event()}
+    return st
+
+
+def load_block(path: str, device, cache: bool = True):
     """(NGPradianceField, occupancy binary [r,r,r] bool on device, meta dict) of a reference NeRF block checkpoint
-    (keys: train_ngp_nerf.py:187-209), through a byte-bounded LRU cache."""
+    (keys: train_ngp_nerf.py:187-209), through a byte-bounded LRU cache (cache=False: a block that is used once — grid extraction,
+    eval_pipeline — is neither looked up nor kept).  The device work (uploads, fp16 copy, coarse occupancy bits) is enqueued on the CALLING
+    thread's current stream: loader threads run this under their own stream and hand an event to the consumer."""
     global _block_cache_bytes
     key = (path, str(device))
     with _block_cache_lock:
-        hit = _block_cache.get(key)
+        hit = _block_cache.get(key) if cache else None
         if hit is not None:
             _block_cache.move_to_end(key)
             return hit[:3]
@@ -78,23 +94,65 @@ def load_block(path: str, device):
         snap = torch.load(path, map_location="cpu", weights_only=False)
     meta = {k: snap[k] for k in ("aabb", "unbounded", "grid_resolution", "contraction_type", "render_step_size", "alpha_thre",
                                  "cone_angle", "camera_poses")}
-    with torch.device(device):                                   # parameters allocated on the device, uninitialised: the state_dict's tensors are copied straight in
+    dev = torch.device(device)
+    sd, og = snap["model"], snap["occupancy_grid"]
+    extra = [k for k in sd if k not in ("aabb", "mlp_base.params", "color_mlp.params") and torch.is_tensor(sd[k]) and sd[k].numel() > 0]
+    if extra:
+        raise RuntimeError(f"unexpected non-empty keys in NeRF state_dict: {extra}")
+    res3 = meta["grid_resolution"]
+    res3 = [int(res3)] * 3 if isinstance(res3, int) else [int(v) for v in res3]
+    if getattr(meta["contraction_type"], "name", "AABB") != "AABB":
+        raise NotImplementedError("only ContractionType.AABB is used by the registration data (config.py:63, Objaverse)")
+    binary_h = og["_binary"]
+    if tuple(binary_h.shape) != tuple(res3) or og["_roi_aabb"].shape != (6,):
+        raise RuntimeError(f"occupancy_grid state does not fit grid_resolution {res3}: _binary {tuple(binary_h.shape)}")
+    field_aabb_host = [float(v) for v in sd["aabb"].tolist()]
+    n_occupied = int(binary_h.sum())                            # counted on the host (2 MB): the dense query then needs no readback of it
+    if dev.type == "cuda":
+        # Only what is queried goes to the device, and only as fp16: the 12.6 M fp32 parameters are copied from the mapped file into this thread's
+        # PINNED staging buffer (a plain memcpy), uploaded asynchronously on the calling thread's stream and converted there; the unused EMA densities
+        # (`occs`, 8 MB) are never touched.  (Round 5 built an fp32 module on the device and copied the state_dict into it from pageable memory: 60-130 ms
+        # per block, synchronous copies that also held up other threads' launches.)
+        n_base, n_col = sd["mlp_base.params"].numel(), sd["color_mlp.params"].numel()
+        nb = int(binary_h.numel())
+        st = _load_staging(n_base + n_col, nb)
+        st["ev"].synchronize()                                   # the previous upload from this buffer
+        st["f32"][:n_base].copy_(sd["mlp_base.params"].reshape(-1))
+        st["f32"][n_base:n_base + n_col].copy_(sd["color_mlp.params"].reshape(-1))
+        st["u8"][:nb].copy_(binary_h.reshape(-1).view(torch.uint8) if binary_h.dtype == torch.bool else (binary_h.reshape(-1) != 0).to(torch.uint8))
+        tmp32 = torch.empty(n_base + n_col, dtype=torch.float32, device=dev)
+        tmp32.copy_(st["f32"][:n_base + n_col], non_blocking=True)
+        binary_u8 = torch.empty(res3, dtype=torch.uint8, device=dev)
+        binary_u8.view(-1).copy_(st["u8"][:nb], non_blocking=True)
+        st["ev"].record(torch.cuda.current_stream(dev))
+        base16 = torch.empty(n_base, dtype=torch.float16, device=dev)
+        col16 = torch.empty(n_col, dtype=torch.float16, device=dev)
+        lib = L.load()
+        L.check(lib.dreg_f32_to_f16(tmp32.data_ptr(), L.ptr(base16), n_base, L.stream()), "dreg_f32_to_f16")
+        L.check(lib.dreg_f32_to_f16(tmp32.data_ptr() + 4 * n_base, L.ptr(col16), n_col, L.stream()), "dreg_f32_to_f16")
+        del tmp32
+        field = ngp.NGPradianceField.from_inference_copies(field_aabb_host, bool(meta["unbounded"]), base16, col16, dev)
+        binary = binary_u8.view(torch.bool)
+    else:
         field = ngp.NGPradianceField(meta["aabb"], unbounded=bool(meta["unbounded"]), init=False)
-    occ = ngp.OccupancyGrid(meta["aabb"], meta["grid_resolution"], meta["contraction_type"])
-    field.load_state_dict(snap["model"])
-    occ.load_state_dict(snap["occupancy_grid"])
-    del snap
-    field = field.to(device).eval().freeze_for_inference()     # fp16 inference copies only: the block is never trained here
-    binary = occ.binary.to(device)
+        field.load_state_dict(sd)
+        field = field.eval().freeze_for_inference()
+        binary = binary_h.clone()
+    cam_centres = torch.as_tensor(meta["camera_poses"])[..., :3, 3].float().contiguous().clone()
+    meta = {k: (meta[k].clone() if torch.is_tensor(meta[k]) else meta[k]) for k in meta}       # (views into the mapped file would keep it mapped)
+    del snap, sd, og, binary_h
     nbytes = _block_bytes(field, binary)
     # small meta tensors are cloned: a view into the memory-mapped checkpoint would keep one file mapping alive per cached block
     kept = {k: (meta[k].clone() if torch.is_tensor(meta[k]) else meta[k]) for k in ("aabb", "render_step_size", "cone_angle", "alpha_thre", "camera_poses")}
     # what every call needs, converted ONCE: camera centres on the device, the aabb as host floats (a .tolist() of a device tensor or an
     # H2D copy per call is a host sync per call: eight per training step, each draining the queue the host had run ahead on)
-    kept["cam_centres_dev"] = torch.as_tensor(meta["camera_poses"])[..., :3, 3].float().contiguous().to(device)
+    kept["cam_centres_dev"] = cam_centres.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else cam_centres   # (a copy from pageable memory would stall the host on everything queued)
     kept["aabb_host"] = [float(v) for v in (meta["aabb"].tolist() if torch.is_tensor(meta["aabb"]) else meta["aabb"])]
+    kept["n_occupied"], kept["grid_resolution"], kept["contraction_type"], kept["unbounded"] = n_occupied, meta["grid_resolution"], meta["contraction_type"], bool(meta["unbounded"])
     kept["binary_u8"] = binary.contiguous().view(torch.uint8) if binary.dtype == torch.bool else binary.to(torch.uint8).contiguous()
     kept["coarse_bits"] = coarse_occupancy_bits(kept["binary_u8"])
+    if not cache:
+        return field, binary, kept
     with _block_cache_lock:
         if key in _block_cache:                                  # the other thread loaded it meanwhile
             _block_cache.move_to_end(key)
@@ -185,8 +243,9 @@ class _OverrunWatch:
     """The persistent kernels set bit 63 of a launch's ray counter(s) when a wave leaves the march loop through its safety bound with rays
     still queued or in flight (their points would stay unlabelled).  Reading the counters back right away would be a host sync per label
     launch; instead they are copied to a pinned slot behind the launch and looked at when a later call finds the copy done (or by
-    check(wait=True): tests, the end of an extraction, the end of a training step — train_step.TrainStep.step — so that an overrun is raised
-    before the optimizer has used labels that were never written).  A launch with more counters than a slot holds is watched in several slots.
+    check(wait=True): tests, the end of an extraction, a checkpoint).  The report is therefore LATE in training: train_step.TrainStep.step looks
+    (without waiting) after its optimizer step, so a launch that hit its pass bound has already trained on unlabelled points for at least that step
+    when the error is raised — the run stops, the checkpoint before it is the last clean state.  A launch with more counters than a slot holds is watched in several slots.
     Labels are requested from the loader thread and from the geometry thread: the slot lists are guarded by a lock."""
 
     SLOTS, WORDS = 8, 64           # pinned slots (allocated once), ray counters per slot
@@ -257,7 +316,7 @@ def _desc_staging(nbytes: int, device):
 
 
 @torch.no_grad()
-def compute_visibility_scores_batched(requests, cut_off: float = 0.5) -> List[torch.Tensor]:
+def compute_visibility_scores_batched(requests, cut_off: float = 0.5, max_waves: int = 0) -> List[torch.Tensor]:
     """requests: list of (xyz [L,N,3], nerf_model_path) -> list of [L,N,1] float {0,1}, the labels of compute_visibility_score for each —
     from ONE launch over all blocks (a training step asks for 8: two per pair).  A call's duration is its longest ray, so eight
     launches cost eight tails; here every wave of one persistent launch works through all the blocks' ray queues."""
@@ -296,7 +355,8 @@ def compute_visibility_scores_batched(requests, cut_off: float = 0.5) -> List[to
     if host_ev is not None:
         host_ev.record(torch.cuda.current_stream(device))       # the staging buffer may be refilled once this copy has run
     OVERRUN.check()
-    L.check(lib.dreg_surface_visibility_multi(L.ptr(descs), len(requests), total, L.stream()), "dreg_surface_visibility_multi")
+    # max_waves > 0: a background launch (fewer resident waves, less LDS taken from kernels on other streams; see include/dreg_nerf.h)
+    L.check(lib.dreg_surface_visibility_multi_waves(L.ptr(descs), len(requests), total, int(max_waves), L.stream()), "dreg_surface_visibility_multi_waves")
     OVERRUN.watch(buf[q_off:q_off + 2 * len(requests)])
     if device.type == "cuda":
         cur = torch.cuda.current_stream(device)

@@ -46,10 +46,22 @@ def main():
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", cfg.local_rank)))
     torch.cuda.set_device(dev)
     pattern = os.path.join(cfg.root_dir, cfg.dataset, "nerf_models", cfg.scene or "*", "block_*", "model.pth")
-    for i, path in enumerate(sorted(glob.glob(pattern))):
-        if i % world == rank:
-            n = extract_block(path, dev)
-            print(f"[rank {rank}] {path}: {n} voxels kept", flush=True)
+    mine = [p for i, p in enumerate(sorted(glob.glob(pattern))) if i % world == rank]
+    if os.environ.get("DREG_SERIAL_EXTRACT") == "1":       # the block-at-a-time form (what the reference does); same files, byte for byte
+        for path in mine:
+            print(f"[rank {rank}] {path}: {extract_block(path, dev)} voxels kept", flush=True)
+        return
+    # checkpoint reads, queries and file writes of different blocks overlapped (dreg_nerf_amd/eval_pipeline.py)
+    from dreg_nerf_amd.eval_pipeline import ExtractionPipeline
+    with ExtractionPipeline(dev) as pipe:
+        done = []
+        for ex in pipe.run(mine):
+            done.append(ex)
+            while len(done) > 4:            # report a few blocks behind the GPU: reading a count back waits for that block's query only
+                e = done.pop(0)
+                print(f"[rank {rank}] {e.path}: {e.kept()} voxels kept", flush=True)
+        for e in done:
+            print(f"[rank {rank}] {e.path}: {e.kept()} voxels kept", flush=True)
 
 
 if __name__ == "__main__":

@@ -539,6 +539,11 @@ int dreg_infonce_rows(float* logits, const float* xyz, const float* pose, const 
 int dreg_reg_losses_final(const float* partial, const float* loss_row, const float* count, const int* probs, const int* src_off,
                           float* out, int P, int L, float eps, float w_overlap, float w_cont, float w_feat, float w_corr,
                           void* stream);
+/* dreg_reg_point_losses accepts tilde = NULL: the label-consistency term ('nerf_cont', train_nerf_regtr.py:198-201 — no gradient) is
+ * then left out (partial[.][1] = 0, out[1] = 0, out[4] without it) and completed by this call once the 'tilde' labels exist (the training step marches them
+ * on a side stream under backward): partial[.][1], out[1] and out[4] become bit-identical to the one-call form's. */
+int dreg_nerf_cont_deferred(const float* gt, const float* tilde, const int* probs, float* partial, float* out, int P, int L, int R,
+                            float w_overlap, float w_cont, float w_feat, float w_corr, void* stream);
 
 /* batched_grid_subsample (grid_downsample.py:6-44; MinkowskiEngine UNWEIGHTED_AVERAGE): mean of (xyz | feat) over rows
  * sharing (batch, floor(p/dl)); rows out ordered by (batch, ix, iy, iz).  Outputs sized for N rows; n_out / batch_counts
@@ -675,6 +680,9 @@ int dreg_surface_visibility_fill_desc(void* host_desc, const float* cams, const 
                                       int rx, int ry, int rz, int Nc, int Np, float render_step_size, float cut_off, float early_stop_eps,
                                       float alpha_thre, void* queue, const uint32_t* coarse_bits);
 int dreg_surface_visibility_multi(const void* descs_dev, int n, long total_rays, void* stream);
+/* the same launch with at most max_waves one-wave workgroups (0 = default 4096): a background launch next to LDS-hungry kernels on another stream
+ * (each workgroup holds 18.7 KB of LDS while the launch runs); same labels, proportionally longer */
+int dreg_surface_visibility_multi_waves(const void* descs_dev, int n, long total_rays, int max_waves, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- active-set 3^3 convolution with
  * staged-neighbourhood reuse (csrc/conv_brick.hip): the FPN head layers upsample_transform_{1,2} / pyramid_transformation_1 and their
