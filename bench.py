@@ -417,8 +417,9 @@ def ngp_measure(args, rank, world, dev):
     dirs = sg._viewdirs.to(dev)
 
     def block():
-        w, rgb, a, idx, dm = sg.query_dense(f, dev, jitter=jitter)
-        return ngp.build_voxel_grid(w, rgb, a, idx, dm, res)
+        # the evaluation pipeline's form of a block's query (dreg_nerf_amd/eval_pipeline.py): the occupied-cell count is known on the host from the
+        # checkpoint's occupancy grid, the kept-cell count stays on the device — no host readback per block (rounds 2-5 measured the form with two)
+        return sg.query_dense_async(f, dev, jitter=jitter, n_known=npts)[5:8]
 
     def sync():
         if world > 1:
@@ -454,7 +455,7 @@ def ngp_measure(args, rank, world, dev):
         return s.elapsed_time(e) / n
 
     # the product path's first half: cell lists (count, scan, readback of N, build) + encode + MLP with alpha / mask
-    ms_d = ev_time(lambda: sg._cells_and_density_fused(f, dev, 0.7, jitter))
+    ms_d = ev_time(lambda: sg._cells_and_density_fused(f, dev, 0.7, jitter, n_known=npts))
     raw = f.query_raw(world_pts)[1]
     ms_c = ev_time(lambda: f.query_rgb_mean(raw, dirs))
     fl_c = npts * (18 * (64 * 64 + 16 * 64) + 64 * 32) * 2.0        # colour net x 18 directions (geometry half of layer 1 once)
@@ -463,10 +464,10 @@ def ngp_measure(args, rank, world, dev):
     rf = {"bound": "mfma", "kernel": "ngp_rgb_chunks_kernel", "achieved": fl_c / ms_c / 1e9, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
           "frac": fl_c / ms_c / 1e9 / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms_c, "algorithmic_flops_per_launch": fl_c,
           "note": "fp16 MFMA (same dense peak as bf16); HIP events on the launch stream, 5 launches",
-          "density_kernel": {"kernel": "grid_occupied_count + grid_scan2 + [readback of N] + grid_occupied_build + ngp_encode_xcd_kernel + ngp_density_kernel<1,true>", "avg_launch_ms": ms_d, "Gpts_per_s": npts / ms_d / 1e6,
+          "density_kernel": {"kernel": "grid_occupied_count + grid_scan2 + grid_occupied_build + ngp_encode_xcd_kernel + ngp_density_kernel<1,true>", "avg_launch_ms": ms_d, "Gpts_per_s": npts / ms_d / 1e6,
                              "gather_TBps": gather / ms_d / 1e9, "gather_frac_of_hbm_peak": gather / ms_d / 1e9 / (HBM_PEAK_GBPS / 1e3),
                              "mlp_TFLOPs": fl_d / ms_d / 1e9,
-                             "note": "avg_launch_ms = the whole first half of a block's query: occupied-cell lists from the occupancy volume (no torch.nonzero), positions, encode, MLP + alpha / mask (five launches + the zero fill of the voxel grid + one host readback); 512 B gathered per point from the 25.2 MB fp16 table, which lives in the 256 MB Infinity Cache — the encode launch pins two levels to every XCD's 4 MB L2 and runs a wave's lanes along the tables' fastest axis, so the gather rate is a cache rate, not an HBM rate; `traffic` (PMC) is what the encode + MLP launches moved at the memory side"}}
+                             "note": "avg_launch_ms = the whole first half of a block's query: occupied-cell lists from the occupancy volume (no torch.nonzero), positions, encode, MLP + alpha / mask (five launches + the zero fill of the voxel grid; the occupied-cell count comes from the host side of the checkpoint load: no readback); 512 B gathered per point from the 25.2 MB fp16 table, which lives in the 256 MB Infinity Cache — the encode launch pins two levels to every XCD's 4 MB L2 and runs a wave's lanes along the tables' fastest axis, so the gather rate is a cache rate, not an HBM rate; `traffic` (PMC) is what the encode + MLP launches moved at the memory side"}}
     rf["traffic"], src = pmc_traffic("ngp_rgb_chunks_kernel", "ngp", args.ngp_radius == 1.0)
     if src:
         rf["traffic_source"] = src

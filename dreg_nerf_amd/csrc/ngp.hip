@@ -925,7 +925,7 @@ __global__ __launch_bounds__(1024) void grid_scan2_kernel(int* __restrict__ a0, 
 __global__ __launch_bounds__(256) void grid_occupied_build_kernel(const uint8_t* __restrict__ binary, const uint16_t* __restrict__ pre, const int* __restrict__ colbase,
                                                                    const int* __restrict__ rowbase, const float* __restrict__ jitter,
                                                                    int64_t* __restrict__ indices, int* __restrict__ order, float* __restrict__ world,
-                                                                   float* __restrict__ world_slot, int rx, int ry, int rz,
+                                                                   float* __restrict__ world_slot, int rx, int ry, int rz, int N,
                                                                    float lo0, float lo1, float lo2, float hi0, float hi1, float hi2)
 {
     const int lane = threadIdx.x & 63;
@@ -941,13 +941,17 @@ __global__ __launch_bounds__(256) void grid_occupied_build_kernel(const uint8_t*
         if (occ) {
             const int n = n0 + __popcll(m & ((1ull << lane) - 1ull));
             const int j = colbase[z * ry + y] + (int)pre[f];
-            const float u0 = ((float)xx + jitter[(size_t)n * 3]) / (float)rx, u1 = ((float)y + jitter[(size_t)n * 3 + 1]) / (float)ry,
-                        u2 = ((float)z + jitter[(size_t)n * 3 + 2]) / (float)rz;
-            const float w0 = u0 * (hi0 - lo0) + lo0, w1 = u1 * (hi1 - lo1) + lo1, w2 = u2 * (hi2 - lo2) + lo2;
-            indices[n] = f;
-            order[j] = n;
-            world[(size_t)n * 3] = w0; world[(size_t)n * 3 + 1] = w1; world[(size_t)n * 3 + 2] = w2;
-            world_slot[(size_t)j * 3] = w0; world_slot[(size_t)j * 3 + 1] = w1; world_slot[(size_t)j * 3 + 2] = w2;
+            // N is the CALLER's count of occupied cells (the size of every output): a caller that passed a wrong one — the pipeline takes it from the host
+            // side of the checkpoint load instead of reading totals[0] back — must not write outside its buffers (it compares totals[0] with N later)
+            if (n < N && j < N) {
+                const float u0 = ((float)xx + jitter[(size_t)n * 3]) / (float)rx, u1 = ((float)y + jitter[(size_t)n * 3 + 1]) / (float)ry,
+                            u2 = ((float)z + jitter[(size_t)n * 3 + 2]) / (float)rz;
+                const float w0 = u0 * (hi0 - lo0) + lo0, w1 = u1 * (hi1 - lo1) + lo1, w2 = u2 * (hi2 - lo2) + lo2;
+                indices[n] = f;
+                order[j] = n;
+                world[(size_t)n * 3] = w0; world[(size_t)n * 3 + 1] = w1; world[(size_t)n * 3 + 2] = w2;
+                world_slot[(size_t)j * 3] = w0; world_slot[(size_t)j * 3 + 1] = w1; world_slot[(size_t)j * 3 + 2] = w2;
+            }
         }
         n0 += __popcll(m);
     }
@@ -1026,7 +1030,7 @@ int dreg_grid_occupied_build(const uint8_t* binary, void* workspace, const float
     if (!binary || !workspace || !jitter || !indices || !order || !world || !world_slot) return DREG_EINVAL;
     const OccWs w = occ_ws(workspace, rx, ry, rz);
     hipLaunchKernelGGL(grid_occupied_build_kernel, dim3((rx * ry + 3) / 4), dim3(256), 0, (hipStream_t)stream, binary, w.pre, w.colcnt, w.rowcnt, jitter,
-                       indices, order, world, world_slot, rx, ry, rz, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5]);
+                       indices, order, world, world_slot, rx, ry, rz, N, aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5]);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }

@@ -118,21 +118,50 @@ def augment_sparse(data: dict, jitter: float = 0.005, std: float = 0.1, gen=None
     sb = data[side + "_sparse"]
     dev = sb.vals.device
     c = sb.vals[:, :3].sum(dim=0) / sb.n_voxels()      # mean over all voxels of the (zero-filled) dense grid
-    Tc = torch.eye(4, device=dev)
-    Tc[:3, 3] = -c
-    P = torch.linalg.inv(Tc) @ perturb.to(dev) @ Tc
+    # P = T(+c) perturb T(-c): x -> R (x - c) + t + c.  Rigid transforms are composed and inverted in closed form ([R t]^-1 = [R^T, -R^T t]) with small
+    # device ops: torch.linalg.inv on the device is a solver call with a host readback, and a copy from pageable memory stalls the host — several
+    # syncs per sample held the loader thread at ~8 ms per sample (the reference's arithmetic is inv(Tc) @ perturb @ Tc: same values to ~1e-7)
+    pt = perturb.to(torch.float32)
+    pt = pt.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else pt.to(dev)
+    R, t = pt[:3, :3], pt[:3, 3]
+    P = _rigid(R, t + c - R @ c)
     vals = sb.vals.clone()
     vals[:, :3] = vals[:, :3] @ P[:3, :3].T + P[:3, 3]
     data[side + "_sparse"] = SparseBlock(sb.idx, vals, sb.res)
-    pose = data["pose"].to(dev)
-    data["pose"] = pose @ torch.linalg.inv(P) if psrc else P @ pose
+    pose = data["pose"]
+    pose = pose.to(dev) if (pose.device == dev or dev.type != "cuda") else pose.pin_memory().to(dev, non_blocking=True)
+    data["pose"] = pose @ _rigid_inverse(P) if psrc else P @ pose
     swap = draws["swap"] if "swap" in draws else (rng.random() > 0.5)
     if swap:
         data["src_sparse"], data["tgt_sparse"] = data["tgt_sparse"], data["src_sparse"]
         if "src_nerf_path" in data:
             data["src_nerf_path"], data["tgt_nerf_path"] = data["tgt_nerf_path"], data["src_nerf_path"]
-        data["pose"] = torch.linalg.inv(data["pose"])
+        data["pose"] = _rigid_inverse(data["pose"])
     return data
+
+
+def _rigid(R: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """[R t; 0 1] as a 4x4 on R's device (no host round trip)."""
+    top = torch.cat([R, t.reshape(3, 1)], dim=1)
+    return torch.cat([top, top.new_tensor([[0.0, 0.0, 0.0, 1.0]]) if top.device.type != "cuda" else _last_row(top.device)], dim=0)
+
+
+_LAST_ROW = {}
+
+
+def _last_row(dev):
+    r = _LAST_ROW.get(str(dev))
+    if r is None:
+        r = _LAST_ROW[str(dev)] = torch.tensor([[0.0, 0.0, 0.0, 1.0]]).pin_memory().to(dev, non_blocking=True)
+    return r
+
+
+def _rigid_inverse(T: torch.Tensor) -> torch.Tensor:
+    """Inverse of a rigid 4x4 (or [1,4,4] / [4,4]) in closed form."""
+    shape = T.shape
+    M = T.reshape(4, 4)
+    Rt = M[:3, :3].T
+    return _rigid(Rt, -(Rt @ M[:3, 3])).reshape(shape)
 
 
 def augment(data: dict, jitter: float = 0.005, std: float = 0.1, draws=None) -> dict:
@@ -192,6 +221,9 @@ class NeRFRegDataset:
         their NeRF checkpoint exists (eval_nerf_regtr.py --extract_grids writes the grids itself)."""
         self.mode = split
         self.sparse, self.device = sparse, device
+        # sparse blocks that were uploaded once stay on the device (0.5-1 MB each: the 3,284 blocks of an Objaverse epoch are ~3 GB): from the second epoch on a
+        # sample costs its augmentation only — no file read, no upload (DREG_BLOCK_DEVICE_CACHE=0 turns it off)
+        self._dev_blocks = {} if (device is not None and torch.device(device).type == "cuda" and os.environ.get("DREG_BLOCK_DEVICE_CACHE", "1") == "1") else None
         self.meta = []
         scenes = load_split(json_dir, dataset)[split]
         skipped = []
@@ -224,6 +256,16 @@ class NeRFRegDataset:
     def __getitem__(self, index):
         return self.get(index)
 
+    def _sparse_block(self, block_dir: str) -> SparseBlock:
+        if self._dev_blocks is None:
+            return load_block_sparse(block_dir)
+        sb = self._dev_blocks.get(block_dir)
+        if sb is None:
+            h = load_block_sparse(block_dir)
+            sb = SparseBlock(h.idx.pin_memory().to(self.device, non_blocking=True), h.vals.pin_memory().to(self.device, non_blocking=True), h.res)
+            self._dev_blocks[block_dir] = sb
+        return sb
+
     def draw_block_order(self, index, rng=None):
         """The shuffle `get` applies to a scene's block ids (quirk Q15), as a call of its own: evaluation draws it for every scene in scene order on
         every rank and passes it back as get(..., block_order=), so a scene's source / target assignment does not depend on how scenes are sharded."""
@@ -238,13 +280,13 @@ class NeRFRegDataset:
         ids = list(block_order) if block_order is not None else self.draw_block_order(index, rng)  # also in test mode, as the reference (quirk Q15)
         s, t = sm["blocks"][ids[0]], sm["blocks"][ids[1]]
         if self.sparse:
-            data = {"src_sparse": load_block_sparse(s["dir"]), "tgt_sparse": load_block_sparse(t["dir"]),
+            data = {"src_sparse": self._sparse_block(s["dir"]), "tgt_sparse": self._sparse_block(t["dir"]),
                     "src_nerf_path": os.path.join(s["dir"], "model.pth"), "tgt_nerf_path": os.path.join(t["dir"], "model.pth"),
                     "pose": (t["transform"] @ torch.linalg.inv(s["transform"]))[None],
                     "scene": sm["scene"], "dataset": sm["dataset"], "index": index, "block_list": ids[:2]}
             if self.device is not None:
                 data["src_sparse"], data["tgt_sparse"] = data["src_sparse"].to(self.device), data["tgt_sparse"].to(self.device)
-                data["pose"] = data["pose"].to(self.device)
+                data["pose"] = data["pose"].pin_memory().to(self.device, non_blocking=True) if torch.device(self.device).type == "cuda" else data["pose"].to(self.device)
             if self.mode == "train":
                 data["pose"] = data["pose"][0]
                 data = augment_sparse(data, gen=gen, rng=rng, cpu_gen=cpu_gen)

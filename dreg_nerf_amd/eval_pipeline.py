@@ -253,7 +253,7 @@ class ExtractionPipeline:
         # density-field twins first (eval_ngp_nerf.py:350-381), then surface AND density (:383-412)
         ex.dgrid, ex.dmask, kd = ngp.write_kept_async(rows, world, rgb, alpha, indices, dkeep, res, grid=rows[3])
         ex.grid, ex.mask, k = ngp.write_kept_async(rows, world, rgb, alpha, indices, keep, res)
-        counts = torch.cat([kd, k])
+        counts = torch.cat([kd, k, rows[1][0:1]])       # (+ the device's own count of occupied cells: compared with the loader's before anything is written)
         e[3].record(main)
         h4 = time.perf_counter()
         for key, dt in (("cells_density", h1 - h0), ("colour", h2 - h1), ("surface", h3 - h2), ("grid_writers", h4 - h3)):
@@ -343,6 +343,12 @@ class ExtractionPipeline:
             except BaseException as e:                  # noqa: BLE001
                 self._dispatch_err = self._dispatch_err or e
             if out_dir is None:
+                slot.refs = None
+                self._free.put(slot)
+                continue
+            if int(slot.counts[2]) != n and self._debug_skip != "copy":
+                # the query ran with the loader's host-side count of occupied cells; the device counted a different number: nothing of this block is written
+                self._dispatch_err = self._dispatch_err or RuntimeError(f"{out_dir}: occupancy grid has {int(slot.counts[2])} occupied cells on the device, {n} on the host")
                 slot.refs = None
                 self._free.put(slot)
                 continue
@@ -439,7 +445,7 @@ class ExtractionPipeline:
         paths = list(paths)
         loads = {}
         nxt = 0
-        self._counts = torch.zeros(max(len(paths), 1), 2, dtype=torch.int32).pin_memory()     # (density-mask, kept) voxels per block, filled behind each extraction
+        self._counts = torch.zeros(max(len(paths), 1), 3, dtype=torch.int32).pin_memory()     # (density-mask, kept) voxels per block, filled behind each extraction
 
         def top_up(upto):
             nonlocal nxt

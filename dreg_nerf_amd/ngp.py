@@ -387,6 +387,17 @@ class SampleGrid(nn.Module):
         return world, rgb, alpha[:, None], indices, mask
 
     @torch.no_grad()
+    def query_dense_async(self, radiance_field: NGPradianceField, dev, density_thre: float = 0.7, jitter: Optional[torch.Tensor] = None, n_known: int = None):
+        """query_dense + build_voxel_grid for a caller that knows the number of occupied cells (counted on the host when the occupancy grid was
+        loaded): NO host readback anywhere.  Returns (world, rgb, alpha [N], indices, keep uint8 [N], voxel_grid [r,r,r,7], voxel_mask buffer [N],
+        count int32 [1] on the device = valid length of the mask, rows) — `rows` lets write_kept_async write further grids over other masks of
+        the same cells.  The form the evaluation pipeline and bench.py --ngp run (dreg_nerf_amd/eval_pipeline.py)."""
+        world, indices, raw, alpha, keep, rows = self._cells_and_density_fused(radiance_field, torch.device(dev), density_thre, jitter, n_known=n_known)
+        rgb = radiance_field.query_rgb_mean(raw, self._viewdirs_on(dev))
+        grid, mask, count = write_kept_async(rows, world, rgb, alpha, indices, keep, int(rows[2][0]), grid=rows[3])
+        return world, rgb, alpha, indices, keep, grid, mask, count, rows
+
+    @torch.no_grad()
     def _cells_and_density_fused(self, radiance_field: NGPradianceField, dev, density_thre: float, jitter: Optional[torch.Tensor],
                                  n_known: Optional[int] = None):
         """The first half of the fused dense query: occupied cells (ascending), their jittered positions, density / raw features / alpha /

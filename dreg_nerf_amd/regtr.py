@@ -459,6 +459,9 @@ class NeRFRegTr(nn.Module):
         else:
             cond, corr, ov = T.encode_decode_batched(P, feats_all, xyz_all, tab, self.position_embedding)
         outs = []
+        # `pose` is returned DETACHED (requires_grad False), on purpose: the reference's compute_rigid_transform (se3.py:89-140) sits inside autograd, but none of
+        # its training losses reads `pose` (train_nerf_regtr.py:186-229 use the correspondences, overlap scores and features), so the weighted Kabsch solve has
+        # a forward kernel only.  A pose loss added by a user gets NO gradient through `pose` (tests/test_hip_regtr.py asserts the flag).
         poses = A.weighted_kabsch_pairs(xyz_all, corr, ov, tab)   # [P,6,3,4]: every (pair, layer) solve in one launch
         if not self.training and self.__dict__.get("_stem_violation") is not None:
             # evaluation: a call that was handed a grid with values outside its voxel_mask must not return a plausible pose — the poses of THIS call become

@@ -413,6 +413,7 @@ class TrunkExecutor:
 
 
 _AUX = {}
+AUX_CU_MASK = int(__import__("os").environ.get("DREG_AUX_CU_MASK", "0"))     # measurement only, see aux_stream
 
 
 def aux_stream(device) -> "torch.cuda.Stream":
@@ -426,7 +427,20 @@ def aux_stream(device) -> "torch.cuda.Stream":
         # DREG_AUX_PRIORITY=torch: a plain torch stream.
         prio = __import__("os").environ.get("DREG_AUX_PRIORITY", "low")
         st = None
-        if prio != "torch" and device.type == "cuda":
+        if AUX_CU_MASK and device.type == "cuda":
+            # MEASUREMENT (tools/ab_step.py aux:cumask; round-5 review item 6): the second stream restricted to a subset of the 256 CUs
+            # (hipExtStreamCreateWithCUMask: 8 words, bit i = CU i), so that weight-gradient workgroups cannot take LDS / issue slots on the others
+            words = {1: [0xFFFFFFFF] * 4 + [0] * 4, 2: [0x55555555] * 8, 3: [0xFFFFFFFF] * 2 + [0] * 6, 4: [0x11111111] * 8, 5: [0xFFFFFFFF] * 6 + [0] * 2,
+                     6: [0x0000FFFF] * 8, 7: [0x000000FF] * 8}[int(AUX_CU_MASK)]
+            hip = ctypes.CDLL("libamdhip64.so")
+            h = ctypes.c_void_p()
+            arr = (ctypes.c_uint32 * 8)(*words)
+            with torch.cuda.device(device):
+                rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, arr)
+            if rc != 0 or not h.value:
+                raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {rc}")
+            st = torch.cuda.ExternalStream(h.value, device=device)
+        if st is None and prio != "torch" and device.type == "cuda":
             try:
                 hip = ctypes.CDLL("libamdhip64.so")
                 least, greatest = ctypes.c_int(), ctypes.c_int()

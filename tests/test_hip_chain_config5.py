@@ -64,6 +64,12 @@ def test_extract_then_register_at_the_baseline_size_128(tmp_path):
     _chain(tmp_path, 128, (0.75, 0.88), 30000, 1)
 
 
+@pytest.mark.skipif(os.environ.get("DREG_SLOW") != "1", reason="eight 128^3 oracle forwards on the host (~15-20 min): run with DREG_SLOW=1; the round's record is profiles/r06_chain128_all_scenes_oracle.txt")
+def test_extract_then_register_at_128_every_scene_rederived_by_the_oracle(tmp_path):
+    """The 128^3 chain with EVERY row of metrics_test.json re-derived by the reference-pinned CPU oracle (the default variant above re-derives one scene)."""
+    _chain(tmp_path, 128, (0.75, 0.88), 30000, None)
+
+
 def _chain(tmp_path, RES, shell, min_occ, oracle_scenes):
     root, jdir = tmp_path / "root", tmp_path / "json"
     jdir.mkdir()

@@ -100,6 +100,38 @@ def test_dense_query_and_grid_writer(tmp_path):
     assert torch.load(str(tmp_path / "voxel_grid.pt")).shape == (res, res, res, 7)
 
 
+def test_query_dense_async_equals_the_form_with_readbacks():
+    """SampleGrid.query_dense_async (no host readback: the occupied-cell count comes from the caller, the kept-cell count stays on the device — the
+    evaluation pipeline's and bench.py --ngp's form) against query_dense + build_voxel_grid, bit for bit; a second mask over the same cells through
+    write_kept_async (eval_ngp_nerf.py writes the density-mask grid and the density AND surface grid: :350-412)."""
+    res = 64
+    g = torch.Generator().manual_seed(21)
+    f = ngp.NGPradianceField(AABB)
+    with torch.no_grad():
+        f.mlp_base.params[:3072] = torch.randn(3072, generator=g) * 0.5
+        f.mlp_base.params[3072:] = torch.randn(f.mlp_base.params.numel() - 3072, generator=g)
+        f.color_mlp.params.copy_(torch.randn(7168, generator=g) * 0.2)
+    f = f.to(DEV)
+    binary = torch.rand(res, res, res, generator=g) < 0.12
+    sg = ngp.SampleGrid(AABB, res).to(DEV)
+    sg.set_binary_fields(binary.to(DEV))
+    n = int(binary.sum())
+    jitter = torch.rand(n, 3, generator=g).to(DEV)
+    w0, rgb0, a0, idx0, dm0 = sg.query_dense(f, DEV, jitter=jitter)
+    grid0, mask0 = ngp.build_voxel_grid(w0, rgb0, a0, idx0, dm0, res)
+    w1, rgb1, a1, idx1, keep1, grid1, mask1, cnt1, rows = sg.query_dense_async(f, DEV, jitter=jitter, n_known=n)
+    k = int(cnt1)
+    assert 50 < k < n and k == mask0.numel()
+    assert torch.equal(w0, w1) and torch.equal(rgb0, rgb1) and torch.equal(a0[:, 0], a1) and torch.equal(idx0, idx1) and torch.equal(dm0.view(torch.uint8), keep1)
+    assert torch.equal(grid0, grid1) and torch.equal(mask0, mask1[:k])
+    # a second, smaller mask over the same query
+    sub = keep1 & (torch.rand(n, generator=g) < 0.5).to(DEV).view(torch.uint8)
+    grid2, mask2, cnt2 = ngp.write_kept_async(rows, w1, rgb1, a1, idx1, sub, res)
+    want_g, want_m = ngp.build_voxel_grid(w1, rgb1, a1[:, None], idx1, sub.view(torch.bool), res)      # (the scatter form: a mask without row tables)
+    assert int(cnt2) == want_m.numel() and torch.equal(mask2[:int(cnt2)], want_m) and torch.equal(grid2, want_g)
+    assert int(rows[1][0]) == n      # the device's own count of occupied cells: eval_pipeline compares it with the count it passed before a block's files are written
+
+
 def test_unbounded_contraction_and_per_point_directions_vs_oracle():
     """NGPradianceField(unbounded=True).query_density and query_rgb / forward with one direction per point
     (conerf/radiance_fields/ngp.py:41-63,163-167,178-208)."""

@@ -158,7 +158,8 @@ def _emu(golden_dir, name):
 # bf16: direct bounds for the well-conditioned quantities (measured: losses <= 1.1 %, parameter delta <= 0.2 %, BatchNorm statistics
 # <= 0.2 %), yardstick-relative bounds (K = 3) with these floors for pose and gradients.  fp32: direct bounds.
 TOL_BF16 = {"loss": 2e-2, "loss_feature": 4e-2, "pose": 2e-3, "gnorm": 2e-2, "probe": 2e-2, "dnorm": 1e-2, "bn": 1e-2, "K": 3.0}
-TOL_FP32 = {"loss": 1e-3, "loss_feature": 5e-3, "pose": 5e-4, "gnorm": 2e-2, "probe": 2e-3, "dnorm": 5e-3, "bn": 1e-3}
+TOL_FP32 = {"loss": 1e-3, "loss_feature": 5e-3, "pose": 1e-4,      # pose: the north-star tolerance (rotation / translation within 1e-4 of the reference; measured 1.7e-5 at 128^3)
+             "gnorm": 2e-2, "probe": 2e-3, "dnorm": 5e-3, "bn": 1e-3}
 
 
 def test_bf16_product_step_matches_reference_golden_64(golden_dir):

@@ -62,7 +62,10 @@ def test_train_step_64_fp32(golden_dir):
     for k in ("overlap", "nerf_cont", "feature", "corr", "total"):
         # 'feature' thresholds pairwise distances (r_p, r_n): one anchor flipping moves it by ~1/N
         np.testing.assert_allclose(float(losses[k].detach()), float(g["loss_" + k]), rtol=5e-3 if k == "feature" else 1e-3)
-    np.testing.assert_allclose(pred["pose"].detach().cpu().numpy(), g["pose"], atol=5e-4)
+    np.testing.assert_allclose(pred["pose"].detach().cpu().numpy(), g["pose"], atol=1e-4)      # north-star tolerance, train-mode BatchNorm
+    # the pose head has no backward here (se3.py:89-140 is inside autograd in the reference, but no loss of train_nerf_regtr.py:186-229 reads `pose`):
+    # it is returned detached, explicitly — a pose loss added on top must use the correspondences / overlap scores, which do carry gradients
+    assert pred["pose"].requires_grad is False and pred["src_kp_warped"][0].requires_grad and pred["src_overlap"][0].requires_grad
     losses["total"].backward()
     named = dict(m.named_parameters())
     groups = {"resnet": "fpn3d.backbone_net.", "fpn_head": "fpn3d.feature_pyramid.",

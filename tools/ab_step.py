@@ -22,6 +22,11 @@ if setter.startswith("opt:"):
     def fn(v): trunk_exec.OPTS[setter[4:]] = v
 elif setter == "ps:group_wgrad":
     def fn(v): pointset_exec.GROUP_WGRAD = bool(v)
+elif setter == "aux:cumask":      # 0 = the default low-priority second stream; 1..7 = CU masks of trunk_exec.aux_stream
+    def fn(v):
+        trunk_exec.AUX_CU_MASK = v
+        trunk_exec._AUX.clear()
+        ts._pg_stream = None
 else:
     fn = getattr(L.use_probe(), setter)
 dev = torch.device("cuda", 0)
