@@ -136,7 +136,7 @@ class _Slot:
 class Extracted:
     """One block's results on the device (no host sync has happened for them): voxel grids [res,res,res,7], mask buffers of capacity n whose first
     counts[0] (density mask) / counts[1] (density AND surface mask) entries are valid, and the event behind the pinned copy of `counts`."""
-    __slots__ = ("path", "res", "n", "world", "rgb", "dgrid", "dmask", "grid", "mask", "counts_host", "counts_event", "index")
+    __slots__ = ("path", "res", "n", "world", "rgb", "dgrid", "dmask", "grid", "mask", "counts_host", "counts_event", "counts_dev", "index")
 
     def kept(self) -> int:
         """Number of voxels in voxel_mask.pt (waits for this block's extraction on the GPU, not for its files)."""
@@ -283,23 +283,22 @@ class ExtractionPipeline:
 
     def _stage_out(self, ex: Extracted, dkeep, keep, counts):
         main = torch.cuda.current_stream(self.dev)
+        hd = self.timings["host_detail_s"]
+        # the counts first, on the main stream: registration only waits for these
+        row = self._counts[ex.index]
+        row.copy_(counts, non_blocking=True)
+        ev_c = torch.cuda.Event()
+        ev_c.record(main)
+        ex.counts_host, ex.counts_event, ex.counts_dev = row, ev_c, counts
+        if not self.write_files:          # extraction for an in-memory consumer only: no staging, no files
+            return
         h0 = time.perf_counter()
         slot = self._slot(ex.res)
         slot.reserve(ex.n)
+        slot.counts = row
         n = ex.n
-        hd = self.timings["host_detail_s"]
         hd["slot"] = hd.get("slot", 0.0) + time.perf_counter() - h0
         h0 = time.perf_counter()
-        # the two counts first, on the main stream: registration only waits for these
-        slot.counts = self._counts[ex.index]
-        slot.counts.copy_(counts, non_blocking=True)
-        ev_c = torch.cuda.Event()
-        ev_c.record(main)
-        ex.counts_host, ex.counts_event = slot.counts, ev_c
-        if not self.write_files:
-            slot.refs = (ex, counts)
-            self._release_later(slot, ev_c)
-            return
         cs = self._copy_stream
         cs.wait_event(ev_c)
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -324,9 +323,6 @@ class ExtractionPipeline:
         self._dq.put((slot, slot.event, os.path.dirname(ex.path), n))
         hd["copies"] = hd.get("copies", 0.0) + time.perf_counter() - h0
 
-    def _release_later(self, slot, ev):
-        self._dq.put((slot, ev, None, 0))
-
     def _dispatch(self):
         """ONE thread waits for the copies' events, in order, and hands the finished blocks to the writer pool (sixteen threads each blocking in
         hipEventSynchronize kept the runtime's locks busy under the main thread's launches)."""
@@ -342,10 +338,6 @@ class ExtractionPipeline:
                 ev.synchronize()
             except BaseException as e:                  # noqa: BLE001
                 self._dispatch_err = self._dispatch_err or e
-            if out_dir is None:
-                slot.refs = None
-                self._free.put(slot)
-                continue
             if int(slot.counts[2]) != n and self._debug_skip != "copy":
                 # the query ran with the loader's host-side count of occupied cells; the device counted a different number: nothing of this block is written
                 self._dispatch_err = self._dispatch_err or RuntimeError(f"{out_dir}: occupancy grid has {int(slot.counts[2])} occupied cells on the device, {n} on the host")

@@ -95,6 +95,11 @@ def make_split(root, json_dir, n_train, n_test, res=128, ncam=24, pose_std=0.15,
     ids = {sp: [f"uid_{n}" for n in ns] for sp, ns in names.items()}
     json.dump({dataset: ids}, open(os.path.join(json_dir, "objaverse.json"), "w"))
     json.dump({f"uid_{n}": n for ns in names.values() for n in ns}, open(os.path.join(json_dir, "obj_id_names.json"), "w"))
+    # a second set of split files whose 'test' split is the first 16 TRAINING scenes: the in-distribution evaluation of a trained checkpoint
+    sub = json_dir.rstrip("/") + "_trainsub"
+    os.makedirs(sub, exist_ok=True)
+    json.dump({dataset: {"train": [], "test": ids["train"][:16]}}, open(os.path.join(sub, "objaverse.json"), "w"))
+    json.dump({f"uid_{n}": n for ns in names.values() for n in ns}, open(os.path.join(sub, "obj_id_names.json"), "w"))
     occ = []
     for sp, ns in names.items():
         for name in ns:
