@@ -327,7 +327,7 @@ class PrefetchLoader:
     Every yielded sample carries 'ready_event' (recorded on the loader stream after its last device op); NeRFRegTr.forward_batch waits for
     it on the GPU, never on the host."""
 
-    def __init__(self, dataset, indices, device=None, depth: int = 2, prefetch_nerf_blocks: bool = True):
+    def __init__(self, dataset, indices, device=None, depth: int = 2, prefetch_nerf_blocks: bool = True, stream=None):
         import queue
         import threading
         self.ds, self.indices, self.device = dataset, list(indices), device
@@ -335,7 +335,7 @@ class PrefetchLoader:
         # loader thread and stream, so that the training thread finds them resident (a block checkpoint is 60-160 MB on disk)
         self.prefetch_nerf_blocks = prefetch_nerf_blocks and device is not None and torch.device(device).type == "cuda"
         self.q = queue.Queue(maxsize=max(depth, 1))
-        self.stream = torch.cuda.Stream(device=device, priority=-1) if (device is not None and torch.device(device).type == "cuda") else None   # high priority: its few small kernels must not queue behind a saturated training stream
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=device, priority=-1) if (device is not None and torch.device(device).type == "cuda") else None   # high priority: its few small kernels must not queue behind a saturated training stream
         self._err = None
         # The thread owns its generators (seeded from ONE draw of the caller's Python RNG at construction, on the caller's thread): the
         # block order / augmentation are reproducible for a fixed seed and never interleave with the main thread's draws.

@@ -66,6 +66,9 @@ def _default_labels(pred):
     return s_gt, t_gt, s_tl, t_tl
 
 
+STEP_TIMERS = {} if os.environ.get("DREG_STEP_TIMERS") == "1" else None      # diagnostic: host seconds of a step's phases, accumulated (train_nerf_regtr.py prints them per epoch)
+
+
 class _SplitLabels:
     """One step's NeRF-block labels in two launches on TrainStep's label stream (see TrainStep.split_labels)."""
 
@@ -73,14 +76,16 @@ class _SplitLabels:
         self.ts, self.batch, self.dev = ts, batch, dev
         if ts._label_stream is None or ts._label_stream.device != dev:
             ts._label_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("DREG_LABEL_PRIORITY", "0")))
-        self.stream = ts._label_stream
         self.main = torch.cuda.current_stream(dev)
+        dbg = os.environ.get("DREG_LABEL_DEBUG", "")          # diagnostic: "kp_main" / "tilde_main" issue that march on the step's own stream
+        self.kp_stream = self.main if "kp_main" in dbg else ts._label_stream
+        self.stream = self.main if "tilde_main" in dbg else ts._label_stream
         self.gt_row = self.ev_gt = None
 
     def after_geometry(self, pts_l, segs, producer):
         """Called by forward_batch when the key points exist (on `producer`, the geometry stream, which runs ahead of the step stream)."""
         from .visibility import compute_visibility_scores_batched
-        ls = self.stream
+        ls = self.kp_stream
         ls.wait_stream(producer if producer is not None else self.main)
         with torch.cuda.stream(ls), torch.no_grad():
             reqs = []
@@ -88,7 +93,12 @@ class _SplitLabels:
                 pts.record_stream(ls)
                 reqs.append((pts[:ns].reshape(1, ns, 3), d["src_nerf_path"]))
                 reqs.append((pts[ns:ns + nt].reshape(1, nt, 3), d["tgt_nerf_path"]))
+            if STEP_TIMERS is not None:
+                self._e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                self._e[0].record(ls)
             outs = compute_visibility_scores_batched(reqs, max_waves=self.ts.label_waves[0])
+            if STEP_TIMERS is not None:
+                self._e[1].record(ls)
             self.gt_row = torch.cat([o.reshape(-1) for o in outs])                 # [R]: rows in the batch's row space (pair 0 src | tgt, pair 1 ...)
             self.ev_gt = torch.cuda.Event()
             self.ev_gt.record(ls)
@@ -112,7 +122,11 @@ class _SplitLabels:
             for (s0, ns, t0, nt), d in zip(bt["tab"].segs, self.batch):
                 reqs.append((c[:, s0:s0 + ns], d["src_nerf_path"]))
                 reqs.append((c[:, t0:t0 + nt], d["tgt_nerf_path"]))
+            if STEP_TIMERS is not None:
+                self._e[2].record(ls)
             outs = compute_visibility_scores_batched(reqs, max_waves=self.ts.label_waves[1])
+            if STEP_TIMERS is not None:
+                self._e[3].record(ls)
             self.tilde = torch.cat([o[..., 0] for o in outs], dim=1)             # [6,R]
         return gt
 
@@ -131,6 +145,10 @@ class _SplitLabels:
     def join(self):
         self.main.wait_event(self.ev_done)
         self.tilde.record_stream(self.main)
+        if STEP_TIMERS is not None:          # diagnostic only (a device sync per step): how long the two marches took on the label stream
+            torch.cuda.synchronize()
+            STEP_TIMERS["gpu ms kp march"] = STEP_TIMERS.get("gpu ms kp march", 0.0) + self._e[0].elapsed_time(self._e[1])
+            STEP_TIMERS["gpu ms tilde march"] = STEP_TIMERS.get("gpu ms tilde march", 0.0) + self._e[2].elapsed_time(self._e[3])
 
 
 class TrainStep:
@@ -186,16 +204,22 @@ class TrainStep:
         lab = _SplitLabels(self, batch, dev0) if split else None
         if lab is not None:
             self.model.__dict__["_after_geometry"] = lab.after_geometry
+        _t = [__import__("time").perf_counter()] if STEP_TIMERS is not None else None
         try:
             preds = self.model.forward_batch(batch)
         finally:
             self.model.__dict__.pop("_after_geometry", None)
+        if _t is not None:
+            _t.append(__import__("time").perf_counter())
         if self.fused_losses:
             # all pairs at once through csrc/losses.hip: labels in the shared row space [6,R], one autograd node
             bt = self.model.last_batched
             defer = None
             if lab is not None:
+                _q0 = __import__("time").perf_counter()
                 gt, tilde, defer = lab.after_forward(bt), None, {}
+                if STEP_TIMERS is not None:
+                    STEP_TIMERS["  after_forward"] = STEP_TIMERS.get("  after_forward", 0.0) + __import__("time").perf_counter() - _q0
             elif not any(have_nerf) and self.label_fn is _default_labels:
                 with torch.no_grad():
                     gt = synth.synthetic_overlap_gt(bt["xyz"])[..., 0]
@@ -211,7 +235,10 @@ class TrainStep:
             poses = torch.cat([d["pose"].reshape(1, 4, 4) for d in batch]).float()
             ls = FL.regtr_losses(bt, poses, self.feature_loss, gt, tilde, self.robust, defer=defer)
             if lab is not None:
+                _q0 = __import__("time").perf_counter()
                 lab.after_losses(defer)
+                if STEP_TIMERS is not None:
+                    STEP_TIMERS["  after_losses"] = STEP_TIMERS.get("  after_losses", 0.0) + __import__("time").perf_counter() - _q0
             total = ls["total"]
             agg = None                       # the fused losses are batch means already (no x len / len round trip: ten tiny launches)
             means = {k: v.detach() for k, v in ls.items()}
@@ -240,6 +267,8 @@ class TrainStep:
             sync.begin()
             ops.GRAD_SYNC = sync
         ops.PERSISTENT_GRAD_BUFFERS = dev.type == "cuda" and self.persistent_grad_buffers
+        if _t is not None:
+            _t.append(__import__("time").perf_counter())
         try:
             self._backward(total, dev)
         finally:
@@ -261,6 +290,10 @@ class TrainStep:
         gnorm = self.optimizer.grad_norm()
         if not self.finetune:
             self.scheduler.step()
+        if _t is not None:
+            _t.append(__import__("time").perf_counter())
+            for k_, a_, b_ in zip(("forward", "labels+losses", "backward+optimizer"), _t[:-1], _t[1:]):
+                STEP_TIMERS[k_] = STEP_TIMERS.get(k_, 0.0) + b_ - a_
         if lab is not None:
             lab.join()                     # readers of the loss values (this stream) come behind the label stream's completion of 'nerf_cont' / 'total'
         self.last_losses = means if agg is None else {k: v / len(batch) for k, v in agg.items()}

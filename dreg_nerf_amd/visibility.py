@@ -237,6 +237,8 @@ def compute_visibility_score(xyz_list: List[torch.Tensor], nerf_model_path: str,
 # Pinned staging for the descriptor tables: a ring of four buffers per device, each guarded by an event recorded behind its last copy
 # (allocating / freeing pinned memory every step costs a host-side hipHostMalloc / hipHostFree pair, the latter a possible device sync).
 _staging: Dict[str, list] = {}
+STAGING_WAIT = [0.0]       # diagnostic: host seconds spent waiting for a staging slot
+STAGING_RING = int(os.environ.get("DREG_STAGING_RING", "4"))
 
 
 class _OverrunWatch:
@@ -303,13 +305,15 @@ def _desc_staging(nbytes: int, device):
     if torch.device(device).type != "cuda":
         return torch.empty(nbytes, dtype=torch.uint8), None
     ring = _staging.setdefault(str(device), [0, []])
-    if len(ring[1]) < 4:
+    if len(ring[1]) < STAGING_RING:
         ring[1].append([torch.empty(max(nbytes, 16384), dtype=torch.uint8).pin_memory(), torch.cuda.Event()])
         slot = ring[1][-1]
     else:
-        slot = ring[1][ring[0] % 4]
+        slot = ring[1][ring[0] % STAGING_RING]
         ring[0] += 1
+        _t0 = __import__("time").perf_counter()
         slot[1].synchronize()                                   # only waits when the GPU is four label launches behind the host
+        STAGING_WAIT[0] += __import__("time").perf_counter() - _t0
         if slot[0].numel() < nbytes:
             slot[0] = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
     return slot[0], slot[1]

@@ -102,11 +102,17 @@ def main():
             raise SystemExit(f"{len(ids)} training scenes < world ({world}) x pairs_per_step ({per_step}): nothing to train on")
         ids = ids[:usable][rank::world]
         # on-disk data: samples are read, uploaded and augmented two steps ahead on a loader thread / stream
-        loader = PrefetchLoader(train_ds, ids, dev, depth=2 * per_step) if cfg.synthetic == 0 else None
+        # (the loader shares the model's geometry stream: no fifth HIP stream next to the step's four — NeRFRegTr.geometry_stream)
+        loader = PrefetchLoader(train_ds, ids, dev, depth=2 * per_step, stream=None if os.environ.get("DREG_LOADER_OWN_STREAM") == "1" else model.geometry_stream(dev)) if cfg.synthetic == 0 else None
         t_epoch, n_pairs = time.time(), 0
+        t_wait = t_issue = 0.0
         for b in range(0, len(ids) - per_step + 1, per_step):
+            t0 = time.perf_counter()
             batch = [next(loader) for _ in range(per_step)] if loader is not None else [to_device(train_ds[i], dev) for i in ids[b:b + per_step]]
+            t1 = time.perf_counter()
             out = ts.step(batch)
+            t_wait += t1 - t0
+            t_issue += time.perf_counter() - t1
             iteration += 1
             n_pairs += per_step
             if rank == 0 and iteration % cfg.n_tensorboard == 0:
@@ -127,9 +133,17 @@ def main():
         torch.cuda.synchronize()
         if rank == 0:
             dt = time.time() - t_epoch
-            msg = f"epoch {epoch}: {n_pairs} pairs on this rank in {dt:.2f}s = {n_pairs * world / dt:.1f} pairs/s over {world} GPU(s), input pipeline included"
+            msg = (f"epoch {epoch}: {n_pairs} pairs on this rank in {dt:.2f}s = {n_pairs * world / dt:.1f} pairs/s over {world} GPU(s), input pipeline included "
+                   f"(this thread: {t_wait:.2f}s waiting for samples, {t_issue:.2f}s issuing steps)")
             print(msg, flush=True)
             log.write(msg + "\n"); log.flush()
+            from dreg_nerf_amd import train_step as _TS
+            if _TS.STEP_TIMERS is not None:
+                print("  host seconds by phase: " + ", ".join(f"{k} {v:.2f}" for k, v in _TS.STEP_TIMERS.items()), flush=True)
+                _TS.STEP_TIMERS.clear()
+                from dreg_nerf_amd import visibility as _V
+                print(f"  label descriptor staging waits: {_V.STAGING_WAIT[0]:.2f}s", flush=True)
+                _V.STAGING_WAIT[0] = 0.0
     score, r, t = validate(model, val_ds, dev, rank=rank, world=world)
     if rank == 0:
         print(f"final val: R_mean={r:.3f} t_mean={t:.4f}", flush=True)
