@@ -320,6 +320,14 @@ def eval_end_to_end(args, dev, reps: int = 2, scenes_per_pass: int = 16, serial:
                "rre_deg_mean": float(sum(rre) / len(rre)), "rte_mean": float(sum(rte) / len(rte)),
                "note": "wall time of extraction (checkpoint load, query, surface labels, the six files per block) + registration (eval-mode forward in batches of "
                        f"{args.pairs} pairs, RRE / RTE), last file closed inside the timed region; generated blocks, random-init weights: the errors only show that the metric path runs"}
+        rec = os.path.join(ROOT, "profiles", "r06_trained_eval.json")
+        if os.path.exists(rec):      # NOT measured by this run: the committed record of the round's trained checkpoint (245 MB, not shipped) through the same chain
+            r_ = json.load(open(rec))
+            out["trained_checkpoint_record"] = {"source": "profiles/r06_trained_eval.json (tools/trained_regime.sh + tests/test_hip_trained_regime.py on the collection box)",
+                                                "held_out_scenes": r_["scenes"], "rre_deg_mean_bf16_chain": r_["bf16_chain"]["rre_deg_mean"], "rre_deg_median_bf16_chain": r_.get("bf16_chain_rre_deg_median"),
+                                                "rte_mean_bf16_chain": r_["bf16_chain"]["rte_mean"], "rre_deg_mean_fp32_mode": r_["fp32_mode"]["rre_deg_mean"],
+                                                "training_scenes_rre_deg_mean": r_.get("training_scenes_bf16", {}).get("rre_deg_mean"),
+                                                "oracle_scene_rre_deg": {"oracle": r_["oracle_scene"]["oracle_rre_deg"], "fp32_mode": r_["oracle_scene"]["fp32_mode_rre_deg"], "bf16_chain": r_["oracle_scene"]["bf16_chain_rre_deg"]}}
         if tm is not None:      # per-phase breakdown of the LAST pass: thread-seconds of work, what the main thread waited for, GPU time by phase
             gpu_ms = tm["gpu_query_ms"] + tm["gpu_surface_ms"] + tm["gpu_grids_ms"] + tm["gpu_copy_ms"] + tm["gpu_register_ms"]
             out["phases"] = {"load_thread_s": tm["load_thread_s"], "write_thread_s": tm["write_thread_s"], "GB_written": tm["bytes_written"] / 1e9,

@@ -181,6 +181,7 @@ class ExtractionPipeline:
             self._collector = threading.Thread(target=self._collect, name="dreg-collect", daemon=True)
             self._collector.start()
         self._tls = threading.local()
+        self._shared_load_stream = None
         self._free: "queue.Queue[_Slot]" = queue.Queue()
         self._slots_made = 0
         self._jobs: List[cf.Future] = []
@@ -203,7 +204,16 @@ class ExtractionPipeline:
         torch.cuda.set_device(self.dev)
         st = getattr(self._tls, "stream", None)
         if st is None:
-            st = self._tls.stream = torch.cuda.Stream(device=self.dev)
+            # one upload stream for all loader threads by default: every additional HIP stream in flight costs the others (five streams halved the training
+            # step on the collection box); DREG_PIPE_LOADER_STREAMS=per_thread gives each thread its own
+            if os.environ.get("DREG_PIPE_LOADER_STREAMS", "shared") == "per_thread":
+                st = torch.cuda.Stream(device=self.dev)
+            else:
+                with self._tlock:
+                    if self._shared_load_stream is None:
+                        self._shared_load_stream = torch.cuda.Stream(device=self.dev)
+                    st = self._shared_load_stream
+            self._tls.stream = st
         with torch.cuda.stream(st):
             field, binary, meta = visibility.load_block(path, self.dev, cache=False)
             ev = torch.cuda.Event()
