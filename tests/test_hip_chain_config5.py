@@ -59,14 +59,8 @@ def test_extract_then_register_split_matches_oracle(tmp_path):
 def test_extract_then_register_at_the_baseline_size_128(tmp_path):
     """BASELINE.json configs[4] at the BASELINE resolution: four generated scenes of two 128^3 blocks each (a thin occupancy shell: ~4e4 occupied cells
     per block, as on the benchmark's grids) through grid extraction -> registration -> metrics_test.json; the fp32-mode leg is re-derived by the
-    reference-pinned CPU oracle on ONE scene (a 128^3 oracle forward is minutes of host time), the bf16 leg — the script's default precision — is held
-    against the fp32-mode leg on every scene."""
-    _chain(tmp_path, 128, (0.75, 0.88), 30000, 1)
-
-
-@pytest.mark.skipif(os.environ.get("DREG_SLOW") != "1", reason="eight 128^3 oracle forwards on the host (~15-20 min): run with DREG_SLOW=1; the round's record is profiles/r06_chain128_all_scenes_oracle.txt")
-def test_extract_then_register_at_128_every_scene_rederived_by_the_oracle(tmp_path):
-    """The 128^3 chain with EVERY row of metrics_test.json re-derived by the reference-pinned CPU oracle (the default variant above re-derives one scene)."""
+    reference-pinned CPU oracle on EVERY scene (round 6: eight 128^3 oracle forwards take ~1 min on the collection box's 16 cores; rounds 3-5 re-derived
+    one), the bf16 leg — the script's default precision — is held against the fp32-mode leg on every scene."""
     _chain(tmp_path, 128, (0.75, 0.88), 30000, None)
 
 
