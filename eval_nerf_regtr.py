@@ -10,6 +10,7 @@ import time
 import torch
 import torch.distributed as dist
 
+from dreg_nerf_amd import eval_shard as ES
 from dreg_nerf_amd import fgr, vis_dump
 from dreg_nerf_amd import losses as LS
 from dreg_nerf_amd.checkpoint import CheckPointManager
@@ -71,13 +72,10 @@ def main():
         print(f"[WARNING] no checkpoint at {ckpt_path}: evaluating random-init weights", flush=True)
     rows, fgr_rows = {}, {}
     per_scene_extras = cfg.dump_outputs or cfg.fgr_baseline
-    mine = list(range(rank, len(ds), world))
-    # every rank consumes the block-order draws of ALL scenes in scene order (dataset.skip): a scene's source / target assignment is then the
-    # one-rank run's, whatever the rank count — the gathered metrics file does not depend on the sharding
-    order_of = {}
-    if cfg.synthetic == 0:
-        for i in range(len(ds)):
-            order_of[i] = ds.draw_block_order(i)
+    mine = ES.my_scenes(len(ds), rank, world)
+    # every rank consumes the block-order draws of ALL scenes in scene order: a scene's source / target assignment is then the one-rank run's,
+    # whatever the rank count — the gathered metrics file does not depend on the sharding (dreg_nerf_amd/eval_shard.py)
+    order_of = ES.block_orders(ds) if cfg.synthetic == 0 else {}
     if cfg.extract_grids and cfg.synthetic == 0:
         # BASELINE.json configs[4] in one process: this rank's scenes go through grid extraction (the reference's eval_ngp_nerf.py files are written) and are
         # registered from the device-resident grids, extraction of later scenes overlapping registration of earlier ones (dreg_nerf_amd/eval_pipeline.py)
@@ -124,25 +122,16 @@ def main():
                 e = LS.evaluate_camera_alignment(T[None].float(), data["pose"])
                 fgr_rows[data["scene"]] = {"R_mean": float(e["R_error_mean"]), "t_mean": float(e["t_error_mean"]),
                                            "R_med": float(e["R_error_med"]), "t_med": float(e["t_error_med"]), "time": sec}
-    if world > 1:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, rows)
-        rows = {k: v for g in gathered for k, v in g.items()}
-        dist.all_gather_object(gathered, fgr_rows)
-        fgr_rows = {k: v for g in gathered for k, v in g.items()}
+    rows, fgr_rows = ES.gather_rows(rows, world), ES.gather_rows(fgr_rows, world)
     if rank == 0:
-        out = dict(rows)
-        out["R_mean"] = sum(r["R_mean"] for r in rows.values()) / max(len(rows), 1)
-        out["t_mean"] = sum(r["t_mean"] for r in rows.values()) / max(len(rows), 1)
+        out = ES.summary(rows)
         d = os.path.join(cfg.root_dir, "eval", cfg.expname, cfg.dataset or "synthetic")
         os.makedirs(d, exist_ok=True)
         with open(os.path.join(d, f"metrics_{split}.json"), "w") as f:
             json.dump(out, f, indent=2)
         print(f"{len(rows)} scenes: R_mean={out['R_mean']:.3f} deg, t_mean={out['t_mean']:.4f} -> {d}/metrics_{split}.json", flush=True)
         if fgr_rows:
-            fo = dict(fgr_rows)
-            fo["R_mean"] = sum(r["R_mean"] for r in fgr_rows.values()) / len(fgr_rows)
-            fo["t_mean"] = sum(r["t_mean"] for r in fgr_rows.values()) / len(fgr_rows)
+            fo = ES.summary(fgr_rows)
             with open(os.path.join(d, f"fgr_metrics_{split}.json"), "w") as f:
                 json.dump(fo, f, indent=4)
             print(f"FGR baseline: R_mean={fo['R_mean']:.3f} deg, t_mean={fo['t_mean']:.4f} -> {d}/fgr_metrics_{split}.json", flush=True)

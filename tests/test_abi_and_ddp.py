@@ -323,3 +323,67 @@ def test_profiler_labels_come_from_the_librarys_dispatch_rules():
     assert lib.dreg_conv3d_wgrad_variant(8, 64, 64, 64, 256, 256, 3, 0, 0, 0) == 256256
     assert lib.dreg_conv3d_wgrad_variant(8, 64, 64, 64, 64, 256, 3, 0, 0, 0) == 256256      # 27 x 64 columns: ragged last tile of the 256-wide form
     assert lib.dreg_conv3d_wgrad_variant(8, 16, 16, 16, 128, 128, 3, 0, 0, 0) == 128128
+
+
+class _FakeSplit:
+    """Stands in for NeRFRegDataset on the host: scenes with two or three blocks, block order drawn like dataset.draw_block_order (quirk Q15)."""
+
+    def __init__(self, n):
+        self.meta = [{"scene": f"s{i:02d}", "blocks": {k: None for k in range(2 + (i % 3 == 0))}} for i in range(n)]
+
+    def __len__(self):
+        return len(self.meta)
+
+    def draw_block_order(self, index):
+        import random
+        ids = list(self.meta[index]["blocks"].keys())
+        random.shuffle(ids)
+        return ids
+
+
+def _eval_shard_worker(rank, world, port, q):
+    """eval_nerf_regtr.py's sharding (dreg_nerf_amd/eval_shard.py) over gloo: every rank seeds like the script, draws ALL scenes' block orders, 'evaluates'
+    its scenes rank::world (a row derived from the scene and its drawn order), gathers."""
+    import random
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dreg_nerf_amd import eval_shard as ES
+    random.seed(3407)
+    ds = _FakeSplit(11)
+    orders = ES.block_orders(ds)
+    rows = {}
+    for i in ES.my_scenes(len(ds), rank, world):
+        s, t = orders[i][0], orders[i][1]
+        rows[ds.meta[i]["scene"]] = {"R_mean": 10.0 * i + s, "t_mean": 0.1 * i + 0.01 * t, "order": orders[i]}
+    allrows = ES.gather_rows(rows, world)
+    q.put((rank, ES.summary({k: {"R_mean": v["R_mean"], "t_mean": v["t_mean"]} for k, v in allrows.items()}), {k: v["order"] for k, v in allrows.items()}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_eval_scene_sharding_gloo_world2_equals_one_rank():
+    """SURVEY.md 8(e) 'RegTR eval': scenes sharded rank::world, rows gathered with all_gather_object — the two-rank result (on BOTH ranks) is the one-rank
+    result, including which block of every scene is the source (the order is drawn for all scenes on every rank)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    one = ctx.Process(target=_eval_shard_worker, args=(0, 1, 0, q))
+    one.start()
+    _, want, want_orders = q.get(timeout=120)
+    one.join(timeout=60)
+    port = 29741 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_eval_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(want) == 11 + 2 and any(len(o) == 3 for o in want_orders.values())
+    for _, summ, orders in got:
+        assert orders == want_orders
+        assert set(summ) == set(want) and all(summ[k] == want[k] for k in want)
+    from dreg_nerf_amd import eval_shard as ES
+    assert ES.my_scenes(7, 1, 3) == [1, 4] and ES.my_scenes(2, 3, 4) == []
