@@ -78,6 +78,7 @@ class _SplitLabels:
             ts._label_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("DREG_LABEL_PRIORITY", "0")))
         self.main = torch.cuda.current_stream(dev)
         dbg = os.environ.get("DREG_LABEL_DEBUG", "")          # diagnostic: "kp_main" / "tilde_main" issue that march on the step's own stream
+        self.dbg = dbg                                        # ("kp_geo": the key-point march on the geometry stream that produced the points; "skip_kp" / "skip_tilde": timing ablations, WRONG labels)
         self.kp_stream = self.main if "kp_main" in dbg else ts._label_stream
         self.stream = self.main if "tilde_main" in dbg else ts._label_stream
         self.gt_row = self.ev_gt = None
@@ -85,8 +86,9 @@ class _SplitLabels:
     def after_geometry(self, pts_l, segs, producer):
         """Called by forward_batch when the key points exist (on `producer`, the geometry stream, which runs ahead of the step stream)."""
         from .visibility import compute_visibility_scores_batched
-        ls = self.kp_stream
-        ls.wait_stream(producer if producer is not None else self.main)
+        ls = producer if ("kp_geo" in self.dbg and producer is not None) else self.kp_stream
+        if ls is not producer:
+            ls.wait_stream(producer if producer is not None else self.main)
         with torch.cuda.stream(ls), torch.no_grad():
             reqs = []
             for pts, (ns, nt), d in zip(pts_l, segs, self.batch):
@@ -96,7 +98,7 @@ class _SplitLabels:
             if STEP_TIMERS is not None:
                 self._e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
                 self._e[0].record(ls)
-            outs = compute_visibility_scores_batched(reqs, max_waves=self.ts.label_waves[0])
+            outs = compute_visibility_scores_batched(reqs, max_waves=self.ts.label_waves[0]) if "skip_kp" not in self.dbg else [torch.zeros(x.shape[0], x.shape[1], 1, device=x.device) for x, _ in reqs]
             if STEP_TIMERS is not None:
                 self._e[1].record(ls)
             self.gt_row = torch.cat([o.reshape(-1) for o in outs])                 # [R]: rows in the batch's row space (pair 0 src | tgt, pair 1 ...)
@@ -124,7 +126,7 @@ class _SplitLabels:
                 reqs.append((c[:, t0:t0 + nt], d["tgt_nerf_path"]))
             if STEP_TIMERS is not None:
                 self._e[2].record(ls)
-            outs = compute_visibility_scores_batched(reqs, max_waves=self.ts.label_waves[1])
+            outs = compute_visibility_scores_batched(reqs, max_waves=self.ts.label_waves[1]) if "skip_tilde" not in self.dbg else [torch.zeros(x.shape[0], x.shape[1], 1, device=x.device) for x, _ in reqs]
             if STEP_TIMERS is not None:
                 self._e[3].record(ls)
             self.tilde = torch.cat([o[..., 0] for o in outs], dim=1)             # [6,R]

@@ -34,10 +34,15 @@ ts.split_labels = False
 out["synthetic_labels_ms"] = run(base)
 out["unsplit_ms"] = run(batch)
 ts.split_labels = True
-# (a low-priority label stream — torch priority 1 — was measured at 31-34 ms per step whatever the width: dropped)
-for w in ((0, 0), (256, 256), (128, 128), (64, 64), (32, 32), (16, 16), (8, 8), (128, 32), (32, 128), (128, 128)):
+ts.label_waves = (128, 128)
+for dbg in ("", "skip_tilde", "skip_kp", "skip_kp,skip_tilde", "kp_geo", ""):
+    os.environ["DREG_LABEL_DEBUG"] = dbg
+    out[f"split_128_{dbg or 'default'}_ms"] = run(batch)
+os.environ["DREG_LABEL_DEBUG"] = "kp_geo"
+for w in ((0, 128), (512, 128), (128, 96), (128, 64)):
     ts.label_waves = w
-    out[f"split_waves{w[0]}_{w[1]}_ms"] = run(batch)
+    out[f"kp_geo_waves{w[0]}_{w[1]}_ms"] = run(batch)
+os.environ["DREG_LABEL_DEBUG"] = ""
 ts.split_labels = False
 out["unsplit_again_ms"] = run(batch)
 out["synthetic_again_ms"] = run(base)
