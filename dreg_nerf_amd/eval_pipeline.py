@@ -6,12 +6,16 @@ grid, write voxel_grid.pt / voxel_mask.pt / the PLY and their density_voxel_* tw
 back, one pair per call.  A block's query is ~0.3 ms of GPU time between ~80 ms of checkpoint reading and ~120 MB of file writing, so
 the serial chain leaves the GPU idle > 95 % of the time (2.95 pairs/s measured in round 5).  Here the same work is laid out in stages:
 
-  loader threads   model.pth of block k+1.. is memory-mapped, its parameters uploaded, converted to fp16 and the occupancy grid's cells
-                   counted ON THE HOST (so the query never reads a size back) — each thread on its own HIP stream, an event per block;
+  loader threads   model.pth of block k+1.. is memory-mapped; only the field's parameters and the occupancy bits are touched: copied into the thread's
+                   pinned staging, uploaded asynchronously (one upload stream shared by the loader threads), converted to fp16 on the device; the
+                   occupancy grid's cells are counted ON THE HOST (so the query never reads a size back); an event per block;
   main thread      waits for block k's event on the GPU, enqueues the dense query, the surface ray march and both grid writers — no host
-                   readback anywhere — then the device -> pinned-host copies of the results on a copy stream;
-  writer threads   wait for the copy's event and write the reference's six files of block k-1.. (torch.save releases the GIL while it
-                   writes; a 58.7 MB grid file costs ~17 ms of one core, 16 threads reach ~9-10 GB/s on the collection box);
+                   readback anywhere — then the device -> host-staging copies of the results on a copy stream;
+  dispatcher       ONE thread waits for the copies' events in order, compares the device's cell count with the loader's, hands the block on;
+  writer PROCESSES (spawned; grid_writer.worker_main) write the reference's six files of block k-1.. straight from the staging, which is shared
+                   memory (files under /dev/shm mapped by both sides, page-locked here with hipHostRegister).  Writer THREADS in this process
+                   (writer_mode="thread", the fallback without /dev/shm) starve the launching thread: 8 of them cut its launch rate from 182 k/s
+                   to 42 /s on the collection box (tools/writer_probe.py);
   registration     every `batch_pairs` finished pairs go through NeRFRegTr.forward_batch straight from the device tensors (the grids are
                    handed over in memory as dataset.SparseBlock; the files are still written), RRE / RTE stay on the device until the end.
 
