@@ -384,8 +384,10 @@ class SubsampleRound:
     __slots__ = ("order", "starts", "n_out_dev", "inv_seg", "inv_cnt", "n_in", "n_out")
 
 
-def plan_voxel_downsample(points, lengths, dl: float):
-    """xyz-only half of voxel_mean_downsample: returns (round, averaged points [M,3], per-batch counts list)."""
+def plan_voxel_downsample(points, lengths, dl: float, frozen=None):
+    """xyz-only half of voxel_mean_downsample: returns (round, averaged points [M,3], per-batch counts list).
+    frozen (list of bool per batch, optional): those batches pass through unchanged and in order (dreg_voxel_downsample_plan_frozen) — how one round serves
+    all pairs of a step although some of them have stopped subsampling (transformer_ops.plan_hierarchical_subsample_all)."""
     lib = L.load()
     lens = [int(v) for v in lengths]
     dev = points.device
@@ -402,9 +404,10 @@ def plan_voxel_downsample(points, lengths, dl: float):
     r.starts = torch.empty(n + 1, dtype=torch.int32, device=dev)
     nbytes = lib.dreg_voxel_downsample_workspace_bytes(n)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    L.check(lib.dreg_voxel_downsample_plan(L.ptr(points), L.ptr(pt_batch), L.ptr(out_p), meta.data_ptr(), meta.data_ptr() + 8,
-                                           L.ptr(r.inv_seg), L.ptr(r.inv_cnt), meta.data_ptr() + 4, L.ptr(r.order), L.ptr(r.starts),
-                                           L.ptr(ws), nbytes, n, len(lens), float(dl), L.stream()), "dreg_voxel_downsample_plan")
+    fz = L.to_device_async([int(bool(f)) for f in frozen], torch.uint8, dev) if (frozen is not None and any(frozen)) else None
+    L.check(lib.dreg_voxel_downsample_plan_frozen(L.ptr(points), L.ptr(pt_batch), L.ptr(out_p), meta.data_ptr(), meta.data_ptr() + 8,
+                                                  L.ptr(r.inv_seg), L.ptr(r.inv_cnt), meta.data_ptr() + 4, L.ptr(r.order), L.ptr(r.starts),
+                                                  L.ptr(ws), nbytes, n, len(lens), float(dl), L.ptr(fz), L.stream()), "dreg_voxel_downsample_plan_frozen")
     host = meta.tolist()  # the host sync of the round (the reference's .shape[0] test, grid_downsample.py:91)
     if host[1]:
         raise L.DregError("voxel coordinates overflow the 16-bit cell range")
@@ -557,11 +560,11 @@ class _GatherSubsampleFn(torch.autograd.Function):
                         "dreg_voxel_downsample_bwd")
                 gy = gx
             row = [rounds[0].inv_seg.data_ptr(), rounds[0].inv_cnt.data_ptr(), pstart, ro]
-            table += [row, row]                  # both grids of the pair (point sets: source then target, one plan)
+            table += [row] * (B // len(ctx.plans))      # the grids this plan covers: both grids of a pair (per-pair plans) or every grid of the step (one global plan)
             oo += no
             ro += n1[i]
             pstart += sz
-        assert len(table) == B, "one plan per pair of grids"
+        assert len(table) == B, "one plan per pair of grids, or one for all of them"
         descs = L.to_device_async([v for r in table for v in r], torch.int64, dev)
         fmap = torch.empty(B * Zr * Xr * Yr, dtype=torch.int32, device=dev)
         if ops.PERSISTENT_GRAD_BUFFERS:          # the dense gradient buffer kept across steps, zero outside the rows of the step that wrote it (ops.TrilinearGatherFn)

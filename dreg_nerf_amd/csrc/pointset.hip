@@ -361,12 +361,19 @@ template <typename Acc> __device__ void kabsch_body(const Acc& X, int N, float* 
 }
 
 // ------------------------------------------------------------------------------------------------ voxel-average downsample
+// frozen (may be null): uint8 per batch id; the rows of a frozen batch keep their identity — key = (batch, row index), every row a cell of its own, so the
+// round passes them through unchanged (a mean over one row) and in order.  It lets ONE launch set serve all pairs of a step although the reference's stopping
+// rule is per pair (grid_downsample.py:83-94: a pair whose point count has dropped to <= 3,000 takes no further round).
 __global__ void voxel_keys_kernel(const float* __restrict__ pts, const int* __restrict__ pt_batch, uint64_t* __restrict__ keys,
-                                  uint32_t* __restrict__ vals, int N, float dl, int* __restrict__ err)
+                                  uint32_t* __restrict__ vals, int N, float dl, int* __restrict__ err, const uint8_t* __restrict__ frozen)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     uint64_t key = (uint64_t)(uint32_t)pt_batch[i] << 48;
+    if (frozen != nullptr && frozen[pt_batch[i]]) {
+        keys[i] = key | (uint64_t)(uint32_t)i; vals[i] = (uint32_t)i;
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float q = floorf(pts[(size_t)i * 3 + c] / dl);   // true division, as the CPU oracle
@@ -859,7 +866,7 @@ void dreg_voxel_set_own_sort(int on) { g_own_sort = on ? 1 : 0; }
 static int voxel_downsample_impl(const float* pts, const float* feats, const int* pt_batch, float* out_pts, float* out_feats,
                                  int* n_out, int* batch_counts, uint32_t* inv_seg, float* inv_cnt, int* err,
                                  uint32_t* order_out, uint32_t* starts_out,
-                                 void* workspace, size_t workspace_bytes, int N, int C, int nbatch, float dl, void* stream)
+                                 void* workspace, size_t workspace_bytes, int N, int C, int nbatch, float dl, void* stream, const uint8_t* frozen = nullptr)
 {
     if (N <= 0 || C % 4) return DREG_EINVAL;
     if (workspace_bytes < dreg_voxel_downsample_workspace_bytes(N)) return DREG_EINVAL;
@@ -877,7 +884,7 @@ static int voxel_downsample_impl(const float* pts, const float* feats, const int
     if (starts_out) starts = starts_out;
     void* tmp = w;
     size_t tmp_bytes = workspace_bytes - (size_t)(w - (char*)workspace);
-    if (g_own_sort && N <= VS_MAX_N) {
+    if (g_own_sort && N <= VS_MAX_N && frozen == nullptr) {
         // keys, sort, segments in one launch (voxel_sort_segments_kernel); `scan` / `head` stay unused
         hipLaunchKernelGGL(voxel_sort_segments_kernel, dim3(1), dim3(VS_THREADS), 0, st, pts, pt_batch, dl, keys, keys_s, vals, order, starts, batch_counts, n_out, err, N, nbatch);
         DREG_LAUNCH_CHECK();
@@ -888,7 +895,7 @@ static int voxel_downsample_impl(const float* pts, const float* feats, const int
     if (hipMemsetAsync(batch_counts, 0, sizeof(int) * nbatch, st) != hipSuccess) return DREG_ELAUNCH;
     if (hipMemsetAsync(err, 0, sizeof(int), st) != hipSuccess) return DREG_ELAUNCH;
     const int nb = (N + 255) / 256;
-    hipLaunchKernelGGL(voxel_keys_kernel, dim3(nb), dim3(256), 0, st, pts, pt_batch, keys, vals, N, dl, err);
+    hipLaunchKernelGGL(voxel_keys_kernel, dim3(nb), dim3(256), 0, st, pts, pt_batch, keys, vals, N, dl, err, frozen);
     DREG_LAUNCH_CHECK();
     size_t sb = tmp_bytes;
     if (rocprim::radix_sort_pairs(tmp, sb, keys, keys_s, vals, order, (size_t)N, 0, 64, st) != hipSuccess) return DREG_ELAUNCH;
@@ -919,6 +926,15 @@ int dreg_voxel_downsample_plan(const float* pts, const int* pt_batch, float* out
     if (!order || !starts) return DREG_EINVAL;
     return voxel_downsample_impl(pts, nullptr, pt_batch, out_pts, nullptr, n_out, batch_counts, inv_seg, inv_cnt, err, order, starts,
                                  workspace, workspace_bytes, N, 0, nbatch, dl, stream);
+}
+// plan with per-batch pass-through flags (frozen uint8 [nbatch] on the device, may be null): see voxel_keys_kernel
+int dreg_voxel_downsample_plan_frozen(const float* pts, const int* pt_batch, float* out_pts, int* n_out, int* batch_counts,
+                                      uint32_t* inv_seg, float* inv_cnt, int* err, uint32_t* order, uint32_t* starts,
+                                      void* workspace, size_t workspace_bytes, int N, int nbatch, float dl, const uint8_t* frozen, void* stream)
+{
+    if (!order || !starts || nbatch > 65535) return DREG_EINVAL;
+    return voxel_downsample_impl(pts, nullptr, pt_batch, out_pts, nullptr, n_out, batch_counts, inv_seg, inv_cnt, err, order, starts,
+                                 workspace, workspace_bytes, N, 0, nbatch, dl, stream, frozen);
 }
 // apply = segment means of a feature matrix over a plan: out_feats [M,C] fp32, M = the plan's n_out (device int, rows beyond it untouched)
 int dreg_voxel_segment_mean(const float* feats, const uint32_t* order, const uint32_t* starts, const int* n_out, float* out_feats,

@@ -199,6 +199,7 @@ SIGNATURES = {
     "dreg_voxel_downsample_fwd": (I, [P] * 11 + [Z, I, I, I, F, P]),
     "dreg_voxel_downsample_bwd": (I, [P, P, P, P, I, I, P]),
     "dreg_voxel_downsample_plan": (I, [P] * 11 + [Z, I, I, F, P]),
+    "dreg_voxel_downsample_plan_frozen": (I, [P] * 11 + [Z, I, I, F, P, P]),
     "dreg_voxel_segment_mean": (I, [P] * 5 + [I, I, P]),
     "dreg_grad_norm": (I, [P, P, P, Z, P]),
     "dreg_adamw_step": (I, [P] * 5 + [Z] + [F] * 5 + [I, F, P]),

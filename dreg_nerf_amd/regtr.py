@@ -19,6 +19,11 @@ from . import transformer_ops as T
 from . import attn_ops as A
 
 
+class _GlobalPlan(list):
+    """[rounds]: ONE subsample plan over the rows of every pair of the step (NeRFRegTr.global_subsample); pts_all = the subsampled points of all pairs."""
+    pts_all = None
+
+
 class _Node(nn.Module):
     """Anonymous container used to reproduce the reference's dotted parameter names."""
 
@@ -121,6 +126,9 @@ class NeRFRegTr(nn.Module):
         # with per-row occupancy flags taken from the VALUES.
         self.stem_rows = True
         self.batched_subsample = True   # the pairs' voxel-average rounds as one autograd node (attn_ops.subsample_all)
+        # ... and PLANNED for all pairs at once: one set of launches and one host sync per round instead of one per pair and round (round 6;
+        # transformer_ops.plan_hierarchical_subsample_all: pairs that have stopped subsampling pass through the later rounds unchanged)
+        self.global_subsample = True
         self.fused_gather_subsample = True   # ... together with the trilinear gather in front of them (attn_ops.gather_subsample)
         self._spec = params.regtr_spec(self.pos_emb_type)
         _build_tree(self, self._spec)
@@ -367,7 +375,18 @@ class NeRFRegTr(nn.Module):
         s1_rows = rows[0] if rows is not None else \
             ops.active_sets(idxs, res, tuple((r + 1) // 2 for r in res), dev, pt_batch=pb_cat, idx_cat=idx_cat, density_cap=1.0, level2=False)[0]
         plans, pts_l, segs = [], [], []
-        for i in range(len(batch)):
+        if self.global_subsample and dev.type == "cuda" and self.batched_subsample:
+            # the voxel-average rounds of ALL pairs from one set of launches per round (pairs that have stopped pass through): one plan over the whole row space
+            rounds, pts_all, lens = T.plan_hierarchical_subsample_all(xyz_cat, counts, self.num_downsample)
+            plans = _GlobalPlan([rounds])
+            o = 0
+            for i in range(len(batch)):
+                n_i = int(lens[2 * i]) + int(lens[2 * i + 1])
+                pts_l.append(pts_all[o:o + n_i])
+                segs.append((int(lens[2 * i]), int(lens[2 * i + 1])))
+                o += n_i
+            plans.pts_all = pts_all
+        for i in range(len(batch) if not plans else 0):
             ns, nt = idxs[2 * i].shape[0], idxs[2 * i + 1].shape[0]
             rounds, pts, lens = T.plan_hierarchical_subsample(xyz_cat[offs[2 * i]:offs[2 * i + 2]], [ns, nt], self.num_downsample)
             plans.append(rounds)
@@ -423,6 +442,8 @@ class NeRFRegTr(nn.Module):
                     bt.record_stream(main)
             if rows is not None and getattr(rows, "stem", None) is not None:
                 keep.append(rows.stem)
+            if isinstance(plans, _GlobalPlan):
+                keep.append(plans.pts_all)
             for rounds in plans:
                 for rnd in rounds:
                     keep += [rnd.order, rnd.starts, rnd.n_out_dev, rnd.inv_seg, rnd.inv_cnt]
@@ -444,7 +465,12 @@ class NeRFRegTr(nn.Module):
         # one split (backward: one concatenation) instead of per-pair slices: autograd turns every slice of the [N_mask_total, 256]
         # feature tensor into a zero-filled full-size gradient plus an add (2.3 GB of traffic per step at 4 pairs)
         sizes = [idxs[2 * i].shape[0] + idxs[2 * i + 1].shape[0] for i in range(len(batch))]
-        xyz_all = torch.cat(pts_l) if len(pts_l) > 1 else pts_l[0]
+        self.__dict__["_last_plans"] = plans       # (tests: how many rounds the step's plan(s) took)
+        if isinstance(plans, _GlobalPlan):      # one plan over all pairs' rows
+            sizes = [sum(sizes)]
+            xyz_all = plans.pts_all
+        else:
+            xyz_all = torch.cat(pts_l) if len(pts_l) > 1 else pts_l[0]
         if self.batched_subsample and self.fused_gather_subsample and A.gather_subsample_applies(p1, s1_rows, plans):
             # gather + rounds as one node: its backward never writes the [N_mask_total, 256] gradient of the gathered features
             feats_all = A.gather_subsample(p1, idx_cat, pb_cat, res, s1_rows, plans, sizes)

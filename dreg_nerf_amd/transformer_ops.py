@@ -52,6 +52,31 @@ def plan_hierarchical_subsample(points, lengths, num_hierarchical=6, init_dl=0.0
     return rounds, points, lengths
 
 
+def plan_hierarchical_subsample_all(points, lengths, num_hierarchical=6, init_dl=0.025, radius=2.75, max_points=1500):
+    """plan_hierarchical_subsample for ALL pairs of a step with one set of launches (and one host sync) per round: points = the pairs' point sets one after the
+    other, lengths = [ns_0, nt_0, ns_1, nt_1, ...].  The reference's stopping rule is per pair (grid_downsample.py:83-94): a pair whose point count has
+    dropped to <= 2 * max_points takes no further round — here its two batches are FROZEN in the later rounds (they pass through unchanged and in order), so
+    the rounds' arrays cover every pair and downstream consumers see one plan over the whole row space.  Same key points, same segment means as the per-pair
+    plans (tests/test_hip_pointset_ops.py); 8 rounds of launches + 8 host syncs per step become 2-3 at the benchmark's batch.
+    Returns (rounds, subsampled points of all pairs, lengths)."""
+    lens = [int(v) for v in lengths]
+    npairs = len(lens) // 2
+    frozen = [False] * npairs
+    radius_normal = init_dl * radius
+    rounds = []
+    for _ in range(num_hierarchical):
+        dl = 2 * radius_normal / radius
+        rnd, points, lens = A.plan_voxel_downsample(points, lens, dl, frozen=[frozen[b // 2] for b in range(2 * npairs)])
+        rounds.append(rnd)
+        radius_normal *= 2
+        for p in range(npairs):
+            if lens[2 * p] + lens[2 * p + 1] <= 2 * max_points:
+                frozen[p] = True
+        if all(frozen):
+            break
+    return rounds, points, lens
+
+
 def apply_subsample_plan(rounds, feats):
     for rnd in rounds:
         feats = A.segment_mean(feats, rnd)

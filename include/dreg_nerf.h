@@ -558,6 +558,12 @@ int dreg_voxel_downsample_fwd(const float* pts, const float* feats, const int* p
 int dreg_voxel_downsample_plan(const float* pts, const int* pt_batch, float* out_pts, int* n_out, int* batch_counts,
                                uint32_t* inv_seg, float* inv_cnt, int* err, uint32_t* order, uint32_t* starts,
                                void* workspace, size_t workspace_bytes, int N, int nbatch, float dl, void* stream);
+/* the same with pass-through flags per batch id (frozen uint8 [nbatch] on the device, NULL = none): the rows of a frozen batch come out unchanged and in
+ * order (each row a cell of its own).  One set of launches then serves every pair of a step although a pair whose point count has dropped to <= 3,000
+ * takes no further round (grid_downsample.py:83-94). */
+int dreg_voxel_downsample_plan_frozen(const float* pts, const int* pt_batch, float* out_pts, int* n_out, int* batch_counts,
+                                      uint32_t* inv_seg, float* inv_cnt, int* err, uint32_t* order, uint32_t* starts,
+                                      void* workspace, size_t workspace_bytes, int N, int nbatch, float dl, const uint8_t* frozen, void* stream);
 int dreg_voxel_segment_mean(const float* feats, const uint32_t* order, const uint32_t* starts, const int* n_out,
                             float* out_feats, int M, int C, void* stream);
 int dreg_voxel_downsample_bwd(const float* gout, const uint32_t* inv_seg, const float* inv_cnt, float* gin, int N, int C,

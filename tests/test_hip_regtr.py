@@ -197,3 +197,38 @@ def test_training_step_with_learned_position_embedding():
             assert torch.isfinite(v).all() and not torch.equal(v.detach(), w0[k]), k
     sd = m.state_dict()
     assert sd["correspondence_decoder.pos_embed.mlp.0.weight"].data_ptr() == sd["pos_embed.mlp.0.weight"].data_ptr()
+
+
+def test_global_subsample_plan_equals_the_per_pair_plans():
+    """The voxel-average rounds planned for ALL pairs of a step at once (NeRFRegTr.global_subsample: one set of launches and one host sync per round; pairs that
+    have stopped — grid_downsample.py:83-94 — pass through the later rounds) against one plan per pair: same key points, same predictions, same parameter
+    gradients.  Three pairs with different point counts, so that they stop after different numbers of rounds."""
+    from dreg_nerf_amd.train_step import TrainStep  # noqa: F401
+    pose = synth.fixed_pose()
+    batch = []
+    for i, (r1, res) in enumerate(((0.83, 128), (0.90, 128), (0.815, 128))):       # ~19 k, ~50 k+, ~10 k occupied voxels per side
+        gs, ms = synth.shell_grid(res, 1 + 2 * i, 0.8, r1)
+        gt, mt = synth.shell_grid(res, 2 + 2 * i, 0.8, r1, pose=pose)
+        batch.append({"src_xyz_rgba": gs.permute(3, 2, 0, 1).unsqueeze(0).contiguous().cuda(), "tgt_xyz_rgba": gt.permute(3, 2, 0, 1).unsqueeze(0).contiguous().cuda(),
+                      "src_mask": ms.cuda(), "tgt_mask": mt.cuda(), "pose": pose[None].clone().cuda(), "src_nerf_path": "", "tgt_nerf_path": ""})
+    res = {}
+    for mode in (False, True):
+        m = _model("bf16", True)
+        m.native_trunk = False            # (per-op trunk: the comparison is about the point sets; the executor needs FlatAdamW's gradient buffers)
+        m.global_subsample = mode
+        preds = m.forward_batch(batch)
+        nrounds = [len(r) for r in m.__dict__.get("_last_plans", [])]
+        loss = sum((p["src_kp_warped"][0] ** 2).sum() + p["tgt_overlap"][0].sum() + (p["src_feats"][0][-1] ** 2).mean() for p in preds)
+        loss.backward()
+        named = dict(m.named_parameters())
+        res[mode] = ([(p["src_kp"][0].cpu(), p["tgt_kp"][0].cpu(), p["src_kp_warped"][0].detach().cpu(), p["pose"].cpu()) for p in preds],
+                     {k: named[k].grad.float().cpu() for k in ("fpn3d.feature_pyramid.upsample_transform_1.weight", "fpn3d.backbone_net.conv1.weight",
+                                                              "transformer_encoder.layers.0.linear1.weight", "correspondence_decoder.q_proj.weight")}, nrounds)
+    a, b = res[False], res[True]
+    assert len(a[2]) == 3 and len(set(a[2])) > 1, f"the pairs must stop after different numbers of rounds: {a[2]}"
+    assert len(b[2]) == 1 and b[2][0] == max(a[2])
+    for pa, pb in zip(a[0], b[0]):
+        for x, y in zip(pa, pb):
+            assert x.shape == y.shape and torch.equal(x, y)
+    for k in a[1]:
+        assert torch.equal(a[1][k], b[1][k]), k
