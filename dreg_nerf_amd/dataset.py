@@ -236,7 +236,9 @@ class NeRFRegDataset:
             blocks = {}
             for k in sorted(transforms):
                 d = os.path.join(root_fp, dataset, model_dir, scene, f"block_{k}")
-                if os.path.exists(os.path.join(d, "voxel_grid.pt")) or (not require_grids and os.path.exists(os.path.join(d, "model.pth"))):
+                # (voxel_sparse.pt alone counts: the lossless (idx, vals) cache load_block_sparse writes — a split whose 58.7 MB dense grids were dropped after caching)
+                if os.path.exists(os.path.join(d, "voxel_grid.pt")) or (sparse and os.path.exists(os.path.join(d, "voxel_sparse.pt"))) or \
+                        (not require_grids and os.path.exists(os.path.join(d, "model.pth"))):
                     blocks[k] = {"dir": d, "transform": transforms[k]}
             if len(blocks) >= 2:
                 self.meta.append({"scene": scene, "dataset": dataset, "blocks": blocks})
