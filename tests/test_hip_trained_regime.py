@@ -82,8 +82,7 @@ def test_trained_checkpoint_registers_held_out_scenes():
     # the exact-fp32 mode reproduces the reference-pinned oracle on the same grids; bf16 stays within the well-conditioned bounds of the pinned-step tests
     assert abs(fp32[name]["R_mean"] - orc[0]) < 2e-2 and abs(fp32[name]["t_mean"] - orc[1]) < 2e-4, rec["oracle_scene"]
     assert rec["bf16_vs_fp32_max_abs_diff"]["rre_deg"] < 0.5 and rec["bf16_vs_fp32_max_abs_diff"]["rte"] < 5e-3, rec["bf16_vs_fp32_max_abs_diff"]
-    # what training reached on the scenes it saw, reported by the evaluation chain (the best-VALIDATION checkpoint is an early one: 1.13 deg at step 12,000
-    # of run 2; the last checkpoints of both runs sit at 0.1-0.5 deg on their training batches — profiles/r06_trained_regime_run*_log.txt)
+    # what training reached on the scenes it saw, reported by the evaluation chain (0.41 deg in run 5; short / small runs: 1.1-1.5 deg — profiles/r06_trained_regime_run*_log.txt)
     assert insample["R_mean"] < 2.0, f"trained checkpoint: mean RRE {insample['R_mean']:.3f} deg on training scenes"
     # held-out objects: recorded; the bound is the caller's (a few hundred geometry-only synthetic objects do not give the reference's generalisation)
     bound = float(os.environ.get("DREG_TRAINED_RRE_BOUND", "1.0"))
@@ -97,7 +96,9 @@ def test_committed_trained_regime_record_is_consistent():
         pytest.skip("profiles/r06_trained_eval.json not collected")
     r = json.load(open(p))
     assert r["scenes"] >= 8 and r["checkpoint_step"] > 1000
-    assert r["training_scenes_bf16"]["rre_deg_mean"] < 2.0 and r["bf16_chain"]["rre_deg_mean"] < 10.0       # from ~15 deg at initialisation (identity prediction)
+    # run 5 (1,200 scenes, 40 k steps): sub-degree on the scenes it was trained on and in the median of the held-out scenes; from ~15 deg at initialisation
+    assert r["training_scenes_bf16"]["rre_deg_mean"] < 1.0 and r["bf16_chain_rre_deg_median"] < 1.0 and r["bf16_chain"]["rre_deg_mean"] < 5.0
+    assert sum(v[0] < 1.0 for v in r["per_scene_bf16"].values()) >= len(r["per_scene_bf16"]) // 2
     assert abs(r["oracle_scene"]["bf16_chain_rre_deg"] - r["oracle_scene"]["oracle_rre_deg"]) < 0.1
     assert abs(r["oracle_scene"]["fp32_mode_rre_deg"] - r["oracle_scene"]["oracle_rre_deg"]) < 2e-2
     assert r["bf16_vs_fp32_max_abs_diff"]["rre_deg"] < 0.5
