@@ -265,6 +265,9 @@ class NeRFRegDataset:
         if sb is None:
             h = load_block_sparse(block_dir)
             sb = SparseBlock(h.idx.pin_memory().to(self.device, non_blocking=True), h.vals.pin_memory().to(self.device, non_blocking=True), h.res)
+            # first upload only: wait for it on the uploading stream, so that a consumer on ANOTHER stream (forward_batch's geometry stream, when a script calls
+            # model(dataset[i]) without a loader's ready_event) never reads the block before it has arrived
+            torch.cuda.current_stream(torch.device(self.device)).synchronize()
             self._dev_blocks[block_dir] = sb
         return sb
 

@@ -558,6 +558,12 @@ def extract_and_register(scenes, model, device, batch_pairs: int = 4, pipeline: 
             batch.append({"src_sparse": a.sparse(), "tgt_sparse": b.sparse(), "pose": torch.as_tensor(pose, dtype=torch.float32)[None].to(dev, non_blocking=True),
                           "src_nerf_path": "", "tgt_nerf_path": ""})
         main = torch.cuda.current_stream(dev)
+        # the sparse blocks were gathered on THIS stream just now; forward_batch's geometry phase reads them on its own (side) stream: hand it the event
+        # (without it the side stream can read the coordinates before the gather has written them — seen once as "voxel coordinates overflow")
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for d in batch:
+            d["ready_event"] = ready
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(main)
         preds = model.forward_batch(batch)
