@@ -89,7 +89,7 @@ class _Slot:
         self.lock = threading.Lock()
 
     def reserve(self, n: int):
-        if n <= self.cap:
+        if n <= self.cap and self.cap > 0:          # (cap == 0: a fresh slot — an EMPTY block (n = 0) still needs its small buffers to exist)
             return
         cap = max(1 << max(n - 1, 1).bit_length(), 16384)
         if self.shared:

@@ -63,6 +63,36 @@ def test_pipelined_extraction_writes_the_serial_paths_files_byte_for_byte(tmp_pa
     assert not glob.glob(f"/dev/shm/dreg_{os.getpid()}_*"), "staging segments left behind after close()"
 
 
+def test_empty_and_nearly_empty_blocks_go_through_both_chains(tmp_path):
+    """Edge cases of the block loop (eval_ngp_nerf.py:336-451): a block whose occupancy grid is EMPTY, one with a handful of occupied cells and one with EVERY
+    cell occupied between ordinary blocks — both chains write the same files and the blocks around them are unaffected."""
+    import eval_ngp_nerf as E
+    from dreg_nerf_amd.eval_pipeline import ExtractionPipeline
+    mk = _chain_helpers()._make_block
+    a, b = str(tmp_path / "serial"), str(tmp_path / "pipelined")
+    shells = [(0.55, 1.05), (3.0, 3.1), (0.6, 1.0), (2.38, 2.6), (-1.0, 3.0)]          # ordinary, empty (no cell that far out), ordinary, only the aabb's corner cells, EVERY cell occupied
+    pa = []
+    for i, sh in enumerate(shells):
+        p = os.path.join(a, f"scene_{i // 2}", f"block_{i % 2}", "model.pth")
+        n_occ = mk(p, 70 + i, 32, sh)
+        assert (n_occ == 0) == (i == 1) and (i != 3 or 0 < n_occ < 200) and (i != 4 or n_occ == 32 ** 3)
+        pa.append(p)
+    shutil.copytree(a, b)
+    pb = [p.replace(a, b) for p in pa]
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(6)
+    kept_a = [E.extract_block(p, dev) for p in pa]
+    torch.manual_seed(6)
+    with ExtractionPipeline(dev, loaders=2, writers=2, slots=2, prefetch=2) as pipe:
+        kept_b = [e.kept() for e in pipe.run(pb)]
+    assert kept_a == kept_b and kept_a[1] == 0 and kept_a[0] > 50
+    for p, q in zip(pa, pb):
+        for f in FILES:
+            assert filecmp.cmp(os.path.join(os.path.dirname(p), f), os.path.join(os.path.dirname(q), f), shallow=False), (f, p)
+    empty = torch.load(os.path.join(os.path.dirname(pb[1]), "voxel_mask.pt"))
+    assert empty.dtype == torch.int64 and empty.numel() == 0 and float(torch.load(os.path.join(os.path.dirname(pb[1]), "voxel_grid.pt")).abs().sum()) == 0.0
+
+
 def test_extract_and_register_matches_registration_from_the_files(tmp_path):
     """The in-memory hand-over (device grids -> SparseBlock -> forward_batch in batches) gives the rows the file-based evaluation gives."""
     from dreg_nerf_amd import losses as LS
