@@ -296,6 +296,206 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same idea for 64 output channels: the three 64 -> 64 3^3 convolutions of layer1's bottlenecks at 32^3 (ResNet50 conv2 of
+// conerf/model/backbone/resnet.py Bottleneck; forward and data gradient).  In the implicit GEMM they gather 27 x 128 B per output row
+// through L2 and run at 0.29 of the MFMA roof.  With 64 output channels a wave can own ALL of them, so the 4 waves of a workgroup
+// split M only: a wave owns two z-planes (128 voxels) x 64 channels — the same 12 fragment reads per 16 MFMAs as the 256-channel
+// kernel — and a workgroup an 8 x 8 x 8 box whose 10^3 halo (one 32-channel chunk: 62.5 KiB) sits in LDS.
+// LDS 76 KiB (halo 64 KiB | weight ring 3 x 4 KiB): TWO workgroups per CU, so one workgroup's exposed halo load (there is no room for
+// a second halo buffer) and epilogue run under the other's MFMAs; the two are not synchronised, which also takes the place of the
+// anti-phase groups above.  One barrier per unit: at the top of unit u every wave has waited for its piece of unit u (vmcnt 1: only
+// unit u+1 may be outstanding) — behind the barrier unit u is complete and unit u-1 has been read by everyone, so unit u+2 goes into
+// unit u-1's slot.  27 % 3 == 0: ring slots are compile-time constants of the tap.
+namespace halo64 {
+constexpr int TZ = 8, TY = 8, TX = 8;
+constexpr int HY = TY + 2, HX = TX + 2, HVOX = (TZ + 2) * HY * HX;           // 1000
+constexpr int CK = 32;
+constexpr int HPW = 16;                                 // DMA pieces of 16 voxels x 64 B per wave: 64 >= ceil(1000 / 16) = 63
+constexpr int HBUF = 4 * HPW * 1024;                    // 65,536 B
+constexpr int UNIT = 64 * CK * 2;                       // 4,096 B of weights per (chunk, tap): one 1 KiB piece per wave
+constexpr int RING = 3;
+constexpr int LDS = HBUF + RING * UNIT;                 // 77,824 B
+}
+
+template <bool SPLITDS>
+__global__ __launch_bounds__(256, 2) void conv3_halo64_kernel(
+    const bf16_t* __restrict__ in, const bf16_t* __restrict__ wpk, bf16_t* __restrict__ out,
+    const float* __restrict__ bias, const bf16_t* __restrict__ addend, HaloGeom g, uint32_t in_bytes, uint32_t wt_bytes)
+{
+    using namespace halo64;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t tile = halo_xcd_remap(blockIdx.x, gridDim.x);
+    const int b = tile / g.tilesPerGrid;
+    int rem = tile - b * g.tilesPerGrid;
+    const int tz = rem / (g.tilesY * g.tilesX);
+    rem -= tz * (g.tilesY * g.tilesX);
+    const int ty = rem / g.tilesX, tx = rem - ty * g.tilesX;
+    const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wt = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, wt_bytes, 0x00020000);
+
+    // halo staging: this wave moves pieces wave, wave+4, ..., wave+60 (lane -> voxel lane>>2 of the piece, slot lane&3); same image as above
+    uint32_t hoff[HPW];
+#pragma unroll
+    for (int j = 0; j < HPW; ++j) {
+        const int hv = (wave + 4 * j) * 16 + (lane >> 2);
+        const int hz = hv / (HY * HX), r2 = hv - hz * (HY * HX), hy = r2 / HX, hx = r2 - hy * HX;
+        const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool v = hv < HVOX && (unsigned)gz < (unsigned)g.D && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+        const uint32_t vox = (uint32_t)(((b * g.D + gz) * g.H + gy) * g.W + gx);
+        hoff[j] = v ? vox * (uint32_t)(g.Cin * 2) + (uint32_t)((((lane & 3) ^ (hy & 3))) << 4) : halo::OOB;
+    }
+    // weight staging: piece `wave` of every unit (rows 16*wave .. +15; lane -> row lane>>2, slot lane&3)
+    const uint32_t wlane = (uint32_t)(wave * 1024 + (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
+
+    const int fr = lane & 31, fq = lane >> 5;
+    const int fx = fr & 7, fy = fr >> 3;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t a_lane = lds0 + (uint32_t)((((2 * wave) * HY + fy) * HX + fx) * 64);
+    uint32_t aA0[3], aA1[3];                               // per dy: k-half 0 / 1 address of this lane's row
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const uint32_t sw = (uint32_t)((fq ^ ((fy + dy) & 3)) << 4);
+        aA0[dy] = a_lane + sw;
+        aA1[dy] = a_lane + (sw ^ 32u);
+    }
+    const uint32_t b_sw0 = (uint32_t)((fq ^ ((fr >> 2) & 3)) << 4);
+    const uint32_t aB0 = lds0 + HBUF + (uint32_t)(fr * 64) + b_sw0;
+    const uint32_t aB1 = lds0 + HBUF + (uint32_t)(fr * 64) + (b_sw0 ^ 32u);
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto issue_halo = [&](int chunk) {
+        char* dst = smem + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < HPW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(dst + j * 4096), 16, (int)hoff[j], chunk * (CK * 2), 0, 0);
+    };
+    auto issue_unit = [&](int ring_w, int src_off) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wt, (lds_ptr_t)(smem + HBUF + ring_w + wave * 1024), 16, (int)(wlane + (uint32_t)src_off), 0, 0, 0);
+    };
+
+    issue_halo(0);
+    issue_unit(0, 0);
+    issue_unit(UNIT, UNIT);
+    int src_off = 2 * UNIT;               // byte offset of unit u+2 in the pack (units past the pack read as zeros: buffer bounds)
+#pragma unroll 1
+    for (int c = 0; c < g.nchunks; ++c) {
+        static_for(std::make_integer_sequence<int, 27>{}, [&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+            constexpr int dz = T / 9, dy = (T / 3) % 3, dx = T % 3;
+            constexpr int OA = ((dz * HY + dy) * HX + dx) * 64;
+            constexpr int OB = (T % RING) * UNIT, OW = ((T + 2) % RING) * UNIT;
+            if (T == 0) wait_vmcnt<0>(); else wait_vmcnt<1>();     // (tap 0: the chunk's halo pieces are the youngest loads)
+            __builtin_amdgcn_s_barrier();
+            i32x4_t a00, a01, a10, a11, a20, a21, a30, a31, b00, b01, b10, b11;   // [tile][k-half]
+            HALO_DSR(b00, aB0, OB);            HALO_DSR(b10, aB0, OB + 2048);
+            HALO_DSR(a00, aA0[dy], OA);        HALO_DSR(a10, aA0[dy], OA + 2560);  HALO_DSR(a20, aA0[dy], OA + 6400);  HALO_DSR(a30, aA0[dy], OA + 8960);
+            if (!SPLITDS) {
+                HALO_DSR(b01, aB1, OB);        HALO_DSR(b11, aB1, OB + 2048);
+                HALO_DSR(a01, aA1[dy], OA);    HALO_DSR(a11, aA1[dy], OA + 2560);  HALO_DSR(a21, aA1[dy], OA + 6400);  HALO_DSR(a31, aA1[dy], OA + 8960);
+            }
+            issue_unit(OW, src_off);
+            src_off += UNIT;
+            if (SPLITDS)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a00), "+v"(a10), "+v"(a20), "+v"(a30), "+v"(b00), "+v"(b10));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11), "+v"(a20), "+v"(a21), "+v"(a30), "+v"(a31),
+                               "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11));
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#define HALO_MM(i, j, A, Bv) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A), __builtin_bit_cast(bf16x8_t, Bv), acc[i][j], 0, 0, 0)
+#define HALO_SB() __builtin_amdgcn_sched_barrier(0)
+            if (SPLITDS) {
+                HALO_MM(0, 0, a00, b00); HALO_SB(); HALO_DSR(b01, aB1, OB);            HALO_SB();
+                HALO_MM(1, 0, a10, b00); HALO_SB(); HALO_DSR(b11, aB1, OB + 2048);     HALO_SB();
+                HALO_MM(2, 0, a20, b00); HALO_SB(); HALO_DSR(a01, aA1[dy], OA);        HALO_SB();
+                HALO_MM(3, 0, a30, b00); HALO_SB(); HALO_DSR(a11, aA1[dy], OA + 2560); HALO_SB();
+                HALO_MM(0, 1, a00, b10); HALO_SB(); HALO_DSR(a21, aA1[dy], OA + 6400); HALO_SB();
+                HALO_MM(1, 1, a10, b10); HALO_SB(); HALO_DSR(a31, aA1[dy], OA + 8960); HALO_SB();
+                HALO_MM(2, 1, a20, b10); HALO_MM(3, 1, a30, b10);
+                HALO_SB();
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a01), "+v"(a11), "+v"(a21), "+v"(a31), "+v"(b01), "+v"(b11));
+                HALO_SB();
+            } else {
+                HALO_MM(0, 0, a00, b00); HALO_MM(1, 0, a10, b00); HALO_MM(2, 0, a20, b00); HALO_MM(3, 0, a30, b00);
+                HALO_MM(0, 1, a00, b10); HALO_MM(1, 1, a10, b10); HALO_MM(2, 1, a20, b10); HALO_MM(3, 1, a30, b10);
+            }
+            HALO_MM(0, 0, a01, b01); HALO_MM(1, 0, a11, b01); HALO_MM(2, 0, a21, b01); HALO_MM(3, 0, a31, b01);
+            HALO_MM(0, 1, a01, b11); HALO_MM(1, 1, a11, b11); HALO_MM(2, 1, a21, b11); HALO_MM(3, 1, a31, b11);
+#undef HALO_MM
+#undef HALO_SB
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (c + 1 < g.nchunks) {
+            __builtin_amdgcn_s_barrier();          // every wave is done with this chunk's halo
+            issue_halo(c + 1);
+        }
+    }
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue: two passes of 256 voxels x 64 channels (fp32) through the halo buffer, then coalesced 16-byte stores with bias /
+    // addend applied in fp32.  Row r of a pass = (wave & 1) * 128 + tile * 32 + row of the MFMA tile; the two 32-channel halves of rows
+    // with bit 2 set are swapped (the MFMA's two k-groups of lanes hold rows 4 apart: without the swap they hit the same banks).
+    float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if ((wave >> 1) == p) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = (wave & 1) * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fq;
+                        sC[row * 64 + ((j * 32 + fr) ^ (fq << 5))] = acc[i][j][e];
+                    }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int cidx = t + 256 * it;
+            const int row = cidx >> 3, c8 = (cidx & 7) * 8;
+            const int i = (row >> 5) & 3, r = row & 31;
+            const int z = z0 + 2 * (2 * p + (row >> 7)) + (i >> 1), y = y0 + 4 * (i & 1) + (r >> 3), x = x0 + (r & 7);
+            const float* sp = sC + row * 64 + (c8 ^ (((row >> 2) & 1) << 5));
+            const float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4);
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            if (bias) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bias[c8 + e];
+            }
+            if (addend) {
+                const bf16_t* ap = addend + ((size_t)((b * g.Da + (z >> g.add_shift)) * g.Ha + (y >> g.add_shift)) * g.Wa + (x >> g.add_shift)) * 64 + c8;
+                const uint4 q = *reinterpret_cast<const uint4*>(ap);
+                const uint32_t w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(w4[e] << 16); v[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u); }
+            }
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = f2bf2(v[2 * e], v[2 * e + 1]);
+            *reinterpret_cast<uint4*>(out + ((size_t)((b * g.D + z) * g.H + y) * g.W + x) * 64 + c8) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        __syncthreads();
+    }
+}
+
 // torch weight [Cout][Cin][3][3][3] fp32 -> [Cin/32][27][256 rows][32] bf16.
 //   forward      : row = co,  column = ci within the chunk, tap as stored:            pack[c][t][co][k] = W[co][32c+k][t]
 //   data gradient: row = ci,  column = co within the chunk, tap flipped (26 - t):     pack[c][t][ci][k] = W[32c+k][ci][26-t]
@@ -303,6 +503,8 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(
 // experiments only (include/dreg_nerf_probe.h): 0 = anti-phase groups (default); 1 = lockstep; 3 = all 12 fragment reads in the load half;
 // 5 = profiled; 1x = ablations; -1 = dreg_conv3_halo_use() answers 0 (the implicit-GEMM kernel serves every shape: A/B tests)
 DREG_KNOB(int, g_halo_variant, 0);
+// 64-output-channel kernel: 1 = on (default), 0 = dreg_conv3_halo_use() answers 0 for Cout = 64 (A/B tests), 2 = all 12 fragment reads before the MFMAs
+DREG_KNOB(int, g_halo64, 1);
 
 __global__ __launch_bounds__(256) void pack_weight_halo_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int transposed)
 {
@@ -333,34 +535,40 @@ extern "C" {
 
 #ifdef DREG_PROBE
 void dreg_conv3_halo_set_variant(int v) { g_halo_variant = v; }
+void dreg_conv3_halo64_set(int v) { g_halo64 = v; }
 void dreg_conv3_halo_set_prof(void* buf) { g_halo_prof = (unsigned long long*)buf; }   // 64 blocks x 8 waves x 5 u64 (variant 5)
 #endif
 
-// 1 when (shape) is served by the halo kernel: 3^3 / stride 1 / pad 1, 256 output channels, Cin % 32 == 0, volume divisible by the
-// 4 x 8 x 8 box, operands below 2 GiB (32-bit buffer offsets)
+// 1 when (shape) is served by a halo kernel: 3^3 / stride 1 / pad 1, Cin % 32 == 0, operands below 2 GiB (32-bit buffer offsets) and
+// 256 output channels with the volume divisible by the 4 x 8 x 8 box, or 64 output channels with the volume divisible by 8 x 8 x 8
 int dreg_conv3_halo_supported(int B, int D, int H, int W, int Cin, int Cout)
 {
-    if (Cout != 256 || Cin % 32 != 0 || Cin < 32 || D % halo::TZ || H % halo::TY || W % halo::TX) return 0;
-    if ((uint64_t)B * D * H * W * (Cin > 256 ? Cin : 256) * 2 >= 0x7fffff00ull) return 0;
+    if (Cin % 32 != 0 || Cin < 32) return 0;
+    if (Cout == 256) { if (D % halo::TZ || H % halo::TY || W % halo::TX) return 0; }
+    else if (Cout == 64) { if (D % halo64::TZ || H % halo64::TY || W % halo64::TX) return 0; }
+    else return 0;
+    if ((uint64_t)B * D * H * W * (Cin > Cout ? Cin : Cout) * 2 >= 0x7fffff00ull) return 0;
     return 1;
 }
 
-// 1 when a bf16 convolution (ksz, stride, pad; Cin -> Cout over [B,D,H,W]) should run on the halo kernel: supported shape and enough
-// 4 x 8 x 8 boxes to fill the chip (a box keeps a CU busy for ~100 us; small volumes are better served by the split-K implicit GEMM).
-// The decision depends on the per-grid shape only, never on B: a pair's result does not depend on its batch mates.
+// 1 when a bf16 convolution (ksz, stride, pad; Cin -> Cout over [B,D,H,W]) should run on a halo kernel: supported shape and enough
+// boxes to fill the chip (a 4 x 8 x 8 box of the 256-channel kernel keeps a CU busy for ~100 us; small volumes are better served by the
+// split-K implicit GEMM).  The decision depends on the per-grid shape only, never on B: a pair's result does not depend on its batch mates.
 int dreg_conv3_halo_use(int B, int D, int H, int W, int Cin, int Cout, int ksz, int stride, int pad)
 {
     if (g_halo_variant < 0 || ksz != 3 || stride != 1 || pad != 1 || !dreg_conv3_halo_supported(B, D, H, W, Cin, Cout)) return 0;
+    if (Cout == 64) return g_halo64 && (D / halo64::TZ) * (H / halo64::TY) * (W / halo64::TX) >= 64;      // >= 32^3 per grid
     return (D / halo::TZ) * (H / halo::TY) * (W / halo::TX) >= 128;      // >= 32^3 per grid
 }
 
 size_t dreg_conv3_halo_pack_bytes(int Cin_red) { return (size_t)(Cin_red / 32) * 27 * halo::UNIT; }
+size_t dreg_conv3_halo_pack_bytes_n(int Cin_red, int rows) { return (size_t)(Cin_red / 32) * 27 * rows * halo::CK * 2; }
 
-// w: torch layout fp32 [Cout][Cin][27]; transposed = 0: forward pack (Cout must be 256), 1: data-gradient pack (Cin must be 256)
+// w: torch layout fp32 [Cout][Cin][27]; transposed = 0: forward pack (Cout must be 256 or 64), 1: data-gradient pack (Cin must be 256 or 64)
 int dreg_pack_conv_weight_halo(const float* w, void* out, int Cout, int Cin, int transposed, void* stream)
 {
     const int rows = transposed ? Cin : Cout, red = transposed ? Cout : Cin;
-    if (rows != 256 || red % 32 != 0) return DREG_EINVAL;
+    if ((rows != 256 && rows != 64) || red % 32 != 0) return DREG_EINVAL;
     hipLaunchKernelGGL(pack_weight_halo_kernel, dim3((red / 32) * 27), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)out, Cout, Cin, transposed);
     DREG_LAUNCH_CHECK();
     return DREG_OK;
@@ -401,5 +609,34 @@ int dreg_conv3_halo(const void* in, const void* wpk, void* out, const float* bia
     DREG_LAUNCH_CHECK();
     return DREG_OK;
 }
+
+// The same for Cout output channels (256: dreg_conv3_halo; 64: the 8 x 8 x 8-box kernel, bf16 output only).
+int dreg_conv3_halo_n(const void* in, const void* wpk, void* out, const float* bias, const void* addend,
+                      int B, int D, int H, int W, int Cin, int Cout, int Da, int Ha, int Wa, int add_same, int out_f32, void* stream)
+{
+    if (Cout == 256) return dreg_conv3_halo(in, wpk, out, bias, addend, B, D, H, W, Cin, Da, Ha, Wa, add_same, out_f32, stream);
+    using namespace halo64;
+    if (Cout != 64 || out_f32 || !dreg_conv3_halo_supported(B, D, H, W, Cin, 64)) return DREG_EINVAL;
+    HaloGeom g;
+    g.B = B; g.D = D; g.H = H; g.W = W; g.Cin = Cin; g.nchunks = Cin / CK;
+    g.tilesY = H / TY; g.tilesX = W / TX; g.tilesPerGrid = (D / TZ) * g.tilesY * g.tilesX;
+    g.Da = Da; g.Ha = Ha; g.Wa = Wa; g.add_shift = add_same ? 0 : 1;
+    const uint32_t ntiles = (uint32_t)B * g.tilesPerGrid;
+    if (ntiles == 0) return DREG_OK;
+    const uint32_t in_bytes = (uint32_t)((uint64_t)B * D * H * W * Cin * 2), wt_bytes = (uint32_t)dreg_conv3_halo_pack_bytes_n(Cin, 64);
+    hipStream_t st = (hipStream_t)stream;
+    if (g_halo64 == 2) {
+        (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipLaunchKernelGGL((conv3_halo64_kernel<false>), dim3(ntiles), dim3(256), LDS, st, (const bf16_t*)in, (const bf16_t*)wpk, (bf16_t*)out,
+                           bias, (const bf16_t*)addend, g, in_bytes, wt_bytes);
+    } else {
+        (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipLaunchKernelGGL((conv3_halo64_kernel<true>), dim3(ntiles), dim3(256), LDS, st, (const bf16_t*)in, (const bf16_t*)wpk, (bf16_t*)out,
+                           bias, (const bf16_t*)addend, g, in_bytes, wt_bytes);
+    }
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
+
 
 }  // extern "C"

@@ -366,7 +366,13 @@ void* dreg_exec_create_opts(const int* tensors, int nt, const int* ops, int nops
             if (V % 128 != 0 || dreg_bn_small(x.B, V, x.C, 0)) continue;
             int prod = -1, writers = 0;
             for (size_t i = 0; i < j; ++i) if (e->ops[i].out == bn.in) { prod = (int)i; ++writers; }
-            if (writers != 1 || e->ops[prod].kind != OP_CONV || (e->ops[prod].halo & 1) || e->ops[prod].stats_bn >= 0) continue;
+            if (writers != 1 || e->ops[prod].kind != OP_CONV || e->ops[prod].stats_bn >= 0) continue;
+            {   // a forward on a halo kernel (decided below by the same predicate) has no statistics epilogue: that BatchNorm runs its own pass
+                const Op& pc = e->ops[prod];
+                const Tensor& px = e->t[pc.in];
+                const Param& pp = e->prm[pc.w];
+                if (!pc.relu && pp.d1 == px.C && dreg_conv3_halo_use(px.B, px.D, px.H, px.W, px.C, pp.d0, pc.ksz, pc.stride, pc.pad)) continue;
+            }
             e->ops[prod].stats_bn = (int)j;
             bn.stats_conv = prod;
             off.name("epilogue chunk sums of BatchNorm op", (int)j);
@@ -473,7 +479,7 @@ void* dreg_exec_create_opts(const int* tensors, int nt, const int* ops, int nops
     };
     auto add_halo_pack = [&](Param& p, int transposed) {
         HaloPack hp{p.val, poff, p.d0, p.d1, transposed, 0};
-        poff += align256(dreg_conv3_halo_pack_bytes(transposed ? p.d0 : p.d1));
+        poff += align256(dreg_conv3_halo_pack_bytes_n(transposed ? p.d0 : p.d1, transposed ? p.d1 : p.d0));
         e->halo_packs.push_back(hp);
         return hp.off;
     };
@@ -489,7 +495,7 @@ void* dreg_exec_create_opts(const int* tensors, int nt, const int* ops, int nops
         const Tensor& x = e->t[o.in];
         const Tensor& y = e->t[o.out];
         if (o.kind == OP_CONV && !o.relu) {
-            // dense 3^3 convolutions with 256 output channels on large volumes: forward x -> y, data gradient gy -> gx (needs 256 INPUT channels)
+            // dense 3^3 convolutions with 256 (or 64) output channels on large volumes: forward x -> y, data gradient gy -> gx (needs 256 / 64 INPUT channels)
             if (dreg_conv3_halo_use(x.B, x.D, x.H, x.W, x.C, p.d0, o.ksz, o.stride, o.pad) && p.d1 == x.C) o.halo |= 1;
             if (e->needs_grad[o.in] && dreg_conv3_halo_use(y.B, y.D, y.H, y.W, p.d0, p.d1, o.ksz, o.stride, o.pad) && p.d0 % 32 == 0) o.halo |= 2;
         }
@@ -725,8 +731,8 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
             }
             Scope sc(e, st, (int)i, 0);
             if (o.halo & 1) {
-                CK(dreg_conv3_halo(act(o.in), PK + w.pk_halo_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0,
-                                   o.add_same, 0, stream));
+                CK(dreg_conv3_halo_n(act(o.in), PK + w.pk_halo_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, w.d0, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0,
+                                     o.add_same, 0, stream));
                 continue;
             }
             if (train && o.stats_bn >= 0 && !(o.in == 0 && e->in_rowocc)) {
@@ -1092,8 +1098,8 @@ int dreg_exec_backward_range(void* h, void* arena, size_t arena_bytes, const voi
                 Scope sc(e, st, i, 1);
                 if (halo_d) {
                     // gx = [gx +] conv(gy, flipped-tap pack): the halo kernel's same-size addend is the in-place accumulation
-                    CK(dreg_conv3_halo(gy, PK + w.pk_halo_dgrad, gx, nullptr, fused_add ? gx : nullptr, y.B, y.D, y.H, y.W, w.d0,
-                                       fused_add ? x.D : 0, fused_add ? x.H : 0, fused_add ? x.W : 0, 1, 0, stream));
+                    CK(dreg_conv3_halo_n(gy, PK + w.pk_halo_dgrad, gx, nullptr, fused_add ? gx : nullptr, y.B, y.D, y.H, y.W, w.d0, w.d1,
+                                         fused_add ? x.D : 0, fused_add ? x.H : 0, fused_add ? x.W : 0, 1, 0, stream));
                 } else if (fused_add && s2_cls) {
                     CK(dreg_conv3d_dgrad_s2_acc(gy, PK + w.pk_cls, gx, x.B, x.D, x.H, x.W, x.C, y.D, y.H, y.W, w.d0, o.ksz, o.pad, stream));
                 } else if (fused_add) {

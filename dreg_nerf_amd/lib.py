@@ -71,6 +71,8 @@ SIGNATURES = {
     "dreg_conv3_halo_pack_bytes": (Z, [I]),
     "dreg_pack_conv_weight_halo": (I, [P, P, I, I, I, P]),
     "dreg_conv3_halo": (I, [P, P, P, P, P] + [I] * 10 + [P]),
+    "dreg_conv3_halo_pack_bytes_n": (Z, [I, I]),
+    "dreg_conv3_halo_n": (I, [P, P, P, P, P] + [I] * 11 + [P]),
     "dreg_conv3d_wgrad_variant": (I, [I] * 10),
     "dreg_conv3d_igemm_variant": (I, [I] * 17),
     "dreg_conv3d_wgrad_group_fill": (I, [P, P, P, P, Z] + [I] * 12 + [P, P]),
@@ -262,6 +264,7 @@ PROBE_SIGNATURES = {
     "dreg_voxel_set_own_sort": (None, [I]),
     "dreg_conv_set_bn_stats_epilogue": (None, [I]),
     "dreg_conv3_halo_set_variant": (None, [I]),
+    "dreg_conv3_halo64_set": (None, [I]),
     "dreg_conv3_halo_set_prof": (None, [P]),
     "dreg_bn_set_small_max_voxels": (None, [I]),
     "dreg_ngp_set_rgb_chunks": (None, [I]),

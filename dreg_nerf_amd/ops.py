@@ -275,7 +275,7 @@ _halo_cache = {}
 
 
 def halo_packed_weight(w: torch.Tensor, transposed: bool) -> torch.Tensor:
-    """bf16 [chunk][tap][256][32] pack of a 3^3 weight for the halo kernel (forward, or the flipped-tap data-gradient form), cached
+    """bf16 [chunk][tap][rows][32] pack (rows = 256 or 64 output channels) of a 3^3 weight for the halo kernels (forward, or the flipped-tap data-gradient form), cached
     against the parameter's version / the optimizer generation like packed_weight()."""
     wait_packs()
     base = w._base if w._base is not None else w
@@ -287,7 +287,7 @@ def halo_packed_weight(w: torch.Tensor, transposed: bool) -> torch.Tensor:
     lib = L.load()
     cout, cin = w.shape[0], w.shape[1]
     out = hit[2] if hit is not None and hit[0]() is base else \
-        torch.empty(lib.dreg_conv3_halo_pack_bytes(cout if transposed else cin) // 2, dtype=torch.bfloat16, device=w.device)
+        torch.empty(lib.dreg_conv3_halo_pack_bytes_n(cout if transposed else cin, cin if transposed else cout) // 2, dtype=torch.bfloat16, device=w.device)
     L.check(lib.dreg_pack_conv_weight_halo(L.ptr(w.detach().contiguous()), L.ptr(out), cout, cin, int(transposed), L.stream()), "dreg_pack_conv_weight_halo")
     if len(_halo_cache) > 64:
         for k in [k for k, v in _halo_cache.items() if v[0]() is None]:
@@ -297,28 +297,29 @@ def halo_packed_weight(w: torch.Tensor, transposed: bool) -> torch.Tensor:
 
 
 def halo_applies(x_shape, cin, cout, ksz, stride, pad, dt) -> bool:
-    """The dense 3^3 / 256-output-channel convolutions of large volumes run on the halo kernel (csrc/conv_halo.hip) — the same
+    """The dense 3^3 convolutions with 256 (or 64) output channels on large volumes run on the halo kernels (csrc/conv_halo.hip) — the same
     predicate the native trunk executor uses."""
     return dt == L.DT_BF16 and bool(L.load().dreg_conv3_halo_use(x_shape[0], x_shape[1], x_shape[2], x_shape[3], cin, cout, ksz, stride, pad))
 
 
 def conv_halo(x, w, bias, addend, transposed: bool, add_same: bool = False, out_f32: bool = False):
-    """x [B,D,H,W,C] bf16 -> [B,D,H,W,256]: 3^3 / stride 1 / pad 1 with w [Cout,Cin,3,3,3] (transposed: the data gradient, x = dOut)."""
+    """x [B,D,H,W,C] bf16 -> [B,D,H,W,n] (n = 256 or 64): 3^3 / stride 1 / pad 1 with w [Cout,Cin,3,3,3] (transposed: the data gradient, x = dOut, n = Cin)."""
     lib = L.load()
     B, D, H, W, C = x.shape
-    out = torch.empty(B, D, H, W, 256, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    n = w.shape[1] if transposed else w.shape[0]
+    out = torch.empty(B, D, H, W, n, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     Da = Ha = Wa = 0
     if addend is not None:
-        assert addend.dtype == out.dtype and addend.shape[0] == B and addend.shape[4] == 256
+        assert addend.dtype == out.dtype and addend.shape[0] == B and addend.shape[4] == n
         Da, Ha, Wa = addend.shape[1:4]
     ev = None
     if PROFILER is not None:
-        label = f"{'dgrad' if transposed else 'fwd'} B{B} {D}x{H}x{W}x{C}->{D}x{H}x{W}x256 k3s1"
-        ev = PROFILER.record("conv3_halo_kernel<bf16>", label, 2.0 * B * D * H * W * 256 * 27 * C)
+        label = f"{'dgrad' if transposed else 'fwd'} B{B} {D}x{H}x{W}x{C}->{D}x{H}x{W}x{n} k3s1"
+        ev = PROFILER.record("conv3_halo64_kernel<bf16>" if n == 64 else "conv3_halo_kernel<bf16>", label, 2.0 * B * D * H * W * n * 27 * C)
         if ev is not None:
             ev[0].record()
-    L.check(lib.dreg_conv3_halo(L.ptr(x), L.ptr(halo_packed_weight(w, transposed)), L.ptr(out), L.ptr(bias), L.ptr(addend), B, D, H, W, C,
-                                Da, Ha, Wa, int(add_same), int(out_f32), L.stream()), "dreg_conv3_halo")
+    L.check(lib.dreg_conv3_halo_n(L.ptr(x), L.ptr(halo_packed_weight(w, transposed)), L.ptr(out), L.ptr(bias), L.ptr(addend), B, D, H, W, C, n,
+                                  Da, Ha, Wa, int(add_same), int(out_f32), L.stream()), "dreg_conv3_halo_n")
     if ev is not None:
         ev[1].record()
     return out

@@ -214,9 +214,9 @@ class TrunkExecutor:
             dname_add = None if is_rows else dgrad_name(0, add=True)      # the accumulating form (the executor reports which one ran)
             halo = self.lib.dreg_exec_op_halo(self.h, i)
             if halo & 1:
-                fname = "conv3_halo_kernel<bf16>"
+                fname = "conv3_halo64_kernel<bf16>" if cout == 64 else "conv3_halo_kernel<bf16>"
             if halo & 2:
-                dname = "conv3_halo_kernel<bf16>"
+                dname = "conv3_halo64_kernel<bf16>" if x[4] == 64 else "conv3_halo_kernel<bf16>"
             rows = "-rows" if is_rows else ""
             fl = 2.0 * M * cout * k ** 3 * cin
             # active-set launches: flops per row, scaled by the step's row count (list id) when the records are drained

@@ -94,18 +94,26 @@ int dreg_bn3d_fwd_from_sums(const void* x, const void* res, void* y, const float
  * the FeaturePyramid_v1 head's upsample_transform_* / pyramid_transformation_1 layers (conerf/model/feature_pyramid_net.py:47-56,
  * 97-103; cuDNN conv3d in the reference) and their data gradients.  A workgroup owns a 4 x 8 x 8 box of output voxels, stages its
  * 6 x 10 x 10 input halo once per 32-channel chunk and runs all 27 taps out of LDS; only the weights stream per tap.
- * dreg_conv3_halo_supported: 1 when the shape qualifies (Cout == 256, Cin % 32 == 0, D % 4 == H % 8 == W % 8 == 0, operands < 2 GiB).
+ * A second kernel serves 64 output channels — conv2 of layer1's bottlenecks at 32^3 (conerf/model/backbone/resnet.py Bottleneck) and its data
+ * gradient: 8 x 8 x 8 boxes, four waves that each own two z-planes x all 64 channels, two workgroups per CU (dreg_conv3_halo_n).
+ * dreg_conv3_halo_supported: 1 when the shape qualifies (Cin % 32 == 0, operands < 2 GiB; Cout == 256 with D % 4 == H % 8 == W % 8 == 0, or
+ *   Cout == 64 with D % 8 == H % 8 == W % 8 == 0).
  * dreg_pack_conv_weight_halo: torch weight fp32 [Cout][Cin][27] -> bf16 [Cin'/32][27][256][32] (dreg_conv3_halo_pack_bytes(Cin') bytes);
  *   transposed = 0: forward pack (Cout must be 256, Cin' = Cin); 1: data-gradient pack (Cin must be 256, Cin' = Cout, taps flipped).
  * dreg_conv3_halo: out[b,v,:] = bias + addend + sum_d in[b, v - 1 + d, :] . W[:, d, :]; in [B,D,H,W,Cin] bf16, out [B,D,H,W,256] bf16
  *   (fp32 when out_f32), addend [B,Da,Ha,Wa,256] of out's dtype added with nearest x2 upsampling (add_same = 0) or element-wise (1). */
 int dreg_conv3_halo_supported(int B, int D, int H, int W, int Cin, int Cout);
-/* supported AND large enough per grid (>= 128 boxes, i.e. 32^3) to beat the split-K implicit GEMM; independent of B */
+/* supported AND large enough per grid (>= 32^3) to beat the split-K implicit GEMM; independent of B */
 int dreg_conv3_halo_use(int B, int D, int H, int W, int Cin, int Cout, int ksz, int stride, int pad);
 size_t dreg_conv3_halo_pack_bytes(int Cin_reduced);
 int dreg_pack_conv_weight_halo(const float* w, void* out, int Cout, int Cin, int transposed, void* stream);
 int dreg_conv3_halo(const void* in, const void* wpk, void* out, const float* bias, const void* addend,
                     int B, int D, int H, int W, int Cin, int Da, int Ha, int Wa, int add_same, int out_f32, void* stream);
+/* rows = 256 or 64 output channels: pack size ([Cin'/32][27][rows][32] bf16; dreg_pack_conv_weight_halo takes either) and the launch
+ * (out / addend [..., Cout]; Cout == 64: bf16 output only) */
+size_t dreg_conv3_halo_pack_bytes_n(int Cin_reduced, int rows);
+int dreg_conv3_halo_n(const void* in, const void* wpk, void* out, const float* bias, const void* addend,
+                      int B, int D, int H, int W, int Cin, int Cout, int Da, int Ha, int Wa, int add_same, int out_f32, void* stream);
 
 /* Data gradient of a stride-2 convolution (ksz 3 / pad 1: resnet3d.py conv2 of the first block of layer2-4; ksz 1 / pad 0: the
  * downsample branch) without the 7/8 structurally-zero taps of the gather form: ONE 2^3-tap convolution over dOut whose

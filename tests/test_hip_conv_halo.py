@@ -87,3 +87,87 @@ def test_halo_agrees_with_implicit_gemm_kernel_on_the_dominant_layer():
     # both round the same fp32 sum (up to ~1e-6 relative) to bf16: they differ by at most one bf16 ulp, and only rarely
     assert diff.max().item() <= 2 ** -7 * a.abs().max().item()
     assert (diff > 0).float().mean().item() < 0.02
+
+
+# ---- the 64-output-channel kernel (conv2 of layer1's bottlenecks at 32^3 and its data gradient): 8 x 8 x 8 boxes, two workgroups per CU
+
+def _halo64(x, w, bias=None, addend=None, add_same=False, transposed=False, mode=1):
+    """x [B,D,H,W,C] bf16, w fp32 [Cout,Cin,3,3,3] -> [B,D,H,W,64] bf16 (transposed: the data gradient, 64 = Cin); mode 2: the unsplit-read form"""
+    if mode != 1:
+        with L.probe() as pr:
+            pr.set("dreg_conv3_halo64_set", mode, 1)
+            return _halo64(x, w, bias, addend, add_same, transposed, 1)
+    lib = L.load()
+    B, D, H, W, C = x.shape
+    cout, cin = w.shape[0], w.shape[1]
+    red, rows = (cout, cin) if transposed else (cin, cout)
+    assert rows == 64 and red == C and lib.dreg_conv3_halo_supported(B, D, H, W, red, 64) == 1
+    pk = torch.empty(lib.dreg_conv3_halo_pack_bytes_n(red, 64) // 2, dtype=torch.bfloat16, device=x.device)
+    L.check(lib.dreg_pack_conv_weight_halo(L.ptr(w.contiguous()), L.ptr(pk), cout, cin, int(transposed), L.stream()), "pack_halo")
+    out = addend if (addend is not None and add_same == "inplace") else torch.empty(B, D, H, W, 64, dtype=torch.bfloat16, device=x.device)
+    da, ha, wa = (addend.shape[1:4] if addend is not None else (0, 0, 0))
+    L.check(lib.dreg_conv3_halo_n(L.ptr(x), L.ptr(pk), L.ptr(out), L.ptr(bias), L.ptr(addend), B, D, H, W, red, 64, da, ha, wa, int(bool(add_same)), 0,
+                                  L.stream()), "dreg_conv3_halo_n")
+    return out
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("cin,shape", [(64, (2, 8, 16, 16)), (32, (1, 16, 8, 8)), (256, (1, 8, 8, 24)), (64, (3, 24, 8, 16))])
+def test_halo64_forward_matches_fp32_reference(cin, shape, mode):
+    g = torch.Generator().manual_seed(17)
+    B, D, H, W = shape
+    x = torch.randn(B, D, H, W, cin, generator=g).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(64, cin, 3, 3, 3, generator=g) * (2.0 / (27 * cin)) ** 0.5).to(DEV)
+    bias = torch.randn(64, generator=g).to(DEV)
+    tol = lambda ref: 2 ** -8 * ref.abs().max().item() + 1e-6          # one bf16 rounding of the fp32 sum  # noqa: E731
+    ref = _ref(x, w)
+    assert (_halo64(x, w, mode=mode).float() - ref).abs().max().item() <= tol(ref)
+    add2 = torch.randn(B, D // 2, H // 2, W // 2, 64, generator=g).to(DEV).to(torch.bfloat16)
+    ref = _ref(x, w, bias, add2)
+    assert (_halo64(x, w, bias, add2, mode=mode).float() - ref).abs().max().item() <= tol(ref)
+    add1 = torch.randn(B, D, H, W, 64, generator=g).to(DEV).to(torch.bfloat16)
+    ref = _ref(x, w, None, add1, add_same=True)
+    assert (_halo64(x, w, None, add1, add_same=True, mode=mode).float() - ref).abs().max().item() <= tol(ref)
+    # the accumulating form of the data gradients: the addend IS the output tensor
+    acc = add1.clone()
+    got = _halo64(x, w, None, acc, add_same="inplace", mode=mode)
+    assert got.data_ptr() == acc.data_ptr() and (got.float() - ref).abs().max().item() <= tol(ref)
+
+
+def test_halo64_data_gradient_matches_autograd():
+    g = torch.Generator().manual_seed(18)
+    B, D, H, W = 2, 8, 16, 8
+    for cout in (64, 128):                                                  # dOut of a 64 -> cout layer: the gradient has 64 channels
+        gy = torch.randn(B, D, H, W, cout, generator=g).to(DEV).to(torch.bfloat16)
+        w = (torch.randn(cout, 64, 3, 3, 3, generator=g) * 0.03).to(DEV)
+        xr = torch.zeros(B, 64, D, H, W, device=DEV, dtype=torch.float64, requires_grad=True)
+        y = F.conv3d(xr, w.to(torch.bfloat16).double(), padding=1)
+        y.backward(gy.double().permute(0, 4, 1, 2, 3))
+        ref = xr.grad.permute(0, 2, 3, 4, 1).float()
+        got = _halo64(gy, w, transposed=True).float()
+        assert (got - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-6
+
+
+def test_halo64_agrees_with_implicit_gemm_and_is_the_kernel_the_layer_runs_on():
+    """conv2 of a layer1 bottleneck (64 -> 64) on 32^3 x 2: same operands through both kernels (the accumulation order differs: chunk-major vs tap-major),
+    through ops.conv3d forward and backward — which routes the shape to the halo kernel — and with the kernel switched off in the measurement build."""
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(2, 32, 32, 32, 64, generator=g).to(DEV).to(torch.bfloat16).requires_grad_(True)
+    w = (torch.randn(64, 64, 3, 3, 3, generator=g) * 0.034).to(DEV).requires_grad_(True)
+    gy = torch.randn(2, 32, 32, 32, 64, generator=g).to(DEV).to(torch.bfloat16)
+    assert ops.halo_applies(x.shape, 64, 64, 3, 1, 1, L.DT_BF16) and not ops.halo_applies((2, 16, 16, 16, 64), 64, 64, 3, 1, 1, L.DT_BF16)
+    y = ops.conv3d(x, w, None, pad=1)
+    y.backward(gy)
+    direct = _halo64(x.detach(), w.detach())
+    assert torch.equal(y, direct)
+    assert torch.equal(x.grad, _halo64(gy, w.detach(), transposed=True))
+    gx_h = x.grad.clone()
+    x.grad = w.grad = None
+    with L.probe() as pr:
+        pr.set("dreg_conv3_halo64_set", 0, 1)
+        assert not ops.halo_applies(x.shape, 64, 64, 3, 1, 1, L.DT_BF16)
+        y2 = ops.conv3d(x, w, None, pad=1)
+        y2.backward(gy)
+    for a, b in ((y, y2), (gx_h, x.grad)):
+        diff = (a.float() - b.float()).abs()
+        assert diff.max().item() <= 2 ** -7 * b.float().abs().max().item() and (diff > 0).float().mean().item() < 0.02
