@@ -318,10 +318,14 @@ constexpr int RING = 3;
 constexpr int LDS = HBUF + RING * UNIT;                 // 77,824 B
 }
 
-template <bool SPLITDS>
+// STATS: the BatchNorm behind this convolution gets its chunk sums from here (the layout of dreg_conv3d_igemm_bnstats: [B][V / 128][64][2] sums of the
+// STORED values and of their squares; a chunk is one wave's 128 voxels — two z-planes of the box —, chunk index tile * 4 + wave).  The order of
+// every addition is fixed by the box geometry alone, never by how many grids share the launch.
+template <bool SPLITDS, bool STATS>
 __global__ __launch_bounds__(256, 2) void conv3_halo64_kernel(
     const bf16_t* __restrict__ in, const bf16_t* __restrict__ wpk, bf16_t* __restrict__ out,
-    const float* __restrict__ bias, const bf16_t* __restrict__ addend, HaloGeom g, uint32_t in_bytes, uint32_t wt_bytes)
+    const float* __restrict__ bias, const bf16_t* __restrict__ addend, HaloGeom g, uint32_t in_bytes, uint32_t wt_bytes,
+    float* __restrict__ bn_part)
 {
     using namespace halo64;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -467,6 +471,13 @@ __global__ __launch_bounds__(256, 2) void conv3_halo64_kernel(
                     }
         }
         __syncthreads();
+        float bs1[2][8], bs2[2][8];                  // STATS: this thread's 8 channels, rows t/8 + 32 * it: it < 4 -> the pass's first chunk, else its second
+        if constexpr (STATS) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { bs1[h][e] = 0.f; bs2[h][e] = 0.f; }
+        }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int cidx = t + 256 * it;
@@ -491,6 +502,33 @@ __global__ __launch_bounds__(256, 2) void conv3_halo64_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) w[e] = f2bf2(v[2 * e], v[2 * e + 1]);
             *reinterpret_cast<uint4*>(out + ((size_t)((b * g.D + z) * g.H + y) * g.W + x) * 64 + c8) = make_uint4(w[0], w[1], w[2], w[3]);
+            if constexpr (STATS) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = __uint_as_float(w[e] << 16), c = __uint_as_float(w[e] & 0xffff0000u);
+                    bs1[it >> 2][2 * e] += a;      bs2[it >> 2][2 * e] += a * a;
+                    bs1[it >> 2][2 * e + 1] += c;  bs2[it >> 2][2 * e + 1] += c * c;
+                }
+            }
+        }
+        if constexpr (STATS) {
+            // the 32 threads with the same t & 7 hold a chunk's 128 rows: 8 lanes of each wave (xor 8, 16, 32), then the four waves in order
+            float* red = reinterpret_cast<float*>(smem + HBUF);              // [wave][chunk of the pass][64 channels][2] (the weight ring is idle)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float a = bs1[h][e], c = bs2[h][e];
+#pragma unroll
+                    for (int o = 8; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+                    if (lane < 8) { red[((wave * 2 + h) * 64 + lane * 8 + e) * 2] = a; red[((wave * 2 + h) * 64 + lane * 8 + e) * 2 + 1] = c; }
+                }
+            __syncthreads();
+            {
+                const int h = t >> 7, cw = t & 127;                          // (channel, which) of chunk h
+                const float sum = ((red[(0 * 2 + h) * 128 + cw] + red[(1 * 2 + h) * 128 + cw]) + red[(2 * 2 + h) * 128 + cw]) + red[(3 * 2 + h) * 128 + cw];
+                bn_part[((size_t)tile * 4 + 2 * p + h) * 128 + cw] = sum;
+            }
         }
         __syncthreads();
     }
@@ -611,9 +649,12 @@ int dreg_conv3_halo(const void* in, const void* wpk, void* out, const float* bia
 }
 
 // The same for Cout output channels (256: dreg_conv3_halo; 64: the 8 x 8 x 8-box kernel, bf16 output only).
-int dreg_conv3_halo_n(const void* in, const void* wpk, void* out, const float* bias, const void* addend,
-                      int B, int D, int H, int W, int Cin, int Cout, int Da, int Ha, int Wa, int add_same, int out_f32, void* stream)
+// dreg_conv3_halo_n_bnstats: the forward that also leaves the BatchNorm statistics of its output behind, like dreg_conv3d_igemm_bnstats: bn_partial
+// [B][V / *rows_per_chunk][Cout][2]; *rows_per_chunk = 0 when the kernel has no such epilogue (Cout = 256: the BatchNorm runs its own pass).
+static int halo_n_impl(const void* in, const void* wpk, void* out, const float* bias, const void* addend, int B, int D, int H, int W, int Cin, int Cout,
+                       int Da, int Ha, int Wa, int add_same, int out_f32, float* bn_partial, int* rows_per_chunk, void* stream)
 {
+    if (rows_per_chunk) *rows_per_chunk = 0;
     if (Cout == 256) return dreg_conv3_halo(in, wpk, out, bias, addend, B, D, H, W, Cin, Da, Ha, Wa, add_same, out_f32, stream);
     using namespace halo64;
     if (Cout != 64 || out_f32 || !dreg_conv3_halo_supported(B, D, H, W, Cin, 64)) return DREG_EINVAL;
@@ -625,18 +666,27 @@ int dreg_conv3_halo_n(const void* in, const void* wpk, void* out, const float* b
     if (ntiles == 0) return DREG_OK;
     const uint32_t in_bytes = (uint32_t)((uint64_t)B * D * H * W * Cin * 2), wt_bytes = (uint32_t)dreg_conv3_halo_pack_bytes_n(Cin, 64);
     hipStream_t st = (hipStream_t)stream;
-    if (g_halo64 == 2) {
-        (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        hipLaunchKernelGGL((conv3_halo64_kernel<false>), dim3(ntiles), dim3(256), LDS, st, (const bf16_t*)in, (const bf16_t*)wpk, (bf16_t*)out,
-                           bias, (const bf16_t*)addend, g, in_bytes, wt_bytes);
-    } else {
-        (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        hipLaunchKernelGGL((conv3_halo64_kernel<true>), dim3(ntiles), dim3(256), LDS, st, (const bf16_t*)in, (const bf16_t*)wpk, (bf16_t*)out,
-                           bias, (const bf16_t*)addend, g, in_bytes, wt_bytes);
-    }
+#define HALO64_LAUNCH(SD, STv) do { \
+        (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<SD, STv>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+        hipLaunchKernelGGL((conv3_halo64_kernel<SD, STv>), dim3(ntiles), dim3(256), LDS, st, (const bf16_t*)in, (const bf16_t*)wpk, (bf16_t*)out, \
+                           bias, (const bf16_t*)addend, g, in_bytes, wt_bytes, bn_partial); } while (0)
+    if (g_halo64 == 2) { if (bn_partial) HALO64_LAUNCH(false, true); else HALO64_LAUNCH(false, false); }
+    else { if (bn_partial) HALO64_LAUNCH(true, true); else HALO64_LAUNCH(true, false); }
+#undef HALO64_LAUNCH
     DREG_LAUNCH_CHECK();
+    if (rows_per_chunk && bn_partial) *rows_per_chunk = 128;
     return DREG_OK;
 }
-
+int dreg_conv3_halo_n(const void* in, const void* wpk, void* out, const float* bias, const void* addend,
+                      int B, int D, int H, int W, int Cin, int Cout, int Da, int Ha, int Wa, int add_same, int out_f32, void* stream)
+{
+    return halo_n_impl(in, wpk, out, bias, addend, B, D, H, W, Cin, Cout, Da, Ha, Wa, add_same, out_f32, nullptr, nullptr, stream);
+}
+int dreg_conv3_halo_n_bnstats(const void* in, const void* wpk, void* out, const float* bias, const void* addend,
+                              int B, int D, int H, int W, int Cin, int Cout, int Da, int Ha, int Wa, int add_same, float* bn_partial, int* rows_per_chunk, void* stream)
+{
+    if (!rows_per_chunk) return DREG_EINVAL;
+    return halo_n_impl(in, wpk, out, bias, addend, B, D, H, W, Cin, Cout, Da, Ha, Wa, add_same, 0, bn_partial, rows_per_chunk, stream);
+}
 
 }  // extern "C"

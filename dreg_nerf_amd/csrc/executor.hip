@@ -367,11 +367,12 @@ void* dreg_exec_create_opts(const int* tensors, int nt, const int* ops, int nops
             int prod = -1, writers = 0;
             for (size_t i = 0; i < j; ++i) if (e->ops[i].out == bn.in) { prod = (int)i; ++writers; }
             if (writers != 1 || e->ops[prod].kind != OP_CONV || e->ops[prod].stats_bn >= 0) continue;
-            {   // a forward on a halo kernel (decided below by the same predicate) has no statistics epilogue: that BatchNorm runs its own pass
+            {   // a forward on the 256-channel halo kernel (decided below by the same predicate) has no statistics epilogue: that BatchNorm runs its own
+                // pass; the 64-channel kernel has one (dreg_conv3_halo_n_bnstats)
                 const Op& pc = e->ops[prod];
                 const Tensor& px = e->t[pc.in];
                 const Param& pp = e->prm[pc.w];
-                if (!pc.relu && pp.d1 == px.C && dreg_conv3_halo_use(px.B, px.D, px.H, px.W, px.C, pp.d0, pc.ksz, pc.stride, pc.pad)) continue;
+                if (!pc.relu && pp.d1 == px.C && pp.d0 != 64 && dreg_conv3_halo_use(px.B, px.D, px.H, px.W, px.C, pp.d0, pc.ksz, pc.stride, pc.pad)) continue;
             }
             e->ops[prod].stats_bn = (int)j;
             bn.stats_conv = prod;
@@ -731,8 +732,12 @@ int dreg_exec_forward(void* h, void* arena, size_t arena_bytes, const void* pack
             }
             Scope sc(e, st, (int)i, 0);
             if (o.halo & 1) {
-                CK(dreg_conv3_halo_n(act(o.in), PK + w.pk_halo_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, w.d0, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0,
-                                     o.add_same, 0, stream));
+                if (train && o.stats_bn >= 0)
+                    CK(dreg_conv3_halo_n_bnstats(act(o.in), PK + w.pk_halo_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, w.d0, ta ? ta->D : 0, ta ? ta->H : 0,
+                                                 ta ? ta->W : 0, o.add_same, (float*)(A + e->ops[o.stats_bn].stats_off), &sums_rpc[o.stats_bn], stream));
+                else
+                    CK(dreg_conv3_halo_n(act(o.in), PK + w.pk_halo_fwd, act(o.out), bias, add, x.B, x.D, x.H, x.W, x.C, w.d0, ta ? ta->D : 0, ta ? ta->H : 0, ta ? ta->W : 0,
+                                         o.add_same, 0, stream));
                 continue;
             }
             if (train && o.stats_bn >= 0 && !(o.in == 0 && e->in_rowocc)) {

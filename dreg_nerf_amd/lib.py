@@ -73,6 +73,7 @@ SIGNATURES = {
     "dreg_conv3_halo": (I, [P, P, P, P, P] + [I] * 10 + [P]),
     "dreg_conv3_halo_pack_bytes_n": (Z, [I, I]),
     "dreg_conv3_halo_n": (I, [P, P, P, P, P] + [I] * 11 + [P]),
+    "dreg_conv3_halo_n_bnstats": (I, [P, P, P, P, P] + [I] * 10 + [P, P, P]),
     "dreg_conv3d_wgrad_variant": (I, [I] * 10),
     "dreg_conv3d_igemm_variant": (I, [I] * 17),
     "dreg_conv3d_wgrad_group_fill": (I, [P, P, P, P, Z] + [I] * 12 + [P, P]),

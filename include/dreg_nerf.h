@@ -114,6 +114,11 @@ int dreg_conv3_halo(const void* in, const void* wpk, void* out, const float* bia
 size_t dreg_conv3_halo_pack_bytes_n(int Cin_reduced, int rows);
 int dreg_conv3_halo_n(const void* in, const void* wpk, void* out, const float* bias, const void* addend,
                       int B, int D, int H, int W, int Cin, int Cout, int Da, int Ha, int Wa, int add_same, int out_f32, void* stream);
+/* the bf16 forward that also leaves the BatchNorm statistics of its OUTPUT behind, like dreg_conv3d_igemm_bnstats: bn_partial [B][V / *rows_per_chunk][Cout][2]
+ * (sums of the stored values and of their squares); *rows_per_chunk = 128 for Cout == 64 (a chunk = two z-planes of an 8^3 box), 0 = nothing was written
+ * (Cout == 256, or bn_partial == NULL: the BatchNorm runs its own statistics pass) */
+int dreg_conv3_halo_n_bnstats(const void* in, const void* wpk, void* out, const float* bias, const void* addend,
+                              int B, int D, int H, int W, int Cin, int Cout, int Da, int Ha, int Wa, int add_same, float* bn_partial, int* rows_per_chunk, void* stream);
 
 /* Data gradient of a stride-2 convolution (ksz 3 / pad 1: resnet3d.py conv2 of the first block of layer2-4; ksz 1 / pad 0: the
  * downsample branch) without the 7/8 structurally-zero taps of the gather form: ONE 2^3-tap convolution over dOut whose

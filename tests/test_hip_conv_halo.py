@@ -171,3 +171,36 @@ def test_halo64_agrees_with_implicit_gemm_and_is_the_kernel_the_layer_runs_on():
     for a, b in ((y, y2), (gx_h, x.grad)):
         diff = (a.float() - b.float()).abs()
         assert diff.max().item() <= 2 ** -7 * b.float().abs().max().item() and (diff > 0).float().mean().item() < 0.02
+
+
+def test_halo64_statistics_epilogue_sums_the_stored_values_per_chunk_and_does_not_depend_on_batch_mates():
+    """dreg_conv3_halo_n_bnstats: the output is the plain launch's bit for bit; the chunk sums [B][V/128][64][2] are those of the STORED values over one
+    wave's 128 voxels (two z-planes of an 8^3 box, boxes in (z, y, x) order), and a grid's sums are the same bits whether it is launched alone or with others."""
+    import ctypes
+    lib = L.load()
+    g = torch.Generator().manual_seed(23)
+    B, D, H, W, cin = 3, 16, 8, 24, 64
+    x = torch.randn(B, D, H, W, cin, generator=g).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(64, cin, 3, 3, 3, generator=g) * 0.034).to(DEV)
+    pk = torch.empty(lib.dreg_conv3_halo_pack_bytes_n(cin, 64) // 2, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.dreg_pack_conv_weight_halo(L.ptr(w), L.ptr(pk), 64, cin, 0, L.stream()), "pack_halo")
+
+    def run(xs):
+        nb = xs.shape[0]
+        out = torch.empty(nb, D, H, W, 64, dtype=torch.bfloat16, device=DEV)
+        sums = torch.full((nb, D * H * W // 128, 64, 2), float("nan"), device=DEV)
+        rpc = ctypes.c_int(-1)
+        L.check(lib.dreg_conv3_halo_n_bnstats(L.ptr(xs), L.ptr(pk), L.ptr(out), None, None, nb, D, H, W, cin, 64, 0, 0, 0, 0, L.ptr(sums), ctypes.addressof(rpc),
+                                              L.stream()), "dreg_conv3_halo_n_bnstats")
+        torch.cuda.synchronize()
+        assert rpc.value == 128
+        return out, sums
+
+    out, sums = run(x)
+    assert torch.equal(out, _halo64(x, w))
+    o = out.double().view(B, D // 8, 4, 2, H // 8, 8, W // 8, 8, 64)                 # [b, tz, wave, z in wave, ty, y, tx, x, c]
+    want1 = o.sum(dim=(3, 5, 7)).permute(0, 1, 3, 4, 2, 5).reshape(B, -1, 64)         # [b, (tz, ty, tx, wave), c]
+    want2 = (o * o).sum(dim=(3, 5, 7)).permute(0, 1, 3, 4, 2, 5).reshape(B, -1, 64)
+    assert torch.allclose(sums[..., 0].double(), want1, rtol=1e-5, atol=1e-4) and torch.allclose(sums[..., 1].double(), want2, rtol=1e-5, atol=1e-4)
+    o1, s1 = run(x[1:2].contiguous())
+    assert torch.equal(o1[0], out[1]) and torch.equal(s1[0], sums[1])
