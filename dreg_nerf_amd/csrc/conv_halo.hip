@@ -321,7 +321,7 @@ constexpr int LDS = HBUF + RING * UNIT;                 // 77,824 B
 // STATS: the BatchNorm behind this convolution gets its chunk sums from here (the layout of dreg_conv3d_igemm_bnstats: [B][V / 128][64][2] sums of the
 // STORED values and of their squares; a chunk is one wave's 128 voxels — two z-planes of the box —, chunk index tile * 4 + wave).  The order of
 // every addition is fixed by the box geometry alone, never by how many grids share the launch.
-template <bool SPLITDS, bool STATS>
+template <bool PF, bool STATS>
 __global__ __launch_bounds__(256, 2) void conv3_halo64_kernel(
     const bf16_t* __restrict__ in, const bf16_t* __restrict__ wpk, bf16_t* __restrict__ out,
     const float* __restrict__ bias, const bf16_t* __restrict__ addend, HaloGeom g, uint32_t in_bytes, uint32_t wt_bytes,
@@ -395,51 +395,53 @@ __global__ __launch_bounds__(256, 2) void conv3_halo64_kernel(
     issue_unit(0, 0);
     issue_unit(UNIT, UNIT);
     int src_off = 2 * UNIT;               // byte offset of unit u+2 in the pack (units past the pack read as zeros: buffer bounds)
+    // PF: the halo does not change inside a chunk, so tap T+1's four A fragments (k-half 0) are read under the last MFMAs of tap T; behind the
+    // barrier of tap T+1 only its two weight fragments are on the wave's critical path
+    i32x4_t af[4];
 #pragma unroll 1
     for (int c = 0; c < g.nchunks; ++c) {
         static_for(std::make_integer_sequence<int, 27>{}, [&](auto tc) {
             constexpr int T = decltype(tc)::value;
             constexpr int dz = T / 9, dy = (T / 3) % 3, dx = T % 3;
             constexpr int OA = ((dz * HY + dy) * HX + dx) * 64;
+            constexpr int Tn = T < 26 ? T + 1 : 0, dyn = (Tn / 3) % 3;
+            constexpr int OAn = (((Tn / 9) * HY + dyn) * HX + Tn % 3) * 64;
             constexpr int OB = (T % RING) * UNIT, OW = ((T + 2) % RING) * UNIT;
             if (T == 0) wait_vmcnt<0>(); else wait_vmcnt<1>();     // (tap 0: the chunk's halo pieces are the youngest loads)
             __builtin_amdgcn_s_barrier();
-            i32x4_t a00, a01, a10, a11, a20, a21, a30, a31, b00, b01, b10, b11;   // [tile][k-half]
+            i32x4_t a01, a11, a21, a31, b00, b01, b10, b11;        // [tile][k-half]
             HALO_DSR(b00, aB0, OB);            HALO_DSR(b10, aB0, OB + 2048);
-            HALO_DSR(a00, aA0[dy], OA);        HALO_DSR(a10, aA0[dy], OA + 2560);  HALO_DSR(a20, aA0[dy], OA + 6400);  HALO_DSR(a30, aA0[dy], OA + 8960);
-            if (!SPLITDS) {
-                HALO_DSR(b01, aB1, OB);        HALO_DSR(b11, aB1, OB + 2048);
-                HALO_DSR(a01, aA1[dy], OA);    HALO_DSR(a11, aA1[dy], OA + 2560);  HALO_DSR(a21, aA1[dy], OA + 6400);  HALO_DSR(a31, aA1[dy], OA + 8960);
+            if (!PF || T == 0) {
+                HALO_DSR(af[0], aA0[dy], OA);  HALO_DSR(af[1], aA0[dy], OA + 2560);  HALO_DSR(af[2], aA0[dy], OA + 6400);  HALO_DSR(af[3], aA0[dy], OA + 8960);
             }
             issue_unit(OW, src_off);
             src_off += UNIT;
-            if (SPLITDS)
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a00), "+v"(a10), "+v"(a20), "+v"(a30), "+v"(b00), "+v"(b10));
-            else
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11), "+v"(a20), "+v"(a21), "+v"(a30), "+v"(a31),
-                               "+v"(b00), "+v"(b01), "+v"(b10), "+v"(b11));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(b00), "+v"(b10));
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #define HALO_MM(i, j, A, Bv) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A), __builtin_bit_cast(bf16x8_t, Bv), acc[i][j], 0, 0, 0)
 #define HALO_SB() __builtin_amdgcn_sched_barrier(0)
-            if (SPLITDS) {
-                HALO_MM(0, 0, a00, b00); HALO_SB(); HALO_DSR(b01, aB1, OB);            HALO_SB();
-                HALO_MM(1, 0, a10, b00); HALO_SB(); HALO_DSR(b11, aB1, OB + 2048);     HALO_SB();
-                HALO_MM(2, 0, a20, b00); HALO_SB(); HALO_DSR(a01, aA1[dy], OA);        HALO_SB();
-                HALO_MM(3, 0, a30, b00); HALO_SB(); HALO_DSR(a11, aA1[dy], OA + 2560); HALO_SB();
-                HALO_MM(0, 1, a00, b10); HALO_SB(); HALO_DSR(a21, aA1[dy], OA + 6400); HALO_SB();
-                HALO_MM(1, 1, a10, b10); HALO_SB(); HALO_DSR(a31, aA1[dy], OA + 8960); HALO_SB();
-                HALO_MM(2, 1, a20, b10); HALO_MM(3, 1, a30, b10);
-                HALO_SB();
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a01), "+v"(a11), "+v"(a21), "+v"(a31), "+v"(b01), "+v"(b11));
-                HALO_SB();
+            // the second k-half's six fragment reads ride in the issue gaps of the first eight MFMAs
+            HALO_MM(0, 0, af[0], b00); HALO_SB(); HALO_DSR(b01, aB1, OB);            HALO_SB();
+            HALO_MM(1, 0, af[1], b00); HALO_SB(); HALO_DSR(b11, aB1, OB + 2048);     HALO_SB();
+            HALO_MM(2, 0, af[2], b00); HALO_SB(); HALO_DSR(a01, aA1[dy], OA);        HALO_SB();
+            HALO_MM(3, 0, af[3], b00); HALO_SB(); HALO_DSR(a11, aA1[dy], OA + 2560); HALO_SB();
+            HALO_MM(0, 1, af[0], b10); HALO_SB(); HALO_DSR(a21, aA1[dy], OA + 6400); HALO_SB();
+            HALO_MM(1, 1, af[1], b10); HALO_SB(); HALO_DSR(a31, aA1[dy], OA + 8960); HALO_SB();
+            HALO_MM(2, 1, af[2], b10); HALO_MM(3, 1, af[3], b10);
+            HALO_SB();
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a01), "+v"(a11), "+v"(a21), "+v"(a31), "+v"(b01), "+v"(b11));
+            HALO_SB();
+            if (PF && T < 26) {
+                HALO_MM(0, 0, a01, b01); HALO_MM(1, 0, a11, b01); HALO_SB(); HALO_DSR(af[0], aA0[dyn], OAn);        HALO_SB();
+                HALO_MM(2, 0, a21, b01); HALO_SB();                          HALO_DSR(af[1], aA0[dyn], OAn + 2560); HALO_SB();
+                HALO_MM(3, 0, a31, b01); HALO_SB();                          HALO_DSR(af[2], aA0[dyn], OAn + 6400); HALO_SB();
+                HALO_MM(0, 1, a01, b11); HALO_SB();                          HALO_DSR(af[3], aA0[dyn], OAn + 8960); HALO_SB();
+                HALO_MM(1, 1, a11, b11); HALO_MM(2, 1, a21, b11); HALO_MM(3, 1, a31, b11);
             } else {
-                HALO_MM(0, 0, a00, b00); HALO_MM(1, 0, a10, b00); HALO_MM(2, 0, a20, b00); HALO_MM(3, 0, a30, b00);
-                HALO_MM(0, 1, a00, b10); HALO_MM(1, 1, a10, b10); HALO_MM(2, 1, a20, b10); HALO_MM(3, 1, a30, b10);
+                HALO_MM(0, 0, a01, b01); HALO_MM(1, 0, a11, b01); HALO_MM(2, 0, a21, b01); HALO_MM(3, 0, a31, b01);
+                HALO_MM(0, 1, a01, b11); HALO_MM(1, 1, a11, b11); HALO_MM(2, 1, a21, b11); HALO_MM(3, 1, a31, b11);
             }
-            HALO_MM(0, 0, a01, b01); HALO_MM(1, 0, a11, b01); HALO_MM(2, 0, a21, b01); HALO_MM(3, 0, a31, b01);
-            HALO_MM(0, 1, a01, b11); HALO_MM(1, 1, a11, b11); HALO_MM(2, 1, a21, b11); HALO_MM(3, 1, a31, b11);
 #undef HALO_MM
 #undef HALO_SB
             __builtin_amdgcn_s_setprio(0);
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void conv3_halo64_kernel(
 // experiments only (include/dreg_nerf_probe.h): 0 = anti-phase groups (default); 1 = lockstep; 3 = all 12 fragment reads in the load half;
 // 5 = profiled; 1x = ablations; -1 = dreg_conv3_halo_use() answers 0 (the implicit-GEMM kernel serves every shape: A/B tests)
 DREG_KNOB(int, g_halo_variant, 0);
-// 64-output-channel kernel: 1 = on (default), 0 = dreg_conv3_halo_use() answers 0 for Cout = 64 (A/B tests), 2 = all 12 fragment reads before the MFMAs
+// 64-output-channel kernel: 1 = on (default), 0 = dreg_conv3_halo_use() answers 0 for Cout = 64 (A/B tests), 2 = without the prefetch of the next tap's A fragments (53.3 -> 54.6 us on 32^3 x 8, 64 -> 64)
 DREG_KNOB(int, g_halo64, 1);
 
 __global__ __launch_bounds__(256) void pack_weight_halo_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int transposed)

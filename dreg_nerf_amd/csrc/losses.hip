@@ -384,7 +384,36 @@ __global__ void infonce_wsym_kernel(const float* __restrict__ W, float* __restri
     out[i] = (r <= c ? W[(size_t)r * E + c] : 0.f) + (c <= r ? W[(size_t)c * E + r] : 0.f);
 }
 
+// The stand-in {0,1} visibility labels of data WITHOUT NeRF blocks on disk (synthetic scenes: dreg_nerf_amd/synth.py synthetic_overlap_gt — bench.py's default
+// workload, the tests): the half-space test 1[x + 0.31 y - 0.17 z > 0.0123] of the key points (gt, the same row for all L layers) and of the L layers'
+// predicted correspondences (tilde), with the roundings of the element-wise fp32 formula (no contraction).
+__device__ __forceinline__ float halfspace_label(const float* __restrict__ p)
+{
+    const float s = __fsub_rn(__fadd_rn(p[0], __fmul_rn(0.31f, p[1])), __fmul_rn(0.17f, p[2]));
+    return s > 0.0123f ? 1.f : 0.f;
+}
+__global__ __launch_bounds__(256) void halfspace_labels_kernel(const float* __restrict__ xyz, const float* __restrict__ corr, float* __restrict__ gt,
+                                                               float* __restrict__ tilde, int L, int R)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const float g = halfspace_label(xyz + (size_t)r * 3);
+    for (int l = 0; l < L; ++l) {
+        gt[(size_t)l * R + r] = g;
+        tilde[(size_t)l * R + r] = halfspace_label(corr + ((size_t)l * R + r) * 3);
+    }
+}
+
 extern "C" {
+
+int dreg_halfspace_labels(const float* xyz, const float* corr, float* gt, float* tilde, int L, int R, void* stream)
+{
+    if (R <= 0 || L <= 0) return DREG_OK;
+    if (!xyz || !corr || !gt || !tilde) return DREG_EINVAL;
+    hipLaunchKernelGGL(halfspace_labels_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, xyz, corr, gt, tilde, L, R);
+    DREG_LAUNCH_CHECK();
+    return DREG_OK;
+}
 
 int dreg_reg_point_losses(const float* gt, const float* tilde, const float* ov, const float* corr, const float* xyz, const float* pose,
                           const int* probs, float* partial, float* d_ov, float* d_corr, int L, int R, int P, int robust, float eps,

@@ -198,6 +198,7 @@ SIGNATURES = {
     "dreg_infonce_rows": (I, [P] * 10 + [I, I, F, F, I, P]),
     "dreg_reg_losses_final": (I, [P] * 6 + [I, I, F, F, F, F, F, P]),
     "dreg_nerf_cont_deferred": (I, [P] * 5 + [I, I, I, F, F, F, F, P]),
+    "dreg_halfspace_labels": (I, [P, P, P, P, I, I, P]),
     "dreg_voxel_downsample_workspace_bytes": (Z, [I]),
     "dreg_voxel_downsample_fwd": (I, [P] * 11 + [Z, I, I, I, F, P]),
     "dreg_voxel_downsample_bwd": (I, [P, P, P, P, I, I, P]),

@@ -66,6 +66,22 @@ def _default_labels(pred):
     return s_gt, t_gt, s_tl, t_tl
 
 
+def synthetic_labels_rows(xyz, corr):
+    """The labels of _default_labels in the fused losses' shared row space: gt, tilde [L, R] from the key points xyz [R, 3] and the predicted
+    correspondences corr [L, R, 3] — one launch on the GPU (csrc/losses.hip, the same bits as the element-wise formula)."""
+    with torch.no_grad():
+        if xyz.is_cuda and xyz.dtype == torch.float32 and corr.dtype == torch.float32:
+            from . import lib as L
+            nl, R = corr.shape[0], corr.shape[1]
+            gt, tilde = torch.empty(nl, R, device=xyz.device), torch.empty(nl, R, device=xyz.device)
+            L.check(L.load().dreg_halfspace_labels(L.ptr(xyz.detach().contiguous()), L.ptr(corr.detach().contiguous()), L.ptr(gt), L.ptr(tilde), nl, R, L.stream()),
+                    "dreg_halfspace_labels")
+            return gt, tilde
+        gt = synth.synthetic_overlap_gt(xyz, corr.shape[0])[..., 0]
+        tilde = (corr[..., 0] + 0.31 * corr[..., 1] - 0.17 * corr[..., 2] > 0.0123).to(corr.dtype)
+    return gt, tilde
+
+
 STEP_TIMERS = {} if os.environ.get("DREG_STEP_TIMERS") == "1" else None      # diagnostic: host seconds of a step's phases, accumulated (train_nerf_regtr.py prints them per epoch)
 
 
@@ -223,9 +239,7 @@ class TrainStep:
                 if STEP_TIMERS is not None:
                     STEP_TIMERS["  after_forward"] = STEP_TIMERS.get("  after_forward", 0.0) + __import__("time").perf_counter() - _q0
             elif not any(have_nerf) and self.label_fn is _default_labels:
-                with torch.no_grad():
-                    gt = synth.synthetic_overlap_gt(bt["xyz"])[..., 0]
-                    tilde = (bt["corr"][..., 0] + 0.31 * bt["corr"][..., 1] - 0.17 * bt["corr"][..., 2] > 0.0123).float()
+                gt, tilde = synthetic_labels_rows(bt["xyz"], bt["corr"])
             else:
                 gts, tls = [], []
                 from_blocks = iter(nerf_labels_batched([p for p, hn in zip(preds, have_nerf) if hn], [d for d, hn in zip(batch, have_nerf) if hn]))

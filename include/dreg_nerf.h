@@ -558,6 +558,11 @@ int dreg_reg_losses_final(const float* partial, const float* loss_row, const flo
 int dreg_nerf_cont_deferred(const float* gt, const float* tilde, const int* probs, float* partial, float* out, int P, int L, int R,
                             float w_overlap, float w_cont, float w_feat, float w_corr, void* stream);
 
+/* Stand-in {0,1} visibility labels of data without NeRF blocks on disk (synthetic scenes; the reference always ray-marches them: train_nerf_regtr.py:186-201):
+ * gt[l, r] = 1[x + 0.31 y - 0.17 z > 0.0123] of key point xyz[r] (fp32 [R,3]) for every layer l < L, tilde[l, r] the same test of corr[l, r] (fp32 [L,R,3]);
+ * gt, tilde fp32 [L,R].  One launch for the dozen element-wise ones of the torch formula (dreg_nerf_amd/synth.py), same bits. */
+int dreg_halfspace_labels(const float* xyz, const float* corr, float* gt, float* tilde, int L, int R, void* stream);
+
 /* batched_grid_subsample (grid_downsample.py:6-44; MinkowskiEngine UNWEIGHTED_AVERAGE): mean of (xyz | feat) over rows
  * sharing (batch, floor(p/dl)); rows out ordered by (batch, ix, iy, iz).  Outputs sized for N rows; n_out / batch_counts
  * are device ints; inv_seg / inv_cnt (per input row) feed the backward pass; err is set when |p/dl| >= 32768. */

@@ -13,7 +13,7 @@ extern "C" {
 
 /* experiments (tools/bench_conv_halo.py): 0 = anti-phase wave groups, weights 2 units ahead (default); 1 = lockstep; 2 = 3 units ahead */
 void dreg_conv3_halo_set_variant(int variant);
-void dreg_conv3_halo64_set(int v);   /* 64-output-channel halo kernel: 1 = on (default), 0 = off (implicit GEMM serves the shape), 2 = unsplit fragment reads */
+void dreg_conv3_halo64_set(int v);   /* 64-output-channel halo kernel: 1 = on (default), 0 = off (implicit GEMM serves the shape), 2 = the other loop form (A-fragment prefetch on / off) */
 void dreg_conv3_halo_set_prof(void* u64_buf_64x8x5);   /* variant 5: per-wave shader-clock breakdown of the first 64 workgroups */
 /* 1 (default): bf16 stride-1 convolutions stage operands with buffer_load...lds; 0: register-staged kernel (A/B checks) */
 void dreg_conv_set_glds(int enable);

@@ -92,7 +92,7 @@ def test_halo_agrees_with_implicit_gemm_kernel_on_the_dominant_layer():
 # ---- the 64-output-channel kernel (conv2 of layer1's bottlenecks at 32^3 and its data gradient): 8 x 8 x 8 boxes, two workgroups per CU
 
 def _halo64(x, w, bias=None, addend=None, add_same=False, transposed=False, mode=1):
-    """x [B,D,H,W,C] bf16, w fp32 [Cout,Cin,3,3,3] -> [B,D,H,W,64] bf16 (transposed: the data gradient, 64 = Cin); mode 2: the unsplit-read form"""
+    """x [B,D,H,W,C] bf16, w fp32 [Cout,Cin,3,3,3] -> [B,D,H,W,64] bf16 (transposed: the data gradient, 64 = Cin); mode 2: the other loop form of the measurement build"""
     if mode != 1:
         with L.probe() as pr:
             pr.set("dreg_conv3_halo64_set", mode, 1)

@@ -119,3 +119,28 @@ def test_batched_fp32_gemm_all_operand_forms(tA, tB, M, N, K):
         assert float((got[1] - 2.0 * ref).abs().max()) <= 2 * tol
         if pad:
             assert torch.isnan(c[:, :, N:]).all()                          # nothing outside the [M x N] block is written
+
+
+def test_fused_synthetic_labels_equal_the_elementwise_formula_bit_for_bit():
+    """dreg_halfspace_labels (one launch) against synth.synthetic_overlap_gt and the training step's former torch expression — including points within
+    a few ulps of the plane, where a fused multiply-add would flip labels."""
+    from dreg_nerf_amd import synth
+    from dreg_nerf_amd.train_step import synthetic_labels_rows
+    g = torch.Generator().manual_seed(5)
+    R, L_ = 10007, 6
+    xyz = (torch.rand(R, 3, generator=g) * 3 - 1.5)
+    corr = (torch.rand(L_, R, 3, generator=g) * 3 - 1.5)
+    # rows ON the plane up to rounding: x = 0.0123 - 0.31 y + 0.17 z evaluated in fp32, then nudged by -2..2 ulps
+    for t in (xyz, corr.view(-1, 3)):
+        n = t.shape[0] // 2
+        x0 = (torch.tensor(0.0123) - 0.31 * t[:n, 1]) + 0.17 * t[:n, 2]
+        ulps = torch.randint(-2, 3, (n,), generator=g)
+        t[:n, 0] = (x0.view(torch.int32) + ulps.int()).view(torch.float32)
+    xyz, corr = xyz.to(DEV), corr.to(DEV)
+    gt, tilde = synthetic_labels_rows(xyz, corr)
+    want_gt = synth.synthetic_overlap_gt(xyz, L_)[..., 0]
+    want_tilde = (corr[..., 0] + 0.31 * corr[..., 1] - 0.17 * corr[..., 2] > 0.0123).float()
+    assert torch.equal(gt, want_gt) and torch.equal(tilde, want_tilde)
+    assert 0.2 < float(tilde.mean()) < 0.8 and 0.2 < float(want_gt.mean()) < 0.8
+    cpu_gt, cpu_tilde = synthetic_labels_rows(xyz.cpu(), corr.cpu())                 # the CPU branch (gloo tests) is the formula itself
+    assert torch.equal(cpu_gt, want_gt.cpu()) and torch.equal(cpu_tilde, want_tilde.cpu())

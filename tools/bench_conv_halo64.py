@@ -37,7 +37,7 @@ def main():
                                       R if add is not None else 0, R if add is not None else 0, R if add is not None else 0, 1, L.DT_BF16, 0, L.stream()), "igemm")
 
     acc2 = acc.clone()
-    arms = {"igemm": igemm, "halo64": lambda: halo(1), "halo64_unsplit_reads": lambda: halo(2),
+    arms = {"igemm": igemm, "halo64": lambda: halo(1), "halo64_no_prefetch": lambda: halo(2),
             "igemm+acc": lambda: igemm(acc2), "halo64+acc": lambda: halo(1, acc)}
     for f in arms.values():
         f()
