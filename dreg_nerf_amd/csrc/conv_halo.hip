@@ -321,10 +321,11 @@ constexpr int LDS = HBUF + RING * UNIT;                 // 77,824 B
 // STATS: the BatchNorm behind this convolution gets its chunk sums from here (the layout of dreg_conv3d_igemm_bnstats: [B][V / 128][64][2] sums of the
 // STORED values and of their squares; a chunk is one wave's 128 voxels — two z-planes of the box —, chunk index tile * 4 + wave).  The order of
 // every addition is fixed by the box geometry alone, never by how many grids share the launch.
-template <bool PF, bool STATS>
+// (TO: the output type — bf16 only; it keeps the instantiation's name in step with conv3_halo_kernel<TO, ...> for the profile labels)
+template <typename TO, bool PF, bool STATS>
 __global__ __launch_bounds__(256, 2) void conv3_halo64_kernel(
-    const bf16_t* __restrict__ in, const bf16_t* __restrict__ wpk, bf16_t* __restrict__ out,
-    const float* __restrict__ bias, const bf16_t* __restrict__ addend, HaloGeom g, uint32_t in_bytes, uint32_t wt_bytes,
+    const bf16_t* __restrict__ in, const bf16_t* __restrict__ wpk, TO* __restrict__ out,
+    const float* __restrict__ bias, const TO* __restrict__ addend, HaloGeom g, uint32_t in_bytes, uint32_t wt_bytes,
     float* __restrict__ bn_part)
 {
     using namespace halo64;
@@ -669,8 +670,8 @@ static int halo_n_impl(const void* in, const void* wpk, void* out, const float* 
     const uint32_t in_bytes = (uint32_t)((uint64_t)B * D * H * W * Cin * 2), wt_bytes = (uint32_t)dreg_conv3_halo_pack_bytes_n(Cin, 64);
     hipStream_t st = (hipStream_t)stream;
 #define HALO64_LAUNCH(SD, STv) do { \
-        (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<SD, STv>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
-        hipLaunchKernelGGL((conv3_halo64_kernel<SD, STv>), dim3(ntiles), dim3(256), LDS, st, (const bf16_t*)in, (const bf16_t*)wpk, (bf16_t*)out, \
+        (void)hipFuncSetAttribute((const void*)conv3_halo64_kernel<bf16_t, SD, STv>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+        hipLaunchKernelGGL((conv3_halo64_kernel<bf16_t, SD, STv>), dim3(ntiles), dim3(256), LDS, st, (const bf16_t*)in, (const bf16_t*)wpk, (bf16_t*)out, \
                            bias, (const bf16_t*)addend, g, in_bytes, wt_bytes, bn_partial); } while (0)
     if (g_halo64 == 2) { if (bn_partial) HALO64_LAUNCH(false, true); else HALO64_LAUNCH(false, false); }
     else { if (bn_partial) HALO64_LAUNCH(true, true); else HALO64_LAUNCH(true, false); }
