@@ -298,7 +298,7 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // The same idea for 64 output channels: the three 64 -> 64 3^3 convolutions of layer1's bottlenecks at 32^3 (ResNet50 conv2 of
-// conerf/model/backbone/resnet.py Bottleneck; forward and data gradient).  In the implicit GEMM they gather 27 x 128 B per output row
+// conerf/model/resnet3d.py:76-113, Bottleneck; forward and data gradient).  In the implicit GEMM they gather 27 x 128 B per output row
 // through L2 and run at 0.29 of the MFMA roof.  With 64 output channels a wave can own ALL of them, so the 4 waves of a workgroup
 // split M only: a wave owns two z-planes (128 voxels) x 64 channels — the same 12 fragment reads per 16 MFMAs as the 256-channel
 // kernel — and a workgroup an 8 x 8 x 8 box whose 10^3 halo (one 32-channel chunk: 62.5 KiB) sits in LDS.

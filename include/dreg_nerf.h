@@ -94,7 +94,7 @@ int dreg_bn3d_fwd_from_sums(const void* x, const void* res, void* y, const float
  * the FeaturePyramid_v1 head's upsample_transform_* / pyramid_transformation_1 layers (conerf/model/feature_pyramid_net.py:47-56,
  * 97-103; cuDNN conv3d in the reference) and their data gradients.  A workgroup owns a 4 x 8 x 8 box of output voxels, stages its
  * 6 x 10 x 10 input halo once per 32-channel chunk and runs all 27 taps out of LDS; only the weights stream per tap.
- * A second kernel serves 64 output channels — conv2 of layer1's bottlenecks at 32^3 (conerf/model/backbone/resnet.py Bottleneck) and its data
+ * A second kernel serves 64 output channels — conv2 of layer1's bottlenecks at 32^3 (conerf/model/resnet3d.py:76-113, Bottleneck) and its data
  * gradient: 8 x 8 x 8 boxes, four waves that each own two z-planes x all 64 channels, two workgroups per CU (dreg_conv3_halo_n).
  * dreg_conv3_halo_supported: 1 when the shape qualifies (Cin % 32 == 0, operands < 2 GiB; Cout == 256 with D % 4 == H % 8 == W % 8 == 0, or
  *   Cout == 64 with D % 8 == H % 8 == W % 8 == 0).
