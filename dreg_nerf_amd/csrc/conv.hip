@@ -2522,12 +2522,17 @@ int dreg_pack_conv_weights_batched(const void* descs, int n, int total_rows, int
 
 // number of voxel splits the weight-gradient kernel will use (pure function of the shape)
 DREG_KNOB(int, g_force_wgrad_splits, 0);
-DREG_KNOB(int, g_wgrad_target_blocks, 3072);
+// Workgroups the split choice aims for.  Rounds 1-5 used 3,072 (12 per CU: the weight-gradient kernel ALONE is fastest with ~1,024 voxels per split), but every split
+// writes a Cout x Kpad fp32 slab that the batched sum reads back — 1.8 GB written + read per step at 3,072, more HBM time than the MFMA work of the 16^3 / 32^3
+// layers, taken from a main stream whose 1^3 layers and BatchNorm passes are HBM-bound too.  On the whole step (tools/ab_step.py dreg_conv_set_wgrad_target_blocks,
+// values alternated in one process, profiles/r06_ab_wgrad_target_blocks.txt): 3,072 16.10 ms, 768 16.02, 512 15.90, 384 15.87, 256 15.92, 128 16.05 on one box;
+// 3,072 16.20, 640 16.07, 512 15.97, 448 15.99, 384 15.93, 320 15.97 on another.
+DREG_KNOB(int, g_wgrad_target_blocks, 384);
 #ifdef DREG_PROBE
 void dreg_conv_set_narrow_small(int on) { if (on >= 10) { g_narrow_small = 2; g_narrow_thr = on; } else { g_narrow_small = on; g_narrow_thr = 224; } }   // 0 off, 1 forward / data gradient only, 2 weight gradients too; >= 10: mode 2 with this tile-count threshold
 // tuning knob: workgroups the automatic voxel-split choice of the weight-gradient kernels aims for
 void dreg_conv_set_glds_stages(int stages) { g_glds_stages = (stages >= 2 && stages <= 4) ? stages : 0; }
-void dreg_conv_set_wgrad_target_blocks(int blocks) { g_wgrad_target_blocks = blocks > 0 ? blocks : 3072; }
+void dreg_conv_set_wgrad_target_blocks(int blocks) { g_wgrad_target_blocks = blocks > 0 ? blocks : 384; }
 // tuning / test knob: force the number of voxel splits of the weight-gradient kernels (0 = automatic)
 void dreg_conv_set_wgrad_splits(int splits) { g_force_wgrad_splits = splits; }
 #endif

@@ -33,7 +33,7 @@ void dreg_conv_igemm_probe(int enable);               /* MEASUREMENT ONLY: bf16 
 int dreg_conv_igemm_probe_read(unsigned long long* out6); /* { wait-for-loads, barrier, issue, compute cycles; K steps x waves; waves }, summed over the waves since the last read */
 void dreg_conv_set_wgrad_big(int mode);             /* large dense layers: 3 (default) the 8-wave 256 x 256 tile, 1 four waves on 256 x 128 with 32-voxel stages, 11-13 ablations of the 8-wave tile, 0 neither */
 void dreg_conv_set_glds_stages(int stages);          /* LDS pipeline stages of the direct-to-LDS convolution: 0 = default (2), 2..4 forces; results do not depend on it */
-void dreg_conv_set_wgrad_target_blocks(int blocks);   /* workgroups the automatic split choice aims for (default 3072) */
+void dreg_conv_set_wgrad_target_blocks(int blocks);   /* workgroups the automatic split choice aims for (default 384; 3072 until round 6) */
 /* largest per-grid volume (voxels) whose BatchNorm runs the fused statistics+apply kernels (default 512 = the 8^3 level; 16^3 measured slower fused); 0 = never */
 void dreg_bn_set_small_max_voxels(int v);
 void dreg_sstem_set_pool_blocks(int n);              /* measurement: workgroups of the sparse stem's pooling launch (default 8192 = one pooled granule per thread at 8 x 32^3 x 64) */
